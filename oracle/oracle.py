@@ -1,0 +1,161 @@
+"""ctypes front-end of the CPU oracle (oracle/es_oracle.c).
+
+TEST INFRASTRUCTURE ONLY -- importable from tests/, __graft_entry__.smoke() and the
+`cpu_baseline` leg of bench.py; the product package never imports this module.
+All arrays are NumPy, channels-last, float32 / int32 / bool.
+"""
+import ctypes as C
+import os
+import subprocess
+from types import SimpleNamespace
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIBS = {}
+
+
+class _Cfg(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("depth", "reduction", "head", "embed_dim", "kernel_size", "expansion",
+                                       "n_blocks", "block_depth", "dec_kernel", "n_mel", "vocab")]
+
+
+class _Weights(C.Structure):
+    _fields_ = [("n", C.c_int), ("names", C.POINTER(C.c_char_p)), ("ptrs", C.POINTER(C.c_void_p))]
+
+
+def build(force=False):
+    """Compile both oracle variants with gcc (called by __graft_entry__.build())."""
+    if force or not all(os.path.exists(os.path.join(_HERE, f)) for f in ("libes_oracle.so", "libes_oracle_f32.so")):
+        subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
+
+
+def lib(f32=False):
+    name = "libes_oracle_f32.so" if f32 else "libes_oracle.so"
+    if name not in _LIBS:
+        path = os.path.join(_HERE, name)
+        if not os.path.exists(path):
+            build()
+        L = C.CDLL(path)
+        L.eso_block_len.restype = C.c_int
+        L.eso_acc_bytes.restype = C.c_int
+        for fn in ("eso_phoneme_encoder", "eso_mel_decoder", "eso_encoder", "eso_fuse", "eso_acoustic"):
+            getattr(L, fn).restype = C.c_int
+        _LIBS[name] = L
+    return _LIBS[name]
+
+
+def _cfg(cfg):
+    from efficientspeech_amd.config import N_SYMBOLS
+    return _Cfg(cfg.depth, cfg.reduction, cfg.head, cfg.embed_dim, cfg.kernel_size, cfg.expansion,
+                cfg.n_blocks, cfg.block_depth, cfg.decoder_kernel_size, cfg.n_mel_channels, N_SYMBOLS + 1)
+
+
+class Weights:
+    """Keeps the name/pointer tables (and the arrays behind them) alive."""
+
+    def __init__(self, sd):
+        self.arrays = {k: np.ascontiguousarray(np.asarray(v), dtype=np.float32) for k, v in sd.items()}
+        keys = list(self.arrays)
+        self._names = (C.c_char_p * len(keys))(*[k.encode() for k in keys])
+        self._ptrs = (C.c_void_p * len(keys))(*[self.arrays[k].ctypes.data for k in keys])
+        self.c = _Weights(len(keys), self._names, self._ptrs)
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _chk(rc, what):
+    if rc != 0:
+        raise RuntimeError(f"es_oracle {what} failed with code {rc}")
+
+
+def block_len(cfg, T, i):
+    c = _cfg(cfg)
+    return lib().eso_block_len(C.byref(c), int(T), int(i))
+
+
+def phoneme_encoder(cfg, w: Weights, phoneme, mask=None, pitch=None, energy=None, duration=None, f32=False, taps=False):
+    """PhonemeEncoder.forward up to the rounded durations (networks.py:336-384).
+    mask: bool (B,T), required iff B>1.  pitch/energy/duration: teacher values (train=True) or None."""
+    L = lib(f32)
+    phoneme = np.ascontiguousarray(phoneme, dtype=np.int32)
+    B, T = phoneme.shape
+    dim = cfg.dim
+    m8 = None if mask is None else np.ascontiguousarray(mask).astype(np.uint8)
+    pt = None if pitch is None else np.ascontiguousarray(pitch, dtype=np.float32)
+    et = None if energy is None else np.ascontiguousarray(energy, dtype=np.float32)
+    dt = None if duration is None else np.ascontiguousarray(duration, dtype=np.int32)
+    o = SimpleNamespace(
+        pitch=np.empty((B, T, 1), np.float32), energy=np.empty((B, T, 1), np.float32),
+        duration=np.empty((B, T, 1), np.float32), pitch_idx=np.empty((B, T), np.int32),
+        energy_idx=np.empty((B, T), np.int32), feat=np.empty((B, T, 4 * dim), np.float32),
+        dur=np.empty((B, T), np.int32), mel_len=np.empty((B,), np.int32), f_taps=None, fused=None)
+    tp, fz = None, None
+    if taps:
+        o.f_taps = [np.empty((B, block_len(cfg, T, i), dim << i), np.float32) for i in range(cfg.depth)]
+        o.fused = np.empty((B, T, dim), np.float32)
+        tp = (C.c_void_p * cfg.depth)(*[a.ctypes.data for a in o.f_taps])
+        fz = _p(o.fused)
+    c = _cfg(cfg)
+    rc = L.eso_phoneme_encoder(C.byref(c), C.byref(w.c), B, T, _p(phoneme), _p(m8), _p(pt), _p(et), _p(dt),
+                               _p(o.pitch), _p(o.energy), _p(o.duration), _p(o.pitch_idx), _p(o.energy_idx),
+                               _p(o.feat), _p(o.dur), _p(o.mel_len), tp, fz)
+    _chk(rc, "phoneme_encoder")
+    o.mask = m8 if B > 1 else None
+    return o
+
+
+def length_regulate(dur, L):
+    dur = np.ascontiguousarray(dur, dtype=np.int32)
+    B, T = dur.shape
+    idx = np.empty((B, L), np.int32)
+    lib().eso_length_regulate(B, T, _p(dur), int(L), _p(idx))
+    return idx
+
+
+def upsample(feat, fmask, idx):
+    feat = np.ascontiguousarray(feat, dtype=np.float32)
+    B, T, Cc = feat.shape
+    L = idx.shape[1]
+    out = np.empty((B, L, Cc), np.float32)
+    om = np.empty((B, L), np.uint8)
+    fm = None if fmask is None else np.ascontiguousarray(fmask).astype(np.uint8)
+    lib().eso_upsample(B, T, Cc, L, _p(feat), _p(fm), _p(np.ascontiguousarray(idx, dtype=np.int32)), _p(out), _p(om))
+    return out, om.astype(bool)
+
+
+def mel_decoder(cfg, w: Weights, features, f32=False):
+    features = np.ascontiguousarray(features, dtype=np.float32)
+    B, L, d4 = features.shape
+    assert d4 == cfg.d4
+    mel = np.empty((B, L, cfg.n_mel_channels), np.float32)
+    c = _cfg(cfg)
+    _chk(lib(f32).eso_mel_decoder(C.byref(c), C.byref(w.c), B, L, _p(features), _p(mel)), "mel_decoder")
+    return mel
+
+
+def phoneme2mel(cfg, w: Weights, phoneme, mask=None, pitch=None, energy=None, duration=None, max_mel_len=None,
+                f32=False, taps=False):
+    """Phoneme2Mel.forward (networks.py:415-434).  Teacher values given => the train=True data
+    flow (targets bucketised / forced durations, padded to max_mel_len); else the eval flow.
+    Returns a namespace with mel (B,L,80), mel_len, duration pred, and all intermediates."""
+    o = phoneme_encoder(cfg, w, phoneme, mask, pitch, energy, duration, f32=f32, taps=taps)
+    B = o.dur.shape[0]
+    L = int(max_mel_len) if max_mel_len is not None else int(o.mel_len.max())
+    o.idx = length_regulate(o.dur, L)
+    o.features, o.masks = upsample(o.feat, o.mask, o.idx)
+    o.mel = mel_decoder(cfg, w, o.features, f32=f32)
+    if o.mask is not None and B > 1:
+        o.mel[o.masks] = 0.0                       # networks.py:424-427
+    else:
+        o.masks = None
+    return o
+
+
+def mask_from_lengths(lengths, T):
+    lengths = np.ascontiguousarray(lengths, dtype=np.int32)
+    m = np.empty((len(lengths), T), np.uint8)
+    lib().eso_mask_from_lengths(len(lengths), int(T), _p(lengths), _p(m))
+    return m.astype(bool)

@@ -1,0 +1,101 @@
+"""Pins the CPU oracle (oracle/es_oracle.c) to outputs of the reference itself.
+
+The fixtures under tests/golden/ were produced by tools/gen_golden.py running the reference
+modules (/root/reference/layers) in the build container; this test never touches the reference.
+Tolerances: continuous tensors 2e-5 (fp32 reference vs double-accumulating oracle), discrete
+decisions (bucket indices, rounded durations, mel_len, length-regulator rows) bit-exact.
+"""
+import glob
+import os
+import zlib
+
+import numpy as np
+import pytest
+
+from efficientspeech_amd.config import CONFIGS
+from efficientspeech_amd.synth import synth_state_dict
+from oracle import oracle
+
+GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")))
+TOL = 2e-5
+
+
+def _crc(sd):
+    c = 0
+    for k, v in sd.items():
+        c = zlib.crc32(v.tobytes(), zlib.crc32(k.encode(), c))
+    return c
+
+
+@pytest.fixture(scope="module")
+def weights():
+    cache = {}
+
+    def get(name, g):
+        if name not in cache:
+            sd = synth_state_dict(CONFIGS[name], int(g["seed"]))
+            sd["encoder.pitch_decoder.pitch_bins"] = g["pitch_bins"]
+            sd["encoder.energy_decoder.energy_bins"] = g["energy_bins"]
+            assert _crc(sd) == int(g["weights_crc"]), "synthetic weight recipe drifted from the fixtures"
+            cache[name] = oracle.Weights(sd)
+        return cache[name]
+    return get
+
+
+def test_fixtures_present():
+    assert len(GOLDEN) == 18
+
+
+@pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p)[:-4] for p in GOLDEN])
+def test_oracle_matches_reference(path, weights):
+    g = np.load(path)
+    name = os.path.basename(path).split("_")[0]
+    cfg = CONFIGS[name]
+    w = weights(name, g)
+    train = bool(g["train"])
+    kw = {}
+    if train:
+        kw = dict(pitch=g["in_pitch"], energy=g["in_energy"], duration=g["in_duration"],
+                  max_mel_len=int(g["in_mel_len"].max()))
+    mask = g["in_phoneme_mask"] if "in_phoneme_mask" in g.files else None
+    o = oracle.phoneme2mel(cfg, w, g["in_phoneme"], mask, taps=True, **kw)
+    # stage taps (Encoder blocks, Fuse)
+    for i in range(cfg.depth):
+        np.testing.assert_allclose(o.f_taps[i], g[f"f{i}"], atol=TOL, rtol=0)
+    np.testing.assert_allclose(o.fused, g["fused"], atol=TOL, rtol=0)
+    # predictions (AcousticDecoder x3)
+    np.testing.assert_allclose(o.duration, g["duration"], atol=TOL, rtol=0)
+    if train:
+        np.testing.assert_allclose(o.pitch, g["pitch"], atol=TOL, rtol=0)
+        np.testing.assert_allclose(o.energy, g["energy"], atol=TOL, rtol=0)
+    # discrete decisions: bit-exact
+    assert np.array_equal(o.pitch_idx, g["pitch_idx"])
+    assert np.array_equal(o.energy_idx, g["energy_idx"])
+    assert np.array_equal(o.dur, g["dur"])
+    assert np.array_equal(o.mel_len, g["mel_len"])
+    # variance-adaptor concat and length regulator
+    np.testing.assert_allclose(o.feat, g["feat"], atol=TOL, rtol=0)
+    if "features" in g.files:
+        np.testing.assert_allclose(o.features, g["features"], atol=TOL, rtol=0)
+    B = g["in_phoneme"].shape[0]
+    if B > 1:
+        assert np.array_equal(o.masks, g["masks"])
+    else:
+        assert o.masks is None
+    # mel
+    assert o.mel.shape == g["mel"].shape
+    err = np.abs(o.mel - g["mel"]).max()
+    assert err < 1e-4, err
+    assert err < 5e-5, f"oracle drifted further from the reference than expected: {err}"
+
+
+def test_length_regulator_rule():
+    """cumsum rule of networks.py:233-244 / acoustic.py:33-42 incl. zeros, crop and pad."""
+    dur = np.array([[2, 0, 3, 1], [0, 0, 0, 0], [1, 1, 1, 5]], np.int32)
+    idx = oracle.length_regulate(dur, 7)
+    assert idx.tolist() == [[0, 0, 2, 2, 2, 3, -1], [-1] * 7, [0, 1, 2, 3, 3, 3, 3]]
+
+
+def test_mask_from_lengths():
+    m = oracle.mask_from_lengths([3, 0, 5], 5)
+    assert m.tolist() == [[False] * 3 + [True] * 2, [True] * 5, [False] * 5]
