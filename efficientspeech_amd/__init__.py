@@ -1,0 +1,13 @@
+"""efficientspeech_amd -- MI355X-native EfficientSpeech acoustic-model forward path.
+
+Drop-in for the reference's `layers` package (layers/__init__.py:1 exports exactly these three
+names); all arithmetic runs in hand-written HIP kernels behind the C-ABI of include/esmi.h.
+"""
+from .config import CONFIGS, ESConfig
+from .networks import (Encoder, Fuse, AcousticDecoder, FeatureUpsampler, MelDecoder, PhonemeEncoder, Phoneme2Mel,
+                       SelfAttention, MixFFN, get_mask_from_lengths)
+from .model import build_phoneme2mel, load_numpy_state_dict
+
+__all__ = ["PhonemeEncoder", "MelDecoder", "Phoneme2Mel", "Encoder", "Fuse", "AcousticDecoder", "FeatureUpsampler",
+           "SelfAttention", "MixFFN", "get_mask_from_lengths", "CONFIGS", "ESConfig", "build_phoneme2mel",
+           "load_numpy_state_dict"]

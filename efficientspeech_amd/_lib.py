@@ -1,0 +1,121 @@
+"""ctypes binding of the esmi C-ABI (include/esmi.h).
+
+The product library is `efficientspeech_amd/libesmi.so`, built for gfx950 by
+`__graft_entry__.build()` (hipcc).  There is NO CPU fallback: if the library is missing
+or fails to load, `load()` raises.  (tests/ may bind the wave-simulator build of the very
+same sources through `bind()`; nothing in this package does.)
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libesmi.so")
+MAX_DEPTH = 4
+MAX_DEC_LAYERS = 16
+
+ESMI_OK = 0
+_ERRS = {-1: "ESMI_ERR_ARG (null pointer / bad size / misaligned)",
+         -2: "ESMI_ERR_UNSUPPORTED (shape outside what the kernels are built for)",
+         -3: "ESMI_ERR_WORKSPACE (workspace too small)"}
+
+fp = C.c_void_p  # device pointers travel as integers
+
+
+class EncoderBlockWeights(C.Structure):
+    _fields_ = [(n, fp) for n in ("merge_w", "merge1_w", "qkv_w", "proj_w", "proj_b", "mlp1_w", "mlp1_b",
+                                  "conv_w", "conv_b", "mlp2_w", "mlp2_b", "ln1_g", "ln1_b", "ln2_g", "ln2_b")]
+
+
+class EncoderBlockShape(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("B", "n_in", "c_in", "c_out", "heads", "kernel", "stride", "expansion", "vocab")]
+
+
+class FuseWeights(C.Structure):
+    _fields_ = [("mlp_w", fp * MAX_DEPTH), ("mlp_b", fp * MAX_DEPTH), ("up_w", fp * MAX_DEPTH),
+                ("up_b", fp * MAX_DEPTH), ("fuse_w", fp), ("fuse_b", fp)]
+
+
+class PredictorWeights(C.Structure):
+    _fields_ = [(n, fp) for n in ("conv1_w", "conv1_b", "ln1_g", "ln1_b", "conv2_w", "conv2_b", "ln2_g", "ln2_b",
+                                  "lin_w", "lin_b", "bins", "emb")]
+
+
+class DecoderWeights(C.Structure):
+    _fields_ = [("proj_w", fp), ("proj_b", fp), ("proj_ln_g", fp), ("proj_ln_b", fp)] + \
+               [(n, fp * MAX_DEC_LAYERS) for n in ("dw_w", "dw_b", "pw_w", "pw_b", "ln_g", "ln_b", "skip_g", "skip_b")] + \
+               [("mel_w", fp), ("mel_b", fp)]
+
+
+class DecoderShape(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("d4", "dx2", "kernel", "n_blocks", "block_depth", "n_mel")]
+
+
+EXPORTS = (
+    "esmi_version", "esmi_backend", "esmi_pack_conv_weight_f32", "esmi_pack_convT_weight_f32",
+    "esmi_encoder_block_workspace_bytes", "esmi_encoder_block_f32", "esmi_pool_mask_u8",
+    "esmi_fuse_workspace_bytes", "esmi_fuse_f32", "esmi_variance_adaptor_workspace_bytes",
+    "esmi_variance_adaptor_f32", "esmi_length_regulate_i32", "esmi_length_regulator_indices_i32",
+    "esmi_upsample_f32", "esmi_mel_decoder_blob_bytes", "esmi_mel_decoder_pack_f32", "esmi_mel_decoder_f32",
+    "esmi_mask_rows_f32",
+)
+
+
+def bind(lib):
+    """Declare argument / return types of every entry point of include/esmi.h on `lib`."""
+    i, sz, P = C.c_int, C.c_size_t, C.POINTER
+    lib.esmi_version.restype = i
+    lib.esmi_backend.restype = C.c_char_p
+    lib.esmi_pack_conv_weight_f32.argtypes = [fp, fp, i, i, i, fp]
+    lib.esmi_pack_convT_weight_f32.argtypes = [fp, fp, i, i, i, fp]
+    lib.esmi_encoder_block_workspace_bytes.argtypes = [P(EncoderBlockShape)]
+    lib.esmi_encoder_block_workspace_bytes.restype = sz
+    lib.esmi_encoder_block_f32.argtypes = [P(EncoderBlockWeights), P(EncoderBlockShape), fp, fp, fp, fp, fp, fp, sz, fp]
+    lib.esmi_pool_mask_u8.argtypes = [fp, i, i, i, fp, i, fp]
+    lib.esmi_fuse_workspace_bytes.argtypes = [i, i, i, i]
+    lib.esmi_fuse_workspace_bytes.restype = sz
+    lib.esmi_fuse_f32.argtypes = [P(FuseWeights), i, i, i, i, i, P(fp), P(i), fp, fp, i, fp, sz, fp]
+    lib.esmi_variance_adaptor_workspace_bytes.argtypes = [i, i, i]
+    lib.esmi_variance_adaptor_workspace_bytes.restype = sz
+    lib.esmi_variance_adaptor_f32.argtypes = [P(PredictorWeights)] * 3 + [i, i, i] + [fp] * 11 + [fp, sz, fp]
+    lib.esmi_length_regulate_i32.argtypes = [fp, i, i, fp, fp, fp, fp]
+    lib.esmi_length_regulator_indices_i32.argtypes = [fp, i, i, i, fp, fp]
+    lib.esmi_upsample_f32.argtypes = [fp, fp, fp, i, i, i, i, fp, fp, fp]
+    lib.esmi_mel_decoder_blob_bytes.argtypes = [P(DecoderShape)]
+    lib.esmi_mel_decoder_blob_bytes.restype = sz
+    lib.esmi_mel_decoder_pack_f32.argtypes = [P(DecoderWeights), P(DecoderShape), fp, fp]
+    lib.esmi_mel_decoder_f32.argtypes = [fp, P(DecoderShape), fp, fp, fp, fp, i, i, i, i, i, fp, fp]
+    lib.esmi_mask_rows_f32.argtypes = [fp, fp, C.c_int64, i, fp]
+    for name in EXPORTS:
+        fn = getattr(lib, name)
+        if fn.restype is C.c_int and name != "esmi_version":
+            fn.errcheck = _make_check(name)
+    return lib
+
+
+def _make_check(name):
+    def check(rc, func, args):
+        if rc != ESMI_OK:
+            what = _ERRS.get(rc, f"hipError_t {rc}" if rc > 0 else f"error {rc}")
+            raise RuntimeError(f"{name} failed: {what}")
+        return rc
+    return check
+
+
+_LIB = None
+
+
+def load():
+    """Return the bound HIP library; raise if it is not built (no silent fallback)."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} not found: the esmi HIP extension is not built. Run "
+                "`python -c 'import __graft_entry__ as g; g.build()'` (hipcc --offload-arch=gfx950). "
+                "There is no CPU fallback for this path.")
+        _LIB = bind(C.CDLL(LIB_PATH))
+    return _LIB
+
+
+def backend(lib=None):
+    return (lib or load()).esmi_backend().decode()

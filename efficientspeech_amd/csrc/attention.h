@@ -1,0 +1,130 @@
+// attention core of SelfAttention.forward (layers/blocks.py:49-64):
+//     attn = softmax((q @ k^T) * scale, dim=-1);  ctx = attn @ v
+// for one (utterance, head, 32-query tile) per WAVE.  Faithful quirks: every head spans the FULL
+// channel width C (q/k/v of head hd are channels [s*h*C + hd*C, +C) of the qkv row), scale is
+// (C // heads)^-1/2 (blocks.py:37-38), and NO padding mask is applied to the scores (blocks.py:59-63
+// builds one and never uses it) -- padded keys take part exactly as in the reference.
+//
+// Layout trick (no LDS, no transposes): the scores are computed TRANSPOSED, S^T = K Q^T, so the
+// MFMA C/D registers of a lane hold one query column (query = lane&31) and 16 keys per key tile.
+// Softmax over keys is then an in-lane reduction plus one xor-32 exchange, and the probabilities
+// already sit in the A-operand arrangement of the second MFMA chain (ctx = P V): the k-step that
+// consumes accumulator register r of key tile kt pairs key 32*kt + tile_row(r) of the low half
+// wave with the same register of the high half wave, and V rows are fetched to match.
+#pragma once
+#include "esmi_dev.h"
+
+namespace esmi {
+
+struct AttnP {
+    const float* qkv;  // (B, N, 3, h, C)
+    int B, N, C, h;
+    float scale;
+    float* ctx;  // (B, N, h*C), head-major channels (blocks.py:64 transpose(1,2).reshape)
+};
+
+// NKT = key tiles of 32 (N <= 32*NKT)
+template <int NKT>
+__global__ __launch_bounds__(256) void attn_kernel(const AttnP p) {
+    const int lane = lane_id();
+    const int qtiles = (p.N + 31) >> 5;
+    const int wt = (int)blockIdx.x * 4 + wave_id();
+    if (wt >= p.B * p.h * qtiles) return;
+    const int b = wt / (p.h * qtiles);
+    const int rem = wt - b * (p.h * qtiles);
+    const int hd = rem / qtiles;
+    const int q0 = (rem - hd * qtiles) << 5;
+    const int i = lane & 31, h2 = lane >> 5;
+    const int ld = 3 * p.h * p.C;
+    const float* base = p.qkv + (long)b * p.N * ld;
+    const float* qb = base + 0 * p.h * p.C + hd * p.C;
+    const float* kb = base + 1 * p.h * p.C + hd * p.C;
+    const float* vb = base + 2 * p.h * p.C + hd * p.C;
+
+    // ---- S^T[key][query] = sum_c K[key][c] Q[query][c]
+    f32x16 s[NKT];
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) s[kt] = zero16();
+    const bool qok = q0 + i < p.N;
+    const float* qrow = qb + (long)(qok ? q0 + i : 0) * ld;
+    const float* krow[NKT];
+    bool kok[NKT];
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+        kok[kt] = 32 * kt + i < p.N;
+        krow[kt] = kb + (long)(kok[kt] ? 32 * kt + i : 0) * ld;
+    }
+    for (int kc = 0; kc < (p.C >> 3); ++kc) {
+        const int c = 8 * kc + 4 * h2;
+        const f32x4 qv = qok ? ld4(qrow + c) : zero4();
+        f32x4 kv[NKT];
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt) kv[kt] = kok[kt] ? ld4(krow[kt] + c) : zero4();
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+#pragma unroll
+            for (int kt = 0; kt < NKT; ++kt) s[kt] = mfma32(kv[kt][t], qv[t], s[kt]);
+        }
+    }
+    // ---- softmax over keys for this lane's query: in-lane over (kt, r), then the other half wave
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = 32 * kt + tile_row(r, lane);
+            const float v = key < p.N ? s[kt][r] * p.scale : -INFINITY;
+            s[kt][r] = v;
+            mx = fmaxf(mx, v);
+        }
+    }
+    mx = fmaxf(mx, shfl_xor_f(mx, 32));
+    float den = 0.0f;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float e = expf(s[kt][r] - mx);  // exp(-inf) = 0 for keys >= N
+            s[kt][r] = e;
+            den += e;
+        }
+    }
+    den += shfl_xor_f(den, 32);
+    const float inv = 1.0f / den;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[kt][r] *= inv;
+    }
+    // ---- ctx[query][c] = sum_key P[query][key] V[key][c], 128 output channels per pass
+    for (int c0 = 0; c0 < p.C; c0 += 128) {
+        f32x16 o[4];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) o[nt] = zero16();
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = 32 * kt + tile_row(r, lane);  // differs between the two half waves: that IS the k index
+                const bool vok = key < p.N;
+                const float* vrow = vb + (long)(vok ? key : 0) * ld + c0 + i;
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) {
+                    const float vv = (vok && c0 + 32 * nt + i < p.C) ? vrow[32 * nt] : 0.0f;
+                    o[nt] = mfma32(s[kt][r], vv, o[nt]);
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int q = q0 + tile_row(r, lane);
+            if (q >= p.N) continue;
+            float* orow = p.ctx + ((long)b * p.N + q) * (p.h * p.C) + hd * p.C + c0 + i;
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+                if (c0 + 32 * nt + i < p.C) orow[32 * nt] = o[nt][r];
+        }
+    }
+}
+
+}  // namespace esmi

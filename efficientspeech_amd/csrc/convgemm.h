@@ -1,0 +1,168 @@
+// convgemm -- channels-last Conv1d / ConvTranspose1d / Linear as an implicit GEMM on the exact-fp32
+// MFMA (v_mfma_f32_32x32x2_f32), with the encoder-side epilogues fused:
+//   out = mask( post_relu( LN( act(acc + bias) + residual ) ) ),  optional row-dot side output.
+//
+// One WAVE owns a 32-position x (32*NT)-channel output tile; waves are independent (no LDS, no
+// barrier), a 256-thread workgroup is just four consecutive wave tiles.  Operands stream straight
+// from global/L2 as 16-byte pieces: lane (i = lane&31, h = lane>>5) loads channels
+// [8*kc + 4*h, +4) of input row i (A) and of weight row n (B); the four values feed four
+// consecutive MFMA k-steps.  The contraction order over channels is therefore a fixed permutation
+// of 0..Cin-1 -- irrelevant to the result beyond fp32 rounding.
+//
+// Reference ops covered (all in layers/networks.py / layers/blocks.py):
+//   nn.Embedding + Conv1d (networks.py:54,64-67), qkv / proj Linear (blocks.py:44,65),
+//   MixFFN Linear-Conv1d-GELU-Linear (blocks.py:22-29), LN + residual + masked_fill
+//   (networks.py:73-83), Fuse Linear / ConvTranspose1d (networks.py:196-214),
+//   AcousticDecoder Conv1d+ReLU+LN (networks.py:151-160).
+#pragma once
+#include "esmi_dev.h"
+
+namespace esmi {
+
+enum ConvMode { MODE_CONV = 0, MODE_CONVT = 1 };
+
+struct ConvGemmP {
+    // input rows: A + (b*n_in + t)*lda + a_coff, or embedding rows table + ids[b*n_in + t]*ld_table
+    const float* A;
+    int lda, a_coff;
+    const int* ids;
+    const float* table;
+    int ld_table, vocab;
+    int B, n_in, c_in, n_out, c_out;
+    int k, stride, pad, mode;
+    const float* W;  // (k, c_out, c_in) tap-major
+    const float* bias;
+    int act;
+    const float* res;  // residual rows res + (b*n_out + t)*ldr + r_coff, added after act
+    int ldr, r_coff;
+    const float* ln_g;  // LayerNorm over c_out (requires c_out == 32*NT)
+    const float* ln_b;
+    int post_relu;
+    const unsigned char* rowmask;  // (B, n_out), 1 => row zeroed
+    float* out;                    // may be NULL (side output only)
+    int ldo, o_coff;
+    const float* dot_w;  // optional: dot_out[b*n_out+t] = (relu)(sum_c v[c]*dot_w[c] + dot_b[0]) on the pre-LN value
+    const float* dot_b;
+    float* dot_out;
+    int dot_relu;
+};
+
+template <int NT>
+__global__ __launch_bounds__(256) void convgemm_kernel(const ConvGemmP p) {
+    const int lane = lane_id();
+    const int tiles_per_b = (p.n_out + 31) >> 5;
+    const int wt = (int)blockIdx.x * 4 + wave_id();
+    if (wt >= p.B * tiles_per_b) return;  // whole wave leaves together; no barriers in this kernel
+    const int b = wt / tiles_per_b;
+    const int t0 = (wt - b * tiles_per_b) << 5;
+    const int n0 = (int)blockIdx.y * (NT * 32);
+    const int i = lane & 31, h = lane >> 5;
+    const int t_out = t0 + i;
+
+    f32x16 acc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[nt] = zero16();
+
+    const int kcs = p.c_in >> 3;
+    for (int j = 0; j < p.k; ++j) {
+        // which input row feeds output position t_out through tap j
+        int ti;
+        bool ok = t_out < p.n_out;
+        if (p.mode == MODE_CONV) {
+            ti = t_out * p.stride + j - p.pad;
+            ok = ok && ti >= 0 && ti < p.n_in;
+        } else {  // ConvTranspose1d, no padding: out[n*stride + j] += in[n] * W[:, :, j]
+            const int q = t_out - j;
+            ti = q / p.stride;
+            ok = ok && q >= 0 && (q - ti * p.stride) == 0 && ti < p.n_in;
+        }
+        const float* arow = p.A;
+        if (ok) {
+            if (p.ids) {
+                int id = p.ids[b * p.n_in + ti];
+                if (id < 0 || id >= p.vocab) id = 0;  // the reference raises IndexError; stay in bounds
+                arow = p.table + (long)id * p.ld_table;
+            } else {
+                arow = p.A + ((long)b * p.n_in + ti) * p.lda + p.a_coff;
+            }
+        }
+        const float* wj = p.W + (long)j * p.c_out * p.c_in;
+        const float* wrow[NT];
+        bool wok[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int n = n0 + 32 * nt + i;
+            wok[nt] = n < p.c_out;
+            wrow[nt] = wj + (long)(wok[nt] ? n : 0) * p.c_in;
+        }
+        for (int kc = 0; kc < kcs; ++kc) {
+            const int c = 8 * kc + 4 * h;
+            const f32x4 av = ok ? ld4(arow + c) : zero4();
+            f32x4 bv[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) bv[nt] = wok[nt] ? ld4(wrow[nt] + c) : zero4();
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc[nt] = mfma32(av[s], bv[nt][s], acc[nt]);
+            }
+        }
+    }
+
+    // ---------------- epilogue in the MFMA C/D layout: row = tile_row(r), col = n0 + 32*nt + i
+    int col[NT];
+    bool cok[NT];
+    float bias[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        col[nt] = n0 + 32 * nt + i;
+        cok[nt] = col[nt] < p.c_out;
+        bias[nt] = (p.bias && cok[nt]) ? p.bias[col[nt]] : 0.0f;
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int t = t0 + tile_row(r, lane);
+        const bool rok = t < p.n_out;
+        const long row = (long)b * p.n_out + t;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            float v = apply_act(acc[nt][r] + bias[nt], p.act);
+            if (p.res && rok && cok[nt]) v += p.res[row * p.ldr + p.r_coff + col[nt]];
+            acc[nt][r] = v;
+        }
+    }
+    if (p.dot_out) {
+        float dw[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) dw[nt] = cok[nt] ? p.dot_w[col[nt]] : 0.0f;
+        const float db = p.dot_b[0];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float s = 0.0f;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) s = fmaf(acc[nt][r], dw[nt], s);
+            s = row_sum32(s) + db;
+            if (p.dot_relu) s = fmaxf(s, 0.0f);
+            const int t = t0 + tile_row(r, lane);
+            if (i == 0 && t < p.n_out) p.dot_out[(long)b * p.n_out + t] = s;
+        }
+    }
+    if (!p.out) return;
+    if (p.ln_g) layernorm_tile<NT>(acc, p.ln_g, p.ln_b, lane);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int t = t0 + tile_row(r, lane);
+        if (t >= p.n_out) continue;
+        const long row = (long)b * p.n_out + t;
+        const bool masked = p.rowmask && p.rowmask[row];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            float v = acc[nt][r];
+            if (p.post_relu) v = fmaxf(v, 0.0f);
+            if (masked) v = 0.0f;
+            if (cok[nt]) p.out[row * p.ldo + p.o_coff + col[nt]] = v;
+        }
+    }
+}
+
+}  // namespace esmi

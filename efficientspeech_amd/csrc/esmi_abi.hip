@@ -1,0 +1,407 @@
+// esmi C-ABI: the host-side launch sequences behind include/esmi.h.
+// Built by `hipcc --offload-arch=gfx950` into libesmi.so (product) and, unchanged, by the host
+// clang++ with -DESMI_WAVESIM into libesmi_sim.so (CPU wave simulator used only by tests).
+#include "../../include/esmi.h"
+
+#include <cmath>
+#include <cstring>
+
+#include "attention.h"
+#include "convgemm.h"
+#include "esmi_dev.h"
+#include "mel_decoder.h"
+#include "small_kernels.h"
+
+using namespace esmi;
+
+namespace {
+
+inline hipStream_t S(esmi_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+inline int launch_status() {
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? ESMI_OK : (int)e;
+}
+inline size_t align256(size_t n) { return (n + 255) & ~(size_t)255; }
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+ConvGemmP conv_defaults() {
+    ConvGemmP p;
+    memset(&p, 0, sizeof p);
+    p.k = 1; p.stride = 1; p.pad = 0; p.mode = MODE_CONV;
+    return p;
+}
+
+// full_row: the epilogue needs a whole output row inside one wave (LayerNorm / row-dot)
+int launch_convgemm(ConvGemmP p, hipStream_t st) {
+    if ((p.c_in & 7) || p.c_in <= 0 || p.c_out <= 0 || p.n_out <= 0 || p.B <= 0) return ESMI_ERR_ARG;
+    if (!p.W || !aligned16(p.W)) return ESMI_ERR_ARG;
+    if (p.ids) {
+        if (!p.table || (p.ld_table & 3) || !aligned16(p.table)) return ESMI_ERR_ARG;
+    } else if (!p.A || (p.lda & 3) || (p.a_coff & 3) || !aligned16(p.A)) return ESMI_ERR_ARG;
+    const bool full_row = p.ln_g || p.dot_out;
+    int nt;
+    if (full_row) {
+        nt = (p.c_out + 31) / 32;
+        if (nt == 3) nt = 4;
+        if (nt > 4 && nt <= 8) nt = 8;
+        if (nt > 8) return ESMI_ERR_UNSUPPORTED;
+        if (p.ln_g && p.c_out != 32 * nt) return ESMI_ERR_UNSUPPORTED;  // LN width must be 32/64/128/256
+    } else {
+        nt = p.c_out > 64 ? 4 : (p.c_out > 32 ? 2 : 1);
+    }
+    const int tiles = p.B * ((p.n_out + 31) / 32);
+    dim3 grid((tiles + 3) / 4, full_row ? 1 : (p.c_out + 32 * nt - 1) / (32 * nt));
+    dim3 block(256);
+    switch (nt) {
+        case 1: ESMI_LAUNCH((convgemm_kernel<1>), grid, block, 0, st, p); break;
+        case 2: ESMI_LAUNCH((convgemm_kernel<2>), grid, block, 0, st, p); break;
+        case 4: ESMI_LAUNCH((convgemm_kernel<4>), grid, block, 0, st, p); break;
+        case 8: ESMI_LAUNCH((convgemm_kernel<8>), grid, block, 0, st, p); break;
+        default: return ESMI_ERR_UNSUPPORTED;
+    }
+    return launch_status();
+}
+
+int launch_attn(const AttnP& p, hipStream_t st) {
+    if ((p.C & 7) || p.N <= 0) return ESMI_ERR_ARG;
+    const int nkt = (p.N + 31) / 32;
+    if (nkt > 8) return ESMI_ERR_UNSUPPORTED;  // N <= 256 keys held in registers (all BASELINE configs)
+    const int tiles = p.B * p.h * nkt;
+    dim3 grid((tiles + 3) / 4), block(256);
+    if (nkt == 1) ESMI_LAUNCH((attn_kernel<1>), grid, block, 0, st, p);
+    else if (nkt == 2) ESMI_LAUNCH((attn_kernel<2>), grid, block, 0, st, p);
+    else if (nkt <= 4) ESMI_LAUNCH((attn_kernel<4>), grid, block, 0, st, p);
+    else ESMI_LAUNCH((attn_kernel<8>), grid, block, 0, st, p);
+    return launch_status();
+}
+
+inline int conv_out_len(int n, int k, int stride, int pad) { return (n + 2 * pad - k) / stride + 1; }
+
+struct EncWs {
+    size_t t_merge, qkv, ctx, y1, m1, m2, total;
+};
+EncWs enc_ws(const esmi_encoder_block_shape* s) {
+    const int n = conv_out_len(s->n_in, s->kernel, s->stride, s->kernel / 2);
+    const size_t rows = (size_t)s->B * n;
+    EncWs w;
+    size_t o = 0;
+    w.t_merge = o; o += align256(rows * s->c_in * 4);
+    w.qkv = o; o += align256(rows * 3 * s->heads * s->c_out * 4);
+    w.ctx = o; o += align256(rows * s->heads * s->c_out * 4);
+    w.y1 = o; o += align256(rows * s->c_out * 4);
+    w.m1 = o; o += align256(rows * s->c_out * s->expansion * 4);
+    w.m2 = o; o += align256(rows * s->c_out * s->expansion * 4);
+    w.total = o;
+    return w;
+}
+
+}  // namespace
+
+extern "C" {
+
+int esmi_version(void) { return ESMI_VERSION; }
+const char* esmi_backend(void) {
+#ifdef ESMI_WAVESIM
+    return "wavesim";
+#else
+    return "hip:gfx950";
+#endif
+}
+
+int esmi_pack_conv_weight_f32(const float* src, float* dst, int cout, int cin, int k, esmi_stream_t stream) {
+    if (!src || !dst || cout <= 0 || cin <= 0 || k <= 0) return ESMI_ERR_ARG;
+    const long n = (long)cout * cin * k;
+    ESMI_LAUNCH(pack_conv_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, S(stream), src, dst, cout, cin, k, 0);
+    return launch_status();
+}
+int esmi_pack_convT_weight_f32(const float* src, float* dst, int cin, int cout, int k, esmi_stream_t stream) {
+    if (!src || !dst || cout <= 0 || cin <= 0 || k <= 0) return ESMI_ERR_ARG;
+    const long n = (long)cout * cin * k;
+    ESMI_LAUNCH(pack_conv_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, S(stream), src, dst, cout, cin, k, 1);
+    return launch_status();
+}
+
+int esmi_pool_mask_u8(const uint8_t* mask, int B, int T, int pool, uint8_t* out, int n_out, esmi_stream_t stream) {
+    if (!mask || !out || B <= 0 || T <= 0 || pool <= 0 || n_out <= 0) return ESMI_ERR_ARG;
+    ESMI_LAUNCH(pool_mask_kernel, dim3((B * n_out + 255) / 256), dim3(256), 0, S(stream), mask, B, T, pool, out, n_out);
+    return launch_status();
+}
+
+size_t esmi_encoder_block_workspace_bytes(const esmi_encoder_block_shape* s) { return s ? enc_ws(s).total : 0; }
+
+int esmi_encoder_block_f32(const esmi_encoder_block_weights* w, const esmi_encoder_block_shape* s, const int32_t* ids,
+                           const float* embed, const float* x_in, const uint8_t* mask, float* x_out, void* workspace,
+                           size_t workspace_bytes, esmi_stream_t stream) {
+    if (!w || !s || !x_out || !workspace) return ESMI_ERR_ARG;
+    if (!ids && !x_in) return ESMI_ERR_ARG;
+    const EncWs ws = enc_ws(s);
+    if (workspace_bytes < ws.total) return ESMI_ERR_WORKSPACE;
+    char* wsb = static_cast<char*>(workspace);
+    float* t_merge = reinterpret_cast<float*>(wsb + ws.t_merge);
+    float* qkv = reinterpret_cast<float*>(wsb + ws.qkv);
+    float* ctx = reinterpret_cast<float*>(wsb + ws.ctx);
+    float* y1 = reinterpret_cast<float*>(wsb + ws.y1);
+    float* m1 = reinterpret_cast<float*>(wsb + ws.m1);
+    float* m2 = reinterpret_cast<float*>(wsb + ws.m2);
+    const int B = s->B, C = s->c_out, h = s->heads, E = s->c_out * s->expansion;
+    const int n = conv_out_len(s->n_in, s->kernel, s->stride, s->kernel / 2);
+    hipStream_t st = S(stream);
+    int rc;
+    // merge conv k x k (dense, bias-free), networks.py:64-66
+    ConvGemmP p = conv_defaults();
+    p.B = B; p.n_in = s->n_in; p.c_in = s->c_in; p.n_out = n; p.c_out = s->c_in;
+    p.k = s->kernel; p.stride = s->stride; p.pad = s->kernel / 2;
+    if (ids) { p.ids = ids; p.table = embed; p.ld_table = s->c_in; p.vocab = s->vocab; }
+    else { p.A = x_in; p.lda = s->c_in; }
+    p.W = w->merge_w; p.out = t_merge; p.ldo = s->c_in;
+    if ((rc = launch_convgemm(p, st))) return rc;
+    // merge 1x1, networks.py:67
+    p = conv_defaults();
+    p.B = B; p.n_in = n; p.c_in = s->c_in; p.n_out = n; p.c_out = C;
+    p.A = t_merge; p.lda = s->c_in; p.W = w->merge1_w; p.out = x_out; p.ldo = C;
+    if ((rc = launch_convgemm(p, st))) return rc;
+    // qkv Linear (bias-free), blocks.py:44
+    p = conv_defaults();
+    p.B = B; p.n_in = n; p.c_in = C; p.n_out = n; p.c_out = 3 * h * C;
+    p.A = x_out; p.lda = C; p.W = w->qkv_w; p.out = qkv; p.ldo = 3 * h * C;
+    if ((rc = launch_convgemm(p, st))) return rc;
+    // softmax(q k^T scale) v, blocks.py:49-64
+    AttnP a;
+    a.qkv = qkv; a.B = B; a.N = n; a.C = C; a.h = h; a.ctx = ctx;
+    a.scale = 1.0f / sqrtf((float)(C / h));
+    if ((rc = launch_attn(a, st))) return rc;
+    // proj + residual + LN1 + mask, blocks.py:65 + networks.py:73-75
+    p = conv_defaults();
+    p.B = B; p.n_in = n; p.c_in = h * C; p.n_out = n; p.c_out = C;
+    p.A = ctx; p.lda = h * C; p.W = w->proj_w; p.bias = w->proj_b;
+    p.res = x_out; p.ldr = C; p.ln_g = w->ln1_g; p.ln_b = w->ln1_b; p.rowmask = mask;
+    p.out = y1; p.ldo = C;
+    if ((rc = launch_convgemm(p, st))) return rc;
+    // MixFFN, blocks.py:22-29
+    p = conv_defaults();
+    p.B = B; p.n_in = n; p.c_in = C; p.n_out = n; p.c_out = E;
+    p.A = y1; p.lda = C; p.W = w->mlp1_w; p.bias = w->mlp1_b; p.out = m1; p.ldo = E;
+    if ((rc = launch_convgemm(p, st))) return rc;
+    p = conv_defaults();
+    p.B = B; p.n_in = n; p.c_in = E; p.n_out = n; p.c_out = E; p.k = 3; p.pad = 1;
+    p.A = m1; p.lda = E; p.W = w->conv_w; p.bias = w->conv_b; p.act = ACT_GELU; p.out = m2; p.ldo = E;
+    if ((rc = launch_convgemm(p, st))) return rc;
+    // mlp2 + residual + LN2 + mask, networks.py:80-83
+    p = conv_defaults();
+    p.B = B; p.n_in = n; p.c_in = E; p.n_out = n; p.c_out = C;
+    p.A = m2; p.lda = E; p.W = w->mlp2_w; p.bias = w->mlp2_b;
+    p.res = y1; p.ldr = C; p.ln_g = w->ln2_g; p.ln_b = w->ln2_b; p.rowmask = mask;
+    p.out = x_out; p.ldo = C;
+    return launch_convgemm(p, st);
+}
+
+size_t esmi_fuse_workspace_bytes(int B, int T, int dim, int depth) {
+    return align256((size_t)B * T * dim * depth * 4) + align256((size_t)B * T * dim * 4);
+}
+
+int esmi_fuse_f32(const esmi_fuse_weights* w, int depth, int dim, int kernel, int B, int T, const float* const* feats,
+                  const int* n_i, const uint8_t* mask, float* out, int ld_out, void* workspace, size_t workspace_bytes,
+                  esmi_stream_t stream) {
+    if (!w || !feats || !n_i || !out || !workspace || depth < 1 || depth > ESMI_MAX_DEPTH) return ESMI_ERR_ARG;
+    if (workspace_bytes < esmi_fuse_workspace_bytes(B, T, dim, depth)) return ESMI_ERR_WORKSPACE;
+    float* cat = static_cast<float*>(workspace);
+    float* tmp = reinterpret_cast<float*>(static_cast<char*>(workspace) + align256((size_t)B * T * dim * depth * 4));
+    hipStream_t st = S(stream);
+    int rc;
+    for (int i = 0; i < depth; ++i) {
+        const int ci = dim << i, s = 1 << i;
+        ConvGemmP p = conv_defaults();  // Linear(dim*2^i, dim), networks.py:197
+        p.B = B; p.n_in = n_i[i]; p.c_in = ci; p.n_out = n_i[i]; p.c_out = dim;
+        p.A = feats[i]; p.lda = ci; p.W = w->mlp_w[i]; p.bias = w->mlp_b[i];
+        if (i == 0) {
+            if (n_i[0] != T) return ESMI_ERR_ARG;
+            p.out = cat; p.ldo = dim * depth; p.o_coff = 0;
+            if ((rc = launch_convgemm(p, st))) return rc;
+        } else {
+            p.out = tmp; p.ldo = dim;
+            if ((rc = launch_convgemm(p, st))) return rc;
+            if ((n_i[i] - 1) * s + kernel < T) return ESMI_ERR_UNSUPPORTED;  // torch.cat would raise in the reference
+            p = conv_defaults();  // ConvTranspose1d(dim, dim, k, stride 2^i) cropped to T, networks.py:199-206
+            p.mode = MODE_CONVT; p.k = kernel; p.stride = s;
+            p.B = B; p.n_in = n_i[i]; p.c_in = dim; p.n_out = T; p.c_out = dim;
+            p.A = tmp; p.lda = dim; p.W = w->up_w[i]; p.bias = w->up_b[i];
+            p.out = cat; p.ldo = dim * depth; p.o_coff = i * dim;
+            if ((rc = launch_convgemm(p, st))) return rc;
+        }
+    }
+    ConvGemmP p = conv_defaults();  // Linear(depth*dim, dim) + masked_fill, networks.py:215-217
+    p.B = B; p.n_in = T; p.c_in = dim * depth; p.n_out = T; p.c_out = dim;
+    p.A = cat; p.lda = dim * depth; p.W = w->fuse_w; p.bias = w->fuse_b; p.rowmask = mask;
+    p.out = out; p.ldo = ld_out;
+    return launch_convgemm(p, st);
+}
+
+size_t esmi_variance_adaptor_workspace_bytes(int B, int T, int dim) { return align256((size_t)B * T * dim * 4); }
+
+int esmi_variance_adaptor_f32(const esmi_predictor_weights* pitch, const esmi_predictor_weights* energy,
+                              const esmi_predictor_weights* duration, int dim, int B, int T, const uint8_t* mask,
+                              const float* pitch_target, const float* energy_target, const int32_t* duration_target,
+                              float* feat, float* pitch_pred, float* energy_pred, float* duration_pred,
+                              int32_t* pitch_idx, int32_t* energy_idx, int32_t* dur, void* workspace,
+                              size_t workspace_bytes, esmi_stream_t stream) {
+    if (!pitch || !energy || !duration || !feat || !pitch_pred || !energy_pred || !duration_pred || !dur || !workspace)
+        return ESMI_ERR_ARG;
+    if (workspace_bytes < esmi_variance_adaptor_workspace_bytes(B, T, dim)) return ESMI_ERR_WORKSPACE;
+    float* t1 = static_cast<float*>(workspace);
+    hipStream_t st = S(stream);
+    const esmi_predictor_weights* pw[3] = {pitch, energy, duration};
+    float* preds[3] = {pitch_pred, energy_pred, duration_pred};
+    int rc;
+    for (int q = 0; q < 3; ++q) {
+        // conv1 + ReLU -> LN1 -> ReLU, networks.py:152-155
+        ConvGemmP p = conv_defaults();
+        p.B = B; p.n_in = T; p.c_in = dim; p.n_out = T; p.c_out = dim; p.k = 3; p.pad = 1;
+        p.A = feat; p.lda = 4 * dim; p.a_coff = 0; p.W = pw[q]->conv1_w; p.bias = pw[q]->conv1_b; p.act = ACT_RELU;
+        p.ln_g = pw[q]->ln1_g; p.ln_b = pw[q]->ln1_b; p.post_relu = 1; p.out = t1; p.ldo = dim;
+        if ((rc = launch_convgemm(p, st))) return rc;
+        // conv2 + ReLU; pred = Linear(dim,1) on the PRE-norm2 tensor (:157-160); duration: ReLU + features = LN2
+        p = conv_defaults();
+        p.B = B; p.n_in = T; p.c_in = dim; p.n_out = T; p.c_out = dim; p.k = 3; p.pad = 1;
+        p.A = t1; p.lda = dim; p.W = pw[q]->conv2_w; p.bias = pw[q]->conv2_b; p.act = ACT_RELU;
+        p.dot_w = pw[q]->lin_w; p.dot_b = pw[q]->lin_b; p.dot_out = preds[q]; p.dot_relu = q == 2;
+        if (q == 2) {
+            p.ln_g = pw[q]->ln2_g; p.ln_b = pw[q]->ln2_b; p.rowmask = mask;   // :366-368
+            p.out = feat; p.ldo = 4 * dim; p.o_coff = 3 * dim;
+        }
+        if ((rc = launch_convgemm(p, st))) return rc;
+    }
+    VaTailP v;
+    v.rows = B * T; v.T = T; v.dim = dim; v.mask = mask;
+    v.pitch_pred = pitch_pred; v.energy_pred = energy_pred; v.dur_pred = duration_pred;
+    v.pitch_t = pitch_target; v.energy_t = energy_target; v.dur_t = duration_target;
+    v.pbins = pitch->bins; v.ebins = energy->bins; v.pemb = pitch->emb; v.eemb = energy->emb;
+    v.feat = feat; v.pitch_idx = pitch_idx; v.energy_idx = energy_idx; v.dur = dur;
+    if (!v.pbins || !v.ebins || !v.pemb || !v.eemb) return ESMI_ERR_ARG;
+    const long n = (long)B * T * dim;
+    ESMI_LAUNCH(va_tail_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, v);
+    return launch_status();
+}
+
+int esmi_length_regulate_i32(const int32_t* dur, int B, int T, int32_t* cum, int32_t* mel_len, int32_t* lmax,
+                             esmi_stream_t stream) {
+    if (!dur || !cum || !mel_len || !lmax || B <= 0 || T <= 0) return ESMI_ERR_ARG;
+    hipError_t e = hipMemsetAsync(lmax, 0, sizeof(int32_t), S(stream));
+    if (e != hipSuccess) return (int)e;
+    ESMI_LAUNCH(length_regulate_kernel, dim3(B), dim3(64), 0, S(stream), dur, T, cum, mel_len, lmax);
+    return launch_status();
+}
+
+int esmi_length_regulator_indices_i32(const int32_t* cum, int B, int T, int L, int32_t* idx, esmi_stream_t stream) {
+    if (!cum || !idx || B <= 0 || T <= 0 || L <= 0) return ESMI_ERR_ARG;
+    const long n = (long)B * L;
+    ESMI_LAUNCH(lr_indices_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, S(stream), cum, B, T, L, idx);
+    return launch_status();
+}
+
+int esmi_upsample_f32(const float* feat, const uint8_t* fmask, const int32_t* cum, int B, int T, int C, int L,
+                      float* features, uint8_t* masks, esmi_stream_t stream) {
+    if (!feat || !cum || !features || B <= 0 || T <= 0 || L <= 0 || (C & 3)) return ESMI_ERR_ARG;
+    const long n = (long)B * L * (C / 4);
+    ESMI_LAUNCH(upsample_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, S(stream), feat, fmask, cum, B, T, C, L,
+                features, masks);
+    return launch_status();
+}
+
+int esmi_mask_rows_f32(float* x, const uint8_t* mask, int64_t rows, int C, esmi_stream_t stream) {
+    if (!x || !mask || rows <= 0 || C <= 0) return ESMI_ERR_ARG;
+    const long n = (long)rows * C;
+    ESMI_LAUNCH(mask_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, S(stream), x, mask, (long)rows, C);
+    return launch_status();
+}
+
+// ------------------------------------------------------------------ mel decoder
+static int dec_check(const esmi_decoder_shape* s) {
+    if (!s) return ESMI_ERR_ARG;
+    if (s->dx2 != 128 && s->dx2 != 256) return ESMI_ERR_UNSUPPORTED;
+    if (s->d4 <= 0 || s->d4 % s->dx2) return ESMI_ERR_UNSUPPORTED;
+    if (s->kernel != 3 && s->kernel != 5) return ESMI_ERR_UNSUPPORTED;
+    if (s->n_mel <= 0 || s->n_mel > 32 * kMelNT) return ESMI_ERR_UNSUPPORTED;
+    if (s->n_blocks < 1 || s->block_depth < 1 || s->n_blocks * s->block_depth > ESMI_MAX_DEC_LAYERS) return ESMI_ERR_UNSUPPORTED;
+    if (2 * (s->kernel / 2) * s->n_blocks * s->block_depth >= kDecRows - 32) return ESMI_ERR_UNSUPPORTED;
+    return ESMI_OK;
+}
+
+size_t esmi_mel_decoder_blob_bytes(const esmi_decoder_shape* s) {
+    if (dec_check(s)) return 0;
+    return (size_t)dec_layout(s->d4, s->dx2, s->kernel, s->n_blocks, s->block_depth).total * sizeof(float);
+}
+
+int esmi_mel_decoder_pack_f32(const esmi_decoder_weights* w, const esmi_decoder_shape* s, float* blob,
+                              esmi_stream_t stream) {
+    int rc = dec_check(s);
+    if (rc) return rc;
+    if (!w || !blob) return ESMI_ERR_ARG;
+    const DecLayout L = dec_layout(s->d4, s->dx2, s->kernel, s->n_blocks, s->block_depth);
+    hipStream_t st = S(stream);
+    const int dx2 = s->dx2, nt = dx2 / 32;
+    auto bfrag = [&](const float* src, long off, int N, int K, int NT) {
+        const long n = (long)(K / 8) * NT * 256;
+        ESMI_LAUNCH(pack_bfrag_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src, blob + off, N, K, NT);
+    };
+    auto vec = [&](const float* src, long off, int n, int n_pad) {
+        ESMI_LAUNCH(copy_pad_kernel, dim3((n_pad + 255) / 256), dim3(256), 0, st, src, blob + off, n, n_pad);
+    };
+    bfrag(w->proj_w, L.proj_w, dx2, s->d4, nt);
+    vec(w->proj_b, L.proj_b, dx2, dx2);
+    vec(w->proj_ln_g, L.proj_g, dx2, dx2);
+    vec(w->proj_ln_b, L.proj_beta, dx2, dx2);
+    for (int l = 0; l < s->n_blocks * s->block_depth; ++l) {
+        const long base = L.layer0 + (long)l * L.layer_stride;
+        if (!w->dw_w[l] || !w->pw_w[l]) return ESMI_ERR_ARG;
+        ESMI_LAUNCH(pack_dw_kernel, dim3((dx2 * s->kernel + 255) / 256), dim3(256), 0, st, w->dw_w[l], blob + base + L.l_dw,
+                    dx2, s->kernel);
+        vec(w->dw_b[l], base + L.l_dwb, dx2, dx2);
+        bfrag(w->pw_w[l], base + L.l_pw, dx2, dx2, nt);
+        vec(w->pw_b[l], base + L.l_pwb, dx2, dx2);
+        vec(w->ln_g[l], base + L.l_g, dx2, dx2);
+        vec(w->ln_b[l], base + L.l_b, dx2, dx2);
+    }
+    for (int b = 0; b < s->n_blocks; ++b) {
+        vec(w->skip_g[b], L.skip0 + 2L * dx2 * b, dx2, dx2);
+        vec(w->skip_b[b], L.skip0 + 2L * dx2 * b + dx2, dx2, dx2);
+    }
+    bfrag(w->mel_w, L.mel_w, s->n_mel, dx2, kMelNT);
+    vec(w->mel_b, L.mel_b, s->n_mel, 32 * kMelNT);
+    return launch_status();
+}
+
+int esmi_mel_decoder_f32(const float* blob, const esmi_decoder_shape* s, const float* x, const int32_t* cum,
+                         const int32_t* mel_len, const int32_t* lmax_dev, int lmax_host, int apply_mask, int B, int T,
+                         int L_out, float* mel, esmi_stream_t stream) {
+    int rc = dec_check(s);
+    if (rc) return rc;
+    if (!blob || !x || !mel || B <= 0 || L_out <= 0 || !aligned16(blob) || !aligned16(x)) return ESMI_ERR_ARG;
+    if (!cum && lmax_dev) return ESMI_ERR_ARG;  // direct mode: L is the tensor's own length, known to the host
+    if (!lmax_dev && lmax_host <= 0) return ESMI_ERR_ARG;
+    MelDecP p;
+    p.blob = blob;
+    p.lay = dec_layout(s->d4, s->dx2, s->kernel, s->n_blocks, s->block_depth);
+    p.d4 = s->d4; p.n_blocks = s->n_blocks; p.block_depth = s->block_depth; p.n_mel = s->n_mel;
+    p.x = x; p.cum = cum; p.mel_len = mel_len; p.lmax_dev = lmax_dev; p.lmax_host = lmax_host;
+    p.apply_mask = apply_mask && mel_len; p.B = B; p.T = T; p.L_out = L_out; p.mel = mel;
+    p.halo = (s->kernel / 2) * s->n_blocks * s->block_depth;
+    p.TL = kDecRows - 2 * p.halo;
+    dim3 grid((L_out + p.TL - 1) / p.TL, B), block(256);
+    hipStream_t st = S(stream);
+#define ESMI_DEC_CASE(DX2, KD)                                                                                     \
+    {                                                                                                              \
+        const int lds = dec_lds_floats<DX2>(KD) * (int)sizeof(float);                                              \
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mel_decoder_kernel<DX2, KD>),             \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds);                      \
+        if (e != hipSuccess) return (int)e;                                                                        \
+        ESMI_LAUNCH((mel_decoder_kernel<DX2, KD>), grid, block, lds, st, p);                                       \
+    }
+    if (s->dx2 == 128 && s->kernel == 5) ESMI_DEC_CASE(128, 5)
+    else if (s->dx2 == 128 && s->kernel == 3) ESMI_DEC_CASE(128, 3)
+    else if (s->dx2 == 256 && s->kernel == 5) ESMI_DEC_CASE(256, 5)
+    else ESMI_DEC_CASE(256, 3)
+#undef ESMI_DEC_CASE
+    return launch_status();
+}
+
+}  // extern "C"

@@ -1,0 +1,143 @@
+// Device-side primitives shared by the esmi kernels (gfx950 / CDNA4, wave64).
+//
+// The kernels are written once, against the handful of primitives below.  The product build
+// (hipcc --offload-arch=gfx950) maps them to the CDNA4 instructions; the test-only wave
+// simulator (tools/wavesim, -DESMI_WAVESIM, host clang++) maps them to lane-accurate CPU
+// emulation so that index math / MFMA layouts / LDS protocols can be checked without a GPU.
+#pragma once
+
+#ifdef ESMI_WAVESIM
+#include "wavesim.h"
+#define ESMI_DYN_LDS(name) float* name = (float*)wavesim::dyn_lds()
+#define ESMI_LAUNCH(kern, grid, block, lds, stream, ...) \
+    wavesim::launch(grid, block, lds, [&]() { kern(__VA_ARGS__); })
+#else
+#include <hip/hip_runtime.h>
+#define ESMI_DYN_LDS(name) extern __shared__ __attribute__((aligned(16))) float name[]
+#define ESMI_LAUNCH(kern, grid, block, lds, stream, ...) hipLaunchKernelGGL(kern, grid, block, lds, stream, __VA_ARGS__)
+#endif
+
+namespace esmi {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// ---- MFMA, exact fp32 (v_mfma_f32_32x32x2_f32: 64 cycles/SIMD, == k-ordered fmaf chain)
+//   A[i = lane&31][k = lane>>5],  B[k = lane>>5][j = lane&31]
+//   D reg r of lane l: row = (r&3) + 8*(r>>2) + 4*(l>>5), col = l&31
+__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
+#ifdef ESMI_WAVESIM
+    return wavesim::mfma_32x32x2(a, b, c);
+#else
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+#endif
+}
+
+__device__ __forceinline__ float shfl_xor_f(float v, int mask) {
+#ifdef ESMI_WAVESIM
+    return wavesim::shfl_xor(v, mask);
+#else
+    return __shfl_xor(v, mask, 64);
+#endif
+}
+__device__ __forceinline__ int shfl_up_i(int v, int delta) {
+#ifdef ESMI_WAVESIM
+    return wavesim::shfl_up_i(v, delta);
+#else
+    return __shfl_up(v, delta, 64);
+#endif
+}
+__device__ __forceinline__ int shfl_i(int v, int src) {
+#ifdef ESMI_WAVESIM
+    return wavesim::shfl_i(v, src);
+#else
+    return __shfl(v, src, 64);
+#endif
+}
+
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }
+__device__ __forceinline__ int wave_id() { return (int)(threadIdx.x >> 6); }
+
+// row of accumulator register r inside a 32-row MFMA tile
+__device__ __forceinline__ int tile_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+
+// sum over the 32 lanes that hold one tile row (lanes sharing lane>>5)
+__device__ __forceinline__ float row_sum32(float v) {
+    v += shfl_xor_f(v, 1);
+    v += shfl_xor_f(v, 2);
+    v += shfl_xor_f(v, 4);
+    v += shfl_xor_f(v, 8);
+    v += shfl_xor_f(v, 16);
+    return v;
+}
+__device__ __forceinline__ float row_max32(float v) {
+    v = fmaxf(v, shfl_xor_f(v, 1));
+    v = fmaxf(v, shfl_xor_f(v, 2));
+    v = fmaxf(v, shfl_xor_f(v, 4));
+    v = fmaxf(v, shfl_xor_f(v, 8));
+    v = fmaxf(v, shfl_xor_f(v, 16));
+    return v;
+}
+
+// ---- activations (fp32; |err| <= ~2e-7 absolute, far inside the 1e-4 parity budget)
+__device__ __forceinline__ float tanh_f32(float x) {
+    const float ax = fabsf(x);
+    const float e = expf(-2.0f * ax);
+    const float t = (1.0f - e) / (1.0f + e);
+    return copysignf(t, x);
+}
+__device__ __forceinline__ float gelu_erf_f32(float x) {  // nn.GELU() default = exact erf form
+    return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+}
+enum Act { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU = 2, ACT_TANH = 3 };
+__device__ __forceinline__ float apply_act(float v, int act) {
+    switch (act) {
+        case ACT_RELU: return fmaxf(v, 0.0f);
+        case ACT_GELU: return gelu_erf_f32(v);
+        case ACT_TANH: return tanh_f32(v);
+        default: return v;
+    }
+}
+
+// ---- LayerNorm over the C = 32*NT columns of each tile row, in the MFMA C/D register layout.
+// v[nt][r] holds (row = tile_row(r), col = 32*nt + (lane&31)).  Two-pass (mean, then centred
+// variance), biased variance, eps inside the sqrt -- nn.LayerNorm semantics.
+template <int NT>
+__device__ __forceinline__ void layernorm_tile(f32x16 (&v)[NT], const float* __restrict__ g,
+                                               const float* __restrict__ b, int lane, float eps = 1e-5f) {
+    const float inv_c = 1.0f / (float)(32 * NT);
+    float gg[NT], bb[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        gg[nt] = g[32 * nt + (lane & 31)];
+        bb[nt] = b[32 * nt + (lane & 31)];
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        float s = 0.0f;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) s += v[nt][r];
+        const float mean = row_sum32(s) * inv_c;
+        float q = 0.0f;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const float d = v[nt][r] - mean;
+            q = fmaf(d, d, q);
+        }
+        const float var = row_sum32(q) * inv_c;
+        const float rstd = 1.0f / sqrtf(var + eps);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) v[nt][r] = fmaf((v[nt][r] - mean) * rstd, gg[nt], bb[nt]);
+    }
+}
+
+__device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ f32x4 zero4() { f32x4 z = {0.f, 0.f, 0.f, 0.f}; return z; }
+__device__ __forceinline__ f32x16 zero16() {
+    f32x16 z;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) z[i] = 0.f;
+    return z;
+}
+
+}  // namespace esmi

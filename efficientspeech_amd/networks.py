@@ -1,0 +1,516 @@
+"""Host-side mirror of the reference acoustic model API (layers/networks.py, layers/blocks.py).
+
+Same class names, constructor arguments, `forward` signatures, return types and -- because the
+sub-module nesting is reproduced -- the same `state_dict()` keys, so a Lightning
+checkpoint's `phoneme2mel.*` tensors load with strict=True and `demo.py`-style callers work
+unchanged.  None of the arithmetic happens here: every `forward` is a sequence of calls into the
+esmi C-ABI (include/esmi.h -> libesmi.so, hand-written HIP for gfx950).  The torch layers below
+are used purely as parameter containers; PyTorch supplies device memory and streams.
+
+There is no CPU fallback: tensors must live on the MI355X and libesmi.so must be built.
+"""
+import ctypes as C
+
+import torch
+from torch import nn
+
+from . import _lib
+from .config import N_SYMBOLS
+
+
+# --------------------------------------------------------------------------- plumbing
+def _runtime(t):
+    """(lib, stream handle) for the device `t` lives on."""
+    lib = _lib.load()
+    if _lib.backend(lib).startswith("hip"):
+        if not t.is_cuda:
+            raise RuntimeError("efficientspeech_amd: tensors must be on the GPU (no CPU fallback); "
+                               "call .to('cuda') on the module and its inputs")
+        return lib, torch.cuda.current_stream(t.device).cuda_stream
+    if t.is_cuda:                                   # wave-simulator library injected by tests/
+        raise RuntimeError("wave-simulator backend only accepts host tensors")
+    return lib, None
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def _f32(t):
+    t = t.detach()
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+def _mask_u8(mask):
+    """bool (B,T) padding mask -> contiguous uint8 (utils/tools.py:43-51 convention: True = pad)."""
+    if mask is None:
+        return None
+    return mask.detach().to(torch.bool).contiguous().view(torch.uint8)
+
+
+def get_mask_from_lengths(lengths, max_len=None):
+    """utils/tools.py:43-51: mask[b, t] = t >= lengths[b] (True marks padding)."""
+    if max_len is None:
+        max_len = int(torch.max(lengths).item())
+    ids = torch.arange(0, max_len, device=lengths.device).unsqueeze(0)
+    return ids >= lengths.unsqueeze(1)
+
+
+class _PackCache:
+    """Re-packs weights (tap-major convs, MFMA blob) only when a parameter changed."""
+
+    def __init__(self):
+        self.key = None
+        self.val = None
+
+    def get(self, params, build):
+        key = tuple((p.data_ptr(), p._version, str(p.device), p.dtype) for p in params)
+        if key != self.key:
+            self.val = build()
+            self.key = key
+        return self.val
+
+
+def _pack_conv(lib, stream, w, transposed=False):
+    """(Cout,Cin,k) [or ConvTranspose (Cin,Cout,k)] -> tap-major (k,Cout,Cin) on device."""
+    w = _f32(w)
+    a, b, k = w.shape
+    cout, cin = (b, a) if transposed else (a, b)
+    dst = torch.empty((k, cout, cin), dtype=torch.float32, device=w.device)
+    if transposed:
+        lib.esmi_pack_convT_weight_f32(_ptr(w), _ptr(dst), cin, cout, k, stream)
+    else:
+        lib.esmi_pack_conv_weight_f32(_ptr(w), _ptr(dst), cout, cin, k, stream)
+    return dst, w
+
+
+# --------------------------------------------------------------------------- parameter containers
+class SelfAttention(nn.Module):
+    """Parameters of blocks.py:32-41 (qkv bias-free; every head is full width: qkv = 3*h*dim)."""
+
+    def __init__(self, dim, num_heads=1, qkv_bias=False):
+        super().__init__()
+        assert dim % num_heads == 0, 'dim should be divisible by num_heads'
+        self.num_heads = num_heads
+        self.qkv = nn.Linear(dim, dim * 3 * num_heads, bias=qkv_bias)
+        self.proj = nn.Linear(dim * num_heads, dim)
+
+
+class MixFFN(nn.Module):
+    """Parameters of blocks.py:8-20."""
+
+    def __init__(self, dim, expansion_factor):
+        super().__init__()
+        hidden = dim * expansion_factor
+        self.mlp1 = nn.Linear(dim, hidden)
+        self.conv = nn.Conv1d(hidden, hidden, 3, padding=1)
+        self.mlp2 = nn.Linear(hidden, dim)
+
+
+class Encoder(nn.Module):
+    """Phoneme encoder pyramid (networks.py:15-87): per block merge convs -> attention -> MixFFN."""
+
+    def __init__(self, depth=2, embed_dim=128, kernel_size=3, expansion=1, reduction=4, head=1):
+        super().__init__()
+        dim = embed_dim // reduction
+        self.depth, self.embed_dim, self.expansion = depth, embed_dim, expansion
+        self.dim_outs = [dim * 2 ** i for i in range(depth)]
+        self.dim_ins = [embed_dim] + self.dim_outs[:-1]
+        self.heads = [head * (i + 1) for i in range(depth)]
+        self.kernels = [kernel_size - (2 if i > 0 else 0) for i in range(depth)]
+        self.strides = [1] + [2] * (depth - 1)
+        self.embed = nn.Embedding(N_SYMBOLS + 1, embed_dim, padding_idx=0)
+        self.attn_blocks = nn.ModuleList([
+            nn.ModuleList([
+                nn.Conv1d(ci, ci, kernel_size=k, stride=s, padding=k // 2, bias=False),   # dense, NOT depthwise
+                nn.Conv1d(ci, co, kernel_size=1, bias=False),
+                SelfAttention(co, num_heads=h),
+                MixFFN(co, expansion),
+                nn.LayerNorm(co),
+                nn.LayerNorm(co),
+            ]) for ci, co, h, k, s in zip(self.dim_ins, self.dim_outs, self.heads, self.kernels, self.strides)])
+        self._cache = _PackCache()
+
+    def get_feature_dims(self):
+        return self.dim_outs
+
+    def block_len(self, T, i):
+        n = T
+        for j in range(i + 1):
+            k = self.kernels[j]
+            n = (n + 2 * (k // 2) - k) // self.strides[j] + 1
+        return n
+
+    def _packed(self, lib, stream):
+        def build():
+            out = []
+            for merge, merge1, attn, ffn, n1, n2 in self.attn_blocks:
+                keep = []
+                mw, _ = _pack_conv(lib, stream, merge.weight)
+                cw, _ = _pack_conv(lib, stream, ffn.conv.weight)
+                t = dict(merge_w=mw, merge1_w=_f32(merge1.weight), qkv_w=_f32(attn.qkv.weight),
+                         proj_w=_f32(attn.proj.weight), proj_b=_f32(attn.proj.bias),
+                         mlp1_w=_f32(ffn.mlp1.weight), mlp1_b=_f32(ffn.mlp1.bias), conv_w=cw,
+                         conv_b=_f32(ffn.conv.bias), mlp2_w=_f32(ffn.mlp2.weight), mlp2_b=_f32(ffn.mlp2.bias),
+                         ln1_g=_f32(n1.weight), ln1_b=_f32(n1.bias), ln2_g=_f32(n2.weight), ln2_b=_f32(n2.bias))
+                keep.extend(t.values())
+                out.append((_lib.EncoderBlockWeights(**{k: _ptr(v) for k, v in t.items()}), keep))
+            return out, _f32(self.embed.weight)
+        return self._cache.get(list(self.parameters()), build)
+
+    def forward(self, phoneme, mask=None):
+        """phoneme int (B,T); mask bool (B,T) or None -> ([f_0..f_{depth-1}], decoder_mask (B,T,dim) or None)."""
+        feats, masks = self._run(phoneme, mask)
+        decoder_mask = None
+        if mask is not None:
+            decoder_mask = masks[0].bool().unsqueeze(-1).expand(-1, -1, self.dim_outs[0])
+        return feats, decoder_mask
+
+    def _run(self, phoneme, mask):
+        lib, stream = _runtime(self.embed.weight)
+        (blocks, embed) = self._packed(lib, stream)
+        dev = embed.device
+        ids = phoneme.detach().to(device=dev, dtype=torch.int32).contiguous()
+        B, T = ids.shape
+        m8 = _mask_u8(mask)
+        feats, masks = [], []
+        x_in, n_in = None, T
+        for i, (wts, _keep) in enumerate(blocks):
+            n = self.block_len(T, i)
+            bm = None
+            if m8 is not None:                                   # networks.py:69-70 + blocks.py:51-57
+                pool = int(round(T / n))                         # torch.round == Python round: half to even
+                if (T + pool - 1) // pool != n:
+                    raise RuntimeError(f"pooled mask length {(T + pool - 1) // pool} != sequence length {n}")
+                if pool == 1:
+                    bm = m8
+                else:
+                    bm = torch.empty((B, n), dtype=torch.uint8, device=dev)
+                    lib.esmi_pool_mask_u8(_ptr(m8), B, T, pool, _ptr(bm), n, stream)
+            shape = _lib.EncoderBlockShape(B, n_in, self.dim_ins[i], self.dim_outs[i], self.heads[i], self.kernels[i],
+                                           self.strides[i], self.expansion, N_SYMBOLS + 1)
+            ws_bytes = lib.esmi_encoder_block_workspace_bytes(C.byref(shape))
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+            x_out = torch.empty((B, n, self.dim_outs[i]), dtype=torch.float32, device=dev)
+            lib.esmi_encoder_block_f32(C.byref(wts), C.byref(shape), _ptr(ids) if i == 0 else None,
+                                       _ptr(embed) if i == 0 else None, _ptr(x_in), _ptr(bm), _ptr(x_out),
+                                       _ptr(ws), ws_bytes, stream)
+            feats.append(x_out)
+            masks.append(bm)
+            x_in, n_in = x_out, n
+        return feats, masks
+
+
+class AcousticDecoder(nn.Module):
+    """Pitch / energy / duration predictor parameters (networks.py:90-125)."""
+
+    def __init__(self, dim, pitch_stats=None, energy_stats=None, n_mel_channels=80, duration=False):
+        super().__init__()
+        self.n_mel_channels = n_mel_channels
+        self.duration = duration
+        self.conv1 = nn.Sequential(nn.Conv1d(dim, dim, kernel_size=3, padding=1), nn.ReLU())
+        self.norm1 = nn.LayerNorm(dim)
+        self.conv2 = nn.Sequential(nn.Conv1d(dim, dim, kernel_size=3, padding=1), nn.ReLU())
+        self.norm2 = nn.LayerNorm(dim)
+        self.linear = nn.Linear(dim, 1)
+        self.pitch_bins = self.pitch_embedding = self.energy_bins = self.energy_embedding = None
+        if pitch_stats is not None:
+            lo, hi = pitch_stats
+            self.pitch_bins = nn.Parameter(torch.linspace(lo, hi, dim - 1), requires_grad=False)
+            self.pitch_embedding = nn.Embedding(dim, dim)
+        if energy_stats is not None:
+            lo, hi = energy_stats
+            self.energy_bins = nn.Parameter(torch.linspace(lo, hi, dim - 1), requires_grad=False)
+            self.energy_embedding = nn.Embedding(dim, dim)
+
+    def _weights(self, lib, stream):
+        c1, _ = _pack_conv(lib, stream, self.conv1[0].weight)
+        c2, _ = _pack_conv(lib, stream, self.conv2[0].weight)
+        bins = self.pitch_bins if self.pitch_bins is not None else self.energy_bins
+        emb = self.pitch_embedding if self.pitch_embedding is not None else self.energy_embedding
+        t = dict(conv1_w=c1, conv1_b=_f32(self.conv1[0].bias), ln1_g=_f32(self.norm1.weight), ln1_b=_f32(self.norm1.bias),
+                 conv2_w=c2, conv2_b=_f32(self.conv2[0].bias), ln2_g=_f32(self.norm2.weight), ln2_b=_f32(self.norm2.bias),
+                 lin_w=_f32(self.linear.weight), lin_b=_f32(self.linear.bias),
+                 bins=None if bins is None else _f32(bins), emb=None if emb is None else _f32(emb.weight))
+        return _lib.PredictorWeights(**{k: _ptr(v) for k, v in t.items()}), list(t.values())
+
+
+class Fuse(nn.Module):
+    """Fuses the pyramid features back to phoneme rate (networks.py:168-219)."""
+
+    def __init__(self, dims, kernel_size=3):
+        super().__init__()
+        assert len(dims) > 0
+        dim = dims[0]
+        self.dims, self.kernel_size = list(dims), kernel_size
+        self.mlps = nn.ModuleList([
+            nn.ModuleList([nn.Linear(d, dim),
+                           nn.ConvTranspose1d(dim, dim, kernel_size=kernel_size, stride=d // dim)
+                           if d // dim > 1 else nn.Identity()]) for d in dims])
+        self.fuse = nn.Linear(dim * len(dims), dim)
+        self._cache = _PackCache()
+
+    def _packed(self, lib, stream):
+        def build():
+            w = _lib.FuseWeights()
+            keep = []
+            for i, (lin, up) in enumerate(self.mlps):
+                lw, lb = _f32(lin.weight), _f32(lin.bias)
+                keep += [lw, lb]
+                w.mlp_w[i], w.mlp_b[i] = _ptr(lw), _ptr(lb)
+                if isinstance(up, nn.ConvTranspose1d):
+                    uw, _ = _pack_conv(lib, stream, up.weight, transposed=True)
+                    ub = _f32(up.bias)
+                    keep += [uw, ub]
+                    w.up_w[i], w.up_b[i] = _ptr(uw), _ptr(ub)
+            fw, fb = _f32(self.fuse.weight), _f32(self.fuse.bias)
+            keep += [fw, fb]
+            w.fuse_w, w.fuse_b = _ptr(fw), _ptr(fb)
+            return w, keep
+        return self._cache.get(list(self.parameters()), build)
+
+    def _run(self, feats, m8, out=None, ld_out=None):
+        lib, stream = _runtime(self.fuse.weight)
+        w, _keep = self._packed(lib, stream)
+        dim, depth = self.dims[0], len(self.dims)
+        B, T = feats[0].shape[0], feats[0].shape[1]
+        dev = feats[0].device
+        if out is None:
+            out = torch.empty((B, T, dim), dtype=torch.float32, device=dev)
+            ld_out = dim
+        ws_bytes = lib.esmi_fuse_workspace_bytes(B, T, dim, depth)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        fp = (C.c_void_p * depth)(*[_ptr(f) for f in feats])
+        ni = (C.c_int * depth)(*[f.shape[1] for f in feats])
+        lib.esmi_fuse_f32(C.byref(w), depth, dim, self.kernel_size, B, T, fp, ni, _ptr(m8), _ptr(out), ld_out,
+                          _ptr(ws), ws_bytes, stream)
+        return out
+
+    def forward(self, features, mask=None):
+        """features: list of (B,N_i,dim*2^i); mask: (B,T,dim) bool or None -> (B,T,dim)."""
+        m8 = None if mask is None else _mask_u8(mask[..., 0])
+        return self._run([_f32(f) for f in features], m8)
+
+
+class FeatureUpsampler(nn.Module):
+    """Length regulator (networks.py:222-258) as a device-side scan + gather (no per-utterance host sync)."""
+
+    def forward(self, fused_features, fused_masks, duration, max_mel_len=None):
+        """fused_features (B,T,C); fused_masks (B,T,C) bool; duration (B,T[,1]) -> features, masks, mel_len."""
+        feat = _f32(fused_features)
+        lib, stream = _runtime(feat)
+        B, T, Cc = feat.shape
+        dev = feat.device
+        dur = duration.detach().reshape(B, T).to(device=dev, dtype=torch.int32).contiguous()
+        cum = torch.empty((B, T), dtype=torch.int32, device=dev)
+        mel_len = torch.empty((B,), dtype=torch.int32, device=dev)
+        lmax = torch.empty((1,), dtype=torch.int32, device=dev)
+        lib.esmi_length_regulate_i32(_ptr(dur), B, T, _ptr(cum), _ptr(mel_len), _ptr(lmax), stream)
+        L = int(max_mel_len) if max_mel_len is not None else int(lmax.item())
+        fm = None if fused_masks is None else _mask_u8(fused_masks[..., 0])
+        features = torch.empty((B, L, Cc), dtype=torch.float32, device=dev)
+        masks = torch.empty((B, L), dtype=torch.uint8, device=dev)
+        if L > 0:
+            lib.esmi_upsample_f32(_ptr(feat), _ptr(fm), _ptr(cum), B, T, Cc, L, _ptr(features), _ptr(masks), stream)
+        return features, masks.bool().unsqueeze(-1).expand(-1, -1, Cc), mel_len
+
+
+class MelDecoder(nn.Module):
+    """Mel spectrogram decoder (networks.py:261-304), one fused HIP kernel per call."""
+
+    def __init__(self, dim, kernel_size=5, n_mel_channels=80, n_blocks=2, block_depth=2):
+        super().__init__()
+        self.n_mel_channels = n_mel_channels
+        self.kernel_size, self.n_blocks, self.block_depth = kernel_size, n_blocks, block_depth
+        self.dim_x4 = 4 * dim
+        self.dim_x2 = dx2 = min(4 * dim, 256)
+        self.proj = nn.Sequential(nn.Linear(self.dim_x4, dx2), nn.Tanh(), nn.LayerNorm(dx2))
+        self.blocks = nn.ModuleList([
+            nn.ModuleList([
+                nn.ModuleList([
+                    nn.ModuleList([
+                        nn.Sequential(nn.Conv1d(dx2, dx2, groups=dx2, kernel_size=kernel_size, padding=kernel_size // 2),
+                                      nn.Conv1d(dx2, dx2, kernel_size=1), nn.Tanh()),
+                        nn.LayerNorm(dx2)]) for _ in range(block_depth)]),
+                nn.LayerNorm(dx2)]) for _ in range(n_blocks)])
+        self.mel_linear = nn.Linear(dx2, n_mel_channels)
+        self._cache = _PackCache()
+
+    def _shape(self):
+        return _lib.DecoderShape(self.dim_x4, self.dim_x2, self.kernel_size, self.n_blocks, self.block_depth,
+                                 self.n_mel_channels)
+
+    def _packed(self, lib, stream):
+        def build():
+            shape = self._shape()
+            nbytes = lib.esmi_mel_decoder_blob_bytes(C.byref(shape))
+            if nbytes == 0:
+                raise RuntimeError(f"mel decoder shape not supported by the HIP kernel: d4={self.dim_x4} "
+                                   f"dx2={self.dim_x2} k={self.kernel_size} ({self.n_blocks}x{self.block_depth})")
+            w = _lib.DecoderWeights()
+            keep = []
+
+            def put(name, t, idx=None):
+                t = _f32(t)
+                keep.append(t)
+                if idx is None:
+                    setattr(w, name, _ptr(t))
+                else:
+                    getattr(w, name)[idx] = _ptr(t)
+            put("proj_w", self.proj[0].weight); put("proj_b", self.proj[0].bias)
+            put("proj_ln_g", self.proj[2].weight); put("proj_ln_b", self.proj[2].bias)
+            layer = 0
+            for b, (convs, skip_norm) in enumerate(self.blocks):
+                for conv, norm in convs:
+                    put("dw_w", conv[0].weight, layer); put("dw_b", conv[0].bias, layer)
+                    put("pw_w", conv[1].weight, layer); put("pw_b", conv[1].bias, layer)
+                    put("ln_g", norm.weight, layer); put("ln_b", norm.bias, layer)
+                    layer += 1
+                put("skip_g", skip_norm.weight, b); put("skip_b", skip_norm.bias, b)
+            put("mel_w", self.mel_linear.weight); put("mel_b", self.mel_linear.bias)
+            blob = torch.empty(nbytes // 4, dtype=torch.float32, device=keep[0].device)
+            lib.esmi_mel_decoder_pack_f32(C.byref(w), C.byref(shape), _ptr(blob), stream)
+            return blob
+        return self._cache.get(list(self.parameters()), build)
+
+    def forward(self, features):
+        """features (B,L,4*dim) -> mel (B,L,n_mel).  (Direct mode: rows exactly as given.)"""
+        x = _f32(features)
+        lib, stream = _runtime(x)
+        B, L, _ = x.shape
+        mel = torch.empty((B, L, self.n_mel_channels), dtype=torch.float32, device=x.device)
+        if L > 0:
+            shape = self._shape()
+            lib.esmi_mel_decoder_f32(_ptr(self._packed(lib, stream)), C.byref(shape), _ptr(x), None, None, None, L, 0,
+                                     B, 0, L, _ptr(mel), stream)
+        return mel
+
+    def _fused(self, feat, cum, mel_len, lmax_dev, lmax_host, apply_mask, L_out):
+        """Length-regulator gather fused into the decoder: feat (B,T,d4) phoneme-rate."""
+        lib, stream = _runtime(feat)
+        B, T, _ = feat.shape
+        mel = torch.empty((B, L_out, self.n_mel_channels), dtype=torch.float32, device=feat.device)
+        if L_out > 0:
+            shape = self._shape()
+            lib.esmi_mel_decoder_f32(_ptr(self._packed(lib, stream)), C.byref(shape), _ptr(feat), _ptr(cum),
+                                     _ptr(mel_len), _ptr(lmax_dev), int(lmax_host), int(apply_mask), B, T, L_out,
+                                     _ptr(mel), stream)
+        return mel
+
+
+class PhonemeEncoder(nn.Module):
+    """Phonemes -> variance-adapted, length-regulated acoustic features (networks.py:307-401)."""
+
+    def __init__(self, pitch_stats=None, energy_stats=None, depth=2, reduction=4, head=1, embed_dim=128,
+                 kernel_size=3, expansion=1):
+        super().__init__()
+        self.encoder = Encoder(depth=depth, reduction=reduction, head=head, embed_dim=embed_dim,
+                               kernel_size=kernel_size, expansion=expansion)
+        dim = embed_dim // reduction
+        self.dim = dim
+        self.fuse = Fuse(self.encoder.get_feature_dims(), kernel_size=kernel_size)
+        self.feature_upsampler = FeatureUpsampler()
+        self.pitch_decoder = AcousticDecoder(dim, pitch_stats=pitch_stats)
+        self.energy_decoder = AcousticDecoder(dim, energy_stats=energy_stats)
+        self.duration_decoder = AcousticDecoder(dim, duration=True)
+        self._cache = _PackCache()
+
+    def _predictors(self, lib, stream):
+        def build():
+            return [d._weights(lib, stream) for d in (self.pitch_decoder, self.energy_decoder, self.duration_decoder)]
+        params = [p for d in (self.pitch_decoder, self.energy_decoder, self.duration_decoder) for p in d.parameters()]
+        return self._cache.get(params, build)
+
+    def _encode(self, x, train=False):
+        """Everything up to (and including) the duration scan; nothing frame-rate is materialised."""
+        phoneme = x["phoneme"]
+        B = phoneme.shape[0]
+        phoneme_mask = x["phoneme_mask"] if B > 1 else None           # KeyError for B>1, as the reference (:338)
+        dev = self.encoder.embed.weight.device
+        lib, stream = _runtime(self.encoder.embed.weight)
+        feats, bmasks = self.encoder._run(phoneme, phoneme_mask)
+        T, dim = feats[0].shape[1], self.dim
+        m8 = bmasks[0]
+        feat = torch.empty((B, T, 4 * dim), dtype=torch.float32, device=dev)
+        self.fuse._run(feats, m8, out=feat, ld_out=4 * dim)            # fused features land in channels [0, dim)
+        (pw, _k0), (ew, _k1), (dw, _k2) = self._predictors(lib, stream)
+
+        def tgt(key, dtype):
+            if not train:
+                return None
+            return x[key].detach().reshape(B, T).to(device=dev, dtype=dtype).contiguous()
+        pitch_t, energy_t = tgt("pitch", torch.float32), tgt("energy", torch.float32)
+        dur_t = tgt("duration", torch.int32)
+        if not train and "duration_forced" in x:                       # extension: inject durations at inference
+            dur_t = x["duration_forced"].detach().reshape(B, T).to(device=dev, dtype=torch.int32).contiguous()
+        preds = torch.empty((3, B, T, 1), dtype=torch.float32, device=dev)
+        idxs = torch.empty((2, B, T), dtype=torch.int32, device=dev)
+        dur = torch.empty((B, T), dtype=torch.int32, device=dev)
+        ws_bytes = lib.esmi_variance_adaptor_workspace_bytes(B, T, dim)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        lib.esmi_variance_adaptor_f32(C.byref(pw), C.byref(ew), C.byref(dw), dim, B, T, _ptr(m8), _ptr(pitch_t),
+                                      _ptr(energy_t), _ptr(dur_t), _ptr(feat), _ptr(preds[0]), _ptr(preds[1]),
+                                      _ptr(preds[2]), _ptr(idxs[0]), _ptr(idxs[1]), _ptr(dur), _ptr(ws), ws_bytes, stream)
+        cum = torch.empty((B, T), dtype=torch.int32, device=dev)
+        mel_len = torch.empty((B,), dtype=torch.int32, device=dev)
+        lmax = torch.empty((1,), dtype=torch.int32, device=dev)
+        lib.esmi_length_regulate_i32(_ptr(dur), B, T, _ptr(cum), _ptr(mel_len), _ptr(lmax), stream)
+        return dict(feat=feat, mask_u8=m8, pitch=preds[0], energy=preds[1], duration=preds[2], pitch_idx=idxs[0],
+                    energy_idx=idxs[1], dur=dur, cum=cum, mel_len=mel_len, lmax=lmax, feats=feats)
+
+    @staticmethod
+    def _padded_len(x, enc, train):
+        """L the reference pads to: max(x['mel_len']) when training (:344), the batch max otherwise.
+        `max_mel_len` in x (extension) supplies it without a device->host sync."""
+        if train:
+            return int(torch.max(x["mel_len"]).item()), None
+        if "max_mel_len" in x:
+            return int(x["max_mel_len"]), enc["lmax"]
+        return int(enc["lmax"].item()), None
+
+    def forward(self, x, train=False):
+        enc = self._encode(x, train)
+        lib, stream = _runtime(enc["feat"])
+        feat, cum, m8 = enc["feat"], enc["cum"], enc["mask_u8"]
+        B, T, C4 = feat.shape
+        L, _ = self._padded_len(x, enc, train)
+        features = torch.empty((B, L, C4), dtype=torch.float32, device=feat.device)
+        masks8 = torch.empty((B, L), dtype=torch.uint8, device=feat.device)
+        if L > 0:
+            lib.esmi_upsample_f32(_ptr(feat), _ptr(m8), _ptr(cum), B, T, C4, L, _ptr(features), _ptr(masks8), stream)
+        masks = None if m8 is None else masks8.bool().unsqueeze(-1).expand(-1, -1, C4)
+        return {"pitch": enc["pitch"], "energy": enc["energy"], "duration": enc["duration"],
+                "mel_len": enc["mel_len"], "features": features, "masks": masks}
+
+
+class Phoneme2Mel(nn.Module):
+    """Phoneme sequence -> mel spectrogram (networks.py:404-434)."""
+
+    def __init__(self, encoder, decoder):
+        super().__init__()
+        self.encoder = encoder
+        self.decoder = decoder
+
+    def forward(self, x, train=False):
+        if isinstance(x, list):                                       # ONNX-export quirk kept (:418-419)
+            x = x[0]
+        if train:
+            pred = self.encoder(x, train=True)
+            mel = self.decoder(pred["features"])
+            mask = pred["masks"]
+            if mask is not None and mel.size(0) > 1:                  # :424-427
+                lib, stream = _runtime(mel)
+                m8 = mask[:, :, 0].contiguous().view(torch.uint8)
+                lib.esmi_mask_rows_f32(_ptr(mel), _ptr(m8), mel.shape[0] * mel.shape[1], mel.shape[2], stream)
+            pred["mel"] = mel
+            return pred
+        # inference: the (B,L,4*dim) tensor is never materialised -- the decoder gathers through the
+        # duration scan and applies the final masked_fill itself.
+        enc = self.encoder._encode(x, train=False)
+        B = enc["feat"].shape[0]
+        L, lmax_dev = PhonemeEncoder._padded_len(x, enc, False)
+        apply_mask = enc["mask_u8"] is not None and B > 1
+        mel = self.decoder._fused(enc["feat"], enc["cum"], enc["mel_len"], lmax_dev, L, apply_mask, L)
+        return mel, enc["mel_len"], enc["duration"]

@@ -1,0 +1,216 @@
+/*
+ * esmi.h -- C ABI of the MI355X-native EfficientSpeech acoustic-model forward path.
+ *
+ * The reference (roatienza/efficientspeech) has no FFI: its boundary for this path is the
+ * Python nn.Module API of layers/networks.py + layers/blocks.py.  This header is the C-ABI that
+ * sits UNDER that API: one entry point per reference stage, plain device pointers and sizes,
+ * no torch types.  efficientspeech_amd/networks.py (the host-side mirror of the reference
+ * modules) binds these with ctypes; INTEGRATION.md shows the stub a reference maintainer adds.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer (hipMalloc'd / torch CUDA tensor .data_ptr()); tensors are
+ *    channels-last (B, N, C) contiguous fp32 unless noted; masks are uint8 (1 = padding), the
+ *    convention of utils/tools.py:43-51 get_mask_from_lengths.
+ *  - functions only ENQUEUE work on `stream` (a hipStream_t); they never allocate, free or
+ *    synchronise, so they can be captured into a hipGraph.  Scratch comes from the caller.
+ *  - return 0 on success, a negative ESMI_ERR_* for argument errors, a positive hipError_t
+ *    if a launch failed.
+ *  - conv weights are taken TAP-MAJOR (k, Cout, Cin); use esmi_pack_conv_weight_f32 /
+ *    esmi_pack_convT_weight_f32 once at checkpoint-load time to convert from the checkpoint
+ *    layouts (Cout, Cin, k) / (Cin, Cout, k).  nn.Linear weights (Cout, Cin) are used as stored.
+ */
+#ifndef ESMI_H
+#define ESMI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ESMI_VERSION 100 /* 0.1.0 */
+
+#define ESMI_OK 0
+#define ESMI_ERR_ARG (-1)         /* null pointer / bad size */
+#define ESMI_ERR_UNSUPPORTED (-2) /* shape outside what the kernels are built for */
+#define ESMI_ERR_WORKSPACE (-3)   /* workspace too small */
+
+typedef void* esmi_stream_t; /* hipStream_t */
+
+int esmi_version(void);
+/* "hip:gfx950" for the product build; "wavesim" for the CPU test simulator build. */
+const char* esmi_backend(void);
+
+/* ------------------------------------------------------------------ weight packing
+ * nn.Conv1d weight (Cout, Cin, k) -> (k, Cout, Cin)            [networks.py:40-42, blocks.py:17] */
+int esmi_pack_conv_weight_f32(const float* src, float* dst, int cout, int cin, int k, esmi_stream_t stream);
+/* nn.ConvTranspose1d weight (Cin, Cout, k) -> (k, Cout, Cin)   [networks.py:183] */
+int esmi_pack_convT_weight_f32(const float* src, float* dst, int cin, int cout, int k, esmi_stream_t stream);
+
+/* ------------------------------------------------------------------ Encoder block
+ * One pass of the loop body of Encoder.forward, layers/networks.py:62-85:
+ *   merge convs (dense Conv1d k/stride, then 1x1, both bias-free) -> SelfAttention
+ *   (blocks.py:43-71: every head uses the full width C, scale (C//h)^-1/2, scores NOT masked)
+ *   -> x = LN1(attn + x) -> mask -> x = LN2(MixFFN(x) + x) -> mask.
+ * Block 0 fuses the nn.Embedding gather (networks.py:54): pass ids+embed, x_in = NULL.       */
+typedef struct esmi_encoder_block_weights {
+    const float* merge_w;  /* (k, Cin, Cin) tap-major  <- attn_blocks.{i}.0.weight (Cin,Cin,k) */
+    const float* merge1_w; /* (Cout, Cin)              <- attn_blocks.{i}.1.weight (Cout,Cin,1) */
+    const float* qkv_w;    /* (3*h*C, C)               <- attn_blocks.{i}.2.qkv.weight          */
+    const float* proj_w;   /* (C, h*C)                 <- attn_blocks.{i}.2.proj.weight         */
+    const float* proj_b;   /* (C)                                                               */
+    const float* mlp1_w;   /* (e*C, C)                 <- attn_blocks.{i}.3.mlp1.weight         */
+    const float* mlp1_b;
+    const float* conv_w;   /* (3, e*C, e*C) tap-major  <- attn_blocks.{i}.3.conv.weight         */
+    const float* conv_b;
+    const float* mlp2_w;   /* (C, e*C)                 <- attn_blocks.{i}.3.mlp2.weight         */
+    const float* mlp2_b;
+    const float* ln1_g;    /* attn_blocks.{i}.4.{weight,bias} */
+    const float* ln1_b;
+    const float* ln2_g;    /* attn_blocks.{i}.5.{weight,bias} */
+    const float* ln2_b;
+} esmi_encoder_block_weights;
+
+typedef struct esmi_encoder_block_shape {
+    int B, n_in, c_in;       /* input  (B, n_in, c_in)  (block 0: c_in = embed_dim, n_in = T) */
+    int c_out, heads;        /* output (B, n_out, c_out), n_out = (n_in + 2*(k/2) - k)/stride + 1 */
+    int kernel, stride;      /* merge conv kernel / stride (networks.py:27-30)                */
+    int expansion;           /* MixFFN hidden = expansion * c_out                             */
+    int vocab;               /* rows of the embedding table (block 0 only)                    */
+} esmi_encoder_block_shape;
+
+size_t esmi_encoder_block_workspace_bytes(const esmi_encoder_block_shape* s);
+int esmi_encoder_block_f32(const esmi_encoder_block_weights* w, const esmi_encoder_block_shape* s,
+                           const int32_t* ids, const float* embed, /* block 0: (B,n_in) ids, (vocab,c_in) table */
+                           const float* x_in,                      /* blocks >= 1: (B, n_in, c_in), else NULL   */
+                           const uint8_t* mask,                    /* (B, n_out) pooled padding mask or NULL    */
+                           float* x_out,                           /* (B, n_out, c_out)                         */
+                           void* workspace, size_t workspace_bytes, esmi_stream_t stream);
+
+/* Pooled padding mask of an encoder block, blocks.py:51-57: pad (B,T) with True to a multiple
+ * of `pool`, max over groups of `pool` -> (B, n_out).                                        */
+int esmi_pool_mask_u8(const uint8_t* mask, int B, int T, int pool, uint8_t* out, int n_out, esmi_stream_t stream);
+
+/* ------------------------------------------------------------------ Fuse
+ * Fuse.forward, layers/networks.py:189-219.  feats[i] = encoder block i output (B, n_i, dim*2^i).
+ * out rows are written with leading dimension ld_out (>= dim) so that the result can land
+ * directly in the first `dim` channels of the (B,T,4*dim) variance-adaptor tensor.           */
+#define ESMI_MAX_DEPTH 4
+typedef struct esmi_fuse_weights {
+    const float* mlp_w[ESMI_MAX_DEPTH];   /* (dim, dim*2^i)      <- fuse.mlps.{i}.0.weight */
+    const float* mlp_b[ESMI_MAX_DEPTH];
+    const float* up_w[ESMI_MAX_DEPTH];    /* (k, dim, dim) tap-major <- fuse.mlps.{i>=1}.1.weight (Cin,Cout,k) */
+    const float* up_b[ESMI_MAX_DEPTH];
+    const float* fuse_w;                  /* (dim, depth*dim)    <- fuse.fuse.weight       */
+    const float* fuse_b;
+} esmi_fuse_weights;
+size_t esmi_fuse_workspace_bytes(int B, int T, int dim, int depth);
+int esmi_fuse_f32(const esmi_fuse_weights* w, int depth, int dim, int kernel, int B, int T,
+                  const float* const* feats, const int* n_i, /* host arrays of `depth` entries */
+                  const uint8_t* mask,                       /* (B,T) or NULL                 */
+                  float* out, int ld_out, void* workspace, size_t workspace_bytes, esmi_stream_t stream);
+
+/* ------------------------------------------------------------------ Variance adaptor
+ * PhonemeEncoder.forward lines 349-384 (layers/networks.py): the three AcousticDecoders
+ * (networks.py:151-165; `linear` reads the PRE-norm2 tensor), bucketize + embedding of
+ * pitch / energy (networks.py:128-149), the channel concat and the duration rounding
+ * (torch.round = half-to-even; masked_fill(mask,0).clamp(min=0) when a mask is given).
+ *
+ * feat is the (B,T,4*dim) tensor whose first `dim` channels already hold the fused features
+ * (esmi_fuse_f32 with ld_out = 4*dim); this call fills channels [dim, 4*dim).                */
+typedef struct esmi_predictor_weights {
+    const float* conv1_w; /* (3, dim, dim) tap-major <- {x}_decoder.conv1.0.weight */
+    const float* conv1_b;
+    const float* ln1_g;
+    const float* ln1_b;
+    const float* conv2_w; /* (3, dim, dim) tap-major */
+    const float* conv2_b;
+    const float* ln2_g;   /* used by the duration predictor only (features = LN2(y)) */
+    const float* ln2_b;
+    const float* lin_w;   /* (dim)  <- {x}_decoder.linear.weight (1,dim) */
+    const float* lin_b;   /* (1) */
+    const float* bins;    /* (dim-1) bucket edges  (pitch / energy), NULL for duration */
+    const float* emb;     /* (dim, dim) embedding  (pitch / energy), NULL for duration */
+} esmi_predictor_weights;
+size_t esmi_variance_adaptor_workspace_bytes(int B, int T, int dim);
+int esmi_variance_adaptor_f32(const esmi_predictor_weights* pitch, const esmi_predictor_weights* energy,
+                              const esmi_predictor_weights* duration, int dim, int B, int T,
+                              const uint8_t* mask,          /* (B,T) or NULL (B == 1 path)              */
+                              const float* pitch_target,    /* (B,T) teacher values or NULL (use pred)  */
+                              const float* energy_target,   /* (B,T) or NULL                            */
+                              const int32_t* duration_target, /* (B,T) forced durations or NULL         */
+                              float* feat,                  /* (B,T,4*dim) in/out                       */
+                              float* pitch_pred, float* energy_pred, float* duration_pred, /* (B,T)     */
+                              int32_t* pitch_idx, int32_t* energy_idx, /* (B,T) bucket ids (may be NULL) */
+                              int32_t* dur,                 /* (B,T) integer repeat counts              */
+                              void* workspace, size_t workspace_bytes, esmi_stream_t stream);
+
+/* ------------------------------------------------------------------ Length regulator
+ * FeatureUpsampler.forward, layers/networks.py:228-258 (and its dead twin acoustic.py:33-42):
+ * frame j of utterance b is phoneme i with cum[b][i-1] <= j < cum[b][i], cum = inclusive
+ * cumsum of max(dur,0).  Writes cum (B,T), mel_len (B) and *lmax = max_b mel_len[b]
+ * (all on device: no host round-trip, unlike the reference's 2*B syncs).                     */
+int esmi_length_regulate_i32(const int32_t* dur, int B, int T, int32_t* cum, int32_t* mel_len, int32_t* lmax,
+                             esmi_stream_t stream);
+/* explicit frame -> phoneme map idx (B,L): -1 for padding frames (j >= mel_len[b]). */
+int esmi_length_regulator_indices_i32(const int32_t* cum, int B, int T, int L, int32_t* idx, esmi_stream_t stream);
+/* materialise `features` (B,L,C) and `masks` (B,L) u8 exactly as FeatureUpsampler returns them
+ * (padding: 0.0 / True).  fmask: (B,T) phoneme mask or NULL.                                  */
+int esmi_upsample_f32(const float* feat, const uint8_t* fmask, const int32_t* cum, int B, int T, int C, int L,
+                      float* features, uint8_t* masks, esmi_stream_t stream);
+
+/* ------------------------------------------------------------------ Mel decoder
+ * MelDecoder.forward, layers/networks.py:291-304, fully fused: proj Linear+Tanh+LN, n_blocks x
+ * [block_depth x (depthwise k conv -> pointwise conv -> Tanh -> LN); skip LN], mel Linear.
+ * Weights are packed once into one blob (MFMA B-fragment order).              */
+#define ESMI_MAX_DEC_LAYERS 16
+typedef struct esmi_decoder_weights {   /* checkpoint layouts, device pointers */
+    const float* proj_w;   /* (dx2, d4)     <- decoder.proj.0.weight */
+    const float* proj_b;
+    const float* proj_ln_g; /* decoder.proj.2.{weight,bias} */
+    const float* proj_ln_b;
+    const float* dw_w[ESMI_MAX_DEC_LAYERS]; /* (dx2,1,k)   <- decoder.blocks.{b}.0.{d}.0.0.weight */
+    const float* dw_b[ESMI_MAX_DEC_LAYERS];
+    const float* pw_w[ESMI_MAX_DEC_LAYERS]; /* (dx2,dx2,1) <- decoder.blocks.{b}.0.{d}.0.1.weight */
+    const float* pw_b[ESMI_MAX_DEC_LAYERS];
+    const float* ln_g[ESMI_MAX_DEC_LAYERS]; /* decoder.blocks.{b}.0.{d}.1.{weight,bias}           */
+    const float* ln_b[ESMI_MAX_DEC_LAYERS];
+    const float* skip_g[ESMI_MAX_DEC_LAYERS]; /* decoder.blocks.{b}.1.{weight,bias}               */
+    const float* skip_b[ESMI_MAX_DEC_LAYERS];
+    const float* mel_w;    /* (n_mel, dx2)  <- decoder.mel_linear.weight */
+    const float* mel_b;
+} esmi_decoder_weights;
+
+typedef struct esmi_decoder_shape {
+    int d4, dx2;              /* input channels 4*dim, hidden min(4*dim, 256): dx2 in {128, 256} */
+    int kernel;               /* depthwise kernel (3 or 5)                                       */
+    int n_blocks, block_depth;
+    int n_mel;                /* <= 96                                                           */
+} esmi_decoder_shape;
+
+size_t esmi_mel_decoder_blob_bytes(const esmi_decoder_shape* s);
+int esmi_mel_decoder_pack_f32(const esmi_decoder_weights* w, const esmi_decoder_shape* s, float* blob,
+                              esmi_stream_t stream);
+
+/* Two input modes:
+ *  - fused length-regulator (cum != NULL): `x` is the phoneme-rate tensor (B,T,d4); frame j of
+ *    utterance b reads row searchsorted(cum[b], j); frames >= mel_len[b] read zeros.  This is
+ *    Phoneme2Mel.forward's encoder->decoder hand-off without materialising (B,L,d4).
+ *  - direct (cum == NULL): `x` is (B,L,d4) exactly as MelDecoder.forward receives it.
+ * L is the padded length the reference's Conv1d sees (zero padding beyond it): *lmax_dev if
+ * lmax_dev != NULL, else lmax_host.  mel is (B, L_out, n_mel); rows in [L, L_out) are zeroed.
+ * mel_len != NULL && apply_mask: rows >= mel_len[b] are zeroed (Phoneme2Mel's final
+ * masked_fill, networks.py:424-427).                                                          */
+int esmi_mel_decoder_f32(const float* blob, const esmi_decoder_shape* s, const float* x, const int32_t* cum,
+                         const int32_t* mel_len, const int32_t* lmax_dev, int lmax_host, int apply_mask, int B,
+                         int T, int L_out, float* mel, esmi_stream_t stream);
+
+/* x.masked_fill(mask[:, :, None], 0) on (rows, C) fp32 -- used by the module-level API when the
+ * decoder is called stand-alone.                                                              */
+int esmi_mask_rows_f32(float* x, const uint8_t* mask, int64_t rows, int C, esmi_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ESMI_H */

@@ -1,0 +1,41 @@
+"""Test helper: build + bind the CPU wave-simulator build of the kernel sources (tools/wavesim).
+
+Only tests use this.  `use_sim()` temporarily swaps the library handle inside
+efficientspeech_amd._lib so the very same host-side modules drive the simulated kernels on
+host tensors; the product never does this (it loads libesmi.so or raises).
+"""
+import contextlib
+import ctypes
+import os
+import subprocess
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SIM_SO = os.path.join(ROOT, "tools", "wavesim", "_build", "libesmi_sim.so")
+_SRCS = [os.path.join(ROOT, "efficientspeech_amd", "csrc", f) for f in
+         ("esmi_abi.hip", "convgemm.h", "attention.h", "mel_decoder.h", "small_kernels.h", "esmi_dev.h")] + \
+        [os.path.join(ROOT, "tools", "wavesim", f) for f in ("wavesim.h", "wavesim.cpp")] + \
+        [os.path.join(ROOT, "include", "esmi.h")]
+_handle = None
+
+
+def sim_lib():
+    global _handle
+    if _handle is None:
+        stale = not os.path.exists(SIM_SO) or any(os.path.getmtime(s) > os.path.getmtime(SIM_SO) for s in _SRCS)
+        if stale:
+            subprocess.check_call([os.path.join(ROOT, "tools", "wavesim", "build.sh")], stdout=subprocess.DEVNULL)
+        from efficientspeech_amd import _lib
+        _handle = _lib.bind(ctypes.CDLL(SIM_SO))
+        assert _handle.esmi_backend() == b"wavesim"
+    return _handle
+
+
+@contextlib.contextmanager
+def use_sim():
+    from efficientspeech_amd import _lib
+    old = _lib._LIB
+    _lib._LIB = sim_lib()
+    try:
+        yield _lib._LIB
+    finally:
+        _lib._LIB = old
