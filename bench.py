@@ -1,0 +1,152 @@
+#!/usr/bin/env python3
+"""bench.py -- mel-frames/sec of the EfficientSpeech acoustic-model forward path on MI355X.
+
+One "step" = one full Phoneme2Mel inference forward (phoneme ids -> mel) over one synthetic batch
+on every rank: tiny ES, B=256 utterances x T=128 phonemes per GPU, injected durations D-const = 6
+(BASELINE.json configs[1]; random-init durations round to 0, fact 6), inputs already
+resident in HBM.  With N > 1 ranks the utterance batch is sharded (weak scaling: 256 per GPU) and
+each step ends with the RCCL all-gather of the mel shards over xGMI, pipelined one step behind the
+compute on a side stream.
+
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (the fused mel decoder),
+timed live with HIP events on the launch stream; `cpu_baseline` is the C oracle (oracle/, fp32
+accumulation, OpenMP) timed on this box's host cores -- a reported baseline, not the target.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+FP32_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 == fp32 vector peak
+HBM_PEAK_GBS = 8000.0
+# SURVEY.md §8d algorithmic work per valid mel frame, decoder only: (flops, bytes)
+DECODER_WORK = {"tiny": (189_440, 832), "small": (973_824, 1344), "base": (1_505_792, 2368)}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--config", default="tiny", choices=["tiny", "small", "base"])
+    ap.add_argument("--batch", type=int, default=None, help="utterances per GPU (default: BASELINE config)")
+    ap.add_argument("--phonemes", type=int, default=None)
+    ap.add_argument("--dur", type=int, default=6, help="injected frames per phoneme (D-const)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-gather", action="store_true", help="skip the mel all-gather (N>1 debugging)")
+    return ap.parse_args()
+
+
+def cpu_baseline(cfg, sd, T, dur):
+    """Time the oracle (fp32-accumulating build) on a bounded sample of the same workload."""
+    from oracle import oracle
+    from efficientspeech_amd.synth import synth_phonemes
+    w = oracle.Weights(sd)
+    B = 256 if cfg.name == "tiny" else 64
+
+    def run(b):
+        ids, mask = synth_phonemes(b, T, 99)
+        d = np.full((b, T), dur, np.int32)
+        z = np.zeros((b, T), np.float32)
+        t0 = time.perf_counter()
+        o = oracle.phoneme2mel(cfg, w, ids, mask, pitch=z, energy=z, duration=d, f32=True)
+        return int(o.mel_len.sum()), time.perf_counter() - t0
+    run(4)                                   # spin up the OpenMP pool
+    frames, dt = run(B)
+    cores = len(os.sched_getaffinity(0))
+    return {"value": frames / dt, "unit": "mel-frames/s", "cores": cores, "kind": "port",
+            "sample": f"oracle/es_oracle.c (fp32 accumulate, OpenMP {cores} threads), {cfg.name} ES full forward, "
+                      f"B={B} T={T} D-const {dur}: {frames} frames in {dt:.2f} s"}
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", 0))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)     # "nccl" is RCCL on ROCm
+
+    from efficientspeech_amd import CONFIGS, build_phoneme2mel, load_numpy_state_dict
+    from efficientspeech_amd.synth import synth_state_dict, synth_phonemes
+    from efficientspeech_amd.sharded import ShardedMelPipeline
+    cfg = CONFIGS[a.config]
+    B = a.batch or {"tiny": 256, "small": 256, "base": 512}[a.config]
+    T = a.phonemes or {"tiny": 128, "small": 256, "base": 256}[a.config]
+    L = T * a.dur
+    sd = synth_state_dict(cfg, 1234)
+    net = build_phoneme2mel(cfg)
+    load_numpy_state_dict(net, sd)
+    net = net.to(dev)
+    ids, mask = synth_phonemes(B, T, 1234 + rank)
+    x = {"phoneme": torch.from_numpy(ids).to(dev), "phoneme_mask": torch.from_numpy(mask).to(dev),
+         "duration_forced": torch.full((B, T), a.dur, dtype=torch.int32, device=dev), "max_mel_len": L}
+    pipe = ShardedMelPipeline(net, world_size=world, gather=(world > 1 and not a.no_gather))
+
+    def sync_all():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    with torch.no_grad():
+        for _ in range(a.warmup):
+            pipe.step(x)
+        pipe.flush()
+        net.decoder.timing = []
+        sync_all()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            pipe.step(x)
+        pipe.flush()
+        sync_all()
+        dt = time.perf_counter() - t0
+    ev = net.decoder.timing
+    net.decoder.timing = None
+    dec_ms = float(np.mean([s.elapsed_time(e) for s, e in ev])) if ev else float("nan")
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    frames_per_step = B * L * world                       # every frame valid under D-const, no padding
+    value = frames_per_step * a.steps / dt
+    flops, nbytes = DECODER_WORK[a.config]
+    ach_tf = flops * B * L / (dec_ms * 1e-3) / 1e12
+    out = {
+        "metric": "mel-frames/sec (whole node), full Phoneme2Mel forward", "value": value, "unit": "mel-frames/s",
+        "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "mRTF": value * 256 / 22050,
+        "config": {"workload": f"{a.config} ES ({sum(v.size for v in sd.values())} params, seeded random weights), "
+                               f"synthetic phoneme batch B={B} T={T} per GPU, injected durations D-const {a.dur} "
+                               f"(L={L}), eval path, mel all-gather over RCCL when N>1",
+                   "global_batch": B * world, "phonemes": T, "frames_per_step": frames_per_step,
+                   "parallelism": f"batch-shard x{world}"},
+        "roofline": {"bound": "mfma", "kernel": "mel_decoder_kernel", "achieved": ach_tf, "peak": FP32_PEAK_TFLOPS,
+                     "unit": "TFLOP/s", "frac": ach_tf / FP32_PEAK_TFLOPS, "traffic": None,
+                     "kernel_ms": dec_ms, "algorithmic_flops_per_frame": flops, "algorithmic_bytes_per_frame": nbytes,
+                     "hbm_frac": nbytes * B * L / (dec_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                     "note": "exact-fp32 MFMA bound (228 FLOP/B >> 20 FLOP/B machine balance); hbm_frac reported "
+                             "because north_star quotes the HBM roofline"},
+    }
+    if rank == 0:
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(cfg, sd, T, a.dur)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

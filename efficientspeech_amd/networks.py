@@ -337,6 +337,7 @@ class MelDecoder(nn.Module):
                 nn.LayerNorm(dx2)]) for _ in range(n_blocks)])
         self.mel_linear = nn.Linear(dx2, n_mel_channels)
         self._cache = _PackCache()
+        self.timing = None      # bench.py sets this to a list to collect (start, end) HIP events per launch
 
     def _shape(self):
         return _lib.DecoderShape(self.dim_x4, self.dim_x2, self.kernel_size, self.n_blocks, self.block_depth,
@@ -394,9 +395,17 @@ class MelDecoder(nn.Module):
         mel = torch.empty((B, L_out, self.n_mel_channels), dtype=torch.float32, device=feat.device)
         if L_out > 0:
             shape = self._shape()
-            lib.esmi_mel_decoder_f32(_ptr(self._packed(lib, stream)), C.byref(shape), _ptr(feat), _ptr(cum),
+            blob = self._packed(lib, stream)
+            ev = None
+            if self.timing is not None and feat.is_cuda:      # events on the stream the kernel is launched on
+                ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                ev[0].record()
+            lib.esmi_mel_decoder_f32(_ptr(blob), C.byref(shape), _ptr(feat), _ptr(cum),
                                      _ptr(mel_len), _ptr(lmax_dev), int(lmax_host), int(apply_mask), B, T, L_out,
                                      _ptr(mel), stream)
+            if ev is not None:
+                ev[1].record()
+                self.timing.append(ev)
         return mel
 
 

@@ -1,0 +1,108 @@
+"""Batch-sharded multi-GPU inference: one process per GPU, utterances split across ranks, one
+all-gather of the mel shards at the end (RCCL over xGMI).
+
+The reference has no multi-GPU inference; utterances are independent (no cross-batch op anywhere on
+the path), so the only exchange is
+  1. all_reduce(MAX) of the local padded length, so that every rank pads -- and zero-pads its
+     convolutions -- at the same L as a single-GPU run of the whole batch would (skipped when the
+     caller supplies `max_mel_len`), and
+  2. all_gather of mel (B/G, L, 80) fp32 and mel_len (B/G,) int32.
+The gathered result is bit-identical to the single-GPU result (tests/test_sharded.py).
+
+`ShardedMelPipeline` overlaps step i's all-gather (side stream) with step i+1's compute: on xGMI the
+gather of a tiny-ES batch costs about as much as computing it, so serialising them would halve the
+throughput.
+"""
+import torch
+import torch.distributed as dist
+
+
+def shard_batch(x, rank, world):
+    """Contiguous utterance shard of every batch-leading tensor in the input dict."""
+    B = x["phoneme"].shape[0]
+    assert B % world == 0, f"batch {B} not divisible by world size {world}"
+    per = B // world
+    out = {}
+    for k, v in x.items():
+        out[k] = v[rank * per:(rank + 1) * per] if torch.is_tensor(v) and v.dim() > 0 and v.shape[0] == B else v
+    return out
+
+
+def sharded_forward(net, x_full, group=None):
+    """Run Phoneme2Mel inference on this rank's shard of `x_full`, return the full
+    (mel (B,L,80), mel_len (B,), duration (B,T,1)) on every rank."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    if world == 1:
+        return net(x_full)
+    x = shard_batch(x_full, rank, world)
+    if "phoneme_mask" not in x_full and x_full["phoneme"].shape[0] > 1:
+        raise KeyError("phoneme_mask")                     # same contract as the reference for B > 1
+    if x["phoneme"].shape[0] == 1:
+        # a 1-utterance shard of a B>1 batch must still take the masked (B>1) code path of the
+        # reference (networks.py:338); duplicate the utterance and drop the copy afterwards.
+        x = {k: (torch.cat([v, v]) if torch.is_tensor(v) and v.dim() > 0 and v.shape[0] == 1 else v) for k, v in x.items()}
+        dup = True
+    else:
+        dup = False
+    if "max_mel_len" not in x:
+        enc = net.encoder._encode(x, train=False)
+        lmax = enc["lmax"].clone()
+        dist.all_reduce(lmax, op=dist.ReduceOp.MAX, group=group)
+        L = int(lmax.item())
+        B = enc["feat"].shape[0]
+        mel = net.decoder._fused(enc["feat"], enc["cum"], enc["mel_len"], None, L, True, L)
+        mel_len, dur = enc["mel_len"], enc["duration"]
+    else:
+        mel, mel_len, dur = net(x)
+    if dup:
+        mel, mel_len, dur = mel[:1], mel_len[:1], dur[:1]
+    outs = []
+    for t in (mel.contiguous(), mel_len.contiguous(), dur.contiguous()):
+        full = torch.empty((t.shape[0] * world,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+        dist.all_gather_into_tensor(full, t, group=group)
+        outs.append(full)
+    return tuple(outs)
+
+
+class ShardedMelPipeline:
+    """Steady-state serving loop: step(x) computes this rank's shard; its all-gather runs on a side
+    stream while the next step computes.  `results()` yields gathered batches in order."""
+
+    def __init__(self, net, world_size=1, gather=True, group=None, depth=2):
+        self.net, self.world, self.group = net, world_size, group
+        self.gather = gather and world_size > 1
+        self.depth = depth
+        self.comm = None
+        self.inflight = []       # (done_event, gathered mel, gathered mel_len)
+        self.last = None
+
+    def step(self, x):
+        mel, mel_len, _ = self.net(x)
+        if not self.gather:
+            self.last = (mel, mel_len)
+            return self.last
+        if self.comm is None:
+            self.comm = torch.cuda.Stream(device=mel.device)
+        while len(self.inflight) >= self.depth:            # bound queue depth / memory
+            self.inflight.pop(0)[0].synchronize()
+        ready = torch.cuda.Event()
+        ready.record()                                      # compute stream: mel is complete here
+        mel.record_stream(self.comm)
+        mel_len.record_stream(self.comm)
+        with torch.cuda.stream(self.comm):
+            self.comm.wait_event(ready)
+            full = torch.empty((mel.shape[0] * self.world,) + tuple(mel.shape[1:]), dtype=mel.dtype, device=mel.device)
+            lens = torch.empty((mel_len.shape[0] * self.world,), dtype=mel_len.dtype, device=mel.device)
+            dist.all_gather_into_tensor(full, mel, group=self.group)
+            dist.all_gather_into_tensor(lens, mel_len, group=self.group)
+            done = torch.cuda.Event()
+            done.record()
+        self.inflight.append((done, full, lens))
+        self.last = (full, lens)
+        return self.last
+
+    def flush(self):
+        for done, _, _ in self.inflight:
+            done.synchronize()
+        self.inflight.clear()

@@ -1,0 +1,190 @@
+"""Parity tests proper: the HIP path on a real MI355X, through the C-ABI, against
+(1) the committed golden vectors (outputs of the reference itself) and (2) the CPU oracle.
+
+Tolerances: mel L-inf < 1e-4 (north_star), continuous predictions 2e-5, discrete decisions
+(bucket ids, rounded durations, mel_len, length-regulator rows) bit-exact.
+"""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from efficientspeech_amd import CONFIGS, _lib
+from efficientspeech_amd.synth import synth_phonemes
+from oracle import oracle
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")))
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _hip_library_loaded():
+    lib = _lib.load()
+    assert _lib.backend(lib) == "hip:gfx950", "GPU tests must run on the HIP library, nothing else"
+    assert torch.cuda.is_available()
+
+
+@pytest.fixture(scope="module")
+def nets():
+    cache = {}
+
+    def get(name, g=None):
+        if name not in cache:
+            cache[name] = H.make_net(name, DEV, golden=g)
+        return cache[name]
+    return get
+
+
+@pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p)[:-4] for p in GOLDEN])
+def test_golden_vectors(path, nets):
+    g = np.load(path)
+    name = os.path.basename(path).split("_")[0]
+    net, cfg, sd = nets(name, g)
+    H.check_against_golden(net, g, DEV)
+
+
+@pytest.mark.parametrize("name,B,T,lens", [
+    ("tiny", 8, 70, [70, 66, 51, 40, 33, 17, 9, 2]),      # 3 row tiles, N=70/35 keys, 3 decoder windows
+    ("tiny", 5, 128, [128, 128, 100, 64, 1]),
+    ("small", 4, 100, [100, 77, 50, 13]),
+    ("base", 3, 64, [64, 40, 7]),
+    ("base", 2, 256, [256, 200]),                         # T=256: 8 key tiles (attn_kernel<8>)
+])
+def test_eval_path_vs_oracle(name, B, T, lens, nets):
+    net, cfg, sd = nets(name)
+    ids, mask = synth_phonemes(B, T, 4321, lens)
+    x = {"phoneme": torch.from_numpy(ids).to(DEV), "phoneme_mask": torch.from_numpy(mask).to(DEV)}
+    with torch.no_grad():
+        enc = net.encoder._encode(x)
+        mel, mel_len, _ = net(x)
+    o = oracle.phoneme2mel(cfg, oracle.Weights(sd), ids, mask)
+    err = H.compare_eval_with_oracle(cfg, o, enc, mel, mel_len, sd)
+    assert err == err, "a discrete decision flipped inside its margin; pick another seed for this case"
+    # rows beyond mel_len are exactly zero (final masked_fill)
+    m = mel.cpu().numpy()
+    for b in range(B):
+        assert not m[b, int(o.mel_len[b]):].any()
+
+
+def test_b1_path_has_no_masks(nets):
+    net, cfg, sd = nets("tiny")
+    ids, _ = synth_phonemes(1, 50, 5)
+    with torch.no_grad():
+        mel, mel_len, dur = net({"phoneme": torch.from_numpy(ids).to(DEV)})
+        pe = net.encoder({"phoneme": torch.from_numpy(ids).to(DEV)})
+    assert pe["masks"] is None
+    o = oracle.phoneme2mel(cfg, oracle.Weights(sd), ids, None)
+    assert np.array_equal(mel_len.cpu().numpy(), o.mel_len)
+    assert np.abs(mel.cpu().numpy() - o.mel).max() < H.MEL_TOL
+
+
+def test_batch_gt1_requires_mask(nets):
+    net, _, _ = nets("tiny")
+    with pytest.raises(KeyError):
+        net({"phoneme": torch.ones((2, 8), dtype=torch.int32, device=DEV)})
+
+
+def test_list_input_quirk(nets):
+    net, _, _ = nets("tiny")
+    ids, _ = synth_phonemes(1, 12, 5)
+    x = {"phoneme": torch.from_numpy(ids).to(DEV)}
+    with torch.no_grad():
+        a = net([x])[0]
+        b = net(x)[0]
+    assert torch.equal(a, b)
+
+
+def test_decoder_direct_mode_vs_oracle(nets):
+    """MelDecoder.forward(features) stand-alone (the reference's module-level API)."""
+    for name, L in (("tiny", 300), ("small", 150), ("base", 131)):
+        net, cfg, sd = nets(name)
+        rng = np.random.default_rng(3)
+        feats = rng.standard_normal((3, L, cfg.d4)).astype(np.float32)
+        with torch.no_grad():
+            mel = net.decoder(torch.from_numpy(feats).to(DEV)).cpu().numpy()
+        ref = oracle.mel_decoder(cfg, oracle.Weights(sd), feats)
+        assert np.abs(mel - ref).max() < H.MEL_TOL
+
+
+def test_length_regulator_bit_exact():
+    lib = _lib.load()
+    rng = np.random.default_rng(11)
+    for B, T in ((64, 128), (3, 257), (1, 1)):
+        dur = rng.integers(-2, 12, size=(B, T)).astype(np.int32)
+        dur[rng.random((B, T)) < 0.2] = 0
+        d = torch.from_numpy(dur).to(DEV)
+        cum = torch.empty((B, T), dtype=torch.int32, device=DEV)
+        mel_len = torch.empty((B,), dtype=torch.int32, device=DEV)
+        lmax = torch.empty((1,), dtype=torch.int32, device=DEV)
+        s = torch.cuda.current_stream().cuda_stream
+        lib.esmi_length_regulate_i32(d.data_ptr(), B, T, cum.data_ptr(), mel_len.data_ptr(), lmax.data_ptr(), s)
+        ref_cum = np.cumsum(np.maximum(dur, 0), 1).astype(np.int32)
+        assert np.array_equal(cum.cpu().numpy(), ref_cum)
+        assert np.array_equal(mel_len.cpu().numpy(), ref_cum[:, -1])
+        L = int(lmax.item())
+        assert L == ref_cum[:, -1].max()
+        for Lq in (L, L + 5, max(L - 3, 1)):
+            idx = torch.empty((B, Lq), dtype=torch.int32, device=DEV)
+            lib.esmi_length_regulator_indices_i32(cum.data_ptr(), B, T, Lq, idx.data_ptr(), s)
+            assert np.array_equal(idx.cpu().numpy(), oracle.length_regulate(dur, Lq))
+
+
+def test_upsampler_module_vs_oracle(nets):
+    net, cfg, _ = nets("tiny")
+    rng = np.random.default_rng(5)
+    B, T, Cc = 4, 33, 128
+    feat = rng.standard_normal((B, T, Cc)).astype(np.float32)
+    dur = rng.integers(0, 7, size=(B, T)).astype(np.int32)
+    mask = np.arange(T)[None] >= np.array([33, 20, 11, 5])[:, None]
+    dur[mask] = 0
+    fm = np.repeat(mask[:, :, None], Cc, 2)
+    f, m, ml = net.encoder.feature_upsampler(torch.from_numpy(feat).to(DEV), torch.from_numpy(fm).to(DEV),
+                                             torch.from_numpy(dur).to(DEV))
+    L = int(dur.sum(1).max())
+    idx = oracle.length_regulate(dur, L)
+    rf, rm = oracle.upsample(feat, mask, idx)
+    assert ml.dtype == torch.int32 and np.array_equal(ml.cpu().numpy(), dur.sum(1))
+    assert np.array_equal(f.cpu().numpy(), rf)
+    assert m.dtype == torch.bool and np.array_equal(m[:, :, 0].cpu().numpy(), rm)
+
+
+def test_full_size_tiny_properties(nets):
+    """BASELINE configs[1]: tiny ES, B=256 T=128, D-const 6 (L=768): spot-check against the oracle and
+    size-independent properties (determinism, batch-split invariance, mel_len == sum of durations)."""
+    net, cfg, sd = nets("tiny")
+    B, T, D = 256, 128, 6
+    ids, mask = synth_phonemes(B, T, 1234)
+    dur = torch.full((B, T), D, dtype=torch.int32, device=DEV)
+    x = {"phoneme": torch.from_numpy(ids).to(DEV), "phoneme_mask": torch.from_numpy(mask).to(DEV),
+         "duration_forced": dur, "max_mel_len": T * D}
+    with torch.no_grad():
+        enc = net.encoder._encode(x)
+        mel, mel_len, _ = net(x)
+        mel2, _, _ = net(x)
+    assert mel.shape == (B, T * D, 80)
+    assert torch.equal(mel, mel2), "non-deterministic kernel"
+    assert (mel_len == T * D).all()
+    assert torch.isfinite(mel).all()
+    # batch-split invariance: a 32-utterance shard with the same padded length is bit-identical
+    xs = {k: (v[64:96] if torch.is_tensor(v) else v) for k, v in x.items()}
+    with torch.no_grad():
+        mel_s, _, _ = net(xs)
+    assert torch.equal(mel_s, mel[64:96])
+    # oracle spot check on 6 utterances (teacher-forced with the HIP path's own predictions so that the
+    # bucket decisions are identical; durations forced)
+    sel = [0, 1, 77, 128, 200, 255]
+    o = oracle.phoneme2mel(cfg, oracle.Weights(sd), ids[sel], mask[sel],
+                           pitch=enc["pitch"][sel, :, 0].cpu().numpy(), energy=enc["energy"][sel, :, 0].cpu().numpy(),
+                           duration=np.full((len(sel), T), D, np.int32), max_mel_len=T * D)
+    np.testing.assert_allclose(enc["pitch"][sel].cpu().numpy(), o.pitch, atol=H.PRED_TOL, rtol=0)
+    err = np.abs(mel[sel].cpu().numpy() - o.mel).max()
+    assert err < H.MEL_TOL, err
+
+
+def test_smoke_entry():
+    import __graft_entry__ as g
+    g.smoke()
