@@ -45,16 +45,17 @@ def sharded_forward(net, x_full, group=None):
         dup = True
     else:
         dup = False
-    if "max_mel_len" not in x:
-        enc = net.encoder._encode(x, train=False)
-        lmax = enc["lmax"].clone()
-        dist.all_reduce(lmax, op=dist.ReduceOp.MAX, group=group)
-        L = int(lmax.item())
-        B = enc["feat"].shape[0]
-        mel = net.decoder._fused(enc["feat"], enc["cum"], enc["mel_len"], None, L, True, L)
-        mel_len, dur = enc["mel_len"], enc["duration"]
+    # The padded length L is a property of the WHOLE batch (the reference zero-pads its convolutions at the
+    # batch max), so the local maxima are MAX-reduced on the device before the decoder runs.  With a
+    # caller-supplied bound (`max_mel_len`) the output is allocated at that bound and no host sync happens.
+    enc = net.encoder._encode(x, train=False)
+    dist.all_reduce(enc["lmax"], op=dist.ReduceOp.MAX, group=group)
+    if "max_mel_len" in x:
+        L_out, lmax_dev = int(x["max_mel_len"]), enc["lmax"]
     else:
-        mel, mel_len, dur = net(x)
+        L_out, lmax_dev = int(enc["lmax"].item()), None
+    mel = net.decoder._fused(enc["feat"], enc["cum"], enc["mel_len"], lmax_dev, L_out, True, L_out)
+    mel_len, dur = enc["mel_len"], enc["duration"]
     if dup:
         mel, mel_len, dur = mel[:1], mel_len[:1], dur[:1]
     outs = []
@@ -78,7 +79,19 @@ class ShardedMelPipeline:
         self.last = None
 
     def step(self, x):
-        mel, mel_len, _ = self.net(x)
+        if self.world == 1:
+            mel, mel_len, _ = self.net(x)
+            self.last = (mel, mel_len)
+            return self.last
+        # global padded length: 4-byte MAX all-reduce on the compute stream (see sharded_forward)
+        enc = self.net.encoder._encode(x, train=False)
+        dist.all_reduce(enc["lmax"], op=dist.ReduceOp.MAX, group=self.group)
+        if "max_mel_len" in x:
+            L_out, lmax_dev = int(x["max_mel_len"]), enc["lmax"]
+        else:
+            L_out, lmax_dev = int(enc["lmax"].item()), None
+        mel = self.net.decoder._fused(enc["feat"], enc["cum"], enc["mel_len"], lmax_dev, L_out, True, L_out)
+        mel_len = enc["mel_len"]
         if not self.gather:
             self.last = (mel, mel_len)
             return self.last

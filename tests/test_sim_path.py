@@ -1,0 +1,134 @@
+"""CPU coverage of the HIP kernels' logic: the unmodified kernel sources compiled for the lane-level
+wave simulator (tools/wavesim) are driven through the same C-ABI and the same host-side modules,
+and compared with the golden vectors and the oracle.  This does NOT replace the GPU parity tests
+(tests/test_gpu_parity.py) -- it lets index math, MFMA fragment layouts, LDS protocols and the host
+logic be checked in the GPU-less build container.
+"""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from efficientspeech_amd.synth import synth_phonemes
+from oracle import oracle
+from tests import helpers as H
+from tests.simlib import use_sim
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+# all tiny fixtures + a padded / teacher-forced one for the wider models (keeps the CPU suite short)
+CASES = sorted(glob.glob(os.path.join(GOLD, "tiny_*.npz"))) + \
+    [os.path.join(GOLD, f) for f in ("small_eval_pad_t17.npz", "small_train_tf_padtail.npz",
+                                     "base_eval_pad_t17.npz", "base_eval_b1_fox.npz")]
+
+
+@pytest.fixture(scope="module")
+def nets():
+    cache = {}
+
+    def get(name, g=None):
+        if name not in cache:
+            cache[name] = H.make_net(name, "cpu", golden=g)
+        return cache[name]
+    return get
+
+
+@pytest.mark.parametrize("path", CASES, ids=[os.path.basename(p)[:-4] for p in CASES])
+def test_simulated_kernels_match_golden(path, nets):
+    g = np.load(path)
+    net, cfg, sd = nets(os.path.basename(path).split("_")[0], g)
+    with use_sim():
+        H.check_against_golden(net, g, "cpu")
+
+
+@pytest.mark.parametrize("name,B,T,lens", [
+    ("tiny", 3, 70, [70, 41, 9]),        # 3 row tiles; 70 / 35 keys; multi-window decoder (L > 112)
+    ("small", 2, 40, [40, 23]),
+])
+def test_simulated_eval_vs_oracle_multi_tile(name, B, T, lens, nets):
+    net, cfg, sd = nets(name)
+    ids, mask = synth_phonemes(B, T, 4321, lens)
+    x = {"phoneme": torch.from_numpy(ids), "phoneme_mask": torch.from_numpy(mask)}
+    with use_sim(), torch.no_grad():
+        enc = net.encoder._encode(x)
+        mel, mel_len, _ = net(x)
+    o = oracle.phoneme2mel(cfg, oracle.Weights(sd), ids, mask)
+    err = H.compare_eval_with_oracle(cfg, o, enc, mel, mel_len, sd)
+    assert err == err
+    assert int(mel_len.max()) > 128 - 2 * cfg.halo or name != "tiny"   # really multi-window for tiny
+
+
+def test_simulated_forced_durations_and_hint(nets):
+    """`duration_forced` + `max_mel_len` (bench path): padded length larger than every utterance."""
+    net, cfg, sd = nets("tiny")
+    B, T = 2, 24
+    ids, mask = synth_phonemes(B, T, 9, [24, 15])
+    dur = np.full((B, T), 6, np.int32)
+    x = {"phoneme": torch.from_numpy(ids), "phoneme_mask": torch.from_numpy(mask),
+         "duration_forced": torch.from_numpy(dur), "max_mel_len": 150}
+    with use_sim(), torch.no_grad():
+        enc = net.encoder._encode(x)
+        mel, mel_len, _ = net(x)
+    assert mel.shape == (B, 150, 80)
+    # the reference semantics for a hint larger than the batch max: L = true batch max (144), rows beyond are 0
+    o = oracle.phoneme2mel(cfg, oracle.Weights(sd), ids, mask, pitch=enc["pitch"][..., 0].numpy(),
+                           energy=enc["energy"][..., 0].numpy(), duration=dur)
+    assert np.array_equal(mel_len.numpy(), o.mel_len) and o.mel.shape[1] == 144
+    assert np.abs(mel[:, :144].numpy() - o.mel).max() < H.MEL_TOL
+    assert not mel[:, 144:].any()
+
+
+def test_simulated_module_level_apis(nets):
+    """Encoder / Fuse / MelDecoder / FeatureUpsampler / PhonemeEncoder called stand-alone like the reference's."""
+    net, cfg, sd = nets("tiny")
+    w = oracle.Weights(sd)
+    ids, mask = synth_phonemes(2, 19, 3, [19, 12])
+    o = oracle.phoneme2mel(cfg, w, ids, mask, taps=True)
+    with use_sim(), torch.no_grad():
+        feats, dmask = net.encoder.encoder(torch.from_numpy(ids), mask=torch.from_numpy(mask))
+        fused = net.encoder.fuse(feats, mask=dmask)
+        mel = net.decoder(torch.from_numpy(o.features))
+        pe = net.encoder({"phoneme": torch.from_numpy(ids), "phoneme_mask": torch.from_numpy(mask)})
+        f, m, ml = net.encoder.feature_upsampler(torch.from_numpy(o.feat),
+                                                 torch.from_numpy(np.repeat(mask[:, :, None], cfg.d4, 2)),
+                                                 torch.from_numpy(o.dur))
+    for a, b in zip(feats, o.f_taps):
+        np.testing.assert_allclose(a.numpy(), b, atol=H.PRED_TOL, rtol=0)
+    assert dmask.shape == (2, 19, cfg.dim) and np.array_equal(dmask[:, :, 0].numpy(), mask)
+    np.testing.assert_allclose(fused.numpy(), o.fused, atol=H.PRED_TOL, rtol=0)
+    raw = oracle.mel_decoder(cfg, w, o.features)               # decoder alone: no final masked_fill
+    assert np.abs(mel.numpy() - raw).max() < H.MEL_TOL
+    assert set(pe) == {"pitch", "energy", "duration", "mel_len", "features", "masks"}
+    np.testing.assert_allclose(pe["features"].numpy(), o.features, atol=H.PRED_TOL, rtol=0)
+    assert pe["masks"].dtype == torch.bool and pe["masks"].shape == pe["features"].shape
+    assert np.array_equal(pe["masks"][:, :, 0].numpy(), o.masks)
+    assert np.array_equal(f.numpy(), o.features) and np.array_equal(m[:, :, 0].numpy(), o.masks)
+    assert np.array_equal(ml.numpy(), o.mel_len)
+
+
+def test_simulated_length_regulator_bit_exact():
+    from efficientspeech_amd import _lib  # noqa: F401
+    rng = np.random.default_rng(11)
+    with use_sim() as lib:
+        for B, T in ((5, 70), (2, 129), (1, 1)):
+            dur = rng.integers(-2, 9, size=(B, T)).astype(np.int32)
+            dur[rng.random((B, T)) < 0.25] = 0
+            d = torch.from_numpy(dur)
+            cum = torch.empty((B, T), dtype=torch.int32)
+            mel_len = torch.empty((B,), dtype=torch.int32)
+            lmax = torch.empty((1,), dtype=torch.int32)
+            lib.esmi_length_regulate_i32(d.data_ptr(), B, T, cum.data_ptr(), mel_len.data_ptr(), lmax.data_ptr(), None)
+            ref = np.cumsum(np.maximum(dur, 0), 1).astype(np.int32)
+            assert np.array_equal(cum.numpy(), ref) and int(lmax) == ref[:, -1].max()
+            L = max(int(lmax) + 3, 1)
+            idx = torch.empty((B, L), dtype=torch.int32)
+            lib.esmi_length_regulator_indices_i32(cum.data_ptr(), B, T, L, idx.data_ptr(), None)
+            assert np.array_equal(idx.numpy(), oracle.length_regulate(dur, L))
+
+
+def test_simulated_errors(nets):
+    net, cfg, _ = nets("tiny")
+    with use_sim():
+        with pytest.raises(KeyError):                            # B>1 without phoneme_mask (networks.py:338)
+            net({"phoneme": torch.ones((2, 8), dtype=torch.int32)})
