@@ -97,6 +97,11 @@ EncWs enc_ws(const esmi_encoder_block_shape* s) {
 
 }  // namespace
 
+#ifdef ESMI_DEC_TRACE
+long long* g_esmi_trace = nullptr;
+extern "C" void esmi_dev_set_trace(long long* ptr) { g_esmi_trace = ptr; }
+#endif
+
 extern "C" {
 
 int esmi_version(void) { return ESMI_VERSION; }
@@ -318,9 +323,9 @@ int esmi_mask_rows_f32(float* x, const uint8_t* mask, int64_t rows, int C, esmi_
 static int dec_check(const esmi_decoder_shape* s) {
     if (!s) return ESMI_ERR_ARG;
     if (s->dx2 != 128 && s->dx2 != 256) return ESMI_ERR_UNSUPPORTED;
-    if (s->d4 <= 0 || s->d4 % s->dx2) return ESMI_ERR_UNSUPPORTED;
+    if (s->d4 <= 0 || s->d4 % 128) return ESMI_ERR_UNSUPPORTED;
     if (s->kernel != 3 && s->kernel != 5) return ESMI_ERR_UNSUPPORTED;
-    if (s->n_mel <= 0 || s->n_mel > 32 * kMelNT) return ESMI_ERR_UNSUPPORTED;
+    if (s->n_mel <= 0 || s->n_mel > kMelCols) return ESMI_ERR_UNSUPPORTED;
     if (s->n_blocks < 1 || s->block_depth < 1 || s->n_blocks * s->block_depth > ESMI_MAX_DEC_LAYERS) return ESMI_ERR_UNSUPPORTED;
     if (2 * (s->kernel / 2) * s->n_blocks * s->block_depth >= kDecRows - 32) return ESMI_ERR_UNSUPPORTED;
     return ESMI_OK;
@@ -338,15 +343,15 @@ int esmi_mel_decoder_pack_f32(const esmi_decoder_weights* w, const esmi_decoder_
     if (!w || !blob) return ESMI_ERR_ARG;
     const DecLayout L = dec_layout(s->d4, s->dx2, s->kernel, s->n_blocks, s->block_depth);
     hipStream_t st = S(stream);
-    const int dx2 = s->dx2, nt = dx2 / 32;
-    auto bfrag = [&](const float* src, long off, int N, int K, int NT) {
-        const long n = (long)(K / 8) * NT * 256;
-        ESMI_LAUNCH(pack_bfrag_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src, blob + off, N, K, NT);
+    const int dx2 = s->dx2, ntw = dx2 / 128;
+    auto bslice = [&](const float* src, long off, int N, int K) {
+        const long n = (long)(K / 128) * 4 * ntw * 16 * 256;
+        ESMI_LAUNCH(pack_bslice_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src, blob + off, N, K, ntw);
     };
     auto vec = [&](const float* src, long off, int n, int n_pad) {
         ESMI_LAUNCH(copy_pad_kernel, dim3((n_pad + 255) / 256), dim3(256), 0, st, src, blob + off, n, n_pad);
     };
-    bfrag(w->proj_w, L.proj_w, dx2, s->d4, nt);
+    bslice(w->proj_w, L.proj_w, dx2, s->d4);
     vec(w->proj_b, L.proj_b, dx2, dx2);
     vec(w->proj_ln_g, L.proj_g, dx2, dx2);
     vec(w->proj_ln_b, L.proj_beta, dx2, dx2);
@@ -356,7 +361,7 @@ int esmi_mel_decoder_pack_f32(const esmi_decoder_weights* w, const esmi_decoder_
         ESMI_LAUNCH(pack_dw_kernel, dim3((dx2 * s->kernel + 255) / 256), dim3(256), 0, st, w->dw_w[l], blob + base + L.l_dw,
                     dx2, s->kernel);
         vec(w->dw_b[l], base + L.l_dwb, dx2, dx2);
-        bfrag(w->pw_w[l], base + L.l_pw, dx2, dx2, nt);
+        bslice(w->pw_w[l], base + L.l_pw, dx2, dx2);
         vec(w->pw_b[l], base + L.l_pwb, dx2, dx2);
         vec(w->ln_g[l], base + L.l_g, dx2, dx2);
         vec(w->ln_b[l], base + L.l_b, dx2, dx2);
@@ -365,8 +370,8 @@ int esmi_mel_decoder_pack_f32(const esmi_decoder_weights* w, const esmi_decoder_
         vec(w->skip_g[b], L.skip0 + 2L * dx2 * b, dx2, dx2);
         vec(w->skip_b[b], L.skip0 + 2L * dx2 * b + dx2, dx2, dx2);
     }
-    bfrag(w->mel_w, L.mel_w, s->n_mel, dx2, kMelNT);
-    vec(w->mel_b, L.mel_b, s->n_mel, 32 * kMelNT);
+    bslice(w->mel_w, L.mel_w, s->n_mel, dx2);
+    vec(w->mel_b, L.mel_b, s->n_mel, dx2);
     return launch_status();
 }
 
@@ -386,7 +391,11 @@ int esmi_mel_decoder_f32(const float* blob, const esmi_decoder_shape* s, const f
     p.apply_mask = apply_mask && mel_len; p.B = B; p.T = T; p.L_out = L_out; p.mel = mel;
     p.halo = (s->kernel / 2) * s->n_blocks * s->block_depth;
     p.TL = kDecRows - 2 * p.halo;
-    dim3 grid((L_out + p.TL - 1) / p.TL, B), block(256);
+    p.trace = nullptr;
+#ifdef ESMI_DEC_TRACE
+    p.trace = g_esmi_trace;   // development only, see tools/trace_decoder.py
+#endif
+    dim3 grid((L_out + p.TL - 1) / p.TL, B), block(kDecThreads);
     hipStream_t st = S(stream);
 #define ESMI_DEC_CASE(DX2, KD)                                                                                     \
     {                                                                                                              \

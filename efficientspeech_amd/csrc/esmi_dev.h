@@ -86,6 +86,16 @@ __device__ __forceinline__ float tanh_f32(float x) {
     const float t = (1.0f - e) / (1.0f + e);
     return copysignf(t, x);
 }
+// hardware-transcendental form: 1 - 2/(1 + 2^(2x*log2 e)); v_exp_f32 + v_rcp_f32, |err| ~ 1e-6 absolute
+__device__ __forceinline__ float tanh_fast_f32(float x) {
+#ifdef ESMI_WAVESIM
+    return tanh_f32(x);
+#else
+    const float e = __builtin_amdgcn_exp2f(x * 2.885390081777927f);   // e^(2x); inf for large x -> rcp = 0 -> 1
+    return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + e);
+#endif
+}
+__device__ __forceinline__ float ident_f32(float x) { return x; }
 __device__ __forceinline__ float gelu_erf_f32(float x) {  // nn.GELU() default = exact erf form
     return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
 }

@@ -6,21 +6,28 @@
 //   n_blocks x { x = skip; block_depth x [ x = LN(tanh(Conv1x1(dwConv_k(x)))) ]; skip = LN_s(x + skip) }
 //   mel  = Linear(dx2, n_mel)(skip)
 //
-// One 256-thread workgroup owns a 128-frame window of one utterance: TL = 128 - 2*halo frames
-// are kept, halo = (k/2)*n_blocks*block_depth frames per side are recomputed so that no
-// activation ever leaves the CU.  Activations live in LDS as a [132][DX2+4] fp32 tile (two zero
-// rows per side give the depthwise conv its in-tile padding; +4 floats per row make the
-// per-row 16-byte fragment reads bank-conflict free).  Each wave owns 32 complete rows, so
-// LayerNorm statistics are wave-local (5 xor-shuffles per row in the MFMA C/D layout) and the
-// skip tensor stays in registers.  Every contraction runs on v_mfma_f32_32x32x2_f32 (exact fp32):
-//   A fragment = lane (i = lane&31, h = lane>>5) reads 4 channels [8kc+4h, +4) of row i from LDS,
-//                applying the depthwise k-tap filter on the fly (VALU, hidden under the MFMAs);
-//   B fragment = one coalesced 16-byte load per lane from the pre-packed weight blob (L2-resident).
+// One 512-thread workgroup (8 waves) owns a 128-frame window of one utterance: TL = 128 - 2*halo
+// frames are kept, halo = (k/2)*n_blocks*block_depth frames per side are recomputed so that no
+// activation ever leaves the CU.  Activations live in ONE LDS tile [132][DX2+4] fp32 (two zero rows
+// per side = the depthwise conv's in-window padding; +4 floats/row keep the 16-byte row-fragment
+// reads bank-conflict free).
+//
+// Weight-stationary GEMMs on v_mfma_f32_32x32x2_f32 (exact fp32).  Wave w = (mh = w>>2, ns = w&3)
+// owns rows [64mh, 64mh+64) x columns [ns*DX2/4, +DX2/4).  For each 128-channel K chunk it loads
+// its weight slice ONCE into registers (16 coalesced 16-byte loads per 32-column tile, from the
+// pre-packed blob) and streams the A fragments of its 64 rows from LDS: the K loop touches no
+// global memory.  (Round-1 ablation: with one wave owning 32 full rows, re-streaming the weights
+// from L2 for every 32 rows cost 150 us of a 675 us kernel.)
+//
+// Per conv layer, five short phases separated by workgroup barriers:
+//   1. depthwise k-tap conv IN PLACE on the tile (each thread: 4 channels x 8 or 16 rows, window in
+//      registers);  2. K loop (MFMA only + ds_read_b128);  3. bias + tanh, accumulators -> tile;
+//   4. LayerNorm by row-owner threads (4 threads per row, the row's values and the skip tensor in
+//      registers; block end: LN_s(x + skip));  rows outside [0, L) are forced to 0.
 //
 // Fidelity notes (SURVEY.md §7 "hard parts"):
-//  * frames in [mel_len[b], L) are PADDING FRAMES: their input rows are zero but they are computed
-//    like any other frame, because the reference computes them and the k-tap conv leaks them into
-//    the last valid frames;
+//  * frames in [mel_len[b], L) are PADDING FRAMES: zero input rows, but computed like any other frame,
+//    because the reference computes them and the k-tap conv leaks them into the last valid frames;
 //  * frames outside [0, L) do not exist in the reference: every layer's Conv1d zero-pads there, so
 //    such rows are forced to 0 after every LayerNorm;
 //  * rows >= mel_len[b] of the output are zeroed only at the very end (the final masked_fill).
@@ -28,11 +35,22 @@
 #include "esmi_dev.h"
 #include "small_kernels.h"
 
+#ifndef ESMI_DEC_TANH
+#define ESMI_DEC_TANH tanh_fast_f32
+#endif
+#ifndef ESMI_DEC_WPS
+#define ESMI_DEC_WPS 2   // __launch_bounds__ waves/SIMD: 2 = one 512-thread workgroup per CU, up to 256 VGPRs (a 128-VGPR build spills)
+#endif
+#ifndef ESMI_DEC_KSUB
+#define ESMI_DEC_KSUB 8  // k-steps (of 8 channels) of the weight slice held in registers at a time
+#endif
+
 namespace esmi {
 
 constexpr int kDecRows = 128;     // frames per workgroup window
 constexpr int kDecPadRows = 2;    // zero rows above/below the window in LDS (>= k/2)
-constexpr int kMelNT = 3;         // mel Linear: n_mel <= 96 columns
+constexpr int kDecThreads = 512;
+constexpr int kMelCols = 96;      // n_mel <= 96 (three 32-column MFMA tiles)
 
 struct DecLayout {  // offsets in floats into the packed blob
     long proj_w, proj_b, proj_g, proj_beta;
@@ -47,22 +65,42 @@ inline DecLayout dec_layout(int d4, int dx2, int kd, int n_blocks, int block_dep
     DecLayout L;
     long o = 0;
     L.proj_w = o; o += (long)d4 * dx2;
-    L.proj_b = o; o += dx2;
+    L.proj_b = o; o += dx2;                    // proj_b, proj_g, proj_beta contiguous
     L.proj_g = o; o += dx2;
     L.proj_beta = o; o += dx2;
-    L.l_dw = 0;
+    L.l_dw = 0;                                // per layer: taps[kd][dx2], dw_b, pw_b, ln_g, ln_b contiguous ...
     L.l_dwb = (long)kd * dx2;
-    L.l_pw = L.l_dwb + dx2;
-    L.l_pwb = L.l_pw + (long)dx2 * dx2;
+    L.l_pwb = L.l_dwb + dx2;
     L.l_g = L.l_pwb + dx2;
     L.l_b = L.l_g + dx2;
-    L.layer_stride = L.l_b + dx2;
+    L.l_pw = L.l_b + dx2;                      // ... then the packed pointwise matrix
+    L.layer_stride = L.l_pw + (long)dx2 * dx2;
     L.layer0 = o; o += L.layer_stride * n_blocks * block_depth;
     L.skip0 = o; o += 2L * dx2 * n_blocks;
-    L.mel_w = o; o += (long)dx2 * 32 * kMelNT;
-    L.mel_b = o; o += 32 * kMelNT;
+    L.mel_w = o; o += (long)dx2 * dx2;         // packed like a dx2 x dx2 matrix, rows >= n_mel zero
+    L.mel_b = o; o += dx2;                     // zero padded
     L.total = o;
     return L;
+}
+
+// Weight-stationary B-fragment packing of a (N, K) row-major matrix, K a multiple of 128, for a
+// workgroup whose 4 column slices are WCOLS = 32*NTW wide:
+//   dst[(((((c*4 + ns)*NTW + ntw)*16 + kc)*64 + lane)*4 + s] =
+//       W[ns*WCOLS + 32*ntw + (lane&31)][128*c + 8*kc + 4*(lane>>5) + s]      (0 for rows >= N)
+__global__ void pack_bslice_kernel(const float* __restrict__ src, float* __restrict__ dst, int N, int K, int NTW) {
+    const long n = (long)(K / 128) * 4 * NTW * 16 * 256;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
+        const int s = (int)(e & 3);
+        const int lane = (int)((e >> 2) & 63);
+        long q = e >> 8;
+        const int kc = (int)(q & 15); q >>= 4;
+        const int ntw = (int)(q % NTW); q /= NTW;
+        const int ns = (int)(q & 3);
+        const int c = (int)(q >> 2);
+        const int row = ns * 32 * NTW + 32 * ntw + (lane & 31);
+        const int col = 128 * c + 8 * kc + 4 * (lane >> 5) + s;
+        dst[e] = row < N ? src[(long)row * K + col] : 0.0f;
+    }
 }
 
 struct MelDecP {
@@ -78,63 +116,42 @@ struct MelDecP {
     int B, T, L_out;
     float* mel;            // (B, L_out, n_mel)
     int halo, TL;
+    long long* trace;      // development only (-DESMI_DEC_TRACE): [wave][stamp] shader-clock stamps of block (1,0)
 };
 
 template <int DX2>
 __host__ __device__ constexpr int dec_lds_floats(int kd) {
-    return (kDecRows + 2 * kDecPadRows) * (DX2 + 4) + (kd + 1) * DX2 + kDecRows;
-}
-
-// bias + tanh + LN (+ skip add + LN) + zero rows outside [0,L) + write the tile back to LDS
-template <int NT>
-__device__ __forceinline__ void dec_epilogue(f32x16 (&acc)[NT], f32x16 (&skip)[NT], const float* __restrict__ bias,
-                                             const float* __restrict__ g, const float* __restrict__ be,
-                                             const float* __restrict__ sg, const float* __restrict__ sb, bool set_skip,
-                                             float* __restrict__ xs_w, const int* __restrict__ src_w, int lane) {
-    constexpr int LDSROW = 32 * NT + 4;
-    const int i = lane & 31;
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-        const float bc = bias[32 * nt + i];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[nt][r] = tanh_f32(acc[nt][r] + bc);
-    }
-    layernorm_tile<NT>(acc, g, be, lane);
-    if (sg) {  // end of a decoder block: skip = LN_s(x + skip), networks.py:299
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) acc[nt] += skip[nt];
-        layernorm_tile<NT>(acc, sg, sb, lane);
-    }
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int row = tile_row(r, lane);
-        const bool inside = src_w[row] != -1;
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            const float v = inside ? acc[nt][r] : 0.0f;
-            acc[nt][r] = v;
-            xs_w[row * LDSROW + 32 * nt + i] = v;
-        }
-    }
-    if (set_skip) {
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) skip[nt] = acc[nt];
-    }
+    return (kDecRows + 2 * kDecPadRows) * (DX2 + 4) + (kd + 6) * DX2 + kDecRows;
 }
 
 template <int DX2, int KD>
-__global__ __launch_bounds__(256, (DX2 <= 128 ? 2 : 1)) void mel_decoder_kernel(const MelDecP p) {
-    constexpr int NT = DX2 / 32;
+__global__ __launch_bounds__(kDecThreads, (DX2 <= 128 ? ESMI_DEC_WPS : 2)) void mel_decoder_kernel(const MelDecP p) {
+    constexpr int NTW = DX2 / 128;          // 32-column MFMA tiles per wave
+    constexpr int WCOLS = 32 * NTW;         // columns per wave (4 column slices per workgroup)
+    constexpr int KCH = DX2 / 128;          // 128-channel K chunks of a dx2-wide contraction
     constexpr int LDSROW = DX2 + 4;
     constexpr int PAD = KD / 2;
-    constexpr int KCS = DX2 / 8;
+    constexpr int CG = DX2 / 4;             // 4-channel groups per row
+    constexpr int RS = kDecRows / (kDecThreads / CG);  // rows per depthwise strip (8 or 16)
+    constexpr int NV = DX2 / 16;            // float4 per LayerNorm thread (4 threads per row)
     ESMI_DYN_LDS(lds);
+    // per-layer small parameters in LDS: [taps KD*DX2 | dw_b] (group A: read by the depthwise phase) and
+    // [pw_b | ln_g | ln_b | skip_g | skip_b] (group B: read by the tanh / LayerNorm phases).  Single buffer:
+    // layer l+1's group A is committed during layer l's tanh phase, its group B during layer l+1's
+    // depthwise phase -- each when no reader of the old contents is left.
+    constexpr int PB = (KD + 6) * DX2;
+    constexpr int P_DWB = KD * DX2, P_PWB = P_DWB + DX2, P_G = P_PWB + DX2, P_B = P_G + DX2, P_SG = P_B + DX2,
+                  P_SB = P_SG + DX2;
+    constexpr int NA4 = (KD + 1) * DX2 / 4;                            // float4 in group A
+    constexpr int NB4 = 3 * DX2 / 4;                                   // float4 of pw_b, ln_g, ln_b
+    static_assert(NA4 <= kDecThreads && NB4 + DX2 / 2 <= kDecThreads, "param staging: one float4 per thread per group");
     float* xs = lds;                                                  // [132][LDSROW]
-    float* wbuf = lds + (kDecRows + 2 * kDecPadRows) * LDSROW;        // [KD+1][DX2]: taps then bias
-    int* src = reinterpret_cast<int*>(wbuf + (KD + 1) * DX2);         // [128]
+    float* pbuf = lds + (kDecRows + 2 * kDecPadRows) * LDSROW;        // [PB]
+    int* src = reinterpret_cast<int*>(pbuf + PB);                     // [128]
 
     const int tid = (int)threadIdx.x, lane = lane_id(), w = wave_id();
     const int i = lane & 31, h = lane >> 5;
+    const int mh = w >> 2, ns = w & 3;
     const int tile = (int)blockIdx.x, b = (int)blockIdx.y;
     const int L = p.lmax_dev ? *p.lmax_dev : p.lmax_host;
     const int mlen = p.mel_len ? min(p.mel_len[b], L) : L;
@@ -145,11 +162,47 @@ __global__ __launch_bounds__(256, (DX2 <= 128 ? 2 : 1)) void mel_decoder_kernel(
     if (f_lo >= valid_end) {  // whole window is padding: the final masked_fill (or the [L, L_out) tail) zeroes it
         const int n = (out_hi - f_lo) * p.n_mel;
         float* o = p.mel + ((long)b * p.L_out + f_lo) * p.n_mel;
-        for (int e = tid; e < n; e += 256) o[e] = 0.0f;
+        for (int e = tid; e < n; e += kDecThreads) o[e] = 0.0f;
         return;
     }
+    const int n_layers = p.n_blocks * p.block_depth;
+    const f32x4* blob4 = reinterpret_cast<const f32x4*>(p.blob);
+#ifdef ESMI_DEC_TRACE
+    int tr_n = 0;
+    const bool tr_on = p.trace && blockIdx.x == 1 && blockIdx.y == 0 && lane == 0;
+#define ESMI_STAMP() do { if (tr_on) p.trace[w * 64 + tr_n] = (long long)__builtin_amdgcn_s_memtime(); ++tr_n; } while (0)
+#else
+#define ESMI_STAMP() do {} while (0)
+#endif
 
-    // ---- phase 0: source row of every window row, zero the LDS pad rows
+    // ---- parameter staging: global -> register (issued early) ... register -> LDS (committed later).
+    // "layer" n_layers is the mel Linear (group B = its bias only).
+    f32x4 pstA = zero4(), pstB = zero4();
+    auto issue_A = [&](int l) __attribute__((always_inline)) {
+        if (l < n_layers && tid < NA4) pstA = blob4[((p.lay.layer0 + (long)l * p.lay.layer_stride) >> 2) + tid];
+    };
+    auto commit_A = [&](int l) __attribute__((always_inline)) {
+        if (l < n_layers && tid < NA4) reinterpret_cast<f32x4*>(pbuf)[tid] = pstA;
+    };
+    auto issue_B = [&](int l) __attribute__((always_inline)) {
+        if (l < n_layers) {
+            if (tid < NB4) pstB = blob4[((p.lay.layer0 + (long)l * p.lay.layer_stride + p.lay.l_pwb) >> 2) + tid];
+            else if (((l + 1) % p.block_depth) == 0 && tid < NB4 + DX2 / 2)   // block end: skip LN params
+                pstB = blob4[((p.lay.skip0 + (long)(l / p.block_depth) * 2 * DX2) >> 2) + tid - NB4];
+        } else if (tid < DX2 / 4) {
+            pstB = blob4[(p.lay.mel_b >> 2) + tid];
+        }
+    };
+    auto commit_B = [&](int l) __attribute__((always_inline)) {
+        f32x4* d4 = reinterpret_cast<f32x4*>(pbuf + P_PWB);
+        if (l < n_layers) {
+            if (tid < NB4 || (((l + 1) % p.block_depth) == 0 && tid < NB4 + DX2 / 2)) d4[tid] = pstB;
+        } else if (tid < DX2 / 4) {
+            d4[tid] = pstB;
+        }
+    };
+
+    // ---- phase 0: source row of every window row, zero the LDS pad rows, stage proj + layer-0 params
     if (tid < kDecRows) {
         const int f = f0 + tid;
         int s;
@@ -162,123 +215,252 @@ __global__ __launch_bounds__(256, (DX2 <= 128 ? 2 : 1)) void mel_decoder_kernel(
         } else s = b * L + f;
         src[tid] = s;
     }
-    for (int e = tid; e < 2 * kDecPadRows * LDSROW; e += 256) {
+    for (int e = tid; e < 2 * kDecPadRows * LDSROW; e += kDecThreads) {
         const int r = e / LDSROW, c = e - r * LDSROW;
         const int rr = r < kDecPadRows ? r : kDecRows + r;             // rows 0,1 and 130,131
         xs[rr * LDSROW + c] = 0.0f;
     }
+    if (tid < NB4)                                                     // proj_b, proj_g, proj_beta -> group B
+        reinterpret_cast<f32x4*>(pbuf + P_PWB)[tid] = blob4[(p.lay.proj_b >> 2) + tid];
+    issue_A(0);
+    commit_A(0);
     __syncthreads();
 
-    float* xs_w = xs + (kDecPadRows + 32 * w) * LDSROW;               // this wave's 32 rows
-    const int* src_w = src + 32 * w;
-    const f32x4* blob4 = reinterpret_cast<const f32x4*>(p.blob);
+    // A-fragment base of this wave's 64 rows; LayerNorm ownership: row = 16w + (lane&15), quarter = lane>>4
+    const float* a_base = xs + (kDecPadRows + 64 * mh + i) * LDSROW + 4 * h;
+    const int ln_row = 16 * w + (lane & 15), ln_q = lane >> 4;
+    float* ln_ptr = xs + (kDecPadRows + ln_row) * LDSROW + 4 * ln_q;
+    const bool ln_inside = src[ln_row] != -1;
 
-    f32x16 acc[NT], skip[NT];
+    f32x16 acc[2][NTW];
+    f32x4 skip[NV];
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) { acc[nt] = zero16(); skip[nt] = zero16(); }
+    for (int v = 0; v < NV; ++v) skip[v] = zero4();
 
-    // ---- proj: Linear(d4, dx2), K processed in chunks of DX2 channels staged through the tile
-    const int nchunks = p.d4 / DX2;
+    // weight-stationary GEMM pieces.  bf = this wave's weight slice for KSUB k-steps (64 VGPRs); it is
+    // (re)loaded right after the previous K loop so the L2 latency hides under the non-MFMA phases.
+    constexpr int KSUB = ESMI_DEC_KSUB;
+    f32x4 bf[NTW][KSUB];
+    auto load_b = [&](const f32x4* wsl, int k0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) {
+#pragma unroll
+            for (int kc = 0; kc < KSUB; ++kc) bf[t][kc] = wsl[(t * 16 + k0 + kc) * 64];
+        }
+    };
+    auto mma_sub = [&](int a_col0, int k0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+            for (int kc = 0; kc < KSUB; ++kc) {
+                const f32x4 av = *reinterpret_cast<const f32x4*>(a_base + 32 * mt * LDSROW + a_col0 + 8 * (k0 + kc));
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+#pragma unroll
+                    for (int t = 0; t < NTW; ++t) acc[mt][t] = mfma32(av[s], bf[t][kc][s], acc[mt][t]);
+                }
+            }
+        }
+    };
+    // slice pointer of chunk c of the matrix at float offset `off`
+    auto wslice = [&](long off, int c) __attribute__((always_inline)) { return blob4 + (off >> 2) + (long)((c * 4 + ns) * NTW) * 16 * 64 + lane; };
+    // full dx2-wide contraction with the first sub-slice already in bf; leaves `next`'s first sub-slice in bf
+    auto gemm_dx2 = [&](long off, const f32x4* next) __attribute__((always_inline)) {
+#pragma unroll
+        for (int c = 0; c < KCH; ++c) {
+#pragma unroll
+            for (int k0 = 0; k0 < 16; k0 += KSUB) {
+                if (c > 0 || k0 > 0) load_b(wslice(off, c), k0);
+                mma_sub(128 * c, k0);
+            }
+        }
+        if (next) load_b(next, 0);
+    };
+    auto zero_acc = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+            for (int t = 0; t < NTW; ++t) acc[mt][t] = zero16();
+        }
+    };
+    // accumulators (+ bias, tanh) -> tile, in the MFMA C/D layout
+    auto store_tanh = [&](const float* bias) __attribute__((always_inline)) {
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) {
+            const int col = ns * WCOLS + 32 * t + i;
+            const float bc = bias[col];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = 64 * mh + 32 * mt + tile_row(r, lane);
+                    xs[(kDecPadRows + row) * LDSROW + col] = ESMI_DEC_TANH(acc[mt][t][r] + bc);
+                }
+            }
+        }
+    };
+    // LayerNorm of this thread's quarter row held in v[] (two-pass; 4 threads per row: xor 16, 32)
+    auto ln_regs = [&](f32x4 (&v)[NV], const float* g, const float* be) {
+        float s = 0.0f;
+#pragma unroll
+        for (int k = 0; k < NV; ++k) s += (v[k][0] + v[k][1]) + (v[k][2] + v[k][3]);
+        s += shfl_xor_f(s, 16);
+        s += shfl_xor_f(s, 32);
+        const float mean = s * (1.0f / DX2);
+        float q = 0.0f;
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float d = v[k][e] - mean;
+                q = fmaf(d, d, q);
+            }
+        }
+        q += shfl_xor_f(q, 16);
+        q += shfl_xor_f(q, 32);
+        const float rstd = 1.0f / sqrtf(q * (1.0f / DX2) + 1e-5f);
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            const f32x4 gg = *reinterpret_cast<const f32x4*>(g + 16 * k + 4 * ln_q);
+            const f32x4 bb = *reinterpret_cast<const f32x4*>(be + 16 * k + 4 * ln_q);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[k][e] = fmaf((v[k][e] - mean) * rstd, gg[e], bb[e]);
+        }
+    };
+    // LN pass over the tile (in place): x = LN(x) [; x = LN_s(x + skip)] ; outside rows -> 0 ; skip update
+    auto ln_pass = [&](const float* pb, bool block_end, bool set_skip) __attribute__((always_inline)) {
+        f32x4 v[NV];
+#pragma unroll
+        for (int k = 0; k < NV; ++k) v[k] = *reinterpret_cast<const f32x4*>(ln_ptr + 16 * k);
+#ifndef ESMI_ABL_NO_LN
+        ln_regs(v, pb + P_G, pb + P_B);
+        if (block_end) {  // end of a decoder block: skip = LN_s(x + skip), networks.py:299
+#pragma unroll
+            for (int k = 0; k < NV; ++k) v[k] += skip[k];
+            ln_regs(v, pb + P_SG, pb + P_SB);
+        }
+#endif
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            if (!ln_inside) v[k] = zero4();
+            *reinterpret_cast<f32x4*>(ln_ptr + 16 * k) = v[k];
+        }
+        if (set_skip) {
+#pragma unroll
+            for (int k = 0; k < NV; ++k) skip[k] = v[k];
+        }
+    };
+
+    // ---- proj: Linear(d4, dx2); the gathered input rows are staged through the tile 128 channels at a time
+    zero_acc();
+    const int nchunks = p.d4 / 128;
+    load_b(wslice(p.lay.proj_w, 0), 0);
     for (int ch = 0; ch < nchunks; ++ch) {
         if (ch > 0) __syncthreads();  // previous chunk fully consumed
-        for (int e = tid; e < kDecRows * (DX2 / 4); e += 256) {
-            const int r = e / (DX2 / 4), q = e - r * (DX2 / 4);
+        for (int e = tid; e < kDecRows * 32; e += kDecThreads) {
+            const int r = e >> 5, q = e & 31;
             const int s = src[r];
             f32x4 v = zero4();
-            if (s >= 0) v = ld4(p.x + (long)s * p.d4 + ch * DX2 + 4 * q);
+            if (s >= 0) v = ld4(p.x + (long)s * p.d4 + ch * 128 + 4 * q);
             *reinterpret_cast<f32x4*>(xs + (kDecPadRows + r) * LDSROW + 4 * q) = v;
         }
         __syncthreads();
-        const f32x4* bw = blob4 + (p.lay.proj_w >> 2) + (long)ch * KCS * NT * 64 + lane;
-        for (int kc = 0; kc < KCS; ++kc) {
-            const f32x4 av = *reinterpret_cast<const f32x4*>(xs_w + i * LDSROW + 8 * kc + 4 * h);
-            f32x4 bv[NT];
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) bv[nt] = bw[(kc * NT + nt) * 64];
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) acc[nt] = mfma32(av[s], bv[nt][s], acc[nt]);
-            }
+        for (int k0 = 0; k0 < 16; k0 += KSUB) {
+            if (ch > 0 || k0 > 0) load_b(wslice(p.lay.proj_w, ch), k0);
+            mma_sub(0, k0);
         }
     }
+    // weights of the first conv layer (or of the mel Linear) start flowing while proj's epilogue runs
+    load_b(n_layers > 0 ? wslice(p.lay.layer0 + p.lay.l_pw, 0) : wslice(p.lay.mel_w, 0), 0);
     __syncthreads();  // every wave finished reading the staged input
-    const int n_layers = p.n_blocks * p.block_depth;
-    {
-        dec_epilogue<NT>(acc, skip, p.blob + p.lay.proj_b, p.blob + p.lay.proj_g, p.blob + p.lay.proj_beta, nullptr,
-                         nullptr, true, xs_w, src_w, lane);
-        if (n_layers > 0) {
-            const float* lw = p.blob + p.lay.layer0;
-            for (int e = tid; e < (KD + 1) * DX2; e += 256) wbuf[e] = lw[e];  // taps + bias are contiguous
-        }
-    }
+    issue_B(0);
+    store_tanh(pbuf + P_PWB);
+    __syncthreads();
+    ln_pass(pbuf, false, true);
     __syncthreads();
 
     // ---- conv layers
+    const int dw_cg = tid % CG, dw_r0 = (tid / CG) * RS;
     for (int l = 0; l < n_layers; ++l) {
-        const float* lw = p.blob + p.lay.layer0 + (long)l * p.lay.layer_stride;
-        const f32x4* bw = blob4 + ((p.lay.layer0 + (long)l * p.lay.layer_stride + p.lay.l_pw) >> 2) + lane;
+        const float* pb = pbuf;
+        const long lbase = p.lay.layer0 + (long)l * p.lay.layer_stride;
+        ESMI_STAMP();   // 0: layer start
+        // 1. depthwise conv in place: window -> registers | barrier | filtered rows -> tile
+        {
+            f32x4 win[RS + 2 * PAD];
+            float* col = xs + (kDecPadRows + dw_r0 - PAD) * LDSROW + 4 * dw_cg;
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) acc[nt] = zero16();
-        for (int kc = 0; kc < KCS; ++kc) {
-            const int c = 8 * kc + 4 * h;
-            f32x4 av = *reinterpret_cast<const f32x4*>(wbuf + KD * DX2 + c);  // depthwise bias
+            for (int r = 0; r < RS + 2 * PAD; ++r) win[r] = *reinterpret_cast<const f32x4*>(col + r * LDSROW);
+            f32x4 tap[KD];
 #pragma unroll
-            for (int j = 0; j < KD; ++j) {
-                const f32x4 xv = *reinterpret_cast<const f32x4*>(xs_w + (i + j - PAD) * LDSROW + c);
-                const f32x4 wv = *reinterpret_cast<const f32x4*>(wbuf + j * DX2 + c);
+            for (int j = 0; j < KD; ++j) tap[j] = *reinterpret_cast<const f32x4*>(pb + j * DX2 + 4 * dw_cg);
+            const f32x4 tb = *reinterpret_cast<const f32x4*>(pb + P_DWB + 4 * dw_cg);
+            ESMI_STAMP();   // 1: window loaded (issued)
+            __syncthreads();
+            ESMI_STAMP();   // 2: barrier passed
 #pragma unroll
-                for (int s = 0; s < 4; ++s) av[s] = fmaf(xv[s], wv[s], av[s]);
-            }
-            f32x4 bv[NT];
+            for (int r = 0; r < RS; ++r) {
+                f32x4 a = tb;
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) bv[nt] = bw[(kc * NT + nt) * 64];
+                for (int j = 0; j < KD; ++j) {
+#ifdef ESMI_ABL_NO_DW
+                    if (j != PAD) continue;
+#endif
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) acc[nt] = mfma32(av[s], bv[nt][s], acc[nt]);
+                    for (int e = 0; e < 4; ++e) a[e] = fmaf(win[r + j][e], tap[j][e], a[e]);
+                }
+                *reinterpret_cast<f32x4*>(col + (r + PAD) * LDSROW) = a;
             }
         }
-        __syncthreads();  // all reads of xs / wbuf for this layer done
-        const bool block_end = ((l + 1) % p.block_depth) == 0;
-        const float* sk = p.blob + p.lay.skip0 + (long)(l / p.block_depth) * 2 * DX2;
-        dec_epilogue<NT>(acc, skip, lw + p.lay.l_pwb, lw + p.lay.l_g, lw + p.lay.l_b, block_end ? sk : nullptr,
-                         block_end ? sk + DX2 : nullptr, block_end, xs_w, src_w, lane);
-        if (l + 1 < n_layers) {
-            const float* nw = lw + p.lay.layer_stride;
-            for (int e = tid; e < (KD + 1) * DX2; e += 256) wbuf[e] = nw[e];
-        }
+        commit_B(l);                         // this layer's bias / LN params (issued during the previous layer)
+        issue_A(l + 1);                      // next layer's taps: in flight during the K loop
+        ESMI_STAMP();   // 3: dw written
         __syncthreads();
+        ESMI_STAMP();   // 4: barrier
+        // 2. pointwise conv: K = dx2, weights register-stationary; then prefetch the next matrix's first slice
+        zero_acc();
+        gemm_dx2(lbase + p.lay.l_pw, l + 1 < n_layers ? wslice(lbase + p.lay.layer_stride + p.lay.l_pw, 0)
+                                                      : wslice(p.lay.mel_w, 0));
+        ESMI_STAMP();   // 5: K loop issued
+        __syncthreads();  // all reads of the filtered tile done
+        ESMI_STAMP();   // 6: barrier
+        // 3. bias + tanh -> tile; commit the staged params of layer l+1 to the other buffer
+        store_tanh(pb + P_PWB);
+        commit_A(l + 1);
+        issue_B(l + 1);
+        ESMI_STAMP();   // 7: tanh stored
+        __syncthreads();
+        ESMI_STAMP();   // 8: barrier
+        // 4. LayerNorm (+ block-end skip LayerNorm) by row owners
+        const bool block_end = ((l + 1) % p.block_depth) == 0;
+        ln_pass(pb, block_end, block_end);
+        ESMI_STAMP();   // 9: LN done
+        __syncthreads();
+        ESMI_STAMP();   // 10: barrier
     }
 
-    // ---- mel Linear(dx2, n_mel) on skip (held in the LDS tile), masked store
-    {
-        f32x16 m[kMelNT];
+    // ---- mel Linear(dx2, n_mel) on skip (held in the tile), masked store
+    if (n_layers == 0) issue_B(0);
+    commit_B(n_layers);    // mel bias; the last LayerNorm's reads of group B finished before its closing barrier
+    __syncthreads();
+    if (ns * WCOLS < p.n_mel) {   // wave-uniform: column slices beyond n_mel have nothing to do
+        zero_acc();
+        gemm_dx2(p.lay.mel_w, nullptr);
+        const float* mb = pbuf + P_PWB;
 #pragma unroll
-        for (int nt = 0; nt < kMelNT; ++nt) m[nt] = zero16();
-        const f32x4* bw = blob4 + (p.lay.mel_w >> 2) + lane;
-        for (int kc = 0; kc < KCS; ++kc) {
-            const f32x4 av = *reinterpret_cast<const f32x4*>(xs_w + i * LDSROW + 8 * kc + 4 * h);
-            f32x4 bv[kMelNT];
+        for (int t = 0; t < NTW; ++t) {
+            const int col = ns * WCOLS + 32 * t + i;
+            if (col >= p.n_mel) continue;
+            const float bc = mb[col];
 #pragma unroll
-            for (int nt = 0; nt < kMelNT; ++nt) bv[nt] = bw[(kc * kMelNT + nt) * 64];
+            for (int mt = 0; mt < 2; ++mt) {
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
-#pragma unroll
-                for (int nt = 0; nt < kMelNT; ++nt) m[nt] = mfma32(av[s], bv[nt][s], m[nt]);
-            }
-        }
-        const float* mb = p.blob + p.lay.mel_b;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int f = f0 + 32 * w + tile_row(r, lane);
-            if (f < f_lo || f >= out_hi) continue;
-            float* orow = p.mel + ((long)b * p.L_out + f) * p.n_mel;
-            const bool live = f < valid_end;
-#pragma unroll
-            for (int nt = 0; nt < kMelNT; ++nt) {
-                const int col = 32 * nt + i;
-                if (col < p.n_mel) orow[col] = live ? m[nt][r] + mb[col] : 0.0f;
+                for (int r = 0; r < 16; ++r) {
+                    const int f = f0 + 64 * mh + 32 * mt + tile_row(r, lane);
+                    if (f < f_lo || f >= out_hi) continue;
+                    p.mel[((long)b * p.L_out + f) * p.n_mel + col] = f < valid_end ? acc[mt][t][r] + bc : 0.0f;
+                }
             }
         }
     }
