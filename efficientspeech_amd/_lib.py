@@ -51,7 +51,8 @@ class DecoderShape(C.Structure):
 
 
 EXPORTS = (
-    "esmi_version", "esmi_backend", "esmi_pack_conv_weight_f32", "esmi_pack_convT_weight_f32",
+    "esmi_version", "esmi_backend", "esmi_set_fusion", "esmi_fuse_variance_adaptor_workspace_bytes",
+    "esmi_fuse_variance_adaptor_f32", "esmi_pack_conv_weight_f32", "esmi_pack_convT_weight_f32",
     "esmi_encoder_block_workspace_bytes", "esmi_encoder_block_f32", "esmi_pool_mask_u8",
     "esmi_fuse_workspace_bytes", "esmi_fuse_f32", "esmi_variance_adaptor_workspace_bytes",
     "esmi_variance_adaptor_f32", "esmi_length_regulate_i32", "esmi_length_regulator_indices_i32",
@@ -77,6 +78,12 @@ def bind(lib):
     lib.esmi_variance_adaptor_workspace_bytes.argtypes = [i, i, i]
     lib.esmi_variance_adaptor_workspace_bytes.restype = sz
     lib.esmi_variance_adaptor_f32.argtypes = [P(PredictorWeights)] * 3 + [i, i, i] + [fp] * 11 + [fp, sz, fp]
+    lib.esmi_set_fusion.argtypes = [i]
+    lib.esmi_set_fusion.restype = i
+    lib.esmi_fuse_variance_adaptor_workspace_bytes.argtypes = [i, i, i, i]
+    lib.esmi_fuse_variance_adaptor_workspace_bytes.restype = sz
+    lib.esmi_fuse_variance_adaptor_f32.argtypes = [P(FuseWeights), i, i, i, i, i, P(fp), P(i)] + [P(PredictorWeights)] * 3 + \
+        [fp] * 11 + [fp, sz, fp]
     lib.esmi_length_regulate_i32.argtypes = [fp, i, i, fp, fp, fp, fp]
     lib.esmi_length_regulator_indices_i32.argtypes = [fp, i, i, i, fp, fp]
     lib.esmi_upsample_f32.argtypes = [fp, fp, fp, i, i, i, i, fp, fp, fp]
@@ -87,7 +94,7 @@ def bind(lib):
     lib.esmi_mask_rows_f32.argtypes = [fp, fp, C.c_int64, i, fp]
     for name in EXPORTS:
         fn = getattr(lib, name)
-        if fn.restype is C.c_int and name != "esmi_version":
+        if fn.restype is C.c_int and name not in ("esmi_version", "esmi_set_fusion"):
             fn.errcheck = _make_check(name)
     return lib
 

@@ -54,16 +54,23 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnP p) {
         kok[kt] = 32 * kt + i < p.N;
         krow[kt] = kb + (long)(kok[kt] ? 32 * kt + i : 0) * ld;
     }
-    for (int kc = 0; kc < (p.C >> 3); ++kc) {
-        const int c = 8 * kc + 4 * h2;
-        const f32x4 qv = qok ? ld4(qrow + c) : zero4();
-        f32x4 kv[NKT];
+    // operands for 4 k-steps groups are fetched together (one memory round trip per 32 channels)
+    for (int kc = 0; kc < (p.C >> 3); kc += 4) {
+        f32x4 qv[4], kv[4][NKT];
 #pragma unroll
-        for (int kt = 0; kt < NKT; ++kt) kv[kt] = kok[kt] ? ld4(krow[kt] + c) : zero4();
+        for (int g = 0; g < 4; ++g) {
+            const int c = 8 * (kc + g) + 4 * h2;
+            qv[g] = qok ? ld4(qrow + c) : zero4();
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
+            for (int kt = 0; kt < NKT; ++kt) kv[g][kt] = kok[kt] ? ld4(krow[kt] + c) : zero4();
+        }
 #pragma unroll
-            for (int kt = 0; kt < NKT; ++kt) s[kt] = mfma32(kv[kt][t], qv[t], s[kt]);
+        for (int g = 0; g < 4; ++g) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+#pragma unroll
+                for (int kt = 0; kt < NKT; ++kt) s[kt] = mfma32(kv[g][kt][t], qv[g][t], s[kt]);
+            }
         }
     }
     // ---- softmax over keys for this lane's query: in-lane over (kt, r), then the other half wave
@@ -104,14 +111,20 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnP p) {
 #pragma unroll
         for (int kt = 0; kt < NKT; ++kt) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int key = 32 * kt + tile_row(r, lane);  // differs between the two half waves: that IS the k index
-                const bool vok = key < p.N;
-                const float* vrow = vb + (long)(vok ? key : 0) * ld + c0 + i;
+            for (int r4 = 0; r4 < 16; r4 += 4) {   // four key rows' V values in flight at a time
+                float vv[4][4];
 #pragma unroll
-                for (int nt = 0; nt < 4; ++nt) {
-                    const float vv = (vok && c0 + 32 * nt + i < p.C) ? vrow[32 * nt] : 0.0f;
-                    o[nt] = mfma32(s[kt][r], vv, o[nt]);
+                for (int rr = 0; rr < 4; ++rr) {
+                    const int key = 32 * kt + tile_row(r4 + rr, lane);  // differs between the half waves: that IS the k index
+                    const bool vok = key < p.N;
+                    const float* vrow = vb + (long)(vok ? key : 0) * ld + c0 + i;
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt) vv[rr][nt] = (vok && c0 + 32 * nt + i < p.C) ? vrow[32 * nt] : 0.0f;
+                }
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) {
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt) o[nt] = mfma32(s[kt][r4 + rr], vv[rr][nt], o[nt]);
                 }
             }
         }

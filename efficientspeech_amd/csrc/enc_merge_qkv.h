@@ -1,0 +1,87 @@
+// Fused first half of an encoder block (layers/networks.py:54,64-67 + layers/blocks.py:44):
+//     x   = Conv1x1( Conv1d_k,stride( Embedding(ids) | x_in ) )        both convs dense and bias-free
+//     qkv = Linear(C, 3*h*C, bias=False)(x)
+// one wave per (utterance, 32-position tile); the k-tap conv reads its shifted input rows straight from
+// global memory / the embedding table, the two follow-up GEMMs take their A fragments from the wave's LDS tile.
+#pragma once
+#include "wave_chain.h"
+
+namespace esmi {
+
+struct EncMergeP {
+    const int* ids;        // block 0: (B, n_in) phoneme ids, else NULL
+    const float* table;    // block 0: (vocab, Cin) embedding
+    int vocab;
+    const float* x_in;     // blocks >= 1: (B, n_in, Cin)
+    int B, n_in, n_out, k, stride, pad, h;
+    const float* merge_w;  // (k, Cin, Cin) tap-major
+    const float* merge1_w; // (C, Cin)
+    const float* qkv_w;    // (3*h*C, C)
+    float* x_out;          // (B, n_out, C)
+    float* qkv;            // (B, n_out, 3*h*C)
+    int tiles_per_b;       // ceil(n_out / 32)
+};
+
+template <int NCI, int NC>   // Cin = 32*NCI, C = 32*NC
+__global__ __launch_bounds__(64) void enc_merge_qkv_kernel(const EncMergeP p) {
+    constexpr int CIN = 32 * NCI, C = 32 * NC;
+    constexpr int LD = (NCI > NC ? CIN : C) + 4;
+    ESMI_DYN_LDS(buf);             // [32][LD]
+    const int lane = lane_id(), i = lane & 31, h2 = lane >> 5;
+    const int b = (int)blockIdx.x / p.tiles_per_b, tile = (int)blockIdx.x - b * p.tiles_per_b;
+    const int t0 = tile * 32, t_out = t0 + i;
+    const float* a_row = buf + i * LD + 4 * h2;
+
+    // ---- dense k-tap conv (stride s, zero padding)
+    f32x16 a1[NCI];
+    zero_tiles<NCI>(a1);
+    for (int j = 0; j < p.k; ++j) {
+        const int ti = t_out * p.stride + j - p.pad;
+        const float* arow = nullptr;
+        if (t_out < p.n_out && ti >= 0 && ti < p.n_in) {
+            if (p.ids) {
+                int id = p.ids[b * p.n_in + ti];
+                if (id < 0 || id >= p.vocab) id = 0;   // the reference raises IndexError; stay in bounds
+                arow = p.table + (long)id * CIN + 4 * h2;
+            } else {
+                arow = p.x_in + ((long)b * p.n_in + ti) * CIN + 4 * h2;
+            }
+        }
+        wave_gemm<NCI>(a1, arow, CIN, p.merge_w + (long)j * CIN * CIN, CIN, 0, 0, CIN, lane);
+    }
+    tile_store<NCI>(buf, LD, 0, a1, lane);
+    __syncthreads();
+    // ---- 1x1 conv -> x
+    f32x16 x[NC];
+    zero_tiles<NC>(x);
+    wave_gemm<NC>(x, a_row, CIN, p.merge1_w, CIN, 0, 0, C, lane);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int t = t0 + tile_row(r, lane);
+        if (t >= p.n_out) continue;
+        float* orow = p.x_out + ((long)b * p.n_out + t) * C + i;
+#pragma unroll
+        for (int nt = 0; nt < NC; ++nt) orow[32 * nt] = x[nt][r];
+    }
+    __syncthreads();
+    tile_store<NC>(buf, LD, 0, x, lane);
+    __syncthreads();
+    // ---- qkv, 128 output channels per pass
+    const int nq = 3 * p.h * C;
+    for (int n0 = 0; n0 < nq; n0 += 128) {
+        f32x16 q[4];
+        zero_tiles<4>(q);
+        wave_gemm<4>(q, a_row, C, p.qkv_w, C, 0, n0, nq, lane);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int t = t0 + tile_row(r, lane);
+            if (t >= p.n_out) continue;
+            float* orow = p.qkv + ((long)b * p.n_out + t) * nq + n0 + i;
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+                if (n0 + 32 * nt + i < nq) orow[32 * nt] = q[nt][r];
+        }
+    }
+}
+
+}  // namespace esmi

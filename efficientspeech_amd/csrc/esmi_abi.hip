@@ -8,6 +8,9 @@
 
 #include "attention.h"
 #include "convgemm.h"
+#include "enc_attn_ffn.h"
+#include "enc_fuse_va.h"
+#include "enc_merge_qkv.h"
 #include "esmi_dev.h"
 #include "mel_decoder.h"
 #include "small_kernels.h"
@@ -63,7 +66,7 @@ int launch_convgemm(ConvGemmP p, hipStream_t st) {
 }
 
 int launch_attn(const AttnP& p, hipStream_t st) {
-    if ((p.C & 7) || p.N <= 0) return ESMI_ERR_ARG;
+    if ((p.C & 31) || p.N <= 0) return ESMI_ERR_ARG;   // channel groups of 32 (4 k-steps fetched together)
     const int nkt = (p.N + 31) / 32;
     if (nkt > 8) return ESMI_ERR_UNSUPPORTED;  // N <= 256 keys held in registers (all BASELINE configs)
     const int tiles = p.B * p.h * nkt;
@@ -76,6 +79,42 @@ int launch_attn(const AttnP& p, hipStream_t st) {
 }
 
 inline int conv_out_len(int n, int k, int stride, int pad) { return (n + 2 * pad - k) / stride + 1; }
+
+int g_fusion = ESMI_FUSE_ALL;   // esmi_set_fusion(): bit mask of enabled wave-chain stages
+
+// E1: merge conv + 1x1 + qkv in one launch.  Returns ESMI_ERR_UNSUPPORTED when no instantiation fits.
+int launch_enc_merge_qkv(const EncMergeP& p, int c_in, int c_out, hipStream_t st) {
+    const int nci = c_in / 32, nc = c_out / 32;
+    if ((c_in & 31) || (c_out & 31)) return ESMI_ERR_UNSUPPORTED;
+    dim3 grid(p.B * p.tiles_per_b), block(64);
+    const int lds = 32 * ((nci > nc ? c_in : c_out) + 4) * (int)sizeof(float);
+#define ESMI_E1(NCI, NC) \
+    if (nci == NCI && nc == NC) { ESMI_LAUNCH((enc_merge_qkv_kernel<NCI, NC>), grid, block, lds, st, p); return launch_status(); }
+    ESMI_E1(4, 1) ESMI_E1(1, 2) ESMI_E1(4, 2) ESMI_E1(2, 4) ESMI_E1(4, 4)
+#undef ESMI_E1
+    return ESMI_ERR_UNSUPPORTED;
+}
+
+bool enc_attn_ffn_supported(int C, int N, int expansion) {
+    if ((C & 31) || N > 256 || N < 1) return false;
+    const int nc = C / 32;
+    return (expansion == 1 && (nc == 1 || nc == 2 || nc == 4)) || (expansion == 2 && nc == 4);
+}
+
+// E2: attention + proj + LN1 + MixFFN + LN2 in one launch.
+int launch_enc_attn_ffn(const EncAttnFfnP& p, int expansion, hipStream_t st) {
+    if ((p.C & 31) || p.N > 256) return ESMI_ERR_UNSUPPORTED;
+    const int nc = p.C / 32, nkt = p.N <= 64 ? 2 : (p.N <= 128 ? 4 : 8);
+    dim3 grid(p.B * p.tiles_per_b), block(64);
+    const int lds = 34 * (p.C * expansion + 4) * (int)sizeof(float);
+#define ESMI_E2(NKT, NC, E) \
+    if (nkt == NKT && nc == NC && expansion == E) { ESMI_LAUNCH((enc_attn_ffn_kernel<NKT, NC, E>), grid, block, lds, st, p); return launch_status(); }
+#define ESMI_E2K(NC, E) ESMI_E2(2, NC, E) ESMI_E2(4, NC, E) ESMI_E2(8, NC, E)
+    ESMI_E2K(1, 1) ESMI_E2K(2, 1) ESMI_E2K(4, 1) ESMI_E2K(4, 2)
+#undef ESMI_E2K
+#undef ESMI_E2
+    return ESMI_ERR_UNSUPPORTED;
+}
 
 struct EncWs {
     size_t t_merge, qkv, ctx, y1, m1, m2, total;
@@ -103,6 +142,12 @@ extern "C" void esmi_dev_set_trace(long long* ptr) { g_esmi_trace = ptr; }
 #endif
 
 extern "C" {
+
+int esmi_set_fusion(int enabled) {
+    const int old = g_fusion;
+    g_fusion = enabled & ESMI_FUSE_ALL;
+    return old;
+}
 
 int esmi_version(void) { return ESMI_VERSION; }
 const char* esmi_backend(void) {
@@ -152,24 +197,52 @@ int esmi_encoder_block_f32(const esmi_encoder_block_weights* w, const esmi_encod
     const int n = conv_out_len(s->n_in, s->kernel, s->stride, s->kernel / 2);
     hipStream_t st = S(stream);
     int rc;
-    // merge conv k x k (dense, bias-free), networks.py:64-66
     ConvGemmP p = conv_defaults();
-    p.B = B; p.n_in = s->n_in; p.c_in = s->c_in; p.n_out = n; p.c_out = s->c_in;
-    p.k = s->kernel; p.stride = s->stride; p.pad = s->kernel / 2;
-    if (ids) { p.ids = ids; p.table = embed; p.ld_table = s->c_in; p.vocab = s->vocab; }
-    else { p.A = x_in; p.lda = s->c_in; }
-    p.W = w->merge_w; p.out = t_merge; p.ldo = s->c_in;
-    if ((rc = launch_convgemm(p, st))) return rc;
-    // merge 1x1, networks.py:67
-    p = conv_defaults();
-    p.B = B; p.n_in = n; p.c_in = s->c_in; p.n_out = n; p.c_out = C;
-    p.A = t_merge; p.lda = s->c_in; p.W = w->merge1_w; p.out = x_out; p.ldo = C;
-    if ((rc = launch_convgemm(p, st))) return rc;
-    // qkv Linear (bias-free), blocks.py:44
-    p = conv_defaults();
-    p.B = B; p.n_in = n; p.c_in = C; p.n_out = n; p.c_out = 3 * h * C;
-    p.A = x_out; p.lda = C; p.W = w->qkv_w; p.out = qkv; p.ldo = 3 * h * C;
-    if ((rc = launch_convgemm(p, st))) return rc;
+    bool fused1 = false;
+    // With the fused second stage, x (the block input after the merge convs) lives in scratch and the final
+    // result is written straight to x_out: tiles read their neighbours' x rows, so in-place is not possible.
+    const bool fused2 = (g_fusion & ESMI_FUSE_ATTN_FFN) && enc_attn_ffn_supported(C, n, s->expansion);
+    float* x_mid = fused2 ? y1 : x_out;
+    if (g_fusion & ESMI_FUSE_MERGE_QKV) {   // E1: merge conv + 1x1 + qkv as one wave-chain kernel
+        EncMergeP m;
+        memset(&m, 0, sizeof m);
+        m.ids = ids; m.table = embed; m.vocab = s->vocab; m.x_in = ids ? nullptr : x_in;
+        m.B = B; m.n_in = s->n_in; m.n_out = n; m.k = s->kernel; m.stride = s->stride; m.pad = s->kernel / 2; m.h = h;
+        m.merge_w = w->merge_w; m.merge1_w = w->merge1_w; m.qkv_w = w->qkv_w; m.x_out = x_mid; m.qkv = qkv;
+        m.tiles_per_b = (n + 31) / 32;
+        rc = launch_enc_merge_qkv(m, s->c_in, C, st);
+        if (rc == ESMI_OK) fused1 = true;
+        else if (rc != ESMI_ERR_UNSUPPORTED) return rc;
+    }
+    if (!fused1) {
+        // merge conv k x k (dense, bias-free), networks.py:64-66
+        p.B = B; p.n_in = s->n_in; p.c_in = s->c_in; p.n_out = n; p.c_out = s->c_in;
+        p.k = s->kernel; p.stride = s->stride; p.pad = s->kernel / 2;
+        if (ids) { p.ids = ids; p.table = embed; p.ld_table = s->c_in; p.vocab = s->vocab; }
+        else { p.A = x_in; p.lda = s->c_in; }
+        p.W = w->merge_w; p.out = t_merge; p.ldo = s->c_in;
+        if ((rc = launch_convgemm(p, st))) return rc;
+        // merge 1x1, networks.py:67
+        p = conv_defaults();
+        p.B = B; p.n_in = n; p.c_in = s->c_in; p.n_out = n; p.c_out = C;
+        p.A = t_merge; p.lda = s->c_in; p.W = w->merge1_w; p.out = x_mid; p.ldo = C;
+        if ((rc = launch_convgemm(p, st))) return rc;
+        // qkv Linear (bias-free), blocks.py:44
+        p = conv_defaults();
+        p.B = B; p.n_in = n; p.c_in = C; p.n_out = n; p.c_out = 3 * h * C;
+        p.A = x_mid; p.lda = C; p.W = w->qkv_w; p.out = qkv; p.ldo = 3 * h * C;
+        if ((rc = launch_convgemm(p, st))) return rc;
+    }
+    if (fused2) {   // E2: attention + proj + LN1 + MixFFN + LN2 as one wave-chain kernel
+        EncAttnFfnP f;
+        memset(&f, 0, sizeof f);
+        f.x = x_mid; f.qkv = qkv; f.B = B; f.N = n; f.C = C; f.h = h; f.scale = 1.0f / sqrtf((float)(C / h));
+        f.proj_w = w->proj_w; f.proj_b = w->proj_b; f.ln1_g = w->ln1_g; f.ln1_b = w->ln1_b;
+        f.mlp1_w = w->mlp1_w; f.mlp1_b = w->mlp1_b; f.conv_w = w->conv_w; f.conv_b = w->conv_b;
+        f.mlp2_w = w->mlp2_w; f.mlp2_b = w->mlp2_b; f.ln2_g = w->ln2_g; f.ln2_b = w->ln2_b;
+        f.mask = mask; f.out = x_out; f.tiles_per_b = (n + kEncTileRows - 1) / kEncTileRows;
+        return launch_enc_attn_ffn(f, s->expansion, st);
+    }
     // softmax(q k^T scale) v, blocks.py:49-64
     AttnP a;
     a.qkv = qkv; a.B = B; a.N = n; a.C = C; a.h = h; a.ctx = ctx;
@@ -285,6 +358,59 @@ int esmi_variance_adaptor_f32(const esmi_predictor_weights* pitch, const esmi_pr
     const long n = (long)B * T * dim;
     ESMI_LAUNCH(va_tail_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, v);
     return launch_status();
+}
+
+size_t esmi_fuse_variance_adaptor_workspace_bytes(int B, int T, int dim, int depth) {
+    return esmi_fuse_workspace_bytes(B, T, dim, depth) + esmi_variance_adaptor_workspace_bytes(B, T, dim);
+}
+
+int esmi_fuse_variance_adaptor_f32(const esmi_fuse_weights* fw, int depth, int dim, int kernel, int B, int T,
+                                   const float* const* feats, const int* n_i, const esmi_predictor_weights* pitch,
+                                   const esmi_predictor_weights* energy, const esmi_predictor_weights* duration,
+                                   const uint8_t* mask, const float* pitch_target, const float* energy_target,
+                                   const int32_t* duration_target, float* feat, float* pitch_pred, float* energy_pred,
+                                   float* duration_pred, int32_t* pitch_idx, int32_t* energy_idx, int32_t* dur,
+                                   void* workspace, size_t workspace_bytes, esmi_stream_t stream) {
+    if (!fw || !feats || !n_i || !pitch || !energy || !duration || !feat || !pitch_pred || !energy_pred ||
+        !duration_pred || !dur || depth < 1 || depth > ESMI_MAX_DEPTH)
+        return ESMI_ERR_ARG;
+    bool chain = (g_fusion & ESMI_FUSE_VARIANCE) && (dim == 32 || dim == 64) && kernel <= 7 && n_i[0] == T;
+    for (int i = 1; i < depth && chain; ++i)
+        if ((n_i[i] - 1) * (1 << i) + kernel < T) return ESMI_ERR_UNSUPPORTED;   // torch.cat would raise in the reference
+    if (chain) {
+        FuseVaP p;
+        memset(&p, 0, sizeof p);
+        p.B = B; p.T = T; p.depth = depth; p.kernel = kernel;
+        for (int i = 0; i < depth; ++i) {
+            p.feats[i] = feats[i]; p.n_i[i] = n_i[i];
+            p.mlp_w[i] = fw->mlp_w[i]; p.mlp_b[i] = fw->mlp_b[i]; p.up_w[i] = fw->up_w[i]; p.up_b[i] = fw->up_b[i];
+        }
+        p.fuse_w = fw->fuse_w; p.fuse_b = fw->fuse_b;
+        const esmi_predictor_weights* pw[3] = {pitch, energy, duration};
+        for (int q = 0; q < 3; ++q) {
+            PredW& d = p.pred[q];
+            d.conv1_w = pw[q]->conv1_w; d.conv1_b = pw[q]->conv1_b; d.ln1_g = pw[q]->ln1_g; d.ln1_b = pw[q]->ln1_b;
+            d.conv2_w = pw[q]->conv2_w; d.conv2_b = pw[q]->conv2_b; d.ln2_g = pw[q]->ln2_g; d.ln2_b = pw[q]->ln2_b;
+            d.lin_w = pw[q]->lin_w; d.lin_b = pw[q]->lin_b; d.bins = pw[q]->bins; d.emb = pw[q]->emb;
+        }
+        if (!pitch->bins || !pitch->emb || !energy->bins || !energy->emb) return ESMI_ERR_ARG;
+        p.mask = mask; p.pitch_t = pitch_target; p.energy_t = energy_target; p.dur_t = duration_target;
+        p.feat = feat; p.preds[0] = pitch_pred; p.preds[1] = energy_pred; p.preds[2] = duration_pred;
+        p.pitch_idx = pitch_idx; p.energy_idx = energy_idx; p.dur = dur;
+        p.tiles_per_b = (T + kVaTileRows - 1) / kVaTileRows;
+        dim3 grid(B * p.tiles_per_b), block(64);
+        const int lds = fuse_va_lds_floats(dim, depth) * (int)sizeof(float);
+        if (dim == 32) ESMI_LAUNCH((enc_fuse_va_kernel<1>), grid, block, lds, S(stream), p);
+        else ESMI_LAUNCH((enc_fuse_va_kernel<2>), grid, block, lds, S(stream), p);
+        return launch_status();
+    }
+    if (!workspace || workspace_bytes < esmi_fuse_variance_adaptor_workspace_bytes(B, T, dim, depth)) return ESMI_ERR_WORKSPACE;
+    const size_t fws = esmi_fuse_workspace_bytes(B, T, dim, depth);
+    int rc = esmi_fuse_f32(fw, depth, dim, kernel, B, T, feats, n_i, mask, feat, 4 * dim, workspace, fws, stream);
+    if (rc) return rc;
+    return esmi_variance_adaptor_f32(pitch, energy, duration, dim, B, T, mask, pitch_target, energy_target,
+                                     duration_target, feat, pitch_pred, energy_pred, duration_pred, pitch_idx, energy_idx,
+                                     dur, static_cast<char*>(workspace) + fws, workspace_bytes - fws, stream);
 }
 
 int esmi_length_regulate_i32(const int32_t* dur, int B, int T, int32_t* cum, int32_t* mel_len, int32_t* lmax,

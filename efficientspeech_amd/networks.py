@@ -443,7 +443,7 @@ class PhonemeEncoder(nn.Module):
         T, dim = feats[0].shape[1], self.dim
         m8 = bmasks[0]
         feat = torch.empty((B, T, 4 * dim), dtype=torch.float32, device=dev)
-        self.fuse._run(feats, m8, out=feat, ld_out=4 * dim)            # fused features land in channels [0, dim)
+        fw, _kf = self.fuse._packed(lib, stream)
         (pw, _k0), (ew, _k1), (dw, _k2) = self._predictors(lib, stream)
 
         def tgt(key, dtype):
@@ -457,11 +457,16 @@ class PhonemeEncoder(nn.Module):
         preds = torch.empty((3, B, T, 1), dtype=torch.float32, device=dev)
         idxs = torch.empty((2, B, T), dtype=torch.int32, device=dev)
         dur = torch.empty((B, T), dtype=torch.int32, device=dev)
-        ws_bytes = lib.esmi_variance_adaptor_workspace_bytes(B, T, dim)
+        depth = len(feats)
+        ws_bytes = lib.esmi_fuse_variance_adaptor_workspace_bytes(B, T, dim, depth)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-        lib.esmi_variance_adaptor_f32(C.byref(pw), C.byref(ew), C.byref(dw), dim, B, T, _ptr(m8), _ptr(pitch_t),
-                                      _ptr(energy_t), _ptr(dur_t), _ptr(feat), _ptr(preds[0]), _ptr(preds[1]),
-                                      _ptr(preds[2]), _ptr(idxs[0]), _ptr(idxs[1]), _ptr(dur), _ptr(ws), ws_bytes, stream)
+        fp = (C.c_void_p * depth)(*[_ptr(f) for f in feats])
+        ni = (C.c_int * depth)(*[f.shape[1] for f in feats])
+        # Fuse (channels [0,dim) of feat) + the three predictors, embeddings, concat and duration rounding
+        lib.esmi_fuse_variance_adaptor_f32(C.byref(fw), depth, dim, self.fuse.kernel_size, B, T, fp, ni, C.byref(pw),
+                                           C.byref(ew), C.byref(dw), _ptr(m8), _ptr(pitch_t), _ptr(energy_t), _ptr(dur_t),
+                                           _ptr(feat), _ptr(preds[0]), _ptr(preds[1]), _ptr(preds[2]), _ptr(idxs[0]),
+                                           _ptr(idxs[1]), _ptr(dur), _ptr(ws), ws_bytes, stream)
         cum = torch.empty((B, T), dtype=torch.int32, device=dev)
         mel_len = torch.empty((B,), dtype=torch.int32, device=dev)
         lmax = torch.empty((1,), dtype=torch.int32, device=dev)

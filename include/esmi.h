@@ -42,6 +42,15 @@ int esmi_version(void);
 /* "hip:gfx950" for the product build; "wavesim" for the CPU test simulator build. */
 const char* esmi_backend(void);
 
+/* Fusion switch (process-global bit mask, default ESMI_FUSE_ALL): a cleared bit forces one kernel per
+ * reference op for that stage instead of the fused wave-chain kernel.  Returns the previous mask.
+ * Exists for tests and ablation; both launch plans are parity-tested. */
+#define ESMI_FUSE_MERGE_QKV 1 /* merge convs + 1x1 + qkv                 */
+#define ESMI_FUSE_ATTN_FFN 2  /* attention + proj + LN1 + MixFFN + LN2   */
+#define ESMI_FUSE_VARIANCE 4  /* Fuse + 3 predictors + embeddings + round */
+#define ESMI_FUSE_ALL 7
+int esmi_set_fusion(int enabled);
+
 /* ------------------------------------------------------------------ weight packing
  * nn.Conv1d weight (Cout, Cin, k) -> (k, Cout, Cin)            [networks.py:40-42, blocks.py:17] */
 int esmi_pack_conv_weight_f32(const float* src, float* dst, int cout, int cin, int k, esmi_stream_t stream);
@@ -145,6 +154,18 @@ int esmi_variance_adaptor_f32(const esmi_predictor_weights* pitch, const esmi_pr
                               int32_t* pitch_idx, int32_t* energy_idx, /* (B,T) bucket ids (may be NULL) */
                               int32_t* dur,                 /* (B,T) integer repeat counts              */
                               void* workspace, size_t workspace_bytes, esmi_stream_t stream);
+
+/* Fuse + variance adaptor in ONE call (what PhonemeEncoder.forward does between the encoder and the length
+ * regulator, networks.py:347-384); uses a single fused kernel when the shape allows (dim 32 or 64), else the two
+ * calls above.  `feat` (B,T,4*dim) is fully written.  Arguments as in esmi_fuse_f32 / esmi_variance_adaptor_f32. */
+size_t esmi_fuse_variance_adaptor_workspace_bytes(int B, int T, int dim, int depth);
+int esmi_fuse_variance_adaptor_f32(const esmi_fuse_weights* fuse, int depth, int dim, int kernel, int B, int T,
+                                   const float* const* feats, const int* n_i, const esmi_predictor_weights* pitch,
+                                   const esmi_predictor_weights* energy, const esmi_predictor_weights* duration,
+                                   const uint8_t* mask, const float* pitch_target, const float* energy_target,
+                                   const int32_t* duration_target, float* feat, float* pitch_pred, float* energy_pred,
+                                   float* duration_pred, int32_t* pitch_idx, int32_t* energy_idx, int32_t* dur,
+                                   void* workspace, size_t workspace_bytes, esmi_stream_t stream);
 
 /* ------------------------------------------------------------------ Length regulator
  * FeatureUpsampler.forward, layers/networks.py:228-258 (and its dead twin acoustic.py:33-42):

@@ -39,12 +39,19 @@ def nets():
     return get
 
 
+@pytest.mark.parametrize("fusion", [7, 0], ids=["fused", "unfused"])
 @pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p)[:-4] for p in GOLDEN])
-def test_golden_vectors(path, nets):
+def test_golden_vectors(path, fusion, nets):
+    """Both launch plans: fused wave-chain kernels (default) and one kernel per reference op."""
     g = np.load(path)
     name = os.path.basename(path).split("_")[0]
     net, cfg, sd = nets(name, g)
-    H.check_against_golden(net, g, DEV)
+    lib = _lib.load()
+    old = lib.esmi_set_fusion(fusion)
+    try:
+        H.check_against_golden(net, g, DEV)
+    finally:
+        lib.esmi_set_fusion(old)
 
 
 @pytest.mark.parametrize("name,B,T,lens", [
@@ -54,7 +61,16 @@ def test_golden_vectors(path, nets):
     ("base", 3, 64, [64, 40, 7]),
     ("base", 2, 256, [256, 200]),                         # T=256: 8 key tiles (attn_kernel<8>)
 ])
-def test_eval_path_vs_oracle(name, B, T, lens, nets):
+@pytest.mark.parametrize("fusion", [7, 0], ids=["fused", "unfused"])
+def test_eval_path_vs_oracle(name, B, T, lens, fusion, nets):
+    _lib.load().esmi_set_fusion(fusion)
+    try:
+        _eval_path_vs_oracle(name, B, T, lens, nets)
+    finally:
+        _lib.load().esmi_set_fusion(7)
+
+
+def _eval_path_vs_oracle(name, B, T, lens, nets):
     net, cfg, sd = nets(name)
     ids, mask = synth_phonemes(B, T, 4321, lens)
     x = {"phoneme": torch.from_numpy(ids).to(DEV), "phoneme_mask": torch.from_numpy(mask).to(DEV)}

@@ -42,6 +42,23 @@ def test_simulated_kernels_match_golden(path, nets):
         H.check_against_golden(net, g, "cpu")
 
 
+UNFUSED = [os.path.join(GOLD, f) for f in ("tiny_eval_pad_t17.npz", "tiny_train_tf_t17.npz", "tiny_eval_b1_fox.npz",
+                                           "small_eval_pad_t17.npz")]
+
+
+@pytest.mark.parametrize("path", UNFUSED, ids=[os.path.basename(p)[:-4] for p in UNFUSED])
+def test_simulated_unfused_path_matches_golden(path, nets):
+    """esmi_set_fusion(0): one kernel per reference op (the fallback for shapes the chain kernels do not cover)."""
+    g = np.load(path)
+    net, cfg, sd = nets(os.path.basename(path).split("_")[0], g)
+    with use_sim() as lib:
+        old = lib.esmi_set_fusion(0)
+        try:
+            H.check_against_golden(net, g, "cpu")
+        finally:
+            lib.esmi_set_fusion(old)
+
+
 @pytest.mark.parametrize("name,B,T,lens", [
     ("tiny", 3, 70, [70, 41, 9]),        # 3 row tiles; 70 / 35 keys; multi-window decoder (L > 112)
     ("small", 2, 40, [40, 23]),
