@@ -15,6 +15,11 @@
 #include "mel_decoder.h"
 #include "small_kernels.h"
 
+#ifndef ESMI_DEC_NW128
+#define ESMI_DEC_NW128 8   // waves per decoder window at dx2 = 128.  8: one workgroup per CU (235 VGPRs, no spill).
+                           // 4 would put two workgroups on a CU, but hipcc spills 212 VGPRs there: 700 vs 560 us.
+#endif
+
 using namespace esmi;
 
 namespace {
@@ -523,18 +528,18 @@ int esmi_mel_decoder_f32(const float* blob, const esmi_decoder_shape* s, const f
 #endif
     dim3 grid((L_out + p.TL - 1) / p.TL, B), block(kDecThreads);
     hipStream_t st = S(stream);
-#define ESMI_DEC_CASE(DX2, KD)                                                                                     \
+#define ESMI_DEC_CASE(DX2, KD, NW)                                                                                 \
     {                                                                                                              \
         const int lds = dec_lds_floats<DX2>(KD) * (int)sizeof(float);                                              \
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mel_decoder_kernel<DX2, KD>),             \
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mel_decoder_kernel<DX2, KD, NW>),         \
                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds);                      \
         if (e != hipSuccess) return (int)e;                                                                        \
-        ESMI_LAUNCH((mel_decoder_kernel<DX2, KD>), grid, block, lds, st, p);                                       \
+        ESMI_LAUNCH((mel_decoder_kernel<DX2, KD, NW>), grid, dim3(64 * NW), lds, st, p);                           \
     }
-    if (s->dx2 == 128 && s->kernel == 5) ESMI_DEC_CASE(128, 5)
-    else if (s->dx2 == 128 && s->kernel == 3) ESMI_DEC_CASE(128, 3)
-    else if (s->dx2 == 256 && s->kernel == 5) ESMI_DEC_CASE(256, 5)
-    else ESMI_DEC_CASE(256, 3)
+    if (s->dx2 == 128 && s->kernel == 5) ESMI_DEC_CASE(128, 5, ESMI_DEC_NW128)
+    else if (s->dx2 == 128 && s->kernel == 3) ESMI_DEC_CASE(128, 3, ESMI_DEC_NW128)
+    else if (s->dx2 == 256 && s->kernel == 5) ESMI_DEC_CASE(256, 5, 8)
+    else ESMI_DEC_CASE(256, 3, 8)
 #undef ESMI_DEC_CASE
     return launch_status();
 }

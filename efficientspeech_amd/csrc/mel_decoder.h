@@ -49,7 +49,7 @@ namespace esmi {
 
 constexpr int kDecRows = 128;     // frames per workgroup window
 constexpr int kDecPadRows = 2;    // zero rows above/below the window in LDS (>= k/2)
-constexpr int kDecThreads = 512;
+constexpr int kDecThreads = 512;  // 8-wave windows (dx2 = 256); dx2 = 128 uses 4-wave windows, two workgroups per CU
 constexpr int kMelCols = 96;      // n_mel <= 96 (three 32-column MFMA tiles)
 
 struct DecLayout {  // offsets in floats into the packed blob
@@ -124,8 +124,17 @@ __host__ __device__ constexpr int dec_lds_floats(int kd) {
     return (kDecRows + 2 * kDecPadRows) * (DX2 + 4) + (kd + 6) * DX2 + kDecRows;
 }
 
-template <int DX2, int KD>
-__global__ __launch_bounds__(kDecThreads, (DX2 <= 128 ? ESMI_DEC_WPS : 2)) void mel_decoder_kernel(const MelDecP p) {
+// NW = waves per window.  NW = 8: wave (mh = w>>2, ns = w&3) owns 64 rows x DX2/4 columns, one workgroup per CU.
+// NW = 4: wave ns owns all 128 rows x DX2/4 columns; the workgroup fits twice on a CU (76 KB LDS), which would let
+// one workgroup's tanh / LayerNorm / depthwise phases run under the other's K loop -- but with ROCm 7.2's hipcc the
+// 4-wave build needs 256 VGPRs + 212 spilled and is slower (700 vs 560 us); kept selectable for the next round.
+// (Also tried and dropped in round 1: two windows per workgroup in explicit ping-pong -- correct, 330-450 spills.)
+template <int DX2, int KD, int NW>
+__global__ __launch_bounds__(64 * NW, 2) void mel_decoder_kernel(const MelDecP p) {
+    constexpr int kDecThreads = 64 * NW;    // shadows the namespace constant inside this kernel
+    constexpr int MH = NW / 4;              // row halves (1 or 2)
+    constexpr int MT = 4 / MH;              // 32-row MFMA tiles per wave (4 or 2)
+    constexpr int TPR = kDecThreads / kDecRows;   // LayerNorm threads per row (2 or 4)
     constexpr int NTW = DX2 / 128;          // 32-column MFMA tiles per wave
     constexpr int WCOLS = 32 * NTW;         // columns per wave (4 column slices per workgroup)
     constexpr int KCH = DX2 / 128;          // 128-channel K chunks of a dx2-wide contraction
@@ -133,7 +142,7 @@ __global__ __launch_bounds__(kDecThreads, (DX2 <= 128 ? ESMI_DEC_WPS : 2)) void 
     constexpr int PAD = KD / 2;
     constexpr int CG = DX2 / 4;             // 4-channel groups per row
     constexpr int RS = kDecRows / (kDecThreads / CG);  // rows per depthwise strip (8 or 16)
-    constexpr int NV = DX2 / 16;            // float4 per LayerNorm thread (4 threads per row)
+    constexpr int NV = DX2 / (4 * TPR);     // float4 per LayerNorm thread
     ESMI_DYN_LDS(lds);
     // per-layer small parameters in LDS: [taps KD*DX2 | dw_b] (group A: read by the depthwise phase) and
     // [pw_b | ln_g | ln_b | skip_g | skip_b] (group B: read by the tanh / LayerNorm phases).  Single buffer:
@@ -144,14 +153,14 @@ __global__ __launch_bounds__(kDecThreads, (DX2 <= 128 ? ESMI_DEC_WPS : 2)) void 
                   P_SB = P_SG + DX2;
     constexpr int NA4 = (KD + 1) * DX2 / 4;                            // float4 in group A
     constexpr int NB4 = 3 * DX2 / 4;                                   // float4 of pw_b, ln_g, ln_b
-    static_assert(NA4 <= kDecThreads && NB4 + DX2 / 2 <= kDecThreads, "param staging: one float4 per thread per group");
+    static_assert(NA4 <= 2 * kDecThreads && NB4 + DX2 / 2 <= kDecThreads, "param staging: one float4 per thread per group");
     float* xs = lds;                                                  // [132][LDSROW]
     float* pbuf = lds + (kDecRows + 2 * kDecPadRows) * LDSROW;        // [PB]
     int* src = reinterpret_cast<int*>(pbuf + PB);                     // [128]
 
     const int tid = (int)threadIdx.x, lane = lane_id(), w = wave_id();
     const int i = lane & 31, h = lane >> 5;
-    const int mh = w >> 2, ns = w & 3;
+    const int mh = w >> 2, ns = w & 3;      // NW = 4: mh == 0
     const int tile = (int)blockIdx.x, b = (int)blockIdx.y;
     const int L = p.lmax_dev ? *p.lmax_dev : p.lmax_host;
     const int mlen = p.mel_len ? min(p.mel_len[b], L) : L;
@@ -177,12 +186,15 @@ __global__ __launch_bounds__(kDecThreads, (DX2 <= 128 ? ESMI_DEC_WPS : 2)) void 
 
     // ---- parameter staging: global -> register (issued early) ... register -> LDS (committed later).
     // "layer" n_layers is the mel Linear (group B = its bias only).
-    f32x4 pstA = zero4(), pstB = zero4();
+    f32x4 pstA = zero4(), pstA2 = zero4(), pstB = zero4();
     auto issue_A = [&](int l) __attribute__((always_inline)) {
         if (l < n_layers && tid < NA4) pstA = blob4[((p.lay.layer0 + (long)l * p.lay.layer_stride) >> 2) + tid];
+        if (l < n_layers && tid + kDecThreads < NA4)
+            pstA2 = blob4[((p.lay.layer0 + (long)l * p.lay.layer_stride) >> 2) + tid + kDecThreads];
     };
     auto commit_A = [&](int l) __attribute__((always_inline)) {
         if (l < n_layers && tid < NA4) reinterpret_cast<f32x4*>(pbuf)[tid] = pstA;
+        if (l < n_layers && tid + kDecThreads < NA4) reinterpret_cast<f32x4*>(pbuf)[tid + kDecThreads] = pstA2;
     };
     auto issue_B = [&](int l) __attribute__((always_inline)) {
         if (l < n_layers) {
@@ -226,13 +238,14 @@ __global__ __launch_bounds__(kDecThreads, (DX2 <= 128 ? ESMI_DEC_WPS : 2)) void 
     commit_A(0);
     __syncthreads();
 
-    // A-fragment base of this wave's 64 rows; LayerNorm ownership: row = 16w + (lane&15), quarter = lane>>4
-    const float* a_base = xs + (kDecPadRows + 64 * mh + i) * LDSROW + 4 * h;
-    const int ln_row = 16 * w + (lane & 15), ln_q = lane >> 4;
+    // A-fragment base of this wave's rows; LayerNorm ownership: TPR threads per row, a row's threads 64/TPR lanes apart
+    constexpr int RPW = 64 / TPR;           // rows per wave in the LayerNorm pass (16 or 32)
+    const float* a_base = xs + (kDecPadRows + 32 * MT * mh + i) * LDSROW + 4 * h;
+    const int ln_row = RPW * w + (lane & (RPW - 1)), ln_q = lane / RPW;
     float* ln_ptr = xs + (kDecPadRows + ln_row) * LDSROW + 4 * ln_q;
     const bool ln_inside = src[ln_row] != -1;
 
-    f32x16 acc[2][NTW];
+    f32x16 acc[MT][NTW];
     f32x4 skip[NV];
 #pragma unroll
     for (int v = 0; v < NV; ++v) skip[v] = zero4();
@@ -250,7 +263,7 @@ __global__ __launch_bounds__(kDecThreads, (DX2 <= 128 ? ESMI_DEC_WPS : 2)) void 
     };
     auto mma_sub = [&](int a_col0, int k0) __attribute__((always_inline)) {
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
+        for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
             for (int kc = 0; kc < KSUB; ++kc) {
                 const f32x4 av = *reinterpret_cast<const f32x4*>(a_base + 32 * mt * LDSROW + a_col0 + 8 * (k0 + kc));
@@ -278,7 +291,7 @@ __global__ __launch_bounds__(kDecThreads, (DX2 <= 128 ? ESMI_DEC_WPS : 2)) void 
     };
     auto zero_acc = [&]() __attribute__((always_inline)) {
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
+        for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
             for (int t = 0; t < NTW; ++t) acc[mt][t] = zero16();
         }
@@ -290,10 +303,10 @@ __global__ __launch_bounds__(kDecThreads, (DX2 <= 128 ? ESMI_DEC_WPS : 2)) void 
             const int col = ns * WCOLS + 32 * t + i;
             const float bc = bias[col];
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt) {
+            for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int row = 64 * mh + 32 * mt + tile_row(r, lane);
+                    const int row = 32 * MT * mh + 32 * mt + tile_row(r, lane);
                     xs[(kDecPadRows + row) * LDSROW + col] = ESMI_DEC_TANH(acc[mt][t][r] + bc);
                 }
             }
@@ -304,7 +317,7 @@ __global__ __launch_bounds__(kDecThreads, (DX2 <= 128 ? ESMI_DEC_WPS : 2)) void 
         float s = 0.0f;
 #pragma unroll
         for (int k = 0; k < NV; ++k) s += (v[k][0] + v[k][1]) + (v[k][2] + v[k][3]);
-        s += shfl_xor_f(s, 16);
+        if (TPR == 4) s += shfl_xor_f(s, 16);
         s += shfl_xor_f(s, 32);
         const float mean = s * (1.0f / DX2);
         float q = 0.0f;
@@ -316,13 +329,13 @@ __global__ __launch_bounds__(kDecThreads, (DX2 <= 128 ? ESMI_DEC_WPS : 2)) void 
                 q = fmaf(d, d, q);
             }
         }
-        q += shfl_xor_f(q, 16);
+        if (TPR == 4) q += shfl_xor_f(q, 16);
         q += shfl_xor_f(q, 32);
         const float rstd = 1.0f / sqrtf(q * (1.0f / DX2) + 1e-5f);
 #pragma unroll
         for (int k = 0; k < NV; ++k) {
-            const f32x4 gg = *reinterpret_cast<const f32x4*>(g + 16 * k + 4 * ln_q);
-            const f32x4 bb = *reinterpret_cast<const f32x4*>(be + 16 * k + 4 * ln_q);
+            const f32x4 gg = *reinterpret_cast<const f32x4*>(g + 4 * TPR * k + 4 * ln_q);
+            const f32x4 bb = *reinterpret_cast<const f32x4*>(be + 4 * TPR * k + 4 * ln_q);
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[k][e] = fmaf((v[k][e] - mean) * rstd, gg[e], bb[e]);
         }
@@ -331,7 +344,7 @@ __global__ __launch_bounds__(kDecThreads, (DX2 <= 128 ? ESMI_DEC_WPS : 2)) void 
     auto ln_pass = [&](const float* pb, bool block_end, bool set_skip) __attribute__((always_inline)) {
         f32x4 v[NV];
 #pragma unroll
-        for (int k = 0; k < NV; ++k) v[k] = *reinterpret_cast<const f32x4*>(ln_ptr + 16 * k);
+        for (int k = 0; k < NV; ++k) v[k] = *reinterpret_cast<const f32x4*>(ln_ptr + 4 * TPR * k);
 #ifndef ESMI_ABL_NO_LN
         ln_regs(v, pb + P_G, pb + P_B);
         if (block_end) {  // end of a decoder block: skip = LN_s(x + skip), networks.py:299
@@ -343,7 +356,7 @@ __global__ __launch_bounds__(kDecThreads, (DX2 <= 128 ? ESMI_DEC_WPS : 2)) void 
 #pragma unroll
         for (int k = 0; k < NV; ++k) {
             if (!ln_inside) v[k] = zero4();
-            *reinterpret_cast<f32x4*>(ln_ptr + 16 * k) = v[k];
+            *reinterpret_cast<f32x4*>(ln_ptr + 4 * TPR * k) = v[k];
         }
         if (set_skip) {
 #pragma unroll
@@ -454,10 +467,10 @@ __global__ __launch_bounds__(kDecThreads, (DX2 <= 128 ? ESMI_DEC_WPS : 2)) void 
             if (col >= p.n_mel) continue;
             const float bc = mb[col];
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt) {
+            for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int f = f0 + 64 * mh + 32 * mt + tile_row(r, lane);
+                    const int f = f0 + 32 * MT * mh + 32 * mt + tile_row(r, lane);
                     if (f < f_lo || f >= out_hi) continue;
                     p.mel[((long)b * p.L_out + f) * p.n_mel + col] = f < valid_end ? acc[mt][t][r] + bc : 0.0f;
                 }
