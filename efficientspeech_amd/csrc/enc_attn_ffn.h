@@ -50,6 +50,39 @@ __global__ __launch_bounds__(64) void enc_attn_ffn_kernel(const EncAttnFfnP p) {
     const float* a_row = buf + i * LD + 4 * h2;
     const int ld = 3 * p.h * C;
     const float* base = p.qkv + (long)b * p.N * ld;
+    ESMI_CT_INIT(NC == 1 ? 0 : 1);
+    ESMI_CT();   // 0 start
+    // Everything that does not depend on the attention result is requested now, so that its memory round trips
+    // (~2 us each for tensors the previous kernel just wrote) overlap the attention instead of following it.
+    bool rz[16], rout[16];      // rows that are padding (mask) / outside the sequence
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int pos = t0 + tile_row(r, lane);
+        rout[r] = pos < 0 || pos >= p.N;
+        rz[r] = !rout[r] && p.mask && p.mask[(long)b * p.N + pos];
+    }
+    constexpr bool kHoistRes = NC <= 2;
+    f32x16 xres[kHoistRes ? NC : 1];
+    if (kHoistRes) {
+#pragma unroll
+        for (int nt = 0; nt < (kHoistRes ? NC : 1); ++nt) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                xres[nt][r] = rout[r] ? 0.0f : p.x[((long)b * p.N + t0 + tile_row(r, lane)) * C + 32 * nt + i];
+        }
+    }
+    float pb_[NC], g1_[NC], be1_[NC], b2_[NC], g2_[NC], be2_[NC], m1b_[NE], cb_[NE];
+#pragma unroll
+    for (int nt = 0; nt < NC; ++nt) {
+        const int col = 32 * nt + i;
+        pb_[nt] = p.proj_b[col]; g1_[nt] = p.ln1_g[col]; be1_[nt] = p.ln1_b[col];
+        b2_[nt] = p.mlp2_b[col]; g2_[nt] = p.ln2_g[col]; be2_[nt] = p.ln2_b[col];
+    }
+#pragma unroll
+    for (int nt = 0; nt < NE; ++nt) {
+        m1b_[nt] = p.mlp1_b[32 * nt + i];
+        cb_[nt] = p.conv_b[32 * nt + i];
+    }
 
     // ---------------- attention, one head at a time; proj accumulates over heads
     f32x16 y[NC];
@@ -85,6 +118,7 @@ __global__ __launch_bounds__(64) void enc_attn_ffn_kernel(const EncAttnFfnP p) {
                 }
             }
         }
+        ESMI_CT();   // 1 S^T done
         float mx = -INFINITY;   // softmax over keys of this lane's query: in-lane, then the other half wave
 #pragma unroll
         for (int kt = 0; kt < NKT; ++kt) {
@@ -109,55 +143,63 @@ __global__ __launch_bounds__(64) void enc_attn_ffn_kernel(const EncAttnFfnP p) {
         }
         den += shfl_xor_f(den, 32);
         const float inv = 1.0f / den;
+        ESMI_CT();   // 2 softmax done
         f32x16 o[NC];           // ctx[query][c] = sum_key P[query][key] V[key][c]
         zero_tiles<NC>(o);
-#pragma unroll
-        for (int kt = 0; kt < NKT; ++kt) {
-#pragma unroll
-            for (int r4 = 0; r4 < 16; r4 += 4) {
-                float vv[4][NC];
+        {   // P V: 4*NKT groups of four key rows, software pipelined (next group's V rows in flight during the MFMAs)
+            struct VG { float v[4][NC]; };
+            auto vfetch = [&](int f, VG& gq) __attribute__((always_inline)) {
+                const int kt = f >> 2, r4 = (f & 3) << 2;
 #pragma unroll
                 for (int rr = 0; rr < 4; ++rr) {
-                    const int key = 32 * kt + tile_row(r4 + rr, lane);
+                    const int key = 32 * kt + tile_row(r4 + rr, lane);   // differs between the half waves: that IS the k index
                     const bool vok = key < p.N;
                     const float* vrow = vb + (long)(vok ? key : 0) * ld + i;
 #pragma unroll
-                    for (int nt = 0; nt < NC; ++nt) vv[rr][nt] = vok ? vrow[32 * nt] : 0.0f;
+                    for (int nt = 0; nt < NC; ++nt) gq.v[rr][nt] = vok ? vrow[32 * nt] : 0.0f;
                 }
+            };
+            VG v0, v1;
+            vfetch(0, v0);
+#pragma unroll
+            for (int f = 0; f < 4 * NKT; f += 2) {
+                vfetch(f + 1, v1);
 #pragma unroll
                 for (int rr = 0; rr < 4; ++rr) {
 #pragma unroll
-                    for (int nt = 0; nt < NC; ++nt) o[nt] = mfma32(s[kt][r4 + rr] * inv, vv[rr][nt], o[nt]);
+                    for (int nt = 0; nt < NC; ++nt)
+                        o[nt] = mfma32(s[f >> 2][((f & 3) << 2) + rr] * inv, v0.v[rr][nt], o[nt]);
+                }
+                if (f + 2 < 4 * NKT) vfetch(f + 2, v0);
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) {
+#pragma unroll
+                    for (int nt = 0; nt < NC; ++nt)
+                        o[nt] = mfma32(s[(f + 1) >> 2][(((f + 1) & 3) << 2) + rr] * inv, v1.v[rr][nt], o[nt]);
                 }
             }
         }
+        ESMI_CT();   // 3 PV done
         __syncthreads();        // the previous head's proj has finished reading the tile
         tile_store<NC>(buf, LD, 0, o, lane);
         __syncthreads();
         wave_gemm<NC>(y, a_row, C, p.proj_w, p.h * C, hd * C, 0, C, lane);
     }
 
+    ESMI_CT();   // 4 proj done
     // ---------------- y1 = mask(LN1(y + bias + x))
 #pragma unroll
     for (int nt = 0; nt < NC; ++nt) {
         const int col = 32 * nt + i;
-        const float bc = p.proj_b[col];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int pos = t0 + tile_row(r, lane);
-            const bool ok = pos >= 0 && pos < p.N;
-            y[nt][r] += bc + (ok ? p.x[((long)b * p.N + pos) * C + col] : 0.0f);
+            float xr;
+            if (kHoistRes) xr = xres[kHoistRes ? nt : 0][r];
+            else xr = rout[r] ? 0.0f : p.x[((long)b * p.N + t0 + tile_row(r, lane)) * C + col];
+            y[nt][r] += pb_[nt] + xr;
         }
     }
-    layernorm_tile<NC>(y, p.ln1_g, p.ln1_b, lane);
-    bool rz[16];                // rows that are padding (mask) or outside the sequence
-    bool rout[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int pos = t0 + tile_row(r, lane);
-        rout[r] = pos < 0 || pos >= p.N;
-        rz[r] = !rout[r] && p.mask && p.mask[(long)b * p.N + pos];
-    }
+    layernorm_tile_regs<NC>(y, g1_, be1_);
 #pragma unroll
     for (int nt = 0; nt < NC; ++nt) {
 #pragma unroll
@@ -168,42 +210,45 @@ __global__ __launch_bounds__(64) void enc_attn_ffn_kernel(const EncAttnFfnP p) {
     tile_store<NC>(buf, LD, 0, y, lane);
     __syncthreads();
 
+    ESMI_CT();   // 5 LN1 + store done
     // ---------------- MixFFN: mlp1 -> dense conv k3 -> GELU -> mlp2
     f32x16 m[NE];
     zero_tiles<NE>(m);
     wave_gemm<NE>(m, a_row, C, p.mlp1_w, C, 0, 0, EC, lane);
 #pragma unroll
     for (int nt = 0; nt < NE; ++nt) {
-        const float bc = p.mlp1_b[32 * nt + i];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) m[nt][r] = rout[r] ? 0.0f : m[nt][r] + bc;   // outside rows = the conv's zero padding
+        for (int r = 0; r < 16; ++r) m[nt][r] = rout[r] ? 0.0f : m[nt][r] + m1b_[nt];   // outside rows = the conv's zero padding
     }
     __syncthreads();
     tile_store<NE>(buf, LD, 0, m, lane);
     __syncthreads();
+    ESMI_CT();   // 6 mlp1 + store
     zero_tiles<NE>(m);
-#pragma unroll
-    for (int j = 0; j < 3; ++j)
-        wave_gemm<NE>(m, a_row + (j - 1) * LD, EC, p.conv_w + (long)j * EC * EC, EC, 0, 0, EC, lane);
+    {
+        const float* const taps[3] = {a_row - LD, a_row, a_row + LD};
+        wave_gemm_taps<NE, 3>(m, taps, 3, EC, p.conv_w, (long)EC * EC, EC, 0, 0, EC, lane);
+    }
 #pragma unroll
     for (int nt = 0; nt < NE; ++nt) {
-        const float bc = p.conv_b[32 * nt + i];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) m[nt][r] = gelu_erf_f32(m[nt][r] + bc);
+        for (int r = 0; r < 16; ++r) m[nt][r] = gelu_erf_f32(m[nt][r] + cb_[nt]);
     }
     __syncthreads();
     tile_store<NE>(buf, LD, 0, m, lane);
     __syncthreads();
+    ESMI_CT();   // 7 conv + gelu + store
     f32x16 z[NC];
     zero_tiles<NC>(z);
     wave_gemm<NC>(z, a_row, EC, p.mlp2_w, EC, 0, 0, C, lane);
 #pragma unroll
     for (int nt = 0; nt < NC; ++nt) {
-        const float bc = p.mlp2_b[32 * nt + i];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) z[nt][r] += bc + y[nt][r];
+        for (int r = 0; r < 16; ++r) z[nt][r] += b2_[nt] + y[nt][r];
     }
-    layernorm_tile<NC>(z, p.ln2_g, p.ln2_b, lane);
+    ESMI_CT();   // 8 mlp2
+    layernorm_tile_regs<NC>(z, g2_, be2_);
+    ESMI_CT();   // 9 LN2
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int row = tile_row(r, lane);

@@ -74,6 +74,8 @@ __global__ __launch_bounds__(64) void enc_fuse_va_kernel(const FuseVaP p) {
         rz[r] = !rout[r] && p.mask && p.mask[(long)b * p.T + rpos[r]];
     }
 
+    ESMI_CT_INIT(2);
+    ESMI_CT();   // 0
     // ---------------- Fuse
     f32x16 a[ND];
     {   // level 0: Linear(dim, dim) on f_0 rows
@@ -108,12 +110,15 @@ __global__ __launch_bounds__(64) void enc_fuse_va_kernel(const FuseVaP p) {
         tile_store<ND>(tmp, LDD, 0, a, lane);
         __syncthreads();
         zero_tiles<ND>(a);
-        for (int j = 0; j < p.kernel; ++j) {   // out[n*s + j] += in[n] W[:, :, j]
-            const int q = pos_i - j;
-            const int nq = q / s;
-            const bool ok = q >= 0 && (q - nq * s) == 0 && nq < nl;
-            wave_gemm<ND>(a, ok ? tmp + (nq - n_base) * LDD + 4 * h2 : nullptr, DIM, p.up_w[lv] + (long)j * DIM * DIM, DIM, 0,
-                          0, DIM, lane);
+        {   // out[n*s + j] += in[n] W[:, :, j]
+            const float* taps[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+#pragma unroll
+            for (int j = 0; j < 7; ++j) {
+                const int q = pos_i - j;
+                const int nq = q / s;
+                if (j < p.kernel && q >= 0 && (q - nq * s) == 0 && nq < nl) taps[j] = tmp + (nq - n_base) * LDD + 4 * h2;
+            }
+            wave_gemm_taps<ND, 7>(a, taps, p.kernel, DIM, p.up_w[lv], (long)DIM * DIM, DIM, 0, 0, DIM, lane);
         }
 #pragma unroll
         for (int nt = 0; nt < ND; ++nt) {
@@ -141,23 +146,40 @@ __global__ __launch_bounds__(64) void enc_fuse_va_kernel(const FuseVaP p) {
     tile_store<ND>(fb, LDD, 0, a, lane);
     __syncthreads();
 
+    ESMI_CT();   // 1 fuse done
     // ---------------- three predictors
     const float* f_row = fb + i * LDD + 4 * h2;
     const float* t_row = tb + i * LDD + 4 * h2;
     for (int q = 0; q < 3; ++q) {
         const PredW& w = p.pred[q];
-        f32x16 c[ND];
-        zero_tiles<ND>(c);
-#pragma unroll
-        for (int j = 0; j < 3; ++j)
-            wave_gemm<ND>(c, f_row + (j - 1) * LDD, DIM, w.conv1_w + (long)j * DIM * DIM, DIM, 0, 0, DIM, lane);
+        // every small parameter of this predictor is requested up front: one memory round trip instead of six
+        float b1[ND], g1[ND], be1[ND], b2[ND], lw[ND], g2[ND], be2[ND];
 #pragma unroll
         for (int nt = 0; nt < ND; ++nt) {
-            const float bc = w.conv1_b[32 * nt + i];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) c[nt][r] = fmaxf(c[nt][r] + bc, 0.0f);
+            const int col = 32 * nt + i;
+            b1[nt] = w.conv1_b[col]; g1[nt] = w.ln1_g[col]; be1[nt] = w.ln1_b[col];
+            b2[nt] = w.conv2_b[col]; lw[nt] = w.lin_w[col];
+            g2[nt] = q == 2 ? w.ln2_g[col] : 0.0f; be2[nt] = q == 2 ? w.ln2_b[col] : 0.0f;
         }
-        layernorm_tile<ND>(c, w.ln1_g, w.ln1_b, lane);
+        const float lb = w.lin_b[0];
+        // bucket edges replicated in both half waves: lane l holds edges (l&31) + 32*e; +inf beyond the dim-1 edges
+        float edge[ND];
+#pragma unroll
+        for (int e = 0; e < ND; ++e) edge[e] = (q < 2 && 32 * e + i < DIM - 1) ? w.bins[32 * e + i] : INFINITY;
+        f32x16 c[ND];
+        zero_tiles<ND>(c);
+        {
+            const float* const taps[3] = {f_row - LDD, f_row, f_row + LDD};
+            wave_gemm_taps<ND, 3>(c, taps, 3, DIM, w.conv1_w, (long)DIM * DIM, DIM, 0, 0, DIM, lane);
+        }
+#pragma unroll
+        for (int nt = 0; nt < ND; ++nt) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) c[nt][r] = fmaxf(c[nt][r] + b1[nt], 0.0f);
+        }
+        ESMI_CT();   // conv1 done
+        layernorm_tile_regs<ND>(c, g1, be1);
+        ESMI_CT();   // LN1 done
 #pragma unroll
         for (int nt = 0; nt < ND; ++nt) {
 #pragma unroll
@@ -167,19 +189,18 @@ __global__ __launch_bounds__(64) void enc_fuse_va_kernel(const FuseVaP p) {
         tile_store<ND>(tb, LDD, 0, c, lane);
         __syncthreads();
         zero_tiles<ND>(c);
-#pragma unroll
-        for (int j = 0; j < 3; ++j)
-            wave_gemm<ND>(c, t_row + (j - 1) * LDD, DIM, w.conv2_w + (long)j * DIM * DIM, DIM, 0, 0, DIM, lane);
-        float lw[ND];
+        {
+            const float* const taps[3] = {t_row - LDD, t_row, t_row + LDD};
+            wave_gemm_taps<ND, 3>(c, taps, 3, DIM, w.conv2_w, (long)DIM * DIM, DIM, 0, 0, DIM, lane);
+        }
+        ESMI_CT();   // conv2 done
 #pragma unroll
         for (int nt = 0; nt < ND; ++nt) {
-            const float bc = w.conv2_b[32 * nt + i];
-            lw[nt] = w.lin_w[32 * nt + i];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) c[nt][r] = fmaxf(c[nt][r] + bc, 0.0f);
+            for (int r = 0; r < 16; ++r) c[nt][r] = fmaxf(c[nt][r] + b2[nt], 0.0f);
         }
         float pr[16];      // Linear(dim, 1) on the pre-norm2 tensor (networks.py:157-160)
-        const float lb = w.lin_b[0];
+        int bidx[16];      // torch.bucketize(v, edges, right=False) = number of edges strictly below v
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             float s = 0.0f;
@@ -188,19 +209,31 @@ __global__ __launch_bounds__(64) void enc_fuse_va_kernel(const FuseVaP p) {
             s = row_sum32(s) + lb;
             if (q == 2) s = fmaxf(s, 0.0f);
             pr[r] = s;
+            bidx[r] = 0;
+            if (q < 2) {   // wave-uniform branch: the ballots below are executed by all lanes
+                const float* tv = q == 0 ? p.pitch_t : p.energy_t;
+                const float v = (tv && !rout[r]) ? tv[(long)b * p.T + rpos[r]] : s;
+#pragma unroll
+                for (int e = 0; e < ND; ++e) {
+                    const unsigned long long m = ballot64(edge[e] < v);
+                    bidx[r] += __builtin_popcount((unsigned)(h2 ? (m >> 32) : m));
+                }
+            }
         }
-        if (q == 2) layernorm_tile<ND>(c, w.ln2_g, w.ln2_b, lane);   // duration features (networks.py:161-163)
+        ESMI_CT();   // dot done
+        if (q == 2) layernorm_tile_regs<ND>(c, g2, be2);   // duration features (networks.py:161-163)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = tile_row(r, lane);
-            if (row < 2 || row >= 2 + kVaTileRows || rout[r]) continue;
-            const long grow = (long)b * p.T + rpos[r];
+            const bool live = row >= 2 && row < 2 + kVaTileRows && !rout[r];
+            const long grow = live ? (long)b * p.T + rpos[r] : 0;
             float* frow = p.feat + grow * 4 * DIM + (q == 2 ? 3 : 1 + q) * DIM + i;
-            if (i == 0) p.preds[q][grow] = pr[r];
+            if (live && i == 0) p.preds[q][grow] = pr[r];
             if (q == 2) {
 #pragma unroll
-                for (int nt = 0; nt < ND; ++nt) frow[32 * nt] = rz[r] ? 0.0f : c[nt][r];
-                if (i == 0) {
+                for (int nt = 0; nt < ND; ++nt)
+                    if (live) frow[32 * nt] = rz[r] ? 0.0f : c[nt][r];
+                if (live && i == 0) {
                     float d = p.dur_t ? (float)p.dur_t[grow] : rintf(pr[r]);   // torch.round: half to even
                     if (p.mask) {                                              // networks.py:381-382
                         if (rz[r]) d = 0.0f;
@@ -209,16 +242,16 @@ __global__ __launch_bounds__(64) void enc_fuse_va_kernel(const FuseVaP p) {
                     p.dur[grow] = (int)d;
                 }
             } else {
-                const float* tv = q == 0 ? p.pitch_t : p.energy_t;
-                const int idx = bucketize_left(tv ? tv[grow] : pr[r], w.bins, DIM - 1);
 #pragma unroll
-                for (int nt = 0; nt < ND; ++nt) frow[32 * nt] = rz[r] ? 0.0f : w.emb[idx * DIM + 32 * nt + i];
-                if (i == 0) {
+                for (int nt = 0; nt < ND; ++nt)
+                    if (live) frow[32 * nt] = rz[r] ? 0.0f : w.emb[bidx[r] * DIM + 32 * nt + i];
+                if (live && i == 0) {
                     int* ip = q == 0 ? p.pitch_idx : p.energy_idx;
-                    if (ip) ip[grow] = idx;
+                    if (ip) ip[grow] = bidx[r];
                 }
             }
         }
+        ESMI_CT();   // outputs done
     }
 }
 

@@ -35,20 +35,21 @@ __global__ __launch_bounds__(64) void enc_merge_qkv_kernel(const EncMergeP p) {
     // ---- dense k-tap conv (stride s, zero padding)
     f32x16 a1[NCI];
     zero_tiles<NCI>(a1);
-    for (int j = 0; j < p.k; ++j) {
+    const float* taps[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // merge kernels are 1, 3 or 5 wide
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
         const int ti = t_out * p.stride + j - p.pad;
-        const float* arow = nullptr;
-        if (t_out < p.n_out && ti >= 0 && ti < p.n_in) {
+        if (j < p.k && t_out < p.n_out && ti >= 0 && ti < p.n_in) {
             if (p.ids) {
                 int id = p.ids[b * p.n_in + ti];
                 if (id < 0 || id >= p.vocab) id = 0;   // the reference raises IndexError; stay in bounds
-                arow = p.table + (long)id * CIN + 4 * h2;
+                taps[j] = p.table + (long)id * CIN + 4 * h2;
             } else {
-                arow = p.x_in + ((long)b * p.n_in + ti) * CIN + 4 * h2;
+                taps[j] = p.x_in + ((long)b * p.n_in + ti) * CIN + 4 * h2;
             }
         }
-        wave_gemm<NCI>(a1, arow, CIN, p.merge_w + (long)j * CIN * CIN, CIN, 0, 0, CIN, lane);
     }
+    wave_gemm_taps<NCI, 5>(a1, taps, p.k, CIN, p.merge_w, (long)CIN * CIN, CIN, 0, 0, CIN, lane);
     tile_store<NCI>(buf, LD, 0, a1, lane);
     __syncthreads();
     // ---- 1x1 conv -> x

@@ -141,6 +141,12 @@ EncWs enc_ws(const esmi_encoder_block_shape* s) {
 
 }  // namespace
 
+#ifdef ESMI_CHAIN_TRACE
+__device__ long long* g_chain_trace_dev = nullptr;
+extern "C" void esmi_dev_set_chain_trace(long long* ptr) {
+    hipMemcpyToSymbol(HIP_SYMBOL(g_chain_trace_dev), &ptr, sizeof(ptr));
+}
+#endif
 #ifdef ESMI_DEC_TRACE
 long long* g_esmi_trace = nullptr;
 extern "C" void esmi_dev_set_trace(long long* ptr) { g_esmi_trace = ptr; }

@@ -55,6 +55,14 @@ __device__ __forceinline__ int shfl_i(int v, int src) {
 #endif
 }
 
+__device__ __forceinline__ unsigned long long ballot64(bool pred) {
+#ifdef ESMI_WAVESIM
+    return wavesim::ballot(pred);
+#else
+    return __ballot(pred);
+#endif
+}
+
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }
 __device__ __forceinline__ int wave_id() { return (int)(threadIdx.x >> 6); }
 
@@ -122,6 +130,30 @@ __device__ __forceinline__ void layernorm_tile(f32x16 (&v)[NT], const float* __r
         gg[nt] = g[32 * nt + (lane & 31)];
         bb[nt] = b[32 * nt + (lane & 31)];
     }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        float s = 0.0f;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) s += v[nt][r];
+        const float mean = row_sum32(s) * inv_c;
+        float q = 0.0f;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const float d = v[nt][r] - mean;
+            q = fmaf(d, d, q);
+        }
+        const float var = row_sum32(q) * inv_c;
+        const float rstd = 1.0f / sqrtf(var + eps);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) v[nt][r] = fmaf((v[nt][r] - mean) * rstd, gg[nt], bb[nt]);
+    }
+}
+
+// same, gain / bias already in registers (gg[nt], bb[nt] = values of column 32*nt + (lane&31))
+template <int NT>
+__device__ __forceinline__ void layernorm_tile_regs(f32x16 (&v)[NT], const float (&gg)[NT], const float (&bb)[NT],
+                                                    float eps = 1e-5f) {
+    const float inv_c = 1.0f / (float)(32 * NT);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         float s = 0.0f;

@@ -130,7 +130,7 @@ __host__ __device__ constexpr int dec_lds_floats(int kd) {
 // 4-wave build needs 256 VGPRs + 212 spilled and is slower (700 vs 560 us); kept selectable for the next round.
 // (Also tried and dropped in round 1: two windows per workgroup in explicit ping-pong -- correct, 330-450 spills.)
 template <int DX2, int KD, int NW>
-__global__ __launch_bounds__(64 * NW, 2) void mel_decoder_kernel(const MelDecP p) {
+__global__ __launch_bounds__(64 * NW, (DX2 <= 128 && NW == 8 ? ESMI_DEC_WPS : 2)) void mel_decoder_kernel(const MelDecP p) {
     constexpr int kDecThreads = 64 * NW;    // shadows the namespace constant inside this kernel
     constexpr int MH = NW / 4;              // row halves (1 or 2)
     constexpr int MT = 4 / MH;              // 32-row MFMA tiles per wave (4 or 2)

@@ -1,0 +1,22 @@
+#!/usr/bin/env python3
+"""Development tool: shader-clock phase stamps of the chain kernels (needs a -DESMI_CHAIN_TRACE build)."""
+import ctypes as C, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np, torch
+from efficientspeech_amd import CONFIGS, _lib, build_phoneme2mel, load_numpy_state_dict
+from efficientspeech_amd.synth import synth_state_dict, synth_phonemes
+lib = C.CDLL(os.path.abspath(sys.argv[1])); _lib._LIB = _lib.bind(lib)
+cfg = CONFIGS["tiny"]; B, T = 256, 128
+net = build_phoneme2mel(cfg); load_numpy_state_dict(net, synth_state_dict(cfg)); net = net.cuda()
+ids, mask = synth_phonemes(B, T, 1)
+x = {"phoneme": torch.from_numpy(ids).cuda(), "phoneme_mask": torch.from_numpy(mask).cuda(),
+     "duration_forced": torch.full((B, T), 6, dtype=torch.int32, device="cuda"), "max_mel_len": 768}
+tr = torch.zeros((4, 64), dtype=torch.int64, device="cuda")
+lib.esmi_dev_set_chain_trace.argtypes = [C.c_void_p]
+for _ in range(3): net(x)
+lib.esmi_dev_set_chain_trace(tr.data_ptr()); net(x); torch.cuda.synchronize()
+t = tr.cpu().numpy()
+for slot, name in ((0, "E2 blk0 (NC=1)"), (1, "E2 blk1 (NC=2)"), (2, "E3 fuse+VA")):
+    v = t[slot]; n = int((v != 0).sum())
+    print(name, "total", v[n - 1] - v[0], "deltas", np.diff(v[:n]).tolist())

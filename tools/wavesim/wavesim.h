@@ -120,6 +120,13 @@ static inline int shfl_i(int v, int src) {
     const uint32_t* t = wave_exchange(&w, 1);
     return (int)t[src & 63];
 }
+static inline unsigned long long ballot(bool pred) {
+    uint32_t w = pred ? 1u : 0u;
+    const uint32_t* t = wave_exchange(&w, 1);
+    unsigned long long m = 0;
+    for (int l = 0; l < 64; ++l) m |= (unsigned long long)(t[l] & 1u) << l;
+    return m;
+}
 static inline int shfl_up_i(int v, int delta) {   // lanes < delta keep their own value
     uint32_t w = (uint32_t)v;
     const uint32_t* t = wave_exchange(&w, 1);
