@@ -41,6 +41,9 @@ def parse():
     ap.add_argument("--dur", type=int, default=6, help="injected frames per phoneme (D-const)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true", help="skip the mel all-gather (N>1 debugging)")
+    ap.add_argument("--graph", action="store_true",
+                    help="replay the forward as two hipGraphs per step instead of eager launches (measured 2.5 %% slower "
+                         "on an idle host: the step is GPU-bound; useful when the host is slow)")
     return ap.parse_args()
 
 
@@ -64,6 +67,22 @@ def cpu_baseline(cfg, sd, T, dur):
     return {"value": frames / dt, "unit": "mel-frames/s", "cores": cores, "kind": "port",
             "sample": f"oracle/es_oracle.c (fp32 accumulate, OpenMP {cores} threads), {cfg.name} ES full forward, "
                       f"B={B} T={T} D-const {dur}: {frames} frames in {dt:.2f} s"}
+
+
+def pmc_traffic(config, B, T, dur):
+    """HBM bytes per mel_decoder launch from the committed rocprofv3 PMC passes (profiles/*pmc_counters.json:
+    FETCH_SIZE and WRITE_SIZE collected in separate passes, read side doubled per the gfx950 note in
+    MI355X_MICROARCH.md).  Only valid for the workload the counters were collected on; otherwise null."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_counters.json")), reverse=True):
+        try:
+            d = json.load(open(path))
+        except Exception:
+            continue
+        if d.get("workload", "").startswith(f"{config} ES B={B} T={T} D-const {dur} "):
+            m = d["mel_decoder"]
+            return m["hbm_traffic_bytes_corrected"], os.path.basename(path), m.get("mfma_pipe_utilisation")
+    return None, None, None
 
 
 def main():
@@ -92,7 +111,7 @@ def main():
     ids, mask = synth_phonemes(B, T, 1234 + rank)
     x = {"phoneme": torch.from_numpy(ids).to(dev), "phoneme_mask": torch.from_numpy(mask).to(dev),
          "duration_forced": torch.full((B, T), a.dur, dtype=torch.int32, device=dev), "max_mel_len": L}
-    pipe = ShardedMelPipeline(net, world_size=world, gather=(world > 1 and not a.no_gather))
+    pipe = ShardedMelPipeline(net, world_size=world, gather=(world > 1 and not a.no_gather), use_graph=a.graph)
 
     def sync_all():
         torch.cuda.synchronize(dev)
@@ -105,6 +124,7 @@ def main():
             pipe.step(x)
         pipe.flush()
         net.decoder.timing = []
+        pipe.dec_events = [] if a.graph else None
         sync_all()
         t0 = time.perf_counter()
         for _ in range(a.steps):
@@ -112,7 +132,7 @@ def main():
         pipe.flush()
         sync_all()
         dt = time.perf_counter() - t0
-    ev = net.decoder.timing
+    ev = pipe.dec_events if pipe.dec_events else net.decoder.timing
     net.decoder.timing = None
     dec_ms = float(np.mean([s.elapsed_time(e) for s, e in ev])) if ev else float("nan")
     if world > 1:
@@ -123,6 +143,7 @@ def main():
     value = frames_per_step * a.steps / dt
     flops, nbytes = DECODER_WORK[a.config]
     ach_tf = flops * B * L / (dec_ms * 1e-3) / 1e12
+    traffic, traffic_src, mfma_util = pmc_traffic(a.config, B, T, a.dur)
     out = {
         "metric": "mel-frames/sec (whole node), full Phoneme2Mel forward", "value": value, "unit": "mel-frames/s",
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
@@ -132,9 +153,13 @@ def main():
                                f"synthetic phoneme batch B={B} T={T} per GPU, injected durations D-const {a.dur} "
                                f"(L={L}), eval path, mel all-gather over RCCL when N>1",
                    "global_batch": B * world, "phonemes": T, "frames_per_step": frames_per_step,
-                   "parallelism": f"batch-shard x{world}"},
+                   "parallelism": f"batch-shard x{world}",
+                   "launch": "hipGraph replay (encoder graph + decoder graph per step)" if a.graph else "eager"},
         "roofline": {"bound": "mfma", "kernel": "mel_decoder_kernel", "achieved": ach_tf, "peak": FP32_PEAK_TFLOPS,
-                     "unit": "TFLOP/s", "frac": ach_tf / FP32_PEAK_TFLOPS, "traffic": None,
+                     "unit": "TFLOP/s", "frac": ach_tf / FP32_PEAK_TFLOPS, "traffic": traffic,
+                     "traffic_unit": "HBM bytes per launch (rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE)",
+                     "traffic_source": traffic_src, "mfma_pipe_utilisation_pmc": mfma_util,
+                     "algorithmic_bytes_per_launch": nbytes * B * L,
                      "kernel_ms": dec_ms, "algorithmic_flops_per_frame": flops, "algorithmic_bytes_per_frame": nbytes,
                      "hbm_frac": nbytes * B * L / (dec_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                      "note": "exact-fp32 MFMA bound (228 FLOP/B >> 20 FLOP/B machine balance); hbm_frac reported "

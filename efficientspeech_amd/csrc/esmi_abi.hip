@@ -537,9 +537,13 @@ int esmi_mel_decoder_f32(const float* blob, const esmi_decoder_shape* s, const f
 #define ESMI_DEC_CASE(DX2, KD, NW)                                                                                 \
     {                                                                                                              \
         const int lds = dec_lds_floats<DX2>(KD) * (int)sizeof(float);                                              \
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mel_decoder_kernel<DX2, KD, NW>),         \
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds);                      \
-        if (e != hipSuccess) return (int)e;                                                                        \
+        static bool attr_set = false; /* once per instantiation: keeps the call out of hipGraph captures */       \
+        if (!attr_set) {                                                                                           \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mel_decoder_kernel<DX2, KD, NW>),     \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, lds);                  \
+            if (e != hipSuccess) return (int)e;                                                                    \
+            attr_set = true;                                                                                       \
+        }                                                                                                          \
         ESMI_LAUNCH((mel_decoder_kernel<DX2, KD, NW>), grid, dim3(64 * NW), lds, st, p);                           \
     }
     if (s->dx2 == 128 && s->kernel == 5) ESMI_DEC_CASE(128, 5, ESMI_DEC_NW128)

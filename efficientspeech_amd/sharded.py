@@ -66,23 +66,95 @@ def sharded_forward(net, x_full, group=None):
     return tuple(outs)
 
 
+class GraphedForward:
+    """The inference forward of one fixed shape as two hipGraphs (encoder side, mel decoder) so that a step costs
+    two graph launches instead of ~10 kernel launches + the Python between them.  Needs the `max_mel_len` bound
+    (static output size, no host sync).  Between the graphs the caller may MAX-reduce `lmax` across ranks.
+    Inputs are copied into static buffers; the mel output alternates between `nbuf` buffers so that a result can
+    still be in flight (all-gather on a side stream) while the next step computes."""
+
+    def __init__(self, net, x, nbuf=3, warmup=3):
+        assert "max_mel_len" in x, "graph replay needs a static output length (x['max_mel_len'])"
+        self.net = net
+        self.L = int(x["max_mel_len"])
+        self.x = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in x.items()}
+        B = self.x["phoneme"].shape[0]
+        self.apply_mask = ("phoneme_mask" in self.x) and B > 1
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side), torch.no_grad():       # warm-up off the capture: weight packing, attributes
+            for _ in range(warmup):
+                enc = net.encoder._encode(self.x, train=False)
+                net.decoder._fused(enc["feat"], enc["cum"], enc["mel_len"], enc["lmax"], self.L, self.apply_mask, self.L)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.g_enc = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.g_enc), torch.no_grad():
+            self.enc = net.encoder._encode(self.x, train=False)
+        self.g_dec, self.mels = [], []
+        for _ in range(nbuf):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g), torch.no_grad():
+                mel = net.decoder._fused(self.enc["feat"], self.enc["cum"], self.enc["mel_len"], self.enc["lmax"],
+                                         self.L, self.apply_mask, self.L)
+            self.g_dec.append(g)
+            self.mels.append(mel)
+        self.i = 0
+
+    def load(self, x):
+        for k, v in x.items():
+            if torch.is_tensor(v) and v.data_ptr() != self.x[k].data_ptr():
+                self.x[k].copy_(v, non_blocking=True)
+
+    def encode(self):
+        self.g_enc.replay()
+        return self.enc
+
+    def decode(self):
+        j = self.i % len(self.g_dec)
+        self.i += 1
+        self.g_dec[j].replay()
+        return self.mels[j]
+
+
 class ShardedMelPipeline:
     """Steady-state serving loop: step(x) computes this rank's shard; its all-gather runs on a side
-    stream while the next step computes.  `results()` yields gathered batches in order."""
+    stream while the next step computes.  With use_graph (and a `max_mel_len` bound) the compute is two
+    hipGraph replays per step."""
 
-    def __init__(self, net, world_size=1, gather=True, group=None, depth=2):
+    def __init__(self, net, world_size=1, gather=True, group=None, depth=2, use_graph=False):
         self.net, self.world, self.group = net, world_size, group
         self.gather = gather and world_size > 1
         self.depth = depth
         self.comm = None
         self.inflight = []       # (done_event, gathered mel, gathered mel_len)
         self.last = None
+        self.use_graph = use_graph
+        self.graphed = None
+        self.dec_events = None   # bench.py: list collecting (start, end) events around the decoder launch
 
-    def step(self, x):
+    def _compute(self, x):
+        """-> (mel, mel_len) of this rank's shard; global padded length MAX-reduced when world > 1."""
+        if self.use_graph and "max_mel_len" in x:
+            if self.graphed is None:
+                self.graphed = GraphedForward(self.net, x, nbuf=self.depth + 1)
+            g = self.graphed
+            g.load(x)
+            enc = g.encode()
+            if self.world > 1:
+                dist.all_reduce(enc["lmax"], op=dist.ReduceOp.MAX, group=self.group)
+            if self.dec_events is not None:
+                ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                ev[0].record()
+                mel = g.decode()
+                ev[1].record()
+                self.dec_events.append(ev)
+            else:
+                mel = g.decode()
+            return mel, enc["mel_len"]
         if self.world == 1:
             mel, mel_len, _ = self.net(x)
-            self.last = (mel, mel_len)
-            return self.last
+            return mel, mel_len
         # global padded length: 4-byte MAX all-reduce on the compute stream (see sharded_forward)
         enc = self.net.encoder._encode(x, train=False)
         dist.all_reduce(enc["lmax"], op=dist.ReduceOp.MAX, group=self.group)
@@ -91,7 +163,10 @@ class ShardedMelPipeline:
         else:
             L_out, lmax_dev = int(enc["lmax"].item()), None
         mel = self.net.decoder._fused(enc["feat"], enc["cum"], enc["mel_len"], lmax_dev, L_out, True, L_out)
-        mel_len = enc["mel_len"]
+        return mel, enc["mel_len"]
+
+    def step(self, x):
+        mel, mel_len = self._compute(x)
         if not self.gather:
             self.last = (mel, mel_len)
             return self.last
@@ -101,8 +176,9 @@ class ShardedMelPipeline:
             self.inflight.pop(0)[0].synchronize()
         ready = torch.cuda.Event()
         ready.record()                                      # compute stream: mel is complete here
-        mel.record_stream(self.comm)
-        mel_len.record_stream(self.comm)
+        if self.graphed is None:                            # graph buffers are static: nothing to protect
+            mel.record_stream(self.comm)
+            mel_len.record_stream(self.comm)
         with torch.cuda.stream(self.comm):
             self.comm.wait_event(ready)
             full = torch.empty((mel.shape[0] * self.world,) + tuple(mel.shape[1:]), dtype=mel.dtype, device=mel.device)

@@ -60,18 +60,30 @@ int eso_acc_bytes(void) { return (int)sizeof(acc_t); }
 
 /* ---------------------------------------------------------------- primitives */
 
-/* nn.Linear: y[r][n] = sum_k x[r][k] W[n][k] + b[n]   (torch F.linear; W is (N,K)) */
+/* nn.Linear: y[r][n] = sum_k x[r][k] W[n][k] + b[n]   (torch F.linear; W is (N,K)).
+ * W is transposed once per call so that the inner loop runs over contiguous output channels (vectorises
+ * without horizontal reductions); the accumulation order over k is the natural one. */
 static void linear(const float* x, long rows, int K, const float* Wt, const float* b, int N, float* y) {
-#pragma omp parallel for schedule(static)
-    for (long r = 0; r < rows; ++r) {
-        const float* xr = x + r * K;
-        for (int n = 0; n < N; ++n) {
-            const float* wn = Wt + (long)n * K;
-            acc_t s = b ? (acc_t)b[n] : (acc_t)0;
-            for (int k = 0; k < K; ++k) s += (acc_t)xr[k] * (acc_t)wn[k];
-            y[r * N + n] = (float)s;
+    acc_t* wT = (acc_t*)malloc(sizeof(acc_t) * (size_t)K * N);
+    for (int n = 0; n < N; ++n)
+        for (int k = 0; k < K; ++k) wT[(size_t)k * N + n] = (acc_t)Wt[(size_t)n * K + k];
+#pragma omp parallel
+    {
+        acc_t* t = (acc_t*)malloc(sizeof(acc_t) * (size_t)N);
+#pragma omp for schedule(static)
+        for (long r = 0; r < rows; ++r) {
+            const float* xr = x + r * K;
+            for (int n = 0; n < N; ++n) t[n] = b ? (acc_t)b[n] : (acc_t)0;
+            for (int k = 0; k < K; ++k) {
+                const acc_t xk = (acc_t)xr[k];
+                const acc_t* wk = wT + (size_t)k * N;
+                for (int n = 0; n < N; ++n) t[n] += xk * wk[n];
+            }
+            for (int n = 0; n < N; ++n) y[r * N + n] = (float)t[n];
         }
+        free(t);
     }
+    free(wT);
 }
 
 /* nn.Conv1d on channels-last data: cross-correlation, zero padding, weight (Cout,Cin,k).
@@ -137,6 +149,7 @@ static void layernorm(float* x, long rows, int C, const float* g, const float* b
 }
 
 static void add_inplace(float* y, const float* x, long n) {
+#pragma omp parallel for schedule(static)
     for (long i = 0; i < n; ++i) y[i] = y[i] + x[i];
 }
 
@@ -209,6 +222,7 @@ static void mixffn(const float* x, int B, int N, int C, int e, const float* w1, 
     float* t2 = (float*)malloc(sizeof(float) * (size_t)B * N * E);
     linear(x, (long)B * N, C, w1, b1, E, t1);
     conv1d_cl(t1, B, N, E, wc, bc, E, 3, 1, 1, t2);
+#pragma omp parallel for schedule(static)
     for (long i = 0; i < (long)B * N * E; ++i) t2[i] = gelu_erf(t2[i]);
     linear(t2, (long)B * N, E, w2, b2, C, y);
     free(t1);
@@ -550,6 +564,7 @@ int eso_mel_decoder(const eso_cfg* c, const eso_weights* w, int B, int L, const 
     float* x = (float*)malloc(sizeof(float) * (size_t)rows * dx2);
     float* t = (float*)malloc(sizeof(float) * (size_t)rows * dx2);
     linear(features, rows, d4, pw, pb, dx2, skip);
+#pragma omp parallel for schedule(static)
     for (long i = 0; i < rows * dx2; ++i) skip[i] = (float)tanh((double)skip[i]);
     layernorm(skip, rows, dx2, pg, pbb);
     for (int b = 0; b < c->n_blocks && !err; ++b) {
@@ -564,6 +579,7 @@ int eso_mel_decoder(const eso_cfg* c, const eso_weights* w, int B, int L, const 
             if (err) break;
             dwconv1d_cl(x, B, L, dx2, dw, db, k, t);
             linear(t, rows, dx2, qw, qb, dx2, x);
+#pragma omp parallel for schedule(static)
             for (long i = 0; i < rows * dx2; ++i) x[i] = (float)tanh((double)x[i]);
             layernorm(x, rows, dx2, lg, lb);
         }
