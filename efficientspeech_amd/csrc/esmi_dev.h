@@ -64,26 +64,52 @@ __device__ __forceinline__ unsigned long long ballot64(bool pred) {
 }
 
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }
+__device__ __forceinline__ int lane_id_raw() { return (int)(threadIdx.x & 63u); }
 __device__ __forceinline__ int wave_id() { return (int)(threadIdx.x >> 6); }
 
 // row of accumulator register r inside a 32-row MFMA tile
 __device__ __forceinline__ int tile_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
 
-// sum over the 32 lanes that hold one tile row (lanes sharing lane>>5)
+// ---- cross-lane moves inside a 32-lane half wave without an LDS round trip: DPP (VALU rate) for the four
+// in-row steps and ds_swizzle SWAPX16 for the row pair.  A ds_bpermute butterfly (what __shfl_xor lowers to)
+// costs ~100+ cycles of latency per step; LayerNorm / softmax reductions run 10 steps per tile row.
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {   // CTRL: 0xB1 quad xor1, 0x4E quad xor2, 0x141 half mirror, 0x140 mirror
+#ifdef ESMI_WAVESIM
+    const int l = lane_id_raw();
+    int src = l;
+    if (CTRL == 0xB1) src = l ^ 1;
+    else if (CTRL == 0x4E) src = l ^ 2;
+    else if (CTRL == 0x141) src = (l & ~7) | (7 - (l & 7));
+    else if (CTRL == 0x140) src = (l & ~15) | (15 - (l & 15));
+    return wavesim::shfl(v, src);
+#else
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+#endif
+}
+__device__ __forceinline__ float swz_xor16_f(float v) {   // lane l <- lane l^16 (within each 32-lane half)
+#ifdef ESMI_WAVESIM
+    return wavesim::shfl(v, lane_id_raw() ^ 16);
+#else
+    return __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), 0x401F));
+#endif
+}
+
+// sum over the 32 lanes that hold one tile row (lanes sharing lane>>5); every lane ends with the same bits
 __device__ __forceinline__ float row_sum32(float v) {
-    v += shfl_xor_f(v, 1);
-    v += shfl_xor_f(v, 2);
-    v += shfl_xor_f(v, 4);
-    v += shfl_xor_f(v, 8);
-    v += shfl_xor_f(v, 16);
+    v += dpp_f<0xB1>(v);
+    v += dpp_f<0x4E>(v);
+    v += dpp_f<0x141>(v);
+    v += dpp_f<0x140>(v);
+    v += swz_xor16_f(v);
     return v;
 }
 __device__ __forceinline__ float row_max32(float v) {
-    v = fmaxf(v, shfl_xor_f(v, 1));
-    v = fmaxf(v, shfl_xor_f(v, 2));
-    v = fmaxf(v, shfl_xor_f(v, 4));
-    v = fmaxf(v, shfl_xor_f(v, 8));
-    v = fmaxf(v, shfl_xor_f(v, 16));
+    v = fmaxf(v, dpp_f<0xB1>(v));
+    v = fmaxf(v, dpp_f<0x4E>(v));
+    v = fmaxf(v, dpp_f<0x141>(v));
+    v = fmaxf(v, dpp_f<0x140>(v));
+    v = fmaxf(v, swz_xor16_f(v));
     return v;
 }
 
