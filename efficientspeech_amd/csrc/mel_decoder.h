@@ -252,7 +252,7 @@ __global__ __launch_bounds__(64 * NW, (DX2 <= 128 && NW == 8 ? ESMI_DEC_WPS : 2)
 
     // weight-stationary GEMM pieces.  bf = this wave's weight slice for KSUB k-steps (64 VGPRs); it is
     // (re)loaded right after the previous K loop so the L2 latency hides under the non-MFMA phases.
-    constexpr int KSUB = ESMI_DEC_KSUB;
+    constexpr int KSUB = ESMI_DEC_KSUB;   // k-steps of weights in registers at a time
     f32x4 bf[NTW][KSUB];
     auto load_b = [&](const f32x4* wsl, int k0) __attribute__((always_inline)) {
 #pragma unroll
