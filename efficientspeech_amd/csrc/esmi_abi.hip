@@ -536,7 +536,7 @@ int esmi_mel_decoder_f32(const float* blob, const esmi_decoder_shape* s, const f
     hipStream_t st = S(stream);
 #define ESMI_DEC_CASE(DX2, KD, NW)                                                                                 \
     {                                                                                                              \
-        const int lds = dec_lds_floats<DX2>(KD) * (int)sizeof(float);                                              \
+        const int lds = dec_lds_floats<DX2>(KD) * (int)sizeof(float) ;                                             \
         static bool attr_set = false; /* once per instantiation: keeps the call out of hipGraph captures */       \
         if (!attr_set) {                                                                                           \
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mel_decoder_kernel<DX2, KD, NW>),     \

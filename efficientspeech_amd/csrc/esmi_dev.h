@@ -199,6 +199,17 @@ __device__ __forceinline__ void layernorm_tile_regs(f32x16 (&v)[NT], const float
     }
 }
 
+// An offset the optimiser must treat as freshly computed here.  Used on the lane-dependent part of LDS addresses
+// inside loops: without it LLVM's LICM hoists every `base + constant` address of the loop body into its own
+// loop-invariant VGPR (measured: ~100 address registers in the mel decoder, 80+ of them spilled at a 128-VGPR
+// budget), and instruction selection can then no longer fold the constants into the 16-bit DS offset field.
+__device__ __forceinline__ int opaque_i(int v) {
+#ifndef ESMI_WAVESIM
+    asm volatile("" : "+v"(v));
+#endif
+    return v;
+}
+
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 __device__ __forceinline__ f32x4 zero4() { f32x4 z = {0.f, 0.f, 0.f, 0.f}; return z; }
 __device__ __forceinline__ f32x16 zero16() {

@@ -41,8 +41,13 @@
 #ifndef ESMI_DEC_WPS
 #define ESMI_DEC_WPS 2   // __launch_bounds__ waves/SIMD: 2 = one 512-thread workgroup per CU, up to 256 VGPRs (a 128-VGPR build spills)
 #endif
+#ifndef ESMI_DEC_LOWREG
+#define ESMI_DEC_LOWREG 0   // 1: no cross-phase prefetch (weights, taps, params fetched where used): fewer live registers.
+                            // With WPS=4 this gives two workgroups per CU (61 spills): measured 552 vs 546 us -- the
+                            // co-resident workgroup's K loop starves the other's LayerNorm phase (3k -> 11-19k cycles).
+#endif
 #ifndef ESMI_DEC_KSUB
-#define ESMI_DEC_KSUB 8  // k-steps (of 8 channels) of the weight slice held in registers at a time
+#define ESMI_DEC_KSUB 16 // k-steps (of 8 channels) of the weight slice held in registers at a time (16 = all of K = 128)
 #endif
 
 namespace esmi {
@@ -135,6 +140,7 @@ __global__ __launch_bounds__(64 * NW, (DX2 <= 128 && NW == 8 ? ESMI_DEC_WPS : 2)
     constexpr int MH = NW / 4;              // row halves (1 or 2)
     constexpr int MT = 4 / MH;              // 32-row MFMA tiles per wave (4 or 2)
     constexpr int TPR = kDecThreads / kDecRows;   // LayerNorm threads per row (2 or 4)
+    constexpr bool LOWREG = ESMI_DEC_LOWREG && DX2 <= 128;
     constexpr int NTW = DX2 / 128;          // 32-column MFMA tiles per wave
     constexpr int WCOLS = 32 * NTW;         // columns per wave (4 column slices per workgroup)
     constexpr int KCH = DX2 / 128;          // 128-channel K chunks of a dx2-wide contraction
@@ -188,15 +194,22 @@ __global__ __launch_bounds__(64 * NW, (DX2 <= 128 && NW == 8 ? ESMI_DEC_WPS : 2)
     // "layer" n_layers is the mel Linear (group B = its bias only).
     f32x4 pstA = zero4(), pstA2 = zero4(), pstB = zero4();
     auto issue_A = [&](int l) __attribute__((always_inline)) {
+        if (LOWREG) return;
         if (l < n_layers && tid < NA4) pstA = blob4[((p.lay.layer0 + (long)l * p.lay.layer_stride) >> 2) + tid];
         if (l < n_layers && tid + kDecThreads < NA4)
             pstA2 = blob4[((p.lay.layer0 + (long)l * p.lay.layer_stride) >> 2) + tid + kDecThreads];
     };
     auto commit_A = [&](int l) __attribute__((always_inline)) {
+        if (LOWREG) {
+            if (l < n_layers)
+                for (int e = tid; e < NA4; e += kDecThreads)
+                    reinterpret_cast<f32x4*>(pbuf)[e] = blob4[((p.lay.layer0 + (long)l * p.lay.layer_stride) >> 2) + e];
+            return;
+        }
         if (l < n_layers && tid < NA4) reinterpret_cast<f32x4*>(pbuf)[tid] = pstA;
         if (l < n_layers && tid + kDecThreads < NA4) reinterpret_cast<f32x4*>(pbuf)[tid + kDecThreads] = pstA2;
     };
-    auto issue_B = [&](int l) __attribute__((always_inline)) {
+    auto issue_B_now = [&](int l) __attribute__((always_inline)) {
         if (l < n_layers) {
             if (tid < NB4) pstB = blob4[((p.lay.layer0 + (long)l * p.lay.layer_stride + p.lay.l_pwb) >> 2) + tid];
             else if (((l + 1) % p.block_depth) == 0 && tid < NB4 + DX2 / 2)   // block end: skip LN params
@@ -205,7 +218,11 @@ __global__ __launch_bounds__(64 * NW, (DX2 <= 128 && NW == 8 ? ESMI_DEC_WPS : 2)
             pstB = blob4[(p.lay.mel_b >> 2) + tid];
         }
     };
+    auto issue_B = [&](int l) __attribute__((always_inline)) {
+        if (!LOWREG) issue_B_now(l);
+    };
     auto commit_B = [&](int l) __attribute__((always_inline)) {
+        if (LOWREG) issue_B_now(l);
         f32x4* d4 = reinterpret_cast<f32x4*>(pbuf + P_PWB);
         if (l < n_layers) {
             if (tid < NB4 || (((l + 1) % p.block_depth) == 0 && tid < NB4 + DX2 / 2)) d4[tid] = pstB;
@@ -240,9 +257,7 @@ __global__ __launch_bounds__(64 * NW, (DX2 <= 128 && NW == 8 ? ESMI_DEC_WPS : 2)
 
     // A-fragment base of this wave's rows; LayerNorm ownership: TPR threads per row, a row's threads 64/TPR lanes apart
     constexpr int RPW = 64 / TPR;           // rows per wave in the LayerNorm pass (16 or 32)
-    const float* a_base = xs + (kDecPadRows + 32 * MT * mh + i) * LDSROW + 4 * h;
     const int ln_row = RPW * w + (lane & (RPW - 1)), ln_q = lane / RPW;
-    float* ln_ptr = xs + (kDecPadRows + ln_row) * LDSROW + 4 * ln_q;
     const bool ln_inside = src[ln_row] != -1;
 
     f32x16 acc[MT][NTW];
@@ -252,7 +267,7 @@ __global__ __launch_bounds__(64 * NW, (DX2 <= 128 && NW == 8 ? ESMI_DEC_WPS : 2)
 
     // weight-stationary GEMM pieces.  bf = this wave's weight slice for KSUB k-steps (64 VGPRs); it is
     // (re)loaded right after the previous K loop so the L2 latency hides under the non-MFMA phases.
-    constexpr int KSUB = ESMI_DEC_KSUB;   // k-steps of weights in registers at a time
+    constexpr int KSUB = NTW == 1 ? ESMI_DEC_KSUB : 8;   // k-steps of weights in registers at a time (64 VGPRs)
     f32x4 bf[NTW][KSUB];
     auto load_b = [&](const f32x4* wsl, int k0) __attribute__((always_inline)) {
 #pragma unroll
@@ -262,6 +277,7 @@ __global__ __launch_bounds__(64 * NW, (DX2 <= 128 && NW == 8 ? ESMI_DEC_WPS : 2)
         }
     };
     auto mma_sub = [&](int a_col0, int k0) __attribute__((always_inline)) {
+        const float* a_base = xs + opaque_i((kDecPadRows + 32 * MT * mh + i) * LDSROW + 4 * h);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
@@ -283,11 +299,11 @@ __global__ __launch_bounds__(64 * NW, (DX2 <= 128 && NW == 8 ? ESMI_DEC_WPS : 2)
         for (int c = 0; c < KCH; ++c) {
 #pragma unroll
             for (int k0 = 0; k0 < 16; k0 += KSUB) {
-                if (c > 0 || k0 > 0) load_b(wslice(off, c), k0);
+                if (LOWREG || c > 0 || k0 > 0) load_b(wslice(off, c), k0);
                 mma_sub(128 * c, k0);
             }
         }
-        if (next) load_b(next, 0);
+        if (next && !LOWREG) load_b(next, 0);
     };
     auto zero_acc = [&]() __attribute__((always_inline)) {
 #pragma unroll
@@ -298,17 +314,18 @@ __global__ __launch_bounds__(64 * NW, (DX2 <= 128 && NW == 8 ? ESMI_DEC_WPS : 2)
     };
     // accumulators (+ bias, tanh) -> tile, in the MFMA C/D layout
     auto store_tanh = [&](const float* bias) __attribute__((always_inline)) {
+        // one base address per column tile; every (mt, r) store is base + a compile-time offset, so the
+        // compiler has no per-store address to hoist out of the layer loop (32 loop-invariant VGPRs otherwise)
 #pragma unroll
         for (int t = 0; t < NTW; ++t) {
             const int col = ns * WCOLS + 32 * t + i;
             const float bc = bias[col];
+            float* base = xs + opaque_i((kDecPadRows + 32 * MT * mh + 4 * h) * LDSROW + col);
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = 32 * MT * mh + 32 * mt + tile_row(r, lane);
-                    xs[(kDecPadRows + row) * LDSROW + col] = ESMI_DEC_TANH(acc[mt][t][r] + bc);
-                }
+                for (int r = 0; r < 16; ++r)
+                    base[(32 * mt + (r & 3) + 8 * (r >> 2)) * LDSROW] = ESMI_DEC_TANH(acc[mt][t][r] + bc);
             }
         }
     };
@@ -334,14 +351,16 @@ __global__ __launch_bounds__(64 * NW, (DX2 <= 128 && NW == 8 ? ESMI_DEC_WPS : 2)
         const float rstd = 1.0f / sqrtf(q * (1.0f / DX2) + 1e-5f);
 #pragma unroll
         for (int k = 0; k < NV; ++k) {
-            const f32x4 gg = *reinterpret_cast<const f32x4*>(g + 4 * TPR * k + 4 * ln_q);
-            const f32x4 bb = *reinterpret_cast<const f32x4*>(be + 4 * TPR * k + 4 * ln_q);
+            const f32x4 gg = *reinterpret_cast<const f32x4*>(g + 4 * TPR * k);
+            const f32x4 bb = *reinterpret_cast<const f32x4*>(be + 4 * TPR * k);
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[k][e] = fmaf((v[k][e] - mean) * rstd, gg[e], bb[e]);
         }
     };
     // LN pass over the tile (in place): x = LN(x) [; x = LN_s(x + skip)] ; outside rows -> 0 ; skip update
-    auto ln_pass = [&](const float* pb, bool block_end, bool set_skip) __attribute__((always_inline)) {
+    auto ln_pass = [&](const float* pb0, bool block_end, bool set_skip) __attribute__((always_inline)) {
+        const float* pb = pb0 + opaque_i(4 * ln_q);           // this thread's column quarter of every param vector
+        float* ln_ptr = xs + opaque_i((kDecPadRows + ln_row) * LDSROW + 4 * ln_q);
         f32x4 v[NV];
 #pragma unroll
         for (int k = 0; k < NV; ++k) v[k] = *reinterpret_cast<const f32x4*>(ln_ptr + 4 * TPR * k);
@@ -367,7 +386,7 @@ __global__ __launch_bounds__(64 * NW, (DX2 <= 128 && NW == 8 ? ESMI_DEC_WPS : 2)
     // ---- proj: Linear(d4, dx2); the gathered input rows are staged through the tile 128 channels at a time
     zero_acc();
     const int nchunks = p.d4 / 128;
-    load_b(wslice(p.lay.proj_w, 0), 0);
+    if (!LOWREG) load_b(wslice(p.lay.proj_w, 0), 0);
     for (int ch = 0; ch < nchunks; ++ch) {
         if (ch > 0) __syncthreads();  // previous chunk fully consumed
         for (int e = tid; e < kDecRows * 32; e += kDecThreads) {
@@ -380,12 +399,12 @@ __global__ __launch_bounds__(64 * NW, (DX2 <= 128 && NW == 8 ? ESMI_DEC_WPS : 2)
         __syncthreads();
 #pragma unroll
         for (int k0 = 0; k0 < 16; k0 += KSUB) {
-            if (ch > 0 || k0 > 0) load_b(wslice(p.lay.proj_w, ch), k0);
+            if (LOWREG || ch > 0 || k0 > 0) load_b(wslice(p.lay.proj_w, ch), k0);
             mma_sub(0, k0);
         }
     }
     // weights of the first conv layer (or of the mel Linear) start flowing while proj's epilogue runs
-    load_b(n_layers > 0 ? wslice(p.lay.layer0 + p.lay.l_pw, 0) : wslice(p.lay.mel_w, 0), 0);
+    if (!LOWREG) load_b(n_layers > 0 ? wslice(p.lay.layer0 + p.lay.l_pw, 0) : wslice(p.lay.mel_w, 0), 0);
     __syncthreads();  // every wave finished reading the staged input
     issue_B(0);
     store_tanh(pbuf + P_PWB);
@@ -402,13 +421,16 @@ __global__ __launch_bounds__(64 * NW, (DX2 <= 128 && NW == 8 ? ESMI_DEC_WPS : 2)
         // 1. depthwise conv in place: window -> registers | barrier | filtered rows -> tile
         {
             f32x4 win[RS + 2 * PAD];
-            float* col = xs + (kDecPadRows + dw_r0 - PAD) * LDSROW + 4 * dw_cg;
+            float* col = xs + opaque_i((kDecPadRows + dw_r0 - PAD) * LDSROW + 4 * dw_cg);
+            const float* pbt = pb + opaque_i(4 * dw_cg);
 #pragma unroll
             for (int r = 0; r < RS + 2 * PAD; ++r) win[r] = *reinterpret_cast<const f32x4*>(col + r * LDSROW);
             f32x4 tap[KD];
+            if (!LOWREG) {
 #pragma unroll
-            for (int j = 0; j < KD; ++j) tap[j] = *reinterpret_cast<const f32x4*>(pb + j * DX2 + 4 * dw_cg);
-            const f32x4 tb = *reinterpret_cast<const f32x4*>(pb + P_DWB + 4 * dw_cg);
+                for (int j = 0; j < KD; ++j) tap[j] = *reinterpret_cast<const f32x4*>(pbt + j * DX2);
+            }
+            const f32x4 tb = *reinterpret_cast<const f32x4*>(pbt + P_DWB);
             ESMI_STAMP();   // 1: window loaded (issued)
             __syncthreads();
             ESMI_STAMP();   // 2: barrier passed
@@ -420,8 +442,9 @@ __global__ __launch_bounds__(64 * NW, (DX2 <= 128 && NW == 8 ? ESMI_DEC_WPS : 2)
 #ifdef ESMI_ABL_NO_DW
                     if (j != PAD) continue;
 #endif
+                    const f32x4 tj = LOWREG ? *reinterpret_cast<const f32x4*>(pbt + j * DX2) : tap[j];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) a[e] = fmaf(win[r + j][e], tap[j][e], a[e]);
+                    for (int e = 0; e < 4; ++e) a[e] = fmaf(win[r + j][e], tj[e], a[e]);
                 }
                 *reinterpret_cast<f32x4*>(col + (r + PAD) * LDSROW) = a;
             }
