@@ -41,6 +41,8 @@ def parse():
     ap.add_argument("--dur", type=int, default=6, help="injected frames per phoneme (D-const)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true", help="skip the mel all-gather (N>1 debugging)")
+    ap.add_argument("--two-stream", action="store_true",
+                    help="software-pipeline consecutive steps: encoder side of step i+1 concurrent with the decoder of step i")
     ap.add_argument("--graph", action="store_true",
                     help="replay the forward as two hipGraphs per step instead of eager launches (measured 2.5 %% slower "
                          "on an idle host: the step is GPU-bound; useful when the host is slow)")
@@ -111,7 +113,7 @@ def main():
     ids, mask = synth_phonemes(B, T, 1234 + rank)
     x = {"phoneme": torch.from_numpy(ids).to(dev), "phoneme_mask": torch.from_numpy(mask).to(dev),
          "duration_forced": torch.full((B, T), a.dur, dtype=torch.int32, device=dev), "max_mel_len": L}
-    pipe = ShardedMelPipeline(net, world_size=world, gather=(world > 1 and not a.no_gather), use_graph=a.graph)
+    pipe = ShardedMelPipeline(net, world_size=world, gather=(world > 1 and not a.no_gather), use_graph=a.graph, two_stream=a.two_stream)
 
     def sync_all():
         torch.cuda.synchronize(dev)
@@ -154,7 +156,7 @@ def main():
                                f"(L={L}), eval path, mel all-gather over RCCL when N>1",
                    "global_batch": B * world, "phonemes": T, "frames_per_step": frames_per_step,
                    "parallelism": f"batch-shard x{world}",
-                   "launch": "hipGraph replay (encoder graph + decoder graph per step)" if a.graph else "eager"},
+                   "launch": ("hipGraph replay (encoder graph + decoder graph per step)" if a.graph else "eager") + (", encoder/decoder on two streams (steps software-pipelined)" if a.two_stream else "")},
         "roofline": {"bound": "mfma", "kernel": "mel_decoder_kernel", "achieved": ach_tf, "peak": FP32_PEAK_TFLOPS,
                      "unit": "TFLOP/s", "frac": ach_tf / FP32_PEAK_TFLOPS, "traffic": traffic,
                      "traffic_unit": "HBM bytes per launch (rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE)",

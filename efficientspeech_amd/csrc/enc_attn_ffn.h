@@ -32,7 +32,7 @@ struct EncAttnFfnP {
 constexpr int kEncTileRows = 30;    // useful rows per 32-row tile (one halo row each side)
 
 template <int NKT, int NC, int E>   // keys <= 32*NKT, C = 32*NC, MixFFN hidden = E*C
-__global__ __launch_bounds__(64) void enc_attn_ffn_kernel(const EncAttnFfnP p) {
+__global__ __launch_bounds__(64, ESMI_CHAIN_WPS) void enc_attn_ffn_kernel(const EncAttnFfnP p) {
     constexpr int NE = NC * E;
     constexpr int C = 32 * NC, EC = 32 * NE;
     constexpr int LD = EC + 4;

@@ -46,7 +46,7 @@ __host__ __device__ inline int fuse_va_lds_floats(int dim, int depth) {
 __device__ __forceinline__ int floor_div(int a, int b) { return a >= 0 ? a / b : -((-a + b - 1) / b); }
 
 template <int ND>   // dim = 32*ND
-__global__ __launch_bounds__(64) void enc_fuse_va_kernel(const FuseVaP p) {
+__global__ __launch_bounds__(64, ESMI_CHAIN_WPS) void enc_fuse_va_kernel(const FuseVaP p) {
     constexpr int DIM = 32 * ND, LDD = DIM + 4;
     ESMI_DYN_LDS(lds);
     const int ldc = p.depth * DIM + 4;

@@ -23,7 +23,7 @@ struct EncMergeP {
 };
 
 template <int NCI, int NC>   // Cin = 32*NCI, C = 32*NC
-__global__ __launch_bounds__(64) void enc_merge_qkv_kernel(const EncMergeP p) {
+__global__ __launch_bounds__(64, ESMI_CHAIN_WPS) void enc_merge_qkv_kernel(const EncMergeP p) {
     constexpr int CIN = 32 * NCI, C = 32 * NC;
     constexpr int LD = (NCI > NC ? CIN : C) + 4;
     ESMI_DYN_LDS(buf);             // [32][LD]

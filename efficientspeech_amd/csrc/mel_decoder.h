@@ -38,16 +38,20 @@
 #ifndef ESMI_DEC_TANH
 #define ESMI_DEC_TANH tanh_fast_f32
 #endif
+// Build knobs of the dx2 = 128 instantiation (measured on MI355X, tiny ES B=256 T=128, decoder time inside bench.py):
+//   WPS=2 KSUB=16 LOWREG=0 : 235 VGPRs, no spill, ONE workgroup per CU ........ 0.500 ms
+//   WPS=3 KSUB=16 LOWREG=1 : 168 VGPRs, no spill, one workgroup per CU ........ 0.505 ms
+//   WPS=4 KSUB=8  LOWREG=1 : 128 VGPRs, 61 spilled, TWO workgroups per CU ..... 0.479 ms   <- default
+// Two co-resident workgroups hide part of each other's non-MFMA phases; the gain is small because the resident
+// partner's K loop starves the other's LayerNorm phase (phase traces: 3k -> 11-19k cycles).
 #ifndef ESMI_DEC_WPS
-#define ESMI_DEC_WPS 2   // __launch_bounds__ waves/SIMD: 2 = one 512-thread workgroup per CU, up to 256 VGPRs (a 128-VGPR build spills)
+#define ESMI_DEC_WPS 4      // __launch_bounds__ waves/SIMD (512-thread workgroups: 2 -> 256 VGPRs, 4 -> 128 VGPRs)
 #endif
 #ifndef ESMI_DEC_LOWREG
-#define ESMI_DEC_LOWREG 0   // 1: no cross-phase prefetch (weights, taps, params fetched where used): fewer live registers.
-                            // With WPS=4 this gives two workgroups per CU (61 spills): measured 552 vs 546 us -- the
-                            // co-resident workgroup's K loop starves the other's LayerNorm phase (3k -> 11-19k cycles).
+#define ESMI_DEC_LOWREG 1   // 1: no cross-phase prefetch (weights, taps, params fetched where used): fewer live registers
 #endif
 #ifndef ESMI_DEC_KSUB
-#define ESMI_DEC_KSUB 16 // k-steps (of 8 channels) of the weight slice held in registers at a time (16 = all of K = 128)
+#define ESMI_DEC_KSUB 8     // k-steps (of 8 channels) of the weight slice held in registers at a time (16 = all of K = 128)
 #endif
 
 namespace esmi {

@@ -19,6 +19,10 @@ extern __device__ long long* g_chain_trace_dev;
 #define ESMI_CT() do {} while (0)
 #endif
 
+#ifndef ESMI_CHAIN_WPS
+#define ESMI_CHAIN_WPS 1   // __launch_bounds__ waves/SIMD of the one-wave chain kernels (3 => at most 168 VGPRs)
+#endif
+
 namespace esmi {
 
 // acc[nt] += sum over taps j < ntaps of  A_j(32 x K) * W_j[n0 + 32nt + (0..31)][wcol0 + (0..K-1)]^T

@@ -122,7 +122,7 @@ class ShardedMelPipeline:
     stream while the next step computes.  With use_graph (and a `max_mel_len` bound) the compute is two
     hipGraph replays per step."""
 
-    def __init__(self, net, world_size=1, gather=True, group=None, depth=2, use_graph=False):
+    def __init__(self, net, world_size=1, gather=True, group=None, depth=2, use_graph=False, two_stream=False):
         self.net, self.world, self.group = net, world_size, group
         self.gather = gather and world_size > 1
         self.depth = depth
@@ -132,6 +132,11 @@ class ShardedMelPipeline:
         self.use_graph = use_graph
         self.graphed = None
         self.dec_events = None   # bench.py: list collecting (start, end) events around the decoder launch
+        # two_stream: the encoder side of step i+1 runs on its own stream while the mel decoder of step i is
+        # still running -- the encoder kernels are latency-bound one-wave chains that fit beside the decoder's
+        # workgroups on every CU (needs the <=168-VGPR builds of both).
+        self.two_stream = two_stream
+        self.s_enc = self.s_dec = None
 
     def _compute(self, x):
         """-> (mel, mel_len) of this rank's shard; global padded length MAX-reduced when world > 1."""
@@ -152,6 +157,8 @@ class ShardedMelPipeline:
             else:
                 mel = g.decode()
             return mel, enc["mel_len"]
+        if self.two_stream:
+            return self._compute_two_stream(x)
         if self.world == 1:
             mel, mel_len, _ = self.net(x)
             return mel, mel_len
@@ -165,8 +172,41 @@ class ShardedMelPipeline:
         mel = self.net.decoder._fused(enc["feat"], enc["cum"], enc["mel_len"], lmax_dev, L_out, True, L_out)
         return mel, enc["mel_len"]
 
+    def _compute_two_stream(self, x):
+        dev = x["phoneme"].device
+        if self.s_enc is None:
+            self.s_enc, self.s_dec = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+        cur = torch.cuda.current_stream(dev)
+        self.s_enc.wait_stream(cur)                       # inputs produced on the caller's stream
+        with torch.cuda.stream(self.s_enc):
+            enc = self.net.encoder._encode(x, train=False)
+            if self.world > 1:
+                dist.all_reduce(enc["lmax"], op=dist.ReduceOp.MAX, group=self.group)
+            ready = torch.cuda.Event()
+            ready.record()
+        if "max_mel_len" in x:
+            L_out, lmax_dev = int(x["max_mel_len"]), enc["lmax"]
+        else:
+            ready.synchronize()
+            L_out, lmax_dev = int(enc["lmax"].item()), None
+        with torch.cuda.stream(self.s_dec):
+            self.s_dec.wait_event(ready)
+            for t in (enc["feat"], enc["cum"], enc["mel_len"], enc["lmax"]):
+                t.record_stream(self.s_dec)
+            mel = self.net.decoder._fused(enc["feat"], enc["cum"], enc["mel_len"], lmax_dev, L_out, True, L_out)
+            done = torch.cuda.Event()
+            done.record()
+        self._dec_done = done
+        mel.record_stream(cur)
+        return mel, enc["mel_len"]
+
     def step(self, x):
         mel, mel_len = self._compute(x)
+        if self.two_stream and not self.gather:
+            self.last = (mel, mel_len)
+            return self.last
+        if self.two_stream:
+            torch.cuda.current_stream().wait_event(self._dec_done)
         if not self.gather:
             self.last = (mel, mel_len)
             return self.last
@@ -192,6 +232,9 @@ class ShardedMelPipeline:
         return self.last
 
     def flush(self):
+        if self.two_stream and self.s_dec is not None:
+            self.s_enc.synchronize()
+            self.s_dec.synchronize()
         for done, _, _ in self.inflight:
             done.synchronize()
         self.inflight.clear()
