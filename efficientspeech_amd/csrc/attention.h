@@ -85,7 +85,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnP p) {
             mx = fmaxf(mx, v);
         }
     }
-    mx = fmaxf(mx, shfl_xor_f(mx, 32));
+    mx = fmaxf(mx, swap32_f(mx));
     float den = 0.0f;
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt) {
@@ -96,7 +96,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnP p) {
             den += e;
         }
     }
-    den += shfl_xor_f(den, 32);
+    den += swap32_f(den);
     const float inv = 1.0f / den;
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt) {

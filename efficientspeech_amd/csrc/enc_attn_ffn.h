@@ -130,7 +130,7 @@ __global__ __launch_bounds__(64, ESMI_CHAIN_WPS) void enc_attn_ffn_kernel(const 
                 mx = fmaxf(mx, v);
             }
         }
-        mx = fmaxf(mx, shfl_xor_f(mx, 32));
+        mx = fmaxf(mx, swap32_f(mx));
         float den = 0.0f;
 #pragma unroll
         for (int kt = 0; kt < NKT; ++kt) {
@@ -141,7 +141,7 @@ __global__ __launch_bounds__(64, ESMI_CHAIN_WPS) void enc_attn_ffn_kernel(const 
                 den += e;
             }
         }
-        den += shfl_xor_f(den, 32);
+        den += swap32_f(den);
         const float inv = 1.0f / den;
         ESMI_CT();   // 2 softmax done
         f32x16 o[NC];           // ctx[query][c] = sum_key P[query][key] V[key][c]

@@ -95,6 +95,16 @@ __device__ __forceinline__ float swz_xor16_f(float v) {   // lane l <- lane l^16
 #endif
 }
 
+__device__ __forceinline__ float swap32_f(float v) {     // lane l <- lane l^32, VALU only (v_permlane32_swap, gfx950)
+#ifdef ESMI_WAVESIM
+    return wavesim::shfl(v, lane_id_raw() ^ 32);
+#else
+    const unsigned x = __builtin_bit_cast(unsigned, v);
+    const auto r = __builtin_amdgcn_permlane32_swap(x, x, false, false);   // r[0]: lanes 32-63 <- x[0-31]; r[1]: lanes 0-31 <- x[32-63]
+    return __builtin_bit_cast(float, lane_id_raw() < 32 ? r[1] : r[0]);
+#endif
+}
+
 // sum over the 32 lanes that hold one tile row (lanes sharing lane>>5); every lane ends with the same bits
 __device__ __forceinline__ float row_sum32(float v) {
     v += dpp_f<0xB1>(v);
