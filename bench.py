@@ -83,8 +83,8 @@ def pmc_traffic(config, B, T, dur):
             continue
         if d.get("workload", "").startswith(f"{config} ES B={B} T={T} D-const {dur} "):
             m = d["mel_decoder"]
-            return m["hbm_traffic_bytes_corrected"], os.path.basename(path), m.get("mfma_pipe_utilisation")
-    return None, None, None
+            return m["hbm_traffic_bytes_corrected"], os.path.basename(path), m.get("mfma_pipe_utilisation"), m.get("note_scratch")
+    return None, None, None, None
 
 
 def main():
@@ -145,7 +145,7 @@ def main():
     value = frames_per_step * a.steps / dt
     flops, nbytes = DECODER_WORK[a.config]
     ach_tf = flops * B * L / (dec_ms * 1e-3) / 1e12
-    traffic, traffic_src, mfma_util = pmc_traffic(a.config, B, T, a.dur)
+    traffic, traffic_src, mfma_util, traffic_note = pmc_traffic(a.config, B, T, a.dur)
     out = {
         "metric": "mel-frames/sec (whole node), full Phoneme2Mel forward", "value": value, "unit": "mel-frames/s",
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
@@ -160,7 +160,7 @@ def main():
         "roofline": {"bound": "mfma", "kernel": "mel_decoder_kernel", "achieved": ach_tf, "peak": FP32_PEAK_TFLOPS,
                      "unit": "TFLOP/s", "frac": ach_tf / FP32_PEAK_TFLOPS, "traffic": traffic,
                      "traffic_unit": "HBM bytes per launch (rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE)",
-                     "traffic_source": traffic_src, "mfma_pipe_utilisation_pmc": mfma_util,
+                     "traffic_source": traffic_src, "traffic_note": traffic_note, "mfma_pipe_utilisation_pmc": mfma_util,
                      "algorithmic_bytes_per_launch": nbytes * B * L,
                      "kernel_ms": dec_ms, "algorithmic_flops_per_frame": flops, "algorithmic_bytes_per_frame": nbytes,
                      "hbm_frac": nbytes * B * L / (dec_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,

@@ -41,7 +41,9 @@
 // Build knobs of the dx2 = 128 instantiation (measured on MI355X, tiny ES B=256 T=128, decoder time inside bench.py):
 //   WPS=2 KSUB=16 LOWREG=0 : 235 VGPRs, no spill, ONE workgroup per CU ........ 0.500 ms
 //   WPS=3 KSUB=16 LOWREG=1 : 168 VGPRs, no spill, one workgroup per CU ........ 0.505 ms
-//   WPS=4 KSUB=8  LOWREG=1 : 128 VGPRs, 61 spilled, TWO workgroups per CU ..... 0.479 ms   <- default
+//   WPS=4 KSUB=8  LOWREG=1 : 128 VGPRs, 55 spilled, TWO workgroups per CU ..... 0.477 ms   <- default
+//     (the spill is mostly the 32-register skip tensor, dead during the K loops; it shows as ~390 MB of scratch
+//      traffic per launch in the PMC counters -- profiles/r01_e_pmc_counters.json)
 // Two co-resident workgroups hide part of each other's non-MFMA phases; the gain is small because the resident
 // partner's K loop starves the other's LayerNorm phase (phase traces: 3k -> 11-19k cycles).
 #ifndef ESMI_DEC_WPS
@@ -66,7 +68,7 @@ namespace esmi {
 
 constexpr int kDecRows = 128;     // frames per workgroup window
 constexpr int kDecPadRows = 2;    // zero rows above/below the window in LDS (>= k/2)
-constexpr int kDecThreads = 512;  // 8-wave windows (dx2 = 256); dx2 = 128 uses 4-wave windows, two workgroups per CU
+constexpr int kDecThreads = 512;  // 8-wave windows (NW = 8, the default for every dx2)
 constexpr int kMelCols = 96;      // n_mel <= 96 (three 32-column MFMA tiles)
 
 struct DecLayout {  // offsets in floats into the packed blob

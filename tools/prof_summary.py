@@ -1,21 +1,133 @@
 #!/usr/bin/env python3
-"""Dump the per-kernel summary (rocprofv3 --kernel-trace --stats) from a rocpd .db into a small CSV/markdown
-that can be committed under profiles/.   usage: prof_summary.py results.db out.md [note]"""
-import sqlite3
+"""Summarise what tools/collect_profiles.sh wrote (rocprofv3 csv output) into the two small files committed
+under profiles/:  <dir>/kernel_stats.md  (per-kernel call count / total / average from the kernel trace) and
+<dir>/pmc_counters.json (mean counter value per launch and kernel, plus the derived mel-decoder figures).
+usage: prof_summary.py gpurun_out/<tag>"""
+import csv
+import glob
+import json
+import os
+import re
 import sys
+from collections import defaultdict
+
+
+def short(name):
+    m = re.search(r"esmi::(\w+(?:<[^>]*>)?)", name)
+    return m.group(1) if m else name[:60]
+
+
+def find(d, pat):
+    r = sorted(glob.glob(os.path.join(d, "**", pat), recursive=True))
+    return r[0] if r else None
+
+
+def kernel_stats(d):
+    path = find(os.path.join(d, "stats"), "*kernel_trace.csv")
+    if not path:
+        return None
+    agg = defaultdict(lambda: [0, 0.0])
+    for r in csv.DictReader(open(path)):
+        a = agg[r["Kernel_Name"]]
+        a[0] += 1
+        a[1] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+    tot = sum(v[1] for v in agg.values())
+    rows = sorted(agg.items(), key=lambda kv: -kv[1][1])
+    lines = ["| kernel | calls | total (us) | avg (us) | % |", "|---|---:|---:|---:|---:|"]
+    for name, (n, t) in rows:
+        lines.append(f"| `{name[:100]}` | {n} | {t:.1f} | {t / n:.2f} | {100 * t / tot:.2f} |")
+    return "\n".join(lines)
+
+
+def pmc(d):
+    per = defaultdict(dict)
+    for cdir in sorted(glob.glob(os.path.join(d, "pmc_*"))):
+        if not os.path.isdir(cdir):
+            continue
+        path = find(cdir, "*counter_collection.csv")
+        if not path:
+            continue
+        acc = defaultdict(lambda: defaultdict(float))
+        for r in csv.DictReader(open(path)):
+            acc[(r["Kernel_Name"], r["Dispatch_Id"])][r["Counter_Name"]] += float(r["Counter_Value"])
+        byk = defaultdict(lambda: defaultdict(list))
+        for (k, _), cs in acc.items():
+            if "esmi::" in k:
+                for c, v in cs.items():
+                    byk[short(k)][c].append(v)
+        for k, cs in byk.items():
+            for c, vs in cs.items():
+                per[k][c] = sum(vs) / len(vs)
+    return per
+
+
+def workload_tag(bench):
+    """Same tag bench.py's pmc_traffic() matches on: '<cfg> ES B=.. T=.. D-const .. (...)'."""
+    if not bench:
+        return ""
+    c = bench["config"]
+    B, T = c["global_batch"] // bench["n_gpus"], c["phonemes"]
+    dur = c["frames_per_step"] // (c["global_batch"] * T)
+    return (f"{c['workload'].split()[0]} ES B={B} T={T} D-const {dur} ({B * T * dur} frames per launch), "
+            f"{bench['n_gpus']}x MI355X")
+
+
+def scratch_bytes(d, kernel_prefix):
+    path = find(os.path.join(d, "stats"), "*kernel_trace.csv")
+    if path:
+        for r in csv.DictReader(open(path)):
+            if kernel_prefix in r["Kernel_Name"]:
+                return int(r["Scratch_Size"])
+    return None
 
 
 def main():
-    db, out = sys.argv[1], sys.argv[2]
-    note = sys.argv[3] if len(sys.argv) > 3 else ""
-    cur = sqlite3.connect(db).cursor()
-    rows = list(cur.execute("select name, total_calls, total_duration, average, percentage from top_kernels"))
-    with open(out, "w") as f:
-        f.write(f"# rocprofv3 --kernel-trace --stats summary\n\n{note}\n\n")
-        f.write("| kernel | calls | total (us) | avg (us) | % |\n|---|---:|---:|---:|---:|\n")
-        for name, calls, tot, avg, pct in rows:
-            f.write(f"| `{name[:100]}` | {calls} | {tot:.1f} | {avg:.2f} | {pct:.2f} |\n")
-    print(open(out).read())
+    d = sys.argv[1]
+    bench = {}
+    try:
+        bench = json.loads(open(os.path.join(d, "bench_unprofiled.json")).read().strip().splitlines()[-1])
+    except Exception:
+        pass
+    ks = kernel_stats(d)
+    if ks:
+        with open(os.path.join(d, "kernel_stats.md"), "w") as f:
+            f.write("# rocprofv3 --kernel-trace --stats (csv) summary\n\n"
+                    "`rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --steps 10 --warmup 3 "
+                    "--no-cpu-baseline` (tools/collect_profiles.sh), 1x MI355X; 13 forward steps.\n")
+            if bench:
+                f.write(f"Un-profiled `bench.py` of the same build on the same box: {bench['ms_per_step']:.3f} ms/step = "
+                        f"{bench['value']:.3e} frames/s, {bench['roofline']['kernel']} {bench['roofline']['kernel_ms']:.3f} ms "
+                        f"by live HIP events ({100 * bench['roofline']['frac']:.1f} % of the fp32-MFMA peak).\n")
+            f.write("\n" + ks + "\n")
+        print(ks)
+    per = pmc(d)
+    if per:
+        out = {"command": "rocprofv3 --pmc <group> --kernel-trace --output-format csv -- python bench.py --steps 3 --warmup 2 "
+                          "--no-cpu-baseline; one pass per counter group (tools/collect_profiles.sh)",
+               "workload": workload_tag(bench),
+               "per_kernel_mean_per_launch": per}
+        dec = next((k for k in per if k.startswith("mel_decoder_kernel")), None)
+        if dec and "FETCH_SIZE" in per[dec] and "WRITE_SIZE" in per[dec]:
+            m = per[dec]
+            fr, wr = m["FETCH_SIZE"] * 1024, m["WRITE_SIZE"] * 1024
+            o = {"fetch_bytes_raw": fr, "fetch_bytes_corrected_x2": 2 * fr, "write_bytes": wr,
+                 "hbm_traffic_bytes_corrected": 2 * fr + wr,
+                 "note": "gfx950 rocprofv3 reports FETCH_SIZE at 1/2 for wide coalesced 16 B/lane reads "
+                         "(MI355X_MICROARCH.md, HBM section); the decoder's global reads are 16 B/lane row gathers and "
+                         "weight-slice loads, so the read side is doubled."}
+            if "SQ_VALU_MFMA_BUSY_CYCLES" in m and "GRBM_GUI_ACTIVE" in m:
+                # GRBM_GUI_ACTIVE is summed over the 8 XCDs; 1024 SIMDs = 128 per XCD
+                o["mfma_pipe_utilisation"] = m["SQ_VALU_MFMA_BUSY_CYCLES"] / (m["GRBM_GUI_ACTIVE"] * 128)
+            if "SQ_INSTS_MFMA" in m:
+                o["mfma_insts"] = m["SQ_INSTS_MFMA"]
+            if "SQ_LDS_BANK_CONFLICT" in m and "SQ_ACTIVE_INST_LDS" in m:
+                o["lds_bank_conflict_over_active"] = m["SQ_LDS_BANK_CONFLICT"] / m["SQ_ACTIVE_INST_LDS"]
+            sc = scratch_bytes(d, "mel_decoder_kernel")
+            if sc is not None:
+                o["scratch_bytes_per_lane"] = sc
+            out["mel_decoder"] = o
+        json.dump(out, open(os.path.join(d, "pmc_counters.json"), "w"), indent=1)
+        print(json.dumps(out.get("mel_decoder", {}), indent=1))
 
 
 if __name__ == "__main__":
