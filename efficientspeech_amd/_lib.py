@@ -23,7 +23,8 @@ fp = C.c_void_p  # device pointers travel as integers
 
 class EncoderBlockWeights(C.Structure):
     _fields_ = [(n, fp) for n in ("merge_w", "merge1_w", "qkv_w", "proj_w", "proj_b", "mlp1_w", "mlp1_b",
-                                  "conv_w", "conv_b", "mlp2_w", "mlp2_b", "ln1_g", "ln1_b", "ln2_g", "ln2_b")]
+                                  "conv_w", "conv_b", "mlp2_w", "mlp2_b", "ln1_g", "ln1_b", "ln2_g", "ln2_b",
+                                  "merge_wp", "merge1_wp", "qkv_wp", "proj_wp", "mlp1_wp", "conv_wp", "mlp2_wp")]
 
 
 class EncoderBlockShape(C.Structure):
@@ -32,12 +33,13 @@ class EncoderBlockShape(C.Structure):
 
 class FuseWeights(C.Structure):
     _fields_ = [("mlp_w", fp * MAX_DEPTH), ("mlp_b", fp * MAX_DEPTH), ("up_w", fp * MAX_DEPTH),
-                ("up_b", fp * MAX_DEPTH), ("fuse_w", fp), ("fuse_b", fp)]
+                ("up_b", fp * MAX_DEPTH), ("fuse_w", fp), ("fuse_b", fp),
+                ("mlp_wp", fp * MAX_DEPTH), ("up_wp", fp * MAX_DEPTH), ("fuse_wp", fp)]
 
 
 class PredictorWeights(C.Structure):
     _fields_ = [(n, fp) for n in ("conv1_w", "conv1_b", "ln1_g", "ln1_b", "conv2_w", "conv2_b", "ln2_g", "ln2_b",
-                                  "lin_w", "lin_b", "bins", "emb")]
+                                  "lin_w", "lin_b", "bins", "emb", "conv1_wp", "conv2_wp")]
 
 
 class DecoderWeights(C.Structure):
@@ -57,7 +59,7 @@ EXPORTS = (
     "esmi_fuse_workspace_bytes", "esmi_fuse_f32", "esmi_variance_adaptor_workspace_bytes",
     "esmi_variance_adaptor_f32", "esmi_length_regulate_i32", "esmi_length_regulator_indices_i32",
     "esmi_upsample_f32", "esmi_mel_decoder_blob_bytes", "esmi_mel_decoder_pack_f32", "esmi_mel_decoder_f32",
-    "esmi_mask_rows_f32",
+    "esmi_mask_rows_f32", "esmi_pack_bfrag_floats", "esmi_pack_bfrag_f32",
 )
 
 
@@ -68,6 +70,9 @@ def bind(lib):
     lib.esmi_backend.restype = C.c_char_p
     lib.esmi_pack_conv_weight_f32.argtypes = [fp, fp, i, i, i, fp]
     lib.esmi_pack_convT_weight_f32.argtypes = [fp, fp, i, i, i, fp]
+    lib.esmi_pack_bfrag_floats.argtypes = [i, i, i]
+    lib.esmi_pack_bfrag_floats.restype = sz
+    lib.esmi_pack_bfrag_f32.argtypes = [fp, fp, i, i, i, fp]
     lib.esmi_encoder_block_workspace_bytes.argtypes = [P(EncoderBlockShape)]
     lib.esmi_encoder_block_workspace_bytes.restype = sz
     lib.esmi_encoder_block_f32.argtypes = [P(EncoderBlockWeights), P(EncoderBlockShape), fp, fp, fp, fp, fp, fp, sz, fp]

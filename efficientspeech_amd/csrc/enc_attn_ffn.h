@@ -11,6 +11,10 @@
 #pragma once
 #include "wave_chain.h"
 
+#ifndef ESMI_E2_WPS
+#define ESMI_E2_WPS ESMI_CHAIN_WPS
+#endif
+
 namespace esmi {
 
 struct EncAttnFfnP {
@@ -18,6 +22,7 @@ struct EncAttnFfnP {
     const float* qkv;  // (B,N,3,h,C)
     int B, N, C, h;
     float scale;
+    // the four weight matrices are in MFMA B-fragment order (esmi_pack_bfrag_f32, see wave_chain.h)
     const float *proj_w, *proj_b;   // (C, h*C), (C)
     const float *ln1_g, *ln1_b;
     const float *mlp1_w, *mlp1_b;   // (E*C, C)
@@ -32,7 +37,7 @@ struct EncAttnFfnP {
 constexpr int kEncTileRows = 30;    // useful rows per 32-row tile (one halo row each side)
 
 template <int NKT, int NC, int E>   // keys <= 32*NKT, C = 32*NC, MixFFN hidden = E*C
-__global__ __launch_bounds__(64, ESMI_CHAIN_WPS) void enc_attn_ffn_kernel(const EncAttnFfnP p) {
+__global__ __launch_bounds__(64, ESMI_E2_WPS) void enc_attn_ffn_kernel(const EncAttnFfnP p) {
     constexpr int NE = NC * E;
     constexpr int C = 32 * NC, EC = 32 * NE;
     constexpr int LD = EC + 4;
@@ -55,11 +60,16 @@ __global__ __launch_bounds__(64, ESMI_CHAIN_WPS) void enc_attn_ffn_kernel(const 
     // Everything that does not depend on the attention result is requested now, so that its memory round trips
     // (~2 us each for tensors the previous kernel just wrote) overlap the attention instead of following it.
     bool rz[16], rout[16];      // rows that are padding (mask) / outside the sequence
+    {   // ONE mask byte per lane (row i) + a ballot, instead of 16 dependent byte loads per lane
+        const unsigned char mb = (in_i && p.mask) ? p.mask[(long)b * p.N + pos_i] : (unsigned char)0;
+        const unsigned mbits = (unsigned)ballot64(mb != 0);   // bit i = row i (both half waves hold the same rows)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int pos = t0 + tile_row(r, lane);
-        rout[r] = pos < 0 || pos >= p.N;
-        rz[r] = !rout[r] && p.mask && p.mask[(long)b * p.N + pos];
+        for (int r = 0; r < 16; ++r) {
+            const int row = tile_row(r, lane);
+            const int pos = t0 + row;
+            rout[r] = pos < 0 || pos >= p.N;
+            rz[r] = !rout[r] && ((mbits >> row) & 1u);
+        }
     }
     constexpr bool kHoistRes = NC <= 2;
     f32x16 xres[kHoistRes ? NC : 1];
@@ -183,7 +193,7 @@ __global__ __launch_bounds__(64, ESMI_CHAIN_WPS) void enc_attn_ffn_kernel(const 
         __syncthreads();        // the previous head's proj has finished reading the tile
         tile_store<NC>(buf, LD, 0, o, lane);
         __syncthreads();
-        wave_gemm<NC>(y, a_row, C, p.proj_w, p.h * C, hd * C, 0, C, lane);
+        wave_gemm<NC>(y, a_row, true, C, p.proj_w, NC, (hd * C) >> 3, 0, lane);
     }
 
     ESMI_CT();   // 4 proj done
@@ -214,7 +224,7 @@ __global__ __launch_bounds__(64, ESMI_CHAIN_WPS) void enc_attn_ffn_kernel(const 
     // ---------------- MixFFN: mlp1 -> dense conv k3 -> GELU -> mlp2
     f32x16 m[NE];
     zero_tiles<NE>(m);
-    wave_gemm<NE>(m, a_row, C, p.mlp1_w, C, 0, 0, EC, lane);
+    wave_gemm<NE>(m, a_row, true, C, p.mlp1_w, NE, 0, 0, lane);
 #pragma unroll
     for (int nt = 0; nt < NE; ++nt) {
 #pragma unroll
@@ -227,7 +237,8 @@ __global__ __launch_bounds__(64, ESMI_CHAIN_WPS) void enc_attn_ffn_kernel(const 
     zero_tiles<NE>(m);
     {
         const float* const taps[3] = {a_row - LD, a_row, a_row + LD};
-        wave_gemm_taps<NE, 3>(m, taps, 3, EC, p.conv_w, (long)EC * EC, EC, 0, 0, EC, lane);
+        const bool tok[3] = {true, true, true};   // rows 0 and 33 of the tile are the zero rows
+        wave_gemm_taps<NE, 3, NE, false>(m, taps, tok, 3, p.conv_w, (long)EC * EC, NE, 0, 0, lane);
     }
 #pragma unroll
     for (int nt = 0; nt < NE; ++nt) {
@@ -240,7 +251,7 @@ __global__ __launch_bounds__(64, ESMI_CHAIN_WPS) void enc_attn_ffn_kernel(const 
     ESMI_CT();   // 7 conv + gelu + store
     f32x16 z[NC];
     zero_tiles<NC>(z);
-    wave_gemm<NC>(z, a_row, EC, p.mlp2_w, EC, 0, 0, C, lane);
+    wave_gemm<NC>(z, a_row, true, EC, p.mlp2_w, NC, 0, 0, lane);
 #pragma unroll
     for (int nt = 0; nt < NC; ++nt) {
 #pragma unroll

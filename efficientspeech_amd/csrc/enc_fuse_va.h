@@ -8,9 +8,13 @@
 #include "small_kernels.h"
 #include "wave_chain.h"
 
+#ifndef ESMI_E3_WPS
+#define ESMI_E3_WPS ESMI_CHAIN_WPS
+#endif
+
 namespace esmi {
 
-struct PredW {
+struct PredW {   // conv1_w / conv2_w in MFMA B-fragment order (esmi_pack_bfrag_f32)
     const float *conv1_w, *conv1_b, *ln1_g, *ln1_b, *conv2_w, *conv2_b, *ln2_g, *ln2_b, *lin_w, *lin_b, *bins, *emb;
 };
 
@@ -18,7 +22,7 @@ struct FuseVaP {
     int B, T, depth, kernel;
     const float* feats[4];
     int n_i[4];
-    const float* mlp_w[4];
+    const float* mlp_w[4];  // mlp_w, up_w, fuse_w: MFMA B-fragment order (esmi_pack_bfrag_f32, see wave_chain.h)
     const float* mlp_b[4];
     const float* up_w[4];   // (k, dim, dim) tap-major
     const float* up_b[4];
@@ -46,7 +50,7 @@ __host__ __device__ inline int fuse_va_lds_floats(int dim, int depth) {
 __device__ __forceinline__ int floor_div(int a, int b) { return a >= 0 ? a / b : -((-a + b - 1) / b); }
 
 template <int ND>   // dim = 32*ND
-__global__ __launch_bounds__(64, ESMI_CHAIN_WPS) void enc_fuse_va_kernel(const FuseVaP p) {
+__global__ __launch_bounds__(64, ESMI_E3_WPS) void enc_fuse_va_kernel(const FuseVaP p) {
     constexpr int DIM = 32 * ND, LDD = DIM + 4;
     ESMI_DYN_LDS(lds);
     const int ldc = p.depth * DIM + 4;
@@ -67,11 +71,16 @@ __global__ __launch_bounds__(64, ESMI_CHAIN_WPS) void enc_fuse_va_kernel(const F
     const bool in_i = pos_i >= 0 && pos_i < p.T;
     bool rout[16], rz[16];                  // per accumulator row: outside the sequence / masked (padding)
     int rpos[16];
+    {   // ONE mask byte per lane (row i) + a ballot, instead of 16 dependent byte loads per lane
+        const unsigned char mb = (in_i && p.mask) ? p.mask[(long)b * p.T + pos_i] : (unsigned char)0;
+        const unsigned mbits = (unsigned)ballot64(mb != 0);   // bit i = row i (both half waves hold the same rows)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        rpos[r] = p0 + tile_row(r, lane);
-        rout[r] = rpos[r] < 0 || rpos[r] >= p.T;
-        rz[r] = !rout[r] && p.mask && p.mask[(long)b * p.T + rpos[r]];
+        for (int r = 0; r < 16; ++r) {
+            const int row = tile_row(r, lane);
+            rpos[r] = p0 + row;
+            rout[r] = rpos[r] < 0 || rpos[r] >= p.T;
+            rz[r] = !rout[r] && ((mbits >> row) & 1u);
+        }
     }
 
     ESMI_CT_INIT(2);
@@ -80,8 +89,8 @@ __global__ __launch_bounds__(64, ESMI_CHAIN_WPS) void enc_fuse_va_kernel(const F
     f32x16 a[ND];
     {   // level 0: Linear(dim, dim) on f_0 rows
         zero_tiles<ND>(a);
-        const float* arow = in_i ? p.feats[0] + ((long)b * p.n_i[0] + pos_i) * DIM + 4 * h2 : nullptr;
-        wave_gemm<ND>(a, arow, DIM, p.mlp_w[0], DIM, 0, 0, DIM, lane);
+        const float* arow = p.feats[0] + ((long)b * p.n_i[0] + (in_i ? pos_i : 0)) * DIM + 4 * h2;
+        wave_gemm<ND>(a, arow, in_i, DIM, p.mlp_w[0], ND, 0, 0, lane);
 #pragma unroll
         for (int nt = 0; nt < ND; ++nt) {
             const float bc = p.mlp_b[0][32 * nt + i];
@@ -95,8 +104,9 @@ __global__ __launch_bounds__(64, ESMI_CHAIN_WPS) void enc_fuse_va_kernel(const F
         const int n_base = floor_div(p0 - (p.kernel - 1), s);
         zero_tiles<ND>(a);
         const int n = n_base + i;
-        const float* arow = (n >= 0 && n < nl) ? p.feats[lv] + ((long)b * nl + n) * cl + 4 * h2 : nullptr;
-        wave_gemm<ND>(a, arow, cl, p.mlp_w[lv], cl, 0, 0, DIM, lane);
+        const bool n_ok = n >= 0 && n < nl;
+        const float* arow = p.feats[lv] + ((long)b * nl + (n_ok ? n : 0)) * cl + 4 * h2;
+        wave_gemm<ND>(a, arow, n_ok, cl, p.mlp_w[lv], ND, 0, 0, lane);
 #pragma unroll
         for (int nt = 0; nt < ND; ++nt) {
             const float bc = p.mlp_b[lv][32 * nt + i];
@@ -111,14 +121,16 @@ __global__ __launch_bounds__(64, ESMI_CHAIN_WPS) void enc_fuse_va_kernel(const F
         __syncthreads();
         zero_tiles<ND>(a);
         {   // out[n*s + j] += in[n] W[:, :, j]
-            const float* taps[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+            const float* taps[7];
+            bool tok[7];
 #pragma unroll
             for (int j = 0; j < 7; ++j) {
                 const int q = pos_i - j;
                 const int nq = q / s;
-                if (j < p.kernel && q >= 0 && (q - nq * s) == 0 && nq < nl) taps[j] = tmp + (nq - n_base) * LDD + 4 * h2;
+                tok[j] = j < p.kernel && q >= 0 && (q - nq * s) == 0 && nq < nl;
+                taps[j] = tmp + (tok[j] ? nq - n_base : 0) * LDD + 4 * h2;
             }
-            wave_gemm_taps<ND, 7>(a, taps, p.kernel, DIM, p.up_w[lv], (long)DIM * DIM, DIM, 0, 0, DIM, lane);
+            wave_gemm_taps<ND, 7, ND, true>(a, taps, tok, p.kernel, p.up_w[lv], (long)DIM * DIM, ND, 0, 0, lane);
         }
 #pragma unroll
         for (int nt = 0; nt < ND; ++nt) {
@@ -130,7 +142,7 @@ __global__ __launch_bounds__(64, ESMI_CHAIN_WPS) void enc_fuse_va_kernel(const F
     }
     __syncthreads();
     zero_tiles<ND>(a);
-    wave_gemm<ND>(a, cat + i * ldc + 4 * h2, p.depth * DIM, p.fuse_w, p.depth * DIM, 0, 0, DIM, lane);
+    wave_gemm<ND>(a, cat + i * ldc + 4 * h2, true, p.depth * DIM, p.fuse_w, ND, 0, 0, lane);
 #pragma unroll
     for (int nt = 0; nt < ND; ++nt) {
         const int col = 32 * nt + i;
@@ -150,6 +162,7 @@ __global__ __launch_bounds__(64, ESMI_CHAIN_WPS) void enc_fuse_va_kernel(const F
     // ---------------- three predictors
     const float* f_row = fb + i * LDD + 4 * h2;
     const float* t_row = tb + i * LDD + 4 * h2;
+    const bool tok3[3] = {true, true, true};   // the tiles carry their own zero rows
     for (int q = 0; q < 3; ++q) {
         const PredW& w = p.pred[q];
         // every small parameter of this predictor is requested up front: one memory round trip instead of six
@@ -170,7 +183,7 @@ __global__ __launch_bounds__(64, ESMI_CHAIN_WPS) void enc_fuse_va_kernel(const F
         zero_tiles<ND>(c);
         {
             const float* const taps[3] = {f_row - LDD, f_row, f_row + LDD};
-            wave_gemm_taps<ND, 3>(c, taps, 3, DIM, w.conv1_w, (long)DIM * DIM, DIM, 0, 0, DIM, lane);
+            wave_gemm_taps<ND, 3, ND, false>(c, taps, tok3, 3, w.conv1_w, (long)DIM * DIM, ND, 0, 0, lane);
         }
 #pragma unroll
         for (int nt = 0; nt < ND; ++nt) {
@@ -191,7 +204,7 @@ __global__ __launch_bounds__(64, ESMI_CHAIN_WPS) void enc_fuse_va_kernel(const F
         zero_tiles<ND>(c);
         {
             const float* const taps[3] = {t_row - LDD, t_row, t_row + LDD};
-            wave_gemm_taps<ND, 3>(c, taps, 3, DIM, w.conv2_w, (long)DIM * DIM, DIM, 0, 0, DIM, lane);
+            wave_gemm_taps<ND, 3, ND, false>(c, taps, tok3, 3, w.conv2_w, (long)DIM * DIM, ND, 0, 0, lane);
         }
         ESMI_CT();   // conv2 done
 #pragma unroll

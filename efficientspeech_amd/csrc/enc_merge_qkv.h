@@ -6,6 +6,10 @@
 #pragma once
 #include "wave_chain.h"
 
+#ifndef ESMI_E1_WPS
+#define ESMI_E1_WPS ESMI_CHAIN_WPS
+#endif
+
 namespace esmi {
 
 struct EncMergeP {
@@ -14,19 +18,21 @@ struct EncMergeP {
     int vocab;
     const float* x_in;     // blocks >= 1: (B, n_in, Cin)
     int B, n_in, n_out, k, stride, pad, h;
-    const float* merge_w;  // (k, Cin, Cin) tap-major
-    const float* merge1_w; // (C, Cin)
-    const float* qkv_w;    // (3*h*C, C)
+    const float* merge_w;  // (k, Cin, Cin) tap-major     } all three in MFMA B-fragment order
+    const float* merge1_w; // (C, Cin)                    } (esmi_pack_bfrag_f32, see wave_chain.h)
+    const float* qkv_w;    // (3*h*C, C)                  }
     float* x_out;          // (B, n_out, C)
     float* qkv;            // (B, n_out, 3*h*C)
     int tiles_per_b;       // ceil(n_out / 32)
 };
 
 template <int NCI, int NC>   // Cin = 32*NCI, C = 32*NC
-__global__ __launch_bounds__(64, ESMI_CHAIN_WPS) void enc_merge_qkv_kernel(const EncMergeP p) {
+__global__ __launch_bounds__(64, ESMI_E1_WPS) void enc_merge_qkv_kernel(const EncMergeP p) {
     constexpr int CIN = 32 * NCI, C = 32 * NC;
     constexpr int LD = (NCI > NC ? CIN : C) + 4;
     ESMI_DYN_LDS(buf);             // [32][LD]
+    ESMI_CT_INIT(NCI == 4 && NC == 1 ? 3 : 4);
+    ESMI_CT();
     const int lane = lane_id(), i = lane & 31, h2 = lane >> 5;
     const int b = (int)blockIdx.x / p.tiles_per_b, tile = (int)blockIdx.x - b * p.tiles_per_b;
     const int t0 = tile * 32, t_out = t0 + i;
@@ -35,27 +41,32 @@ __global__ __launch_bounds__(64, ESMI_CHAIN_WPS) void enc_merge_qkv_kernel(const
     // ---- dense k-tap conv (stride s, zero padding)
     f32x16 a1[NCI];
     zero_tiles<NCI>(a1);
-    const float* taps[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // merge kernels are 1, 3 or 5 wide
+    const float* taps[5];   // merge kernels are 1, 3 or 5 wide; masked taps point at a readable row
+    bool tok[5];
 #pragma unroll
     for (int j = 0; j < 5; ++j) {
         const int ti = t_out * p.stride + j - p.pad;
-        if (j < p.k && t_out < p.n_out && ti >= 0 && ti < p.n_in) {
-            if (p.ids) {
-                int id = p.ids[b * p.n_in + ti];
-                if (id < 0 || id >= p.vocab) id = 0;   // the reference raises IndexError; stay in bounds
-                taps[j] = p.table + (long)id * CIN + 4 * h2;
-            } else {
-                taps[j] = p.x_in + ((long)b * p.n_in + ti) * CIN + 4 * h2;
-            }
+        tok[j] = j < p.k && t_out < p.n_out && ti >= 0 && ti < p.n_in;
+        const int tic = tok[j] ? ti : 0;
+        if (p.ids) {
+            int id = p.ids[b * p.n_in + tic];
+            if (id < 0 || id >= p.vocab) id = 0;   // the reference raises IndexError; stay in bounds
+            taps[j] = p.table + (long)id * CIN + 4 * h2;
+        } else {
+            taps[j] = p.x_in + ((long)b * p.n_in + tic) * CIN + 4 * h2;
         }
     }
-    wave_gemm_taps<NCI, 5>(a1, taps, p.k, CIN, p.merge_w, (long)CIN * CIN, CIN, 0, 0, CIN, lane);
+    ESMI_CT();
+    wave_gemm_taps<NCI, 5, NCI, true>(a1, taps, tok, p.k, p.merge_w, (long)CIN * CIN, NCI, 0, 0, lane);
+    ESMI_CT();
     tile_store<NCI>(buf, LD, 0, a1, lane);
     __syncthreads();
+    ESMI_CT();
     // ---- 1x1 conv -> x
     f32x16 x[NC];
     zero_tiles<NC>(x);
-    wave_gemm<NC>(x, a_row, CIN, p.merge1_w, CIN, 0, 0, C, lane);
+    wave_gemm<NC>(x, a_row, true, CIN, p.merge1_w, NC, 0, 0, lane);
+    ESMI_CT();
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int t = t0 + tile_row(r, lane);
@@ -67,12 +78,13 @@ __global__ __launch_bounds__(64, ESMI_CHAIN_WPS) void enc_merge_qkv_kernel(const
     __syncthreads();
     tile_store<NC>(buf, LD, 0, x, lane);
     __syncthreads();
+    ESMI_CT();
     // ---- qkv, 128 output channels per pass
     const int nq = 3 * p.h * C;
     for (int n0 = 0; n0 < nq; n0 += 128) {
         f32x16 q[4];
         zero_tiles<4>(q);
-        wave_gemm<4>(q, a_row, C, p.qkv_w, C, 0, n0, nq, lane);
+        wave_gemm<4>(q, a_row, true, C, p.qkv_w, nq >> 5, 0, n0 >> 5, lane);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int t = t0 + tile_row(r, lane);
@@ -82,6 +94,7 @@ __global__ __launch_bounds__(64, ESMI_CHAIN_WPS) void enc_merge_qkv_kernel(const
             for (int nt = 0; nt < 4; ++nt)
                 if (n0 + 32 * nt + i < nq) orow[32 * nt] = q[nt][r];
         }
+        ESMI_CT();
     }
 }
 

@@ -182,6 +182,17 @@ int esmi_pack_convT_weight_f32(const float* src, float* dst, int cin, int cout, 
     return launch_status();
 }
 
+size_t esmi_pack_bfrag_floats(int n, int k, int taps) {
+    if (n <= 0 || k <= 0 || taps <= 0 || (k & 7)) return 0;
+    return (size_t)taps * k * 32 * ((n + 31) / 32);
+}
+int esmi_pack_bfrag_f32(const float* src, float* dst, int n, int k, int taps, esmi_stream_t stream) {
+    if (!src || !dst || n <= 0 || k <= 0 || taps <= 0 || (k & 7)) return ESMI_ERR_ARG;
+    const long tot = (long)esmi_pack_bfrag_floats(n, k, taps);
+    ESMI_LAUNCH(pack_bfrag_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, S(stream), src, dst, n, k, (n + 31) / 32, taps);
+    return launch_status();
+}
+
 int esmi_pool_mask_u8(const uint8_t* mask, int B, int T, int pool, uint8_t* out, int n_out, esmi_stream_t stream) {
     if (!mask || !out || B <= 0 || T <= 0 || pool <= 0 || n_out <= 0) return ESMI_ERR_ARG;
     ESMI_LAUNCH(pool_mask_kernel, dim3((B * n_out + 255) / 256), dim3(256), 0, S(stream), mask, B, T, pool, out, n_out);
@@ -212,14 +223,15 @@ int esmi_encoder_block_f32(const esmi_encoder_block_weights* w, const esmi_encod
     bool fused1 = false;
     // With the fused second stage, x (the block input after the merge convs) lives in scratch and the final
     // result is written straight to x_out: tiles read their neighbours' x rows, so in-place is not possible.
-    const bool fused2 = (g_fusion & ESMI_FUSE_ATTN_FFN) && enc_attn_ffn_supported(C, n, s->expansion);
+    const bool packed = w->merge_wp && w->merge1_wp && w->qkv_wp && w->proj_wp && w->mlp1_wp && w->conv_wp && w->mlp2_wp;
+    const bool fused2 = packed && (g_fusion & ESMI_FUSE_ATTN_FFN) && enc_attn_ffn_supported(C, n, s->expansion);
     float* x_mid = fused2 ? y1 : x_out;
-    if (g_fusion & ESMI_FUSE_MERGE_QKV) {   // E1: merge conv + 1x1 + qkv as one wave-chain kernel
+    if (packed && (g_fusion & ESMI_FUSE_MERGE_QKV)) {   // E1: merge conv + 1x1 + qkv as one wave-chain kernel
         EncMergeP m;
         memset(&m, 0, sizeof m);
         m.ids = ids; m.table = embed; m.vocab = s->vocab; m.x_in = ids ? nullptr : x_in;
         m.B = B; m.n_in = s->n_in; m.n_out = n; m.k = s->kernel; m.stride = s->stride; m.pad = s->kernel / 2; m.h = h;
-        m.merge_w = w->merge_w; m.merge1_w = w->merge1_w; m.qkv_w = w->qkv_w; m.x_out = x_mid; m.qkv = qkv;
+        m.merge_w = w->merge_wp; m.merge1_w = w->merge1_wp; m.qkv_w = w->qkv_wp; m.x_out = x_mid; m.qkv = qkv;
         m.tiles_per_b = (n + 31) / 32;
         rc = launch_enc_merge_qkv(m, s->c_in, C, st);
         if (rc == ESMI_OK) fused1 = true;
@@ -248,9 +260,9 @@ int esmi_encoder_block_f32(const esmi_encoder_block_weights* w, const esmi_encod
         EncAttnFfnP f;
         memset(&f, 0, sizeof f);
         f.x = x_mid; f.qkv = qkv; f.B = B; f.N = n; f.C = C; f.h = h; f.scale = 1.0f / sqrtf((float)(C / h));
-        f.proj_w = w->proj_w; f.proj_b = w->proj_b; f.ln1_g = w->ln1_g; f.ln1_b = w->ln1_b;
-        f.mlp1_w = w->mlp1_w; f.mlp1_b = w->mlp1_b; f.conv_w = w->conv_w; f.conv_b = w->conv_b;
-        f.mlp2_w = w->mlp2_w; f.mlp2_b = w->mlp2_b; f.ln2_g = w->ln2_g; f.ln2_b = w->ln2_b;
+        f.proj_w = w->proj_wp; f.proj_b = w->proj_b; f.ln1_g = w->ln1_g; f.ln1_b = w->ln1_b;
+        f.mlp1_w = w->mlp1_wp; f.mlp1_b = w->mlp1_b; f.conv_w = w->conv_wp; f.conv_b = w->conv_b;
+        f.mlp2_w = w->mlp2_wp; f.mlp2_b = w->mlp2_b; f.ln2_g = w->ln2_g; f.ln2_b = w->ln2_b;
         f.mask = mask; f.out = x_out; f.tiles_per_b = (n + kEncTileRows - 1) / kEncTileRows;
         return launch_enc_attn_ffn(f, s->expansion, st);
     }
@@ -385,7 +397,10 @@ int esmi_fuse_variance_adaptor_f32(const esmi_fuse_weights* fw, int depth, int d
     if (!fw || !feats || !n_i || !pitch || !energy || !duration || !feat || !pitch_pred || !energy_pred ||
         !duration_pred || !dur || depth < 1 || depth > ESMI_MAX_DEPTH)
         return ESMI_ERR_ARG;
-    bool chain = (g_fusion & ESMI_FUSE_VARIANCE) && (dim == 32 || dim == 64) && kernel <= 7 && n_i[0] == T;
+    bool chain = (g_fusion & ESMI_FUSE_VARIANCE) && (dim == 32 || dim == 64) && kernel <= 7 && n_i[0] == T && fw->fuse_wp &&
+                 pitch->conv1_wp && pitch->conv2_wp && energy->conv1_wp && energy->conv2_wp && duration->conv1_wp &&
+                 duration->conv2_wp;
+    for (int i = 0; i < depth && chain; ++i) chain = fw->mlp_wp[i] && (i == 0 || fw->up_wp[i]);
     for (int i = 1; i < depth && chain; ++i)
         if ((n_i[i] - 1) * (1 << i) + kernel < T) return ESMI_ERR_UNSUPPORTED;   // torch.cat would raise in the reference
     if (chain) {
@@ -394,14 +409,14 @@ int esmi_fuse_variance_adaptor_f32(const esmi_fuse_weights* fw, int depth, int d
         p.B = B; p.T = T; p.depth = depth; p.kernel = kernel;
         for (int i = 0; i < depth; ++i) {
             p.feats[i] = feats[i]; p.n_i[i] = n_i[i];
-            p.mlp_w[i] = fw->mlp_w[i]; p.mlp_b[i] = fw->mlp_b[i]; p.up_w[i] = fw->up_w[i]; p.up_b[i] = fw->up_b[i];
+            p.mlp_w[i] = fw->mlp_wp[i]; p.mlp_b[i] = fw->mlp_b[i]; p.up_w[i] = fw->up_wp[i]; p.up_b[i] = fw->up_b[i];
         }
-        p.fuse_w = fw->fuse_w; p.fuse_b = fw->fuse_b;
+        p.fuse_w = fw->fuse_wp; p.fuse_b = fw->fuse_b;
         const esmi_predictor_weights* pw[3] = {pitch, energy, duration};
         for (int q = 0; q < 3; ++q) {
             PredW& d = p.pred[q];
-            d.conv1_w = pw[q]->conv1_w; d.conv1_b = pw[q]->conv1_b; d.ln1_g = pw[q]->ln1_g; d.ln1_b = pw[q]->ln1_b;
-            d.conv2_w = pw[q]->conv2_w; d.conv2_b = pw[q]->conv2_b; d.ln2_g = pw[q]->ln2_g; d.ln2_b = pw[q]->ln2_b;
+            d.conv1_w = pw[q]->conv1_wp; d.conv1_b = pw[q]->conv1_b; d.ln1_g = pw[q]->ln1_g; d.ln1_b = pw[q]->ln1_b;
+            d.conv2_w = pw[q]->conv2_wp; d.conv2_b = pw[q]->conv2_b; d.ln2_g = pw[q]->ln2_g; d.ln2_b = pw[q]->ln2_b;
             d.lin_w = pw[q]->lin_w; d.lin_b = pw[q]->lin_b; d.bins = pw[q]->bins; d.emb = pw[q]->emb;
         }
         if (!pitch->bins || !pitch->emb || !energy->bins || !energy->emb) return ESMI_ERR_ARG;

@@ -19,18 +19,21 @@ __global__ void pack_conv_kernel(const float* __restrict__ src, float* __restric
     }
 }
 
-// MFMA B-fragment packing of a (N, K) row-major matrix for the mel decoder:
-//   dst[((kc*NT + nt)*64 + lane)*4 + s] = src[(32*nt + (lane&31))*K + 8*kc + 4*(lane>>5) + s]   (0 for rows >= N)
-__global__ void pack_bfrag_kernel(const float* __restrict__ src, float* __restrict__ dst, int N, int K, int NT) {
-    const long n = (long)(K / 8) * NT * 256;
+// MFMA B-fragment packing of `taps` row-major (N, K) matrices (wave_chain.h), NT = ceil(N/32):
+//   dst[(((t*(K/8) + kc)*NT + nt)*64 + lane)*4 + s] = src[(t*N + 32*nt + (lane&31))*K + 8*kc + 4*(lane>>5) + s]   (0 for rows >= N)
+__global__ void pack_bfrag_kernel(const float* __restrict__ src, float* __restrict__ dst, int N, int K, int NT, int taps) {
+    const long per = (long)(K / 8) * NT * 256;
+    const long n = per * taps;
     for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
-        const int s = (int)(e & 3);
-        const int lane = (int)((e >> 2) & 63);
-        const int nt = (int)((e >> 8) % NT);
-        const int kc = (int)((e >> 8) / NT);
+        const int t = (int)(e / per);
+        const long f = e - (long)t * per;
+        const int s = (int)(f & 3);
+        const int lane = (int)((f >> 2) & 63);
+        const int nt = (int)((f >> 8) % NT);
+        const int kc = (int)((f >> 8) / NT);
         const int row = 32 * nt + (lane & 31);
         const int colk = 8 * kc + 4 * (lane >> 5) + s;
-        dst[e] = row < N ? src[(long)row * K + colk] : 0.0f;
+        dst[e] = row < N ? src[((long)t * N + row) * K + colk] : 0.0f;
     }
 }
 

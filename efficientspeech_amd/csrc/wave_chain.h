@@ -5,7 +5,7 @@
 // written to a private LDS tile [rows][K+4] and re-read as the next stage's A fragments (lane
 // (i = lane&31, h = lane>>5) reads 16 bytes: channels [8kc+4h, +4) of row i).  Convolutions along the
 // sequence are row shifts of the A fragment inside the tile (halo rows are recomputed by neighbouring
-// tiles); weights stream from L2 as 16-byte pieces, four k-steps per round trip.
+// tiles); weights stream from L2 in pre-packed MFMA-fragment order, four k-steps per round trip.
 #pragma once
 #include "esmi_dev.h"
 
@@ -25,72 +25,115 @@ extern __device__ long long* g_chain_trace_dev;
 
 namespace esmi {
 
-// acc[nt] += sum over taps j < ntaps of  A_j(32 x K) * W_j[n0 + 32nt + (0..31)][wcol0 + (0..K-1)]^T
-//   a_rows[j] : this lane's A row of tap j, + 4*h  (LDS or global), or nullptr for an all-zero row
-//   W_j       : W + j*w_tap_stride, row-major (n, ldw); rows >= n_valid contribute zeros
+// Weights of every GEMM in the chain kernels are pre-packed once per checkpoint in MFMA B-fragment order
+// (pack_bfrag_kernel, small_kernels.h): for a row-major (N, K) matrix, NTW = ceil(N / 32),
+//     Wp[((kc*NTW + nt)*64 + lane)*4 + s] = W[32nt + (lane&31)][8kc + 4(lane>>5) + s]      (0 for rows >= N)
+// so one wave-level operand fetch (four k-steps of one 32-column tile) is ONE fully coalesced 1 KiB
+// global_load_dwordx4.  (Round-1 finding: reading row-major weights -- 32 rows x 32 B per instruction, every
+// 128-byte line touched by four different instructions -- made the L1/L2 path, not the MFMA pipe, the limit of
+// these kernels: enc_merge_qkv spent 100k cycles on a 49k-cycle MFMA chain.)
+//
+// acc[nt] += sum over taps j < ntaps of  A_j(32 x 32*KG) * W_j[32(nt0+nt) + (0..31)][8kc0 + (0..32*KG-1)]^T
+//   a_rows[j] : this lane's A row of tap j, + 4*h  (LDS or global; must be a readable address even when masked)
+//   a_ok[j]   : false -> this lane's row of tap j is all zero (MASKED = false: no row is ever masked)
+//   W_j       : Wp + j*w_tap_stride, packed as above with NTW = ntw column tiles; tiles >= ntw contribute zeros
 // Operands are fetched in groups of four k-steps (one memory round trip per 32 channels) and the groups of
-// ALL taps form one software pipeline: group f+1 is in flight while the 16*NT MFMAs of group f execute.
-// (Without the pipeline every group exposed a full L2 latency behind its dependent MFMA chain.)
-template <int NT, int MAXTAPS>
-__device__ __forceinline__ void wave_gemm_taps(f32x16 (&acc)[NT], const float* const (&a_rows)[MAXTAPS], int ntaps, int K,
-                                               const float* __restrict__ W, long w_tap_stride, int ldw, int wcol0, int n0,
-                                               int n_valid, int lane) {
-    const int i = lane & 31, h = lane >> 5;
-    long wofs[NT];
-    bool wok[NT];
+// ALL taps form one software pipeline: group n+1 is in flight while the 16*NT MFMAs of group n execute.
+// Tap indices and buffer parity are compile-time everywhere: an earlier version selected the tap's row pointer
+// with a runtime index, which hipcc turned into a scratch array of generic pointers + flat_load (vmcnt AND
+// lgkmcnt), and the pipeline collapsed to one exposed round trip per group (127 instead of 70 cycles per MFMA).
+template <int NT>
+struct WaveGrp { f32x4 a[4]; f32x4 b[4][NT]; };
+
+template <int NT, bool MASKED>
+__device__ __forceinline__ void wave_grp_fetch(WaveGrp<NT>& gq, const float* ar, bool ok, int g, const float* wj, int ntw,
+                                               const bool (&wok)[NT]) {
+    const float* wg = wj + (long)(4 * g) * ntw * 256;
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-        const int n = n0 + 32 * nt + i;
-        wok[nt] = n < n_valid;
-        wofs[nt] = (long)(wok[nt] ? n : 0) * ldw + wcol0 + 4 * h;
+    for (int q = 0; q < 4; ++q) {
+        gq.a[q] = ld4(ar + 32 * g + 8 * q);
+        if (MASKED && !ok) gq.a[q] = zero4();
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) gq.b[q][nt] = wok[nt] ? ld4(wg + (q * ntw + nt) * 256) : zero4();
     }
-    const int ng = K >> 5;            // K is a multiple of 32 on every call site
-    const int total = ntaps * ng;
-    struct Grp { f32x4 a[4]; f32x4 b[4][NT]; };
-    auto fetch = [&](int f, Grp& gq) __attribute__((always_inline)) {
-        int j = 0, g = f;
-#pragma unroll
-        for (int t = 1; t < MAXTAPS; ++t)
-            if (g >= ng && t < ntaps) { g -= ng; j = t; }
-        const float* ar = a_rows[0];
-#pragma unroll
-        for (int t = 1; t < MAXTAPS; ++t)
-            if (j == t) ar = a_rows[t];
-        const float* wj = W + (long)j * w_tap_stride;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            gq.a[q] = ar ? ld4(ar + 32 * g + 8 * q) : zero4();
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) gq.b[q][nt] = wok[nt] ? ld4(wj + wofs[nt] + 32 * g + 8 * q) : zero4();
-        }
-    };
-    auto mma = [&](const Grp& gq) __attribute__((always_inline)) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) acc[nt] = mfma32(gq.a[q][s], gq.b[q][nt][s], acc[nt]);
-            }
-        }
-    };
-    Grp g0, g1;
-    fetch(0, g0);
-    int f = 0;
-    for (; f + 2 <= total; f += 2) {   // two groups per trip: the buffers alternate without register copies
-        fetch(f + 1, g1);
-        mma(g0);
-        if (f + 2 < total) fetch(f + 2, g0);
-        mma(g1);
-    }
-    if (f < total) mma(g0);
 }
 
 template <int NT>
-__device__ __forceinline__ void wave_gemm(f32x16 (&acc)[NT], const float* a_row, int K, const float* __restrict__ W,
-                                          int ldw, int wcol0, int n0, int n_valid, int lane) {
-    const float* const rows[1] = {a_row};
-    wave_gemm_taps<NT, 1>(acc, rows, 1, K, W, 0, ldw, wcol0, n0, n_valid, lane);
+__device__ __forceinline__ void wave_grp_mma(f32x16 (&acc)[NT], const WaveGrp<NT>& gq) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[nt] = mfma32(gq.a[q][s], gq.b[q][nt][s], acc[nt]);
+        }
+    }
+}
+
+template <int NT, int MAXTAPS, int KG, bool MASKED>
+__device__ __forceinline__ void wave_gemm_taps(f32x16 (&acc)[NT], const float* const (&a_rows)[MAXTAPS],
+                                               const bool (&a_ok)[MAXTAPS], int ntaps, const float* __restrict__ Wp,
+                                               long w_tap_stride, int ntw, int kc0, int nt0, int lane) {
+    bool wok[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) wok[nt] = nt0 + nt < ntw;
+    const float* wl = Wp + ((long)kc0 * ntw + nt0) * 256 + 4 * lane;
+    WaveGrp<NT> g0, g1;
+    wave_grp_fetch<NT, MASKED>(g0, a_rows[0], a_ok[0], 0, wl, ntw, wok);
+    if constexpr (KG % 2 == 0 && KG >= 4) {
+        // taps unrolled, group pairs of one tap in a rolled loop (code size); the tap boundary prefetch is static
+#pragma unroll
+        for (int j = 0; j < MAXTAPS; ++j) {
+            if (j < ntaps) {
+                const float* wj = wl + (long)j * w_tap_stride;
+                for (int g = 0; g < KG; g += 2) {
+                    wave_grp_fetch<NT, MASKED>(g1, a_rows[j], a_ok[j], g + 1, wj, ntw, wok);
+                    wave_grp_mma<NT>(acc, g0);
+                    if (g + 2 < KG) wave_grp_fetch<NT, MASKED>(g0, a_rows[j], a_ok[j], g + 2, wj, ntw, wok);
+                    else if (j + 1 < MAXTAPS && j + 1 < ntaps)
+                        wave_grp_fetch<NT, MASKED>(g0, a_rows[j + 1 < MAXTAPS ? j + 1 : j], a_ok[j + 1 < MAXTAPS ? j + 1 : j], 0,
+                                                   wj + w_tap_stride, ntw, wok);
+                    wave_grp_mma<NT>(acc, g1);
+                }
+            }
+        }
+    } else {
+        // fully unrolled: step n = j*KG + g; buffer parity and tap index are compile-time
+#pragma unroll
+        for (int n = 0; n < MAXTAPS * KG; ++n) {
+            const int j = n / KG;
+            const int jn = (n + 1) / KG < MAXTAPS ? (n + 1) / KG : MAXTAPS - 1, gn = (n + 1) % KG;
+            if (j < ntaps) {
+                if (n + 1 < MAXTAPS * KG && jn < ntaps) {
+                    if (n & 1) wave_grp_fetch<NT, MASKED>(g0, a_rows[jn], a_ok[jn], gn, wl + (long)jn * w_tap_stride, ntw, wok);
+                    else wave_grp_fetch<NT, MASKED>(g1, a_rows[jn], a_ok[jn], gn, wl + (long)jn * w_tap_stride, ntw, wok);
+                }
+                if (n & 1) wave_grp_mma<NT>(acc, g1);
+                else wave_grp_mma<NT>(acc, g0);
+            }
+        }
+    }
+}
+
+// single-tap GEMM with a run-time K (a multiple of 32); a_row must be readable, ok = false -> zero row
+template <int NT>
+__device__ __forceinline__ void wave_gemm(f32x16 (&acc)[NT], const float* a_row, bool ok, int K, const float* __restrict__ Wp,
+                                          int ntw, int kc0, int nt0, int lane) {
+    bool wok[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) wok[nt] = nt0 + nt < ntw;
+    const float* wl = Wp + ((long)kc0 * ntw + nt0) * 256 + 4 * lane;
+    const int ng = K >> 5;
+    WaveGrp<NT> g0, g1;
+    wave_grp_fetch<NT, true>(g0, a_row, ok, 0, wl, ntw, wok);
+    int f = 0;
+    for (; f + 2 <= ng; f += 2) {   // two groups per trip: the buffers alternate without register copies
+        wave_grp_fetch<NT, true>(g1, a_row, ok, f + 1, wl, ntw, wok);
+        wave_grp_mma<NT>(acc, g0);
+        if (f + 2 < ng) wave_grp_fetch<NT, true>(g0, a_row, ok, f + 2, wl, ntw, wok);
+        wave_grp_mma<NT>(acc, g1);
+    }
+    if (f < ng) wave_grp_mma<NT>(acc, g0);
 }
 
 // C/D-layout accumulators -> LDS tile rows [0,32): tile[row][col0 + 32nt + i]

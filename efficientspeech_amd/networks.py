@@ -86,6 +86,15 @@ def _pack_conv(lib, stream, w, transposed=False):
     return dst, w
 
 
+def _pack_bfrag(lib, stream, w):
+    """(n,k) Linear weight or tap-major (taps,n,k) conv weight -> MFMA B-fragment order (include/esmi.h)."""
+    w = _f32(w)
+    taps, n, k = (1, *w.shape) if w.dim() == 2 else w.shape
+    dst = torch.empty(lib.esmi_pack_bfrag_floats(n, k, taps), dtype=torch.float32, device=w.device)
+    lib.esmi_pack_bfrag_f32(_ptr(w), _ptr(dst), n, k, taps, stream)
+    return dst
+
+
 # --------------------------------------------------------------------------- parameter containers
 class SelfAttention(nn.Module):
     """Parameters of blocks.py:32-41 (qkv bias-free; every head is full width: qkv = 3*h*dim)."""
@@ -155,6 +164,9 @@ class Encoder(nn.Module):
                          mlp1_w=_f32(ffn.mlp1.weight), mlp1_b=_f32(ffn.mlp1.bias), conv_w=cw,
                          conv_b=_f32(ffn.conv.bias), mlp2_w=_f32(ffn.mlp2.weight), mlp2_b=_f32(ffn.mlp2.bias),
                          ln1_g=_f32(n1.weight), ln1_b=_f32(n1.bias), ln2_g=_f32(n2.weight), ln2_b=_f32(n2.bias))
+                for name in ("merge_w", "merge1_w", "qkv_w", "proj_w", "mlp1_w", "conv_w", "mlp2_w"):
+                    v = t[name]
+                    t[name + "p"] = _pack_bfrag(lib, stream, v.reshape(v.shape[0], v.shape[1]) if name == "merge1_w" else v)
                 keep.extend(t.values())
                 out.append((_lib.EncoderBlockWeights(**{k: _ptr(v) for k, v in t.items()}), keep))
             return out, _f32(self.embed.weight)
@@ -234,6 +246,7 @@ class AcousticDecoder(nn.Module):
                  conv2_w=c2, conv2_b=_f32(self.conv2[0].bias), ln2_g=_f32(self.norm2.weight), ln2_b=_f32(self.norm2.bias),
                  lin_w=_f32(self.linear.weight), lin_b=_f32(self.linear.bias),
                  bins=None if bins is None else _f32(bins), emb=None if emb is None else _f32(emb.weight))
+        t["conv1_wp"], t["conv2_wp"] = _pack_bfrag(lib, stream, c1), _pack_bfrag(lib, stream, c2)
         return _lib.PredictorWeights(**{k: _ptr(v) for k, v in t.items()}), list(t.values())
 
 
@@ -258,16 +271,19 @@ class Fuse(nn.Module):
             keep = []
             for i, (lin, up) in enumerate(self.mlps):
                 lw, lb = _f32(lin.weight), _f32(lin.bias)
-                keep += [lw, lb]
-                w.mlp_w[i], w.mlp_b[i] = _ptr(lw), _ptr(lb)
+                lwp = _pack_bfrag(lib, stream, lw)
+                keep += [lw, lb, lwp]
+                w.mlp_w[i], w.mlp_b[i], w.mlp_wp[i] = _ptr(lw), _ptr(lb), _ptr(lwp)
                 if isinstance(up, nn.ConvTranspose1d):
                     uw, _ = _pack_conv(lib, stream, up.weight, transposed=True)
                     ub = _f32(up.bias)
-                    keep += [uw, ub]
-                    w.up_w[i], w.up_b[i] = _ptr(uw), _ptr(ub)
+                    uwp = _pack_bfrag(lib, stream, uw)
+                    keep += [uw, ub, uwp]
+                    w.up_w[i], w.up_b[i], w.up_wp[i] = _ptr(uw), _ptr(ub), _ptr(uwp)
             fw, fb = _f32(self.fuse.weight), _f32(self.fuse.bias)
-            keep += [fw, fb]
-            w.fuse_w, w.fuse_b = _ptr(fw), _ptr(fb)
+            fwp = _pack_bfrag(lib, stream, fw)
+            keep += [fw, fb, fwp]
+            w.fuse_w, w.fuse_b, w.fuse_wp = _ptr(fw), _ptr(fb), _ptr(fwp)
             return w, keep
         return self._cache.get(list(self.parameters()), build)
 

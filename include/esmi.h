@@ -18,6 +18,9 @@
  *  - conv weights are taken TAP-MAJOR (k, Cout, Cin); use esmi_pack_conv_weight_f32 /
  *    esmi_pack_convT_weight_f32 once at checkpoint-load time to convert from the checkpoint
  *    layouts (Cout, Cin, k) / (Cin, Cout, k).  nn.Linear weights (Cout, Cin) are used as stored.
+ *  - the fused (wave-chain) encoder-side kernels additionally take every GEMM weight in MFMA
+ *    B-fragment order (the `*_wp` fields, made once with esmi_pack_bfrag_f32): one operand fetch of a
+ *    wave is then a single coalesced 1 KiB load.  A NULL `*_wp` selects the one-kernel-per-op plan.
  */
 #ifndef ESMI_H
 #define ESMI_H
@@ -57,6 +60,13 @@ int esmi_pack_conv_weight_f32(const float* src, float* dst, int cout, int cin, i
 /* nn.ConvTranspose1d weight (Cin, Cout, k) -> (k, Cout, Cin)   [networks.py:183] */
 int esmi_pack_convT_weight_f32(const float* src, float* dst, int cin, int cout, int k, esmi_stream_t stream);
 
+/* MFMA B-fragment order of `taps` row-major (n, k) matrices (k a multiple of 8), NT = ceil(n/32):
+ *   dst[(((t*(k/8) + kc)*NT + nt)*64 + lane)*4 + s] = src[t][32nt + (lane&31)][8kc + 4(lane>>5) + s]   (0 for rows >= n)
+ * src is an nn.Linear weight (taps = 1) or a tap-major conv weight (k_taps, Cout, Cin).
+ * dst holds esmi_pack_bfrag_floats(n, k, taps) = taps * k * 32 * NT floats.                     */
+size_t esmi_pack_bfrag_floats(int n, int k, int taps);
+int esmi_pack_bfrag_f32(const float* src, float* dst, int n, int k, int taps, esmi_stream_t stream);
+
 /* ------------------------------------------------------------------ Encoder block
  * One pass of the loop body of Encoder.forward, layers/networks.py:62-85:
  *   merge convs (dense Conv1d k/stride, then 1x1, both bias-free) -> SelfAttention
@@ -79,6 +89,15 @@ typedef struct esmi_encoder_block_weights {
     const float* ln1_b;
     const float* ln2_g;    /* attn_blocks.{i}.5.{weight,bias} */
     const float* ln2_b;
+    /* esmi_pack_bfrag_f32 of the seven matrices above (merge_w / conv_w with taps = kernel / 3);
+     * all non-NULL enables the fused kernels, any NULL -> one kernel per op.                 */
+    const float* merge_wp;
+    const float* merge1_wp;
+    const float* qkv_wp;
+    const float* proj_wp;
+    const float* mlp1_wp;
+    const float* conv_wp;
+    const float* mlp2_wp;
 } esmi_encoder_block_weights;
 
 typedef struct esmi_encoder_block_shape {
@@ -113,6 +132,9 @@ typedef struct esmi_fuse_weights {
     const float* up_b[ESMI_MAX_DEPTH];
     const float* fuse_w;                  /* (dim, depth*dim)    <- fuse.fuse.weight       */
     const float* fuse_b;
+    const float* mlp_wp[ESMI_MAX_DEPTH];  /* esmi_pack_bfrag_f32 of mlp_w / up_w (taps = kernel) / fuse_w; */
+    const float* up_wp[ESMI_MAX_DEPTH];   /* used by esmi_fuse_variance_adaptor_f32's fused kernel,        */
+    const float* fuse_wp;                 /* NULL -> unfused plan                                          */
 } esmi_fuse_weights;
 size_t esmi_fuse_workspace_bytes(int B, int T, int dim, int depth);
 int esmi_fuse_f32(const esmi_fuse_weights* w, int depth, int dim, int kernel, int B, int T,
@@ -141,6 +163,8 @@ typedef struct esmi_predictor_weights {
     const float* lin_b;   /* (1) */
     const float* bins;    /* (dim-1) bucket edges  (pitch / energy), NULL for duration */
     const float* emb;     /* (dim, dim) embedding  (pitch / energy), NULL for duration */
+    const float* conv1_wp; /* esmi_pack_bfrag_f32 of conv1_w / conv2_w (taps = 3); NULL -> unfused plan */
+    const float* conv2_wp;
 } esmi_predictor_weights;
 size_t esmi_variance_adaptor_workspace_bytes(int B, int T, int dim);
 int esmi_variance_adaptor_f32(const esmi_predictor_weights* pitch, const esmi_predictor_weights* energy,

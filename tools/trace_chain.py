@@ -12,11 +12,11 @@ net = build_phoneme2mel(cfg); load_numpy_state_dict(net, synth_state_dict(cfg));
 ids, mask = synth_phonemes(B, T, 1)
 x = {"phoneme": torch.from_numpy(ids).cuda(), "phoneme_mask": torch.from_numpy(mask).cuda(),
      "duration_forced": torch.full((B, T), 6, dtype=torch.int32, device="cuda"), "max_mel_len": 768}
-tr = torch.zeros((4, 64), dtype=torch.int64, device="cuda")
+tr = torch.zeros((6, 64), dtype=torch.int64, device="cuda")
 lib.esmi_dev_set_chain_trace.argtypes = [C.c_void_p]
 for _ in range(3): net(x)
 lib.esmi_dev_set_chain_trace(tr.data_ptr()); net(x); torch.cuda.synchronize()
 t = tr.cpu().numpy()
-for slot, name in ((0, "E2 blk0 (NC=1)"), (1, "E2 blk1 (NC=2)"), (2, "E3 fuse+VA")):
+for slot, name in ((0, "E2 blk0 (NC=1)"), (1, "E2 blk1 (NC=2)"), (2, "E3 fuse+VA"), (3, "E1 blk0 merge+qkv"), (4, "E1 blk1 merge+qkv")):
     v = t[slot]; n = int((v != 0).sum())
     print(name, "total", v[n - 1] - v[0], "deltas", np.diff(v[:n]).tolist())
