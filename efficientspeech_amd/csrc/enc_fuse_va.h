@@ -90,7 +90,9 @@ __global__ __launch_bounds__(64, ESMI_E3_WPS) void enc_fuse_va_kernel(const Fuse
     {   // level 0: Linear(dim, dim) on f_0 rows
         zero_tiles<ND>(a);
         const float* arow = p.feats[0] + ((long)b * p.n_i[0] + (in_i ? pos_i : 0)) * DIM + 4 * h2;
-        wave_gemm<ND>(a, arow, in_i, DIM, p.mlp_w[0], ND, 0, 0, lane);
+        WaveGrp<ND> gw;
+        wave_prefetch<ND>(gw, p.mlp_w[0], ND, 0, 0, lane);
+        wave_gemm<ND>(a, gw, arow, in_i, DIM, p.mlp_w[0], ND, 0, 0, lane);
 #pragma unroll
         for (int nt = 0; nt < ND; ++nt) {
             const float bc = p.mlp_b[0][32 * nt + i];
@@ -106,7 +108,9 @@ __global__ __launch_bounds__(64, ESMI_E3_WPS) void enc_fuse_va_kernel(const Fuse
         const int n = n_base + i;
         const bool n_ok = n >= 0 && n < nl;
         const float* arow = p.feats[lv] + ((long)b * nl + (n_ok ? n : 0)) * cl + 4 * h2;
-        wave_gemm<ND>(a, arow, n_ok, cl, p.mlp_w[lv], ND, 0, 0, lane);
+        WaveGrp<ND> gw;
+        wave_prefetch<ND>(gw, p.mlp_w[lv], ND, 0, 0, lane);
+        wave_gemm<ND>(a, gw, arow, n_ok, cl, p.mlp_w[lv], ND, 0, 0, lane);
 #pragma unroll
         for (int nt = 0; nt < ND; ++nt) {
             const float bc = p.mlp_b[lv][32 * nt + i];
@@ -130,7 +134,9 @@ __global__ __launch_bounds__(64, ESMI_E3_WPS) void enc_fuse_va_kernel(const Fuse
                 tok[j] = j < p.kernel && q >= 0 && (q - nq * s) == 0 && nq < nl;
                 taps[j] = tmp + (tok[j] ? nq - n_base : 0) * LDD + 4 * h2;
             }
-            wave_gemm_taps<ND, 7, ND, true>(a, taps, tok, p.kernel, p.up_w[lv], (long)DIM * DIM, ND, 0, 0, lane);
+            WaveGrp<ND> gu;
+            wave_prefetch<ND>(gu, p.up_w[lv], ND, 0, 0, lane);
+            wave_gemm_taps<ND, 7, ND, true>(a, gu, taps, tok, p.kernel, p.up_w[lv], (long)DIM * DIM, ND, 0, 0, lane);
         }
 #pragma unroll
         for (int nt = 0; nt < ND; ++nt) {
@@ -142,7 +148,11 @@ __global__ __launch_bounds__(64, ESMI_E3_WPS) void enc_fuse_va_kernel(const Fuse
     }
     __syncthreads();
     zero_tiles<ND>(a);
-    wave_gemm<ND>(a, cat + i * ldc + 4 * h2, true, p.depth * DIM, p.fuse_w, ND, 0, 0, lane);
+    {
+        WaveGrp<ND> gw;
+        wave_prefetch<ND>(gw, p.fuse_w, ND, 0, 0, lane);
+        wave_gemm<ND>(a, gw, cat + i * ldc + 4 * h2, true, p.depth * DIM, p.fuse_w, ND, 0, 0, lane);
+    }
 #pragma unroll
     for (int nt = 0; nt < ND; ++nt) {
         const int col = 32 * nt + i;
@@ -183,7 +193,9 @@ __global__ __launch_bounds__(64, ESMI_E3_WPS) void enc_fuse_va_kernel(const Fuse
         zero_tiles<ND>(c);
         {
             const float* const taps[3] = {f_row - LDD, f_row, f_row + LDD};
-            wave_gemm_taps<ND, 3, ND, false>(c, taps, tok3, 3, w.conv1_w, (long)DIM * DIM, ND, 0, 0, lane);
+            WaveGrp<ND> gw;
+            wave_prefetch<ND>(gw, w.conv1_w, ND, 0, 0, lane);
+            wave_gemm_taps<ND, 3, ND, false>(c, gw, taps, tok3, 3, w.conv1_w, (long)DIM * DIM, ND, 0, 0, lane);
         }
 #pragma unroll
         for (int nt = 0; nt < ND; ++nt) {
@@ -204,7 +216,9 @@ __global__ __launch_bounds__(64, ESMI_E3_WPS) void enc_fuse_va_kernel(const Fuse
         zero_tiles<ND>(c);
         {
             const float* const taps[3] = {t_row - LDD, t_row, t_row + LDD};
-            wave_gemm_taps<ND, 3, ND, false>(c, taps, tok3, 3, w.conv2_w, (long)DIM * DIM, ND, 0, 0, lane);
+            WaveGrp<ND> gw;
+            wave_prefetch<ND>(gw, w.conv2_w, ND, 0, 0, lane);
+            wave_gemm_taps<ND, 3, ND, false>(c, gw, taps, tok3, 3, w.conv2_w, (long)DIM * DIM, ND, 0, 0, lane);
         }
         ESMI_CT();   // conv2 done
 #pragma unroll

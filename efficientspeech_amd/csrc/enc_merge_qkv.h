@@ -57,7 +57,11 @@ __global__ __launch_bounds__(64, ESMI_E1_WPS) void enc_merge_qkv_kernel(const En
         }
     }
     ESMI_CT();
-    wave_gemm_taps<NCI, 5, NCI, true>(a1, taps, tok, p.k, p.merge_w, (long)CIN * CIN, NCI, 0, 0, lane);
+    WaveGrp<NCI> gc;
+    wave_prefetch<NCI>(gc, p.merge_w, NCI, 0, 0, lane);
+    wave_gemm_taps<NCI, 5, NCI, true>(a1, gc, taps, tok, p.k, p.merge_w, (long)CIN * CIN, NCI, 0, 0, lane);
+    WaveGrp<NC> g1x;
+    wave_prefetch<NC>(g1x, p.merge1_w, NC, 0, 0, lane);
     ESMI_CT();
     tile_store<NCI>(buf, LD, 0, a1, lane);
     __syncthreads();
@@ -65,7 +69,7 @@ __global__ __launch_bounds__(64, ESMI_E1_WPS) void enc_merge_qkv_kernel(const En
     // ---- 1x1 conv -> x
     f32x16 x[NC];
     zero_tiles<NC>(x);
-    wave_gemm<NC>(x, a_row, true, CIN, p.merge1_w, NC, 0, 0, lane);
+    wave_gemm<NC>(x, g1x, a_row, true, CIN, p.merge1_w, NC, 0, 0, lane);
     ESMI_CT();
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -84,7 +88,9 @@ __global__ __launch_bounds__(64, ESMI_E1_WPS) void enc_merge_qkv_kernel(const En
     for (int n0 = 0; n0 < nq; n0 += 128) {
         f32x16 q[4];
         zero_tiles<4>(q);
-        wave_gemm<4>(q, a_row, true, C, p.qkv_w, nq >> 5, 0, n0 >> 5, lane);
+        WaveGrp<4> gq;
+        wave_prefetch<4>(gq, p.qkv_w, nq >> 5, 0, n0 >> 5, lane);
+        wave_gemm<4>(q, gq, a_row, true, C, p.qkv_w, nq >> 5, 0, n0 >> 5, lane);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int t = t0 + tile_row(r, lane);

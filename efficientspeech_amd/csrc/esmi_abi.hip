@@ -110,10 +110,24 @@ bool enc_attn_ffn_supported(int C, int N, int expansion) {
 int launch_enc_attn_ffn(const EncAttnFfnP& p, int expansion, hipStream_t st) {
     if ((p.C & 31) || p.N > 256) return ESMI_ERR_UNSUPPORTED;
     const int nc = p.C / 32, nkt = p.N <= 64 ? 2 : (p.N <= 128 ? 4 : 8);
-    dim3 grid(p.B * p.tiles_per_b), block(64);
-    const int lds = 34 * (p.C * expansion + 4) * (int)sizeof(float);
+    int nw, wgs, useful, halo;
+    enc_attn_ffn_plan(p.N, p.C * expansion + 4, &nw, &wgs, &useful, &halo);
+    EncAttnFfnP q = p;
+    q.wgs_per_b = wgs; q.useful = useful; q.halo = halo;
+    dim3 grid(p.B * wgs), block(64 * nw);
+    const int lds = (32 * nw + 2) * (p.C * expansion + 4) * (int)sizeof(float);
 #define ESMI_E2(NKT, NC, E) \
-    if (nkt == NKT && nc == NC && expansion == E) { ESMI_LAUNCH((enc_attn_ffn_kernel<NKT, NC, E>), grid, block, lds, st, p); return launch_status(); }
+    if (nkt == NKT && nc == NC && expansion == E) {                                                                            \
+        static bool attr_set = false; /* once per instantiation: keeps the call out of hipGraph captures */                    \
+        if (!attr_set && lds > 48 * 1024) {                                                                                    \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(enc_attn_ffn_kernel<NKT, NC, E>),                 \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                       \
+            if (e != hipSuccess) return (int)e;                                                                                \
+            attr_set = true;                                                                                                   \
+        }                                                                                                                      \
+        ESMI_LAUNCH((enc_attn_ffn_kernel<NKT, NC, E>), grid, block, lds, st, q);                                               \
+        return launch_status();                                                                                                \
+    }
 #define ESMI_E2K(NC, E) ESMI_E2(2, NC, E) ESMI_E2(4, NC, E) ESMI_E2(8, NC, E)
     ESMI_E2K(1, 1) ESMI_E2K(2, 1) ESMI_E2K(4, 1) ESMI_E2K(4, 2)
 #undef ESMI_E2K
@@ -263,7 +277,7 @@ int esmi_encoder_block_f32(const esmi_encoder_block_weights* w, const esmi_encod
         f.proj_w = w->proj_wp; f.proj_b = w->proj_b; f.ln1_g = w->ln1_g; f.ln1_b = w->ln1_b;
         f.mlp1_w = w->mlp1_wp; f.mlp1_b = w->mlp1_b; f.conv_w = w->conv_wp; f.conv_b = w->conv_b;
         f.mlp2_w = w->mlp2_wp; f.mlp2_b = w->mlp2_b; f.ln2_g = w->ln2_g; f.ln2_b = w->ln2_b;
-        f.mask = mask; f.out = x_out; f.tiles_per_b = (n + kEncTileRows - 1) / kEncTileRows;
+        f.mask = mask; f.out = x_out;
         return launch_enc_attn_ffn(f, s->expansion, st);
     }
     // softmax(q k^T scale) v, blocks.py:49-64

@@ -220,6 +220,62 @@ __device__ __forceinline__ int opaque_i(int v) {
     return v;
 }
 
+// ---- bounds-checked buffer access (raw buffer resources, stride 0).  An access whose byte offset is not inside
+// [0, bytes) reads 0 / is dropped BY THE HARDWARE, so ragged tile edges need no branch: a branch around a load or a
+// store makes hipcc's s_waitcnt counting fall back to vmcnt(0) for everything still in flight (the number of younger
+// operations is no longer known), which serialises every software pipeline around it.  `kBufOOB` is an offset that is
+// always out of range (tensors here are < 2 GiB).  The base must be wave-uniform.
+constexpr unsigned kBufOOB = 0x80000000u;
+#ifdef ESMI_WAVESIM
+struct BufRsrc { const char* base; unsigned bytes; };
+__device__ __forceinline__ BufRsrc make_rsrc(const void* p, long bytes) {
+    BufRsrc r = {static_cast<const char*>(p), p ? (unsigned)(bytes < 0 ? 0 : (bytes > 0x7fffffffL ? 0x7fffffffL : bytes)) : 0u};
+    return r;
+}
+__device__ __forceinline__ float buf_ld(const BufRsrc& r, unsigned off) {
+    return (off < r.bytes && off + 4u <= r.bytes) ? *reinterpret_cast<const float*>(r.base + off) : 0.0f;
+}
+__device__ __forceinline__ f32x4 buf_ld4(const BufRsrc& r, unsigned off) {
+    f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    return (off < r.bytes && off + 16u <= r.bytes) ? *reinterpret_cast<const f32x4*>(r.base + off) : z;
+}
+__device__ __forceinline__ unsigned buf_ld_u8(const BufRsrc& r, unsigned off) {
+    return off < r.bytes ? (unsigned)*reinterpret_cast<const unsigned char*>(r.base + off) : 0u;
+}
+__device__ __forceinline__ void buf_st(const BufRsrc& r, unsigned off, float v) {
+    if (off < r.bytes && off + 4u <= r.bytes) *reinterpret_cast<float*>(const_cast<char*>(r.base) + off) = v;
+}
+__device__ __forceinline__ void buf_st_i(const BufRsrc& r, unsigned off, int v) {
+    if (off < r.bytes && off + 4u <= r.bytes) *reinterpret_cast<int*>(const_cast<char*>(r.base) + off) = v;
+}
+__device__ __forceinline__ void lds_wave_sync() { wavesim::shfl_i(0, 0); }   // a wave-level collective: all 64 fibers arrive
+#else
+typedef __amdgpu_buffer_rsrc_t BufRsrc;
+__device__ __forceinline__ BufRsrc make_rsrc(const void* p, long bytes) {
+    const int n = p ? (int)(bytes < 0 ? 0 : (bytes > 0x7fffffffL ? 0x7fffffffL : bytes)) : 0;
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, n, 0x00020000);   // gfx9 raw buffer, dword 3
+}
+__device__ __forceinline__ float buf_ld(BufRsrc r, unsigned off) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)off, 0, 0));
+}
+__device__ __forceinline__ f32x4 buf_ld4(BufRsrc r, unsigned off) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0));
+}
+__device__ __forceinline__ unsigned buf_ld_u8(BufRsrc r, unsigned off) {
+    return (unsigned)__builtin_amdgcn_raw_buffer_load_b8(r, (int)off, 0, 0);
+}
+__device__ __forceinline__ void buf_st(BufRsrc r, unsigned off, float v) {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, (int)off, 0, 0);
+}
+__device__ __forceinline__ void buf_st_i(BufRsrc r, unsigned off, int v) {
+    __builtin_amdgcn_raw_buffer_store_b32((unsigned)v, r, (int)off, 0, 0);
+}
+// Hand-off through LDS between lanes of ONE wave (tile_store -> A-fragment reads): LDS operations of a wave execute
+// in issue order, so only the compiler has to be kept from reordering; no s_barrier, and global loads in flight
+// (weight prefetches) stay in flight.
+__device__ __forceinline__ void lds_wave_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+#endif
+
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 __device__ __forceinline__ f32x4 zero4() { f32x4 z = {0.f, 0.f, 0.f, 0.f}; return z; }
 __device__ __forceinline__ f32x16 zero16() {

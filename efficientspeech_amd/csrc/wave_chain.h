@@ -12,7 +12,7 @@
 #ifdef ESMI_CHAIN_TRACE
 // development only: shader-clock stamps of workgroup 7 of each chain kernel -> g_chain_trace[kernel_slot*64 + n]
 extern __device__ long long* g_chain_trace_dev;
-#define ESMI_CT_INIT(slot) int ct_n_ = 0; const bool ct_on_ = blockIdx.x == 7 && (threadIdx.x & 63) == 0; const int ct_slot_ = (slot)
+#define ESMI_CT_INIT(slot) int ct_n_ = 0; const bool ct_on_ = blockIdx.x == 7 && threadIdx.x == 0; const int ct_slot_ = (slot)
 #define ESMI_CT() do { if (ct_on_ && g_chain_trace_dev) g_chain_trace_dev[ct_slot_ * 64 + ct_n_] = (long long)__builtin_amdgcn_s_memtime(); ++ct_n_; } while (0)
 #else
 #define ESMI_CT_INIT(slot) do {} while (0)
@@ -45,16 +45,32 @@ namespace esmi {
 template <int NT>
 struct WaveGrp { f32x4 a[4]; f32x4 b[4][NT]; };
 
+// this lane's base into a packed matrix: column tile nt0 (clamped to the last tile: results of tiles >= ntw are
+// garbage the caller must drop), k-step kc0
+__device__ __forceinline__ const float* wave_wbase(const float* Wp, int ntw, int kc0, int nt0, int lane) {
+    return Wp + ((long)kc0 * ntw + nt0) * 256 + 4 * lane;
+}
+
+// weights of group g (four k-steps) of NT column tiles; tiles beyond the matrix alias its last tile
+template <int NT>
+__device__ __forceinline__ void wave_fetch_b(WaveGrp<NT>& gq, const float* wl, int ntw, int nt0, int g) {
+    const float* wg = wl + (long)(4 * g) * ntw * 256;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int ntc = nt0 + nt < ntw ? nt : ntw - 1 - nt0;   // wave-uniform clamp, no branch around the load
+            gq.b[q][nt] = ld4(wg + (q * ntw + ntc) * 256);
+        }
+    }
+}
+
 template <int NT, bool MASKED>
-__device__ __forceinline__ void wave_grp_fetch(WaveGrp<NT>& gq, const float* ar, bool ok, int g, const float* wj, int ntw,
-                                               const bool (&wok)[NT]) {
-    const float* wg = wj + (long)(4 * g) * ntw * 256;
+__device__ __forceinline__ void wave_fetch_a(WaveGrp<NT>& gq, const float* ar, bool ok, int g) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         gq.a[q] = ld4(ar + 32 * g + 8 * q);
         if (MASKED && !ok) gq.a[q] = zero4();
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) gq.b[q][nt] = wok[nt] ? ld4(wg + (q * ntw + nt) * 256) : zero4();
     }
 }
 
@@ -70,29 +86,40 @@ __device__ __forceinline__ void wave_grp_mma(f32x16 (&acc)[NT], const WaveGrp<NT
     }
 }
 
+// Request the weights of the FIRST group of a GEMM ahead of time (before the tile store / LDS hand-off / reduction that
+// precedes the GEMM), so that every stage of a chain starts with its operands already on the way.
+template <int NT>
+__device__ __forceinline__ void wave_prefetch(WaveGrp<NT>& g0, const float* __restrict__ Wp, int ntw, int kc0, int nt0, int lane) {
+    wave_fetch_b<NT>(g0, wave_wbase(Wp, ntw, kc0, nt0 < ntw ? nt0 : ntw - 1, lane), ntw, nt0 < ntw ? nt0 : ntw - 1, 0);
+}
+
+// g0.b must hold the weights of (tap 0, group 0): wave_prefetch(g0, Wp, ntw, kc0, nt0, lane)
 template <int NT, int MAXTAPS, int KG, bool MASKED>
-__device__ __forceinline__ void wave_gemm_taps(f32x16 (&acc)[NT], const float* const (&a_rows)[MAXTAPS],
+__device__ __forceinline__ void wave_gemm_taps(f32x16 (&acc)[NT], WaveGrp<NT>& g0, const float* const (&a_rows)[MAXTAPS],
                                                const bool (&a_ok)[MAXTAPS], int ntaps, const float* __restrict__ Wp,
                                                long w_tap_stride, int ntw, int kc0, int nt0, int lane) {
-    bool wok[NT];
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) wok[nt] = nt0 + nt < ntw;
-    const float* wl = Wp + ((long)kc0 * ntw + nt0) * 256 + 4 * lane;
-    WaveGrp<NT> g0, g1;
-    wave_grp_fetch<NT, MASKED>(g0, a_rows[0], a_ok[0], 0, wl, ntw, wok);
+    if (nt0 >= ntw) nt0 = ntw - 1;
+    const float* wl = wave_wbase(Wp, ntw, kc0, nt0, lane);
+    WaveGrp<NT> g1;
+    wave_fetch_a<NT, MASKED>(g0, a_rows[0], a_ok[0], 0);
     if constexpr (KG % 2 == 0 && KG >= 4) {
         // taps unrolled, group pairs of one tap in a rolled loop (code size); the tap boundary prefetch is static
 #pragma unroll
         for (int j = 0; j < MAXTAPS; ++j) {
             if (j < ntaps) {
                 const float* wj = wl + (long)j * w_tap_stride;
+                const int jn = j + 1 < MAXTAPS ? j + 1 : j;
                 for (int g = 0; g < KG; g += 2) {
-                    wave_grp_fetch<NT, MASKED>(g1, a_rows[j], a_ok[j], g + 1, wj, ntw, wok);
+                    wave_fetch_b<NT>(g1, wj, ntw, nt0, g + 1);
+                    wave_fetch_a<NT, MASKED>(g1, a_rows[j], a_ok[j], g + 1);
                     wave_grp_mma<NT>(acc, g0);
-                    if (g + 2 < KG) wave_grp_fetch<NT, MASKED>(g0, a_rows[j], a_ok[j], g + 2, wj, ntw, wok);
-                    else if (j + 1 < MAXTAPS && j + 1 < ntaps)
-                        wave_grp_fetch<NT, MASKED>(g0, a_rows[j + 1 < MAXTAPS ? j + 1 : j], a_ok[j + 1 < MAXTAPS ? j + 1 : j], 0,
-                                                   wj + w_tap_stride, ntw, wok);
+                    if (g + 2 < KG) {
+                        wave_fetch_b<NT>(g0, wj, ntw, nt0, g + 2);
+                        wave_fetch_a<NT, MASKED>(g0, a_rows[j], a_ok[j], g + 2);
+                    } else if (j + 1 < MAXTAPS && j + 1 < ntaps) {
+                        wave_fetch_b<NT>(g0, wj + w_tap_stride, ntw, nt0, 0);
+                        wave_fetch_a<NT, MASKED>(g0, a_rows[jn], a_ok[jn], 0);
+                    }
                     wave_grp_mma<NT>(acc, g1);
                 }
             }
@@ -105,8 +132,13 @@ __device__ __forceinline__ void wave_gemm_taps(f32x16 (&acc)[NT], const float* c
             const int jn = (n + 1) / KG < MAXTAPS ? (n + 1) / KG : MAXTAPS - 1, gn = (n + 1) % KG;
             if (j < ntaps) {
                 if (n + 1 < MAXTAPS * KG && jn < ntaps) {
-                    if (n & 1) wave_grp_fetch<NT, MASKED>(g0, a_rows[jn], a_ok[jn], gn, wl + (long)jn * w_tap_stride, ntw, wok);
-                    else wave_grp_fetch<NT, MASKED>(g1, a_rows[jn], a_ok[jn], gn, wl + (long)jn * w_tap_stride, ntw, wok);
+                    if (n & 1) {
+                        wave_fetch_b<NT>(g0, wl + (long)jn * w_tap_stride, ntw, nt0, gn);
+                        wave_fetch_a<NT, MASKED>(g0, a_rows[jn], a_ok[jn], gn);
+                    } else {
+                        wave_fetch_b<NT>(g1, wl + (long)jn * w_tap_stride, ntw, nt0, gn);
+                        wave_fetch_a<NT, MASKED>(g1, a_rows[jn], a_ok[jn], gn);
+                    }
                 }
                 if (n & 1) wave_grp_mma<NT>(acc, g1);
                 else wave_grp_mma<NT>(acc, g0);
@@ -115,22 +147,25 @@ __device__ __forceinline__ void wave_gemm_taps(f32x16 (&acc)[NT], const float* c
     }
 }
 
-// single-tap GEMM with a run-time K (a multiple of 32); a_row must be readable, ok = false -> zero row
+// single-tap GEMM with a run-time K (a multiple of 32); a_row must be readable, ok = false -> zero row.
+// g0.b must hold the weights of group 0 (wave_prefetch).
 template <int NT>
-__device__ __forceinline__ void wave_gemm(f32x16 (&acc)[NT], const float* a_row, bool ok, int K, const float* __restrict__ Wp,
-                                          int ntw, int kc0, int nt0, int lane) {
-    bool wok[NT];
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) wok[nt] = nt0 + nt < ntw;
-    const float* wl = Wp + ((long)kc0 * ntw + nt0) * 256 + 4 * lane;
+__device__ __forceinline__ void wave_gemm(f32x16 (&acc)[NT], WaveGrp<NT>& g0, const float* a_row, bool ok, int K,
+                                          const float* __restrict__ Wp, int ntw, int kc0, int nt0, int lane) {
+    if (nt0 >= ntw) nt0 = ntw - 1;
+    const float* wl = wave_wbase(Wp, ntw, kc0, nt0, lane);
     const int ng = K >> 5;
-    WaveGrp<NT> g0, g1;
-    wave_grp_fetch<NT, true>(g0, a_row, ok, 0, wl, ntw, wok);
+    WaveGrp<NT> g1;
+    wave_fetch_a<NT, true>(g0, a_row, ok, 0);
     int f = 0;
     for (; f + 2 <= ng; f += 2) {   // two groups per trip: the buffers alternate without register copies
-        wave_grp_fetch<NT, true>(g1, a_row, ok, f + 1, wl, ntw, wok);
+        wave_fetch_b<NT>(g1, wl, ntw, nt0, f + 1);
+        wave_fetch_a<NT, true>(g1, a_row, ok, f + 1);
         wave_grp_mma<NT>(acc, g0);
-        if (f + 2 < ng) wave_grp_fetch<NT, true>(g0, a_row, ok, f + 2, wl, ntw, wok);
+        if (f + 2 < ng) {
+            wave_fetch_b<NT>(g0, wl, ntw, nt0, f + 2);
+            wave_fetch_a<NT, true>(g0, a_row, ok, f + 2);
+        }
         wave_grp_mma<NT>(acc, g1);
     }
     if (f < ng) wave_grp_mma<NT>(acc, g0);
