@@ -41,64 +41,70 @@ __global__ __launch_bounds__(64, ESMI_E1_WPS) void enc_merge_qkv_kernel(const En
     // ---- dense k-tap conv (stride s, zero padding)
     f32x16 a1[NCI];
     zero_tiles<NCI>(a1);
+    WaveGrp<NCI> gc;
+    wave_prefetch<NCI>(gc, p.merge_w, NCI, 0, 0, lane);
     const float* taps[5];   // merge kernels are 1, 3 or 5 wide; masked taps point at a readable row
     bool tok[5];
+    int tic[5];
 #pragma unroll
     for (int j = 0; j < 5; ++j) {
         const int ti = t_out * p.stride + j - p.pad;
         tok[j] = j < p.k && t_out < p.n_out && ti >= 0 && ti < p.n_in;
-        const int tic = tok[j] ? ti : 0;
-        if (p.ids) {
-            int id = p.ids[b * p.n_in + tic];
-            if (id < 0 || id >= p.vocab) id = 0;   // the reference raises IndexError; stay in bounds
-            taps[j] = p.table + (long)id * CIN + 4 * h2;
-        } else {
-            taps[j] = p.x_in + ((long)b * p.n_in + tic) * CIN + 4 * h2;
+        tic[j] = tok[j] ? ti : 0;
+    }
+    if (p.ids) {            // block 0: the embedding gather is the conv's A operand
+        int id[5];
+#pragma unroll
+        for (int j = 0; j < 5; ++j) id[j] = p.ids[b * p.n_in + tic[j]];
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            if (id[j] < 0 || id[j] >= p.vocab) id[j] = 0;   // the reference raises IndexError; stay in bounds
+            taps[j] = p.table + (long)id[j] * CIN + 4 * h2;
         }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 5; ++j) taps[j] = p.x_in + ((long)b * p.n_in + tic[j]) * CIN + 4 * h2;
     }
     ESMI_CT();
-    WaveGrp<NCI> gc;
-    wave_prefetch<NCI>(gc, p.merge_w, NCI, 0, 0, lane);
     wave_gemm_taps<NCI, 5, NCI, true>(a1, gc, taps, tok, p.k, p.merge_w, (long)CIN * CIN, NCI, 0, 0, lane);
     WaveGrp<NC> g1x;
     wave_prefetch<NC>(g1x, p.merge1_w, NC, 0, 0, lane);
     ESMI_CT();
     tile_store<NCI>(buf, LD, 0, a1, lane);
-    __syncthreads();
+    lds_wave_sync();
     ESMI_CT();
     // ---- 1x1 conv -> x
     f32x16 x[NC];
     zero_tiles<NC>(x);
     wave_gemm<NC>(x, g1x, a_row, true, CIN, p.merge1_w, NC, 0, 0, lane);
+    const int nq = 3 * p.h * C, ntq = nq >> 5;
+    WaveGrp<4> gq;
+    wave_prefetch<4>(gq, p.qkv_w, ntq, 0, 0, lane);
     ESMI_CT();
+    // rows >= n_out fall off the end of the per-utterance buffers: the stores need no branch
+    const BufRsrc r_xo = make_rsrc(p.x_out + (long)b * p.n_out * C, (long)p.n_out * C * 4);
+    const BufRsrc r_qkv = make_rsrc(p.qkv + (long)b * p.n_out * nq, (long)p.n_out * nq * 4);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-        const int t = t0 + tile_row(r, lane);
-        if (t >= p.n_out) continue;
-        float* orow = p.x_out + ((long)b * p.n_out + t) * C + i;
+        const unsigned off = (unsigned)(((t0 + tile_row(r, lane)) * C + i) * 4);
 #pragma unroll
-        for (int nt = 0; nt < NC; ++nt) orow[32 * nt] = x[nt][r];
+        for (int nt = 0; nt < NC; ++nt) buf_st(r_xo, off + 128u * nt, x[nt][r]);
     }
-    __syncthreads();
+    lds_wave_sync();
     tile_store<NC>(buf, LD, 0, x, lane);
-    __syncthreads();
+    lds_wave_sync();
     ESMI_CT();
     // ---- qkv, 128 output channels per pass
-    const int nq = 3 * p.h * C;
     for (int n0 = 0; n0 < nq; n0 += 128) {
         f32x16 q[4];
         zero_tiles<4>(q);
-        WaveGrp<4> gq;
-        wave_prefetch<4>(gq, p.qkv_w, nq >> 5, 0, n0 >> 5, lane);
-        wave_gemm<4>(q, gq, a_row, true, C, p.qkv_w, nq >> 5, 0, n0 >> 5, lane);
+        wave_gemm<4>(q, gq, a_row, true, C, p.qkv_w, ntq, 0, n0 >> 5, lane);
+        if (n0 + 128 < nq) wave_prefetch<4>(gq, p.qkv_w, ntq, 0, (n0 + 128) >> 5, lane);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int t = t0 + tile_row(r, lane);
-            if (t >= p.n_out) continue;
-            float* orow = p.qkv + ((long)b * p.n_out + t) * nq + n0 + i;
+            const unsigned off = (unsigned)(((t0 + tile_row(r, lane)) * nq + n0 + i) * 4);
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt)
-                if (n0 + 32 * nt + i < nq) orow[32 * nt] = q[nt][r];
+            for (int nt = 0; nt < 4; ++nt) buf_st(r_qkv, n0 + 32 * nt < nq ? off + 128u * nt : kBufOOB, q[nt][r]);
         }
         ESMI_CT();
     }

@@ -437,9 +437,20 @@ int esmi_fuse_variance_adaptor_f32(const esmi_fuse_weights* fw, int depth, int d
         p.mask = mask; p.pitch_t = pitch_target; p.energy_t = energy_target; p.dur_t = duration_target;
         p.feat = feat; p.preds[0] = pitch_pred; p.preds[1] = energy_pred; p.preds[2] = duration_pred;
         p.pitch_idx = pitch_idx; p.energy_idx = energy_idx; p.dur = dur;
-        p.tiles_per_b = (T + kVaTileRows - 1) / kVaTileRows;
-        dim3 grid(B * p.tiles_per_b), block(64);
-        const int lds = fuse_va_lds_floats(dim, depth) * (int)sizeof(float);
+        int nw;
+        fuse_va_plan(T, dim, depth, &nw, &p.wgs_per_b, &p.useful, &p.halo);
+        dim3 grid(B * p.wgs_per_b), block(64 * nw);
+        const int lds = fuse_va_lds_floats(dim, depth, nw) * (int)sizeof(float);
+        static bool attr_set = false;   // once: keeps the call out of hipGraph captures
+        if (!attr_set) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(enc_fuse_va_kernel<1>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e == hipSuccess)
+                e = hipFuncSetAttribute(reinterpret_cast<const void*>(enc_fuse_va_kernel<2>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) return (int)e;
+            attr_set = true;
+        }
         if (dim == 32) ESMI_LAUNCH((enc_fuse_va_kernel<1>), grid, block, lds, S(stream), p);
         else ESMI_LAUNCH((enc_fuse_va_kernel<2>), grid, block, lds, S(stream), p);
         return launch_status();
