@@ -46,6 +46,9 @@ def parse():
     ap.add_argument("--graph", action="store_true",
                     help="replay the forward as two hipGraphs per step instead of eager launches (measured 2.5 %% slower "
                          "on an idle host: the step is GPU-bound; useful when the host is slow)")
+    ap.add_argument("--dec-lds-pad", type=int, default=0,
+                    help="development: extra LDS bytes per decoder workgroup (fewer decoder workgroups per CU, leaves room "
+                         "for the encoder-side kernels of the next step under --two-stream)")
     return ap.parse_args()
 
 
@@ -102,6 +105,9 @@ def main():
     from efficientspeech_amd import CONFIGS, build_phoneme2mel, load_numpy_state_dict
     from efficientspeech_amd.synth import synth_state_dict, synth_phonemes
     from efficientspeech_amd.sharded import ShardedMelPipeline
+    if a.dec_lds_pad:
+        from efficientspeech_amd import _lib
+        _lib.load().esmi_dev_set_decoder_lds_pad(int(a.dec_lds_pad))
     cfg = CONFIGS[a.config]
     B = a.batch or {"tiny": 256, "small": 256, "base": 512}[a.config]
     T = a.phonemes or {"tiny": 128, "small": 256, "base": 256}[a.config]

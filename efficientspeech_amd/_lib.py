@@ -24,11 +24,12 @@ fp = C.c_void_p  # device pointers travel as integers
 class EncoderBlockWeights(C.Structure):
     _fields_ = [(n, fp) for n in ("merge_w", "merge1_w", "qkv_w", "proj_w", "proj_b", "mlp1_w", "mlp1_b",
                                   "conv_w", "conv_b", "mlp2_w", "mlp2_b", "ln1_g", "ln1_b", "ln2_g", "ln2_b",
-                                  "merge_wp", "merge1_wp", "qkv_wp", "proj_wp", "mlp1_wp", "conv_wp", "mlp2_wp")]
+                                  "merge_cwp", "qkv_wp", "proj_wp", "mlp1_wp", "conv_wp", "mlp2_wp")]
 
 
 class EncoderBlockShape(C.Structure):
-    _fields_ = [(n, C.c_int) for n in ("B", "n_in", "c_in", "c_out", "heads", "kernel", "stride", "expansion", "vocab")]
+    _fields_ = [(n, C.c_int) for n in ("B", "n_in", "c_in", "c_out", "heads", "kernel", "stride", "expansion", "vocab",
+                                       "mask_pool", "mask_len")]
 
 
 class FuseWeights(C.Structure):
@@ -59,7 +60,7 @@ EXPORTS = (
     "esmi_fuse_workspace_bytes", "esmi_fuse_f32", "esmi_variance_adaptor_workspace_bytes",
     "esmi_variance_adaptor_f32", "esmi_length_regulate_i32", "esmi_length_regulator_indices_i32",
     "esmi_upsample_f32", "esmi_mel_decoder_blob_bytes", "esmi_mel_decoder_pack_f32", "esmi_mel_decoder_f32",
-    "esmi_mask_rows_f32", "esmi_pack_bfrag_floats", "esmi_pack_bfrag_f32",
+    "esmi_mask_rows_f32", "esmi_pack_bfrag_floats", "esmi_pack_bfrag_f32", "esmi_compose_merge_f32",
 )
 
 
@@ -73,6 +74,7 @@ def bind(lib):
     lib.esmi_pack_bfrag_floats.argtypes = [i, i, i]
     lib.esmi_pack_bfrag_floats.restype = sz
     lib.esmi_pack_bfrag_f32.argtypes = [fp, fp, i, i, i, fp]
+    lib.esmi_compose_merge_f32.argtypes = [fp, fp, i, i, i, fp, fp]
     lib.esmi_encoder_block_workspace_bytes.argtypes = [P(EncoderBlockShape)]
     lib.esmi_encoder_block_workspace_bytes.restype = sz
     lib.esmi_encoder_block_f32.argtypes = [P(EncoderBlockWeights), P(EncoderBlockShape), fp, fp, fp, fp, fp, fp, sz, fp]

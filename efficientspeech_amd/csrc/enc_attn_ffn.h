@@ -36,7 +36,8 @@ struct EncAttnFfnP {
     const float *conv_w, *conv_b;   // (3, E*C, E*C) tap-major
     const float *mlp2_w, *mlp2_b;   // (C, E*C)
     const float *ln2_g, *ln2_b;
-    const unsigned char* mask;      // (B,N) or NULL
+    const unsigned char* mask;      // (B, mask_len) or NULL; row n is padding iff any of mask[n*mask_pool .. +mask_pool) is set / beyond mask_len
+    int mask_pool, mask_len;
     float* out;                     // (B,N,C)
     int wgs_per_b;                  // workgroups per utterance
     int useful;                     // positions stored per workgroup: 32*nw - 2*halo
@@ -79,14 +80,18 @@ __global__ __launch_bounds__(64 * kEncMaxWaves, ESMI_E2_WPS) void enc_attn_ffn_k
     const int ld = 3 * p.h * C;
     const BufRsrc r_qkv = make_rsrc(p.qkv + (long)b * p.N * ld, (long)p.N * ld * 4);
     const BufRsrc r_x = make_rsrc(p.x + (long)b * p.N * C, (long)p.N * C * 4);
-    const BufRsrc r_mask = make_rsrc(p.mask ? p.mask + (long)b * p.N : nullptr, p.N);
+    const BufRsrc r_mask = make_rsrc(p.mask ? p.mask + (long)b * p.mask_len : nullptr, p.mask_len);
     const BufRsrc r_out = make_rsrc(p.out + (long)b * p.N * C, (long)p.N * C * 4);
     ESMI_CT_INIT(NC == 1 ? 0 : 1);
     ESMI_CT();   // 0 start
 
     // ---------------- prologue: everything that does not depend on a result is requested now, nothing is waited for.
     // Rows outside [0, N) are out of range of their buffers: negative positions wrap to huge unsigned offsets.
-    const unsigned mb = buf_ld_u8(r_mask, (unsigned)pos_i);
+    unsigned mb = 0;                // blocks.py:51-57: the mask is padded with True and max-pooled by the block's total stride
+    for (int q = 0; q < p.mask_pool; ++q) {
+        const int idx = pos_i * p.mask_pool + q;
+        mb |= buf_ld_u8(r_mask, pos_i >= 0 ? (unsigned)idx : kBufOOB) | (unsigned)(p.mask && pos_i >= 0 && idx >= p.mask_len);
+    }
     const unsigned q_off = (unsigned)((pos_i * ld + 4 * h2) * 4);
     unsigned k_off[NKT];
 #pragma unroll
@@ -205,7 +210,7 @@ __global__ __launch_bounds__(64 * kEncMaxWaves, ESMI_E2_WPS) void enc_attn_ffn_k
         lds_wave_sync();        // the previous head's proj has finished reading the tile
         tile_store<NC>(buf, LD, 0, o, lane);
         lds_wave_sync();
-        wave_gemm<NC>(y, gp, a_row, true, C, p.proj_w, NC, (hd * C) >> 3, 0, lane);
+        wave_gemm_k<NC, NC>(y, gp, a_row, true, p.proj_w, NC, (hd * C) >> 3, 0, lane);
         if (hd + 1 < p.h) wave_prefetch<NC>(gp, p.proj_w, NC, ((hd + 1) * C) >> 3, 0, lane);
     }
     WaveGrp<NE> gm;                 // mlp1 weights
@@ -249,7 +254,7 @@ __global__ __launch_bounds__(64 * kEncMaxWaves, ESMI_E2_WPS) void enc_attn_ffn_k
     // ---------------- MixFFN: mlp1 -> dense conv k3 -> GELU -> mlp2
     f32x16 m[NE];
     zero_tiles<NE>(m);
-    wave_gemm<NE>(m, gm, a_row, true, C, p.mlp1_w, NE, 0, 0, lane);
+    wave_gemm_k<NE, NC>(m, gm, a_row, true, p.mlp1_w, NE, 0, 0, lane);
     wave_prefetch<NE>(gm, p.conv_w, NE, 0, 0, lane);   // conv weights, tap 0
 #pragma unroll
     for (int nt = 0; nt < NE; ++nt) {
@@ -279,7 +284,7 @@ __global__ __launch_bounds__(64 * kEncMaxWaves, ESMI_E2_WPS) void enc_attn_ffn_k
     ESMI_CT();   // 7 conv + gelu + store
     f32x16 z[NC];
     zero_tiles<NC>(z);
-    wave_gemm<NC>(z, g2, a_row, true, EC, p.mlp2_w, NC, 0, 0, lane);
+    wave_gemm_k<NC, NE>(z, g2, a_row, true, p.mlp2_w, NC, 0, 0, lane);
 #pragma unroll
     for (int nt = 0; nt < NC; ++nt) {
 #pragma unroll
@@ -296,6 +301,290 @@ __global__ __launch_bounds__(64 * kEncMaxWaves, ESMI_E2_WPS) void enc_attn_ffn_k
         const unsigned off = keep ? (unsigned)(((t0 + row) * C + i) * 4) : kBufOOB;
 #pragma unroll
         for (int nt = 0; nt < NC; ++nt) buf_st(r_out, off + 128u * nt, rz[r] ? 0.0f : z[nt][r]);
+    }
+}
+
+}  // namespace esmi
+
+// ---------------------------------------------------------------------------------------------------------------
+// Column-split variant for two-head blocks on short sequences (tiny ES block 1: N = 64, C = 64, h = 2).  With one
+// wave per 32 rows such a block keeps only B*N/32 waves busy (512 of the 1024 SIMDs at B = 256) on a long serial
+// chain.  Here TWO waves share a row tile: wave c computes the attention of head c, then owns half of the output
+// columns of every later GEMM (proj over both heads' contexts, mlp1, conv, mlp2).  What crosses between the two goes
+// through the shared LDS tile (contexts, y1, hidden) or, for the two LayerNorms, as per-row (mean, M2) pairs that are
+// merged with the parallel-variance formula -- both waves compute bit-identical statistics.
+namespace esmi {
+
+constexpr int kEncSplitMaxTiles = 2;     // row tiles per workgroup (2 waves each)
+
+inline void enc_attn_ffn_split_plan(int n, int* nw, int* wgs, int* useful, int* halo) {
+    if (n <= 32 * kEncSplitMaxTiles) { *nw = (n + 31) / 32; *wgs = 1; *useful = 32 * *nw; *halo = 0; return; }
+    *nw = kEncSplitMaxTiles; *useful = 32 * *nw - 2; *wgs = (n + *useful - 1) / *useful; *halo = 1;
+}
+inline int enc_attn_ffn_split_lds_floats(int C, int h, int expansion, int nw) {
+    const int wide = (h * C > expansion * C ? h * C : expansion * C) + 4;
+    return (32 * nw + 2) * wide + nw * 2 * 32 * 2;
+}
+
+// LayerNorm over C = 2 * 32*NH columns of which this wave holds 32*NH; partner statistics through `stats`
+// ([tile][wave][32 rows][2]); two workgroup barriers inside.
+template <int NH>
+__device__ __forceinline__ void layernorm_split(f32x16 (&v)[NH], const float (&gg)[NH], const float (&bb)[NH], float* stats, int rt,
+                                                int c, int lane, float eps = 1e-5f) {
+    const int i = lane & 31;
+    const float inv_h = 1.0f / (float)(32 * NH);
+    float mean_l[16], m2_l[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        float s = 0.0f;
+#pragma unroll
+        for (int nt = 0; nt < NH; ++nt) s += v[nt][r];
+        mean_l[r] = row_sum32(s) * inv_h;
+        float q = 0.0f;
+#pragma unroll
+        for (int nt = 0; nt < NH; ++nt) {
+            const float d = v[nt][r] - mean_l[r];
+            q = fmaf(d, d, q);
+        }
+        m2_l[r] = row_sum32(q);
+    }
+    __syncthreads();            // the statistics buffer is free (previous LayerNorm fully consumed)
+    float* mine = stats + ((rt * 2 + c) * 32) * 2;
+    const float* other = stats + ((rt * 2 + (c ^ 1)) * 32) * 2;
+    if (i == 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            mine[2 * tile_row(r, lane)] = mean_l[r];
+            mine[2 * tile_row(r, lane) + 1] = m2_l[r];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const float mo = other[2 * tile_row(r, lane)], qo = other[2 * tile_row(r, lane) + 1];
+        const float ma = c == 0 ? mean_l[r] : mo, mb = c == 0 ? mo : mean_l[r];   // same operand order in both waves
+        const float qa = c == 0 ? m2_l[r] : qo, qb = c == 0 ? qo : m2_l[r];
+        const float mean = 0.5f * (ma + mb);
+        const float d = mb - ma;
+        const float m2 = (qa + qb) + d * d * (float)(16 * NH);                      // n_a n_b / (n_a + n_b) = 32*NH / 2
+        const float rstd = 1.0f / sqrtf(m2 * (0.5f * inv_h) + eps);
+#pragma unroll
+        for (int nt = 0; nt < NH; ++nt) v[nt][r] = fmaf((v[nt][r] - mean) * rstd, gg[nt], bb[nt]);
+    }
+}
+
+template <int NKT, int NC, int E>   // h == 2; keys <= 32*NKT, C = 32*NC (NC even), MixFFN hidden = E*C
+__global__ __launch_bounds__(128 * kEncSplitMaxTiles, ESMI_E2_WPS) void enc_attn_ffn_split_kernel(const EncAttnFfnP p) {
+    constexpr int NE = NC * E, NCH = NC / 2, NEH = NE / 2;
+    constexpr int C = 32 * NC, EC = 32 * NE, HC = 2 * C;
+    constexpr int LD = (HC > EC ? HC : EC) + 4;
+    ESMI_DYN_LDS(lds);              // [32*nw + 2][LD] shared tile (zero rows around), then the LayerNorm statistics
+    const int nw = (int)(blockDim.x >> 7), w = wave_id();
+    const int rt = w >> 1, c = w & 1;                       // row tile, column half / head
+    const int lane = lane_id(), i = lane & 31, h2 = lane >> 5;
+    const int b = (int)blockIdx.x / p.wgs_per_b, wg = (int)blockIdx.x - b * p.wgs_per_b;
+    const int r0 = 32 * rt;
+    const int t0 = wg * p.useful - p.halo + r0;
+    float* buf = lds + LD * (1 + r0);
+    float* stats = lds + (32 * nw + 2) * LD;
+    for (int cc = (int)threadIdx.x; cc < LD; cc += (int)blockDim.x) {
+        lds[cc] = 0.0f;
+        lds[(32 * nw + 1) * LD + cc] = 0.0f;
+    }
+    const int pos_i = t0 + i;
+    const float* a_row = buf + i * LD + 4 * h2;
+    const int ld = 3 * 2 * C;
+    const BufRsrc r_qkv = make_rsrc(p.qkv + (long)b * p.N * ld, (long)p.N * ld * 4);
+    const BufRsrc r_x = make_rsrc(p.x + (long)b * p.N * C, (long)p.N * C * 4);
+    const BufRsrc r_mask = make_rsrc(p.mask ? p.mask + (long)b * p.mask_len : nullptr, p.mask_len);
+    const BufRsrc r_out = make_rsrc(p.out + (long)b * p.N * C, (long)p.N * C * 4);
+    const int c0 = 32 * NCH * c;                            // first output column of this wave (width C stages)
+    const int e0 = 32 * NEH * c;                            // first hidden column of this wave
+
+    // ---------------- prologue loads (nothing waited for)
+    unsigned mb = 0;
+    for (int q = 0; q < p.mask_pool; ++q) {
+        const int idx = pos_i * p.mask_pool + q;
+        mb |= buf_ld_u8(r_mask, pos_i >= 0 ? (unsigned)idx : kBufOOB) | (unsigned)(p.mask && pos_i >= 0 && idx >= p.mask_len);
+    }
+    const unsigned q_off = (unsigned)((pos_i * ld + c * C + 4 * h2) * 4);
+    unsigned k_off[NKT];
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) k_off[kt] = (unsigned)((((32 * kt + i) * ld) + (2 + c) * C + 4 * h2) * 4);
+    const unsigned v_base = (unsigned)(((4 + c) * C + i) * 4);
+    WaveGrp<NCH> gp;
+    wave_prefetch<NCH>(gp, p.proj_w, NC, 0, c * NCH, lane);
+    f32x16 xres[NCH];
+#pragma unroll
+    for (int nt = 0; nt < NCH; ++nt) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) xres[nt][r] = buf_ld(r_x, (unsigned)(((t0 + tile_row(r, lane)) * C + c0 + 32 * nt + i) * 4));
+    }
+    float pb_[NCH], g1_[NCH], be1_[NCH], b2_[NCH], g2_[NCH], be2_[NCH], m1b_[NEH], cb_[NEH];
+#pragma unroll
+    for (int nt = 0; nt < NCH; ++nt) {
+        const int col = c0 + 32 * nt + i;
+        pb_[nt] = p.proj_b[col]; g1_[nt] = p.ln1_g[col]; be1_[nt] = p.ln1_b[col];
+        b2_[nt] = p.mlp2_b[col]; g2_[nt] = p.ln2_g[col]; be2_[nt] = p.ln2_b[col];
+    }
+#pragma unroll
+    for (int nt = 0; nt < NEH; ++nt) {
+        m1b_[nt] = p.mlp1_b[e0 + 32 * nt + i];
+        cb_[nt] = p.conv_b[e0 + 32 * nt + i];
+    }
+
+    // ---------------- attention of head c
+    f32x16 s[NKT];
+    zero_tiles<NKT>(s);
+    for (int kc = 0; kc < (C >> 3); kc += 4) {   // S^T[key][query] = sum_ch K[key][ch] Q[query][ch]
+        f32x4 qv[4], kv[4][NKT];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            qv[g] = buf_ld4(r_qkv, q_off + 32u * (kc + g));
+#pragma unroll
+            for (int kt = 0; kt < NKT; ++kt) kv[g][kt] = buf_ld4(r_qkv, k_off[kt] + 32u * (kc + g));
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+#pragma unroll
+                for (int kt = 0; kt < NKT; ++kt) s[kt] = mfma32(kv[g][kt][t], qv[g][t], s[kt]);
+            }
+        }
+    }
+    struct VG { float v[4][NC]; };
+    auto vfetch = [&](int f, VG& gq) __attribute__((always_inline)) {
+        const int kt = f >> 2, r4 = (f & 3) << 2;
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const int key = 32 * kt + tile_row(r4 + rr, lane);
+#pragma unroll
+            for (int nt = 0; nt < NC; ++nt) gq.v[rr][nt] = buf_ld(r_qkv, v_base + (unsigned)((key * ld + 32 * nt) * 4));
+        }
+    };
+    VG v0, v1;
+    vfetch(0, v0);
+    vfetch(1, v1);
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = 32 * kt + tile_row(r, lane);
+            const float v = key < p.N ? s[kt][r] * p.scale : -INFINITY;
+            s[kt][r] = v;
+            mx = fmaxf(mx, v);
+        }
+    }
+    mx = fmaxf(mx, swap32_f(mx));
+    float den = 0.0f;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float e = expf(s[kt][r] - mx);
+            s[kt][r] = e;
+            den += e;
+        }
+    }
+    den += swap32_f(den);
+    const float inv = 1.0f / den;
+    f32x16 o[NC];
+    zero_tiles<NC>(o);
+#pragma unroll
+    for (int f = 0; f < 4 * NKT; f += 2) {
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+#pragma unroll
+            for (int nt = 0; nt < NC; ++nt) o[nt] = mfma32(s[f >> 2][((f & 3) << 2) + rr] * inv, v0.v[rr][nt], o[nt]);
+        }
+        if (f + 2 < 4 * NKT) vfetch(f + 2, v0);
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+#pragma unroll
+            for (int nt = 0; nt < NC; ++nt)
+                o[nt] = mfma32(s[(f + 1) >> 2][(((f + 1) & 3) << 2) + rr] * inv, v1.v[rr][nt], o[nt]);
+        }
+        if (f + 3 < 4 * NKT) vfetch(f + 3, v1);
+    }
+    tile_store<NC>(buf, LD, c * C, o, lane);     // contexts of both heads side by side: proj's K dimension
+    __syncthreads();
+    // ---------------- proj (this wave's output columns, K = 2C), residual, LN1
+    f32x16 y[NCH];
+    zero_tiles<NCH>(y);
+    wave_gemm_k<NCH, 2 * NC>(y, gp, a_row, true, p.proj_w, NC, 0, c * NCH, lane);
+    WaveGrp<NEH> gm;
+    wave_prefetch<NEH>(gm, p.mlp1_w, NE, 0, c * NEH, lane);
+    const unsigned mbits = (unsigned)ballot64(mb != 0);
+    bool rz[16], rout[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = tile_row(r, lane);
+        const int pos = t0 + row;
+        rout[r] = pos < 0 || pos >= p.N;
+        rz[r] = !rout[r] && ((mbits >> row) & 1u);
+    }
+#pragma unroll
+    for (int nt = 0; nt < NCH; ++nt) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) y[nt][r] += pb_[nt] + xres[nt][r];
+    }
+    layernorm_split<NCH>(y, g1_, be1_, stats, rt, c, lane);   // (its barriers also fence the proj reads of the tile)
+#pragma unroll
+    for (int nt = 0; nt < NCH; ++nt) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            if (rz[r]) y[nt][r] = 0.0f;
+    }
+    tile_store<NCH>(buf, LD, c0, y, lane);
+    __syncthreads();
+    // ---------------- MixFFN
+    f32x16 m[NEH];
+    zero_tiles<NEH>(m);
+    wave_gemm_k<NEH, NC>(m, gm, a_row, true, p.mlp1_w, NE, 0, c * NEH, lane);
+    wave_prefetch<NEH>(gm, p.conv_w, NE, 0, c * NEH, lane);
+#pragma unroll
+    for (int nt = 0; nt < NEH; ++nt) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) m[nt][r] = rout[r] ? 0.0f : m[nt][r] + m1b_[nt];
+    }
+    __syncthreads();            // both waves finished reading y1
+    tile_store<NEH>(buf, LD, e0, m, lane);
+    __syncthreads();            // hidden rows of partner and neighbours in place
+    zero_tiles<NEH>(m);
+    {
+        const float* const taps[3] = {a_row - LD, a_row, a_row + LD};
+        const bool tok[3] = {true, true, true};
+        wave_gemm_taps<NEH, 3, NE, false>(m, gm, taps, tok, 3, p.conv_w, (long)EC * EC, NE, 0, c * NEH, lane);
+    }
+    WaveGrp<NCH> g2;
+    wave_prefetch<NCH>(g2, p.mlp2_w, NC, 0, c * NCH, lane);
+#pragma unroll
+    for (int nt = 0; nt < NEH; ++nt) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) m[nt][r] = gelu_erf_f32(m[nt][r] + cb_[nt]);
+    }
+    __syncthreads();            // every wave has read what it needs of the hidden tile
+    tile_store<NEH>(buf, LD, e0, m, lane);
+    __syncthreads();
+    f32x16 z[NCH];
+    zero_tiles<NCH>(z);
+    wave_gemm_k<NCH, NE>(z, g2, a_row, true, p.mlp2_w, NC, 0, c * NCH, lane);
+#pragma unroll
+    for (int nt = 0; nt < NCH; ++nt) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) z[nt][r] += b2_[nt] + y[nt][r];
+    }
+    layernorm_split<NCH>(z, g2_, be2_, stats, rt, c, lane);
+    const int row_lo = p.halo, row_hi = 32 * nw - p.halo;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = tile_row(r, lane);
+        const bool keep = r0 + row >= row_lo && r0 + row < row_hi && t0 + row >= 0;
+        const unsigned off = keep ? (unsigned)(((t0 + row) * C + c0 + i) * 4) : kBufOOB;
+#pragma unroll
+        for (int nt = 0; nt < NCH; ++nt) buf_st(r_out, off + 128u * nt, rz[r] ? 0.0f : z[nt][r]);
     }
 }
 

@@ -105,7 +105,7 @@ __global__ __launch_bounds__(64 * kVaMaxWaves, ESMI_E3_WPS) void enc_fuse_va_ker
         wave_prefetch<ND>(gw, p.mlp_w[0], ND, 0, 0, lane);
         zero_tiles<ND>(a);
         const float* arow = p.feats[0] + ((long)b * p.n_i[0] + (in_i ? pos_i : 0)) * DIM + 4 * h2;
-        wave_gemm<ND>(a, gw, arow, in_i, DIM, p.mlp_w[0], ND, 0, 0, lane);
+        wave_gemm_k<ND, ND>(a, gw, arow, in_i, p.mlp_w[0], ND, 0, 0, lane);
         if (p.depth > 1) wave_prefetch<ND>(gw, p.mlp_w[1], ND, 0, 0, lane);
         else wave_prefetch<ND>(gw, p.fuse_w, ND, 0, 0, lane);
 #pragma unroll

@@ -1,8 +1,11 @@
 // Fused first half of an encoder block (layers/networks.py:54,64-67 + layers/blocks.py:44):
 //     x   = Conv1x1( Conv1d_k,stride( Embedding(ids) | x_in ) )        both convs dense and bias-free
 //     qkv = Linear(C, 3*h*C, bias=False)(x)
-// one wave per (utterance, 32-position tile); the k-tap conv reads its shifted input rows straight from
-// global memory / the embedding table, the two follow-up GEMMs take their A fragments from the wave's LDS tile.
+// The two merge convolutions are linear with nothing in between, so they are applied as ONE k-tap convolution
+// Cin -> C whose weights W'[j] = W_1x1 . W_merge[j] are composed once per checkpoint (esmi_compose_merge_f32, fp64
+// accumulation): tiny ES block 0 needs 192 instead of 832 MFMAs per tile.  One wave per (utterance, 32-position
+// tile); the conv reads its shifted input rows straight from global memory / the embedding table, the qkv GEMM
+// takes its A fragments from the wave's LDS tile.
 #pragma once
 #include "wave_chain.h"
 
@@ -18,18 +21,31 @@ struct EncMergeP {
     int vocab;
     const float* x_in;     // blocks >= 1: (B, n_in, Cin)
     int B, n_in, n_out, k, stride, pad, h;
-    const float* merge_w;  // (k, Cin, Cin) tap-major     } all three in MFMA B-fragment order
-    const float* merge1_w; // (C, Cin)                    } (esmi_pack_bfrag_f32, see wave_chain.h)
-    const float* qkv_w;    // (3*h*C, C)                  }
+    const float* merge_w;  // (k, C, Cin) composed merge conv  } both in MFMA B-fragment order
+    const float* qkv_w;    // (3*h*C, C)                        } (esmi_pack_bfrag_f32, see wave_chain.h)
     float* x_out;          // (B, n_out, C)
     float* qkv;            // (B, n_out, 3*h*C)
     int tiles_per_b;       // ceil(n_out / 32)
 };
 
+// W'[j][o][i] = sum_m W1[o][m] * Wm[j][m][i]     (fp64 accumulation, once per checkpoint)
+__global__ void compose_merge_kernel(const float* __restrict__ wm, const float* __restrict__ w1, float* __restrict__ dst, int k,
+                                     int cin, int cout) {
+    const long n = (long)k * cout * cin;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
+        const int i = (int)(e % cin);
+        const int o = (int)((e / cin) % cout);
+        const int j = (int)(e / ((long)cin * cout));
+        double acc = 0.0;
+        for (int m = 0; m < cin; ++m) acc += (double)w1[(long)o * cin + m] * (double)wm[((long)j * cin + m) * cin + i];
+        dst[e] = (float)acc;
+    }
+}
+
 template <int NCI, int NC>   // Cin = 32*NCI, C = 32*NC
 __global__ __launch_bounds__(64, ESMI_E1_WPS) void enc_merge_qkv_kernel(const EncMergeP p) {
     constexpr int CIN = 32 * NCI, C = 32 * NC;
-    constexpr int LD = (NCI > NC ? CIN : C) + 4;
+    constexpr int LD = C + 4;
     ESMI_DYN_LDS(buf);             // [32][LD]
     ESMI_CT_INIT(NCI == 4 && NC == 1 ? 3 : 4);
     ESMI_CT();
@@ -38,11 +54,11 @@ __global__ __launch_bounds__(64, ESMI_E1_WPS) void enc_merge_qkv_kernel(const En
     const int t0 = tile * 32, t_out = t0 + i;
     const float* a_row = buf + i * LD + 4 * h2;
 
-    // ---- dense k-tap conv (stride s, zero padding)
-    f32x16 a1[NCI];
-    zero_tiles<NCI>(a1);
-    WaveGrp<NCI> gc;
-    wave_prefetch<NCI>(gc, p.merge_w, NCI, 0, 0, lane);
+    // ---- composed k-tap conv (stride s, zero padding) -> x
+    f32x16 x[NC];
+    zero_tiles<NC>(x);
+    WaveGrp<NC> gc;
+    wave_prefetch<NC>(gc, p.merge_w, NC, 0, 0, lane);
     const float* taps[5];   // merge kernels are 1, 3 or 5 wide; masked taps point at a readable row
     bool tok[5];
     int tic[5];
@@ -66,17 +82,7 @@ __global__ __launch_bounds__(64, ESMI_E1_WPS) void enc_merge_qkv_kernel(const En
         for (int j = 0; j < 5; ++j) taps[j] = p.x_in + ((long)b * p.n_in + tic[j]) * CIN + 4 * h2;
     }
     ESMI_CT();
-    wave_gemm_taps<NCI, 5, NCI, true>(a1, gc, taps, tok, p.k, p.merge_w, (long)CIN * CIN, NCI, 0, 0, lane);
-    WaveGrp<NC> g1x;
-    wave_prefetch<NC>(g1x, p.merge1_w, NC, 0, 0, lane);
-    ESMI_CT();
-    tile_store<NCI>(buf, LD, 0, a1, lane);
-    lds_wave_sync();
-    ESMI_CT();
-    // ---- 1x1 conv -> x
-    f32x16 x[NC];
-    zero_tiles<NC>(x);
-    wave_gemm<NC>(x, g1x, a_row, true, CIN, p.merge1_w, NC, 0, 0, lane);
+    wave_gemm_taps<NC, 5, NCI, true>(x, gc, taps, tok, p.k, p.merge_w, (long)CIN * C, NC, 0, 0, lane);
     const int nq = 3 * p.h * C, ntq = nq >> 5;
     WaveGrp<4> gq;
     wave_prefetch<4>(gq, p.qkv_w, ntq, 0, 0, lane);
@@ -90,7 +96,6 @@ __global__ __launch_bounds__(64, ESMI_E1_WPS) void enc_merge_qkv_kernel(const En
 #pragma unroll
         for (int nt = 0; nt < NC; ++nt) buf_st(r_xo, off + 128u * nt, x[nt][r]);
     }
-    lds_wave_sync();
     tile_store<NC>(buf, LD, 0, x, lane);
     lds_wave_sync();
     ESMI_CT();
@@ -98,7 +103,7 @@ __global__ __launch_bounds__(64, ESMI_E1_WPS) void enc_merge_qkv_kernel(const En
     for (int n0 = 0; n0 < nq; n0 += 128) {
         f32x16 q[4];
         zero_tiles<4>(q);
-        wave_gemm<4>(q, gq, a_row, true, C, p.qkv_w, ntq, 0, n0 >> 5, lane);
+        wave_gemm_k<4, NC>(q, gq, a_row, true, p.qkv_w, ntq, 0, n0 >> 5, lane);
         if (n0 + 128 < nq) wave_prefetch<4>(gq, p.qkv_w, ntq, 0, (n0 + 128) >> 5, lane);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {

@@ -85,6 +85,7 @@ int launch_attn(const AttnP& p, hipStream_t st) {
 
 inline int conv_out_len(int n, int k, int stride, int pad) { return (n + 2 * pad - k) / stride + 1; }
 
+int g_dec_lds_pad = 0;         // esmi_dev_set_decoder_lds_pad(): extra dynamic LDS per decoder workgroup (limits workgroups per CU)
 int g_fusion = ESMI_FUSE_ALL;   // esmi_set_fusion(): bit mask of enabled wave-chain stages
 
 // E1: merge conv + 1x1 + qkv in one launch.  Returns ESMI_ERR_UNSUPPORTED when no instantiation fits.
@@ -92,7 +93,7 @@ int launch_enc_merge_qkv(const EncMergeP& p, int c_in, int c_out, hipStream_t st
     const int nci = c_in / 32, nc = c_out / 32;
     if ((c_in & 31) || (c_out & 31)) return ESMI_ERR_UNSUPPORTED;
     dim3 grid(p.B * p.tiles_per_b), block(64);
-    const int lds = 32 * ((nci > nc ? c_in : c_out) + 4) * (int)sizeof(float);
+    const int lds = 32 * (c_out + 4) * (int)sizeof(float);
 #define ESMI_E1(NCI, NC) \
     if (nci == NCI && nc == NC) { ESMI_LAUNCH((enc_merge_qkv_kernel<NCI, NC>), grid, block, lds, st, p); return launch_status(); }
     ESMI_E1(4, 1) ESMI_E1(1, 2) ESMI_E1(4, 2) ESMI_E1(2, 4) ESMI_E1(4, 4)
@@ -111,8 +112,19 @@ int launch_enc_attn_ffn(const EncAttnFfnP& p, int expansion, hipStream_t st) {
     if ((p.C & 31) || p.N > 256) return ESMI_ERR_UNSUPPORTED;
     const int nc = p.C / 32, nkt = p.N <= 64 ? 2 : (p.N <= 128 ? 4 : 8);
     int nw, wgs, useful, halo;
-    enc_attn_ffn_plan(p.N, p.C * expansion + 4, &nw, &wgs, &useful, &halo);
     EncAttnFfnP q = p;
+    if (p.h == 2 && nc == 2 && expansion == 1 && (g_fusion & ESMI_FUSE_SPLIT2)) {   // two waves per row tile when rows are scarce
+        enc_attn_ffn_split_plan(p.N, &nw, &wgs, &useful, &halo);
+        if ((long)p.B * wgs * 2 * nw <= 1024 && nkt <= 4) {
+            q.wgs_per_b = wgs; q.useful = useful; q.halo = halo;
+            dim3 grid(p.B * wgs), block(128 * nw);
+            const int lds = enc_attn_ffn_split_lds_floats(p.C, p.h, expansion, nw) * (int)sizeof(float);
+            if (nkt == 2) ESMI_LAUNCH((enc_attn_ffn_split_kernel<2, 2, 1>), grid, block, lds, st, q);
+            else ESMI_LAUNCH((enc_attn_ffn_split_kernel<4, 2, 1>), grid, block, lds, st, q);
+            return launch_status();
+        }
+    }
+    enc_attn_ffn_plan(p.N, p.C * expansion + 4, &nw, &wgs, &useful, &halo);
     q.wgs_per_b = wgs; q.useful = useful; q.halo = halo;
     dim3 grid(p.B * wgs), block(64 * nw);
     const int lds = (32 * nw + 2) * (p.C * expansion + 4) * (int)sizeof(float);
@@ -136,7 +148,7 @@ int launch_enc_attn_ffn(const EncAttnFfnP& p, int expansion, hipStream_t st) {
 }
 
 struct EncWs {
-    size_t t_merge, qkv, ctx, y1, m1, m2, total;
+    size_t t_merge, qkv, ctx, y1, m1, m2, pmask, total;
 };
 EncWs enc_ws(const esmi_encoder_block_shape* s) {
     const int n = conv_out_len(s->n_in, s->kernel, s->stride, s->kernel / 2);
@@ -149,11 +161,15 @@ EncWs enc_ws(const esmi_encoder_block_shape* s) {
     w.y1 = o; o += align256(rows * s->c_out * 4);
     w.m1 = o; o += align256(rows * s->c_out * s->expansion * 4);
     w.m2 = o; o += align256(rows * s->c_out * s->expansion * 4);
+    w.pmask = o; o += align256(rows);
     w.total = o;
     return w;
 }
 
 }  // namespace
+
+// development hook: pad the decoder's dynamic LDS so that fewer workgroups fit on a CU (two-stream co-residency experiments)
+extern "C" void esmi_dev_set_decoder_lds_pad(int bytes) { g_dec_lds_pad = bytes < 0 ? 0 : bytes; }
 
 #ifdef ESMI_CHAIN_TRACE
 __device__ long long* g_chain_trace_dev = nullptr;
@@ -207,6 +223,14 @@ int esmi_pack_bfrag_f32(const float* src, float* dst, int n, int k, int taps, es
     return launch_status();
 }
 
+int esmi_compose_merge_f32(const float* merge_w, const float* merge1_w, int k, int cin, int cout, float* dst,
+                           esmi_stream_t stream) {
+    if (!merge_w || !merge1_w || !dst || k <= 0 || cin <= 0 || cout <= 0) return ESMI_ERR_ARG;
+    const long n = (long)k * cin * cout;
+    ESMI_LAUNCH(compose_merge_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, S(stream), merge_w, merge1_w, dst, k, cin, cout);
+    return launch_status();
+}
+
 int esmi_pool_mask_u8(const uint8_t* mask, int B, int T, int pool, uint8_t* out, int n_out, esmi_stream_t stream) {
     if (!mask || !out || B <= 0 || T <= 0 || pool <= 0 || n_out <= 0) return ESMI_ERR_ARG;
     ESMI_LAUNCH(pool_mask_kernel, dim3((B * n_out + 255) / 256), dim3(256), 0, S(stream), mask, B, T, pool, out, n_out);
@@ -237,7 +261,7 @@ int esmi_encoder_block_f32(const esmi_encoder_block_weights* w, const esmi_encod
     bool fused1 = false;
     // With the fused second stage, x (the block input after the merge convs) lives in scratch and the final
     // result is written straight to x_out: tiles read their neighbours' x rows, so in-place is not possible.
-    const bool packed = w->merge_wp && w->merge1_wp && w->qkv_wp && w->proj_wp && w->mlp1_wp && w->conv_wp && w->mlp2_wp;
+    const bool packed = w->merge_cwp && w->qkv_wp && w->proj_wp && w->mlp1_wp && w->conv_wp && w->mlp2_wp;
     const bool fused2 = packed && (g_fusion & ESMI_FUSE_ATTN_FFN) && enc_attn_ffn_supported(C, n, s->expansion);
     float* x_mid = fused2 ? y1 : x_out;
     if (packed && (g_fusion & ESMI_FUSE_MERGE_QKV)) {   // E1: merge conv + 1x1 + qkv as one wave-chain kernel
@@ -245,7 +269,7 @@ int esmi_encoder_block_f32(const esmi_encoder_block_weights* w, const esmi_encod
         memset(&m, 0, sizeof m);
         m.ids = ids; m.table = embed; m.vocab = s->vocab; m.x_in = ids ? nullptr : x_in;
         m.B = B; m.n_in = s->n_in; m.n_out = n; m.k = s->kernel; m.stride = s->stride; m.pad = s->kernel / 2; m.h = h;
-        m.merge_w = w->merge_wp; m.merge1_w = w->merge1_wp; m.qkv_w = w->qkv_wp; m.x_out = x_mid; m.qkv = qkv;
+        m.merge_w = w->merge_cwp; m.qkv_w = w->qkv_wp; m.x_out = x_mid; m.qkv = qkv;
         m.tiles_per_b = (n + 31) / 32;
         rc = launch_enc_merge_qkv(m, s->c_in, C, st);
         if (rc == ESMI_OK) fused1 = true;
@@ -278,7 +302,13 @@ int esmi_encoder_block_f32(const esmi_encoder_block_weights* w, const esmi_encod
         f.mlp1_w = w->mlp1_wp; f.mlp1_b = w->mlp1_b; f.conv_w = w->conv_wp; f.conv_b = w->conv_b;
         f.mlp2_w = w->mlp2_wp; f.mlp2_b = w->mlp2_b; f.ln2_g = w->ln2_g; f.ln2_b = w->ln2_b;
         f.mask = mask; f.out = x_out;
+        f.mask_pool = s->mask_pool > 0 ? s->mask_pool : 1; f.mask_len = s->mask_pool > 0 ? s->mask_len : n;
         return launch_enc_attn_ffn(f, s->expansion, st);
+    }
+    if (mask && s->mask_pool > 1) {   // the one-kernel-per-op plan takes a pooled (B, n) mask: blocks.py:51-57
+        uint8_t* pm = reinterpret_cast<uint8_t*>(wsb + ws.pmask);
+        if ((rc = esmi_pool_mask_u8(mask, B, s->mask_len, s->mask_pool, pm, n, stream))) return rc;
+        mask = pm;
     }
     // softmax(q k^T scale) v, blocks.py:49-64
     AttnP a;
@@ -576,11 +606,11 @@ int esmi_mel_decoder_f32(const float* blob, const esmi_decoder_shape* s, const f
     hipStream_t st = S(stream);
 #define ESMI_DEC_CASE(DX2, KD, NW)                                                                                 \
     {                                                                                                              \
-        const int lds = dec_lds_floats<DX2>(KD) * (int)sizeof(float) ;                                             \
+        const int lds = dec_lds_floats<DX2>(KD) * (int)sizeof(float) + g_dec_lds_pad;                              \
         static bool attr_set = false; /* once per instantiation: keeps the call out of hipGraph captures */       \
         if (!attr_set) {                                                                                           \
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mel_decoder_kernel<DX2, KD, NW>),     \
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, lds);                  \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);           \
             if (e != hipSuccess) return (int)e;                                                                    \
             attr_set = true;                                                                                       \
         }                                                                                                          \

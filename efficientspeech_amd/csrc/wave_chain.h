@@ -43,6 +43,12 @@ namespace esmi {
 // with a runtime index, which hipcc turned into a scratch array of generic pointers + flat_load (vmcnt AND
 // lgkmcnt), and the pipeline collapsed to one exposed round trip per group (127 instead of 70 cycles per MFMA).
 template <int NT>
+__device__ __forceinline__ void zero_tiles(f32x16 (&v)[NT]) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) v[nt] = zero16();
+}
+
+template <int NT>
 struct WaveGrp { f32x4 a[4]; f32x4 b[4][NT]; };
 
 // this lane's base into a packed matrix: column tile nt0 (clamped to the last tile: results of tiles >= ntw are
@@ -60,7 +66,11 @@ __device__ __forceinline__ void wave_fetch_b(WaveGrp<NT>& gq, const float* wl, i
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             const int ntc = nt0 + nt < ntw ? nt : ntw - 1 - nt0;   // wave-uniform clamp, no branch around the load
+#ifdef ESMI_ABL_NOB
+            gq.b[q][nt] = ld4(wl + ntc * 256);      // ablation probe: always the same 1 KiB
+#else
             gq.b[q][nt] = ld4(wg + (q * ntw + ntc) * 256);
+#endif
         }
     }
 }
@@ -69,20 +79,37 @@ template <int NT, bool MASKED>
 __device__ __forceinline__ void wave_fetch_a(WaveGrp<NT>& gq, const float* ar, bool ok, int g) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
+#ifdef ESMI_ABL_NOA
+        gq.a[q] = ld4(ar);                           // ablation probe: always the same 16 bytes per lane
+#else
         gq.a[q] = ld4(ar + 32 * g + 8 * q);
+#endif
         if (MASKED && !ok) gq.a[q] = zero4();
     }
 }
 
+// 16*NT MFMAs of one group.  A dependent v_mfma_f32_32x32x2_f32 (same accumulator) issues only ~114 cycles after its
+// predecessor instead of 64 (probe_wavegemm: NT = 1 ran at 114 cycles per MFMA), so narrow GEMMs (NT <= 2) alternate
+// between two accumulator sets by k-step; the caller adds them up at the end (wave_acc_join).
 template <int NT>
-__device__ __forceinline__ void wave_grp_mma(f32x16 (&acc)[NT], const WaveGrp<NT>& gq) {
+__device__ __forceinline__ void wave_grp_mma(f32x16 (&acc)[NT], f32x16 (&acc2)[NT], const WaveGrp<NT>& gq) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) acc[nt] = mfma32(gq.a[q][s], gq.b[q][nt][s], acc[nt]);
+            for (int nt = 0; nt < NT; ++nt) {
+                if (NT <= 2 && (s & 1)) acc2[nt] = mfma32(gq.a[q][s], gq.b[q][nt][s], acc2[nt]);
+                else acc[nt] = mfma32(gq.a[q][s], gq.b[q][nt][s], acc[nt]);
+            }
         }
+    }
+}
+template <int NT>
+__device__ __forceinline__ void wave_acc_join(f32x16 (&acc)[NT], const f32x16 (&acc2)[NT]) {
+    if (NT <= 2) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[nt] += acc2[nt];
     }
 }
 
@@ -93,17 +120,21 @@ __device__ __forceinline__ void wave_prefetch(WaveGrp<NT>& g0, const float* __re
     wave_fetch_b<NT>(g0, wave_wbase(Wp, ntw, kc0, nt0 < ntw ? nt0 : ntw - 1, lane), ntw, nt0 < ntw ? nt0 : ntw - 1, 0);
 }
 
-// g0.b must hold the weights of (tap 0, group 0): wave_prefetch(g0, Wp, ntw, kc0, nt0, lane)
+// g0.b must hold the weights of (tap 0, group 0): wave_prefetch(g0, Wp, ntw, kc0, nt0, lane).
+// The pipeline is a ring of D group buffers with compile-time indices; D grows as the GEMM gets narrower, because a
+// group of a narrow GEMM is only 16*NT MFMAs (~1k cycles at NT = 1) while an L2 round trip under load is 2-3k.
 template <int NT, int MAXTAPS, int KG, bool MASKED>
 __device__ __forceinline__ void wave_gemm_taps(f32x16 (&acc)[NT], WaveGrp<NT>& g0, const float* const (&a_rows)[MAXTAPS],
                                                const bool (&a_ok)[MAXTAPS], int ntaps, const float* __restrict__ Wp,
                                                long w_tap_stride, int ntw, int kc0, int nt0, int lane) {
     if (nt0 >= ntw) nt0 = ntw - 1;
     const float* wl = wave_wbase(Wp, ntw, kc0, nt0, lane);
-    WaveGrp<NT> g1;
+    f32x16 acc2[NT];
+    zero_tiles<NT>(acc2);
     wave_fetch_a<NT, MASKED>(g0, a_rows[0], a_ok[0], 0);
-    if constexpr (KG % 2 == 0 && KG >= 4) {
-        // taps unrolled, group pairs of one tap in a rolled loop (code size); the tap boundary prefetch is static
+    if constexpr (NT >= 4 && KG % 2 == 0 && KG >= 4) {
+        // wide and long: taps unrolled, group pairs of one tap in a rolled loop (code size), two buffers
+        WaveGrp<NT> g1;
 #pragma unroll
         for (int j = 0; j < MAXTAPS; ++j) {
             if (j < ntaps) {
@@ -112,7 +143,7 @@ __device__ __forceinline__ void wave_gemm_taps(f32x16 (&acc)[NT], WaveGrp<NT>& g
                 for (int g = 0; g < KG; g += 2) {
                     wave_fetch_b<NT>(g1, wj, ntw, nt0, g + 1);
                     wave_fetch_a<NT, MASKED>(g1, a_rows[j], a_ok[j], g + 1);
-                    wave_grp_mma<NT>(acc, g0);
+                    wave_grp_mma<NT>(acc, acc2, g0);
                     if (g + 2 < KG) {
                         wave_fetch_b<NT>(g0, wj, ntw, nt0, g + 2);
                         wave_fetch_a<NT, MASKED>(g0, a_rows[j], a_ok[j], g + 2);
@@ -120,31 +151,44 @@ __device__ __forceinline__ void wave_gemm_taps(f32x16 (&acc)[NT], WaveGrp<NT>& g
                         wave_fetch_b<NT>(g0, wj + w_tap_stride, ntw, nt0, 0);
                         wave_fetch_a<NT, MASKED>(g0, a_rows[jn], a_ok[jn], 0);
                     }
-                    wave_grp_mma<NT>(acc, g1);
+                    wave_grp_mma<NT>(acc, acc2, g1);
                 }
             }
         }
     } else {
-        // fully unrolled: step n = j*KG + g; buffer parity and tap index are compile-time
+        // fully unrolled: step n = j*KG + g lives in ring slot n % D (slot 0 = g0); everything is compile-time
+        constexpr int STEPS = MAXTAPS * KG;
+        constexpr int D0 = NT == 1 ? 4 : (NT == 2 ? 3 : 2);
+        constexpr int D = D0 < STEPS ? D0 : (STEPS > 1 ? STEPS : 2);
+        WaveGrp<NT> ring[D - 1];
+        auto slot = [&](int n) __attribute__((always_inline)) -> WaveGrp<NT>& { return n % D == 0 ? g0 : ring[n % D - 1]; };
+        auto fetch = [&](int m) __attribute__((always_inline)) {   // operands of step m, if that step exists
+            const int jm = m / KG < MAXTAPS ? m / KG : MAXTAPS - 1, gm = m % KG;
+            if (m < STEPS && jm < ntaps) {
+                wave_fetch_b<NT>(slot(m), wl + (long)jm * w_tap_stride, ntw, nt0, gm);
+                wave_fetch_a<NT, MASKED>(slot(m), a_rows[jm], a_ok[jm], gm);
+            }
+        };
 #pragma unroll
-        for (int n = 0; n < MAXTAPS * KG; ++n) {
-            const int j = n / KG;
-            const int jn = (n + 1) / KG < MAXTAPS ? (n + 1) / KG : MAXTAPS - 1, gn = (n + 1) % KG;
-            if (j < ntaps) {
-                if (n + 1 < MAXTAPS * KG && jn < ntaps) {
-                    if (n & 1) {
-                        wave_fetch_b<NT>(g0, wl + (long)jn * w_tap_stride, ntw, nt0, gn);
-                        wave_fetch_a<NT, MASKED>(g0, a_rows[jn], a_ok[jn], gn);
-                    } else {
-                        wave_fetch_b<NT>(g1, wl + (long)jn * w_tap_stride, ntw, nt0, gn);
-                        wave_fetch_a<NT, MASKED>(g1, a_rows[jn], a_ok[jn], gn);
-                    }
-                }
-                if (n & 1) wave_grp_mma<NT>(acc, g1);
-                else wave_grp_mma<NT>(acc, g0);
+        for (int m = 1; m < D - 1; ++m) fetch(m);
+#pragma unroll
+        for (int n = 0; n < STEPS; ++n) {
+            if (n / KG < ntaps) {
+                fetch(n + D - 1);
+                wave_grp_mma<NT>(acc, acc2, slot(n));
             }
         }
     }
+    wave_acc_join<NT>(acc, acc2);
+}
+
+// single-tap GEMM with a compile-time K = 32*KG (deep static pipeline)
+template <int NT, int KG>
+__device__ __forceinline__ void wave_gemm_k(f32x16 (&acc)[NT], WaveGrp<NT>& g0, const float* a_row, bool ok,
+                                            const float* __restrict__ Wp, int ntw, int kc0, int nt0, int lane) {
+    const float* const rows[1] = {a_row};
+    const bool oks[1] = {ok};
+    wave_gemm_taps<NT, 1, KG, true>(acc, g0, rows, oks, 1, Wp, 0, ntw, kc0, nt0, lane);
 }
 
 // single-tap GEMM with a run-time K (a multiple of 32); a_row must be readable, ok = false -> zero row.
@@ -156,19 +200,22 @@ __device__ __forceinline__ void wave_gemm(f32x16 (&acc)[NT], WaveGrp<NT>& g0, co
     const float* wl = wave_wbase(Wp, ntw, kc0, nt0, lane);
     const int ng = K >> 5;
     WaveGrp<NT> g1;
+    f32x16 acc2[NT];
+    zero_tiles<NT>(acc2);
     wave_fetch_a<NT, true>(g0, a_row, ok, 0);
     int f = 0;
     for (; f + 2 <= ng; f += 2) {   // two groups per trip: the buffers alternate without register copies
         wave_fetch_b<NT>(g1, wl, ntw, nt0, f + 1);
         wave_fetch_a<NT, true>(g1, a_row, ok, f + 1);
-        wave_grp_mma<NT>(acc, g0);
+        wave_grp_mma<NT>(acc, acc2, g0);
         if (f + 2 < ng) {
             wave_fetch_b<NT>(g0, wl, ntw, nt0, f + 2);
             wave_fetch_a<NT, true>(g0, a_row, ok, f + 2);
         }
-        wave_grp_mma<NT>(acc, g1);
+        wave_grp_mma<NT>(acc, acc2, g1);
     }
-    if (f < ng) wave_grp_mma<NT>(acc, g0);
+    if (f < ng) wave_grp_mma<NT>(acc, acc2, g0);
+    wave_acc_join<NT>(acc, acc2);
 }
 
 // C/D-layout accumulators -> LDS tile rows [0,32): tile[row][col0 + 32nt + i]
@@ -192,10 +239,5 @@ __device__ __forceinline__ void tile_store(float* tile, int ld, int col0, const 
     }
 }
 
-template <int NT>
-__device__ __forceinline__ void zero_tiles(f32x16 (&v)[NT]) {
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) v[nt] = zero16();
-}
 
 }  // namespace esmi

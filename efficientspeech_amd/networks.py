@@ -164,9 +164,12 @@ class Encoder(nn.Module):
                          mlp1_w=_f32(ffn.mlp1.weight), mlp1_b=_f32(ffn.mlp1.bias), conv_w=cw,
                          conv_b=_f32(ffn.conv.bias), mlp2_w=_f32(ffn.mlp2.weight), mlp2_b=_f32(ffn.mlp2.bias),
                          ln1_g=_f32(n1.weight), ln1_b=_f32(n1.bias), ln2_g=_f32(n2.weight), ln2_b=_f32(n2.bias))
-                for name in ("merge_w", "merge1_w", "qkv_w", "proj_w", "mlp1_w", "conv_w", "mlp2_w"):
-                    v = t[name]
-                    t[name + "p"] = _pack_bfrag(lib, stream, v.reshape(v.shape[0], v.shape[1]) if name == "merge1_w" else v)
+                for name in ("qkv_w", "proj_w", "mlp1_w", "conv_w", "mlp2_w"):
+                    t[name + "p"] = _pack_bfrag(lib, stream, t[name])
+                k, cin, co = mw.shape[0], mw.shape[2], merge1.weight.shape[0]
+                comp = torch.empty((k, co, cin), dtype=torch.float32, device=mw.device)   # merge1 o merge as one conv
+                lib.esmi_compose_merge_f32(_ptr(mw), _ptr(t["merge1_w"]), k, cin, co, _ptr(comp), stream)
+                t["merge_cwp"] = _pack_bfrag(lib, stream, comp)
                 keep.extend(t.values())
                 out.append((_lib.EncoderBlockWeights(**{k: _ptr(v) for k, v in t.items()}), keep))
             return out, _f32(self.embed.weight)
@@ -191,26 +194,22 @@ class Encoder(nn.Module):
         x_in, n_in = None, T
         for i, (wts, _keep) in enumerate(blocks):
             n = self.block_len(T, i)
-            bm = None
+            pool = 1
             if m8 is not None:                                   # networks.py:69-70 + blocks.py:51-57
                 pool = int(round(T / n))                         # torch.round == Python round: half to even
                 if (T + pool - 1) // pool != n:
                     raise RuntimeError(f"pooled mask length {(T + pool - 1) // pool} != sequence length {n}")
-                if pool == 1:
-                    bm = m8
-                else:
-                    bm = torch.empty((B, n), dtype=torch.uint8, device=dev)
-                    lib.esmi_pool_mask_u8(_ptr(m8), B, T, pool, _ptr(bm), n, stream)
+            # the padding mask is pooled on the fly inside the block (mask_pool): no pooled copy is materialised
             shape = _lib.EncoderBlockShape(B, n_in, self.dim_ins[i], self.dim_outs[i], self.heads[i], self.kernels[i],
-                                           self.strides[i], self.expansion, N_SYMBOLS + 1)
+                                           self.strides[i], self.expansion, N_SYMBOLS + 1, pool, T)
             ws_bytes = lib.esmi_encoder_block_workspace_bytes(C.byref(shape))
             ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
             x_out = torch.empty((B, n, self.dim_outs[i]), dtype=torch.float32, device=dev)
             lib.esmi_encoder_block_f32(C.byref(wts), C.byref(shape), _ptr(ids) if i == 0 else None,
-                                       _ptr(embed) if i == 0 else None, _ptr(x_in), _ptr(bm), _ptr(x_out),
+                                       _ptr(embed) if i == 0 else None, _ptr(x_in), _ptr(m8), _ptr(x_out),
                                        _ptr(ws), ws_bytes, stream)
             feats.append(x_out)
-            masks.append(bm)
+            masks.append(m8 if pool == 1 else None)
             x_in, n_in = x_out, n
         return feats, masks
 

@@ -51,7 +51,8 @@ const char* esmi_backend(void);
 #define ESMI_FUSE_MERGE_QKV 1 /* merge convs + 1x1 + qkv                 */
 #define ESMI_FUSE_ATTN_FFN 2  /* attention + proj + LN1 + MixFFN + LN2   */
 #define ESMI_FUSE_VARIANCE 4  /* Fuse + 3 predictors + embeddings + round */
-#define ESMI_FUSE_ALL 7
+#define ESMI_FUSE_SPLIT2 8    /* two-head blocks on short sequences: two waves per row tile */
+#define ESMI_FUSE_ALL 15
 int esmi_set_fusion(int enabled);
 
 /* ------------------------------------------------------------------ weight packing
@@ -66,6 +67,12 @@ int esmi_pack_convT_weight_f32(const float* src, float* dst, int cin, int cout, 
  * dst holds esmi_pack_bfrag_floats(n, k, taps) = taps * k * 32 * NT floats.                     */
 size_t esmi_pack_bfrag_floats(int n, int k, int taps);
 int esmi_pack_bfrag_f32(const float* src, float* dst, int n, int k, int taps, esmi_stream_t stream);
+
+/* The two merge convolutions of an encoder block (networks.py:64-67) are linear and bias-free with nothing in
+ * between, so merge1(merge(x)) is ONE k-tap convolution Cin -> Cout with W'[j] = merge1_w @ merge_w[j].
+ * merge_w (k,Cin,Cin) tap-major, merge1_w (Cout,Cin) -> dst (k,Cout,Cin) tap-major, accumulated in fp64.   */
+int esmi_compose_merge_f32(const float* merge_w, const float* merge1_w, int k, int cin, int cout, float* dst,
+                           esmi_stream_t stream);
 
 /* ------------------------------------------------------------------ Encoder block
  * One pass of the loop body of Encoder.forward, layers/networks.py:62-85:
@@ -89,10 +96,10 @@ typedef struct esmi_encoder_block_weights {
     const float* ln1_b;
     const float* ln2_g;    /* attn_blocks.{i}.5.{weight,bias} */
     const float* ln2_b;
-    /* esmi_pack_bfrag_f32 of the seven matrices above (merge_w / conv_w with taps = kernel / 3);
-     * all non-NULL enables the fused kernels, any NULL -> one kernel per op.                 */
-    const float* merge_wp;
-    const float* merge1_wp;
+    /* MFMA B-fragment copies for the fused kernels (all non-NULL enables them, any NULL -> one kernel per op):
+     * merge_cwp = esmi_pack_bfrag_f32(esmi_compose_merge_f32(merge_w, merge1_w), taps = kernel); the others are
+     * esmi_pack_bfrag_f32 of the matrix of the same name (conv_w with taps = 3).                              */
+    const float* merge_cwp;
     const float* qkv_wp;
     const float* proj_wp;
     const float* mlp1_wp;
@@ -106,13 +113,16 @@ typedef struct esmi_encoder_block_shape {
     int kernel, stride;      /* merge conv kernel / stride (networks.py:27-30)                */
     int expansion;           /* MixFFN hidden = expansion * c_out                             */
     int vocab;               /* rows of the embedding table (block 0 only)                    */
+    int mask_pool, mask_len; /* `mask` is (B, mask_len) and output row n is padding iff any of
+                              * mask[n*mask_pool .. +mask_pool) is set or lies beyond mask_len
+                              * (blocks.py:51-57 applied on the fly).  0 / 0 = mask is (B, n_out). */
 } esmi_encoder_block_shape;
 
 size_t esmi_encoder_block_workspace_bytes(const esmi_encoder_block_shape* s);
 int esmi_encoder_block_f32(const esmi_encoder_block_weights* w, const esmi_encoder_block_shape* s,
                            const int32_t* ids, const float* embed, /* block 0: (B,n_in) ids, (vocab,c_in) table */
                            const float* x_in,                      /* blocks >= 1: (B, n_in, c_in), else NULL   */
-                           const uint8_t* mask,                    /* (B, n_out) pooled padding mask or NULL    */
+                           const uint8_t* mask,                    /* padding mask (see mask_pool) or NULL      */
                            float* x_out,                           /* (B, n_out, c_out)                         */
                            void* workspace, size_t workspace_bytes, esmi_stream_t stream);
 

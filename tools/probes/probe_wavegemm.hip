@@ -15,7 +15,9 @@ __global__ __launch_bounds__(64, 1) void probe(const float* A, const float* Wp, 
     bool tok[5];
     for (int j = 0; j < 5; ++j) { taps[j] = A + ((blockIdx.x * 37 + i + j) % 150) * K + 4 * h; tok[j] = (i + j) % 7 != 0; }
     long long t0 = __builtin_amdgcn_s_memtime();
-    wave_gemm_taps<NT, 5, KG, true>(acc, taps, tok, ntaps, Wp, (long)K * 32 * NT, NT, 0, 0, lane);
+    WaveGrp<NT> g0;
+    wave_prefetch<NT>(g0, Wp, NT, 0, 0, lane);
+    wave_gemm_taps<NT, 5, KG, true>(acc, g0, taps, tok, ntaps, Wp, (long)K * 32 * NT, NT, 0, 0, lane);
     float s = 0;
     for (int nt = 0; nt < NT; ++nt) for (int r = 0; r < 16; ++r) s += acc[nt][r];
     long long t1 = __builtin_amdgcn_s_memtime();
