@@ -50,10 +50,11 @@ struct FuseVaP {
 constexpr int kVaMaxWaves = 4;
 
 // LDS floats of an nw-wave workgroup: fb0 [32nw+2][dim+4], then one region shared over time by the per-wave Fuse
-// scratch (cat [32][depth*dim+4] + tmp [32][dim+4] each) and the predictor-hidden tile tb0 [32nw+2][dim+4]
+// scratch (cat [32][depth*dim+4] + tmp [32][dim+4] each) and the predictor-hidden tile tb0 [32nw+2][3*dim+4]
 inline int fuse_va_lds_floats(int dim, int depth, int nw) {
-    const int shared = (32 * nw + 2) * (dim + 4), priv = nw * (32 * (depth * dim + 4) + 32 * (dim + 4));
-    return shared + (priv > shared ? priv : shared);
+    const int fbt = (32 * nw + 2) * (dim + 4), tbt = (32 * nw + 2) * (3 * dim + 4);
+    const int priv = nw * (32 * (depth * dim + 4) + 32 * (dim + 4));
+    return fbt + (priv > tbt ? priv : tbt);
 }
 
 inline void fuse_va_plan(int n, int dim, int depth, int* nw, int* wgs, int* useful, int* halo) {
@@ -72,18 +73,18 @@ __device__ __forceinline__ int floor_div(int a, int b) { return a >= 0 ? a / b :
 
 template <int ND>   // dim = 32*ND
 __global__ __launch_bounds__(64 * kVaMaxWaves, ESMI_E3_WPS) void enc_fuse_va_kernel(const FuseVaP p) {
-    constexpr int DIM = 32 * ND, LDD = DIM + 4;
+    constexpr int DIM = 32 * ND, LDD = DIM + 4, LDT = 3 * DIM + 4;
     ESMI_DYN_LDS(lds);
     const int nw = (int)(blockDim.x >> 6), w = wave_id();
     const int lane = lane_id(), i = lane & 31, h2 = lane >> 5;
     const int ldc = p.depth * DIM + 4;
     float* fb0 = lds;                                 // [32nw+2][LDD] fused features, zero rows around
-    float* tb0 = fb0 + (32 * nw + 2) * LDD;           // [32nw+2][LDD] predictor hidden, zero rows around ...
+    float* tb0 = fb0 + (32 * nw + 2) * LDD;           // [32nw+2][LDT] hidden of the three predictors side by side, zero rows around ...
     float* cat = tb0 + w * (32 * ldc + 32 * LDD);     // ... aliased, during Fuse, by each wave's [32][ldc]
     float* tmp = cat + 32 * ldc;                      //     and [32][LDD]
     const int r0 = 32 * w;
     float* fb = fb0 + LDD * (1 + r0);
-    float* tb = tb0 + LDD * (1 + r0);
+    float* tb = tb0 + LDT * (1 + r0);
     const int b = (int)blockIdx.x / p.wgs_per_b, wg = (int)blockIdx.x - b * p.wgs_per_b;
     const int p0 = wg * p.useful - p.halo + r0;       // position of this wave's row 0
     for (int c = (int)threadIdx.x; c < LDD; c += (int)blockDim.x) {
@@ -163,7 +164,6 @@ __global__ __launch_bounds__(64 * kVaMaxWaves, ESMI_E3_WPS) void enc_fuse_va_ker
     lds_wave_sync();
     zero_tiles<ND>(a);
     wave_gemm<ND>(a, gw, cat + i * ldc + 4 * h2, true, p.depth * DIM, p.fuse_w, ND, 0, 0, lane);
-    wave_prefetch<ND>(gw, p.pred[0].conv1_w, ND, 0, 0, lane);
 
     bool rout[16], rz[16], live[16];        // per accumulator row: outside the sequence / masked (padding) / stored by this workgroup
     int rpos[16];
@@ -192,108 +192,179 @@ __global__ __launch_bounds__(64 * kVaMaxWaves, ESMI_E3_WPS) void enc_fuse_va_ker
     }
     tile_store<ND>(fb, LDD, 0, a, lane);
     __syncthreads();            // Fuse scratch is dead in every wave; fused rows of the neighbours are in place
-    for (int c = (int)threadIdx.x; c < LDD; c += (int)blockDim.x) {   // tb0's zero rows (they alias wave 0's / the last wave's scratch)
+    for (int c = (int)threadIdx.x; c < LDT; c += (int)blockDim.x) {   // tb0's zero rows (they alias wave 0's / the last wave's scratch)
         tb0[c] = 0.0f;
-        tb0[(32 * nw + 1) * LDD + c] = 0.0f;
+        tb0[(32 * nw + 1) * LDT + c] = 0.0f;
     }
 
     ESMI_CT();   // 1 fuse done
-    // ---------------- three predictors
+    // ---------------- three predictors, side by side: one barrier pair instead of three, three independent MFMA /
+    // LayerNorm chains to interleave, the embedding gathers of pitch / energy overlap the duration tail
     const float* f_row = fb + i * LDD + 4 * h2;
-    const float* t_row = tb + i * LDD + 4 * h2;
-    const bool tok3[3] = {true, true, true};   // the tiles carry their own zero rows
+    const float* t_row = tb + i * LDT + 4 * h2;
     const BufRsrc r_pt = make_rsrc(p.pitch_t ? p.pitch_t + (long)b * p.T : nullptr, (long)p.T * 4);
     const BufRsrc r_et = make_rsrc(p.energy_t ? p.energy_t + (long)b * p.T : nullptr, (long)p.T * 4);
     const BufRsrc r_dt = make_rsrc(p.dur_t ? p.dur_t + (long)b * p.T : nullptr, (long)p.T * 4);
     const BufRsrc r_dur = make_rsrc(p.dur + (long)b * p.T, (long)p.T * 4);
+    // every small parameter is requested up front: one memory round trip
+    float b1[3][ND], g1[3][ND], be1[3][ND], b2[3][ND], lw[3][ND], g2[ND], be2[ND], lb[3];
 #pragma unroll
-    for (int q = 0; q < 3; ++q) {   // unrolled: q is a compile-time constant below
+    for (int q = 0; q < 3; ++q) {
         const PredW& w_ = p.pred[q];
-        // every small parameter of this predictor is requested up front: one memory round trip instead of six
-        float b1[ND], g1[ND], be1[ND], b2[ND], lw[ND], g2[ND], be2[ND];
 #pragma unroll
         for (int nt = 0; nt < ND; ++nt) {
             const int col = 32 * nt + i;
-            b1[nt] = w_.conv1_b[col]; g1[nt] = w_.ln1_g[col]; be1[nt] = w_.ln1_b[col];
-            b2[nt] = w_.conv2_b[col]; lw[nt] = w_.lin_w[col];
-            g2[nt] = q == 2 ? w_.ln2_g[col] : 0.0f; be2[nt] = q == 2 ? w_.ln2_b[col] : 0.0f;
+            b1[q][nt] = w_.conv1_b[col]; g1[q][nt] = w_.ln1_g[col]; be1[q][nt] = w_.ln1_b[col];
+            b2[q][nt] = w_.conv2_b[col]; lw[q][nt] = w_.lin_w[col];
         }
-        const float lb = w_.lin_b[0];
-        // bucket edges replicated in both half waves: lane l holds edges (l&31) + 32*e; +inf beyond the dim-1 edges
-        float edge[ND];
+        lb[q] = w_.lin_b[0];
+    }
+#pragma unroll
+    for (int nt = 0; nt < ND; ++nt) {
+        g2[nt] = p.pred[2].ln2_g[32 * nt + i];
+        be2[nt] = p.pred[2].ln2_b[32 * nt + i];
+    }
+    // bucket edges replicated in both half waves: lane l holds edges (l&31) + 32*e; +inf beyond the dim-1 edges
+    float edge[2][ND];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
 #pragma unroll
         for (int e = 0; e < ND; ++e) {
             const int ei = 32 * e + i;
-            edge[e] = INFINITY;
-            if (q < 2) {
-                const float ev = w_.bins[ei < DIM - 1 ? ei : DIM - 2];   // clamped: no branch around the load
-                if (ei < DIM - 1) edge[e] = ev;
+            const float ev = p.pred[q].bins[ei < DIM - 1 ? ei : DIM - 2];   // clamped: no branch around the load
+            edge[q][e] = ei < DIM - 1 ? ev : INFINITY;
+        }
+    }
+    float tv[3][16];            // teacher values of this lane's rows (0 when absent; duration: int bits)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const unsigned off = rout[r] ? kBufOOB : (unsigned)(rpos[r] * 4);
+        tv[0][r] = buf_ld(r_pt, off);
+        tv[1][r] = buf_ld(r_et, off);
+        tv[2][r] = buf_ld(r_dt, off);
+    }
+
+    // one k=3 conv step for the three predictors: A rows either shared (conv1: the fused features) or one column
+    // block per predictor (conv2: its own hidden); weights from the three packed matrices
+    struct TriGrp { f32x4 a[3][4]; f32x4 b[3][4][ND]; };
+    auto tri_fetch = [&](TriGrp& gq, const float* arow, int a_qstride, const float* const (&wq)[3], int tap, int g)
+        __attribute__((always_inline)) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const float* wl = wq[q] + (long)tap * DIM * DIM + (long)(4 * g) * ND * 256 + 4 * lane;
+#pragma unroll
+            for (int kq = 0; kq < 4; ++kq) {
+                if (q == 0 || a_qstride) gq.a[q][kq] = ld4(arow + q * a_qstride + 32 * g + 8 * kq);
+#pragma unroll
+                for (int nt = 0; nt < ND; ++nt) gq.b[q][kq][nt] = ld4(wl + (kq * ND + nt) * 256);
             }
         }
-        float tv[16];           // teacher values of this lane's rows (0 when absent)
-        {
-            const BufRsrc& rt = q == 0 ? r_pt : (q == 1 ? r_et : r_dt);
+    };
+    auto tri_mma = [&](f32x16 (&acc)[3][ND], const TriGrp& gq, bool shared_a) __attribute__((always_inline)) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) tv[r] = buf_ld(rt, rout[r] ? kBufOOB : (unsigned)(rpos[r] * 4));
+        for (int kq = 0; kq < 4; ++kq) {
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) {
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+#pragma unroll
+                    for (int nt = 0; nt < ND; ++nt)
+                        acc[q][nt] = mfma32(gq.a[shared_a ? 0 : q][kq][s4], gq.b[q][kq][nt][s4], acc[q][nt]);
+                }
+            }
         }
-        f32x16 c[ND];
-        zero_tiles<ND>(c);
-        {
-            const float* const taps[3] = {f_row - LDD, f_row, f_row + LDD};
-            wave_gemm_taps<ND, 3, ND, false>(c, gw, taps, tok3, 3, w_.conv1_w, (long)DIM * DIM, ND, 0, 0, lane);
+    };
+    auto tri_conv = [&](f32x16 (&acc)[3][ND], const float* row, int ldrow, int a_qstride, const float* const (&wq)[3])
+        __attribute__((always_inline)) {
+        constexpr int STEPS = 3 * ND;   // tap-major: step n = tap*ND + g
+        TriGrp ga, gb;
+        tri_fetch(ga, row - ldrow, a_qstride, wq, 0, 0);
+#pragma unroll
+        for (int n = 0; n < STEPS; ++n) {
+            const int tn = (n + 1) / ND, gn = (n + 1) % ND;
+            if (n + 1 < STEPS) {
+                if (n & 1) tri_fetch(ga, row + (tn - 1) * ldrow, a_qstride, wq, tn, gn);
+                else tri_fetch(gb, row + (tn - 1) * ldrow, a_qstride, wq, tn, gn);
+            }
+            if (n & 1) tri_mma(acc, gb, a_qstride == 0);
+            else tri_mma(acc, ga, a_qstride == 0);
         }
-        wave_prefetch<ND>(gw, w_.conv2_w, ND, 0, 0, lane);
+    };
+
+    f32x16 c[3][ND];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) zero_tiles<ND>(c[q]);
+    {
+        const float* const w1[3] = {p.pred[0].conv1_w, p.pred[1].conv1_w, p.pred[2].conv1_w};
+        tri_conv(c, f_row, LDD, 0, w1);
+    }
+    ESMI_CT();   // conv1 issued
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
 #pragma unroll
         for (int nt = 0; nt < ND; ++nt) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) c[nt][r] = fmaxf(c[nt][r] + b1[nt], 0.0f);
+            for (int r = 0; r < 16; ++r) c[q][nt][r] = fmaxf(c[q][nt][r] + b1[q][nt], 0.0f);
         }
-        ESMI_CT();   // conv1 done
-        layernorm_tile_regs<ND>(c, g1, be1);
-        ESMI_CT();   // LN1 done
+        layernorm_tile_regs<ND>(c[q], g1[q], be1[q]);
 #pragma unroll
         for (int nt = 0; nt < ND; ++nt) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) c[nt][r] = rout[r] ? 0.0f : fmaxf(c[nt][r], 0.0f);
+            for (int r = 0; r < 16; ++r) c[q][nt][r] = rout[r] ? 0.0f : fmaxf(c[q][nt][r], 0.0f);
         }
-        __syncthreads();   // every wave finished reading tb (previous predictor's conv2)
-        tile_store<ND>(tb, LDD, 0, c, lane);
-        __syncthreads();   // neighbours' hidden rows are in place
-        zero_tiles<ND>(c);
-        {
-            const float* const taps[3] = {t_row - LDD, t_row, t_row + LDD};
-            wave_gemm_taps<ND, 3, ND, false>(c, gw, taps, tok3, 3, w_.conv2_w, (long)DIM * DIM, ND, 0, 0, lane);
-        }
-        if (q < 2) wave_prefetch<ND>(gw, p.pred[q + 1].conv1_w, ND, 0, 0, lane);
-        ESMI_CT();   // conv2 done
+        tile_store<ND>(tb, LDT, q * DIM, c[q], lane);
+        zero_tiles<ND>(c[q]);
+    }
+    ESMI_CT();   // LN1 + store
+    __syncthreads();   // neighbours' hidden rows (and tb0's zero rows) are in place
+    {
+        const float* const w2[3] = {p.pred[0].conv2_w, p.pred[1].conv2_w, p.pred[2].conv2_w};
+        tri_conv(c, t_row, LDT, DIM, w2);
+    }
+    ESMI_CT();   // conv2 issued
+    float pr[3][16];   // Linear(dim, 1) on the pre-norm2 tensor (networks.py:157-160)
+    int bidx[2][16];   // torch.bucketize(v, edges, right=False) = number of edges strictly below v
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
 #pragma unroll
         for (int nt = 0; nt < ND; ++nt) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) c[nt][r] = fmaxf(c[nt][r] + b2[nt], 0.0f);
+            for (int r = 0; r < 16; ++r) c[q][nt][r] = fmaxf(c[q][nt][r] + b2[q][nt], 0.0f);
         }
-        float pr[16];      // Linear(dim, 1) on the pre-norm2 tensor (networks.py:157-160)
-        int bidx[16];      // torch.bucketize(v, edges, right=False) = number of edges strictly below v
         const bool has_t = q == 0 ? p.pitch_t != nullptr : p.energy_t != nullptr;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             float s = 0.0f;
 #pragma unroll
-            for (int nt = 0; nt < ND; ++nt) s = fmaf(c[nt][r], lw[nt], s);
-            s = row_sum32(s) + lb;
+            for (int nt = 0; nt < ND; ++nt) s = fmaf(c[q][nt][r], lw[q][nt], s);
+            s = row_sum32(s) + lb[q];
             if (q == 2) s = fmaxf(s, 0.0f);
-            pr[r] = s;
-            bidx[r] = 0;
-            if (q < 2) {   // wave-uniform branch: the ballots below are executed by all lanes
-                const float v = (has_t && !rout[r]) ? tv[r] : s;
+            pr[q][r] = s;
+            if (q < 2) {   // compile-time branch; the ballots are executed by all lanes
+                const float v = (has_t && !rout[r]) ? tv[q][r] : s;
+                int bi = 0;
 #pragma unroll
                 for (int e = 0; e < ND; ++e) {
-                    const unsigned long long m = ballot64(edge[e] < v);
-                    bidx[r] += __builtin_popcount((unsigned)(h2 ? (m >> 32) : m));
+                    const unsigned long long m = ballot64(edge[q][e] < v);
+                    bi += __builtin_popcount((unsigned)(h2 ? (m >> 32) : m));
                 }
+                bidx[q][r] = bi;
             }
         }
-        ESMI_CT();   // dot done
-        if (q == 2) layernorm_tile_regs<ND>(c, g2, be2);   // duration features (networks.py:161-163)
+    }
+    ESMI_CT();   // dots done
+    float emb[2][16][ND];      // pitch / energy embedding rows: gathers in flight during the duration tail
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+#pragma unroll
+            for (int nt = 0; nt < ND; ++nt) emb[q][r][nt] = p.pred[q].emb[bidx[q][r] * DIM + 32 * nt + i];
+        }
+    }
+    layernorm_tile_regs<ND>(c[2], g2, be2);   // duration features (networks.py:161-163)
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
         const BufRsrc r_pred = make_rsrc(p.preds[q] + (long)b * p.T, (long)p.T * 4);
         int* const ip = q == 0 ? p.pitch_idx : p.energy_idx;
         const BufRsrc r_idx = make_rsrc((q < 2 && ip) ? ip + (long)b * p.T : nullptr, (long)p.T * 4);
@@ -301,25 +372,24 @@ __global__ __launch_bounds__(64 * kVaMaxWaves, ESMI_E3_WPS) void enc_fuse_va_ker
         for (int r = 0; r < 16; ++r) {
             const unsigned frow = live[r] ? (unsigned)((rpos[r] * 4 * DIM + (q == 2 ? 3 : 1 + q) * DIM + i) * 4) : kBufOOB;
             const unsigned srow = (live[r] && i == 0) ? (unsigned)(rpos[r] * 4) : kBufOOB;   // one lane per row
-            buf_st(r_pred, srow, pr[r]);
+            buf_st(r_pred, srow, pr[q][r]);
             if (q == 2) {
 #pragma unroll
-                for (int nt = 0; nt < ND; ++nt) buf_st(r_feat, frow + 128u * nt, rz[r] ? 0.0f : c[nt][r]);
-                float d = p.dur_t ? (float)__builtin_bit_cast(int, tv[r]) : rintf(pr[r]);   // torch.round: half to even
-                if (p.mask) {                                                                  // networks.py:381-382
+                for (int nt = 0; nt < ND; ++nt) buf_st(r_feat, frow + 128u * nt, rz[r] ? 0.0f : c[2][nt][r]);
+                float d = p.dur_t ? (float)__builtin_bit_cast(int, tv[2][r]) : rintf(pr[2][r]);   // torch.round: half to even
+                if (p.mask) {                                                                        // networks.py:381-382
                     if (rz[r]) d = 0.0f;
                     d = fmaxf(d, 0.0f);
                 }
                 buf_st_i(r_dur, srow, (int)d);
             } else {
 #pragma unroll
-                for (int nt = 0; nt < ND; ++nt)
-                    buf_st(r_feat, frow + 128u * nt, rz[r] ? 0.0f : w_.emb[bidx[r] * DIM + 32 * nt + i]);
-                buf_st_i(r_idx, srow, bidx[r]);
+                for (int nt = 0; nt < ND; ++nt) buf_st(r_feat, frow + 128u * nt, rz[r] ? 0.0f : emb[q][r][nt]);
+                buf_st_i(r_idx, srow, bidx[q][r]);
             }
         }
-        ESMI_CT();   // outputs done
     }
+    ESMI_CT();   // outputs done
 }
 
 }  // namespace esmi
