@@ -269,7 +269,7 @@ __global__ __launch_bounds__(64 * kEncMaxWaves, ESMI_E2_WPS) void enc_attn_ffn_k
     {
         const float* const taps[3] = {a_row - LD, a_row, a_row + LD};
         const bool tok[3] = {true, true, true};
-        wave_gemm_taps<NE, 3, NE, false>(m, gm, taps, tok, 3, p.conv_w, (long)EC * EC, NE, 0, 0, lane);
+        wave_gemm_taps<NE, 3, NE, false>(m, gm, taps, tok, p.conv_w, (long)EC * EC, NE, 0, 0, lane);
     }
     WaveGrp<NC> g2;                 // mlp2 weights
     wave_prefetch<NC>(g2, p.mlp2_w, NC, 0, 0, lane);
@@ -556,7 +556,7 @@ __global__ __launch_bounds__(128 * kEncSplitMaxTiles, ESMI_E2_WPS) void enc_attn
     {
         const float* const taps[3] = {a_row - LD, a_row, a_row + LD};
         const bool tok[3] = {true, true, true};
-        wave_gemm_taps<NEH, 3, NE, false>(m, gm, taps, tok, 3, p.conv_w, (long)EC * EC, NE, 0, c * NEH, lane);
+        wave_gemm_taps<NEH, 3, NE, false>(m, gm, taps, tok, p.conv_w, (long)EC * EC, NE, 0, c * NEH, lane);
     }
     WaveGrp<NCH> g2;
     wave_prefetch<NCH>(g2, p.mlp2_w, NC, 0, c * NCH, lane);

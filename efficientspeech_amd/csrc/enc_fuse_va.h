@@ -71,7 +71,7 @@ inline void fuse_va_plan(int n, int dim, int depth, int* nw, int* wgs, int* usef
 
 __device__ __forceinline__ int floor_div(int a, int b) { return a >= 0 ? a / b : -((-a + b - 1) / b); }
 
-template <int ND>   // dim = 32*ND
+template <int ND, int KU>   // dim = 32*ND, ConvTranspose1d kernel KU
 __global__ __launch_bounds__(64 * kVaMaxWaves, ESMI_E3_WPS) void enc_fuse_va_kernel(const FuseVaP p) {
     constexpr int DIM = 32 * ND, LDD = DIM + 4, LDT = 3 * DIM + 4;
     ESMI_DYN_LDS(lds);
@@ -119,7 +119,7 @@ __global__ __launch_bounds__(64 * kVaMaxWaves, ESMI_E3_WPS) void enc_fuse_va_ker
     }
     for (int lv = 1; lv < p.depth; ++lv) {   // Linear(dim*2^lv, dim) -> ConvTranspose1d(stride 2^lv), cropped to T
         const int s = 1 << lv, cl = DIM << lv, nl = p.n_i[lv];
-        const int n_base = floor_div(p0 - (p.kernel - 1), s);
+        const int n_base = floor_div(p0 - (KU - 1), s);
         zero_tiles<ND>(a);
         const int n = n_base + i;
         const bool n_ok = n >= 0 && n < nl;
@@ -140,16 +140,16 @@ __global__ __launch_bounds__(64 * kVaMaxWaves, ESMI_E3_WPS) void enc_fuse_va_ker
         lds_wave_sync();
         zero_tiles<ND>(a);
         {   // out[n*s + j] += in[n] W[:, :, j]
-            const float* taps[7];
-            bool tok[7];
+            const float* taps[KU];
+            bool tok[KU];
 #pragma unroll
-            for (int j = 0; j < 7; ++j) {
+            for (int j = 0; j < KU; ++j) {
                 const int q = pos_i - j;
                 const int nq = q / s;
-                tok[j] = j < p.kernel && q >= 0 && (q - nq * s) == 0 && nq < nl;
+                tok[j] = q >= 0 && (q - nq * s) == 0 && nq < nl;
                 taps[j] = tmp + (tok[j] ? nq - n_base : 0) * LDD + 4 * h2;
             }
-            wave_gemm_taps<ND, 7, ND, true>(a, gw, taps, tok, p.kernel, p.up_w[lv], (long)DIM * DIM, ND, 0, 0, lane);
+            wave_gemm_taps<ND, KU, ND, true>(a, gw, taps, tok, p.up_w[lv], (long)DIM * DIM, ND, 0, 0, lane);
         }
         if (lv + 1 < p.depth) wave_prefetch<ND>(gw, p.mlp_w[lv + 1], ND, 0, 0, lane);
         else wave_prefetch<ND>(gw, p.fuse_w, ND, 0, 0, lane);
@@ -286,8 +286,10 @@ __global__ __launch_bounds__(64 * kVaMaxWaves, ESMI_E3_WPS) void enc_fuse_va_ker
                 if (n & 1) tri_fetch(ga, row + (tn - 1) * ldrow, a_qstride, wq, tn, gn);
                 else tri_fetch(gb, row + (tn - 1) * ldrow, a_qstride, wq, tn, gn);
             }
+            sched_fence();
             if (n & 1) tri_mma(acc, gb, a_qstride == 0);
             else tri_mma(acc, ga, a_qstride == 0);
+            sched_fence();
         }
     };
 

@@ -42,47 +42,77 @@ __global__ void compose_merge_kernel(const float* __restrict__ wm, const float* 
     }
 }
 
-template <int NCI, int NC>   // Cin = 32*NCI, C = 32*NC
+inline int enc_merge_lds_floats(int c_in, int c_out, int k, int stride) {
+    const int in_t = (31 * stride + k) * (c_in + 4), x_t = 32 * (c_out + 4);
+    return in_t > x_t ? in_t : x_t;
+}
+
+template <int NCI, int NC, int KT, int STRIDE>   // Cin = 32*NCI, C = 32*NC, merge kernel KT, stride STRIDE
 __global__ __launch_bounds__(64, ESMI_E1_WPS) void enc_merge_qkv_kernel(const EncMergeP p) {
     constexpr int CIN = 32 * NCI, C = 32 * NC;
-    constexpr int LD = C + 4;
-    ESMI_DYN_LDS(buf);             // [32][LD]
+    constexpr int LDI = CIN + 4, LD = C + 4;
+    constexpr int LPR = 8 * NCI;               // lanes per input row (16 bytes each)
+    constexpr int RPI = 64 / LPR;              // input rows per wave-wide load
+    constexpr int NROWS = 31 * STRIDE + KT;     // input rows under one 32-row output tile
+    constexpr int MAXI = (NROWS + RPI - 1) / RPI;
+    ESMI_DYN_LDS(buf);             // input rows [NROWS][LDI], later the x tile [32][LD]
     ESMI_CT_INIT(NCI == 4 && NC == 1 ? 3 : 4);
     ESMI_CT();
     const int lane = lane_id(), i = lane & 31, h2 = lane >> 5;
     const int b = (int)blockIdx.x / p.tiles_per_b, tile = (int)blockIdx.x - b * p.tiles_per_b;
-    const int t0 = tile * 32, t_out = t0 + i;
+    const int t0 = tile * 32;
     const float* a_row = buf + i * LD + 4 * h2;
 
-    // ---- composed k-tap conv (stride s, zero padding) -> x
-    f32x16 x[NC];
-    zero_tiles<NC>(x);
+    // ---- stage the input rows of this tile in LDS with full-row coalesced loads.  (Reading the A fragments
+    // straight from global memory -- 32 rows x 32 bytes per instruction, every 128-byte line touched by four
+    // instructions -- cost more than the MFMAs of the composed conv.)  Rows outside [0, n_in) are the conv's zero
+    // padding.
     WaveGrp<NC> gc;
     wave_prefetch<NC>(gc, p.merge_w, NC, 0, 0, lane);
-    const float* taps[5];   // merge kernels are 1, 3 or 5 wide; masked taps point at a readable row
-    bool tok[5];
-    int tic[5];
+    const int ti0 = t0 * STRIDE - p.pad;        // input position of staged row 0
+    const int lrow = lane / LPR, lchunk = lane - lrow * LPR;
+    f32x4 stg[MAXI];
+    if (p.ids) {                   // block 0: the embedding gather is the conv's input
+        int id[MAXI];
 #pragma unroll
-    for (int j = 0; j < 5; ++j) {
-        const int ti = t_out * p.stride + j - p.pad;
-        tok[j] = j < p.k && t_out < p.n_out && ti >= 0 && ti < p.n_in;
-        tic[j] = tok[j] ? ti : 0;
-    }
-    if (p.ids) {            // block 0: the embedding gather is the conv's A operand
-        int id[5];
+        for (int m = 0; m < MAXI; ++m) {
+            const int ti = ti0 + m * RPI + lrow;
+            id[m] = p.ids[b * p.n_in + (ti >= 0 && ti < p.n_in ? ti : 0)];
+        }
 #pragma unroll
-        for (int j = 0; j < 5; ++j) id[j] = p.ids[b * p.n_in + tic[j]];
-#pragma unroll
-        for (int j = 0; j < 5; ++j) {
-            if (id[j] < 0 || id[j] >= p.vocab) id[j] = 0;   // the reference raises IndexError; stay in bounds
-            taps[j] = p.table + (long)id[j] * CIN + 4 * h2;
+        for (int m = 0; m < MAXI; ++m) {
+            const int ti = ti0 + m * RPI + lrow;
+            if (id[m] < 0 || id[m] >= p.vocab) id[m] = 0;   // the reference raises IndexError; stay in bounds
+            stg[m] = ld4(p.table + (long)id[m] * CIN + 4 * lchunk);
+            if (ti < 0 || ti >= p.n_in) stg[m] = zero4();
         }
     } else {
+        const BufRsrc r_in = make_rsrc(p.x_in + (long)b * p.n_in * CIN, (long)p.n_in * CIN * 4);
 #pragma unroll
-        for (int j = 0; j < 5; ++j) taps[j] = p.x_in + ((long)b * p.n_in + tic[j]) * CIN + 4 * h2;
+        for (int m = 0; m < MAXI; ++m) {
+            const int ti = ti0 + m * RPI + lrow;
+            stg[m] = buf_ld4(r_in, (unsigned)((ti * CIN + 4 * lchunk) * 4));   // out of range reads 0
+        }
     }
+#pragma unroll
+    for (int m = 0; m < MAXI; ++m) {
+        const int rr = m * RPI + lrow;
+        if (rr < NROWS) *reinterpret_cast<f32x4*>(buf + rr * LDI + 4 * lchunk) = stg[m];
+    }
+    lds_wave_sync();
     ESMI_CT();
-    wave_gemm_taps<NC, 5, NCI, true>(x, gc, taps, tok, p.k, p.merge_w, (long)CIN * C, NC, 0, 0, lane);
+
+    // ---- composed k-tap conv (stride s) -> x
+    f32x16 x[NC];
+    zero_tiles<NC>(x);
+    const float* taps[KT];
+    bool tok[KT];
+#pragma unroll
+    for (int j = 0; j < KT; ++j) {
+        taps[j] = buf + (i * STRIDE + j) * LDI + 4 * h2;
+        tok[j] = true;
+    }
+    wave_gemm_taps<NC, KT, NCI, false>(x, gc, taps, tok, p.merge_w, (long)CIN * C, NC, 0, 0, lane);
     const int nq = 3 * p.h * C, ntq = nq >> 5;
     WaveGrp<4> gq;
     wave_prefetch<4>(gq, p.qkv_w, ntq, 0, 0, lane);
@@ -96,6 +126,7 @@ __global__ __launch_bounds__(64, ESMI_E1_WPS) void enc_merge_qkv_kernel(const En
 #pragma unroll
         for (int nt = 0; nt < NC; ++nt) buf_st(r_xo, off + 128u * nt, x[nt][r]);
     }
+    lds_wave_sync();               // the conv has read its last input row
     tile_store<NC>(buf, LD, 0, x, lane);
     lds_wave_sync();
     ESMI_CT();

@@ -93,10 +93,11 @@ int launch_enc_merge_qkv(const EncMergeP& p, int c_in, int c_out, hipStream_t st
     const int nci = c_in / 32, nc = c_out / 32;
     if ((c_in & 31) || (c_out & 31)) return ESMI_ERR_UNSUPPORTED;
     dim3 grid(p.B * p.tiles_per_b), block(64);
-    const int lds = 32 * (c_out + 4) * (int)sizeof(float);
-#define ESMI_E1(NCI, NC) \
-    if (nci == NCI && nc == NC) { ESMI_LAUNCH((enc_merge_qkv_kernel<NCI, NC>), grid, block, lds, st, p); return launch_status(); }
-    ESMI_E1(4, 1) ESMI_E1(1, 2) ESMI_E1(4, 2) ESMI_E1(2, 4) ESMI_E1(4, 4)
+    const int lds = enc_merge_lds_floats(c_in, c_out, p.k, p.stride) * (int)sizeof(float);
+#define ESMI_E1(NCI, NC, KT, ST) \
+    if (nci == NCI && nc == NC && p.k == KT && p.stride == ST) { ESMI_LAUNCH((enc_merge_qkv_kernel<NCI, NC, KT, ST>), grid, block, lds, st, p); return launch_status(); }
+    // (Cin/32, C/32, kernel, stride) of the three published sizes: tiny, small, base (block 1 of base is not fused)
+    ESMI_E1(4, 1, 3, 1) ESMI_E1(1, 2, 1, 2) ESMI_E1(4, 2, 3, 1) ESMI_E1(2, 4, 1, 2) ESMI_E1(4, 4, 5, 1)
 #undef ESMI_E1
     return ESMI_ERR_UNSUPPORTED;
 }
@@ -441,7 +442,7 @@ int esmi_fuse_variance_adaptor_f32(const esmi_fuse_weights* fw, int depth, int d
     if (!fw || !feats || !n_i || !pitch || !energy || !duration || !feat || !pitch_pred || !energy_pred ||
         !duration_pred || !dur || depth < 1 || depth > ESMI_MAX_DEPTH)
         return ESMI_ERR_ARG;
-    bool chain = (g_fusion & ESMI_FUSE_VARIANCE) && (dim == 32 || dim == 64) && kernel <= 7 && n_i[0] == T && fw->fuse_wp &&
+    bool chain = (g_fusion & ESMI_FUSE_VARIANCE) && (dim == 32 || dim == 64) && (kernel == 3 || kernel == 5) && n_i[0] == T && fw->fuse_wp &&
                  pitch->conv1_wp && pitch->conv2_wp && energy->conv1_wp && energy->conv2_wp && duration->conv1_wp &&
                  duration->conv2_wp;
     for (int i = 0; i < depth && chain; ++i) chain = fw->mlp_wp[i] && (i == 0 || fw->up_wp[i]);
@@ -473,16 +474,18 @@ int esmi_fuse_variance_adaptor_f32(const esmi_fuse_weights* fw, int depth, int d
         const int lds = fuse_va_lds_floats(dim, depth, nw) * (int)sizeof(float);
         static bool attr_set = false;   // once: keeps the call out of hipGraph captures
         if (!attr_set) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(enc_fuse_va_kernel<1>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            if (e == hipSuccess)
-                e = hipFuncSetAttribute(reinterpret_cast<const void*>(enc_fuse_va_kernel<2>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            if (e != hipSuccess) return (int)e;
+            const void* fns[4] = {reinterpret_cast<const void*>(enc_fuse_va_kernel<1, 3>), reinterpret_cast<const void*>(enc_fuse_va_kernel<2, 3>),
+                                  reinterpret_cast<const void*>(enc_fuse_va_kernel<1, 5>), reinterpret_cast<const void*>(enc_fuse_va_kernel<2, 5>)};
+            for (const void* fn : fns) {
+                hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                if (e != hipSuccess) return (int)e;
+            }
             attr_set = true;
         }
-        if (dim == 32) ESMI_LAUNCH((enc_fuse_va_kernel<1>), grid, block, lds, S(stream), p);
-        else ESMI_LAUNCH((enc_fuse_va_kernel<2>), grid, block, lds, S(stream), p);
+        if (dim == 32 && kernel == 3) ESMI_LAUNCH((enc_fuse_va_kernel<1, 3>), grid, block, lds, S(stream), p);
+        else if (dim == 64 && kernel == 3) ESMI_LAUNCH((enc_fuse_va_kernel<2, 3>), grid, block, lds, S(stream), p);
+        else if (dim == 32) ESMI_LAUNCH((enc_fuse_va_kernel<1, 5>), grid, block, lds, S(stream), p);
+        else ESMI_LAUNCH((enc_fuse_va_kernel<2, 5>), grid, block, lds, S(stream), p);
         return launch_status();
     }
     if (!workspace || workspace_bytes < esmi_fuse_variance_adaptor_workspace_bytes(B, T, dim, depth)) return ESMI_ERR_WORKSPACE;

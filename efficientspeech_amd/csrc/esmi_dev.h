@@ -276,6 +276,15 @@ __device__ __forceinline__ void buf_st_i(BufRsrc r, unsigned off, int v) {
 __device__ __forceinline__ void lds_wave_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 #endif
 
+// Pin the instruction order at this point.  hipcc's scheduler sinks prefetch loads down to their first use to shorten
+// live ranges (seen in the chain kernels: `global_load; s_waitcnt vmcnt(0); 4 x v_mfma` per k-step, i.e. every
+// software pipeline collapsed); a scheduling barrier after each prefetch block keeps the loads where they were written.
+__device__ __forceinline__ void sched_fence() {
+#ifndef ESMI_WAVESIM
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+}
+
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 __device__ __forceinline__ f32x4 zero4() { f32x4 z = {0.f, 0.f, 0.f, 0.f}; return z; }
 __device__ __forceinline__ f32x16 zero16() {

@@ -19,6 +19,12 @@ extern __device__ long long* g_chain_trace_dev;
 #define ESMI_CT() do {} while (0)
 #endif
 
+#ifndef ESMI_RING_NT1
+#define ESMI_RING_NT1 6   // operand-ring depth (groups in flight) of GEMMs one column tile wide
+#endif
+#ifndef ESMI_RING_NT2
+#define ESMI_RING_NT2 4
+#endif
 #ifndef ESMI_CHAIN_WPS
 #define ESMI_CHAIN_WPS 1   // __launch_bounds__ waves/SIMD of the one-wave chain kernels (3 => at most 168 VGPRs)
 #endif
@@ -33,13 +39,14 @@ namespace esmi {
 // 128-byte line touched by four different instructions -- made the L1/L2 path, not the MFMA pipe, the limit of
 // these kernels: enc_merge_qkv spent 100k cycles on a 49k-cycle MFMA chain.)
 //
-// acc[nt] += sum over taps j < ntaps of  A_j(32 x 32*KG) * W_j[32(nt0+nt) + (0..31)][8kc0 + (0..32*KG-1)]^T
+// acc[nt] += sum over the MAXTAPS taps j of  A_j(32 x 32*KG) * W_j[32(nt0+nt) + (0..31)][8kc0 + (0..32*KG-1)]^T
 //   a_rows[j] : this lane's A row of tap j, + 4*h  (LDS or global; must be a readable address even when masked)
 //   a_ok[j]   : false -> this lane's row of tap j is all zero (MASKED = false: no row is ever masked)
 //   W_j       : Wp + j*w_tap_stride, packed as above with NTW = ntw column tiles; tiles >= ntw contribute zeros
 // Operands are fetched in groups of four k-steps (one memory round trip per 32 channels) and the groups of
 // ALL taps form one software pipeline: group n+1 is in flight while the 16*NT MFMAs of group n execute.
-// Tap indices and buffer parity are compile-time everywhere: an earlier version selected the tap's row pointer
+// Tap COUNT, tap indices and buffer parity are compile-time everywhere (a run-time tap count puts a branch between the
+// steps, after which hipcc can only wait with vmcnt(0): no prefetch distance left): an earlier version selected the tap's row pointer
 // with a runtime index, which hipcc turned into a scratch array of generic pointers + flat_load (vmcnt AND
 // lgkmcnt), and the pipeline collapsed to one exposed round trip per group (127 instead of 70 cycles per MFMA).
 template <int NT>
@@ -118,6 +125,7 @@ __device__ __forceinline__ void wave_acc_join(f32x16 (&acc)[NT], const f32x16 (&
 template <int NT>
 __device__ __forceinline__ void wave_prefetch(WaveGrp<NT>& g0, const float* __restrict__ Wp, int ntw, int kc0, int nt0, int lane) {
     wave_fetch_b<NT>(g0, wave_wbase(Wp, ntw, kc0, nt0 < ntw ? nt0 : ntw - 1, lane), ntw, nt0 < ntw ? nt0 : ntw - 1, 0);
+    sched_fence();
 }
 
 // g0.b must hold the weights of (tap 0, group 0): wave_prefetch(g0, Wp, ntw, kc0, nt0, lane).
@@ -125,7 +133,7 @@ __device__ __forceinline__ void wave_prefetch(WaveGrp<NT>& g0, const float* __re
 // group of a narrow GEMM is only 16*NT MFMAs (~1k cycles at NT = 1) while an L2 round trip under load is 2-3k.
 template <int NT, int MAXTAPS, int KG, bool MASKED>
 __device__ __forceinline__ void wave_gemm_taps(f32x16 (&acc)[NT], WaveGrp<NT>& g0, const float* const (&a_rows)[MAXTAPS],
-                                               const bool (&a_ok)[MAXTAPS], int ntaps, const float* __restrict__ Wp,
+                                               const bool (&a_ok)[MAXTAPS], const float* __restrict__ Wp,
                                                long w_tap_stride, int ntw, int kc0, int nt0, int lane) {
     if (nt0 >= ntw) nt0 = ntw - 1;
     const float* wl = wave_wbase(Wp, ntw, kc0, nt0, lane);
@@ -137,34 +145,38 @@ __device__ __forceinline__ void wave_gemm_taps(f32x16 (&acc)[NT], WaveGrp<NT>& g
         WaveGrp<NT> g1;
 #pragma unroll
         for (int j = 0; j < MAXTAPS; ++j) {
-            if (j < ntaps) {
+            {
                 const float* wj = wl + (long)j * w_tap_stride;
                 const int jn = j + 1 < MAXTAPS ? j + 1 : j;
                 for (int g = 0; g < KG; g += 2) {
                     wave_fetch_b<NT>(g1, wj, ntw, nt0, g + 1);
                     wave_fetch_a<NT, MASKED>(g1, a_rows[j], a_ok[j], g + 1);
+                    sched_fence();
                     wave_grp_mma<NT>(acc, acc2, g0);
+                    sched_fence();
                     if (g + 2 < KG) {
                         wave_fetch_b<NT>(g0, wj, ntw, nt0, g + 2);
                         wave_fetch_a<NT, MASKED>(g0, a_rows[j], a_ok[j], g + 2);
-                    } else if (j + 1 < MAXTAPS && j + 1 < ntaps) {
+                    } else if (j + 1 < MAXTAPS) {
                         wave_fetch_b<NT>(g0, wj + w_tap_stride, ntw, nt0, 0);
                         wave_fetch_a<NT, MASKED>(g0, a_rows[jn], a_ok[jn], 0);
                     }
+                    sched_fence();
                     wave_grp_mma<NT>(acc, acc2, g1);
+                    sched_fence();
                 }
             }
         }
     } else {
         // fully unrolled: step n = j*KG + g lives in ring slot n % D (slot 0 = g0); everything is compile-time
         constexpr int STEPS = MAXTAPS * KG;
-        constexpr int D0 = NT == 1 ? 4 : (NT == 2 ? 3 : 2);
+        constexpr int D0 = NT == 1 ? ESMI_RING_NT1 : (NT == 2 ? ESMI_RING_NT2 : 2);
         constexpr int D = D0 < STEPS ? D0 : (STEPS > 1 ? STEPS : 2);
         WaveGrp<NT> ring[D - 1];
         auto slot = [&](int n) __attribute__((always_inline)) -> WaveGrp<NT>& { return n % D == 0 ? g0 : ring[n % D - 1]; };
         auto fetch = [&](int m) __attribute__((always_inline)) {   // operands of step m, if that step exists
             const int jm = m / KG < MAXTAPS ? m / KG : MAXTAPS - 1, gm = m % KG;
-            if (m < STEPS && jm < ntaps) {
+            if (m < STEPS) {
                 wave_fetch_b<NT>(slot(m), wl + (long)jm * w_tap_stride, ntw, nt0, gm);
                 wave_fetch_a<NT, MASKED>(slot(m), a_rows[jm], a_ok[jm], gm);
             }
@@ -173,10 +185,10 @@ __device__ __forceinline__ void wave_gemm_taps(f32x16 (&acc)[NT], WaveGrp<NT>& g
         for (int m = 1; m < D - 1; ++m) fetch(m);
 #pragma unroll
         for (int n = 0; n < STEPS; ++n) {
-            if (n / KG < ntaps) {
-                fetch(n + D - 1);
-                wave_grp_mma<NT>(acc, acc2, slot(n));
-            }
+            fetch(n + D - 1);
+            sched_fence();
+            wave_grp_mma<NT>(acc, acc2, slot(n));
+            sched_fence();
         }
     }
     wave_acc_join<NT>(acc, acc2);
@@ -188,7 +200,7 @@ __device__ __forceinline__ void wave_gemm_k(f32x16 (&acc)[NT], WaveGrp<NT>& g0, 
                                             const float* __restrict__ Wp, int ntw, int kc0, int nt0, int lane) {
     const float* const rows[1] = {a_row};
     const bool oks[1] = {ok};
-    wave_gemm_taps<NT, 1, KG, true>(acc, g0, rows, oks, 1, Wp, 0, ntw, kc0, nt0, lane);
+    wave_gemm_taps<NT, 1, KG, true>(acc, g0, rows, oks, Wp, 0, ntw, kc0, nt0, lane);
 }
 
 // single-tap GEMM with a run-time K (a multiple of 32); a_row must be readable, ok = false -> zero row.
@@ -207,12 +219,16 @@ __device__ __forceinline__ void wave_gemm(f32x16 (&acc)[NT], WaveGrp<NT>& g0, co
     for (; f + 2 <= ng; f += 2) {   // two groups per trip: the buffers alternate without register copies
         wave_fetch_b<NT>(g1, wl, ntw, nt0, f + 1);
         wave_fetch_a<NT, true>(g1, a_row, ok, f + 1);
+        sched_fence();
         wave_grp_mma<NT>(acc, acc2, g0);
+        sched_fence();
         if (f + 2 < ng) {
             wave_fetch_b<NT>(g0, wl, ntw, nt0, f + 2);
             wave_fetch_a<NT, true>(g0, a_row, ok, f + 2);
         }
+        sched_fence();
         wave_grp_mma<NT>(acc, acc2, g1);
+        sched_fence();
     }
     if (f < ng) wave_grp_mma<NT>(acc, acc2, g0);
     wave_acc_join<NT>(acc, acc2);

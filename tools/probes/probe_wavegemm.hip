@@ -17,7 +17,7 @@ __global__ __launch_bounds__(64, 1) void probe(const float* A, const float* Wp, 
     long long t0 = __builtin_amdgcn_s_memtime();
     WaveGrp<NT> g0;
     wave_prefetch<NT>(g0, Wp, NT, 0, 0, lane);
-    wave_gemm_taps<NT, 5, KG, true>(acc, g0, taps, tok, ntaps, Wp, (long)K * 32 * NT, NT, 0, 0, lane);
+    wave_gemm_taps<NT, 3, KG, true>(acc, g0, reinterpret_cast<const float* const (&)[3]>(taps), reinterpret_cast<const bool (&)[3]>(tok), Wp, (long)K * 32 * NT, NT, 0, 0, lane);
     float s = 0;
     for (int nt = 0; nt < NT; ++nt) for (int r = 0; r < 16; ++r) s += acc[nt][r];
     long long t1 = __builtin_amdgcn_s_memtime();
