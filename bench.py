@@ -166,7 +166,10 @@ def main():
         "roofline": {"bound": "mfma", "kernel": "mel_decoder_kernel", "achieved": ach_tf, "peak": FP32_PEAK_TFLOPS,
                      "unit": "TFLOP/s", "frac": ach_tf / FP32_PEAK_TFLOPS, "traffic": traffic,
                      "traffic_unit": "HBM bytes per launch (rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE)",
-                     "traffic_source": traffic_src, "traffic_note": traffic_note, "mfma_pipe_utilisation_pmc": mfma_util,
+                     "traffic_source": traffic_src,
+                     "traffic_note": ("includes ~390 MB of register-spill scratch of the 128-VGPR two-workgroups-per-CU build; "
+                                      "see profiles/" + traffic_src) if traffic_note else None,
+                     "mfma_pipe_utilisation_pmc": mfma_util,
                      "algorithmic_bytes_per_launch": nbytes * B * L,
                      "kernel_ms": dec_ms, "algorithmic_flops_per_frame": flops, "algorithmic_bytes_per_frame": nbytes,
                      "hbm_frac": nbytes * B * L / (dec_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
