@@ -46,6 +46,9 @@ def parse():
     ap.add_argument("--graph", action="store_true",
                     help="replay the forward as two hipGraphs per step instead of eager launches (measured 2.5 %% slower "
                          "on an idle host: the step is GPU-bound; useful when the host is slow)")
+    ap.add_argument("--event-every", type=int, default=5,
+                    help="bracket every n-th mel-decoder launch of the timed region with HIP events for roofline.kernel_ms "
+                         "(each event pair drains the queue: ~12 us per step when placed on every launch)")
     ap.add_argument("--dec-lds-pad", type=int, default=0,
                     help="development: extra LDS bytes per decoder workgroup (fewer decoder workgroups per CU, leaves room "
                          "for the encoder-side kernels of the next step under --two-stream)")
@@ -132,6 +135,7 @@ def main():
             pipe.step(x)
         pipe.flush()
         net.decoder.timing = []
+        net.decoder.timing_every = a.event_every
         pipe.dec_events = [] if a.graph else None
         sync_all()
         t0 = time.perf_counter()
@@ -171,7 +175,7 @@ def main():
                                       "see profiles/" + traffic_src) if traffic_note else None,
                      "mfma_pipe_utilisation_pmc": mfma_util,
                      "algorithmic_bytes_per_launch": nbytes * B * L,
-                     "kernel_ms": dec_ms, "algorithmic_flops_per_frame": flops, "algorithmic_bytes_per_frame": nbytes,
+                     "kernel_ms": dec_ms, "kernel_ms_samples": len(ev), "algorithmic_flops_per_frame": flops, "algorithmic_bytes_per_frame": nbytes,
                      "hbm_frac": nbytes * B * L / (dec_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                      "note": "exact-fp32 MFMA bound (228 FLOP/B >> 20 FLOP/B machine balance); hbm_frac reported "
                              "because north_star quotes the HBM roofline"},

@@ -264,8 +264,11 @@ __device__ __forceinline__ f32x4 buf_ld4(BufRsrc r, unsigned off) {
 __device__ __forceinline__ unsigned buf_ld_u8(BufRsrc r, unsigned off) {
     return (unsigned)__builtin_amdgcn_raw_buffer_load_b8(r, (int)off, 0, 0);
 }
+#ifndef ESMI_ST_AUX
+#define ESMI_ST_AUX 0   // cache policy bits of the tensor-output stores (gfx94x: 1 = sc0, 2 = nt, 16 = sc1)
+#endif
 __device__ __forceinline__ void buf_st(BufRsrc r, unsigned off, float v) {
-    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, (int)off, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, (int)off, 0, ESMI_ST_AUX);
 }
 __device__ __forceinline__ void buf_st_i(BufRsrc r, unsigned off, int v) {
     __builtin_amdgcn_raw_buffer_store_b32((unsigned)v, r, (int)off, 0, 0);

@@ -10,6 +10,11 @@
 #include "esmi_dev.h"
 
 #ifdef ESMI_CHAIN_TRACE
+#ifdef ESMI_CT_REALTIME
+#define ESMI_CT_CLOCK __builtin_amdgcn_s_memrealtime   // constant 100 MHz
+#else
+#define ESMI_CT_CLOCK __builtin_amdgcn_s_memtime       // shader clock
+#endif
 #ifndef ESMI_CT_BLOCK
 #define ESMI_CT_BLOCK 7
 #define ESMI_CT_THREAD 0
@@ -17,7 +22,7 @@
 // development only: shader-clock stamps of workgroup 7 of each chain kernel -> g_chain_trace[kernel_slot*64 + n]
 extern __device__ long long* g_chain_trace_dev;
 #define ESMI_CT_INIT(slot) int ct_n_ = 0; const bool ct_on_ = blockIdx.x == ESMI_CT_BLOCK && threadIdx.x == ESMI_CT_THREAD; const int ct_slot_ = (slot)
-#define ESMI_CT() do { if (ct_on_ && g_chain_trace_dev) g_chain_trace_dev[ct_slot_ * 64 + ct_n_] = (long long)__builtin_amdgcn_s_memtime(); ++ct_n_; } while (0)
+#define ESMI_CT() do { if (ct_on_ && g_chain_trace_dev) g_chain_trace_dev[ct_slot_ * 64 + ct_n_] = (long long)ESMI_CT_CLOCK(); ++ct_n_; } while (0)
 #else
 #define ESMI_CT_INIT(slot) do {} while (0)
 #define ESMI_CT() do {} while (0)

@@ -352,7 +352,9 @@ class MelDecoder(nn.Module):
                 nn.LayerNorm(dx2)]) for _ in range(n_blocks)])
         self.mel_linear = nn.Linear(dx2, n_mel_channels)
         self._cache = _PackCache()
-        self.timing = None      # bench.py sets this to a list to collect (start, end) HIP events per launch
+        self.timing = None      # bench.py sets this to a list to collect (start, end) HIP events per timed launch
+        self.timing_every = 1   # ... on every n-th launch only (an event pair costs ~10 us of pipeline drain per step)
+        self._launches = 0
 
     def _shape(self):
         return _lib.DecoderShape(self.dim_x4, self.dim_x2, self.kernel_size, self.n_blocks, self.block_depth,
@@ -412,7 +414,8 @@ class MelDecoder(nn.Module):
             shape = self._shape()
             blob = self._packed(lib, stream)
             ev = None
-            if self.timing is not None and feat.is_cuda:      # events on the stream the kernel is launched on
+            self._launches += 1
+            if self.timing is not None and feat.is_cuda and self._launches % self.timing_every == 0:   # events on the launch stream
                 ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
                 ev[0].record()
             lib.esmi_mel_decoder_f32(_ptr(blob), C.byref(shape), _ptr(feat), _ptr(cum),

@@ -149,3 +149,49 @@ def test_simulated_errors(nets):
     with use_sim():
         with pytest.raises(KeyError):                            # B>1 without phoneme_mask (networks.py:338)
             net({"phoneme": torch.ones((2, 8), dtype=torch.int32)})
+
+
+def test_simulated_long_sequence_halo_paths(nets):
+    """T = 150 > 128: every cooperative chain kernel needs several workgroups per utterance, i.e. the halo-recompute
+    branches of enc_attn_ffn (block 0, halo 1), enc_attn_ffn_split (block 1, N = 75 > 64) and enc_fuse_va (halo 2)."""
+    net, cfg, sd = nets("tiny")
+    B, T = 2, 150
+    ids, mask = synth_phonemes(B, T, 77, [150, 97])
+    dur = np.ones((B, T), np.int32)
+    dur[:, ::7] = 2
+    x = {"phoneme": torch.from_numpy(ids), "phoneme_mask": torch.from_numpy(mask), "duration_forced": torch.from_numpy(dur)}
+    with use_sim(), torch.no_grad():
+        enc = net.encoder._encode(x)
+        mel, mel_len, _ = net(x)
+    o = oracle.phoneme2mel(cfg, oracle.Weights(sd), ids, mask, duration=dur, taps=True)
+    np.testing.assert_allclose(enc["duration"].numpy(), o.duration, atol=H.PRED_TOL, rtol=0)
+    np.testing.assert_allclose(enc["pitch"].numpy(), o.pitch, atol=H.PRED_TOL, rtol=0)
+    np.testing.assert_allclose(enc["feat"].numpy()[..., :cfg.dim], o.fused, atol=H.PRED_TOL, rtol=0)
+    if np.array_equal(enc["pitch_idx"].numpy(), o.pitch_idx) and np.array_equal(enc["energy_idx"].numpy(), o.energy_idx):
+        assert np.array_equal(mel_len.numpy(), o.mel_len)
+        assert np.abs(mel.numpy() - o.mel).max() < H.MEL_TOL
+
+
+def test_simulated_weight_packers():
+    """esmi_pack_bfrag_f32 / esmi_compose_merge_f32 against their definitions in include/esmi.h."""
+    rng = np.random.default_rng(5)
+    with use_sim() as lib:
+        for taps, n, k in ((1, 96, 32), (3, 40, 64), (5, 32, 128)):
+            w = rng.standard_normal((taps, n, k)).astype(np.float32)
+            nt = (n + 31) // 32
+            assert lib.esmi_pack_bfrag_floats(n, k, taps) == taps * k * 32 * nt
+            dst = torch.empty(taps * k * 32 * nt, dtype=torch.float32)
+            lib.esmi_pack_bfrag_f32(torch.from_numpy(w).data_ptr(), dst.data_ptr(), n, k, taps, None)
+            d = dst.numpy().reshape(taps, k // 8, nt, 64, 4)
+            t, kc, t32, lane, s = np.meshgrid(np.arange(taps), np.arange(k // 8), np.arange(nt), np.arange(64), np.arange(4),
+                                              indexing="ij")
+            row, col = 32 * t32 + (lane & 31), 8 * kc + 4 * (lane >> 5) + s
+            ref = np.where(row < n, w[t, np.minimum(row, n - 1), col], 0.0)
+            assert np.array_equal(d, ref.astype(np.float32))
+        k, cin, cout = 3, 64, 32
+        wm = rng.standard_normal((k, cin, cin)).astype(np.float32)
+        w1 = rng.standard_normal((cout, cin)).astype(np.float32)
+        dst = torch.empty((k, cout, cin), dtype=torch.float32)
+        lib.esmi_compose_merge_f32(torch.from_numpy(wm).data_ptr(), torch.from_numpy(w1).data_ptr(), k, cin, cout, dst.data_ptr(), None)
+        ref = np.einsum("om,jmi->joi", w1.astype(np.float64), wm.astype(np.float64)).astype(np.float32)
+        assert np.array_equal(dst.numpy(), ref)
