@@ -16,6 +16,7 @@
 // of every GEMM is requested one stage ahead (wave_prefetch), so hipcc can count vmcnt exactly and no stage starts
 // with an exposed round trip.  Six kernel launches and five HBM round trips of the unfused path become one launch.
 #pragma once
+#include "enc_merge_qkv.h"
 #include "wave_chain.h"
 
 #ifndef ESMI_E2_WPS
@@ -42,6 +43,7 @@ struct EncAttnFfnP {
     int wgs_per_b;                  // workgroups per utterance
     int useful;                     // positions stored per workgroup: 32*nw - 2*halo
     int halo;                       // 0: one workgroup covers the sequence, 1: one recomputed row per side
+    EncMergeP m;                    // whole-block instantiations (NCI > 0) only: the merge conv / qkv stage's inputs
 };
 
 constexpr int kEncMaxWaves = 4;     // waves per workgroup (one per SIMD)
@@ -59,11 +61,24 @@ inline void enc_attn_ffn_plan(int n, int ld_floats, int* nw, int* wgs, int* usef
     *nw = best; *useful = 32 * best - 2; *wgs = (n + *useful - 1) / *useful; *halo = 1;
 }
 
-template <int NKT, int NC, int E>   // keys <= 32*NKT, C = 32*NC, MixFFN hidden = E*C
+// row stride of the LDS-resident qkv tile of the whole-block kernels: == 4 (mod 64) floats, so that the 16-byte
+// K / Q row fragments of 32 consecutive rows are bank-conflict free
+__host__ __device__ inline int enc_qkv_ld(int h, int C) { return ((3 * h * C + 63) & ~63) + 4; }
+inline int enc_block_lds_floats(int C, int h, int expansion, int c_in, int k, int stride, int nw) {
+    const int stg = nw * (31 * stride + k) * (c_in + 4), qkv = 32 * nw * enc_qkv_ld(h, C);
+    return (32 * nw + 2) * (expansion * C + 4) + (stg > qkv ? stg : qkv);
+}
+
+// NCI == 0: x and qkv come from global memory (written by enc_merge_qkv_kernel).
+// NCI  > 0: WHOLE BLOCK in one launch, for sequences one workgroup covers (N <= 128): each wave first runs the merge
+//           conv + qkv stage of its 32 rows (Cin = 32*NCI, kernel KT, stride STRIDE); q/k/v go to an LDS tile shared by
+//           the workgroup and x stays in registers as the residual -- neither ever touches HBM.
+template <int NKT, int NC, int E, int NCI = 0, int KT = 1, int STRIDE = 1>   // keys <= 32*NKT, C = 32*NC, MixFFN hidden = E*C
 __global__ __launch_bounds__(64 * kEncMaxWaves, ESMI_E2_WPS) void enc_attn_ffn_kernel(const EncAttnFfnP p) {
     constexpr int NE = NC * E;
     constexpr int C = 32 * NC, EC = 32 * NE;
     constexpr int LD = EC + 4;
+    constexpr bool FUSED = NCI > 0;
     ESMI_DYN_LDS(lds);              // [32*nw + 2][LD]: first and last row are the zero rows around the workgroup's tile
     const int nw = (int)(blockDim.x >> 6), w = wave_id();
     const int lane = lane_id(), i = lane & 31, h2 = lane >> 5;
@@ -84,6 +99,34 @@ __global__ __launch_bounds__(64 * kEncMaxWaves, ESMI_E2_WPS) void enc_attn_ffn_k
     const BufRsrc r_out = make_rsrc(p.out + (long)b * p.N * C, (long)p.N * C * 4);
     ESMI_CT_INIT(NC == 1 ? 0 : 1);
     ESMI_CT();   // 0 start
+    const int ldq = enc_qkv_ld(p.h, C);
+    float* qkv_t = lds + (32 * nw + 2) * LD;               // FUSED: [32*nw][ldq], aliased by the waves' input staging tiles
+    f32x16 xacc[FUSED ? NC : 1];
+    if constexpr (FUSED) {
+        // ---------------- merge conv + qkv of this wave's rows (enc_merge_qkv.h), results stay on the CU
+        constexpr int CIN = 32 * NCI;
+        float* stg = qkv_t + w * ((31 * STRIDE + KT) * (CIN + 4));
+        merge_conv_tile<NCI, NC, KT, STRIDE>(p.m, b, r0, stg, lane, xacc);
+        const int nq = 3 * p.h * C, ntq = nq >> 5;
+        WaveGrp<4> gq;
+        wave_prefetch<4>(gq, p.m.qkv_w, ntq, 0, 0, lane);
+        tile_store<NC>(buf, LD, 0, xacc, lane);
+        __syncthreads();            // every wave is done with its staging tile: the region becomes the qkv tile
+        for (int n0 = 0; n0 < nq; n0 += 128) {
+            f32x16 q[4];
+            zero_tiles<4>(q);
+            wave_gemm_k<4, NC>(q, gq, a_row, true, p.m.qkv_w, ntq, 0, n0 >> 5, lane);
+            if (n0 + 128 < nq) wave_prefetch<4>(gq, p.m.qkv_w, ntq, 0, (n0 + 128) >> 5, lane);
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                if (n0 + 32 * nt < nq) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) qkv_t[(r0 + tile_row(r, lane)) * ldq + n0 + 32 * nt + i] = q[nt][r];
+                }
+            }
+        }
+        __syncthreads();            // q / k / v of the whole sequence are in place
+    }
 
     // ---------------- prologue: everything that does not depend on a result is requested now, nothing is waited for.
     // Rows outside [0, N) are out of range of their buffers: negative positions wrap to huge unsigned offsets.
@@ -98,7 +141,7 @@ __global__ __launch_bounds__(64 * kEncMaxWaves, ESMI_E2_WPS) void enc_attn_ffn_k
     for (int kt = 0; kt < NKT; ++kt) k_off[kt] = (unsigned)((((32 * kt + i) * ld) + p.h * C + 4 * h2) * 4);
     WaveGrp<NC> gp;                 // proj weights, head 0
     wave_prefetch<NC>(gp, p.proj_w, NC, 0, 0, lane);
-    constexpr bool kHoistRes = NC <= 2;
+    constexpr bool kHoistRes = NC <= 2 && !FUSED;
     f32x16 xres[kHoistRes ? NC : 1];
     if (kHoistRes) {
 #pragma unroll
@@ -133,9 +176,18 @@ __global__ __launch_bounds__(64 * kEncMaxWaves, ESMI_E2_WPS) void enc_attn_ffn_k
             f32x4 qv[4], kv[4][NKT];
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                qv[g] = buf_ld4(r_qkv, q_off + hd_off + 32u * (kc + g));
+                if constexpr (FUSED) {
+                    qv[g] = ld4(qkv_t + (r0 + i) * ldq + hd * C + 8 * (kc + g) + 4 * h2);
 #pragma unroll
-                for (int kt = 0; kt < NKT; ++kt) kv[g][kt] = buf_ld4(r_qkv, k_off[kt] + hd_off + 32u * (kc + g));
+                    for (int kt = 0; kt < NKT; ++kt) {   // key tiles beyond the workgroup's rows alias its last tile (their scores are masked)
+                        const int krow = 32 * (kt < nw ? kt : nw - 1) + i;
+                        kv[g][kt] = ld4(qkv_t + krow * ldq + (p.h + hd) * C + 8 * (kc + g) + 4 * h2);
+                    }
+                } else {
+                    qv[g] = buf_ld4(r_qkv, q_off + hd_off + 32u * (kc + g));
+#pragma unroll
+                    for (int kt = 0; kt < NKT; ++kt) kv[g][kt] = buf_ld4(r_qkv, k_off[kt] + hd_off + 32u * (kc + g));
+                }
             }
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
@@ -155,7 +207,11 @@ __global__ __launch_bounds__(64 * kEncMaxWaves, ESMI_E2_WPS) void enc_attn_ffn_k
             for (int rr = 0; rr < 4; ++rr) {
                 const int key = 32 * kt + tile_row(r4 + rr, lane);   // differs between the half waves: that IS the k index
 #pragma unroll
-                for (int nt = 0; nt < NC; ++nt) gq.v[rr][nt] = buf_ld(r_qkv, v_base + (unsigned)((key * ld + 32 * nt) * 4));
+                for (int nt = 0; nt < NC; ++nt) {
+                    if constexpr (FUSED)   // keys beyond the workgroup's rows: P = 0, any finite V will do
+                        gq.v[rr][nt] = qkv_t[(key < 32 * nw ? key : 32 * nw - 1) * ldq + (2 * p.h + hd) * C + 32 * nt + i];
+                    else gq.v[rr][nt] = buf_ld(r_qkv, v_base + (unsigned)((key * ld + 32 * nt) * 4));
+                }
             }
         };
         VG v0, v1;
@@ -234,7 +290,8 @@ __global__ __launch_bounds__(64 * kEncMaxWaves, ESMI_E2_WPS) void enc_attn_ffn_k
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             float xr;
-            if (kHoistRes) xr = xres[kHoistRes ? nt : 0][r];
+            if (FUSED) xr = xacc[FUSED ? nt : 0][r];
+            else if (kHoistRes) xr = xres[kHoistRes ? nt : 0][r];
             else xr = buf_ld(r_x, (unsigned)(((t0 + tile_row(r, lane)) * C + col) * 4));
             y[nt][r] += pb_[nt] + xr;
         }
@@ -373,11 +430,19 @@ __device__ __forceinline__ void layernorm_split(f32x16 (&v)[NH], const float (&g
     }
 }
 
-template <int NKT, int NC, int E>   // h == 2; keys <= 32*NKT, C = 32*NC (NC even), MixFFN hidden = E*C
+inline int enc_block_split_lds_floats(int C, int h, int expansion, int c_in, int k, int stride, int nw) {
+    const int stg = 2 * nw * (31 * stride + k) * (c_in + 4), qkv = 32 * nw * enc_qkv_ld(h, C);
+    return enc_attn_ffn_split_lds_floats(C, h, expansion, nw) + (stg > qkv ? stg : qkv);
+}
+
+// NCI > 0: whole block in one launch (see enc_attn_ffn_kernel): both waves of a pair run the (cheap) merge conv of their
+// row tile, wave c then computes the q / k / v columns of head c into the shared LDS tile.
+template <int NKT, int NC, int E, int NCI = 0, int KT = 1, int STRIDE = 1>   // h == 2; keys <= 32*NKT, C = 32*NC (NC even), MixFFN hidden = E*C
 __global__ __launch_bounds__(128 * kEncSplitMaxTiles, ESMI_E2_WPS) void enc_attn_ffn_split_kernel(const EncAttnFfnP p) {
     constexpr int NE = NC * E, NCH = NC / 2, NEH = NE / 2;
     constexpr int C = 32 * NC, EC = 32 * NE, HC = 2 * C;
     constexpr int LD = (HC > EC ? HC : EC) + 4;
+    constexpr bool FUSED = NCI > 0;
     ESMI_DYN_LDS(lds);              // [32*nw + 2][LD] shared tile (zero rows around), then the LayerNorm statistics
     const int nw = (int)(blockDim.x >> 7), w = wave_id();
     const int rt = w >> 1, c = w & 1;                       // row tile, column half / head
@@ -387,6 +452,7 @@ __global__ __launch_bounds__(128 * kEncSplitMaxTiles, ESMI_E2_WPS) void enc_attn
     const int t0 = wg * p.useful - p.halo + r0;
     float* buf = lds + LD * (1 + r0);
     float* stats = lds + (32 * nw + 2) * LD;
+    float* qkv_t = stats + nw * 2 * 32 * 2;                 // FUSED: [32*nw][ldq], aliased by the waves' input staging tiles
     for (int cc = (int)threadIdx.x; cc < LD; cc += (int)blockDim.x) {
         lds[cc] = 0.0f;
         lds[(32 * nw + 1) * LD + cc] = 0.0f;
@@ -394,12 +460,38 @@ __global__ __launch_bounds__(128 * kEncSplitMaxTiles, ESMI_E2_WPS) void enc_attn
     const int pos_i = t0 + i;
     const float* a_row = buf + i * LD + 4 * h2;
     const int ld = 3 * 2 * C;
+    const int ldq = enc_qkv_ld(2, C);
     const BufRsrc r_qkv = make_rsrc(p.qkv + (long)b * p.N * ld, (long)p.N * ld * 4);
     const BufRsrc r_x = make_rsrc(p.x + (long)b * p.N * C, (long)p.N * C * 4);
     const BufRsrc r_mask = make_rsrc(p.mask ? p.mask + (long)b * p.mask_len : nullptr, p.mask_len);
     const BufRsrc r_out = make_rsrc(p.out + (long)b * p.N * C, (long)p.N * C * 4);
     const int c0 = 32 * NCH * c;                            // first output column of this wave (width C stages)
     const int e0 = 32 * NEH * c;                            // first hidden column of this wave
+    f32x16 xacc[FUSED ? NC : 1];
+    if constexpr (FUSED) {
+        constexpr int CIN = 32 * NCI;
+        float* stg = qkv_t + w * ((31 * STRIDE + KT) * (CIN + 4));
+        merge_conv_tile<NCI, NC, KT, STRIDE>(p.m, b, r0, stg, lane, xacc);
+        const int ntq = (3 * 2 * C) >> 5;
+        WaveGrp<NC> gq;
+        wave_prefetch<NC>(gq, p.m.qkv_w, ntq, 0, c * NC, lane);
+        if (c == 0) tile_store<NC>(buf, LD, 0, xacc, lane);   // both waves of the pair hold the same x
+        __syncthreads();            // x tile written; every wave is done with its staging tile
+#pragma unroll
+        for (int part = 0; part < 3; ++part) {                // q, k, v columns of head c
+            f32x16 q[NC];
+            zero_tiles<NC>(q);
+            wave_gemm_k<NC, NC>(q, gq, a_row, true, p.m.qkv_w, ntq, 0, (2 * part + c) * NC, lane);
+            if (part < 2) wave_prefetch<NC>(gq, p.m.qkv_w, ntq, 0, (2 * (part + 1) + c) * NC, lane);
+#pragma unroll
+            for (int nt = 0; nt < NC; ++nt) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    qkv_t[(r0 + tile_row(r, lane)) * ldq + (2 * part + c) * C + 32 * nt + i] = q[nt][r];
+            }
+        }
+        __syncthreads();            // q / k / v of the whole sequence are in place; the x tile has been read
+    }
 
     // ---------------- prologue loads (nothing waited for)
     unsigned mb = 0;
@@ -417,8 +509,14 @@ __global__ __launch_bounds__(128 * kEncSplitMaxTiles, ESMI_E2_WPS) void enc_attn
     f32x16 xres[NCH];
 #pragma unroll
     for (int nt = 0; nt < NCH; ++nt) {
+        if constexpr (FUSED) {      // this wave's column half of x (static register indices, wave-uniform select)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) xres[nt][r] = buf_ld(r_x, (unsigned)(((t0 + tile_row(r, lane)) * C + c0 + 32 * nt + i) * 4));
+            for (int r = 0; r < 16; ++r) xres[nt][r] = c ? xacc[FUSED ? NCH + nt : 0][r] : xacc[FUSED ? nt : 0][r];
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                xres[nt][r] = buf_ld(r_x, (unsigned)(((t0 + tile_row(r, lane)) * C + c0 + 32 * nt + i) * 4));
+        }
     }
     float pb_[NCH], g1_[NCH], be1_[NCH], b2_[NCH], g2_[NCH], be2_[NCH], m1b_[NEH], cb_[NEH];
 #pragma unroll
@@ -440,9 +538,18 @@ __global__ __launch_bounds__(128 * kEncSplitMaxTiles, ESMI_E2_WPS) void enc_attn
         f32x4 qv[4], kv[4][NKT];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            qv[g] = buf_ld4(r_qkv, q_off + 32u * (kc + g));
+            if constexpr (FUSED) {
+                qv[g] = ld4(qkv_t + (r0 + i) * ldq + c * C + 8 * (kc + g) + 4 * h2);
 #pragma unroll
-            for (int kt = 0; kt < NKT; ++kt) kv[g][kt] = buf_ld4(r_qkv, k_off[kt] + 32u * (kc + g));
+                for (int kt = 0; kt < NKT; ++kt) {   // key tiles beyond the workgroup's rows alias its last tile (scores masked)
+                    const int krow = 32 * (kt < nw ? kt : nw - 1) + i;
+                    kv[g][kt] = ld4(qkv_t + krow * ldq + (2 + c) * C + 8 * (kc + g) + 4 * h2);
+                }
+            } else {
+                qv[g] = buf_ld4(r_qkv, q_off + 32u * (kc + g));
+#pragma unroll
+                for (int kt = 0; kt < NKT; ++kt) kv[g][kt] = buf_ld4(r_qkv, k_off[kt] + 32u * (kc + g));
+            }
         }
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -460,7 +567,10 @@ __global__ __launch_bounds__(128 * kEncSplitMaxTiles, ESMI_E2_WPS) void enc_attn
         for (int rr = 0; rr < 4; ++rr) {
             const int key = 32 * kt + tile_row(r4 + rr, lane);
 #pragma unroll
-            for (int nt = 0; nt < NC; ++nt) gq.v[rr][nt] = buf_ld(r_qkv, v_base + (unsigned)((key * ld + 32 * nt) * 4));
+            for (int nt = 0; nt < NC; ++nt) {
+                if constexpr (FUSED) gq.v[rr][nt] = qkv_t[(key < 32 * nw ? key : 32 * nw - 1) * ldq + (4 + c) * C + 32 * nt + i];
+                else gq.v[rr][nt] = buf_ld(r_qkv, v_base + (unsigned)((key * ld + 32 * nt) * 4));
+            }
         }
     };
     VG v0, v1;

@@ -47,31 +47,25 @@ inline int enc_merge_lds_floats(int c_in, int c_out, int k, int stride) {
     return in_t > x_t ? in_t : x_t;
 }
 
-template <int NCI, int NC, int KT, int STRIDE>   // Cin = 32*NCI, C = 32*NC, merge kernel KT, stride STRIDE
-__global__ __launch_bounds__(64, ESMI_E1_WPS) void enc_merge_qkv_kernel(const EncMergeP p) {
+// Stage the input rows under one 32-row output tile in `stg` ([31*STRIDE + KT][Cin + 4], private to the wave) with
+// full-row coalesced loads, then run the composed k-tap conv: x = tile rows [t0, t0 + 32) of utterance b.
+// (Reading the A fragments straight from global memory -- 32 rows x 32 bytes per instruction, every 128-byte line
+// touched by four instructions -- cost more than the MFMAs of the composed conv.)  Rows outside [0, n_in) are the
+// conv's zero padding.
+template <int NCI, int NC, int KT, int STRIDE>
+__device__ __forceinline__ void merge_conv_tile(const EncMergeP& p, int b, int t0, float* stg, int lane, f32x16 (&x)[NC]) {
     constexpr int CIN = 32 * NCI, C = 32 * NC;
-    constexpr int LDI = CIN + 4, LD = C + 4;
+    constexpr int LDI = CIN + 4;
     constexpr int LPR = 8 * NCI;               // lanes per input row (16 bytes each)
     constexpr int RPI = 64 / LPR;              // input rows per wave-wide load
-    constexpr int NROWS = 31 * STRIDE + KT;     // input rows under one 32-row output tile
+    constexpr int NROWS = 31 * STRIDE + KT;    // input rows under one 32-row output tile
     constexpr int MAXI = (NROWS + RPI - 1) / RPI;
-    ESMI_DYN_LDS(buf);             // input rows [NROWS][LDI], later the x tile [32][LD]
-    ESMI_CT_INIT(NCI == 4 && NC == 1 ? 3 : 4);
-    ESMI_CT();
-    const int lane = lane_id(), i = lane & 31, h2 = lane >> 5;
-    const int b = (int)blockIdx.x / p.tiles_per_b, tile = (int)blockIdx.x - b * p.tiles_per_b;
-    const int t0 = tile * 32;
-    const float* a_row = buf + i * LD + 4 * h2;
-
-    // ---- stage the input rows of this tile in LDS with full-row coalesced loads.  (Reading the A fragments
-    // straight from global memory -- 32 rows x 32 bytes per instruction, every 128-byte line touched by four
-    // instructions -- cost more than the MFMAs of the composed conv.)  Rows outside [0, n_in) are the conv's zero
-    // padding.
+    const int i = lane & 31, h2 = lane >> 5;
     WaveGrp<NC> gc;
     wave_prefetch<NC>(gc, p.merge_w, NC, 0, 0, lane);
     const int ti0 = t0 * STRIDE - p.pad;        // input position of staged row 0
     const int lrow = lane / LPR, lchunk = lane - lrow * LPR;
-    f32x4 stg[MAXI];
+    f32x4 sv[MAXI];
     if (p.ids) {                   // block 0: the embedding gather is the conv's input
         int id[MAXI];
 #pragma unroll
@@ -83,36 +77,47 @@ __global__ __launch_bounds__(64, ESMI_E1_WPS) void enc_merge_qkv_kernel(const En
         for (int m = 0; m < MAXI; ++m) {
             const int ti = ti0 + m * RPI + lrow;
             if (id[m] < 0 || id[m] >= p.vocab) id[m] = 0;   // the reference raises IndexError; stay in bounds
-            stg[m] = ld4(p.table + (long)id[m] * CIN + 4 * lchunk);
-            if (ti < 0 || ti >= p.n_in) stg[m] = zero4();
+            sv[m] = ld4(p.table + (long)id[m] * CIN + 4 * lchunk);
+            if (ti < 0 || ti >= p.n_in) sv[m] = zero4();
         }
     } else {
         const BufRsrc r_in = make_rsrc(p.x_in + (long)b * p.n_in * CIN, (long)p.n_in * CIN * 4);
 #pragma unroll
         for (int m = 0; m < MAXI; ++m) {
             const int ti = ti0 + m * RPI + lrow;
-            stg[m] = buf_ld4(r_in, (unsigned)((ti * CIN + 4 * lchunk) * 4));   // out of range reads 0
+            sv[m] = buf_ld4(r_in, (unsigned)((ti * CIN + 4 * lchunk) * 4));   // out of range reads 0
         }
     }
 #pragma unroll
     for (int m = 0; m < MAXI; ++m) {
         const int rr = m * RPI + lrow;
-        if (rr < NROWS) *reinterpret_cast<f32x4*>(buf + rr * LDI + 4 * lchunk) = stg[m];
+        if (rr < NROWS) *reinterpret_cast<f32x4*>(stg + rr * LDI + 4 * lchunk) = sv[m];
     }
     lds_wave_sync();
-    ESMI_CT();
-
-    // ---- composed k-tap conv (stride s) -> x
-    f32x16 x[NC];
     zero_tiles<NC>(x);
     const float* taps[KT];
     bool tok[KT];
 #pragma unroll
     for (int j = 0; j < KT; ++j) {
-        taps[j] = buf + (i * STRIDE + j) * LDI + 4 * h2;
+        taps[j] = stg + (i * STRIDE + j) * LDI + 4 * h2;
         tok[j] = true;
     }
     wave_gemm_taps<NC, KT, NCI, false>(x, gc, taps, tok, p.merge_w, (long)CIN * C, NC, 0, 0, lane);
+}
+
+template <int NCI, int NC, int KT, int STRIDE>   // Cin = 32*NCI, C = 32*NC, merge kernel KT, stride STRIDE
+__global__ __launch_bounds__(64, ESMI_E1_WPS) void enc_merge_qkv_kernel(const EncMergeP p) {
+    constexpr int C = 32 * NC;
+    constexpr int LD = C + 4;
+    ESMI_DYN_LDS(buf);             // input rows [31*STRIDE + KT][Cin + 4], later the x tile [32][LD]
+    ESMI_CT_INIT(NCI == 4 && NC == 1 ? 3 : 4);
+    ESMI_CT();
+    const int lane = lane_id(), i = lane & 31, h2 = lane >> 5;
+    const int b = (int)blockIdx.x / p.tiles_per_b, tile = (int)blockIdx.x - b * p.tiles_per_b;
+    const int t0 = tile * 32;
+    const float* a_row = buf + i * LD + 4 * h2;
+    f32x16 x[NC];
+    merge_conv_tile<NCI, NC, KT, STRIDE>(p, b, t0, buf, lane, x);
     const int nq = 3 * p.h * C, ntq = nq >> 5;
     WaveGrp<4> gq;
     wave_prefetch<4>(gq, p.qkv_w, ntq, 0, 0, lane);

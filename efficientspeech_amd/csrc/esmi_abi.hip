@@ -108,6 +108,58 @@ bool enc_attn_ffn_supported(int C, int N, int expansion) {
     return (expansion == 1 && (nc == 1 || nc == 2 || nc == 4)) || (expansion == 2 && nc == 4);
 }
 
+// Whole encoder block (merge conv + qkv + attention + MixFFN) in one launch: sequences one workgroup covers, shapes
+// whose q/k/v tile fits in LDS.  Returns ESMI_ERR_UNSUPPORTED otherwise (-> enc_merge_qkv + enc_attn_ffn launches).
+int launch_enc_block(const EncAttnFfnP& p, int expansion, int c_in, hipStream_t st) {
+    if ((p.C & 31) || (c_in & 31) || p.N > 128) return ESMI_ERR_UNSUPPORTED;
+    const int nc = p.C / 32, nci = c_in / 32, nkt = p.N <= 64 ? 2 : 4;
+    if (p.h == 2 && nc == 2 && expansion == 1 && (g_fusion & ESMI_FUSE_SPLIT2)) {   // two waves per row tile when rows are scarce
+        int nw, wgs, useful, halo;
+        enc_attn_ffn_split_plan(p.N, &nw, &wgs, &useful, &halo);
+        if ((long)p.B * wgs * 2 * nw <= 1024) {
+            const int lds = enc_block_split_lds_floats(p.C, p.h, expansion, c_in, p.m.k, p.m.stride, nw) * (int)sizeof(float);
+            if (halo != 0 || lds > 150 * 1024 || !(nci == 1 && p.m.k == 1 && p.m.stride == 2)) return ESMI_ERR_UNSUPPORTED;
+            EncAttnFfnP q = p;
+            q.wgs_per_b = 1; q.useful = useful; q.halo = 0;
+            dim3 grid(p.B), block(128 * nw);
+            static bool attr_set = false;   // once: keeps the call out of hipGraph captures
+            if (!attr_set) {
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(enc_attn_ffn_split_kernel<2, 2, 1, 1, 1, 2>),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                if (e != hipSuccess) return (int)e;
+                attr_set = true;
+            }
+            ESMI_LAUNCH((enc_attn_ffn_split_kernel<2, 2, 1, 1, 1, 2>), grid, block, lds, st, q);   // N <= 64 here: NKT = 2
+            return launch_status();
+        }
+    }
+    int nw, wgs, useful, halo;
+    enc_attn_ffn_plan(p.N, p.C * expansion + 4, &nw, &wgs, &useful, &halo);
+    if (halo != 0) return ESMI_ERR_UNSUPPORTED;
+    const int lds = enc_block_lds_floats(p.C, p.h, expansion, c_in, p.m.k, p.m.stride, nw) * (int)sizeof(float);
+    if (lds > 150 * 1024) return ESMI_ERR_UNSUPPORTED;
+    EncAttnFfnP q = p;
+    q.wgs_per_b = 1; q.useful = useful; q.halo = 0;
+    dim3 grid(p.B), block(64 * nw);
+#define ESMI_EB(NKT, NC, E, NCI, KT, ST) \
+    if (nkt == NKT && nc == NC && expansion == E && nci == NCI && p.m.k == KT && p.m.stride == ST) {                           \
+        static bool attr_set = false; /* once per instantiation: keeps the call out of hipGraph captures */                    \
+        if (!attr_set) {                                                                                                       \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(enc_attn_ffn_kernel<NKT, NC, E, NCI, KT, ST>),    \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                       \
+            if (e != hipSuccess) return (int)e;                                                                                \
+            attr_set = true;                                                                                                   \
+        }                                                                                                                      \
+        ESMI_LAUNCH((enc_attn_ffn_kernel<NKT, NC, E, NCI, KT, ST>), grid, block, lds, st, q);                                  \
+        return launch_status();                                                                                                \
+    }
+    // tiny block 0 / small block 0 / tiny block 1 (when the split kernel does not apply)
+    ESMI_EB(2, 1, 1, 4, 3, 1) ESMI_EB(4, 1, 1, 4, 3, 1) ESMI_EB(2, 2, 1, 4, 3, 1) ESMI_EB(4, 2, 1, 4, 3, 1)
+    ESMI_EB(2, 2, 1, 1, 1, 2)
+#undef ESMI_EB
+    return ESMI_ERR_UNSUPPORTED;
+}
+
 // E2: attention + proj + LN1 + MixFFN + LN2 in one launch.
 int launch_enc_attn_ffn(const EncAttnFfnP& p, int expansion, hipStream_t st) {
     if ((p.C & 31) || p.N > 256) return ESMI_ERR_UNSUPPORTED;
@@ -265,13 +317,28 @@ int esmi_encoder_block_f32(const esmi_encoder_block_weights* w, const esmi_encod
     const bool packed = w->merge_cwp && w->qkv_wp && w->proj_wp && w->mlp1_wp && w->conv_wp && w->mlp2_wp;
     const bool fused2 = packed && (g_fusion & ESMI_FUSE_ATTN_FFN) && enc_attn_ffn_supported(C, n, s->expansion);
     float* x_mid = fused2 ? y1 : x_out;
+    EncMergeP m;
+    memset(&m, 0, sizeof m);
+    m.ids = ids; m.table = embed; m.vocab = s->vocab; m.x_in = ids ? nullptr : x_in;
+    m.B = B; m.n_in = s->n_in; m.n_out = n; m.k = s->kernel; m.stride = s->stride; m.pad = s->kernel / 2; m.h = h;
+    m.merge_w = w->merge_cwp; m.qkv_w = w->qkv_wp; m.x_out = x_mid; m.qkv = qkv;
+    m.tiles_per_b = (n + 31) / 32;
+    EncAttnFfnP f;
+    memset(&f, 0, sizeof f);
+    f.x = x_mid; f.qkv = qkv; f.B = B; f.N = n; f.C = C; f.h = h; f.scale = 1.0f / sqrtf((float)(C / h));
+    f.proj_w = w->proj_wp; f.proj_b = w->proj_b; f.ln1_g = w->ln1_g; f.ln1_b = w->ln1_b;
+    f.mlp1_w = w->mlp1_wp; f.mlp1_b = w->mlp1_b; f.conv_w = w->conv_wp; f.conv_b = w->conv_b;
+    f.mlp2_w = w->mlp2_wp; f.mlp2_b = w->mlp2_b; f.ln2_g = w->ln2_g; f.ln2_b = w->ln2_b;
+    f.mask = mask; f.out = x_out;
+    f.mask_pool = s->mask_pool > 0 ? s->mask_pool : 1; f.mask_len = s->mask_pool > 0 ? s->mask_len : n;
+    if (fused2 && (g_fusion & ESMI_FUSE_MERGE_QKV) && (g_fusion & ESMI_FUSE_BLOCK)) {   // the whole block in one launch
+        f.m = m;
+        f.x = nullptr; f.qkv = nullptr;
+        rc = launch_enc_block(f, s->expansion, s->c_in, st);
+        if (rc != ESMI_ERR_UNSUPPORTED) return rc;
+        f.x = x_mid; f.qkv = qkv;
+    }
     if (packed && (g_fusion & ESMI_FUSE_MERGE_QKV)) {   // E1: merge conv + 1x1 + qkv as one wave-chain kernel
-        EncMergeP m;
-        memset(&m, 0, sizeof m);
-        m.ids = ids; m.table = embed; m.vocab = s->vocab; m.x_in = ids ? nullptr : x_in;
-        m.B = B; m.n_in = s->n_in; m.n_out = n; m.k = s->kernel; m.stride = s->stride; m.pad = s->kernel / 2; m.h = h;
-        m.merge_w = w->merge_cwp; m.qkv_w = w->qkv_wp; m.x_out = x_mid; m.qkv = qkv;
-        m.tiles_per_b = (n + 31) / 32;
         rc = launch_enc_merge_qkv(m, s->c_in, C, st);
         if (rc == ESMI_OK) fused1 = true;
         else if (rc != ESMI_ERR_UNSUPPORTED) return rc;
@@ -296,14 +363,6 @@ int esmi_encoder_block_f32(const esmi_encoder_block_weights* w, const esmi_encod
         if ((rc = launch_convgemm(p, st))) return rc;
     }
     if (fused2) {   // E2: attention + proj + LN1 + MixFFN + LN2 as one wave-chain kernel
-        EncAttnFfnP f;
-        memset(&f, 0, sizeof f);
-        f.x = x_mid; f.qkv = qkv; f.B = B; f.N = n; f.C = C; f.h = h; f.scale = 1.0f / sqrtf((float)(C / h));
-        f.proj_w = w->proj_wp; f.proj_b = w->proj_b; f.ln1_g = w->ln1_g; f.ln1_b = w->ln1_b;
-        f.mlp1_w = w->mlp1_wp; f.mlp1_b = w->mlp1_b; f.conv_w = w->conv_wp; f.conv_b = w->conv_b;
-        f.mlp2_w = w->mlp2_wp; f.mlp2_b = w->mlp2_b; f.ln2_g = w->ln2_g; f.ln2_b = w->ln2_b;
-        f.mask = mask; f.out = x_out;
-        f.mask_pool = s->mask_pool > 0 ? s->mask_pool : 1; f.mask_len = s->mask_pool > 0 ? s->mask_len : n;
         return launch_enc_attn_ffn(f, s->expansion, st);
     }
     if (mask && s->mask_pool > 1) {   // the one-kernel-per-op plan takes a pooled (B, n) mask: blocks.py:51-57

@@ -52,7 +52,8 @@ const char* esmi_backend(void);
 #define ESMI_FUSE_ATTN_FFN 2  /* attention + proj + LN1 + MixFFN + LN2   */
 #define ESMI_FUSE_VARIANCE 4  /* Fuse + 3 predictors + embeddings + round */
 #define ESMI_FUSE_SPLIT2 8    /* two-head blocks on short sequences: two waves per row tile */
-#define ESMI_FUSE_ALL 15
+#define ESMI_FUSE_BLOCK 16    /* whole encoder block in one launch when one workgroup covers the sequence */
+#define ESMI_FUSE_ALL 31
 int esmi_set_fusion(int enabled);
 
 /* ------------------------------------------------------------------ weight packing
