@@ -60,7 +60,7 @@ EXPORTS = (
     "esmi_fuse_workspace_bytes", "esmi_fuse_f32", "esmi_variance_adaptor_workspace_bytes",
     "esmi_variance_adaptor_f32", "esmi_length_regulate_i32", "esmi_length_regulator_indices_i32",
     "esmi_upsample_f32", "esmi_mel_decoder_blob_bytes", "esmi_mel_decoder_pack_f32", "esmi_mel_decoder_f32",
-    "esmi_mask_rows_f32", "esmi_pack_bfrag_floats", "esmi_pack_bfrag_f32", "esmi_compose_merge_f32",
+    "esmi_mask_rows_f32", "esmi_pack_bfrag_floats", "esmi_pack_bfrag_f32", "esmi_compose_merge_f32", "esmi_max_i32",
 )
 
 
@@ -90,7 +90,8 @@ def bind(lib):
     lib.esmi_fuse_variance_adaptor_workspace_bytes.argtypes = [i, i, i, i]
     lib.esmi_fuse_variance_adaptor_workspace_bytes.restype = sz
     lib.esmi_fuse_variance_adaptor_f32.argtypes = [P(FuseWeights), i, i, i, i, i, P(fp), P(i)] + [P(PredictorWeights)] * 3 + \
-        [fp] * 11 + [fp, sz, fp]
+        [fp] * 13 + [fp, sz, fp]
+    lib.esmi_max_i32.argtypes = [fp, i, fp, fp]
     lib.esmi_length_regulate_i32.argtypes = [fp, i, i, fp, fp, fp, fp]
     lib.esmi_length_regulator_indices_i32.argtypes = [fp, i, i, i, fp, fp]
     lib.esmi_upsample_f32.argtypes = [fp, fp, fp, i, i, i, i, fp, fp, fp]

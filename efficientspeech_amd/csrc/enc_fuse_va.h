@@ -42,6 +42,8 @@ struct FuseVaP {
     int* pitch_idx;
     int* energy_idx;
     int* dur;
+    int* cum;               // (B,T) inclusive cumsum of max(dur,0) and
+    int* mel_len;           // (B) its total: written when one workgroup covers the utterance (halo == 0), else NULL
     int wgs_per_b;          // workgroups per utterance
     int useful;             // positions stored per workgroup: 32*nw - 2*halo
     int halo;               // 0: one workgroup covers the sequence, 2: two recomputed rows per side
@@ -206,6 +208,7 @@ __global__ __launch_bounds__(64 * kVaMaxWaves, ESMI_E3_WPS) void enc_fuse_va_ker
     const BufRsrc r_et = make_rsrc(p.energy_t ? p.energy_t + (long)b * p.T : nullptr, (long)p.T * 4);
     const BufRsrc r_dt = make_rsrc(p.dur_t ? p.dur_t + (long)b * p.T : nullptr, (long)p.T * 4);
     const BufRsrc r_dur = make_rsrc(p.dur + (long)b * p.T, (long)p.T * 4);
+    int* sdur = reinterpret_cast<int*>(fb0);   // durations of the workgroup's rows (fb0 is dead after conv1)
     // every small parameter is requested up front: one memory round trip
     float b1[3][ND], g1[3][ND], be1[3][ND], b2[3][ND], lw[3][ND], g2[ND], be2[ND], lb[3];
 #pragma unroll
@@ -384,6 +387,7 @@ __global__ __launch_bounds__(64 * kVaMaxWaves, ESMI_E3_WPS) void enc_fuse_va_ker
                     d = fmaxf(d, 0.0f);
                 }
                 buf_st_i(r_dur, srow, (int)d);
+                if (p.cum && i == 0) sdur[r0 + tile_row(r, lane)] = rout[r] ? 0 : max((int)d, 0);
             } else {
 #pragma unroll
                 for (int nt = 0; nt < ND; ++nt) buf_st(r_feat, frow + 128u * nt, rz[r] ? 0.0f : emb[q][r][nt]);
@@ -392,6 +396,28 @@ __global__ __launch_bounds__(64 * kVaMaxWaves, ESMI_E3_WPS) void enc_fuse_va_ker
         }
     }
     ESMI_CT();   // outputs done
+    if (p.cum) {   // FeatureUpsampler's scan (networks.py:233-244) while the durations are still on the CU; T <= 128 here
+        __syncthreads();
+        if (w == 0) {
+            const int per = (p.T + 63) / 64, q0 = lane * per;
+            int local = 0;
+            for (int q = 0; q < per; ++q) local += (q0 + q < p.T) ? sdur[q0 + q] : 0;
+            int incl = local;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const int v = shfl_up_i(incl, d);
+                if (lane >= d) incl += v;
+            }
+            const BufRsrc r_cum = make_rsrc(p.cum + (long)b * p.T, (long)p.T * 4);
+            int run = incl - local;
+            for (int q = 0; q < per; ++q) {
+                run += (q0 + q < p.T) ? sdur[q0 + q] : 0;
+                buf_st_i(r_cum, (unsigned)((q0 + q) * 4), run);      // positions >= T fall off the buffer end
+            }
+            const int total = shfl_i(incl, 63);
+            if (lane == 0) p.mel_len[b] = total;
+        }
+    }
 }
 
 }  // namespace esmi

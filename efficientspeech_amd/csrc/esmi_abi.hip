@@ -497,7 +497,9 @@ int esmi_fuse_variance_adaptor_f32(const esmi_fuse_weights* fw, int depth, int d
                                    const uint8_t* mask, const float* pitch_target, const float* energy_target,
                                    const int32_t* duration_target, float* feat, float* pitch_pred, float* energy_pred,
                                    float* duration_pred, int32_t* pitch_idx, int32_t* energy_idx, int32_t* dur,
-                                   void* workspace, size_t workspace_bytes, esmi_stream_t stream) {
+                                   int32_t* cum, int32_t* mel_len, void* workspace, size_t workspace_bytes,
+                                   esmi_stream_t stream) {
+    if ((cum == nullptr) != (mel_len == nullptr)) return ESMI_ERR_ARG;
     if (!fw || !feats || !n_i || !pitch || !energy || !duration || !feat || !pitch_pred || !energy_pred ||
         !duration_pred || !dur || depth < 1 || depth > ESMI_MAX_DEPTH)
         return ESMI_ERR_ARG;
@@ -529,6 +531,8 @@ int esmi_fuse_variance_adaptor_f32(const esmi_fuse_weights* fw, int depth, int d
         p.pitch_idx = pitch_idx; p.energy_idx = energy_idx; p.dur = dur;
         int nw;
         fuse_va_plan(T, dim, depth, &nw, &p.wgs_per_b, &p.useful, &p.halo);
+        const bool scan_fused = cum && p.halo == 0;   // one workgroup sees every duration of its utterance
+        p.cum = scan_fused ? cum : nullptr; p.mel_len = scan_fused ? mel_len : nullptr;
         dim3 grid(B * p.wgs_per_b), block(64 * nw);
         const int lds = fuse_va_lds_floats(dim, depth, nw) * (int)sizeof(float);
         static bool attr_set = false;   // once: keeps the call out of hipGraph captures
@@ -545,15 +549,25 @@ int esmi_fuse_variance_adaptor_f32(const esmi_fuse_weights* fw, int depth, int d
         else if (dim == 64 && kernel == 3) ESMI_LAUNCH((enc_fuse_va_kernel<2, 3>), grid, block, lds, S(stream), p);
         else if (dim == 32) ESMI_LAUNCH((enc_fuse_va_kernel<1, 5>), grid, block, lds, S(stream), p);
         else ESMI_LAUNCH((enc_fuse_va_kernel<2, 5>), grid, block, lds, S(stream), p);
+        if (cum && !scan_fused) ESMI_LAUNCH(length_regulate_kernel, dim3(B), dim3(64), 0, S(stream), dur, T, cum, mel_len, (int*)nullptr);
         return launch_status();
     }
     if (!workspace || workspace_bytes < esmi_fuse_variance_adaptor_workspace_bytes(B, T, dim, depth)) return ESMI_ERR_WORKSPACE;
     const size_t fws = esmi_fuse_workspace_bytes(B, T, dim, depth);
     int rc = esmi_fuse_f32(fw, depth, dim, kernel, B, T, feats, n_i, mask, feat, 4 * dim, workspace, fws, stream);
     if (rc) return rc;
-    return esmi_variance_adaptor_f32(pitch, energy, duration, dim, B, T, mask, pitch_target, energy_target,
-                                     duration_target, feat, pitch_pred, energy_pred, duration_pred, pitch_idx, energy_idx,
-                                     dur, static_cast<char*>(workspace) + fws, workspace_bytes - fws, stream);
+    rc = esmi_variance_adaptor_f32(pitch, energy, duration, dim, B, T, mask, pitch_target, energy_target,
+                                   duration_target, feat, pitch_pred, energy_pred, duration_pred, pitch_idx, energy_idx,
+                                   dur, static_cast<char*>(workspace) + fws, workspace_bytes - fws, stream);
+    if (rc || !cum) return rc;
+    ESMI_LAUNCH(length_regulate_kernel, dim3(B), dim3(64), 0, S(stream), dur, T, cum, mel_len, (int*)nullptr);
+    return launch_status();
+}
+
+int esmi_max_i32(const int32_t* v, int n, int32_t* out, esmi_stream_t stream) {
+    if (!v || !out || n <= 0) return ESMI_ERR_ARG;
+    ESMI_LAUNCH(max_i32_kernel, dim3(1), dim3(64), 0, S(stream), v, n, out);
+    return launch_status();
 }
 
 int esmi_length_regulate_i32(const int32_t* dur, int B, int T, int32_t* cum, int32_t* mel_len, int32_t* lmax,
@@ -651,7 +665,8 @@ int esmi_mel_decoder_f32(const float* blob, const esmi_decoder_shape* s, const f
     if (rc) return rc;
     if (!blob || !x || !mel || B <= 0 || L_out <= 0 || !aligned16(blob) || !aligned16(x)) return ESMI_ERR_ARG;
     if (!cum && lmax_dev) return ESMI_ERR_ARG;  // direct mode: L is the tensor's own length, known to the host
-    if (!lmax_dev && lmax_host <= 0) return ESMI_ERR_ARG;
+    if (!lmax_dev && lmax_host == 0) return ESMI_ERR_ARG;
+    if (!lmax_dev && lmax_host < 0 && (!mel_len || !cum)) return ESMI_ERR_ARG;   // L derived from mel_len
     MelDecP p;
     p.blob = blob;
     p.lay = dec_layout(s->d4, s->dx2, s->kernel, s->n_blocks, s->block_depth);

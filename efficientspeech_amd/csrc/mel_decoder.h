@@ -182,7 +182,16 @@ __global__ __launch_bounds__(64 * NW, (DX2 <= 128 && NW == 8 ? ESMI_DEC_WPS : 2)
     const int i = lane & 31, h = lane >> 5;
     const int mh = w >> 2, ns = w & 3;      // NW = 4: mh == 0
     const int tile = (int)blockIdx.x, b = (int)blockIdx.y;
-    const int L = p.lmax_dev ? *p.lmax_dev : p.lmax_host;
+    int L;
+    if (p.lmax_dev) L = *p.lmax_dev;
+    else if (p.lmax_host >= 0) L = p.lmax_host;
+    else {   // the batch maximum of mel_len, by every wave for itself: one coalesced read, no extra launch, no atomics
+        int v = 0;
+        for (int j = lane; j < p.B; j += 64) v = max(v, p.mel_len[j]);
+        float f = row_max32((float)v);      // lengths are far below 2^24: exact in fp32
+        f = fmaxf(f, swap32_f(f));
+        L = (int)f;
+    }
     const int mlen = p.mel_len ? min(p.mel_len[b], L) : L;
     const int f_lo = tile * p.TL, f0 = f_lo - p.halo;
     const int out_hi = min(f_lo + p.TL, p.L_out);

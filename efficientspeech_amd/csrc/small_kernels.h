@@ -139,8 +139,18 @@ __global__ __launch_bounds__(64) void length_regulate_kernel(const int* __restri
     const int total = shfl_i(incl, 63);
     if (lane == 0) {
         mel_len[b] = total;
-        atomicMax(lmax, total);
+        if (lmax) atomicMax(lmax, total);
     }
+}
+
+// out[0] = max(v[0..n), 0): one workgroup, no atomics, no zero-initialised output needed
+__global__ __launch_bounds__(64) void max_i32_kernel(const int* __restrict__ v, int n, int* __restrict__ out) {
+    const int lane = lane_id();
+    int m = 0;
+    for (int j = lane; j < n; j += 64) m = max(m, v[j]);
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) m = max(m, shfl_i(m, lane ^ d));
+    if (lane == 0) out[0] = m;
 }
 
 // first i with cum[i] > f  (searchsorted right); T if none

@@ -450,7 +450,7 @@ class PhonemeEncoder(nn.Module):
         params = [p for d in (self.pitch_decoder, self.energy_decoder, self.duration_decoder) for p in d.parameters()]
         return self._cache.get(params, build)
 
-    def _encode(self, x, train=False):
+    def _encode(self, x, train=False, need_lmax=True):
         """Everything up to (and including) the duration scan; nothing frame-rate is materialised."""
         phoneme = x["phoneme"]
         B = phoneme.shape[0]
@@ -478,36 +478,53 @@ class PhonemeEncoder(nn.Module):
         depth = len(feats)
         ws_bytes = lib.esmi_fuse_variance_adaptor_workspace_bytes(B, T, dim, depth)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        cum = torch.empty((B, T), dtype=torch.int32, device=dev)
+        mel_len = torch.empty((B,), dtype=torch.int32, device=dev)
         fp = (C.c_void_p * depth)(*[_ptr(f) for f in feats])
         ni = (C.c_int * depth)(*[f.shape[1] for f in feats])
-        # Fuse (channels [0,dim) of feat) + the three predictors, embeddings, concat and duration rounding
+        # Fuse (channels [0,dim) of feat) + the three predictors, embeddings, concat, duration rounding and the
+        # length regulator's scan (cum, mel_len)
         lib.esmi_fuse_variance_adaptor_f32(C.byref(fw), depth, dim, self.fuse.kernel_size, B, T, fp, ni, C.byref(pw),
                                            C.byref(ew), C.byref(dw), _ptr(m8), _ptr(pitch_t), _ptr(energy_t), _ptr(dur_t),
                                            _ptr(feat), _ptr(preds[0]), _ptr(preds[1]), _ptr(preds[2]), _ptr(idxs[0]),
-                                           _ptr(idxs[1]), _ptr(dur), _ptr(ws), ws_bytes, stream)
-        cum = torch.empty((B, T), dtype=torch.int32, device=dev)
-        mel_len = torch.empty((B,), dtype=torch.int32, device=dev)
-        lmax = torch.empty((1,), dtype=torch.int32, device=dev)
-        lib.esmi_length_regulate_i32(_ptr(dur), B, T, _ptr(cum), _ptr(mel_len), _ptr(lmax), stream)
-        return dict(feat=feat, mask_u8=m8, pitch=preds[0], energy=preds[1], duration=preds[2], pitch_idx=idxs[0],
-                    energy_idx=idxs[1], dur=dur, cum=cum, mel_len=mel_len, lmax=lmax, feats=feats)
+                                           _ptr(idxs[1]), _ptr(dur), _ptr(cum), _ptr(mel_len), _ptr(ws), ws_bytes, stream)
+        enc = dict(feat=feat, mask_u8=m8, pitch=preds[0], energy=preds[1], duration=preds[2], pitch_idx=idxs[0],
+                   energy_idx=idxs[1], dur=dur, cum=cum, mel_len=mel_len, lmax=None, feats=feats)
+        if need_lmax:
+            PhonemeEncoder._lmax(enc)
+        return enc
+
+    @staticmethod
+    def _lmax(enc):
+        """Device scalar max_b mel_len[b] (the padded length L); computed on demand: with a caller-supplied output
+        length the decoder derives it from mel_len itself and no extra launch is needed."""
+        if enc["lmax"] is None:
+            lib, stream = _runtime(enc["feat"])
+            mel_len = enc["mel_len"]
+            enc["lmax"] = torch.empty((1,), dtype=torch.int32, device=mel_len.device)
+            lib.esmi_max_i32(_ptr(mel_len), mel_len.shape[0], _ptr(enc["lmax"]), stream)
+        return enc["lmax"]
 
     @staticmethod
     def _padded_len(x, enc, train):
-        """L the reference pads to: max(x['mel_len']) when training (:344), the batch max otherwise.
-        `max_mel_len` in x (extension) supplies it without a device->host sync."""
+        """(L_out, lmax_dev, lmax_host) for the decoder: L the reference pads to is max(x['mel_len']) when training
+        (:344), the batch max otherwise.  `max_mel_len` in x (extension) supplies the allocation length without a
+        device->host sync; the exact L then comes from the device (enc['lmax'] if computed, else the decoder derives
+        it from mel_len: lmax_host = -1)."""
         if train:
-            return int(torch.max(x["mel_len"]).item()), None
+            L = int(torch.max(x["mel_len"]).item())
+            return L, None, L
         if "max_mel_len" in x:
-            return int(x["max_mel_len"]), enc["lmax"]
-        return int(enc["lmax"].item()), None
+            return int(x["max_mel_len"]), enc["lmax"], -1
+        L = int(PhonemeEncoder._lmax(enc).item())
+        return L, None, L
 
     def forward(self, x, train=False):
         enc = self._encode(x, train)
         lib, stream = _runtime(enc["feat"])
         feat, cum, m8 = enc["feat"], enc["cum"], enc["mask_u8"]
         B, T, C4 = feat.shape
-        L, _ = self._padded_len(x, enc, train)
+        L, _, _ = self._padded_len(x, enc, train)
         features = torch.empty((B, L, C4), dtype=torch.float32, device=feat.device)
         masks8 = torch.empty((B, L), dtype=torch.uint8, device=feat.device)
         if L > 0:
@@ -540,9 +557,9 @@ class Phoneme2Mel(nn.Module):
             return pred
         # inference: the (B,L,4*dim) tensor is never materialised -- the decoder gathers through the
         # duration scan and applies the final masked_fill itself.
-        enc = self.encoder._encode(x, train=False)
+        enc = self.encoder._encode(x, train=False, need_lmax="max_mel_len" not in x)
         B = enc["feat"].shape[0]
-        L, lmax_dev = PhonemeEncoder._padded_len(x, enc, False)
+        L, lmax_dev, lmax_host = PhonemeEncoder._padded_len(x, enc, False)
         apply_mask = enc["mask_u8"] is not None and B > 1
-        mel = self.decoder._fused(enc["feat"], enc["cum"], enc["mel_len"], lmax_dev, L, apply_mask, L)
+        mel = self.decoder._fused(enc["feat"], enc["cum"], enc["mel_len"], lmax_dev, lmax_host, apply_mask, L)
         return mel, enc["mel_len"], enc["duration"]

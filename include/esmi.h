@@ -192,7 +192,9 @@ int esmi_variance_adaptor_f32(const esmi_predictor_weights* pitch, const esmi_pr
 
 /* Fuse + variance adaptor in ONE call (what PhonemeEncoder.forward does between the encoder and the length
  * regulator, networks.py:347-384); uses a single fused kernel when the shape allows (dim 32 or 64), else the two
- * calls above.  `feat` (B,T,4*dim) is fully written.  Arguments as in esmi_fuse_f32 / esmi_variance_adaptor_f32. */
+ * calls above.  `feat` (B,T,4*dim) is fully written.  Arguments as in esmi_fuse_f32 / esmi_variance_adaptor_f32.
+ * cum / mel_len (both or neither): also run the length regulator's scan (esmi_length_regulate_i32 without lmax) --
+ * inside the fused kernel when one workgroup covers an utterance (T <= 128), as one more launch otherwise.      */
 size_t esmi_fuse_variance_adaptor_workspace_bytes(int B, int T, int dim, int depth);
 int esmi_fuse_variance_adaptor_f32(const esmi_fuse_weights* fuse, int depth, int dim, int kernel, int B, int T,
                                    const float* const* feats, const int* n_i, const esmi_predictor_weights* pitch,
@@ -200,6 +202,7 @@ int esmi_fuse_variance_adaptor_f32(const esmi_fuse_weights* fuse, int depth, int
                                    const uint8_t* mask, const float* pitch_target, const float* energy_target,
                                    const int32_t* duration_target, float* feat, float* pitch_pred, float* energy_pred,
                                    float* duration_pred, int32_t* pitch_idx, int32_t* energy_idx, int32_t* dur,
+                                   int32_t* cum, int32_t* mel_len, /* (B,T), (B) or NULL, NULL                  */
                                    void* workspace, size_t workspace_bytes, esmi_stream_t stream);
 
 /* ------------------------------------------------------------------ Length regulator
@@ -209,6 +212,9 @@ int esmi_fuse_variance_adaptor_f32(const esmi_fuse_weights* fuse, int depth, int
  * (all on device: no host round-trip, unlike the reference's 2*B syncs).                     */
 int esmi_length_regulate_i32(const int32_t* dur, int B, int T, int32_t* cum, int32_t* mel_len, int32_t* lmax,
                              esmi_stream_t stream);
+/* out[0] = max(v[0..n), 0) -- e.g. the padded length lmax from mel_len when the scan ran inside
+ * esmi_fuse_variance_adaptor_f32 (one small workgroup, no atomics).                                 */
+int esmi_max_i32(const int32_t* v, int n, int32_t* out, esmi_stream_t stream);
 /* explicit frame -> phoneme map idx (B,L): -1 for padding frames (j >= mel_len[b]). */
 int esmi_length_regulator_indices_i32(const int32_t* cum, int B, int T, int L, int32_t* idx, esmi_stream_t stream);
 /* materialise `features` (B,L,C) and `masks` (B,L) u8 exactly as FeatureUpsampler returns them
@@ -255,7 +261,8 @@ int esmi_mel_decoder_pack_f32(const esmi_decoder_weights* w, const esmi_decoder_
  *    Phoneme2Mel.forward's encoder->decoder hand-off without materialising (B,L,d4).
  *  - direct (cum == NULL): `x` is (B,L,d4) exactly as MelDecoder.forward receives it.
  * L is the padded length the reference's Conv1d sees (zero padding beyond it): *lmax_dev if
- * lmax_dev != NULL, else lmax_host.  mel is (B, L_out, n_mel); rows in [L, L_out) are zeroed.
+ * lmax_dev != NULL, else lmax_host if >= 0, else max_b mel_len[b] (every workgroup derives it from
+ * mel_len, which is then required).  mel is (B, L_out, n_mel); rows in [L, L_out) are zeroed.
  * mel_len != NULL && apply_mask: rows >= mel_len[b] are zeroed (Phoneme2Mel's final
  * masked_fill, networks.py:424-427).                                                          */
 int esmi_mel_decoder_f32(const float* blob, const esmi_decoder_shape* s, const float* x, const int32_t* cum,
