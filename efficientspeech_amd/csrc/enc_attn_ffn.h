@@ -74,12 +74,14 @@ inline int enc_block_lds_floats(int C, int h, int expansion, int c_in, int k, in
 //           conv + qkv stage of its 32 rows (Cin = 32*NCI, kernel KT, stride STRIDE); q/k/v go to an LDS tile shared by
 //           the workgroup and x stays in registers as the residual -- neither ever touches HBM.
 template <int NKT, int NC, int E, int NCI = 0, int KT = 1, int STRIDE = 1>   // keys <= 32*NKT, C = 32*NC, MixFFN hidden = E*C
-__global__ __launch_bounds__(64 * kEncMaxWaves, ESMI_E2_WPS) void enc_attn_ffn_kernel(const EncAttnFfnP p) {
+__device__ __forceinline__ void enc_attn_ffn_body(const EncAttnFfnP& p) {
     constexpr int NE = NC * E;
     constexpr int C = 32 * NC, EC = 32 * NE;
     constexpr int LD = EC + 4;
     constexpr bool FUSED = NCI > 0;
     ESMI_DYN_LDS(lds);              // [32*nw + 2][LD]: first and last row are the zero rows around the workgroup's tile
+    ESMI_CT_INIT(NC == 1 ? 0 : 1);
+    ESMI_CT();   // entry
     const int nw = (int)(blockDim.x >> 6), w = wave_id();
     const int lane = lane_id(), i = lane & 31, h2 = lane >> 5;
     const int b = (int)blockIdx.x / p.wgs_per_b, wg = (int)blockIdx.x - b * p.wgs_per_b;
@@ -97,7 +99,6 @@ __global__ __launch_bounds__(64 * kEncMaxWaves, ESMI_E2_WPS) void enc_attn_ffn_k
     const BufRsrc r_x = make_rsrc(p.x + (long)b * p.N * C, (long)p.N * C * 4);
     const BufRsrc r_mask = make_rsrc(p.mask ? p.mask + (long)b * p.mask_len : nullptr, p.mask_len);
     const BufRsrc r_out = make_rsrc(p.out + (long)b * p.N * C, (long)p.N * C * 4);
-    ESMI_CT_INIT(NC == 1 ? 0 : 1);
     ESMI_CT();   // 0 start
     const int ldq = enc_qkv_ld(p.h, C);
     float* qkv_t = lds + (32 * nw + 2) * LD;               // FUSED: [32*nw][ldq], aliased by the waves' input staging tiles
@@ -361,6 +362,12 @@ __global__ __launch_bounds__(64 * kEncMaxWaves, ESMI_E2_WPS) void enc_attn_ffn_k
     }
 }
 
+template <int NKT, int NC, int E, int NCI = 0, int KT = 1, int STRIDE = 1>
+__global__ __launch_bounds__(64 * kEncMaxWaves, ESMI_E2_WPS) void enc_attn_ffn_kernel(const EncAttnFfnP p) {
+    enc_attn_ffn_body<NKT, NC, E, NCI, KT, STRIDE>(p);
+}
+
+
 }  // namespace esmi
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -438,12 +445,14 @@ inline int enc_block_split_lds_floats(int C, int h, int expansion, int c_in, int
 // NCI > 0: whole block in one launch (see enc_attn_ffn_kernel): both waves of a pair run the (cheap) merge conv of their
 // row tile, wave c then computes the q / k / v columns of head c into the shared LDS tile.
 template <int NKT, int NC, int E, int NCI = 0, int KT = 1, int STRIDE = 1>   // h == 2; keys <= 32*NKT, C = 32*NC (NC even), MixFFN hidden = E*C
-__global__ __launch_bounds__(128 * kEncSplitMaxTiles, ESMI_E2_WPS) void enc_attn_ffn_split_kernel(const EncAttnFfnP p) {
+__device__ __forceinline__ void enc_attn_ffn_split_body(const EncAttnFfnP& p) {
     constexpr int NE = NC * E, NCH = NC / 2, NEH = NE / 2;
     constexpr int C = 32 * NC, EC = 32 * NE, HC = 2 * C;
     constexpr int LD = (HC > EC ? HC : EC) + 4;
     constexpr bool FUSED = NCI > 0;
     ESMI_DYN_LDS(lds);              // [32*nw + 2][LD] shared tile (zero rows around), then the LayerNorm statistics
+    ESMI_CT_INIT(1);
+    ESMI_CT();   // entry
     const int nw = (int)(blockDim.x >> 7), w = wave_id();
     const int rt = w >> 1, c = w & 1;                       // row tile, column half / head
     const int lane = lane_id(), i = lane & 31, h2 = lane >> 5;
@@ -687,6 +696,7 @@ __global__ __launch_bounds__(128 * kEncSplitMaxTiles, ESMI_E2_WPS) void enc_attn
         for (int r = 0; r < 16; ++r) z[nt][r] += b2_[nt] + y[nt][r];
     }
     layernorm_split<NCH>(z, g2_, be2_, stats, rt, c, lane);
+    ESMI_CT();   // LN2 done
     const int row_lo = p.halo, row_hi = 32 * nw - p.halo;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -697,5 +707,11 @@ __global__ __launch_bounds__(128 * kEncSplitMaxTiles, ESMI_E2_WPS) void enc_attn
         for (int nt = 0; nt < NCH; ++nt) buf_st(r_out, off + 128u * nt, rz[r] ? 0.0f : z[nt][r]);
     }
 }
+
+template <int NKT, int NC, int E, int NCI = 0, int KT = 1, int STRIDE = 1>
+__global__ __launch_bounds__(128 * kEncSplitMaxTiles, ESMI_E2_WPS) void enc_attn_ffn_split_kernel(const EncAttnFfnP p) {
+    enc_attn_ffn_split_body<NKT, NC, E, NCI, KT, STRIDE>(p);
+}
+
 
 }  // namespace esmi

@@ -74,7 +74,7 @@ inline void fuse_va_plan(int n, int dim, int depth, int* nw, int* wgs, int* usef
 __device__ __forceinline__ int floor_div(int a, int b) { return a >= 0 ? a / b : -((-a + b - 1) / b); }
 
 template <int ND, int KU>   // dim = 32*ND, ConvTranspose1d kernel KU
-__global__ __launch_bounds__(64 * kVaMaxWaves, ESMI_E3_WPS) void enc_fuse_va_kernel(const FuseVaP p) {
+__device__ __forceinline__ void enc_fuse_va_body(const FuseVaP& p) {
     constexpr int DIM = 32 * ND, LDD = DIM + 4, LDT = 3 * DIM + 4;
     ESMI_DYN_LDS(lds);
     const int nw = (int)(blockDim.x >> 6), w = wave_id();
@@ -419,5 +419,11 @@ __global__ __launch_bounds__(64 * kVaMaxWaves, ESMI_E3_WPS) void enc_fuse_va_ker
         }
     }
 }
+
+template <int ND, int KU>
+__global__ __launch_bounds__(64 * kVaMaxWaves, ESMI_E3_WPS) void enc_fuse_va_kernel(const FuseVaP p) {
+    enc_fuse_va_body<ND, KU>(p);
+}
+
 
 }  // namespace esmi

@@ -148,6 +148,21 @@ __host__ __device__ constexpr int dec_lds_floats(int kd) {
 // one workgroup's tanh / LayerNorm / depthwise phases run under the other's K loop -- but with ROCm 7.2's hipcc the
 // 4-wave build needs 256 VGPRs + 212 spilled and is slower (700 vs 560 us); kept selectable for the next round.
 // (Also tried and dropped in round 1: two windows per workgroup in explicit ping-pong -- correct, 330-450 spills.)
+// max_b mel_len[b], by every wave for itself: one coalesced read, no extra launch, no atomics; the result is made
+// wave-uniform (SGPR) at once.
+__device__ __forceinline__ int batch_max_len(const int* __restrict__ mel_len, int B) {
+    const int lane = lane_id();
+    int v = 0;
+    for (int j = lane; j < B; j += 64) v = max(v, mel_len[j]);
+    float f = row_max32((float)v);      // lengths are far below 2^24: exact in fp32
+    f = fmaxf(f, swap32_f(f));
+#ifdef ESMI_WAVESIM
+    return (int)f;
+#else
+    return __builtin_amdgcn_readfirstlane((int)f);
+#endif
+}
+
 template <int DX2, int KD, int NW>
 __global__ __launch_bounds__(64 * NW, (DX2 <= 128 && NW == 8 ? ESMI_DEC_WPS : 2)) void mel_decoder_kernel(const MelDecP p) {
     constexpr int kDecThreads = 64 * NW;    // shadows the namespace constant inside this kernel
@@ -182,16 +197,7 @@ __global__ __launch_bounds__(64 * NW, (DX2 <= 128 && NW == 8 ? ESMI_DEC_WPS : 2)
     const int i = lane & 31, h = lane >> 5;
     const int mh = w >> 2, ns = w & 3;      // NW = 4: mh == 0
     const int tile = (int)blockIdx.x, b = (int)blockIdx.y;
-    int L;
-    if (p.lmax_dev) L = *p.lmax_dev;
-    else if (p.lmax_host >= 0) L = p.lmax_host;
-    else {   // the batch maximum of mel_len, by every wave for itself: one coalesced read, no extra launch, no atomics
-        int v = 0;
-        for (int j = lane; j < p.B; j += 64) v = max(v, p.mel_len[j]);
-        float f = row_max32((float)v);      // lengths are far below 2^24: exact in fp32
-        f = fmaxf(f, swap32_f(f));
-        L = (int)f;
-    }
+    const int L = p.lmax_dev ? *p.lmax_dev : (p.lmax_host >= 0 ? p.lmax_host : batch_max_len(p.mel_len, p.B));
     const int mlen = p.mel_len ? min(p.mel_len[b], L) : L;
     const int f_lo = tile * p.TL, f0 = f_lo - p.halo;
     const int out_hi = min(f_lo + p.TL, p.L_out);
