@@ -236,13 +236,13 @@ __device__ __forceinline__ void enc_attn_ffn_body(const EncAttnFfnP& p) {
         for (int kt = 0; kt < NKT; ++kt) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float e = expf(s[kt][r] - mx);
+                const float e = exp_fast_f32(s[kt][r] - mx);
                 s[kt][r] = e;
                 den += e;
             }
         }
         den += swap32_f(den);
-        const float inv = 1.0f / den;
+        const float inv = rcp_fast_f32(den);
         ESMI_CT();   // 2 softmax done
         f32x16 o[NC];           // ctx[query][c] = sum_key P[query][key] V[key][c]
         zero_tiles<NC>(o);
@@ -334,7 +334,7 @@ __device__ __forceinline__ void enc_attn_ffn_body(const EncAttnFfnP& p) {
 #pragma unroll
     for (int nt = 0; nt < NE; ++nt) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) m[nt][r] = gelu_erf_f32(m[nt][r] + cb_[nt]);
+        for (int r = 0; r < 16; ++r) m[nt][r] = gelu_fast_f32(m[nt][r] + cb_[nt]);
     }
     __syncthreads();            // every wave has read its neighbours' rows
     tile_store<NE>(buf, LD, 0, m, lane);
@@ -431,7 +431,7 @@ __device__ __forceinline__ void layernorm_split(f32x16 (&v)[NH], const float (&g
         const float mean = 0.5f * (ma + mb);
         const float d = mb - ma;
         const float m2 = (qa + qb) + d * d * (float)(16 * NH);                      // n_a n_b / (n_a + n_b) = 32*NH / 2
-        const float rstd = 1.0f / sqrtf(m2 * (0.5f * inv_h) + eps);
+        const float rstd = rsqrt_fast_f32(m2 * (0.5f * inv_h) + eps);
 #pragma unroll
         for (int nt = 0; nt < NH; ++nt) v[nt][r] = fmaf((v[nt][r] - mean) * rstd, gg[nt], bb[nt]);
     }
@@ -602,13 +602,13 @@ __device__ __forceinline__ void enc_attn_ffn_split_body(const EncAttnFfnP& p) {
     for (int kt = 0; kt < NKT; ++kt) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const float e = expf(s[kt][r] - mx);
+            const float e = exp_fast_f32(s[kt][r] - mx);
             s[kt][r] = e;
             den += e;
         }
     }
     den += swap32_f(den);
-    const float inv = 1.0f / den;
+    const float inv = rcp_fast_f32(den);
     f32x16 o[NC];
     zero_tiles<NC>(o);
 #pragma unroll
@@ -682,7 +682,7 @@ __device__ __forceinline__ void enc_attn_ffn_split_body(const EncAttnFfnP& p) {
 #pragma unroll
     for (int nt = 0; nt < NEH; ++nt) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) m[nt][r] = gelu_erf_f32(m[nt][r] + cb_[nt]);
+        for (int r = 0; r < 16; ++r) m[nt][r] = gelu_fast_f32(m[nt][r] + cb_[nt]);
     }
     __syncthreads();            // every wave has read what it needs of the hidden tile
     tile_store<NEH>(buf, LD, e0, m, lane);

@@ -139,6 +139,40 @@ __device__ __forceinline__ float tanh_fast_f32(float x) {
     return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + e);
 #endif
 }
+// hardware transcendentals for the fused encoder-side kernels (v_exp_f32 / v_rsq_f32: ~1 ulp); the one-kernel-per-op plan and
+// the oracle keep the libm forms.  The simulator mirrors the formulas with libm calls.
+__device__ __forceinline__ float exp_fast_f32(float x) {
+#ifdef ESMI_WAVESIM
+    return exp2f(x * 1.4426950408889634f);
+#else
+    return __builtin_amdgcn_exp2f(x * 1.4426950408889634f);
+#endif
+}
+__device__ __forceinline__ float rsqrt_fast_f32(float x) {
+#ifdef ESMI_WAVESIM
+    return 1.0f / sqrtf(x);
+#else
+    return __builtin_amdgcn_rsqf(x);
+#endif
+}
+__device__ __forceinline__ float rcp_fast_f32(float x) {
+#ifdef ESMI_WAVESIM
+    return 1.0f / x;
+#else
+    return __builtin_amdgcn_rcpf(x);
+#endif
+}
+// exact-erf GELU to 1.5e-7: erf by Abramowitz & Stegun 7.1.26 (|err| <= 1.5e-7), branch-free: 1 rcp + 1 exp + 7 fma
+__device__ __forceinline__ float gelu_fast_f32(float x) {
+    const float z = fabsf(x) * 0.70710678118654752440f;
+    const float t = rcp_fast_f32(fmaf(0.3275911f, z, 1.0f));
+    float pl = fmaf(1.061405429f, t, -1.453152027f);
+    pl = fmaf(pl, t, 1.421413741f);
+    pl = fmaf(pl, t, -0.284496736f);
+    pl = fmaf(pl, t, 0.254829592f);
+    const float erf_abs = 1.0f - pl * t * exp_fast_f32(-z * z);
+    return 0.5f * x * (1.0f + copysignf(erf_abs, x));
+}
 __device__ __forceinline__ float ident_f32(float x) { return x; }
 __device__ __forceinline__ float gelu_erf_f32(float x) {  // nn.GELU() default = exact erf form
     return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
@@ -203,7 +237,7 @@ __device__ __forceinline__ void layernorm_tile_regs(f32x16 (&v)[NT], const float
             q = fmaf(d, d, q);
         }
         const float var = row_sum32(q) * inv_c;
-        const float rstd = 1.0f / sqrtf(var + eps);
+        const float rstd = rsqrt_fast_f32(var + eps);
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) v[nt][r] = fmaf((v[nt][r] - mean) * rstd, gg[nt], bb[nt]);
     }
