@@ -70,11 +70,12 @@ def cpu_baseline(cfg, sd, T, dur):
         o = oracle.phoneme2mel(cfg, w, ids, mask, pitch=z, energy=z, duration=d, f32=True)
         return int(o.mel_len.sum()), time.perf_counter() - t0
     run(4)                                   # spin up the OpenMP pool
-    frames, dt = run(B)
+    reps = [run(B) for _ in range(3)]        # the whole workload three times: a few seconds of wall, ~10 min of core time
+    frames, dt = reps[0][0], sum(r[1] for r in reps) / len(reps)
     cores = len(os.sched_getaffinity(0))
     return {"value": frames / dt, "unit": "mel-frames/s", "cores": cores, "kind": "port",
             "sample": f"oracle/es_oracle.c (fp32 accumulate, OpenMP {cores} threads), {cfg.name} ES full forward, "
-                      f"B={B} T={T} D-const {dur}: {frames} frames in {dt:.2f} s"}
+                      f"B={B} T={T} D-const {dur}: {frames} frames in {dt:.2f} s (mean of 3 runs)"}
 
 
 def pmc_traffic(config, B, T, dur):

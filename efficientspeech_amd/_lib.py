@@ -53,6 +53,9 @@ class DecoderShape(C.Structure):
     _fields_ = [(n, C.c_int) for n in ("d4", "dx2", "kernel", "n_blocks", "block_depth", "n_mel")]
 
 
+# esmi_set_fusion() bits (include/esmi.h)
+FUSE_MERGE_QKV, FUSE_ATTN_FFN, FUSE_VARIANCE, FUSE_SPLIT2, FUSE_BLOCK, FUSE_ALL = 1, 2, 4, 8, 16, 31
+
 EXPORTS = (
     "esmi_version", "esmi_backend", "esmi_set_fusion", "esmi_fuse_variance_adaptor_workspace_bytes",
     "esmi_fuse_variance_adaptor_f32", "esmi_pack_conv_weight_f32", "esmi_pack_convT_weight_f32",

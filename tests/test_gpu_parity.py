@@ -39,10 +39,16 @@ def nets():
     return get
 
 
-@pytest.mark.parametrize("fusion", [7, 0], ids=["fused", "unfused"])
+# launch plans: everything fused (default: whole-block kernels, column split, scan inside the variance kernel), one chain
+# kernel per stage (merge+qkv | attention+FFN | fuse+variance; also what long sequences use), one kernel per reference op
+PLANS = [_lib.FUSE_ALL, 7, 0]
+PLAN_IDS = ["fused", "staged", "unfused"]
+
+
+@pytest.mark.parametrize("fusion", PLANS, ids=PLAN_IDS)
 @pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p)[:-4] for p in GOLDEN])
 def test_golden_vectors(path, fusion, nets):
-    """Both launch plans: fused wave-chain kernels (default) and one kernel per reference op."""
+    """All launch plans against the reference-generated vectors."""
     g = np.load(path)
     name = os.path.basename(path).split("_")[0]
     net, cfg, sd = nets(name, g)
@@ -61,13 +67,13 @@ def test_golden_vectors(path, fusion, nets):
     ("base", 3, 64, [64, 40, 7]),
     ("base", 2, 256, [256, 200]),                         # T=256: 8 key tiles (attn_kernel<8>)
 ])
-@pytest.mark.parametrize("fusion", [7, 0], ids=["fused", "unfused"])
+@pytest.mark.parametrize("fusion", PLANS, ids=PLAN_IDS)
 def test_eval_path_vs_oracle(name, B, T, lens, fusion, nets):
-    _lib.load().esmi_set_fusion(fusion)
+    old = _lib.load().esmi_set_fusion(fusion)
     try:
         _eval_path_vs_oracle(name, B, T, lens, nets)
     finally:
-        _lib.load().esmi_set_fusion(7)
+        _lib.load().esmi_set_fusion(old)
 
 
 def _eval_path_vs_oracle(name, B, T, lens, nets):

@@ -151,6 +151,20 @@ def test_simulated_errors(nets):
             net({"phoneme": torch.ones((2, 8), dtype=torch.int32)})
 
 
+@pytest.mark.parametrize("fusion", [7, 31 - 8], ids=["staged", "no-split"])
+def test_simulated_intermediate_plans(fusion, nets):
+    """Fusion masks between 'everything fused' and 'one kernel per op': per-stage chain kernels (7), whole-block
+    without the column-split variant (23)."""
+    g = np.load(os.path.join(GOLD, "tiny_eval_pad_t17.npz"))
+    net, cfg, sd = nets("tiny", g)
+    with use_sim() as lib:
+        old = lib.esmi_set_fusion(fusion)
+        try:
+            H.check_against_golden(net, g, "cpu")
+        finally:
+            lib.esmi_set_fusion(old)
+
+
 def test_simulated_long_sequence_halo_paths(nets):
     """T = 150 > 128: every cooperative chain kernel needs several workgroups per utterance, i.e. the halo-recompute
     branches of enc_attn_ffn (block 0, halo 1), enc_attn_ffn_split (block 1, N = 75 > 64) and enc_fuse_va (halo 2)."""
