@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: tools/_ovl.sh "<lib> <bench flags>" ...   (development: A/B variants on one box)
+# usage: tools/ab_bench.sh "<lib> <bench flags>" ...   (development: A/B variants on one box)
 cp efficientspeech_amd/libesmi.so /tmp/libesmi_default.so
 for i in 1 2; do for spec in "$@"; do
   set -- $spec; lib=$1; shift

@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: tools/_tl.sh <lib> ...   (development: per-kernel timeline of variants on one box)
+# usage: tools/ab_timeline.sh <lib> ...   (development: per-kernel timeline of variants on one box)
 cp efficientspeech_amd/libesmi.so /tmp/libesmi_default.so
 for lib in "$@"; do
   cp $lib efficientspeech_amd/libesmi.so
