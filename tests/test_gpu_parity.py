@@ -210,3 +210,55 @@ def test_full_size_tiny_properties(nets):
 def test_smoke_entry():
     import __graft_entry__ as g
     g.smoke()
+
+
+def test_edge_cases(nets):
+    """T = 1; all durations zero (empty mel); an output-length hint above the true batch maximum (the decoder then derives
+    the padded length L from mel_len itself); T = 256 on tiny ES (8 key tiles, three workgroups per utterance)."""
+    net, cfg, sd = nets("tiny")
+    w = oracle.Weights(sd)
+    # T = 1, B = 1 and B = 3
+    for B in (1, 3):
+        ids, mask = synth_phonemes(B, 1, 3)
+        x = {"phoneme": torch.from_numpy(ids).to(DEV)}
+        if B > 1:
+            x["phoneme_mask"] = torch.from_numpy(mask).to(DEV)
+        with torch.no_grad():
+            mel, mel_len, _ = net(x)
+        o = oracle.phoneme2mel(cfg, w, ids, mask if B > 1 else None)
+        assert np.array_equal(mel_len.cpu().numpy(), o.mel_len) and mel.shape == o.mel.shape
+        if o.mel.size:
+            assert np.abs(mel.cpu().numpy() - o.mel).max() < H.MEL_TOL
+    # every duration zero: L = 0
+    ids, mask = synth_phonemes(2, 9, 4, [9, 5])
+    x = {"phoneme": torch.from_numpy(ids).to(DEV), "phoneme_mask": torch.from_numpy(mask).to(DEV),
+         "duration_forced": torch.zeros((2, 9), dtype=torch.int32, device=DEV)}
+    with torch.no_grad():
+        mel, mel_len, _ = net(x)
+    assert mel.shape == (2, 0, 80) and not mel_len.any()
+    # hint above the batch maximum
+    B, T = 3, 40
+    ids, mask = synth_phonemes(B, T, 9, [40, 31, 7])
+    dur = np.full((B, T), 5, np.int32)
+    x = {"phoneme": torch.from_numpy(ids).to(DEV), "phoneme_mask": torch.from_numpy(mask).to(DEV),
+         "duration_forced": torch.from_numpy(dur).to(DEV), "max_mel_len": 230}
+    with torch.no_grad():
+        enc = net.encoder._encode(x)
+        mel, mel_len, _ = net(x)
+    o = oracle.phoneme2mel(cfg, w, ids, mask, pitch=enc["pitch"][..., 0].cpu().numpy(),
+                           energy=enc["energy"][..., 0].cpu().numpy(), duration=dur)
+    assert mel.shape == (B, 230, 80) and np.array_equal(mel_len.cpu().numpy(), o.mel_len) and o.mel.shape[1] == 200
+    assert np.abs(mel[:, :200].cpu().numpy() - o.mel).max() < H.MEL_TOL and not mel[:, 200:].any()
+    # T = 256
+    ids, mask = synth_phonemes(2, 256, 21, [256, 190])
+    dur = np.ones((2, 256), np.int32)
+    x = {"phoneme": torch.from_numpy(ids).to(DEV), "phoneme_mask": torch.from_numpy(mask).to(DEV),
+         "duration_forced": torch.from_numpy(dur).to(DEV)}
+    with torch.no_grad():
+        enc = net.encoder._encode(x)
+        mel, mel_len, _ = net(x)
+    o = oracle.phoneme2mel(cfg, w, ids, mask, pitch=enc["pitch"][..., 0].cpu().numpy(),
+                           energy=enc["energy"][..., 0].cpu().numpy(), duration=dur)
+    np.testing.assert_allclose(enc["pitch"].cpu().numpy(), o.pitch, atol=H.PRED_TOL, rtol=0)
+    assert np.array_equal(mel_len.cpu().numpy(), o.mel_len)
+    assert np.abs(mel.cpu().numpy() - o.mel).max() < H.MEL_TOL
