@@ -93,11 +93,18 @@ def main():
         with open(os.path.join(d, "kernel_stats.md"), "w") as f:
             f.write("# rocprofv3 --kernel-trace --stats (csv) summary\n\n"
                     "`rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --steps 10 --warmup 3 "
-                    "--no-cpu-baseline` (tools/collect_profiles.sh), 1x MI355X; 13 forward steps.\n")
+                    "--event-every 1 --no-cpu-baseline` (tools/collect_profiles.sh), 1x MI355X; 13 forward steps.\n")
             if bench:
                 f.write(f"Un-profiled `bench.py` of the same build on the same box: {bench['ms_per_step']:.3f} ms/step = "
                         f"{bench['value']:.3e} frames/s, {bench['roofline']['kernel']} {bench['roofline']['kernel_ms']:.3f} ms "
                         f"by live HIP events ({100 * bench['roofline']['frac']:.1f} % of the fp32-MFMA peak).\n")
+            try:   # the live HIP-event timing printed by bench.py INSIDE the profiled run: must agree with the trace average
+                prof = json.loads([ln for ln in open(os.path.join(d, "stats.log")).read().splitlines() if ln.startswith("{")][-1])
+                f.write(f"Inside the profiled run, bench.py's live HIP events (every launch of the 10 timed steps) gave "
+                        f"{prof['roofline']['kernel_ms']:.4f} ms for {prof['roofline']['kernel']}: compare with the trace average below "
+                        f"(13 launches incl. 3 warm-up).\n")
+            except Exception:
+                pass
             f.write("\n" + ks + "\n")
         print(ks)
     per = pmc(d)
