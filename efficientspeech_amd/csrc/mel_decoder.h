@@ -60,6 +60,10 @@
 #else
 #define ESMI_PRIO(n) do { if (ESMI_DEC_CHAIN_PRIO) __builtin_amdgcn_s_setprio(n); } while (0)
 #endif
+#ifndef ESMI_DEC_NS
+#define ESMI_DEC_NS 4      // column slices per workgroup of the dx2 = 128 build: 4 (two row groups) or 2 (four row groups: half the
+                           // LDS A-fragment reads but twice the weight sub-slices per K loop: measured 0.522 vs 0.484 ms)
+#endif
 #ifndef ESMI_DEC_KSUB
 #define ESMI_DEC_KSUB 8     // k-steps (of 8 channels) of the weight slice held in registers at a time (16 = all of K = 128)
 #endif
@@ -166,12 +170,13 @@ __device__ __forceinline__ int batch_max_len(const int* __restrict__ mel_len, in
 template <int DX2, int KD, int NW>
 __global__ __launch_bounds__(64 * NW, (DX2 <= 128 && NW == 8 ? ESMI_DEC_WPS : 2)) void mel_decoder_kernel(const MelDecP p) {
     constexpr int kDecThreads = 64 * NW;    // shadows the namespace constant inside this kernel
-    constexpr int MH = NW / 4;              // row halves (1 or 2)
-    constexpr int MT = 4 / MH;              // 32-row MFMA tiles per wave (4 or 2)
+    constexpr int NS = (DX2 <= 128 && NW == 8) ? ESMI_DEC_NS : 4;   // column slices per workgroup
+    constexpr int MH = NW / NS;             // row groups (1, 2 or 4)
+    constexpr int MT = 4 / MH;              // 32-row MFMA tiles per wave (4, 2 or 1)
     constexpr int TPR = kDecThreads / kDecRows;   // LayerNorm threads per row (2 or 4)
     constexpr bool LOWREG = ESMI_DEC_LOWREG && DX2 <= 128;
-    constexpr int NTW = DX2 / 128;          // 32-column MFMA tiles per wave
-    constexpr int WCOLS = 32 * NTW;         // columns per wave (4 column slices per workgroup)
+    constexpr int NTW = DX2 / (32 * NS);    // 32-column MFMA tiles per wave
+    constexpr int WCOLS = 32 * NTW;         // columns per wave
     constexpr int KCH = DX2 / 128;          // 128-channel K chunks of a dx2-wide contraction
     constexpr int LDSROW = DX2 + 4;
     constexpr int PAD = KD / 2;
@@ -195,7 +200,7 @@ __global__ __launch_bounds__(64 * NW, (DX2 <= 128 && NW == 8 ? ESMI_DEC_WPS : 2)
 
     const int tid = (int)threadIdx.x, lane = lane_id(), w = wave_id();
     const int i = lane & 31, h = lane >> 5;
-    const int mh = w >> 2, ns = w & 3;      // NW = 4: mh == 0
+    const int mh = w / NS, ns = w % NS;     // NW = 4: mh == 0
     const int tile = (int)blockIdx.x, b = (int)blockIdx.y;
     const int L = p.lmax_dev ? *p.lmax_dev : (p.lmax_host >= 0 ? p.lmax_host : batch_max_len(p.mel_len, p.B));
     const int mlen = p.mel_len ? min(p.mel_len[b], L) : L;
@@ -296,7 +301,7 @@ __global__ __launch_bounds__(64 * NW, (DX2 <= 128 && NW == 8 ? ESMI_DEC_WPS : 2)
 
     // weight-stationary GEMM pieces.  bf = this wave's weight slice for KSUB k-steps (64 VGPRs); it is
     // (re)loaded right after the previous K loop so the L2 latency hides under the non-MFMA phases.
-    constexpr int KSUB = NTW == 1 ? ESMI_DEC_KSUB : 8;   // k-steps of weights in registers at a time (64 VGPRs)
+    constexpr int KSUB = DX2 <= 128 ? ESMI_DEC_KSUB / NTW : 8;   // k-steps of weights in registers at a time (32 / 64 VGPRs)
     f32x4 bf[NTW][KSUB];
     auto load_b = [&](const f32x4* wsl, int k0) __attribute__((always_inline)) {
 #pragma unroll
@@ -321,7 +326,7 @@ __global__ __launch_bounds__(64 * NW, (DX2 <= 128 && NW == 8 ? ESMI_DEC_WPS : 2)
         }
     };
     // slice pointer of chunk c of the matrix at float offset `off`
-    auto wslice = [&](long off, int c) __attribute__((always_inline)) { return blob4 + (off >> 2) + (long)((c * 4 + ns) * NTW) * 16 * 64 + lane; };
+    auto wslice = [&](long off, int c) __attribute__((always_inline)) { return blob4 + (off >> 2) + (long)(c * (DX2 / 32) + ns * NTW) * 16 * 64 + lane; };
     // full dx2-wide contraction with the first sub-slice already in bf; leaves `next`'s first sub-slice in bf
     auto gemm_dx2 = [&](long off, const f32x4* next) __attribute__((always_inline)) {
 #pragma unroll
