@@ -43,6 +43,10 @@ class PredictorWeights(C.Structure):
                                   "lin_w", "lin_b", "bins", "emb", "conv1_wp", "conv2_wp")]
 
 
+class DecoderHead(C.Structure):
+    _fields_ = [("proj_wp", fp), ("proj_b", fp), ("ln_g", fp), ("ln_b", fp), ("d4", C.c_int), ("dx2", C.c_int)]
+
+
 class DecoderWeights(C.Structure):
     _fields_ = [("proj_w", fp), ("proj_b", fp), ("proj_ln_g", fp), ("proj_ln_b", fp)] + \
                [(n, fp * MAX_DEC_LAYERS) for n in ("dw_w", "dw_b", "pw_w", "pw_b", "ln_g", "ln_b", "skip_g", "skip_b")] + \
@@ -93,7 +97,7 @@ def bind(lib):
     lib.esmi_fuse_variance_adaptor_workspace_bytes.argtypes = [i, i, i, i]
     lib.esmi_fuse_variance_adaptor_workspace_bytes.restype = sz
     lib.esmi_fuse_variance_adaptor_f32.argtypes = [P(FuseWeights), i, i, i, i, i, P(fp), P(i)] + [P(PredictorWeights)] * 3 + \
-        [fp] * 13 + [fp, sz, fp]
+        [fp] * 13 + [P(DecoderHead), fp] + [fp, sz, fp]
     lib.esmi_max_i32.argtypes = [fp, i, fp, fp]
     lib.esmi_length_regulate_i32.argtypes = [fp, i, i, fp, fp, fp, fp]
     lib.esmi_length_regulator_indices_i32.argtypes = [fp, i, i, i, fp, fp]
@@ -101,7 +105,7 @@ def bind(lib):
     lib.esmi_mel_decoder_blob_bytes.argtypes = [P(DecoderShape)]
     lib.esmi_mel_decoder_blob_bytes.restype = sz
     lib.esmi_mel_decoder_pack_f32.argtypes = [P(DecoderWeights), P(DecoderShape), fp, fp]
-    lib.esmi_mel_decoder_f32.argtypes = [fp, P(DecoderShape), fp, fp, fp, fp, i, i, i, i, i, fp, fp]
+    lib.esmi_mel_decoder_f32.argtypes = [fp, P(DecoderShape), fp, fp, fp, fp, fp, i, i, i, i, i, fp, fp]
     lib.esmi_mask_rows_f32.argtypes = [fp, fp, C.c_int64, i, fp]
     for name in EXPORTS:
         fn = getattr(lib, name)
@@ -110,8 +114,14 @@ def bind(lib):
     return lib
 
 
+class Unsupported(RuntimeError):
+    """ESMI_ERR_UNSUPPORTED: the shape is outside what this entry point's kernels are built for."""
+
+
 def _make_check(name):
     def check(rc, func, args):
+        if rc == -2:
+            raise Unsupported(f"{name}: shape not supported")
         if rc != ESMI_OK:
             what = _ERRS.get(rc, f"hipError_t {rc}" if rc > 0 else f"error {rc}")
             raise RuntimeError(f"{name} failed: {what}")

@@ -42,6 +42,9 @@ struct FuseVaP {
     int* pitch_idx;
     int* energy_idx;
     int* dur;
+    // optional decoder head, dim == 32 only (4*dim = dx2 = 128): h0 = LN(tanh(Linear(4*dim, dx2)(feat))) at phoneme rate
+    const float *head_w, *head_b, *head_g, *head_beta;   // head_w in MFMA B-fragment order
+    float* h0;              // (B,T,128) or NULL
     int* cum;               // (B,T) inclusive cumsum of max(dur,0) and
     int* mel_len;           // (B) its total: written when one workgroup covers the utterance (halo == 0), else NULL
     int wgs_per_b;          // workgroups per utterance
@@ -53,10 +56,12 @@ constexpr int kVaMaxWaves = 4;
 
 // LDS floats of an nw-wave workgroup: fb0 [32nw+2][dim+4], then one region shared over time by the per-wave Fuse
 // scratch (cat [32][depth*dim+4] + tmp [32][dim+4] each) and the predictor-hidden tile tb0 [32nw+2][3*dim+4]
-inline int fuse_va_lds_floats(int dim, int depth, int nw) {
+inline int fuse_va_lds_floats(int dim, int depth, int nw, bool head = false) {
     const int fbt = (32 * nw + 2) * (dim + 4), tbt = (32 * nw + 2) * (3 * dim + 4);
     const int priv = nw * (32 * (depth * dim + 4) + 32 * (dim + 4));
-    return fbt + (priv > tbt ? priv : tbt);
+    const int ft = head ? nw * 32 * (4 * dim + 4) : 0;       // per-wave feature tiles of the decoder-head stage
+    const int m = priv > tbt ? priv : tbt;
+    return fbt + (ft > m ? ft : m);
 }
 
 inline void fuse_va_plan(int n, int dim, int depth, int* nw, int* wgs, int* useful, int* halo) {
@@ -396,6 +401,48 @@ __device__ __forceinline__ void enc_fuse_va_body(const FuseVaP& p) {
         }
     }
     ESMI_CT();   // outputs done
+    if (ND == 1 && p.h0) {
+        // ---------------- decoder head at phoneme rate: h0 = LN(tanh(feat . Wp^T + b)).  MelDecoder's first stage is
+        // row-wise and every frame of a phoneme reads the same row, so it is computed here once per phoneme while the
+        // 4*dim features are still in registers; the decoder then only gathers (mel_decoder.h).
+        constexpr int D4 = 4 * DIM, LDF = D4 + 4;
+        float* ft = tb0 + w * (32 * LDF);       // [32][LDF], aliases the predictor-hidden tile
+        WaveGrp<4> gh;
+        wave_prefetch<4>(gh, p.head_w, 4, 0, 0, lane);
+        float hb[4], hg[4], hbe[4];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            hb[nt] = p.head_b[32 * nt + i]; hg[nt] = p.head_g[32 * nt + i]; hbe[nt] = p.head_beta[32 * nt + i];
+        }
+        __syncthreads();                        // every wave is done with tb0 (conv2) and fb0
+        f32x16 fe[1];
+#pragma unroll
+        for (int part = 0; part < 4; ++part) {  // the row of feat exactly as stored: fused | pitch emb | energy emb | duration feats
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float v = part == 0 ? a[0][r] : (part == 1 ? emb[0][r][0] : (part == 2 ? emb[1][r][0] : c[2][0][r]));
+                fe[0][r] = (part > 0 && rz[r]) ? 0.0f : v;
+            }
+            tile_store<1>(ft, LDF, part * DIM, fe, lane);
+        }
+        lds_wave_sync();
+        f32x16 hh[4];
+        zero_tiles<4>(hh);
+        wave_gemm_k<4, 4>(hh, gh, ft + i * LDF + 4 * h2, true, p.head_w, 4, 0, 0, lane);
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) hh[nt][r] = tanh_fast_f32(hh[nt][r] + hb[nt]);
+        }
+        layernorm_tile_regs<4>(hh, hg, hbe);
+        const BufRsrc r_h0 = make_rsrc(p.h0 + (long)b * p.T * D4, (long)p.T * D4 * 4);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const unsigned off = live[r] ? (unsigned)((rpos[r] * D4 + i) * 4) : kBufOOB;
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) buf_st(r_h0, off + 128u * nt, hh[nt][r]);
+        }
+    }
     if (p.cum) {   // FeatureUpsampler's scan (networks.py:233-244) while the durations are still on the CU; T <= 128 here
         __syncthreads();
         if (w == 0) {

@@ -497,9 +497,10 @@ int esmi_fuse_variance_adaptor_f32(const esmi_fuse_weights* fw, int depth, int d
                                    const uint8_t* mask, const float* pitch_target, const float* energy_target,
                                    const int32_t* duration_target, float* feat, float* pitch_pred, float* energy_pred,
                                    float* duration_pred, int32_t* pitch_idx, int32_t* energy_idx, int32_t* dur,
-                                   int32_t* cum, int32_t* mel_len, void* workspace, size_t workspace_bytes,
-                                   esmi_stream_t stream) {
+                                   int32_t* cum, int32_t* mel_len, const esmi_decoder_head* head, float* h0,
+                                   void* workspace, size_t workspace_bytes, esmi_stream_t stream) {
     if ((cum == nullptr) != (mel_len == nullptr)) return ESMI_ERR_ARG;
+    if (h0 && (!head || !head->proj_wp || !head->proj_b || !head->ln_g || !head->ln_b)) return ESMI_ERR_ARG;
     if (!fw || !feats || !n_i || !pitch || !energy || !duration || !feat || !pitch_pred || !energy_pred ||
         !duration_pred || !dur || depth < 1 || depth > ESMI_MAX_DEPTH)
         return ESMI_ERR_ARG;
@@ -507,6 +508,7 @@ int esmi_fuse_variance_adaptor_f32(const esmi_fuse_weights* fw, int depth, int d
                  pitch->conv1_wp && pitch->conv2_wp && energy->conv1_wp && energy->conv2_wp && duration->conv1_wp &&
                  duration->conv2_wp;
     for (int i = 0; i < depth && chain; ++i) chain = fw->mlp_wp[i] && (i == 0 || fw->up_wp[i]);
+    if (h0 && !(chain && dim == 32 && head->d4 == 128 && head->dx2 == 128)) return ESMI_ERR_UNSUPPORTED;
     for (int i = 1; i < depth && chain; ++i)
         if ((n_i[i] - 1) * (1 << i) + kernel < T) return ESMI_ERR_UNSUPPORTED;   // torch.cat would raise in the reference
     if (chain) {
@@ -534,7 +536,8 @@ int esmi_fuse_variance_adaptor_f32(const esmi_fuse_weights* fw, int depth, int d
         const bool scan_fused = cum && p.halo == 0;   // one workgroup sees every duration of its utterance
         p.cum = scan_fused ? cum : nullptr; p.mel_len = scan_fused ? mel_len : nullptr;
         dim3 grid(B * p.wgs_per_b), block(64 * nw);
-        const int lds = fuse_va_lds_floats(dim, depth, nw) * (int)sizeof(float);
+        if (h0) { p.head_w = head->proj_wp; p.head_b = head->proj_b; p.head_g = head->ln_g; p.head_beta = head->ln_b; p.h0 = h0; }
+        const int lds = fuse_va_lds_floats(dim, depth, nw, h0 != nullptr) * (int)sizeof(float);
         static bool attr_set = false;   // once: keeps the call out of hipGraph captures
         if (!attr_set) {
             const void* fns[4] = {reinterpret_cast<const void*>(enc_fuse_va_kernel<1, 3>), reinterpret_cast<const void*>(enc_fuse_va_kernel<2, 3>),
@@ -658,12 +661,13 @@ int esmi_mel_decoder_pack_f32(const esmi_decoder_weights* w, const esmi_decoder_
     return launch_status();
 }
 
-int esmi_mel_decoder_f32(const float* blob, const esmi_decoder_shape* s, const float* x, const int32_t* cum,
-                         const int32_t* mel_len, const int32_t* lmax_dev, int lmax_host, int apply_mask, int B, int T,
+int esmi_mel_decoder_f32(const float* blob, const esmi_decoder_shape* s, const float* x, const float* h0,
+                         const int32_t* cum, const int32_t* mel_len, const int32_t* lmax_dev, int lmax_host, int apply_mask, int B, int T,
                          int L_out, float* mel, esmi_stream_t stream) {
     int rc = dec_check(s);
     if (rc) return rc;
-    if (!blob || !x || !mel || B <= 0 || L_out <= 0 || !aligned16(blob) || !aligned16(x)) return ESMI_ERR_ARG;
+    if (!blob || (!x && !h0) || !mel || B <= 0 || L_out <= 0 || !aligned16(blob) || (x && !aligned16(x))) return ESMI_ERR_ARG;
+    if (h0 && (!cum || !aligned16(h0))) return ESMI_ERR_ARG;   // the phoneme-rate head only exists in the fused-gather mode
     if (!cum && lmax_dev) return ESMI_ERR_ARG;  // direct mode: L is the tensor's own length, known to the host
     if (!lmax_dev && lmax_host == 0) return ESMI_ERR_ARG;
     if (!lmax_dev && lmax_host < 0 && (!mel_len || !cum)) return ESMI_ERR_ARG;   // L derived from mel_len
@@ -671,7 +675,7 @@ int esmi_mel_decoder_f32(const float* blob, const esmi_decoder_shape* s, const f
     p.blob = blob;
     p.lay = dec_layout(s->d4, s->dx2, s->kernel, s->n_blocks, s->block_depth);
     p.d4 = s->d4; p.n_blocks = s->n_blocks; p.block_depth = s->block_depth; p.n_mel = s->n_mel;
-    p.x = x; p.cum = cum; p.mel_len = mel_len; p.lmax_dev = lmax_dev; p.lmax_host = lmax_host;
+    p.x = x; p.h0 = h0; p.cum = cum; p.mel_len = mel_len; p.lmax_dev = lmax_dev; p.lmax_host = lmax_host;
     p.apply_mask = apply_mask && mel_len; p.B = B; p.T = T; p.L_out = L_out; p.mel = mel;
     p.halo = (s->kernel / 2) * s->n_blocks * s->block_depth;
     p.TL = kDecRows - 2 * p.halo;

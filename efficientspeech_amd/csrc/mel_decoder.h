@@ -131,6 +131,7 @@ struct MelDecP {
     DecLayout lay;
     int d4, n_blocks, block_depth, n_mel;
     const float* x;        // (B,T,d4) phoneme-rate (cum != NULL) or (B,L,d4) frame-rate
+    const float* h0;       // optional (cum != NULL): (B,T,dx2) = LN(tanh(proj(x))) already computed at PHONEME rate
     const int* cum;        // (B,T) inclusive duration cumsum or NULL
     const int* mel_len;    // (B) or NULL
     const int* lmax_dev;   // device scalar or NULL
@@ -417,7 +418,49 @@ __global__ __launch_bounds__(64 * NW, (DX2 <= 128 && NW == 8 ? ESMI_DEC_WPS : 2)
         }
     };
 
-    // ---- proj: Linear(d4, dx2); the gathered input rows are staged through the tile 128 channels at a time
+    // ---- proj: Linear(d4, dx2) + Tanh + LN.  All three are row-wise, and a frame's input row is its phoneme's row: when
+    // the caller supplies h0 = LN(tanh(proj(x))) at PHONEME rate (enc_fuse_va_kernel computes it while the features
+    // are still on the CU) the stage reduces to a gather -- one of the six GEMM stages of the window disappears
+    // (D frames per phoneme share one row).  Padding frames (zero input rows) get LN(tanh(proj_b)).
+    if (p.h0) {
+        for (int e = tid; e < kDecRows * (DX2 / 4); e += kDecThreads) {
+            const int r = e / (DX2 / 4), q = e - r * (DX2 / 4);
+            const int s = src[r];
+            f32x4 v = zero4();
+            if (s >= 0) v = ld4(p.h0 + (long)s * DX2 + 4 * q);
+            else if (s == -2) {
+                const f32x4 bb = *reinterpret_cast<const f32x4*>(pbuf + P_PWB + 4 * q);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) v[c] = ESMI_DEC_TANH(bb[c]);
+            }
+            *reinterpret_cast<f32x4*>(xs + (kDecPadRows + r) * LDSROW + 4 * q) = v;
+        }
+        if (!LOWREG) load_b(n_layers > 0 ? wslice(p.lay.layer0 + p.lay.l_pw, 0) : wslice(p.lay.mel_w, 0), 0);
+        issue_B(0);
+        __syncthreads();
+        {   // row owners: LayerNorm only for the padding frames' rows; skip = the stage's output
+            const float* pb = pbuf + opaque_i(4 * ln_q);
+            float* ln_ptr = xs + opaque_i((kDecPadRows + ln_row) * LDSROW + 4 * ln_q);
+            f32x4 v[NV];
+#pragma unroll
+            for (int k = 0; k < NV; ++k) v[k] = *reinterpret_cast<const f32x4*>(ln_ptr + 4 * TPR * k);
+            const bool pad_row = src[ln_row] == -2;
+            if (ballot64(pad_row) != 0ull) {   // wave-uniform: the row reductions inside are wave-level exchanges
+                f32x4 u[NV];
+#pragma unroll
+                for (int k = 0; k < NV; ++k) u[k] = v[k];
+                ln_regs(u, pb + P_G, pb + P_B);
+#pragma unroll
+                for (int k = 0; k < NV; ++k) {
+                    if (pad_row) v[k] = u[k];
+                    *reinterpret_cast<f32x4*>(ln_ptr + 4 * TPR * k) = v[k];
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < NV; ++k) skip[k] = v[k];
+        }
+        __syncthreads();
+    } else {
     zero_acc();
     const int nchunks = p.d4 / 128;
     if (!LOWREG) load_b(wslice(p.lay.proj_w, 0), 0);
@@ -445,6 +488,8 @@ __global__ __launch_bounds__(64 * NW, (DX2 <= 128 && NW == 8 ? ESMI_DEC_WPS : 2)
     __syncthreads();
     ln_pass(pbuf, false, true);
     __syncthreads();
+
+    }
 
     // ---- conv layers
     const int dw_cg = tid % CG, dw_r0 = (tid / CG) * RS;

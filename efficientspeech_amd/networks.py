@@ -352,6 +352,7 @@ class MelDecoder(nn.Module):
                 nn.LayerNorm(dx2)]) for _ in range(n_blocks)])
         self.mel_linear = nn.Linear(dx2, n_mel_channels)
         self._cache = _PackCache()
+        self._head_cache = _PackCache()
         self.timing = None      # bench.py sets this to a list to collect (start, end) HIP events per timed launch
         self.timing_every = 1   # ... on every n-th launch only (an event pair costs ~10 us of pipeline drain per step)
         self._launches = 0
@@ -401,12 +402,25 @@ class MelDecoder(nn.Module):
         mel = torch.empty((B, L, self.n_mel_channels), dtype=torch.float32, device=x.device)
         if L > 0:
             shape = self._shape()
-            lib.esmi_mel_decoder_f32(_ptr(self._packed(lib, stream)), C.byref(shape), _ptr(x), None, None, None, L, 0,
+            lib.esmi_mel_decoder_f32(_ptr(self._packed(lib, stream)), C.byref(shape), _ptr(x), None, None, None, None, L, 0,
                                      B, 0, L, _ptr(mel), stream)
         return mel
 
-    def _fused(self, feat, cum, mel_len, lmax_dev, lmax_host, apply_mask, L_out):
-        """Length-regulator gather fused into the decoder: feat (B,T,d4) phoneme-rate."""
+    def _head(self, lib, stream):
+        """The decoder's first stage (proj Linear + Tanh + LN) as the fused variance-adaptor kernel takes it: it is
+        row-wise, so it runs once per PHONEME there and the decoder only gathers.  None when the shape is not served."""
+        if self.dim_x4 != 128 or self.dim_x2 != 128:
+            return None
+
+        def build():
+            t = dict(proj_wp=_pack_bfrag(lib, stream, self.proj[0].weight), proj_b=_f32(self.proj[0].bias),
+                     ln_g=_f32(self.proj[2].weight), ln_b=_f32(self.proj[2].bias))
+            return _lib.DecoderHead(d4=self.dim_x4, dx2=self.dim_x2, **{k: _ptr(v) for k, v in t.items()}), list(t.values())
+        return self._head_cache.get(list(self.proj.parameters()), build)
+
+    def _fused(self, feat, cum, mel_len, lmax_dev, lmax_host, apply_mask, L_out, h0=None):
+        """Length-regulator gather fused into the decoder: feat (B,T,d4) phoneme-rate; h0 (B,T,dx2) = the first stage's
+        output at phoneme rate when the encoder side computed it."""
         lib, stream = _runtime(feat)
         B, T, _ = feat.shape
         mel = torch.empty((B, L_out, self.n_mel_channels), dtype=torch.float32, device=feat.device)
@@ -418,7 +432,7 @@ class MelDecoder(nn.Module):
             if self.timing is not None and feat.is_cuda and self._launches % self.timing_every == 0:   # events on the launch stream
                 ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
                 ev[0].record()
-            lib.esmi_mel_decoder_f32(_ptr(blob), C.byref(shape), _ptr(feat), _ptr(cum),
+            lib.esmi_mel_decoder_f32(_ptr(blob), C.byref(shape), _ptr(feat), _ptr(h0), _ptr(cum),
                                      _ptr(mel_len), _ptr(lmax_dev), int(lmax_host), int(apply_mask), B, T, L_out,
                                      _ptr(mel), stream)
             if ev is not None:
@@ -450,7 +464,7 @@ class PhonemeEncoder(nn.Module):
         params = [p for d in (self.pitch_decoder, self.energy_decoder, self.duration_decoder) for p in d.parameters()]
         return self._cache.get(params, build)
 
-    def _encode(self, x, train=False, need_lmax=True):
+    def _encode(self, x, train=False, need_lmax=True, head=None):
         """Everything up to (and including) the duration scan; nothing frame-rate is materialised."""
         phoneme = x["phoneme"]
         B = phoneme.shape[0]
@@ -480,16 +494,24 @@ class PhonemeEncoder(nn.Module):
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
         cum = torch.empty((B, T), dtype=torch.int32, device=dev)
         mel_len = torch.empty((B,), dtype=torch.int32, device=dev)
+        # `head` = MelDecoder._head(): also produce the decoder's first stage at phoneme rate (inference only)
+        h0 = None if (head is None or train) else torch.empty((B, T, head[0].dx2), dtype=torch.float32, device=dev)
         fp = (C.c_void_p * depth)(*[_ptr(f) for f in feats])
         ni = (C.c_int * depth)(*[f.shape[1] for f in feats])
         # Fuse (channels [0,dim) of feat) + the three predictors, embeddings, concat, duration rounding and the
         # length regulator's scan (cum, mel_len)
-        lib.esmi_fuse_variance_adaptor_f32(C.byref(fw), depth, dim, self.fuse.kernel_size, B, T, fp, ni, C.byref(pw),
-                                           C.byref(ew), C.byref(dw), _ptr(m8), _ptr(pitch_t), _ptr(energy_t), _ptr(dur_t),
-                                           _ptr(feat), _ptr(preds[0]), _ptr(preds[1]), _ptr(preds[2]), _ptr(idxs[0]),
-                                           _ptr(idxs[1]), _ptr(dur), _ptr(cum), _ptr(mel_len), _ptr(ws), ws_bytes, stream)
+        args = (C.byref(fw), depth, dim, self.fuse.kernel_size, B, T, fp, ni, C.byref(pw), C.byref(ew), C.byref(dw), _ptr(m8),
+                _ptr(pitch_t), _ptr(energy_t), _ptr(dur_t), _ptr(feat), _ptr(preds[0]), _ptr(preds[1]), _ptr(preds[2]),
+                _ptr(idxs[0]), _ptr(idxs[1]), _ptr(dur), _ptr(cum), _ptr(mel_len))
+        if h0 is not None:
+            try:
+                lib.esmi_fuse_variance_adaptor_f32(*args, C.byref(head[0]), _ptr(h0), _ptr(ws), ws_bytes, stream)
+            except _lib.Unsupported:           # long sequences / other widths: the decoder runs its first stage itself
+                h0 = None
+        if h0 is None:
+            lib.esmi_fuse_variance_adaptor_f32(*args, None, None, _ptr(ws), ws_bytes, stream)
         enc = dict(feat=feat, mask_u8=m8, pitch=preds[0], energy=preds[1], duration=preds[2], pitch_idx=idxs[0],
-                   energy_idx=idxs[1], dur=dur, cum=cum, mel_len=mel_len, lmax=None, feats=feats)
+                   energy_idx=idxs[1], dur=dur, cum=cum, mel_len=mel_len, lmax=None, feats=feats, h0=h0)
         if need_lmax:
             PhonemeEncoder._lmax(enc)
         return enc
@@ -557,9 +579,10 @@ class Phoneme2Mel(nn.Module):
             return pred
         # inference: the (B,L,4*dim) tensor is never materialised -- the decoder gathers through the
         # duration scan and applies the final masked_fill itself.
-        enc = self.encoder._encode(x, train=False, need_lmax="max_mel_len" not in x)
+        lib, stream = _runtime(self.decoder.mel_linear.weight)
+        enc = self.encoder._encode(x, train=False, need_lmax="max_mel_len" not in x, head=self.decoder._head(lib, stream))
         B = enc["feat"].shape[0]
         L, lmax_dev, lmax_host = PhonemeEncoder._padded_len(x, enc, False)
         apply_mask = enc["mask_u8"] is not None and B > 1
-        mel = self.decoder._fused(enc["feat"], enc["cum"], enc["mel_len"], lmax_dev, lmax_host, apply_mask, L)
+        mel = self.decoder._fused(enc["feat"], enc["cum"], enc["mel_len"], lmax_dev, lmax_host, apply_mask, L, h0=enc["h0"])
         return mel, enc["mel_len"], enc["duration"]

@@ -17,6 +17,15 @@ import torch
 import torch.distributed as dist
 
 
+
+def _encode_with_head(net, x):
+    """Encoder side of the forward, including the decoder's row-wise first stage at phoneme rate when the fused kernel
+    can produce it (networks.MelDecoder._head)."""
+    from .networks import _runtime
+    lib, stream = _runtime(net.decoder.mel_linear.weight)
+    return net.encoder._encode(x, train=False, head=net.decoder._head(lib, stream))
+
+
 def shard_batch(x, rank, world):
     """Contiguous utterance shard of every batch-leading tensor in the input dict."""
     B = x["phoneme"].shape[0]
@@ -48,13 +57,13 @@ def sharded_forward(net, x_full, group=None):
     # The padded length L is a property of the WHOLE batch (the reference zero-pads its convolutions at the
     # batch max), so the local maxima are MAX-reduced on the device before the decoder runs.  With a
     # caller-supplied bound (`max_mel_len`) the output is allocated at that bound and no host sync happens.
-    enc = net.encoder._encode(x, train=False)
+    enc = _encode_with_head(net, x)
     dist.all_reduce(enc["lmax"], op=dist.ReduceOp.MAX, group=group)
     if "max_mel_len" in x:
         L_out, lmax_dev = int(x["max_mel_len"]), enc["lmax"]
     else:
         L_out, lmax_dev = int(enc["lmax"].item()), None
-    mel = net.decoder._fused(enc["feat"], enc["cum"], enc["mel_len"], lmax_dev, L_out, True, L_out)
+    mel = net.decoder._fused(enc["feat"], enc["cum"], enc["mel_len"], lmax_dev, L_out, True, L_out, h0=enc["h0"])
     mel_len, dur = enc["mel_len"], enc["duration"]
     if dup:
         mel, mel_len, dur = mel[:1], mel_len[:1], dur[:1]
@@ -84,19 +93,19 @@ class GraphedForward:
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side), torch.no_grad():       # warm-up off the capture: weight packing, attributes
             for _ in range(warmup):
-                enc = net.encoder._encode(self.x, train=False)
-                net.decoder._fused(enc["feat"], enc["cum"], enc["mel_len"], enc["lmax"], self.L, self.apply_mask, self.L)
+                enc = _encode_with_head(net, self.x)
+                net.decoder._fused(enc["feat"], enc["cum"], enc["mel_len"], enc["lmax"], self.L, self.apply_mask, self.L, h0=enc["h0"])
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.g_enc = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.g_enc), torch.no_grad():
-            self.enc = net.encoder._encode(self.x, train=False)
+            self.enc = _encode_with_head(net, self.x)
         self.g_dec, self.mels = [], []
         for _ in range(nbuf):
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g), torch.no_grad():
                 mel = net.decoder._fused(self.enc["feat"], self.enc["cum"], self.enc["mel_len"], self.enc["lmax"],
-                                         self.L, self.apply_mask, self.L)
+                                         self.L, self.apply_mask, self.L, h0=self.enc["h0"])
             self.g_dec.append(g)
             self.mels.append(mel)
         self.i = 0
@@ -163,13 +172,13 @@ class ShardedMelPipeline:
             mel, mel_len, _ = self.net(x)
             return mel, mel_len
         # global padded length: 4-byte MAX all-reduce on the compute stream (see sharded_forward)
-        enc = self.net.encoder._encode(x, train=False)
+        enc = _encode_with_head(self.net, x)
         dist.all_reduce(enc["lmax"], op=dist.ReduceOp.MAX, group=self.group)
         if "max_mel_len" in x:
             L_out, lmax_dev = int(x["max_mel_len"]), enc["lmax"]
         else:
             L_out, lmax_dev = int(enc["lmax"].item()), None
-        mel = self.net.decoder._fused(enc["feat"], enc["cum"], enc["mel_len"], lmax_dev, L_out, True, L_out)
+        mel = self.net.decoder._fused(enc["feat"], enc["cum"], enc["mel_len"], lmax_dev, L_out, True, L_out, h0=enc["h0"])
         return mel, enc["mel_len"]
 
     def _compute_two_stream(self, x):
@@ -179,7 +188,7 @@ class ShardedMelPipeline:
         cur = torch.cuda.current_stream(dev)
         self.s_enc.wait_stream(cur)                       # inputs produced on the caller's stream
         with torch.cuda.stream(self.s_enc):
-            enc = self.net.encoder._encode(x, train=False)
+            enc = _encode_with_head(self.net, x)
             if self.world > 1:
                 dist.all_reduce(enc["lmax"], op=dist.ReduceOp.MAX, group=self.group)
             ready = torch.cuda.Event()
@@ -193,7 +202,7 @@ class ShardedMelPipeline:
             self.s_dec.wait_event(ready)
             for t in (enc["feat"], enc["cum"], enc["mel_len"], enc["lmax"]):
                 t.record_stream(self.s_dec)
-            mel = self.net.decoder._fused(enc["feat"], enc["cum"], enc["mel_len"], lmax_dev, L_out, True, L_out)
+            mel = self.net.decoder._fused(enc["feat"], enc["cum"], enc["mel_len"], lmax_dev, L_out, True, L_out, h0=enc["h0"])
             done = torch.cuda.Event()
             done.record()
         self._dec_done = done

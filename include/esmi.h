@@ -195,6 +195,17 @@ int esmi_variance_adaptor_f32(const esmi_predictor_weights* pitch, const esmi_pr
  * calls above.  `feat` (B,T,4*dim) is fully written.  Arguments as in esmi_fuse_f32 / esmi_variance_adaptor_f32.
  * cum / mel_len (both or neither): also run the length regulator's scan (esmi_length_regulate_i32 without lmax) --
  * inside the fused kernel when one workgroup covers an utterance (T <= 128), as one more launch otherwise.      */
+/* MelDecoder's first stage, proj = Linear(4*dim, dx2) + Tanh + LayerNorm (networks.py:272-276,292), is row-wise and every
+ * frame of a phoneme reads the same input row: the fused kernel can compute h0 = LN(tanh(proj(feat))) at PHONEME
+ * rate while the features are still on the CU (esmi_mel_decoder_f32 then gathers h0 instead of running the GEMM).   */
+typedef struct esmi_decoder_head {
+    const float* proj_wp;   /* esmi_pack_bfrag_f32 of decoder.proj.0.weight (dx2, 4*dim) */
+    const float* proj_b;    /* decoder.proj.0.bias */
+    const float* ln_g;      /* decoder.proj.2.{weight,bias} */
+    const float* ln_b;
+    int d4, dx2;
+} esmi_decoder_head;
+
 size_t esmi_fuse_variance_adaptor_workspace_bytes(int B, int T, int dim, int depth);
 int esmi_fuse_variance_adaptor_f32(const esmi_fuse_weights* fuse, int depth, int dim, int kernel, int B, int T,
                                    const float* const* feats, const int* n_i, const esmi_predictor_weights* pitch,
@@ -203,6 +214,9 @@ int esmi_fuse_variance_adaptor_f32(const esmi_fuse_weights* fuse, int depth, int
                                    const int32_t* duration_target, float* feat, float* pitch_pred, float* energy_pred,
                                    float* duration_pred, int32_t* pitch_idx, int32_t* energy_idx, int32_t* dur,
                                    int32_t* cum, int32_t* mel_len, /* (B,T), (B) or NULL, NULL                  */
+                                   const esmi_decoder_head* head, float* h0, /* (B,T,dx2) or NULL, NULL; returns
+                                      ESMI_ERR_UNSUPPORTED (nothing launched) when h0 is requested for a shape the
+                                      fused kernel cannot serve: call again without it                            */
                                    void* workspace, size_t workspace_bytes, esmi_stream_t stream);
 
 /* ------------------------------------------------------------------ Length regulator
@@ -265,8 +279,9 @@ int esmi_mel_decoder_pack_f32(const esmi_decoder_weights* w, const esmi_decoder_
  * mel_len, which is then required).  mel is (B, L_out, n_mel); rows in [L, L_out) are zeroed.
  * mel_len != NULL && apply_mask: rows >= mel_len[b] are zeroed (Phoneme2Mel's final
  * masked_fill, networks.py:424-427).                                                          */
-int esmi_mel_decoder_f32(const float* blob, const esmi_decoder_shape* s, const float* x, const int32_t* cum,
-                         const int32_t* mel_len, const int32_t* lmax_dev, int lmax_host, int apply_mask, int B,
+int esmi_mel_decoder_f32(const float* blob, const esmi_decoder_shape* s, const float* x,
+                         const float* h0, /* optional, fused mode only: (B,T,dx2) = LN(tanh(proj(x))), see esmi_decoder_head */
+                         const int32_t* cum, const int32_t* mel_len, const int32_t* lmax_dev, int lmax_host, int apply_mask, int B,
                          int T, int L_out, float* mel, esmi_stream_t stream);
 
 /* x.masked_fill(mask[:, :, None], 0) on (rows, C) fp32 -- used by the module-level API when the
