@@ -33,8 +33,8 @@ DECODER_WORK = {"tiny": (189_440, 832), "small": (973_824, 1344), "base": (1_505
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--config", default="tiny", choices=["tiny", "small", "base"])
     ap.add_argument("--batch", type=int, default=None, help="utterances per GPU (default: BASELINE config)")
     ap.add_argument("--phonemes", type=int, default=None)
