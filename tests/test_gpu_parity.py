@@ -262,3 +262,37 @@ def test_edge_cases(nets):
     np.testing.assert_allclose(enc["pitch"].cpu().numpy(), o.pitch, atol=H.PRED_TOL, rtol=0)
     assert np.array_equal(mel_len.cpu().numpy(), o.mel_len)
     assert np.abs(mel.cpu().numpy() - o.mel).max() < H.MEL_TOL
+
+
+@pytest.mark.parametrize("seed", list(range(12)))
+def test_random_shapes_vs_oracle(seed, nets):
+    """Seeded random batch shapes, ragged lengths and forced durations (0..7, zeros included) on tiny ES: every tiling /
+    halo / gather branch of the default plan (T <= 128: whole-block kernels, phoneme-rate decoder head, scan inside the
+    variance kernel; T > 128: per-stage kernels with halo workgroups, in-kernel proj) against the oracle."""
+    rng = np.random.default_rng(1000 + seed)
+    net, cfg, sd = nets("tiny")
+    B = int(rng.integers(1, 9))
+    T = int(rng.integers(1, 200)) if seed % 3 else int(rng.integers(97, 129))
+    lens = sorted((int(v) for v in rng.integers(1, T + 1, size=B)), reverse=True)
+    lens[0] = T
+    ids, mask = synth_phonemes(B, T, 50 + seed, lens)
+    dur = rng.integers(0, 8, size=(B, T)).astype(np.int32)
+    dur[rng.random((B, T)) < 0.15] = 0
+    x = {"phoneme": torch.from_numpy(ids).to(DEV), "duration_forced": torch.from_numpy(dur).to(DEV)}
+    if B > 1:
+        x["phoneme_mask"] = torch.from_numpy(mask).to(DEV)
+    if seed % 2:
+        x["max_mel_len"] = int(dur.sum(1).max()) + int(rng.integers(0, 40))
+    with torch.no_grad():
+        enc = net.encoder._encode(x)
+        mel, mel_len, _ = net(x)
+    o = oracle.phoneme2mel(cfg, oracle.Weights(sd), ids, mask if B > 1 else None,
+                           pitch=enc["pitch"][..., 0].cpu().numpy(), energy=enc["energy"][..., 0].cpu().numpy(), duration=dur)
+    np.testing.assert_allclose(enc["pitch"].cpu().numpy(), o.pitch, atol=H.PRED_TOL, rtol=0)
+    np.testing.assert_allclose(enc["duration"].cpu().numpy(), o.duration, atol=H.PRED_TOL, rtol=0)
+    assert np.array_equal(mel_len.cpu().numpy(), o.mel_len)
+    L = o.mel.shape[1]
+    m = mel.cpu().numpy()
+    assert m.shape[1] >= L and not m[:, L:].any()
+    if L:
+        assert np.abs(m[:, :L] - o.mel).max() < H.MEL_TOL

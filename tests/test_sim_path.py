@@ -209,3 +209,26 @@ def test_simulated_weight_packers():
         lib.esmi_compose_merge_f32(torch.from_numpy(wm).data_ptr(), torch.from_numpy(w1).data_ptr(), k, cin, cout, dst.data_ptr(), None)
         ref = np.einsum("om,jmi->joi", w1.astype(np.float64), wm.astype(np.float64)).astype(np.float32)
         assert np.array_equal(dst.numpy(), ref)
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_simulated_random_shapes(seed, nets):
+    """Small seeded random shapes / ragged lengths / forced durations (zeros included) through the simulated default plan."""
+    rng = np.random.default_rng(2000 + seed)
+    net, cfg, sd = nets("tiny")
+    B, T = int(rng.integers(1, 4)), int(rng.integers(1, 60))
+    lens = sorted((int(v) for v in rng.integers(1, T + 1, size=B)), reverse=True)
+    lens[0] = T
+    ids, mask = synth_phonemes(B, T, 70 + seed, lens)
+    dur = rng.integers(0, 4, size=(B, T)).astype(np.int32)
+    x = {"phoneme": torch.from_numpy(ids), "duration_forced": torch.from_numpy(dur)}
+    if B > 1:
+        x["phoneme_mask"] = torch.from_numpy(mask)
+    with use_sim(), torch.no_grad():
+        enc = net.encoder._encode(x)
+        mel, mel_len, _ = net(x)
+    o = oracle.phoneme2mel(cfg, oracle.Weights(sd), ids, mask if B > 1 else None, pitch=enc["pitch"][..., 0].numpy(),
+                           energy=enc["energy"][..., 0].numpy(), duration=dur)
+    assert np.array_equal(mel_len.numpy(), o.mel_len) and mel.shape == o.mel.shape
+    if o.mel.size:
+        assert np.abs(mel.numpy() - o.mel).max() < H.MEL_TOL
