@@ -100,11 +100,14 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    if os.environ.get("ESMI_BENCH_ONE_DEVICE"):            # development: exercise the N>1 code path on a 1-GPU box
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)     # "nccl" is RCCL on ROCm
+        backend = os.environ.get("ESMI_BENCH_BACKEND", "nccl")     # "nccl" is RCCL on ROCm; "gloo" only for the 1-GPU dry run
+        dist.init_process_group(backend, **({"device_id": dev} if backend == "nccl" else {}))
 
     from efficientspeech_amd import CONFIGS, build_phoneme2mel, load_numpy_state_dict
     from efficientspeech_amd.synth import synth_state_dict, synth_phonemes
