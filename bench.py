@@ -43,6 +43,10 @@ def parse():
     ap.add_argument("--no-gather", action="store_true", help="skip the mel all-gather (N>1 debugging)")
     ap.add_argument("--two-stream", action="store_true",
                     help="software-pipeline consecutive steps: encoder side of step i+1 concurrent with the decoder of step i")
+    ap.add_argument("--no-auto-launch", action="store_true",
+                    help="N=1 only: do not try the two-stream pipeline during warm-up (default: warm up both launch modes and "
+                         "keep two-stream only if it is >= 5 %% faster -- it is on boxes whose GPU drops to a low sclk state "
+                         "during the light encoder-side kernels, and ~3 %% slower elsewhere)")
     ap.add_argument("--graph", action="store_true",
                     help="replay the forward as two hipGraphs per step instead of eager launches (measured 2.5 %% slower "
                          "on an idle host: the step is GPU-bound; useful when the host is slow)")
@@ -134,10 +138,29 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(dev)
 
+    launch_note = ""
     with torch.no_grad():
         for _ in range(a.warmup):
             pipe.step(x)
         pipe.flush()
+        if world == 1 and not (a.graph or a.two_stream or a.no_auto_launch):
+            # untimed: which launch mode is faster on THIS box?  (same kernels, same work; only the stream schedule differs)
+            alt = ShardedMelPipeline(net, world_size=1, gather=False, two_stream=True)
+
+            def trial(pl, n):
+                for _ in range(3):
+                    pl.step(x)
+                pl.flush(); torch.cuda.synchronize(dev)
+                t = time.perf_counter()
+                for _ in range(n):
+                    pl.step(x)
+                pl.flush(); torch.cuda.synchronize(dev)
+                return (time.perf_counter() - t) / n
+            n_try = max(10, a.warmup)
+            t_eager, t_two = trial(pipe, n_try), trial(alt, n_try)
+            if t_two < 0.95 * t_eager:
+                pipe, a.two_stream = alt, True
+            launch_note = f"; warm-up trial: eager {t_eager * 1e3:.3f} ms/step, two-stream {t_two * 1e3:.3f} ms/step"
         net.decoder.timing = []
         net.decoder.timing_every = a.event_every
         pipe.dec_events = [] if a.graph else None
@@ -174,7 +197,7 @@ def main():
                                f"(L={L}), eval path, mel all-gather over RCCL when N>1",
                    "global_batch": B * world, "phonemes": T, "frames_per_step": frames_per_step,
                    "parallelism": f"batch-shard x{world}",
-                   "launch": ("hipGraph replay (encoder graph + decoder graph per step)" if a.graph else "eager") + (", encoder/decoder on two streams (steps software-pipelined)" if a.two_stream else "")},
+                   "launch": ("hipGraph replay (encoder graph + decoder graph per step)" if a.graph else "eager") + (", encoder/decoder on two streams (steps software-pipelined)" if a.two_stream else "") + launch_note},
         "roofline": {"bound": "mfma", "kernel": "mel_decoder_kernel", "achieved": ach_tf, "peak": FP32_PEAK_TFLOPS,
                      "unit": "TFLOP/s", "frac": ach_tf / FP32_PEAK_TFLOPS, "traffic": traffic,
                      "traffic_unit": "HBM bytes per launch (rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE)",
