@@ -123,6 +123,7 @@ __device__ __forceinline__ void enc_fuse_va_body(const FuseVaP& p) {
             for (int r = 0; r < 16; ++r) a[nt][r] += bc;
         }
         tile_store<ND>(cat, ldc, 0, a, lane);
+        ESMI_CT();   // level 0 done
     }
     for (int lv = 1; lv < p.depth; ++lv) {   // Linear(dim*2^lv, dim) -> ConvTranspose1d(stride 2^lv), cropped to T
         const int s = 1 << lv, cl = DIM << lv, nl = p.n_i[lv];
@@ -145,6 +146,7 @@ __device__ __forceinline__ void enc_fuse_va_body(const FuseVaP& p) {
         lds_wave_sync();
         tile_store<ND>(tmp, LDD, 0, a, lane);
         lds_wave_sync();
+        ESMI_CT();   // level linear done
         zero_tiles<ND>(a);
         {   // out[n*s + j] += in[n] W[:, :, j]
             const float* taps[KU];
@@ -167,6 +169,7 @@ __device__ __forceinline__ void enc_fuse_va_body(const FuseVaP& p) {
             for (int r = 0; r < 16; ++r) a[nt][r] += bc;
         }
         tile_store<ND>(cat, ldc, lv * DIM, a, lane);
+        ESMI_CT();   // up-conv done
     }
     lds_wave_sync();
     zero_tiles<ND>(a);
