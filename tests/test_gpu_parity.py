@@ -296,3 +296,23 @@ def test_random_shapes_vs_oracle(seed, nets):
     assert m.shape[1] >= L and not m[:, L:].any()
     if L:
         assert np.abs(m[:, :L] - o.mel).max() < H.MEL_TOL
+
+
+def test_large_batch_uses_other_kernels(nets):
+    """B = 512, T = 64: too many waves for the column-split block-1 kernel, so the plain whole-block instantiation runs;
+    four utterances against the oracle (teacher-forced with the HIP path's own pitch / energy, durations forced)."""
+    net, cfg, sd = nets("tiny")
+    B, T = 512, 64
+    ids, mask = synth_phonemes(B, T, 5)
+    dur = np.full((B, T), 2, np.int32)
+    x = {"phoneme": torch.from_numpy(ids).to(DEV), "phoneme_mask": torch.from_numpy(mask).to(DEV),
+         "duration_forced": torch.from_numpy(dur).to(DEV), "max_mel_len": 2 * T}
+    with torch.no_grad():
+        enc = net.encoder._encode(x)
+        mel, mel_len, _ = net(x)
+    sel = [0, 100, 300, 511]
+    o = oracle.phoneme2mel(cfg, oracle.Weights(sd), ids[sel], mask[sel], pitch=enc["pitch"][sel, :, 0].cpu().numpy(),
+                           energy=enc["energy"][sel, :, 0].cpu().numpy(), duration=dur[sel], max_mel_len=2 * T)
+    np.testing.assert_allclose(enc["pitch"][sel].cpu().numpy(), o.pitch, atol=H.PRED_TOL, rtol=0)
+    assert (mel_len == 2 * T).all()
+    assert np.abs(mel[sel].cpu().numpy() - o.mel).max() < H.MEL_TOL
