@@ -683,7 +683,8 @@ int esmi_mel_decoder_f32(const float* blob, const esmi_decoder_shape* s, const f
 #ifdef ESMI_DEC_TRACE
     p.trace = g_esmi_trace;   // development only, see tools/trace_decoder.py
 #endif
-    dim3 grid((L_out + p.TL - 1) / p.TL, B), block(kDecThreads);
+    p.n_tiles = (L_out + p.TL - 1) / p.TL;
+    dim3 grid((unsigned)(p.n_tiles * ((B + 7) / 8) * 8)), block(kDecThreads);
     hipStream_t st = S(stream);
 #define ESMI_DEC_CASE(DX2, KD, NW)                                                                                 \
     {                                                                                                              \

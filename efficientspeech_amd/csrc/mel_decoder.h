@@ -140,6 +140,7 @@ struct MelDecP {
     int B, T, L_out;
     float* mel;            // (B, L_out, n_mel)
     int halo, TL;
+    int n_tiles;           // windows per utterance
     long long* trace;      // development only (-DESMI_DEC_TRACE): [wave][stamp] shader-clock stamps of block (1,0)
 };
 
@@ -202,7 +203,16 @@ __global__ __launch_bounds__(64 * NW, (DX2 <= 128 && NW == 8 ? ESMI_DEC_WPS : 2)
     const int tid = (int)threadIdx.x, lane = lane_id(), w = wave_id();
     const int i = lane & 31, h = lane >> 5;
     const int mh = w / NS, ns = w % NS;     // NW = 4: mh == 0
-    const int tile = (int)blockIdx.x, b = (int)blockIdx.y;
+    // XCD-aware workgroup -> (utterance, window) map: workgroup id % 8 is the XCD (round-robin dispatch), so the windows
+    // of one utterance are given ids that agree mod 8 and its h0 / cum rows are fetched into ONE XCD's L2 instead of eight.
+    int tile, b;
+    {
+        const int id = (int)blockIdx.x, per8 = 8 * p.n_tiles;
+        const int g = id / per8, r = id - g * per8;
+        tile = r >> 3;
+        b = 8 * g + (r & 7);
+        if (b >= p.B) return;
+    }
     const int L = p.lmax_dev ? *p.lmax_dev : (p.lmax_host >= 0 ? p.lmax_host : batch_max_len(p.mel_len, p.B));
     const int mlen = p.mel_len ? min(p.mel_len[b], L) : L;
     const int f_lo = tile * p.TL, f0 = f_lo - p.halo;
@@ -219,7 +229,7 @@ __global__ __launch_bounds__(64 * NW, (DX2 <= 128 && NW == 8 ? ESMI_DEC_WPS : 2)
     const f32x4* blob4 = reinterpret_cast<const f32x4*>(p.blob);
 #ifdef ESMI_DEC_TRACE
     int tr_n = 0;
-    const bool tr_on = p.trace && blockIdx.x == 1 && blockIdx.y == 0 && lane == 0;
+    const bool tr_on = p.trace && tile == 1 && b == 0 && lane == 0;
 #define ESMI_STAMP() do { if (tr_on) p.trace[w * 64 + tr_n] = (long long)__builtin_amdgcn_s_memtime(); ++tr_n; } while (0)
 #else
 #define ESMI_STAMP() do {} while (0)
