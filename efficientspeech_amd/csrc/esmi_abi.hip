@@ -631,8 +631,14 @@ int esmi_mel_decoder_pack_f32(const esmi_decoder_weights* w, const esmi_decoder_
     hipStream_t st = S(stream);
     const int dx2 = s->dx2, ntw = dx2 / 128;
     auto bslice = [&](const float* src, long off, int N, int K) {
+#if ESMI_DEC_BF16X3
+        const long n = (long)(K / 128) * 4 * ntw * 8 * 3 * 256;
+        ESMI_LAUNCH(pack_bslice3_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src,
+                    reinterpret_cast<unsigned*>(blob + off), N, K, ntw);
+#else
         const long n = (long)(K / 128) * 4 * ntw * 16 * 256;
         ESMI_LAUNCH(pack_bslice_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src, blob + off, N, K, ntw);
+#endif
     };
     auto vec = [&](const float* src, long off, int n, int n_pad) {
         ESMI_LAUNCH(copy_pad_kernel, dim3((n_pad + 255) / 256), dim3(256), 0, st, src, blob + off, n, n_pad);

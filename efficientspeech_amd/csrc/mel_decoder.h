@@ -64,6 +64,9 @@
 #define ESMI_DEC_NS 4      // column slices per workgroup of the dx2 = 128 build: 4 (two row groups) or 2 (four row groups: half the
                            // LDS A-fragment reads but twice the weight sub-slices per K loop: measured 0.522 vs 0.484 ms)
 #endif
+#ifndef ESMI_DEC_BF16X3
+#define ESMI_DEC_BF16X3 1   // 1: pointwise GEMMs as fp32-accurate split products on the bf16 matrix pipe (esmi_dev.h), 0: v_mfma_f32_32x32x2_f32
+#endif
 #ifndef ESMI_DEC_KSUB
 #define ESMI_DEC_KSUB 8     // k-steps (of 8 channels) of the weight slice held in registers at a time (16 = all of K = 128)
 #endif
@@ -87,7 +90,8 @@ struct DecLayout {  // offsets in floats into the packed blob
 inline DecLayout dec_layout(int d4, int dx2, int kd, int n_blocks, int block_depth) {
     DecLayout L;
     long o = 0;
-    L.proj_w = o; o += (long)d4 * dx2;
+    constexpr long kWNum = ESMI_DEC_BF16X3 ? 3 : 2;   // matrix storage: three bf16 planes (1.5x) or fp32
+    L.proj_w = o; o += (long)d4 * dx2 * kWNum / 2;
     L.proj_b = o; o += dx2;                    // proj_b, proj_g, proj_beta contiguous
     L.proj_g = o; o += dx2;
     L.proj_beta = o; o += dx2;
@@ -97,10 +101,10 @@ inline DecLayout dec_layout(int d4, int dx2, int kd, int n_blocks, int block_dep
     L.l_g = L.l_pwb + dx2;
     L.l_b = L.l_g + dx2;
     L.l_pw = L.l_b + dx2;                      // ... then the packed pointwise matrix
-    L.layer_stride = L.l_pw + (long)dx2 * dx2;
+    L.layer_stride = L.l_pw + (long)dx2 * dx2 * kWNum / 2;
     L.layer0 = o; o += L.layer_stride * n_blocks * block_depth;
     L.skip0 = o; o += 2L * dx2 * n_blocks;
-    L.mel_w = o; o += (long)dx2 * dx2;         // packed like a dx2 x dx2 matrix, rows >= n_mel zero
+    L.mel_w = o; o += (long)dx2 * dx2 * kWNum / 2;   // packed like a dx2 x dx2 matrix, rows >= n_mel zero
     L.mel_b = o; o += dx2;                     // zero padded
     L.total = o;
     return L;
@@ -123,6 +127,36 @@ __global__ void pack_bslice_kernel(const float* __restrict__ src, float* __restr
         const int row = ns * 32 * NTW + 32 * ntw + (lane & 31);
         const int col = 128 * c + 8 * kc + 4 * (lane >> 5) + s;
         dst[e] = row < N ? src[(long)row * K + col] : 0.0f;
+    }
+}
+
+// The same slices as three bf16 planes (hi / mid / lo by truncation, esmi_dev.h) in the B layout of
+// v_mfma_f32_32x32x16_bf16: per (chunk c, column slice ns, tile ntw, 16-channel step s, plane p) 64 lanes x 4 dwords:
+//   dst[((((((c*4 + ns)*NTW + ntw)*8 + s)*3 + p)*64 + lane)*4 + w] = {plane_p(W[row][k0 + 1]), plane_p(W[row][k0])},
+//   row = ns*32*NTW + 32*ntw + (lane&31),  k0 = 128*c + 16*s + 8*(lane>>5) + 2*w       (0 for rows >= N)
+__global__ void pack_bslice3_kernel(const float* __restrict__ src, unsigned* __restrict__ dst, int N, int K, int NTW) {
+    const long n = (long)(K / 128) * 4 * NTW * 8 * 3 * 256;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
+        const int wd = (int)(e & 3);
+        const int lane = (int)((e >> 2) & 63);
+        long q = e >> 8;
+        const int pl = (int)(q % 3); q /= 3;
+        const int st = (int)(q & 7); q >>= 3;
+        const int ntw = (int)(q % NTW); q /= NTW;
+        const int ns = (int)(q & 3);
+        const int c = (int)(q >> 2);
+        const int row = ns * 32 * NTW + 32 * ntw + (lane & 31);
+        const int k0 = 128 * c + 16 * st + 8 * (lane >> 5) + 2 * wd;
+        unsigned half[2];
+        for (int j = 0; j < 2; ++j) {
+            const float x = row < N ? src[(long)row * K + k0 + j] : 0.0f;
+            const unsigned h = __builtin_bit_cast(unsigned, x) & 0xFFFF0000u;
+            const float r1 = x - __builtin_bit_cast(float, h);
+            const unsigned m = __builtin_bit_cast(unsigned, r1) & 0xFFFF0000u;
+            const float r2 = r1 - __builtin_bit_cast(float, m);
+            half[j] = pl == 0 ? h : (pl == 1 ? m : (__builtin_bit_cast(unsigned, r2) & 0xFFFF0000u));
+        }
+        dst[e] = half[1] | (half[0] >> 16);
     }
 }
 
@@ -313,6 +347,38 @@ __global__ __launch_bounds__(64 * NW, (DX2 <= 128 && NW == 8 ? ESMI_DEC_WPS : 2)
     // weight-stationary GEMM pieces.  bf = this wave's weight slice for KSUB k-steps (64 VGPRs); it is
     // (re)loaded right after the previous K loop so the L2 latency hides under the non-MFMA phases.
     constexpr int KSUB = DX2 <= 128 ? ESMI_DEC_KSUB / NTW : 8;   // k-steps of weights in registers at a time (32 / 64 VGPRs)
+#if ESMI_DEC_BF16X3
+    // split-bf16 contraction (esmi_dev.h): per 16-channel step one A fragment (8 fp32 from the tile, split on the fly) against
+    // the three pre-split weight planes; KSUB/2 steps of weights (3 x 4 VGPRs each per tile) in registers at a time
+    constexpr int KS16 = KSUB / 2;
+    u32x4 bf[NTW][KS16][3];
+    auto load_b = [&](const f32x4* wsl, int k0) __attribute__((always_inline)) {
+        const u32x4* w3 = reinterpret_cast<const u32x4*>(wsl);
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) {
+#pragma unroll
+            for (int st = 0; st < KS16; ++st) {
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) bf[t][st][pl] = w3[((t * 8 + (k0 >> 1) + st) * 3 + pl) * 64];
+            }
+        }
+    };
+    auto mma_sub = [&](int a_col0, int k0) __attribute__((always_inline)) {
+        const float* a_base = xs + opaque_i((kDecPadRows + 32 * MT * mh + i) * LDSROW + 8 * h);
+#pragma unroll
+        for (int st = 0; st < KS16; ++st) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const float* ap = a_base + 32 * mt * LDSROW + a_col0 + 8 * k0 + 16 * st;
+                const bf16x3 a3 = split_bf16x3(*reinterpret_cast<const f32x4*>(ap), *reinterpret_cast<const f32x4*>(ap + 4));
+#pragma unroll
+                for (int t = 0; t < NTW; ++t) acc[mt][t] = mfma32_split(a3, bf[t][st][0], bf[t][st][1], bf[t][st][2], acc[mt][t]);
+            }
+        }
+    };
+    // slice pointer of chunk c of the matrix at float offset `off` (planes: 8 steps x 3 planes x 64 lanes x 16 B per tile)
+    auto wslice = [&](long off, int c) __attribute__((always_inline)) { return blob4 + (off >> 2) + (long)(c * (DX2 / 32) + ns * NTW) * 8 * 3 * 64 + lane; };
+#else
     f32x4 bf[NTW][KSUB];
     auto load_b = [&](const f32x4* wsl, int k0) __attribute__((always_inline)) {
 #pragma unroll
@@ -338,6 +404,7 @@ __global__ __launch_bounds__(64 * NW, (DX2 <= 128 && NW == 8 ? ESMI_DEC_WPS : 2)
     };
     // slice pointer of chunk c of the matrix at float offset `off`
     auto wslice = [&](long off, int c) __attribute__((always_inline)) { return blob4 + (off >> 2) + (long)(c * (DX2 / 32) + ns * NTW) * 16 * 64 + lane; };
+#endif
     // full dx2-wide contraction with the first sub-slice already in bf; leaves `next`'s first sub-slice in bf
     auto gemm_dx2 = [&](long off, const f32x4* next) __attribute__((always_inline)) {
 #pragma unroll

@@ -91,6 +91,26 @@ static inline ws_f32x16 mfma_32x32x2(float a, float b, ws_f32x16 c) {
     return d;
 }
 
+// v_mfma_f32_32x32x16_bf16: lane (i = l&31, kb = l>>5) holds A[i][8kb..8kb+7] / B[8kb..8kb+7][i] as 8 bf16 in 4 dwords
+template <class V4>
+static inline ws_f32x16 mfma_32x32x16_bf16(const V4& a, const V4& b, ws_f32x16 c) {
+    uint32_t w[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    const uint32_t* t = wave_exchange(w, 8);
+    const int l = lane_id();
+    auto elem = [&](int lane, int base, int k) {   // bf16 element k (0..7) of a lane's operand -> float
+        const uint32_t d = t[lane * 8 + base + (k >> 1)];
+        return u2f((k & 1) ? (d & 0xFFFF0000u) : (d << 16));
+    };
+    ws_f32x16 d = c;
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), col = l & 31;
+        float acc = c[r];
+        for (int k = 0; k < 16; ++k) acc = fmaf(elem(row + 32 * (k >> 3), 0, k & 7), elem(col + 32 * (k >> 3), 4, k & 7), acc);
+        d[r] = acc;
+    }
+    return d;
+}
+
 static inline ws_f32x4 mfma_16x16x4(float a, float b, ws_f32x4 c) {
     uint32_t w[2] = {f2u(a), f2u(b)};
     const uint32_t* t = wave_exchange(w, 2);
