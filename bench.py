@@ -186,6 +186,9 @@ def main():
     # variance-adaptor kernel when the shape allows (tiny, T <= 128): the decoder kernel itself then executes this much less
     head_moved = cfg.d4 == 128 and cfg.dx2 == 128 and T <= 128
     kernel_flops = flops - (2 * cfg.d4 * cfg.dx2 if head_moved else 0)
+    from efficientspeech_amd import _lib as _esmi_lib
+    build_cfg = _esmi_lib.load().esmi_build_config().decode()
+    split = "split-bf16x3" in build_cfg
     traffic, traffic_src, mfma_util, traffic_note = pmc_traffic(a.config, B, T, a.dur)
     out = {
         "metric": "mel-frames/sec (whole node), full Phoneme2Mel forward", "value": value, "unit": "mel-frames/s",
@@ -207,6 +210,13 @@ def main():
                      "mfma_pipe_utilisation_pmc": mfma_util,
                      "algorithmic_bytes_per_launch": nbytes * B * L,
                      "kernel_ms": dec_ms, "kernel_ms_samples": len(ev),
+                     "build_config": build_cfg,
+                     "contraction": ("fp32-accurate split products on the bf16 matrix pipe: x = hi+mid+lo bf16 (truncation, 24 "
+                                     "mantissa bits), 6 v_mfma_f32_32x32x16_bf16 per 16 channels, fp32 accumulation; measured error "
+                                     "<= that of an fp32 FMA chain (DESIGN.md 3.1); `peak` stays the fp32-MFMA peak = the bound of "
+                                     "an exact-fp32 implementation" if split else "v_mfma_f32_32x32x2_f32 (exact fp32)"),
+                     "bf16_pipe": ({"executed_tflops": 6 * kernel_flops * B * L / (dec_ms * 1e-3) / 1e12, "peak_tflops": 2500.0,
+                                    "frac": 6 * kernel_flops * B * L / (dec_ms * 1e-3) / 1e12 / 2500.0} if split else None),
                      "proj_stage_at_phoneme_rate": head_moved, "kernel_flops_per_frame": kernel_flops,
                      "frac_kernel_flops": kernel_flops * B * L / (dec_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, "algorithmic_flops_per_frame": flops, "algorithmic_bytes_per_frame": nbytes,
                      "hbm_frac": nbytes * B * L / (dec_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,

@@ -61,7 +61,7 @@ class DecoderShape(C.Structure):
 FUSE_MERGE_QKV, FUSE_ATTN_FFN, FUSE_VARIANCE, FUSE_SPLIT2, FUSE_BLOCK, FUSE_ALL = 1, 2, 4, 8, 16, 31
 
 EXPORTS = (
-    "esmi_version", "esmi_backend", "esmi_set_fusion", "esmi_fuse_variance_adaptor_workspace_bytes",
+    "esmi_version", "esmi_backend", "esmi_build_config", "esmi_set_fusion", "esmi_fuse_variance_adaptor_workspace_bytes",
     "esmi_fuse_variance_adaptor_f32", "esmi_pack_conv_weight_f32", "esmi_pack_convT_weight_f32",
     "esmi_encoder_block_workspace_bytes", "esmi_encoder_block_f32", "esmi_pool_mask_u8",
     "esmi_fuse_workspace_bytes", "esmi_fuse_f32", "esmi_variance_adaptor_workspace_bytes",
@@ -76,6 +76,7 @@ def bind(lib):
     i, sz, P = C.c_int, C.c_size_t, C.POINTER
     lib.esmi_version.restype = i
     lib.esmi_backend.restype = C.c_char_p
+    lib.esmi_build_config.restype = C.c_char_p
     lib.esmi_pack_conv_weight_f32.argtypes = [fp, fp, i, i, i, fp]
     lib.esmi_pack_convT_weight_f32.argtypes = [fp, fp, i, i, i, fp]
     lib.esmi_pack_bfrag_floats.argtypes = [i, i, i]

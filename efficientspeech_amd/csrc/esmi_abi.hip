@@ -252,6 +252,14 @@ const char* esmi_backend(void) {
 #endif
 }
 
+const char* esmi_build_config(void) {
+#if ESMI_DEC_BF16X3
+    return "dec_gemm=split-bf16x3";
+#else
+    return "dec_gemm=fp32-mfma";
+#endif
+}
+
 int esmi_pack_conv_weight_f32(const float* src, float* dst, int cout, int cin, int k, esmi_stream_t stream) {
     if (!src || !dst || cout <= 0 || cin <= 0 || k <= 0) return ESMI_ERR_ARG;
     const long n = (long)cout * cin * k;

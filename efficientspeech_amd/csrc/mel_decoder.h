@@ -68,7 +68,8 @@
 #define ESMI_DEC_BF16X3 1   // 1: pointwise GEMMs as fp32-accurate split products on the bf16 matrix pipe (esmi_dev.h), 0: v_mfma_f32_32x32x2_f32
 #endif
 #ifndef ESMI_DEC_KSUB
-#define ESMI_DEC_KSUB 8     // k-steps (of 8 channels) of the weight slice held in registers at a time (16 = all of K = 128)
+#define ESMI_DEC_KSUB (ESMI_DEC_BF16X3 ? 4 : 8)   // k-steps (of 8 channels) of the weight slice held in registers at a time (16 = all of
+                                                 // K = 128); split-bf16 path: 4 -> 24 VGPRs of planes (measured: 2: 0.319, 4: 0.309-0.317, 8: 0.323 ms)
 #endif
 
 namespace esmi {

@@ -44,6 +44,9 @@ typedef void* esmi_stream_t; /* hipStream_t */
 int esmi_version(void);
 /* "hip:gfx950" for the product build; "wavesim" for the CPU test simulator build. */
 const char* esmi_backend(void);
+/* Build-time choices that change HOW (not what) the library computes, e.g. "dec_gemm=split-bf16x3" (the mel decoder's
+ * contractions as fp32-accurate split products on the bf16 matrix pipe) or "dec_gemm=fp32-mfma". */
+const char* esmi_build_config(void);
 
 /* Fusion switch (process-global bit mask, default ESMI_FUSE_ALL): a cleared bit forces one kernel per
  * reference op for that stage instead of the fused wave-chain kernel.  Returns the previous mask.
