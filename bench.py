@@ -193,7 +193,9 @@ def main():
     out = {
         "metric": "mel-frames/sec (whole node), full Phoneme2Mel forward", "value": value, "unit": "mel-frames/s",
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32" + (" (mel-decoder GEMMs: fp32 operands split exactly into 3 bf16, 6 bf16-MFMA products, fp32 accumulate)" if split else ""),
+        "data": "synthetic",
         "mRTF": value * 256 / 22050,
         "config": {"workload": f"{a.config} ES ({sum(v.size for v in sd.values())} params, seeded random weights), "
                                f"synthetic phoneme batch B={B} T={T} per GPU, injected durations D-const {a.dur} "
