@@ -43,6 +43,9 @@ def parse():
     ap.add_argument("--no-gather", action="store_true", help="skip the mel all-gather (N>1 debugging)")
     ap.add_argument("--two-stream", action="store_true",
                     help="software-pipeline consecutive steps: encoder side of step i+1 concurrent with the decoder of step i")
+    ap.add_argument("--exact-fp32", action="store_true",
+                    help="load efficientspeech_amd/libesmi_fp32mfma.so: the same kernels with the mel decoder's contractions on "
+                         "v_mfma_f32_32x32x2_f32 (exact fp32) instead of split-bf16 products")
     ap.add_argument("--no-auto-launch", action="store_true",
                     help="N=1 only: do not try the two-stream pipeline during warm-up (default: warm up both launch modes and "
                          "keep two-stream only if it is >= 5 %% faster -- it is on boxes whose GPU drops to a low sclk state "
@@ -100,6 +103,8 @@ def pmc_traffic(config, B, T, dur):
 
 def main():
     a = parse()
+    if a.exact_fp32:
+        os.environ["ESMI_LIB"] = os.path.join(ROOT, "efficientspeech_amd", "libesmi_fp32mfma.so")
     rank = int(os.environ.get("RANK", 0))
     local = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
@@ -190,6 +195,8 @@ def main():
     build_cfg = _esmi_lib.load().esmi_build_config().decode()
     split = "split-bf16x3" in build_cfg
     traffic, traffic_src, mfma_util, traffic_note = pmc_traffic(a.config, B, T, a.dur)
+    if a.exact_fp32:    # the committed counters were collected on the default (split-bf16) build
+        traffic, traffic_src, mfma_util, traffic_note = None, None, None, None
     out = {
         "metric": "mel-frames/sec (whole node), full Phoneme2Mel forward", "value": value, "unit": "mel-frames/s",
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,

@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libesmi.so")
+LIB_PATH = os.environ.get("ESMI_LIB") or os.path.join(_HERE, "libesmi.so")   # ESMI_LIB: another build of the same ABI
 MAX_DEPTH = 4
 MAX_DEC_LAYERS = 16
 

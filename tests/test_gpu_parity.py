@@ -316,3 +316,28 @@ def test_large_batch_uses_other_kernels(nets):
     np.testing.assert_allclose(enc["pitch"][sel].cpu().numpy(), o.pitch, atol=H.PRED_TOL, rtol=0)
     assert (mel_len == 2 * T).all()
     assert np.abs(mel[sel].cpu().numpy() - o.mel).max() < H.MEL_TOL
+
+
+def test_exact_fp32_mfma_build():
+    """The alternative build (mel-decoder contractions on v_mfma_f32_32x32x2_f32 instead of split-bf16 products) is the same
+    ABI; run two golden fixtures and the smoke check through it in a fresh interpreter (ESMI_LIB selects the library)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = os.path.join(root, "efficientspeech_amd", "libesmi_fp32mfma.so")
+    if not os.path.exists(lib):
+        pytest.skip("libesmi_fp32mfma.so not built")
+    code = (
+        "import numpy as np, os, sys; sys.path.insert(0, %r)\n"
+        "from tests import helpers as H\n"
+        "from efficientspeech_amd import _lib\n"
+        "assert _lib.load().esmi_build_config().decode() == 'dec_gemm=fp32-mfma'\n"
+        "for f in ('tiny_eval_pad_t17.npz', 'tiny_forced_d6_t16.npz'):\n"
+        "    g = np.load(os.path.join(%r, 'tests', 'golden', f))\n"
+        "    net, cfg, sd = H.make_net('tiny', 'cuda', golden=g)\n"
+        "    H.check_against_golden(net, g, 'cuda')\n"
+        "import __graft_entry__ as ge; ge.smoke()\n" % (root, root))
+    env = dict(os.environ, ESMI_LIB=lib)
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "smoke ok" in r.stdout
