@@ -45,7 +45,7 @@ def parse():
                     help="software-pipeline consecutive steps: encoder side of step i+1 concurrent with the decoder of step i")
     ap.add_argument("--exact-fp32", action="store_true",
                     help="load efficientspeech_amd/libesmi_fp32mfma.so: the same kernels with the mel decoder's contractions on "
-                         "v_mfma_f32_32x32x2_f32 (exact fp32) instead of split-bf16 products")
+                         "v_mfma_f32_32x32x2_f32 (exact fp32) instead of split 16-bit products")
     ap.add_argument("--no-auto-launch", action="store_true",
                     help="N=1 only: do not try the two-stream pipeline during warm-up (default: warm up both launch modes and "
                          "keep two-stream only if it is >= 5 %% faster -- it is on boxes whose GPU drops to a low sclk state "
@@ -193,15 +193,18 @@ def main():
     kernel_flops = flops - (2 * cfg.d4 * cfg.dx2 if head_moved else 0)
     from efficientspeech_amd import _lib as _esmi_lib
     build_cfg = _esmi_lib.load().esmi_build_config().decode()
-    split = "split-bf16x3" in build_cfg
+    split = {"dec_gemm=split-bf16x3": 6, "dec_gemm=split-f16x2": 3}.get(build_cfg, 0)    # low-precision MFMA products per fp32 product
+    split_txt = {6: "fp32 operands split exactly into 3 bf16, 6 bf16-MFMA products, fp32 accumulate",
+                 3: "fp32 operands split into 2 f16 pieces (22 significand bits, weights pre-scaled 2^8), 3 f16-MFMA products, fp32 accumulate",
+                 0: ""}[split]
     traffic, traffic_src, mfma_util, traffic_note = pmc_traffic(a.config, B, T, a.dur)
-    if a.exact_fp32:    # the committed counters were collected on the default (split-bf16) build
+    if a.exact_fp32:    # the committed counters were collected on the default (split) build
         traffic, traffic_src, mfma_util, traffic_note = None, None, None, None
     out = {
         "metric": "mel-frames/sec (whole node), full Phoneme2Mel forward", "value": value, "unit": "mel-frames/s",
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32" + (" (mel-decoder GEMMs: fp32 operands split exactly into 3 bf16, 6 bf16-MFMA products, fp32 accumulate)" if split else ""),
+        "dtype": "f32" + (f" (mel-decoder GEMMs: {split_txt})" if split else ""),
         "data": "synthetic",
         "mRTF": value * 256 / 22050,
         "config": {"workload": f"{a.config} ES ({sum(v.size for v in sd.values())} params, seeded random weights), "
@@ -220,12 +223,12 @@ def main():
                      "algorithmic_bytes_per_launch": nbytes * B * L,
                      "kernel_ms": dec_ms, "kernel_ms_samples": len(ev),
                      "build_config": build_cfg,
-                     "contraction": ("fp32-accurate split products on the bf16 matrix pipe: x = hi+mid+lo bf16 (truncation, 24 "
-                                     "mantissa bits), 6 v_mfma_f32_32x32x16_bf16 per 16 channels, fp32 accumulation; measured error "
-                                     "<= that of an fp32 FMA chain (DESIGN.md 3.1); `peak` stays the fp32-MFMA peak = the bound of "
-                                     "an exact-fp32 implementation" if split else "v_mfma_f32_32x32x2_f32 (exact fp32)"),
-                     "bf16_pipe": ({"executed_tflops": 6 * kernel_flops * B * L / (dec_ms * 1e-3) / 1e12, "peak_tflops": 2500.0,
-                                    "frac": 6 * kernel_flops * B * L / (dec_ms * 1e-3) / 1e12 / 2500.0} if split else None),
+                     "contraction": ((f"fp32-accurate split products on the 16-bit matrix pipe: {split_txt}; {split} "
+                                      f"v_mfma_f32_32x32x16_{'bf16' if split == 6 else 'f16'} per 16 channels; measured error <= that of an "
+                                      "fp32 FMA chain (DESIGN.md 3.1); `peak` stays the fp32-MFMA peak = the bound of an exact-fp32 "
+                                      "implementation (bench.py --exact-fp32 measures that build)") if split else "v_mfma_f32_32x32x2_f32 (exact fp32)"),
+                     "matrix_pipe_16bit": ({"executed_tflops": split * kernel_flops * B * L / (dec_ms * 1e-3) / 1e12, "peak_tflops": 2500.0,
+                                            "frac": split * kernel_flops * B * L / (dec_ms * 1e-3) / 1e12 / 2500.0} if split else None),
                      "proj_stage_at_phoneme_rate": head_moved, "kernel_flops_per_frame": kernel_flops,
                      "frac_kernel_flops": kernel_flops * B * L / (dec_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, "algorithmic_flops_per_frame": flops, "algorithmic_bytes_per_frame": nbytes,
                      "hbm_frac": nbytes * B * L / (dec_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,

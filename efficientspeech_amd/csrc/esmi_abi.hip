@@ -253,7 +253,9 @@ const char* esmi_backend(void) {
 }
 
 const char* esmi_build_config(void) {
-#if ESMI_DEC_BF16X3
+#if ESMI_DEC_SPLIT == 2
+    return "dec_gemm=split-f16x2";
+#elif ESMI_DEC_SPLIT == 1
     return "dec_gemm=split-bf16x3";
 #else
     return "dec_gemm=fp32-mfma";
@@ -639,7 +641,11 @@ int esmi_mel_decoder_pack_f32(const esmi_decoder_weights* w, const esmi_decoder_
     hipStream_t st = S(stream);
     const int dx2 = s->dx2, ntw = dx2 / 128;
     auto bslice = [&](const float* src, long off, int N, int K) {
-#if ESMI_DEC_BF16X3
+#if ESMI_DEC_SPLIT == 2
+        const long n = (long)(K / 128) * 4 * ntw * 8 * 2 * 256;
+        ESMI_LAUNCH(pack_bslice2h_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src,
+                    reinterpret_cast<unsigned*>(blob + off), N, K, ntw);
+#elif ESMI_DEC_SPLIT == 1
         const long n = (long)(K / 128) * 4 * ntw * 8 * 3 * 256;
         ESMI_LAUNCH(pack_bslice3_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src,
                     reinterpret_cast<unsigned*>(blob + off), N, K, ntw);

@@ -87,6 +87,91 @@ __device__ __forceinline__ f32x16 mfma32_split(const bf16x3& a, const u32x4& bh,
     c = mfma32_bf16(a.lo, bh, c);
     return c;
 }
+// the transposed product: acc(32 out-channels x 32 rows) += W planes . A^T (operands swapped: same fragments, D^T)
+__device__ __forceinline__ f32x16 mfma32_split_wx(const u32x4& bh, const u32x4& bm, const u32x4& bl, const bf16x3& a, f32x16 c) {
+    c = mfma32_bf16(bh, a.hi, c);
+    c = mfma32_bf16(bm, a.hi, c);
+    c = mfma32_bf16(bh, a.mid, c);
+    c = mfma32_bf16(bm, a.mid, c);
+    c = mfma32_bf16(bl, a.hi, c);
+    c = mfma32_bf16(bh, a.lo, c);
+    return c;
+}
+
+// ---- the same idea on the f16 matrix pipe with HALF the products: x = h1 + h2 (two binary16 pieces, 11 + 11 significand
+// bits; h1 by round-toward-zero so the residual x - h1 is exact), weights pre-scaled by 2^8 and pre-split the same way
+// (round to nearest), a.w ~= h1.w1 + h1.w2 + h2.w1: the dropped h2.w2 term and the pieces' rounding are ~2^-22 relative,
+// below the fp32 accumulation error of a K >= 32 contraction (numpy emulation, K = 128: max error 0.8-3.2e-6 vs 1.4-4.6e-6
+// for sequential fp32 accumulation).  Operands must be inside the binary16 range: |a| < 65504 and
+// |w| < 255 (2^8 scale keeps the second piece of weights down to 5e-4 a normal number; smaller ones lose nothing that
+// matters: absolute error < 2.4e-10 per weight).  Layout as for v_mfma_f32_32x32x16_bf16.
+struct f16x2p { u32x4 h1, h2; };
+constexpr float kF16WScale = 256.0f, kF16WScaleInv = 1.0f / 256.0f;
+__host__ __device__ inline unsigned f32_to_f16_bits(float f, bool rtz) {     // software conversion (packers, simulator)
+    const unsigned u = __builtin_bit_cast(unsigned, f), sign = (u >> 16) & 0x8000u, a = u & 0x7FFFFFFFu;
+    if (a >= 0x7F800000u) return sign | 0x7C00u | (a > 0x7F800000u ? 0x200u : 0u);
+    const int e = (int)(a >> 23) - 127;
+    if (a == 0 || e < -26) return sign;
+    if (e > 15) return sign | (rtz ? 0x7BFFu : 0x7C00u);
+    const unsigned m = (a & 0x7FFFFFu) | 0x800000u;
+    const int shift = e >= -14 ? 13 : 13 + (-14 - e);
+    if (shift > 25) return sign;
+    unsigned q = m >> shift;
+    const unsigned rem = m & ((1u << shift) - 1u), half = 1u << (shift - 1);
+    if (!rtz && (rem > half || (rem == half && (q & 1u)))) ++q;
+    unsigned h = e >= -14 ? ((unsigned)(e + 14) << 10) + q : q;
+    if (rtz && h >= 0x7C00u) h = 0x7BFFu;
+    return sign | h;
+}
+__host__ __device__ inline float f16_bits_to_f32(unsigned h) {
+    const unsigned sign = (h & 0x8000u) << 16, e = (h >> 10) & 31u, m = h & 0x3FFu;
+    if (e == 31u) return __builtin_bit_cast(float, sign | 0x7F800000u | (m << 13));
+    if (e == 0u) {   // zero / subnormal: m * 2^-24
+        const float v = (float)m * 5.9604644775390625e-08f;
+        return (h & 0x8000u) ? -v : v;
+    }
+    return __builtin_bit_cast(float, sign | ((e + 112u) << 23) | (m << 13));
+}
+__device__ __forceinline__ f16x2p split_f16x2(const f32x4& x0, const f32x4& x1) {   // 8 consecutive k of one row
+    f16x2p o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float a = j < 2 ? x0[2 * j] : x1[2 * j - 4], b = j < 2 ? x0[2 * j + 1] : x1[2 * j - 3];
+#ifdef ESMI_WAVESIM
+        const unsigned ha = f32_to_f16_bits(a, true), hb = f32_to_f16_bits(b, true);
+        const float ra = a - f16_bits_to_f32(ha), rb = b - f16_bits_to_f32(hb);
+        o.h1[j] = ha | (hb << 16);
+        o.h2[j] = f32_to_f16_bits(ra, true) | (f32_to_f16_bits(rb, true) << 16);
+#else
+        const auto h = __builtin_amdgcn_cvt_pkrtz(a, b);            // v_cvt_pkrtz_f16_f32
+        const float ra = a - (float)h[0], rb = b - (float)h[1];     // exact
+        o.h1[j] = __builtin_bit_cast(unsigned, h);
+        o.h2[j] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(ra, rb));
+#endif
+    }
+    return o;
+}
+__device__ __forceinline__ f32x16 mfma32_f16(const u32x4& a, const u32x4& b, f32x16 c) {
+#ifdef ESMI_WAVESIM
+    return wavesim::mfma_32x32x16_f16(a, b, c);
+#else
+    typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+#endif
+}
+// acc += A(32 x 16, fp32 split on the fly) . B(16 x 32, pre-scaled pre-split planes); the caller rescales by kF16WScaleInv
+__device__ __forceinline__ f32x16 mfma32_split2(const f16x2p& a, const u32x4& b1, const u32x4& b2, f32x16 c) {
+    c = mfma32_f16(a.h2, b1, c);
+    c = mfma32_f16(a.h1, b2, c);
+    c = mfma32_f16(a.h1, b1, c);
+    return c;
+}
+__device__ __forceinline__ f32x16 mfma32_split2_wx(const u32x4& b1, const u32x4& b2, const f16x2p& a, f32x16 c) {   // D^T
+    c = mfma32_f16(b1, a.h2, c);
+    c = mfma32_f16(b2, a.h1, c);
+    c = mfma32_f16(b1, a.h1, c);
+    return c;
+}
 
 __device__ __forceinline__ float shfl_xor_f(float v, int mask) {
 #ifdef ESMI_WAVESIM
@@ -167,6 +252,13 @@ __device__ __forceinline__ float row_sum32(float v) {
     v += dpp_f<0x141>(v);
     v += dpp_f<0x140>(v);
     v += swz_xor16_f(v);
+    return v;
+}
+__device__ __forceinline__ float row_sum16(float v) {   // all-reduce over each aligned group of 16 lanes (one DPP row)
+    v += dpp_f<0xB1>(v);
+    v += dpp_f<0x4E>(v);
+    v += dpp_f<0x141>(v);
+    v += dpp_f<0x140>(v);
     return v;
 }
 __device__ __forceinline__ float row_max32(float v) {

@@ -12,7 +12,7 @@
 // per side = the depthwise conv's in-window padding; +4 floats/row keep the 16-byte row-fragment
 // reads bank-conflict free).
 //
-// Weight-stationary GEMMs on v_mfma_f32_32x32x2_f32 (exact fp32).  Wave w = (mh = w>>2, ns = w&3)
+// Weight-stationary GEMMs (ESMI_DEC_SPLIT: exact-fp32 MFMA, or fp32-accurate split products on the bf16 / f16 matrix pipe).  Wave w = (mh = w>>2, ns = w&3)
 // owns rows [64mh, 64mh+64) x columns [ns*DX2/4, +DX2/4).  For each 128-channel K chunk it loads
 // its weight slice ONCE into registers (16 coalesced 16-byte loads per 32-column tile, from the
 // pre-packed blob) and streams the A fragments of its 64 rows from LDS: the K loop touches no
@@ -22,8 +22,9 @@
 // Per conv layer, five short phases separated by workgroup barriers:
 //   1. depthwise k-tap conv IN PLACE on the tile (each thread: 4 channels x 8 or 16 rows, window in
 //      registers);  2. K loop (MFMA only + ds_read_b128);  3. bias + tanh, accumulators -> tile;
-//   4. LayerNorm by row-owner threads (4 threads per row, the row's values and the skip tensor in
-//      registers; block end: LN_s(x + skip));  rows outside [0, L) are forced to 0.
+//   4. LayerNorm by row-owner threads (16 threads = one DPP row per tile row, 4 rows per thread so that the gain / shift
+//      vectors are read once per 4 rows; the rows' values and the skip tensor in registers; block end: LN_s(x + skip));
+//      rows outside [0, L) are forced to 0.
 //
 // Fidelity notes (SURVEY.md §7 "hard parts"):
 //  * frames in [mel_len[b], L) are PADDING FRAMES: zero input rows, but computed like any other frame,
@@ -35,10 +36,16 @@
 #include "esmi_dev.h"
 #include "small_kernels.h"
 
+#ifdef ESMI_ABL_NO_TANH
+#define ESMI_DEC_TANH(x) (x)
+#endif
 #ifndef ESMI_DEC_TANH
 #define ESMI_DEC_TANH tanh_fast_f32
 #endif
-// Build knobs of the dx2 = 128 instantiation (measured on MI355X, tiny ES B=256 T=128, decoder time inside bench.py):
+// Build knobs of the dx2 = 128 instantiation (measured on MI355X, tiny ES B=256 T=128, decoder time inside bench.py; the three
+// lines below are from the exact-fp32 build with the proj stage still at frame rate.  Since then, same workload:
+// proj at phoneme rate 0.41 ms, split-bf16x3 contraction 0.31 ms, split-f16x2 0.24 ms, 16-lane LayerNorm rows 0.215 ms;
+// marginal costs by ablation at the 0.24 ms point: LayerNorm 56 us, operand split 29 us, MFMA 15 us, tanh 9 us):
 //   WPS=2 KSUB=16 LOWREG=0 : 235 VGPRs, no spill, ONE workgroup per CU ........ 0.500 ms
 //   WPS=3 KSUB=16 LOWREG=1 : 168 VGPRs, no spill, one workgroup per CU ........ 0.505 ms
 //   WPS=4 KSUB=8  LOWREG=1 : 128 VGPRs, 55 spilled, TWO workgroups per CU ..... 0.477 ms   <- default
@@ -64,11 +71,11 @@
 #define ESMI_DEC_NS 4      // column slices per workgroup of the dx2 = 128 build: 4 (two row groups) or 2 (four row groups: half the
                            // LDS A-fragment reads but twice the weight sub-slices per K loop: measured 0.522 vs 0.484 ms)
 #endif
-#ifndef ESMI_DEC_BF16X3
-#define ESMI_DEC_BF16X3 1   // 1: pointwise GEMMs as fp32-accurate split products on the bf16 matrix pipe (esmi_dev.h), 0: v_mfma_f32_32x32x2_f32
-#endif
+#ifndef ESMI_DEC_SPLIT      // contraction of the pointwise GEMMs (esmi_dev.h):
+#define ESMI_DEC_SPLIT 2    //   0: v_mfma_f32_32x32x2_f32 (exact fp32)      1: fp32 split into 3 bf16, 6 products on v_mfma_f32_32x32x16_bf16
+#endif                      //   2: fp32 split into 2 f16 (weights pre-scaled by 2^8), 3 products on v_mfma_f32_32x32x16_f16
 #ifndef ESMI_DEC_KSUB
-#define ESMI_DEC_KSUB (ESMI_DEC_BF16X3 ? 4 : 8)   // k-steps (of 8 channels) of the weight slice held in registers at a time (16 = all of
+#define ESMI_DEC_KSUB (ESMI_DEC_SPLIT ? 4 : 8)   // k-steps (of 8 channels) of the weight slice held in registers at a time (16 = all of
                                                  // K = 128); split-bf16 path: 4 -> 24 VGPRs of planes (measured: 2: 0.319, 4: 0.309-0.317, 8: 0.323 ms)
 #endif
 
@@ -91,7 +98,7 @@ struct DecLayout {  // offsets in floats into the packed blob
 inline DecLayout dec_layout(int d4, int dx2, int kd, int n_blocks, int block_depth) {
     DecLayout L;
     long o = 0;
-    constexpr long kWNum = ESMI_DEC_BF16X3 ? 3 : 2;   // matrix storage: three bf16 planes (1.5x) or fp32
+    constexpr long kWNum = ESMI_DEC_SPLIT == 1 ? 3 : 2;   // matrix storage: three bf16 planes (1.5x), two f16 planes or fp32
     L.proj_w = o; o += (long)d4 * dx2 * kWNum / 2;
     L.proj_b = o; o += dx2;                    // proj_b, proj_g, proj_beta contiguous
     L.proj_g = o; o += dx2;
@@ -161,6 +168,31 @@ __global__ void pack_bslice3_kernel(const float* __restrict__ src, unsigned* __r
     }
 }
 
+// ... and as two binary16 planes of 2^8 * W (round to nearest; esmi_dev.h) in the same layout with 2 planes per step:
+//   dst[((((((c*4 + ns)*NTW + ntw)*8 + s)*2 + p)*64 + lane)*4 + w] = {plane_p(W[row][k0 + 1]), plane_p(W[row][k0])}
+__global__ void pack_bslice2h_kernel(const float* __restrict__ src, unsigned* __restrict__ dst, int N, int K, int NTW) {
+    const long n = (long)(K / 128) * 4 * NTW * 8 * 2 * 256;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
+        const int wd = (int)(e & 3);
+        const int lane = (int)((e >> 2) & 63);
+        long q = e >> 8;
+        const int pl = (int)(q & 1); q >>= 1;
+        const int st = (int)(q & 7); q >>= 3;
+        const int ntw = (int)(q % NTW); q /= NTW;
+        const int ns = (int)(q & 3);
+        const int c = (int)(q >> 2);
+        const int row = ns * 32 * NTW + 32 * ntw + (lane & 31);
+        const int k0 = 128 * c + 16 * st + 8 * (lane >> 5) + 2 * wd;
+        unsigned half[2];
+        for (int j = 0; j < 2; ++j) {
+            const float x = (row < N ? src[(long)row * K + k0 + j] : 0.0f) * kF16WScale;
+            const unsigned h1 = f32_to_f16_bits(x, false);
+            half[j] = pl == 0 ? h1 : f32_to_f16_bits(x - f16_bits_to_f32(h1), false);
+        }
+        dst[e] = half[0] | (half[1] << 16);
+    }
+}
+
 struct MelDecP {
     const float* blob;
     DecLayout lay;
@@ -210,16 +242,19 @@ __global__ __launch_bounds__(64 * NW, (DX2 <= 128 && NW == 8 ? ESMI_DEC_WPS : 2)
     constexpr int NS = (DX2 <= 128 && NW == 8) ? ESMI_DEC_NS : 4;   // column slices per workgroup
     constexpr int MH = NW / NS;             // row groups (1, 2 or 4)
     constexpr int MT = 4 / MH;              // 32-row MFMA tiles per wave (4, 2 or 1)
-    constexpr int TPR = kDecThreads / kDecRows;   // LayerNorm threads per row (2 or 4)
+    constexpr int TPR = 16;                       // LayerNorm threads per row: one DPP row, so the row statistics are DPP adds
+    constexpr int RPT = kDecRows * TPR / kDecThreads;   // rows per LayerNorm thread (4 or 8): the gain/shift vectors of its
+                                                  // channels are read from LDS once for all of them
     constexpr bool LOWREG = ESMI_DEC_LOWREG && DX2 <= 128;
     constexpr int NTW = DX2 / (32 * NS);    // 32-column MFMA tiles per wave
     constexpr int WCOLS = 32 * NTW;         // columns per wave
     constexpr int KCH = DX2 / 128;          // 128-channel K chunks of a dx2-wide contraction
     constexpr int LDSROW = DX2 + 4;
+    constexpr float WSI = ESMI_DEC_SPLIT == 2 ? kF16WScaleInv : 1.0f;   // the f16 planes hold 2^8 * W
     constexpr int PAD = KD / 2;
     constexpr int CG = DX2 / 4;             // 4-channel groups per row
     constexpr int RS = kDecRows / (kDecThreads / CG);  // rows per depthwise strip (8 or 16)
-    constexpr int NV = DX2 / (4 * TPR);     // float4 per LayerNorm thread
+    constexpr int NV = DX2 / (4 * TPR);     // float4 per LayerNorm thread and row (channels 4*c + 64*k, c = lane & 15)
     ESMI_DYN_LDS(lds);
     // per-layer small parameters in LDS: [taps KD*DX2 | dw_b] (group A: read by the depthwise phase) and
     // [pw_b | ln_g | ln_b | skip_g | skip_b] (group B: read by the tanh / LayerNorm phases).  Single buffer:
@@ -335,32 +370,41 @@ __global__ __launch_bounds__(64 * NW, (DX2 <= 128 && NW == 8 ? ESMI_DEC_WPS : 2)
     commit_A(0);
     __syncthreads();
 
-    // A-fragment base of this wave's rows; LayerNorm ownership: TPR threads per row, a row's threads 64/TPR lanes apart
-    constexpr int RPW = 64 / TPR;           // rows per wave in the LayerNorm pass (16 or 32)
-    const int ln_row = RPW * w + (lane & (RPW - 1)), ln_q = lane / RPW;
-    const bool ln_inside = src[ln_row] != -1;
+    // LayerNorm ownership: lane = 16*rg + c; the wave owns rows [4*RPT*w, +4*RPT), the thread rows ln_row0 + (0..RPT-1)
+    // and the float4 channel groups c + 16*k of each
+    const int ln_c = lane & 15, ln_row0 = 4 * RPT * w + RPT * (lane >> 4);
+    unsigned ln_inside = 0;                 // bit j: row ln_row0 + j exists in the reference (inside [0, L))
+#pragma unroll
+    for (int j = 0; j < RPT; ++j) ln_inside |= (src[ln_row0 + j] != -1 ? 1u : 0u) << j;
 
     f32x16 acc[MT][NTW];
-    f32x4 skip[NV];
+    f32x4 skip[RPT][NV];
 #pragma unroll
-    for (int v = 0; v < NV; ++v) skip[v] = zero4();
+    for (int j = 0; j < RPT; ++j) {
+#pragma unroll
+        for (int v = 0; v < NV; ++v) skip[j][v] = zero4();
+    }
 
     // weight-stationary GEMM pieces.  bf = this wave's weight slice for KSUB k-steps (64 VGPRs); it is
     // (re)loaded right after the previous K loop so the L2 latency hides under the non-MFMA phases.
     constexpr int KSUB = DX2 <= 128 ? ESMI_DEC_KSUB / NTW : 8;   // k-steps of weights in registers at a time (32 / 64 VGPRs)
-#if ESMI_DEC_BF16X3
-    // split-bf16 contraction (esmi_dev.h): per 16-channel step one A fragment (8 fp32 from the tile, split on the fly) against
-    // the three pre-split weight planes; KSUB/2 steps of weights (3 x 4 VGPRs each per tile) in registers at a time
+#if ESMI_DEC_SPLIT
+    // split contraction (esmi_dev.h): per 16-channel step one A fragment (8 fp32 from the tile, split on the fly) against the
+    // NPL pre-split weight planes; KSUB/2 steps of weights (NPL x 4 VGPRs each per tile) in registers at a time
     constexpr int KS16 = KSUB / 2;
-    u32x4 bf[NTW][KS16][3];
+    constexpr int NPL = ESMI_DEC_SPLIT == 1 ? 3 : 2;
+    u32x4 bf[NTW][KS16][NPL];
     auto load_b = [&](const f32x4* wsl, int k0) __attribute__((always_inline)) {
         const u32x4* w3 = reinterpret_cast<const u32x4*>(wsl);
+#ifdef ESMI_ABL_NOWLOAD
+        if (p.n_mel >= 0) return;
+#endif
 #pragma unroll
         for (int t = 0; t < NTW; ++t) {
 #pragma unroll
             for (int st = 0; st < KS16; ++st) {
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl) bf[t][st][pl] = w3[((t * 8 + (k0 >> 1) + st) * 3 + pl) * 64];
+                for (int pl = 0; pl < NPL; ++pl) bf[t][st][pl] = w3[((t * 8 + (k0 >> 1) + st) * NPL + pl) * 64];
             }
         }
     };
@@ -371,14 +415,33 @@ __global__ __launch_bounds__(64 * NW, (DX2 <= 128 && NW == 8 ? ESMI_DEC_WPS : 2)
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
                 const float* ap = a_base + 32 * mt * LDSROW + a_col0 + 8 * k0 + 16 * st;
+#if ESMI_DEC_SPLIT == 1
                 const bf16x3 a3 = split_bf16x3(*reinterpret_cast<const f32x4*>(ap), *reinterpret_cast<const f32x4*>(ap + 4));
 #pragma unroll
-                for (int t = 0; t < NTW; ++t) acc[mt][t] = mfma32_split(a3, bf[t][st][0], bf[t][st][1], bf[t][st][2], acc[mt][t]);
+                for (int t = 0; t < NTW; ++t) acc[mt][t] = mfma32_split_wx(bf[t][st][0], bf[t][st][1], bf[t][st][2], a3, acc[mt][t]);
+#else
+#if defined(ESMI_ABL_NOSPLIT)
+                f16x2p a2;
+                a2.h1 = __builtin_bit_cast(u32x4, *reinterpret_cast<const f32x4*>(ap));
+                a2.h2 = __builtin_bit_cast(u32x4, *reinterpret_cast<const f32x4*>(ap + 4));
+#elif defined(ESMI_ABL_NOAREAD)
+                f16x2p a2;
+                a2.h1 = u32x4{(unsigned)st, (unsigned)mt, (unsigned)lane, 3u};
+                a2.h2 = a2.h1;
+#else
+                const f16x2p a2 = split_f16x2(*reinterpret_cast<const f32x4*>(ap), *reinterpret_cast<const f32x4*>(ap + 4));
+#endif
+#ifdef ESMI_ABL_NOMFMA
+                if (p.n_mel >= 0) { acc[mt][0][0] += __builtin_bit_cast(float, a2.h1[0] ^ a2.h1[1] ^ a2.h1[2] ^ a2.h1[3] ^ a2.h2[0] ^ a2.h2[1] ^ a2.h2[2] ^ a2.h2[3]); continue; }
+#endif
+#pragma unroll
+                for (int t = 0; t < NTW; ++t) acc[mt][t] = mfma32_split2_wx(bf[t][st][0], bf[t][st][1], a2, acc[mt][t]);
+#endif
             }
         }
     };
-    // slice pointer of chunk c of the matrix at float offset `off` (planes: 8 steps x 3 planes x 64 lanes x 16 B per tile)
-    auto wslice = [&](long off, int c) __attribute__((always_inline)) { return blob4 + (off >> 2) + (long)(c * (DX2 / 32) + ns * NTW) * 8 * 3 * 64 + lane; };
+    // slice pointer of chunk c of the matrix at float offset `off` (planes: 8 steps x NPL planes x 64 lanes x 16 B per tile)
+    auto wslice = [&](long off, int c) __attribute__((always_inline)) { return blob4 + (off >> 2) + (long)(c * (DX2 / 32) + ns * NTW) * 8 * NPL * 64 + lane; };
 #else
     f32x4 bf[NTW][KSUB];
     auto load_b = [&](const f32x4* wsl, int k0) __attribute__((always_inline)) {
@@ -398,7 +461,7 @@ __global__ __launch_bounds__(64 * NW, (DX2 <= 128 && NW == 8 ? ESMI_DEC_WPS : 2)
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
 #pragma unroll
-                    for (int t = 0; t < NTW; ++t) acc[mt][t] = mfma32(av[s], bf[t][kc][s], acc[mt][t]);
+                    for (int t = 0; t < NTW; ++t) acc[mt][t] = mfma32(bf[t][kc][s], av[s], acc[mt][t]);
                 }
             }
         }
@@ -425,30 +488,35 @@ __global__ __launch_bounds__(64 * NW, (DX2 <= 128 && NW == 8 ? ESMI_DEC_WPS : 2)
             for (int t = 0; t < NTW; ++t) acc[mt][t] = zero16();
         }
     };
-    // accumulators (+ bias, tanh) -> tile, in the MFMA C/D layout
+    // accumulators (+ bias, tanh) -> tile.  The products are computed TRANSPOSED (weights as the first MFMA operand): lane
+    // (i, h) holds frame i of the tile and, per register quad g = r >> 2, the four consecutive channels 8g + 4h .. + 3 --
+    // one ds_write_b128 per quad instead of four ds_write_b32 (and float4 global stores for the mel rows).
     auto store_tanh = [&](const float* bias) __attribute__((always_inline)) {
-        // one base address per column tile; every (mt, r) store is base + a compile-time offset, so the
-        // compiler has no per-store address to hoist out of the layer loop (32 loop-invariant VGPRs otherwise)
 #pragma unroll
         for (int t = 0; t < NTW; ++t) {
-            const int col = ns * WCOLS + 32 * t + i;
-            const float bc = bias[col];
-            float* base = xs + opaque_i((kDecPadRows + 32 * MT * mh + 4 * h) * LDSROW + col);
+            const int col = ns * WCOLS + 32 * t + 4 * h;
+            const float* bp = bias + opaque_i(col);
+            float* base = xs + opaque_i((kDecPadRows + 32 * MT * mh + i) * LDSROW + col);
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 bc = *reinterpret_cast<const f32x4*>(bp + 8 * g);
 #pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    base[(32 * mt + (r & 3) + 8 * (r >> 2)) * LDSROW] = ESMI_DEC_TANH(acc[mt][t][r] + bc);
+                for (int mt = 0; mt < MT; ++mt) {
+                    f32x4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = ESMI_DEC_TANH(fmaf(acc[mt][t][4 * g + e], WSI, bc[e]));
+                    *reinterpret_cast<f32x4*>(base + 32 * mt * LDSROW + 8 * g) = v;
+                }
             }
         }
     };
-    // LayerNorm of this thread's quarter row held in v[] (two-pass; 4 threads per row: xor 16, 32)
-    auto ln_regs = [&](f32x4 (&v)[NV], const float* g, const float* be) {
+    // LayerNorm of one row: this thread's NV float4 of it in v[], gain / shift of the same channels in g[] / be[]
+    // (two-pass; 16 threads per row)
+    auto ln_regs = [&](f32x4 (&v)[NV], const f32x4 (&g)[NV], const f32x4 (&be)[NV]) __attribute__((always_inline)) {
         float s = 0.0f;
 #pragma unroll
         for (int k = 0; k < NV; ++k) s += (v[k][0] + v[k][1]) + (v[k][2] + v[k][3]);
-        if (TPR == 4) s += swz_xor16_f(s);
-        s += swap32_f(s);
+        s = row_sum16(s);
         const float mean = s * (1.0f / DX2);
         float q = 0.0f;
 #pragma unroll
@@ -459,40 +527,53 @@ __global__ __launch_bounds__(64 * NW, (DX2 <= 128 && NW == 8 ? ESMI_DEC_WPS : 2)
                 q = fmaf(d, d, q);
             }
         }
-        if (TPR == 4) q += swz_xor16_f(q);
-        q += swap32_f(q);
+        q = row_sum16(q);
         const float rstd = 1.0f / sqrtf(q * (1.0f / DX2) + 1e-5f);
 #pragma unroll
         for (int k = 0; k < NV; ++k) {
-            const f32x4 gg = *reinterpret_cast<const f32x4*>(g + 4 * TPR * k);
-            const f32x4 bb = *reinterpret_cast<const f32x4*>(be + 4 * TPR * k);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[k][e] = fmaf((v[k][e] - mean) * rstd, gg[e], bb[e]);
+            for (int e = 0; e < 4; ++e) v[k][e] = fmaf((v[k][e] - mean) * rstd, g[k][e], be[k][e]);
         }
+    };
+    auto ln_params = [&](const float* pv, f32x4 (&o)[NV]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int k = 0; k < NV; ++k) o[k] = *reinterpret_cast<const f32x4*>(pv + 64 * k);
     };
     // LN pass over the tile (in place): x = LN(x) [; x = LN_s(x + skip)] ; outside rows -> 0 ; skip update
     auto ln_pass = [&](const float* pb0, bool block_end, bool set_skip) __attribute__((always_inline)) {
-        const float* pb = pb0 + opaque_i(4 * ln_q);           // this thread's column quarter of every param vector
-        float* ln_ptr = xs + opaque_i((kDecPadRows + ln_row) * LDSROW + 4 * ln_q);
-        f32x4 v[NV];
+        const float* pb = pb0 + opaque_i(4 * ln_c);           // this thread's channels of every param vector
+        float* ln_ptr = xs + opaque_i((kDecPadRows + ln_row0) * LDSROW + 4 * ln_c);
+        f32x4 g[NV], be[NV];
+        ln_params(pb + P_G, g);
+        ln_params(pb + P_B, be);
+        f32x4 v[RPT][NV];
 #pragma unroll
-        for (int k = 0; k < NV; ++k) v[k] = *reinterpret_cast<const f32x4*>(ln_ptr + 4 * TPR * k);
+        for (int j = 0; j < RPT; ++j) {
+#pragma unroll
+            for (int k = 0; k < NV; ++k) v[j][k] = *reinterpret_cast<const f32x4*>(ln_ptr + j * LDSROW + 64 * k);
+        }
 #ifndef ESMI_ABL_NO_LN
-        ln_regs(v, pb + P_G, pb + P_B);
-        if (block_end) {  // end of a decoder block: skip = LN_s(x + skip), networks.py:299
 #pragma unroll
-            for (int k = 0; k < NV; ++k) v[k] += skip[k];
-            ln_regs(v, pb + P_SG, pb + P_SB);
+        for (int j = 0; j < RPT; ++j) ln_regs(v[j], g, be);
+        if (block_end) {  // end of a decoder block: skip = LN_s(x + skip), networks.py:299
+            ln_params(pb + P_SG, g);
+            ln_params(pb + P_SB, be);
+#pragma unroll
+            for (int j = 0; j < RPT; ++j) {
+#pragma unroll
+                for (int k = 0; k < NV; ++k) v[j][k] += skip[j][k];
+                ln_regs(v[j], g, be);
+            }
         }
 #endif
 #pragma unroll
-        for (int k = 0; k < NV; ++k) {
-            if (!ln_inside) v[k] = zero4();
-            *reinterpret_cast<f32x4*>(ln_ptr + 4 * TPR * k) = v[k];
-        }
-        if (set_skip) {
+        for (int j = 0; j < RPT; ++j) {
 #pragma unroll
-            for (int k = 0; k < NV; ++k) skip[k] = v[k];
+            for (int k = 0; k < NV; ++k) {
+                if (!((ln_inside >> j) & 1u)) v[j][k] = zero4();
+                *reinterpret_cast<f32x4*>(ln_ptr + j * LDSROW + 64 * k) = v[j][k];
+                if (set_skip) skip[j][k] = v[j][k];
+            }
         }
     };
 
@@ -517,25 +598,33 @@ __global__ __launch_bounds__(64 * NW, (DX2 <= 128 && NW == 8 ? ESMI_DEC_WPS : 2)
         issue_B(0);
         __syncthreads();
         {   // row owners: LayerNorm only for the padding frames' rows; skip = the stage's output
-            const float* pb = pbuf + opaque_i(4 * ln_q);
-            float* ln_ptr = xs + opaque_i((kDecPadRows + ln_row) * LDSROW + 4 * ln_q);
-            f32x4 v[NV];
+            const float* pb = pbuf + opaque_i(4 * ln_c);
+            float* ln_ptr = xs + opaque_i((kDecPadRows + ln_row0) * LDSROW + 4 * ln_c);
 #pragma unroll
-            for (int k = 0; k < NV; ++k) v[k] = *reinterpret_cast<const f32x4*>(ln_ptr + 4 * TPR * k);
-            const bool pad_row = src[ln_row] == -2;
-            if (ballot64(pad_row) != 0ull) {   // wave-uniform: the row reductions inside are wave-level exchanges
-                f32x4 u[NV];
+            for (int j = 0; j < RPT; ++j) {
 #pragma unroll
-                for (int k = 0; k < NV; ++k) u[k] = v[k];
-                ln_regs(u, pb + P_G, pb + P_B);
+                for (int k = 0; k < NV; ++k) skip[j][k] = *reinterpret_cast<const f32x4*>(ln_ptr + j * LDSROW + 64 * k);
+            }
+            unsigned pad_rows = 0;
 #pragma unroll
-                for (int k = 0; k < NV; ++k) {
-                    if (pad_row) v[k] = u[k];
-                    *reinterpret_cast<f32x4*>(ln_ptr + 4 * TPR * k) = v[k];
+            for (int j = 0; j < RPT; ++j) pad_rows |= (src[ln_row0 + j] == -2 ? 1u : 0u) << j;
+            if (ballot64(pad_rows != 0u) != 0ull) {   // wave-uniform: the row reductions inside are wave-level exchanges
+                f32x4 g[NV], be[NV];
+                ln_params(pb + P_G, g);
+                ln_params(pb + P_B, be);
+#pragma unroll
+                for (int j = 0; j < RPT; ++j) {
+                    f32x4 u[NV];
+#pragma unroll
+                    for (int k = 0; k < NV; ++k) u[k] = skip[j][k];
+                    ln_regs(u, g, be);
+#pragma unroll
+                    for (int k = 0; k < NV; ++k) {
+                        if ((pad_rows >> j) & 1u) skip[j][k] = u[k];
+                        *reinterpret_cast<f32x4*>(ln_ptr + j * LDSROW + 64 * k) = skip[j][k];
+                    }
                 }
             }
-#pragma unroll
-            for (int k = 0; k < NV; ++k) skip[k] = v[k];
         }
         __syncthreads();
     } else {
@@ -643,18 +732,30 @@ __global__ __launch_bounds__(64 * NW, (DX2 <= 128 && NW == 8 ? ESMI_DEC_WPS : 2)
         zero_acc();
         gemm_dx2(p.lay.mel_w, nullptr);
         const float* mb = pbuf + P_PWB;
+        const bool vec_ok = (p.n_mel & 3) == 0;      // rows of 16-byte multiples: float4 stores
 #pragma unroll
         for (int t = 0; t < NTW; ++t) {
-            const int col = ns * WCOLS + 32 * t + i;
-            if (col >= p.n_mel) continue;
-            const float bc = mb[col];
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
+                const int f = f0 + 32 * MT * mh + 32 * mt + i;
+                if (f < f_lo || f >= out_hi) continue;
+                float* orow = p.mel + ((long)b * p.L_out + f) * p.n_mel;
+                const bool live = f < valid_end;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int f = f0 + 32 * MT * mh + 32 * mt + tile_row(r, lane);
-                    if (f < f_lo || f >= out_hi) continue;
-                    p.mel[((long)b * p.L_out + f) * p.n_mel + col] = f < valid_end ? acc[mt][t][r] + bc : 0.0f;
+                for (int g = 0; g < 4; ++g) {
+                    const int col = ns * WCOLS + 32 * t + 8 * g + 4 * h;
+                    if (col >= p.n_mel) continue;
+                    const f32x4 bc = *reinterpret_cast<const f32x4*>(mb + col);
+                    f32x4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = live ? fmaf(acc[mt][t][4 * g + e], WSI, bc[e]) : 0.0f;
+                    if (vec_ok) {
+                        *reinterpret_cast<f32x4*>(orow + col) = v;
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (col + e < p.n_mel) orow[col + e] = v[e];
+                    }
                 }
             }
         }

@@ -319,7 +319,7 @@ def test_large_batch_uses_other_kernels(nets):
 
 
 def test_exact_fp32_mfma_build():
-    """The alternative build (mel-decoder contractions on v_mfma_f32_32x32x2_f32 instead of split-bf16 products) is the same
+    """The alternative build (mel-decoder contractions on v_mfma_f32_32x32x2_f32 instead of split 16-bit products) is the same
     ABI; run two golden fixtures and the smoke check through it in a fresh interpreter (ESMI_LIB selects the library)."""
     import subprocess
     import sys

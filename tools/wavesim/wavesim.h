@@ -111,6 +111,32 @@ static inline ws_f32x16 mfma_32x32x16_bf16(const V4& a, const V4& b, ws_f32x16 c
     return d;
 }
 
+// v_mfma_f32_32x32x16_f16: the same operand layout with binary16 elements
+static inline float ws_half_to_float(uint32_t h) {
+    const uint32_t sign = (h & 0x8000u) << 16, e = (h >> 10) & 31u, m = h & 0x3FFu;
+    if (e == 31u) return u2f(sign | 0x7F800000u | (m << 13));
+    if (e == 0u) { const float v = (float)m * 5.9604644775390625e-08f; return (h & 0x8000u) ? -v : v; }
+    return u2f(sign | ((e + 112u) << 23) | (m << 13));
+}
+template <class V4>
+static inline ws_f32x16 mfma_32x32x16_f16(const V4& a, const V4& b, ws_f32x16 c) {
+    uint32_t w[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    const uint32_t* t = wave_exchange(w, 8);
+    const int l = lane_id();
+    auto elem = [&](int lane, int base, int k) {
+        const uint32_t d = t[lane * 8 + base + (k >> 1)];
+        return ws_half_to_float((k & 1) ? (d >> 16) : (d & 0xFFFFu));
+    };
+    ws_f32x16 d = c;
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), col = l & 31;
+        float acc = c[r];
+        for (int k = 0; k < 16; ++k) acc = fmaf(elem(row + 32 * (k >> 3), 0, k & 7), elem(col + 32 * (k >> 3), 4, k & 7), acc);
+        d[r] = acc;
+    }
+    return d;
+}
+
 static inline ws_f32x4 mfma_16x16x4(float a, float b, ws_f32x4 c) {
     uint32_t w[2] = {f2u(a), f2u(b)};
     const uint32_t* t = wave_exchange(w, 2);
