@@ -132,22 +132,28 @@ __host__ __device__ inline float f16_bits_to_f32(unsigned h) {
     }
     return __builtin_bit_cast(float, sign | ((e + 112u) << 23) | (m << 13));
 }
+__device__ __forceinline__ void split_f16_pair(float a, float b, unsigned& h1, unsigned& h2) {   // {b, a} pieces, a in the low half
+#ifdef ESMI_WAVESIM
+    const unsigned ha = f32_to_f16_bits(a, true), hb = f32_to_f16_bits(b, true);
+    const float ra = a - f16_bits_to_f32(ha), rb = b - f16_bits_to_f32(hb);
+    h1 = ha | (hb << 16);
+    h2 = f32_to_f16_bits(ra, true) | (f32_to_f16_bits(rb, true) << 16);
+#else
+    const auto h = __builtin_amdgcn_cvt_pkrtz(a, b);            // v_cvt_pkrtz_f16_f32
+    const float ra = a - (float)h[0], rb = b - (float)h[1];     // exact
+    h1 = __builtin_bit_cast(unsigned, h);
+    h2 = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(ra, rb));
+#endif
+}
 __device__ __forceinline__ f16x2p split_f16x2(const f32x4& x0, const f32x4& x1) {   // 8 consecutive k of one row
     f16x2p o;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const float a = j < 2 ? x0[2 * j] : x1[2 * j - 4], b = j < 2 ? x0[2 * j + 1] : x1[2 * j - 3];
-#ifdef ESMI_WAVESIM
-        const unsigned ha = f32_to_f16_bits(a, true), hb = f32_to_f16_bits(b, true);
-        const float ra = a - f16_bits_to_f32(ha), rb = b - f16_bits_to_f32(hb);
-        o.h1[j] = ha | (hb << 16);
-        o.h2[j] = f32_to_f16_bits(ra, true) | (f32_to_f16_bits(rb, true) << 16);
-#else
-        const auto h = __builtin_amdgcn_cvt_pkrtz(a, b);            // v_cvt_pkrtz_f16_f32
-        const float ra = a - (float)h[0], rb = b - (float)h[1];     // exact
-        o.h1[j] = __builtin_bit_cast(unsigned, h);
-        o.h2[j] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(ra, rb));
-#endif
+        unsigned h1, h2;
+        split_f16_pair(a, b, h1, h2);
+        o.h1[j] = h1;
+        o.h2[j] = h2;
     }
     return o;
 }

@@ -53,6 +53,13 @@
 //      traffic per launch in the PMC counters -- profiles/r01_e_pmc_counters.json)
 // Two co-resident workgroups hide part of each other's non-MFMA phases; the gain is small because the resident
 // partner's K loop starves the other's LayerNorm phase (phase traces: 3k -> 11-19k cycles).
+#ifndef ESMI_DEC_RSQRT
+#define ESMI_DEC_RSQRT rsqrt_fast_f32   // v_rsq_f32 (1 ulp); every LayerNorm thread computes it for 4 rows
+#endif
+#ifndef ESMI_DEC_PRESPLIT
+#define ESMI_DEC_PRESPLIT 1   // split-f16x2 only: the depthwise phase writes its output rows as the two f16 planes (same bytes as
+                              // fp32, in place), so the K loop's A fragments need no conversion (4 waves read every element)
+#endif
 #ifndef ESMI_DEC_WPS
 #define ESMI_DEC_WPS 4      // __launch_bounds__ waves/SIMD (512-thread workgroups: 2 -> 256 VGPRs, 4 -> 128 VGPRs)
 #endif
@@ -442,6 +449,28 @@ __global__ __launch_bounds__(64 * NW, (DX2 <= 128 && NW == 8 ? ESMI_DEC_WPS : 2)
     };
     // slice pointer of chunk c of the matrix at float offset `off` (planes: 8 steps x NPL planes x 64 lanes x 16 B per tile)
     auto wslice = [&](long off, int c) __attribute__((always_inline)) { return blob4 + (off >> 2) + (long)(c * (DX2 / 32) + ns * NTW) * 8 * NPL * 64 + lane; };
+#if ESMI_DEC_SPLIT == 2 && ESMI_DEC_PRESPLIT
+    // the same with the A rows already stored as planes by the depthwise phase: row = [DX2 halves h1 | DX2 halves h2 | pad]
+    auto mma_sub_pre = [&](int a_col0, int k0) __attribute__((always_inline)) {
+        const unsigned* a_base = reinterpret_cast<const unsigned*>(xs) + opaque_i((kDecPadRows + 32 * MT * mh + i) * LDSROW + 4 * h);
+#pragma unroll
+        for (int st = 0; st < KS16; ++st) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const unsigned* ap = a_base + 32 * mt * LDSROW + (a_col0 >> 1) + 4 * k0 + 8 * st;
+                f16x2p a2;
+                a2.h1 = *reinterpret_cast<const u32x4*>(ap);
+                a2.h2 = *reinterpret_cast<const u32x4*>(ap + DX2 / 2);
+#pragma unroll
+                for (int t = 0; t < NTW; ++t) acc[mt][t] = mfma32_split2_wx(bf[t][st][0], bf[t][st][1], a2, acc[mt][t]);
+            }
+        }
+    };
+    constexpr bool PRESPLIT = true;
+#else
+    auto mma_sub_pre = [&](int, int) __attribute__((always_inline)) {};
+    constexpr bool PRESPLIT = false;
+#endif
 #else
     f32x4 bf[NTW][KSUB];
     auto load_b = [&](const f32x4* wsl, int k0) __attribute__((always_inline)) {
@@ -466,17 +495,20 @@ __global__ __launch_bounds__(64 * NW, (DX2 <= 128 && NW == 8 ? ESMI_DEC_WPS : 2)
             }
         }
     };
+    auto mma_sub_pre = [&](int, int) __attribute__((always_inline)) {};
+    constexpr bool PRESPLIT = false;
     // slice pointer of chunk c of the matrix at float offset `off`
     auto wslice = [&](long off, int c) __attribute__((always_inline)) { return blob4 + (off >> 2) + (long)(c * (DX2 / 32) + ns * NTW) * 16 * 64 + lane; };
 #endif
     // full dx2-wide contraction with the first sub-slice already in bf; leaves `next`'s first sub-slice in bf
-    auto gemm_dx2 = [&](long off, const f32x4* next) __attribute__((always_inline)) {
+    auto gemm_dx2 = [&](long off, const f32x4* next, bool pre) __attribute__((always_inline)) {
 #pragma unroll
         for (int c = 0; c < KCH; ++c) {
 #pragma unroll
             for (int k0 = 0; k0 < 16; k0 += KSUB) {
                 if (LOWREG || c > 0 || k0 > 0) load_b(wslice(off, c), k0);
-                mma_sub(128 * c, k0);
+                if (pre) mma_sub_pre(128 * c, k0);
+                else mma_sub(128 * c, k0);
             }
         }
         if (next && !LOWREG) load_b(next, 0);
@@ -528,7 +560,7 @@ __global__ __launch_bounds__(64 * NW, (DX2 <= 128 && NW == 8 ? ESMI_DEC_WPS : 2)
             }
         }
         q = row_sum16(q);
-        const float rstd = 1.0f / sqrtf(q * (1.0f / DX2) + 1e-5f);
+        const float rstd = ESMI_DEC_RSQRT(q * (1.0f / DX2) + 1e-5f);
 #pragma unroll
         for (int k = 0; k < NV; ++k) {
 #pragma unroll
@@ -669,6 +701,7 @@ __global__ __launch_bounds__(64 * NW, (DX2 <= 128 && NW == 8 ? ESMI_DEC_WPS : 2)
             f32x4 win[RS + 2 * PAD];
             float* col = xs + opaque_i((kDecPadRows + dw_r0 - PAD) * LDSROW + 4 * dw_cg);
             const float* pbt = pb + opaque_i(4 * dw_cg);
+            unsigned* prow = reinterpret_cast<unsigned*>(xs) + opaque_i((kDecPadRows + dw_r0) * LDSROW + 2 * dw_cg);
 #pragma unroll
             for (int r = 0; r < RS + 2 * PAD; ++r) win[r] = *reinterpret_cast<const f32x4*>(col + r * LDSROW);
             f32x4 tap[KD];
@@ -692,7 +725,17 @@ __global__ __launch_bounds__(64 * NW, (DX2 <= 128 && NW == 8 ? ESMI_DEC_WPS : 2)
 #pragma unroll
                     for (int e = 0; e < 4; ++e) a[e] = fmaf(win[r + j][e], tj[e], a[e]);
                 }
-                *reinterpret_cast<f32x4*>(col + (r + PAD) * LDSROW) = a;
+                if (PRESPLIT) {   // the K loop's A operand, already split (esmi_dev.h): 4 channels = 2 dwords per plane
+                    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+                    unsigned h1a, h2a, h1b, h2b;
+                    split_f16_pair(a[0], a[1], h1a, h2a);
+                    split_f16_pair(a[2], a[3], h1b, h2b);
+                    unsigned* rowp = prow + r * LDSROW;
+                    *reinterpret_cast<u32x2*>(rowp) = u32x2{h1a, h1b};
+                    *reinterpret_cast<u32x2*>(rowp + DX2 / 2) = u32x2{h2a, h2b};
+                } else {
+                    *reinterpret_cast<f32x4*>(col + (r + PAD) * LDSROW) = a;
+                }
             }
         }
         commit_B(l);                         // this layer's bias / LN params (issued during the previous layer)
@@ -704,7 +747,7 @@ __global__ __launch_bounds__(64 * NW, (DX2 <= 128 && NW == 8 ? ESMI_DEC_WPS : 2)
         ESMI_PRIO(0);
         zero_acc();
         gemm_dx2(lbase + p.lay.l_pw, l + 1 < n_layers ? wslice(lbase + p.lay.layer_stride + p.lay.l_pw, 0)
-                                                      : wslice(p.lay.mel_w, 0));
+                                                      : wslice(p.lay.mel_w, 0), PRESPLIT);
         ESMI_STAMP();   // 5: K loop issued
         ESMI_PRIO(ESMI_DEC_CHAIN_PRIO);
         __syncthreads();  // all reads of the filtered tile done
@@ -730,7 +773,7 @@ __global__ __launch_bounds__(64 * NW, (DX2 <= 128 && NW == 8 ? ESMI_DEC_WPS : 2)
     __syncthreads();
     if (ns * WCOLS < p.n_mel) {   // wave-uniform: column slices beyond n_mel have nothing to do
         zero_acc();
-        gemm_dx2(p.lay.mel_w, nullptr);
+        gemm_dx2(p.lay.mel_w, nullptr, false);
         const float* mb = pbuf + P_PWB;
         const bool vec_ok = (p.n_mel & 3) == 0;      // rows of 16-byte multiples: float4 stores
 #pragma unroll
