@@ -193,7 +193,7 @@ def main():
     kernel_flops = flops - (2 * cfg.d4 * cfg.dx2 if head_moved else 0)
     from efficientspeech_amd import _lib as _esmi_lib
     build_cfg = _esmi_lib.load().esmi_build_config().decode()
-    split = {"dec_gemm=split-bf16x3": 6, "dec_gemm=split-f16x2": 3}.get(build_cfg, 0)    # low-precision MFMA products per fp32 product
+    split = {"dec_gemm=split-bf16x3": 6, "dec_gemm=split-f16x2": 3}.get(build_cfg.split(",")[0], 0)    # low-precision MFMA products per fp32 product
     split_txt = {6: "fp32 operands split exactly into 3 bf16, 6 bf16-MFMA products, fp32 accumulate",
                  3: "fp32 operands split into 2 f16 pieces (22 significand bits, weights pre-scaled 2^8), 3 f16-MFMA products, fp32 accumulate",
                  0: ""}[split]

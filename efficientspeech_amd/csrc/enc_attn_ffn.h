@@ -267,7 +267,13 @@ __device__ __forceinline__ void enc_attn_ffn_body(const EncAttnFfnP& p) {
         lds_wave_sync();        // the previous head's proj has finished reading the tile
         tile_store<NC>(buf, LD, 0, o, lane);
         lds_wave_sync();
-        wave_gemm_k<NC, NC>(y, gp, a_row, true, p.proj_w, NC, (hd * C) >> 3, 0, lane);
+        {   // this head's slice of the projection, added to the heads before it (a GEMM starts from zero: wave_acc_join)
+            f32x16 yh[NC];
+            zero_tiles<NC>(yh);
+            wave_gemm_k<NC, NC>(yh, gp, a_row, true, p.proj_w, NC, (hd * C) >> 3, 0, lane);
+#pragma unroll
+            for (int nt = 0; nt < NC; ++nt) y[nt] += yh[nt];
+        }
         if (hd + 1 < p.h) wave_prefetch<NC>(gp, p.proj_w, NC, ((hd + 1) * C) >> 3, 0, lane);
     }
     WaveGrp<NE> gm;                 // mlp1 weights

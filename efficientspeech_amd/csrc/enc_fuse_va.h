@@ -272,6 +272,20 @@ __device__ __forceinline__ void enc_fuse_va_body(const FuseVaP& p) {
         }
     };
     auto tri_mma = [&](f32x16 (&acc)[3][ND], const TriGrp& gq, bool shared_a) __attribute__((always_inline)) {
+#if ESMI_CHAIN_SPLIT
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {      // split-f16x2: see wave_grp_mma
+            f16x2p a2 = split_f16x2(gq.a[0][2 * st], gq.a[0][2 * st + 1]);
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                if (q > 0 && !shared_a) a2 = split_f16x2(gq.a[q][2 * st], gq.a[q][2 * st + 1]);
+#pragma unroll
+                for (int nt = 0; nt < ND; ++nt)
+                    acc[q][nt] = mfma32_split2(a2, __builtin_bit_cast(u32x4, gq.b[q][2 * st][nt]),
+                                               __builtin_bit_cast(u32x4, gq.b[q][2 * st + 1][nt]), acc[q][nt]);
+            }
+        }
+#else
 #pragma unroll
         for (int kq = 0; kq < 4; ++kq) {
 #pragma unroll
@@ -284,6 +298,7 @@ __device__ __forceinline__ void enc_fuse_va_body(const FuseVaP& p) {
                 }
             }
         }
+#endif
     };
     auto tri_conv = [&](f32x16 (&acc)[3][ND], const float* row, int ldrow, int a_qstride, const float* const (&wq)[3])
         __attribute__((always_inline)) {
@@ -302,6 +317,13 @@ __device__ __forceinline__ void enc_fuse_va_body(const FuseVaP& p) {
             else tri_mma(acc, ga, a_qstride == 0);
             sched_fence();
         }
+#if ESMI_CHAIN_SPLIT
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {   // acc was zero at the start (both call sites): take the weights' 2^8 out
+#pragma unroll
+            for (int nt = 0; nt < ND; ++nt) acc[q][nt] *= kF16WScaleInv;
+        }
+#endif
     };
 
     f32x16 c[3][ND];

@@ -253,12 +253,17 @@ const char* esmi_backend(void) {
 }
 
 const char* esmi_build_config(void) {
-#if ESMI_DEC_SPLIT == 2
-    return "dec_gemm=split-f16x2";
-#elif ESMI_DEC_SPLIT == 1
-    return "dec_gemm=split-bf16x3";
+#if ESMI_CHAIN_SPLIT
+#define ESMI_CFG_ENC_ ",enc_gemm=split-f16x2"
 #else
-    return "dec_gemm=fp32-mfma";
+#define ESMI_CFG_ENC_ ",enc_gemm=fp32-mfma"
+#endif
+#if ESMI_DEC_SPLIT == 2
+    return "dec_gemm=split-f16x2" ESMI_CFG_ENC_;
+#elif ESMI_DEC_SPLIT == 1
+    return "dec_gemm=split-bf16x3" ESMI_CFG_ENC_;
+#else
+    return "dec_gemm=fp32-mfma" ESMI_CFG_ENC_;
 #endif
 }
 

@@ -106,6 +106,9 @@ __device__ __forceinline__ f32x16 mfma32_split_wx(const u32x4& bh, const u32x4& 
 // |w| < 255 (2^8 scale keeps the second piece of weights down to 5e-4 a normal number; smaller ones lose nothing that
 // matters: absolute error < 2.4e-10 per weight).  Layout as for v_mfma_f32_32x32x16_bf16.
 struct f16x2p { u32x4 h1, h2; };
+#ifndef ESMI_CHAIN_SPLIT
+#define ESMI_CHAIN_SPLIT 1   // weight GEMMs of the encoder-side chain kernels: 1 = split-f16x2 (3 f16 MFMAs per 16 channels), 0 = fp32 MFMA
+#endif
 constexpr float kF16WScale = 256.0f, kF16WScaleInv = 1.0f / 256.0f;
 __host__ __device__ inline unsigned f32_to_f16_bits(float f, bool rtz) {     // software conversion (packers, simulator)
     const unsigned u = __builtin_bit_cast(unsigned, f), sign = (u >> 16) & 0x8000u, a = u & 0x7FFFFFFFu;

@@ -56,6 +56,9 @@
 #ifndef ESMI_DEC_RSQRT
 #define ESMI_DEC_RSQRT rsqrt_fast_f32   // v_rsq_f32 (1 ulp); every LayerNorm thread computes it for 4 rows
 #endif
+#ifndef ESMI_DEC_TAPS_IN_REGS
+#define ESMI_DEC_TAPS_IN_REGS 1
+#endif
 #ifndef ESMI_DEC_PRESPLIT
 #define ESMI_DEC_PRESPLIT 1   // split-f16x2 only: the depthwise phase writes its output rows as the two f16 planes (same bytes as
                               // fp32, in place), so the K loop's A fragments need no conversion (4 waves read every element)
@@ -67,7 +70,7 @@
 #define ESMI_DEC_LOWREG 1   // 1: no cross-phase prefetch (weights, taps, params fetched where used): fewer live registers
 #endif
 #ifndef ESMI_DEC_CHAIN_PRIO
-#define ESMI_DEC_CHAIN_PRIO 1   // wave priority during the non-MFMA phases (measured +1 % with two workgroups per CU)
+#define ESMI_DEC_CHAIN_PRIO 0   // wave priority during the non-MFMA phases (exact-fp32 build: +1 % with two workgroups per CU; split-f16 build: -1 %)
 #endif
 #if defined(ESMI_WAVESIM)
 #define ESMI_PRIO(n) do {} while (0)
@@ -306,7 +309,7 @@ __global__ __launch_bounds__(64 * NW, (DX2 <= 128 && NW == 8 ? ESMI_DEC_WPS : 2)
     const f32x4* blob4 = reinterpret_cast<const f32x4*>(p.blob);
 #ifdef ESMI_DEC_TRACE
     int tr_n = 0;
-    const bool tr_on = p.trace && tile == 1 && b == 0 && lane == 0;
+    const bool tr_on = p.trace && tile == 3 && b == p.B / 2 + 5 && lane == 0;
 #define ESMI_STAMP() do { if (tr_on) p.trace[w * 64 + tr_n] = (long long)__builtin_amdgcn_s_memtime(); ++tr_n; } while (0)
 #else
 #define ESMI_STAMP() do {} while (0)
@@ -704,8 +707,8 @@ __global__ __launch_bounds__(64 * NW, (DX2 <= 128 && NW == 8 ? ESMI_DEC_WPS : 2)
             unsigned* prow = reinterpret_cast<unsigned*>(xs) + opaque_i((kDecPadRows + dw_r0) * LDSROW + 2 * dw_cg);
 #pragma unroll
             for (int r = 0; r < RS + 2 * PAD; ++r) win[r] = *reinterpret_cast<const f32x4*>(col + r * LDSROW);
-            f32x4 tap[KD];
-            if (!LOWREG) {
+            f32x4 tap[KD];       // in registers for all RS rows: re-reading them per row cost 8 x KD ds_read_b128 per thread
+            if (ESMI_DEC_TAPS_IN_REGS) {
 #pragma unroll
                 for (int j = 0; j < KD; ++j) tap[j] = *reinterpret_cast<const f32x4*>(pbt + j * DX2);
             }
@@ -721,7 +724,7 @@ __global__ __launch_bounds__(64 * NW, (DX2 <= 128 && NW == 8 ? ESMI_DEC_WPS : 2)
 #ifdef ESMI_ABL_NO_DW
                     if (j != PAD) continue;
 #endif
-                    const f32x4 tj = LOWREG ? *reinterpret_cast<const f32x4*>(pbt + j * DX2) : tap[j];
+                    const f32x4 tj = ESMI_DEC_TAPS_IN_REGS ? tap[j] : *reinterpret_cast<const f32x4*>(pbt + j * DX2);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) a[e] = fmaf(win[r + j][e], tj[e], a[e]);
                 }

@@ -32,8 +32,24 @@ __global__ void pack_bfrag_kernel(const float* __restrict__ src, float* __restri
         const int nt = (int)((f >> 8) % NT);
         const int kc = (int)((f >> 8) / NT);
         const int row = 32 * nt + (lane & 31);
+#if ESMI_CHAIN_SPLIT
+        // split-f16x2 operands (esmi_dev.h): within a group of four k-steps (32 channels) the four 1 KiB slots hold
+        // {step 0 piece 1, step 0 piece 2, step 1 piece 1, step 1 piece 2}; a lane's 8 k-slots of 16-channel step st are
+        // the channels 16*st + 4*(lane>>5) + (0..3) and + 8 of that -- exactly the two float4 the A side reads there
+        // (wave_fetch_a), so A needs no shuffle.  Dword s = k-slots 2s, 2s + 1;  values are 2^8 * W.
+        const int st = (kc >> 1) & 1, pl = kc & 1;
+        const int ch0 = 32 * (kc >> 2) + 16 * st + 4 * (lane >> 5) + (s < 2 ? 2 * s : 8 + 2 * (s - 2));
+        unsigned half[2];
+        for (int j = 0; j < 2; ++j) {
+            const float x = (row < N ? src[((long)t * N + row) * K + ch0 + j] : 0.0f) * kF16WScale;
+            const unsigned h1 = f32_to_f16_bits(x, false);
+            half[j] = pl == 0 ? h1 : f32_to_f16_bits(x - f16_bits_to_f32(h1), false);
+        }
+        dst[e] = __builtin_bit_cast(float, half[0] | (half[1] << 16));
+#else
         const int colk = 8 * kc + 4 * (lane >> 5) + s;
         dst[e] = row < N ? src[((long)t * N + row) * K + colk] : 0.0f;
+#endif
     }
 }
 

@@ -109,6 +109,32 @@ __device__ __forceinline__ void wave_fetch_a(WaveGrp<NT>& gq, const float* ar, b
 // between two accumulator sets by k-step; the caller adds them up at the end (wave_acc_join).
 template <int NT>
 __device__ __forceinline__ void wave_grp_mma(f32x16 (&acc)[NT], f32x16 (&acc2)[NT], const WaveGrp<NT>& gq) {
+#if ESMI_CHAIN_SPLIT
+    // split-f16x2 (esmi_dev.h): the group's 32 channels are two 16-channel steps; the weights arrive pre-split (slots
+    // 2st, 2st + 1 = pieces 1, 2 of step st: pack_bfrag_kernel), the A rows are split here.  3 MFMAs of 8 passes per step
+    // and tile instead of 8 MFMAs of 16 passes.
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {
+        const f16x2p a2 = split_f16x2(gq.a[2 * st], gq.a[2 * st + 1]);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const u32x4 b1 = __builtin_bit_cast(u32x4, gq.b[2 * st][nt]), b2 = __builtin_bit_cast(u32x4, gq.b[2 * st + 1][nt]);
+            if (NT <= 2) {      // two accumulator sets: no MFMA waits for its predecessor's result
+                if (st == 0) {
+                    acc2[nt] = mfma32_f16(a2.h2, b1, acc2[nt]);
+                    acc[nt] = mfma32_f16(a2.h1, b2, acc[nt]);
+                    acc2[nt] = mfma32_f16(a2.h1, b1, acc2[nt]);
+                } else {
+                    acc[nt] = mfma32_f16(a2.h2, b1, acc[nt]);
+                    acc2[nt] = mfma32_f16(a2.h1, b2, acc2[nt]);
+                    acc[nt] = mfma32_f16(a2.h1, b1, acc[nt]);
+                }
+            } else {
+                acc[nt] = mfma32_split2(a2, b1, b2, acc[nt]);
+            }
+        }
+    }
+#else
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
 #pragma unroll
@@ -120,13 +146,24 @@ __device__ __forceinline__ void wave_grp_mma(f32x16 (&acc)[NT], f32x16 (&acc2)[N
             }
         }
     }
+#endif
 }
+// End of a GEMM: add the two accumulator sets.  The split path REQUIRES acc to have been zero at the start of the GEMM: its
+// weights carry a factor 2^8 that is taken out here (accumulate across GEMMs in a separate tile: enc_attn_ffn's proj).
 template <int NT>
 __device__ __forceinline__ void wave_acc_join(f32x16 (&acc)[NT], const f32x16 (&acc2)[NT]) {
+#if ESMI_CHAIN_SPLIT
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        if (NT <= 2) acc[nt] = (acc[nt] + acc2[nt]) * kF16WScaleInv;
+        else acc[nt] *= kF16WScaleInv;
+    }
+#else
     if (NT <= 2) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[nt] += acc2[nt];
     }
+#endif
 }
 
 // Request the weights of the FIRST group of a GEMM ahead of time (before the tile store / LDS hand-off / reduction that

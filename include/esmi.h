@@ -68,6 +68,12 @@ int esmi_pack_convT_weight_f32(const float* src, float* dst, int cin, int cout, 
 /* MFMA B-fragment order of `taps` row-major (n, k) matrices (k a multiple of 8), NT = ceil(n/32):
  *   dst[(((t*(k/8) + kc)*NT + nt)*64 + lane)*4 + s] = src[t][32nt + (lane&31)][8kc + 4(lane>>5) + s]   (0 for rows >= n)
  * src is an nn.Linear weight (taps = 1) or a tap-major conv weight (k_taps, Cout, Cin).
+ * That is the fp32-MFMA build (enc_gemm=fp32-mfma in esmi_build_config()).  The default build (enc_gemm=split-f16x2)
+ * stores the same number of bytes as pre-split binary16 pieces of 2^8 * W: within each group of four kc (32 channels)
+ * slot kc&3 = (16-channel step st = (kc>>1)&1, piece pl = kc&1), and dword s of a lane holds the two pieces for channels
+ * 32(kc>>2) + 16st + 4(lane>>5) + {2s, 2s+1} (s < 2) or + 8 + {2(s-2), 2(s-2)+1} (s >= 2), low half first
+ * (piece 1 = round-to-nearest binary16, piece 2 = binary16 of the remainder; efficientspeech_amd/csrc/small_kernels.h).
+ * The blob is opaque to callers either way: only kernels of the same library read it.
  * dst holds esmi_pack_bfrag_floats(n, k, taps) = taps * k * 32 * NT floats.                     */
 size_t esmi_pack_bfrag_floats(int n, int k, int taps);
 int esmi_pack_bfrag_f32(const float* src, float* dst, int n, int k, int taps, esmi_stream_t stream);

@@ -199,9 +199,22 @@ def test_simulated_weight_packers():
             d = dst.numpy().reshape(taps, k // 8, nt, 64, 4)
             t, kc, t32, lane, s = np.meshgrid(np.arange(taps), np.arange(k // 8), np.arange(nt), np.arange(64), np.arange(4),
                                               indexing="ij")
-            row, col = 32 * t32 + (lane & 31), 8 * kc + 4 * (lane >> 5) + s
-            ref = np.where(row < n, w[t, np.minimum(row, n - 1), col], 0.0)
-            assert np.array_equal(d, ref.astype(np.float32))
+            row = 32 * t32 + (lane & 31)
+            if "enc_gemm=split-f16x2" in lib.esmi_build_config().decode():
+                # split operands: slot kc & 3 of a 32-channel group = (16-channel step, piece); dword s = two binary16 values
+                st, pl = (kc >> 1) & 1, kc & 1
+                ch0 = 32 * (kc >> 2) + 16 * st + 4 * (lane >> 5) + np.where(s < 2, 2 * s, 8 + 2 * (s - 2))
+                word = np.zeros(d.shape, np.uint32)
+                for j in range(2):
+                    x = np.where(row < n, w[t, np.minimum(row, n - 1), ch0 + j], 0.0).astype(np.float32) * np.float32(256.0)
+                    h1 = x.astype(np.float16)
+                    piece = np.where(pl == 0, h1, (x - h1.astype(np.float32)).astype(np.float16)).astype(np.float16)
+                    word |= piece.view(np.uint16).astype(np.uint32) << np.uint32(16 * j)
+                assert np.array_equal(d.view(np.uint32), word)
+            else:
+                col = 8 * kc + 4 * (lane >> 5) + s
+                ref = np.where(row < n, w[t, np.minimum(row, n - 1), col], 0.0)
+                assert np.array_equal(d, ref.astype(np.float32))
         k, cin, cout = 3, 64, 32
         wm = rng.standard_normal((k, cin, cin)).astype(np.float32)
         w1 = rng.standard_normal((cout, cin)).astype(np.float32)
