@@ -56,6 +56,11 @@
 #ifndef ESMI_DEC_RSQRT
 #define ESMI_DEC_RSQRT rsqrt_fast_f32   // v_rsq_f32 (1 ulp); every LayerNorm thread computes it for 4 rows
 #endif
+#ifndef ESMI_DEC_FUSED_LN
+#define ESMI_DEC_FUSED_LN 0   // (measured: 0.2085 vs 0.1928 ms, i.e. slower, kept as an option) bias + tanh + LayerNorm (+ block-end skip LayerNorm) on the accumulators in registers: every wave
+                              // reduces its column slice of a row in-lane, the four slices' (mean, M2) meet in a small LDS
+                              // table (Chan merge); the activations are stored once instead of store / load / store
+#endif
 #ifndef ESMI_DEC_TAPS_IN_REGS
 #define ESMI_DEC_TAPS_IN_REGS 1
 #endif
@@ -223,7 +228,7 @@ struct MelDecP {
 
 template <int DX2>
 __host__ __device__ constexpr int dec_lds_floats(int kd) {
-    return (kDecRows + 2 * kDecPadRows) * (DX2 + 4) + (kd + 6) * DX2 + kDecRows;
+    return (kDecRows + 2 * kDecPadRows) * (DX2 + 4) + (kd + 6) * DX2 + kDecRows + (ESMI_DEC_FUSED_LN ? kDecRows * 8 : 0);
 }
 
 // NW = waves per window.  NW = 8: wave (mh = w>>2, ns = w&3) owns 64 rows x DX2/4 columns, one workgroup per CU.
@@ -279,6 +284,7 @@ __global__ __launch_bounds__(64 * NW, (DX2 <= 128 && NW == 8 ? ESMI_DEC_WPS : 2)
     float* xs = lds;                                                  // [132][LDSROW]
     float* pbuf = lds + (kDecRows + 2 * kDecPadRows) * LDSROW;        // [PB]
     int* src = reinterpret_cast<int*>(pbuf + PB);                     // [128]
+    float* stats = pbuf + PB + kDecRows;                              // [128][4 column slices][mean, M2]   (ESMI_DEC_FUSED_LN)
 
     const int tid = (int)threadIdx.x, lane = lane_id(), w = wave_id();
     const int i = lane & 31, h = lane >> 5;
@@ -612,6 +618,119 @@ __global__ __launch_bounds__(64 * NW, (DX2 <= 128 && NW == 8 ? ESMI_DEC_WPS : 2)
         }
     };
 
+    // ---- fused epilogue (ESMI_DEC_FUSED_LN).  In the transposed accumulator layout lane (i, h) of wave (mh, ns) holds, for
+    // each of its MT row tiles, row 32*MT*mh + 32*mt + i and the channels ns*WCOLS + 32t + 8g + 4h + (0..3): half of the
+    // wave's column slice of that row, the other half sits in lane i + 32.  A row's LayerNorm statistics are therefore
+    // in-lane sums + one v_permlane32_swap per wave, and a 2-float LDS entry per (row, slice) to meet the other slices.
+    f32x16 skp[MT][NTW];         // the skip tensor in that layout
+    unsigned acc_inside = 0;     // bit mt: the lane's row of tile mt exists in the reference (inside [0, L))
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) acc_inside |= (src[32 * MT * mh + 32 * mt + i] != -1 ? 1u : 0u) << mt;
+    const int ep_col = ns * WCOLS + 4 * h;      // + 32t + 8g
+    float* ep_stats = stats + opaque_i((32 * MT * mh + i) * 2 * NS);   // + 64*NS*mt: this lane's row entry [NS][2]
+    float* ep_tile = xs + opaque_i((kDecPadRows + 32 * MT * mh + i) * LDSROW + ep_col);
+    // x = LN(x) over the full rows; gp / bp = the gain / shift vectors in LDS.  Contains one workgroup barrier.
+    auto ln_exchange = [&](f32x16 (&x)[MT][NTW], const float* gp, const float* bp) __attribute__((always_inline)) {
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {   // two-pass statistics of this wave's WCOLS channels of the row
+            float sm = 0.0f;
+#pragma unroll
+            for (int t = 0; t < NTW; ++t) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) sm += (x[mt][t][4 * g] + x[mt][t][4 * g + 1]) + (x[mt][t][4 * g + 2] + x[mt][t][4 * g + 3]);
+            }
+            sm += swap32_f(sm);
+            const float mean = sm * (1.0f / WCOLS);
+            float q = 0.0f;
+#pragma unroll
+            for (int t = 0; t < NTW; ++t) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float d = x[mt][t][r] - mean;
+                    q = fmaf(d, d, q);
+                }
+            }
+            q += swap32_f(q);
+            *reinterpret_cast<f32x2*>(ep_stats + 64 * NS * mt + 2 * ns) = f32x2{mean, q};   // both half-wave lanes: same value
+        }
+        __syncthreads();
+        float mean[MT], rstd[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {   // Chan merge of the NS equal-sized slices (identical in every wave)
+            f32x2 st[NS];
+#pragma unroll
+            for (int k = 0; k < NS; ++k) st[k] = *reinterpret_cast<const f32x2*>(ep_stats + 64 * NS * mt + 2 * k);
+            float m = 0.0f;
+#pragma unroll
+            for (int k = 0; k < NS; ++k) m += st[k][0];
+            m *= 1.0f / NS;
+            float m2 = 0.0f;
+#pragma unroll
+            for (int k = 0; k < NS; ++k) {
+                const float d = st[k][0] - m;
+                m2 += fmaf((float)WCOLS * d, d, st[k][1]);
+            }
+            mean[mt] = m;
+            rstd[mt] = ESMI_DEC_RSQRT(m2 * (1.0f / DX2) + 1e-5f);
+        }
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 gg = *reinterpret_cast<const f32x4*>(gp + ep_col + 32 * t + 8 * g);
+                const f32x4 bb = *reinterpret_cast<const f32x4*>(bp + ep_col + 32 * t + 8 * g);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) x[mt][t][4 * g + e] = fmaf((x[mt][t][4 * g + e] - mean[mt]) * rstd[mt], gg[e], bb[e]);
+                }
+            }
+        }
+    };
+    // bias + tanh + LN [+ LN_s(x + skip)] on the accumulators, rows outside the sequence -> 0, result -> tile (and skip)
+    auto epilogue_ln = [&](const float* pb, bool block_end, int l_next) __attribute__((always_inline)) {
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 bc = *reinterpret_cast<const f32x4*>(pb + P_PWB + ep_col + 32 * t + 8 * g);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[mt][t][4 * g + e] = ESMI_DEC_TANH(fmaf(acc[mt][t][4 * g + e], WSI, bc[e]));
+                }
+            }
+        }
+        commit_A(l_next);                    // next layer's taps (their LDS slots were last read by this layer's depthwise phase)
+        issue_B(l_next);
+        ln_exchange(acc, pb + P_G, pb + P_B);       // its barrier also ends the K loop's reads of the tile
+        if (block_end) {   // end of a decoder block: skip = LN_s(x + skip), networks.py:299
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+                for (int t = 0; t < NTW; ++t) acc[mt][t] += skp[mt][t];
+            }
+            __syncthreads();                 // every wave has read the first table
+            ln_exchange(acc, pb + P_SG, pb + P_SB);
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+            for (int t = 0; t < NTW; ++t) {
+                if (!((acc_inside >> mt) & 1u)) acc[mt][t] = zero16();
+                if (block_end) skp[mt][t] = acc[mt][t];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    f32x4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = acc[mt][t][4 * g + e];
+                    *reinterpret_cast<f32x4*>(ep_tile + 32 * mt * LDSROW + 32 * t + 8 * g) = v;
+                }
+            }
+        }
+    };
+
     // ---- proj: Linear(d4, dx2) + Tanh + LN.  All three are row-wise, and a frame's input row is its phoneme's row: when
     // the caller supplies h0 = LN(tanh(proj(x))) at PHONEME rate (enc_fuse_va_kernel computes it while the features
     // are still on the CU) the stage reduces to a gather -- one of the six GEMM stages of the window disappears
@@ -693,6 +812,21 @@ __global__ __launch_bounds__(64 * NW, (DX2 <= 128 && NW == 8 ? ESMI_DEC_WPS : 2)
 
     }
 
+    if (ESMI_DEC_FUSED_LN) {   // the stage's output (in the tile) is the first skip tensor
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+            for (int t = 0; t < NTW; ++t) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(ep_tile + 32 * mt * LDSROW + 32 * t + 8 * g);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) skp[mt][t][4 * g + e] = v[e];
+                }
+            }
+        }
+    }
+
     // ---- conv layers
     const int dw_cg = tid % CG, dw_r0 = (tid / CG) * RS;
     for (int l = 0; l < n_layers; ++l) {
@@ -753,21 +887,31 @@ __global__ __launch_bounds__(64 * NW, (DX2 <= 128 && NW == 8 ? ESMI_DEC_WPS : 2)
                                                       : wslice(p.lay.mel_w, 0), PRESPLIT);
         ESMI_STAMP();   // 5: K loop issued
         ESMI_PRIO(ESMI_DEC_CHAIN_PRIO);
-        __syncthreads();  // all reads of the filtered tile done
-        ESMI_STAMP();   // 6: barrier
-        // 3. bias + tanh -> tile; commit the staged params of layer l+1 to the other buffer
-        store_tanh(pb + P_PWB);
-        commit_A(l + 1);
-        issue_B(l + 1);
-        ESMI_STAMP();   // 7: tanh stored
-        __syncthreads();
-        ESMI_STAMP();   // 8: barrier
-        // 4. LayerNorm (+ block-end skip LayerNorm) by row owners
         const bool block_end = ((l + 1) % p.block_depth) == 0;
-        ln_pass(pb, block_end, block_end);
-        ESMI_STAMP();   // 9: LN done
-        __syncthreads();
-        ESMI_STAMP();   // 10: barrier
+        if (ESMI_DEC_FUSED_LN) {
+            ESMI_STAMP();   // 6
+            ESMI_STAMP();   // 7
+            ESMI_STAMP();   // 8
+            epilogue_ln(pb, block_end, l + 1);
+            ESMI_STAMP();   // 9: epilogue done
+            __syncthreads();
+            ESMI_STAMP();   // 10: barrier
+        } else {
+            __syncthreads();  // all reads of the filtered tile done
+            ESMI_STAMP();   // 6: barrier
+            // 3. bias + tanh -> tile; commit the staged params of layer l+1 to the other buffer
+            store_tanh(pb + P_PWB);
+            commit_A(l + 1);
+            issue_B(l + 1);
+            ESMI_STAMP();   // 7: tanh stored
+            __syncthreads();
+            ESMI_STAMP();   // 8: barrier
+            // 4. LayerNorm (+ block-end skip LayerNorm) by row owners
+            ln_pass(pb, block_end, block_end);
+            ESMI_STAMP();   // 9: LN done
+            __syncthreads();
+            ESMI_STAMP();   // 10: barrier
+        }
     }
 
     // ---- mel Linear(dx2, n_mel) on skip (held in the tile), masked store
