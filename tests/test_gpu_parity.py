@@ -341,3 +341,30 @@ def test_exact_fp32_mfma_build():
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "smoke ok" in r.stdout
+
+
+@pytest.mark.parametrize("s_w,s_g", [(8.0, 1.0), (0.02, 1.0), (1.0, 30.0), (1.0, 1e-3), (5.0, 0.01)])
+def test_split_contraction_operand_scales(s_w, s_g):
+    """The split-f16 contractions (esmi_dev.h) keep fp32-level accuracy when weights and activations sit far from O(1): pointwise
+    / mel weights scaled by s_w, LayerNorm gains (= the magnitude of the activations feeding the next contraction) by s_g."""
+    from efficientspeech_amd import build_phoneme2mel, load_numpy_state_dict
+    from efficientspeech_amd.synth import synth_state_dict
+    cfg = CONFIGS["tiny"]
+    sd = synth_state_dict(cfg, 77)
+    for k in list(sd):
+        if not k.startswith("decoder."):
+            continue
+        if k.endswith(".0.1.weight") or k == "decoder.mel_linear.weight" or k == "decoder.proj.0.weight":
+            sd[k] = (sd[k] * np.float32(s_w)).astype(np.float32)              # pointwise conv / Linear weights
+        elif k.endswith(".weight") and sd[k].ndim == 1:
+            sd[k] = (sd[k] * np.float32(s_g)).astype(np.float32)              # LayerNorm gains
+    net = build_phoneme2mel(cfg)
+    load_numpy_state_dict(net, sd)
+    net = net.to(DEV)
+    rng = np.random.default_rng(9)
+    feats = rng.standard_normal((2, 200, cfg.d4)).astype(np.float32)
+    with torch.no_grad():
+        mel = net.decoder(torch.from_numpy(feats).to(DEV)).cpu().numpy()
+    ref = oracle.mel_decoder(cfg, oracle.Weights(sd), feats)
+    assert np.isfinite(mel).all()
+    assert np.abs(mel - ref).max() < H.MEL_TOL * max(1.0, float(np.abs(ref).max())), (np.abs(mel - ref).max(), np.abs(ref).max())
