@@ -3,7 +3,7 @@
 set -e
 ROOT="$(cd "$(dirname "$0")/.." && pwd)"
 OUT="$ROOT/tools/_abl"; mkdir -p "$OUT"
-build() { tag=$1; shift; hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC "$@" -o "$OUT/libesmi_$tag.so" "$ROOT/efficientspeech_amd/csrc/esmi_abi.hip" & }
+build() { tag=$1; shift; hipcc --offload-arch=gfx950 -O2 -std=c++17 -shared -fPIC "$@" -o "$OUT/libesmi_$tag.so" "$ROOT/efficientspeech_amd/csrc/esmi_abi.hip" & }
 build base
 build fasttanh -DESMI_DEC_TANH=tanh_fast_f32
 build notanh -DESMI_DEC_TANH=ident_f32
