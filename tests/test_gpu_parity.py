@@ -368,3 +368,31 @@ def test_split_contraction_operand_scales(s_w, s_g):
     ref = oracle.mel_decoder(cfg, oracle.Weights(sd), feats)
     assert np.isfinite(mel).all()
     assert np.abs(mel - ref).max() < H.MEL_TOL * max(1.0, float(np.abs(ref).max())), (np.abs(mel - ref).max(), np.abs(ref).max())
+
+
+@pytest.mark.parametrize("n_mel", [78, 33, 96])
+def test_decoder_other_mel_widths(n_mel):
+    """n_mel not a multiple of 4 takes the scalar mel-store path of the decoder (rows are not 16-byte multiples); 96 is the
+    widest supported (three column tiles)."""
+    import dataclasses
+    from efficientspeech_amd import build_phoneme2mel, load_numpy_state_dict
+    from efficientspeech_amd.synth import synth_state_dict
+    cfg = dataclasses.replace(CONFIGS["tiny"], n_mel_channels=n_mel)
+    sd = synth_state_dict(cfg, 5)
+    net = build_phoneme2mel(cfg)
+    load_numpy_state_dict(net, sd)
+    net = net.to(DEV)
+    rng = np.random.default_rng(2)
+    feats = rng.standard_normal((2, 150, cfg.d4)).astype(np.float32)
+    with torch.no_grad():
+        mel = net.decoder(torch.from_numpy(feats).to(DEV)).cpu().numpy()
+    ref = oracle.mel_decoder(cfg, oracle.Weights(sd), feats)
+    assert mel.shape == ref.shape == (2, 150, n_mel)
+    assert np.abs(mel - ref).max() < H.MEL_TOL
+    ids, mask = synth_phonemes(3, 40, 9, [40, 31, 7])       # and through the fused encoder -> decoder path (h0 gather)
+    x = {"phoneme": torch.from_numpy(ids).to(DEV), "phoneme_mask": torch.from_numpy(mask).to(DEV)}
+    with torch.no_grad():
+        mel2, mel_len, _ = net(x)
+    o = oracle.phoneme2mel(cfg, oracle.Weights(sd), ids, mask)
+    if np.array_equal(mel_len.cpu().numpy(), o.mel_len):
+        assert np.abs(mel2.cpu().numpy() - o.mel).max() < H.MEL_TOL
