@@ -295,6 +295,15 @@ __device__ __forceinline__ float tanh_fast_f32(float x) {
     return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + e);
 #endif
 }
+// tanh(s*x + b) with the scale of the exponent folded into the fma: pass s2 = s * 2 log2(e), b2 = b * 2 log2(e)
+constexpr float kTanhExpScale = 2.885390081777927f;
+__device__ __forceinline__ float tanh_fast_fma_f32(float x, float s2, float b2) {
+#ifdef ESMI_WAVESIM
+    return tanh_f32(fmaf(x, s2, b2) * (1.0f / kTanhExpScale));
+#else
+    return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(fmaf(x, s2, b2)));
+#endif
+}
 // hardware transcendentals for the fused encoder-side kernels (v_exp_f32 / v_rsq_f32: ~1 ulp); the one-kernel-per-op plan and
 // the oracle keep the libm forms.  The simulator mirrors the formulas with libm calls.
 __device__ __forceinline__ float exp_fast_f32(float x) {

@@ -540,12 +540,21 @@ __global__ __launch_bounds__(64 * NW, (DX2 <= 128 && NW == 8 ? ESMI_DEC_WPS : 2)
             float* base = xs + opaque_i((kDecPadRows + 32 * MT * mh + i) * LDSROW + col);
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const f32x4 bc = *reinterpret_cast<const f32x4*>(bp + 8 * g);
+                f32x4 bc = *reinterpret_cast<const f32x4*>(bp + 8 * g);
+#if !defined(ESMI_ABL_NO_TANH)
+                bc *= kTanhExpScale;     // the exponent's 2 log2(e) goes into the bias and the scale of the fma
+#endif
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) {
                     f32x4 v;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = ESMI_DEC_TANH(fmaf(acc[mt][t][4 * g + e], WSI, bc[e]));
+                    for (int e = 0; e < 4; ++e) {
+#if defined(ESMI_ABL_NO_TANH)
+                        v[e] = fmaf(acc[mt][t][4 * g + e], WSI, bc[e]);
+#else
+                        v[e] = tanh_fast_fma_f32(acc[mt][t][4 * g + e], WSI * kTanhExpScale, bc[e]);
+#endif
+                    }
                     *reinterpret_cast<f32x4*>(base + 32 * mt * LDSROW + 8 * g) = v;
                 }
             }
