@@ -97,7 +97,7 @@ def main():
             if bench:
                 f.write(f"Un-profiled `bench.py` of the same build on the same box: {bench['ms_per_step']:.3f} ms/step = "
                         f"{bench['value']:.3e} frames/s, {bench['roofline']['kernel']} {bench['roofline']['kernel_ms']:.3f} ms "
-                        f"by live HIP events ({100 * bench['roofline']['frac']:.1f} % of the fp32-MFMA peak).\n")
+                        f"by live HIP events ({100 * bench['roofline']['frac']:.1f} % of roofline.peak = {bench['roofline']['peak']:.0f} TFLOP/s).\n")
             try:   # the live HIP-event timing printed by bench.py INSIDE the profiled run: must agree with the trace average
                 prof = json.loads([ln for ln in open(os.path.join(d, "stats.log")).read().splitlines() if ln.startswith("{")][-1])
                 f.write(f"Inside the profiled run, bench.py's live HIP events (every launch of the 10 timed steps) gave "
