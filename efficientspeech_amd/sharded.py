@@ -184,7 +184,11 @@ class ShardedMelPipeline:
     def _compute_two_stream(self, x):
         dev = x["phoneme"].device
         if self.s_enc is None:
-            self.s_enc, self.s_dec = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+            # the encoder side is three short latency-bound launches: high priority, so that its few workgroups take the
+            # first slot a finishing decoder workgroup frees on each CU instead of queueing behind the decoder's own
+            import os
+            prio = int(os.environ.get("ESMI_ENC_STREAM_PRIORITY", "-1"))
+            self.s_enc, self.s_dec = torch.cuda.Stream(device=dev, priority=prio), torch.cuda.Stream(device=dev)
         cur = torch.cuda.current_stream(dev)
         self.s_enc.wait_stream(cur)                       # inputs produced on the caller's stream
         with torch.cuda.stream(self.s_enc):
