@@ -209,7 +209,7 @@ def main():
         "metric": "mel-frames/sec (whole node), full Phoneme2Mel forward", "value": value, "unit": "mel-frames/s",
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32" + (f" (mel-decoder GEMMs: {split_txt})" if split else ""),
+        "dtype": "f32" + (f" (weight GEMMs: {split_txt})" if split else ""),
         "data": "synthetic",
         "mRTF": value * 256 / 22050,
         "config": {"workload": f"{a.config} ES ({sum(v.size for v in sd.values())} params, seeded random weights), "
