@@ -270,6 +270,14 @@ __device__ __forceinline__ float row_sum16(float v) {   // all-reduce over each 
     v += dpp_f<0x140>(v);
     return v;
 }
+template <int N>   // all-reduce over aligned groups of N = 4, 8 or 16 adjacent lanes
+__device__ __forceinline__ float row_sum_n(float v) {
+    v += dpp_f<0xB1>(v);
+    v += dpp_f<0x4E>(v);
+    if (N >= 8) v += dpp_f<0x141>(v);
+    if (N >= 16) v += dpp_f<0x140>(v);
+    return v;
+}
 __device__ __forceinline__ float row_max32(float v) {
     v = fmaxf(v, dpp_f<0xB1>(v));
     v = fmaxf(v, dpp_f<0x4E>(v));

@@ -56,6 +56,9 @@
 #ifndef ESMI_DEC_RSQRT
 #define ESMI_DEC_RSQRT rsqrt_fast_f32   // v_rsq_f32 (1 ulp); every LayerNorm thread computes it for 4 rows
 #endif
+#ifndef ESMI_DEC_LN_TPR
+#define ESMI_DEC_LN_TPR 16    // LayerNorm threads per row: 16 (4 rows per thread, gain/shift read once per 4 rows), 8 or 4
+#endif
 #ifndef ESMI_DEC_FUSED_LN
 #define ESMI_DEC_FUSED_LN 0   // (measured: 0.2085 vs 0.1928 ms, i.e. slower, kept as an option) bias + tanh + LayerNorm (+ block-end skip LayerNorm) on the accumulators in registers: every wave
                               // reduces its column slice of a row in-lane, the four slices' (mean, M2) meet in a small LDS
@@ -257,7 +260,7 @@ __global__ __launch_bounds__(64 * NW, (DX2 <= 128 && NW == 8 ? ESMI_DEC_WPS : 2)
     constexpr int NS = (DX2 <= 128 && NW == 8) ? ESMI_DEC_NS : 4;   // column slices per workgroup
     constexpr int MH = NW / NS;             // row groups (1, 2 or 4)
     constexpr int MT = 4 / MH;              // 32-row MFMA tiles per wave (4, 2 or 1)
-    constexpr int TPR = 16;                       // LayerNorm threads per row: one DPP row, so the row statistics are DPP adds
+    constexpr int TPR = ESMI_DEC_LN_TPR;          // LayerNorm threads per row (adjacent lanes inside one DPP row: the statistics are DPP adds)
     constexpr int RPT = kDecRows * TPR / kDecThreads;   // rows per LayerNorm thread (4 or 8): the gain/shift vectors of its
                                                   // channels are read from LDS once for all of them
     constexpr bool LOWREG = ESMI_DEC_LOWREG && DX2 <= 128;
@@ -269,7 +272,7 @@ __global__ __launch_bounds__(64 * NW, (DX2 <= 128 && NW == 8 ? ESMI_DEC_WPS : 2)
     constexpr int PAD = KD / 2;
     constexpr int CG = DX2 / 4;             // 4-channel groups per row
     constexpr int RS = kDecRows / (kDecThreads / CG);  // rows per depthwise strip (8 or 16)
-    constexpr int NV = DX2 / (4 * TPR);     // float4 per LayerNorm thread and row (channels 4*c + 64*k, c = lane & 15)
+    constexpr int NV = DX2 / (4 * TPR);     // float4 per LayerNorm thread and row (channels 4*c + 4*TPR*k, c = lane % TPR)
     ESMI_DYN_LDS(lds);
     // per-layer small parameters in LDS: [taps KD*DX2 | dw_b] (group A: read by the depthwise phase) and
     // [pw_b | ln_g | ln_b | skip_g | skip_b] (group B: read by the tanh / LayerNorm phases).  Single buffer:
@@ -388,7 +391,7 @@ __global__ __launch_bounds__(64 * NW, (DX2 <= 128 && NW == 8 ? ESMI_DEC_WPS : 2)
 
     // LayerNorm ownership: lane = 16*rg + c; the wave owns rows [4*RPT*w, +4*RPT), the thread rows ln_row0 + (0..RPT-1)
     // and the float4 channel groups c + 16*k of each
-    const int ln_c = lane & 15, ln_row0 = 4 * RPT * w + RPT * (lane >> 4);
+    const int ln_c = lane & (TPR - 1), ln_row0 = (64 / TPR) * RPT * w + RPT * (lane / TPR);
     unsigned ln_inside = 0;                 // bit j: row ln_row0 + j exists in the reference (inside [0, L))
 #pragma unroll
     for (int j = 0; j < RPT; ++j) ln_inside |= (src[ln_row0 + j] != -1 ? 1u : 0u) << j;
@@ -566,7 +569,7 @@ __global__ __launch_bounds__(64 * NW, (DX2 <= 128 && NW == 8 ? ESMI_DEC_WPS : 2)
         float s = 0.0f;
 #pragma unroll
         for (int k = 0; k < NV; ++k) s += (v[k][0] + v[k][1]) + (v[k][2] + v[k][3]);
-        s = row_sum16(s);
+        s = row_sum_n<TPR>(s);
         const float mean = s * (1.0f / DX2);
         float q = 0.0f;
 #pragma unroll
@@ -577,7 +580,7 @@ __global__ __launch_bounds__(64 * NW, (DX2 <= 128 && NW == 8 ? ESMI_DEC_WPS : 2)
                 q = fmaf(d, d, q);
             }
         }
-        q = row_sum16(q);
+        q = row_sum_n<TPR>(q);
         const float rstd = ESMI_DEC_RSQRT(q * (1.0f / DX2) + 1e-5f);
 #pragma unroll
         for (int k = 0; k < NV; ++k) {
@@ -587,7 +590,7 @@ __global__ __launch_bounds__(64 * NW, (DX2 <= 128 && NW == 8 ? ESMI_DEC_WPS : 2)
     };
     auto ln_params = [&](const float* pv, f32x4 (&o)[NV]) __attribute__((always_inline)) {
 #pragma unroll
-        for (int k = 0; k < NV; ++k) o[k] = *reinterpret_cast<const f32x4*>(pv + 64 * k);
+        for (int k = 0; k < NV; ++k) o[k] = *reinterpret_cast<const f32x4*>(pv + 4 * TPR * k);
     };
     // LN pass over the tile (in place): x = LN(x) [; x = LN_s(x + skip)] ; outside rows -> 0 ; skip update
     auto ln_pass = [&](const float* pb0, bool block_end, bool set_skip) __attribute__((always_inline)) {
@@ -600,7 +603,7 @@ __global__ __launch_bounds__(64 * NW, (DX2 <= 128 && NW == 8 ? ESMI_DEC_WPS : 2)
 #pragma unroll
         for (int j = 0; j < RPT; ++j) {
 #pragma unroll
-            for (int k = 0; k < NV; ++k) v[j][k] = *reinterpret_cast<const f32x4*>(ln_ptr + j * LDSROW + 64 * k);
+            for (int k = 0; k < NV; ++k) v[j][k] = *reinterpret_cast<const f32x4*>(ln_ptr + j * LDSROW + 4 * TPR * k);
         }
 #ifndef ESMI_ABL_NO_LN
 #pragma unroll
@@ -621,7 +624,7 @@ __global__ __launch_bounds__(64 * NW, (DX2 <= 128 && NW == 8 ? ESMI_DEC_WPS : 2)
 #pragma unroll
             for (int k = 0; k < NV; ++k) {
                 if (!((ln_inside >> j) & 1u)) v[j][k] = zero4();
-                *reinterpret_cast<f32x4*>(ln_ptr + j * LDSROW + 64 * k) = v[j][k];
+                *reinterpret_cast<f32x4*>(ln_ptr + j * LDSROW + 4 * TPR * k) = v[j][k];
                 if (set_skip) skip[j][k] = v[j][k];
             }
         }
@@ -766,7 +769,7 @@ __global__ __launch_bounds__(64 * NW, (DX2 <= 128 && NW == 8 ? ESMI_DEC_WPS : 2)
 #pragma unroll
             for (int j = 0; j < RPT; ++j) {
 #pragma unroll
-                for (int k = 0; k < NV; ++k) skip[j][k] = *reinterpret_cast<const f32x4*>(ln_ptr + j * LDSROW + 64 * k);
+                for (int k = 0; k < NV; ++k) skip[j][k] = *reinterpret_cast<const f32x4*>(ln_ptr + j * LDSROW + 4 * TPR * k);
             }
             unsigned pad_rows = 0;
 #pragma unroll
@@ -784,7 +787,7 @@ __global__ __launch_bounds__(64 * NW, (DX2 <= 128 && NW == 8 ? ESMI_DEC_WPS : 2)
 #pragma unroll
                     for (int k = 0; k < NV; ++k) {
                         if ((pad_rows >> j) & 1u) skip[j][k] = u[k];
-                        *reinterpret_cast<f32x4*>(ln_ptr + j * LDSROW + 64 * k) = skip[j][k];
+                        *reinterpret_cast<f32x4*>(ln_ptr + j * LDSROW + 4 * TPR * k) = skip[j][k];
                     }
                 }
             }
