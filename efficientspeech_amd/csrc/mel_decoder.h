@@ -56,6 +56,9 @@
 #ifndef ESMI_DEC_RSQRT
 #define ESMI_DEC_RSQRT rsqrt_fast_f32   // v_rsq_f32 (1 ulp); every LayerNorm thread computes it for 4 rows
 #endif
+#ifndef ESMI_DEC_WPS16
+#define ESMI_DEC_WPS16 8      // waves/SIMD of the 16-wave-per-window build (ESMI_DEC_NW128=16): 8 = two workgroups per CU at 64 VGPRs
+#endif
 #ifndef ESMI_DEC_LN_TPR
 #define ESMI_DEC_LN_TPR 16    // LayerNorm threads per row: 16 (4 rows per thread, gain/shift read once per 4 rows), 8 or 4
 #endif
@@ -255,7 +258,7 @@ __device__ __forceinline__ int batch_max_len(const int* __restrict__ mel_len, in
 }
 
 template <int DX2, int KD, int NW>
-__global__ __launch_bounds__(64 * NW, (DX2 <= 128 && NW == 8 ? ESMI_DEC_WPS : 2)) void mel_decoder_kernel(const MelDecP p) {
+__global__ __launch_bounds__(64 * NW, (DX2 <= 128 && NW == 8 ? ESMI_DEC_WPS : (NW == 16 ? ESMI_DEC_WPS16 : 2))) void mel_decoder_kernel(const MelDecP p) {
     constexpr int kDecThreads = 64 * NW;    // shadows the namespace constant inside this kernel
     constexpr int NS = (DX2 <= 128 && NW == 8) ? ESMI_DEC_NS : 4;   // column slices per workgroup
     constexpr int MH = NW / NS;             // row groups (1, 2 or 4)
