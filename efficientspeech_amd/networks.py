@@ -64,13 +64,42 @@ class _PackCache:
     def __init__(self):
         self.key = None
         self.val = None
+        self.plist = None
 
     def get(self, params, build):
-        key = tuple((p.data_ptr(), p._version, str(p.device), p.dtype) for p in params)
+        """`params`: callable returning the parameters the packed form depends on.  The list is collected once (walking the
+        module tree costs more host time than a whole forward step's launches: 118 `parameters()` walks = 0.1 ms per step
+        before this was cached); a change of storage (`.to()`, `.float()`) or content (`load_state_dict`, in-place
+        updates) of those Parameter objects is seen through (data_ptr, _version).  Replacing a Parameter OBJECT needs
+        `invalidate()` (the module mirrors call it from `_apply` and after `load_state_dict`)."""
+        if self.plist is None:
+            self.plist = list(params())
+        key = tuple((p.data_ptr(), p._version) for p in self.plist)
         if key != self.key:
             self.val = build()
             self.key = key
         return self.val
+
+    def invalidate(self):
+        self.key = self.val = self.plist = None
+
+
+class _PackedModule(nn.Module):
+    """nn.Module whose `_PackCache` attributes are dropped whenever its parameters may have been replaced: `_apply`
+    (`.to()`, `.cuda()`, `.float()` ...) and `load_state_dict` (incl. `assign=True`)."""
+
+    def __init__(self):
+        super().__init__()
+        self.register_load_state_dict_post_hook(lambda module, incompatible_keys: module._drop_packed())
+
+    def _drop_packed(self):
+        for v in self.__dict__.values():
+            if isinstance(v, _PackCache):
+                v.invalidate()
+
+    def _apply(self, fn, *args, **kwargs):
+        self._drop_packed()
+        return super()._apply(fn, *args, **kwargs)
 
 
 def _pack_conv(lib, stream, w, transposed=False):
@@ -118,7 +147,7 @@ class MixFFN(nn.Module):
         self.mlp2 = nn.Linear(hidden, dim)
 
 
-class Encoder(nn.Module):
+class Encoder(_PackedModule):
     """Phoneme encoder pyramid (networks.py:15-87): per block merge convs -> attention -> MixFFN."""
 
     def __init__(self, depth=2, embed_dim=128, kernel_size=3, expansion=1, reduction=4, head=1):
@@ -173,7 +202,7 @@ class Encoder(nn.Module):
                 keep.extend(t.values())
                 out.append((_lib.EncoderBlockWeights(**{k: _ptr(v) for k, v in t.items()}), keep))
             return out, _f32(self.embed.weight)
-        return self._cache.get(list(self.parameters()), build)
+        return self._cache.get(lambda: list(self.parameters()), build)
 
     def forward(self, phoneme, mask=None):
         """phoneme int (B,T); mask bool (B,T) or None -> ([f_0..f_{depth-1}], decoder_mask (B,T,dim) or None)."""
@@ -249,7 +278,7 @@ class AcousticDecoder(nn.Module):
         return _lib.PredictorWeights(**{k: _ptr(v) for k, v in t.items()}), list(t.values())
 
 
-class Fuse(nn.Module):
+class Fuse(_PackedModule):
     """Fuses the pyramid features back to phoneme rate (networks.py:168-219)."""
 
     def __init__(self, dims, kernel_size=3):
@@ -284,7 +313,7 @@ class Fuse(nn.Module):
             keep += [fw, fb, fwp]
             w.fuse_w, w.fuse_b, w.fuse_wp = _ptr(fw), _ptr(fb), _ptr(fwp)
             return w, keep
-        return self._cache.get(list(self.parameters()), build)
+        return self._cache.get(lambda: list(self.parameters()), build)
 
     def _run(self, feats, m8, out=None, ld_out=None):
         lib, stream = _runtime(self.fuse.weight)
@@ -332,7 +361,7 @@ class FeatureUpsampler(nn.Module):
         return features, masks.bool().unsqueeze(-1).expand(-1, -1, Cc), mel_len
 
 
-class MelDecoder(nn.Module):
+class MelDecoder(_PackedModule):
     """Mel spectrogram decoder (networks.py:261-304), one fused HIP kernel per call."""
 
     def __init__(self, dim, kernel_size=5, n_mel_channels=80, n_blocks=2, block_depth=2):
@@ -392,7 +421,7 @@ class MelDecoder(nn.Module):
             blob = torch.empty(nbytes // 4, dtype=torch.float32, device=keep[0].device)
             lib.esmi_mel_decoder_pack_f32(C.byref(w), C.byref(shape), _ptr(blob), stream)
             return blob
-        return self._cache.get(list(self.parameters()), build)
+        return self._cache.get(lambda: list(self.parameters()), build)
 
     def forward(self, features):
         """features (B,L,4*dim) -> mel (B,L,n_mel).  (Direct mode: rows exactly as given.)"""
@@ -416,7 +445,7 @@ class MelDecoder(nn.Module):
             t = dict(proj_wp=_pack_bfrag(lib, stream, self.proj[0].weight), proj_b=_f32(self.proj[0].bias),
                      ln_g=_f32(self.proj[2].weight), ln_b=_f32(self.proj[2].bias))
             return _lib.DecoderHead(d4=self.dim_x4, dx2=self.dim_x2, **{k: _ptr(v) for k, v in t.items()}), list(t.values())
-        return self._head_cache.get(list(self.proj.parameters()), build)
+        return self._head_cache.get(lambda: list(self.proj.parameters()), build)
 
     def _fused(self, feat, cum, mel_len, lmax_dev, lmax_host, apply_mask, L_out, h0=None):
         """Length-regulator gather fused into the decoder: feat (B,T,d4) phoneme-rate; h0 (B,T,dx2) = the first stage's
@@ -441,7 +470,7 @@ class MelDecoder(nn.Module):
         return mel
 
 
-class PhonemeEncoder(nn.Module):
+class PhonemeEncoder(_PackedModule):
     """Phonemes -> variance-adapted, length-regulated acoustic features (networks.py:307-401)."""
 
     def __init__(self, pitch_stats=None, energy_stats=None, depth=2, reduction=4, head=1, embed_dim=128,
@@ -461,8 +490,8 @@ class PhonemeEncoder(nn.Module):
     def _predictors(self, lib, stream):
         def build():
             return [d._weights(lib, stream) for d in (self.pitch_decoder, self.energy_decoder, self.duration_decoder)]
-        params = [p for d in (self.pitch_decoder, self.energy_decoder, self.duration_decoder) for p in d.parameters()]
-        return self._cache.get(params, build)
+        return self._cache.get(lambda: [p for d in (self.pitch_decoder, self.energy_decoder, self.duration_decoder)
+                                        for p in d.parameters()], build)
 
     def _encode(self, x, train=False, need_lmax=True, head=None):
         """Everything up to (and including) the duration scan; nothing frame-rate is materialised."""

@@ -6,7 +6,7 @@ import numpy as np, torch
 from efficientspeech_amd import CONFIGS, build_phoneme2mel, load_numpy_state_dict
 from efficientspeech_amd.synth import synth_state_dict, synth_phonemes
 from efficientspeech_amd.sharded import ShardedMelPipeline
-cfg = CONFIGS["tiny"]; B, T = 256, 128
+cfg = CONFIGS["tiny"]; B, T = int(os.environ.get("HB", "256")), 128
 net = build_phoneme2mel(cfg); load_numpy_state_dict(net, synth_state_dict(cfg, 1234)); net = net.cuda()
 ids, mask = synth_phonemes(B, T, 1234)
 x = {"phoneme": torch.from_numpy(ids).cuda(), "phoneme_mask": torch.from_numpy(mask).cuda(),
