@@ -248,7 +248,10 @@ int esmi_upsample_f32(const float* feat, const uint8_t* fmask, const int32_t* cu
 /* ------------------------------------------------------------------ Mel decoder
  * MelDecoder.forward, layers/networks.py:291-304, fully fused: proj Linear+Tanh+LN, n_blocks x
  * [block_depth x (depthwise k conv -> pointwise conv -> Tanh -> LN); skip LN], mel Linear.
- * Weights are packed once into one blob (MFMA B-fragment order).              */
+ * Weights are packed once into one blob (MFMA B-fragment order).  In the default build the
+ * matrices are stored as two binary16 pieces of 2^8 * W (same bytes as fp32; esmi_build_config() says
+ * "dec_gemm=split-f16x2"): |W| must be < 255 and activations inside the binary16 range;
+ * the blob is opaque and only valid for the library that packed it.                                  */
 #define ESMI_MAX_DEC_LAYERS 16
 typedef struct esmi_decoder_weights {   /* checkpoint layouts, device pointers */
     const float* proj_w;   /* (dx2, d4)     <- decoder.proj.0.weight */
