@@ -1,16 +1,22 @@
 #!/usr/bin/env python3
 """bench.py -- mel-frames/sec of the EfficientSpeech acoustic-model forward path on MI355X.
 
-One "step" = one full Phoneme2Mel inference forward (phoneme ids -> mel) over one synthetic batch
-on every rank: tiny ES, B=256 utterances x T=128 phonemes per GPU, injected durations D-const = 6
-(BASELINE.json configs[1]; random-init durations round to 0, fact 6), inputs already
-resident in HBM.  With N > 1 ranks the utterance batch is sharded (weak scaling: 256 per GPU) and
-each step ends with the RCCL all-gather of the mel shards over xGMI, pipelined one step behind the
-compute on a side stream.
+One "step" = one full Phoneme2Mel inference forward (phoneme ids -> mel) over one synthetic batch on every rank: by default
+tiny ES, B=256 utterances x T=128 phonemes per GPU, injected durations D-const = 6 (BASELINE.json configs[1]; SURVEY.md §8d;
+random-init durations round to 0, fact 6), inputs already resident in HBM.  With N > 1 ranks the utterance batch is sharded
+(`--scaling weak`: B per GPU, the default; `--scaling strong`: B is the GLOBAL batch, B/N per GPU) and each step ends with the
+RCCL all-gather of the mel shards over xGMI, pipelined one step behind the compute on a side stream.
 
-Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (the fused mel decoder),
-timed live with HIP events on the launch stream; `cpu_baseline` is the C oracle (oracle/, fp32
-accumulation, OpenMP) timed on this box's host cores -- a reported baseline, not the target.
+Prints ONE JSON line (rank 0):
+  value / ms_per_step    whole-job frames/s of the timed region (barrier + synchronize on both sides, max over ranks)
+  roofline               the dominant kernel (fused mel decoder), timed live with HIP events on the launch stream
+  exact_fp32             (N=1) the same step on efficientspeech_amd/libesmi_fp32mfma.so: every contraction on
+                         v_mfma_f32_32x32x2_f32, with its own kernel time and fraction of the 157.3 TFLOP/s fp32-MFMA peak
+  decoder_only           (N=1) MelDecoder.forward alone on frame-rate features ~ N(0,1)
+  allgather              (N>1) the mel all-gather timed by itself: GB/s received per rank vs 7 xGMI links x 76.8 GB/s
+  cpu_baseline           (N=1) the C oracle (oracle/, fp32 accumulation, OpenMP) on this box's host cores: all cores and
+                         n=24 (the reference's --threads default), plus the B=1 fox-sentence latency (BASELINE configs[0]) --
+                         a reported baseline, not the target.
 """
 import argparse
 import json
@@ -25,9 +31,15 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 FP32_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 == fp32 vector peak
+F16_PEAK_TFLOPS = 2500.0     # dense 16-bit MFMA peak
 HBM_PEAK_GBS = 8000.0
+XGMI_LINK_GBS, XGMI_LINKS = 76.8, 7      # per direction and link; 7 peers on an 8-GPU node
 # SURVEY.md §8d algorithmic work per valid mel frame, decoder only: (flops, bytes)
 DECODER_WORK = {"tiny": (189_440, 832), "small": (973_824, 1344), "base": (1_505_792, 2368)}
+DEFAULT_BATCH = {"tiny": 256, "small": 256, "base": 512}
+DEFAULT_PHONEMES = {"tiny": 128, "small": 256, "base": 256}
+FOX_IDS = [92, 74, 117, 145, 110, 117, 89, 131, 83, 120, 105, 67, 117, 132, 116, 75, 119, 130, 132, 124, 144, 98, 92, 74, 118, 103,
+           147, 113, 91, 79, 106]     # "the quick brown fox ..." as ARPAbet ids
 
 
 def parse():
@@ -36,53 +48,84 @@ def parse():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--config", default="tiny", choices=["tiny", "small", "base"])
-    ap.add_argument("--batch", type=int, default=None, help="utterances per GPU (default: BASELINE config)")
+    ap.add_argument("--batch", type=int, default=None, help="utterances per GPU (weak) or in total (strong); default: BASELINE config")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: --batch utterances per GPU; strong: --batch utterances in total, sharded over the ranks")
     ap.add_argument("--phonemes", type=int, default=None)
     ap.add_argument("--dur", type=int, default=6, help="injected frames per phoneme (D-const)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="N=1: skip the exact-fp32 and decoder-only legs")
     ap.add_argument("--no-gather", action="store_true", help="skip the mel all-gather (N>1 debugging)")
     ap.add_argument("--two-stream", action="store_true",
                     help="software-pipeline consecutive steps: encoder side of step i+1 concurrent with the decoder of step i")
     ap.add_argument("--exact-fp32", action="store_true",
-                    help="load efficientspeech_amd/libesmi_fp32mfma.so: the same kernels with the mel decoder's contractions on "
-                         "v_mfma_f32_32x32x2_f32 (exact fp32) instead of split 16-bit products")
+                    help="run the MAIN measurement on efficientspeech_amd/libesmi_fp32mfma.so (all contractions on "
+                         "v_mfma_f32_32x32x2_f32) instead of the split-f16 default build")
     ap.add_argument("--no-auto-launch", action="store_true",
                     help="N=1 only: do not try the two-stream pipeline during warm-up (default: warm up both launch modes and "
                          "keep two-stream only if it is >= 5 %% faster -- it is on boxes whose GPU drops to a low sclk state "
                          "during the light encoder-side kernels, and ~3 %% slower elsewhere)")
     ap.add_argument("--graph", action="store_true",
-                    help="replay the forward as two hipGraphs per step instead of eager launches (measured 2.5 %% slower "
-                         "on an idle host: the step is GPU-bound; useful when the host is slow)")
+                    help="replay the forward as two hipGraphs per step instead of eager launches")
     ap.add_argument("--event-every", type=int, default=5,
                     help="bracket every n-th mel-decoder launch of the timed region with HIP events for roofline.kernel_ms "
                          "(each event pair drains the queue: ~12 us per step when placed on every launch)")
-    ap.add_argument("--dec-lds-pad", type=int, default=0,
-                    help="development: extra LDS bytes per decoder workgroup (fewer decoder workgroups per CU, leaves room "
-                         "for the encoder-side kernels of the next step under --two-stream)")
     return ap.parse_args()
 
 
+def _omp_threads(n):
+    import ctypes
+    try:
+        ctypes.CDLL("libgomp.so.1").omp_set_num_threads(int(n))
+        return True
+    except OSError:
+        return False
+
+
 def cpu_baseline(cfg, sd, T, dur):
-    """Time the oracle (fp32-accumulating build) on a bounded sample of the same workload."""
+    """Time the oracle (fp32-accumulating build) on bounded samples of the same workload: all host cores, n = 24 threads (the
+    reference's --threads default, utils/tools.py:324), and the B = 1 fox sentence (BASELINE configs[0])."""
     from oracle import oracle
     from efficientspeech_amd.synth import synth_phonemes
     w = oracle.Weights(sd)
-    B = 256 if cfg.name == "tiny" else 64
+    cores = len(os.sched_getaffinity(0))
 
-    def run(b):
-        ids, mask = synth_phonemes(b, T, 99)
-        d = np.full((b, T), dur, np.int32)
-        z = np.zeros((b, T), np.float32)
+    def run(b, t=T, ids=None):
+        if ids is None:
+            ids, mask = synth_phonemes(b, t, 99)
+        else:
+            mask = None
+        d = np.full(ids.shape, dur, np.int32)
+        z = np.zeros(ids.shape, np.float32)
         t0 = time.perf_counter()
         o = oracle.phoneme2mel(cfg, w, ids, mask, pitch=z, energy=z, duration=d, f32=True)
         return int(o.mel_len.sum()), time.perf_counter() - t0
-    run(4)                                   # spin up the OpenMP pool
-    reps = [run(B) for _ in range(3)]        # the whole workload three times: a few seconds of wall, ~10 min of core time
-    frames, dt = reps[0][0], sum(r[1] for r in reps) / len(reps)
-    cores = len(os.sched_getaffinity(0))
-    return {"value": frames / dt, "unit": "mel-frames/s", "cores": cores, "kind": "port",
-            "sample": f"oracle/es_oracle.c (fp32 accumulate, OpenMP {cores} threads), {cfg.name} ES full forward, "
-                      f"B={B} T={T} D-const {dur}: {frames} frames in {dt:.2f} s (mean of 3 runs)"}
+
+    def sample(threads, b, reps):
+        _omp_threads(threads)
+        run(4)                                   # spin up the OpenMP pool at this width
+        r = [run(b) for _ in range(reps)]
+        return r[0][0], sum(x[1] for x in r) / len(r)
+    b_all = 256 if cfg.name == "tiny" else 64
+    frames, dt = sample(cores, b_all, 3)
+    out = {"value": frames / dt, "unit": "mel-frames/s", "cores": cores, "kind": "port",
+           "sample": f"oracle/es_oracle.c (fp32 accumulate, OpenMP {cores} threads), {cfg.name} ES full forward, "
+                     f"B={b_all} T={T} D-const {dur}: {frames} frames in {dt:.2f} s (mean of 3 runs)"}
+    n24 = min(24, cores)
+    b24 = max(8, b_all // 4)
+    f24, dt24 = sample(n24, b24, 2)
+    out["n24"] = {"value": f24 / dt24, "cores": n24,
+                  "sample": f"same code, OpenMP {n24} threads (reference --threads default), B={b24}: {f24} frames in {dt24:.2f} s"}
+    fox = np.asarray([FOX_IDS], np.int32)
+    for threads, key in ((n24, "b1_fox_latency_ms_n24"), (1, "b1_fox_latency_ms_n1")):
+        _omp_threads(threads)
+        run(1, ids=fox)
+        ts = [run(1, ids=fox)[1] for _ in range(5)]
+        out[key] = float(np.median(ts) * 1e3)
+    out["b1_fox_note"] = (f"B=1, T={len(FOX_IDS)} fox sentence (BASELINE configs[0] shape), D-const {dur}: {len(FOX_IDS) * dur} frames; "
+                          "median of 5")
+    _omp_threads(cores)
+    return out
 
 
 def pmc_traffic(config, B, T, dur):
@@ -97,14 +140,44 @@ def pmc_traffic(config, B, T, dur):
             continue
         if d.get("workload", "").startswith(f"{config} ES B={B} T={T} D-const {dur} "):
             m = d["mel_decoder"]
-            return m["hbm_traffic_bytes_corrected"], os.path.basename(path), m.get("mfma_pipe_utilisation"), m.get("note_scratch")
-    return None, None, None, None
+            return m["hbm_traffic_bytes_corrected"], os.path.basename(path), m.get("mfma_pipe_utilisation")
+    return None, None, None
+
+
+def make_net(cfg, sd, dev):
+    from efficientspeech_amd import build_phoneme2mel, load_numpy_state_dict
+    net = build_phoneme2mel(cfg)
+    load_numpy_state_dict(net, sd)
+    return net.to(dev)
+
+
+def timed_steps(pipe, net, x, steps, warmup, sync_all, event_every, graph):
+    """warm-up, then exactly `steps` steps bracketed by sync_all(); -> (seconds, mean decoder kernel ms, samples)"""
+    with torch.no_grad():
+        for _ in range(warmup):
+            pipe.step(x)
+        pipe.flush()
+        net.decoder.timing = []
+        net.decoder.timing_every = event_every
+        pipe.dec_events = [] if graph else None
+        sync_all()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            pipe.step(x)
+        pipe.flush()
+        sync_all()
+        dt = time.perf_counter() - t0
+    ev = pipe.dec_events if pipe.dec_events else net.decoder.timing
+    net.decoder.timing = None
+    dec_ms = float(np.mean([s.elapsed_time(e) for s, e in ev])) if ev else float("nan")
+    return dt, dec_ms, len(ev)
 
 
 def main():
     a = parse()
+    fp32_lib = os.path.join(ROOT, "efficientspeech_amd", "libesmi_fp32mfma.so")
     if a.exact_fp32:
-        os.environ["ESMI_LIB"] = os.path.join(ROOT, "efficientspeech_amd", "libesmi_fp32mfma.so")
+        os.environ["ESMI_LIB"] = fp32_lib
     rank = int(os.environ.get("RANK", 0))
     local = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
@@ -118,23 +191,24 @@ def main():
         backend = os.environ.get("ESMI_BENCH_BACKEND", "nccl")     # "nccl" is RCCL on ROCm; "gloo" only for the 1-GPU dry run
         dist.init_process_group(backend, **({"device_id": dev} if backend == "nccl" else {}))
 
-    from efficientspeech_amd import CONFIGS, build_phoneme2mel, load_numpy_state_dict
+    from efficientspeech_amd import CONFIGS, _lib
     from efficientspeech_amd.synth import synth_state_dict, synth_phonemes
     from efficientspeech_amd.sharded import ShardedMelPipeline
-    if a.dec_lds_pad:
-        from efficientspeech_amd import _lib
-        _lib.load().esmi_dev_set_decoder_lds_pad(int(a.dec_lds_pad))
     cfg = CONFIGS[a.config]
-    B = a.batch or {"tiny": 256, "small": 256, "base": 512}[a.config]
-    T = a.phonemes or {"tiny": 128, "small": 256, "base": 256}[a.config]
+    B_arg = a.batch or DEFAULT_BATCH[a.config]
+    if a.scaling == "strong":
+        assert B_arg % world == 0, f"global batch {B_arg} not divisible by {world} ranks"
+        B = B_arg // world
+    else:
+        B = B_arg
+    T = a.phonemes or DEFAULT_PHONEMES[a.config]
     L = T * a.dur
     sd = synth_state_dict(cfg, 1234)
-    net = build_phoneme2mel(cfg)
-    load_numpy_state_dict(net, sd)
-    net = net.to(dev)
+    net = make_net(cfg, sd, dev)
     ids, mask = synth_phonemes(B, T, 1234 + rank)
+    # D-const: the padded length is known on the host and exact -> no device->host sync and (N > 1) no MAX all-reduce of it
     x = {"phoneme": torch.from_numpy(ids).to(dev), "phoneme_mask": torch.from_numpy(mask).to(dev),
-         "duration_forced": torch.full((B, T), a.dur, dtype=torch.int32, device=dev), "max_mel_len": L}
+         "duration_forced": torch.full((B, T), a.dur, dtype=torch.int32, device=dev), "max_mel_len": L, "max_mel_len_exact": True}
     pipe = ShardedMelPipeline(net, world_size=world, gather=(world > 1 and not a.no_gather), use_graph=a.graph, two_stream=a.two_stream)
 
     def sync_all():
@@ -144,41 +218,26 @@ def main():
             torch.cuda.synchronize(dev)
 
     launch_note = ""
-    with torch.no_grad():
-        for _ in range(a.warmup):
-            pipe.step(x)
-        pipe.flush()
-        if world == 1 and not (a.graph or a.two_stream or a.no_auto_launch):
-            # untimed: which launch mode is faster on THIS box?  (same kernels, same work; only the stream schedule differs)
-            alt = ShardedMelPipeline(net, world_size=1, gather=False, two_stream=True)
+    if world == 1 and not (a.graph or a.two_stream or a.no_auto_launch):
+        # untimed: which launch mode is faster on THIS box?  (same kernels, same work; only the stream schedule differs)
+        alt = ShardedMelPipeline(net, world_size=1, gather=False, two_stream=True)
 
-            def trial(pl, n):
-                for _ in range(3):
+        def trial(pl, n):
+            with torch.no_grad():
+                for _ in range(5):
                     pl.step(x)
                 pl.flush(); torch.cuda.synchronize(dev)
                 t = time.perf_counter()
                 for _ in range(n):
                     pl.step(x)
                 pl.flush(); torch.cuda.synchronize(dev)
-                return (time.perf_counter() - t) / n
-            n_try = max(10, a.warmup)
-            t_eager, t_two = trial(pipe, n_try), trial(alt, n_try)
-            if t_two < 0.95 * t_eager:
-                pipe, a.two_stream = alt, True
-            launch_note = f"; warm-up trial: eager {t_eager * 1e3:.3f} ms/step, two-stream {t_two * 1e3:.3f} ms/step"
-        net.decoder.timing = []
-        net.decoder.timing_every = a.event_every
-        pipe.dec_events = [] if a.graph else None
-        sync_all()
-        t0 = time.perf_counter()
-        for _ in range(a.steps):
-            pipe.step(x)
-        pipe.flush()
-        sync_all()
-        dt = time.perf_counter() - t0
-    ev = pipe.dec_events if pipe.dec_events else net.decoder.timing
-    net.decoder.timing = None
-    dec_ms = float(np.mean([s.elapsed_time(e) for s, e in ev])) if ev else float("nan")
+            return (time.perf_counter() - t) / n
+        n_try = max(10, a.warmup)
+        t_eager, t_two = trial(pipe, n_try), trial(alt, n_try)
+        if t_two < 0.95 * t_eager:
+            pipe, a.two_stream = alt, True
+        launch_note = f"; warm-up trial: eager {t_eager * 1e3:.3f} ms/step, two-stream {t_two * 1e3:.3f} ms/step"
+    dt, dec_ms, n_ev = timed_steps(pipe, net, x, a.steps, a.warmup, sync_all, a.event_every, a.graph)
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -186,63 +245,107 @@ def main():
     frames_per_step = B * L * world                       # every frame valid under D-const, no padding
     value = frames_per_step * a.steps / dt
     flops, nbytes = DECODER_WORK[a.config]
-    ach_tf = flops * B * L / (dec_ms * 1e-3) / 1e12
     # MelDecoder's first stage (proj Linear + Tanh + LN) is row-wise and runs at PHONEME rate inside the fused
     # variance-adaptor kernel when the shape allows (tiny, T <= 128): the decoder kernel itself then executes this much less
     head_moved = cfg.d4 == 128 and cfg.dx2 == 128 and T <= 128
     kernel_flops = flops - (2 * cfg.d4 * cfg.dx2 if head_moved else 0)
-    from efficientspeech_amd import _lib as _esmi_lib
-    build_cfg = _esmi_lib.load().esmi_build_config().decode()
-    split = {"dec_gemm=split-bf16x3": 6, "dec_gemm=split-f16x2": 3}.get(build_cfg.split(",")[0], 0)    # low-precision MFMA products per fp32 product
-    split_txt = {6: "fp32 operands split exactly into 3 bf16, 6 bf16-MFMA products, fp32 accumulate",
-                 3: "fp32 operands split into 2 f16 pieces (22 significand bits, weights pre-scaled 2^8), 3 f16-MFMA products, fp32 accumulate",
-                 0: ""}[split]
+    build_cfg = _lib.load().esmi_build_config().decode()
+    split = 3 if build_cfg.startswith("dec_gemm=split-f16x2") else 0      # 16-bit MFMA products per fp32-accurate product
+    split_txt = ("fp32 operands split into 2 f16 pieces (22 significand bits, weights pre-scaled 2^8), 3 f16-MFMA products, fp32 "
+                 "accumulate") if split else ""
     # roofline peak of the contraction actually executed: an fp32-accurate product costs `split` products on the 16-bit matrix
     # pipe (dense peak 2500 TFLOP/s, MI355X_MICROARCH.md), or one on the fp32 MFMA path (157.3)
-    peak_tf = 2500.0 / split if split else FP32_PEAK_TFLOPS
-    peak_txt = (f"dense 16-bit MFMA peak 2500 TFLOP/s / {split} products per fp32-accurate product" if split
-                else "v_mfma_f32_32x32x2_f32 peak")
-    traffic, traffic_src, mfma_util, traffic_note = pmc_traffic(a.config, B, T, a.dur)
-    if a.exact_fp32:    # the committed counters were collected on the default (split) build
-        traffic, traffic_src, mfma_util, traffic_note = None, None, None, None
+    peak_tf = F16_PEAK_TFLOPS / split if split else FP32_PEAK_TFLOPS
+    ach_tf = flops * B * L / (dec_ms * 1e-3) / 1e12
+    traffic, traffic_src, mfma_util = (None, None, None) if a.exact_fp32 else pmc_traffic(a.config, B, T, a.dur)
     out = {
         "metric": "mel-frames/sec (whole node), full Phoneme2Mel forward", "value": value, "unit": "mel-frames/s",
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32" + (f" (weight GEMMs: {split_txt})" if split else ""),
+        "higher_is_better": True, "scaling": a.scaling, "vs_baseline": None,
+        "dtype": "f32" + (f" (weight GEMMs: {split_txt})" if split else " (every contraction on v_mfma_f32_32x32x2_f32)"),
         "data": "synthetic",
         "mRTF": value * 256 / 22050,
         "config": {"workload": f"{a.config} ES ({sum(v.size for v in sd.values())} params, seeded random weights), "
                                f"synthetic phoneme batch B={B} T={T} per GPU, injected durations D-const {a.dur} "
                                f"(L={L}), eval path, mel all-gather over RCCL when N>1",
-                   "global_batch": B * world, "phonemes": T, "frames_per_step": frames_per_step,
+                   "global_batch": B * world, "per_gpu_batch": B, "phonemes": T, "frames_per_step": frames_per_step,
                    "parallelism": f"batch-shard x{world}",
-                   "launch": ("hipGraph replay (encoder graph + decoder graph per step)" if a.graph else "eager") + (", encoder/decoder on two streams (steps software-pipelined)" if a.two_stream else "") + launch_note},
+                   "launch": ("hipGraph replay (encoder graph + decoder graph per step)" if a.graph else "eager")
+                             + (", encoder/decoder on two streams (steps software-pipelined)" if a.two_stream else "") + launch_note},
         "roofline": {"bound": "mfma", "kernel": "mel_decoder_kernel", "achieved": ach_tf, "peak": peak_tf,
-                     "unit": "TFLOP/s", "frac": ach_tf / peak_tf, "peak_is": peak_txt,
-                     "frac_of_fp32_mfma_peak": ach_tf / FP32_PEAK_TFLOPS, "traffic": traffic,
-                     "traffic_unit": "HBM bytes per launch (rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE)",
-                     "traffic_source": traffic_src,
-                     "traffic_note": ("includes ~390 MB of register-spill scratch of the 128-VGPR two-workgroups-per-CU build; "
-                                      "see profiles/" + traffic_src) if traffic_note else None,
-                     "mfma_pipe_utilisation_pmc": mfma_util,
-                     "algorithmic_bytes_per_launch": nbytes * B * L,
-                     "kernel_ms": dec_ms, "kernel_ms_samples": len(ev),
-                     "build_config": build_cfg,
-                     "contraction": ((f"fp32-accurate split products on the 16-bit matrix pipe: {split_txt}; {split} "
-                                      f"v_mfma_f32_32x32x16_{'bf16' if split == 6 else 'f16'} per 16 channels; measured error <= that of an "
-                                      "fp32 FMA chain (DESIGN.md 3.1); `peak` is the 16-bit matrix-pipe peak divided by the products per "
-                                      "fp32-accurate product; bench.py --exact-fp32 measures the v_mfma_f32_32x32x2_f32 build") if split else "v_mfma_f32_32x32x2_f32 (exact fp32)"),
-                     "matrix_pipe_16bit": ({"executed_tflops": split * kernel_flops * B * L / (dec_ms * 1e-3) / 1e12, "peak_tflops": 2500.0,
-                                            "frac": split * kernel_flops * B * L / (dec_ms * 1e-3) / 1e12 / 2500.0} if split else None),
+                     "unit": "TFLOP/s", "frac": ach_tf / peak_tf,
+                     "peak_is": (f"dense 16-bit MFMA peak {F16_PEAK_TFLOPS:.0f} TFLOP/s / {split} products per fp32-accurate product"
+                                 if split else "v_mfma_f32_32x32x2_f32 peak"),
+                     "traffic": traffic, "traffic_unit": "HBM bytes per launch (rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE)",
+                     "traffic_source": traffic_src, "mfma_pipe_utilisation_pmc": mfma_util,
+                     "algorithmic_bytes_per_launch": nbytes * B * L, "algorithmic_flops_per_frame": flops,
+                     "algorithmic_bytes_per_frame": nbytes,
+                     "kernel_ms": dec_ms, "kernel_ms_samples": n_ev, "build_config": build_cfg,
+                     "contraction": ((f"{split_txt}; measured error <= that of an fp32 FMA chain (DESIGN.md 3); `peak` is the 16-bit "
+                                      "matrix-pipe peak divided by the products per fp32-accurate product; `exact_fp32` below is the "
+                                      "same step on the v_mfma_f32_32x32x2_f32 build") if split else "v_mfma_f32_32x32x2_f32 (exact fp32)"),
                      "proj_stage_at_phoneme_rate": head_moved, "kernel_flops_per_frame": kernel_flops,
-                     "frac_kernel_flops": kernel_flops * B * L / (dec_ms * 1e-3) / 1e12 / peak_tf, "algorithmic_flops_per_frame": flops, "algorithmic_bytes_per_frame": nbytes,
+                     "frac_kernel_flops": kernel_flops * B * L / (dec_ms * 1e-3) / 1e12 / peak_tf,
                      "hbm_frac": nbytes * B * L / (dec_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                     "note": "MFMA bound (228 FLOP/B >> machine balance); hbm_frac reported "
-                             "because north_star quotes the HBM roofline.  achieved/frac use SURVEY 8d's algorithmic FLOP "
-                             "per frame; frac_kernel_flops counts only what the decoder kernel still computes per frame "
-                             "(its row-wise first stage runs once per phoneme in enc_fuse_va_kernel)"},
+                     "note": "MFMA bound (228 FLOP/B >> machine balance); hbm_frac reported because north_star quotes the HBM "
+                             "roofline.  achieved/frac use SURVEY 8d's algorithmic FLOP per frame; frac_kernel_flops counts only what "
+                             "the decoder kernel still computes per frame (its row-wise first stage runs once per phoneme in "
+                             "enc_fuse_va_kernel)"},
     }
+
+    if world > 1 and pipe.gather:
+        # the exchange by itself: all-gather of one step's mel shards (what every step hides behind the next step's compute)
+        mel_shard = torch.randn((B, L, cfg.n_mel_channels), device=dev)
+        full = torch.empty((B * world, L, cfg.n_mel_channels), device=dev)
+        for _ in range(3):
+            dist.all_gather_into_tensor(full, mel_shard)
+        sync_all()
+        t0 = time.perf_counter()
+        n_g = 10
+        for _ in range(n_g):
+            dist.all_gather_into_tensor(full, mel_shard)
+        sync_all()
+        tg = (time.perf_counter() - t0) / n_g
+        recv = mel_shard.numel() * 4 * (world - 1)
+        out["allgather"] = {"ms": tg * 1e3, "bytes_received_per_rank": recv, "GBps_received_per_rank": recv / tg / 1e9,
+                            "xgmi_peak_GBps": XGMI_LINKS * XGMI_LINK_GBS, "frac_of_7_links": recv / tg / 1e9 / (XGMI_LINKS * XGMI_LINK_GBS),
+                            "frac_of_links_in_use": recv / tg / 1e9 / (min(world - 1, XGMI_LINKS) * XGMI_LINK_GBS),
+                            "note": "all_gather_into_tensor of the (B, L, 80) fp32 mel shards alone, blocking; in the timed steps it "
+                                    "runs on a side stream under the next step's compute"}
+
+    if rank == 0 and world == 1 and not a.no_extras:
+        steps2, warm2 = max(10, a.steps // 2), max(5, a.warmup // 2)
+        # ---- decoder only: MelDecoder.forward on frame-rate features ~ N(0,1), in-kernel proj stage
+        g = torch.Generator(device=dev).manual_seed(7)
+        feats = torch.randn((B, L, cfg.d4), device=dev, generator=g)
+        with torch.no_grad():
+            for _ in range(warm2):
+                net.decoder(feats)
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for _ in range(steps2):
+                net.decoder(feats)
+            torch.cuda.synchronize(dev)
+            td = (time.perf_counter() - t0) / steps2
+        del feats
+        out["decoder_only"] = {"frames_per_s": B * L / td, "ms": td * 1e3, "steps": steps2,
+                               "achieved_tflops": flops * B * L / td / 1e12, "frac": flops * B * L / td / 1e12 / peak_tf,
+                               "hbm_frac": nbytes * B * L / td / 1e9 / HBM_PEAK_GBS,
+                               "note": f"MelDecoder.forward alone, features ~ N(0,1) (B={B}, L={L}, {cfg.d4}) resident in HBM, "
+                                       "wall clock over back-to-back launches (includes the proj stage the full forward runs at phoneme rate)"}
+        # ---- the same full step with every contraction on the exact-fp32 MFMA instruction
+        if not a.exact_fp32 and os.path.exists(fp32_lib):
+            with _lib.use_library(fp32_lib):
+                net32 = make_net(cfg, sd, dev)
+                pipe32 = ShardedMelPipeline(net32, world_size=1, gather=False)
+                dt32, dec32, n32 = timed_steps(pipe32, net32, x, steps2, warm2, sync_all, a.event_every, False)
+                cfg32 = _lib.load().esmi_build_config().decode()
+            ach32 = flops * B * L / (dec32 * 1e-3) / 1e12
+            out["exact_fp32"] = {"ms_per_step": dt32 / steps2 * 1e3, "value": frames_per_step * steps2 / dt32, "steps": steps2,
+                                 "kernel_ms": dec32, "kernel_ms_samples": n32, "achieved_tflops": ach32,
+                                 "frac_of_157.3": ach32 / FP32_PEAK_TFLOPS, "build_config": cfg32,
+                                 "library": "efficientspeech_amd/libesmi_fp32mfma.so"}
+            del net32, pipe32
     if rank == 0:
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, sd, T, a.dur)

@@ -5,8 +5,10 @@ The product library is `efficientspeech_amd/libesmi.so`, built for gfx950 by
 or fails to load, `load()` raises.  (tests/ may bind the wave-simulator build of the very
 same sources through `bind()`; nothing in this package does.)
 """
+import contextlib
 import ctypes as C
 import os
+import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("ESMI_LIB") or os.path.join(_HERE, "libesmi.so")   # ESMI_LIB: another build of the same ABI
@@ -29,7 +31,7 @@ class EncoderBlockWeights(C.Structure):
 
 class EncoderBlockShape(C.Structure):
     _fields_ = [(n, C.c_int) for n in ("B", "n_in", "c_in", "c_out", "heads", "kernel", "stride", "expansion", "vocab",
-                                       "mask_pool", "mask_len")]
+                                       "mask_pool", "mask_len", "plan")]
 
 
 class FuseWeights(C.Structure):
@@ -57,17 +59,52 @@ class DecoderShape(C.Structure):
     _fields_ = [(n, C.c_int) for n in ("d4", "dx2", "kernel", "n_blocks", "block_depth", "n_mel")]
 
 
-# esmi_set_fusion() bits (include/esmi.h)
+class ForwardArgs(C.Structure):
+    """esmi_forward_args (include/esmi.h): the whole inference forward behind one call."""
+    _fields_ = [(n, C.c_int) for n in ("B", "T", "depth", "dim", "fuse_kernel", "plan")] + \
+               [("blocks", EncoderBlockWeights * MAX_DEPTH), ("shapes", EncoderBlockShape * MAX_DEPTH), ("embed", fp),
+                ("fuse", FuseWeights), ("pitch", PredictorWeights), ("energy", PredictorWeights), ("duration", PredictorWeights),
+                ("head", DecoderHead), ("dec_blob", fp), ("dec_shape", DecoderShape),
+                ("ids", fp), ("mask", fp), ("dur_forced", fp),
+                ("duration_pred", fp), ("mel_len", fp), ("mel", fp), ("L_out", C.c_int), ("lmax_host", C.c_int), ("lmax_dev", fp),
+                ("pitch_pred", fp), ("energy_pred", fp), ("pitch_idx", fp), ("energy_idx", fp), ("dur", fp), ("cum", fp),
+                ("arena", fp), ("arena_bytes", C.c_size_t)]
+
+
+# launch-plan bits (include/esmi.h ESMI_FUSE_*): passed per call, the library keeps no state
 FUSE_MERGE_QKV, FUSE_ATTN_FFN, FUSE_VARIANCE, FUSE_SPLIT2, FUSE_BLOCK, FUSE_ALL = 1, 2, 4, 8, 16, 31
 
+
+_tls = threading.local()
+
+
+def current_plan():
+    """Launch plan the module mirrors pass to the C-ABI on this thread (default: everything fused)."""
+    return getattr(_tls, "plan", FUSE_ALL)
+
+
+@contextlib.contextmanager
+def launch_plan(mask):
+    """Thread-local override of the launch plan (tests / ablation): `with _lib.launch_plan(0): net(x)` runs one kernel per
+    reference op.  Nothing global is touched: the mask travels as an argument of each C-ABI call."""
+    old = current_plan()
+    _tls.plan = int(mask) & FUSE_ALL
+    try:
+        yield
+    finally:
+        _tls.plan = old
+
 EXPORTS = (
-    "esmi_version", "esmi_backend", "esmi_build_config", "esmi_set_fusion", "esmi_fuse_variance_adaptor_workspace_bytes",
+    "esmi_version", "esmi_backend", "esmi_build_config", "esmi_fuse_variance_adaptor_workspace_bytes",
     "esmi_fuse_variance_adaptor_f32", "esmi_pack_conv_weight_f32", "esmi_pack_convT_weight_f32",
     "esmi_encoder_block_workspace_bytes", "esmi_encoder_block_f32", "esmi_pool_mask_u8",
     "esmi_fuse_workspace_bytes", "esmi_fuse_f32", "esmi_variance_adaptor_workspace_bytes",
     "esmi_variance_adaptor_f32", "esmi_length_regulate_i32", "esmi_length_regulator_indices_i32",
     "esmi_upsample_f32", "esmi_mel_decoder_blob_bytes", "esmi_mel_decoder_pack_f32", "esmi_mel_decoder_f32",
     "esmi_mask_rows_f32", "esmi_pack_bfrag_floats", "esmi_pack_bfrag_f32", "esmi_compose_merge_f32", "esmi_max_i32",
+    "esmi_self_attention_workspace_bytes", "esmi_self_attention_f32", "esmi_mixffn_workspace_bytes", "esmi_mixffn_f32",
+    "esmi_acoustic_decoder_f32", "esmi_bucket_embedding_f32", "esmi_split_weight_limit", "esmi_absmax_f32",
+    "esmi_forward_arena_bytes", "esmi_phoneme2mel_forward_f32",
 )
 
 
@@ -93,12 +130,10 @@ def bind(lib):
     lib.esmi_variance_adaptor_workspace_bytes.argtypes = [i, i, i]
     lib.esmi_variance_adaptor_workspace_bytes.restype = sz
     lib.esmi_variance_adaptor_f32.argtypes = [P(PredictorWeights)] * 3 + [i, i, i] + [fp] * 11 + [fp, sz, fp]
-    lib.esmi_set_fusion.argtypes = [i]
-    lib.esmi_set_fusion.restype = i
     lib.esmi_fuse_variance_adaptor_workspace_bytes.argtypes = [i, i, i, i]
     lib.esmi_fuse_variance_adaptor_workspace_bytes.restype = sz
     lib.esmi_fuse_variance_adaptor_f32.argtypes = [P(FuseWeights), i, i, i, i, i, P(fp), P(i)] + [P(PredictorWeights)] * 3 + \
-        [fp] * 13 + [P(DecoderHead), fp] + [fp, sz, fp]
+        [fp] * 13 + [P(DecoderHead), fp, i] + [fp, sz, fp]
     lib.esmi_max_i32.argtypes = [fp, i, fp, fp]
     lib.esmi_length_regulate_i32.argtypes = [fp, i, i, fp, fp, fp, fp]
     lib.esmi_length_regulator_indices_i32.argtypes = [fp, i, i, i, fp, fp]
@@ -108,9 +143,23 @@ def bind(lib):
     lib.esmi_mel_decoder_pack_f32.argtypes = [P(DecoderWeights), P(DecoderShape), fp, fp]
     lib.esmi_mel_decoder_f32.argtypes = [fp, P(DecoderShape), fp, fp, fp, fp, fp, i, i, i, i, i, fp, fp]
     lib.esmi_mask_rows_f32.argtypes = [fp, fp, C.c_int64, i, fp]
+    lib.esmi_self_attention_workspace_bytes.argtypes = [i, i, i, i]
+    lib.esmi_self_attention_workspace_bytes.restype = sz
+    lib.esmi_self_attention_f32.argtypes = [fp, fp, fp, i, i, i, i, fp, fp, fp, sz, fp]
+    lib.esmi_mixffn_workspace_bytes.argtypes = [i, i, i, i]
+    lib.esmi_mixffn_workspace_bytes.restype = sz
+    lib.esmi_mixffn_f32.argtypes = [fp] * 6 + [i, i, i, i, fp, fp, fp, sz, fp]
+    lib.esmi_acoustic_decoder_f32.argtypes = [P(PredictorWeights), i, i, i, i, fp, i, fp, fp, fp, sz, fp]
+    lib.esmi_bucket_embedding_f32.argtypes = [fp, fp, fp, C.c_int64, i, fp, fp, fp]
+    lib.esmi_split_weight_limit.argtypes = []
+    lib.esmi_split_weight_limit.restype = C.c_float
+    lib.esmi_absmax_f32.argtypes = [fp, C.c_int64, fp, fp]
+    lib.esmi_forward_arena_bytes.argtypes = [P(ForwardArgs)]
+    lib.esmi_forward_arena_bytes.restype = sz
+    lib.esmi_phoneme2mel_forward_f32.argtypes = [P(ForwardArgs), i, fp]
     for name in EXPORTS:
         fn = getattr(lib, name)
-        if fn.restype is C.c_int and name not in ("esmi_version", "esmi_set_fusion"):
+        if fn.restype is C.c_int and name != "esmi_version":
             fn.errcheck = _make_check(name)
     return lib
 
@@ -144,6 +193,19 @@ def load():
                 "There is no CPU fallback for this path.")
         _LIB = bind(C.CDLL(LIB_PATH))
     return _LIB
+
+
+@contextlib.contextmanager
+def use_library(path):
+    """Bind another build of the SAME ABI (e.g. libesmi_fp32mfma.so) for the duration of the block.  Packed weight blobs are
+    only valid for the library that made them: build the modules used inside the block inside the block."""
+    global _LIB
+    old = _LIB
+    _LIB = bind(C.CDLL(os.path.abspath(path)))
+    try:
+        yield _LIB
+    finally:
+        _LIB = old
 
 
 def backend(lib=None):

@@ -15,11 +15,6 @@
 #include "mel_decoder.h"
 #include "small_kernels.h"
 
-#ifndef ESMI_DEC_NW128
-#define ESMI_DEC_NW128 8   // waves per decoder window at dx2 = 128.  8: one workgroup per CU (235 VGPRs, no spill).
-                           // 4 would put two workgroups on a CU, but hipcc spills 212 VGPRs there: 700 vs 560 us.
-#endif
-
 using namespace esmi;
 
 namespace {
@@ -30,6 +25,25 @@ inline int launch_status() {
     return e == hipSuccess ? ESMI_OK : (int)e;
 }
 inline size_t align256(size_t n) { return (n + 255) & ~(size_t)255; }
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a PER-DEVICE setting: remember per (instantiation, device ordinal) that
+// it was made (once: keeps the call out of hipGraph captures).  `done` is one static table per call site.
+constexpr int kMaxDevices = 64;
+struct AttrOnce { bool done[kMaxDevices] = {}; };
+inline int raise_lds_limit(const void* fn, AttrOnce& once) {
+#ifndef ESMI_WAVESIM
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return (int)e;
+    if (dev < 0 || dev >= kMaxDevices) return ESMI_ERR_UNSUPPORTED;
+    if (!once.done[dev]) {
+        e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return (int)e;
+        once.done[dev] = true;
+    }
+#endif
+    return ESMI_OK;
+}
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 ConvGemmP conv_defaults() {
@@ -85,8 +99,6 @@ int launch_attn(const AttnP& p, hipStream_t st) {
 
 inline int conv_out_len(int n, int k, int stride, int pad) { return (n + 2 * pad - k) / stride + 1; }
 
-int g_dec_lds_pad = 0;         // esmi_dev_set_decoder_lds_pad(): extra dynamic LDS per decoder workgroup (limits workgroups per CU)
-int g_fusion = ESMI_FUSE_ALL;   // esmi_set_fusion(): bit mask of enabled wave-chain stages
 
 // E1: merge conv + 1x1 + qkv in one launch.  Returns ESMI_ERR_UNSUPPORTED when no instantiation fits.
 int launch_enc_merge_qkv(const EncMergeP& p, int c_in, int c_out, hipStream_t st) {
@@ -110,10 +122,10 @@ bool enc_attn_ffn_supported(int C, int N, int expansion) {
 
 // Whole encoder block (merge conv + qkv + attention + MixFFN) in one launch: sequences one workgroup covers, shapes
 // whose q/k/v tile fits in LDS.  Returns ESMI_ERR_UNSUPPORTED otherwise (-> enc_merge_qkv + enc_attn_ffn launches).
-int launch_enc_block(const EncAttnFfnP& p, int expansion, int c_in, hipStream_t st) {
+int launch_enc_block(const EncAttnFfnP& p, int expansion, int c_in, int plan, hipStream_t st) {
     if ((p.C & 31) || (c_in & 31) || p.N > 128) return ESMI_ERR_UNSUPPORTED;
     const int nc = p.C / 32, nci = c_in / 32, nkt = p.N <= 64 ? 2 : 4;
-    if (p.h == 2 && nc == 2 && expansion == 1 && (g_fusion & ESMI_FUSE_SPLIT2)) {   // two waves per row tile when rows are scarce
+    if (p.h == 2 && nc == 2 && expansion == 1 && (plan & ESMI_FUSE_SPLIT2)) {   // two waves per row tile when rows are scarce
         int nw, wgs, useful, halo;
         enc_attn_ffn_split_plan(p.N, &nw, &wgs, &useful, &halo);
         if ((long)p.B * wgs * 2 * nw <= 1024) {
@@ -122,13 +134,8 @@ int launch_enc_block(const EncAttnFfnP& p, int expansion, int c_in, hipStream_t 
             EncAttnFfnP q = p;
             q.wgs_per_b = 1; q.useful = useful; q.halo = 0;
             dim3 grid(p.B), block(128 * nw);
-            static bool attr_set = false;   // once: keeps the call out of hipGraph captures
-            if (!attr_set) {
-                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(enc_attn_ffn_split_kernel<2, 2, 1, 1, 1, 2>),
-                                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-                if (e != hipSuccess) return (int)e;
-                attr_set = true;
-            }
+            static AttrOnce once;
+            if (int rc = raise_lds_limit(reinterpret_cast<const void*>(enc_attn_ffn_split_kernel<2, 2, 1, 1, 1, 2>), once)) return rc;
             ESMI_LAUNCH((enc_attn_ffn_split_kernel<2, 2, 1, 1, 1, 2>), grid, block, lds, st, q);   // N <= 64 here: NKT = 2
             return launch_status();
         }
@@ -143,13 +150,8 @@ int launch_enc_block(const EncAttnFfnP& p, int expansion, int c_in, hipStream_t 
     dim3 grid(p.B), block(64 * nw);
 #define ESMI_EB(NKT, NC, E, NCI, KT, ST) \
     if (nkt == NKT && nc == NC && expansion == E && nci == NCI && p.m.k == KT && p.m.stride == ST) {                           \
-        static bool attr_set = false; /* once per instantiation: keeps the call out of hipGraph captures */                    \
-        if (!attr_set) {                                                                                                       \
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(enc_attn_ffn_kernel<NKT, NC, E, NCI, KT, ST>),    \
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                       \
-            if (e != hipSuccess) return (int)e;                                                                                \
-            attr_set = true;                                                                                                   \
-        }                                                                                                                      \
+        static AttrOnce once; /* per instantiation */                                                                          \
+        if (int rc = raise_lds_limit(reinterpret_cast<const void*>(enc_attn_ffn_kernel<NKT, NC, E, NCI, KT, ST>), once)) return rc; \
         ESMI_LAUNCH((enc_attn_ffn_kernel<NKT, NC, E, NCI, KT, ST>), grid, block, lds, st, q);                                  \
         return launch_status();                                                                                                \
     }
@@ -161,12 +163,12 @@ int launch_enc_block(const EncAttnFfnP& p, int expansion, int c_in, hipStream_t 
 }
 
 // E2: attention + proj + LN1 + MixFFN + LN2 in one launch.
-int launch_enc_attn_ffn(const EncAttnFfnP& p, int expansion, hipStream_t st) {
+int launch_enc_attn_ffn(const EncAttnFfnP& p, int expansion, int plan, hipStream_t st) {
     if ((p.C & 31) || p.N > 256) return ESMI_ERR_UNSUPPORTED;
     const int nc = p.C / 32, nkt = p.N <= 64 ? 2 : (p.N <= 128 ? 4 : 8);
     int nw, wgs, useful, halo;
     EncAttnFfnP q = p;
-    if (p.h == 2 && nc == 2 && expansion == 1 && (g_fusion & ESMI_FUSE_SPLIT2)) {   // two waves per row tile when rows are scarce
+    if (p.h == 2 && nc == 2 && expansion == 1 && (plan & ESMI_FUSE_SPLIT2)) {   // two waves per row tile when rows are scarce
         enc_attn_ffn_split_plan(p.N, &nw, &wgs, &useful, &halo);
         if ((long)p.B * wgs * 2 * nw <= 1024 && nkt <= 4) {
             q.wgs_per_b = wgs; q.useful = useful; q.halo = halo;
@@ -183,13 +185,9 @@ int launch_enc_attn_ffn(const EncAttnFfnP& p, int expansion, hipStream_t st) {
     const int lds = (32 * nw + 2) * (p.C * expansion + 4) * (int)sizeof(float);
 #define ESMI_E2(NKT, NC, E) \
     if (nkt == NKT && nc == NC && expansion == E) {                                                                            \
-        static bool attr_set = false; /* once per instantiation: keeps the call out of hipGraph captures */                    \
-        if (!attr_set && lds > 48 * 1024) {                                                                                    \
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(enc_attn_ffn_kernel<NKT, NC, E>),                 \
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                       \
-            if (e != hipSuccess) return (int)e;                                                                                \
-            attr_set = true;                                                                                                   \
-        }                                                                                                                      \
+        static AttrOnce once; /* per instantiation */                                                                          \
+        if (lds > 48 * 1024)                                                                                                   \
+            if (int rc = raise_lds_limit(reinterpret_cast<const void*>(enc_attn_ffn_kernel<NKT, NC, E>), once)) return rc;     \
         ESMI_LAUNCH((enc_attn_ffn_kernel<NKT, NC, E>), grid, block, lds, st, q);                                               \
         return launch_status();                                                                                                \
     }
@@ -198,6 +196,20 @@ int launch_enc_attn_ffn(const EncAttnFfnP& p, int expansion, hipStream_t st) {
 #undef ESMI_E2K
 #undef ESMI_E2
     return ESMI_ERR_UNSUPPORTED;
+}
+
+// does the fused Fuse + variance-adaptor chain kernel serve this call?  (needs the packed weights and one of its instantiations)
+bool fuse_va_chain_ok(const esmi_fuse_weights* fw, int depth, int dim, int kernel, int n0, int T, const esmi_predictor_weights* pitch,
+                      const esmi_predictor_weights* energy, const esmi_predictor_weights* duration, int plan) {
+    bool chain = (plan & ESMI_FUSE_VARIANCE) && (dim == 32 || dim == 64) && (kernel == 3 || kernel == 5) && n0 == T && fw->fuse_wp &&
+                 pitch->conv1_wp && pitch->conv2_wp && energy->conv1_wp && energy->conv2_wp && duration->conv1_wp &&
+                 duration->conv2_wp;
+    for (int i = 0; i < depth && chain; ++i) chain = fw->mlp_wp[i] && (i == 0 || fw->up_wp[i]);
+    return chain;
+}
+// ... and can it also produce the mel decoder's first stage at phoneme rate?
+bool fuse_va_head_ok(bool chain, int dim, const esmi_decoder_head* head) {
+    return chain && head && head->proj_wp && dim == 32 && head->d4 == 128 && head->dx2 == 128;
 }
 
 struct EncWs {
@@ -221,9 +233,6 @@ EncWs enc_ws(const esmi_encoder_block_shape* s) {
 
 }  // namespace
 
-// development hook: pad the decoder's dynamic LDS so that fewer workgroups fit on a CU (two-stream co-residency experiments)
-extern "C" void esmi_dev_set_decoder_lds_pad(int bytes) { g_dec_lds_pad = bytes < 0 ? 0 : bytes; }
-
 #ifdef ESMI_CHAIN_TRACE
 __device__ long long* g_chain_trace_dev = nullptr;
 extern "C" void esmi_dev_set_chain_trace(long long* ptr) {
@@ -236,12 +245,6 @@ extern "C" void esmi_dev_set_trace(long long* ptr) { g_esmi_trace = ptr; }
 #endif
 
 extern "C" {
-
-int esmi_set_fusion(int enabled) {
-    const int old = g_fusion;
-    g_fusion = enabled & ESMI_FUSE_ALL;
-    return old;
-}
 
 int esmi_version(void) { return ESMI_VERSION; }
 const char* esmi_backend(void) {
@@ -260,8 +263,6 @@ const char* esmi_build_config(void) {
 #endif
 #if ESMI_DEC_SPLIT == 2
     return "dec_gemm=split-f16x2" ESMI_CFG_ENC_;
-#elif ESMI_DEC_SPLIT == 1
-    return "dec_gemm=split-bf16x3" ESMI_CFG_ENC_;
 #else
     return "dec_gemm=fp32-mfma" ESMI_CFG_ENC_;
 #endif
@@ -286,6 +287,9 @@ size_t esmi_pack_bfrag_floats(int n, int k, int taps) {
 }
 int esmi_pack_bfrag_f32(const float* src, float* dst, int n, int k, int taps, esmi_stream_t stream) {
     if (!src || !dst || n <= 0 || k <= 0 || taps <= 0 || (k & 7)) return ESMI_ERR_ARG;
+#if ESMI_CHAIN_SPLIT
+    if (k & 31) return ESMI_ERR_UNSUPPORTED;   // the split-f16 packing works on groups of 32 channels (two 16-channel MFMA steps)
+#endif
     const long tot = (long)esmi_pack_bfrag_floats(n, k, taps);
     ESMI_LAUNCH(pack_bfrag_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, S(stream), src, dst, n, k, (n + 31) / 32, taps);
     return launch_status();
@@ -312,6 +316,7 @@ int esmi_encoder_block_f32(const esmi_encoder_block_weights* w, const esmi_encod
                            size_t workspace_bytes, esmi_stream_t stream) {
     if (!w || !s || !x_out || !workspace) return ESMI_ERR_ARG;
     if (!ids && !x_in) return ESMI_ERR_ARG;
+    const int plan = s->plan & ESMI_FUSE_ALL;
     const EncWs ws = enc_ws(s);
     if (workspace_bytes < ws.total) return ESMI_ERR_WORKSPACE;
     char* wsb = static_cast<char*>(workspace);
@@ -330,7 +335,7 @@ int esmi_encoder_block_f32(const esmi_encoder_block_weights* w, const esmi_encod
     // With the fused second stage, x (the block input after the merge convs) lives in scratch and the final
     // result is written straight to x_out: tiles read their neighbours' x rows, so in-place is not possible.
     const bool packed = w->merge_cwp && w->qkv_wp && w->proj_wp && w->mlp1_wp && w->conv_wp && w->mlp2_wp;
-    const bool fused2 = packed && (g_fusion & ESMI_FUSE_ATTN_FFN) && enc_attn_ffn_supported(C, n, s->expansion);
+    const bool fused2 = packed && (plan & ESMI_FUSE_ATTN_FFN) && enc_attn_ffn_supported(C, n, s->expansion);
     float* x_mid = fused2 ? y1 : x_out;
     EncMergeP m;
     memset(&m, 0, sizeof m);
@@ -346,14 +351,14 @@ int esmi_encoder_block_f32(const esmi_encoder_block_weights* w, const esmi_encod
     f.mlp2_w = w->mlp2_wp; f.mlp2_b = w->mlp2_b; f.ln2_g = w->ln2_g; f.ln2_b = w->ln2_b;
     f.mask = mask; f.out = x_out;
     f.mask_pool = s->mask_pool > 0 ? s->mask_pool : 1; f.mask_len = s->mask_pool > 0 ? s->mask_len : n;
-    if (fused2 && (g_fusion & ESMI_FUSE_MERGE_QKV) && (g_fusion & ESMI_FUSE_BLOCK)) {   // the whole block in one launch
+    if (fused2 && (plan & ESMI_FUSE_MERGE_QKV) && (plan & ESMI_FUSE_BLOCK)) {   // the whole block in one launch
         f.m = m;
         f.x = nullptr; f.qkv = nullptr;
-        rc = launch_enc_block(f, s->expansion, s->c_in, st);
+        rc = launch_enc_block(f, s->expansion, s->c_in, plan, st);
         if (rc != ESMI_ERR_UNSUPPORTED) return rc;
         f.x = x_mid; f.qkv = qkv;
     }
-    if (packed && (g_fusion & ESMI_FUSE_MERGE_QKV)) {   // E1: merge conv + 1x1 + qkv as one wave-chain kernel
+    if (packed && (plan & ESMI_FUSE_MERGE_QKV)) {   // E1: merge conv + 1x1 + qkv as one wave-chain kernel
         rc = launch_enc_merge_qkv(m, s->c_in, C, st);
         if (rc == ESMI_OK) fused1 = true;
         else if (rc != ESMI_ERR_UNSUPPORTED) return rc;
@@ -378,7 +383,7 @@ int esmi_encoder_block_f32(const esmi_encoder_block_weights* w, const esmi_encod
         if ((rc = launch_convgemm(p, st))) return rc;
     }
     if (fused2) {   // E2: attention + proj + LN1 + MixFFN + LN2 as one wave-chain kernel
-        return launch_enc_attn_ffn(f, s->expansion, st);
+        return launch_enc_attn_ffn(f, s->expansion, plan, st);
     }
     if (mask && s->mask_pool > 1) {   // the one-kernel-per-op plan takes a pooled (B, n) mask: blocks.py:51-57
         uint8_t* pm = reinterpret_cast<uint8_t*>(wsb + ws.pmask);
@@ -512,18 +517,15 @@ int esmi_fuse_variance_adaptor_f32(const esmi_fuse_weights* fw, int depth, int d
                                    const uint8_t* mask, const float* pitch_target, const float* energy_target,
                                    const int32_t* duration_target, float* feat, float* pitch_pred, float* energy_pred,
                                    float* duration_pred, int32_t* pitch_idx, int32_t* energy_idx, int32_t* dur,
-                                   int32_t* cum, int32_t* mel_len, const esmi_decoder_head* head, float* h0,
+                                   int32_t* cum, int32_t* mel_len, const esmi_decoder_head* head, float* h0, int plan,
                                    void* workspace, size_t workspace_bytes, esmi_stream_t stream) {
     if ((cum == nullptr) != (mel_len == nullptr)) return ESMI_ERR_ARG;
     if (h0 && (!head || !head->proj_wp || !head->proj_b || !head->ln_g || !head->ln_b)) return ESMI_ERR_ARG;
     if (!fw || !feats || !n_i || !pitch || !energy || !duration || !feat || !pitch_pred || !energy_pred ||
         !duration_pred || !dur || depth < 1 || depth > ESMI_MAX_DEPTH)
         return ESMI_ERR_ARG;
-    bool chain = (g_fusion & ESMI_FUSE_VARIANCE) && (dim == 32 || dim == 64) && (kernel == 3 || kernel == 5) && n_i[0] == T && fw->fuse_wp &&
-                 pitch->conv1_wp && pitch->conv2_wp && energy->conv1_wp && energy->conv2_wp && duration->conv1_wp &&
-                 duration->conv2_wp;
-    for (int i = 0; i < depth && chain; ++i) chain = fw->mlp_wp[i] && (i == 0 || fw->up_wp[i]);
-    if (h0 && !(chain && dim == 32 && head->d4 == 128 && head->dx2 == 128)) return ESMI_ERR_UNSUPPORTED;
+    const bool chain = fuse_va_chain_ok(fw, depth, dim, kernel, n_i[0], T, pitch, energy, duration, plan);
+    if (h0 && !fuse_va_head_ok(chain, dim, head)) return ESMI_ERR_UNSUPPORTED;
     for (int i = 1; i < depth && chain; ++i)
         if ((n_i[i] - 1) * (1 << i) + kernel < T) return ESMI_ERR_UNSUPPORTED;   // torch.cat would raise in the reference
     if (chain) {
@@ -553,16 +555,11 @@ int esmi_fuse_variance_adaptor_f32(const esmi_fuse_weights* fw, int depth, int d
         dim3 grid(B * p.wgs_per_b), block(64 * nw);
         if (h0) { p.head_w = head->proj_wp; p.head_b = head->proj_b; p.head_g = head->ln_g; p.head_beta = head->ln_b; p.h0 = h0; }
         const int lds = fuse_va_lds_floats(dim, depth, nw, h0 != nullptr) * (int)sizeof(float);
-        static bool attr_set = false;   // once: keeps the call out of hipGraph captures
-        if (!attr_set) {
-            const void* fns[4] = {reinterpret_cast<const void*>(enc_fuse_va_kernel<1, 3>), reinterpret_cast<const void*>(enc_fuse_va_kernel<2, 3>),
-                                  reinterpret_cast<const void*>(enc_fuse_va_kernel<1, 5>), reinterpret_cast<const void*>(enc_fuse_va_kernel<2, 5>)};
-            for (const void* fn : fns) {
-                hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-                if (e != hipSuccess) return (int)e;
-            }
-            attr_set = true;
-        }
+        static AttrOnce once[4];
+        const void* fns[4] = {reinterpret_cast<const void*>(enc_fuse_va_kernel<1, 3>), reinterpret_cast<const void*>(enc_fuse_va_kernel<2, 3>),
+                              reinterpret_cast<const void*>(enc_fuse_va_kernel<1, 5>), reinterpret_cast<const void*>(enc_fuse_va_kernel<2, 5>)};
+        for (int q = 0; q < 4; ++q)
+            if (int rc = raise_lds_limit(fns[q], once[q])) return rc;
         if (dim == 32 && kernel == 3) ESMI_LAUNCH((enc_fuse_va_kernel<1, 3>), grid, block, lds, S(stream), p);
         else if (dim == 64 && kernel == 3) ESMI_LAUNCH((enc_fuse_va_kernel<2, 3>), grid, block, lds, S(stream), p);
         else if (dim == 32) ESMI_LAUNCH((enc_fuse_va_kernel<1, 5>), grid, block, lds, S(stream), p);
@@ -579,6 +576,111 @@ int esmi_fuse_variance_adaptor_f32(const esmi_fuse_weights* fw, int depth, int d
                                    dur, static_cast<char*>(workspace) + fws, workspace_bytes - fws, stream);
     if (rc || !cum) return rc;
     ESMI_LAUNCH(length_regulate_kernel, dim3(B), dim3(64), 0, S(stream), dur, T, cum, mel_len, (int*)nullptr);
+    return launch_status();
+}
+
+float esmi_split_weight_limit(void) {
+#if ESMI_CHAIN_SPLIT || ESMI_DEC_SPLIT
+    return 65504.0f / kF16WScale;   // 2^8 * W must stay a finite binary16 number
+#else
+    return __builtin_huge_valf();
+#endif
+}
+
+int esmi_absmax_f32(const float* x, int64_t n, float* out, esmi_stream_t stream) {
+    if (!x || !out || n <= 0) return ESMI_ERR_ARG;
+    hipError_t e = hipMemsetAsync(out, 0, sizeof(float), S(stream));
+    if (e != hipSuccess) return (int)e;
+    const long blocks = (n + 256L * 8 - 1) / (256L * 8);
+    ESMI_LAUNCH(absmax_kernel, dim3((unsigned)(blocks > 1024 ? 1024 : blocks)), dim3(256), 0, S(stream), x, (long)n, reinterpret_cast<int*>(out));
+    return launch_status();
+}
+
+// ------------------------------------------------------------------ module-level forwards (one kernel per reference op)
+size_t esmi_self_attention_workspace_bytes(int B, int N, int C, int heads) {
+    if (B <= 0 || N <= 0 || C <= 0 || heads <= 0) return 0;
+    const size_t rows = (size_t)B * N;
+    return align256(rows * 3 * heads * C * 4) + align256(rows * heads * C * 4);
+}
+
+int esmi_self_attention_f32(const float* qkv_w, const float* proj_w, const float* proj_b, int B, int N, int C, int heads,
+                            const float* x, float* out, void* workspace, size_t workspace_bytes, esmi_stream_t stream) {
+    if (!qkv_w || !proj_w || !proj_b || !x || !out || !workspace || B <= 0 || N <= 0 || C <= 0 || heads <= 0) return ESMI_ERR_ARG;
+    if (workspace_bytes < esmi_self_attention_workspace_bytes(B, N, C, heads)) return ESMI_ERR_WORKSPACE;
+    float* qkv = static_cast<float*>(workspace);
+    float* ctx = reinterpret_cast<float*>(static_cast<char*>(workspace) + align256((size_t)B * N * 3 * heads * C * 4));
+    hipStream_t st = S(stream);
+    int rc;
+    ConvGemmP p = conv_defaults();   // qkv Linear (bias-free), blocks.py:44
+    p.B = B; p.n_in = N; p.c_in = C; p.n_out = N; p.c_out = 3 * heads * C;
+    p.A = x; p.lda = C; p.W = qkv_w; p.out = qkv; p.ldo = 3 * heads * C;
+    if ((rc = launch_convgemm(p, st))) return rc;
+    AttnP a;                          // softmax(q k^T scale) v, blocks.py:49-64 (scores not masked)
+    a.qkv = qkv; a.B = B; a.N = N; a.C = C; a.h = heads; a.ctx = ctx;
+    a.scale = 1.0f / sqrtf((float)(C / heads));
+    if ((rc = launch_attn(a, st))) return rc;
+    p = conv_defaults();              // proj, blocks.py:65
+    p.B = B; p.n_in = N; p.c_in = heads * C; p.n_out = N; p.c_out = C;
+    p.A = ctx; p.lda = heads * C; p.W = proj_w; p.bias = proj_b; p.out = out; p.ldo = C;
+    return launch_convgemm(p, st);
+}
+
+size_t esmi_mixffn_workspace_bytes(int B, int N, int C, int expansion) {
+    if (B <= 0 || N <= 0 || C <= 0 || expansion <= 0) return 0;
+    return 2 * align256((size_t)B * N * C * expansion * 4);
+}
+
+int esmi_mixffn_f32(const float* mlp1_w, const float* mlp1_b, const float* conv_w, const float* conv_b, const float* mlp2_w,
+                    const float* mlp2_b, int B, int N, int C, int expansion, const float* x, float* out, void* workspace,
+                    size_t workspace_bytes, esmi_stream_t stream) {
+    if (!mlp1_w || !mlp1_b || !conv_w || !conv_b || !mlp2_w || !mlp2_b || !x || !out || !workspace) return ESMI_ERR_ARG;
+    if (B <= 0 || N <= 0 || C <= 0 || expansion <= 0) return ESMI_ERR_ARG;
+    if (workspace_bytes < esmi_mixffn_workspace_bytes(B, N, C, expansion)) return ESMI_ERR_WORKSPACE;
+    const int E = C * expansion;
+    float* m1 = static_cast<float*>(workspace);
+    float* m2 = reinterpret_cast<float*>(static_cast<char*>(workspace) + align256((size_t)B * N * E * 4));
+    hipStream_t st = S(stream);
+    int rc;
+    ConvGemmP p = conv_defaults();   // mlp1, blocks.py:23
+    p.B = B; p.n_in = N; p.c_in = C; p.n_out = N; p.c_out = E;
+    p.A = x; p.lda = C; p.W = mlp1_w; p.bias = mlp1_b; p.out = m1; p.ldo = E;
+    if ((rc = launch_convgemm(p, st))) return rc;
+    p = conv_defaults();              // dense k=3 conv + exact-erf GELU, blocks.py:24-27
+    p.B = B; p.n_in = N; p.c_in = E; p.n_out = N; p.c_out = E; p.k = 3; p.pad = 1;
+    p.A = m1; p.lda = E; p.W = conv_w; p.bias = conv_b; p.act = ACT_GELU; p.out = m2; p.ldo = E;
+    if ((rc = launch_convgemm(p, st))) return rc;
+    p = conv_defaults();              // mlp2, blocks.py:28
+    p.B = B; p.n_in = N; p.c_in = E; p.n_out = N; p.c_out = C;
+    p.A = m2; p.lda = E; p.W = mlp2_w; p.bias = mlp2_b; p.out = out; p.ldo = C;
+    return launch_convgemm(p, st);
+}
+
+int esmi_acoustic_decoder_f32(const esmi_predictor_weights* w, int dim, int B, int T, int duration, const float* x, int ldx,
+                              float* pred, float* features, void* workspace, size_t workspace_bytes, esmi_stream_t stream) {
+    if (!w || !x || !pred || !workspace || dim <= 0 || B <= 0 || T <= 0 || ldx < dim) return ESMI_ERR_ARG;
+    if (duration && !features) return ESMI_ERR_ARG;
+    if (workspace_bytes < esmi_variance_adaptor_workspace_bytes(B, T, dim)) return ESMI_ERR_WORKSPACE;
+    float* t1 = static_cast<float*>(workspace);
+    hipStream_t st = S(stream);
+    ConvGemmP p = conv_defaults();   // conv1 + ReLU -> LN1 -> ReLU, networks.py:152-155
+    p.B = B; p.n_in = T; p.c_in = dim; p.n_out = T; p.c_out = dim; p.k = 3; p.pad = 1;
+    p.A = x; p.lda = ldx; p.W = w->conv1_w; p.bias = w->conv1_b; p.act = ACT_RELU;
+    p.ln_g = w->ln1_g; p.ln_b = w->ln1_b; p.post_relu = 1; p.out = t1; p.ldo = dim;
+    int rc = launch_convgemm(p, st);
+    if (rc) return rc;
+    p = conv_defaults();              // conv2 + ReLU; y = Linear(dim,1) on the PRE-norm2 tensor (:157-160); duration: ReLU + features = LN2
+    p.B = B; p.n_in = T; p.c_in = dim; p.n_out = T; p.c_out = dim; p.k = 3; p.pad = 1;
+    p.A = t1; p.lda = dim; p.W = w->conv2_w; p.bias = w->conv2_b; p.act = ACT_RELU;
+    p.dot_w = w->lin_w; p.dot_b = w->lin_b; p.dot_out = pred; p.dot_relu = duration != 0;
+    if (duration) { p.ln_g = w->ln2_g; p.ln_b = w->ln2_b; p.out = features; p.ldo = dim; }
+    return launch_convgemm(p, st);
+}
+
+int esmi_bucket_embedding_f32(const float* v, const float* bins, const float* emb, int64_t rows, int dim, float* out,
+                              int32_t* idx, esmi_stream_t stream) {
+    if (!v || !bins || !emb || !out || rows <= 0 || dim <= 1) return ESMI_ERR_ARG;
+    const long n = (long)rows * dim;
+    ESMI_LAUNCH(bucket_embed_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, S(stream), v, bins, emb, (long)rows, dim, out, idx);
     return launch_status();
 }
 
@@ -650,10 +752,6 @@ int esmi_mel_decoder_pack_f32(const esmi_decoder_weights* w, const esmi_decoder_
         const long n = (long)(K / 128) * 4 * ntw * 8 * 2 * 256;
         ESMI_LAUNCH(pack_bslice2h_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src,
                     reinterpret_cast<unsigned*>(blob + off), N, K, ntw);
-#elif ESMI_DEC_SPLIT == 1
-        const long n = (long)(K / 128) * 4 * ntw * 8 * 3 * 256;
-        ESMI_LAUNCH(pack_bslice3_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src,
-                    reinterpret_cast<unsigned*>(blob + off), N, K, ntw);
 #else
         const long n = (long)(K / 128) * 4 * ntw * 16 * 256;
         ESMI_LAUNCH(pack_bslice_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src, blob + off, N, K, ntw);
@@ -711,24 +809,123 @@ int esmi_mel_decoder_f32(const float* blob, const esmi_decoder_shape* s, const f
     p.n_tiles = (L_out + p.TL - 1) / p.TL;
     dim3 grid((unsigned)(p.n_tiles * ((B + 7) / 8) * 8)), block(kDecThreads);
     hipStream_t st = S(stream);
-#define ESMI_DEC_CASE(DX2, KD, NW)                                                                                 \
+#define ESMI_DEC_CASE(DX2, KD)                                                                                     \
     {                                                                                                              \
-        const int lds = dec_lds_floats<DX2>(KD) * (int)sizeof(float) + g_dec_lds_pad;                              \
-        static bool attr_set = false; /* once per instantiation: keeps the call out of hipGraph captures */       \
-        if (!attr_set) {                                                                                           \
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mel_decoder_kernel<DX2, KD, NW>),     \
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);           \
-            if (e != hipSuccess) return (int)e;                                                                    \
-            attr_set = true;                                                                                       \
-        }                                                                                                          \
-        ESMI_LAUNCH((mel_decoder_kernel<DX2, KD, NW>), grid, dim3(64 * NW), lds, st, p);                           \
+        const int lds = dec_lds_floats<DX2>(KD) * (int)sizeof(float);                                              \
+        static AttrOnce once; /* per instantiation */                                                              \
+        if (int rc2 = raise_lds_limit(reinterpret_cast<const void*>(mel_decoder_kernel<DX2, KD>), once)) return rc2; \
+        ESMI_LAUNCH((mel_decoder_kernel<DX2, KD>), grid, dim3(kDecThreads), lds, st, p);                           \
     }
-    if (s->dx2 == 128 && s->kernel == 5) ESMI_DEC_CASE(128, 5, ESMI_DEC_NW128)
-    else if (s->dx2 == 128 && s->kernel == 3) ESMI_DEC_CASE(128, 3, ESMI_DEC_NW128)
-    else if (s->dx2 == 256 && s->kernel == 5) ESMI_DEC_CASE(256, 5, 8)
-    else ESMI_DEC_CASE(256, 3, 8)
+    if (s->dx2 == 128 && s->kernel == 5) ESMI_DEC_CASE(128, 5)
+    else if (s->dx2 == 128 && s->kernel == 3) ESMI_DEC_CASE(128, 3)
+    else if (s->dx2 == 256 && s->kernel == 5) ESMI_DEC_CASE(256, 5)
+    else ESMI_DEC_CASE(256, 3)
 #undef ESMI_DEC_CASE
     return launch_status();
+}
+
+// ------------------------------------------------------------------ whole forward behind one call
+namespace {
+struct FwdArena {
+    size_t feats[ESMI_MAX_DEPTH], ws, feat, preds[3], idx[2], dur, cum, h0, total;
+    int n[ESMI_MAX_DEPTH];
+};
+int fwd_arena(const esmi_forward_args* a, FwdArena* o) {
+    if (!a || a->depth < 1 || a->depth > ESMI_MAX_DEPTH || a->B <= 0 || a->T <= 0 || a->dim <= 0) return ESMI_ERR_ARG;
+    size_t off = 0, ws = 0;
+    int n_in = a->T;
+    for (int i = 0; i < a->depth; ++i) {
+        esmi_encoder_block_shape sh = a->shapes[i];
+        sh.B = a->B; sh.n_in = n_in;
+        const int n = conv_out_len(n_in, sh.kernel, sh.stride, sh.kernel / 2);
+        if (n <= 0) return ESMI_ERR_ARG;
+        o->n[i] = n;
+        o->feats[i] = off; off += align256((size_t)a->B * n * sh.c_out * 4);
+        const size_t w = esmi_encoder_block_workspace_bytes(&sh);
+        ws = w > ws ? w : ws;
+        n_in = n;
+    }
+    const size_t wv = esmi_fuse_variance_adaptor_workspace_bytes(a->B, a->T, a->dim, a->depth);
+    ws = wv > ws ? wv : ws;
+    const size_t rows = (size_t)a->B * a->T;
+    o->ws = off; off += align256(ws);
+    o->feat = off; off += align256(rows * 4 * a->dim * 4);
+    for (int q = 0; q < 3; ++q) { o->preds[q] = off; off += align256(rows * 4); }
+    for (int q = 0; q < 2; ++q) { o->idx[q] = off; off += align256(rows * 4); }
+    o->dur = off; off += align256(rows * 4);
+    o->cum = off; off += align256(rows * 4);
+    o->h0 = off; off += a->head.proj_wp ? align256(rows * a->head.dx2 * 4) : 0;
+    o->total = off;
+    return ESMI_OK;
+}
+}  // namespace
+
+size_t esmi_forward_arena_bytes(const esmi_forward_args* a) {
+    FwdArena o;
+    return fwd_arena(a, &o) == ESMI_OK ? o.total : 0;
+}
+
+int esmi_phoneme2mel_forward_f32(const esmi_forward_args* a, int stage, esmi_stream_t stream) {
+    FwdArena o;
+    int rc = fwd_arena(a, &o);
+    if (rc) return rc;
+    if (!a->ids || !a->mel_len || !a->duration_pred || !a->arena || stage < 0 || stage > 2) return ESMI_ERR_ARG;
+    if ((reinterpret_cast<uintptr_t>(a->arena) & 255u) || a->arena_bytes < o.total) return ESMI_ERR_WORKSPACE;
+    char* base = static_cast<char*>(a->arena);
+    auto F = [&](size_t off) { return reinterpret_cast<float*>(base + off); };
+    auto I = [&](size_t off) { return reinterpret_cast<int32_t*>(base + off); };
+    const int B = a->B, T = a->T, plan = a->plan & ESMI_FUSE_ALL;
+    float* feat = F(o.feat);
+    int32_t* cum = a->cum ? a->cum : I(o.cum);
+    float* h0 = a->head.proj_wp ? F(o.h0) : nullptr;
+    const uint8_t* mask = a->mask;
+    if (stage != 2) {
+        const float* x_in = nullptr;
+        int n_in = T;
+        for (int i = 0; i < a->depth; ++i) {
+            esmi_encoder_block_shape sh = a->shapes[i];
+            sh.B = B; sh.n_in = n_in; sh.plan = plan;
+            sh.mask_pool = 1; sh.mask_len = T;
+            if (mask) {   // networks.py:69-70: pool = round(T / n), half to even
+                const double r = (double)T / o.n[i];
+                sh.mask_pool = (int)nearbyint(r);
+                if ((T + sh.mask_pool - 1) / sh.mask_pool != o.n[i]) return ESMI_ERR_UNSUPPORTED;
+            }
+            rc = esmi_encoder_block_f32(&a->blocks[i], &sh, i == 0 ? a->ids : nullptr, i == 0 ? a->embed : nullptr, x_in, mask,
+                                        F(o.feats[i]), base + o.ws, esmi_encoder_block_workspace_bytes(&sh), stream);
+            if (rc) return rc;
+            x_in = F(o.feats[i]);
+            n_in = o.n[i];
+        }
+        const float* feats[ESMI_MAX_DEPTH];
+        for (int i = 0; i < a->depth; ++i) feats[i] = F(o.feats[i]);
+        float* pp = a->pitch_pred ? a->pitch_pred : F(o.preds[0]);
+        float* ep = a->energy_pred ? a->energy_pred : F(o.preds[1]);
+        int32_t* pi = a->pitch_idx ? a->pitch_idx : I(o.idx[0]);
+        int32_t* ei = a->energy_idx ? a->energy_idx : I(o.idx[1]);
+        int32_t* dur = a->dur ? a->dur : I(o.dur);
+        const size_t wsb = esmi_fuse_variance_adaptor_workspace_bytes(B, T, a->dim, a->depth);
+        const bool head_ok = fuse_va_head_ok(fuse_va_chain_ok(&a->fuse, a->depth, a->dim, a->fuse_kernel, o.n[0], T, &a->pitch, &a->energy,
+                                                              &a->duration, plan), a->dim, &a->head);
+        rc = esmi_fuse_variance_adaptor_f32(&a->fuse, a->depth, a->dim, a->fuse_kernel, B, T, feats, o.n, &a->pitch, &a->energy,
+                                            &a->duration, mask, nullptr, nullptr, a->dur_forced, feat, pp, ep, a->duration_pred,
+                                            pi, ei, dur, cum, a->mel_len, head_ok ? &a->head : nullptr, head_ok ? h0 : nullptr, plan,
+                                            base + o.ws, wsb, stream);
+        if (rc) return rc;
+        if (a->lmax_dev && (rc = esmi_max_i32(a->mel_len, B, a->lmax_dev, stream))) return rc;
+    }
+    if (stage != 1) {
+        if (a->L_out <= 0) return ESMI_OK;   // every duration zero: empty mel, nothing to launch
+        if (!a->mel || !a->dec_blob) return ESMI_ERR_ARG;
+        // (a stage-2 call re-derives whether stage 1 produced the phoneme-rate head: the same static test)
+        const bool head_ok = fuse_va_head_ok(fuse_va_chain_ok(&a->fuse, a->depth, a->dim, a->fuse_kernel, o.n[0], T, &a->pitch, &a->energy,
+                                                              &a->duration, plan), a->dim, &a->head);
+        rc = esmi_mel_decoder_f32(a->dec_blob, &a->dec_shape, feat, head_ok ? h0 : nullptr, cum, a->mel_len,
+                                  a->lmax_host < 0 ? a->lmax_dev : nullptr, a->lmax_host, mask != nullptr && B > 1, B, T, a->L_out,
+                                  a->mel, stream);
+        if (rc) return rc;
+    }
+    return ESMI_OK;
 }
 
 }  // extern "C"

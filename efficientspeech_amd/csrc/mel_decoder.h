@@ -33,72 +33,38 @@
 //    such rows are forced to 0 after every LayerNorm;
 //  * rows >= mel_len[b] of the output are zeroed only at the very end (the final masked_fill).
 #pragma once
+#include <type_traits>
+
 #include "esmi_dev.h"
 #include "small_kernels.h"
 
-#ifdef ESMI_ABL_NO_TANH
-#define ESMI_DEC_TANH(x) (x)
-#endif
-#ifndef ESMI_DEC_TANH
-#define ESMI_DEC_TANH tanh_fast_f32
-#endif
-// Build knobs of the dx2 = 128 instantiation (measured on MI355X, tiny ES B=256 T=128, decoder time inside bench.py; the three
-// lines below are from the exact-fp32 build with the proj stage still at frame rate.  Since then, same workload:
-// proj at phoneme rate 0.41 ms, split-bf16x3 contraction 0.31 ms, split-f16x2 0.24 ms, 16-lane LayerNorm rows 0.215 ms;
-// marginal costs by ablation at the 0.24 ms point: LayerNorm 56 us, operand split 29 us, MFMA 15 us, tanh 9 us):
-//   WPS=2 KSUB=16 LOWREG=0 : 235 VGPRs, no spill, ONE workgroup per CU ........ 0.500 ms
-//   WPS=3 KSUB=16 LOWREG=1 : 168 VGPRs, no spill, one workgroup per CU ........ 0.505 ms
-//   WPS=4 KSUB=8  LOWREG=1 : 128 VGPRs, 55 spilled, TWO workgroups per CU ..... 0.477 ms   <- default
-//     (the spill is mostly the 32-register skip tensor, dead during the K loops; it shows as ~390 MB of scratch
-//      traffic per launch in the PMC counters -- profiles/r01_e_pmc_counters.json)
-// Two co-resident workgroups hide part of each other's non-MFMA phases; the gain is small because the resident
-// partner's K loop starves the other's LayerNorm phase (phase traces: 3k -> 11-19k cycles).
-#ifndef ESMI_DEC_RSQRT
-#define ESMI_DEC_RSQRT rsqrt_fast_f32   // v_rsq_f32 (1 ulp); every LayerNorm thread computes it for 4 rows
-#endif
-#ifndef ESMI_DEC_WPS16
-#define ESMI_DEC_WPS16 8      // waves/SIMD of the 16-wave-per-window build (ESMI_DEC_NW128=16): 8 = two workgroups per CU at 64 VGPRs
-#endif
-#ifndef ESMI_DEC_LN_TPR
-#define ESMI_DEC_LN_TPR 16    // LayerNorm threads per row: 16 (4 rows per thread, gain/shift read once per 4 rows), 8 or 4
-#endif
-#ifndef ESMI_DEC_FUSED_LN
-#define ESMI_DEC_FUSED_LN 0   // (measured: 0.2085 vs 0.1928 ms, i.e. slower, kept as an option) bias + tanh + LayerNorm (+ block-end skip LayerNorm) on the accumulators in registers: every wave
-                              // reduces its column slice of a row in-lane, the four slices' (mean, M2) meet in a small LDS
-                              // table (Chan merge); the activations are stored once instead of store / load / store
-#endif
-#ifndef ESMI_DEC_TAPS_IN_REGS
-#define ESMI_DEC_TAPS_IN_REGS 1
-#endif
-#ifndef ESMI_DEC_PRESPLIT
-#define ESMI_DEC_PRESPLIT 1   // split-f16x2 only: the depthwise phase writes its output rows as the two f16 planes (same bytes as
-                              // fp32, in place), so the K loop's A fragments need no conversion (4 waves read every element)
+// Build knobs (defaults = the measured best on MI355X, tiny ES B=256 T=128; history in DESIGN.md 3.1)
+#ifndef ESMI_DEC_SPLIT      // contraction of the pointwise GEMMs (esmi_dev.h):
+#define ESMI_DEC_SPLIT 2    //   0: v_mfma_f32_32x32x2_f32 (exact fp32; the libesmi_fp32mfma.so build)
+#endif                      //   2: fp32 split into 2 f16 (weights pre-scaled by 2^8), 3 products on v_mfma_f32_32x32x16_f16
+#if ESMI_DEC_SPLIT != 0 && ESMI_DEC_SPLIT != 2
+#error "ESMI_DEC_SPLIT must be 0 (fp32 MFMA) or 2 (split f16x2)"
 #endif
 #ifndef ESMI_DEC_WPS
-#define ESMI_DEC_WPS 4      // __launch_bounds__ waves/SIMD (512-thread workgroups: 2 -> 256 VGPRs, 4 -> 128 VGPRs)
+#define ESMI_DEC_WPS 4      // __launch_bounds__ waves/SIMD of the dx2 = 128 kernel (512-thread workgroups: 4 -> 128 VGPRs, two workgroups per CU)
 #endif
-#ifndef ESMI_DEC_LOWREG
-#define ESMI_DEC_LOWREG 1   // 1: no cross-phase prefetch (weights, taps, params fetched where used): fewer live registers
-#endif
-#ifndef ESMI_DEC_CHAIN_PRIO
-#define ESMI_DEC_CHAIN_PRIO 0   // wave priority during the non-MFMA phases (exact-fp32 build: +1 % with two workgroups per CU; split-f16 build: -1 %)
-#endif
-#if defined(ESMI_WAVESIM)
-#define ESMI_PRIO(n) do {} while (0)
-#else
-#define ESMI_PRIO(n) do { if (ESMI_DEC_CHAIN_PRIO) __builtin_amdgcn_s_setprio(n); } while (0)
-#endif
-#ifndef ESMI_DEC_NS
-#define ESMI_DEC_NS 4      // column slices per workgroup of the dx2 = 128 build: 4 (two row groups) or 2 (four row groups: half the
-                           // LDS A-fragment reads but twice the weight sub-slices per K loop: measured 0.522 vs 0.484 ms)
-#endif
-#ifndef ESMI_DEC_SPLIT      // contraction of the pointwise GEMMs (esmi_dev.h):
-#define ESMI_DEC_SPLIT 2    //   0: v_mfma_f32_32x32x2_f32 (exact fp32)      1: fp32 split into 3 bf16, 6 products on v_mfma_f32_32x32x16_bf16
-#endif                      //   2: fp32 split into 2 f16 (weights pre-scaled by 2^8), 3 products on v_mfma_f32_32x32x16_f16
 #ifndef ESMI_DEC_KSUB
-#define ESMI_DEC_KSUB (ESMI_DEC_SPLIT ? 4 : 8)   // k-steps (of 8 channels) of the weight slice held in registers at a time (16 = all of
-                                                 // K = 128); split-bf16 path: 4 -> 24 VGPRs of planes (measured: 2: 0.319, 4: 0.309-0.317, 8: 0.323 ms)
+#define ESMI_DEC_KSUB (ESMI_DEC_SPLIT ? 4 : 8)   // un-pipelined contractions (fp32 build, in-kernel proj stage): k-steps (of 8 channels) of weights in registers at a time
 #endif
+#ifndef ESMI_DEC_WD
+#define ESMI_DEC_WD 1       // pipelined K loop: weight fragments in flight, in 16-channel steps (global/L2 -> VGPR ring)
+#endif
+#ifndef ESMI_DEC_AD
+#define ESMI_DEC_AD 1       // pipelined K loop: A fragments in flight, in (step, row tile) items (LDS -> VGPR ring)
+#endif
+#ifndef ESMI_DEC_LN_SPREAD
+#define ESMI_DEC_LN_SPREAD 1
+#endif
+#ifndef ESMI_DEC_YOUNG_PRIO
+#define ESMI_DEC_YOUNG_PRIO 0   // static s_setprio for waves 4-7 (the arbitration losers of every phase on their SIMD)
+#endif
+#define ESMI_DEC_TANH tanh_fast_f32
+#define ESMI_DEC_RSQRT rsqrt_fast_f32   // v_rsq_f32 (1 ulp)
 
 namespace esmi {
 
@@ -119,7 +85,7 @@ struct DecLayout {  // offsets in floats into the packed blob
 inline DecLayout dec_layout(int d4, int dx2, int kd, int n_blocks, int block_depth) {
     DecLayout L;
     long o = 0;
-    constexpr long kWNum = ESMI_DEC_SPLIT == 1 ? 3 : 2;   // matrix storage: three bf16 planes (1.5x), two f16 planes or fp32
+    constexpr long kWNum = 2;   // matrix storage in units of DX2*DX2/2 floats: two f16 planes or fp32 (the same bytes)
     L.proj_w = o; o += (long)d4 * dx2 * kWNum / 2;
     L.proj_b = o; o += dx2;                    // proj_b, proj_g, proj_beta contiguous
     L.proj_g = o; o += dx2;
@@ -159,37 +125,9 @@ __global__ void pack_bslice_kernel(const float* __restrict__ src, float* __restr
     }
 }
 
-// The same slices as three bf16 planes (hi / mid / lo by truncation, esmi_dev.h) in the B layout of
-// v_mfma_f32_32x32x16_bf16: per (chunk c, column slice ns, tile ntw, 16-channel step s, plane p) 64 lanes x 4 dwords:
-//   dst[((((((c*4 + ns)*NTW + ntw)*8 + s)*3 + p)*64 + lane)*4 + w] = {plane_p(W[row][k0 + 1]), plane_p(W[row][k0])},
+// The same slices as two binary16 planes of 2^8 * W (round to nearest; esmi_dev.h) in the B layout of v_mfma_f32_32x32x16_f16:
+// per (chunk c, column slice ns, tile ntw, 16-channel step s, plane p) 64 lanes x 4 dwords,
 //   row = ns*32*NTW + 32*ntw + (lane&31),  k0 = 128*c + 16*s + 8*(lane>>5) + 2*w       (0 for rows >= N)
-__global__ void pack_bslice3_kernel(const float* __restrict__ src, unsigned* __restrict__ dst, int N, int K, int NTW) {
-    const long n = (long)(K / 128) * 4 * NTW * 8 * 3 * 256;
-    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
-        const int wd = (int)(e & 3);
-        const int lane = (int)((e >> 2) & 63);
-        long q = e >> 8;
-        const int pl = (int)(q % 3); q /= 3;
-        const int st = (int)(q & 7); q >>= 3;
-        const int ntw = (int)(q % NTW); q /= NTW;
-        const int ns = (int)(q & 3);
-        const int c = (int)(q >> 2);
-        const int row = ns * 32 * NTW + 32 * ntw + (lane & 31);
-        const int k0 = 128 * c + 16 * st + 8 * (lane >> 5) + 2 * wd;
-        unsigned half[2];
-        for (int j = 0; j < 2; ++j) {
-            const float x = row < N ? src[(long)row * K + k0 + j] : 0.0f;
-            const unsigned h = __builtin_bit_cast(unsigned, x) & 0xFFFF0000u;
-            const float r1 = x - __builtin_bit_cast(float, h);
-            const unsigned m = __builtin_bit_cast(unsigned, r1) & 0xFFFF0000u;
-            const float r2 = r1 - __builtin_bit_cast(float, m);
-            half[j] = pl == 0 ? h : (pl == 1 ? m : (__builtin_bit_cast(unsigned, r2) & 0xFFFF0000u));
-        }
-        dst[e] = half[1] | (half[0] >> 16);
-    }
-}
-
-// ... and as two binary16 planes of 2^8 * W (round to nearest; esmi_dev.h) in the same layout with 2 planes per step:
 //   dst[((((((c*4 + ns)*NTW + ntw)*8 + s)*2 + p)*64 + lane)*4 + w] = {plane_p(W[row][k0 + 1]), plane_p(W[row][k0])}
 __global__ void pack_bslice2h_kernel(const float* __restrict__ src, unsigned* __restrict__ dst, int N, int K, int NTW) {
     const long n = (long)(K / 128) * 4 * NTW * 8 * 2 * 256;
@@ -234,14 +172,9 @@ struct MelDecP {
 
 template <int DX2>
 __host__ __device__ constexpr int dec_lds_floats(int kd) {
-    return (kDecRows + 2 * kDecPadRows) * (DX2 + 4) + (kd + 6) * DX2 + kDecRows + (ESMI_DEC_FUSED_LN ? kDecRows * 8 : 0);
+    return (kDecRows + 2 * kDecPadRows) * (DX2 + 4) + (kd + 6) * DX2 + kDecRows;
 }
 
-// NW = waves per window.  NW = 8: wave (mh = w>>2, ns = w&3) owns 64 rows x DX2/4 columns, one workgroup per CU.
-// NW = 4: wave ns owns all 128 rows x DX2/4 columns; the workgroup fits twice on a CU (76 KB LDS), which would let
-// one workgroup's tanh / LayerNorm / depthwise phases run under the other's K loop -- but with ROCm 7.2's hipcc the
-// 4-wave build needs 256 VGPRs + 212 spilled and is slower (700 vs 560 us); kept selectable for the next round.
-// (Also tried and dropped in round 1: two windows per workgroup in explicit ping-pong -- correct, 330-450 spills.)
 // max_b mel_len[b], by every wave for itself: one coalesced read, no extra launch, no atomics; the result is made
 // wave-uniform (SGPR) at once.
 __device__ __forceinline__ int batch_max_len(const int* __restrict__ mel_len, int B) {
@@ -257,44 +190,42 @@ __device__ __forceinline__ int batch_max_len(const int* __restrict__ mel_len, in
 #endif
 }
 
-template <int DX2, int KD, int NW>
-__global__ __launch_bounds__(64 * NW, (DX2 <= 128 && NW == 8 ? ESMI_DEC_WPS : (NW == 16 ? ESMI_DEC_WPS16 : 2))) void mel_decoder_kernel(const MelDecP p) {
-    constexpr int kDecThreads = 64 * NW;    // shadows the namespace constant inside this kernel
-    constexpr int NS = (DX2 <= 128 && NW == 8) ? ESMI_DEC_NS : 4;   // column slices per workgroup
-    constexpr int MH = NW / NS;             // row groups (1, 2 or 4)
-    constexpr int MT = 4 / MH;              // 32-row MFMA tiles per wave (4, 2 or 1)
-    constexpr int TPR = ESMI_DEC_LN_TPR;          // LayerNorm threads per row (adjacent lanes inside one DPP row: the statistics are DPP adds)
-    constexpr int RPT = kDecRows * TPR / kDecThreads;   // rows per LayerNorm thread (4 or 8): the gain/shift vectors of its
-                                                  // channels are read from LDS once for all of them
-    constexpr bool LOWREG = ESMI_DEC_LOWREG && DX2 <= 128;
+// 8 waves per window: wave (mh = w>>2, ns = w&3) owns rows [64mh, +64) x columns [ns*DX2/4, +DX2/4).
+template <int DX2, int KD>
+__global__ __launch_bounds__(kDecThreads, (DX2 <= 128 ? ESMI_DEC_WPS : 2)) void mel_decoder_kernel(const MelDecP p) {
+    constexpr int NS = 4;                   // column slices per workgroup
+    constexpr int MH = 8 / NS;              // row groups
+    constexpr int MT = 4 / MH;              // 32-row MFMA tiles per wave
+    constexpr int TPR = 16;                 // LayerNorm threads per row (one DPP row: the statistics are 4 DPP adds)
+    constexpr int RPT = kDecRows * TPR / kDecThreads;   // rows per LayerNorm thread (4): gain / shift vectors are read once for all of them
     constexpr int NTW = DX2 / (32 * NS);    // 32-column MFMA tiles per wave
     constexpr int WCOLS = 32 * NTW;         // columns per wave
     constexpr int KCH = DX2 / 128;          // 128-channel K chunks of a dx2-wide contraction
     constexpr int LDSROW = DX2 + 4;
-    constexpr float WSI = ESMI_DEC_SPLIT == 2 ? kF16WScaleInv : 1.0f;   // the f16 planes hold 2^8 * W
+    constexpr bool SPLIT = ESMI_DEC_SPLIT == 2;
+    constexpr float WSI = SPLIT ? kF16WScaleInv : 1.0f;   // the f16 planes hold 2^8 * W
     constexpr int PAD = KD / 2;
     constexpr int CG = DX2 / 4;             // 4-channel groups per row
     constexpr int RS = kDecRows / (kDecThreads / CG);  // rows per depthwise strip (8 or 16)
-    constexpr int NV = DX2 / (4 * TPR);     // float4 per LayerNorm thread and row (channels 4*c + 4*TPR*k, c = lane % TPR)
+    constexpr int NV = DX2 / (4 * TPR);     // float4 per LayerNorm thread and row (channel groups c + 16k, c = lane % 16)
     ESMI_DYN_LDS(lds);
     // per-layer small parameters in LDS: [taps KD*DX2 | dw_b] (group A: read by the depthwise phase) and
-    // [pw_b | ln_g | ln_b | skip_g | skip_b] (group B: read by the tanh / LayerNorm phases).  Single buffer:
-    // layer l+1's group A is committed during layer l's tanh phase, its group B during layer l+1's
-    // depthwise phase -- each when no reader of the old contents is left.
+    // [pw_b | ln_g | ln_b | skip_g | skip_b] (group B: read by the tanh / LayerNorm phases).  Single buffer: layer l+1's
+    // group A is fetched at the start of layer l's tanh phase and committed at its end, group B of layer l during layer l's
+    // depthwise phase -- each when no reader of the old contents is left; the global-memory latency hides behind the phase.
     constexpr int PB = (KD + 6) * DX2;
     constexpr int P_DWB = KD * DX2, P_PWB = P_DWB + DX2, P_G = P_PWB + DX2, P_B = P_G + DX2, P_SG = P_B + DX2,
                   P_SB = P_SG + DX2;
     constexpr int NA4 = (KD + 1) * DX2 / 4;                            // float4 in group A
     constexpr int NB4 = 3 * DX2 / 4;                                   // float4 of pw_b, ln_g, ln_b
-    static_assert(NA4 <= 2 * kDecThreads && NB4 + DX2 / 2 <= kDecThreads, "param staging: one float4 per thread per group");
+    static_assert(NA4 <= kDecThreads && NB4 + DX2 / 2 <= kDecThreads, "param staging: one float4 per thread per group");
     float* xs = lds;                                                  // [132][LDSROW]
     float* pbuf = lds + (kDecRows + 2 * kDecPadRows) * LDSROW;        // [PB]
     int* src = reinterpret_cast<int*>(pbuf + PB);                     // [128]
-    float* stats = pbuf + PB + kDecRows;                              // [128][4 column slices][mean, M2]   (ESMI_DEC_FUSED_LN)
 
     const int tid = (int)threadIdx.x, lane = lane_id(), w = wave_id();
     const int i = lane & 31, h = lane >> 5;
-    const int mh = w / NS, ns = w % NS;     // NW = 4: mh == 0
+    const int mh = w / NS, ns = w % NS;
     // XCD-aware workgroup -> (utterance, window) map: workgroup id % 8 is the XCD (round-robin dispatch), so the windows
     // of one utterance are given ids that agree mod 8 and its h0 / cum rows are fetched into ONE XCD's L2 instead of eight.
     int tile, b;
@@ -317,6 +248,9 @@ __global__ __launch_bounds__(64 * NW, (DX2 <= 128 && NW == 8 ? ESMI_DEC_WPS : (N
         for (int e = tid; e < n; e += kDecThreads) o[e] = 0.0f;
         return;
     }
+#if ESMI_DEC_YOUNG_PRIO && !defined(ESMI_WAVESIM)
+    if (w >= 4) __builtin_amdgcn_s_setprio(ESMI_DEC_YOUNG_PRIO);
+#endif
     const int n_layers = p.n_blocks * p.block_depth;
     const f32x4* blob4 = reinterpret_cast<const f32x4*>(p.blob);
 #ifdef ESMI_DEC_TRACE
@@ -327,44 +261,30 @@ __global__ __launch_bounds__(64 * NW, (DX2 <= 128 && NW == 8 ? ESMI_DEC_WPS : (N
 #define ESMI_STAMP() do {} while (0)
 #endif
 
-    // ---- parameter staging: global -> register (issued early) ... register -> LDS (committed later).
+    // ---- parameter staging: fetch (global -> register) at the start of a phase, commit (register -> LDS) at its end.
     // "layer" n_layers is the mel Linear (group B = its bias only).
-    f32x4 pstA = zero4(), pstA2 = zero4(), pstB = zero4();
-    auto issue_A = [&](int l) __attribute__((always_inline)) {
-        if (LOWREG) return;
-        if (l < n_layers && tid < NA4) pstA = blob4[((p.lay.layer0 + (long)l * p.lay.layer_stride) >> 2) + tid];
-        if (l < n_layers && tid + kDecThreads < NA4)
-            pstA2 = blob4[((p.lay.layer0 + (long)l * p.lay.layer_stride) >> 2) + tid + kDecThreads];
+    f32x4 pst = zero4();
+    auto fetch_A = [&](int l) __attribute__((always_inline)) {
+        if (l < n_layers && tid < NA4) pst = blob4[((p.lay.layer0 + (long)l * p.lay.layer_stride) >> 2) + tid];
     };
     auto commit_A = [&](int l) __attribute__((always_inline)) {
-        if (LOWREG) {
-            if (l < n_layers)
-                for (int e = tid; e < NA4; e += kDecThreads)
-                    reinterpret_cast<f32x4*>(pbuf)[e] = blob4[((p.lay.layer0 + (long)l * p.lay.layer_stride) >> 2) + e];
-            return;
-        }
-        if (l < n_layers && tid < NA4) reinterpret_cast<f32x4*>(pbuf)[tid] = pstA;
-        if (l < n_layers && tid + kDecThreads < NA4) reinterpret_cast<f32x4*>(pbuf)[tid + kDecThreads] = pstA2;
+        if (l < n_layers && tid < NA4) reinterpret_cast<f32x4*>(pbuf)[tid] = pst;
     };
-    auto issue_B_now = [&](int l) __attribute__((always_inline)) {
+    auto fetch_B = [&](int l) __attribute__((always_inline)) {
         if (l < n_layers) {
-            if (tid < NB4) pstB = blob4[((p.lay.layer0 + (long)l * p.lay.layer_stride + p.lay.l_pwb) >> 2) + tid];
+            if (tid < NB4) pst = blob4[((p.lay.layer0 + (long)l * p.lay.layer_stride + p.lay.l_pwb) >> 2) + tid];
             else if (((l + 1) % p.block_depth) == 0 && tid < NB4 + DX2 / 2)   // block end: skip LN params
-                pstB = blob4[((p.lay.skip0 + (long)(l / p.block_depth) * 2 * DX2) >> 2) + tid - NB4];
+                pst = blob4[((p.lay.skip0 + (long)(l / p.block_depth) * 2 * DX2) >> 2) + tid - NB4];
         } else if (tid < DX2 / 4) {
-            pstB = blob4[(p.lay.mel_b >> 2) + tid];
+            pst = blob4[(p.lay.mel_b >> 2) + tid];
         }
-    };
-    auto issue_B = [&](int l) __attribute__((always_inline)) {
-        if (!LOWREG) issue_B_now(l);
     };
     auto commit_B = [&](int l) __attribute__((always_inline)) {
-        if (LOWREG) issue_B_now(l);
         f32x4* d4 = reinterpret_cast<f32x4*>(pbuf + P_PWB);
         if (l < n_layers) {
-            if (tid < NB4 || (((l + 1) % p.block_depth) == 0 && tid < NB4 + DX2 / 2)) d4[tid] = pstB;
+            if (tid < NB4 || (((l + 1) % p.block_depth) == 0 && tid < NB4 + DX2 / 2)) d4[tid] = pst;
         } else if (tid < DX2 / 4) {
-            d4[tid] = pstB;
+            d4[tid] = pst;
         }
     };
 
@@ -388,13 +308,21 @@ __global__ __launch_bounds__(64 * NW, (DX2 <= 128 && NW == 8 ? ESMI_DEC_WPS : (N
     }
     if (tid < NB4)                                                     // proj_b, proj_g, proj_beta -> group B
         reinterpret_cast<f32x4*>(pbuf + P_PWB)[tid] = blob4[(p.lay.proj_b >> 2) + tid];
-    issue_A(0);
+    fetch_A(0);
     commit_A(0);
     __syncthreads();
 
-    // LayerNorm ownership: lane = 16*rg + c; the wave owns rows [4*RPT*w, +4*RPT), the thread rows ln_row0 + (0..RPT-1)
-    // and the float4 channel groups c + 16*k of each
+    // LayerNorm ownership: lane = 16*rg + c; the thread owns rows ln_row0 + (0..3) and the float4 channel groups c + 16*k of
+    // each.  The four row groups of a wave sit 16 rows apart (rows 64(w>>2) + 16rg + 4(w&3) + j): the LDS bank of a lane's
+    // 16-byte access is 4*(row + c) mod 64, so rows that agree mod 16 make every ds_read_b128 / ds_write_b128 of the pass
+    // conflict-free (with four CONSECUTIVE row quadruples per wave, lanes of neighbouring groups met in the same banks:
+    // 17.8 % of the kernel's LDS cycles were bank conflicts, profiles/r01_l).
+#if ESMI_DEC_LN_SPREAD
+    const int ln_c = lane & (TPR - 1), ln_row0 = 64 * (w >> 2) + 16 * (lane / TPR) + RPT * (w & 3);
+#else
     const int ln_c = lane & (TPR - 1), ln_row0 = (64 / TPR) * RPT * w + RPT * (lane / TPR);
+#endif
+    const bool edge_window = f0 < 0 || f0 + kDecRows > L;   // some window rows lie outside [0, L) (SGPR: a scalar branch)
     unsigned ln_inside = 0;                 // bit j: row ln_row0 + j exists in the reference (inside [0, L))
 #pragma unroll
     for (int j = 0; j < RPT; ++j) ln_inside |= (src[ln_row0 + j] != -1 ? 1u : 0u) << j;
@@ -406,30 +334,33 @@ __global__ __launch_bounds__(64 * NW, (DX2 <= 128 && NW == 8 ? ESMI_DEC_WPS : (N
 #pragma unroll
         for (int v = 0; v < NV; ++v) skip[j][v] = zero4();
     }
+    auto zero_acc = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+            for (int t = 0; t < NTW; ++t) acc[mt][t] = zero16();
+        }
+    };
 
-    // weight-stationary GEMM pieces.  bf = this wave's weight slice for KSUB k-steps (64 VGPRs); it is
-    // (re)loaded right after the previous K loop so the L2 latency hides under the non-MFMA phases.
-    constexpr int KSUB = DX2 <= 128 ? ESMI_DEC_KSUB / NTW : 8;   // k-steps of weights in registers at a time (32 / 64 VGPRs)
+    // ================================================================== contractions
+    // Un-pipelined form (exact-fp32 build; in-kernel proj stage of the split build): the wave's weight slice for KSUB k-steps
+    // is loaded, then the A fragments of its rows stream from LDS.
+    constexpr int KSUB = DX2 <= 128 ? ESMI_DEC_KSUB / NTW : 8;   // k-steps (of 8 channels) of weights in registers at a time
 #if ESMI_DEC_SPLIT
-    // split contraction (esmi_dev.h): per 16-channel step one A fragment (8 fp32 from the tile, split on the fly) against the
-    // NPL pre-split weight planes; KSUB/2 steps of weights (NPL x 4 VGPRs each per tile) in registers at a time
     constexpr int KS16 = KSUB / 2;
-    constexpr int NPL = ESMI_DEC_SPLIT == 1 ? 3 : 2;
-    u32x4 bf[NTW][KS16][NPL];
+    u32x4 bf[NTW][KS16][2];
     auto load_b = [&](const f32x4* wsl, int k0) __attribute__((always_inline)) {
         const u32x4* w3 = reinterpret_cast<const u32x4*>(wsl);
-#ifdef ESMI_ABL_NOWLOAD
-        if (p.n_mel >= 0) return;
-#endif
 #pragma unroll
         for (int t = 0; t < NTW; ++t) {
 #pragma unroll
             for (int st = 0; st < KS16; ++st) {
 #pragma unroll
-                for (int pl = 0; pl < NPL; ++pl) bf[t][st][pl] = w3[((t * 8 + (k0 >> 1) + st) * NPL + pl) * 64];
+                for (int pl = 0; pl < 2; ++pl) bf[t][st][pl] = w3[((t * 8 + (k0 >> 1) + st) * 2 + pl) * 64];
             }
         }
     };
+    // fp32 rows in the tile, split on the fly (esmi_dev.h)
     auto mma_sub = [&](int a_col0, int k0) __attribute__((always_inline)) {
         const float* a_base = xs + opaque_i((kDecPadRows + 32 * MT * mh + i) * LDSROW + 8 * h);
 #pragma unroll
@@ -437,55 +368,62 @@ __global__ __launch_bounds__(64 * NW, (DX2 <= 128 && NW == 8 ? ESMI_DEC_WPS : (N
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
                 const float* ap = a_base + 32 * mt * LDSROW + a_col0 + 8 * k0 + 16 * st;
-#if ESMI_DEC_SPLIT == 1
-                const bf16x3 a3 = split_bf16x3(*reinterpret_cast<const f32x4*>(ap), *reinterpret_cast<const f32x4*>(ap + 4));
-#pragma unroll
-                for (int t = 0; t < NTW; ++t) acc[mt][t] = mfma32_split_wx(bf[t][st][0], bf[t][st][1], bf[t][st][2], a3, acc[mt][t]);
-#else
-#if defined(ESMI_ABL_NOSPLIT)
-                f16x2p a2;
-                a2.h1 = __builtin_bit_cast(u32x4, *reinterpret_cast<const f32x4*>(ap));
-                a2.h2 = __builtin_bit_cast(u32x4, *reinterpret_cast<const f32x4*>(ap + 4));
-#elif defined(ESMI_ABL_NOAREAD)
-                f16x2p a2;
-                a2.h1 = u32x4{(unsigned)st, (unsigned)mt, (unsigned)lane, 3u};
-                a2.h2 = a2.h1;
-#else
                 const f16x2p a2 = split_f16x2(*reinterpret_cast<const f32x4*>(ap), *reinterpret_cast<const f32x4*>(ap + 4));
-#endif
-#ifdef ESMI_ABL_NOMFMA
-                if (p.n_mel >= 0) { acc[mt][0][0] += __builtin_bit_cast(float, a2.h1[0] ^ a2.h1[1] ^ a2.h1[2] ^ a2.h1[3] ^ a2.h2[0] ^ a2.h2[1] ^ a2.h2[2] ^ a2.h2[3]); continue; }
-#endif
 #pragma unroll
                 for (int t = 0; t < NTW; ++t) acc[mt][t] = mfma32_split2_wx(bf[t][st][0], bf[t][st][1], a2, acc[mt][t]);
-#endif
             }
         }
     };
-    // slice pointer of chunk c of the matrix at float offset `off` (planes: 8 steps x NPL planes x 64 lanes x 16 B per tile)
-    auto wslice = [&](long off, int c) __attribute__((always_inline)) { return blob4 + (off >> 2) + (long)(c * (DX2 / 32) + ns * NTW) * 8 * NPL * 64 + lane; };
-#if ESMI_DEC_SPLIT == 2 && ESMI_DEC_PRESPLIT
-    // the same with the A rows already stored as planes by the depthwise phase: row = [DX2 halves h1 | DX2 halves h2 | pad]
-    auto mma_sub_pre = [&](int a_col0, int k0) __attribute__((always_inline)) {
+    // slice pointer of chunk c of the matrix at float offset `off` (planes: 8 steps x 2 planes x 64 lanes x 16 B per tile)
+    auto wslice = [&](long off, int c) __attribute__((always_inline)) { return blob4 + (off >> 2) + (long)(c * (DX2 / 32) + ns * NTW) * 8 * 2 * 64 + lane; };
+
+    // Pipelined form: the A operand rows are already stored as the two f16 planes (row = [DX2 halves h1 | DX2 halves h2 | pad],
+    // written by the depthwise phase / the last LayerNorm), so an item = (16-channel step s, row tile mt) is two ds_read_b128 +
+    // 3*NTW MFMAs.  Software pipelined by hand: weight fragments of step s + WD and A fragments of item q + AD are requested
+    // while item q's MFMAs run (VGPR rings; scheduling fences keep hipcc from sinking the loads back to their first use --
+    // left to itself it emits `ds_read; s_waitcnt lgkmcnt(0); v_mfma` per product and the matrix pipe idles through every LDS
+    // and L2 round trip: measured 4.3-9k cycles per K loop against 1.5k of MFMA issue).
+    constexpr int WD = ESMI_DEC_WD, AD = ESMI_DEC_AD;
+    constexpr int NSTEP = 8 * KCH, NITEM = NSTEP * MT;
+    static_assert(WD >= 1 && WD <= NSTEP && AD >= 1 && AD <= NITEM, "ring depths");
+    u32x4 wr[WD][NTW][2];
+    auto w_fetch = [&](long off, int s, int slot) __attribute__((always_inline)) {
+        const u32x4* w3 = reinterpret_cast<const u32x4*>(wslice(off, s >> 3));
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) {
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) wr[slot][t][pl] = w3[((t * 8 + (s & 7)) * 2 + pl) * 64];
+        }
+    };
+    // the first WD weight steps of the matrix at `off` (issued ahead of the barrier that precedes the K loop: the L2 round
+    // trip then overlaps the barrier wait)
+    auto gemm_prefetch = [&](long off) __attribute__((always_inline)) {
+#pragma unroll
+        for (int s = 0; s < WD; ++s) w_fetch(off, s, s);
+        sched_fence();
+    };
+    auto gemm_planes = [&](long off) __attribute__((always_inline)) {
         const unsigned* a_base = reinterpret_cast<const unsigned*>(xs) + opaque_i((kDecPadRows + 32 * MT * mh + i) * LDSROW + 4 * h);
+        f16x2p ar[AD];
+        auto a_fetch = [&](int q, int slot) __attribute__((always_inline)) {
+            const int s = q / MT, mt = q % MT;
+            const unsigned* ap = a_base + 32 * mt * LDSROW + 64 * (s >> 3) + 8 * (s & 7);
+            ar[slot].h1 = *reinterpret_cast<const u32x4*>(ap);
+            ar[slot].h2 = *reinterpret_cast<const u32x4*>(ap + DX2 / 2);
+        };
 #pragma unroll
-        for (int st = 0; st < KS16; ++st) {
+        for (int q = 0; q < AD; ++q) a_fetch(q, q);
+        sched_fence();
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                const unsigned* ap = a_base + 32 * mt * LDSROW + (a_col0 >> 1) + 4 * k0 + 8 * st;
-                f16x2p a2;
-                a2.h1 = *reinterpret_cast<const u32x4*>(ap);
-                a2.h2 = *reinterpret_cast<const u32x4*>(ap + DX2 / 2);
+        for (int q = 0; q < NITEM; ++q) {
+            const int s = q / MT, mt = q % MT;
 #pragma unroll
-                for (int t = 0; t < NTW; ++t) acc[mt][t] = mfma32_split2_wx(bf[t][st][0], bf[t][st][1], a2, acc[mt][t]);
-            }
+            for (int t = 0; t < NTW; ++t) acc[mt][t] = mfma32_split2_wx(wr[s % WD][t][0], wr[s % WD][t][1], ar[q % AD], acc[mt][t]);
+            if (q + AD < NITEM) a_fetch(q + AD, q % AD);
+            if (mt == MT - 1 && s + WD < NSTEP) w_fetch(off, s + WD, s % WD);
+            sched_fence();
         }
     };
-    constexpr bool PRESPLIT = true;
-#else
-    auto mma_sub_pre = [&](int, int) __attribute__((always_inline)) {};
-    constexpr bool PRESPLIT = false;
-#endif
 #else
     f32x4 bf[NTW][KSUB];
     auto load_b = [&](const f32x4* wsl, int k0) __attribute__((always_inline)) {
@@ -510,31 +448,24 @@ __global__ __launch_bounds__(64 * NW, (DX2 <= 128 && NW == 8 ? ESMI_DEC_WPS : (N
             }
         }
     };
-    auto mma_sub_pre = [&](int, int) __attribute__((always_inline)) {};
-    constexpr bool PRESPLIT = false;
     // slice pointer of chunk c of the matrix at float offset `off`
     auto wslice = [&](long off, int c) __attribute__((always_inline)) { return blob4 + (off >> 2) + (long)(c * (DX2 / 32) + ns * NTW) * 16 * 64 + lane; };
+    auto gemm_prefetch = [&](long) __attribute__((always_inline)) {};
+    auto gemm_planes = [&](long) __attribute__((always_inline)) {};
 #endif
-    // full dx2-wide contraction with the first sub-slice already in bf; leaves `next`'s first sub-slice in bf
-    auto gemm_dx2 = [&](long off, const f32x4* next, bool pre) __attribute__((always_inline)) {
+    // full dx2-wide contraction over fp32 rows of the tile, un-pipelined
+    auto gemm_rows = [&](long off) __attribute__((always_inline)) {
 #pragma unroll
         for (int c = 0; c < KCH; ++c) {
 #pragma unroll
             for (int k0 = 0; k0 < 16; k0 += KSUB) {
-                if (LOWREG || c > 0 || k0 > 0) load_b(wslice(off, c), k0);
-                if (pre) mma_sub_pre(128 * c, k0);
-                else mma_sub(128 * c, k0);
+                load_b(wslice(off, c), k0);
+                mma_sub(128 * c, k0);
             }
         }
-        if (next && !LOWREG) load_b(next, 0);
     };
-    auto zero_acc = [&]() __attribute__((always_inline)) {
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-#pragma unroll
-            for (int t = 0; t < NTW; ++t) acc[mt][t] = zero16();
-        }
-    };
+
+    // ================================================================== epilogues
     // accumulators (+ bias, tanh) -> tile.  The products are computed TRANSPOSED (weights as the first MFMA operand): lane
     // (i, h) holds frame i of the tile and, per register quad g = r >> 2, the four consecutive channels 8g + 4h .. + 3 --
     // one ds_write_b128 per quad instead of four ds_write_b32 (and float4 global stores for the mel rows).
@@ -544,23 +475,16 @@ __global__ __launch_bounds__(64 * NW, (DX2 <= 128 && NW == 8 ? ESMI_DEC_WPS : (N
             const int col = ns * WCOLS + 32 * t + 4 * h;
             const float* bp = bias + opaque_i(col);
             float* base = xs + opaque_i((kDecPadRows + 32 * MT * mh + i) * LDSROW + col);
+            f32x4 bc[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) bc[g] = *reinterpret_cast<const f32x4*>(bp + 8 * g) * kTanhExpScale;   // the exponent's 2 log2(e) goes into the bias and the scale of the fma
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                f32x4 bc = *reinterpret_cast<const f32x4*>(bp + 8 * g);
-#if !defined(ESMI_ABL_NO_TANH)
-                bc *= kTanhExpScale;     // the exponent's 2 log2(e) goes into the bias and the scale of the fma
-#endif
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) {
                     f32x4 v;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-#if defined(ESMI_ABL_NO_TANH)
-                        v[e] = fmaf(acc[mt][t][4 * g + e], WSI, bc[e]);
-#else
-                        v[e] = tanh_fast_fma_f32(acc[mt][t][4 * g + e], WSI * kTanhExpScale, bc[e]);
-#endif
-                    }
+                    for (int e = 0; e < 4; ++e) v[e] = tanh_fast_fma_f32(acc[mt][t][4 * g + e], WSI * kTanhExpScale, bc[g][e]);
                     *reinterpret_cast<f32x4*>(base + 32 * mt * LDSROW + 8 * g) = v;
                 }
             }
@@ -579,8 +503,8 @@ __global__ __launch_bounds__(64 * NW, (DX2 <= 128 && NW == 8 ? ESMI_DEC_WPS : (N
         for (int k = 0; k < NV; ++k) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const float d = v[k][e] - mean;
-                q = fmaf(d, d, q);
+                v[k][e] -= mean;
+                q = fmaf(v[k][e], v[k][e], q);
             }
         }
         q = row_sum_n<TPR>(q);
@@ -588,15 +512,18 @@ __global__ __launch_bounds__(64 * NW, (DX2 <= 128 && NW == 8 ? ESMI_DEC_WPS : (N
 #pragma unroll
         for (int k = 0; k < NV; ++k) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[k][e] = fmaf((v[k][e] - mean) * rstd, g[k][e], be[k][e]);
+            for (int e = 0; e < 4; ++e) v[k][e] = fmaf(v[k][e] * rstd, g[k][e], be[k][e]);
         }
     };
     auto ln_params = [&](const float* pv, f32x4 (&o)[NV]) __attribute__((always_inline)) {
 #pragma unroll
         for (int k = 0; k < NV; ++k) o[k] = *reinterpret_cast<const f32x4*>(pv + 4 * TPR * k);
     };
-    // LN pass over the tile (in place): x = LN(x) [; x = LN_s(x + skip)] ; outside rows -> 0 ; skip update
-    auto ln_pass = [&](const float* pb0, bool block_end, bool set_skip) __attribute__((always_inline)) {
+    // LN pass over the tile (in place): x = LN(x) [; x = LN_s(x + skip), skip = x at a block end]; rows outside [0, L) -> 0.
+    // PLANES: the rows are written as the two f16 planes the pipelined K loop reads (the last LayerNorm feeds the mel Linear
+    // only), otherwise as fp32.  BLOCK_END is a template-like constant at both call sites so that `skip = v` costs nothing.
+    auto ln_pass = [&](const float* pb0, auto block_end_c, auto planes_c) __attribute__((always_inline)) {
+        constexpr bool BLOCK_END = decltype(block_end_c)::value, PLANES = decltype(planes_c)::value;
         const float* pb = pb0 + opaque_i(4 * ln_c);           // this thread's channels of every param vector
         float* ln_ptr = xs + opaque_i((kDecPadRows + ln_row0) * LDSROW + 4 * ln_c);
         f32x4 g[NV], be[NV];
@@ -608,10 +535,9 @@ __global__ __launch_bounds__(64 * NW, (DX2 <= 128 && NW == 8 ? ESMI_DEC_WPS : (N
 #pragma unroll
             for (int k = 0; k < NV; ++k) v[j][k] = *reinterpret_cast<const f32x4*>(ln_ptr + j * LDSROW + 4 * TPR * k);
         }
-#ifndef ESMI_ABL_NO_LN
 #pragma unroll
         for (int j = 0; j < RPT; ++j) ln_regs(v[j], g, be);
-        if (block_end) {  // end of a decoder block: skip = LN_s(x + skip), networks.py:299
+        if (BLOCK_END) {  // end of a decoder block: skip = LN_s(x + skip), networks.py:299
             ln_params(pb + P_SG, g);
             ln_params(pb + P_SB, be);
 #pragma unroll
@@ -621,130 +547,35 @@ __global__ __launch_bounds__(64 * NW, (DX2 <= 128 && NW == 8 ? ESMI_DEC_WPS : (N
                 ln_regs(v[j], g, be);
             }
         }
-#endif
+        if (edge_window) {   // workgroup-uniform: only the first / last windows of an utterance hold rows outside [0, L)
+#pragma unroll
+            for (int j = 0; j < RPT; ++j) {
+#pragma unroll
+                for (int k = 0; k < NV; ++k)
+                    if (!((ln_inside >> j) & 1u)) v[j][k] = zero4();
+            }
+        }
 #pragma unroll
         for (int j = 0; j < RPT; ++j) {
 #pragma unroll
             for (int k = 0; k < NV; ++k) {
-                if (!((ln_inside >> j) & 1u)) v[j][k] = zero4();
-                *reinterpret_cast<f32x4*>(ln_ptr + j * LDSROW + 4 * TPR * k) = v[j][k];
-                if (set_skip) skip[j][k] = v[j][k];
+                if (PLANES) {
+                    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+                    unsigned h1a, h2a, h1b, h2b;
+                    split_f16_pair(v[j][k][0], v[j][k][1], h1a, h2a);
+                    split_f16_pair(v[j][k][2], v[j][k][3], h1b, h2b);
+                    unsigned* rowp = reinterpret_cast<unsigned*>(ln_ptr + j * LDSROW) - 2 * ln_c + 2 * TPR * k;   // dword 2*(channel group)
+                    *reinterpret_cast<u32x2*>(rowp) = u32x2{h1a, h1b};
+                    *reinterpret_cast<u32x2*>(rowp + DX2 / 2) = u32x2{h2a, h2b};
+                } else {
+                    *reinterpret_cast<f32x4*>(ln_ptr + j * LDSROW + 4 * TPR * k) = v[j][k];
+                }
+                if (BLOCK_END) skip[j][k] = v[j][k];
             }
         }
     };
-
-    // ---- fused epilogue (ESMI_DEC_FUSED_LN).  In the transposed accumulator layout lane (i, h) of wave (mh, ns) holds, for
-    // each of its MT row tiles, row 32*MT*mh + 32*mt + i and the channels ns*WCOLS + 32t + 8g + 4h + (0..3): half of the
-    // wave's column slice of that row, the other half sits in lane i + 32.  A row's LayerNorm statistics are therefore
-    // in-lane sums + one v_permlane32_swap per wave, and a 2-float LDS entry per (row, slice) to meet the other slices.
-    f32x16 skp[MT][NTW];         // the skip tensor in that layout
-    unsigned acc_inside = 0;     // bit mt: the lane's row of tile mt exists in the reference (inside [0, L))
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) acc_inside |= (src[32 * MT * mh + 32 * mt + i] != -1 ? 1u : 0u) << mt;
-    const int ep_col = ns * WCOLS + 4 * h;      // + 32t + 8g
-    float* ep_stats = stats + opaque_i((32 * MT * mh + i) * 2 * NS);   // + 64*NS*mt: this lane's row entry [NS][2]
-    float* ep_tile = xs + opaque_i((kDecPadRows + 32 * MT * mh + i) * LDSROW + ep_col);
-    // x = LN(x) over the full rows; gp / bp = the gain / shift vectors in LDS.  Contains one workgroup barrier.
-    auto ln_exchange = [&](f32x16 (&x)[MT][NTW], const float* gp, const float* bp) __attribute__((always_inline)) {
-        typedef float f32x2 __attribute__((ext_vector_type(2)));
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {   // two-pass statistics of this wave's WCOLS channels of the row
-            float sm = 0.0f;
-#pragma unroll
-            for (int t = 0; t < NTW; ++t) {
-#pragma unroll
-                for (int g = 0; g < 4; ++g) sm += (x[mt][t][4 * g] + x[mt][t][4 * g + 1]) + (x[mt][t][4 * g + 2] + x[mt][t][4 * g + 3]);
-            }
-            sm += swap32_f(sm);
-            const float mean = sm * (1.0f / WCOLS);
-            float q = 0.0f;
-#pragma unroll
-            for (int t = 0; t < NTW; ++t) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float d = x[mt][t][r] - mean;
-                    q = fmaf(d, d, q);
-                }
-            }
-            q += swap32_f(q);
-            *reinterpret_cast<f32x2*>(ep_stats + 64 * NS * mt + 2 * ns) = f32x2{mean, q};   // both half-wave lanes: same value
-        }
-        __syncthreads();
-        float mean[MT], rstd[MT];
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {   // Chan merge of the NS equal-sized slices (identical in every wave)
-            f32x2 st[NS];
-#pragma unroll
-            for (int k = 0; k < NS; ++k) st[k] = *reinterpret_cast<const f32x2*>(ep_stats + 64 * NS * mt + 2 * k);
-            float m = 0.0f;
-#pragma unroll
-            for (int k = 0; k < NS; ++k) m += st[k][0];
-            m *= 1.0f / NS;
-            float m2 = 0.0f;
-#pragma unroll
-            for (int k = 0; k < NS; ++k) {
-                const float d = st[k][0] - m;
-                m2 += fmaf((float)WCOLS * d, d, st[k][1]);
-            }
-            mean[mt] = m;
-            rstd[mt] = ESMI_DEC_RSQRT(m2 * (1.0f / DX2) + 1e-5f);
-        }
-#pragma unroll
-        for (int t = 0; t < NTW; ++t) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const f32x4 gg = *reinterpret_cast<const f32x4*>(gp + ep_col + 32 * t + 8 * g);
-                const f32x4 bb = *reinterpret_cast<const f32x4*>(bp + ep_col + 32 * t + 8 * g);
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) x[mt][t][4 * g + e] = fmaf((x[mt][t][4 * g + e] - mean[mt]) * rstd[mt], gg[e], bb[e]);
-                }
-            }
-        }
-    };
-    // bias + tanh + LN [+ LN_s(x + skip)] on the accumulators, rows outside the sequence -> 0, result -> tile (and skip)
-    auto epilogue_ln = [&](const float* pb, bool block_end, int l_next) __attribute__((always_inline)) {
-#pragma unroll
-        for (int t = 0; t < NTW; ++t) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const f32x4 bc = *reinterpret_cast<const f32x4*>(pb + P_PWB + ep_col + 32 * t + 8 * g);
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) acc[mt][t][4 * g + e] = ESMI_DEC_TANH(fmaf(acc[mt][t][4 * g + e], WSI, bc[e]));
-                }
-            }
-        }
-        commit_A(l_next);                    // next layer's taps (their LDS slots were last read by this layer's depthwise phase)
-        issue_B(l_next);
-        ln_exchange(acc, pb + P_G, pb + P_B);       // its barrier also ends the K loop's reads of the tile
-        if (block_end) {   // end of a decoder block: skip = LN_s(x + skip), networks.py:299
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-#pragma unroll
-                for (int t = 0; t < NTW; ++t) acc[mt][t] += skp[mt][t];
-            }
-            __syncthreads();                 // every wave has read the first table
-            ln_exchange(acc, pb + P_SG, pb + P_SB);
-        }
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-#pragma unroll
-            for (int t = 0; t < NTW; ++t) {
-                if (!((acc_inside >> mt) & 1u)) acc[mt][t] = zero16();
-                if (block_end) skp[mt][t] = acc[mt][t];
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    f32x4 v;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = acc[mt][t][4 * g + e];
-                    *reinterpret_cast<f32x4*>(ep_tile + 32 * mt * LDSROW + 32 * t + 8 * g) = v;
-                }
-            }
-        }
-    };
+    typedef std::true_type TrueC;
+    typedef std::false_type FalseC;
 
     // ---- proj: Linear(d4, dx2) + Tanh + LN.  All three are row-wise, and a frame's input row is its phoneme's row: when
     // the caller supplies h0 = LN(tanh(proj(x))) at PHONEME rate (enc_fuse_va_kernel computes it while the features
@@ -763,8 +594,6 @@ __global__ __launch_bounds__(64 * NW, (DX2 <= 128 && NW == 8 ? ESMI_DEC_WPS : (N
             }
             *reinterpret_cast<f32x4*>(xs + (kDecPadRows + r) * LDSROW + 4 * q) = v;
         }
-        if (!LOWREG) load_b(n_layers > 0 ? wslice(p.lay.layer0 + p.lay.l_pw, 0) : wslice(p.lay.mel_w, 0), 0);
-        issue_B(0);
         __syncthreads();
         {   // row owners: LayerNorm only for the padding frames' rows; skip = the stage's output
             const float* pb = pbuf + opaque_i(4 * ln_c);
@@ -797,49 +626,46 @@ __global__ __launch_bounds__(64 * NW, (DX2 <= 128 && NW == 8 ? ESMI_DEC_WPS : (N
         }
         __syncthreads();
     } else {
-    zero_acc();
-    const int nchunks = p.d4 / 128;
-    if (!LOWREG) load_b(wslice(p.lay.proj_w, 0), 0);
-    for (int ch = 0; ch < nchunks; ++ch) {
-        if (ch > 0) __syncthreads();  // previous chunk fully consumed
-        for (int e = tid; e < kDecRows * 32; e += kDecThreads) {
-            const int r = e >> 5, q = e & 31;
-            const int s = src[r];
-            f32x4 v = zero4();
-            if (s >= 0) v = ld4(p.x + (long)s * p.d4 + ch * 128 + 4 * q);
-            *reinterpret_cast<f32x4*>(xs + (kDecPadRows + r) * LDSROW + 4 * q) = v;
+        zero_acc();
+        const int nchunks = p.d4 / 128;
+        for (int ch = 0; ch < nchunks; ++ch) {
+            if (ch > 0) __syncthreads();  // previous chunk fully consumed
+            for (int e = tid; e < kDecRows * 32; e += kDecThreads) {
+                const int r = e >> 5, q = e & 31;
+                const int s = src[r];
+                f32x4 v = zero4();
+                if (s >= 0) v = ld4(p.x + (long)s * p.d4 + ch * 128 + 4 * q);
+                *reinterpret_cast<f32x4*>(xs + (kDecPadRows + r) * LDSROW + 4 * q) = v;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int k0 = 0; k0 < 16; k0 += KSUB) {
+                load_b(wslice(p.lay.proj_w, ch), k0);
+                mma_sub(0, k0);
+            }
         }
+        __syncthreads();  // every wave finished reading the staged input
+        store_tanh(pbuf + P_PWB);
         __syncthreads();
+        {   // LN(tanh(proj)); skip = the stage's output
+            const float* pb = pbuf + opaque_i(4 * ln_c);
+            float* ln_ptr = xs + opaque_i((kDecPadRows + ln_row0) * LDSROW + 4 * ln_c);
+            f32x4 g[NV], be[NV];
+            ln_params(pb + P_G, g);
+            ln_params(pb + P_B, be);
 #pragma unroll
-        for (int k0 = 0; k0 < 16; k0 += KSUB) {
-            if (LOWREG || ch > 0 || k0 > 0) load_b(wslice(p.lay.proj_w, ch), k0);
-            mma_sub(0, k0);
-        }
-    }
-    // weights of the first conv layer (or of the mel Linear) start flowing while proj's epilogue runs
-    if (!LOWREG) load_b(n_layers > 0 ? wslice(p.lay.layer0 + p.lay.l_pw, 0) : wslice(p.lay.mel_w, 0), 0);
-    __syncthreads();  // every wave finished reading the staged input
-    issue_B(0);
-    store_tanh(pbuf + P_PWB);
-    __syncthreads();
-    ln_pass(pbuf, false, true);
-    __syncthreads();
-
-    }
-
-    if (ESMI_DEC_FUSED_LN) {   // the stage's output (in the tile) is the first skip tensor
+            for (int j = 0; j < RPT; ++j) {
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
+                for (int k = 0; k < NV; ++k) skip[j][k] = *reinterpret_cast<const f32x4*>(ln_ptr + j * LDSROW + 4 * TPR * k);
+                ln_regs(skip[j], g, be);
 #pragma unroll
-            for (int t = 0; t < NTW; ++t) {
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const f32x4 v = *reinterpret_cast<const f32x4*>(ep_tile + 32 * mt * LDSROW + 32 * t + 8 * g);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) skp[mt][t][4 * g + e] = v[e];
+                for (int k = 0; k < NV; ++k) {
+                    if (!((ln_inside >> j) & 1u)) skip[j][k] = zero4();
+                    *reinterpret_cast<f32x4*>(ln_ptr + j * LDSROW + 4 * TPR * k) = skip[j][k];
                 }
             }
         }
+        __syncthreads();
     }
 
     // ---- conv layers
@@ -847,20 +673,20 @@ __global__ __launch_bounds__(64 * NW, (DX2 <= 128 && NW == 8 ? ESMI_DEC_WPS : (N
     for (int l = 0; l < n_layers; ++l) {
         const float* pb = pbuf;
         const long lbase = p.lay.layer0 + (long)l * p.lay.layer_stride;
+        const bool block_end = ((l + 1) % p.block_depth) == 0;
         ESMI_STAMP();   // 0: layer start
-        // 1. depthwise conv in place: window -> registers | barrier | filtered rows -> tile
+        // 1. depthwise conv in place: window -> registers | barrier | filtered rows -> tile (as the K loop's operand planes)
         {
             f32x4 win[RS + 2 * PAD];
             float* col = xs + opaque_i((kDecPadRows + dw_r0 - PAD) * LDSROW + 4 * dw_cg);
             const float* pbt = pb + opaque_i(4 * dw_cg);
             unsigned* prow = reinterpret_cast<unsigned*>(xs) + opaque_i((kDecPadRows + dw_r0) * LDSROW + 2 * dw_cg);
+            fetch_B(l);          // this layer's bias / LN params: global -> register now, -> LDS at the end of the phase
 #pragma unroll
             for (int r = 0; r < RS + 2 * PAD; ++r) win[r] = *reinterpret_cast<const f32x4*>(col + r * LDSROW);
-            f32x4 tap[KD];       // in registers for all RS rows: re-reading them per row cost 8 x KD ds_read_b128 per thread
-            if (ESMI_DEC_TAPS_IN_REGS) {
+            f32x4 tap[KD];       // in registers for all RS rows
 #pragma unroll
-                for (int j = 0; j < KD; ++j) tap[j] = *reinterpret_cast<const f32x4*>(pbt + j * DX2);
-            }
+            for (int j = 0; j < KD; ++j) tap[j] = *reinterpret_cast<const f32x4*>(pbt + j * DX2);
             const f32x4 tb = *reinterpret_cast<const f32x4*>(pbt + P_DWB);
             ESMI_STAMP();   // 1: window loaded (issued)
             __syncthreads();
@@ -870,14 +696,10 @@ __global__ __launch_bounds__(64 * NW, (DX2 <= 128 && NW == 8 ? ESMI_DEC_WPS : (N
                 f32x4 a = tb;
 #pragma unroll
                 for (int j = 0; j < KD; ++j) {
-#ifdef ESMI_ABL_NO_DW
-                    if (j != PAD) continue;
-#endif
-                    const f32x4 tj = ESMI_DEC_TAPS_IN_REGS ? tap[j] : *reinterpret_cast<const f32x4*>(pbt + j * DX2);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) a[e] = fmaf(win[r + j][e], tj[e], a[e]);
+                    for (int e = 0; e < 4; ++e) a[e] = fmaf(win[r + j][e], tap[j][e], a[e]);
                 }
-                if (PRESPLIT) {   // the K loop's A operand, already split (esmi_dev.h): 4 channels = 2 dwords per plane
+                if (SPLIT) {   // the K loop's A operand, already split (esmi_dev.h): 4 channels = 2 dwords per plane
                     typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
                     unsigned h1a, h2a, h1b, h2b;
                     split_f16_pair(a[0], a[1], h1a, h2a);
@@ -890,53 +712,54 @@ __global__ __launch_bounds__(64 * NW, (DX2 <= 128 && NW == 8 ? ESMI_DEC_WPS : (N
                 }
             }
         }
-        commit_B(l);                         // this layer's bias / LN params (issued during the previous layer)
-        issue_A(l + 1);                      // next layer's taps: in flight during the K loop
+        commit_B(l);
+        gemm_prefetch(lbase + p.lay.l_pw);   // first weight steps: in flight across the barrier
         ESMI_STAMP();   // 3: dw written
         __syncthreads();
         ESMI_STAMP();   // 4: barrier
-        // 2. pointwise conv: K = dx2, weights register-stationary; then prefetch the next matrix's first slice
-        ESMI_PRIO(0);
+        // 2. pointwise conv: K = dx2
         zero_acc();
-        gemm_dx2(lbase + p.lay.l_pw, l + 1 < n_layers ? wslice(lbase + p.lay.layer_stride + p.lay.l_pw, 0)
-                                                      : wslice(p.lay.mel_w, 0), PRESPLIT);
+        if (SPLIT) gemm_planes(lbase + p.lay.l_pw);
+        else gemm_rows(lbase + p.lay.l_pw);
         ESMI_STAMP();   // 5: K loop issued
-        ESMI_PRIO(ESMI_DEC_CHAIN_PRIO);
-        const bool block_end = ((l + 1) % p.block_depth) == 0;
-        if (ESMI_DEC_FUSED_LN) {
-            ESMI_STAMP();   // 6
-            ESMI_STAMP();   // 7
-            ESMI_STAMP();   // 8
-            epilogue_ln(pb, block_end, l + 1);
-            ESMI_STAMP();   // 9: epilogue done
-            __syncthreads();
-            ESMI_STAMP();   // 10: barrier
+        fetch_A(l + 1);      // next layer's taps: in flight during the tanh phase
+        __syncthreads();  // all reads of the filtered tile done
+        ESMI_STAMP();   // 6: barrier
+        // 3. bias + tanh -> tile
+        store_tanh(pb + P_PWB);
+        commit_A(l + 1);     // (the taps' LDS slots were last read by this layer's depthwise phase)
+        ESMI_STAMP();   // 7: tanh stored
+        __syncthreads();
+        ESMI_STAMP();   // 8: barrier
+        // 4. LayerNorm (+ block-end skip LayerNorm) by row owners; the last one writes the mel Linear's operand planes
+        if (l + 1 == n_layers) fetch_B(n_layers);   // mel bias (pst is free: group A of a non-existent layer was not fetched)
+        if (SPLIT && l + 1 == n_layers) {
+            if (block_end) ln_pass(pb, TrueC{}, TrueC{});
+            else ln_pass(pb, FalseC{}, TrueC{});
         } else {
-            __syncthreads();  // all reads of the filtered tile done
-            ESMI_STAMP();   // 6: barrier
-            // 3. bias + tanh -> tile; commit the staged params of layer l+1 to the other buffer
-            store_tanh(pb + P_PWB);
-            commit_A(l + 1);
-            issue_B(l + 1);
-            ESMI_STAMP();   // 7: tanh stored
-            __syncthreads();
-            ESMI_STAMP();   // 8: barrier
-            // 4. LayerNorm (+ block-end skip LayerNorm) by row owners
-            ln_pass(pb, block_end, block_end);
-            ESMI_STAMP();   // 9: LN done
-            __syncthreads();
-            ESMI_STAMP();   // 10: barrier
+            if (block_end) ln_pass(pb, TrueC{}, FalseC{});
+            else ln_pass(pb, FalseC{}, FalseC{});
         }
+        ESMI_STAMP();   // 9: LN done
+        if (l + 1 == n_layers) {   // the LayerNorm's reads of group B are done only after the barrier: the mel bias goes to the (now unused) group A slots
+            if (tid < DX2 / 4) reinterpret_cast<f32x4*>(pbuf)[tid] = pst;
+            gemm_prefetch(p.lay.mel_w);
+        }
+        __syncthreads();
+        ESMI_STAMP();   // 10: barrier
     }
 
     // ---- mel Linear(dx2, n_mel) on skip (held in the tile), masked store
-    if (n_layers == 0) issue_B(0);
-    commit_B(n_layers);    // mel bias; the last LayerNorm's reads of group B finished before its closing barrier
-    __syncthreads();
+    if (n_layers == 0) {   // (degenerate: proj output straight into the mel Linear, fp32 rows)
+        fetch_B(0);
+        if (tid < DX2 / 4) reinterpret_cast<f32x4*>(pbuf)[tid] = pst;
+        __syncthreads();
+    }
     if (ns * WCOLS < p.n_mel) {   // wave-uniform: column slices beyond n_mel have nothing to do
         zero_acc();
-        gemm_dx2(p.lay.mel_w, nullptr, false);
-        const float* mb = pbuf + P_PWB;
+        if (SPLIT && n_layers > 0) gemm_planes(p.lay.mel_w);
+        else gemm_rows(p.lay.mel_w);
+        const float* mb = pbuf;                      // mel bias (zero padded to dx2)
         const bool vec_ok = (p.n_mel & 3) == 0;      // rows of 16-byte multiples: float4 stores
 #pragma unroll
         for (int t = 0; t < NTW; ++t) {

@@ -205,6 +205,32 @@ __global__ void upsample_kernel(const float* __restrict__ feat, const unsigned c
     if (q == 0 && omask) omask[bf] = i < T ? (fmask ? fmask[b * T + i] : (unsigned char)0) : (unsigned char)1;
 }
 
+// get_embedding, networks.py:128-149: idx = bucketize(v, bins) (right = False), out row = emb[idx]; one thread per (row, channel)
+__global__ void bucket_embed_kernel(const float* __restrict__ v, const float* __restrict__ bins, const float* __restrict__ emb,
+                                    long rows, int dim, float* __restrict__ out, int* __restrict__ idx) {
+    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= rows * dim) return;
+    const long row = e / dim;
+    const int c = (int)(e - row * dim);
+    const int bi = bucketize_left(v[row], bins, dim - 1);
+    out[e] = emb[(long)bi * dim + c];
+    if (c == 0 && idx) idx[row] = bi;
+}
+
+// out[0] = max(out[0], max_i |x[i]|) as the bit pattern of a non-negative float (NaN counts as +inf); out[0] zeroed by the caller
+__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, long n, int* __restrict__ out) {
+    int m = 0;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
+        const float a = fabsf(x[e]);
+        const int bits = a != a ? 0x7F800000 : (__builtin_bit_cast(int, a) & 0x7FFFFFFF);
+        m = max(m, bits);
+    }
+    const int lane = lane_id();
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) m = max(m, shfl_i(m, lane ^ d));
+    if (lane == 0 && m > 0) atomicMax(out, m);
+}
+
 __global__ void mask_rows_kernel(float* __restrict__ x, const unsigned char* __restrict__ mask, long rows, int C) {
     const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= rows * C) return;

@@ -20,16 +20,53 @@ from .config import N_SYMBOLS
 
 # --------------------------------------------------------------------------- plumbing
 def _runtime(t):
-    """(lib, stream handle) for the device `t` lives on."""
+    """(lib, stream handle) for the device `t` lives on.  The product binds libesmi.so (HIP, gfx950) and nothing else; tests
+    replace this hook to drive the CPU wave-simulator build of the same sources (tests/simlib.py)."""
     lib = _lib.load()
-    if _lib.backend(lib).startswith("hip"):
-        if not t.is_cuda:
-            raise RuntimeError("efficientspeech_amd: tensors must be on the GPU (no CPU fallback); "
-                               "call .to('cuda') on the module and its inputs")
-        return lib, torch.cuda.current_stream(t.device).cuda_stream
-    if t.is_cuda:                                   # wave-simulator library injected by tests/
-        raise RuntimeError("wave-simulator backend only accepts host tensors")
-    return lib, None
+    if not t.is_cuda:
+        raise RuntimeError("efficientspeech_amd: tensors must be on the GPU (no CPU fallback); "
+                           "call .to('cuda') on the module and its inputs")
+    return lib, torch.cuda.current_stream(t.device).cuda_stream
+
+
+class _on_device_of:
+    """Make the device of `t` current for the duration of a forward: kernel launches and per-device function attributes go
+    to the CURRENT device, so a model on cuda:1 must not be driven while cuda:0 is current."""
+
+    def __init__(self, t):
+        self.idx = t.device.index if t.is_cuda else None
+        self.prev = None
+
+    def __enter__(self):
+        if self.idx is not None:
+            cur = torch.cuda.current_device()
+            if cur != self.idx:
+                self.prev = cur
+                torch.cuda.set_device(self.idx)
+        return self
+
+    def __exit__(self, *exc):
+        if self.prev is not None:
+            torch.cuda.set_device(self.prev)
+        return False
+
+
+def _check_split_range(lib, stream, tensors, what):
+    """Pack-time operand-range guard of the split-f16 build (include/esmi.h): every weight that feeds a split contraction
+    must satisfy 2^8 |w| < 65504.  One device reduction per tensor, ONE host sync per checkpoint load."""
+    limit = float(lib.esmi_split_weight_limit())
+    tensors = [t for t in tensors if t is not None and t.numel() > 0]
+    if limit == float("inf") or not tensors:
+        return
+    out = torch.zeros(len(tensors), dtype=torch.float32, device=tensors[0].device)
+    for i, t in enumerate(tensors):
+        t = _f32(t)
+        lib.esmi_absmax_f32(_ptr(t), t.numel(), out[i:i + 1].data_ptr(), stream)
+    m = float(out.max().item())
+    if not m < limit:
+        raise ValueError(f"{what}: max |weight| = {m:g} is outside the operand range of the split-f16 contractions "
+                         f"(|w| < {limit:g}, include/esmi.h); use the exact-fp32 MFMA build for this checkpoint: "
+                         f"ESMI_LIB=efficientspeech_amd/libesmi_fp32mfma.so")
 
 
 def _ptr(t):
@@ -124,27 +161,71 @@ def _pack_bfrag(lib, stream, w):
     return dst
 
 
-# --------------------------------------------------------------------------- parameter containers
+# --------------------------------------------------------------------------- encoder sub-modules
 class SelfAttention(nn.Module):
-    """Parameters of blocks.py:32-41 (qkv bias-free; every head is full width: qkv = 3*h*dim)."""
+    """blocks.py:32-71 (qkv bias-free; every head is full width: qkv = 3*h*dim).  Inside `Encoder` the block runs fused
+    (esmi_encoder_block_f32); `forward` is the module-level API through esmi_self_attention_f32."""
 
     def __init__(self, dim, num_heads=1, qkv_bias=False):
         super().__init__()
         assert dim % num_heads == 0, 'dim should be divisible by num_heads'
+        if qkv_bias:
+            raise NotImplementedError("qkv_bias=True: the reference never sets it (networks.py:43) and the kernels take a bias-free qkv")
         self.num_heads = num_heads
+        self.scale = (dim // num_heads) ** -0.5
         self.qkv = nn.Linear(dim, dim * 3 * num_heads, bias=qkv_bias)
         self.proj = nn.Linear(dim * num_heads, dim)
 
+    def forward(self, x, mask=None, pool=1):
+        """x (B,N,C); mask bool (B,T) or None -> (proj(softmax(q k^T scale) v) (B,N,C), attn_mask bool (B,N,C) or None).
+        As in the reference the scores are NOT masked; the returned mask is the max-pooled padding mask (blocks.py:51-69)."""
+        x = _f32(x)
+        with _on_device_of(x):
+            lib, stream = _runtime(x)
+            B, N, Cc = x.shape
+            out = torch.empty_like(x)
+            ws_bytes = lib.esmi_self_attention_workspace_bytes(B, N, Cc, self.num_heads)
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device)
+            lib.esmi_self_attention_f32(_ptr(_f32(self.qkv.weight)), _ptr(_f32(self.proj.weight)), _ptr(_f32(self.proj.bias)),
+                                        B, N, Cc, self.num_heads, _ptr(x), _ptr(out), _ptr(ws), ws_bytes, stream)
+            attn_mask = None
+            if mask is not None:
+                m8 = _mask_u8(mask)
+                if pool > 1:
+                    T = m8.shape[-1]
+                    n_out = (T + pool - 1) // pool
+                    pm = torch.empty((B, n_out), dtype=torch.uint8, device=x.device)
+                    lib.esmi_pool_mask_u8(_ptr(m8), B, T, int(pool), _ptr(pm), n_out, stream)
+                    m8 = pm
+                attn_mask = m8.bool().unsqueeze(-1).expand(-1, -1, Cc)
+            return out, attn_mask
+
 
 class MixFFN(nn.Module):
-    """Parameters of blocks.py:8-20."""
+    """blocks.py:8-29: Linear -> dense Conv1d k3 -> GELU (exact erf) -> Linear."""
 
     def __init__(self, dim, expansion_factor):
         super().__init__()
         hidden = dim * expansion_factor
+        self.expansion_factor = expansion_factor
         self.mlp1 = nn.Linear(dim, hidden)
         self.conv = nn.Conv1d(hidden, hidden, 3, padding=1)
         self.mlp2 = nn.Linear(hidden, dim)
+
+    def forward(self, x):
+        """x (B,N,C) -> (B,N,C) through esmi_mixffn_f32."""
+        x = _f32(x)
+        with _on_device_of(x):
+            lib, stream = _runtime(x)
+            B, N, Cc = x.shape
+            cw, _ = _pack_conv(lib, stream, self.conv.weight)
+            out = torch.empty_like(x)
+            ws_bytes = lib.esmi_mixffn_workspace_bytes(B, N, Cc, self.expansion_factor)
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device)
+            lib.esmi_mixffn_f32(_ptr(_f32(self.mlp1.weight)), _ptr(_f32(self.mlp1.bias)), _ptr(cw), _ptr(_f32(self.conv.bias)),
+                                _ptr(_f32(self.mlp2.weight)), _ptr(_f32(self.mlp2.bias)), B, N, Cc, self.expansion_factor,
+                                _ptr(x), _ptr(out), _ptr(ws), ws_bytes, stream)
+            return out
 
 
 class Encoder(_PackedModule):
@@ -199,12 +280,18 @@ class Encoder(_PackedModule):
                 comp = torch.empty((k, co, cin), dtype=torch.float32, device=mw.device)   # merge1 o merge as one conv
                 lib.esmi_compose_merge_f32(_ptr(mw), _ptr(t["merge1_w"]), k, cin, co, _ptr(comp), stream)
                 t["merge_cwp"] = _pack_bfrag(lib, stream, comp)
+                _check_split_range(lib, stream, [comp, t["qkv_w"], t["proj_w"], t["mlp1_w"], cw, t["mlp2_w"]],
+                                   "encoder block weights")
                 keep.extend(t.values())
                 out.append((_lib.EncoderBlockWeights(**{k: _ptr(v) for k, v in t.items()}), keep))
             return out, _f32(self.embed.weight)
         return self._cache.get(lambda: list(self.parameters()), build)
 
     def forward(self, phoneme, mask=None):
+        with _on_device_of(self.embed.weight):
+            return self._forward(phoneme, mask)
+
+    def _forward(self, phoneme, mask=None):
         """phoneme int (B,T); mask bool (B,T) or None -> ([f_0..f_{depth-1}], decoder_mask (B,T,dim) or None)."""
         feats, masks = self._run(phoneme, mask)
         decoder_mask = None
@@ -230,7 +317,7 @@ class Encoder(_PackedModule):
                     raise RuntimeError(f"pooled mask length {(T + pool - 1) // pool} != sequence length {n}")
             # the padding mask is pooled on the fly inside the block (mask_pool): no pooled copy is materialised
             shape = _lib.EncoderBlockShape(B, n_in, self.dim_ins[i], self.dim_outs[i], self.heads[i], self.kernels[i],
-                                           self.strides[i], self.expansion, N_SYMBOLS + 1, pool, T)
+                                           self.strides[i], self.expansion, N_SYMBOLS + 1, pool, T, _lib.current_plan())
             ws_bytes = lib.esmi_encoder_block_workspace_bytes(C.byref(shape))
             ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
             x_out = torch.empty((B, n, self.dim_outs[i]), dtype=torch.float32, device=dev)
@@ -275,7 +362,41 @@ class AcousticDecoder(nn.Module):
                  lin_w=_f32(self.linear.weight), lin_b=_f32(self.linear.bias),
                  bins=None if bins is None else _f32(bins), emb=None if emb is None else _f32(emb.weight))
         t["conv1_wp"], t["conv2_wp"] = _pack_bfrag(lib, stream, c1), _pack_bfrag(lib, stream, c2)
+        _check_split_range(lib, stream, [c1, c2], "variance predictor weights")
         return _lib.PredictorWeights(**{k: _ptr(v) for k, v in t.items()}), list(t.values())
+
+    def forward(self, fused_features):
+        """networks.py:151-165 through esmi_acoustic_decoder_f32: (B,T,dim) -> y (B,T,1) [duration: (relu(y), features = LN2(.))];
+        `linear` reads the PRE-norm2 tensor.  (PhonemeEncoder runs all three predictors in one fused kernel instead.)"""
+        x = _f32(fused_features)
+        with _on_device_of(x):
+            lib, stream = _runtime(x)
+            B, T, dim = x.shape
+            w, _keep = self._weights(lib, stream)
+            pred = torch.empty((B, T, 1), dtype=torch.float32, device=x.device)
+            feats = torch.empty((B, T, dim), dtype=torch.float32, device=x.device) if self.duration else None
+            ws_bytes = lib.esmi_variance_adaptor_workspace_bytes(B, T, dim)
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device)
+            lib.esmi_acoustic_decoder_f32(C.byref(w), dim, B, T, int(self.duration), _ptr(x), dim, _ptr(pred), _ptr(feats),
+                                          _ptr(ws), ws_bytes, stream)
+            return (pred, feats) if self.duration else pred
+
+    def get_embedding(self, pred, target, mask, control=1.):
+        """networks.py:128-149: embedding(bucketize(target if target is not None else pred, bins)); shape = v.shape + (dim,)."""
+        bins = self.pitch_bins if self.pitch_bins is not None else self.energy_bins
+        emb = self.pitch_embedding if self.pitch_embedding is not None else self.energy_embedding
+        if emb is None:
+            return None
+        v = _f32(target if target is not None else pred)
+        with _on_device_of(v):
+            lib, stream = _runtime(v)
+            dim = emb.weight.shape[1]
+            out = torch.empty(tuple(v.shape) + (dim,), dtype=torch.float32, device=v.device)
+            if v.numel():
+                lib.esmi_bucket_embedding_f32(_ptr(v), _ptr(_f32(bins)), _ptr(_f32(emb.weight)), v.numel(), dim, _ptr(out), None, stream)
+            return out
+
+    get_pitch_embedding = get_energy_embedding = get_embedding
 
 
 class Fuse(_PackedModule):
@@ -312,6 +433,7 @@ class Fuse(_PackedModule):
             fwp = _pack_bfrag(lib, stream, fw)
             keep += [fw, fb, fwp]
             w.fuse_w, w.fuse_b, w.fuse_wp = _ptr(fw), _ptr(fb), _ptr(fwp)
+            _check_split_range(lib, stream, [t for t in keep if t.dim() >= 2 and t.dtype == torch.float32], "Fuse weights")
             return w, keep
         return self._cache.get(lambda: list(self.parameters()), build)
 
@@ -333,6 +455,10 @@ class Fuse(_PackedModule):
         return out
 
     def forward(self, features, mask=None):
+        with _on_device_of(self.fuse.weight):
+            return self._forward(features, mask)
+
+    def _forward(self, features, mask=None):
         """features: list of (B,N_i,dim*2^i); mask: (B,T,dim) bool or None -> (B,T,dim)."""
         m8 = None if mask is None else _mask_u8(mask[..., 0])
         return self._run([_f32(f) for f in features], m8)
@@ -342,6 +468,10 @@ class FeatureUpsampler(nn.Module):
     """Length regulator (networks.py:222-258) as a device-side scan + gather (no per-utterance host sync)."""
 
     def forward(self, fused_features, fused_masks, duration, max_mel_len=None):
+        with _on_device_of(fused_features):
+            return self._forward(fused_features, fused_masks, duration, max_mel_len)
+
+    def _forward(self, fused_features, fused_masks, duration, max_mel_len=None):
         """fused_features (B,T,C); fused_masks (B,T,C) bool; duration (B,T[,1]) -> features, masks, mel_len."""
         feat = _f32(fused_features)
         lib, stream = _runtime(feat)
@@ -419,11 +549,16 @@ class MelDecoder(_PackedModule):
                 put("skip_g", skip_norm.weight, b); put("skip_b", skip_norm.bias, b)
             put("mel_w", self.mel_linear.weight); put("mel_b", self.mel_linear.bias)
             blob = torch.empty(nbytes // 4, dtype=torch.float32, device=keep[0].device)
+            _check_split_range(lib, stream, [t for t in keep if t.dim() >= 2 and t.shape[1] > 1], "mel decoder weights")
             lib.esmi_mel_decoder_pack_f32(C.byref(w), C.byref(shape), _ptr(blob), stream)
             return blob
         return self._cache.get(lambda: list(self.parameters()), build)
 
     def forward(self, features):
+        with _on_device_of(self.mel_linear.weight):
+            return self._forward(features)
+
+    def _forward(self, features):
         """features (B,L,4*dim) -> mel (B,L,n_mel).  (Direct mode: rows exactly as given.)"""
         x = _f32(features)
         lib, stream = _runtime(x)
@@ -532,13 +667,14 @@ class PhonemeEncoder(_PackedModule):
         args = (C.byref(fw), depth, dim, self.fuse.kernel_size, B, T, fp, ni, C.byref(pw), C.byref(ew), C.byref(dw), _ptr(m8),
                 _ptr(pitch_t), _ptr(energy_t), _ptr(dur_t), _ptr(feat), _ptr(preds[0]), _ptr(preds[1]), _ptr(preds[2]),
                 _ptr(idxs[0]), _ptr(idxs[1]), _ptr(dur), _ptr(cum), _ptr(mel_len))
+        plan = _lib.current_plan()
         if h0 is not None:
             try:
-                lib.esmi_fuse_variance_adaptor_f32(*args, C.byref(head[0]), _ptr(h0), _ptr(ws), ws_bytes, stream)
+                lib.esmi_fuse_variance_adaptor_f32(*args, C.byref(head[0]), _ptr(h0), plan, _ptr(ws), ws_bytes, stream)
             except _lib.Unsupported:           # long sequences / other widths: the decoder runs its first stage itself
                 h0 = None
         if h0 is None:
-            lib.esmi_fuse_variance_adaptor_f32(*args, None, None, _ptr(ws), ws_bytes, stream)
+            lib.esmi_fuse_variance_adaptor_f32(*args, None, None, plan, _ptr(ws), ws_bytes, stream)
         enc = dict(feat=feat, mask_u8=m8, pitch=preds[0], energy=preds[1], duration=preds[2], pitch_idx=idxs[0],
                    energy_idx=idxs[1], dur=dur, cum=cum, mel_len=mel_len, lmax=None, feats=feats, h0=h0)
         if need_lmax:
@@ -571,6 +707,10 @@ class PhonemeEncoder(_PackedModule):
         return L, None, L
 
     def forward(self, x, train=False):
+        with _on_device_of(self.encoder.embed.weight):
+            return self._forward(x, train)
+
+    def _forward(self, x, train=False):
         enc = self._encode(x, train)
         lib, stream = _runtime(enc["feat"])
         feat, cum, m8 = enc["feat"], enc["cum"], enc["mask_u8"]
@@ -594,6 +734,10 @@ class Phoneme2Mel(nn.Module):
         self.decoder = decoder
 
     def forward(self, x, train=False):
+        with _on_device_of(self.decoder.mel_linear.weight):
+            return self._forward(x, train)
+
+    def _forward(self, x, train=False):
         if isinstance(x, list):                                       # ONNX-export quirk kept (:418-419)
             x = x[0]
         if train:
@@ -606,12 +750,86 @@ class Phoneme2Mel(nn.Module):
                 lib.esmi_mask_rows_f32(_ptr(mel), _ptr(m8), mel.shape[0] * mel.shape[1], mel.shape[2], stream)
             pred["mel"] = mel
             return pred
-        # inference: the (B,L,4*dim) tensor is never materialised -- the decoder gathers through the
-        # duration scan and applies the final masked_fill itself.
-        lib, stream = _runtime(self.decoder.mel_linear.weight)
-        enc = self.encoder._encode(x, train=False, need_lmax="max_mel_len" not in x, head=self.decoder._head(lib, stream))
-        B = enc["feat"].shape[0]
-        L, lmax_dev, lmax_host = PhonemeEncoder._padded_len(x, enc, False)
-        apply_mask = enc["mask_u8"] is not None and B > 1
-        mel = self.decoder._fused(enc["feat"], enc["cum"], enc["mel_len"], lmax_dev, lmax_host, apply_mask, L, h0=enc["h0"])
-        return mel, enc["mel_len"], enc["duration"]
+        # inference: the (B,L,4*dim) tensor is never materialised -- the decoder gathers through the duration scan and
+        # applies the final masked_fill itself; the whole forward is ONE C-ABI call (esmi_phoneme2mel_forward_f32)
+        st = self._launch(x)
+        return st.mel, st.mel_len, st.duration
+
+    # ------------------------------------------------------------------ one-call forward
+    def _static_args(self, lib, stream):
+        """The checkpoint-dependent part of esmi_forward_args (packed weights, shapes), rebuilt only when a packed cache was."""
+        enc = self.encoder
+        blocks, embed = enc.encoder._packed(lib, stream)
+        fw, _kf = enc.fuse._packed(lib, stream)
+        preds = enc._predictors(lib, stream)
+        blob = self.decoder._packed(lib, stream)
+        head = self.decoder._head(lib, stream)
+        ident = (id(blocks), id(fw), id(preds), id(blob), id(head), id(lib))
+        if getattr(self, "_fwd_ident", None) != ident:
+            a = _lib.ForwardArgs()
+            e = enc.encoder
+            a.depth, a.dim, a.fuse_kernel = e.depth, enc.dim, enc.fuse.kernel_size
+            for i, (wts, _keep) in enumerate(blocks):
+                a.blocks[i] = wts
+                a.shapes[i] = _lib.EncoderBlockShape(0, 0, e.dim_ins[i], e.dim_outs[i], e.heads[i], e.kernels[i], e.strides[i],
+                                                     e.expansion, N_SYMBOLS + 1, 0, 0, 0)
+            a.embed = _ptr(embed)
+            a.fuse = fw
+            a.pitch, a.energy, a.duration = preds[0][0], preds[1][0], preds[2][0]
+            if head is not None:
+                a.head = head[0]
+            a.dec_blob = _ptr(blob)
+            a.dec_shape = self.decoder._shape()
+            self._fwd_args, self._fwd_keep, self._fwd_ident = a, (blocks, embed, fw, preds, blob, head), ident
+        return self._fwd_args
+
+    def _launch(self, x, stage=0, state=None):
+        """Enqueue the inference forward (stage 0), its encoder side only (1), or the decoder (2) on the `state` a stage-1
+        call returned (a multi-GPU caller MAX-reduces `state.lmax` in between).  -> namespace with mel, mel_len,
+        duration (B,T,1), lmax (device scalar or None)."""
+        from types import SimpleNamespace
+        w = self.decoder.mel_linear.weight
+        lib, stream = _runtime(w)
+        dev = w.device
+        a = self._static_args(lib, stream)
+        if stage == 2:
+            st = state
+        else:
+            phoneme = x["phoneme"]
+            B = phoneme.shape[0]
+            phoneme_mask = x["phoneme_mask"] if B > 1 else None       # KeyError for B>1, as the reference (:338)
+            ids = phoneme.detach().to(device=dev, dtype=torch.int32).contiguous()
+            T = ids.shape[1]
+            dur_t = None
+            if "duration_forced" in x:                                # extension: inject durations at inference
+                dur_t = x["duration_forced"].detach().reshape(B, T).to(device=dev, dtype=torch.int32).contiguous()
+            st = SimpleNamespace(ids=ids, m8=_mask_u8(phoneme_mask), dur_t=dur_t, B=B, T=T, lmax=None, mel=None, L_out=None,
+                                 lmax_host=None, plan=_lib.current_plan(),
+                                 mel_len=torch.empty((B,), dtype=torch.int32, device=dev),
+                                 duration=torch.empty((B, T, 1), dtype=torch.float32, device=dev))
+            if "max_mel_len" in x:                                    # extension: output length from the caller, no host sync
+                st.L_out = int(x["max_mel_len"])
+                st.lmax_host = st.L_out if bool(x.get("max_mel_len_exact", False)) else -1
+            if st.L_out is None or (stage == 1 and st.lmax_host < 0):
+                st.lmax = torch.empty((1,), dtype=torch.int32, device=dev)
+        # per-call fields of THIS state
+        a.B, a.T, a.plan = st.B, st.T, st.plan
+        a.ids, a.mask, a.dur_forced = _ptr(st.ids), _ptr(st.m8), _ptr(st.dur_t)
+        a.duration_pred, a.mel_len, a.lmax_dev = _ptr(st.duration), _ptr(st.mel_len), _ptr(st.lmax)
+        a.pitch_pred = a.energy_pred = a.pitch_idx = a.energy_idx = a.dur = a.cum = None
+        if stage != 2:
+            nbytes = lib.esmi_forward_arena_bytes(C.byref(a))
+            st.arena = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        a.arena, a.arena_bytes = _ptr(st.arena), st.arena.numel()
+        if stage != 2 and (stage == 1 or st.L_out is None):          # encoder side as its own call
+            a.L_out, a.lmax_host, a.mel = 0, 0, None
+            lib.esmi_phoneme2mel_forward_f32(C.byref(a), 1, stream)
+            if stage == 1:
+                return st
+            stage = 2
+        if st.L_out is None:                                          # the reference's behaviour: L = batch maximum (host sync)
+            st.L_out = st.lmax_host = int(st.lmax.item())
+        st.mel = torch.empty((st.B, st.L_out, self.decoder.n_mel_channels), dtype=torch.float32, device=dev)
+        a.mel, a.L_out, a.lmax_host = _ptr(st.mel), st.L_out, st.lmax_host
+        lib.esmi_phoneme2mel_forward_f32(C.byref(a), stage, stream)
+        return st

@@ -18,12 +18,12 @@ import torch.distributed as dist
 
 
 
-def _encode_with_head(net, x):
+def _encode_with_head(net, x, need_lmax=True):
     """Encoder side of the forward, including the decoder's row-wise first stage at phoneme rate when the fused kernel
     can produce it (networks.MelDecoder._head)."""
-    from .networks import _runtime
-    lib, stream = _runtime(net.decoder.mel_linear.weight)
-    return net.encoder._encode(x, train=False, head=net.decoder._head(lib, stream))
+    from . import networks
+    lib, stream = networks._runtime(net.decoder.mel_linear.weight)
+    return net.encoder._encode(x, train=False, need_lmax=need_lmax, head=net.decoder._head(lib, stream))
 
 
 def shard_batch(x, rank, world):
@@ -37,6 +37,21 @@ def shard_batch(x, rank, world):
     return out
 
 
+def _masked_path_inputs(x):
+    """A 1-utterance shard of a B > 1 batch must still take the masked (B > 1) code path of the reference
+    (networks.py:338: the mask is dropped for B == 1): duplicate the utterance; the caller drops the copy afterwards.
+    -> (x, duplicated?)"""
+    if x["phoneme"].shape[0] != 1:
+        return x, False
+    return {k: (torch.cat([v, v]) if torch.is_tensor(v) and v.dim() > 0 and v.shape[0] == 1 else v) for k, v in x.items()}, True
+
+
+def _exact_len(x):
+    """The caller states that x['max_mel_len'] IS the batch's padded length (e.g. forced durations known on the host):
+    the 4-byte MAX all-reduce of the padded length is then unnecessary (extension key `max_mel_len_exact`)."""
+    return "max_mel_len" in x and bool(x.get("max_mel_len_exact", False))
+
+
 def sharded_forward(net, x_full, group=None):
     """Run Phoneme2Mel inference on this rank's shard of `x_full`, return the full
     (mel (B,L,80), mel_len (B,), duration (B,T,1)) on every rank."""
@@ -47,23 +62,21 @@ def sharded_forward(net, x_full, group=None):
     x = shard_batch(x_full, rank, world)
     if "phoneme_mask" not in x_full and x_full["phoneme"].shape[0] > 1:
         raise KeyError("phoneme_mask")                     # same contract as the reference for B > 1
-    if x["phoneme"].shape[0] == 1:
-        # a 1-utterance shard of a B>1 batch must still take the masked (B>1) code path of the
-        # reference (networks.py:338); duplicate the utterance and drop the copy afterwards.
-        x = {k: (torch.cat([v, v]) if torch.is_tensor(v) and v.dim() > 0 and v.shape[0] == 1 else v) for k, v in x.items()}
-        dup = True
-    else:
-        dup = False
+    x, dup = _masked_path_inputs(x)
     # The padded length L is a property of the WHOLE batch (the reference zero-pads its convolutions at the
     # batch max), so the local maxima are MAX-reduced on the device before the decoder runs.  With a
     # caller-supplied bound (`max_mel_len`) the output is allocated at that bound and no host sync happens.
-    enc = _encode_with_head(net, x)
-    dist.all_reduce(enc["lmax"], op=dist.ReduceOp.MAX, group=group)
-    if "max_mel_len" in x:
-        L_out, lmax_dev = int(x["max_mel_len"]), enc["lmax"]
+    enc = _encode_with_head(net, x, need_lmax=not _exact_len(x))
+    if _exact_len(x):
+        L_out, lmax_dev, lmax_host = int(x["max_mel_len"]), None, int(x["max_mel_len"])
     else:
-        L_out, lmax_dev = int(enc["lmax"].item()), None
-    mel = net.decoder._fused(enc["feat"], enc["cum"], enc["mel_len"], lmax_dev, L_out, True, L_out, h0=enc["h0"])
+        dist.all_reduce(enc["lmax"], op=dist.ReduceOp.MAX, group=group)
+        if "max_mel_len" in x:
+            L_out, lmax_dev, lmax_host = int(x["max_mel_len"]), enc["lmax"], -1
+        else:
+            L_out = int(enc["lmax"].item())
+            lmax_dev, lmax_host = None, L_out
+    mel = net.decoder._fused(enc["feat"], enc["cum"], enc["mel_len"], lmax_dev, lmax_host, True, L_out, h0=enc["h0"])
     mel_len, dur = enc["mel_len"], enc["duration"]
     if dup:
         mel, mel_len, dur = mel[:1], mel_len[:1], dur[:1]
@@ -146,6 +159,7 @@ class ShardedMelPipeline:
         # workgroups on every CU (needs the <=168-VGPR builds of both).
         self.two_stream = two_stream
         self.s_enc = self.s_dec = None
+        self.last_ready = None   # event after which `last` may be read (None: it was produced on the caller's stream)
 
     def _compute(self, x):
         """-> (mel, mel_len) of this rank's shard; global padded length MAX-reduced when world > 1."""
@@ -166,22 +180,33 @@ class ShardedMelPipeline:
             else:
                 mel = g.decode()
             return mel, enc["mel_len"]
-        if self.two_stream:
-            return self._compute_two_stream(x)
         if self.world == 1:
             mel, mel_len, _ = self.net(x)
             return mel, mel_len
-        # global padded length: 4-byte MAX all-reduce on the compute stream (see sharded_forward)
-        enc = _encode_with_head(self.net, x)
-        dist.all_reduce(enc["lmax"], op=dist.ReduceOp.MAX, group=self.group)
-        if "max_mel_len" in x:
-            L_out, lmax_dev = int(x["max_mel_len"]), enc["lmax"]
+        # global padded length: 4-byte MAX all-reduce on the compute stream (see sharded_forward) -- unless the caller
+        # vouches for it (max_mel_len_exact): then nothing sits between the encoder side and the decoder
+        x, dup = _masked_path_inputs(x)
+        enc = _encode_with_head(self.net, x, need_lmax=not _exact_len(x))
+        if _exact_len(x):
+            L_out, lmax_dev, lmax_host = int(x["max_mel_len"]), None, int(x["max_mel_len"])
         else:
-            L_out, lmax_dev = int(enc["lmax"].item()), None
-        mel = self.net.decoder._fused(enc["feat"], enc["cum"], enc["mel_len"], lmax_dev, L_out, True, L_out, h0=enc["h0"])
-        return mel, enc["mel_len"]
+            dist.all_reduce(enc["lmax"], op=dist.ReduceOp.MAX, group=self.group)
+            if "max_mel_len" in x:
+                L_out, lmax_dev, lmax_host = int(x["max_mel_len"]), enc["lmax"], -1
+            else:
+                L_out = int(enc["lmax"].item())
+                lmax_dev, lmax_host = None, L_out
+        mel = self.net.decoder._fused(enc["feat"], enc["cum"], enc["mel_len"], lmax_dev, lmax_host, True, L_out, h0=enc["h0"])
+        mel_len = enc["mel_len"]
+        if dup:
+            mel, mel_len = mel[:1], mel_len[:1]
+        return mel, mel_len
 
     def _compute_two_stream(self, x):
+        """Encoder side on s_enc, decoder on s_dec.  -> (mel, mel_len, done): `done` is recorded on s_dec after the decoder;
+        the CALLER's stream is deliberately not made to wait for it here (it would serialise step i+1's encoder side behind
+        step i's decoder through the caller's stream): consumers order themselves after `done` (step() does for the
+        all-gather; `wait_last()` for code that reads `last` on the current stream)."""
         dev = x["phoneme"].device
         if self.s_enc is None:
             # the encoder side is three short latency-bound launches: high priority, so that its few workgroups take the
@@ -191,35 +216,51 @@ class ShardedMelPipeline:
             self.s_enc, self.s_dec = torch.cuda.Stream(device=dev, priority=prio), torch.cuda.Stream(device=dev)
         cur = torch.cuda.current_stream(dev)
         self.s_enc.wait_stream(cur)                       # inputs produced on the caller's stream
+        x, dup = _masked_path_inputs(x) if self.world > 1 else (x, False)
         with torch.cuda.stream(self.s_enc):
-            enc = _encode_with_head(self.net, x)
-            if self.world > 1:
+            exact = _exact_len(x)
+            enc = _encode_with_head(self.net, x, need_lmax=not exact)
+            if self.world > 1 and not exact:
                 dist.all_reduce(enc["lmax"], op=dist.ReduceOp.MAX, group=self.group)
             ready = torch.cuda.Event()
             ready.record()
-        if "max_mel_len" in x:
-            L_out, lmax_dev = int(x["max_mel_len"]), enc["lmax"]
+        if exact:
+            L_out, lmax_dev, lmax_host = int(x["max_mel_len"]), None, int(x["max_mel_len"])
+        elif "max_mel_len" in x:
+            L_out, lmax_dev, lmax_host = int(x["max_mel_len"]), enc["lmax"], -1
         else:
             ready.synchronize()
-            L_out, lmax_dev = int(enc["lmax"].item()), None
+            L_out = int(enc["lmax"].item())
+            lmax_dev, lmax_host = None, L_out
         with torch.cuda.stream(self.s_dec):
             self.s_dec.wait_event(ready)
-            for t in (enc["feat"], enc["cum"], enc["mel_len"], enc["lmax"]):
-                t.record_stream(self.s_dec)
-            mel = self.net.decoder._fused(enc["feat"], enc["cum"], enc["mel_len"], lmax_dev, L_out, True, L_out, h0=enc["h0"])
+            # every tensor the decoder reads was allocated on s_enc: tell the allocator s_dec uses it too, or step i+1's
+            # encoder side (running while this decoder still reads) may be handed the same blocks (h0 was missing)
+            for t in (enc["feat"], enc["cum"], enc["mel_len"], enc["lmax"], enc["h0"], enc["mask_u8"]):
+                if t is not None:
+                    t.record_stream(self.s_dec)
+            mel = self.net.decoder._fused(enc["feat"], enc["cum"], enc["mel_len"], lmax_dev, lmax_host, True, L_out, h0=enc["h0"])
             done = torch.cuda.Event()
             done.record()
-        self._dec_done = done
-        mel.record_stream(cur)
-        return mel, enc["mel_len"]
+        mel_len = enc["mel_len"]
+        if dup:
+            mel, mel_len = mel[:1], mel_len[:1]
+        mel.record_stream(cur)                            # the caller will read it on its own stream (after `done`)
+        mel_len.record_stream(cur)
+        return mel, mel_len, done
+
+    def wait_last(self, stream=None):
+        """Order `stream` (default: the current one) after the producer of `last` (two-stream mode: the decoder stream)."""
+        if self.last_ready is not None:
+            (stream or torch.cuda.current_stream()).wait_event(self.last_ready)
 
     def step(self, x):
-        mel, mel_len = self._compute(x)
-        if self.two_stream and not self.gather:
-            self.last = (mel, mel_len)
-            return self.last
-        if self.two_stream:
-            torch.cuda.current_stream().wait_event(self._dec_done)
+        done = None
+        if self.two_stream and not (self.use_graph and "max_mel_len" in x):
+            mel, mel_len, done = self._compute_two_stream(x)
+        else:
+            mel, mel_len = self._compute(x)
+        self.last_ready = done
         if not self.gather:
             self.last = (mel, mel_len)
             return self.last
@@ -227,21 +268,23 @@ class ShardedMelPipeline:
             self.comm = torch.cuda.Stream(device=mel.device)
         while len(self.inflight) >= self.depth:            # bound queue depth / memory
             self.inflight.pop(0)[0].synchronize()
-        ready = torch.cuda.Event()
-        ready.record()                                      # compute stream: mel is complete here
+        if done is None:
+            done = torch.cuda.Event()
+            done.record()                                   # compute stream: mel is complete here
         if self.graphed is None:                            # graph buffers are static: nothing to protect
             mel.record_stream(self.comm)
             mel_len.record_stream(self.comm)
         with torch.cuda.stream(self.comm):
-            self.comm.wait_event(ready)
+            self.comm.wait_event(done)
             full = torch.empty((mel.shape[0] * self.world,) + tuple(mel.shape[1:]), dtype=mel.dtype, device=mel.device)
             lens = torch.empty((mel_len.shape[0] * self.world,), dtype=mel_len.dtype, device=mel.device)
             dist.all_gather_into_tensor(full, mel, group=self.group)
             dist.all_gather_into_tensor(lens, mel_len, group=self.group)
-            done = torch.cuda.Event()
-            done.record()
-        self.inflight.append((done, full, lens))
+            gathered = torch.cuda.Event()
+            gathered.record()
+        self.inflight.append((gathered, full, lens))
         self.last = (full, lens)
+        self.last_ready = gathered
         return self.last
 
     def flush(self):

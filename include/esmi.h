@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define ESMI_VERSION 100 /* 0.1.0 */
+#define ESMI_VERSION 200 /* 0.2.0: launch plan per call (no process-global state), module-level entry points, range guard */
 
 #define ESMI_OK 0
 #define ESMI_ERR_ARG (-1)         /* null pointer / bad size */
@@ -44,20 +44,20 @@ typedef void* esmi_stream_t; /* hipStream_t */
 int esmi_version(void);
 /* "hip:gfx950" for the product build; "wavesim" for the CPU test simulator build. */
 const char* esmi_backend(void);
-/* Build-time choices that change HOW (not what) the library computes, e.g. "dec_gemm=split-bf16x3" (the mel decoder's
- * contractions as fp32-accurate split products on the bf16 matrix pipe) or "dec_gemm=fp32-mfma". */
+/* Build-time choices that change HOW (not what) the library computes, e.g. "dec_gemm=split-f16x2,enc_gemm=split-f16x2" (weight
+ * GEMMs as fp32-accurate split products on the f16 matrix pipe) or "dec_gemm=fp32-mfma,enc_gemm=fp32-mfma". */
 const char* esmi_build_config(void);
 
-/* Fusion switch (process-global bit mask, default ESMI_FUSE_ALL): a cleared bit forces one kernel per
- * reference op for that stage instead of the fused wave-chain kernel.  Returns the previous mask.
- * Exists for tests and ablation; both launch plans are parity-tested. */
+/* Launch plan: a bit mask passed PER CALL (esmi_encoder_block_shape.plan, the `plan` argument of
+ * esmi_fuse_variance_adaptor_f32) -- the library keeps no mutable state, calls are re-entrant.  A cleared bit forces one kernel
+ * per reference op for that stage instead of the fused wave-chain kernel; every plan is parity-tested.  Normal callers pass
+ * ESMI_FUSE_ALL. */
 #define ESMI_FUSE_MERGE_QKV 1 /* merge convs + 1x1 + qkv                 */
 #define ESMI_FUSE_ATTN_FFN 2  /* attention + proj + LN1 + MixFFN + LN2   */
 #define ESMI_FUSE_VARIANCE 4  /* Fuse + 3 predictors + embeddings + round */
 #define ESMI_FUSE_SPLIT2 8    /* two-head blocks on short sequences: two waves per row tile */
 #define ESMI_FUSE_BLOCK 16    /* whole encoder block in one launch when one workgroup covers the sequence */
 #define ESMI_FUSE_ALL 31
-int esmi_set_fusion(int enabled);
 
 /* ------------------------------------------------------------------ weight packing
  * nn.Conv1d weight (Cout, Cin, k) -> (k, Cout, Cin)            [networks.py:40-42, blocks.py:17] */
@@ -65,7 +65,8 @@ int esmi_pack_conv_weight_f32(const float* src, float* dst, int cout, int cin, i
 /* nn.ConvTranspose1d weight (Cin, Cout, k) -> (k, Cout, Cin)   [networks.py:183] */
 int esmi_pack_convT_weight_f32(const float* src, float* dst, int cin, int cout, int k, esmi_stream_t stream);
 
-/* MFMA B-fragment order of `taps` row-major (n, k) matrices (k a multiple of 8), NT = ceil(n/32):
+/* MFMA B-fragment order of `taps` row-major (n, k) matrices (k a multiple of 8; of 32 in the split-f16 build, else
+ * ESMI_ERR_UNSUPPORTED), NT = ceil(n/32):
  *   dst[(((t*(k/8) + kc)*NT + nt)*64 + lane)*4 + s] = src[t][32nt + (lane&31)][8kc + 4(lane>>5) + s]   (0 for rows >= n)
  * src is an nn.Linear weight (taps = 1) or a tap-major conv weight (k_taps, Cout, Cin).
  * That is the fp32-MFMA build (enc_gemm=fp32-mfma in esmi_build_config()).  The default build (enc_gemm=split-f16x2)
@@ -126,6 +127,7 @@ typedef struct esmi_encoder_block_shape {
     int mask_pool, mask_len; /* `mask` is (B, mask_len) and output row n is padding iff any of
                               * mask[n*mask_pool .. +mask_pool) is set or lies beyond mask_len
                               * (blocks.py:51-57 applied on the fly).  0 / 0 = mask is (B, n_out). */
+    int plan;                /* ESMI_FUSE_* bits (launch plan of THIS call)                   */
 } esmi_encoder_block_shape;
 
 size_t esmi_encoder_block_workspace_bytes(const esmi_encoder_block_shape* s);
@@ -226,7 +228,43 @@ int esmi_fuse_variance_adaptor_f32(const esmi_fuse_weights* fuse, int depth, int
                                    const esmi_decoder_head* head, float* h0, /* (B,T,dx2) or NULL, NULL; returns
                                       ESMI_ERR_UNSUPPORTED (nothing launched) when h0 is requested for a shape the
                                       fused kernel cannot serve: call again without it                            */
+                                   int plan,                                 /* ESMI_FUSE_* bits of this call     */
                                    void* workspace, size_t workspace_bytes, esmi_stream_t stream);
+
+/* ------------------------------------------------------------------ module-level forwards
+ * The reference's sub-modules called on their own (one kernel per reference op, fp32 MFMA):
+ *  SelfAttention.forward, layers/blocks.py:43-71: qkv Linear (bias-free) -> per-head softmax((q k^T) (C//h)^-1/2) v with every
+ *  head at full width C, scores NOT masked -> proj Linear.  x, out: (B,N,C).  N <= 256 (ESMI_ERR_UNSUPPORTED beyond). */
+size_t esmi_self_attention_workspace_bytes(int B, int N, int C, int heads);
+int esmi_self_attention_f32(const float* qkv_w /* (3hC, C) */, const float* proj_w /* (C, hC) */, const float* proj_b, int B, int N,
+                            int C, int heads, const float* x, float* out, void* workspace, size_t workspace_bytes,
+                            esmi_stream_t stream);
+/* MixFFN.forward, layers/blocks.py:22-29: Linear(C, eC) -> dense Conv1d(eC, eC, 3, pad 1) -> exact-erf GELU -> Linear(eC, C).
+ * conv_w tap-major (3, eC, eC). */
+size_t esmi_mixffn_workspace_bytes(int B, int N, int C, int expansion);
+int esmi_mixffn_f32(const float* mlp1_w, const float* mlp1_b, const float* conv_w, const float* conv_b, const float* mlp2_w,
+                    const float* mlp2_b, int B, int N, int C, int expansion, const float* x, float* out, void* workspace,
+                    size_t workspace_bytes, esmi_stream_t stream);
+/* AcousticDecoder.forward, layers/networks.py:151-165: conv1+ReLU -> LN1 -> ReLU -> conv2+ReLU; pred = Linear(dim,1) of the
+ * PRE-norm2 tensor (ReLU'd for the duration predictor, which also returns features = LN2(.)).  x rows have leading dimension
+ * ldx >= dim.  workspace: esmi_variance_adaptor_workspace_bytes(B, T, dim). */
+int esmi_acoustic_decoder_f32(const esmi_predictor_weights* w, int dim, int B, int T, int duration, const float* x, int ldx,
+                              float* pred /* (B,T) */, float* features /* (B,T,dim), duration predictor only, else NULL */,
+                              void* workspace, size_t workspace_bytes, esmi_stream_t stream);
+/* AcousticDecoder.get_embedding, layers/networks.py:128-149: idx = torch.bucketize(v, bins) (right=False, dim-1 edges),
+ * out[row] = emb[idx] (dim floats); idx (rows) may be NULL. */
+int esmi_bucket_embedding_f32(const float* v, const float* bins, const float* emb, int64_t rows, int dim, float* out,
+                              int32_t* idx, esmi_stream_t stream);
+
+/* ------------------------------------------------------------------ operand-range guard of the split-f16 build
+ * The default build computes weight GEMMs as fp32-accurate split products on the f16 matrix pipe: 2^8 * W must
+ * be a finite binary16 number.  esmi_split_weight_limit() is the largest admissible |W| (inf for the fp32-MFMA build);
+ * esmi_absmax_f32 reduces max|x| (NaN -> inf) into a device float so that a loader can check a checkpoint ONCE at pack time
+ * (efficientspeech_amd/networks.py raises ValueError and names libesmi_fp32mfma.so as the build to use instead).
+ * Activations saturate gracefully: the first piece is converted round-toward-zero (never inf), so values up to 131008 are
+ * represented by the two pieces (with fewer bits above 65504); LayerNorm / tanh / GELU outputs are orders of magnitude below. */
+float esmi_split_weight_limit(void);
+int esmi_absmax_f32(const float* x, int64_t n, float* out, esmi_stream_t stream);
 
 /* ------------------------------------------------------------------ Length regulator
  * FeatureUpsampler.forward, layers/networks.py:228-258 (and its dead twin acoustic.py:33-42):
@@ -295,6 +333,45 @@ int esmi_mel_decoder_f32(const float* blob, const esmi_decoder_shape* s, const f
                          const float* h0, /* optional, fused mode only: (B,T,dx2) = LN(tanh(proj(x))), see esmi_decoder_head */
                          const int32_t* cum, const int32_t* mel_len, const int32_t* lmax_dev, int lmax_host, int apply_mask, int B,
                          int T, int L_out, float* mel, esmi_stream_t stream);
+
+/* ------------------------------------------------------------------ whole inference forward in ONE call
+ * Phoneme2Mel.forward (eval), layers/networks.py:415-434 = Encoder blocks -> Fuse + variance adaptor (+ length-regulator scan,
+ * + the decoder's phoneme-rate first stage when the fused kernel serves the shape) -> fused mel decoder, enqueued by a C
+ * host loop: one FFI crossing per forward instead of one per stage (the Python glue between the per-stage calls cost
+ * ~0.1 ms per forward in round 1 -- more than the GPU time of a 32-utterance shard).  Same kernels, same results as the
+ * per-stage entry points above.
+ *
+ * Scratch: ONE caller-provided arena of esmi_forward_arena_bytes() bytes (256-byte aligned base); nothing in it needs to
+ * survive the call.  Outputs the reference returns are separate caller buffers: mel, mel_len, duration_pred.            */
+typedef struct esmi_forward_args {
+    int B, T, depth, dim, fuse_kernel, plan;
+    esmi_encoder_block_weights blocks[ESMI_MAX_DEPTH];
+    esmi_encoder_block_shape shapes[ESMI_MAX_DEPTH]; /* B / n_in / mask_pool / mask_len / plan are filled in by the call */
+    const float* embed;
+    esmi_fuse_weights fuse;
+    esmi_predictor_weights pitch, energy, duration;
+    esmi_decoder_head head;       /* proj_wp == NULL: the decoder runs its first stage itself                     */
+    const float* dec_blob;
+    esmi_decoder_shape dec_shape;
+    /* inputs */
+    const int32_t* ids;           /* (B,T)                                                                         */
+    const uint8_t* mask;          /* (B,T) or NULL (the reference's B == 1 path)                                   */
+    const int32_t* dur_forced;    /* (B,T) or NULL: injected durations (extension)                  */
+    /* outputs */
+    float* duration_pred;         /* (B,T)                                                                         */
+    int32_t* mel_len;             /* (B)                                                                           */
+    float* mel;                   /* (B, L_out, n_mel)                                                             */
+    int L_out;                    /* allocation length of mel; rows >= the batch's padded length are zeroed        */
+    int lmax_host;                /* >= 0: the caller knows the padded length exactly; -1: derived from mel_len on the device */
+    int32_t* lmax_dev;            /* optional out: device scalar max_b mel_len[b] (multi-GPU MAX-reduce); NULL to skip */
+    /* optional taps (NULL to skip): what PhonemeEncoder._encode exposes to tests / training-style callers */
+    float* pitch_pred; float* energy_pred; int32_t* pitch_idx; int32_t* energy_idx; int32_t* dur; int32_t* cum;
+    void* arena; size_t arena_bytes;
+} esmi_forward_args;
+size_t esmi_forward_arena_bytes(const esmi_forward_args* a);
+/* stage = 0: everything; 1: encoder side only (up to cum / mel_len / lmax_dev / h0, kept in the arena); 2: mel decoder only,
+ * on the arena a stage-1 call filled (same args) -- lets a multi-GPU caller put its MAX all-reduce of lmax_dev in between. */
+int esmi_phoneme2mel_forward_f32(const esmi_forward_args* a, int stage, esmi_stream_t stream);
 
 /* x.masked_fill(mask[:, :, None], 0) on (rows, C) fp32 -- used by the module-level API when the
  * decoder is called stand-alone.                                                              */

@@ -229,6 +229,18 @@ static void mixffn(const float* x, int B, int N, int C, int e, const float* w1, 
     free(t2);
 }
 
+/* the two sub-module forwards on their own (tests of the module-level API; weights in checkpoint layouts) */
+int eso_self_attention(int B, int N, int C, int h, const float* x, const float* Wqkv, const float* Wproj,
+                       const float* bproj, float* y) {
+    self_attention(x, B, N, C, h, Wqkv, Wproj, bproj, y);
+    return ESO_OK;
+}
+int eso_mixffn(int B, int N, int C, int e, const float* x, const float* w1, const float* b1, const float* wc,
+               const float* bc, const float* w2, const float* b2, float* y) {
+    mixffn(x, B, N, C, e, w1, b1, wc, bc, w2, b2, y);
+    return ESO_OK;
+}
+
 /* pooled padding mask of an encoder block: blocks.py:51-57.
  * pad the (B,T) mask with True to a multiple of `pool`, then max over groups of `pool`. */
 static void pool_mask(const uint8_t* mask, int B, int T, int pool, uint8_t* out, int Nout) {

@@ -26,7 +26,9 @@ class _Weights(C.Structure):
 
 def build(force=False):
     """Compile both oracle variants with gcc (called by __graft_entry__.build())."""
-    if force or not all(os.path.exists(os.path.join(_HERE, f)) for f in ("libes_oracle.so", "libes_oracle_f32.so")):
+    src = os.path.join(_HERE, "es_oracle.c")
+    libs = [os.path.join(_HERE, f) for f in ("libes_oracle.so", "libes_oracle_f32.so")]
+    if force or not all(os.path.exists(f) and os.path.getmtime(f) >= os.path.getmtime(src) for f in libs):
         subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
 
 
@@ -39,7 +41,8 @@ def lib(f32=False):
         L = C.CDLL(path)
         L.eso_block_len.restype = C.c_int
         L.eso_acc_bytes.restype = C.c_int
-        for fn in ("eso_phoneme_encoder", "eso_mel_decoder", "eso_encoder", "eso_fuse", "eso_acoustic"):
+        for fn in ("eso_phoneme_encoder", "eso_mel_decoder", "eso_encoder", "eso_fuse", "eso_acoustic", "eso_self_attention",
+                   "eso_mixffn"):
             getattr(L, fn).restype = C.c_int
         _LIBS[name] = L
     return _LIBS[name]
@@ -152,6 +155,42 @@ def phoneme2mel(cfg, w: Weights, phoneme, mask=None, pitch=None, energy=None, du
     else:
         o.masks = None
     return o
+
+
+def _f(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def self_attention(x, qkv_w, proj_w, proj_b, heads):
+    """SelfAttention.forward's tensor output (blocks.py:43-71; scores not masked); weights in checkpoint layout."""
+    x, qkv_w, proj_w, proj_b = _f(x), _f(qkv_w), _f(proj_w), _f(proj_b)
+    B, N, Cc = x.shape
+    y = np.empty_like(x)
+    _chk(lib().eso_self_attention(B, N, Cc, int(heads), _p(x), _p(qkv_w), _p(proj_w), _p(proj_b), _p(y)), "self_attention")
+    return y
+
+
+def mixffn(x, mlp1_w, mlp1_b, conv_w, conv_b, mlp2_w, mlp2_b):
+    """MixFFN.forward (blocks.py:22-29); conv_w (eC, eC, 3) as stored in the checkpoint."""
+    x = _f(x)
+    B, N, Cc = x.shape
+    e = mlp1_w.shape[0] // Cc
+    y = np.empty_like(x)
+    _chk(lib().eso_mixffn(B, N, Cc, int(e), _p(x), _p(_f(mlp1_w)), _p(_f(mlp1_b)), _p(_f(conv_w)), _p(_f(conv_b)),
+                          _p(_f(mlp2_w)), _p(_f(mlp2_b)), _p(y)), "mixffn")
+    return y
+
+
+def acoustic(cfg, w: Weights, which, fused):
+    """AcousticDecoder.forward (networks.py:151-165) of the pitch (0) / energy (1) / duration (2) predictor:
+    -> (pred (B,T,1), features (B,T,dim) [LN2 output; the reference returns it for the duration predictor only])."""
+    fused = _f(fused)
+    B, T, dim = fused.shape
+    pred = np.empty((B, T, 1), np.float32)
+    feats = np.empty((B, T, dim), np.float32)
+    c = _cfg(cfg)
+    _chk(lib().eso_acoustic(C.byref(c), C.byref(w.c), int(which), B, T, _p(fused), _p(pred), _p(feats)), "acoustic")
+    return pred, feats
 
 
 def mask_from_lengths(lengths, T):

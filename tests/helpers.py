@@ -97,3 +97,53 @@ def compare_eval_with_oracle(cfg, o, enc, mel, mel_len, sd):
     err = float(np.abs(m - o.mel).max())
     assert err < MEL_TOL, err
     return err
+
+
+def check_submodule_forwards(net, cfg, sd, device, seed=3):
+    """The reference's sub-modules called on their own (SelfAttention / MixFFN / AcousticDecoder.forward, get_embedding,
+    blocks.py:22-29,43-71, networks.py:128-165) against the oracle's restatement of the same functions."""
+    from oracle import oracle
+    rng = np.random.default_rng(seed)
+    enc = net.encoder.encoder
+    for i, blk in enumerate(enc.attn_blocks):
+        attn, ffn = blk[2], blk[3]
+        Cc, B, N = enc.dim_outs[i], 2, 37
+        x = rng.standard_normal((B, N, Cc)).astype(np.float32)
+        pre = f"encoder.encoder.attn_blocks.{i}."
+        ref = oracle.self_attention(x, sd[pre + "2.qkv.weight"], sd[pre + "2.proj.weight"], sd[pre + "2.proj.bias"], enc.heads[i])
+        mask = np.arange(2 * N)[None, :] >= np.array([2 * N, 41])[:, None]
+        with torch.no_grad():
+            y, am = attn(torch.from_numpy(x).to(device), mask=torch.from_numpy(mask).to(device), pool=2)
+            y2, am2 = attn(torch.from_numpy(x).to(device))
+        assert am2 is None and torch.equal(y, y2)
+        np.testing.assert_allclose(y.cpu().numpy(), ref, atol=PRED_TOL, rtol=0)
+        pooled = mask.reshape(B, N, 2).max(-1)
+        assert am.shape == (B, N, Cc) and am.dtype == torch.bool and np.array_equal(am[:, :, 0].cpu().numpy(), pooled)
+        ref = oracle.mixffn(x, sd[pre + "3.mlp1.weight"], sd[pre + "3.mlp1.bias"], sd[pre + "3.conv.weight"],
+                            sd[pre + "3.conv.bias"], sd[pre + "3.mlp2.weight"], sd[pre + "3.mlp2.bias"])
+        with torch.no_grad():
+            y = ffn(torch.from_numpy(x).to(device))
+        np.testing.assert_allclose(y.cpu().numpy(), ref, atol=PRED_TOL, rtol=0)
+    w = oracle.Weights(sd)
+    fused = rng.standard_normal((3, 29, cfg.dim)).astype(np.float32)
+    for which, dec in enumerate((net.encoder.pitch_decoder, net.encoder.energy_decoder, net.encoder.duration_decoder)):
+        pred, feats = oracle.acoustic(cfg, w, which, fused)
+        with torch.no_grad():
+            out = dec(torch.from_numpy(fused).to(device))
+        if which == 2:
+            np.testing.assert_allclose(out[0].cpu().numpy(), pred, atol=PRED_TOL, rtol=0)
+            np.testing.assert_allclose(out[1].cpu().numpy(), feats, atol=PRED_TOL, rtol=0)
+        else:
+            assert out.shape == (3, 29, 1)
+            np.testing.assert_allclose(out.cpu().numpy(), pred, atol=PRED_TOL, rtol=0)
+            bins = sd[f"encoder.{'pitch' if which == 0 else 'energy'}_decoder.{'pitch' if which == 0 else 'energy'}_bins"]
+            emb = sd[f"encoder.{'pitch' if which == 0 else 'energy'}_decoder.{'pitch' if which == 0 else 'energy'}_embedding.weight"]
+            v = rng.uniform(bins[0] - 1, bins[-1] + 1, size=(3, 29)).astype(np.float32)
+            v[0, :len(bins)] = bins[:29][:len(bins)] if len(bins) >= 29 else v[0, :len(bins)]   # values exactly ON edges: right=False
+            with torch.no_grad():
+                e_t = dec.get_embedding(None, torch.from_numpy(v).to(device), None)
+                e_p = dec.get_embedding(torch.from_numpy(v[..., None]).to(device), None, None)
+            idx = np.searchsorted(bins, v, side="left")
+            assert e_t.shape == (3, 29, cfg.dim) and e_p.shape == (3, 29, 1, cfg.dim)
+            assert np.array_equal(e_t.cpu().numpy(), emb[idx]) and np.array_equal(e_p.cpu().numpy()[:, :, 0], emb[idx])
+    assert net.encoder.duration_decoder.get_embedding(None, None, None) is None

@@ -12,7 +12,8 @@ import subprocess
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SIM_SO = os.path.join(ROOT, "tools", "wavesim", "_build", "libesmi_sim.so")
 _SRCS = [os.path.join(ROOT, "efficientspeech_amd", "csrc", f) for f in
-         ("esmi_abi.hip", "convgemm.h", "attention.h", "mel_decoder.h", "small_kernels.h", "esmi_dev.h")] + \
+         ("esmi_abi.hip", "convgemm.h", "attention.h", "mel_decoder.h", "small_kernels.h", "esmi_dev.h", "wave_chain.h",
+          "enc_merge_qkv.h", "enc_attn_ffn.h", "enc_fuse_va.h")] + \
         [os.path.join(ROOT, "tools", "wavesim", f) for f in ("wavesim.h", "wavesim.cpp")] + \
         [os.path.join(ROOT, "include", "esmi.h")]
 _handle = None
@@ -30,12 +31,19 @@ def sim_lib():
     return _handle
 
 
+def _sim_runtime(t):
+    """Stand-in for efficientspeech_amd.networks._runtime while the simulator is bound: host tensors only, no stream."""
+    if t.is_cuda:
+        raise RuntimeError("wave-simulator backend only accepts host tensors")
+    return sim_lib(), None
+
+
 @contextlib.contextmanager
 def use_sim():
-    from efficientspeech_amd import _lib
-    old = _lib._LIB
-    _lib._LIB = sim_lib()
+    from efficientspeech_amd import _lib, networks
+    old_lib, old_rt = _lib._LIB, networks._runtime
+    _lib._LIB, networks._runtime = sim_lib(), _sim_runtime
     try:
         yield _lib._LIB
     finally:
-        _lib._LIB = old
+        _lib._LIB, networks._runtime = old_lib, old_rt

@@ -27,17 +27,42 @@ def test_header_lists_expected_entry_points():
     assert sorted(_lib.EXPORTS) == header_functions()
 
 
-def test_library_exports_every_declared_symbol(built):
-    lib = ctypes.CDLL(built)
+def exported_esmi_symbols(path):
+    """Dynamic symbols of the shared library that start with esmi_ (nm -D --defined-only)."""
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True, check=True).stdout
+    return sorted({ln.split()[-1] for ln in out.splitlines() if ln.split() and ln.split()[-1].startswith("esmi_")})
+
+
+@pytest.mark.parametrize("which", ["libesmi.so", "libesmi_fp32mfma.so"])
+def test_library_exports_exactly_the_declared_symbols(built, which):
+    """Both directions: every declared entry point is exported, and nothing named esmi_* is exported that the header does
+    not declare (no undeclared development hooks in the product library)."""
+    path = os.path.join(os.path.dirname(built), which)
+    lib = ctypes.CDLL(path)
     for name in header_functions():
-        assert hasattr(lib, name), f"libesmi.so does not export {name}"
+        assert hasattr(lib, name), f"{which} does not export {name}"
+    assert exported_esmi_symbols(path) == header_functions()
+
+
+def test_library_keeps_no_mutable_launch_state(built):
+    """The launch plan travels per call (esmi_encoder_block_shape.plan / the plan argument): no setter, no global."""
+    assert "esmi_set_fusion" not in exported_esmi_symbols(built)
+    from efficientspeech_amd import _lib
+    assert _lib.current_plan() == _lib.FUSE_ALL
+    with _lib.launch_plan(5):
+        assert _lib.current_plan() == 5
+        with _lib.launch_plan(0):
+            assert _lib.current_plan() == 0
+        assert _lib.current_plan() == 5
+    assert _lib.current_plan() == _lib.FUSE_ALL
 
 
 def test_backend_is_hip_gfx950(built):
     from efficientspeech_amd import _lib
     lib = _lib.load()
     assert _lib.backend(lib) == "hip:gfx950"
-    assert lib.esmi_version() == 100
+    assert lib.esmi_version() == 200
 
 
 def test_code_object_targets_gfx950(built):
@@ -60,6 +85,51 @@ def test_missing_library_raises(monkeypatch, built):
     monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libesmi.so")
     with pytest.raises(RuntimeError, match="not built"):
         _lib.load()
+
+
+def test_get_mask_from_lengths_matches_reference_semantics():
+    """utils/tools.py:43-51: mask[b, t] = t >= lengths[b]; max_len defaults to max(lengths); True marks padding."""
+    import torch
+    from efficientspeech_amd import get_mask_from_lengths
+    lengths = torch.tensor([5, 1, 3, 0])
+    m = get_mask_from_lengths(lengths)
+    assert m.dtype == torch.bool and m.shape == (4, 5)
+    ref = torch.arange(5)[None, :] >= lengths[:, None]
+    assert torch.equal(m, ref)
+    m7 = get_mask_from_lengths(lengths, max_len=7)
+    assert m7.shape == (4, 7) and torch.equal(m7[:, :5], ref) and bool(m7[:, 5:].all())
+    assert torch.equal(get_mask_from_lengths(torch.tensor([2]), 2), torch.zeros((1, 2), dtype=torch.bool))
+
+
+def test_from_lightning_checkpoint_loads_reference_shaped_dict():
+    """A Lightning-shaped checkpoint {'state_dict': {'phoneme2mel.*', 'hifigan.*'}, 'hyper_parameters': ...} (what
+    demo.py:122 / synthesize.py:103-119 load): the phoneme2mel.* slice loads strict=True, vocoder keys are ignored, a
+    missing or unexpected acoustic-model key raises."""
+    import numpy as np
+    import torch
+    from efficientspeech_amd import CONFIGS
+    from efficientspeech_amd.model import from_lightning_checkpoint
+    from efficientspeech_amd.synth import synth_state_dict
+    for name in ("tiny", "base"):
+        cfg = CONFIGS[name]
+        sd = synth_state_dict(cfg, 31)
+        ckpt = {"state_dict": {"phoneme2mel." + k: torch.from_numpy(v) for k, v in sd.items()},
+                "hyper_parameters": {"depth": cfg.depth, "reduction": cfg.reduction}}
+        ckpt["state_dict"]["hifigan.conv_pre.weight_g"] = torch.zeros(3)
+        ckpt["state_dict"]["hifigan.conv_pre.bias"] = torch.zeros(3)
+        net = from_lightning_checkpoint(ckpt, cfg)
+        got = net.state_dict()
+        assert list(got) == list(sd)
+        for k, v in sd.items():
+            assert np.array_equal(got[k].numpy(), v), k
+        broken = {"state_dict": dict(ckpt["state_dict"])}
+        del broken["state_dict"]["phoneme2mel.decoder.mel_linear.bias"]
+        with pytest.raises(RuntimeError, match="mel_linear.bias"):
+            from_lightning_checkpoint(broken, cfg)
+        extra = {"state_dict": dict(ckpt["state_dict"])}
+        extra["state_dict"]["phoneme2mel.decoder.nope"] = torch.zeros(1)
+        with pytest.raises(RuntimeError, match="nope"):
+            from_lightning_checkpoint(extra, cfg)
 
 
 def test_state_dict_keys_match_reference_table():

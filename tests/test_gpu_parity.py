@@ -52,12 +52,8 @@ def test_golden_vectors(path, fusion, nets):
     g = np.load(path)
     name = os.path.basename(path).split("_")[0]
     net, cfg, sd = nets(name, g)
-    lib = _lib.load()
-    old = lib.esmi_set_fusion(fusion)
-    try:
+    with _lib.launch_plan(fusion):
         H.check_against_golden(net, g, DEV)
-    finally:
-        lib.esmi_set_fusion(old)
 
 
 @pytest.mark.parametrize("name,B,T,lens", [
@@ -69,11 +65,8 @@ def test_golden_vectors(path, fusion, nets):
 ])
 @pytest.mark.parametrize("fusion", PLANS, ids=PLAN_IDS)
 def test_eval_path_vs_oracle(name, B, T, lens, fusion, nets):
-    old = _lib.load().esmi_set_fusion(fusion)
-    try:
+    with _lib.launch_plan(fusion):
         _eval_path_vs_oracle(name, B, T, lens, nets)
-    finally:
-        _lib.load().esmi_set_fusion(old)
 
 
 def _eval_path_vs_oracle(name, B, T, lens, nets):
@@ -390,9 +383,127 @@ def test_decoder_other_mel_widths(n_mel):
     assert mel.shape == ref.shape == (2, 150, n_mel)
     assert np.abs(mel - ref).max() < H.MEL_TOL
     ids, mask = synth_phonemes(3, 40, 9, [40, 31, 7])       # and through the fused encoder -> decoder path (h0 gather)
-    x = {"phoneme": torch.from_numpy(ids).to(DEV), "phoneme_mask": torch.from_numpy(mask).to(DEV)}
+    dur = np.random.default_rng(4).integers(0, 6, size=(3, 40)).astype(np.int32)   # forced: no rounding decision can flip
+    x = {"phoneme": torch.from_numpy(ids).to(DEV), "phoneme_mask": torch.from_numpy(mask).to(DEV),
+         "duration_forced": torch.from_numpy(dur).to(DEV)}
     with torch.no_grad():
+        enc = net.encoder._encode(x)
         mel2, mel_len, _ = net(x)
-    o = oracle.phoneme2mel(cfg, oracle.Weights(sd), ids, mask)
-    if np.array_equal(mel_len.cpu().numpy(), o.mel_len):
-        assert np.abs(mel2.cpu().numpy() - o.mel).max() < H.MEL_TOL
+    o = oracle.phoneme2mel(cfg, oracle.Weights(sd), ids, mask, pitch=enc["pitch"][..., 0].cpu().numpy(),
+                           energy=enc["energy"][..., 0].cpu().numpy(), duration=dur)
+    assert np.array_equal(mel_len.cpu().numpy(), o.mel_len)
+    assert mel2.shape == o.mel.shape and np.abs(mel2.cpu().numpy() - o.mel).max() < H.MEL_TOL
+
+
+def _full_size_properties(name, B, T, D, nets, n_spot=4):
+    """BASELINE shape of one model size under ALL THREE launch plans: determinism, batch-shard invariance at the same padded
+    length, mel_len, and an oracle spot check on `n_spot` utterances (teacher-forced with the HIP path's own pitch / energy so
+    that bucket decisions agree; durations forced D-const)."""
+    net, cfg, sd = nets(name)
+    ids, mask = synth_phonemes(B, T, 1234)
+    x = {"phoneme": torch.from_numpy(ids).to(DEV), "phoneme_mask": torch.from_numpy(mask).to(DEV),
+         "duration_forced": torch.full((B, T), D, dtype=torch.int32, device=DEV), "max_mel_len": T * D}
+    sel = sorted({0, 1, B // 3, B // 2, B - 1})[:max(n_spot, 4)]
+    ref = None
+    for plan in PLANS:
+        with _lib.launch_plan(plan), torch.no_grad():
+            enc = net.encoder._encode(x)
+            mel, mel_len, _ = net(x)
+            mel2, _, _ = net(x)
+            lo = B // 4
+            xs = {k: (v[lo:lo + 32] if torch.is_tensor(v) else v) for k, v in x.items()}
+            mel_s, _, _ = net(xs)
+        assert mel.shape == (B, T * D, 80) and (mel_len == T * D).all() and torch.isfinite(mel).all()
+        assert torch.equal(mel, mel2), f"plan {plan}: non-deterministic"
+        assert torch.equal(mel_s, mel[lo:lo + 32]), f"plan {plan}: result depends on the batch split"
+        if ref is None:
+            o = oracle.phoneme2mel(cfg, oracle.Weights(sd), ids[sel], mask[sel],
+                                   pitch=enc["pitch"][sel, :, 0].cpu().numpy(), energy=enc["energy"][sel, :, 0].cpu().numpy(),
+                                   duration=np.full((len(sel), T), D, np.int32), max_mel_len=T * D)
+            np.testing.assert_allclose(enc["pitch"][sel].cpu().numpy(), o.pitch, atol=H.PRED_TOL, rtol=0)
+            np.testing.assert_allclose(enc["energy"][sel].cpu().numpy(), o.energy, atol=H.PRED_TOL, rtol=0)
+            np.testing.assert_allclose(enc["duration"][sel].cpu().numpy(), o.duration, atol=H.PRED_TOL, rtol=0)
+            ref = o.mel
+        err = np.abs(mel[sel].cpu().numpy() - ref).max()
+        assert err < H.MEL_TOL, (plan, err)
+        del mel, mel2, mel_s, enc
+
+
+def test_full_size_small_properties(nets):
+    """BASELINE configs[2]: small ES, B=256 T=256, D-const 6 (L=1536): the dim-64 halo-plan instantiations at size."""
+    _full_size_properties("small", 256, 256, 6, nets)
+
+
+def test_full_size_base_properties(nets):
+    """BASELINE configs[3] (per-node batch): base ES, B=512 T=256, D-const 6."""
+    _full_size_properties("base", 512, 256, 6, nets)
+    torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("name", ["tiny", "small", "base"])
+def test_submodule_forwards(name, nets):
+    """SelfAttention / MixFFN / AcousticDecoder.forward and get_embedding on their own (reference module-level API)."""
+    net, cfg, sd = nets(name)
+    H.check_submodule_forwards(net, cfg, sd, DEV)
+
+
+def test_split_range_guard_and_encoder_operand_scales():
+    """(1) a weight outside the split-f16 range is refused at pack time; (2) encoder-side operands far from O(1): embedding
+    rows x 40 (the un-normalised conv output that feeds qkv grows with them), merge / qkv / MixFFN weights x 0.05 .. x 6."""
+    from efficientspeech_amd import build_phoneme2mel, load_numpy_state_dict
+    from efficientspeech_amd.synth import synth_state_dict
+    cfg = CONFIGS["tiny"]
+    if _lib.load().esmi_split_weight_limit() != float("inf"):
+        sd = synth_state_dict(cfg, 5)
+        sd["encoder.encoder.attn_blocks.1.3.mlp1.weight"] = sd["encoder.encoder.attn_blocks.1.3.mlp1.weight"] * np.float32(4000.0)
+        net = build_phoneme2mel(cfg)
+        load_numpy_state_dict(net, sd)
+        net = net.to(DEV)
+        ids, mask = synth_phonemes(2, 9, 1, [9, 4])
+        with pytest.raises(ValueError, match="libesmi_fp32mfma"), torch.no_grad():
+            net({"phoneme": torch.from_numpy(ids).to(DEV), "phoneme_mask": torch.from_numpy(mask).to(DEV)})
+    for s_e, s_w in ((40.0, 1.0), (1.0, 6.0), (0.02, 1.0), (3.0, 0.05), (25.0, 3.0)):
+        sd = synth_state_dict(cfg, 77)
+        sd["encoder.encoder.embed.weight"] = (sd["encoder.encoder.embed.weight"] * np.float32(s_e)).astype(np.float32)
+        for k in list(sd):
+            if k.startswith("encoder.encoder.attn_blocks.") and k.endswith("weight") and sd[k].ndim >= 2:
+                sd[k] = (sd[k] * np.float32(s_w)).astype(np.float32)
+        net = build_phoneme2mel(cfg)
+        load_numpy_state_dict(net, sd)
+        net = net.to(DEV)
+        ids, mask = synth_phonemes(3, 50, 8, [50, 37, 12])
+        x = {"phoneme": torch.from_numpy(ids).to(DEV), "phoneme_mask": torch.from_numpy(mask).to(DEV)}
+        with torch.no_grad():
+            feats, _ = net.encoder.encoder(x["phoneme"], x["phoneme_mask"])
+        o = oracle.phoneme_encoder(cfg, oracle.Weights(sd), ids, mask, taps=True)
+        for i, f in enumerate(feats):
+            got, ref = f.cpu().numpy(), o.f_taps[i]
+            assert np.isfinite(got).all()
+            # the block outputs are LayerNorm'd (O(1)); the tolerance is the predictors' one
+            np.testing.assert_allclose(got, ref, atol=5 * H.PRED_TOL, rtol=0, err_msg=f"embed x{s_e}, weights x{s_w}, block {i}")
+
+
+def test_two_stream_pipeline_matches_single_stream(nets):
+    """ShardedMelPipeline(two_stream=True): encoder side of step i+1 under the decoder of step i.  DIFFERENT inputs every
+    step (a recycled h0 / feat block would show), results compared with plain single-stream forwards."""
+    from efficientspeech_amd.sharded import ShardedMelPipeline
+    net, cfg, sd = nets("tiny")
+    B, T, D = 64, 96, 5
+    xs = []
+    for step in range(6):
+        ids, mask = synth_phonemes(B, T, 500 + step)
+        xs.append({"phoneme": torch.from_numpy(ids).to(DEV), "phoneme_mask": torch.from_numpy(mask).to(DEV),
+                   "duration_forced": torch.full((B, T), D, dtype=torch.int32, device=DEV), "max_mel_len": T * D})
+    with torch.no_grad():
+        refs = [net(x)[0].clone() for x in xs]
+        pipe = ShardedMelPipeline(net, world_size=1, gather=False, two_stream=True)
+        got = []
+        for x in xs:
+            mel, _ = pipe.step(x)
+            with torch.cuda.stream(pipe.s_dec):          # a consumer on the producing stream: no wait on the caller's stream,
+                got.append(mel.clone())                   # so step i+1's encoder side really runs under step i's decoder
+        pipe.flush()
+        pipe.wait_last()
+        torch.cuda.synchronize()
+    for step, (a, b) in enumerate(zip(refs, got)):
+        assert torch.equal(a, b), f"step {step}"

@@ -11,6 +11,7 @@ import numpy as np
 import pytest
 import torch
 
+from efficientspeech_amd import _lib
 from efficientspeech_amd.synth import synth_phonemes
 from oracle import oracle
 from tests import helpers as H
@@ -48,15 +49,11 @@ UNFUSED = [os.path.join(GOLD, f) for f in ("tiny_eval_pad_t17.npz", "tiny_train_
 
 @pytest.mark.parametrize("path", UNFUSED, ids=[os.path.basename(p)[:-4] for p in UNFUSED])
 def test_simulated_unfused_path_matches_golden(path, nets):
-    """esmi_set_fusion(0): one kernel per reference op (the fallback for shapes the chain kernels do not cover)."""
+    """launch plan 0: one kernel per reference op (the fallback for shapes the chain kernels do not cover)."""
     g = np.load(path)
     net, cfg, sd = nets(os.path.basename(path).split("_")[0], g)
-    with use_sim() as lib:
-        old = lib.esmi_set_fusion(0)
-        try:
-            H.check_against_golden(net, g, "cpu")
-        finally:
-            lib.esmi_set_fusion(old)
+    with use_sim(), _lib.launch_plan(0):
+        H.check_against_golden(net, g, "cpu")
 
 
 @pytest.mark.parametrize("name,B,T,lens", [
@@ -157,12 +154,8 @@ def test_simulated_intermediate_plans(fusion, nets):
     without the column-split variant (23)."""
     g = np.load(os.path.join(GOLD, "tiny_eval_pad_t17.npz"))
     net, cfg, sd = nets("tiny", g)
-    with use_sim() as lib:
-        old = lib.esmi_set_fusion(fusion)
-        try:
-            H.check_against_golden(net, g, "cpu")
-        finally:
-            lib.esmi_set_fusion(old)
+    with use_sim(), _lib.launch_plan(fusion):
+        H.check_against_golden(net, g, "cpu")
 
 
 def test_simulated_long_sequence_halo_paths(nets):
@@ -245,3 +238,30 @@ def test_simulated_random_shapes(seed, nets):
     assert np.array_equal(mel_len.numpy(), o.mel_len) and mel.shape == o.mel.shape
     if o.mel.size:
         assert np.abs(mel.numpy() - o.mel).max() < H.MEL_TOL
+
+
+@pytest.mark.parametrize("name", ["tiny", "base"])
+def test_simulated_submodule_forwards(name, nets):
+    """SelfAttention / MixFFN / AcousticDecoder called on their own (the reference's module-level API)."""
+    net, cfg, sd = nets(name)
+    with use_sim():
+        H.check_submodule_forwards(net, cfg, sd, "cpu")
+
+
+def test_simulated_split_range_guard(nets):
+    """A weight outside the split-f16 operand range is refused at pack time (ValueError naming the fp32 build), not
+    silently turned into inf."""
+    from efficientspeech_amd import CONFIGS, build_phoneme2mel, load_numpy_state_dict
+    from efficientspeech_amd.synth import synth_state_dict
+    cfg = CONFIGS["tiny"]
+    for key in ("encoder.encoder.attn_blocks.0.2.qkv.weight", "decoder.blocks.1.0.0.0.1.weight", "encoder.fuse.fuse.weight",
+                "encoder.pitch_decoder.conv2.0.weight"):
+        sd = synth_state_dict(cfg, 5)
+        sd[key] = sd[key].copy()
+        sd[key].flat[7] = 300.0
+        net = build_phoneme2mel(cfg)
+        load_numpy_state_dict(net, sd)
+        ids, mask = synth_phonemes(2, 9, 1, [9, 4])
+        with use_sim(), torch.no_grad():
+            with pytest.raises(ValueError, match="libesmi_fp32mfma"):
+                net({"phoneme": torch.from_numpy(ids), "phoneme_mask": torch.from_numpy(mask)})

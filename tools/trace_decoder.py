@@ -13,12 +13,13 @@ net = build_phoneme2mel(cfg); load_numpy_state_dict(net, synth_state_dict(cfg));
 feat = torch.randn((B, T, cfg.d4), device="cuda")
 cum = (torch.arange(1, T + 1, device="cuda", dtype=torch.int32) * D).repeat(B, 1).contiguous()
 mel_len = torch.full((B,), L, dtype=torch.int32, device="cuda")
+h0 = torch.randn((B, T, cfg.dx2), device="cuda") if "--h0" in sys.argv else None
 tr = torch.zeros((8, 64), dtype=torch.int64, device="cuda")
 lib.esmi_dev_set_trace.argtypes = [C.c_void_p]
 for _ in range(3):
-    net.decoder._fused(feat, cum, mel_len, None, L, True, L)
+    net.decoder._fused(feat, cum, mel_len, None, L, True, L, h0=h0)
 lib.esmi_dev_set_trace(tr.data_ptr())
-net.decoder._fused(feat, cum, mel_len, None, L, True, L)
+net.decoder._fused(feat, cum, mel_len, None, L, True, L, h0=h0)
 torch.cuda.synchronize()
 t = tr.cpu().numpy()
 names = ["dw window load", "barrier", "dw compute+write", "barrier", "K loop (MFMA)", "barrier", "bias+tanh store", "barrier", "LayerNorm", "barrier"]
