@@ -870,7 +870,7 @@ int esmi_phoneme2mel_forward_f32(const esmi_forward_args* a, int stage, esmi_str
     int rc = fwd_arena(a, &o);
     if (rc) return rc;
     if (!a->ids || !a->mel_len || !a->duration_pred || !a->arena || stage < 0 || stage > 2) return ESMI_ERR_ARG;
-    if ((reinterpret_cast<uintptr_t>(a->arena) & 255u) || a->arena_bytes < o.total) return ESMI_ERR_WORKSPACE;
+    if ((reinterpret_cast<uintptr_t>(a->arena) & 15u) || a->arena_bytes < o.total) return ESMI_ERR_WORKSPACE;
     char* base = static_cast<char*>(a->arena);
     auto F = [&](size_t off) { return reinterpret_cast<float*>(base + off); };
     auto I = [&](size_t off) { return reinterpret_cast<int32_t*>(base + off); };

@@ -821,7 +821,12 @@ class Phoneme2Mel(nn.Module):
             nbytes = lib.esmi_forward_arena_bytes(C.byref(a))
             st.arena = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         a.arena, a.arena_bytes = _ptr(st.arena), st.arena.numel()
-        if stage != 2 and (stage == 1 or st.L_out is None):          # encoder side as its own call
+        dec = self.decoder
+        timed = False
+        if stage == 0 and dec.timing is not None:                     # bench.py: HIP events around the decoder launch only
+            dec._launches += 1
+            timed = dec._launches % dec.timing_every == 0
+        if stage != 2 and (stage == 1 or st.L_out is None or timed):  # encoder side as its own call
             a.L_out, a.lmax_host, a.mel = 0, 0, None
             lib.esmi_phoneme2mel_forward_f32(C.byref(a), 1, stream)
             if stage == 1:
@@ -831,5 +836,12 @@ class Phoneme2Mel(nn.Module):
             st.L_out = st.lmax_host = int(st.lmax.item())
         st.mel = torch.empty((st.B, st.L_out, self.decoder.n_mel_channels), dtype=torch.float32, device=dev)
         a.mel, a.L_out, a.lmax_host = _ptr(st.mel), st.L_out, st.lmax_host
-        lib.esmi_phoneme2mel_forward_f32(C.byref(a), stage, stream)
+        if timed and st.L_out > 0:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
+            lib.esmi_phoneme2mel_forward_f32(C.byref(a), stage, stream)
+            ev[1].record()
+            dec.timing.append(ev)
+        else:
+            lib.esmi_phoneme2mel_forward_f32(C.byref(a), stage, stream)
         return st

@@ -63,21 +63,14 @@ def sharded_forward(net, x_full, group=None):
     if "phoneme_mask" not in x_full and x_full["phoneme"].shape[0] > 1:
         raise KeyError("phoneme_mask")                     # same contract as the reference for B > 1
     x, dup = _masked_path_inputs(x)
-    # The padded length L is a property of the WHOLE batch (the reference zero-pads its convolutions at the
-    # batch max), so the local maxima are MAX-reduced on the device before the decoder runs.  With a
-    # caller-supplied bound (`max_mel_len`) the output is allocated at that bound and no host sync happens.
-    enc = _encode_with_head(net, x, need_lmax=not _exact_len(x))
-    if _exact_len(x):
-        L_out, lmax_dev, lmax_host = int(x["max_mel_len"]), None, int(x["max_mel_len"])
-    else:
-        dist.all_reduce(enc["lmax"], op=dist.ReduceOp.MAX, group=group)
-        if "max_mel_len" in x:
-            L_out, lmax_dev, lmax_host = int(x["max_mel_len"]), enc["lmax"], -1
-        else:
-            L_out = int(enc["lmax"].item())
-            lmax_dev, lmax_host = None, L_out
-    mel = net.decoder._fused(enc["feat"], enc["cum"], enc["mel_len"], lmax_dev, lmax_host, True, L_out, h0=enc["h0"])
-    mel_len, dur = enc["mel_len"], enc["duration"]
+    # The padded length L is a property of the WHOLE batch (the reference zero-pads its convolutions at the batch max), so the
+    # local maxima are MAX-reduced on the device between the encoder side and the decoder -- unless the caller vouches for
+    # `max_mel_len` (max_mel_len_exact).  With a caller-supplied bound the output is allocated at it and no host sync happens.
+    st = net._launch(x, stage=1)
+    if st.lmax is not None:
+        dist.all_reduce(st.lmax, op=dist.ReduceOp.MAX, group=group)
+    st = net._launch(None, stage=2, state=st)
+    mel, mel_len, dur = st.mel, st.mel_len, st.duration
     if dup:
         mel, mel_len, dur = mel[:1], mel_len[:1], dur[:1]
     outs = []
@@ -184,20 +177,15 @@ class ShardedMelPipeline:
             mel, mel_len, _ = self.net(x)
             return mel, mel_len
         # global padded length: 4-byte MAX all-reduce on the compute stream (see sharded_forward) -- unless the caller
-        # vouches for it (max_mel_len_exact): then nothing sits between the encoder side and the decoder
+        # vouches for it (max_mel_len_exact): then the whole forward is one C-ABI call with nothing in between
         x, dup = _masked_path_inputs(x)
-        enc = _encode_with_head(self.net, x, need_lmax=not _exact_len(x))
         if _exact_len(x):
-            L_out, lmax_dev, lmax_host = int(x["max_mel_len"]), None, int(x["max_mel_len"])
+            st = self.net._launch(x)
         else:
-            dist.all_reduce(enc["lmax"], op=dist.ReduceOp.MAX, group=self.group)
-            if "max_mel_len" in x:
-                L_out, lmax_dev, lmax_host = int(x["max_mel_len"]), enc["lmax"], -1
-            else:
-                L_out = int(enc["lmax"].item())
-                lmax_dev, lmax_host = None, L_out
-        mel = self.net.decoder._fused(enc["feat"], enc["cum"], enc["mel_len"], lmax_dev, lmax_host, True, L_out, h0=enc["h0"])
-        mel_len = enc["mel_len"]
+            st = self.net._launch(x, stage=1)
+            dist.all_reduce(st.lmax, op=dist.ReduceOp.MAX, group=self.group)
+            st = self.net._launch(None, stage=2, state=st)
+        mel, mel_len = st.mel, st.mel_len
         if dup:
             mel, mel_len = mel[:1], mel_len[:1]
         return mel, mel_len
@@ -218,31 +206,26 @@ class ShardedMelPipeline:
         self.s_enc.wait_stream(cur)                       # inputs produced on the caller's stream
         x, dup = _masked_path_inputs(x) if self.world > 1 else (x, False)
         with torch.cuda.stream(self.s_enc):
-            exact = _exact_len(x)
-            enc = _encode_with_head(self.net, x, need_lmax=not exact)
-            if self.world > 1 and not exact:
-                dist.all_reduce(enc["lmax"], op=dist.ReduceOp.MAX, group=self.group)
+            st = self.net._launch(x, stage=1)
+            if self.world > 1 and st.lmax is not None and not _exact_len(x):
+                dist.all_reduce(st.lmax, op=dist.ReduceOp.MAX, group=self.group)
             ready = torch.cuda.Event()
             ready.record()
-        if exact:
-            L_out, lmax_dev, lmax_host = int(x["max_mel_len"]), None, int(x["max_mel_len"])
-        elif "max_mel_len" in x:
-            L_out, lmax_dev, lmax_host = int(x["max_mel_len"]), enc["lmax"], -1
-        else:
-            ready.synchronize()
-            L_out = int(enc["lmax"].item())
-            lmax_dev, lmax_host = None, L_out
+        if st.L_out is None:
+            ready.synchronize()                           # no caller-supplied output length: the host needs the padded length
         with torch.cuda.stream(self.s_dec):
             self.s_dec.wait_event(ready)
             # every tensor the decoder reads was allocated on s_enc: tell the allocator s_dec uses it too, or step i+1's
-            # encoder side (running while this decoder still reads) may be handed the same blocks (h0 was missing)
-            for t in (enc["feat"], enc["cum"], enc["mel_len"], enc["lmax"], enc["h0"], enc["mask_u8"]):
+            # encoder side (running while this decoder still reads) may be handed the same blocks (h0 was missing;
+            # everything the encoder side hands over now lives in ONE arena)
+            for t in (st.arena, st.mel_len, st.lmax, st.ids, st.m8, st.dur_t):
                 if t is not None:
                     t.record_stream(self.s_dec)
-            mel = self.net.decoder._fused(enc["feat"], enc["cum"], enc["mel_len"], lmax_dev, lmax_host, True, L_out, h0=enc["h0"])
+            st = self.net._launch(None, stage=2, state=st)
+            mel = st.mel
             done = torch.cuda.Event()
             done.record()
-        mel_len = enc["mel_len"]
+        mel_len = st.mel_len
         if dup:
             mel, mel_len = mel[:1], mel_len[:1]
         mel.record_stream(cur)                            # the caller will read it on its own stream (after `done`)

@@ -341,7 +341,7 @@ int esmi_mel_decoder_f32(const float* blob, const esmi_decoder_shape* s, const f
  * ~0.1 ms per forward in round 1 -- more than the GPU time of a 32-utterance shard).  Same kernels, same results as the
  * per-stage entry points above.
  *
- * Scratch: ONE caller-provided arena of esmi_forward_arena_bytes() bytes (256-byte aligned base); nothing in it needs to
+ * Scratch: ONE caller-provided arena of esmi_forward_arena_bytes() bytes (16-byte aligned base); nothing in it needs to
  * survive the call.  Outputs the reference returns are separate caller buffers: mel, mel_len, duration_pred.            */
 typedef struct esmi_forward_args {
     int B, T, depth, dim, fuse_kernel, plan;
