@@ -106,16 +106,20 @@ def cpu_baseline(cfg, sd, T, dur):
         run(4)                                   # spin up the OpenMP pool at this width
         r = [run(b) for _ in range(reps)]
         return r[0][0], sum(x[1] for x in r) / len(r)
-    b_all = 256 if cfg.name == "tiny" else 64
-    frames, dt = sample(cores, b_all, 3)
-    out = {"value": frames / dt, "unit": "mel-frames/s", "cores": cores, "kind": "port",
-           "sample": f"oracle/es_oracle.c (fp32 accumulate, OpenMP {cores} threads), {cfg.name} ES full forward, "
-                     f"B={b_all} T={T} D-const {dur}: {frames} frames in {dt:.2f} s (mean of 3 runs)"}
+    # n = 24: the reference's --threads default -- and the fastest setting for this port (its OpenMP regions are one layer
+    # each: beyond ~32 threads the fork/join cost dominates; measured on the MI355X box's 256 hardware threads, B = 64:
+    # 24 threads 8.7e5 frames/s, 64: 4.0e5, 128: 1.6e5, 256: 5e3).  `value` is the n = 24 number; all cores is reported beside it.
     n24 = min(24, cores)
-    b24 = max(8, b_all // 4)
-    f24, dt24 = sample(n24, b24, 2)
-    out["n24"] = {"value": f24 / dt24, "cores": n24,
-                  "sample": f"same code, OpenMP {n24} threads (reference --threads default), B={b24}: {f24} frames in {dt24:.2f} s"}
+    b24 = 256 if cfg.name == "tiny" else 64
+    frames, dt = sample(n24, b24, 3)
+    out = {"value": frames / dt, "unit": "mel-frames/s", "cores": n24, "kind": "port",
+           "sample": f"oracle/es_oracle.c (fp32 accumulate, OpenMP {n24} threads = the reference's --threads default), {cfg.name} ES "
+                     f"full forward, B={b24} T={T} D-const {dur}: {frames} frames in {dt:.2f} s (mean of 3 runs)"}
+    b_all = 16
+    f_all, dt_all = sample(cores, b_all, 1)
+    out["all_cores"] = {"value": f_all / dt_all, "cores": cores,
+                        "sample": f"same code, OpenMP {cores} threads (every hardware thread of the box), B={b_all}: {f_all} frames in "
+                                  f"{dt_all:.2f} s -- slower than n = 24: one parallel region per layer, fork/join bound"}
     fox = np.asarray([FOX_IDS], np.int32)
     for threads, key in ((n24, "b1_fox_latency_ms_n24"), (1, "b1_fox_latency_ms_n1")):
         _omp_threads(threads)
