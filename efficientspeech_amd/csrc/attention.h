@@ -140,4 +140,133 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnP p) {
     }
 }
 
+// Long sequences (N > 256 keys: more than a wave can hold as one score tile set): the same transposed-score scheme over key
+// CHUNKS of 128, in two sweeps -- sweep 0 finds each query's row maximum and normaliser (running max / rescaled sum, per-lane
+// scalars only), sweep 1 recomputes the scores, forms P = exp(s - max) / sum exactly as the one-chunk kernel does and
+// accumulates ctx = P V for all C channels (NC = C/32 accumulator tiles).  Twice the Q K^T work buys a kernel with no
+// cross-lane rescale of the output tiles; the reference has no sequence limit (README "long text"), this is its path here.
+template <int NC>
+__global__ __launch_bounds__(256) void attn_long_kernel(const AttnP p) {
+    constexpr int NKT = 4;
+    const int lane = lane_id();
+    const int qtiles = (p.N + 31) >> 5;
+    const int wt = (int)blockIdx.x * 4 + wave_id();
+    if (wt >= p.B * p.h * qtiles) return;
+    const int b = wt / (p.h * qtiles);
+    const int rem = wt - b * (p.h * qtiles);
+    const int hd = rem / qtiles;
+    const int q0 = (rem - hd * qtiles) << 5;
+    const int i = lane & 31, h2 = lane >> 5;
+    const int ld = 3 * p.h * p.C;
+    const float* base = p.qkv + (long)b * p.N * ld;
+    const float* qb = base + 0 * p.h * p.C + hd * p.C;
+    const float* kb = base + 1 * p.h * p.C + hd * p.C;
+    const float* vb = base + 2 * p.h * p.C + hd * p.C;
+    const bool qok = q0 + i < p.N;
+    const float* qrow = qb + (long)(qok ? q0 + i : 0) * ld;
+
+    f32x16 s[NKT];
+    // scores of key chunk [k0, k0 + 128) for this lane's query, scaled; keys >= N -> -inf
+    auto scores = [&](int k0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt) s[kt] = zero16();
+        const float* krow[NKT];
+        bool kok[NKT];
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt) {
+            kok[kt] = k0 + 32 * kt + i < p.N;
+            krow[kt] = kb + (long)(kok[kt] ? k0 + 32 * kt + i : 0) * ld;
+        }
+        for (int kc = 0; kc < (p.C >> 3); kc += 4) {
+            f32x4 qv[4], kv[4][NKT];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int c = 8 * (kc + g) + 4 * h2;
+                qv[g] = qok ? ld4(qrow + c) : zero4();
+#pragma unroll
+                for (int kt = 0; kt < NKT; ++kt) kv[g][kt] = kok[kt] ? ld4(krow[kt] + c) : zero4();
+            }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+#pragma unroll
+                    for (int kt = 0; kt < NKT; ++kt) s[kt] = mfma32(kv[g][kt][t], qv[g][t], s[kt]);
+                }
+            }
+        }
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = k0 + 32 * kt + tile_row(r, lane);
+                s[kt][r] = key < p.N ? s[kt][r] * p.scale : -INFINITY;
+            }
+        }
+    };
+    // ---- sweep 0: row maximum and normaliser
+    float mx = -INFINITY, den = 0.0f;
+    for (int k0 = 0; k0 < p.N; k0 += 32 * NKT) {
+        scores(k0);
+        float cm = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) cm = fmaxf(cm, s[kt][r]);
+        }
+        cm = fmaxf(cm, swap32_f(cm));
+        const float nm = fmaxf(mx, cm);            // finite from the first chunk on (it holds at least one real key)
+        float cs = 0.0f;
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) cs += expf(s[kt][r] - nm);
+        }
+        cs += swap32_f(cs);
+        den = den * expf(mx - nm) + cs;            // exp(-inf) = 0 on the first chunk
+        mx = nm;
+    }
+    const float inv = 1.0f / den;
+    // ---- sweep 1: P and ctx = P V
+    f32x16 o[NC];
+#pragma unroll
+    for (int nt = 0; nt < NC; ++nt) o[nt] = zero16();
+    for (int k0 = 0; k0 < p.N; k0 += 32 * NKT) {
+        scores(k0);
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[kt][r] = expf(s[kt][r] - mx) * inv;
+        }
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt) {
+#pragma unroll
+            for (int r4 = 0; r4 < 16; r4 += 4) {
+                float vv[4][NC];
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) {
+                    const int key = k0 + 32 * kt + tile_row(r4 + rr, lane);
+                    const bool vok = key < p.N;
+                    const float* vrow = vb + (long)(vok ? key : 0) * ld + i;
+#pragma unroll
+                    for (int nt = 0; nt < NC; ++nt) vv[rr][nt] = vok ? vrow[32 * nt] : 0.0f;
+                }
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) {
+#pragma unroll
+                    for (int nt = 0; nt < NC; ++nt) o[nt] = mfma32(s[kt][r4 + rr], vv[rr][nt], o[nt]);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int q = q0 + tile_row(r, lane);
+        if (q >= p.N) continue;
+        float* orow = p.ctx + ((long)b * p.N + q) * (p.h * p.C) + hd * p.C + i;
+#pragma unroll
+        for (int nt = 0; nt < NC; ++nt) orow[32 * nt] = o[nt][r];
+    }
+}
+
 }  // namespace esmi

@@ -1,5 +1,5 @@
-// convgemm -- channels-last Conv1d / ConvTranspose1d / Linear as an implicit GEMM on the exact-fp32
-// MFMA (v_mfma_f32_32x32x2_f32), with the encoder-side epilogues fused:
+// convgemm -- channels-last Conv1d / ConvTranspose1d / Linear as an implicit GEMM (fp32-accurate split products on the f16
+// matrix pipe in the default build, v_mfma_f32_32x32x2_f32 in the exact-fp32 build), with the encoder-side epilogues fused:
 //   out = mask( post_relu( LN( act(acc + bias) + residual ) ) ),  optional row-dot side output.
 //
 // One WAVE owns a 32-position x (32*NT)-channel output tile; waves are independent (no LDS, no
@@ -99,6 +99,44 @@ __global__ __launch_bounds__(256) void convgemm_kernel(const ConvGemmP p) {
         // (a plain per-k-step loop serialises one memory latency per 8 channels: 4x slower at K = 32).
         constexpr int KG = NT >= 8 ? 2 : 4;
         int kc = 0;
+#if ESMI_CHAIN_SPLIT
+        // split-f16x2 contraction (esmi_dev.h): two k-steps (16 channels) = three v_mfma_f32_32x32x16_f16 instead of eight
+        // v_mfma_f32_32x32x2_f32.  Both operands are split on the fly (the weights after the 2^8 scale; the epilogue takes it
+        // out again): this plan takes the weights exactly as stored, there is no pre-split copy.  A lane's 8 k-slots of a step are
+        // the channels 8kc + 4h + (0..3) and 8(kc+1) + 4h + (0..3) on BOTH sides, i.e. a fixed permutation of the 16 channels.
+        auto step16 = [&](const f32x4& a0, const f32x4& a1, const f32x4 (&b0)[NT], const f32x4 (&b1)[NT]) __attribute__((always_inline)) {
+            const f16x2p a2 = split_f16x2(a0, a1);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const f16x2p w2 = split_f16x2(b0[nt] * kF16WScale, b1[nt] * kF16WScale);
+                acc[nt] = mfma32_split2(a2, w2.h1, w2.h2, acc[nt]);
+            }
+        };
+        for (; kc + KG <= kcs; kc += KG) {
+            f32x4 av[KG], bv[KG][NT];
+#pragma unroll
+            for (int g = 0; g < KG; ++g) {
+                const int c = 8 * (kc + g) + 4 * h;
+                av[g] = ok ? ld4(arow + c) : zero4();
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) bv[g][nt] = wok[nt] ? ld4(wrow[nt] + c) : zero4();
+            }
+#pragma unroll
+            for (int g = 0; g < KG; g += 2) step16(av[g], av[g + 1], bv[g], bv[g + 1]);
+        }
+        for (; kc < kcs; kc += 2) {   // 8 or 16 channels left
+            const int c = 8 * kc + 4 * h;
+            const bool two = kc + 1 < kcs;
+            const f32x4 a0 = ok ? ld4(arow + c) : zero4(), a1 = (ok && two) ? ld4(arow + c + 8) : zero4();
+            f32x4 b0[NT], b1[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                b0[nt] = wok[nt] ? ld4(wrow[nt] + c) : zero4();
+                b1[nt] = (wok[nt] && two) ? ld4(wrow[nt] + c + 8) : zero4();
+            }
+            step16(a0, a1, b0, b1);
+        }
+#else
         for (; kc + KG <= kcs; kc += KG) {
             f32x4 av[KG], bv[KG][NT];
 #pragma unroll
@@ -129,6 +167,7 @@ __global__ __launch_bounds__(256) void convgemm_kernel(const ConvGemmP p) {
                 for (int nt = 0; nt < NT; ++nt) acc[nt] = mfma32(av[s], bv[nt][s], acc[nt]);
             }
         }
+#endif
     }
 
     // ---------------- epilogue in the MFMA C/D layout: row = tile_row(r), col = n0 + 32*nt + i
@@ -148,7 +187,7 @@ __global__ __launch_bounds__(256) void convgemm_kernel(const ConvGemmP p) {
         const long row = (long)b * p.n_out + t;
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
-            float v = apply_act(acc[nt][r] + bias[nt], p.act);
+            float v = apply_act(fmaf(acc[nt][r], ESMI_CHAIN_SPLIT ? kF16WScaleInv : 1.0f, bias[nt]), p.act);
             if (p.res && rok && cok[nt]) v += p.res[row * p.ldr + p.r_coff + col[nt]];
             acc[nt][r] = v;
         }

@@ -87,9 +87,18 @@ int launch_convgemm(ConvGemmP p, hipStream_t st) {
 int launch_attn(const AttnP& p, hipStream_t st) {
     if ((p.C & 31) || p.N <= 0) return ESMI_ERR_ARG;   // channel groups of 32 (4 k-steps fetched together)
     const int nkt = (p.N + 31) / 32;
-    if (nkt > 8) return ESMI_ERR_UNSUPPORTED;  // N <= 256 keys held in registers (all BASELINE configs)
     const int tiles = p.B * p.h * nkt;
     dim3 grid((tiles + 3) / 4), block(256);
+    if (nkt > 8) {   // N > 256: key-chunked two-sweep kernel (no sequence limit, as the reference)
+        switch (p.C / 32) {
+            case 1: ESMI_LAUNCH((attn_long_kernel<1>), grid, block, 0, st, p); break;
+            case 2: ESMI_LAUNCH((attn_long_kernel<2>), grid, block, 0, st, p); break;
+            case 4: ESMI_LAUNCH((attn_long_kernel<4>), grid, block, 0, st, p); break;
+            case 8: ESMI_LAUNCH((attn_long_kernel<8>), grid, block, 0, st, p); break;
+            default: return ESMI_ERR_UNSUPPORTED;   // widths of the three published sizes: 32 .. 256
+        }
+        return launch_status();
+    }
     if (nkt == 1) ESMI_LAUNCH((attn_kernel<1>), grid, block, 0, st, p);
     else if (nkt == 2) ESMI_LAUNCH((attn_kernel<2>), grid, block, 0, st, p);
     else if (nkt <= 4) ESMI_LAUNCH((attn_kernel<4>), grid, block, 0, st, p);

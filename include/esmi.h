@@ -234,7 +234,7 @@ int esmi_fuse_variance_adaptor_f32(const esmi_fuse_weights* fuse, int depth, int
 /* ------------------------------------------------------------------ module-level forwards
  * The reference's sub-modules called on their own (one kernel per reference op, fp32 MFMA):
  *  SelfAttention.forward, layers/blocks.py:43-71: qkv Linear (bias-free) -> per-head softmax((q k^T) (C//h)^-1/2) v with every
- *  head at full width C, scores NOT masked -> proj Linear.  x, out: (B,N,C).  N <= 256 (ESMI_ERR_UNSUPPORTED beyond). */
+ *  head at full width C, scores NOT masked -> proj Linear.  x, out: (B,N,C); any N (key-chunked kernel beyond 256 keys). */
 size_t esmi_self_attention_workspace_bytes(int B, int N, int C, int heads);
 int esmi_self_attention_f32(const float* qkv_w /* (3hC, C) */, const float* proj_w /* (C, hC) */, const float* proj_b, int B, int N,
                             int C, int heads, const float* x, float* out, void* workspace, size_t workspace_bytes,

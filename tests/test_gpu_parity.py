@@ -507,3 +507,24 @@ def test_two_stream_pipeline_matches_single_stream(nets):
         torch.cuda.synchronize()
     for step, (a, b) in enumerate(zip(refs, got)):
         assert torch.equal(a, b), f"step {step}"
+
+
+@pytest.mark.parametrize("name,B,T,lens", [("tiny", 3, 300, [300, 257, 31]), ("base", 2, 260, [260, 200]), ("small", 1, 513, [513])])
+def test_long_sequences_beyond_256(name, B, T, lens, nets):
+    """The reference has no sequence limit (README: long text).  T > 256: block 0 attends over more than 256 keys -- the
+    key-chunked two-sweep attention kernel (attention.h) behind the per-op plan; everything else tiles as usual."""
+    net, cfg, sd = nets(name)
+    ids, mask = synth_phonemes(B, T, 77, lens)
+    dur = np.random.default_rng(5).integers(0, 4, size=(B, T)).astype(np.int32)
+    x = {"phoneme": torch.from_numpy(ids).to(DEV), "duration_forced": torch.from_numpy(dur).to(DEV)}
+    if B > 1:
+        x["phoneme_mask"] = torch.from_numpy(mask).to(DEV)
+    with torch.no_grad():
+        enc = net.encoder._encode(x)
+        mel, mel_len, _ = net(x)
+    o = oracle.phoneme2mel(cfg, oracle.Weights(sd), ids, mask if B > 1 else None, pitch=enc["pitch"][..., 0].cpu().numpy(),
+                           energy=enc["energy"][..., 0].cpu().numpy(), duration=dur)
+    np.testing.assert_allclose(enc["pitch"].cpu().numpy(), o.pitch, atol=H.PRED_TOL, rtol=0)
+    np.testing.assert_allclose(enc["duration"].cpu().numpy(), o.duration, atol=H.PRED_TOL, rtol=0)
+    assert np.array_equal(mel_len.cpu().numpy(), o.mel_len)
+    assert mel.shape == o.mel.shape and np.abs(mel.cpu().numpy() - o.mel).max() < H.MEL_TOL

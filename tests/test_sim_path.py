@@ -265,3 +265,21 @@ def test_simulated_split_range_guard(nets):
         with use_sim(), torch.no_grad():
             with pytest.raises(ValueError, match="libesmi_fp32mfma"):
                 net({"phoneme": torch.from_numpy(ids), "phoneme_mask": torch.from_numpy(mask)})
+
+
+def test_simulated_long_sequence_beyond_256_keys(nets):
+    """T = 270: block 0 attends over 270 keys -> the key-chunked attention kernel of the per-op plan."""
+    net, cfg, sd = nets("tiny")
+    B, T = 1, 270
+    ids, _ = synth_phonemes(B, T, 78)
+    dur = np.ones((B, T), np.int32)
+    dur[:, ::5] = 0
+    x = {"phoneme": torch.from_numpy(ids), "duration_forced": torch.from_numpy(dur)}
+    with use_sim(), torch.no_grad():
+        enc = net.encoder._encode(x)
+        mel, mel_len, _ = net(x)
+    o = oracle.phoneme2mel(cfg, oracle.Weights(sd), ids, None, pitch=enc["pitch"][..., 0].numpy(),
+                           energy=enc["energy"][..., 0].numpy(), duration=dur)
+    np.testing.assert_allclose(enc["pitch"].numpy(), o.pitch, atol=H.PRED_TOL, rtol=0)
+    assert np.array_equal(mel_len.numpy(), o.mel_len)
+    assert np.abs(mel.numpy() - o.mel).max() < H.MEL_TOL
