@@ -6,8 +6,9 @@ names); all arithmetic runs in hand-written HIP kernels behind the C-ABI of incl
 from .config import CONFIGS, ESConfig
 from .networks import (Encoder, Fuse, AcousticDecoder, FeatureUpsampler, MelDecoder, PhonemeEncoder, Phoneme2Mel,
                        SelfAttention, MixFFN, get_mask_from_lengths)
-from .model import build_phoneme2mel, load_numpy_state_dict
+from .model import EfficientSpeech, build_phoneme2mel, from_lightning_checkpoint, load_numpy_state_dict
+from .scheduler import BucketedSynthesizer
 
 __all__ = ["PhonemeEncoder", "MelDecoder", "Phoneme2Mel", "Encoder", "Fuse", "AcousticDecoder", "FeatureUpsampler",
            "SelfAttention", "MixFFN", "get_mask_from_lengths", "CONFIGS", "ESConfig", "build_phoneme2mel",
-           "load_numpy_state_dict"]
+           "load_numpy_state_dict", "EfficientSpeech", "from_lightning_checkpoint", "BucketedSynthesizer"]

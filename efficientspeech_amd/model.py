@@ -1,7 +1,18 @@
-"""Model construction helpers (the arithmetic-free part of the reference's model.py:127-147)."""
-import torch
+"""Model-level wrapper: the arithmetic-free part of the reference's model.py.
 
-from .config import ESConfig, LJSPEECH_PITCH_STATS, LJSPEECH_ENERGY_STATS
+`EfficientSpeech` mirrors the attribute names and call signatures demo.py / synthesize.py use on the reference's
+LightningModule (`/root/reference/model.py:103-164`, `demo.py:66-67,122-124`, `synthesize.py:103-124`) without Lightning:
+`.phoneme2mel` (the MI355X-native acoustic model of this package), `.hifigan` (whatever vocoder module the caller plugs
+in -- the HiFi-GAN generator is SURVEY §8f-3, outside the path this repo accelerates), `forward(x)`, `predict_step(batch)`,
+`load_from_checkpoint(...)` for Lightning-shaped checkpoint dicts.
+"""
+import json
+import os
+
+import torch
+from torch import nn
+
+from .config import CONFIGS, ESConfig, LJSPEECH_PITCH_STATS, LJSPEECH_ENERGY_STATS
 from .networks import PhonemeEncoder, MelDecoder, Phoneme2Mel
 
 
@@ -24,3 +35,84 @@ def from_lightning_checkpoint(ckpt, cfg: ESConfig, **kw):
     sd = {k[len("phoneme2mel."):]: v for k, v in ckpt["state_dict"].items() if k.startswith("phoneme2mel.")}
     net.load_state_dict(sd, strict=True)
     return net
+
+
+def _stats_from(preprocess_config):
+    """pitch / energy bin ranges: stats.json under preprocess_config['path']['preprocessed_path'] (model.py:127-130), the
+    LJSpeech values shipped with the reference when no config / file is given."""
+    if preprocess_config is not None:
+        path = os.path.join(preprocess_config["path"]["preprocessed_path"], "stats.json")
+        if os.path.exists(path):
+            with open(path) as f:
+                stats = json.load(f)
+            return tuple(stats["pitch"][:2]), tuple(stats["energy"][:2])
+    return LJSPEECH_PITCH_STATS, LJSPEECH_ENERGY_STATS
+
+
+class EfficientSpeech(nn.Module):
+    """Drop-in for the object demo.py / synthesize.py hold (`model.phoneme2mel`, `model.hifigan`, `model(x)`).
+
+    Constructor arguments as `EfficientSpeech.__init__` (model.py:104-121); the training-only ones (lr, weight_decay,
+    max_epochs, wav_path) are accepted and ignored.  NOTE the reference's class default `decoder_kernel_size=3` differs from
+    its CLI default 5 that every published checkpoint uses: like the reference, the class keeps 3, callers
+    (and `from_config`) pass what their checkpoint was trained with.
+
+    `hifigan`: a vocoder module mapping mel (B, 80, L) -> wav (B, 1, samples).  None (default): `predict_step` returns the
+    channels-first mel in place of the waveform -- the vocoder is not part of this repo's path."""
+
+    def __init__(self, preprocess_config=None, lr=1e-3, weight_decay=1e-6, max_epochs=5000, depth=2, n_blocks=2, block_depth=2,
+                 reduction=4, head=1, embed_dim=128, kernel_size=3, decoder_kernel_size=3, expansion=1, wav_path="wavs",
+                 hifigan_checkpoint=None, infer_device=None, verbose=False, hifigan=None):
+        super().__init__()
+        pitch_stats, energy_stats = _stats_from(preprocess_config)
+        encoder = PhonemeEncoder(pitch_stats=pitch_stats, energy_stats=energy_stats, depth=depth, reduction=reduction, head=head,
+                                 embed_dim=embed_dim, kernel_size=kernel_size, expansion=expansion)
+        decoder = MelDecoder(dim=embed_dim // reduction, kernel_size=decoder_kernel_size, n_blocks=n_blocks,
+                             block_depth=block_depth)
+        self.phoneme2mel = Phoneme2Mel(encoder=encoder, decoder=decoder)
+        self.hifigan = hifigan
+        self.hparams = dict(depth=depth, n_blocks=n_blocks, block_depth=block_depth, reduction=reduction, head=head,
+                            embed_dim=embed_dim, kernel_size=kernel_size, decoder_kernel_size=decoder_kernel_size,
+                            expansion=expansion, infer_device=infer_device)
+        if infer_device is not None:
+            self.to(infer_device)
+
+    @classmethod
+    def from_config(cls, name_or_cfg, **kw):
+        """One of the three published sizes ('tiny' / 'small' / 'base') with the CLI hyper-parameters (decoder kernel 5)."""
+        cfg = CONFIGS[name_or_cfg] if isinstance(name_or_cfg, str) else name_or_cfg
+        return cls(depth=cfg.depth, n_blocks=cfg.n_blocks, block_depth=cfg.block_depth, reduction=cfg.reduction, head=cfg.head,
+                   embed_dim=cfg.embed_dim, kernel_size=cfg.kernel_size, decoder_kernel_size=cfg.decoder_kernel_size,
+                   expansion=cfg.expansion, **kw)
+
+    def forward(self, x):
+        """model.py:155-156: the training dict when `self.training`, else `predict_step(x)`."""
+        return self.phoneme2mel(x, train=True) if self.training else self.predict_step(x)
+
+    def predict_step(self, batch, batch_idx=0, dataloader_idx=0):
+        """model.py:159-164: (wav, mel_len, duration); wav = hifigan(mel.transpose(1, 2)).squeeze(1).  Without a vocoder the
+        first element is the channels-first mel (B, 80, L) itself."""
+        mel, mel_len, duration = self.phoneme2mel(batch, train=False)
+        mel = mel.transpose(1, 2)
+        if self.hifigan is None:
+            return mel, mel_len, duration
+        return self.hifigan(mel).squeeze(1), mel_len, duration
+
+    @classmethod
+    def load_from_checkpoint(cls, checkpoint, map_location=None, strict=True, **hparams):
+        """`checkpoint`: path of a Lightning .ckpt (torch.load) or the already-loaded dict
+        {'state_dict': {'phoneme2mel.*', 'hifigan.*'}, 'hyper_parameters': {...}}.  Constructor arguments come from
+        `hparams`, falling back to the checkpoint's own `hyper_parameters` (as Lightning does, synthesize.py:103-119).
+        `phoneme2mel.*` loads strict; `hifigan.*` goes to the plugged-in vocoder when there is one, else it is ignored."""
+        ckpt = torch.load(checkpoint, map_location=map_location or "cpu") if isinstance(checkpoint, (str, os.PathLike)) else checkpoint
+        hp = dict(ckpt.get("hyper_parameters", {}))
+        hp.update(hparams)
+        accepted = cls.__init__.__code__.co_varnames[1:cls.__init__.__code__.co_argcount]
+        model = cls(**{k: v for k, v in hp.items() if k in accepted})
+        sd = ckpt["state_dict"]
+        model.phoneme2mel.load_state_dict({k[len("phoneme2mel."):]: v for k, v in sd.items() if k.startswith("phoneme2mel.")},
+                                          strict=strict)
+        voc = {k[len("hifigan."):]: v for k, v in sd.items() if k.startswith("hifigan.")}
+        if voc and model.hifigan is not None and hasattr(model.hifigan, "load_state_dict"):
+            model.hifigan.load_state_dict(voc, strict=strict)
+        return model.eval()

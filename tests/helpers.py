@@ -147,3 +147,102 @@ def check_submodule_forwards(net, cfg, sd, device, seed=3):
             assert e_t.shape == (3, 29, cfg.dim) and e_p.shape == (3, 29, 1, cfg.dim)
             assert np.array_equal(e_t.cpu().numpy(), emb[idx]) and np.array_equal(e_p.cpu().numpy()[:, :, 0], emb[idx])
     assert net.encoder.duration_decoder.get_embedding(None, None, None) is None
+
+
+def check_wrapper_and_scheduler(device):
+    """model.py-shaped wrapper (`.phoneme2mel`, `.hifigan`, `model(x)`, `predict_step`, Lightning-dict load; model.py:155-164,
+    demo.py:66-67) on a padded B > 1 batch and a B == 1 call, and the length-bucketed scheduler, against the oracle."""
+    from oracle import oracle
+    from efficientspeech_amd import EfficientSpeech, BucketedSynthesizer
+    from efficientspeech_amd.synth import synth_phonemes
+    cfg = CONFIGS["tiny"]
+    sd = synth_state_dict(cfg, 1234)
+    ckpt = {"state_dict": {"phoneme2mel." + k: torch.from_numpy(v) for k, v in sd.items()},
+            "hyper_parameters": dict(depth=cfg.depth, n_blocks=cfg.n_blocks, block_depth=cfg.block_depth, reduction=cfg.reduction,
+                                     head=cfg.head, embed_dim=cfg.embed_dim, kernel_size=cfg.kernel_size,
+                                     decoder_kernel_size=cfg.decoder_kernel_size, expansion=cfg.expansion, lr=1e-3)}
+    ckpt["state_dict"]["hifigan.conv_pre.bias"] = torch.zeros(4)           # vocoder keys present, no vocoder plugged in
+    model = EfficientSpeech.load_from_checkpoint(ckpt).to(device)
+    assert not model.training and model.hifigan is None and hasattr(model, "phoneme2mel")
+    w = oracle.Weights(sd)
+    rng = np.random.default_rng(8)
+    # padded B > 1 batch, durations forced (random-init duration heads round to ~0-4 frames: keep the case non-degenerate)
+    ids, mask = synth_phonemes(3, 23, 4, [23, 15, 6])
+    dur = rng.integers(1, 5, size=(3, 23)).astype(np.int32)
+    x = {"phoneme": torch.from_numpy(ids).to(device), "phoneme_mask": torch.from_numpy(mask).to(device),
+         "duration_forced": torch.from_numpy(dur).to(device)}
+    with torch.no_grad():
+        enc = model.phoneme2mel.encoder._encode(x)
+        wav, mel_len, duration = model(x)                                  # eval: predict_step; no vocoder -> (B, 80, L) mel
+    o = oracle.phoneme2mel(cfg, w, ids, mask, pitch=enc["pitch"][..., 0].cpu().numpy(), energy=enc["energy"][..., 0].cpu().numpy(),
+                           duration=dur)
+    assert wav.shape == (3, 80, o.mel.shape[1]) and np.array_equal(mel_len.cpu().numpy(), o.mel_len)
+    assert np.abs(wav.transpose(1, 2).cpu().numpy() - o.mel).max() < MEL_TOL
+    np.testing.assert_allclose(duration.cpu().numpy(), o.duration, atol=PRED_TOL, rtol=0)
+    # a vocoder plugged in: called on the channels-first mel, its output squeezed (model.py:161-162)
+    seen = {}
+
+    class FakeVocoder(torch.nn.Module):
+        def forward(self, m):
+            seen["shape"] = tuple(m.shape)
+            return m.sum(1, keepdim=True)
+    model.hifigan = FakeVocoder()
+    with torch.no_grad():
+        wav2, _, _ = model.predict_step(x)
+    assert seen["shape"] == tuple(wav.shape) and wav2.shape == (3, wav.shape[2])
+    model.hifigan = None
+    # B == 1 (demo.py:66-67): no mask key at all
+    ids1, _ = synth_phonemes(1, 19, 6)
+    x1 = {"phoneme": torch.from_numpy(ids1).to(device), "duration_forced": torch.from_numpy(dur[:1, :19]).to(device)}
+    with torch.no_grad():
+        e1 = model.phoneme2mel.encoder._encode(x1)
+        m1, l1, _ = model(x1)
+    o1 = oracle.phoneme2mel(cfg, w, ids1, None, pitch=e1["pitch"][..., 0].cpu().numpy(), energy=e1["energy"][..., 0].cpu().numpy(),
+                            duration=dur[:1, :19])
+    assert np.array_equal(l1.cpu().numpy(), o1.mel_len) and np.abs(m1.transpose(1, 2).cpu().numpy() - o1.mel).max() < MEL_TOL
+    # training mode dispatches to the teacher-forced dict (model.py:156)
+    model.train()
+    xt = dict(x)
+    xt.update(pitch=torch.zeros((3, 23), device=device), energy=torch.zeros((3, 23), device=device),
+              duration=torch.from_numpy(dur).to(device), mel_len=torch.from_numpy(dur.sum(1).astype(np.int32)).to(device))
+    del xt["duration_forced"]
+    with torch.no_grad():
+        out = model(xt)
+    assert isinstance(out, dict) and {"mel", "pitch", "energy", "duration", "mel_len", "features", "masks"} <= set(out)
+    model.eval()
+    # length-bucketed scheduler: every request answered once, in order, each batch = one reference-shaped forward
+    lens = [9, 9, 5, 9, 5, 17, 16, 3, 9]
+    seqs = [rng.integers(1, 150, size=n).astype(np.int32) for n in lens]
+    sched = BucketedSynthesizer(model.phoneme2mel, max_batch=3, granularity=4)
+    plan = sched.plan(lens)
+    assert sorted(i for idx, _ in plan for i in idx) == list(range(len(lens))) and all(len(idx) <= 3 for idx, _ in plan)
+    assert all(max(lens[i] for i in idx) == T and (T + 3) // 4 == (min(lens[i] for i in idx) + 3) // 4 for idx, T in plan)
+    forced = {i: rng.integers(1, 4, size=n).astype(np.int32) for i, n in enumerate(lens)}
+
+    def extra(idx, T):
+        d = np.zeros((len(idx), T), np.int32)
+        for r, i in enumerate(idx):
+            d[r, :lens[i]] = forced[i]
+        return {"duration_forced": torch.from_numpy(d).to(device)}
+    res = sched(seqs, extra=extra)
+    assert len(res) == len(lens)
+    for idx, T in plan:                                # oracle on the same batches
+        ids_b = np.zeros((len(idx), T), np.int32)
+        d_b = np.zeros((len(idx), T), np.int32)
+        for r, i in enumerate(idx):
+            ids_b[r, :lens[i]] = seqs[i]
+            d_b[r, :lens[i]] = forced[i]
+        m_b = np.arange(T)[None, :] >= np.array([lens[i] for i in idx])[:, None]
+        xb = {"phoneme": torch.from_numpy(ids_b).to(device), "duration_forced": torch.from_numpy(d_b).to(device)}
+        if len(idx) > 1:
+            xb["phoneme_mask"] = torch.from_numpy(m_b).to(device)
+        with torch.no_grad():
+            eb = model.phoneme2mel.encoder._encode(xb)
+        ob = oracle.phoneme2mel(cfg, w, ids_b, m_b if len(idx) > 1 else None, pitch=eb["pitch"][..., 0].cpu().numpy(),
+                                energy=eb["energy"][..., 0].cpu().numpy(), duration=d_b)
+        for r, i in enumerate(idx):
+            mel_i, dur_i = res[i]
+            n = int(ob.mel_len[r])
+            assert mel_i.shape == (n, 80) and dur_i.shape == (lens[i],)
+            if n:
+                assert np.abs(mel_i.cpu().numpy() - ob.mel[r, :n]).max() < MEL_TOL

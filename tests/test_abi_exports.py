@@ -143,3 +143,21 @@ def test_state_dict_keys_match_reference_table():
         got = [(k, tuple(v.shape)) for k, v in net.state_dict().items()]
         assert got == [(k, s) for k, s, _ in state_dict_spec(cfg)]
         assert sum(p.numel() for p in net.parameters()) == PARAM_COUNTS[name]
+
+
+def test_bucket_plan_covers_every_request_once():
+    from efficientspeech_amd.scheduler import BucketedSynthesizer
+    import numpy as np
+    rng = np.random.default_rng(0)
+    lens = rng.integers(1, 200, size=500).tolist()
+    for g, mb in ((1, 256), (8, 64), (32, 7)):
+        plan = BucketedSynthesizer(None, max_batch=mb, granularity=g).plan(lens)
+        seen = sorted(i for idx, _ in plan for i in idx)
+        assert seen == list(range(500))
+        for idx, T in plan:
+            ls = [lens[i] for i in idx]
+            assert len(idx) <= mb and max(ls) == T and T - min(ls) < g
+        waste = BucketedSynthesizer.padding_waste(lens, plan)
+        assert 0.0 <= waste < g / (np.mean(lens) + g) + 1e-9 if g > 1 else waste == 0.0
+    # one big padded batch, for comparison: what the reference does with a ragged batch
+    assert BucketedSynthesizer.padding_waste(lens, [(list(range(500)), max(lens))]) > 0.3

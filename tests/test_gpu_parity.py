@@ -528,3 +528,8 @@ def test_long_sequences_beyond_256(name, B, T, lens, nets):
     np.testing.assert_allclose(enc["duration"].cpu().numpy(), o.duration, atol=H.PRED_TOL, rtol=0)
     assert np.array_equal(mel_len.cpu().numpy(), o.mel_len)
     assert mel.shape == o.mel.shape and np.abs(mel.cpu().numpy() - o.mel).max() < H.MEL_TOL
+
+
+def test_model_wrapper_and_bucket_scheduler():
+    """model.py-shaped wrapper on a padded B > 1 batch and a B == 1 call, and the length-bucketed scheduler, vs the oracle."""
+    H.check_wrapper_and_scheduler(DEV)

@@ -283,3 +283,8 @@ def test_simulated_long_sequence_beyond_256_keys(nets):
     np.testing.assert_allclose(enc["pitch"].numpy(), o.pitch, atol=H.PRED_TOL, rtol=0)
     assert np.array_equal(mel_len.numpy(), o.mel_len)
     assert np.abs(mel.numpy() - o.mel).max() < H.MEL_TOL
+
+
+def test_simulated_model_wrapper_and_bucket_scheduler():
+    with use_sim():
+        H.check_wrapper_and_scheduler("cpu")
