@@ -47,6 +47,66 @@ struct ConvGemmP {
     int dot_relu;
 };
 
+// Fused epilogue of the implicit-GEMM kernels, in the MFMA C/D layout (row = tile_row(r), col = n0 + 32*nt + (lane&31)):
+//   out = mask( post_relu( LN( act(acc * s + bias) + residual ) ) ), optional row-dot side output on the pre-LN value.
+template <int NT>
+__device__ __forceinline__ void convgemm_epilogue(f32x16 (&acc)[NT], const ConvGemmP& p, int b, int t0, int n0, int lane) {
+    const int i = lane & 31;
+    int col[NT];
+    bool cok[NT];
+    float bias[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        col[nt] = n0 + 32 * nt + i;
+        cok[nt] = col[nt] < p.c_out;
+        bias[nt] = (p.bias && cok[nt]) ? p.bias[col[nt]] : 0.0f;
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int t = t0 + tile_row(r, lane);
+        const bool rok = t < p.n_out;
+        const long row = (long)b * p.n_out + t;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            float v = apply_act(fmaf(acc[nt][r], ESMI_CHAIN_SPLIT ? kF16WScaleInv : 1.0f, bias[nt]), p.act);
+            if (p.res && rok && cok[nt]) v += p.res[row * p.ldr + p.r_coff + col[nt]];
+            acc[nt][r] = v;
+        }
+    }
+    if (p.dot_out) {
+        float dw[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) dw[nt] = cok[nt] ? p.dot_w[col[nt]] : 0.0f;
+        const float db = p.dot_b[0];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float s = 0.0f;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) s = fmaf(acc[nt][r], dw[nt], s);
+            s = row_sum32(s) + db;
+            if (p.dot_relu) s = fmaxf(s, 0.0f);
+            const int t = t0 + tile_row(r, lane);
+            if (i == 0 && t < p.n_out) p.dot_out[(long)b * p.n_out + t] = s;
+        }
+    }
+    if (!p.out) return;
+    if (p.ln_g) layernorm_tile<NT>(acc, p.ln_g, p.ln_b, lane);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int t = t0 + tile_row(r, lane);
+        if (t >= p.n_out) continue;
+        const long row = (long)b * p.n_out + t;
+        const bool masked = p.rowmask && p.rowmask[row];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            float v = acc[nt][r];
+            if (p.post_relu) v = fmaxf(v, 0.0f);
+            if (masked) v = 0.0f;
+            if (cok[nt]) p.out[row * p.ldo + p.o_coff + col[nt]] = v;
+        }
+    }
+}
+
 template <int NT>
 __global__ __launch_bounds__(256) void convgemm_kernel(const ConvGemmP p) {
     const int lane = lane_id();
@@ -170,60 +230,99 @@ __global__ __launch_bounds__(256) void convgemm_kernel(const ConvGemmP p) {
 #endif
     }
 
-    // ---------------- epilogue in the MFMA C/D layout: row = tile_row(r), col = n0 + 32*nt + i
-    int col[NT];
-    bool cok[NT];
-    float bias[NT];
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-        col[nt] = n0 + 32 * nt + i;
-        cok[nt] = col[nt] < p.c_out;
-        bias[nt] = (p.bias && cok[nt]) ? p.bias[col[nt]] : 0.0f;
-    }
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int t = t0 + tile_row(r, lane);
-        const bool rok = t < p.n_out;
-        const long row = (long)b * p.n_out + t;
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            float v = apply_act(fmaf(acc[nt][r], ESMI_CHAIN_SPLIT ? kF16WScaleInv : 1.0f, bias[nt]), p.act);
-            if (p.res && rok && cok[nt]) v += p.res[row * p.ldr + p.r_coff + col[nt]];
-            acc[nt][r] = v;
-        }
-    }
-    if (p.dot_out) {
-        float dw[NT];
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) dw[nt] = cok[nt] ? p.dot_w[col[nt]] : 0.0f;
-        const float db = p.dot_b[0];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            float s = 0.0f;
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) s = fmaf(acc[nt][r], dw[nt], s);
-            s = row_sum32(s) + db;
-            if (p.dot_relu) s = fmaxf(s, 0.0f);
-            const int t = t0 + tile_row(r, lane);
-            if (i == 0 && t < p.n_out) p.dot_out[(long)b * p.n_out + t] = s;
-        }
-    }
-    if (!p.out) return;
-    if (p.ln_g) layernorm_tile<NT>(acc, p.ln_g, p.ln_b, lane);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int t = t0 + tile_row(r, lane);
-        if (t >= p.n_out) continue;
-        const long row = (long)b * p.n_out + t;
-        const bool masked = p.rowmask && p.rowmask[row];
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            float v = acc[nt][r];
-            if (p.post_relu) v = fmaxf(v, 0.0f);
-            if (masked) v = 0.0f;
-            if (cok[nt]) p.out[row * p.ldo + p.o_coff + col[nt]] = v;
-        }
-    }
+    convgemm_epilogue<NT>(acc, p, b, t0, n0, lane);
 }
+
+
+#if ESMI_CHAIN_SPLIT
+// ---- the same implicit GEMM with the WEIGHT tile staged through LDS (large shapes of the per-op plan: base ES block 1,
+// long sequences).  convgemm_kernel streams both operands from L2 per wave: at 65536 rows x 3072 columns (base qkv) every
+// wave re-reads its 128 weight rows for each of its row tiles, and the kernel sits at ~8 % of the matrix pipe behind L2
+// latency.  Here a 256-thread workgroup owns 128 positions x BN = 32*NT channels: each wave keeps its own 32 rows (so the
+// LayerNorm / row-dot epilogues stay in-wave) and reads its A fragments straight from global memory one chunk ahead, while
+// the BN x 32-channel weight chunk is fetched ONCE per workgroup, split into the two f16 planes of 2^8 W once (not once per
+// wave), and double-buffered in LDS: [buffer][plane][BN rows][16 data + 4 pad dwords] -- the 80-byte row stride makes both the
+// ds_write_b64 of the staging threads and the 16-byte B-fragment reads (lane = weight row) bank-conflict free.
+// Restrictions (the launcher falls back to convgemm_kernel otherwise): MODE_CONV, stride 1, no embedding gather, Cin % 32 == 0.
+constexpr int kGemmRowDw = 20;   // dwords per weight row and plane in LDS
+template <int NT>
+__host__ __device__ constexpr int convgemm_lds_bytes() { return 2 * 2 * 32 * NT * kGemmRowDw * 4; }
+
+template <int NT>
+__global__ __launch_bounds__(256, 2) void convgemm_lds_kernel(const ConvGemmP p) {
+    constexpr int BN = 32 * NT, PLANE = BN * kGemmRowDw;
+    ESMI_DYN_LDS(lds);
+    unsigned* wt = reinterpret_cast<unsigned*>(lds);   // [2 buffers][2 planes][PLANE]
+    const int tid = (int)threadIdx.x, lane = lane_id(), w = wave_id();
+    const int i = lane & 31, h = lane >> 5;
+    const int tiles_per_b = (p.n_out + 127) >> 7;
+    const int b = (int)blockIdx.x / tiles_per_b;
+    const int t0 = (((int)blockIdx.x - b * tiles_per_b) << 7) + 32 * w;   // this wave's 32 positions
+    const int n0 = (int)blockIdx.y * BN;
+    const int t_out = t0 + i;
+
+    f32x16 acc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[nt] = zero16();
+    const int kchunks = p.c_in >> 5, n_it = p.k * kchunks;
+    f32x4 a_nxt[2][2], w_nxt[NT];
+    f16x2p a_cur[2];
+    auto fetch = [&](int it) __attribute__((always_inline)) {   // global -> registers: A rows of this wave, W rows of the workgroup
+        const int j = it / kchunks, c = (it - j * kchunks) << 5;
+        const int ti = t_out + j - p.pad;
+        const bool ok = t_out < p.n_out && ti >= 0 && ti < p.n_in;
+        const float* arow = p.A + ((long)b * p.n_in + (ok ? ti : 0)) * p.lda + p.a_coff + c + 8 * h;
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+            a_nxt[st][0] = ok ? ld4(arow + 16 * st) : zero4();
+            a_nxt[st][1] = ok ? ld4(arow + 16 * st + 4) : zero4();
+        }
+        const float* wj = p.W + (long)j * p.c_out * p.c_in + c;
+#pragma unroll
+        for (int u = 0; u < NT; ++u) {
+            const int q = tid + 256 * u, n = n0 + (q >> 3);
+            w_nxt[u] = n < p.c_out ? ld4(wj + (long)n * p.c_in + 4 * (q & 7)) : zero4();
+        }
+    };
+    auto stage = [&](int buf) __attribute__((always_inline)) {   // registers -> LDS planes (weights), A fragments split in place
+        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+        for (int u = 0; u < NT; ++u) {
+            const int q = tid + 256 * u;
+            const f32x4 x = w_nxt[u] * kF16WScale;
+            unsigned h1a, h2a, h1b, h2b;
+            split_f16_pair(x[0], x[1], h1a, h2a);
+            split_f16_pair(x[2], x[3], h1b, h2b);
+            unsigned* d = wt + (buf * 2) * PLANE + (q >> 3) * kGemmRowDw + 2 * (q & 7);
+            *reinterpret_cast<u32x2*>(d) = u32x2{h1a, h1b};
+            *reinterpret_cast<u32x2*>(d + PLANE) = u32x2{h2a, h2b};
+        }
+#pragma unroll
+        for (int st = 0; st < 2; ++st) a_cur[st] = split_f16x2(a_nxt[st][0], a_nxt[st][1]);
+    };
+    fetch(0);
+    stage(0);
+    __syncthreads();
+    for (int it = 0; it < n_it; ++it) {
+        const bool more = it + 1 < n_it;
+        f16x2p a_use[2] = {a_cur[0], a_cur[1]};
+        if (more) fetch(it + 1);                   // in flight under this chunk's MFMAs
+        sched_fence();
+        const unsigned* bp = wt + ((it & 1) * 2) * PLANE + opaque_i(i * kGemmRowDw + 4 * h);
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const u32x4 b1 = *reinterpret_cast<const u32x4*>(bp + 32 * nt * kGemmRowDw + 8 * st);
+                const u32x4 b2 = *reinterpret_cast<const u32x4*>(bp + PLANE + 32 * nt * kGemmRowDw + 8 * st);
+                acc[nt] = mfma32_split2(a_use[st], b1, b2, acc[nt]);
+            }
+        }
+        if (more) stage((it + 1) & 1);             // the other buffer: last read one iteration ago, before the barrier below
+        __syncthreads();
+    }
+    if (t0 < p.n_out) convgemm_epilogue<NT>(acc, p, b, t0, n0, lane);
+}
+#endif
 
 }  // namespace esmi

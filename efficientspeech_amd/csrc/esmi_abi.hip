@@ -15,6 +15,14 @@
 #include "mel_decoder.h"
 #include "small_kernels.h"
 
+#ifndef ESMI_GEMM_LDS_MIN_ROWS   // rows (B * n_out) from which the per-op plan's GEMMs take the LDS-staged kernel
+#ifdef ESMI_WAVESIM
+#define ESMI_GEMM_LDS_MIN_ROWS 1   // the simulator tests are small: run them through it too
+#else
+#define ESMI_GEMM_LDS_MIN_ROWS 2048
+#endif
+#endif
+
 using namespace esmi;
 
 namespace {
@@ -71,6 +79,21 @@ int launch_convgemm(ConvGemmP p, hipStream_t st) {
     } else {
         nt = p.c_out > 64 ? 4 : (p.c_out > 32 ? 2 : 1);
     }
+#if ESMI_CHAIN_SPLIT
+    // large plain convolutions / Linears: weight tile staged through LDS once per 128 positions (convgemm.h)
+    if (p.mode == MODE_CONV && p.stride == 1 && !p.ids && (p.c_in & 31) == 0 && p.c_out > 64 && (long)p.B * p.n_out >= ESMI_GEMM_LDS_MIN_ROWS) {
+        const int nl = full_row ? (nt <= 4 ? 4 : 8) : ((p.c_out & 255) == 0 ? 8 : 4);
+        dim3 g2((unsigned)(p.B * ((p.n_out + 127) / 128)), full_row ? 1 : (p.c_out + 32 * nl - 1) / (32 * nl));
+        if (nl == 4) {
+            ESMI_LAUNCH((convgemm_lds_kernel<4>), g2, dim3(256), convgemm_lds_bytes<4>(), st, p);
+        } else {
+            static AttrOnce once;
+            if (int rc = raise_lds_limit(reinterpret_cast<const void*>(convgemm_lds_kernel<8>), once)) return rc;
+            ESMI_LAUNCH((convgemm_lds_kernel<8>), g2, dim3(256), convgemm_lds_bytes<8>(), st, p);
+        }
+        return launch_status();
+    }
+#endif
     const int tiles = p.B * ((p.n_out + 31) / 32);
     dim3 grid((tiles + 3) / 4, full_row ? 1 : (p.c_out + 32 * nt - 1) / (32 * nt));
     dim3 block(256);
