@@ -291,8 +291,8 @@ __global__ __launch_bounds__(256, 2) void convgemm_lds_kernel(const ConvGemmP p)
             const int q = tid + 256 * u;
             const f32x4 x = w_nxt[u] * kF16WScale;
             unsigned h1a, h2a, h1b, h2b;
-            split_f16_pair(x[0], x[1], h1a, h2a);
-            split_f16_pair(x[2], x[3], h1b, h2b);
+            split_f16_pair_rn(x[0], x[1], h1a, h2a);   // weights: nearest-rounded pieces, as the pack-time splitters
+            split_f16_pair_rn(x[2], x[3], h1b, h2b);
             unsigned* d = wt + (buf * 2) * PLANE + (q >> 3) * kGemmRowDw + 2 * (q & 7);
             *reinterpret_cast<u32x2*>(d) = u32x2{h1a, h1b};
             *reinterpret_cast<u32x2*>(d + PLANE) = u32x2{h2a, h2b};

@@ -841,17 +841,21 @@ int esmi_mel_decoder_f32(const float* blob, const esmi_decoder_shape* s, const f
     p.n_tiles = (L_out + p.TL - 1) / p.TL;
     dim3 grid((unsigned)(p.n_tiles * ((B + 7) / 8) * 8)), block(kDecThreads);
     hipStream_t st = S(stream);
-#define ESMI_DEC_CASE(DX2, KD)                                                                                     \
+#ifndef ESMI_DEC_NW256
+#define ESMI_DEC_NW256 8    // waves per window of the dx2 = 256 decoder (small / base ES): 8, or 16 (measured 30 % slower: 65 spilled
+                            // VGPRs at the 128-register budget and twice the weight traffic; small ES decoder 2.43 vs 1.87 ms)
+#endif
+#define ESMI_DEC_CASE(DX2, KD, NW)                                                                                   \
     {                                                                                                              \
         const int lds = dec_lds_floats<DX2>(KD) * (int)sizeof(float);                                              \
         static AttrOnce once; /* per instantiation */                                                              \
-        if (int rc2 = raise_lds_limit(reinterpret_cast<const void*>(mel_decoder_kernel<DX2, KD>), once)) return rc2; \
-        ESMI_LAUNCH((mel_decoder_kernel<DX2, KD>), grid, dim3(kDecThreads), lds, st, p);                           \
+        if (int rc2 = raise_lds_limit(reinterpret_cast<const void*>(mel_decoder_kernel<DX2, KD, NW>), once)) return rc2; \
+        ESMI_LAUNCH((mel_decoder_kernel<DX2, KD, NW>), grid, dim3(64 * NW), lds, st, p);                           \
     }
-    if (s->dx2 == 128 && s->kernel == 5) ESMI_DEC_CASE(128, 5)
-    else if (s->dx2 == 128 && s->kernel == 3) ESMI_DEC_CASE(128, 3)
-    else if (s->dx2 == 256 && s->kernel == 5) ESMI_DEC_CASE(256, 5)
-    else ESMI_DEC_CASE(256, 3)
+    if (s->dx2 == 128 && s->kernel == 5) ESMI_DEC_CASE(128, 5, 8)
+    else if (s->dx2 == 128 && s->kernel == 3) ESMI_DEC_CASE(128, 3, 8)
+    else if (s->dx2 == 256 && s->kernel == 5) ESMI_DEC_CASE(256, 5, ESMI_DEC_NW256)
+    else ESMI_DEC_CASE(256, 3, ESMI_DEC_NW256)
 #undef ESMI_DEC_CASE
     return launch_status();
 }

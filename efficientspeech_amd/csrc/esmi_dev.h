@@ -150,6 +150,23 @@ __device__ __forceinline__ void split_f16_pair(float a, float b, unsigned& h1, u
     h2 = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(ra, rb));
 #endif
 }
+// the same with both pieces rounded to nearest (what the weight packers do): one bit more than the truncating form, three
+// conversions instead of one packed one -- used where a value is split once and read many times (weight staging)
+__device__ __forceinline__ void split_f16_pair_rn(float a, float b, unsigned& h1, unsigned& h2) {
+#ifdef ESMI_WAVESIM
+    const unsigned ha = f32_to_f16_bits(a, false), hb = f32_to_f16_bits(b, false);
+    const float ra = a - f16_bits_to_f32(ha), rb = b - f16_bits_to_f32(hb);
+    h1 = ha | (hb << 16);
+    h2 = f32_to_f16_bits(ra, false) | (f32_to_f16_bits(rb, false) << 16);
+#else
+    typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+    const f16x2_t h = {(_Float16)a, (_Float16)b};                 // v_cvt_f16_f32: round to nearest even
+    const float ra = a - (float)h[0], rb = b - (float)h[1];       // exact
+    const f16x2_t r = {(_Float16)ra, (_Float16)rb};
+    h1 = __builtin_bit_cast(unsigned, h);
+    h2 = __builtin_bit_cast(unsigned, r);
+#endif
+}
 __device__ __forceinline__ f16x2p split_f16x2(const f32x4& x0, const f32x4& x1) {   // 8 consecutive k of one row
     f16x2p o;
 #pragma unroll

@@ -70,7 +70,7 @@ namespace esmi {
 
 constexpr int kDecRows = 128;     // frames per workgroup window
 constexpr int kDecPadRows = 2;    // zero rows above/below the window in LDS (>= k/2)
-constexpr int kDecThreads = 512;  // 8-wave windows (NW = 8, the default for every dx2)
+constexpr int kDecThreads = 512;  // 8-wave windows (the dx2 = 128 kernel and the host-side launch default)
 constexpr int kMelCols = 96;      // n_mel <= 96 (three 32-column MFMA tiles)
 
 struct DecLayout {  // offsets in floats into the packed blob
@@ -190,11 +190,14 @@ __device__ __forceinline__ int batch_max_len(const int* __restrict__ mel_len, in
 #endif
 }
 
-// 8 waves per window: wave (mh = w>>2, ns = w&3) owns rows [64mh, +64) x columns [ns*DX2/4, +DX2/4).
-template <int DX2, int KD>
-__global__ __launch_bounds__(kDecThreads, (DX2 <= 128 ? ESMI_DEC_WPS : 2)) void mel_decoder_kernel(const MelDecP p) {
+// NW waves per window (8 or 16): wave (mh = w>>2, ns = w&3) owns rows [128/MH*mh, +128/MH) x columns [ns*DX2/4, +DX2/4).
+// NW = 16 (dx2 = 256, one workgroup per CU either way): four waves per SIMD instead of two inside every barrier-separated
+// phase -- the phases are latency-bound, so the extra waves are what hides it -- at 128 VGPRs (one 32-row tile per wave).
+template <int DX2, int KD, int NW>
+__global__ __launch_bounds__(64 * NW, (DX2 <= 128 ? ESMI_DEC_WPS : NW / 4)) void mel_decoder_kernel(const MelDecP p) {
+    constexpr int kDecThreads = 64 * NW;    // shadows the namespace constant inside this kernel
     constexpr int NS = 4;                   // column slices per workgroup
-    constexpr int MH = 8 / NS;              // row groups
+    constexpr int MH = NW / NS;             // row groups (2 or 4)
     constexpr int MT = 4 / MH;              // 32-row MFMA tiles per wave
     constexpr int TPR = 16;                 // LayerNorm threads per row (one DPP row: the statistics are 4 DPP adds)
     constexpr int RPT = kDecRows * TPR / kDecThreads;   // rows per LayerNorm thread (4): gain / shift vectors are read once for all of them
@@ -315,10 +318,11 @@ __global__ __launch_bounds__(kDecThreads, (DX2 <= 128 ? ESMI_DEC_WPS : 2)) void 
     // LayerNorm ownership: lane = 16*rg + c; the thread owns rows ln_row0 + (0..3) and the float4 channel groups c + 16*k of
     // each.  The four row groups of a wave sit 16 rows apart (rows 64(w>>2) + 16rg + 4(w&3) + j): the LDS bank of a lane's
     // 16-byte access is 4*(row + c) mod 64, so rows that agree mod 16 make every ds_read_b128 / ds_write_b128 of the pass
-    // conflict-free (with four CONSECUTIVE row quadruples per wave, lanes of neighbouring groups met in the same banks:
+    // conflict-free; in general rows 64(w / LNPER) + 16rg + RPT(w % LNPER) + j (with four CONSECUTIVE row quadruples per wave, lanes of neighbouring groups met in the same banks:
     // 17.8 % of the kernel's LDS cycles were bank conflicts, profiles/r01_l).
 #if ESMI_DEC_LN_SPREAD
-    const int ln_c = lane & (TPR - 1), ln_row0 = 64 * (w >> 2) + 16 * (lane / TPR) + RPT * (w & 3);
+    constexpr int LNPER = 16 / RPT;         // waves that share one residue class of rows mod 16
+    const int ln_c = lane & (TPR - 1), ln_row0 = 64 * (w / LNPER) + 16 * (lane / TPR) + RPT * (w % LNPER);
 #else
     const int ln_c = lane & (TPR - 1), ln_row0 = (64 / TPR) * RPT * w + RPT * (lane / TPR);
 #endif
@@ -345,7 +349,7 @@ __global__ __launch_bounds__(kDecThreads, (DX2 <= 128 ? ESMI_DEC_WPS : 2)) void 
     // ================================================================== contractions
     // Un-pipelined form (exact-fp32 build; in-kernel proj stage of the split build): the wave's weight slice for KSUB k-steps
     // is loaded, then the A fragments of its rows stream from LDS.
-    constexpr int KSUB = DX2 <= 128 ? ESMI_DEC_KSUB / NTW : 8;   // k-steps (of 8 channels) of weights in registers at a time
+    constexpr int KSUB = DX2 <= 128 ? ESMI_DEC_KSUB / NTW : (NW > 8 ? 2 : 8);   // k-steps (of 8 channels) of weights in registers at a time
 #if ESMI_DEC_SPLIT
     constexpr int KS16 = KSUB / 2;
     u32x4 bf[NTW][KS16][2];
