@@ -52,11 +52,11 @@
 #define ESMI_DEC_KSUB (ESMI_DEC_SPLIT ? 4 : 8)   // un-pipelined contractions (fp32 build, in-kernel proj stage): k-steps (of 8 channels) of weights in registers at a time
 #endif
 #ifndef ESMI_DEC_WD
-#define ESMI_DEC_WD 1       // pipelined K loop: weight fragments in flight, in 16-channel steps (global/L2 -> VGPR ring)
-#endif
-#ifndef ESMI_DEC_AD
-#define ESMI_DEC_AD 1       // pipelined K loop: A fragments in flight, in (step, row tile) items (LDS -> VGPR ring)
-#endif
+#define ESMI_DEC_WD 0       // > 0: hand-pipelined K loop with this many 16-channel steps of weight fragments in flight (global/L2 ->
+#endif                      //      VGPR ring).  Measured on MI355X (tiny B=256 T=128): 0 (weights per sub-block, A fragments where used)
+#ifndef ESMI_DEC_AD         //      178 us; WD/AD = 1/1 181, 2/2 188, 3/2 215, 4/2 228, 4/3 236 us (ring registers spill at the 128-VGPR budget);
+#define ESMI_DEC_AD 1       //      256 VGPRs + 4/4: 228 us -- with four waves per SIMD the other waves already cover the round trips.
+#endif                      // A fragments in flight, in (step, row tile) items (LDS -> VGPR ring), WD > 0 only
 #ifndef ESMI_DEC_LN_SPREAD
 #define ESMI_DEC_LN_SPREAD 1
 #endif
@@ -381,9 +381,34 @@ __global__ __launch_bounds__(64 * NW, (DX2 <= 128 ? ESMI_DEC_WPS : NW / 4)) void
     // slice pointer of chunk c of the matrix at float offset `off` (planes: 8 steps x 2 planes x 64 lanes x 16 B per tile)
     auto wslice = [&](long off, int c) __attribute__((always_inline)) { return blob4 + (off >> 2) + (long)(c * (DX2 / 32) + ns * NTW) * 8 * 2 * 64 + lane; };
 
-    // Pipelined form: the A operand rows are already stored as the two f16 planes (row = [DX2 halves h1 | DX2 halves h2 | pad],
-    // written by the depthwise phase / the last LayerNorm), so an item = (16-channel step s, row tile mt) is two ds_read_b128 +
-    // 3*NTW MFMAs.  Software pipelined by hand: weight fragments of step s + WD and A fragments of item q + AD are requested
+    // The A operand rows already stored as the two f16 planes (row = [DX2 halves h1 | DX2 halves h2 | pad], written by the
+    // depthwise phase / the last LayerNorm): per (16-channel step, row tile) two ds_read_b128 + 3*NTW MFMAs.
+#if ESMI_DEC_WD == 0
+    auto gemm_prefetch = [&](long) __attribute__((always_inline)) {};
+    auto gemm_planes = [&](long off) __attribute__((always_inline)) {
+        const unsigned* a_base = reinterpret_cast<const unsigned*>(xs) + opaque_i((kDecPadRows + 32 * MT * mh + i) * LDSROW + 4 * h);
+#pragma unroll
+        for (int c = 0; c < KCH; ++c) {
+#pragma unroll
+            for (int k0 = 0; k0 < 16; k0 += KSUB) {
+                load_b(wslice(off, c), k0);
+#pragma unroll
+                for (int st = 0; st < KS16; ++st) {
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) {
+                        const unsigned* ap = a_base + 32 * mt * LDSROW + 64 * c + 4 * k0 + 8 * st;
+                        f16x2p a2;
+                        a2.h1 = *reinterpret_cast<const u32x4*>(ap);
+                        a2.h2 = *reinterpret_cast<const u32x4*>(ap + DX2 / 2);
+#pragma unroll
+                        for (int t = 0; t < NTW; ++t) acc[mt][t] = mfma32_split2_wx(bf[t][st][0], bf[t][st][1], a2, acc[mt][t]);
+                    }
+                }
+            }
+        }
+    };
+#else
+    // Hand-pipelined form (measured slower, see the knob): an item = (16-channel step s, row tile mt); weight fragments of step s + WD and A fragments of item q + AD are requested
     // while item q's MFMAs run (VGPR rings; scheduling fences keep hipcc from sinking the loads back to their first use --
     // left to itself it emits `ds_read; s_waitcnt lgkmcnt(0); v_mfma` per product and the matrix pipe idles through every LDS
     // and L2 round trip: measured 4.3-9k cycles per K loop against 1.5k of MFMA issue).
@@ -428,6 +453,7 @@ __global__ __launch_bounds__(64 * NW, (DX2 <= 128 ? ESMI_DEC_WPS : NW / 4)) void
             sched_fence();
         }
     };
+#endif
 #else
     f32x4 bf[NTW][KSUB];
     auto load_b = [&](const f32x4* wsl, int k0) __attribute__((always_inline)) {
@@ -479,16 +505,14 @@ __global__ __launch_bounds__(64 * NW, (DX2 <= 128 ? ESMI_DEC_WPS : NW / 4)) void
             const int col = ns * WCOLS + 32 * t + 4 * h;
             const float* bp = bias + opaque_i(col);
             float* base = xs + opaque_i((kDecPadRows + 32 * MT * mh + i) * LDSROW + col);
-            f32x4 bc[4];
-#pragma unroll
-            for (int g = 0; g < 4; ++g) bc[g] = *reinterpret_cast<const f32x4*>(bp + 8 * g) * kTanhExpScale;   // the exponent's 2 log2(e) goes into the bias and the scale of the fma
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
+                const f32x4 bc = *reinterpret_cast<const f32x4*>(bp + 8 * g) * kTanhExpScale;   // the exponent's 2 log2(e) goes into the bias and the scale of the fma
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) {
                     f32x4 v;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = tanh_fast_fma_f32(acc[mt][t][4 * g + e], WSI * kTanhExpScale, bc[g][e]);
+                    for (int e = 0; e < 4; ++e) v[e] = tanh_fast_fma_f32(acc[mt][t][4 * g + e], WSI * kTanhExpScale, bc[e]);
                     *reinterpret_cast<f32x4*>(base + 32 * mt * LDSROW + 8 * g) = v;
                 }
             }

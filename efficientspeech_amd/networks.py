@@ -823,7 +823,7 @@ class Phoneme2Mel(nn.Module):
         a.arena, a.arena_bytes = _ptr(st.arena), st.arena.numel()
         dec = self.decoder
         timed = False
-        if stage == 0 and dec.timing is not None:                     # bench.py: HIP events around the decoder launch only
+        if stage != 1 and dec.timing is not None:                     # bench.py: HIP events around the decoder launch only
             dec._launches += 1
             timed = dec._launches % dec.timing_every == 0
         if stage != 2 and (stage == 1 or st.L_out is None or timed):  # encoder side as its own call
