@@ -59,6 +59,21 @@ class DecoderShape(C.Structure):
     _fields_ = [(n, C.c_int) for n in ("d4", "dx2", "kernel", "n_blocks", "block_depth", "n_mel")]
 
 
+HIFIGAN_MAX_UP, HIFIGAN_MAX_KERNELS, HIFIGAN_MAX_RBCONV = 8, 8, 96
+
+
+class HifiGanWeights(C.Structure):
+    _fields_ = [("pre_w", fp), ("pre_b", fp), ("up_w", fp * HIFIGAN_MAX_UP), ("up_b", fp * HIFIGAN_MAX_UP),
+                ("rb_w1", fp * HIFIGAN_MAX_RBCONV), ("rb_b1", fp * HIFIGAN_MAX_RBCONV), ("rb_w2", fp * HIFIGAN_MAX_RBCONV),
+                ("rb_b2", fp * HIFIGAN_MAX_RBCONV), ("post_w", fp), ("post_b", fp)]
+
+
+class HifiGanShape(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("n_mel", "initial_channel", "n_up", "n_kernels", "resblock")] + \
+               [("up_rates", C.c_int * HIFIGAN_MAX_UP), ("up_kernels", C.c_int * HIFIGAN_MAX_UP),
+                ("rb_kernels", C.c_int * HIFIGAN_MAX_KERNELS), ("rb_dilations", C.c_int * (HIFIGAN_MAX_KERNELS * 3))]
+
+
 class ForwardArgs(C.Structure):
     """esmi_forward_args (include/esmi.h): the whole inference forward behind one call."""
     _fields_ = [(n, C.c_int) for n in ("B", "T", "depth", "dim", "fuse_kernel", "plan")] + \
@@ -104,7 +119,7 @@ EXPORTS = (
     "esmi_mask_rows_f32", "esmi_pack_bfrag_floats", "esmi_pack_bfrag_f32", "esmi_compose_merge_f32", "esmi_max_i32",
     "esmi_self_attention_workspace_bytes", "esmi_self_attention_f32", "esmi_mixffn_workspace_bytes", "esmi_mixffn_f32",
     "esmi_acoustic_decoder_f32", "esmi_bucket_embedding_f32", "esmi_split_weight_limit", "esmi_absmax_f32",
-    "esmi_forward_arena_bytes", "esmi_phoneme2mel_forward_f32",
+    "esmi_forward_arena_bytes", "esmi_phoneme2mel_forward_f32", "esmi_hifigan_workspace_bytes", "esmi_hifigan_generator_f32",
 )
 
 
@@ -157,6 +172,9 @@ def bind(lib):
     lib.esmi_forward_arena_bytes.argtypes = [P(ForwardArgs)]
     lib.esmi_forward_arena_bytes.restype = sz
     lib.esmi_phoneme2mel_forward_f32.argtypes = [P(ForwardArgs), i, fp]
+    lib.esmi_hifigan_workspace_bytes.argtypes = [P(HifiGanShape), i, i]
+    lib.esmi_hifigan_workspace_bytes.restype = sz
+    lib.esmi_hifigan_generator_f32.argtypes = [P(HifiGanWeights), P(HifiGanShape), fp, i, i, fp, fp, sz, fp]
     for name in EXPORTS:
         fn = getattr(lib, name)
         if fn.restype is C.c_int and name != "esmi_version":

@@ -45,7 +45,26 @@ struct ConvGemmP {
     const float* dot_b;
     float* dot_out;
     int dot_relu;
+    // HiFi-GAN generator (hifigan/models.py): dilated taps, pre-activation on the INPUT rows, accumulation into `out`
+    int dil;             // tap spacing (MODE_CONV): input row = t*stride + j*dil - pad; 0 is read as 1
+    int act_in;          // 1: A values pass through leaky_relu(a_scale * x, act_in_slope) as they are loaded
+    float act_in_slope;
+    float a_scale;       // 0 is read as 1
+    int accum;           // 1: out += value (same element, same thread: no race)
 };
+
+// input-side activation of the HiFi-GAN convolutions, applied to a loaded fragment
+__device__ __forceinline__ f32x4 conv_act_in(f32x4 v, const ConvGemmP& p) {
+    if (p.act_in) {
+        const float sc = p.a_scale != 0.0f ? p.a_scale : 1.0f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float x = v[e] * sc;
+            v[e] = x > 0.0f ? x : x * p.act_in_slope;
+        }
+    }
+    return v;
+}
 
 // Fused epilogue of the implicit-GEMM kernels, in the MFMA C/D layout (row = tile_row(r), col = n0 + 32*nt + (lane&31)):
 //   out = mask( post_relu( LN( act(acc * s + bias) + residual ) ) ), optional row-dot side output on the pre-LN value.
@@ -102,7 +121,10 @@ __device__ __forceinline__ void convgemm_epilogue(f32x16 (&acc)[NT], const ConvG
             float v = acc[nt][r];
             if (p.post_relu) v = fmaxf(v, 0.0f);
             if (masked) v = 0.0f;
-            if (cok[nt]) p.out[row * p.ldo + p.o_coff + col[nt]] = v;
+            if (cok[nt]) {
+                float* o = p.out + row * p.ldo + p.o_coff + col[nt];
+                *o = p.accum ? *o + v : v;
+            }
         }
     }
 }
@@ -129,10 +151,10 @@ __global__ __launch_bounds__(256) void convgemm_kernel(const ConvGemmP p) {
         int ti;
         bool ok = t_out < p.n_out;
         if (p.mode == MODE_CONV) {
-            ti = t_out * p.stride + j - p.pad;
+            ti = t_out * p.stride + j * (p.dil > 0 ? p.dil : 1) - p.pad;
             ok = ok && ti >= 0 && ti < p.n_in;
-        } else {  // ConvTranspose1d, no padding: out[n*stride + j] += in[n] * W[:, :, j]
-            const int q = t_out - j;
+        } else {  // ConvTranspose1d: out[n*stride + j - pad] += in[n] * W[:, :, j]
+            const int q = t_out + p.pad - j;
             ti = q / p.stride;
             ok = ok && q >= 0 && (q - ti * p.stride) == 0 && ti < p.n_in;
         }
@@ -177,7 +199,7 @@ __global__ __launch_bounds__(256) void convgemm_kernel(const ConvGemmP p) {
 #pragma unroll
             for (int g = 0; g < KG; ++g) {
                 const int c = 8 * (kc + g) + 4 * h;
-                av[g] = ok ? ld4(arow + c) : zero4();
+                av[g] = ok ? conv_act_in(ld4(arow + c), p) : zero4();
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) bv[g][nt] = wok[nt] ? ld4(wrow[nt] + c) : zero4();
             }
@@ -187,7 +209,7 @@ __global__ __launch_bounds__(256) void convgemm_kernel(const ConvGemmP p) {
         for (; kc < kcs; kc += 2) {   // 8 or 16 channels left
             const int c = 8 * kc + 4 * h;
             const bool two = kc + 1 < kcs;
-            const f32x4 a0 = ok ? ld4(arow + c) : zero4(), a1 = (ok && two) ? ld4(arow + c + 8) : zero4();
+            const f32x4 a0 = ok ? conv_act_in(ld4(arow + c), p) : zero4(), a1 = (ok && two) ? conv_act_in(ld4(arow + c + 8), p) : zero4();
             f32x4 b0[NT], b1[NT];
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
@@ -202,7 +224,7 @@ __global__ __launch_bounds__(256) void convgemm_kernel(const ConvGemmP p) {
 #pragma unroll
             for (int g = 0; g < KG; ++g) {
                 const int c = 8 * (kc + g) + 4 * h;
-                av[g] = ok ? ld4(arow + c) : zero4();
+                av[g] = ok ? conv_act_in(ld4(arow + c), p) : zero4();
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) bv[g][nt] = wok[nt] ? ld4(wrow[nt] + c) : zero4();
             }
@@ -217,7 +239,7 @@ __global__ __launch_bounds__(256) void convgemm_kernel(const ConvGemmP p) {
         }
         for (; kc < kcs; ++kc) {
             const int c = 8 * kc + 4 * h;
-            const f32x4 av = ok ? ld4(arow + c) : zero4();
+            const f32x4 av = ok ? conv_act_in(ld4(arow + c), p) : zero4();
             f32x4 bv[NT];
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) bv[nt] = wok[nt] ? ld4(wrow[nt] + c) : zero4();
@@ -269,13 +291,13 @@ __global__ __launch_bounds__(256, 2) void convgemm_lds_kernel(const ConvGemmP p)
     f16x2p a_cur[2];
     auto fetch = [&](int it) __attribute__((always_inline)) {   // global -> registers: A rows of this wave, W rows of the workgroup
         const int j = it / kchunks, c = (it - j * kchunks) << 5;
-        const int ti = t_out + j - p.pad;
+        const int ti = t_out + j * (p.dil > 0 ? p.dil : 1) - p.pad;
         const bool ok = t_out < p.n_out && ti >= 0 && ti < p.n_in;
         const float* arow = p.A + ((long)b * p.n_in + (ok ? ti : 0)) * p.lda + p.a_coff + c + 8 * h;
 #pragma unroll
         for (int st = 0; st < 2; ++st) {
-            a_nxt[st][0] = ok ? ld4(arow + 16 * st) : zero4();
-            a_nxt[st][1] = ok ? ld4(arow + 16 * st + 4) : zero4();
+            a_nxt[st][0] = ok ? conv_act_in(ld4(arow + 16 * st), p) : zero4();
+            a_nxt[st][1] = ok ? conv_act_in(ld4(arow + 16 * st + 4), p) : zero4();
         }
         const float* wj = p.W + (long)j * p.c_out * p.c_in + c;
 #pragma unroll

@@ -860,6 +860,121 @@ int esmi_mel_decoder_f32(const float* blob, const esmi_decoder_shape* s, const f
     return launch_status();
 }
 
+// ------------------------------------------------------------------ HiFi-GAN generator
+namespace {
+struct HgPlan {
+    size_t buf;      // bytes of one activation buffer (the largest B * N * C of the chain)
+    long n_last;     // samples per utterance
+};
+int hg_plan(const esmi_hifigan_shape* s, int B, int L, HgPlan* o) {
+    if (!s || B <= 0 || L <= 0 || s->n_up < 1 || s->n_up > ESMI_HIFIGAN_MAX_UP || s->n_kernels < 1 ||
+        s->n_kernels > ESMI_HIFIGAN_MAX_KERNELS || (s->resblock != 1 && s->resblock != 2) || s->n_mel <= 0 || (s->n_mel & 7))
+        return ESMI_ERR_ARG;
+    if (s->n_up * s->n_kernels * 3 > ESMI_HIFIGAN_MAX_RBCONV) return ESMI_ERR_UNSUPPORTED;
+    long n = L;
+    int c = s->initial_channel;
+    size_t mx = (size_t)B * n * c;
+    for (int i = 0; i < s->n_up; ++i) {
+        if (s->up_rates[i] < 1 || s->up_kernels[i] < s->up_rates[i] || ((s->up_kernels[i] - s->up_rates[i]) & 1) || (c & 15)) return ESMI_ERR_UNSUPPORTED;
+        n *= s->up_rates[i];
+        c /= 2;
+        const size_t e = (size_t)B * n * c;
+        mx = e > mx ? e : mx;
+    }
+    if (c & 7) return ESMI_ERR_UNSUPPORTED;   // implicit-GEMM k-steps are 8 channels
+    o->buf = align256(mx * 4);
+    o->n_last = n;
+    return ESMI_OK;
+}
+}  // namespace
+
+size_t esmi_hifigan_workspace_bytes(const esmi_hifigan_shape* s, int B, int L) {
+    HgPlan o;
+    return hg_plan(s, B, L, &o) == ESMI_OK ? 4 * o.buf : 0;
+}
+
+int esmi_hifigan_generator_f32(const esmi_hifigan_weights* w, const esmi_hifigan_shape* s, const float* mel, int B, int L,
+                               float* wav, void* workspace, size_t workspace_bytes, esmi_stream_t stream) {
+    HgPlan o;
+    int rc = hg_plan(s, B, L, &o);
+    if (rc) return rc;
+    if (!w || !mel || !wav || !workspace) return ESMI_ERR_ARG;
+    if (workspace_bytes < 4 * o.buf) return ESMI_ERR_WORKSPACE;
+    hipStream_t st = S(stream);
+    float* bufs[4];
+    for (int q = 0; q < 4; ++q) bufs[q] = reinterpret_cast<float*>(static_cast<char*>(workspace) + q * o.buf);
+    float *x = bufs[0], *y = bufs[1], *r = bufs[2], *t = bufs[3];   // x: stage input / sum over the ResBlocks; y: upsampled; r, t: ResBlock state
+    const float slope = 0.1f;                                       // LRELU_SLOPE, hifigan/models.py:17
+    long n = L;
+    int c = s->initial_channel;
+    ConvGemmP p = conv_defaults();   // conv_pre, models.py:112: Conv1d(n_mel, C0, 7, padding 3)
+    p.B = B; p.n_in = L; p.c_in = s->n_mel; p.n_out = L; p.c_out = c; p.k = 7; p.pad = 3;
+    p.A = mel; p.lda = s->n_mel; p.W = w->pre_w; p.bias = w->pre_b; p.out = x; p.ldo = c;
+    if (!p.W || !p.bias) return ESMI_ERR_ARG;
+    if ((rc = launch_convgemm(p, st))) return rc;
+    float in_scale = 1.0f;           // the mean over the ResBlocks of the previous stage, folded into the next input activation
+    for (int i = 0; i < s->n_up; ++i) {
+        const int u = s->up_rates[i], k = s->up_kernels[i], co = c / 2;
+        const long no = n * u;
+        // x = ups[i](leaky_relu(x, 0.1)), models.py:114-115: ConvTranspose1d(c, c/2, k, u, padding (k-u)//2)
+        p = conv_defaults();
+        p.mode = MODE_CONVT; p.k = k; p.stride = u; p.pad = (k - u) / 2;
+        p.B = B; p.n_in = (int)n; p.c_in = c; p.n_out = (int)no; p.c_out = co;
+        p.A = x; p.lda = c; p.W = w->up_w[i]; p.bias = w->up_b[i]; p.out = y; p.ldo = co;
+        p.act_in = 1; p.act_in_slope = slope; p.a_scale = in_scale;
+        if (!p.W || !p.bias) return ESMI_ERR_ARG;
+        if ((rc = launch_convgemm(p, st))) return rc;
+        n = no; c = co;
+        for (int j = 0; j < s->n_kernels; ++j) {   // xs += resblocks[i*num_kernels + j](x), models.py:116-121
+            const int rb = i * s->n_kernels + j, kk = s->rb_kernels[j];
+            const int nconv = s->resblock == 1 ? 3 : 2;
+            const float* cur = y;                   // the ResBlock's running x (first iteration: the stage input itself)
+            for (int m = 0; m < nconv; ++m) {
+                const int d = s->rb_dilations[j * 3 + m];
+                const bool last = m + 1 == nconv;
+                float* dst = last ? x : (cur == r ? t : r);   // last iteration: straight into the stage sum (accumulated for j > 0)
+                if (s->resblock == 1) {
+                    // xt = c1(leaky_relu(x)); xt = c2(leaky_relu(xt)); x = xt + x   (models.py:49-54)
+                    // buffers: cur in {y, r}; c1 writes t; c2 reads t, adds cur, writes dst in {r (in place when cur == r), x}
+                    p = conv_defaults();
+                    p.B = B; p.n_in = (int)n; p.c_in = c; p.n_out = (int)n; p.c_out = c; p.k = kk; p.dil = d; p.pad = (kk * d - d) / 2;
+                    p.A = cur; p.lda = c; p.W = w->rb_w1[rb * 3 + m]; p.bias = w->rb_b1[rb * 3 + m]; p.out = t; p.ldo = c;
+                    p.act_in = 1; p.act_in_slope = slope;
+                    if (!p.W || !p.bias) return ESMI_ERR_ARG;
+                    if ((rc = launch_convgemm(p, st))) return rc;
+                    p = conv_defaults();
+                    p.B = B; p.n_in = (int)n; p.c_in = c; p.n_out = (int)n; p.c_out = c; p.k = kk; p.dil = 1; p.pad = (kk - 1) / 2;
+                    p.A = t; p.lda = c; p.W = w->rb_w2[rb * 3 + m]; p.bias = w->rb_b2[rb * 3 + m];
+                    p.res = cur; p.ldr = c;
+                    p.out = last ? x : r; p.ldo = c; p.accum = last && j > 0;
+                    p.act_in = 1; p.act_in_slope = slope;
+                    if (!p.W || !p.bias) return ESMI_ERR_ARG;
+                    if ((rc = launch_convgemm(p, st))) return rc;
+                    cur = r;
+                } else {
+                    // xt = c(leaky_relu(x)); x = xt + x   (models.py:75-79): the conv reads neighbours of x, so not in place
+                    p = conv_defaults();
+                    p.B = B; p.n_in = (int)n; p.c_in = c; p.n_out = (int)n; p.c_out = c; p.k = kk; p.dil = d; p.pad = (kk * d - d) / 2;
+                    p.A = cur; p.lda = c; p.W = w->rb_w1[rb * 3 + m]; p.bias = w->rb_b1[rb * 3 + m];
+                    p.res = cur; p.ldr = c; p.out = dst; p.ldo = c; p.accum = last && j > 0;
+                    p.act_in = 1; p.act_in_slope = slope;
+                    if (!p.W || !p.bias) return ESMI_ERR_ARG;
+                    if ((rc = launch_convgemm(p, st))) return rc;
+                    cur = dst;
+                }
+            }
+        }
+        in_scale = 1.0f / (float)s->n_kernels;   // x = xs / num_kernels (models.py:122), applied where x is read next
+    }
+    // x = tanh(conv_post(leaky_relu(x))), models.py:123-125 (F.leaky_relu default slope 0.01)
+    p = conv_defaults();
+    p.B = B; p.n_in = (int)n; p.c_in = c; p.n_out = (int)n; p.c_out = 1; p.k = 7; p.pad = 3;
+    p.A = x; p.lda = c; p.W = w->post_w; p.bias = w->post_b; p.out = wav; p.ldo = 1; p.act = ACT_TANH;
+    p.act_in = 1; p.act_in_slope = 0.01f; p.a_scale = in_scale;
+    if (!p.W || !p.bias) return ESMI_ERR_ARG;
+    return launch_convgemm(p, st);
+}
+
 // ------------------------------------------------------------------ whole forward behind one call
 namespace {
 struct FwdArena {

@@ -373,6 +373,41 @@ size_t esmi_forward_arena_bytes(const esmi_forward_args* a);
  * on the arena a stage-1 call filled (same args) -- lets a multi-GPU caller put its MAX all-reduce of lmax_dev in between. */
 int esmi_phoneme2mel_forward_f32(const esmi_forward_args* a, int stage, esmi_stream_t stream);
 
+/* ------------------------------------------------------------------ HiFi-GAN generator (the vocoder behind model.py:161-162)
+ * hifigan/models.py:84-135 Generator.forward with ResBlock1 (:20-58) or ResBlock2 (:61-82), weights as after
+ * remove_weight_norm():  x = conv_pre(mel); per stage i: x = ConvTranspose1d_i(leaky_relu(x, 0.1)), x = mean_j ResBlock_ij(x);
+ * wav = tanh(conv_post(leaky_relu(x, 0.01))).  Channels-last throughout: mel (B, L, n_mel) is the acoustic model's own output
+ * layout (the reference transposes it to channels-first for its Conv1d; nothing is transposed here), wav (B, L * prod(rates)).
+ * Every convolution is one implicit-GEMM launch (convgemm.h) with the leaky_relu applied to the input rows as they are
+ * loaded, the residual add / the sum over the ResBlocks of a stage folded into the epilogue and the 1/num_kernels of the mean
+ * folded into the next convolution's input scale (leaky_relu is positively homogeneous).
+ * All conv weights tap-major (k, Cout, Cin): esmi_pack_conv_weight_f32 / esmi_pack_convT_weight_f32 of the checkpoint tensors. */
+#define ESMI_HIFIGAN_MAX_UP 8
+#define ESMI_HIFIGAN_MAX_KERNELS 8
+#define ESMI_HIFIGAN_MAX_RBCONV 96 /* (resblock index n = stage * n_kernels + j) * 3 + conv index m */
+typedef struct esmi_hifigan_weights {
+    const float* pre_w;  /* <- conv_pre.weight (C0, n_mel, 7) */
+    const float* pre_b;
+    const float* up_w[ESMI_HIFIGAN_MAX_UP];  /* <- ups.{i}.weight (Cin, Cout, k) via esmi_pack_convT_weight_f32 */
+    const float* up_b[ESMI_HIFIGAN_MAX_UP];
+    const float* rb_w1[ESMI_HIFIGAN_MAX_RBCONV]; /* <- resblocks.{n}.convs1.{m} (ResBlock1) / resblocks.{n}.convs.{m} (ResBlock2) */
+    const float* rb_b1[ESMI_HIFIGAN_MAX_RBCONV];
+    const float* rb_w2[ESMI_HIFIGAN_MAX_RBCONV]; /* <- resblocks.{n}.convs2.{m} (ResBlock1 only) */
+    const float* rb_b2[ESMI_HIFIGAN_MAX_RBCONV];
+    const float* post_w; /* <- conv_post.weight (1, C_last, 7) */
+    const float* post_b;
+} esmi_hifigan_weights;
+typedef struct esmi_hifigan_shape {
+    int n_mel, initial_channel, n_up, n_kernels;
+    int resblock;                                  /* 1 or 2 */
+    int up_rates[ESMI_HIFIGAN_MAX_UP], up_kernels[ESMI_HIFIGAN_MAX_UP];
+    int rb_kernels[ESMI_HIFIGAN_MAX_KERNELS];
+    int rb_dilations[ESMI_HIFIGAN_MAX_KERNELS * 3]; /* [j*3 + m] */
+} esmi_hifigan_shape;
+size_t esmi_hifigan_workspace_bytes(const esmi_hifigan_shape* s, int B, int L);
+int esmi_hifigan_generator_f32(const esmi_hifigan_weights* w, const esmi_hifigan_shape* s, const float* mel, int B, int L,
+                               float* wav, void* workspace, size_t workspace_bytes, esmi_stream_t stream);
+
 /* x.masked_fill(mask[:, :, None], 0) on (rows, C) fp32 -- used by the module-level API when the
  * decoder is called stand-alone.                                                              */
 int esmi_mask_rows_f32(float* x, const uint8_t* mask, int64_t rows, int C, esmi_stream_t stream);

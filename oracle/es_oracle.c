@@ -614,6 +614,132 @@ void eso_mask_mel(int B, int L, int n_mel, const uint8_t* omask, float* mel) {
 }
 
 /* utils/tools.py:43-51 get_mask_from_lengths: mask[b][t] = t >= lengths[b] */
+/* ---------------------------------------------------------------- HiFi-GAN generator
+ * hifigan/models.py:84-135 (Generator.forward) with ResBlock1 (:20-58) / ResBlock2 (:61-82), weights as after
+ * remove_weight_norm() (model.py:44: `weight`, `bias` per conv).  Channels-last restatement: x (B, L, C).
+ *   x = conv_pre(mel); for each upsample stage i: x = ConvTranspose1d_i(leaky_relu(x, 0.1));
+ *       x = mean_j ResBlock_{i,j}(x);   x = tanh(conv_post(leaky_relu(x)))   [the last leaky_relu uses the default slope 0.01]
+ * Conv1d: weight (Cout,Cin,k), dilation d, padding (k*d - d)/2 (get_padding, :14-15).
+ * ConvTranspose1d: weight (Cin,Cout,k), stride u, padding (k-u)//2 -> length L*u.                                        */
+typedef struct {
+    int n_mel, initial_channel, n_up, n_kernels, resblock; /* resblock: 1 or 2 */
+    int up_rates[8], up_kernels[8];
+    int rb_kernels[8], rb_dilations[8][3];
+} eso_hifigan_cfg;
+
+static void lrelu_copy(const float* x, long n, float slope, float* y) {
+#pragma omp parallel for schedule(static)
+    for (long i = 0; i < n; ++i) y[i] = x[i] > 0 ? x[i] : x[i] * slope;
+}
+
+static void conv1d_dil_cl(const float* x, int B, int N, int Cin, const float* Wt, const float* bias, int Cout, int k, int dil,
+                          float* y) {
+    const int pad = (k * dil - dil) / 2;
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int b = 0; b < B; ++b)
+        for (int t = 0; t < N; ++t) {
+            float* yr = y + ((long)b * N + t) * Cout;
+            for (int co = 0; co < Cout; ++co) {
+                acc_t s = (acc_t)bias[co];
+                for (int j = 0; j < k; ++j) {
+                    const int ti = t + j * dil - pad;
+                    if (ti < 0 || ti >= N) continue;
+                    const float* xr = x + ((long)b * N + ti) * Cin;
+                    const float* wr = Wt + (long)co * Cin * k + j;
+                    for (int ci = 0; ci < Cin; ++ci) s += (acc_t)xr[ci] * (acc_t)wr[(long)ci * k];
+                }
+                yr[co] = (float)s;
+            }
+        }
+}
+
+/* y[b][n*u + j - pad][co] += x[b][n][ci] * W[ci][co][j], gathered per output position */
+static void convT1d_cl(const float* x, int B, int N, int Cin, const float* Wt, const float* bias, int Cout, int k, int u, float* y) {
+    const int pad = (k - u) / 2, Nout = (N - 1) * u - 2 * pad + k;
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int b = 0; b < B; ++b)
+        for (int t = 0; t < Nout; ++t) {
+            float* yr = y + ((long)b * Nout + t) * Cout;
+            for (int co = 0; co < Cout; ++co) {
+                acc_t s = (acc_t)bias[co];
+                for (int j = 0; j < k; ++j) {
+                    const int q = t + pad - j;
+                    if (q < 0 || q % u) continue;
+                    const int n = q / u;
+                    if (n >= N) continue;
+                    const float* xr = x + ((long)b * N + n) * Cin;
+                    for (int ci = 0; ci < Cin; ++ci) s += (acc_t)xr[ci] * (acc_t)Wt[((long)ci * Cout + co) * k + j];
+                }
+                yr[co] = (float)s;
+            }
+        }
+}
+
+int eso_hifigan(const eso_hifigan_cfg* c, const eso_weights* w, int B, int L, const float* mel, float* wav) {
+    int err = ESO_OK;
+    if (c->n_up < 1 || c->n_up > 8 || c->n_kernels < 1 || c->n_kernels > 8 || B < 1 || L < 1) return ESO_ERR_ARG;
+    long N = L;
+    int C = c->initial_channel;
+    float* x = (float*)malloc(sizeof(float) * (size_t)B * N * C);
+    conv1d_dil_cl(mel, B, L, c->n_mel, W(w, "conv_pre.weight", 0, 0, &err), W(w, "conv_pre.bias", 0, 0, &err), C, 7, 1, x);
+    if (err) { free(x); return err; }
+    for (int i = 0; i < c->n_up; ++i) {
+        const int u = c->up_rates[i], k = c->up_kernels[i], Co = C / 2;
+        const long No = N * u;
+        float* a = (float*)malloc(sizeof(float) * (size_t)B * N * C);
+        lrelu_copy(x, (long)B * N * C, 0.1f, a);
+        float* y = (float*)malloc(sizeof(float) * (size_t)B * No * Co);
+        convT1d_cl(a, B, (int)N, C, W(w, "ups.%d.weight", i, 0, &err), W(w, "ups.%d.bias", i, 0, &err), Co, k, u, y);
+        free(a); free(x);
+        if (err) { free(y); return err; }
+        N = No; C = Co;
+        const long n = (long)B * N * C;
+        float* xs = (float*)calloc((size_t)n, sizeof(float));
+        float* r = (float*)malloc(sizeof(float) * (size_t)n);
+        float* t1 = (float*)malloc(sizeof(float) * (size_t)n);
+        float* t2 = (float*)malloc(sizeof(float) * (size_t)n);
+        for (int j = 0; j < c->n_kernels; ++j) {
+            const int rb = i * c->n_kernels + j, kk = c->rb_kernels[j];
+            memcpy(r, y, sizeof(float) * (size_t)n);
+            const int nconv = c->resblock == 1 ? 3 : 2;
+            for (int m = 0; m < nconv; ++m) {
+                char f1[96], f2[96];
+                lrelu_copy(r, n, 0.1f, t1);
+                if (c->resblock == 1) {
+                    snprintf(f1, sizeof f1, "resblocks.%d.convs1.%d.weight", rb, m);
+                    snprintf(f2, sizeof f2, "resblocks.%d.convs1.%d.bias", rb, m);
+                    conv1d_dil_cl(t1, B, (int)N, C, W(w, f1, 0, 0, &err), W(w, f2, 0, 0, &err), C, kk, c->rb_dilations[j][m], t2);
+                    lrelu_copy(t2, n, 0.1f, t1);
+                    snprintf(f1, sizeof f1, "resblocks.%d.convs2.%d.weight", rb, m);
+                    snprintf(f2, sizeof f2, "resblocks.%d.convs2.%d.bias", rb, m);
+                    conv1d_dil_cl(t1, B, (int)N, C, W(w, f1, 0, 0, &err), W(w, f2, 0, 0, &err), C, kk, 1, t2);
+                } else {
+                    snprintf(f1, sizeof f1, "resblocks.%d.convs.%d.weight", rb, m);
+                    snprintf(f2, sizeof f2, "resblocks.%d.convs.%d.bias", rb, m);
+                    conv1d_dil_cl(t1, B, (int)N, C, W(w, f1, 0, 0, &err), W(w, f2, 0, 0, &err), C, kk, c->rb_dilations[j][m], t2);
+                }
+                if (err) break;
+                for (long e = 0; e < n; ++e) r[e] = t2[e] + r[e];          /* x = xt + x */
+            }
+            for (long e = 0; e < n; ++e) xs[e] += r[e];
+        }
+        for (long e = 0; e < n; ++e) xs[e] /= (float)c->n_kernels;       /* x = xs / num_kernels */
+        free(r); free(t1); free(t2); free(y);
+        x = xs;
+        if (err) { free(x); return err; }
+    }
+    {
+        const long n = (long)B * N * C;
+        float* a = (float*)malloc(sizeof(float) * (size_t)n);
+        lrelu_copy(x, n, 0.01f, a);                                        /* F.leaky_relu(x): default slope */
+        conv1d_dil_cl(a, B, (int)N, C, W(w, "conv_post.weight", 0, 0, &err), W(w, "conv_post.bias", 0, 0, &err), 1, 7, 1, wav);
+        free(a); free(x);
+        if (err) return err;
+        for (long e = 0; e < (long)B * N; ++e) wav[e] = (float)tanh((double)wav[e]);
+    }
+    return ESO_OK;
+}
+
 void eso_mask_from_lengths(int B, int T, const int32_t* lengths, uint8_t* mask) {
     for (int b = 0; b < B; ++b)
         for (int t = 0; t < T; ++t) mask[b * T + t] = (uint8_t)(t >= lengths[b]);

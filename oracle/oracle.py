@@ -193,6 +193,33 @@ def acoustic(cfg, w: Weights, which, fused):
     return pred, feats
 
 
+class _HgCfg(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("n_mel", "initial_channel", "n_up", "n_kernels", "resblock")] + \
+               [("up_rates", C.c_int * 8), ("up_kernels", C.c_int * 8), ("rb_kernels", C.c_int * 8),
+                ("rb_dilations", (C.c_int * 3) * 8)]
+
+
+def hifigan(h, w: Weights, mel):
+    """HiFi-GAN Generator.forward (hifigan/models.py:84-135) on a channels-last mel (B, L, n_mel) -> wav (B, L * hop).
+    `h`: efficientspeech_amd.hifigan.HifiGanConfig; `w`: Weights over the remove_weight_norm()-form state dict."""
+    mel = _f(mel)
+    B, L, nm = mel.shape
+    c = _HgCfg()
+    c.n_mel, c.initial_channel, c.n_up, c.n_kernels = nm, h.upsample_initial_channel, len(h.upsample_rates), len(h.resblock_kernel_sizes)
+    c.resblock = 1 if str(h.resblock) == "1" else 2
+    for i, (u, k) in enumerate(zip(h.upsample_rates, h.upsample_kernel_sizes)):
+        c.up_rates[i], c.up_kernels[i] = u, k
+    for j, (k, d) in enumerate(zip(h.resblock_kernel_sizes, h.resblock_dilation_sizes)):
+        c.rb_kernels[j] = k
+        for m, dd in enumerate(d):
+            c.rb_dilations[j][m] = dd
+    wav = np.empty((B, L * int(np.prod(h.upsample_rates))), np.float32)
+    L_ = lib()
+    L_.eso_hifigan.restype = C.c_int
+    _chk(L_.eso_hifigan(C.byref(c), C.byref(w.c), B, L, _p(mel), _p(wav)), "hifigan")
+    return wav
+
+
 def mask_from_lengths(lengths, T):
     lengths = np.ascontiguousarray(lengths, dtype=np.int32)
     m = np.empty((len(lengths), T), np.uint8)

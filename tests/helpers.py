@@ -246,3 +246,20 @@ def check_wrapper_and_scheduler(device):
             assert mel_i.shape == (n, 80) and dur_i.shape == (lens[i],)
             if n:
                 assert np.abs(mel_i.cpu().numpy() - ob.mel[r, :n]).max() < MEL_TOL
+
+
+def check_hifigan_golden(path, device):
+    """One reference-generated HiFi-GAN fixture (tools/gen_golden_hifigan.py) through the module mirror / C-ABI."""
+    from efficientspeech_amd.hifigan import HIFIGAN_CONFIGS, Generator, synth_hifigan_state_dict
+    g = np.load(path)
+    h = HIFIGAN_CONFIGS[str(g["config"])]
+    voc = Generator(h)
+    voc.load_state_dict({k: torch.from_numpy(v) for k, v in synth_hifigan_state_dict(h, 1234).items()}, strict=True)
+    voc = voc.to(device).eval()
+    mel = torch.from_numpy(g["mel"]).to(device)                    # (B, L, 80) channels-last, as the acoustic model emits it
+    with torch.no_grad():
+        wav = voc(mel.transpose(1, 2))                             # the reference's calling convention: (B, 80, L)
+    assert wav.shape == (mel.shape[0], 1, mel.shape[1] * h.hop)
+    err = float(np.abs(wav[:, 0].cpu().numpy() - g["wav"]).max())
+    assert err < 5e-5, err
+    return err

@@ -17,7 +17,8 @@ from oracle import oracle
 from tests import helpers as H
 
 pytestmark = pytest.mark.gpu
-GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")))
+GOLDEN = sorted(p for p in glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz"))
+                if not os.path.basename(p).startswith("hifigan_"))     # acoustic-model fixtures (the vocoder has its own tests)
 DEV = "cuda:0"
 
 
@@ -533,3 +534,41 @@ def test_long_sequences_beyond_256(name, B, T, lens, nets):
 def test_model_wrapper_and_bucket_scheduler():
     """model.py-shaped wrapper on a padded B > 1 batch and a B == 1 call, and the length-bucketed scheduler, vs the oracle."""
     H.check_wrapper_and_scheduler(DEV)
+
+
+HIFIGAN_GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "hifigan_*.npz")))
+
+
+@pytest.mark.parametrize("path", HIFIGAN_GOLDEN, ids=[os.path.basename(p)[:-4] for p in HIFIGAN_GOLDEN])
+def test_hifigan_generator_golden(path):
+    """HiFi-GAN generator v1 / v2 / v3 against the waveforms of the reference's hifigan.Generator."""
+    H.check_hifigan_golden(path, DEV)
+
+
+def test_hifigan_end_to_end_vs_oracle():
+    """phonemes -> mel -> waveform through the model.py-shaped wrapper with the HIP vocoder plugged in as `.hifigan`
+    (model.py:159-164), against oracle acoustic model + oracle vocoder; a batch large enough for several row tiles."""
+    from efficientspeech_amd import EfficientSpeech
+    from efficientspeech_amd.hifigan import HIFIGAN_CONFIGS, Generator, synth_hifigan_state_dict
+    from efficientspeech_amd.synth import synth_state_dict
+    cfg, h = CONFIGS["tiny"], HIFIGAN_CONFIGS["v2"]
+    sd, vsd = synth_state_dict(cfg, 1234), synth_hifigan_state_dict(h, 1234)
+    voc = Generator(h)
+    model = EfficientSpeech.from_config("tiny", hifigan=voc)
+    model.phoneme2mel.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    voc.load_state_dict({k: torch.from_numpy(v) for k, v in vsd.items()}, strict=True)
+    model = model.to(DEV).eval()
+    B, T = 3, 40
+    ids, mask = synth_phonemes(B, T, 12, [40, 29, 11])
+    dur = np.random.default_rng(3).integers(1, 5, size=(B, T)).astype(np.int32)
+    x = {"phoneme": torch.from_numpy(ids).to(DEV), "phoneme_mask": torch.from_numpy(mask).to(DEV),
+         "duration_forced": torch.from_numpy(dur).to(DEV)}
+    with torch.no_grad():
+        enc = model.phoneme2mel.encoder._encode(x)
+        wav, mel_len, _ = model(x)
+    o = oracle.phoneme2mel(cfg, oracle.Weights(sd), ids, mask, pitch=enc["pitch"][..., 0].cpu().numpy(),
+                           energy=enc["energy"][..., 0].cpu().numpy(), duration=dur)
+    ref = oracle.hifigan(h, oracle.Weights(vsd), o.mel)
+    assert wav.shape == ref.shape == (B, o.mel.shape[1] * 256)
+    assert np.array_equal(mel_len.cpu().numpy(), o.mel_len)
+    assert np.abs(wav.cpu().numpy() - ref).max() < 2e-4

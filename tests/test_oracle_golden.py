@@ -16,7 +16,8 @@ from efficientspeech_amd.config import CONFIGS
 from efficientspeech_amd.synth import synth_state_dict
 from oracle import oracle
 
-GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")))
+GOLDEN = sorted(p for p in glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz"))
+                if not os.path.basename(p).startswith("hifigan_"))     # acoustic-model fixtures (the vocoder has its own tests)
 TOL = 2e-5
 
 
@@ -99,3 +100,40 @@ def test_length_regulator_rule():
 def test_mask_from_lengths():
     m = oracle.mask_from_lengths([3, 0, 5], 5)
     assert m.tolist() == [[False] * 3 + [True] * 2, [True] * 5, [False] * 5]
+
+
+# ---------------------------------------------------------------- HiFi-GAN generator
+HIFIGAN_GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "hifigan_*.npz")))
+
+
+@pytest.mark.parametrize("path", HIFIGAN_GOLDEN, ids=[os.path.basename(p)[:-4] for p in HIFIGAN_GOLDEN])
+def test_hifigan_oracle_matches_reference_vectors(path):
+    """oracle.hifigan (oracle/es_oracle.c eso_hifigan) vs the waveform the reference's hifigan.Generator produced
+    (tools/gen_golden_hifigan.py) on the same seeded weights and mel."""
+    from efficientspeech_amd.hifigan import HIFIGAN_CONFIGS, synth_hifigan_state_dict
+    g = np.load(path)
+    h = HIFIGAN_CONFIGS[str(g["config"])]
+    w = oracle.Weights(synth_hifigan_state_dict(h, 1234))
+    wav = oracle.hifigan(h, w, g["mel"])
+    assert wav.shape == g["wav"].shape
+    assert np.abs(wav - g["wav"]).max() < 2e-5, np.abs(wav - g["wav"]).max()
+
+
+def test_hifigan_weight_norm_folding_and_key_table():
+    """fold_weight_norm(g, v) == the plain weight the fixture was generated with; the module mirror's keys/shapes are the
+    spec table (which gen_golden_hifigan.py asserted against the reference's Generator)."""
+    import torch
+    from efficientspeech_amd.hifigan import (HIFIGAN_CONFIGS, Generator, fold_weight_norm, hifigan_state_dict_spec,
+                                             synth_hifigan_state_dict)
+    g = np.load([p for p in HIFIGAN_GOLDEN if "hifigan_v2" in p][0])
+    sd = synth_hifigan_state_dict(HIFIGAN_CONFIGS["v2"], 1234)
+    wn = {k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("wn.")}
+    folded = fold_weight_norm(wn)
+    assert sorted(folded) == ["conv_post.bias", "conv_post.weight", "ups.3.bias", "ups.3.weight"]
+    for k, v in folded.items():
+        np.testing.assert_allclose(v.numpy(), sd[k], rtol=2e-6, atol=1e-7)
+    for name, h in HIFIGAN_CONFIGS.items():
+        net = Generator(h)
+        assert sorted((k, tuple(v.shape)) for k, v in net.state_dict().items()) == sorted(hifigan_state_dict_spec(h))
+        net.load_state_dict({k: torch.from_numpy(v) for k, v in synth_hifigan_state_dict(h, 3).items()}, strict=True)
+    assert sum(p.numel() for p in Generator(HIFIGAN_CONFIGS["v2"]).parameters()) == 925_985   # = the reference LJ_V2/generator_v2 checkpoint (weight_v + bias tensors), "926k"

@@ -288,3 +288,10 @@ def test_simulated_long_sequence_beyond_256_keys(nets):
 def test_simulated_model_wrapper_and_bucket_scheduler():
     with use_sim():
         H.check_wrapper_and_scheduler("cpu")
+
+
+@pytest.mark.parametrize("fixture", ["hifigan_v2_b2_l24.npz", "hifigan_v3_b1_l17.npz"])
+def test_simulated_hifigan_generator_matches_reference(fixture):
+    """HiFi-GAN generator: ResBlock1 (v2) and ResBlock2 (v3) chains through esmi_hifigan_generator_f32."""
+    with use_sim():
+        H.check_hifigan_golden(os.path.join(GOLD, fixture), "cpu")
