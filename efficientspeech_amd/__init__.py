@@ -8,7 +8,8 @@ from .networks import (Encoder, Fuse, AcousticDecoder, FeatureUpsampler, MelDeco
                        SelfAttention, MixFFN, get_mask_from_lengths)
 from .model import EfficientSpeech, build_phoneme2mel, from_lightning_checkpoint, load_numpy_state_dict
 from .scheduler import BucketedSynthesizer
+from .hifigan import Generator as HifiGanGenerator, HifiGanConfig, HIFIGAN_CONFIGS, get_hifigan
 
 __all__ = ["PhonemeEncoder", "MelDecoder", "Phoneme2Mel", "Encoder", "Fuse", "AcousticDecoder", "FeatureUpsampler",
            "SelfAttention", "MixFFN", "get_mask_from_lengths", "CONFIGS", "ESConfig", "build_phoneme2mel",
-           "load_numpy_state_dict", "EfficientSpeech", "from_lightning_checkpoint", "BucketedSynthesizer"]
+           "load_numpy_state_dict", "EfficientSpeech", "from_lightning_checkpoint", "BucketedSynthesizer", "HifiGanGenerator", "HifiGanConfig", "HIFIGAN_CONFIGS", "get_hifigan"]
