@@ -65,7 +65,8 @@ HIFIGAN_MAX_UP, HIFIGAN_MAX_KERNELS, HIFIGAN_MAX_RBCONV = 8, 8, 96
 class HifiGanWeights(C.Structure):
     _fields_ = [("pre_w", fp), ("pre_b", fp), ("up_w", fp * HIFIGAN_MAX_UP), ("up_b", fp * HIFIGAN_MAX_UP),
                 ("rb_w1", fp * HIFIGAN_MAX_RBCONV), ("rb_b1", fp * HIFIGAN_MAX_RBCONV), ("rb_w2", fp * HIFIGAN_MAX_RBCONV),
-                ("rb_b2", fp * HIFIGAN_MAX_RBCONV), ("post_w", fp), ("post_b", fp)]
+                ("rb_b2", fp * HIFIGAN_MAX_RBCONV), ("post_w", fp), ("post_b", fp),
+                ("rb_wp1", fp * HIFIGAN_MAX_RBCONV), ("rb_wp2", fp * HIFIGAN_MAX_RBCONV)]
 
 
 class HifiGanShape(C.Structure):
@@ -120,6 +121,7 @@ EXPORTS = (
     "esmi_self_attention_workspace_bytes", "esmi_self_attention_f32", "esmi_mixffn_workspace_bytes", "esmi_mixffn_f32",
     "esmi_acoustic_decoder_f32", "esmi_bucket_embedding_f32", "esmi_split_weight_limit", "esmi_absmax_f32",
     "esmi_forward_arena_bytes", "esmi_phoneme2mel_forward_f32", "esmi_hifigan_workspace_bytes", "esmi_hifigan_generator_f32",
+    "esmi_pack_resblock_bytes", "esmi_pack_resblock_f16",
 )
 
 
@@ -172,6 +174,9 @@ def bind(lib):
     lib.esmi_forward_arena_bytes.argtypes = [P(ForwardArgs)]
     lib.esmi_forward_arena_bytes.restype = sz
     lib.esmi_phoneme2mel_forward_f32.argtypes = [P(ForwardArgs), i, fp]
+    lib.esmi_pack_resblock_bytes.argtypes = [i, i]
+    lib.esmi_pack_resblock_bytes.restype = sz
+    lib.esmi_pack_resblock_f16.argtypes = [fp, fp, i, i, fp]
     lib.esmi_hifigan_workspace_bytes.argtypes = [P(HifiGanShape), i, i]
     lib.esmi_hifigan_workspace_bytes.restype = sz
     lib.esmi_hifigan_generator_f32.argtypes = [P(HifiGanWeights), P(HifiGanShape), fp, i, i, fp, fp, sz, fp]

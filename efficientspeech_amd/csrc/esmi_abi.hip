@@ -8,6 +8,7 @@
 
 #include "attention.h"
 #include "convgemm.h"
+#include "hifigan_resblock.h"
 #include "enc_attn_ffn.h"
 #include "enc_fuse_va.h"
 #include "enc_merge_qkv.h"
@@ -276,6 +277,29 @@ long long* g_esmi_trace = nullptr;
 extern "C" void esmi_dev_set_trace(long long* ptr) { g_esmi_trace = ptr; }
 #endif
 
+namespace {
+// One ResBlock in one launch (hifigan_resblock.h) when its packed weights are there and the channel count has an
+// instantiation; `false` -> the caller runs the block conv by conv.
+template <int C>
+int launch_resblock_c(const ResblockP& p, hipStream_t st) {
+    static AttrOnce once;
+    const size_t lds = rb_lds_bytes(C, p.R);
+    if (lds > 48 * 1024)
+        if (int rc = raise_lds_limit(reinterpret_cast<const void*>(hifigan_resblock_kernel<C>), once)) return rc;
+    ESMI_LAUNCH((hifigan_resblock_kernel<C>), dim3((unsigned)(p.B * p.tiles_per_b)), dim3(64 * kRbWaves), lds, st, p);
+    return launch_status();
+}
+int launch_resblock(const ResblockP& p, int c, hipStream_t st) {
+    switch (c) {
+        case 8: return launch_resblock_c<8>(p, st);
+        case 16: return launch_resblock_c<16>(p, st);
+        case 32: return launch_resblock_c<32>(p, st);
+        case 64: return launch_resblock_c<64>(p, st);
+    }
+    return ESMI_ERR_UNSUPPORTED;
+}
+}  // namespace
+
 extern "C" {
 
 int esmi_version(void) { return ESMI_VERSION; }
@@ -324,6 +348,18 @@ int esmi_pack_bfrag_f32(const float* src, float* dst, int n, int k, int taps, es
 #endif
     const long tot = (long)esmi_pack_bfrag_floats(n, k, taps);
     ESMI_LAUNCH(pack_bfrag_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, S(stream), src, dst, n, k, (n + 31) / 32, taps);
+    return launch_status();
+}
+
+size_t esmi_pack_resblock_bytes(int c, int k) {
+    if ((c != 8 && c != 16 && c != 32 && c != 64) || k < 1 || !(k & 1)) return 0;
+    return rb_pack_dwords(c, k) * 4;
+}
+int esmi_pack_resblock_f16(const float* src, void* dst, int c, int k, esmi_stream_t stream) {
+    if (!src || !dst) return ESMI_ERR_ARG;
+    if (!esmi_pack_resblock_bytes(c, k)) return ESMI_ERR_UNSUPPORTED;
+    const long n = (long)rb_mtiles(c) * rb_ksteps(c, k) * 64;
+    ESMI_LAUNCH(pack_resblock_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, S(stream), src, static_cast<unsigned*>(dst), c, k);
     return launch_status();
 }
 
@@ -886,6 +922,35 @@ int hg_plan(const esmi_hifigan_shape* s, int B, int L, HgPlan* o) {
     o->n_last = n;
     return ESMI_OK;
 }
+
+bool resblock_fused_ok(const esmi_hifigan_weights* w, const esmi_hifigan_shape* s, int rb, int c, int k, int n, ResblockP* o) {
+#if !ESMI_CHAIN_SPLIT
+    return false;   // the exact-fp32 build keeps the per-conv fp32-MFMA launches
+#endif
+    if ((c != 8 && c != 16 && c != 32 && c != 64) || !(k & 1) || k < 3) return false;
+    const int nconv = s->resblock == 1 ? 3 : 2, j = rb % s->n_kernels;
+    ResblockP p = {};
+    int halo = 0, q = 0;
+    for (int m = 0; m < nconv; ++m) {
+        const int d = s->rb_dilations[j * 3 + m];
+        if (d < 1 || !w->rb_wp1[rb * 3 + m] || !w->rb_b1[rb * 3 + m]) return false;
+        p.conv[q++] = RbConv{static_cast<const unsigned*>(w->rb_wp1[rb * 3 + m]), w->rb_b1[rb * 3 + m], d, s->resblock == 1 ? 0 : 1};
+        halo += (k - 1) / 2 * d;
+        if (s->resblock == 1) {
+            if (!w->rb_wp2[rb * 3 + m] || !w->rb_b2[rb * 3 + m]) return false;
+            p.conv[q++] = RbConv{static_cast<const unsigned*>(w->rb_wp2[rb * 3 + m]), w->rb_b2[rb * 3 + m], 1, 1};
+            halo += (k - 1) / 2;
+        }
+    }
+    const int r_max = c == 64 ? 256 : (c == 32 ? 448 : 512);    // 8 waves = 8 (row pair, 32-channel tile) items; LDS <= 160 KB
+    int R = ((n + 2 * halo + 63) / 64) * 64;
+    R = R < r_max ? R : r_max;
+    if (R - 2 * halo < 32 && R - 2 * halo < n) return false;
+    p.n_conv = q; p.k = k; p.halo = halo; p.R = R; p.TL = R - 2 * halo; p.n = n;
+    p.tiles_per_b = (n + p.TL - 1) / p.TL;
+    *o = p;
+    return true;
+}
 }  // namespace
 
 size_t esmi_hifigan_workspace_bytes(const esmi_hifigan_shape* s, int B, int L) {
@@ -928,6 +993,12 @@ int esmi_hifigan_generator_f32(const esmi_hifigan_weights* w, const esmi_hifigan
         for (int j = 0; j < s->n_kernels; ++j) {   // xs += resblocks[i*num_kernels + j](x), models.py:116-121
             const int rb = i * s->n_kernels + j, kk = s->rb_kernels[j];
             const int nconv = s->resblock == 1 ? 3 : 2;
+            ResblockP fp;
+            if (resblock_fused_ok(w, s, rb, c, kk, (int)n, &fp)) {   // the whole block on an LDS-resident window: y -> x (+)=
+                fp.x = y; fp.out = x; fp.B = B; fp.accum = j > 0; fp.slope = slope;
+                if ((rc = launch_resblock(fp, c, st))) return rc;
+                continue;
+            }
             const float* cur = y;                   // the ResBlock's running x (first iteration: the stage input itself)
             for (int m = 0; m < nconv; ++m) {
                 const int d = s->rb_dilations[j * 3 + m];

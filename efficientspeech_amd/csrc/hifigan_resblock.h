@@ -1,0 +1,197 @@
+// One HiFi-GAN ResBlock (hifigan/models.py:20-58 ResBlock1, :61-82 ResBlock2) as ONE kernel: the whole chain of
+// dilated convolutions of a block runs on an LDS-resident window of the signal, so the stage input is read once and the
+// block's result is written (or accumulated into the sum over the stage's ResBlocks, models.py:116-121) once -- instead of
+// a global round trip per convolution (6 per ResBlock1), each of which re-read every input row k times.
+//
+//   ResBlock1:  for (c1, c2) in pairs:  xt = c1(lrelu(x)); xt = c2(lrelu(xt)); x = xt + x
+//   ResBlock2:  for c in convs:         x = c(lrelu(x)) + x
+//   both are a list of convs with a flag: add_res -> out = conv + bias + x, x <- out; otherwise out = conv + bias.
+//
+// Window: R rows (positions), channels-last.  A workgroup produces TL = R - 2.halo output positions, halo = the chain's
+// one-sided receptive field sum((k-1)/2 . dil); every conv is evaluated on all R rows (rows whose inputs fall outside the
+// window read clamped rows and hold finite garbage that never reaches the TL centre rows).  Rows outside the sequence
+// [0, n) are forced to zero after every conv: that is the zero padding each Conv1d of the reference applies to ITS input.
+//
+// Arithmetic: split-f16x2 on the f16 matrix pipe (esmi_dev.h), both operands pre-split.  The activation is split once
+// where it is produced -- leaky_relu(x) as two binary16 planes [row][C] in LDS -- and read as MFMA B fragments (one
+// ds_read_b128 per plane: 8 channels of one tap-shifted row); the weights are pre-scaled by 2^8, pre-split and stored in
+// A-fragment order by esmi_pack_resblock_f16 (one coalesced 1 KB read per plane and k-step, L1/L2 resident).
+//   D[co][pos] += W[co][kidx] . X[kidx][pos],  kidx = tap . C + ci  (16 per MFMA: for C = 8 two taps per step)
+// so a lane ends up holding 4 consecutive channels of one position: 8-byte plane writes, 16-byte global accesses.
+// The residual stream x stays in registers in exactly that layout (fp32, never rounded).
+//
+// Work split: 8 waves; wave = (pair of 32-row tiles, 32-channel M tile).  C < 32 pads M with zero weight rows (the MFMA
+// work of the padding is wasted but the pipe is otherwise idle: these stages are the memory-bound ones).
+#pragma once
+#include "esmi_dev.h"
+
+namespace esmi {
+
+constexpr int kRbMaxConv = 6;
+constexpr int kRbWaves = 8;
+
+struct RbConv {
+    const unsigned* wp;   // esmi_pack_resblock_f16: [mtile][step][plane 2][lane 64][4 dwords]
+    const float* bias;    // (C)
+    int dil, add_res;
+};
+struct ResblockP {
+    const float* x;       // (B, n, C) stage input
+    float* out;           // (B, n, C): out (+)= block(x)
+    int B, n, k, n_conv, R, TL, halo, accum, tiles_per_b;
+    float slope;
+    RbConv conv[kRbMaxConv];
+};
+
+__host__ __device__ constexpr int rb_row_bytes(int c) { return 2 * c + (c == 8 ? 0 : 16); }   // per plane; conflict-free 16-byte reads
+__host__ __device__ constexpr int rb_ksteps(int c, int k) { return (c * k + 15) / 16; }
+__host__ __device__ constexpr int rb_mtiles(int c) { return c > 32 ? c / 32 : 1; }
+__host__ __device__ inline size_t rb_pack_dwords(int c, int k) { return (size_t)rb_mtiles(c) * rb_ksteps(c, k) * 2 * 64 * 4; }
+__host__ __device__ inline size_t rb_lds_bytes(int c, int R) { return (size_t)2 * 2 * R * rb_row_bytes(c); }
+
+// (k, C, C) tap-major fp32 -> A fragments, scaled by 2^8, two nearest-rounded binary16 pieces
+__global__ void pack_resblock_kernel(const float* __restrict__ w, unsigned* __restrict__ dst, int c, int k) {
+    const int steps = rb_ksteps(c, k);
+    const long q = (long)blockIdx.x * blockDim.x + threadIdx.x;   // (mtile, step, lane)
+    if (q >= (long)rb_mtiles(c) * steps * 64) return;
+    const int lane = (int)(q & 63), s = (int)((q >> 6) % steps), m = (int)((q >> 6) / steps);
+    const int co = 32 * m + (lane & 31), h = lane >> 5;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int kidx = 16 * s + 8 * h + e, tap = kidx / c, ci = kidx - tap * c;
+        v[e] = (co < c && tap < k) ? w[((long)tap * c + co) * c + ci] * kF16WScale : 0.0f;
+    }
+    unsigned* d = dst + ((long)(m * steps + s) * 2) * 256 + lane * 4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        unsigned h1, h2;
+        split_f16_pair_rn(v[2 * j], v[2 * j + 1], h1, h2);
+        d[j] = h1;
+        d[256 + j] = h2;
+    }
+}
+
+__device__ __forceinline__ f32x4 lrelu4(const f32x4& v, float slope) {
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = v[e] > 0.0f ? v[e] : v[e] * slope;
+    return o;
+}
+
+template <int C>
+__global__ __launch_bounds__(64 * kRbWaves, C <= 8 ? 4 : 2) void hifigan_resblock_kernel(const ResblockP p) {
+    constexpr int RS = rb_row_bytes(C), MT = rb_mtiles(C), CG = (C < 32 ? C : 32) / 8;
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    ESMI_DYN_LDS(lds_f);
+    char* lds = reinterpret_cast<char*>(lds_f);
+    const int lane = lane_id(), w = wave_id(), i = lane & 31, h = lane >> 5;
+    const int pair = w / MT, mt = w - pair * MT;
+    const bool active = pair * 64 < p.R;
+    const int b = (int)blockIdx.x / p.tiles_per_b;
+    const int t0 = ((int)blockIdx.x - b * p.tiles_per_b) * p.TL - p.halo;   // sequence position of window row 0
+    const int plane = p.R * RS, buf_bytes = 2 * plane;
+    const int steps = rb_ksteps(C, p.k), half = (p.k - 1) >> 1;
+    const int row0 = 64 * pair + i;
+
+    f32x4 xres[2][CG];
+    bool inside[2];
+    auto put_planes = [&](char* dst, int row, int ch, const f32x4& v) __attribute__((always_inline)) {
+        const f32x4 a = lrelu4(v, p.slope);
+        unsigned h1a, h2a, h1b, h2b;
+        split_f16_pair(a[0], a[1], h1a, h2a);
+        split_f16_pair(a[2], a[3], h1b, h2b);
+        char* d = dst + row * RS + ch * 2;
+        *reinterpret_cast<u32x2*>(d) = u32x2{h1a, h1b};
+        *reinterpret_cast<u32x2*>(d + plane) = u32x2{h2a, h2b};
+    };
+    if (active) {
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+            const int row = row0 + 32 * tt, pos = t0 + row;
+            inside[tt] = pos >= 0 && pos < p.n;
+            const float* src = p.x + ((long)b * p.n + (inside[tt] ? pos : 0)) * C + 32 * mt + 4 * h;
+#pragma unroll
+            for (int g = 0; g < CG; ++g) {
+                xres[tt][g] = inside[tt] ? ld4(src + 8 * g) : zero4();
+                put_planes(lds, row, 32 * mt + 8 * g + 4 * h, xres[tt][g]);
+            }
+        }
+    }
+    u32x4 wh = {0, 0, 0, 0}, wl = {0, 0, 0, 0};
+    if (active) {
+        const unsigned* wp = p.conv[0].wp + (long)(mt * steps) * 512 + lane * 4;
+        wh = *reinterpret_cast<const u32x4*>(wp);
+        wl = *reinterpret_cast<const u32x4*>(wp + 256);
+    }
+    __syncthreads();
+
+    for (int ci = 0; ci < p.n_conv; ++ci) {
+        const char* src = lds + (ci & 1) * buf_bytes;
+        char* dst = lds + ((ci + 1) & 1) * buf_bytes;
+        const bool last = ci + 1 == p.n_conv;
+        if (active) {
+            const RbConv cv = p.conv[ci];
+            f32x16 acc[2] = {zero16(), zero16()};
+            const unsigned* wp = cv.wp + (long)(mt * steps) * 512 + lane * 4;
+            for (int s = 0; s < steps; ++s) {
+                u32x4 nh = wh, nl = wl;
+                if (s + 1 < steps) {                       // next step's A fragments, in flight under this step's MFMAs
+                    nh = *reinterpret_cast<const u32x4*>(wp + (long)(s + 1) * 512);
+                    nl = *reinterpret_cast<const u32x4*>(wp + (long)(s + 1) * 512 + 256);
+                } else if (!last) {                        // ... or the next conv's first ones, under the epilogue and the barrier
+                    const unsigned* np = p.conv[ci + 1].wp + (long)(mt * steps) * 512 + lane * 4;
+                    nh = *reinterpret_cast<const u32x4*>(np);
+                    nl = *reinterpret_cast<const u32x4*>(np + 256);
+                }
+                sched_fence();
+                const int kidx = 16 * s + 8 * h;
+                int tap = kidx / C;
+                const int ch = kidx - tap * C;
+                tap = tap < p.k ? tap : p.k - 1;           // zero weight columns past the last tap: any finite row will do
+                const int shift = (tap - half) * cv.dil;
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt) {
+                    int r = row0 + 32 * tt + shift;
+                    r = r < 0 ? 0 : (r >= p.R ? p.R - 1 : r);
+                    const char* a = src + opaque_i(r * RS + ch * 2);
+                    const u32x4 x1 = *reinterpret_cast<const u32x4*>(a);
+                    const u32x4 x2 = *reinterpret_cast<const u32x4*>(a + plane);
+                    acc[tt] = mfma32_f16(wh, x2, acc[tt]);
+                    acc[tt] = mfma32_f16(wl, x1, acc[tt]);
+                    acc[tt] = mfma32_f16(wh, x1, acc[tt]);
+                }
+                wh = nh;
+                wl = nl;
+            }
+            // epilogue: bias, residual, zero outside the sequence; planes for the next conv or the block's result
+            const float* bias = cv.bias + 32 * mt + 4 * h;
+#pragma unroll
+            for (int g = 0; g < CG; ++g) {
+                const f32x4 bv = ld4(bias + 8 * g);
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt) {
+                    const int row = row0 + 32 * tt;
+                    f32x4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = fmaf(acc[tt][4 * g + e], kF16WScaleInv, bv[e]);
+                    if (cv.add_res) {
+                        v = v + xres[tt][g];
+                        xres[tt][g] = inside[tt] ? v : zero4();
+                    }
+                    if (!inside[tt]) v = zero4();
+                    if (!last) {
+                        put_planes(dst, row, 32 * mt + 8 * g + 4 * h, v);
+                    } else if (inside[tt] && row >= p.halo && row < p.halo + p.TL) {
+                        float* o = p.out + ((long)b * p.n + t0 + row) * C + 32 * mt + 8 * g + 4 * h;
+                        if (p.accum) v = v + ld4(o);
+                        *reinterpret_cast<f32x4*>(o) = v;
+                    }
+                }
+            }
+        }
+        if (!last) __syncthreads();
+    }
+}
+
+}  // namespace esmi

@@ -116,6 +116,7 @@ class Generator(_PackedModule):
                 self.resblocks.append(rb(h, ch, k, d))
         self.conv_post = nn.Conv1d(ch, 1, 7, 1, padding=3)
         self._cache = _PackCache()
+        self.fuse_resblocks = True    # one launch per ResBlock where the library has the kernel (False: one per convolution)
         for p in self.parameters():
             p.requires_grad = False
 
@@ -135,6 +136,17 @@ class Generator(_PackedModule):
                 b = _f32(m.bias)
                 keep.extend([wt, b])
                 return _ptr(wt), _ptr(b), wt
+
+            def frag(wt):
+                """Fragment-ordered split-f16 planes for the one-launch ResBlock kernel (None: no such kernel for this shape)."""
+                k, c, _ = wt.shape
+                nbytes = lib.esmi_pack_resblock_bytes(c, k) if self.fuse_resblocks else 0
+                if not nbytes:
+                    return None
+                dst = torch.empty(nbytes, dtype=torch.uint8, device=wt.device)
+                lib.esmi_pack_resblock_f16(_ptr(wt), _ptr(dst), c, k, stream)
+                keep.append(dst)
+                return _ptr(dst)
             mats = []
             w.pre_w, w.pre_b, t = conv(self.conv_pre); mats.append(t)
             for i, up in enumerate(self.ups):
@@ -144,9 +156,12 @@ class Generator(_PackedModule):
                 for m in range(nconv):
                     if h.resblock == "1":
                         w.rb_w1[n * 3 + m], w.rb_b1[n * 3 + m], t = conv(rb.convs1[m]); mats.append(t)
+                        w.rb_wp1[n * 3 + m] = frag(t)
                         w.rb_w2[n * 3 + m], w.rb_b2[n * 3 + m], t = conv(rb.convs2[m]); mats.append(t)
+                        w.rb_wp2[n * 3 + m] = frag(t)
                     else:
                         w.rb_w1[n * 3 + m], w.rb_b1[n * 3 + m], t = conv(rb.convs[m]); mats.append(t)
+                        w.rb_wp1[n * 3 + m] = frag(t)
             w.post_w, w.post_b, t = conv(self.conv_post); mats.append(t)
             _check_split_range(lib, stream, mats, "HiFi-GAN generator weights")
             s.n_mel, s.initial_channel, s.n_up, s.n_kernels = h.num_mels, h.upsample_initial_channel, self.num_upsamples, self.num_kernels

@@ -396,6 +396,11 @@ typedef struct esmi_hifigan_weights {
     const float* rb_b2[ESMI_HIFIGAN_MAX_RBCONV];
     const float* post_w; /* <- conv_post.weight (1, C_last, 7) */
     const float* post_b;
+    /* esmi_pack_resblock_f16 of rb_w1[n] / rb_w2[n] (optional).  When every conv of a ResBlock has one and its channel count
+     * is 8, 16, 32 or 64, the block runs as ONE launch on an LDS-resident window (csrc/hifigan_resblock.h) instead of one
+     * launch per convolution; NULL -> conv by conv.  (libesmi_fp32mfma.so ignores them.) */
+    const void* rb_wp1[ESMI_HIFIGAN_MAX_RBCONV];
+    const void* rb_wp2[ESMI_HIFIGAN_MAX_RBCONV];
 } esmi_hifigan_weights;
 typedef struct esmi_hifigan_shape {
     int n_mel, initial_channel, n_up, n_kernels;
@@ -404,6 +409,10 @@ typedef struct esmi_hifigan_shape {
     int rb_kernels[ESMI_HIFIGAN_MAX_KERNELS];
     int rb_dilations[ESMI_HIFIGAN_MAX_KERNELS * 3]; /* [j*3 + m] */
 } esmi_hifigan_shape;
+/* Fragment-ordered split-f16 form of one ResBlock convolution: src = tap-major (k, C, C) fp32 (esmi_pack_conv_weight_f32),
+ * dst = esmi_pack_resblock_bytes(c, k) bytes (0: no fused kernel for this shape: c in {8, 16, 32, 64}, k odd). */
+size_t esmi_pack_resblock_bytes(int c, int k);
+int esmi_pack_resblock_f16(const float* src, void* dst, int c, int k, esmi_stream_t stream);
 size_t esmi_hifigan_workspace_bytes(const esmi_hifigan_shape* s, int B, int L);
 int esmi_hifigan_generator_f32(const esmi_hifigan_weights* w, const esmi_hifigan_shape* s, const float* mel, int B, int L,
                                float* wav, void* workspace, size_t workspace_bytes, esmi_stream_t stream);
