@@ -53,6 +53,13 @@ struct ConvGemmP {
     int accum;           // 1: out += value (same element, same thread: no race)
 };
 
+// output positions per tile row step, and 32-row tiles per phase and batch item (see convgemm_kernel)
+__host__ __device__ inline int convgemm_row_stride(const ConvGemmP& p) { return (p.mode == MODE_CONVT && p.stride > 1) ? p.stride : 1; }
+__host__ __device__ inline int convgemm_tiles_per_phase(const ConvGemmP& p) {
+    const int ts = convgemm_row_stride(p);
+    return ((p.n_out + ts - 1) / ts + 31) >> 5;
+}
+
 // input-side activation of the HiFi-GAN convolutions, applied to a loaded fragment
 __device__ __forceinline__ f32x4 conv_act_in(f32x4 v, const ConvGemmP& p) {
     if (p.act_in) {
@@ -69,7 +76,7 @@ __device__ __forceinline__ f32x4 conv_act_in(f32x4 v, const ConvGemmP& p) {
 // Fused epilogue of the implicit-GEMM kernels, in the MFMA C/D layout (row = tile_row(r), col = n0 + 32*nt + (lane&31)):
 //   out = mask( post_relu( LN( act(acc * s + bias) + residual ) ) ), optional row-dot side output on the pre-LN value.
 template <int NT>
-__device__ __forceinline__ void convgemm_epilogue(f32x16 (&acc)[NT], const ConvGemmP& p, int b, int t0, int n0, int lane) {
+__device__ __forceinline__ void convgemm_epilogue(f32x16 (&acc)[NT], const ConvGemmP& p, int b, int t0, int n0, int lane, int ts = 1) {
     const int i = lane & 31;
     int col[NT];
     bool cok[NT];
@@ -82,7 +89,7 @@ __device__ __forceinline__ void convgemm_epilogue(f32x16 (&acc)[NT], const ConvG
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-        const int t = t0 + tile_row(r, lane);
+        const int t = t0 + tile_row(r, lane) * ts;
         const bool rok = t < p.n_out;
         const long row = (long)b * p.n_out + t;
 #pragma unroll
@@ -104,7 +111,7 @@ __device__ __forceinline__ void convgemm_epilogue(f32x16 (&acc)[NT], const ConvG
             for (int nt = 0; nt < NT; ++nt) s = fmaf(acc[nt][r], dw[nt], s);
             s = row_sum32(s) + db;
             if (p.dot_relu) s = fmaxf(s, 0.0f);
-            const int t = t0 + tile_row(r, lane);
+            const int t = t0 + tile_row(r, lane) * ts;
             if (i == 0 && t < p.n_out) p.dot_out[(long)b * p.n_out + t] = s;
         }
     }
@@ -112,7 +119,7 @@ __device__ __forceinline__ void convgemm_epilogue(f32x16 (&acc)[NT], const ConvG
     if (p.ln_g) layernorm_tile<NT>(acc, p.ln_g, p.ln_b, lane);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-        const int t = t0 + tile_row(r, lane);
+        const int t = t0 + tile_row(r, lane) * ts;
         if (t >= p.n_out) continue;
         const long row = (long)b * p.n_out + t;
         const bool masked = p.rowmask && p.rowmask[row];
@@ -132,21 +139,27 @@ __device__ __forceinline__ void convgemm_epilogue(f32x16 (&acc)[NT], const ConvG
 template <int NT>
 __global__ __launch_bounds__(256) void convgemm_kernel(const ConvGemmP p) {
     const int lane = lane_id();
-    const int tiles_per_b = (p.n_out + 31) >> 5;
+    // A strided ConvTranspose1d tile holds 32 positions of ONE phase (t mod stride): only the k/stride taps of that phase are
+    // visited, instead of all k with (stride-1)/stride of the rows masked out of each (HiFi-GAN ups: k = 16, stride 8).
+    const int ts = convgemm_row_stride(p);
+    const int tiles_per_phase = convgemm_tiles_per_phase(p);
+    const int tiles_per_b = tiles_per_phase * ts;
     const int wt = (int)blockIdx.x * 4 + wave_id();
     if (wt >= p.B * tiles_per_b) return;  // whole wave leaves together; no barriers in this kernel
     const int b = wt / tiles_per_b;
-    const int t0 = (wt - b * tiles_per_b) << 5;
+    const int rem = wt - b * tiles_per_b, phase = rem / tiles_per_phase;
+    const int t0 = ((rem - phase * tiles_per_phase) << 5) * ts + phase;
     const int n0 = (int)blockIdx.y * (NT * 32);
     const int i = lane & 31, h = lane >> 5;
-    const int t_out = t0 + i;
+    const int t_out = t0 + i * ts;
+    const int j_first = ts > 1 ? (phase + p.pad) % ts : 0;
 
     f32x16 acc[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) acc[nt] = zero16();
 
     const int kcs = p.c_in >> 3;
-    for (int j = 0; j < p.k; ++j) {
+    for (int j = j_first; j < p.k; j += ts) {
         // which input row feeds output position t_out through tap j
         int ti;
         bool ok = t_out < p.n_out;
@@ -252,9 +265,35 @@ __global__ __launch_bounds__(256) void convgemm_kernel(const ConvGemmP p) {
 #endif
     }
 
-    convgemm_epilogue<NT>(acc, p, b, t0, n0, lane);
+    convgemm_epilogue<NT>(acc, p, b, t0, n0, lane, ts);
 }
 
+
+// ---- a convolution down to ONE output channel (HiFi-GAN conv_post, hifigan/models.py:123-125: 8..32 channels -> 1, k = 7,
+// tanh): 1/32 of an MFMA tile's columns would be used, and the op is a plain read of the input (C floats per sample).
+// One thread per output position, fp32 FMAs in tap-major / channel order; neighbouring threads share their rows in L1.
+__global__ __launch_bounds__(256) void conv_to1_kernel(const ConvGemmP p) {
+    const long q = (long)blockIdx.x * 256 + threadIdx.x;
+    if (q >= (long)p.B * p.n_out) return;
+    const int b = (int)(q / p.n_out), t = (int)(q - (long)b * p.n_out);
+    const int dil = p.dil > 0 ? p.dil : 1;
+    float acc = 0.0f;
+    for (int j = 0; j < p.k; ++j) {
+        const int ti = t + j * dil - p.pad;
+        if (ti < 0 || ti >= p.n_in) continue;
+        const float* arow = p.A + ((long)b * p.n_in + ti) * p.lda + p.a_coff;
+        const float* wj = p.W + (long)j * p.c_in;
+        for (int c = 0; c < p.c_in; c += 4) {
+            const f32x4 a = conv_act_in(ld4(arow + c), p), w = ld4(wj + c);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc = fmaf(a[e], w[e], acc);
+        }
+    }
+    float v = apply_act(acc + (p.bias ? p.bias[0] : 0.0f), p.act);
+    if (p.post_relu) v = fmaxf(v, 0.0f);
+    float* o = p.out + ((long)b * p.n_out + t) * p.ldo + p.o_coff;
+    *o = p.accum ? *o + v : v;
+}
 
 #if ESMI_CHAIN_SPLIT
 // ---- the same implicit GEMM with the WEIGHT tile staged through LDS (large shapes of the per-op plan: base ES block 1,

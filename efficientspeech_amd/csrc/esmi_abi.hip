@@ -70,6 +70,11 @@ int launch_convgemm(ConvGemmP p, hipStream_t st) {
         if (!p.table || (p.ld_table & 3) || !aligned16(p.table)) return ESMI_ERR_ARG;
     } else if (!p.A || (p.lda & 3) || (p.a_coff & 3) || !aligned16(p.A)) return ESMI_ERR_ARG;
     const bool full_row = p.ln_g || p.dot_out;
+    if (p.c_out == 1 && p.mode == MODE_CONV && p.stride == 1 && !p.ids && !full_row && !p.res && !p.rowmask && p.out) {
+        const long n = (long)p.B * p.n_out;
+        ESMI_LAUNCH(conv_to1_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p);
+        return launch_status();
+    }
     int nt;
     if (full_row) {
         nt = (p.c_out + 31) / 32;
@@ -95,7 +100,7 @@ int launch_convgemm(ConvGemmP p, hipStream_t st) {
         return launch_status();
     }
 #endif
-    const int tiles = p.B * ((p.n_out + 31) / 32);
+    const int tiles = p.B * convgemm_tiles_per_phase(p) * convgemm_row_stride(p);
     dim3 grid((tiles + 3) / 4, full_row ? 1 : (p.c_out + 32 * nt - 1) / (32 * nt));
     dim3 block(256);
     switch (nt) {
