@@ -283,16 +283,25 @@ extern "C" void esmi_dev_set_trace(long long* ptr) { g_esmi_trace = ptr; }
 #endif
 
 namespace {
-// One ResBlock in one launch (hifigan_resblock.h) when its packed weights are there and the channel count has an
-// instantiation; `false` -> the caller runs the block conv by conv.
-template <int C>
-int launch_resblock_c(const ResblockP& p, hipStream_t st) {
+// One ResBlock in one launch (hifigan_resblock.h) when its packed weights are there and (channels, kernel size) has an
+// instantiation; `false` from resblock_fused_ok -> the caller runs the block conv by conv.
+template <int C, int K>
+int launch_resblock_ck(const ResblockP& p, hipStream_t st) {
     static AttrOnce once;
     const size_t lds = rb_lds_bytes(C, p.R);
     if (lds > 48 * 1024)
-        if (int rc = raise_lds_limit(reinterpret_cast<const void*>(hifigan_resblock_kernel<C>), once)) return rc;
-    ESMI_LAUNCH((hifigan_resblock_kernel<C>), dim3((unsigned)(p.B * p.tiles_per_b)), dim3(64 * kRbWaves), lds, st, p);
+        if (int rc = raise_lds_limit(reinterpret_cast<const void*>(hifigan_resblock_kernel<C, K>), once)) return rc;
+    ESMI_LAUNCH((hifigan_resblock_kernel<C, K>), dim3((unsigned)(p.B * p.tiles_per_b)), dim3(64 * kRbWaves), lds, st, p);
     return launch_status();
+}
+template <int C>
+int launch_resblock_c(const ResblockP& p, hipStream_t st) {
+    switch (p.k) {
+        case 3: return launch_resblock_ck<C, 3>(p, st);
+        case 7: return launch_resblock_ck<C, 7>(p, st);
+        case 11: return launch_resblock_ck<C, 11>(p, st);
+    }
+    return ESMI_ERR_UNSUPPORTED;
 }
 int launch_resblock(const ResblockP& p, int c, hipStream_t st) {
     switch (c) {
@@ -357,7 +366,7 @@ int esmi_pack_bfrag_f32(const float* src, float* dst, int n, int k, int taps, es
 }
 
 size_t esmi_pack_resblock_bytes(int c, int k) {
-    if ((c != 8 && c != 16 && c != 32 && c != 64) || k < 1 || !(k & 1)) return 0;
+    if ((c != 8 && c != 16 && c != 32 && c != 64) || (k != 3 && k != 7 && k != 11)) return 0;
     return rb_pack_dwords(c, k) * 4;
 }
 int esmi_pack_resblock_f16(const float* src, void* dst, int c, int k, esmi_stream_t stream) {
@@ -932,7 +941,7 @@ bool resblock_fused_ok(const esmi_hifigan_weights* w, const esmi_hifigan_shape* 
 #if !ESMI_CHAIN_SPLIT
     return false;   // the exact-fp32 build keeps the per-conv fp32-MFMA launches
 #endif
-    if ((c != 8 && c != 16 && c != 32 && c != 64) || !(k & 1) || k < 3) return false;
+    if ((c != 8 && c != 16 && c != 32 && c != 64) || (k != 3 && k != 7 && k != 11)) return false;   // the instantiations
     const int nconv = s->resblock == 1 ? 3 : 2, j = rb % s->n_kernels;
     ResblockP p = {};
     int halo = 0, q = 0;
@@ -947,7 +956,7 @@ bool resblock_fused_ok(const esmi_hifigan_weights* w, const esmi_hifigan_shape* 
             halo += (k - 1) / 2;
         }
     }
-    const int r_max = c == 64 ? 256 : (c == 32 ? 448 : 512);    // 8 waves = 8 (row pair, 32-channel tile) items; LDS <= 160 KB
+    const int r_max = c == 64 ? 256 : 512;    // 8 waves = 8 (row pair, 32-channel tile) items; LDS <= 80 KB: two workgroups per CU
     int R = ((n + 2 * halo + 63) / 64) * 64;
     R = R < r_max ? R : r_max;
     if (R - 2 * halo < 32 && R - 2 * halo < n) return false;

@@ -20,6 +20,10 @@
 // so a lane ends up holding 4 consecutive channels of one position: 8-byte plane writes, 16-byte global accesses.
 // The residual stream x stays in registers in exactly that layout (fp32, never rounded).
 //
+// The planes are updated IN PLACE: a conv's K loop only reads them, its result waits in registers across a barrier (all reads
+// done), is written, and a second barrier publishes it -- half the LDS of a ping-pong pair, so two workgroups share a CU and
+// one's K loop (matrix pipe) runs under the other's epilogue (VALU) and barriers.
+//
 // Work split: 8 waves; wave = (pair of 32-row tiles, 32-channel M tile).  C < 32 pads M with zero weight rows (the MFMA
 // work of the padding is wasted but the pipe is otherwise idle: these stages are the memory-bound ones).
 #pragma once
@@ -47,7 +51,7 @@ __host__ __device__ constexpr int rb_row_bytes(int c) { return 2 * c + (c == 8 ?
 __host__ __device__ constexpr int rb_ksteps(int c, int k) { return (c * k + 15) / 16; }
 __host__ __device__ constexpr int rb_mtiles(int c) { return c > 32 ? c / 32 : 1; }
 __host__ __device__ inline size_t rb_pack_dwords(int c, int k) { return (size_t)rb_mtiles(c) * rb_ksteps(c, k) * 2 * 64 * 4; }
-__host__ __device__ inline size_t rb_lds_bytes(int c, int R) { return (size_t)2 * 2 * R * rb_row_bytes(c); }
+__host__ __device__ inline size_t rb_lds_bytes(int c, int R) { return (size_t)2 * R * rb_row_bytes(c); }
 
 // (k, C, C) tap-major fp32 -> A fragments, scaled by 2^8, two nearest-rounded binary16 pieces
 __global__ void pack_resblock_kernel(const float* __restrict__ w, unsigned* __restrict__ dst, int c, int k) {
@@ -72,40 +76,85 @@ __global__ void pack_resblock_kernel(const float* __restrict__ w, unsigned* __re
     }
 }
 
-__device__ __forceinline__ f32x4 lrelu4(const f32x4& v, float slope) {
+__device__ __forceinline__ f32x4 lrelu4(const f32x4& v, float slope) {   // 0 <= slope <= 1 (the launcher checks): max(v, slope v)
     f32x4 o;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) o[e] = v[e] > 0.0f ? v[e] : v[e] * slope;
+    for (int e = 0; e < 4; ++e) o[e] = fmaxf(v[e], v[e] * slope);
     return o;
 }
 
-template <int C>
-__global__ __launch_bounds__(64 * kRbWaves, C <= 8 ? 4 : 2) void hifigan_resblock_kernel(const ResblockP p) {
+#ifndef ESMI_RB_WPS
+#define ESMI_RB_WPS 4   // waves per SIMD the kernel is compiled for: 4 = two 8-wave workgroups per CU (128 VGPRs)
+#endif
+#ifndef ESMI_RB_PD
+#define ESMI_RB_PD 1    // weight fragments are fetched this many k-steps ahead
+#endif
+#ifndef ESMI_RB_XPF
+#define ESMI_RB_XPF 0   // 1: the next step's B fragments are read from LDS under this step's MFMAs (16 more VGPRs)
+#endif
+
+template <int C, int K>
+__global__ __launch_bounds__(64 * kRbWaves, ESMI_RB_WPS) void hifigan_resblock_kernel(const ResblockP p) {
     constexpr int RS = rb_row_bytes(C), MT = rb_mtiles(C), CG = (C < 32 ? C : 32) / 8;
+    constexpr int STEPS = rb_ksteps(C, K), HALF = (K - 1) / 2, PD = ESMI_RB_PD < STEPS ? ESMI_RB_PD : STEPS;
+    static_assert(STEPS >= PD, "prefetch distance reaches at most into the next conv");
     typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
     ESMI_DYN_LDS(lds_f);
-    char* lds = reinterpret_cast<char*>(lds_f);
+    char* lds = reinterpret_cast<char*>(lds_f);   // ONE pair of planes [2][R][RS], updated in place between two barriers
     const int lane = lane_id(), w = wave_id(), i = lane & 31, h = lane >> 5;
     const int pair = w / MT, mt = w - pair * MT;
     const bool active = pair * 64 < p.R;
     const int b = (int)blockIdx.x / p.tiles_per_b;
     const int t0 = ((int)blockIdx.x - b * p.tiles_per_b) * p.TL - p.halo;   // sequence position of window row 0
-    const int plane = p.R * RS, buf_bytes = 2 * plane;
-    const int steps = rb_ksteps(C, p.k), half = (p.k - 1) >> 1;
+    const int plane = p.R * RS;
     const int row0 = 64 * pair + i;
+    const long wlane = (long)(mt * STEPS) * 512 + lane * 4;
 
     f32x4 xres[2][CG];
     bool inside[2];
-    auto put_planes = [&](char* dst, int row, int ch, const f32x4& v) __attribute__((always_inline)) {
+    auto split4 = [&](const f32x4& v) __attribute__((always_inline)) {   // leaky_relu, then the two binary16 planes of 4 channels
         const f32x4 a = lrelu4(v, p.slope);
         unsigned h1a, h2a, h1b, h2b;
         split_f16_pair(a[0], a[1], h1a, h2a);
         split_f16_pair(a[2], a[3], h1b, h2b);
-        char* d = dst + row * RS + ch * 2;
-        *reinterpret_cast<u32x2*>(d) = u32x2{h1a, h1b};
-        *reinterpret_cast<u32x2*>(d + plane) = u32x2{h2a, h2b};
+        return u32x4{h1a, h1b, h2a, h2b};
     };
+    auto put_planes = [&](int row, int ch, const u32x4& v) __attribute__((always_inline)) {
+        char* d = lds + row * RS + ch * 2;
+        *reinterpret_cast<u32x2*>(d) = u32x2{v[0], v[1]};
+        *reinterpret_cast<u32x2*>(d + plane) = u32x2{v[2], v[3]};
+    };
+    // weight fragments of flattened step index s (s >= STEPS: the next conv's first steps; past the last conv: nothing)
+    auto wfetch = [&](int ci, int s, u32x4& hi, u32x4& lo) __attribute__((always_inline)) {
+        if (s >= STEPS) { ++ci; s -= STEPS; }
+        if (ci < p.n_conv && (C >= 32 || i < C)) {   // rows past C are the zero padding of the M tile: those lanes keep their zeros
+            const unsigned* q = p.conv[ci].wp + wlane + (long)s * 512;
+            hi = *reinterpret_cast<const u32x4*>(q);
+            lo = *reinterpret_cast<const u32x4*>(q + 256);
+        }
+    };
+    auto xfetch = [&](int s, int dil, u32x4 (&x1)[2], u32x4 (&x2)[2]) __attribute__((always_inline)) {
+        const int kidx = 16 * s + 8 * h;
+        int tap = kidx / C;
+        const int ch = kidx - tap * C;
+        tap = tap < K ? tap : K - 1;               // zero weight columns past the last tap: any finite row will do
+        const int shift = (tap - HALF) * dil;
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+            int r = row0 + 32 * tt + shift;
+            r = r < 0 ? 0 : (r >= p.R ? p.R - 1 : r);
+            const char* a = lds + opaque_i(r * RS + ch * 2);
+            x1[tt] = *reinterpret_cast<const u32x4*>(a);
+            x2[tt] = *reinterpret_cast<const u32x4*>(a + plane);
+        }
+    };
+
+    u32x4 wq[PD][2];
+#pragma unroll
+    for (int q = 0; q < PD; ++q) wq[q][0] = wq[q][1] = u32x4{0, 0, 0, 0};
     if (active) {
+#pragma unroll
+        for (int q = 0; q < PD; ++q) wfetch(0, q, wq[q][0], wq[q][1]);
 #pragma unroll
         for (int tt = 0; tt < 2; ++tt) {
             const int row = row0 + 32 * tt, pos = t0 + row;
@@ -114,83 +163,81 @@ __global__ __launch_bounds__(64 * kRbWaves, C <= 8 ? 4 : 2) void hifigan_resbloc
 #pragma unroll
             for (int g = 0; g < CG; ++g) {
                 xres[tt][g] = inside[tt] ? ld4(src + 8 * g) : zero4();
-                put_planes(lds, row, 32 * mt + 8 * g + 4 * h, xres[tt][g]);
+                put_planes(row, 32 * mt + 8 * g + 4 * h, split4(xres[tt][g]));
             }
         }
-    }
-    u32x4 wh = {0, 0, 0, 0}, wl = {0, 0, 0, 0};
-    if (active) {
-        const unsigned* wp = p.conv[0].wp + (long)(mt * steps) * 512 + lane * 4;
-        wh = *reinterpret_cast<const u32x4*>(wp);
-        wl = *reinterpret_cast<const u32x4*>(wp + 256);
     }
     __syncthreads();
 
     for (int ci = 0; ci < p.n_conv; ++ci) {
-        const char* src = lds + (ci & 1) * buf_bytes;
-        char* dst = lds + ((ci + 1) & 1) * buf_bytes;
         const bool last = ci + 1 == p.n_conv;
+        u32x4 pl[2][CG];      // the conv's result as plane words, held across the barrier that ends everybody's reads
         if (active) {
-            const RbConv cv = p.conv[ci];
+            const int dil = p.conv[ci].dil;
             f32x16 acc[2] = {zero16(), zero16()};
-            const unsigned* wp = cv.wp + (long)(mt * steps) * 512 + lane * 4;
-            for (int s = 0; s < steps; ++s) {
-                u32x4 nh = wh, nl = wl;
-                if (s + 1 < steps) {                       // next step's A fragments, in flight under this step's MFMAs
-                    nh = *reinterpret_cast<const u32x4*>(wp + (long)(s + 1) * 512);
-                    nl = *reinterpret_cast<const u32x4*>(wp + (long)(s + 1) * 512 + 256);
-                } else if (!last) {                        // ... or the next conv's first ones, under the epilogue and the barrier
-                    const unsigned* np = p.conv[ci + 1].wp + (long)(mt * steps) * 512 + lane * 4;
-                    nh = *reinterpret_cast<const u32x4*>(np);
-                    nl = *reinterpret_cast<const u32x4*>(np + 256);
-                }
+            u32x4 x1[2], x2[2];
+            xfetch(0, dil, x1, x2);
+#pragma unroll
+            for (int s = 0; s < STEPS; ++s) {
+                const u32x4 wh = wq[s % PD][0], wl = wq[s % PD][1];
+                u32x4 nh = wh, nl = wl, n1[2] = {x1[0], x1[1]}, n2[2] = {x2[0], x2[1]};
+                wfetch(ci, s + PD, nh, nl);                        // in flight under PD steps of MFMAs (and the epilogue)
+#if ESMI_RB_XPF
+                if (s + 1 < STEPS) xfetch(s + 1, dil, n1, n2);     // next step's B fragments under this step's MFMAs
+#endif
                 sched_fence();
-                const int kidx = 16 * s + 8 * h;
-                int tap = kidx / C;
-                const int ch = kidx - tap * C;
-                tap = tap < p.k ? tap : p.k - 1;           // zero weight columns past the last tap: any finite row will do
-                const int shift = (tap - half) * cv.dil;
 #pragma unroll
                 for (int tt = 0; tt < 2; ++tt) {
-                    int r = row0 + 32 * tt + shift;
-                    r = r < 0 ? 0 : (r >= p.R ? p.R - 1 : r);
-                    const char* a = src + opaque_i(r * RS + ch * 2);
-                    const u32x4 x1 = *reinterpret_cast<const u32x4*>(a);
-                    const u32x4 x2 = *reinterpret_cast<const u32x4*>(a + plane);
-                    acc[tt] = mfma32_f16(wh, x2, acc[tt]);
-                    acc[tt] = mfma32_f16(wl, x1, acc[tt]);
-                    acc[tt] = mfma32_f16(wh, x1, acc[tt]);
+                    acc[tt] = mfma32_f16(wh, x2[tt], acc[tt]);
+                    acc[tt] = mfma32_f16(wl, x1[tt], acc[tt]);
+                    acc[tt] = mfma32_f16(wh, x1[tt], acc[tt]);
                 }
-                wh = nh;
-                wl = nl;
+                wq[s % PD][0] = nh;
+                wq[s % PD][1] = nl;
+#if ESMI_RB_XPF
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt) { x1[tt] = n1[tt]; x2[tt] = n2[tt]; }
+#else
+                if (s + 1 < STEPS) xfetch(s + 1, dil, x1, x2);
+#endif
             }
-            // epilogue: bias, residual, zero outside the sequence; planes for the next conv or the block's result
-            const float* bias = cv.bias + 32 * mt + 4 * h;
+            // bias, residual, zero outside the sequence; the last conv's result goes straight out
+            const float* bias = p.conv[ci].bias + 32 * mt + 4 * h;
+            const bool add_res = p.conv[ci].add_res != 0;
 #pragma unroll
-            for (int g = 0; g < CG; ++g) {
-                const f32x4 bv = ld4(bias + 8 * g);
+            for (int tt = 0; tt < 2; ++tt) {
+                const int row = row0 + 32 * tt;
+                const bool emit = last && inside[tt] && row >= p.halo && row < p.halo + p.TL;
+                float* o = p.out + ((long)b * p.n + (emit ? t0 + row : 0)) * C + 32 * mt + 4 * h;
 #pragma unroll
-                for (int tt = 0; tt < 2; ++tt) {
-                    const int row = row0 + 32 * tt;
+                for (int g = 0; g < CG; ++g) {
+                    const f32x4 bv = ld4(bias + 8 * g);
                     f32x4 v;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = fmaf(acc[tt][4 * g + e], kF16WScaleInv, bv[e]);
-                    if (cv.add_res) {
-                        v = v + xres[tt][g];
-                        xres[tt][g] = inside[tt] ? v : zero4();
-                    }
+                    if (add_res) v = v + xres[tt][g];
                     if (!inside[tt]) v = zero4();
-                    if (!last) {
-                        put_planes(dst, row, 32 * mt + 8 * g + 4 * h, v);
-                    } else if (inside[tt] && row >= p.halo && row < p.halo + p.TL) {
-                        float* o = p.out + ((long)b * p.n + t0 + row) * C + 32 * mt + 8 * g + 4 * h;
-                        if (p.accum) v = v + ld4(o);
-                        *reinterpret_cast<f32x4*>(o) = v;
+                    if (last) {
+                        if (emit) {
+                            if (p.accum) v = v + ld4(o + 8 * g);
+                            *reinterpret_cast<f32x4*>(o + 8 * g) = v;
+                        }
+                    } else {
+                        if (add_res) xres[tt][g] = v;
+                        pl[tt][g] = split4(v);
                     }
                 }
             }
         }
-        if (!last) __syncthreads();
+        if (last) break;
+        __syncthreads();       // every wave has read what it needs of the old planes
+        if (active) {
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+                for (int g = 0; g < CG; ++g) put_planes(row0 + 32 * tt, 32 * mt + 8 * g + 4 * h, pl[tt][g]);
+        }
+        __syncthreads();       // the new planes are complete
     }
 }
 

@@ -410,7 +410,7 @@ typedef struct esmi_hifigan_shape {
     int rb_dilations[ESMI_HIFIGAN_MAX_KERNELS * 3]; /* [j*3 + m] */
 } esmi_hifigan_shape;
 /* Fragment-ordered split-f16 form of one ResBlock convolution: src = tap-major (k, C, C) fp32 (esmi_pack_conv_weight_f32),
- * dst = esmi_pack_resblock_bytes(c, k) bytes (0: no fused kernel for this shape: c in {8, 16, 32, 64}, k odd). */
+ * dst = esmi_pack_resblock_bytes(c, k) bytes (0: no fused kernel for this shape: c in {8, 16, 32, 64}, k in {3, 7, 11}). */
 size_t esmi_pack_resblock_bytes(int c, int k);
 int esmi_pack_resblock_f16(const float* src, void* dst, int c, int k, esmi_stream_t stream);
 size_t esmi_hifigan_workspace_bytes(const esmi_hifigan_shape* s, int B, int L);
