@@ -14,6 +14,7 @@ Prints ONE JSON line (rank 0):
                          v_mfma_f32_32x32x2_f32, with its own kernel time and fraction of the 157.3 TFLOP/s fp32-MFMA peak
   decoder_only           (N=1) MelDecoder.forward alone on frame-rate features ~ N(0,1)
   allgather              (N>1) the mel all-gather timed by itself: GB/s received per rank vs 7 xGMI links x 76.8 GB/s
+  vocoder                (N=1) the HiFi-GAN v2 generator on the mel the forward produced: mel-frames/s, TFLOP/s
   cpu_baseline           (N=1) the C oracle (oracle/, fp32 accumulation, OpenMP) on this box's host cores: all cores and
                          n=24 (the reference's --threads default), plus the B=1 fox-sentence latency (BASELINE configs[0]) --
                          a reported baseline, not the target.
@@ -350,6 +351,34 @@ def main():
                                  "frac_of_157.3": ach32 / FP32_PEAK_TFLOPS, "build_config": cfg32,
                                  "library": "efficientspeech_amd/libesmi_fp32mfma.so"}
             del net32, pipe32
+        # ---- the step after the path: HiFi-GAN v2 generator on the mel the forward just produced
+        if not a.exact_fp32:
+            from efficientspeech_amd.hifigan import HIFIGAN_CONFIGS, Generator, synth_hifigan_state_dict, flops_per_mel_frame
+            hcfg = HIFIGAN_CONFIGS["v2"]
+            voc = Generator(hcfg)
+            voc.load_state_dict({k: torch.from_numpy(v) for k, v in synth_hifigan_state_dict(hcfg, 1234).items()})
+            voc = voc.to(dev).eval()
+            vb = min(B, 32)
+            with torch.no_grad():
+                mel_v = net(x)[0][:vb].contiguous()                      # (vb, L, 80): the acoustic model's own output
+                for _ in range(2):
+                    wav = voc(mel_v.transpose(1, 2))
+                torch.cuda.synchronize(dev)
+                t0 = time.perf_counter()
+                for _ in range(5):
+                    wav = voc(mel_v.transpose(1, 2))
+                torch.cuda.synchronize(dev)
+                tv = (time.perf_counter() - t0) / 5
+            vf = flops_per_mel_frame(hcfg) * vb * L / tv / 1e12
+            voc_fps, am_fps = vb * L / tv, out["value"]
+            out["vocoder"] = {"workload": f"hifigan_v2 generator, B={vb} x L={L} mel frames -> {L * hcfg.hop} samples each",
+                              "ms": tv * 1e3, "mel_frames_per_s": voc_fps, "x_realtime": voc_fps * hcfg.hop / 22050.0,
+                              "achieved_tflops": vf, "frac_of_833": vf / (F16_PEAK_TFLOPS / 3.0),
+                              "text_to_wav_frames_per_s": 1.0 / (1.0 / am_fps + 1.0 / voc_fps),
+                              "finite": bool(torch.isfinite(wav).all()),
+                              "note": "synthetic seeded generator weights; 20 launches (one per ResBlock, csrc/hifigan_resblock.h); "
+                                      "text_to_wav = acoustic model and vocoder back to back on one GPU"}
+            del voc, wav, mel_v
     if rank == 0:
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, sd, T, a.dur)

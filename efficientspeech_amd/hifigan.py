@@ -229,6 +229,19 @@ def get_hifigan(checkpoint="hifigan/LJ_V2/generator_v2", infer_device=None, verb
     return voc
 
 
+def flops_per_mel_frame(h: HifiGanConfig):
+    """Algorithmic FLOPs (2 per multiply-add, convolutions only) the generator spends per input mel frame."""
+    c, rate, f = h.upsample_initial_channel, 1, 2 * h.num_mels * h.upsample_initial_channel * 7
+    for u, k in zip(h.upsample_rates, h.upsample_kernel_sizes):
+        rate *= u
+        f += rate * 2 * c * (c // 2) * (k // u)
+        c //= 2
+        per_conv = 2 if h.resblock == "1" else 1
+        for kk, d in zip(h.resblock_kernel_sizes, h.resblock_dilation_sizes):
+            f += rate * len(d) * per_conv * 2 * c * c * kk
+    return f + rate * 2 * c * 7
+
+
 def hifigan_state_dict_spec(h: HifiGanConfig):
     """[(key, shape)] of Generator.state_dict() after remove_weight_norm, in the reference's registration order."""
     spec = []

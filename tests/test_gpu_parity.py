@@ -572,3 +572,26 @@ def test_hifigan_end_to_end_vs_oracle():
     assert wav.shape == ref.shape == (B, o.mel.shape[1] * 256)
     assert np.array_equal(mel_len.cpu().numpy(), o.mel_len)
     assert np.abs(wav.cpu().numpy() - ref).max() < 2e-4
+
+
+@pytest.mark.parametrize("config,B,L", [("v2", 16, 768), ("v1", 2, 300), ("v3", 3, 411)])
+def test_hifigan_one_launch_resblocks_match_conv_by_conv(config, B, L):
+    """The one-launch ResBlock kernel (csrc/hifigan_resblock.h: windows with halos, several per utterance at these lengths,
+    ragged last window) against the conv-by-conv chain of the same library -- two independent HIP paths, at the size the
+    bench's vocoder leg runs (v2) and through the channel counts that have / have no fused instantiation (v1, v3)."""
+    from efficientspeech_amd.hifigan import HIFIGAN_CONFIGS, Generator, synth_hifigan_state_dict
+    h = HIFIGAN_CONFIGS[config]
+    voc = Generator(h)
+    voc.load_state_dict({k: torch.from_numpy(v) for k, v in synth_hifigan_state_dict(h, 1234).items()}, strict=True)
+    voc = voc.to(DEV).eval()
+    g = torch.Generator(device=DEV).manual_seed(5)
+    mel = torch.randn((B, L, h.num_mels), device=DEV, generator=g) * 2 - 4
+    outs = []
+    for fused in (True, False):
+        voc.fuse_resblocks = fused
+        voc._cache.invalidate()
+        with torch.no_grad():
+            outs.append(voc(mel.transpose(1, 2)))
+    assert outs[0].shape == (B, 1, L * h.hop) and bool(torch.isfinite(outs[0]).all())
+    assert float((outs[0] - outs[1]).abs().max()) < 2e-5
+    assert float(outs[0].abs().max()) > 1e-3      # a real signal, not zeros

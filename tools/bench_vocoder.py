@@ -4,25 +4,13 @@ import argparse, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np, torch
-from efficientspeech_amd.hifigan import HIFIGAN_CONFIGS, Generator, synth_hifigan_state_dict
+from efficientspeech_amd.hifigan import HIFIGAN_CONFIGS, Generator, synth_hifigan_state_dict, flops_per_mel_frame
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--config", default="v2"); ap.add_argument("--batch", type=int, default=16); ap.add_argument("--frames", type=int, default=768)
 ap.add_argument("--iters", type=int, default=5)
 a = ap.parse_args()
 h = HIFIGAN_CONFIGS[a.config]
-
-
-def flops_per_frame(h):
-    c, rate, f = h.upsample_initial_channel, 1, 2 * h.num_mels * h.upsample_initial_channel * 7
-    for u, k in zip(h.upsample_rates, h.upsample_kernel_sizes):
-        rate *= u
-        f += rate * 2 * c * (c // 2) * (k // u)
-        c //= 2
-        per_conv = 2 if h.resblock == "1" else 1
-        for kk, d in zip(h.resblock_kernel_sizes, h.resblock_dilation_sizes):
-            f += rate * len(d) * per_conv * 2 * c * c * kk
-    return f + rate * 2 * c * 7
 
 
 voc = Generator(h)
@@ -38,7 +26,7 @@ with torch.no_grad():
         wav = voc(mel.transpose(1, 2))
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / a.iters
-fl = flops_per_frame(h)
+fl = flops_per_mel_frame(h)
 frames = a.batch * a.frames
 print(f"hifigan {a.config}: B={a.batch} L={a.frames}: {dt*1e3:.2f} ms  {frames/dt:.3e} mel-frames/s  {frames*h.hop/dt/22050:.1f}x real time  "
       f"{fl/1e6:.1f} MFLOP/frame -> {fl*frames/dt/1e12:.1f} TFLOP/s   finite={bool(torch.isfinite(wav).all())}")
