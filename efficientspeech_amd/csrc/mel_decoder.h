@@ -60,6 +60,9 @@
 #ifndef ESMI_DEC_LN_SPREAD
 #define ESMI_DEC_LN_SPREAD 1
 #endif
+#ifndef ESMI_DEC_ST_NT
+#define ESMI_DEC_ST_NT 0   // 1: the mel rows leave with nontemporal stores (tried against the ~6 us bubble either side of the kernel: 0.283 vs 0.278 ms/step, no gain)
+#endif
 #ifndef ESMI_DEC_YOUNG_PRIO
 #define ESMI_DEC_YOUNG_PRIO 0   // static s_setprio for waves 4-7 (the arbitration losers of every phase on their SIMD)
 #endif
@@ -806,7 +809,11 @@ __global__ __launch_bounds__(64 * NW, (DX2 <= 128 ? ESMI_DEC_WPS : NW / 4)) void
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = live ? fmaf(acc[mt][t][4 * g + e], WSI, bc[e]) : 0.0f;
                     if (vec_ok) {
+#if ESMI_DEC_ST_NT && !defined(ESMI_WAVESIM)
+                        __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(orow + col));
+#else
                         *reinterpret_cast<f32x4*>(orow + col) = v;
+#endif
                     } else {
 #pragma unroll
                         for (int e = 0; e < 4; ++e)
