@@ -14,6 +14,7 @@ Prints ONE JSON line (rank 0):
                          v_mfma_f32_32x32x2_f32, with its own kernel time and fraction of the 157.3 TFLOP/s fp32-MFMA peak
   decoder_only           (N=1) MelDecoder.forward alone on frame-rate features ~ N(0,1)
   allgather              (N>1) the mel all-gather timed by itself: GB/s received per rank vs 7 xGMI links x 76.8 GB/s
+  without_allgather      (N>1) the same sharded steps with the exchange switched off (compute scaling next to the link-bound value)
   vocoder                (N=1) the HiFi-GAN v2 generator on the mel the forward produced: mel-frames/s, TFLOP/s
   cpu_baseline           (N=1) the C oracle (oracle/, fp32 accumulation, OpenMP) on this box's host cores: all cores and
                          n=24 (the reference's --threads default), plus the B=1 fox-sentence latency (BASELINE configs[0]) --
@@ -317,6 +318,20 @@ def main():
                             "frac_of_links_in_use": recv / tg / 1e9 / (min(world - 1, XGMI_LINKS) * XGMI_LINK_GBS),
                             "note": "all_gather_into_tensor of the (B, L, 80) fp32 mel shards alone, blocking; in the timed steps it "
                                     "runs on a side stream under the next step's compute"}
+
+    if world > 1 and pipe.gather:
+        # the same steps with the exchange switched off: what the shards compute when nobody collects the mels.  Every rank
+        # RECEIVES (N-1) x 62.9 MB per step in the timed region above, so its rate is capped by its xGMI ingress
+        # (7 links x 76.8 GB/s / 320 B per frame = 1.7e9 frames/s per rank whatever N is); this line separates the two.
+        steps2, warm2 = max(10, a.steps // 2), max(5, a.warmup // 2)
+        pipe_ng = ShardedMelPipeline(net, world_size=world, gather=False)
+        dt2, _, _ = timed_steps(pipe_ng, net, x, steps2, warm2, sync_all, 1 << 30, False)
+        tt = torch.tensor([dt2], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt2 = float(tt.item())
+        out["without_allgather"] = {"value": frames_per_step * steps2 / dt2, "ms_per_step": dt2 / steps2 * 1e3, "steps": steps2,
+                                    "note": "same shards, same barrier/max-over-ranks timing, mels left on the rank that made them"}
+        del pipe_ng
 
     if rank == 0 and world == 1 and not a.no_extras:
         steps2, warm2 = max(10, a.steps // 2), max(5, a.warmup // 2)

@@ -155,7 +155,9 @@ int launch_enc_merge_qkv(const EncMergeP& p, int c_in, int c_out, hipStream_t st
 bool enc_attn_ffn_supported(int C, int N, int expansion) {
     if ((C & 31) || N > 256 || N < 1) return false;
     const int nc = C / 32;
-    return (expansion == 1 && (nc == 1 || nc == 2 || nc == 4)) || (expansion == 2 && nc == 4);
+    // base ES block 0 (C = 128, expansion 2) at N = 256: the chain kernel runs one latency chain per 32 rows against 256 keys
+    // (2.00 ms at B = 512); the same ops as LDS-staged GEMM launches take 1.33 ms, so that shape goes per-op
+    return (expansion == 1 && (nc == 1 || nc == 2 || nc == 4)) || (expansion == 2 && nc == 4 && N <= 128);
 }
 
 // Whole encoder block (merge conv + qkv + attention + MixFFN) in one launch: sequences one workgroup covers, shapes
@@ -287,11 +289,16 @@ namespace {
 // instantiation; `false` from resblock_fused_ok -> the caller runs the block conv by conv.
 template <int C, int K>
 int launch_resblock_ck(const ResblockP& p, hipStream_t st) {
-    static AttrOnce once;
     const size_t lds = rb_lds_bytes(C, p.R);
-    if (lds > 48 * 1024)
-        if (int rc = raise_lds_limit(reinterpret_cast<const void*>(hifigan_resblock_kernel<C, K>), once)) return rc;
-    ESMI_LAUNCH((hifigan_resblock_kernel<C, K>), dim3((unsigned)(p.B * p.tiles_per_b)), dim3(64 * kRbWaves), lds, st, p);
+    const dim3 grid((unsigned)(p.B * p.tiles_per_b)), block(64 * kRbWaves);
+    if constexpr (C <= 16) {   // narrow MFMA tiles (16 channels x 16 positions): LDS <= 32 KB, no limit to raise
+        ESMI_LAUNCH((hifigan_resblock16_kernel<C, K>), grid, block, lds, st, p);
+    } else {
+        static AttrOnce once;
+        if (lds > 48 * 1024)
+            if (int rc = raise_lds_limit(reinterpret_cast<const void*>(hifigan_resblock_kernel<C, K>), once)) return rc;
+        ESMI_LAUNCH((hifigan_resblock_kernel<C, K>), grid, block, lds, st, p);
+    }
     return launch_status();
 }
 template <int C>
@@ -372,6 +379,11 @@ size_t esmi_pack_resblock_bytes(int c, int k) {
 int esmi_pack_resblock_f16(const float* src, void* dst, int c, int k, esmi_stream_t stream) {
     if (!src || !dst) return ESMI_ERR_ARG;
     if (!esmi_pack_resblock_bytes(c, k)) return ESMI_ERR_UNSUPPORTED;
+    if (c <= 16) {
+        const long n16 = (long)rb_ksteps16(c, k) * 64;
+        ESMI_LAUNCH(pack_resblock16_kernel, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, S(stream), src, static_cast<unsigned*>(dst), c, k);
+        return launch_status();
+    }
     const long n = (long)rb_mtiles(c) * rb_ksteps(c, k) * 64;
     ESMI_LAUNCH(pack_resblock_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, S(stream), src, static_cast<unsigned*>(dst), c, k);
     return launch_status();

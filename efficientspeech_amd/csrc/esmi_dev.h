@@ -187,6 +187,15 @@ __device__ __forceinline__ f32x16 mfma32_f16(const u32x4& a, const u32x4& b, f32
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
 #endif
 }
+// v_mfma_f32_16x16x32_f16 (gfx950): A[i = lane&15][k = 8*(lane>>4) + (0..7)], B[k][j = lane&15]; D reg r: row 4*(lane>>4) + r, col lane&15
+__device__ __forceinline__ f32x4 mfma16_f16(const u32x4& a, const u32x4& b, f32x4 c) {
+#ifdef ESMI_WAVESIM
+    return wavesim::mfma_16x16x32_f16(a, b, c);
+#else
+    typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+#endif
+}
 // acc += A(32 x 16, fp32 split on the fly) . B(16 x 32, pre-scaled pre-split planes); the caller rescales by kF16WScaleInv
 __device__ __forceinline__ f32x16 mfma32_split2(const f16x2p& a, const u32x4& b1, const u32x4& b2, f32x16 c) {
     c = mfma32_f16(a.h2, b1, c);

@@ -47,10 +47,13 @@ struct ResblockP {
     RbConv conv[kRbMaxConv];
 };
 
-__host__ __device__ constexpr int rb_row_bytes(int c) { return 2 * c + (c == 8 ? 0 : 16); }   // per plane; conflict-free 16-byte reads
+// per plane.  C >= 32 (32x32x16 tiles: lane = position, 32 consecutive rows per read): 16 pad bytes make the 16-byte reads
+// conflict-free; C <= 16 (16x16x32 tiles: 16 consecutive rows, the k-blocks of a lane group 16 bytes or one tap apart): unpadded
+__host__ __device__ constexpr int rb_row_bytes(int c) { return 2 * c + (c <= 16 ? 0 : 16); }
+__host__ __device__ constexpr int rb_ksteps16(int c, int k) { return (c * k + 31) / 32; }
 __host__ __device__ constexpr int rb_ksteps(int c, int k) { return (c * k + 15) / 16; }
 __host__ __device__ constexpr int rb_mtiles(int c) { return c > 32 ? c / 32 : 1; }
-__host__ __device__ inline size_t rb_pack_dwords(int c, int k) { return (size_t)rb_mtiles(c) * rb_ksteps(c, k) * 2 * 64 * 4; }
+__host__ __device__ inline size_t rb_pack_dwords(int c, int k) { return (size_t)(c <= 16 ? rb_ksteps16(c, k) : rb_mtiles(c) * rb_ksteps(c, k)) * 2 * 64 * 4; }
 __host__ __device__ inline size_t rb_lds_bytes(int c, int R) { return (size_t)2 * R * rb_row_bytes(c); }
 
 // (k, C, C) tap-major fp32 -> A fragments, scaled by 2^8, two nearest-rounded binary16 pieces
@@ -67,6 +70,29 @@ __global__ void pack_resblock_kernel(const float* __restrict__ w, unsigned* __re
         v[e] = (co < c && tap < k) ? w[((long)tap * c + co) * c + ci] * kF16WScale : 0.0f;
     }
     unsigned* d = dst + ((long)(m * steps + s) * 2) * 256 + lane * 4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        unsigned h1, h2;
+        split_f16_pair_rn(v[2 * j], v[2 * j + 1], h1, h2);
+        d[j] = h1;
+        d[256 + j] = h2;
+    }
+}
+
+// the same for the 16x16x32 tiles of C <= 16: [step][plane 2][lane 64][4 dwords], lane = (co = lane & 15, k-block = lane >> 4)
+__global__ void pack_resblock16_kernel(const float* __restrict__ w, unsigned* __restrict__ dst, int c, int k) {
+    const int steps = rb_ksteps16(c, k);
+    const long q = (long)blockIdx.x * blockDim.x + threadIdx.x;   // (step, lane)
+    if (q >= (long)steps * 64) return;
+    const int lane = (int)(q & 63), s = (int)(q >> 6);
+    const int co = lane & 15, kb = lane >> 4;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int kidx = 32 * s + 8 * kb + e, tap = kidx / c, ci = kidx - tap * c;
+        v[e] = (co < c && tap < k) ? w[((long)tap * c + co) * c + ci] * kF16WScale : 0.0f;
+    }
+    unsigned* d = dst + ((long)s * 2) * 256 + lane * 4;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         unsigned h1, h2;
@@ -236,6 +262,127 @@ __global__ __launch_bounds__(64 * kRbWaves, ESMI_RB_WPS) void hifigan_resblock_k
             for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
                 for (int g = 0; g < CG; ++g) put_planes(row0 + 32 * tt, 32 * mt + 8 * g + 4 * h, pl[tt][g]);
+        }
+        __syncthreads();       // the new planes are complete
+    }
+}
+
+// ---- C <= 16: the same kernel on v_mfma_f32_16x16x32_f16 tiles.  A 32-row MFMA tile would be 1/2 (C = 16) or 3/4 (C = 8)
+// zero padding, and these two stages issue 56 % of all MFMAs of the v2 generator; 16 output channels x 16 positions x 32
+// contraction elements per instruction fit C = 16 exactly and halve the matrix-pipe time of both.  A wave owns 64 positions
+// = four 16-position tiles; the conv's weight fragments (<= 6 steps x 2 planes) stay in registers for the whole K loop and the
+// next conv's are fetched under the epilogue and the barriers, so the K loop is LDS reads + MFMAs only.
+//   A[co = lane&15][32s + 8kb + e] (kb = lane>>4),  B[32s + 8kb + e][pos = lane&15],  D: channels 4kb..4kb+3 of position lane&15
+template <int C, int K>
+__global__ __launch_bounds__(64 * kRbWaves, ESMI_RB_WPS) void hifigan_resblock16_kernel(const ResblockP p) {
+    static_assert(C == 8 || C == 16, "narrow-tile kernel");
+    constexpr int RS = rb_row_bytes(C), STEPS = rb_ksteps16(C, K), HALF = (K - 1) / 2;
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    ESMI_DYN_LDS(lds_f);
+    char* lds = reinterpret_cast<char*>(lds_f);
+    const int lane = lane_id(), w = wave_id(), n = lane & 15, kb = lane >> 4;
+    const bool active = w * 64 < p.R, chan_ok = 4 * kb < C;      // C = 8: k-blocks 2, 3 hold the zero rows of the M tile
+    const int b = (int)blockIdx.x / p.tiles_per_b;
+    const int t0 = ((int)blockIdx.x - b * p.tiles_per_b) * p.TL - p.halo;
+    const int plane = p.R * RS;
+    const int row0 = 64 * w + n;
+
+    f32x4 xres[4];
+    bool inside[4];
+    auto split4 = [&](const f32x4& v) __attribute__((always_inline)) {
+        const f32x4 a = lrelu4(v, p.slope);
+        unsigned h1a, h2a, h1b, h2b;
+        split_f16_pair(a[0], a[1], h1a, h2a);
+        split_f16_pair(a[2], a[3], h1b, h2b);
+        return u32x4{h1a, h1b, h2a, h2b};
+    };
+    auto put_planes = [&](int row, const u32x4& v) __attribute__((always_inline)) {
+        char* d = lds + row * RS + 8 * kb;
+        *reinterpret_cast<u32x2*>(d) = u32x2{v[0], v[1]};
+        *reinterpret_cast<u32x2*>(d + plane) = u32x2{v[2], v[3]};
+    };
+    u32x4 wf[STEPS][2];
+    auto wfetch = [&](int ci) __attribute__((always_inline)) {
+        if (ci < p.n_conv && n < C) {              // rows past C are zero padding: those lanes keep their zeros
+            const unsigned* q = p.conv[ci].wp + lane * 4;
+#pragma unroll
+            for (int s = 0; s < STEPS; ++s) {
+                wf[s][0] = *reinterpret_cast<const u32x4*>(q + s * 512);
+                wf[s][1] = *reinterpret_cast<const u32x4*>(q + s * 512 + 256);
+            }
+        }
+    };
+#pragma unroll
+    for (int s = 0; s < STEPS; ++s) wf[s][0] = wf[s][1] = u32x4{0, 0, 0, 0};
+    if (active) {
+        wfetch(0);
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            const int row = row0 + 16 * nt, pos = t0 + row;
+            inside[nt] = pos >= 0 && pos < p.n;
+            xres[nt] = (inside[nt] && chan_ok) ? ld4(p.x + ((long)b * p.n + pos) * C + 4 * kb) : zero4();
+            if (chan_ok) put_planes(row, split4(xres[nt]));
+        }
+    }
+    __syncthreads();
+
+    for (int ci = 0; ci < p.n_conv; ++ci) {
+        const bool last = ci + 1 == p.n_conv;
+        u32x4 pl[4];
+        if (active) {
+            const int dil = p.conv[ci].dil;
+            f32x4 acc[4] = {zero4(), zero4(), zero4(), zero4()};
+#pragma unroll
+            for (int s = 0; s < STEPS; ++s) {
+                const int kidx = 32 * s + 8 * kb;
+                int tap = kidx / C;
+                const int ch = kidx - tap * C;
+                tap = tap < K ? tap : K - 1;       // zero weight columns past the last tap: any finite row will do
+                const int shift = (tap - HALF) * dil;
+                u32x4 x1[4], x2[4];
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) {
+                    int r = row0 + 16 * nt + shift;
+                    r = r < 0 ? 0 : (r >= p.R ? p.R - 1 : r);
+                    const char* a = lds + opaque_i(r * RS + ch * 2);
+                    x1[nt] = *reinterpret_cast<const u32x4*>(a);
+                    x2[nt] = *reinterpret_cast<const u32x4*>(a + plane);
+                }
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) {
+                    acc[nt] = mfma16_f16(wf[s][0], x2[nt], acc[nt]);
+                    acc[nt] = mfma16_f16(wf[s][1], x1[nt], acc[nt]);
+                    acc[nt] = mfma16_f16(wf[s][0], x1[nt], acc[nt]);
+                }
+            }
+            wfetch(ci + 1);                        // under the epilogue and the two barriers
+            const f32x4 bv = chan_ok ? ld4(p.conv[ci].bias + 4 * kb) : zero4();
+            const bool add_res = p.conv[ci].add_res != 0;
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                const int row = row0 + 16 * nt;
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = fmaf(acc[nt][e], kF16WScaleInv, bv[e]);
+                if (add_res) v = v + xres[nt];
+                if (!inside[nt]) v = zero4();
+                if (last) {
+                    if (chan_ok && inside[nt] && row >= p.halo && row < p.halo + p.TL) {
+                        float* o = p.out + ((long)b * p.n + t0 + row) * C + 4 * kb;
+                        if (p.accum) v = v + ld4(o);
+                        *reinterpret_cast<f32x4*>(o) = v;
+                    }
+                } else {
+                    if (add_res) xres[nt] = v;
+                    pl[nt] = split4(v);
+                }
+            }
+        }
+        if (last) break;
+        __syncthreads();       // every wave has read what it needs of the old planes
+        if (active && chan_ok) {
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) put_planes(row0 + 16 * nt, pl[nt]);
         }
         __syncthreads();       // the new planes are complete
     }

@@ -137,6 +137,26 @@ static inline ws_f32x16 mfma_32x32x16_f16(const V4& a, const V4& b, ws_f32x16 c)
     return d;
 }
 
+// v_mfma_f32_16x16x32_f16: lane (i = l&15, kb = l>>4) holds A[i][8kb..8kb+7] / B[8kb..8kb+7][i]; D as the 16x16x4 fp32 MFMA
+template <class V4>
+static inline ws_f32x4 mfma_16x16x32_f16(const V4& a, const V4& b, ws_f32x4 c) {
+    uint32_t w[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    const uint32_t* t = wave_exchange(w, 8);
+    const int l = lane_id();
+    auto elem = [&](int lane, int base, int k) {
+        const uint32_t d = t[lane * 8 + base + (k >> 1)];
+        return ws_half_to_float((k & 1) ? (d >> 16) : (d & 0xFFFFu));
+    };
+    ws_f32x4 d = c;
+    for (int r = 0; r < 4; ++r) {
+        const int row = 4 * (l >> 4) + r, col = l & 15;
+        float acc = c[r];
+        for (int k = 0; k < 32; ++k) acc = fmaf(elem(row + 16 * (k >> 3), 0, k & 7), elem(col + 16 * (k >> 3), 4, k & 7), acc);
+        d[r] = acc;
+    }
+    return d;
+}
+
 static inline ws_f32x4 mfma_16x16x4(float a, float b, ws_f32x4 c) {
     uint32_t w[2] = {f2u(a), f2u(b)};
     const uint32_t* t = wave_exchange(w, 2);
