@@ -98,9 +98,9 @@ def cpu_baseline(cfg, sd, T, dur):
         else:
             mask = None
         d = np.full(ids.shape, dur, np.int32)
-        z = np.zeros(ids.shape, np.float32)
         t0 = time.perf_counter()
-        o = oracle.phoneme2mel(cfg, w, ids, mask, pitch=z, energy=z, duration=d, f32=True)
+        # the same data flow as the timed GPU step: eval path (predicted pitch / energy bucketised), injected durations
+        o = oracle.phoneme2mel(cfg, w, ids, mask, pitch=None, energy=None, duration=d, f32=True)
         return int(o.mel_len.sum()), time.perf_counter() - t0
 
     def sample(threads, b, reps):
