@@ -75,6 +75,18 @@ class HifiGanShape(C.Structure):
                 ("rb_kernels", C.c_int * HIFIGAN_MAX_KERNELS), ("rb_dilations", C.c_int * (HIFIGAN_MAX_KERNELS * 3))]
 
 
+class ConvDesc(C.Structure):
+    """esmi_conv_desc (include/esmi.h): one convolution of the training step, checkpoint weight layout."""
+    _fields_ = [(n, C.c_int) for n in ("B", "n_in", "c_in", "n_out", "c_out", "k", "stride", "pad", "groups", "transposed")]
+
+
+class TrainLossArgs(C.Structure):
+    """esmi_train_loss_args (include/esmi.h): model.py:167-216."""
+    _fields_ = [(n, fp) for n in ("mel_pred", "mel", "pitch_pred", "pitch", "energy_pred", "energy", "dur_pred", "dur", "mel_mask",
+                                  "ph_mask")] + [(n, C.c_int) for n in ("B", "T", "L", "n_mel")] + \
+               [(n, fp) for n in ("out", "d_mel", "d_pitch", "d_energy", "d_dur")]
+
+
 class ForwardArgs(C.Structure):
     """esmi_forward_args (include/esmi.h): the whole inference forward behind one call."""
     _fields_ = [(n, C.c_int) for n in ("B", "T", "depth", "dim", "fuse_kernel", "plan")] + \
@@ -122,6 +134,11 @@ EXPORTS = (
     "esmi_acoustic_decoder_f32", "esmi_bucket_embedding_f32", "esmi_split_weight_limit", "esmi_absmax_f32",
     "esmi_forward_arena_bytes", "esmi_phoneme2mel_forward_f32", "esmi_hifigan_workspace_bytes", "esmi_hifigan_generator_f32",
     "esmi_pack_resblock_bytes", "esmi_pack_resblock_f16",
+    "esmi_train_conv_fwd_f32", "esmi_train_conv_dgrad_f32", "esmi_train_conv_wgrad_f32", "esmi_train_layernorm_fwd_f32",
+    "esmi_train_layernorm_bwd_f32", "esmi_train_act_fwd_f32", "esmi_train_act_bwd_f32", "esmi_train_attention_fwd_f32",
+    "esmi_train_attention_bwd_f32", "esmi_train_embedding_fwd_f32", "esmi_train_embedding_bwd_f32", "esmi_train_mask_rows_f32",
+    "esmi_train_add_f32", "esmi_train_copy_cols_f32", "esmi_train_repeat_fwd_f32", "esmi_train_repeat_bwd_f32",
+    "esmi_train_loss_f32", "esmi_train_adamw_f32",
 )
 
 
@@ -174,6 +191,25 @@ def bind(lib):
     lib.esmi_forward_arena_bytes.argtypes = [P(ForwardArgs)]
     lib.esmi_forward_arena_bytes.restype = sz
     lib.esmi_phoneme2mel_forward_f32.argtypes = [P(ForwardArgs), i, fp]
+    i64, f = C.c_int64, C.c_float
+    lib.esmi_train_conv_fwd_f32.argtypes = [P(ConvDesc), fp, fp, fp, fp, fp]
+    lib.esmi_train_conv_dgrad_f32.argtypes = [P(ConvDesc), fp, fp, fp, fp]
+    lib.esmi_train_conv_wgrad_f32.argtypes = [P(ConvDesc), fp, fp, fp, fp, fp]
+    lib.esmi_train_layernorm_fwd_f32.argtypes = [fp, fp, fp, i64, i, fp, fp, fp, fp]
+    lib.esmi_train_layernorm_bwd_f32.argtypes = [fp, fp, fp, fp, fp, i64, i, fp, fp, fp, fp]
+    lib.esmi_train_act_fwd_f32.argtypes = [fp, i64, i, fp, fp]
+    lib.esmi_train_act_bwd_f32.argtypes = [fp, fp, i64, i, fp, fp]
+    lib.esmi_train_attention_fwd_f32.argtypes = [fp, i, i, i, i, fp, fp, fp]
+    lib.esmi_train_attention_bwd_f32.argtypes = [fp, fp, fp, i, i, i, i, fp, fp, fp]
+    lib.esmi_train_embedding_fwd_f32.argtypes = [fp, fp, i64, i, i, fp, fp]
+    lib.esmi_train_embedding_bwd_f32.argtypes = [fp, fp, i64, i, i, i, fp, fp]
+    lib.esmi_train_mask_rows_f32.argtypes = [fp, fp, i64, i, fp, fp]
+    lib.esmi_train_add_f32.argtypes = [fp, fp, i64, fp, fp]
+    lib.esmi_train_copy_cols_f32.argtypes = [fp, i, i, fp, i, i, i64, i, fp]
+    lib.esmi_train_repeat_fwd_f32.argtypes = [fp, fp, i, i, i, i, fp, fp]
+    lib.esmi_train_repeat_bwd_f32.argtypes = [fp, fp, i, i, i, i, fp, fp]
+    lib.esmi_train_loss_f32.argtypes = [P(TrainLossArgs), fp]
+    lib.esmi_train_adamw_f32.argtypes = [fp, fp, fp, fp, i64, f, f, f, f, f, i, fp]
     lib.esmi_pack_resblock_bytes.argtypes = [i, i]
     lib.esmi_pack_resblock_bytes.restype = sz
     lib.esmi_pack_resblock_f16.argtypes = [fp, fp, i, i, fp]

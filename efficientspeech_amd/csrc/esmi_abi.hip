@@ -9,6 +9,7 @@
 #include "attention.h"
 #include "convgemm.h"
 #include "hifigan_resblock.h"
+#include "train_ops.h"
 #include "enc_attn_ffn.h"
 #include "enc_fuse_va.h"
 #include "enc_merge_qkv.h"
@@ -1174,6 +1175,140 @@ int esmi_phoneme2mel_forward_f32(const esmi_forward_args* a, int stage, esmi_str
         if (rc) return rc;
     }
     return ESMI_OK;
+}
+
+// ------------------------------------------------------------------ training step (csrc/train_ops.h)
+namespace {
+inline unsigned grid1d(long n, int block = 256) { return (unsigned)((n + block - 1) / block); }
+int conv_desc_ok(const esmi_conv_desc* d, ConvDesc* o) {
+    if (!d || d->B <= 0 || d->n_in <= 0 || d->n_out <= 0 || d->c_in <= 0 || d->c_out <= 0 || d->k <= 0 || d->stride <= 0 || d->pad < 0 ||
+        d->groups <= 0)
+        return ESMI_ERR_ARG;
+    if (d->groups != 1 && (d->transposed || d->c_in % d->groups || d->c_out % d->groups)) return ESMI_ERR_UNSUPPORTED;
+    *o = ConvDesc{d->B, d->n_in, d->c_in, d->n_out, d->c_out, d->k, d->stride, d->pad, d->groups, d->transposed ? 1 : 0};
+    return ESMI_OK;
+}
+}  // namespace
+
+int esmi_train_conv_fwd_f32(const esmi_conv_desc* d, const float* x, const float* w, const float* bias, float* y, esmi_stream_t stream) {
+    ConvDesc c;
+    if (int rc = conv_desc_ok(d, &c)) return rc;
+    if (!x || !w || !y) return ESMI_ERR_ARG;
+    const long n = (long)c.B * c.n_out * c.c_out;
+    ESMI_LAUNCH(train_conv_fwd_kernel, grid1d(n), dim3(256), 0, S(stream), c, x, w, bias, y);
+    return launch_status();
+}
+int esmi_train_conv_dgrad_f32(const esmi_conv_desc* d, const float* dy, const float* w, float* dx, esmi_stream_t stream) {
+    ConvDesc c;
+    if (int rc = conv_desc_ok(d, &c)) return rc;
+    if (!dy || !w || !dx) return ESMI_ERR_ARG;
+    const long n = (long)c.B * c.n_in * c.c_in;
+    ESMI_LAUNCH(train_conv_dgrad_kernel, grid1d(n), dim3(256), 0, S(stream), c, dy, w, dx);
+    return launch_status();
+}
+int esmi_train_conv_wgrad_f32(const esmi_conv_desc* d, const float* x, const float* dy, float* dw, float* dbias, esmi_stream_t stream) {
+    ConvDesc c;
+    if (int rc = conv_desc_ok(d, &c)) return rc;
+    if (!x || !dy || !dw) return ESMI_ERR_ARG;
+    const long n = (long)(c.transposed ? c.c_in * c.c_out : c.c_out * (c.c_in / c.groups)) * c.k;
+    ESMI_LAUNCH(train_conv_wgrad_kernel, grid1d(n, 64), dim3(64), 0, S(stream), c, x, dy, dw);
+    if (int rc = launch_status()) return rc;
+    if (dbias) {
+        ESMI_LAUNCH(train_colsum_kernel, grid1d(c.c_out, 64), dim3(64), 0, S(stream), dy, (long)c.B * c.n_out, c.c_out, dbias);
+        return launch_status();
+    }
+    return ESMI_OK;
+}
+int esmi_train_layernorm_fwd_f32(const float* x, const float* g, const float* b, int64_t rows, int C, float* y, float* mean,
+                                 float* rstd, esmi_stream_t stream) {
+    if (!x || !g || !b || !y || !mean || !rstd || rows <= 0 || C <= 0) return ESMI_ERR_ARG;
+    ESMI_LAUNCH(train_ln_fwd_kernel, grid1d(rows, 64), dim3(64), 0, S(stream), x, g, b, (long)rows, C, 1e-5f, y, mean, rstd);
+    return launch_status();
+}
+int esmi_train_layernorm_bwd_f32(const float* x, const float* g, const float* mean, const float* rstd, const float* dy,
+                                 int64_t rows, int C, float* dx, float* dg, float* db, esmi_stream_t stream) {
+    if (!x || !g || !mean || !rstd || !dy || !dx || !dg || !db || rows <= 0 || C <= 0) return ESMI_ERR_ARG;
+    ESMI_LAUNCH(train_ln_bwd_dx_kernel, grid1d(rows, 64), dim3(64), 0, S(stream), x, g, mean, rstd, dy, (long)rows, C, dx);
+    if (int rc = launch_status()) return rc;
+    ESMI_LAUNCH(train_ln_bwd_params_kernel, grid1d(C, 64), dim3(64), 0, S(stream), x, mean, rstd, dy, (long)rows, C, dg, db);
+    return launch_status();
+}
+int esmi_train_act_fwd_f32(const float* x, int64_t n, int kind, float* y, esmi_stream_t stream) {
+    if (!x || !y || n <= 0 || kind < ACT_RELU || kind > ACT_TANH) return ESMI_ERR_ARG;
+    ESMI_LAUNCH(train_act_fwd_kernel, grid1d(n), dim3(256), 0, S(stream), x, (long)n, kind, y);
+    return launch_status();
+}
+int esmi_train_act_bwd_f32(const float* saved, const float* dy, int64_t n, int kind, float* dx, esmi_stream_t stream) {
+    if (!saved || !dy || !dx || n <= 0 || kind < ACT_RELU || kind > ACT_TANH) return ESMI_ERR_ARG;
+    ESMI_LAUNCH(train_act_bwd_kernel, grid1d(n), dim3(256), 0, S(stream), saved, dy, (long)n, kind, dx);
+    return launch_status();
+}
+int esmi_train_attention_fwd_f32(const float* qkv, int B, int N, int C, int h, float* P, float* ctx, esmi_stream_t stream) {
+    if (!qkv || !P || !ctx || B <= 0 || N <= 0 || C <= 0 || h <= 0 || C % h) return ESMI_ERR_ARG;
+    ESMI_LAUNCH(train_attn_fwd_kernel, grid1d((long)B * h * N, 64), dim3(64), 0, S(stream), qkv, B, N, C, h, 1.0f / sqrtf((float)(C / h)), P, ctx);
+    return launch_status();
+}
+int esmi_train_attention_bwd_f32(const float* qkv, const float* P, const float* dctx, int B, int N, int C, int h, float* dS,
+                                 float* dqkv, esmi_stream_t stream) {
+    if (!qkv || !P || !dctx || !dS || !dqkv || B <= 0 || N <= 0 || C <= 0 || h <= 0 || C % h) return ESMI_ERR_ARG;
+    const float scale = 1.0f / sqrtf((float)(C / h));
+    ESMI_LAUNCH(train_attn_bwd_rows_kernel, grid1d((long)B * h * N, 64), dim3(64), 0, S(stream), qkv, P, dctx, B, N, C, h, scale, dS, dqkv);
+    if (int rc = launch_status()) return rc;
+    ESMI_LAUNCH(train_attn_bwd_cols_kernel, grid1d((long)B * h * N, 64), dim3(64), 0, S(stream), qkv, P, dS, dctx, B, N, C, h, scale, dqkv);
+    return launch_status();
+}
+int esmi_train_embedding_fwd_f32(const int32_t* ids, const float* table, int64_t rows, int V, int C, float* out, esmi_stream_t stream) {
+    if (!ids || !table || !out || rows <= 0 || V <= 0 || C <= 0) return ESMI_ERR_ARG;
+    ESMI_LAUNCH(train_embed_fwd_kernel, grid1d(rows * C), dim3(256), 0, S(stream), ids, table, (long)rows, V, C, out);
+    return launch_status();
+}
+int esmi_train_embedding_bwd_f32(const int32_t* ids, const float* dy, int64_t rows, int V, int C, int padding_idx, float* dtable,
+                                 esmi_stream_t stream) {
+    if (!ids || !dy || !dtable || rows <= 0 || V <= 0 || C <= 0) return ESMI_ERR_ARG;
+    ESMI_LAUNCH(train_embed_bwd_kernel, grid1d((long)V * C, 64), dim3(64), 0, S(stream), ids, dy, (long)rows, V, C, padding_idx, dtable);
+    return launch_status();
+}
+int esmi_train_mask_rows_f32(const float* x, const uint8_t* mask, int64_t rows, int C, float* y, esmi_stream_t stream) {
+    if (!x || !mask || !y || rows <= 0 || C <= 0) return ESMI_ERR_ARG;
+    ESMI_LAUNCH(train_mask_rows_kernel, grid1d(rows * C), dim3(256), 0, S(stream), x, mask, (long)rows, C, y);
+    return launch_status();
+}
+int esmi_train_add_f32(const float* a, const float* b, int64_t n, float* y, esmi_stream_t stream) {
+    if (!a || !b || !y || n <= 0) return ESMI_ERR_ARG;
+    ESMI_LAUNCH(train_add_kernel, grid1d(n), dim3(256), 0, S(stream), a, b, (long)n, y);
+    return launch_status();
+}
+int esmi_train_copy_cols_f32(const float* src, int ld_src, int col_src, float* dst, int ld_dst, int col_dst, int64_t rows, int C,
+                             esmi_stream_t stream) {
+    if (!src || !dst || rows <= 0 || C <= 0 || col_src < 0 || col_dst < 0 || col_src + C > ld_src || col_dst + C > ld_dst) return ESMI_ERR_ARG;
+    ESMI_LAUNCH(train_copy_cols_kernel, grid1d(rows * C), dim3(256), 0, S(stream), src, ld_src, col_src, dst, ld_dst, col_dst, (long)rows, C);
+    return launch_status();
+}
+int esmi_train_repeat_fwd_f32(const float* feat, const int32_t* cum, int B, int T, int C, int L, float* out, esmi_stream_t stream) {
+    if (!feat || !cum || !out || B <= 0 || T <= 0 || C <= 0 || L <= 0) return ESMI_ERR_ARG;
+    ESMI_LAUNCH(train_repeat_fwd_kernel, grid1d((long)B * L * C), dim3(256), 0, S(stream), feat, cum, B, T, C, L, out);
+    return launch_status();
+}
+int esmi_train_repeat_bwd_f32(const float* dout, const int32_t* cum, int B, int T, int C, int L, float* dfeat, esmi_stream_t stream) {
+    if (!dout || !cum || !dfeat || B <= 0 || T <= 0 || C <= 0 || L <= 0) return ESMI_ERR_ARG;
+    ESMI_LAUNCH(train_repeat_bwd_kernel, grid1d((long)B * T * C), dim3(256), 0, S(stream), dout, cum, B, T, C, L, dfeat);
+    return launch_status();
+}
+int esmi_train_loss_f32(const esmi_train_loss_args* a, esmi_stream_t stream) {
+    if (!a || !a->mel_pred || !a->mel || !a->pitch_pred || !a->pitch || !a->energy_pred || !a->energy || !a->dur_pred || !a->dur ||
+        !a->out || !a->d_mel || !a->d_pitch || !a->d_energy || !a->d_dur || a->B <= 0 || a->T <= 0 || a->L <= 0 || a->n_mel <= 0)
+        return ESMI_ERR_ARG;
+    LossP p = {a->mel_pred, a->mel, a->pitch_pred, a->pitch, a->energy_pred, a->energy, a->dur_pred, a->dur, a->mel_mask, a->ph_mask,
+               a->B, a->T, a->L, a->n_mel, a->out, a->d_mel, a->d_pitch, a->d_energy, a->d_dur};
+    ESMI_LAUNCH(train_loss_kernel, dim3(1), dim3(1024), 1024 * sizeof(float), S(stream), p);
+    return launch_status();
+}
+int esmi_train_adamw_f32(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+                         float weight_decay, int step, esmi_stream_t stream) {
+    if (!p || !g || !m || !v || n <= 0 || step < 1) return ESMI_ERR_ARG;
+    const float bc1 = 1.0f - powf(beta1, (float)step), bc2 = 1.0f - powf(beta2, (float)step);
+    ESMI_LAUNCH(train_adamw_kernel, grid1d(n), dim3(256), 0, S(stream), p, g, m, v, (long)n, lr, beta1, beta2, eps, weight_decay, bc1, sqrtf(bc2));
+    return launch_status();
 }
 
 }  // extern "C"

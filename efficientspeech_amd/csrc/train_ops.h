@@ -1,0 +1,401 @@
+// Training-step operators (model.py:167-226, 279-283): forward ops that keep what backward reads, their data-
+// and weight-gradient kernels, the fused masked loss and AdamW.
+//
+// FIRST CORRECT VERSION: every kernel is one thread per OUTPUT element with plain fp32 FMA loops -- no atomics anywhere, so
+// a training step is bitwise reproducible -- on channels-last activations (B, n, C) and weights in CHECKPOINT layout (what
+// the optimizer updates): Conv1d (Cout, Cin/groups, k), ConvTranspose1d (Cin, Cout, k), Linear (Cout, Cin) = Conv1d with k = 1.
+// The matrix-pipe versions of the same contractions (convgemm.h for the forward and data gradients, a split-K MFMA
+// reduction for the weight gradients) replace these one by one behind the same entry points.
+#pragma once
+#include "esmi_dev.h"
+
+namespace esmi {
+
+struct ConvDesc {   // mirrors esmi_conv_desc (include/esmi.h)
+    int B, n_in, c_in, n_out, c_out, k, stride, pad, groups, transposed;
+};
+
+// weight element for (output channel co, input channel ci, tap j); false when the pair is not connected (grouped conv)
+__device__ __forceinline__ bool conv_w_index(const ConvDesc& d, int co, int ci, int j, long* idx) {
+    if (d.transposed) { *idx = ((long)ci * d.c_out + co) * d.k + j; return true; }        // (Cin, Cout, k), groups == 1
+    const int cig = d.c_in / d.groups, cog = d.c_out / d.groups;
+    const int g = co / cog;
+    if (ci / cig != g) return false;
+    *idx = ((long)co * cig + (ci - g * cig)) * d.k + j;                                     // (Cout, Cin/groups, k)
+    return true;
+}
+// input position feeding output position t through tap j (or -1)
+__device__ __forceinline__ int conv_in_pos(const ConvDesc& d, int t, int j) {
+    if (!d.transposed) {
+        const int ti = t * d.stride + j - d.pad;
+        return (ti >= 0 && ti < d.n_in) ? ti : -1;
+    }
+    const int q = t + d.pad - j;                      // ConvTranspose1d: out[n*stride + j - pad] += in[n] * W[:, :, j]
+    if (q < 0 || q % d.stride) return -1;
+    const int ti = q / d.stride;
+    return ti < d.n_in ? ti : -1;
+}
+
+// y[b, t, co] = bias[co] + sum_j sum_ci x[b, in_pos(t, j), ci] * w(co, ci, j)
+__global__ void train_conv_fwd_kernel(const ConvDesc d, const float* __restrict__ x, const float* __restrict__ w,
+                                      const float* __restrict__ bias, float* __restrict__ y) {
+    const long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= (long)d.B * d.n_out * d.c_out) return;
+    const int co = (int)(q % d.c_out), t = (int)((q / d.c_out) % d.n_out), b = (int)(q / ((long)d.c_out * d.n_out));
+    const int cig = d.transposed ? d.c_in : d.c_in / d.groups, ci0 = d.transposed ? 0 : (co / (d.c_out / d.groups)) * cig;
+    float acc = bias ? bias[co] : 0.0f;
+    for (int j = 0; j < d.k; ++j) {
+        const int ti = conv_in_pos(d, t, j);
+        if (ti < 0) continue;
+        const float* xr = x + ((long)b * d.n_in + ti) * d.c_in;
+        for (int c = 0; c < cig; ++c) {
+            long wi;
+            conv_w_index(d, co, ci0 + c, j, &wi);
+            acc = fmaf(xr[ci0 + c], w[wi], acc);
+        }
+    }
+    y[q] = acc;
+}
+
+// dx[b, ti, ci] = sum over (t, j) with in_pos(t, j) == ti, and co connected to ci, of dy[b, t, co] * w(co, ci, j)
+__global__ void train_conv_dgrad_kernel(const ConvDesc d, const float* __restrict__ dy, const float* __restrict__ w,
+                                        float* __restrict__ dx) {
+    const long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= (long)d.B * d.n_in * d.c_in) return;
+    const int ci = (int)(q % d.c_in), ti = (int)((q / d.c_in) % d.n_in), b = (int)(q / ((long)d.c_in * d.n_in));
+    const int cog = d.transposed ? d.c_out : d.c_out / d.groups, co0 = d.transposed ? 0 : (ci / (d.c_in / d.groups)) * cog;
+    float acc = 0.0f;
+    for (int j = 0; j < d.k; ++j) {
+        int t;
+        if (!d.transposed) {                          // ti = t*stride + j - pad
+            const int r = ti + d.pad - j;
+            if (r < 0 || r % d.stride) continue;
+            t = r / d.stride;
+        } else {                                      // t = ti*stride + j - pad
+            t = ti * d.stride + j - d.pad;
+        }
+        if (t < 0 || t >= d.n_out) continue;
+        const float* dr = dy + ((long)b * d.n_out + t) * d.c_out;
+        for (int c = 0; c < cog; ++c) {
+            long wi;
+            conv_w_index(d, co0 + c, ci, j, &wi);
+            acc = fmaf(dr[co0 + c], w[wi], acc);
+        }
+    }
+    dx[q] = acc;
+}
+
+// dw(co, ci, j) = sum over (b, t) of dy[b, t, co] * x[b, in_pos(t, j), ci]: one thread per weight element, in checkpoint order
+__global__ void train_conv_wgrad_kernel(const ConvDesc d, const float* __restrict__ x, const float* __restrict__ dy,
+                                        float* __restrict__ dw) {
+    const int cig = d.transposed ? d.c_out : d.c_in / d.groups;      // middle extent of the checkpoint layout
+    const int outer = d.transposed ? d.c_in : d.c_out;
+    const long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= (long)outer * cig * d.k) return;
+    const int j = (int)(q % d.k), mid = (int)((q / d.k) % cig), out = (int)(q / ((long)d.k * cig));
+    int co, ci;
+    if (d.transposed) { ci = out; co = mid; }
+    else { co = out; ci = (co / (d.c_out / d.groups)) * cig + mid; }
+    float acc = 0.0f;
+    for (int b = 0; b < d.B; ++b) {
+        for (int t = 0; t < d.n_out; ++t) {
+            const int ti = conv_in_pos(d, t, j);
+            if (ti < 0) continue;
+            acc = fmaf(dy[((long)b * d.n_out + t) * d.c_out + co], x[((long)b * d.n_in + ti) * d.c_in + ci], acc);
+        }
+    }
+    dw[q] = acc;
+}
+// out[c] = sum over rows of v[row, c]   (bias gradients, LayerNorm shift gradients)
+__global__ void train_colsum_kernel(const float* __restrict__ v, long rows, int C, float* __restrict__ out) {
+    const int c = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (c >= C) return;
+    float acc = 0.0f;
+    for (long r = 0; r < rows; ++r) acc += v[r * C + c];
+    out[c] = acc;
+}
+
+// ---- LayerNorm over the last dim (biased variance, eps inside the sqrt), one thread per row; mean / rstd kept for backward
+__global__ void train_ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ g, const float* __restrict__ b, long rows,
+                                    int C, float eps, float* __restrict__ y, float* __restrict__ mean, float* __restrict__ rstd) {
+    const long r = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= rows) return;
+    const float* xr = x + r * C;
+    float m = 0.0f;
+    for (int c = 0; c < C; ++c) m += xr[c];
+    m /= (float)C;
+    float v = 0.0f;
+    for (int c = 0; c < C; ++c) { const float dlt = xr[c] - m; v = fmaf(dlt, dlt, v); }
+    const float rs = 1.0f / sqrtf(v / (float)C + eps);
+    mean[r] = m;
+    rstd[r] = rs;
+    for (int c = 0; c < C; ++c) y[r * C + c] = fmaf((xr[c] - m) * rs, g[c], b[c]);
+}
+__global__ void train_ln_bwd_dx_kernel(const float* __restrict__ x, const float* __restrict__ g, const float* __restrict__ mean,
+                                       const float* __restrict__ rstd, const float* __restrict__ dy, long rows, int C,
+                                       float* __restrict__ dx) {
+    const long r = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= rows) return;
+    const float m = mean[r], rs = rstd[r];
+    float s1 = 0.0f, s2 = 0.0f;
+    for (int c = 0; c < C; ++c) {
+        const float xh = (x[r * C + c] - m) * rs, dh = dy[r * C + c] * g[c];
+        s1 += dh;
+        s2 = fmaf(dh, xh, s2);
+    }
+    s1 /= (float)C;
+    s2 /= (float)C;
+    for (int c = 0; c < C; ++c) {
+        const float xh = (x[r * C + c] - m) * rs, dh = dy[r * C + c] * g[c];
+        dx[r * C + c] = rs * (dh - s1 - xh * s2);
+    }
+}
+__global__ void train_ln_bwd_params_kernel(const float* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ rstd,
+                                           const float* __restrict__ dy, long rows, int C, float* __restrict__ dg,
+                                           float* __restrict__ db) {
+    const int c = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (c >= C) return;
+    float a = 0.0f, s = 0.0f;
+    for (long r = 0; r < rows; ++r) {
+        const float d = dy[r * C + c];
+        a = fmaf(d, (x[r * C + c] - mean[r]) * rstd[r], a);
+        s += d;
+    }
+    dg[c] = a;
+    db[c] = s;
+}
+
+// ---- activations: kind as esmi_dev.h Act (1 ReLU, 2 GELU erf, 3 tanh); backward reads y for ReLU / tanh and x for GELU
+__global__ void train_act_fwd_kernel(const float* __restrict__ x, long n, int kind, float* __restrict__ y) {
+    const long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= n) return;
+    const float v = x[q];
+    y[q] = kind == ACT_RELU ? fmaxf(v, 0.0f) : (kind == ACT_GELU ? 0.5f * v * (1.0f + erff(v * 0.70710678118654752f)) : tanhf(v));
+}
+__global__ void train_act_bwd_kernel(const float* __restrict__ saved, const float* __restrict__ dy, long n, int kind,
+                                     float* __restrict__ dx) {
+    const long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= n) return;
+    const float s = saved[q];
+    float d;
+    if (kind == ACT_RELU) d = s > 0.0f ? 1.0f : 0.0f;
+    else if (kind == ACT_TANH) d = 1.0f - s * s;
+    else d = 0.5f * (1.0f + erff(s * 0.70710678118654752f)) + s * 0.3989422804014327f * expf(-0.5f * s * s);
+    dx[q] = dy[q] * d;
+}
+
+// ---- attention core, blocks.py:43-64 (scores are NOT masked there): qkv (B, N, 3, h, C) -> P (B, h, N, N), ctx (B, N, h*C)
+__global__ void train_attn_fwd_kernel(const float* __restrict__ qkv, int B, int N, int C, int h, float scale, float* __restrict__ P,
+                                      float* __restrict__ ctx) {
+    const long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= (long)B * h * N) return;
+    const int i = (int)(q % N), hd = (int)((q / N) % h), b = (int)(q / ((long)N * h));
+    const long ld = 3L * h * C;
+    const float* qi = qkv + ((long)b * N + i) * ld + (long)hd * C;
+    float* p = P + (((long)b * h + hd) * N + i) * N;
+    float mx = -3.0e38f;
+    for (int j = 0; j < N; ++j) {
+        const float* kj = qkv + ((long)b * N + j) * ld + (long)(h + hd) * C;
+        float s = 0.0f;
+        for (int c = 0; c < C; ++c) s = fmaf(qi[c], kj[c], s);
+        s *= scale;
+        p[j] = s;
+        mx = fmaxf(mx, s);
+    }
+    float sum = 0.0f;
+    for (int j = 0; j < N; ++j) { const float e = expf(p[j] - mx); p[j] = e; sum += e; }
+    const float inv = 1.0f / sum;
+    for (int j = 0; j < N; ++j) p[j] *= inv;
+    float* o = ctx + ((long)b * N + i) * h * C + (long)hd * C;
+    for (int c = 0; c < C; ++c) {
+        float a = 0.0f;
+        for (int j = 0; j < N; ++j) a = fmaf(p[j], qkv[((long)b * N + j) * ld + (long)(2 * h + hd) * C + c], a);
+        o[c] = a;
+    }
+}
+// row i: dP = dctx_i . V^T, dS = P o (dP - <P, dP>), dq_i = scale dS K;  dS (B, h, N, N) kept for the column pass
+__global__ void train_attn_bwd_rows_kernel(const float* __restrict__ qkv, const float* __restrict__ P, const float* __restrict__ dctx,
+                                           int B, int N, int C, int h, float scale, float* __restrict__ dS, float* __restrict__ dqkv) {
+    const long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= (long)B * h * N) return;
+    const int i = (int)(q % N), hd = (int)((q / N) % h), b = (int)(q / ((long)N * h));
+    const long ld = 3L * h * C;
+    const float* p = P + (((long)b * h + hd) * N + i) * N;
+    float* ds = dS + (((long)b * h + hd) * N + i) * N;
+    const float* go = dctx + ((long)b * N + i) * h * C + (long)hd * C;
+    float dot = 0.0f;
+    for (int j = 0; j < N; ++j) {
+        const float* vj = qkv + ((long)b * N + j) * ld + (long)(2 * h + hd) * C;
+        float a = 0.0f;
+        for (int c = 0; c < C; ++c) a = fmaf(go[c], vj[c], a);
+        ds[j] = a;
+        dot = fmaf(p[j], a, dot);
+    }
+    for (int j = 0; j < N; ++j) ds[j] = p[j] * (ds[j] - dot);
+    float* dq = dqkv + ((long)b * N + i) * ld + (long)hd * C;
+    for (int c = 0; c < C; ++c) {
+        float a = 0.0f;
+        for (int j = 0; j < N; ++j) a = fmaf(ds[j], qkv[((long)b * N + j) * ld + (long)(h + hd) * C + c], a);
+        dq[c] = a * scale;
+    }
+}
+// column j: dk_j = scale dS^T Q, dv_j = P^T dctx
+__global__ void train_attn_bwd_cols_kernel(const float* __restrict__ qkv, const float* __restrict__ P, const float* __restrict__ dS,
+                                           const float* __restrict__ dctx, int B, int N, int C, int h, float scale,
+                                           float* __restrict__ dqkv) {
+    const long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= (long)B * h * N) return;
+    const int j = (int)(q % N), hd = (int)((q / N) % h), b = (int)(q / ((long)N * h));
+    const long ld = 3L * h * C;
+    float* dk = dqkv + ((long)b * N + j) * ld + (long)(h + hd) * C;
+    float* dv = dqkv + ((long)b * N + j) * ld + (long)(2 * h + hd) * C;
+    for (int c = 0; c < C; ++c) {
+        float a = 0.0f, v = 0.0f;
+        for (int i = 0; i < N; ++i) {
+            const long pi = (((long)b * h + hd) * N + i) * N + j;
+            a = fmaf(dS[pi], qkv[((long)b * N + i) * ld + (long)hd * C + c], a);
+            v = fmaf(P[pi], dctx[((long)b * N + i) * h * C + (long)hd * C + c], v);
+        }
+        dk[c] = a * scale;
+        dv[c] = v;
+    }
+}
+
+// ---- embedding: forward gather (out-of-range ids read row 0); backward one thread per table element, rows with id ==
+// padding_idx get no gradient (nn.Embedding(padding_idx), networks.py:32)
+__global__ void train_embed_fwd_kernel(const int* __restrict__ ids, const float* __restrict__ table, long rows, int V, int C,
+                                       float* __restrict__ out) {
+    const long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= rows * C) return;
+    int id = ids[q / C];
+    if (id < 0 || id >= V) id = 0;
+    out[q] = table[(long)id * C + q % C];
+}
+__global__ void train_embed_bwd_kernel(const int* __restrict__ ids, const float* __restrict__ dy, long rows, int V, int C,
+                                       int padding_idx, float* __restrict__ dtable) {
+    const long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= (long)V * C) return;
+    const int v = (int)(q / C), c = (int)(q % C);
+    float acc = 0.0f;
+    if (v != padding_idx)
+        for (long r = 0; r < rows; ++r)
+            if (ids[r] == v) acc += dy[r * C + c];
+    dtable[q] = acc;
+}
+
+// ---- row masking (masked_fill(mask, 0) with a per-row mask), residual add, column-block copy (torch.cat / its gradient)
+__global__ void train_mask_rows_kernel(const float* __restrict__ x, const unsigned char* __restrict__ mask, long rows, int C,
+                                       float* __restrict__ y) {
+    const long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= rows * C) return;
+    y[q] = mask[q / C] ? 0.0f : x[q];
+}
+__global__ void train_add_kernel(const float* __restrict__ a, const float* __restrict__ b, long n, float* __restrict__ y) {
+    const long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q < n) y[q] = a[q] + b[q];
+}
+__global__ void train_copy_cols_kernel(const float* __restrict__ src, int ld_src, int col_src, float* __restrict__ dst, int ld_dst,
+                                       int col_dst, long rows, int C) {
+    const long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= rows * C) return;
+    const long r = q / C;
+    const int c = (int)(q % C);
+    dst[r * ld_dst + col_dst + c] = src[r * ld_src + col_src + c];
+}
+
+// ---- length regulator (networks.py:233-244) forward / backward on the inclusive duration cumsum `cum` (B, T):
+// frame f of utterance b copies phoneme t with cum[t-1] <= f < cum[t]; frames >= cum[T-1] are zero padding
+__global__ void train_repeat_fwd_kernel(const float* __restrict__ feat, const int* __restrict__ cum, int B, int T, int C, int L,
+                                        float* __restrict__ out) {
+    const long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= (long)B * L * C) return;
+    const int c = (int)(q % C), f = (int)((q / C) % L), b = (int)(q / ((long)C * L));
+    const int* cb = cum + (long)b * T;
+    int lo = 0, hi = T;                       // first t with cum[t] > f
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (cb[mid] > f) hi = mid; else lo = mid + 1; }
+    out[q] = lo < T ? feat[((long)b * T + lo) * C + c] : 0.0f;
+}
+__global__ void train_repeat_bwd_kernel(const float* __restrict__ dout, const int* __restrict__ cum, int B, int T, int C, int L,
+                                        float* __restrict__ dfeat) {
+    const long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= (long)B * T * C) return;
+    const int c = (int)(q % C), t = (int)((q / C) % T), b = (int)(q / ((long)C * T));
+    const int f0 = t ? cum[(long)b * T + t - 1] : 0;
+    int f1 = cum[(long)b * T + t];
+    f1 = f1 < L ? f1 : L;
+    float acc = 0.0f;
+    for (int f = f0; f < f1; ++f) acc += dout[((long)b * L + f) * C + c];
+    dfeat[q] = acc;
+}
+
+// ---- the loss of model.py:167-216 and its gradient seeds.  One 1024-thread workgroup (fixed reduction tree: reproducible).
+//   out[0..3] = mel L1, pitch MSE, energy MSE, log-duration MSE (means over the unmasked elements); out[4] = 10 a + 2 b + 2 c + d
+struct LossP {
+    const float *mel_pred, *mel, *pitch_pred, *pitch, *energy_pred, *energy, *dur_pred;
+    const int* dur;
+    const unsigned char *mel_mask, *ph_mask;   // 1 = padding; NULL = nothing masked
+    int B, T, L, n_mel;
+    float *out, *d_mel, *d_pitch, *d_energy, *d_dur;
+};
+__device__ __forceinline__ float block_sum_1024(float v, float* red) {
+    const int tid = (int)threadIdx.x;
+    red[tid] = v;
+    __syncthreads();
+    for (int s = 512; s > 0; s >>= 1) {
+        if (tid < s) red[tid] += red[tid + s];
+        __syncthreads();
+    }
+    const float r = red[0];
+    __syncthreads();
+    return r;
+}
+__global__ __launch_bounds__(1024) void train_loss_kernel(const LossP p) {
+    ESMI_DYN_LDS(red);   // 1024 floats
+    const int tid = (int)threadIdx.x;
+    const long nf = (long)p.B * p.L, np_ = (long)p.B * p.T;
+    float cnt_f = 0.0f, cnt_p = 0.0f;
+    for (long r = tid; r < nf; r += 1024) cnt_f += (p.mel_mask && p.mel_mask[r]) ? 0.0f : 1.0f;
+    for (long r = tid; r < np_; r += 1024) cnt_p += (p.ph_mask && p.ph_mask[r]) ? 0.0f : 1.0f;
+    const float n_mel_el = block_sum_1024(cnt_f, red) * (float)p.n_mel, n_ph = block_sum_1024(cnt_p, red);
+    float a = 0.0f;
+    for (long q = tid; q < nf * p.n_mel; q += 1024) {
+        const bool ok = !(p.mel_mask && p.mel_mask[q / p.n_mel]);
+        const float d = p.mel_pred[q] - p.mel[q];
+        if (ok) a += fabsf(d);
+        p.d_mel[q] = ok ? 10.0f * (d > 0.0f ? 1.0f : (d < 0.0f ? -1.0f : 0.0f)) / n_mel_el : 0.0f;
+    }
+    float s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+    for (long r = tid; r < np_; r += 1024) {
+        const bool ok = !(p.ph_mask && p.ph_mask[r]);
+        const float d1 = p.pitch_pred[r] - p.pitch[r], d2 = p.energy_pred[r] - p.energy[r];
+        const float lp = logf(p.dur_pred[r] + 1.0f), d3 = lp - logf((float)p.dur[r] + 1.0f);
+        if (ok) { s1 = fmaf(d1, d1, s1); s2 = fmaf(d2, d2, s2); s3 = fmaf(d3, d3, s3); }
+        p.d_pitch[r] = ok ? 2.0f * 2.0f * d1 / n_ph : 0.0f;
+        p.d_energy[r] = ok ? 2.0f * 2.0f * d2 / n_ph : 0.0f;
+        p.d_dur[r] = ok ? 2.0f * d3 / (p.dur_pred[r] + 1.0f) / n_ph : 0.0f;
+    }
+    const float mel_l = block_sum_1024(a, red) / n_mel_el;
+    const float l1 = block_sum_1024(s1, red) / n_ph, l2 = block_sum_1024(s2, red) / n_ph, l3 = block_sum_1024(s3, red) / n_ph;
+    if (tid == 0) {
+        p.out[0] = mel_l; p.out[1] = l1; p.out[2] = l2; p.out[3] = l3;
+        p.out[4] = 10.0f * mel_l + 2.0f * l1 + 2.0f * l2 + l3;
+    }
+}
+
+// ---- AdamW, torch.optim.AdamW's arithmetic (decoupled decay first, bias corrections as two scalars), over a flat buffer
+__global__ void train_adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                   long n, float lr, float beta1, float beta2, float eps, float wd, float bc1, float bc2_sqrt) {
+    const long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= n) return;
+    const float grad = g[q];
+    float w = p[q] * (1.0f - lr * wd);
+    const float mm = beta1 * m[q] + (1.0f - beta1) * grad;
+    const float vv = beta2 * v[q] + (1.0f - beta2) * grad * grad;
+    m[q] = mm;
+    v[q] = vv;
+    const float denom = sqrtf(vv) / bc2_sqrt + eps;
+    w -= (lr / bc1) * (mm / denom);
+    p[q] = w;
+}
+
+}  // namespace esmi

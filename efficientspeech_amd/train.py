@@ -1,0 +1,471 @@
+"""Training step of the acoustic model on MI355X (reference: model.py:167-226 loss + training_step,
+:279-283 AdamW, train.py:66-76; the train=True data flow of layers/networks.py:336-434).
+
+Every arithmetic operation of the step is a HIP kernel behind the C-ABI (`esmi_train_*`, csrc/train_ops.h): forward operators
+that keep what their backward reads, data- and weight-gradient kernels, the fused masked loss, AdamW.  torch.autograd is used
+as the TAPE only (which operator's backward runs when, and the accumulation of gradients that fan in); torch.distributed
+(RCCL) carries the one gradient all-reduce.  Parameters and gradients of the model live in ONE flat fp32 buffer each
+(`FlatParams`): the data-parallel exchange is a single all-reduce of 1.07 MB (tiny ES) and the optimizer a single launch.
+
+The operators take the model's own `nn.Parameter`s in checkpoint layout, so `Phoneme2Mel.state_dict()` after N steps is a
+reference-compatible checkpoint and the inference path (`networks.py`) picks the updated weights up through its pack cache.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib, networks
+from .networks import _ptr, _mask_u8
+
+ACT_RELU, ACT_GELU, ACT_TANH = 1, 2, 3
+
+
+def _rt(t):
+    return networks._runtime(t)
+
+
+def _new(shape, like, dtype=torch.float32):
+    return torch.empty(shape, dtype=dtype, device=like.device)
+
+
+# --------------------------------------------------------------------------- operators (autograd = the tape)
+class _Conv(torch.autograd.Function):
+    """Conv1d / ConvTranspose1d / Linear on channels-last (B, n, C); `w` in checkpoint layout (Linear: (Cout, Cin))."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, stride, pad, groups, transposed, n_out):
+        x, w = x.contiguous(), w.contiguous()
+        lib, st = _rt(x)
+        B, n_in, c_in = x.shape
+        w3 = w if w.dim() == 3 else w.unsqueeze(-1)
+        c_out, k = (w3.shape[1] if transposed else w3.shape[0]), w3.shape[2]
+        d = _lib.ConvDesc(B, n_in, c_in, n_out, c_out, k, stride, pad, groups, 1 if transposed else 0)
+        y = _new((B, n_out, c_out), x)
+        lib.esmi_train_conv_fwd_f32(C.byref(d), _ptr(x), _ptr(w), _ptr(b), _ptr(y), st)
+        ctx.save_for_backward(x, w)
+        ctx.d, ctx.has_bias = d, b is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dy = dy.contiguous()
+        lib, st = _rt(dy)
+        d = ctx.d
+        dx = torch.empty_like(x)
+        lib.esmi_train_conv_dgrad_f32(C.byref(d), _ptr(dy), _ptr(w), _ptr(dx), st)
+        dw = torch.empty_like(w)
+        db = _new((d.c_out,), w) if ctx.has_bias else None
+        lib.esmi_train_conv_wgrad_f32(C.byref(d), _ptr(x), _ptr(dy), _ptr(dw), _ptr(db), st)
+        return dx, dw, db, None, None, None, None, None
+
+
+class _LayerNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, g, b):
+        x = x.contiguous()
+        lib, st = _rt(x)
+        rows, Cc = x.numel() // x.shape[-1], x.shape[-1]
+        y, mean, rstd = torch.empty_like(x), _new((rows,), x), _new((rows,), x)
+        lib.esmi_train_layernorm_fwd_f32(_ptr(x), _ptr(g), _ptr(b), rows, Cc, _ptr(y), _ptr(mean), _ptr(rstd), st)
+        ctx.save_for_backward(x, g, mean, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, g, mean, rstd = ctx.saved_tensors
+        dy = dy.contiguous()
+        lib, st = _rt(dy)
+        rows, Cc = x.numel() // x.shape[-1], x.shape[-1]
+        dx, dg, db = torch.empty_like(x), torch.empty_like(g), torch.empty_like(g)
+        lib.esmi_train_layernorm_bwd_f32(_ptr(x), _ptr(g), _ptr(mean), _ptr(rstd), _ptr(dy), rows, Cc, _ptr(dx), _ptr(dg), _ptr(db), st)
+        return dx, dg, db
+
+
+class _Act(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, kind):
+        x = x.contiguous()
+        lib, st = _rt(x)
+        y = torch.empty_like(x)
+        lib.esmi_train_act_fwd_f32(_ptr(x), x.numel(), kind, _ptr(y), st)
+        ctx.save_for_backward(x if kind == ACT_GELU else y)
+        ctx.kind = kind
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (saved,) = ctx.saved_tensors
+        dy = dy.contiguous()
+        lib, st = _rt(dy)
+        dx = torch.empty_like(dy)
+        lib.esmi_train_act_bwd_f32(_ptr(saved), _ptr(dy), dy.numel(), ctx.kind, _ptr(dx), st)
+        return dx, None
+
+
+class _AttnCore(torch.autograd.Function):
+    """qkv (B, N, 3*h*C) as the qkv Linear leaves it -> softmax(q k^T / sqrt(C/h)) v, heads concatenated (B, N, h*C)."""
+
+    @staticmethod
+    def forward(ctx, qkv, h):
+        qkv = qkv.contiguous()
+        lib, st = _rt(qkv)
+        B, N, w = qkv.shape
+        Cc = w // (3 * h)
+        P, out = _new((B, h, N, N), qkv), _new((B, N, h * Cc), qkv)
+        lib.esmi_train_attention_fwd_f32(_ptr(qkv), B, N, Cc, h, _ptr(P), _ptr(out), st)
+        ctx.save_for_backward(qkv, P)
+        ctx.dims = (B, N, Cc, h)
+        return out
+
+    @staticmethod
+    def backward(ctx, dctx):
+        qkv, P = ctx.saved_tensors
+        dctx = dctx.contiguous()
+        lib, st = _rt(dctx)
+        B, N, Cc, h = ctx.dims
+        dS, dqkv = torch.empty_like(P), torch.empty_like(qkv)
+        lib.esmi_train_attention_bwd_f32(_ptr(qkv), _ptr(P), _ptr(dctx), B, N, Cc, h, _ptr(dS), _ptr(dqkv), st)
+        return dqkv, None
+
+
+class _Embedding(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, ids, table, padding_idx):
+        ids = ids.contiguous().to(torch.int32)
+        lib, st = _rt(table)
+        V, Cc = table.shape
+        out = _new(tuple(ids.shape) + (Cc,), table)
+        lib.esmi_train_embedding_fwd_f32(_ptr(ids), _ptr(table), ids.numel(), V, Cc, _ptr(out), st)
+        ctx.save_for_backward(ids)
+        ctx.dims = (V, Cc, padding_idx)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        (ids,) = ctx.saved_tensors
+        dy = dy.contiguous()
+        lib, st = _rt(dy)
+        V, Cc, pad = ctx.dims
+        dt = _new((V, Cc), dy)
+        lib.esmi_train_embedding_bwd_f32(_ptr(ids), _ptr(dy), ids.numel(), V, Cc, pad, _ptr(dt), st)
+        return None, dt, None
+
+
+class _MaskRows(torch.autograd.Function):
+    """x.masked_fill(mask[..., None], 0) for a (B, n) uint8 mask."""
+
+    @staticmethod
+    def forward(ctx, x, mask_u8):
+        x = x.contiguous()
+        lib, st = _rt(x)
+        y = torch.empty_like(x)
+        lib.esmi_train_mask_rows_f32(_ptr(x), _ptr(mask_u8), x.numel() // x.shape[-1], x.shape[-1], _ptr(y), st)
+        ctx.save_for_backward(mask_u8)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (mask_u8,) = ctx.saved_tensors
+        dy = dy.contiguous()
+        lib, st = _rt(dy)
+        dx = torch.empty_like(dy)
+        lib.esmi_train_mask_rows_f32(_ptr(dy), _ptr(mask_u8), dy.numel() // dy.shape[-1], dy.shape[-1], _ptr(dx), st)
+        return dx, None
+
+
+class _Add(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        a, b = a.contiguous(), b.contiguous()
+        lib, st = _rt(a)
+        y = torch.empty_like(a)
+        lib.esmi_train_add_f32(_ptr(a), _ptr(b), a.numel(), _ptr(y), st)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        return dy, dy
+
+
+class _Cat(torch.autograd.Function):
+    """torch.cat(parts, dim=-1)."""
+
+    @staticmethod
+    def forward(ctx, *parts):
+        parts = [p.contiguous() for p in parts]
+        lib, st = _rt(parts[0])
+        widths = [p.shape[-1] for p in parts]
+        rows, tot = parts[0].numel() // widths[0], sum(widths)
+        y = _new(tuple(parts[0].shape[:-1]) + (tot,), parts[0])
+        col = 0
+        for p, w in zip(parts, widths):
+            lib.esmi_train_copy_cols_f32(_ptr(p), w, 0, _ptr(y), tot, col, rows, w, st)
+            col += w
+        ctx.widths = widths
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = dy.contiguous()
+        lib, st = _rt(dy)
+        tot, rows = dy.shape[-1], dy.numel() // dy.shape[-1]
+        outs, col = [], 0
+        for w in ctx.widths:
+            g = _new(tuple(dy.shape[:-1]) + (w,), dy)
+            lib.esmi_train_copy_cols_f32(_ptr(dy), tot, col, _ptr(g), w, 0, rows, w, st)
+            outs.append(g)
+            col += w
+        return tuple(outs)
+
+
+class _Repeat(torch.autograd.Function):
+    """FeatureUpsampler: (B, T, C) -> (B, L, C) by the inclusive duration cumsum `cum` (B, T) int32."""
+
+    @staticmethod
+    def forward(ctx, feat, cum, L):
+        feat = feat.contiguous()
+        lib, st = _rt(feat)
+        B, T, Cc = feat.shape
+        out = _new((B, L, Cc), feat)
+        lib.esmi_train_repeat_fwd_f32(_ptr(feat), _ptr(cum), B, T, Cc, L, _ptr(out), st)
+        ctx.save_for_backward(cum)
+        ctx.dims = (B, T, Cc, L)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (cum,) = ctx.saved_tensors
+        dout = dout.contiguous()
+        lib, st = _rt(dout)
+        B, T, Cc, L = ctx.dims
+        df = _new((B, T, Cc), dout)
+        lib.esmi_train_repeat_bwd_f32(_ptr(dout), _ptr(cum), B, T, Cc, L, _ptr(df), st)
+        return df, None, None
+
+
+class _Loss(torch.autograd.Function):
+    """model.py:167-216.  Returns the 5-vector (mel L1, pitch MSE, energy MSE, log-duration MSE, weighted total); backward
+    seeds d total / d prediction (the seed of element 4 must be 1, as `loss.backward()` gives it)."""
+
+    @staticmethod
+    def forward(ctx, mel_pred, pitch_pred, energy_pred, dur_pred, mel, pitch, energy, dur, mel_mask, ph_mask):
+        mel_pred, pitch_pred, energy_pred, dur_pred = (t.contiguous() for t in (mel_pred, pitch_pred, energy_pred, dur_pred))
+        lib, st = _rt(mel_pred)
+        B, L, nm = mel_pred.shape
+        T = pitch_pred.shape[1]
+        out = _new((5,), mel_pred)
+        grads = [torch.empty_like(t) for t in (mel_pred, pitch_pred, energy_pred, dur_pred)]
+        a = _lib.TrainLossArgs(_ptr(mel_pred), _ptr(mel), _ptr(pitch_pred), _ptr(pitch), _ptr(energy_pred), _ptr(energy),
+                               _ptr(dur_pred), _ptr(dur), _ptr(mel_mask), _ptr(ph_mask), B, T, L, nm, _ptr(out),
+                               *[_ptr(g) for g in grads])
+        lib.esmi_train_loss_f32(C.byref(a), st)
+        ctx.save_for_backward(*grads)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        return tuple(ctx.saved_tensors) + (None,) * 6
+
+
+def conv(x, m, n_out=None):
+    """Apply an nn.Conv1d / nn.ConvTranspose1d / nn.Linear parameter container to channels-last x."""
+    if isinstance(m, torch.nn.Linear):
+        return _Conv.apply(x, m.weight, m.bias, 1, 0, 1, False, x.shape[1])
+    tr = isinstance(m, torch.nn.ConvTranspose1d)
+    k, s, p = m.kernel_size[0], m.stride[0], m.padding[0]
+    full = (x.shape[1] - 1) * s - 2 * p + k if tr else (x.shape[1] + 2 * p - k) // s + 1
+    return _Conv.apply(x, m.weight, m.bias, s, p, m.groups, tr, full if n_out is None else min(full, n_out))
+
+
+def layer_norm(x, m):
+    return _LayerNorm.apply(x, m.weight, m.bias)
+
+
+def act(x, kind):
+    return _Act.apply(x, kind)
+
+
+# --------------------------------------------------------------------------- the train=True forward, operator by operator
+def _pooled_mask(mask_u8, n, T, n_out):
+    """blocks.py:51-57 for the pool factor the encoder derives (networks.py:71-72)."""
+    pool = int(torch.round(torch.tensor([n / n_out])).item())
+    if pool <= 1:
+        return mask_u8
+    lib, st = _rt(mask_u8)
+    out = _new((mask_u8.shape[0], n_out), mask_u8, torch.uint8)
+    lib.esmi_pool_mask_u8(_ptr(mask_u8), mask_u8.shape[0], T, pool, _ptr(out), n_out, st)
+    return out
+
+
+def encoder_forward(enc, phoneme, mask_u8):
+    """Encoder.forward, networks.py:52-87."""
+    x = _Embedding.apply(phoneme, enc.embed.weight, 0)
+    T = x.shape[1]
+    feats = []
+    for merge3, merge1, attn, ffn, norm1, norm2 in enc.attn_blocks:
+        x = conv(conv(x, merge3), merge1)
+        m = _pooled_mask(mask_u8, T, T, x.shape[1]) if mask_u8 is not None else None
+        y = conv(_AttnCore.apply(conv(x, attn.qkv), attn.num_heads), attn.proj)
+        x = layer_norm(_Add.apply(y, x), norm1)
+        if m is not None:
+            x = _MaskRows.apply(x, m)
+        y = conv(act(conv(conv(x, ffn.mlp1), ffn.conv), ACT_GELU), ffn.mlp2)
+        x = layer_norm(_Add.apply(y, x), norm2)
+        if m is not None:
+            x = _MaskRows.apply(x, m)
+        feats.append(x)
+    return feats
+
+
+def fuse_forward(fuse, feats, mask_u8):
+    """Fuse.forward, networks.py:196-219."""
+    T = feats[0].shape[1]
+    parts = []
+    for f, (mlp, up) in zip(feats, fuse.mlps):
+        x = conv(f, mlp)
+        if isinstance(up, torch.nn.ConvTranspose1d):
+            x = conv(x, up, n_out=T)
+        parts.append(x)
+    x = conv(_Cat.apply(*parts), fuse.fuse)
+    return _MaskRows.apply(x, mask_u8) if mask_u8 is not None else x
+
+
+def predictor_forward(dec, fused):
+    """AcousticDecoder.forward, networks.py:151-165 -> (pred (B, T, 1), features (B, T, dim))."""
+    y = act(conv(fused, dec.conv1[0]), ACT_RELU)
+    y = act(layer_norm(y, dec.norm1), ACT_RELU)
+    y = act(conv(y, dec.conv2[0]), ACT_RELU)
+    pred = conv(y, dec.linear)
+    if dec.duration:
+        return act(pred, ACT_RELU), layer_norm(y, dec.norm2)
+    return pred, None
+
+
+def _bucket_embedding(dec, target):
+    """get_embedding with a target (networks.py:128-149): the table row of torch.bucketize(target, bins)."""
+    bins = dec.pitch_bins if dec.pitch_bins is not None else dec.energy_bins
+    emb = dec.pitch_embedding if dec.pitch_embedding is not None else dec.energy_embedding
+    lib, st = _rt(target)
+    t = target.contiguous().float()
+    idx = _new(tuple(t.shape), t, torch.int32)
+    scratch = _new(tuple(t.shape) + (emb.weight.shape[1],), t)
+    lib.esmi_bucket_embedding_f32(_ptr(t), _ptr(bins), _ptr(emb.weight.detach()), t.numel(), emb.weight.shape[1], _ptr(scratch), _ptr(idx), st)
+    return _Embedding.apply(idx, emb.weight, -1)
+
+
+def decoder_forward(dec, features):
+    """MelDecoder.forward, networks.py:291-304."""
+    skip = layer_norm(act(conv(features, dec.proj[0]), ACT_TANH), dec.proj[2])
+    for convs, skip_norm in dec.blocks:
+        x = skip
+        for seq, norm in convs:
+            x = layer_norm(act(conv(conv(x, seq[0]), seq[1]), ACT_TANH), norm)
+        skip = layer_norm(_Add.apply(x, skip), skip_norm)
+    return conv(skip, dec.mel_linear)
+
+
+def train_forward(net, x):
+    """Phoneme2Mel.forward(x, train=True), networks.py:336-434 -> dict(mel, pitch, energy, duration, mel_len)."""
+    pe = net.encoder
+    phoneme = x["phoneme"]
+    B, T = phoneme.shape
+    ph_mask = _mask_u8(x["phoneme_mask"]) if B > 1 else None
+    feats = encoder_forward(pe.encoder, phoneme, ph_mask)
+    fused = fuse_forward(pe.fuse, feats, ph_mask)
+    pitch_pred, _ = predictor_forward(pe.pitch_decoder, fused)
+    energy_pred, _ = predictor_forward(pe.energy_decoder, fused)
+    dur_pred, dur_feat = predictor_forward(pe.duration_decoder, fused)
+    pf, ef = _bucket_embedding(pe.pitch_decoder, x["pitch"]), _bucket_embedding(pe.energy_decoder, x["energy"])
+    if ph_mask is not None:
+        pf, ef, dur_feat = _MaskRows.apply(pf, ph_mask), _MaskRows.apply(ef, ph_mask), _MaskRows.apply(dur_feat, ph_mask)
+    feat4 = _Cat.apply(fused, pf, ef, dur_feat)
+    # length regulator on the TARGET durations (masked, clamped at 0), padded to the batch's longest target mel
+    lib, st = _rt(feat4)
+    dur = x["duration"].to(torch.int32).contiguous()
+    if ph_mask is not None:
+        dur = dur.masked_fill(x["phoneme_mask"], 0)
+    cum, mel_len, lmax = _new((B, T), feat4, torch.int32), _new((B,), feat4, torch.int32), _new((1,), feat4, torch.int32)
+    lib.esmi_length_regulate_i32(_ptr(dur), B, T, _ptr(cum), _ptr(mel_len), _ptr(lmax), st)
+    L = int(x["mel"].shape[1]) if "mel" in x else int(torch.max(x["mel_len"]).item())
+    features = _Repeat.apply(feat4, cum, L)
+    mel = decoder_forward(net.decoder, features)
+    if ph_mask is not None:
+        frames = torch.arange(L, device=mel.device)[None, :] >= mel_len[:, None]        # FeatureUpsampler's masks, one bit per frame
+        mel = _MaskRows.apply(mel, _mask_u8(frames))
+    return {"mel": mel, "pitch": pitch_pred, "energy": energy_pred, "duration": dur_pred, "mel_len": mel_len}
+
+
+def training_loss(net, x, y):
+    """training_step's forward + loss (model.py:212-216): returns the 5-vector (mel, pitch, energy, duration, total)."""
+    xx = dict(x)
+    xx.setdefault("mel", y["mel"])
+    out = train_forward(net, xx)
+    B, T = x["phoneme"].shape
+    ph_mask = _mask_u8(x["phoneme_mask"]) if x.get("phoneme_mask") is not None else None
+    mel_mask = _mask_u8(x["mel_mask"]) if x.get("mel_mask") is not None else None
+    f = lambda t: t.contiguous().float()      # noqa: E731
+    return _Loss.apply(out["mel"], out["pitch"].reshape(B, T), out["energy"].reshape(B, T), out["duration"].reshape(B, T),
+                       f(y["mel"]), f(x["pitch"]), f(x["energy"]), x["duration"].to(torch.int32).contiguous(), mel_mask, ph_mask)
+
+
+# --------------------------------------------------------------------------- flat parameters, AdamW, data-parallel step
+# parameters the train=True graph never reaches (their .grad stays None in the reference, so AdamW skips them): the pitch /
+# energy predictors' norm2 feeds only `features`, which only the duration predictor returns (networks.py:160-165, 347-365)
+_UNREACHED = ("encoder.pitch_decoder.norm2.", "encoder.energy_decoder.norm2.")
+
+
+class FlatParams:
+    """All trainable parameters of a module as views into one flat fp32 buffer, their gradients into another."""
+
+    def __init__(self, net):
+        named = [(k, p) for k, p in net.named_parameters() if p.requires_grad and not k.startswith(_UNREACHED)]
+        self.names = [k for k, _ in named]
+        n = sum(p.numel() for _, p in named)
+        dev = named[0][1].device
+        self.data = torch.empty(n, dtype=torch.float32, device=dev)
+        self.grad = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.m, self.v = torch.zeros_like(self.data), torch.zeros_like(self.data)
+        off = 0
+        for _, p in named:
+            k = p.numel()
+            self.data[off:off + k].copy_(p.detach().reshape(-1))
+            p.data = self.data[off:off + k].view(p.shape)
+            p.grad = self.grad[off:off + k].view(p.shape)
+            off += k
+        self.params = [p for _, p in named]
+
+    def zero_grad(self):
+        self.grad.zero_()
+
+
+class TrainStep:
+    """One optimizer step of the reference's training loop (model.py:212-226 + :279-283) on one GPU of a data-parallel job.
+
+    step(x, y): forward + loss + backward on this rank's batch, ONE all-reduce (mean) of the flat gradient buffer over `group`
+    (RCCL when the process group is `nccl`), one AdamW launch.  lr follows torch.optim.AdamW's defaults as model.py sets them."""
+
+    def __init__(self, net, lr=1e-3, weight_decay=1e-6, betas=(0.9, 0.999), eps=1e-8, group=None, world_size=1):
+        self.net, self.flat = net, FlatParams(net)
+        self.lr, self.wd, self.betas, self.eps = lr, weight_decay, betas, eps
+        self.group, self.world = group, world_size
+        self.t = 0
+
+    def step(self, x, y, lr=None):
+        import torch.distributed as dist
+        self.flat.zero_grad()
+        losses = training_loss(self.net, x, y)
+        losses[4].backward()                       # gradients accumulate straight into the flat buffer's views
+        if self.world > 1:
+            dist.all_reduce(self.flat.grad, op=dist.ReduceOp.SUM, group=self.group)
+            self.flat.grad.div_(self.world)        # DDP averages (train.py:66-70 runs Lightning's default DDP strategy)
+        self.t += 1
+        f = self.flat
+        lib, st = _rt(f.data)
+        lib.esmi_train_adamw_f32(_ptr(f.data), _ptr(f.grad), _ptr(f.m), _ptr(f.v), f.data.numel(), self.lr if lr is None else lr,
+                                 self.betas[0], self.betas[1], self.eps, self.wd, self.t, st)
+        for m in self.net.modules():               # the kernel wrote the weights behind torch's version counters: drop the
+            c = getattr(m, "_cache", None)         # inference path's packed copies so the next eval forward re-packs
+            if c is not None and hasattr(c, "invalidate"):
+                c.invalidate()
+        return losses.detach()

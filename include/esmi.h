@@ -421,6 +421,64 @@ int esmi_hifigan_generator_f32(const esmi_hifigan_weights* w, const esmi_hifigan
  * decoder is called stand-alone.                                                              */
 int esmi_mask_rows_f32(float* x, const uint8_t* mask, int64_t rows, int C, esmi_stream_t stream);
 
+/* ------------------------------------------------------------------ Training step
+ * model.py:167-226 (loss, training_step), :279-283 (AdamW); the train=True data flow of layers/networks.py:336-434.
+ * Operator-level entry points: each forward keeps what its backward reads; activations are channels-last (B, n, C) fp32,
+ * weights and their gradients are in CHECKPOINT layout (what the optimizer updates): Conv1d (Cout, Cin/groups, k),
+ * ConvTranspose1d (Cin, Cout, k), Linear (Cout, Cin) = a conv with k = 1.  First correct version: one thread per output
+ * element, fp32 FMA loops, no atomics (a step is bitwise reproducible); see csrc/train_ops.h.  The Python side
+ * (efficientspeech_amd/train.py) composes them with torch.autograd as the tape. */
+typedef struct esmi_conv_desc {
+    int B, n_in, c_in, n_out, c_out, k, stride, pad;
+    int groups;       /* 1, or c_in == c_out == groups (depthwise, MelDecoder networks.py:275) */
+    int transposed;   /* 1: nn.ConvTranspose1d (Fuse, networks.py:185), groups must be 1 */
+} esmi_conv_desc;
+int esmi_train_conv_fwd_f32(const esmi_conv_desc* d, const float* x, const float* w, const float* bias /* or NULL */, float* y,
+                            esmi_stream_t stream);
+int esmi_train_conv_dgrad_f32(const esmi_conv_desc* d, const float* dy, const float* w, float* dx, esmi_stream_t stream);
+int esmi_train_conv_wgrad_f32(const esmi_conv_desc* d, const float* x, const float* dy, float* dw, float* dbias /* or NULL */,
+                              esmi_stream_t stream);
+/* nn.LayerNorm over the last dim (eps 1e-5); mean / rstd (rows) are kept for the backward */
+int esmi_train_layernorm_fwd_f32(const float* x, const float* g, const float* b, int64_t rows, int C, float* y, float* mean,
+                                 float* rstd, esmi_stream_t stream);
+int esmi_train_layernorm_bwd_f32(const float* x, const float* g, const float* mean, const float* rstd, const float* dy,
+                                 int64_t rows, int C, float* dx, float* dg, float* db, esmi_stream_t stream);
+/* kind: 1 ReLU, 2 GELU (erf), 3 tanh.  Backward reads the OUTPUT for ReLU / tanh and the INPUT for GELU as `saved`. */
+int esmi_train_act_fwd_f32(const float* x, int64_t n, int kind, float* y, esmi_stream_t stream);
+int esmi_train_act_bwd_f32(const float* saved, const float* dy, int64_t n, int kind, float* dx, esmi_stream_t stream);
+/* attention core of blocks.py:43-64 (scores unmasked, scale (C/h)^-1/2): qkv (B, N, 3, h, C) -> P (B, h, N, N), ctx (B, N, h*C);
+ * backward: dqkv from dctx, scratch dS (B, h, N, N) */
+int esmi_train_attention_fwd_f32(const float* qkv, int B, int N, int C, int h, float* P, float* ctx, esmi_stream_t stream);
+int esmi_train_attention_bwd_f32(const float* qkv, const float* P, const float* dctx, int B, int N, int C, int h, float* dS,
+                                 float* dqkv, esmi_stream_t stream);
+/* nn.Embedding: out[r] = table[ids[r]]; dtable[v] = sum of dy rows with ids == v (none for v == padding_idx; -1: no padding row) */
+int esmi_train_embedding_fwd_f32(const int32_t* ids, const float* table, int64_t rows, int V, int C, float* out, esmi_stream_t stream);
+int esmi_train_embedding_bwd_f32(const int32_t* ids, const float* dy, int64_t rows, int V, int C, int padding_idx, float* dtable,
+                                 esmi_stream_t stream);
+int esmi_train_mask_rows_f32(const float* x, const uint8_t* mask, int64_t rows, int C, float* y, esmi_stream_t stream);
+int esmi_train_add_f32(const float* a, const float* b, int64_t n, float* y, esmi_stream_t stream);
+/* dst[r, col_dst + c] = src[r, col_src + c], c < C: torch.cat along channels and its gradient */
+int esmi_train_copy_cols_f32(const float* src, int ld_src, int col_src, float* dst, int ld_dst, int col_dst, int64_t rows, int C,
+                             esmi_stream_t stream);
+/* FeatureUpsampler (networks.py:228-258) on the inclusive duration cumsum (esmi_length_regulate_i32): (B, T, C) -> (B, L, C),
+ * frames past the utterance zero; backward = segment sums */
+int esmi_train_repeat_fwd_f32(const float* feat, const int32_t* cum, int B, int T, int C, int L, float* out, esmi_stream_t stream);
+int esmi_train_repeat_bwd_f32(const float* dout, const int32_t* cum, int B, int T, int C, int L, float* dfeat, esmi_stream_t stream);
+/* model.py:167-216: masked L1 (mel) + masked MSE (pitch, energy, log(duration + 1)), total = 10 a + 2 b + 2 c + d.
+ * out (5 floats, device): the four means and the total; d_*: d total / d prediction (0 under the masks). */
+typedef struct esmi_train_loss_args {
+    const float *mel_pred, *mel;            /* (B, L, n_mel) */
+    const float *pitch_pred, *pitch, *energy_pred, *energy, *dur_pred; /* (B, T) */
+    const int32_t* dur;                     /* (B, T) target repeat counts */
+    const uint8_t *mel_mask, *ph_mask;      /* (B, L) / (B, T), 1 = padding; NULL = nothing masked */
+    int B, T, L, n_mel;
+    float *out, *d_mel, *d_pitch, *d_energy, *d_dur;
+} esmi_train_loss_args;
+int esmi_train_loss_f32(const esmi_train_loss_args* a, esmi_stream_t stream);
+/* torch.optim.AdamW's update of one flat buffer; step >= 1 */
+int esmi_train_adamw_f32(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+                         float weight_decay, int step, esmi_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

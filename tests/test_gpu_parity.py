@@ -574,7 +574,7 @@ def test_hifigan_end_to_end_vs_oracle():
     assert np.abs(wav.cpu().numpy() - ref).max() < 2e-4
 
 
-@pytest.mark.parametrize("config,B,L", [("v2", 16, 768), ("v1", 2, 300), ("v3", 3, 411)])
+@pytest.mark.parametrize("config,B,L", [("v2", 16, 768), ("v1", 2, 300), ("v3", 3, 411), ("v2", 1, 1), ("v2", 3, 7), ("v2", 1, 2500)])
 def test_hifigan_one_launch_resblocks_match_conv_by_conv(config, B, L):
     """The one-launch ResBlock kernel (csrc/hifigan_resblock.h: windows with halos, several per utterance at these lengths,
     ragged last window) against the conv-by-conv chain of the same library -- two independent HIP paths, at the size the
