@@ -135,6 +135,7 @@ EXPORTS = (
     "esmi_forward_arena_bytes", "esmi_phoneme2mel_forward_f32", "esmi_hifigan_workspace_bytes", "esmi_hifigan_generator_f32",
     "esmi_pack_resblock_bytes", "esmi_pack_resblock_f16",
     "esmi_train_conv_fwd_f32", "esmi_train_conv_dgrad_f32", "esmi_train_conv_wgrad_f32", "esmi_train_layernorm_fwd_f32",
+    "esmi_train_conv_wgrad_workspace_bytes", "esmi_train_layernorm_bwd_workspace_bytes", "esmi_train_conv_workspace_bytes",
     "esmi_train_layernorm_bwd_f32", "esmi_train_act_fwd_f32", "esmi_train_act_bwd_f32", "esmi_train_attention_fwd_f32",
     "esmi_train_attention_bwd_f32", "esmi_train_embedding_fwd_f32", "esmi_train_embedding_bwd_f32", "esmi_train_mask_rows_f32",
     "esmi_train_add_f32", "esmi_train_copy_cols_f32", "esmi_train_repeat_fwd_f32", "esmi_train_repeat_bwd_f32",
@@ -192,11 +193,17 @@ def bind(lib):
     lib.esmi_forward_arena_bytes.restype = sz
     lib.esmi_phoneme2mel_forward_f32.argtypes = [P(ForwardArgs), i, fp]
     i64, f = C.c_int64, C.c_float
-    lib.esmi_train_conv_fwd_f32.argtypes = [P(ConvDesc), fp, fp, fp, fp, fp]
-    lib.esmi_train_conv_dgrad_f32.argtypes = [P(ConvDesc), fp, fp, fp, fp]
-    lib.esmi_train_conv_wgrad_f32.argtypes = [P(ConvDesc), fp, fp, fp, fp, fp]
+    lib.esmi_train_conv_fwd_f32.argtypes = [P(ConvDesc), fp, fp, fp, fp, fp, sz, fp]
+    lib.esmi_train_conv_workspace_bytes.argtypes = [P(ConvDesc)]
+    lib.esmi_train_conv_workspace_bytes.restype = sz
+    lib.esmi_train_conv_dgrad_f32.argtypes = [P(ConvDesc), fp, fp, fp, fp, sz, fp]
+    lib.esmi_train_conv_wgrad_f32.argtypes = [P(ConvDesc), fp, fp, fp, fp, fp, sz, fp]
+    lib.esmi_train_conv_wgrad_workspace_bytes.argtypes = [P(ConvDesc)]
+    lib.esmi_train_conv_wgrad_workspace_bytes.restype = sz
+    lib.esmi_train_layernorm_bwd_workspace_bytes.argtypes = [i64, i]
+    lib.esmi_train_layernorm_bwd_workspace_bytes.restype = sz
     lib.esmi_train_layernorm_fwd_f32.argtypes = [fp, fp, fp, i64, i, fp, fp, fp, fp]
-    lib.esmi_train_layernorm_bwd_f32.argtypes = [fp, fp, fp, fp, fp, i64, i, fp, fp, fp, fp]
+    lib.esmi_train_layernorm_bwd_f32.argtypes = [fp, fp, fp, fp, fp, i64, i, fp, fp, fp, fp, sz, fp]
     lib.esmi_train_act_fwd_f32.argtypes = [fp, i64, i, fp, fp]
     lib.esmi_train_act_bwd_f32.argtypes = [fp, fp, i64, i, fp, fp]
     lib.esmi_train_attention_fwd_f32.argtypes = [fp, i, i, i, i, fp, fp, fp]

@@ -1190,31 +1190,87 @@ int conv_desc_ok(const esmi_conv_desc* d, ConvDesc* o) {
 }
 }  // namespace
 
-int esmi_train_conv_fwd_f32(const esmi_conv_desc* d, const float* x, const float* w, const float* bias, float* y, esmi_stream_t stream) {
+// Dense convolutions (groups == 1) of the training step run on the matrix pipe through the inference path's implicit GEMM
+// (convgemm.h) when the caller gives scratch for the tap-major copy of the weight: the forward as it is, the data gradient as
+// the transposed problem -- d(Conv1d) is a ConvTranspose1d of dy with the same (Cout, Cin, k) tensor read as (Cin', Cout', k),
+// d(ConvTranspose1d) is a Conv1d of dy with (Cin, Cout, k) read as (Cout', Cin', k).  Everything else (depthwise, channel
+// counts the GEMM does not take, no scratch) runs the one-thread-per-element kernels of train_ops.h.
+size_t esmi_train_conv_workspace_bytes(const esmi_conv_desc* d) {
+    ConvDesc c;
+    if (conv_desc_ok(d, &c) || c.groups != 1) return 0;
+    return align256((size_t)c.k * c.c_out * c.c_in * sizeof(float));
+}
+namespace {
+// one of the two implicit-GEMM problems of a dense conv: returns ESMI_ERR_UNSUPPORTED when the GEMM does not take the shape
+int train_conv_gemm(const ConvDesc& c, bool grad, const float* in, const float* w, const float* bias, float* out, float* wt,
+                    hipStream_t st) {
+    const int cin = grad ? c.c_out : c.c_in, cout = grad ? c.c_in : c.c_out;      // of the GEMM problem
+    if (c.groups != 1 || (cin & 7) || !wt) return ESMI_ERR_UNSUPPORTED;
+    if (cout == 1 && (grad != (c.transposed != 0) || c.stride != 1)) return ESMI_ERR_UNSUPPORTED;   // the one-channel kernel is a plain conv
+    const long n = (long)c.k * c.c_out * c.c_in;
+    // tap-major (k, cout, cin) of the problem: forward conv / grad of convT read the tensor as Conv1d, the other two as ConvTranspose1d
+    const int as_convT = (grad != (c.transposed != 0)) ? 1 : 0;
+    ESMI_LAUNCH(pack_conv_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, w, wt, cout, cin, c.k, as_convT);
+    if (int rc = launch_status()) return rc;
+    ConvGemmP p = conv_defaults();
+    p.mode = as_convT ? MODE_CONVT : MODE_CONV;
+    p.k = c.k; p.stride = c.stride; p.pad = c.pad;
+    p.B = c.B; p.n_in = grad ? c.n_out : c.n_in; p.n_out = grad ? c.n_in : c.n_out; p.c_in = cin; p.c_out = cout;
+    p.A = in; p.lda = cin; p.W = wt; p.bias = bias; p.out = out; p.ldo = cout;
+    return launch_convgemm(p, st);
+}
+}  // namespace
+
+int esmi_train_conv_fwd_f32(const esmi_conv_desc* d, const float* x, const float* w, const float* bias, float* y, void* workspace,
+                            size_t workspace_bytes, esmi_stream_t stream) {
     ConvDesc c;
     if (int rc = conv_desc_ok(d, &c)) return rc;
     if (!x || !w || !y) return ESMI_ERR_ARG;
+    if (workspace && workspace_bytes >= esmi_train_conv_workspace_bytes(d)) {
+        const int rc = train_conv_gemm(c, false, x, w, bias, y, static_cast<float*>(workspace), S(stream));
+        if (rc != ESMI_ERR_UNSUPPORTED) return rc;
+    }
     const long n = (long)c.B * c.n_out * c.c_out;
     ESMI_LAUNCH(train_conv_fwd_kernel, grid1d(n), dim3(256), 0, S(stream), c, x, w, bias, y);
     return launch_status();
 }
-int esmi_train_conv_dgrad_f32(const esmi_conv_desc* d, const float* dy, const float* w, float* dx, esmi_stream_t stream) {
+int esmi_train_conv_dgrad_f32(const esmi_conv_desc* d, const float* dy, const float* w, float* dx, void* workspace,
+                              size_t workspace_bytes, esmi_stream_t stream) {
     ConvDesc c;
     if (int rc = conv_desc_ok(d, &c)) return rc;
     if (!dy || !w || !dx) return ESMI_ERR_ARG;
+    if (workspace && workspace_bytes >= esmi_train_conv_workspace_bytes(d)) {
+        const int rc = train_conv_gemm(c, true, dy, w, nullptr, dx, static_cast<float*>(workspace), S(stream));
+        if (rc != ESMI_ERR_UNSUPPORTED) return rc;
+    }
     const long n = (long)c.B * c.n_in * c.c_in;
     ESMI_LAUNCH(train_conv_dgrad_kernel, grid1d(n), dim3(256), 0, S(stream), c, dy, w, dx);
     return launch_status();
 }
-int esmi_train_conv_wgrad_f32(const esmi_conv_desc* d, const float* x, const float* dy, float* dw, float* dbias, esmi_stream_t stream) {
+size_t esmi_train_conv_wgrad_workspace_bytes(const esmi_conv_desc* d) {
+    ConvDesc c;
+    if (conv_desc_ok(d, &c)) return 0;
+    const long nw = (long)(c.transposed ? c.c_in * c.c_out : c.c_out * (c.c_in / c.groups)) * c.k;
+    return (size_t)train_chunks((long)c.B * c.n_out) * (size_t)(nw + c.c_out) * sizeof(float);
+}
+int esmi_train_conv_wgrad_f32(const esmi_conv_desc* d, const float* x, const float* dy, float* dw, float* dbias, void* workspace,
+                              size_t workspace_bytes, esmi_stream_t stream) {
     ConvDesc c;
     if (int rc = conv_desc_ok(d, &c)) return rc;
-    if (!x || !dy || !dw) return ESMI_ERR_ARG;
-    const long n = (long)(c.transposed ? c.c_in * c.c_out : c.c_out * (c.c_in / c.groups)) * c.k;
-    ESMI_LAUNCH(train_conv_wgrad_kernel, grid1d(n, 64), dim3(64), 0, S(stream), c, x, dy, dw);
+    if (!x || !dy || !dw || !workspace) return ESMI_ERR_ARG;
+    if (workspace_bytes < esmi_train_conv_wgrad_workspace_bytes(d)) return ESMI_ERR_WORKSPACE;
+    const long nw = (long)(c.transposed ? c.c_in * c.c_out : c.c_out * (c.c_in / c.groups)) * c.k;
+    const long rows = (long)c.B * c.n_out, chunks = train_chunks(rows);
+    float* part = static_cast<float*>(workspace);
+    ESMI_LAUNCH(train_conv_wgrad_kernel, dim3(grid1d(nw, 64), (unsigned)chunks), dim3(64), 0, S(stream), c, x, dy, part);
+    if (int rc = launch_status()) return rc;
+    ESMI_LAUNCH(train_reduce_chunks_kernel, grid1d(nw), dim3(256), 0, S(stream), part, nw, nw, chunks, dw);
     if (int rc = launch_status()) return rc;
     if (dbias) {
-        ESMI_LAUNCH(train_colsum_kernel, grid1d(c.c_out, 64), dim3(64), 0, S(stream), dy, (long)c.B * c.n_out, c.c_out, dbias);
+        float* pb = part + chunks * nw;
+        ESMI_LAUNCH(train_colsum_kernel, dim3(grid1d(c.c_out, 64), (unsigned)chunks), dim3(64), 0, S(stream), dy, rows, c.c_out, pb);
+        if (int rc = launch_status()) return rc;
+        ESMI_LAUNCH(train_reduce_chunks_kernel, grid1d(c.c_out, 64), dim3(64), 0, S(stream), pb, (long)c.c_out, (long)c.c_out, chunks, dbias);
         return launch_status();
     }
     return ESMI_OK;
@@ -1225,12 +1281,23 @@ int esmi_train_layernorm_fwd_f32(const float* x, const float* g, const float* b,
     ESMI_LAUNCH(train_ln_fwd_kernel, grid1d(rows, 64), dim3(64), 0, S(stream), x, g, b, (long)rows, C, 1e-5f, y, mean, rstd);
     return launch_status();
 }
+size_t esmi_train_layernorm_bwd_workspace_bytes(int64_t rows, int C) {
+    return rows > 0 && C > 0 ? (size_t)train_chunks(rows) * 2 * C * sizeof(float) : 0;
+}
 int esmi_train_layernorm_bwd_f32(const float* x, const float* g, const float* mean, const float* rstd, const float* dy,
-                                 int64_t rows, int C, float* dx, float* dg, float* db, esmi_stream_t stream) {
-    if (!x || !g || !mean || !rstd || !dy || !dx || !dg || !db || rows <= 0 || C <= 0) return ESMI_ERR_ARG;
+                                 int64_t rows, int C, float* dx, float* dg, float* db, void* workspace, size_t workspace_bytes,
+                                 esmi_stream_t stream) {
+    if (!x || !g || !mean || !rstd || !dy || !dx || !dg || !db || !workspace || rows <= 0 || C <= 0) return ESMI_ERR_ARG;
+    if (workspace_bytes < esmi_train_layernorm_bwd_workspace_bytes(rows, C)) return ESMI_ERR_WORKSPACE;
     ESMI_LAUNCH(train_ln_bwd_dx_kernel, grid1d(rows, 64), dim3(64), 0, S(stream), x, g, mean, rstd, dy, (long)rows, C, dx);
     if (int rc = launch_status()) return rc;
-    ESMI_LAUNCH(train_ln_bwd_params_kernel, grid1d(C, 64), dim3(64), 0, S(stream), x, mean, rstd, dy, (long)rows, C, dg, db);
+    const long chunks = train_chunks(rows);
+    float* part = static_cast<float*>(workspace);
+    ESMI_LAUNCH(train_ln_bwd_params_kernel, dim3(grid1d(C, 64), (unsigned)chunks), dim3(64), 0, S(stream), x, mean, rstd, dy, (long)rows, C, part);
+    if (int rc = launch_status()) return rc;
+    ESMI_LAUNCH(train_reduce_chunks_kernel, grid1d(C, 64), dim3(64), 0, S(stream), part, (long)C, 2L * C, chunks, dg);   // [chunk][dg | db]
+    if (int rc = launch_status()) return rc;
+    ESMI_LAUNCH(train_reduce_chunks_kernel, grid1d(C, 64), dim3(64), 0, S(stream), part + C, (long)C, 2L * C, chunks, db);
     return launch_status();
 }
 int esmi_train_act_fwd_f32(const float* x, int64_t n, int kind, float* y, esmi_stream_t stream) {

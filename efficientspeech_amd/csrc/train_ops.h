@@ -85,34 +85,50 @@ __global__ void train_conv_dgrad_kernel(const ConvDesc d, const float* __restric
     dx[q] = acc;
 }
 
-// dw(co, ci, j) = sum over (b, t) of dy[b, t, co] * x[b, in_pos(t, j), ci]: one thread per weight element, in checkpoint order
+// Reductions over the rows (B * n positions) run in two deterministic stages: stage 1 gives every (output element, chunk of
+// kTrainChunk rows) its own thread and writes a partial sum, stage 2 adds the partials of an element in chunk order.
+constexpr int kTrainChunk = 256;
+__host__ __device__ inline long train_chunks(long rows) { return (rows + kTrainChunk - 1) / kTrainChunk; }
+
+// dw(co, ci, j) = sum over (b, t) of dy[b, t, co] * x[b, in_pos(t, j), ci]: partial[chunk][weight element in checkpoint order]
 __global__ void train_conv_wgrad_kernel(const ConvDesc d, const float* __restrict__ x, const float* __restrict__ dy,
-                                        float* __restrict__ dw) {
+                                        float* __restrict__ partial) {
     const int cig = d.transposed ? d.c_out : d.c_in / d.groups;      // middle extent of the checkpoint layout
     const int outer = d.transposed ? d.c_in : d.c_out;
+    const long nw = (long)outer * cig * d.k;
     const long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (q >= (long)outer * cig * d.k) return;
+    if (q >= nw) return;
     const int j = (int)(q % d.k), mid = (int)((q / d.k) % cig), out = (int)(q / ((long)d.k * cig));
     int co, ci;
     if (d.transposed) { ci = out; co = mid; }
     else { co = out; ci = (co / (d.c_out / d.groups)) * cig + mid; }
+    const long rows = (long)d.B * d.n_out, r0 = (long)blockIdx.y * kTrainChunk;
+    const long r1 = r0 + kTrainChunk < rows ? r0 + kTrainChunk : rows;
     float acc = 0.0f;
-    for (int b = 0; b < d.B; ++b) {
-        for (int t = 0; t < d.n_out; ++t) {
-            const int ti = conv_in_pos(d, t, j);
-            if (ti < 0) continue;
-            acc = fmaf(dy[((long)b * d.n_out + t) * d.c_out + co], x[((long)b * d.n_in + ti) * d.c_in + ci], acc);
-        }
+    for (long r = r0; r < r1; ++r) {
+        const int b = (int)(r / d.n_out), t = (int)(r - (long)b * d.n_out);
+        const int ti = conv_in_pos(d, t, j);
+        if (ti < 0) continue;
+        acc = fmaf(dy[r * d.c_out + co], x[((long)b * d.n_in + ti) * d.c_in + ci], acc);
     }
-    dw[q] = acc;
+    partial[(long)blockIdx.y * nw + q] = acc;
 }
-// out[c] = sum over rows of v[row, c]   (bias gradients, LayerNorm shift gradients)
-__global__ void train_colsum_kernel(const float* __restrict__ v, long rows, int C, float* __restrict__ out) {
+// out[e] = sum over chunks of partial[chunk * stride + e], e < n
+__global__ void train_reduce_chunks_kernel(const float* __restrict__ partial, long n, long stride, long chunks, float* __restrict__ out) {
+    const long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= n) return;
+    float acc = 0.0f;
+    for (long c = 0; c < chunks; ++c) acc += partial[c * stride + q];
+    out[q] = acc;
+}
+// partial[chunk][c] = sum over the chunk's rows of v[row, c]   (bias gradients)
+__global__ void train_colsum_kernel(const float* __restrict__ v, long rows, int C, float* __restrict__ partial) {
     const int c = (int)(blockIdx.x * blockDim.x + threadIdx.x);
     if (c >= C) return;
+    const long r0 = (long)blockIdx.y * kTrainChunk, r1 = r0 + kTrainChunk < rows ? r0 + kTrainChunk : rows;
     float acc = 0.0f;
-    for (long r = 0; r < rows; ++r) acc += v[r * C + c];
-    out[c] = acc;
+    for (long r = r0; r < r1; ++r) acc += v[r * C + c];
+    partial[(long)blockIdx.y * C + c] = acc;
 }
 
 // ---- LayerNorm over the last dim (biased variance, eps inside the sqrt), one thread per row; mean / rstd kept for backward
@@ -150,19 +166,20 @@ __global__ void train_ln_bwd_dx_kernel(const float* __restrict__ x, const float*
         dx[r * C + c] = rs * (dh - s1 - xh * s2);
     }
 }
+// partial[chunk][0][c] = sum dy * xhat, partial[chunk][1][c] = sum dy over the chunk's rows
 __global__ void train_ln_bwd_params_kernel(const float* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ rstd,
-                                           const float* __restrict__ dy, long rows, int C, float* __restrict__ dg,
-                                           float* __restrict__ db) {
+                                           const float* __restrict__ dy, long rows, int C, float* __restrict__ partial) {
     const int c = (int)(blockIdx.x * blockDim.x + threadIdx.x);
     if (c >= C) return;
+    const long r0 = (long)blockIdx.y * kTrainChunk, r1 = r0 + kTrainChunk < rows ? r0 + kTrainChunk : rows;
     float a = 0.0f, s = 0.0f;
-    for (long r = 0; r < rows; ++r) {
+    for (long r = r0; r < r1; ++r) {
         const float d = dy[r * C + c];
         a = fmaf(d, (x[r * C + c] - mean[r]) * rstd[r], a);
         s += d;
     }
-    dg[c] = a;
-    db[c] = s;
+    partial[(long)blockIdx.y * 2 * C + c] = a;
+    partial[(long)blockIdx.y * 2 * C + C + c] = s;
 }
 
 // ---- activations: kind as esmi_dev.h Act (1 ReLU, 2 GELU erf, 3 tanh); backward reads y for ReLU / tanh and x for GELU

@@ -18,6 +18,7 @@ from . import _lib, networks
 from .networks import _ptr, _mask_u8
 
 ACT_RELU, ACT_GELU, ACT_TANH = 1, 2, 3
+USE_MATRIX_PIPE = True    # dense convolutions (forward and data gradient) through the implicit-GEMM kernels; False: plain fp32 kernels
 
 
 def _rt(t):
@@ -41,7 +42,9 @@ class _Conv(torch.autograd.Function):
         c_out, k = (w3.shape[1] if transposed else w3.shape[0]), w3.shape[2]
         d = _lib.ConvDesc(B, n_in, c_in, n_out, c_out, k, stride, pad, groups, 1 if transposed else 0)
         y = _new((B, n_out, c_out), x)
-        lib.esmi_train_conv_fwd_f32(C.byref(d), _ptr(x), _ptr(w), _ptr(b), _ptr(y), st)
+        nws = lib.esmi_train_conv_workspace_bytes(C.byref(d)) if USE_MATRIX_PIPE else 0
+        ws = _new((nws,), x, torch.uint8) if nws else None
+        lib.esmi_train_conv_fwd_f32(C.byref(d), _ptr(x), _ptr(w), _ptr(b), _ptr(y), _ptr(ws), nws, st)
         ctx.save_for_backward(x, w)
         ctx.d, ctx.has_bias = d, b is not None
         return y
@@ -53,10 +56,14 @@ class _Conv(torch.autograd.Function):
         lib, st = _rt(dy)
         d = ctx.d
         dx = torch.empty_like(x)
-        lib.esmi_train_conv_dgrad_f32(C.byref(d), _ptr(dy), _ptr(w), _ptr(dx), st)
+        nws = lib.esmi_train_conv_workspace_bytes(C.byref(d)) if USE_MATRIX_PIPE else 0
+        ws = _new((nws,), w, torch.uint8) if nws else None
+        lib.esmi_train_conv_dgrad_f32(C.byref(d), _ptr(dy), _ptr(w), _ptr(dx), _ptr(ws), nws, st)
         dw = torch.empty_like(w)
         db = _new((d.c_out,), w) if ctx.has_bias else None
-        lib.esmi_train_conv_wgrad_f32(C.byref(d), _ptr(x), _ptr(dy), _ptr(dw), _ptr(db), st)
+        nws = lib.esmi_train_conv_wgrad_workspace_bytes(C.byref(d))
+        ws = _new((nws,), w, torch.uint8)
+        lib.esmi_train_conv_wgrad_f32(C.byref(d), _ptr(x), _ptr(dy), _ptr(dw), _ptr(db), _ptr(ws), nws, st)
         return dx, dw, db, None, None, None, None, None
 
 
@@ -78,7 +85,10 @@ class _LayerNorm(torch.autograd.Function):
         lib, st = _rt(dy)
         rows, Cc = x.numel() // x.shape[-1], x.shape[-1]
         dx, dg, db = torch.empty_like(x), torch.empty_like(g), torch.empty_like(g)
-        lib.esmi_train_layernorm_bwd_f32(_ptr(x), _ptr(g), _ptr(mean), _ptr(rstd), _ptr(dy), rows, Cc, _ptr(dx), _ptr(dg), _ptr(db), st)
+        nws = lib.esmi_train_layernorm_bwd_workspace_bytes(rows, Cc)
+        ws = _new((nws,), x, torch.uint8)
+        lib.esmi_train_layernorm_bwd_f32(_ptr(x), _ptr(g), _ptr(mean), _ptr(rstd), _ptr(dy), rows, Cc, _ptr(dx), _ptr(dg), _ptr(db),
+                                         _ptr(ws), nws, st)
         return dx, dg, db
 
 

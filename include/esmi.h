@@ -433,16 +433,25 @@ typedef struct esmi_conv_desc {
     int groups;       /* 1, or c_in == c_out == groups (depthwise, MelDecoder networks.py:275) */
     int transposed;   /* 1: nn.ConvTranspose1d (Fuse, networks.py:185), groups must be 1 */
 } esmi_conv_desc;
+/* workspace (esmi_train_conv_workspace_bytes, may be NULL): scratch for the tap-major weight copy; with it, dense convolutions
+ * run on the matrix pipe through the inference path's implicit GEMM (split-f16 products in libesmi.so, fp32 MFMA in
+ * libesmi_fp32mfma.so) -- the data gradient as the transposed problem; without it every shape takes the plain fp32 kernels */
+size_t esmi_train_conv_workspace_bytes(const esmi_conv_desc* d);
 int esmi_train_conv_fwd_f32(const esmi_conv_desc* d, const float* x, const float* w, const float* bias /* or NULL */, float* y,
-                            esmi_stream_t stream);
-int esmi_train_conv_dgrad_f32(const esmi_conv_desc* d, const float* dy, const float* w, float* dx, esmi_stream_t stream);
+                            void* workspace, size_t workspace_bytes, esmi_stream_t stream);
+int esmi_train_conv_dgrad_f32(const esmi_conv_desc* d, const float* dy, const float* w, float* dx, void* workspace,
+                              size_t workspace_bytes, esmi_stream_t stream);
+/* weight (and bias) gradients: a two-stage reduction over the B * n_out rows in fixed order (reproducible); scratch from the caller */
+size_t esmi_train_conv_wgrad_workspace_bytes(const esmi_conv_desc* d);
 int esmi_train_conv_wgrad_f32(const esmi_conv_desc* d, const float* x, const float* dy, float* dw, float* dbias /* or NULL */,
-                              esmi_stream_t stream);
+                              void* workspace, size_t workspace_bytes, esmi_stream_t stream);
 /* nn.LayerNorm over the last dim (eps 1e-5); mean / rstd (rows) are kept for the backward */
 int esmi_train_layernorm_fwd_f32(const float* x, const float* g, const float* b, int64_t rows, int C, float* y, float* mean,
                                  float* rstd, esmi_stream_t stream);
+size_t esmi_train_layernorm_bwd_workspace_bytes(int64_t rows, int C);
 int esmi_train_layernorm_bwd_f32(const float* x, const float* g, const float* mean, const float* rstd, const float* dy,
-                                 int64_t rows, int C, float* dx, float* dg, float* db, esmi_stream_t stream);
+                                 int64_t rows, int C, float* dx, float* dg, float* db, void* workspace, size_t workspace_bytes,
+                                 esmi_stream_t stream);
 /* kind: 1 ReLU, 2 GELU (erf), 3 tanh.  Backward reads the OUTPUT for ReLU / tanh and the INPUT for GELU as `saved`. */
 int esmi_train_act_fwd_f32(const float* x, int64_t n, int kind, float* y, esmi_stream_t stream);
 int esmi_train_act_bwd_f32(const float* saved, const float* dy, int64_t n, int kind, float* dx, esmi_stream_t stream);
