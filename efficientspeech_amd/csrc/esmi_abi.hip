@@ -1262,7 +1262,12 @@ int esmi_train_conv_wgrad_f32(const esmi_conv_desc* d, const float* x, const flo
     const long nw = (long)(c.transposed ? c.c_in * c.c_out : c.c_out * (c.c_in / c.groups)) * c.k;
     const long rows = (long)c.B * c.n_out, chunks = train_chunks(rows);
     float* part = static_cast<float*>(workspace);
-    ESMI_LAUNCH(train_conv_wgrad_kernel, dim3(grid1d(nw, 64), (unsigned)chunks), dim3(64), 0, S(stream), c, x, dy, part);
+    if (c.groups == 1 && c.c_in >= 8 && c.c_out >= 8) {   // dense: one wave per (32 x 32 weight tile, tap, chunk) on the fp32 MFMA
+        const unsigned tiles = (unsigned)(((c.c_out + 31) / 32) * ((c.c_in + 31) / 32) * c.k);
+        ESMI_LAUNCH(train_conv_wgrad_mfma_kernel, dim3(tiles, (unsigned)((chunks + 3) / 4)), dim3(256), 0, S(stream), c, x, dy, part, chunks);
+    } else {
+        ESMI_LAUNCH(train_conv_wgrad_kernel, dim3(grid1d(nw, 64), (unsigned)chunks), dim3(64), 0, S(stream), c, x, dy, part);
+    }
     if (int rc = launch_status()) return rc;
     ESMI_LAUNCH(train_reduce_chunks_kernel, grid1d(nw), dim3(256), 0, S(stream), part, nw, nw, chunks, dw);
     if (int rc = launch_status()) return rc;

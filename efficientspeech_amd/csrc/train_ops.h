@@ -113,6 +113,40 @@ __global__ void train_conv_wgrad_kernel(const ConvDesc d, const float* __restric
     }
     partial[(long)blockIdx.y * nw + q] = acc;
 }
+// The same partial sums for DENSE convolutions on the matrix pipe: dW_j = dY^T X_j is a GEMM with the rows as the contraction.
+// One wave = one 32 x 32 (co, ci) tile of one tap and one chunk of rows, on v_mfma_f32_32x32x2_f32 (exact fp32 products, k-ordered
+// accumulation): lane (i, kh) feeds dY[row + kh][co0 + i] and X[in_pos(row + kh)][ci0 + i] -- both 128-byte coalesced.
+__global__ __launch_bounds__(256) void train_conv_wgrad_mfma_kernel(const ConvDesc d, const float* __restrict__ x,
+                                                                    const float* __restrict__ dy, float* __restrict__ partial,
+                                                                    long chunks) {
+    const int lane = lane_id(), i = lane & 31, kh = lane >> 5;
+    const int tci = (d.c_in + 31) / 32;
+    const int tile = (int)blockIdx.x, j = tile % d.k, ci0 = ((tile / d.k) % tci) * 32, co0 = (tile / (d.k * tci)) * 32;
+    const long chunk = (long)blockIdx.y * 4 + wave_id();
+    if (chunk >= chunks) return;
+    const long rows = (long)d.B * d.n_out, r0 = chunk * kTrainChunk, r1 = r0 + kTrainChunk < rows ? r0 + kTrainChunk : rows;
+    const bool co_ok = co0 + i < d.c_out, ci_ok = ci0 + i < d.c_in;
+    f32x16 acc = zero16();
+    for (long r = r0; r < r1; r += 2) {
+        const long rr = r + kh;
+        float a = 0.0f, bv = 0.0f;
+        if (rr < r1) {
+            const int b = (int)(rr / d.n_out), t = (int)(rr - (long)b * d.n_out);
+            const int ti = conv_in_pos(d, t, j);
+            if (co_ok) a = dy[rr * d.c_out + co0 + i];
+            if (ci_ok && ti >= 0) bv = x[((long)b * d.n_in + ti) * d.c_in + ci0 + i];
+        }
+        acc = mfma32(a, bv, acc);
+    }
+    const long nw = (long)d.c_out * d.c_in * d.k;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int co = co0 + tile_row(r, lane), ci = ci0 + i;
+        long wi;
+        if (co < d.c_out && ci < d.c_in && conv_w_index(d, co, ci, j, &wi)) partial[chunk * nw + wi] = acc[r];
+    }
+}
+
 // out[e] = sum over chunks of partial[chunk * stride + e], e < n
 __global__ void train_reduce_chunks_kernel(const float* __restrict__ partial, long n, long stride, long chunks, float* __restrict__ out) {
     const long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
