@@ -84,7 +84,7 @@ class TrainLossArgs(C.Structure):
     """esmi_train_loss_args (include/esmi.h): model.py:167-216."""
     _fields_ = [(n, fp) for n in ("mel_pred", "mel", "pitch_pred", "pitch", "energy_pred", "energy", "dur_pred", "dur", "mel_mask",
                                   "ph_mask")] + [(n, C.c_int) for n in ("B", "T", "L", "n_mel")] + \
-               [(n, fp) for n in ("out", "d_mel", "d_pitch", "d_energy", "d_dur")]
+               [(n, fp) for n in ("out", "d_mel", "d_pitch", "d_energy", "d_dur", "scratch")]
 
 
 class ForwardArgs(C.Structure):
@@ -136,6 +136,7 @@ EXPORTS = (
     "esmi_pack_resblock_bytes", "esmi_pack_resblock_f16",
     "esmi_train_conv_fwd_f32", "esmi_train_conv_dgrad_f32", "esmi_train_conv_wgrad_f32", "esmi_train_layernorm_fwd_f32",
     "esmi_train_conv_wgrad_workspace_bytes", "esmi_train_layernorm_bwd_workspace_bytes", "esmi_train_conv_workspace_bytes",
+    "esmi_train_embedding_bwd_workspace_bytes",
     "esmi_train_layernorm_bwd_f32", "esmi_train_act_fwd_f32", "esmi_train_act_bwd_f32", "esmi_train_attention_fwd_f32",
     "esmi_train_attention_bwd_f32", "esmi_train_embedding_fwd_f32", "esmi_train_embedding_bwd_f32", "esmi_train_mask_rows_f32",
     "esmi_train_add_f32", "esmi_train_copy_cols_f32", "esmi_train_repeat_fwd_f32", "esmi_train_repeat_bwd_f32",
@@ -209,7 +210,9 @@ def bind(lib):
     lib.esmi_train_attention_fwd_f32.argtypes = [fp, i, i, i, i, fp, fp, fp]
     lib.esmi_train_attention_bwd_f32.argtypes = [fp, fp, fp, i, i, i, i, fp, fp, fp]
     lib.esmi_train_embedding_fwd_f32.argtypes = [fp, fp, i64, i, i, fp, fp]
-    lib.esmi_train_embedding_bwd_f32.argtypes = [fp, fp, i64, i, i, i, fp, fp]
+    lib.esmi_train_embedding_bwd_f32.argtypes = [fp, fp, i64, i, i, i, fp, fp, sz, fp]
+    lib.esmi_train_embedding_bwd_workspace_bytes.argtypes = [i64, i, i]
+    lib.esmi_train_embedding_bwd_workspace_bytes.restype = sz
     lib.esmi_train_mask_rows_f32.argtypes = [fp, fp, i64, i, fp, fp]
     lib.esmi_train_add_f32.argtypes = [fp, fp, i64, fp, fp]
     lib.esmi_train_copy_cols_f32.argtypes = [fp, i, i, fp, i, i, i64, i, fp]

@@ -1317,16 +1317,16 @@ int esmi_train_act_bwd_f32(const float* saved, const float* dy, int64_t n, int k
 }
 int esmi_train_attention_fwd_f32(const float* qkv, int B, int N, int C, int h, float* P, float* ctx, esmi_stream_t stream) {
     if (!qkv || !P || !ctx || B <= 0 || N <= 0 || C <= 0 || h <= 0 || C % h) return ESMI_ERR_ARG;
-    ESMI_LAUNCH(train_attn_fwd_kernel, grid1d((long)B * h * N, 64), dim3(64), 0, S(stream), qkv, B, N, C, h, 1.0f / sqrtf((float)(C / h)), P, ctx);
+    ESMI_LAUNCH(train_attn_fwd_kernel, dim3((unsigned)((long)B * h * N)), dim3(64), 0, S(stream), qkv, B, N, C, h, 1.0f / sqrtf((float)(C / h)), P, ctx);
     return launch_status();
 }
 int esmi_train_attention_bwd_f32(const float* qkv, const float* P, const float* dctx, int B, int N, int C, int h, float* dS,
                                  float* dqkv, esmi_stream_t stream) {
     if (!qkv || !P || !dctx || !dS || !dqkv || B <= 0 || N <= 0 || C <= 0 || h <= 0 || C % h) return ESMI_ERR_ARG;
     const float scale = 1.0f / sqrtf((float)(C / h));
-    ESMI_LAUNCH(train_attn_bwd_rows_kernel, grid1d((long)B * h * N, 64), dim3(64), 0, S(stream), qkv, P, dctx, B, N, C, h, scale, dS, dqkv);
+    ESMI_LAUNCH(train_attn_bwd_rows_kernel, dim3((unsigned)((long)B * h * N)), dim3(64), 0, S(stream), qkv, P, dctx, B, N, C, h, scale, dS, dqkv);
     if (int rc = launch_status()) return rc;
-    ESMI_LAUNCH(train_attn_bwd_cols_kernel, grid1d((long)B * h * N, 64), dim3(64), 0, S(stream), qkv, P, dS, dctx, B, N, C, h, scale, dqkv);
+    ESMI_LAUNCH(train_attn_bwd_cols_kernel, grid1d((long)B * h * N * C), dim3(256), 0, S(stream), qkv, P, dS, dctx, B, N, C, h, scale, dqkv);
     return launch_status();
 }
 int esmi_train_embedding_fwd_f32(const int32_t* ids, const float* table, int64_t rows, int V, int C, float* out, esmi_stream_t stream) {
@@ -1334,10 +1334,18 @@ int esmi_train_embedding_fwd_f32(const int32_t* ids, const float* table, int64_t
     ESMI_LAUNCH(train_embed_fwd_kernel, grid1d(rows * C), dim3(256), 0, S(stream), ids, table, (long)rows, V, C, out);
     return launch_status();
 }
+size_t esmi_train_embedding_bwd_workspace_bytes(int64_t rows, int V, int C) {
+    return rows > 0 && V > 0 && C > 0 ? (size_t)train_chunks(rows) * V * C * sizeof(float) : 0;
+}
 int esmi_train_embedding_bwd_f32(const int32_t* ids, const float* dy, int64_t rows, int V, int C, int padding_idx, float* dtable,
-                                 esmi_stream_t stream) {
-    if (!ids || !dy || !dtable || rows <= 0 || V <= 0 || C <= 0) return ESMI_ERR_ARG;
-    ESMI_LAUNCH(train_embed_bwd_kernel, grid1d((long)V * C, 64), dim3(64), 0, S(stream), ids, dy, (long)rows, V, C, padding_idx, dtable);
+                                 void* workspace, size_t workspace_bytes, esmi_stream_t stream) {
+    if (!ids || !dy || !dtable || !workspace || rows <= 0 || V <= 0 || C <= 0) return ESMI_ERR_ARG;
+    if (workspace_bytes < esmi_train_embedding_bwd_workspace_bytes(rows, V, C)) return ESMI_ERR_WORKSPACE;
+    const long chunks = train_chunks(rows), n = (long)V * C;
+    float* part = static_cast<float*>(workspace);
+    ESMI_LAUNCH(train_embed_bwd_kernel, dim3(grid1d(n, 64), (unsigned)chunks), dim3(64), 0, S(stream), ids, dy, (long)rows, V, C, padding_idx, part);
+    if (int rc = launch_status()) return rc;
+    ESMI_LAUNCH(train_reduce_chunks_kernel, grid1d(n), dim3(256), 0, S(stream), part, n, n, chunks, dtable);
     return launch_status();
 }
 int esmi_train_mask_rows_f32(const float* x, const uint8_t* mask, int64_t rows, int C, float* y, esmi_stream_t stream) {
@@ -1368,11 +1376,17 @@ int esmi_train_repeat_bwd_f32(const float* dout, const int32_t* cum, int B, int 
 }
 int esmi_train_loss_f32(const esmi_train_loss_args* a, esmi_stream_t stream) {
     if (!a || !a->mel_pred || !a->mel || !a->pitch_pred || !a->pitch || !a->energy_pred || !a->energy || !a->dur_pred || !a->dur ||
-        !a->out || !a->d_mel || !a->d_pitch || !a->d_energy || !a->d_dur || a->B <= 0 || a->T <= 0 || a->L <= 0 || a->n_mel <= 0)
+        !a->out || !a->d_mel || !a->d_pitch || !a->d_energy || !a->d_dur || !a->scratch || a->B <= 0 || a->T <= 0 || a->L <= 0 || a->n_mel <= 0)
         return ESMI_ERR_ARG;
+    static_assert(ESMI_TRAIN_LOSS_SCRATCH_FLOATS >= kLossBlocks * 6, "scratch size in the header");
     LossP p = {a->mel_pred, a->mel, a->pitch_pred, a->pitch, a->energy_pred, a->energy, a->dur_pred, a->dur, a->mel_mask, a->ph_mask,
-               a->B, a->T, a->L, a->n_mel, a->out, a->d_mel, a->d_pitch, a->d_energy, a->d_dur};
-    ESMI_LAUNCH(train_loss_kernel, dim3(1), dim3(1024), 1024 * sizeof(float), S(stream), p);
+               a->B, a->T, a->L, a->n_mel, a->out, a->d_mel, a->d_pitch, a->d_energy, a->d_dur, a->scratch};
+    ESMI_LAUNCH(train_loss_partial_kernel, dim3(kLossBlocks), dim3(256), 256 * sizeof(float), S(stream), p);
+    if (int rc = launch_status()) return rc;
+    ESMI_LAUNCH(train_loss_final_kernel, dim3(1), dim3(256), 256 * sizeof(float), S(stream), p);
+    if (int rc = launch_status()) return rc;
+    const long nm = (long)a->B * a->L * a->n_mel, np_ = (long)a->B * a->T;
+    ESMI_LAUNCH(train_loss_grad_kernel, grid1d(nm > np_ ? nm : np_), dim3(256), 0, S(stream), p);
     return launch_status();
 }
 int esmi_train_adamw_f32(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,

@@ -235,17 +235,29 @@ __global__ void train_act_bwd_kernel(const float* __restrict__ saved, const floa
     dx[q] = dy[q] * d;
 }
 
-// ---- attention core, blocks.py:43-64 (scores are NOT masked there): qkv (B, N, 3, h, C) -> P (B, h, N, N), ctx (B, N, h*C)
-__global__ void train_attn_fwd_kernel(const float* __restrict__ qkv, int B, int N, int C, int h, float scale, float* __restrict__ P,
-                                      float* __restrict__ ctx) {
-    const long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (q >= (long)B * h * N) return;
+// ---- attention core, blocks.py:43-64 (scores are NOT masked there): qkv (B, N, 3, h, C) -> P (B, h, N, N), ctx (B, N, h*C).
+// One 64-thread workgroup per (b, head, query row): lanes share the keys for the scores (wave reductions for max / sum in a
+// fixed butterfly order), then the channels for the context row.
+__device__ __forceinline__ float wave_allreduce_max(float v) {
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) v = fmaxf(v, shfl_xor_f(v, m));
+    return v;
+}
+__device__ __forceinline__ float wave_allreduce_sum(float v) {
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) v += shfl_xor_f(v, m);
+    return v;
+}
+__global__ __launch_bounds__(64) void train_attn_fwd_kernel(const float* __restrict__ qkv, int B, int N, int C, int h, float scale,
+                                                            float* __restrict__ P, float* __restrict__ ctx) {
+    const long q = blockIdx.x;
+    const int lane = (int)threadIdx.x;
     const int i = (int)(q % N), hd = (int)((q / N) % h), b = (int)(q / ((long)N * h));
     const long ld = 3L * h * C;
     const float* qi = qkv + ((long)b * N + i) * ld + (long)hd * C;
     float* p = P + (((long)b * h + hd) * N + i) * N;
     float mx = -3.0e38f;
-    for (int j = 0; j < N; ++j) {
+    for (int j = lane; j < N; j += 64) {
         const float* kj = qkv + ((long)b * N + j) * ld + (long)(h + hd) * C;
         float s = 0.0f;
         for (int c = 0; c < C; ++c) s = fmaf(qi[c], kj[c], s);
@@ -253,63 +265,65 @@ __global__ void train_attn_fwd_kernel(const float* __restrict__ qkv, int B, int 
         p[j] = s;
         mx = fmaxf(mx, s);
     }
+    mx = wave_allreduce_max(mx);
     float sum = 0.0f;
-    for (int j = 0; j < N; ++j) { const float e = expf(p[j] - mx); p[j] = e; sum += e; }
+    for (int j = lane; j < N; j += 64) { const float e = expf(p[j] - mx); p[j] = e; sum += e; }
+    sum = wave_allreduce_sum(sum);
     const float inv = 1.0f / sum;
-    for (int j = 0; j < N; ++j) p[j] *= inv;
+    for (int j = lane; j < N; j += 64) p[j] *= inv;
+    __syncthreads();                                   // the row of P is complete for every lane
     float* o = ctx + ((long)b * N + i) * h * C + (long)hd * C;
-    for (int c = 0; c < C; ++c) {
+    for (int c = lane; c < C; c += 64) {
         float a = 0.0f;
         for (int j = 0; j < N; ++j) a = fmaf(p[j], qkv[((long)b * N + j) * ld + (long)(2 * h + hd) * C + c], a);
         o[c] = a;
     }
 }
 // row i: dP = dctx_i . V^T, dS = P o (dP - <P, dP>), dq_i = scale dS K;  dS (B, h, N, N) kept for the column pass
-__global__ void train_attn_bwd_rows_kernel(const float* __restrict__ qkv, const float* __restrict__ P, const float* __restrict__ dctx,
-                                           int B, int N, int C, int h, float scale, float* __restrict__ dS, float* __restrict__ dqkv) {
-    const long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (q >= (long)B * h * N) return;
+__global__ __launch_bounds__(64) void train_attn_bwd_rows_kernel(const float* __restrict__ qkv, const float* __restrict__ P,
+                                                                 const float* __restrict__ dctx, int B, int N, int C, int h,
+                                                                 float scale, float* __restrict__ dS, float* __restrict__ dqkv) {
+    const long q = blockIdx.x;
+    const int lane = (int)threadIdx.x;
     const int i = (int)(q % N), hd = (int)((q / N) % h), b = (int)(q / ((long)N * h));
     const long ld = 3L * h * C;
     const float* p = P + (((long)b * h + hd) * N + i) * N;
     float* ds = dS + (((long)b * h + hd) * N + i) * N;
     const float* go = dctx + ((long)b * N + i) * h * C + (long)hd * C;
     float dot = 0.0f;
-    for (int j = 0; j < N; ++j) {
+    for (int j = lane; j < N; j += 64) {
         const float* vj = qkv + ((long)b * N + j) * ld + (long)(2 * h + hd) * C;
         float a = 0.0f;
         for (int c = 0; c < C; ++c) a = fmaf(go[c], vj[c], a);
         ds[j] = a;
         dot = fmaf(p[j], a, dot);
     }
-    for (int j = 0; j < N; ++j) ds[j] = p[j] * (ds[j] - dot);
+    dot = wave_allreduce_sum(dot);
+    for (int j = lane; j < N; j += 64) ds[j] = p[j] * (ds[j] - dot);
+    __syncthreads();
     float* dq = dqkv + ((long)b * N + i) * ld + (long)hd * C;
-    for (int c = 0; c < C; ++c) {
+    for (int c = lane; c < C; c += 64) {
         float a = 0.0f;
         for (int j = 0; j < N; ++j) a = fmaf(ds[j], qkv[((long)b * N + j) * ld + (long)(h + hd) * C + c], a);
         dq[c] = a * scale;
     }
 }
-// column j: dk_j = scale dS^T Q, dv_j = P^T dctx
+// column j, channel c: dk_j = scale dS^T Q, dv_j = P^T dctx   (one thread per (b, head, j, c))
 __global__ void train_attn_bwd_cols_kernel(const float* __restrict__ qkv, const float* __restrict__ P, const float* __restrict__ dS,
                                            const float* __restrict__ dctx, int B, int N, int C, int h, float scale,
                                            float* __restrict__ dqkv) {
     const long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (q >= (long)B * h * N) return;
-    const int j = (int)(q % N), hd = (int)((q / N) % h), b = (int)(q / ((long)N * h));
+    if (q >= (long)B * h * N * C) return;
+    const int c = (int)(q % C), j = (int)((q / C) % N), hd = (int)((q / ((long)C * N)) % h), b = (int)(q / ((long)C * N * h));
     const long ld = 3L * h * C;
-    float* dk = dqkv + ((long)b * N + j) * ld + (long)(h + hd) * C;
-    float* dv = dqkv + ((long)b * N + j) * ld + (long)(2 * h + hd) * C;
-    for (int c = 0; c < C; ++c) {
-        float a = 0.0f, v = 0.0f;
-        for (int i = 0; i < N; ++i) {
-            const long pi = (((long)b * h + hd) * N + i) * N + j;
-            a = fmaf(dS[pi], qkv[((long)b * N + i) * ld + (long)hd * C + c], a);
-            v = fmaf(P[pi], dctx[((long)b * N + i) * h * C + (long)hd * C + c], v);
-        }
-        dk[c] = a * scale;
-        dv[c] = v;
+    float a = 0.0f, v = 0.0f;
+    for (int i = 0; i < N; ++i) {
+        const long pi = (((long)b * h + hd) * N + i) * N + j;
+        a = fmaf(dS[pi], qkv[((long)b * N + i) * ld + (long)hd * C + c], a);
+        v = fmaf(P[pi], dctx[((long)b * N + i) * h * C + (long)hd * C + c], v);
     }
+    dqkv[((long)b * N + j) * ld + (long)(h + hd) * C + c] = a * scale;
+    dqkv[((long)b * N + j) * ld + (long)(2 * h + hd) * C + c] = v;
 }
 
 // ---- embedding: forward gather (out-of-range ids read row 0); backward one thread per table element, rows with id ==
@@ -323,15 +337,16 @@ __global__ void train_embed_fwd_kernel(const int* __restrict__ ids, const float*
     out[q] = table[(long)id * C + q % C];
 }
 __global__ void train_embed_bwd_kernel(const int* __restrict__ ids, const float* __restrict__ dy, long rows, int V, int C,
-                                       int padding_idx, float* __restrict__ dtable) {
-    const long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
+                                       int padding_idx, float* __restrict__ partial) {
+    const long q = (long)blockIdx.x * blockDim.x + threadIdx.x;   // partial[chunk][v][c] over the chunk's rows
     if (q >= (long)V * C) return;
     const int v = (int)(q / C), c = (int)(q % C);
+    const long r0 = (long)blockIdx.y * kTrainChunk, r1 = r0 + kTrainChunk < rows ? r0 + kTrainChunk : rows;
     float acc = 0.0f;
     if (v != padding_idx)
-        for (long r = 0; r < rows; ++r)
+        for (long r = r0; r < r1; ++r)
             if (ids[r] == v) acc += dy[r * C + c];
-    dtable[q] = acc;
+    partial[(long)blockIdx.y * V * C + q] = acc;
 }
 
 // ---- row masking (masked_fill(mask, 0) with a per-row mask), residual add, column-block copy (torch.cat / its gradient)
@@ -379,7 +394,8 @@ __global__ void train_repeat_bwd_kernel(const float* __restrict__ dout, const in
     dfeat[q] = acc;
 }
 
-// ---- the loss of model.py:167-216 and its gradient seeds.  One 1024-thread workgroup (fixed reduction tree: reproducible).
+// ---- the loss of model.py:167-216 and its gradient seeds, in two deterministic stages: kLossBlocks workgroups write partial
+// sums (counts, mel |d|, three squared errors) in a fixed order, one workgroup adds them up; the gradient kernel then scales.
 //   out[0..3] = mel L1, pitch MSE, energy MSE, log-duration MSE (means over the unmasked elements); out[4] = 10 a + 2 b + 2 c + d
 struct LossP {
     const float *mel_pred, *mel, *pitch_pred, *pitch, *energy_pred, *energy, *dur_pred;
@@ -387,12 +403,14 @@ struct LossP {
     const unsigned char *mel_mask, *ph_mask;   // 1 = padding; NULL = nothing masked
     int B, T, L, n_mel;
     float *out, *d_mel, *d_pitch, *d_energy, *d_dur;
+    float* partial;                            // [kLossBlocks][6]
 };
-__device__ __forceinline__ float block_sum_1024(float v, float* red) {
+constexpr int kLossBlocks = 256;
+__device__ __forceinline__ float block_sum_256(float v, float* red) {
     const int tid = (int)threadIdx.x;
     red[tid] = v;
     __syncthreads();
-    for (int s = 512; s > 0; s >>= 1) {
+    for (int s = 128; s > 0; s >>= 1) {
         if (tid < s) red[tid] += red[tid + s];
         __syncthreads();
     }
@@ -400,36 +418,57 @@ __device__ __forceinline__ float block_sum_1024(float v, float* red) {
     __syncthreads();
     return r;
 }
-__global__ __launch_bounds__(1024) void train_loss_kernel(const LossP p) {
-    ESMI_DYN_LDS(red);   // 1024 floats
-    const int tid = (int)threadIdx.x;
+__global__ __launch_bounds__(256) void train_loss_partial_kernel(const LossP p) {
+    ESMI_DYN_LDS(red);   // 256 floats
+    const long tid = (long)blockIdx.x * 256 + threadIdx.x, nth = (long)kLossBlocks * 256;
     const long nf = (long)p.B * p.L, np_ = (long)p.B * p.T;
-    float cnt_f = 0.0f, cnt_p = 0.0f;
-    for (long r = tid; r < nf; r += 1024) cnt_f += (p.mel_mask && p.mel_mask[r]) ? 0.0f : 1.0f;
-    for (long r = tid; r < np_; r += 1024) cnt_p += (p.ph_mask && p.ph_mask[r]) ? 0.0f : 1.0f;
-    const float n_mel_el = block_sum_1024(cnt_f, red) * (float)p.n_mel, n_ph = block_sum_1024(cnt_p, red);
-    float a = 0.0f;
-    for (long q = tid; q < nf * p.n_mel; q += 1024) {
-        const bool ok = !(p.mel_mask && p.mel_mask[q / p.n_mel]);
-        const float d = p.mel_pred[q] - p.mel[q];
-        if (ok) a += fabsf(d);
-        p.d_mel[q] = ok ? 10.0f * (d > 0.0f ? 1.0f : (d < 0.0f ? -1.0f : 0.0f)) / n_mel_el : 0.0f;
-    }
-    float s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
-    for (long r = tid; r < np_; r += 1024) {
-        const bool ok = !(p.ph_mask && p.ph_mask[r]);
+    float cnt_f = 0.0f, cnt_p = 0.0f, a = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+    for (long r = tid; r < nf; r += nth) cnt_f += (p.mel_mask && p.mel_mask[r]) ? 0.0f : 1.0f;
+    for (long q = tid; q < nf * p.n_mel; q += nth)
+        if (!(p.mel_mask && p.mel_mask[q / p.n_mel])) a += fabsf(p.mel_pred[q] - p.mel[q]);
+    for (long r = tid; r < np_; r += nth) {
+        if (p.ph_mask && p.ph_mask[r]) continue;
         const float d1 = p.pitch_pred[r] - p.pitch[r], d2 = p.energy_pred[r] - p.energy[r];
-        const float lp = logf(p.dur_pred[r] + 1.0f), d3 = lp - logf((float)p.dur[r] + 1.0f);
-        if (ok) { s1 = fmaf(d1, d1, s1); s2 = fmaf(d2, d2, s2); s3 = fmaf(d3, d3, s3); }
-        p.d_pitch[r] = ok ? 2.0f * 2.0f * d1 / n_ph : 0.0f;
-        p.d_energy[r] = ok ? 2.0f * 2.0f * d2 / n_ph : 0.0f;
-        p.d_dur[r] = ok ? 2.0f * d3 / (p.dur_pred[r] + 1.0f) / n_ph : 0.0f;
+        const float d3 = logf(p.dur_pred[r] + 1.0f) - logf((float)p.dur[r] + 1.0f);
+        cnt_p += 1.0f; s1 = fmaf(d1, d1, s1); s2 = fmaf(d2, d2, s2); s3 = fmaf(d3, d3, s3);
     }
-    const float mel_l = block_sum_1024(a, red) / n_mel_el;
-    const float l1 = block_sum_1024(s1, red) / n_ph, l2 = block_sum_1024(s2, red) / n_ph, l3 = block_sum_1024(s3, red) / n_ph;
-    if (tid == 0) {
+    const float v[6] = {cnt_f, cnt_p, a, s1, s2, s3};
+#pragma unroll
+    for (int e = 0; e < 6; ++e) {
+        const float t = block_sum_256(v[e], red);
+        if (threadIdx.x == 0) p.partial[(long)blockIdx.x * 6 + e] = t;
+    }
+}
+__global__ __launch_bounds__(256) void train_loss_final_kernel(const LossP p) {
+    ESMI_DYN_LDS(red);
+    float t[6];
+#pragma unroll
+    for (int e = 0; e < 6; ++e) t[e] = block_sum_256(p.partial[(long)threadIdx.x * 6 + e], red);   // kLossBlocks == blockDim
+    if (threadIdx.x == 0) {
+        const float n_el = t[0] * (float)p.n_mel, n_ph = t[1];
+        const float mel_l = t[2] / n_el, l1 = t[3] / n_ph, l2 = t[4] / n_ph, l3 = t[5] / n_ph;
         p.out[0] = mel_l; p.out[1] = l1; p.out[2] = l2; p.out[3] = l3;
         p.out[4] = 10.0f * mel_l + 2.0f * l1 + 2.0f * l2 + l3;
+        p.partial[0] = n_el;              // hand the counts to the gradient kernel (stream order)
+        p.partial[1] = n_ph;
+    }
+}
+__global__ void train_loss_grad_kernel(const LossP p) {
+    const long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long nm = (long)p.B * p.L * p.n_mel, np_ = (long)p.B * p.T;
+    const float n_el = p.partial[0], n_ph = p.partial[1];
+    if (q < nm) {
+        const bool ok = !(p.mel_mask && p.mel_mask[q / p.n_mel]);
+        const float d = p.mel_pred[q] - p.mel[q];
+        p.d_mel[q] = ok ? 10.0f * (d > 0.0f ? 1.0f : (d < 0.0f ? -1.0f : 0.0f)) / n_el : 0.0f;
+    }
+    if (q < np_) {
+        const bool ok = !(p.ph_mask && p.ph_mask[q]);
+        const float d1 = p.pitch_pred[q] - p.pitch[q], d2 = p.energy_pred[q] - p.energy[q];
+        const float d3 = logf(p.dur_pred[q] + 1.0f) - logf((float)p.dur[q] + 1.0f);
+        p.d_pitch[q] = ok ? 2.0f * 2.0f * d1 / n_ph : 0.0f;
+        p.d_energy[q] = ok ? 2.0f * 2.0f * d2 / n_ph : 0.0f;
+        p.d_dur[q] = ok ? 2.0f * d3 / (p.dur_pred[q] + 1.0f) / n_ph : 0.0f;
     }
 }
 

@@ -158,7 +158,9 @@ class _Embedding(torch.autograd.Function):
         lib, st = _rt(dy)
         V, Cc, pad = ctx.dims
         dt = _new((V, Cc), dy)
-        lib.esmi_train_embedding_bwd_f32(_ptr(ids), _ptr(dy), ids.numel(), V, Cc, pad, _ptr(dt), st)
+        nws = lib.esmi_train_embedding_bwd_workspace_bytes(ids.numel(), V, Cc)
+        ws = _new((nws,), dy, torch.uint8)
+        lib.esmi_train_embedding_bwd_f32(_ptr(ids), _ptr(dy), ids.numel(), V, Cc, pad, _ptr(dt), _ptr(ws), nws, st)
         return None, dt, None
 
 
@@ -268,7 +270,7 @@ class _Loss(torch.autograd.Function):
         grads = [torch.empty_like(t) for t in (mel_pred, pitch_pred, energy_pred, dur_pred)]
         a = _lib.TrainLossArgs(_ptr(mel_pred), _ptr(mel), _ptr(pitch_pred), _ptr(pitch), _ptr(energy_pred), _ptr(energy),
                                _ptr(dur_pred), _ptr(dur), _ptr(mel_mask), _ptr(ph_mask), B, T, L, nm, _ptr(out),
-                               *[_ptr(g) for g in grads])
+                               *[_ptr(g) for g in grads], _ptr(_new((1536,), mel_pred)))
         lib.esmi_train_loss_f32(C.byref(a), st)
         ctx.save_for_backward(*grads)
         return out

@@ -462,8 +462,9 @@ int esmi_train_attention_bwd_f32(const float* qkv, const float* P, const float* 
                                  float* dqkv, esmi_stream_t stream);
 /* nn.Embedding: out[r] = table[ids[r]]; dtable[v] = sum of dy rows with ids == v (none for v == padding_idx; -1: no padding row) */
 int esmi_train_embedding_fwd_f32(const int32_t* ids, const float* table, int64_t rows, int V, int C, float* out, esmi_stream_t stream);
+size_t esmi_train_embedding_bwd_workspace_bytes(int64_t rows, int V, int C);
 int esmi_train_embedding_bwd_f32(const int32_t* ids, const float* dy, int64_t rows, int V, int C, int padding_idx, float* dtable,
-                                 esmi_stream_t stream);
+                                 void* workspace, size_t workspace_bytes, esmi_stream_t stream);
 int esmi_train_mask_rows_f32(const float* x, const uint8_t* mask, int64_t rows, int C, float* y, esmi_stream_t stream);
 int esmi_train_add_f32(const float* a, const float* b, int64_t n, float* y, esmi_stream_t stream);
 /* dst[r, col_dst + c] = src[r, col_src + c], c < C: torch.cat along channels and its gradient */
@@ -475,6 +476,7 @@ int esmi_train_repeat_fwd_f32(const float* feat, const int32_t* cum, int B, int 
 int esmi_train_repeat_bwd_f32(const float* dout, const int32_t* cum, int B, int T, int C, int L, float* dfeat, esmi_stream_t stream);
 /* model.py:167-216: masked L1 (mel) + masked MSE (pitch, energy, log(duration + 1)), total = 10 a + 2 b + 2 c + d.
  * out (5 floats, device): the four means and the total; d_*: d total / d prediction (0 under the masks). */
+#define ESMI_TRAIN_LOSS_SCRATCH_FLOATS 1536
 typedef struct esmi_train_loss_args {
     const float *mel_pred, *mel;            /* (B, L, n_mel) */
     const float *pitch_pred, *pitch, *energy_pred, *energy, *dur_pred; /* (B, T) */
@@ -482,6 +484,7 @@ typedef struct esmi_train_loss_args {
     const uint8_t *mel_mask, *ph_mask;      /* (B, L) / (B, T), 1 = padding; NULL = nothing masked */
     int B, T, L, n_mel;
     float *out, *d_mel, *d_pitch, *d_energy, *d_dur;
+    float* scratch;                         /* ESMI_TRAIN_LOSS_SCRATCH_FLOATS floats (partial sums of the two-stage reduction) */
 } esmi_train_loss_args;
 int esmi_train_loss_f32(const esmi_train_loss_args* a, esmi_stream_t stream);
 /* torch.optim.AdamW's update of one flat buffer; step >= 1 */
