@@ -16,6 +16,7 @@ Prints ONE JSON line (rank 0):
   allgather              (N>1) the mel all-gather timed by itself: GB/s received per rank vs 7 xGMI links x 76.8 GB/s
   without_allgather      (N>1) the same sharded steps with the exchange switched off (compute scaling next to the link-bound value)
   vocoder                (N=1) the HiFi-GAN v2 generator on the mel the forward produced: mel-frames/s, TFLOP/s
+  train_step             the training step (BASELINE configs[4]): ms/step at the reference's batch size per GPU
   cpu_baseline           (N=1) the C oracle (oracle/, fp32 accumulation, OpenMP) on this box's host cores: all cores and
                          n=24 (the reference's --threads default), plus the B=1 fox-sentence latency (BASELINE configs[0]) --
                          a reported baseline, not the target.
@@ -394,6 +395,34 @@ def main():
                               "note": "synthetic seeded generator weights; 20 launches (one per ResBlock, csrc/hifigan_resblock.h); "
                                       "text_to_wav = acoustic model and vocoder back to back on one GPU"}
             del voc, wav, mel_v
+    if not a.no_extras and not a.exact_fp32:
+        # ---- BASELINE configs[4]: the training step (forward + loss + backward + AdamW; N > 1: one RCCL all-reduce of the flat
+        # gradient buffer per step), tiny-ES-shaped synthetic teacher-forced batch of the reference's default batch size per GPU
+        from efficientspeech_amd import train as _train
+        tb, tt = 128, 100
+        tnet = make_net(cfg, sd, dev).train()
+        tx, ty = _train.synthetic_batch(tb, tt, a.dur, dev, seed=77 + rank)
+        ts = _train.TrainStep(tnet, world_size=world)
+        for _ in range(3):
+            tl0 = ts.step(tx, ty)
+        sync_all()
+        t0 = time.perf_counter()
+        n_tr = 10
+        for _ in range(n_tr):
+            tl1 = ts.step(tx, ty)
+        sync_all()
+        ttr = torch.tensor([(time.perf_counter() - t0) / n_tr], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(ttr, op=dist.ReduceOp.MAX)
+        ttr = float(ttr.item())
+        out["train_step"] = {"ms_per_step": ttr * 1e3, "mel_frames_per_s": tb * tt * a.dur * world / ttr, "steps": n_tr,
+                             "per_gpu_batch": tb, "phonemes": tt, "frames_per_utterance": tt * a.dur,
+                             "loss_first_last": [float(tl0[4]), float(tl1[4])],
+                             "allreduce_bytes_per_step": int(ts.flat.grad.numel() * 4) if world > 1 else 0,
+                             "note": "SURVEY 8f-2 / BASELINE configs[4]: train=True forward, masked L1 + 3 MSE loss, backward, AdamW "
+                                     "(efficientspeech_amd/train.py; esmi_train_* kernels); synthetic teacher-forced batch, D-const "
+                                     "durations; data-parallel: one all-reduce of the flat fp32 gradient buffer"}
+        del tnet, ts
     if rank == 0:
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, sd, T, a.dur)

@@ -481,3 +481,19 @@ class TrainStep:
             if c is not None and hasattr(c, "invalidate"):
                 c.invalidate()
         return losses.detach()
+
+
+def synthetic_batch(B, T, dur, device, seed=5):
+    """A seeded teacher-forced batch of the shapes datamodule.collate_fn produces (datamodule.py:29-76): no padding, D-const."""
+    import numpy as np
+    from .synth import synth_phonemes
+    g = np.random.default_rng(seed)
+    ids, mask = synth_phonemes(B, T, seed)
+    L = T * dur
+    x = {"phoneme": torch.from_numpy(ids), "phoneme_mask": torch.from_numpy(mask),
+         "pitch": torch.from_numpy(g.uniform(-3, 10, (B, T)).astype(np.float32)),
+         "energy": torch.from_numpy(g.uniform(-2, 8, (B, T)).astype(np.float32)),
+         "duration": torch.full((B, T), dur, dtype=torch.int32), "mel_len": torch.full((B,), L, dtype=torch.int32),
+         "mel_mask": torch.zeros((B, L), dtype=torch.bool)}
+    y = {"mel": torch.from_numpy(g.normal(-5, 2, (B, L, 80)).astype(np.float32))}
+    return {k: v.to(device) for k, v in x.items()}, {k: v.to(device) for k, v in y.items()}

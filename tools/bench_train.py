@@ -6,21 +6,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np, torch
 from efficientspeech_amd import CONFIGS, build_phoneme2mel, train
-from efficientspeech_amd.synth import synth_state_dict, synth_phonemes
-
-
-def synth_batch(B, T, dur, dev, seed=5):
-    g = np.random.default_rng(seed)
-    ids, mask = synth_phonemes(B, T, seed)
-    d = np.full((B, T), dur, np.int32)
-    L = T * dur
-    x = {"phoneme": torch.from_numpy(ids), "phoneme_mask": torch.from_numpy(mask),
-         "pitch": torch.from_numpy(g.uniform(-3, 10, (B, T)).astype(np.float32)),
-         "energy": torch.from_numpy(g.uniform(-2, 8, (B, T)).astype(np.float32)),
-         "duration": torch.from_numpy(d), "mel_len": torch.full((B,), L, dtype=torch.int32),
-         "mel_mask": torch.zeros((B, L), dtype=torch.bool)}
-    y = {"mel": torch.from_numpy(g.normal(-5, 2, (B, L, 80)).astype(np.float32))}
-    return {k: v.to(dev) for k, v in x.items()}, {k: v.to(dev) for k, v in y.items()}
+from efficientspeech_amd.synth import synth_state_dict
 
 
 if __name__ == "__main__":
@@ -32,7 +18,7 @@ if __name__ == "__main__":
     net = build_phoneme2mel(cfg)
     net.load_state_dict({k: torch.from_numpy(v) for k, v in synth_state_dict(cfg, 1234).items()})
     net = net.cuda().train()
-    x, y = synth_batch(a.batch, a.phonemes, a.dur, "cuda")
+    x, y = train.synthetic_batch(a.batch, a.phonemes, a.dur, "cuda")
     step = train.TrainStep(net)
     for _ in range(2):
         l0 = step.step(x, y)
