@@ -88,7 +88,8 @@ __global__ void train_conv_dgrad_kernel(const ConvDesc d, const float* __restric
 // Reductions over the rows (B * n positions) run in two deterministic stages: stage 1 gives every (output element, chunk of
 // kTrainChunk rows) its own thread and writes a partial sum, stage 2 adds the partials of an element in chunk order.
 constexpr int kTrainChunk = 256;
-__host__ __device__ inline long train_chunks(long rows) { return (rows + kTrainChunk - 1) / kTrainChunk; }
+constexpr int kTrainChunkMfma = 256;    // rows per wave of the matrix-pipe weight gradient (1024 measured slower: too few waves)
+__host__ __device__ inline long train_chunks(long rows, int chunk = kTrainChunk) { return (rows + chunk - 1) / chunk; }
 
 // dw(co, ci, j) = sum over (b, t) of dy[b, t, co] * x[b, in_pos(t, j), ci]: partial[chunk][weight element in checkpoint order]
 __global__ void train_conv_wgrad_kernel(const ConvDesc d, const float* __restrict__ x, const float* __restrict__ dy,
@@ -118,15 +119,16 @@ __global__ void train_conv_wgrad_kernel(const ConvDesc d, const float* __restric
 // accumulation): lane (i, kh) feeds dY[row + kh][co0 + i] and X[in_pos(row + kh)][ci0 + i] -- both 128-byte coalesced.
 __global__ __launch_bounds__(256) void train_conv_wgrad_mfma_kernel(const ConvDesc d, const float* __restrict__ x,
                                                                     const float* __restrict__ dy, float* __restrict__ partial,
-                                                                    long chunks) {
+                                                                    float* __restrict__ partial_bias, long chunks) {
     const int lane = lane_id(), i = lane & 31, kh = lane >> 5;
     const int tci = (d.c_in + 31) / 32;
     const int tile = (int)blockIdx.x, j = tile % d.k, ci0 = ((tile / d.k) % tci) * 32, co0 = (tile / (d.k * tci)) * 32;
     const long chunk = (long)blockIdx.y * 4 + wave_id();
     if (chunk >= chunks) return;
-    const long rows = (long)d.B * d.n_out, r0 = chunk * kTrainChunk, r1 = r0 + kTrainChunk < rows ? r0 + kTrainChunk : rows;
+    const long rows = (long)d.B * d.n_out, r0 = chunk * kTrainChunkMfma, r1 = r0 + kTrainChunkMfma < rows ? r0 + kTrainChunkMfma : rows;
     const bool co_ok = co0 + i < d.c_out, ci_ok = ci0 + i < d.c_in;
     f32x16 acc = zero16();
+    float bsum = 0.0f;                                  // this lane's share of sum over rows of dY[:, co0 + i]: the bias gradient
     for (long r = r0; r < r1; r += 2) {
         const long rr = r + kh;
         float a = 0.0f, bv = 0.0f;
@@ -136,6 +138,7 @@ __global__ __launch_bounds__(256) void train_conv_wgrad_mfma_kernel(const ConvDe
             if (co_ok) a = dy[rr * d.c_out + co0 + i];
             if (ci_ok && ti >= 0) bv = x[((long)b * d.n_in + ti) * d.c_in + ci0 + i];
         }
+        bsum += a;
         acc = mfma32(a, bv, acc);
     }
     const long nw = (long)d.c_out * d.c_in * d.k;
@@ -145,15 +148,25 @@ __global__ __launch_bounds__(256) void train_conv_wgrad_mfma_kernel(const ConvDe
         long wi;
         if (co < d.c_out && ci < d.c_in && conv_w_index(d, co, ci, j, &wi)) partial[chunk * nw + wi] = acc[r];
     }
+    if (partial_bias && j == 0 && ci0 == 0) {           // one tile column per output-channel tile also carries the bias partials
+        bsum += shfl_xor_f(bsum, 32);                   // even rows (kh = 0) + odd rows (kh = 1)
+        if (kh == 0 && co_ok) partial_bias[chunk * d.c_out + co0 + i] = bsum;
+    }
 }
 
-// out[e] = sum over chunks of partial[chunk * stride + e], e < n
-__global__ void train_reduce_chunks_kernel(const float* __restrict__ partial, long n, long stride, long chunks, float* __restrict__ out) {
-    const long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (q >= n) return;
+// out[e] = sum over chunks of partial[chunk * stride + e], e < n.  256 threads = 64 elements x 4 interleaved chunk groups; the
+// four group sums are added in group order (fixed order: reproducible)
+__global__ __launch_bounds__(256) void train_reduce_chunks_kernel(const float* __restrict__ partial, long n, long stride, long chunks,
+                                                                  float* __restrict__ out) {
+    ESMI_DYN_LDS(red);   // 256 floats
+    const int ex = (int)(threadIdx.x & 63), cy = (int)(threadIdx.x >> 6);
+    const long q = (long)blockIdx.x * 64 + ex;
     float acc = 0.0f;
-    for (long c = 0; c < chunks; ++c) acc += partial[c * stride + q];
-    out[q] = acc;
+    if (q < n)
+        for (long c = cy; c < chunks; c += 4) acc += partial[c * stride + q];
+    red[cy * 64 + ex] = acc;
+    __syncthreads();
+    if (cy == 0 && q < n) out[q] = ((red[ex] + red[64 + ex]) + red[128 + ex]) + red[192 + ex];
 }
 // partial[chunk][c] = sum over the chunk's rows of v[row, c]   (bias gradients)
 __global__ void train_colsum_kernel(const float* __restrict__ v, long rows, int C, float* __restrict__ partial) {
@@ -165,37 +178,45 @@ __global__ void train_colsum_kernel(const float* __restrict__ v, long rows, int 
     partial[(long)blockIdx.y * C + c] = acc;
 }
 
-// ---- LayerNorm over the last dim (biased variance, eps inside the sqrt), one thread per row; mean / rstd kept for backward
-__global__ void train_ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ g, const float* __restrict__ b, long rows,
-                                    int C, float eps, float* __restrict__ y, float* __restrict__ mean, float* __restrict__ rstd) {
-    const long r = (long)blockIdx.x * blockDim.x + threadIdx.x;
+// ---- LayerNorm over the last dim (biased variance, eps inside the sqrt): one wave per row, lanes across the channels
+// (coalesced), sums by a fixed butterfly; mean / rstd kept for backward
+__device__ __forceinline__ float ln_wave_sum(float v) {
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) v += shfl_xor_f(v, m);
+    return v;
+}
+__global__ __launch_bounds__(256) void train_ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ g,
+                                                           const float* __restrict__ b, long rows, int C, float eps,
+                                                           float* __restrict__ y, float* __restrict__ mean, float* __restrict__ rstd) {
+    const long r = (long)blockIdx.x * 4 + wave_id();
     if (r >= rows) return;
+    const int lane = lane_id();
     const float* xr = x + r * C;
     float m = 0.0f;
-    for (int c = 0; c < C; ++c) m += xr[c];
-    m /= (float)C;
+    for (int c = lane; c < C; c += 64) m += xr[c];
+    m = ln_wave_sum(m) / (float)C;
     float v = 0.0f;
-    for (int c = 0; c < C; ++c) { const float dlt = xr[c] - m; v = fmaf(dlt, dlt, v); }
-    const float rs = 1.0f / sqrtf(v / (float)C + eps);
-    mean[r] = m;
-    rstd[r] = rs;
-    for (int c = 0; c < C; ++c) y[r * C + c] = fmaf((xr[c] - m) * rs, g[c], b[c]);
+    for (int c = lane; c < C; c += 64) { const float dlt = xr[c] - m; v = fmaf(dlt, dlt, v); }
+    const float rs = 1.0f / sqrtf(ln_wave_sum(v) / (float)C + eps);
+    if (lane == 0) { mean[r] = m; rstd[r] = rs; }
+    for (int c = lane; c < C; c += 64) y[r * C + c] = fmaf((xr[c] - m) * rs, g[c], b[c]);
 }
-__global__ void train_ln_bwd_dx_kernel(const float* __restrict__ x, const float* __restrict__ g, const float* __restrict__ mean,
-                                       const float* __restrict__ rstd, const float* __restrict__ dy, long rows, int C,
-                                       float* __restrict__ dx) {
-    const long r = (long)blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(256) void train_ln_bwd_dx_kernel(const float* __restrict__ x, const float* __restrict__ g,
+                                                              const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                              const float* __restrict__ dy, long rows, int C, float* __restrict__ dx) {
+    const long r = (long)blockIdx.x * 4 + wave_id();
     if (r >= rows) return;
+    const int lane = lane_id();
     const float m = mean[r], rs = rstd[r];
     float s1 = 0.0f, s2 = 0.0f;
-    for (int c = 0; c < C; ++c) {
+    for (int c = lane; c < C; c += 64) {
         const float xh = (x[r * C + c] - m) * rs, dh = dy[r * C + c] * g[c];
         s1 += dh;
         s2 = fmaf(dh, xh, s2);
     }
-    s1 /= (float)C;
-    s2 /= (float)C;
-    for (int c = 0; c < C; ++c) {
+    s1 = ln_wave_sum(s1) / (float)C;
+    s2 = ln_wave_sum(s2) / (float)C;
+    for (int c = lane; c < C; c += 64) {
         const float xh = (x[r * C + c] - m) * rs, dh = dy[r * C + c] * g[c];
         dx[r * C + c] = rs * (dh - s1 - xh * s2);
     }
