@@ -140,7 +140,7 @@ EXPORTS = (
     "esmi_train_layernorm_bwd_f32", "esmi_train_act_fwd_f32", "esmi_train_act_bwd_f32", "esmi_train_attention_fwd_f32",
     "esmi_train_attention_bwd_f32", "esmi_train_embedding_fwd_f32", "esmi_train_embedding_bwd_f32", "esmi_train_mask_rows_f32",
     "esmi_train_add_f32", "esmi_train_copy_cols_f32", "esmi_train_repeat_fwd_f32", "esmi_train_repeat_bwd_f32",
-    "esmi_train_loss_f32", "esmi_train_adamw_f32",
+    "esmi_train_loss_f32", "esmi_train_adamw_f32", "esmi_train_adamw_graph_f32",
 )
 
 
@@ -220,6 +220,7 @@ def bind(lib):
     lib.esmi_train_repeat_bwd_f32.argtypes = [fp, fp, i, i, i, i, fp, fp]
     lib.esmi_train_loss_f32.argtypes = [P(TrainLossArgs), fp]
     lib.esmi_train_adamw_f32.argtypes = [fp, fp, fp, fp, i64, f, f, f, f, f, i, fp]
+    lib.esmi_train_adamw_graph_f32.argtypes = [fp, fp, fp, fp, i64, fp, f, f, f, f, fp, fp]
     lib.esmi_pack_resblock_bytes.argtypes = [i, i]
     lib.esmi_pack_resblock_bytes.restype = sz
     lib.esmi_pack_resblock_f16.argtypes = [fp, fp, i, i, fp]

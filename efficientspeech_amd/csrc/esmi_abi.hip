@@ -1405,4 +1405,13 @@ int esmi_train_adamw_f32(float* p, const float* g, float* m, float* v, int64_t n
     return launch_status();
 }
 
+int esmi_train_adamw_graph_f32(float* p, const float* g, float* m, float* v, int64_t n, const float* lr_dev, float beta1, float beta2,
+                               float eps, float weight_decay, int32_t* step_dev, esmi_stream_t stream) {
+    if (!p || !g || !m || !v || !lr_dev || !step_dev || n <= 0) return ESMI_ERR_ARG;
+    ESMI_LAUNCH(train_bump_step_kernel, dim3(1), dim3(1), 0, S(stream), step_dev);
+    if (int rc = launch_status()) return rc;
+    ESMI_LAUNCH(train_adamw_dev_kernel, grid1d(n), dim3(256), 0, S(stream), p, g, m, v, (long)n, lr_dev, beta1, beta2, eps, weight_decay, step_dev);
+    return launch_status();
+}
+
 }  // extern "C"

@@ -509,4 +509,25 @@ __global__ void train_adamw_kernel(float* __restrict__ p, const float* __restric
     p[q] = w;
 }
 
+// the same with the step count and the learning rate read from device memory, so that a captured hipGraph of the whole
+// training step replays correctly: hyper = {lr}; *step is advanced by train_bump_step_kernel inside the graph
+__global__ void train_bump_step_kernel(int* __restrict__ step) { step[0] += 1; }
+__global__ void train_adamw_dev_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                       long n, const float* __restrict__ lr_dev, float beta1, float beta2, float eps, float wd,
+                                       const int* __restrict__ step) {
+    const long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= n) return;
+    const float lr = lr_dev[0], t = (float)step[0];
+    const float bc1 = 1.0f - powf(beta1, t), bc2_sqrt = sqrtf(1.0f - powf(beta2, t));
+    const float grad = g[q];
+    float w = p[q] * (1.0f - lr * wd);
+    const float mm = beta1 * m[q] + (1.0f - beta1) * grad;
+    const float vv = beta2 * v[q] + (1.0f - beta2) * grad * grad;
+    m[q] = mm;
+    v[q] = vv;
+    const float denom = sqrtf(vv) / bc2_sqrt + eps;
+    w -= (lr / bc1) * (mm / denom);
+    p[q] = w;
+}
+
 }  // namespace esmi

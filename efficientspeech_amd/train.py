@@ -455,32 +455,81 @@ class TrainStep:
     """One optimizer step of the reference's training loop (model.py:212-226 + :279-283) on one GPU of a data-parallel job.
 
     step(x, y): forward + loss + backward on this rank's batch, ONE all-reduce (mean) of the flat gradient buffer over `group`
-    (RCCL when the process group is `nccl`), one AdamW launch.  lr follows torch.optim.AdamW's defaults as model.py sets them."""
+    (RCCL when the process group is `nccl`), one AdamW launch.  lr follows torch.optim.AdamW's defaults as model.py sets them.
 
-    def __init__(self, net, lr=1e-3, weight_decay=1e-6, betas=(0.9, 0.999), eps=1e-8, group=None, world_size=1):
+    graph=True captures the whole step (≈ 650 launches) into one hipGraph the first time a batch SHAPE is seen and replays it for
+    every later batch of that shape (inputs are copied into the graph's static buffers; step count and learning rate live in
+    device memory).  Single-GPU only: the gradient all-reduce stays outside a graph."""
+
+    def __init__(self, net, lr=1e-3, weight_decay=1e-6, betas=(0.9, 0.999), eps=1e-8, group=None, world_size=1, graph=False):
         self.net, self.flat = net, FlatParams(net)
         self.lr, self.wd, self.betas, self.eps = lr, weight_decay, betas, eps
         self.group, self.world = group, world_size
         self.t = 0
+        self.graph = bool(graph) and world_size == 1
+        self._graphs = {}
+        if self.graph:
+            dev = self.flat.data.device
+            self._step_dev = torch.zeros(1, dtype=torch.int32, device=dev)
+            self._lr_dev = torch.full((1,), lr, dtype=torch.float32, device=dev)
 
-    def step(self, x, y, lr=None):
-        import torch.distributed as dist
-        self.flat.zero_grad()
-        losses = training_loss(self.net, x, y)
-        losses[4].backward()                       # gradients accumulate straight into the flat buffer's views
-        if self.world > 1:
-            dist.all_reduce(self.flat.grad, op=dist.ReduceOp.SUM, group=self.group)
-            self.flat.grad.div_(self.world)        # DDP averages (train.py:66-70 runs Lightning's default DDP strategy)
-        self.t += 1
-        f = self.flat
-        lib, st = _rt(f.data)
-        lib.esmi_train_adamw_f32(_ptr(f.data), _ptr(f.grad), _ptr(f.m), _ptr(f.v), f.data.numel(), self.lr if lr is None else lr,
-                                 self.betas[0], self.betas[1], self.eps, self.wd, self.t, st)
+    def _invalidate_packed(self):
         for m in self.net.modules():               # the kernel wrote the weights behind torch's version counters: drop the
             c = getattr(m, "_cache", None)         # inference path's packed copies so the next eval forward re-packs
             if c is not None and hasattr(c, "invalidate"):
                 c.invalidate()
+
+    def _body(self, x, y, lr, graph):
+        f = self.flat
+        f.zero_grad()
+        losses = training_loss(self.net, x, y)
+        losses[4].backward()                       # gradients accumulate straight into the flat buffer's views
+        if self.world > 1:
+            import torch.distributed as dist
+            dist.all_reduce(f.grad, op=dist.ReduceOp.SUM, group=self.group)
+            f.grad.div_(self.world)                # DDP averages (train.py:66-70 runs Lightning's default DDP strategy)
+        lib, st = _rt(f.data)
+        if graph:
+            lib.esmi_train_adamw_graph_f32(_ptr(f.data), _ptr(f.grad), _ptr(f.m), _ptr(f.v), f.data.numel(), _ptr(self._lr_dev),
+                                           self.betas[0], self.betas[1], self.eps, self.wd, _ptr(self._step_dev), st)
+        else:
+            lib.esmi_train_adamw_f32(_ptr(f.data), _ptr(f.grad), _ptr(f.m), _ptr(f.v), f.data.numel(), lr, self.betas[0],
+                                     self.betas[1], self.eps, self.wd, self.t, st)
         return losses.detach()
+
+    def step(self, x, y, lr=None):
+        self.t += 1
+        lr = self.lr if lr is None else lr
+        if not self.graph:
+            out = self._body(x, y, lr, False)
+            self._invalidate_packed()
+            return out
+        self._lr_dev.fill_(lr)
+        key = tuple((k, tuple(v.shape)) for k, v in sorted({**x, **{"y." + k: v for k, v in y.items()}}.items()) if torch.is_tensor(v))
+        ent = self._graphs.get(key)
+        if ent is None:
+            sx = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in x.items()}
+            sy = {k: v.clone() for k, v in y.items()}
+            side = torch.cuda.Stream(device=self.flat.data.device)          # one eager step on a side stream warms the allocator
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                out = self._body(sx, sy, lr, True)
+            torch.cuda.current_stream().wait_stream(side)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                static_out = self._body(sx, sy, lr, True)
+            self._graphs[key] = (g, sx, sy, static_out)
+            self._invalidate_packed()
+            return out.clone()                     # (the capture itself does not execute: this batch's step ran eagerly above)
+        g, sx, sy, static_out = ent
+        for k, v in x.items():
+            if torch.is_tensor(v):
+                sx[k].copy_(v)
+        for k, v in y.items():
+            sy[k].copy_(v)
+        g.replay()
+        self._invalidate_packed()
+        return static_out.clone()
 
 
 def synthetic_batch(B, T, dur, device, seed=5):

@@ -490,6 +490,10 @@ int esmi_train_loss_f32(const esmi_train_loss_args* a, esmi_stream_t stream);
 /* torch.optim.AdamW's update of one flat buffer; step >= 1 */
 int esmi_train_adamw_f32(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
                          float weight_decay, int step, esmi_stream_t stream);
+/* the same update for a captured hipGraph of the whole step: the learning rate (1 float) and the step counter (1 int32, advanced
+ * by this call before the update) live in device memory, so a replay uses the current values */
+int esmi_train_adamw_graph_f32(float* p, const float* g, float* m, float* v, int64_t n, const float* lr_dev, float beta1, float beta2,
+                               float eps, float weight_decay, int32_t* step_dev, esmi_stream_t stream);
 
 #ifdef __cplusplus
 }

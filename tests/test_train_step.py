@@ -161,3 +161,17 @@ def test_two_rank_data_parallel_step_keeps_replicas_identical(tmp_path):
     mp.spawn(_ddp_worker, args=(2, _free_port(), out), nprocs=2, join=True)
     same_params, different_losses, finite = np.load(out)
     assert same_params == 1 and different_losses == 1 and finite == 1
+
+
+@pytest.mark.gpu
+def test_gpu_captured_step_equals_eager_step():
+    """graph=True: the whole step replayed from one hipGraph gives the eager step's losses and parameters."""
+    train, g, net, x, y = _setup("cuda")
+    eager = train.TrainStep(net, lr=1e-3)
+    ref = [eager.step(x, y).clone() for _ in range(4)]
+    t2, g2, net2, x2, y2 = _setup("cuda")
+    cap = t2.TrainStep(net2, lr=1e-3, graph=True)
+    got = [cap.step(x2, y2).clone() for _ in range(4)]      # step 1 captures (and runs eagerly), steps 2-4 replay
+    for a, b in zip(ref, got):                               # (bias corrections: powf on the device vs on the host, ~1 ulp)
+        assert torch.allclose(a, b, rtol=1e-5, atol=0), (a, b)
+    assert torch.allclose(eager.flat.data, cap.flat.data, rtol=1e-4, atol=1e-6)

@@ -12,20 +12,21 @@ from efficientspeech_amd.synth import synth_state_dict
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--config", default="tiny"); ap.add_argument("--batch", type=int, default=32)
-    ap.add_argument("--phonemes", type=int, default=128); ap.add_argument("--dur", type=int, default=6); ap.add_argument("--iters", type=int, default=5)
+    ap.add_argument("--phonemes", type=int, default=128); ap.add_argument("--dur", type=int, default=6); ap.add_argument("--iters", type=int, default=5); ap.add_argument("--graph", action="store_true")
     a = ap.parse_args()
     cfg = CONFIGS[a.config]
     net = build_phoneme2mel(cfg)
     net.load_state_dict({k: torch.from_numpy(v) for k, v in synth_state_dict(cfg, 1234).items()})
     net = net.cuda().train()
     x, y = train.synthetic_batch(a.batch, a.phonemes, a.dur, "cuda")
-    step = train.TrainStep(net)
-    for _ in range(2):
+    step = train.TrainStep(net, graph=a.graph)
+    for _ in range(3):
         l0 = step.step(x, y)
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(a.iters):
         l1 = step.step(x, y)
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / a.iters
     frames = a.batch * a.phonemes * a.dur
-    print(f"train step {a.config}: B={a.batch} T={a.phonemes} L={a.phonemes * a.dur}: {dt * 1e3:.1f} ms/step  {frames / dt:.3e} mel-frames/s  "
+    mode = " (hipGraph)" if a.graph else ""
+    print(f"train step{mode} {a.config}: B={a.batch} T={a.phonemes} L={a.phonemes * a.dur}: {dt * 1e3:.1f} ms/step  {frames / dt:.3e} mel-frames/s  "
           f"loss {float(l0[4]):.3f} -> {float(l1[4]):.3f}")
