@@ -268,9 +268,10 @@ class _Loss(torch.autograd.Function):
         T = pitch_pred.shape[1]
         out = _new((5,), mel_pred)
         grads = [torch.empty_like(t) for t in (mel_pred, pitch_pred, energy_pred, dur_pred)]
+        scratch = _new((1536,), mel_pred)          # ESMI_TRAIN_LOSS_SCRATCH_FLOATS; held until the call has been enqueued
         a = _lib.TrainLossArgs(_ptr(mel_pred), _ptr(mel), _ptr(pitch_pred), _ptr(pitch), _ptr(energy_pred), _ptr(energy),
                                _ptr(dur_pred), _ptr(dur), _ptr(mel_mask), _ptr(ph_mask), B, T, L, nm, _ptr(out),
-                               *[_ptr(g) for g in grads], _ptr(_new((1536,), mel_pred)))
+                               *[_ptr(g) for g in grads], _ptr(scratch))
         lib.esmi_train_loss_f32(C.byref(a), st)
         ctx.save_for_backward(*grads)
         return out

@@ -225,3 +225,40 @@ def mask_from_lengths(lengths, T):
     m = np.empty((len(lengths), T), np.uint8)
     lib().eso_mask_from_lengths(len(lengths), int(T), _p(lengths), _p(m))
     return m.astype(bool)
+
+
+# ---------------------------------------------------------------------- training step: loss and optimizer
+def training_loss(mel_pred, mel, mel_mask, pitch_pred, pitch, energy_pred, energy, dur_pred, dur, ph_mask):
+    """model.py:167-216 in float64 NumPy: masked L1 on mel, masked MSE on pitch / energy / log(duration + 1) (means over the
+    unmasked elements), total = 10 a + 2 b + 2 c + d.  Masks: True = padding.  Returns (four losses + total, gradients of the
+    total with respect to mel_pred / pitch_pred / energy_pred / dur_pred)."""
+    f = lambda a: np.asarray(a, np.float64)     # noqa: E731
+    mel_pred, mel, pitch_pred, pitch, energy_pred, energy, dur_pred = map(f, (mel_pred, mel, pitch_pred, pitch, energy_pred, energy, dur_pred))
+    mv = ~np.asarray(mel_mask, bool) if mel_mask is not None else np.ones(mel.shape[:2], bool)
+    pv = ~np.asarray(ph_mask, bool) if ph_mask is not None else np.ones(pitch.shape, bool)
+    n_el, n_ph = mv.sum() * mel.shape[-1], pv.sum()
+    d = (mel_pred - mel) * mv[..., None]
+    losses = [np.abs(d).sum() / n_el]
+    grads = [10.0 * np.sign(d) / n_el]
+    for pred, tgt, wgt in ((pitch_pred, pitch, 2.0), (energy_pred, energy, 2.0)):
+        e = (pred.reshape(tgt.shape) - tgt) * pv
+        losses.append((e * e).sum() / n_ph)
+        grads.append(wgt * 2.0 * e / n_ph)
+    dp = dur_pred.reshape(pitch.shape)
+    e = (np.log(dp + 1.0) - np.log(f(dur) + 1.0)) * pv
+    losses.append((e * e).sum() / n_ph)
+    grads.append(2.0 * e / (dp + 1.0) / n_ph)
+    losses.append(10.0 * losses[0] + 2.0 * losses[1] + 2.0 * losses[2] + losses[3])
+    return np.array(losses), grads
+
+
+def adamw_step(p, g, m, v, t, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-6):
+    """torch.optim.AdamW's update (model.py:279-283 with its defaults), float32 arithmetic in the same order; t >= 1."""
+    f32 = np.float32
+    p, g, m, v = (np.asarray(a, f32) for a in (p, g, m, v))
+    p = p * f32(1.0 - lr * weight_decay)
+    m = f32(betas[0]) * m + f32(1.0 - betas[0]) * g
+    v = f32(betas[1]) * v + f32(1.0 - betas[1]) * g * g
+    bc1, bc2 = 1.0 - betas[0] ** t, 1.0 - betas[1] ** t
+    denom = np.sqrt(v) / f32(np.sqrt(bc2)) + f32(eps)
+    return (p - f32(lr / bc1) * (m / denom)).astype(f32), m.astype(f32), v.astype(f32)

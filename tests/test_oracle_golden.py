@@ -138,3 +138,23 @@ def test_hifigan_weight_norm_folding_and_key_table():
         assert sorted((k, tuple(v.shape)) for k, v in net.state_dict().items()) == sorted(hifigan_state_dict_spec(h))
         net.load_state_dict({k: torch.from_numpy(v) for k, v in synth_hifigan_state_dict(h, 3).items()}, strict=True)
     assert sum(p.numel() for p in Generator(HIFIGAN_CONFIGS["v2"]).parameters()) == 925_985   # = the reference LJ_V2/generator_v2 checkpoint (weight_v + bias tensors), "926k"
+
+
+def test_oracle_training_loss_and_adamw_match_reference_fixture():
+    """the oracle's restatement of model.py:167-216 (loss) and of torch.optim.AdamW's update, pinned to the
+    reference-generated training fixture (tools/gen_golden_train.py)."""
+    from efficientspeech_amd.synth import synth_state_dict
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "tiny_train_step.npz"))
+    losses, grads = oracle.training_loss(g["mel_pred"], g["in_mel"], g["in_mel_mask"], g["pitch_pred"], g["in_pitch"], g["energy_pred"],
+                                         g["in_energy"], g["duration_pred"], g["in_duration"], g["in_phoneme_mask"])
+    assert np.allclose(losses[:4], g["losses"], rtol=1e-6) and abs(losses[4] - float(g["total"])) < 1e-6 * float(g["total"])
+    assert grads[0].shape == g["mel_pred"].shape and np.all(grads[0][g["in_mel_mask"]] == 0)
+    sd = synth_state_dict(CONFIGS["tiny"], 1234)
+    n = 0
+    for k in g.files:
+        if k.startswith("after."):
+            name = k[6:]
+            p1, _, _ = oracle.adamw_step(sd[name], g["grad." + name], np.zeros_like(sd[name]), np.zeros_like(sd[name]), 1)
+            assert np.abs(p1 - g[k]).max() < 1e-7, name
+            n += 1
+    assert n >= 5

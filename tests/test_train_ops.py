@@ -1,0 +1,179 @@
+"""Operator-level checks of the training kernels (csrc/train_ops.h, esmi_train_*) against plain PyTorch fp32 ops on the same
+device, at sizes that exercise what the small reference fixture cannot: many row chunks in the two-stage reductions, weight
+tiles that are not multiples of 32, strided / transposed / depthwise convolutions, several heads.  (PyTorch is the checker
+here, as the numerics-test rule asks; the step-level parity is pinned to the reference fixture in test_train_step.py.)"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from efficientspeech_amd import train
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _rand(*shape, seed=0, scale=1.0):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(DEV)
+
+
+def _close(a, b, rtol, what):
+    a, b = a.detach(), b.detach()
+    scale = max(1e-6, float(b.abs().max()))
+    err = float((a - b).abs().max()) / scale
+    assert err < rtol, (what, err, scale)
+
+
+CONVS = [  # (c_in, c_out, k, stride, pad, groups, transposed, B, n)
+    (128, 128, 1, 1, 0, 1, False, 5, 700),      # decoder pointwise: 3500 rows = 14 chunks
+    (128, 80, 1, 1, 0, 1, False, 3, 401),       # mel_linear: 80 output channels (2.5 MFMA tiles)
+    (128, 128, 3, 1, 1, 1, False, 4, 130),      # predictor conv
+    (128, 128, 3, 2, 1, 1, False, 4, 131),      # strided merge conv, odd length
+    (32, 64, 1, 1, 0, 1, False, 4, 65),
+    (128, 128, 5, 1, 2, 128, False, 3, 500),    # depthwise k5
+    (128, 128, 3, 2, 0, 1, True, 4, 64),        # Fuse upsample (ConvTranspose1d, cropped to 2n)
+    (128, 1, 1, 1, 0, 1, False, 4, 300),        # predictor output Linear
+    (40, 24, 3, 1, 1, 1, False, 2, 50),         # channel counts the GEMM path does not take
+]
+
+
+@pytest.mark.parametrize("cfg", CONVS, ids=[f"cin{c[0]}_cout{c[1]}_k{c[2]}_s{c[3]}_g{c[5]}_{'T' if c[6] else 'C'}" for c in CONVS])
+@pytest.mark.parametrize("matrix_pipe", [True, False])
+def test_conv_forward_and_gradients(cfg, matrix_pipe, monkeypatch):
+    cin, cout, k, s, p, groups, tr, B, n = cfg
+    monkeypatch.setattr(train, "USE_MATRIX_PIPE", matrix_pipe)
+    x = _rand(B, n, cin, seed=1).requires_grad_()
+    w = (_rand(cin, cout, k, seed=2) if tr else _rand(cout, cin // groups, k, seed=2)) * (1.0 / np.sqrt(cin * k / groups))
+    w = w.detach().requires_grad_()
+    b = _rand(cout, seed=3).requires_grad_()
+    if tr:
+        full = (n - 1) * s - 2 * p + k
+        n_out = min(full, 2 * n)
+        ref = F.conv_transpose1d(x.transpose(1, 2), w, b, stride=s, padding=p)[:, :, :n_out].transpose(1, 2)
+    else:
+        n_out = (n + 2 * p - k) // s + 1
+        ref = F.conv1d(x.transpose(1, 2), w, b, stride=s, padding=p, groups=groups).transpose(1, 2)
+    got = train._Conv.apply(x, w, b, s, p, groups, tr, n_out)
+    _close(got, ref, 2e-5, "forward")
+    dy = _rand(*ref.shape, seed=4)
+    gx, gw, gb = torch.autograd.grad(got, (x, w, b), dy)
+    rx, rw, rb = torch.autograd.grad(ref, (x, w, b), dy)
+    _close(gx, rx, 5e-5, "dgrad")
+    _close(gw, rw, 5e-5, "wgrad")
+    _close(gb, rb, 5e-5, "bias grad")
+
+
+@pytest.mark.parametrize("rows,C", [(5000, 128), (300, 32), (77, 64)])
+def test_layernorm(rows, C):
+    x = _rand(rows, C, seed=1, scale=3.0).requires_grad_()
+    g, b = (_rand(C, seed=2) + 1.0).requires_grad_(), _rand(C, seed=3).requires_grad_()
+    got, ref = train._LayerNorm.apply(x, g, b), F.layer_norm(x, (C,), g, b)
+    _close(got, ref, 1e-5, "forward")
+    dy = _rand(rows, C, seed=4)
+    for a, r, what in zip(torch.autograd.grad(got, (x, g, b), dy), torch.autograd.grad(ref, (x, g, b), dy), ("dx", "dgamma", "dbeta")):
+        _close(a, r, 5e-5, what)
+
+
+@pytest.mark.parametrize("kind,fn", [(train.ACT_RELU, F.relu), (train.ACT_GELU, F.gelu), (train.ACT_TANH, torch.tanh)])
+def test_activations(kind, fn):
+    x = _rand(3, 1000, 64, seed=5, scale=2.0).requires_grad_()
+    got, ref = train._Act.apply(x, kind), fn(x)
+    _close(got, ref, 2e-6, "forward")
+    dy = _rand(3, 1000, 64, seed=6)
+    _close(torch.autograd.grad(got, x, dy)[0], torch.autograd.grad(ref, x, dy)[0], 1e-5, "backward")
+
+
+@pytest.mark.parametrize("B,N,C,h", [(3, 128, 32, 1), (2, 70, 64, 2), (2, 33, 128, 4)])
+def test_attention_core(B, N, C, h):
+    qkv = _rand(B, N, 3 * h * C, seed=7, scale=0.5).requires_grad_()
+    got = train._AttnCore.apply(qkv, h)
+    q, k, v = qkv.reshape(B, N, 3, h, C).permute(2, 0, 3, 1, 4).unbind(0)          # blocks.py:46-48
+    attn = ((q @ k.transpose(-2, -1)) * (C // h) ** -0.5).softmax(dim=-1)
+    ref = (attn @ v).transpose(1, 2).reshape(B, N, -1)
+    _close(got, ref, 1e-5, "forward")
+    dy = _rand(B, N, h * C, seed=8)
+    _close(torch.autograd.grad(got, qkv, dy)[0], torch.autograd.grad(ref, qkv, dy)[0], 5e-5, "backward")
+
+
+def test_embedding_repeat_cat_mask_add():
+    table = _rand(153, 128, seed=9).requires_grad_()
+    ids = torch.randint(0, 153, (6, 200), generator=torch.Generator().manual_seed(1)).to(DEV)
+    got, ref = train._Embedding.apply(ids, table, 0), F.embedding(ids, table, padding_idx=0)
+    assert torch.equal(got, ref)
+    dy = _rand(6, 200, 128, seed=10)
+    _close(torch.autograd.grad(got, table, dy)[0], torch.autograd.grad(ref, table, dy)[0], 2e-5, "embedding grad")
+    # length regulator
+    feat = _rand(3, 50, 16, seed=11).requires_grad_()
+    dur = torch.randint(0, 7, (3, 50), generator=torch.Generator().manual_seed(2)).to(DEV)
+    cum = torch.cumsum(dur, 1).to(torch.int32).contiguous()
+    L = int(cum[:, -1].max()) + 5
+    got = train._Repeat.apply(feat, cum, L)
+    ref = torch.stack([F.pad(f.repeat_interleave(d, dim=0), (0, 0, 0, L - int(d.sum()))) for f, d in zip(feat, dur)])
+    assert torch.equal(got, ref)
+    dy = _rand(3, L, 16, seed=12)
+    _close(torch.autograd.grad(got, feat, dy)[0], torch.autograd.grad(ref, feat, dy)[0], 1e-5, "repeat grad")
+    # cat / mask / add
+    a, b = _rand(4, 30, 8, seed=13).requires_grad_(), _rand(4, 30, 24, seed=14).requires_grad_()
+    m = (torch.arange(30)[None, :] >= torch.tensor([30, 12, 1, 29])[:, None]).to(DEV)
+    got = train._MaskRows.apply(train._Cat.apply(a, train._Add.apply(b, b)), m.view(torch.uint8) if m.dtype != torch.uint8 else m)
+    ref = torch.cat([a, b + b], -1).masked_fill(m[..., None], 0)
+    assert torch.equal(got, ref)
+    dy = _rand(4, 30, 32, seed=15)
+    for x_, y_ in zip(torch.autograd.grad(got, (a, b), dy), torch.autograd.grad(ref, (a, b), dy)):
+        assert torch.equal(x_, y_)
+
+
+def test_loss_and_adamw_against_torch():
+    B, T, L, nm = 5, 40, 300, 80
+    mel_p, mel = _rand(B, L, nm, seed=1).requires_grad_(), _rand(B, L, nm, seed=2)
+    pp, p_ = _rand(B, T, seed=3).requires_grad_(), _rand(B, T, seed=4)
+    ep, e_ = _rand(B, T, seed=5).requires_grad_(), _rand(B, T, seed=6)
+    dp = _rand(B, T, seed=7).abs().requires_grad_()
+    d_ = torch.randint(0, 9, (B, T), generator=torch.Generator().manual_seed(3)).to(DEV).to(torch.int32)
+    mm = (torch.arange(L)[None, :] >= torch.tensor([300, 250, 17, 299, 1])[:, None]).to(DEV)
+    pm = (torch.arange(T)[None, :] >= torch.tensor([40, 33, 2, 39, 1])[:, None]).to(DEV)
+    got = train._Loss.apply(mel_p, pp, ep, dp, mel, p_, e_, d_, mm.view(torch.uint8), pm.view(torch.uint8))
+    sel, ps = ~mm[..., None], ~pm
+    ref = [F.l1_loss(mel_p.masked_select(sel), mel.masked_select(sel)), F.mse_loss(pp.masked_select(ps), p_.masked_select(ps)),
+           F.mse_loss(ep.masked_select(ps), e_.masked_select(ps)),
+           F.mse_loss(torch.log(dp.masked_select(ps) + 1), torch.log(d_.masked_select(ps).float() + 1))]
+    total = 10 * ref[0] + 2 * ref[1] + 2 * ref[2] + ref[3]
+    for a, r in zip(got[:4], ref):
+        assert abs(float(a) - float(r)) < 2e-5 * abs(float(r))
+    assert abs(float(got[4]) - float(total)) < 2e-5 * abs(float(total))
+    for a, r, what in zip(torch.autograd.grad(got[4], (mel_p, pp, ep, dp)), torch.autograd.grad(total, (mel_p, pp, ep, dp)),
+                          ("d mel", "d pitch", "d energy", "d duration")):
+        _close(a, r, 2e-5, what)
+    # AdamW: five steps of the kernel against torch.optim.AdamW on the same gradients
+    from efficientspeech_amd import _lib
+    from efficientspeech_amd.networks import _runtime, _ptr
+    n = 100_003
+    p0 = _rand(n, seed=20)
+    ref_p = p0.clone().requires_grad_()
+    opt = torch.optim.AdamW([ref_p], lr=1e-3, weight_decay=1e-2)
+    p, m, v = p0.clone(), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    lib, st = _runtime(p)
+    for t in range(1, 6):
+        g = _rand(n, seed=30 + t)
+        ref_p.grad = g.clone()
+        opt.step()
+        lib.esmi_train_adamw_f32(_ptr(p), _ptr(g), _ptr(m), _ptr(v), n, 1e-3, 0.9, 0.999, 1e-8, 1e-2, t, st)
+    assert float((p - ref_p.detach()).abs().max()) < 2e-6
+
+
+@pytest.mark.parametrize("name", ["small", "base"])
+def test_training_runs_on_the_wider_configs(name):
+    """small (3 blocks, reduction 2) and base (2 / 4 heads, expansion 2, k = 5, depth 3): the loss falls and stays finite."""
+    from efficientspeech_amd import CONFIGS, build_phoneme2mel
+    from efficientspeech_amd.synth import synth_state_dict
+    cfg = CONFIGS[name]
+    net = build_phoneme2mel(cfg)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in synth_state_dict(cfg, 1234).items()})
+    net = net.to(DEV).train()
+    x, y = train.synthetic_batch(4, 24, 3, DEV)
+    step = train.TrainStep(net, lr=1e-3)
+    first = float(step.step(x, y)[4])
+    for _ in range(8):
+        last = float(step.step(x, y)[4])
+    assert np.isfinite(last) and last < first, (first, last)

@@ -60,6 +60,23 @@ def check_loss_and_gradients(dev):
     assert np.array_equal(out["mel_len"].cpu().numpy(), g["in_mel_len"])
 
 
+def check_loss_kernel_against_oracle(dev):
+    """esmi_train_loss_f32 on the reference's own predictions vs the oracle's float64 restatement (values and gradient seeds)."""
+    from oracle import oracle
+    train, g, net, x, y = _setup(dev)
+    t = lambda k: torch.from_numpy(g[k]).to(dev)     # noqa: E731
+    B, T = g["in_pitch"].shape
+    preds = [t("mel_pred").requires_grad_(), t("pitch_pred").reshape(B, T).requires_grad_(), t("energy_pred").reshape(B, T).requires_grad_(),
+             t("duration_pred").reshape(B, T).requires_grad_()]
+    out = train._Loss.apply(*preds, y["mel"], x["pitch"], x["energy"], x["duration"].to(torch.int32), x["mel_mask"].view(torch.uint8),
+                            x["phoneme_mask"].view(torch.uint8))
+    ref, rg = oracle.training_loss(g["mel_pred"], g["in_mel"], g["in_mel_mask"], g["pitch_pred"], g["in_pitch"], g["energy_pred"],
+                                   g["in_energy"], g["duration_pred"], g["in_duration"], g["in_phoneme_mask"])
+    assert np.allclose(out.detach().cpu().numpy(), ref, rtol=2e-6)
+    for a, r in zip(torch.autograd.grad(out[4], preds), rg):
+        assert np.allclose(a.cpu().numpy(), r.reshape(a.shape), rtol=1e-5, atol=1e-9)
+
+
 def check_adamw_step(dev):
     train, g, net, x, y = _setup(dev)
     step = train.TrainStep(net, lr=1e-3, weight_decay=1e-6)
@@ -110,6 +127,16 @@ def test_gpu_training_reduces_the_loss_and_inference_sees_the_update():
         after = net(xe)[0]
     assert bool(torch.isfinite(before).all()) and after.shape[0] == before.shape[0]
     assert not torch.equal(after[:, :8], before[:, :8])                 # the inference path re-packed the updated weights
+
+
+@pytest.mark.gpu
+def test_gpu_loss_kernel_matches_oracle():
+    check_loss_kernel_against_oracle("cuda")
+
+
+def test_simulated_loss_kernel_matches_oracle():
+    with use_sim():
+        check_loss_kernel_against_oracle("cpu")
 
 
 def test_simulated_loss_and_gradients_match_reference():

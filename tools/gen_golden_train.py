@@ -64,7 +64,8 @@ def main():
         rec = dict(in_phoneme=ph, in_phoneme_mask=m, in_pitch=pitch, in_energy=energy, in_duration=dur, in_mel_len=mel_len,
                    in_mel=mel, in_mel_mask=mel_mask, losses=np.array([float(v) for v in losses], np.float64),
                    total=np.array(float(total), np.float64), weights_crc=np.array(G.sd_crc(sd), dtype=np.uint32),
-                   mel_pred=y_hat["mel"].detach().numpy())
+                   mel_pred=y_hat["mel"].detach().numpy(), pitch_pred=y_hat["pitch"].detach().numpy(),
+                   energy_pred=y_hat["energy"].detach().numpy(), duration_pred=y_hat["duration"].detach().numpy())
         names = [k for k, p in net.named_parameters() if p.requires_grad]
         nograd = [k for k, p in net.named_parameters() if p.requires_grad and p.grad is None]
         for k, p in net.named_parameters():
