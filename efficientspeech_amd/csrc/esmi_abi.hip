@@ -1248,13 +1248,16 @@ int esmi_train_conv_dgrad_f32(const esmi_conv_desc* d, const float* dy, const fl
     return launch_status();
 }
 namespace {
-inline bool wgrad_on_mfma(const ConvDesc& c) { return c.groups == 1 && c.c_in >= 8 && c.c_out >= 8; }
+inline bool wgrad_depthwise(const ConvDesc& c) { return !c.transposed && c.groups == c.c_in && c.c_in == c.c_out && c.k <= 8; }
+inline bool wgrad_on_mfma(const ConvDesc& c);
+inline int wgrad_chunk(const ConvDesc& c) { return wgrad_on_mfma(c) ? kTrainChunkMfma : (wgrad_depthwise(c) ? kTrainChunkDw : kTrainChunk); }
+inline bool wgrad_on_mfma(const ConvDesc& c) { return c.groups == 1 && c.c_in >= 8 && c.c_out >= 8 && (c.c_out & 3) == 0; }
 }
 size_t esmi_train_conv_wgrad_workspace_bytes(const esmi_conv_desc* d) {
     ConvDesc c;
     if (conv_desc_ok(d, &c)) return 0;
     const long nw = (long)(c.transposed ? c.c_in * c.c_out : c.c_out * (c.c_in / c.groups)) * c.k;
-    const long chunks = train_chunks((long)c.B * c.n_out, wgrad_on_mfma(c) ? kTrainChunkMfma : kTrainChunk);
+    const long chunks = train_chunks((long)c.B * c.n_out, wgrad_chunk(c));
     return (size_t)chunks * (size_t)(nw + c.c_out) * sizeof(float);
 }
 int esmi_train_conv_wgrad_f32(const esmi_conv_desc* d, const float* x, const float* dy, float* dw, float* dbias, void* workspace,
@@ -1264,26 +1267,29 @@ int esmi_train_conv_wgrad_f32(const esmi_conv_desc* d, const float* x, const flo
     if (!x || !dy || !dw || !workspace) return ESMI_ERR_ARG;
     if (workspace_bytes < esmi_train_conv_wgrad_workspace_bytes(d)) return ESMI_ERR_WORKSPACE;
     const long nw = (long)(c.transposed ? c.c_in * c.c_out : c.c_out * (c.c_in / c.groups)) * c.k;
-    const bool mfma = wgrad_on_mfma(c);
-    const long rows = (long)c.B * c.n_out, chunks = train_chunks(rows, mfma ? kTrainChunkMfma : kTrainChunk);
+    const bool mfma = wgrad_on_mfma(c), depthwise = wgrad_depthwise(c);
+    const long rows = (long)c.B * c.n_out, chunks = train_chunks(rows, wgrad_chunk(c));
     float* part = static_cast<float*>(workspace);
     float* pb = part + chunks * nw;
-    if (mfma) {   // dense: one wave per (32 x 32 weight tile, tap, chunk) on the fp32 MFMA; the ci0 = 0, tap 0 tiles also sum dY's columns
-        const unsigned tiles = (unsigned)(((c.c_out + 31) / 32) * ((c.c_in + 31) / 32) * c.k);
+    if (mfma) {   // dense: one wave per (128 output channels x 32 input channels, tap, chunk) on the fp32 MFMA; bias partials from the tap 0, ci0 = 0 waves
+        const unsigned tiles = (unsigned)(((c.c_out + 127) / 128) * ((c.c_in + 31) / 32) * c.k);
         ESMI_LAUNCH(train_conv_wgrad_mfma_kernel, dim3(tiles, (unsigned)((chunks + 3) / 4)), dim3(256), 0, S(stream), c, x, dy, part,
                     dbias ? pb : nullptr, chunks);
+    } else if (depthwise) {
+        ESMI_LAUNCH(train_conv_wgrad_dw_kernel, dim3(grid1d(c.c_out, 64), (unsigned)chunks), dim3(64), 0, S(stream), c, x, dy, part,
+                    dbias ? pb : nullptr);
     } else {
         ESMI_LAUNCH(train_conv_wgrad_kernel, dim3(grid1d(nw, 64), (unsigned)chunks), dim3(64), 0, S(stream), c, x, dy, part);
     }
     if (int rc = launch_status()) return rc;
-    ESMI_LAUNCH(train_reduce_chunks_kernel, grid1d(nw, 64), dim3(256), 256 * sizeof(float), S(stream), part, nw, nw, chunks, dw);
+    ESMI_LAUNCH(train_reduce_chunks_kernel, grid1d(nw, 64), dim3(1024), 1024 * sizeof(float), S(stream), part, nw, nw, chunks, dw);
     if (int rc = launch_status()) return rc;
     if (dbias) {
-        if (!mfma) {
+        if (!mfma && !depthwise) {
             ESMI_LAUNCH(train_colsum_kernel, dim3(grid1d(c.c_out, 64), (unsigned)chunks), dim3(64), 0, S(stream), dy, rows, c.c_out, pb);
             if (int rc = launch_status()) return rc;
         }
-        ESMI_LAUNCH(train_reduce_chunks_kernel, grid1d(c.c_out, 64), dim3(256), 256 * sizeof(float), S(stream), pb, (long)c.c_out, (long)c.c_out, chunks, dbias);
+        ESMI_LAUNCH(train_reduce_chunks_kernel, grid1d(c.c_out, 64), dim3(1024), 1024 * sizeof(float), S(stream), pb, (long)c.c_out, (long)c.c_out, chunks, dbias);
         return launch_status();
     }
     return ESMI_OK;
@@ -1295,22 +1301,30 @@ int esmi_train_layernorm_fwd_f32(const float* x, const float* g, const float* b,
     return launch_status();
 }
 size_t esmi_train_layernorm_bwd_workspace_bytes(int64_t rows, int C) {
-    return rows > 0 && C > 0 ? (size_t)train_chunks(rows) * 2 * C * sizeof(float) : 0;
+    if (rows <= 0 || C <= 0) return 0;
+    return (size_t)train_chunks(rows, C <= 256 ? kLnRows : kTrainChunk) * 2 * C * sizeof(float);
 }
 int esmi_train_layernorm_bwd_f32(const float* x, const float* g, const float* mean, const float* rstd, const float* dy,
                                  int64_t rows, int C, float* dx, float* dg, float* db, void* workspace, size_t workspace_bytes,
                                  esmi_stream_t stream) {
     if (!x || !g || !mean || !rstd || !dy || !dx || !dg || !db || !workspace || rows <= 0 || C <= 0) return ESMI_ERR_ARG;
     if (workspace_bytes < esmi_train_layernorm_bwd_workspace_bytes(rows, C)) return ESMI_ERR_WORKSPACE;
-    ESMI_LAUNCH(train_ln_bwd_dx_kernel, grid1d(rows, 4), dim3(256), 0, S(stream), x, g, mean, rstd, dy, (long)rows, C, dx);
-    if (int rc = launch_status()) return rc;
-    const long chunks = train_chunks(rows);
     float* part = static_cast<float*>(workspace);
-    ESMI_LAUNCH(train_ln_bwd_params_kernel, dim3(grid1d(C, 64), (unsigned)chunks), dim3(64), 0, S(stream), x, mean, rstd, dy, (long)rows, C, part);
+    long chunks;
+    if (C <= 256) {   // dx and the parameter partials in one pass
+        chunks = train_chunks(rows, kLnRows);
+        ESMI_LAUNCH(train_ln_bwd_fused_kernel, dim3((unsigned)chunks), dim3(256), 4 * 2 * 256 * sizeof(float), S(stream), x, g, mean, rstd, dy, (long)rows, C, dx, part);
+        if (int rc = launch_status()) return rc;
+    } else {
+        chunks = train_chunks(rows);
+        ESMI_LAUNCH(train_ln_bwd_dx_kernel, grid1d(rows, 4), dim3(256), 0, S(stream), x, g, mean, rstd, dy, (long)rows, C, dx);
+        if (int rc = launch_status()) return rc;
+        ESMI_LAUNCH(train_ln_bwd_params_kernel, dim3(grid1d(C, 64), (unsigned)chunks), dim3(64), 0, S(stream), x, mean, rstd, dy, (long)rows, C, part);
+        if (int rc = launch_status()) return rc;
+    }
+    ESMI_LAUNCH(train_reduce_chunks_kernel, grid1d(C, 64), dim3(1024), 1024 * sizeof(float), S(stream), part, (long)C, 2L * C, chunks, dg);   // [chunk][dg | db]
     if (int rc = launch_status()) return rc;
-    ESMI_LAUNCH(train_reduce_chunks_kernel, grid1d(C, 64), dim3(256), 256 * sizeof(float), S(stream), part, (long)C, 2L * C, chunks, dg);   // [chunk][dg | db]
-    if (int rc = launch_status()) return rc;
-    ESMI_LAUNCH(train_reduce_chunks_kernel, grid1d(C, 64), dim3(256), 256 * sizeof(float), S(stream), part + C, (long)C, 2L * C, chunks, db);
+    ESMI_LAUNCH(train_reduce_chunks_kernel, grid1d(C, 64), dim3(1024), 1024 * sizeof(float), S(stream), part + C, (long)C, 2L * C, chunks, db);
     return launch_status();
 }
 int esmi_train_act_fwd_f32(const float* x, int64_t n, int kind, float* y, esmi_stream_t stream) {
@@ -1353,7 +1367,7 @@ int esmi_train_embedding_bwd_f32(const int32_t* ids, const float* dy, int64_t ro
     float* part = static_cast<float*>(workspace);
     ESMI_LAUNCH(train_embed_bwd_kernel, dim3(grid1d(n, 64), (unsigned)chunks), dim3(64), 0, S(stream), ids, dy, (long)rows, V, C, padding_idx, part);
     if (int rc = launch_status()) return rc;
-    ESMI_LAUNCH(train_reduce_chunks_kernel, grid1d(n, 64), dim3(256), 256 * sizeof(float), S(stream), part, n, n, chunks, dtable);
+    ESMI_LAUNCH(train_reduce_chunks_kernel, grid1d(n, 64), dim3(1024), 1024 * sizeof(float), S(stream), part, n, n, chunks, dtable);
     return launch_status();
 }
 int esmi_train_mask_rows_f32(const float* x, const uint8_t* mask, int64_t rows, int C, float* y, esmi_stream_t stream) {

@@ -88,6 +88,7 @@ __global__ void train_conv_dgrad_kernel(const ConvDesc d, const float* __restric
 // Reductions over the rows (B * n positions) run in two deterministic stages: stage 1 gives every (output element, chunk of
 // kTrainChunk rows) its own thread and writes a partial sum, stage 2 adds the partials of an element in chunk order.
 constexpr int kTrainChunk = 256;
+constexpr int kTrainChunkDw = 32;      // rows per thread of the depthwise weight gradient (few channels: parallelism from the chunks)
 constexpr int kTrainChunkMfma = 256;    // rows per wave of the matrix-pipe weight gradient (1024 measured slower: too few waves)
 __host__ __device__ inline long train_chunks(long rows, int chunk = kTrainChunk) { return (rows + chunk - 1) / chunk; }
 
@@ -114,59 +115,116 @@ __global__ void train_conv_wgrad_kernel(const ConvDesc d, const float* __restric
     }
     partial[(long)blockIdx.y * nw + q] = acc;
 }
-// The same partial sums for DENSE convolutions on the matrix pipe: dW_j = dY^T X_j is a GEMM with the rows as the contraction.
-// One wave = one 32 x 32 (co, ci) tile of one tap and one chunk of rows, on v_mfma_f32_32x32x2_f32 (exact fp32 products, k-ordered
-// accumulation): lane (i, kh) feeds dY[row + kh][co0 + i] and X[in_pos(row + kh)][ci0 + i] -- both 128-byte coalesced.
+// depthwise (groups == C, one input channel per output channel, k <= 8): lanes across the channels (coalesced), every thread
+// keeps the k tap sums and the bias sum of its channel over the chunk's rows
+__global__ void train_conv_wgrad_dw_kernel(const ConvDesc d, const float* __restrict__ x, const float* __restrict__ dy,
+                                           float* __restrict__ partial, float* __restrict__ partial_bias) {
+    const int c = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (c >= d.c_out) return;
+    const long rows = (long)d.B * d.n_out, r0 = (long)blockIdx.y * kTrainChunkDw, r1 = r0 + kTrainChunkDw < rows ? r0 + kTrainChunkDw : rows;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, bs = 0.0f;
+    for (long r = r0; r < r1; ++r) {
+        const int b = (int)(r / d.n_out), t = (int)(r - (long)b * d.n_out);
+        const float g = dy[r * d.c_out + c];
+        bs += g;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            if (j >= d.k) break;
+            const int ti = conv_in_pos(d, t, j);
+            if (ti >= 0) acc[j] = fmaf(g, x[((long)b * d.n_in + ti) * d.c_in + c], acc[j]);
+        }
+    }
+    const long nw = (long)d.c_out * d.k;
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+        if (j < d.k) partial[(long)blockIdx.y * nw + (long)c * d.k + j] = acc[j];
+    if (partial_bias) partial_bias[(long)blockIdx.y * d.c_out + c] = bs;
+}
+
+// The same partial sums for DENSE convolutions on the matrix pipe: dW_j = dY^T X_j is a GEMM with the rows as the contraction
+// (v_mfma_f32_32x32x2_f32: exact fp32 products, k-ordered accumulation).  One wave = a block of 128 output channels x one
+// 32-channel input tile x one tap x one chunk of rows.  Lane (i, kh) reads 16 bytes of dY -- channels 4i..4i+3 of row r + kh,
+// so the 32 lanes of a half cover the whole 128-channel block, fully coalesced -- and one float of X; the four values feed four
+// MFMAs whose tiles are the channel sets {4m + t}: four MFMAs per two loads, dY read once per input tile instead of once per
+// (input tile, output tile).  The (tap 0, first input tile) waves also sum dY's columns: the bias gradient.
 __global__ __launch_bounds__(256) void train_conv_wgrad_mfma_kernel(const ConvDesc d, const float* __restrict__ x,
                                                                     const float* __restrict__ dy, float* __restrict__ partial,
                                                                     float* __restrict__ partial_bias, long chunks) {
     const int lane = lane_id(), i = lane & 31, kh = lane >> 5;
     const int tci = (d.c_in + 31) / 32;
-    const int tile = (int)blockIdx.x, j = tile % d.k, ci0 = ((tile / d.k) % tci) * 32, co0 = (tile / (d.k * tci)) * 32;
+    const int tile = (int)blockIdx.x, j = tile % d.k, ci0 = ((tile / d.k) % tci) * 32, cb = (tile / (d.k * tci)) * 128;
     const long chunk = (long)blockIdx.y * 4 + wave_id();
     if (chunk >= chunks) return;
     const long rows = (long)d.B * d.n_out, r0 = chunk * kTrainChunkMfma, r1 = r0 + kTrainChunkMfma < rows ? r0 + kTrainChunkMfma : rows;
-    const bool co_ok = co0 + i < d.c_out, ci_ok = ci0 + i < d.c_in;
-    f32x16 acc = zero16();
-    float bsum = 0.0f;                                  // this lane's share of sum over rows of dY[:, co0 + i]: the bias gradient
-    for (long r = r0; r < r1; r += 2) {
-        const long rr = r + kh;
-        float a = 0.0f, bv = 0.0f;
-        if (rr < r1) {
-            const int b = (int)(rr / d.n_out), t = (int)(rr - (long)b * d.n_out);
-            const int ti = conv_in_pos(d, t, j);
-            if (co_ok) a = dy[rr * d.c_out + co0 + i];
-            if (ci_ok && ti >= 0) bv = x[((long)b * d.n_in + ti) * d.c_in + ci0 + i];
+    const int co4 = cb + 4 * i;                         // this lane's four output channels
+    const bool vec_ok = co4 + 3 < d.c_out, ci_ok = ci0 + i < d.c_in;
+    f32x16 acc[4] = {zero16(), zero16(), zero16(), zero16()};
+    f32x4 bsum = zero4();
+    for (long r = r0; r < r1; r += 8) {                 // 8 rows per trip: all eight loads in flight before the 16 MFMAs
+        f32x4 a[4];
+        float bv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const long rr = r + 2 * u + kh;
+            a[u] = zero4();
+            bv[u] = 0.0f;
+            if (rr < r1) {
+                const int b = (int)(rr / d.n_out), t = (int)(rr - (long)b * d.n_out);
+                const int ti = conv_in_pos(d, t, j);
+                const float* dr = dy + rr * d.c_out + co4;
+                if (vec_ok) a[u] = ld4(dr);
+                else
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) if (co4 + e < d.c_out) a[u][e] = dr[e];
+                if (ci_ok && ti >= 0) bv[u] = x[((long)b * d.n_in + ti) * d.c_in + ci0 + i];
+            }
         }
-        bsum += a;
-        acc = mfma32(a, bv, acc);
+        sched_fence();
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            bsum = bsum + a[u];
+#pragma unroll
+            for (int t4 = 0; t4 < 4; ++t4) acc[t4] = mfma32(a[u][t4], bv[u], acc[t4]);
+        }
     }
     const long nw = (long)d.c_out * d.c_in * d.k;
+    const int ci = ci0 + i;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int co = co0 + tile_row(r, lane), ci = ci0 + i;
-        long wi;
-        if (co < d.c_out && ci < d.c_in && conv_w_index(d, co, ci, j, &wi)) partial[chunk * nw + wi] = acc[r];
+    for (int t4 = 0; t4 < 4; ++t4) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = cb + 4 * tile_row(r, lane) + t4;
+            long wi;
+            if (co < d.c_out && ci < d.c_in && conv_w_index(d, co, ci, j, &wi)) partial[chunk * nw + wi] = acc[t4][r];
+        }
     }
-    if (partial_bias && j == 0 && ci0 == 0) {           // one tile column per output-channel tile also carries the bias partials
-        bsum += shfl_xor_f(bsum, 32);                   // even rows (kh = 0) + odd rows (kh = 1)
-        if (kh == 0 && co_ok) partial_bias[chunk * d.c_out + co0 + i] = bsum;
+    if (partial_bias && j == 0 && ci0 == 0) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float v = bsum[e] + shfl_xor_f(bsum[e], 32);      // even rows (kh = 0) + odd rows (kh = 1)
+            if (kh == 0 && co4 + e < d.c_out) partial_bias[chunk * d.c_out + co4 + e] = v;
+        }
     }
 }
 
-// out[e] = sum over chunks of partial[chunk * stride + e], e < n.  256 threads = 64 elements x 4 interleaved chunk groups; the
-// four group sums are added in group order (fixed order: reproducible)
-__global__ __launch_bounds__(256) void train_reduce_chunks_kernel(const float* __restrict__ partial, long n, long stride, long chunks,
-                                                                  float* __restrict__ out) {
-    ESMI_DYN_LDS(red);   // 256 floats
+// out[e] = sum over chunks of partial[chunk * stride + e], e < n.  1024 threads = 64 elements x 16 interleaved chunk groups; the
+// sixteen group sums are added in group order (fixed order: reproducible)
+__global__ __launch_bounds__(1024) void train_reduce_chunks_kernel(const float* __restrict__ partial, long n, long stride, long chunks,
+                                                                   float* __restrict__ out) {
+    ESMI_DYN_LDS(red);   // 1024 floats
     const int ex = (int)(threadIdx.x & 63), cy = (int)(threadIdx.x >> 6);
     const long q = (long)blockIdx.x * 64 + ex;
     float acc = 0.0f;
     if (q < n)
-        for (long c = cy; c < chunks; c += 4) acc += partial[c * stride + q];
+        for (long c = cy; c < chunks; c += 16) acc += partial[c * stride + q];
     red[cy * 64 + ex] = acc;
     __syncthreads();
-    if (cy == 0 && q < n) out[q] = ((red[ex] + red[64 + ex]) + red[128 + ex]) + red[192 + ex];
+    if (cy == 0 && q < n) {
+        float t = red[ex];
+#pragma unroll
+        for (int u = 1; u < 16; ++u) t += red[u * 64 + ex];
+        out[q] = t;
+    }
 }
 // partial[chunk][c] = sum over the chunk's rows of v[row, c]   (bias gradients)
 __global__ void train_colsum_kernel(const float* __restrict__ v, long rows, int C, float* __restrict__ partial) {
@@ -221,6 +279,59 @@ __global__ __launch_bounds__(256) void train_ln_bwd_dx_kernel(const float* __res
         dx[r * C + c] = rs * (dh - s1 - xh * s2);
     }
 }
+// dx and the parameter-gradient partials in one pass (C <= 256): a 4-wave workgroup per kLnRows rows, one wave per quarter, lanes
+// across the channels; every lane keeps dgamma / dbeta sums of its (up to four) channels over its wave's rows, the four waves'
+// sums are added in wave order through LDS -> partial[workgroup][dg (C) | db (C)]
+constexpr int kLnRows = 64;
+__global__ __launch_bounds__(256) void train_ln_bwd_fused_kernel(const float* __restrict__ x, const float* __restrict__ g,
+                                                                 const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                                 const float* __restrict__ dy, long rows, int C,
+                                                                 float* __restrict__ dx, float* __restrict__ partial) {
+    ESMI_DYN_LDS(red);   // [4 waves][2][256] floats
+    const long chunk = blockIdx.x;
+    const int lane = lane_id(), w = wave_id();
+    const long r0 = chunk * kLnRows + w * (kLnRows / 4);
+    const long rend = chunk * kLnRows + kLnRows < rows ? chunk * kLnRows + kLnRows : rows;
+    const long r1 = r0 + kLnRows / 4 < rend ? r0 + kLnRows / 4 : rend;
+    float gg[4], dga[4] = {0.f, 0.f, 0.f, 0.f}, dba[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < 4; ++u) gg[u] = lane + 64 * u < C ? g[lane + 64 * u] : 0.0f;
+    for (long r = r0; r < r1; ++r) {
+        const float m = mean[r], rs = rstd[r];
+        float xh[4], dh[4], s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int c = lane + 64 * u;
+            const bool ok = c < C;
+            const float d = ok ? dy[r * C + c] : 0.0f;
+            xh[u] = ok ? (x[r * C + c] - m) * rs : 0.0f;
+            dh[u] = d * gg[u];
+            s1 += dh[u];
+            s2 = fmaf(dh[u], xh[u], s2);
+            dga[u] = fmaf(d, xh[u], dga[u]);
+            dba[u] += d;
+        }
+        s1 = ln_wave_sum(s1) / (float)C;
+        s2 = ln_wave_sum(s2) / (float)C;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int c = lane + 64 * u;
+            if (c < C) dx[r * C + c] = rs * (dh[u] - s1 - xh[u] * s2);
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        red[(w * 2 + 0) * 256 + lane + 64 * u] = dga[u];
+        red[(w * 2 + 1) * 256 + lane + 64 * u] = dba[u];
+    }
+    __syncthreads();
+    for (int e = (int)threadIdx.x; e < 2 * C; e += 256) {      // e < C: dgamma[e], else dbeta[e - C]
+        const int which = e >= C ? 1 : 0, c = e - which * C;
+        partial[chunk * 2 * C + e] = ((red[(0 * 2 + which) * 256 + c] + red[(1 * 2 + which) * 256 + c]) + red[(2 * 2 + which) * 256 + c]) +
+                                     red[(3 * 2 + which) * 256 + c];
+    }
+}
+
 // partial[chunk][0][c] = sum dy * xhat, partial[chunk][1][c] = sum dy over the chunk's rows
 __global__ void train_ln_bwd_params_kernel(const float* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ rstd,
                                            const float* __restrict__ dy, long rows, int C, float* __restrict__ partial) {
