@@ -77,7 +77,7 @@ def check_loss_kernel_against_oracle(dev):
         assert np.allclose(a.cpu().numpy(), r.reshape(a.shape), rtol=1e-5, atol=1e-9)
 
 
-def check_adamw_step(dev):
+def check_adamw_step(dev, reproducible=True):
     train, g, net, x, y = _setup(dev)
     step = train.TrainStep(net, lr=1e-3, weight_decay=1e-6)
     losses = step.step(x, y)
@@ -90,6 +90,8 @@ def check_adamw_step(dev):
             assert np.abs(mine - ref).max() < 2e-6, (k, float(np.abs(mine - ref).max()))
             n += 1
     assert n >= 5
+    if not reproducible:
+        return
     again = step.step(x, y)                                            # bitwise reproducible: no atomics anywhere in the step
     t2, g2, net2, x2, y2 = _setup(dev)
     s2 = t2.TrainStep(net2, lr=1e-3, weight_decay=1e-6)
@@ -146,7 +148,7 @@ def test_simulated_loss_and_gradients_match_reference():
 
 def test_simulated_adamw_step_matches_reference():
     with use_sim():
-        check_adamw_step("cpu")
+        check_adamw_step("cpu", reproducible=False)      # (the run-to-run check costs three more simulated steps: GPU only)
 
 
 def _free_port():
