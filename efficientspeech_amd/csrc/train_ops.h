@@ -89,7 +89,10 @@ __global__ void train_conv_dgrad_kernel(const ConvDesc d, const float* __restric
 // kTrainChunk rows) its own thread and writes a partial sum, stage 2 adds the partials of an element in chunk order.
 constexpr int kTrainChunk = 256;
 constexpr int kTrainChunkDw = 32;      // rows per thread of the depthwise weight gradient (few channels: parallelism from the chunks)
-constexpr int kTrainChunkMfma = 256;    // rows per wave of the matrix-pipe weight gradient (1024 measured slower: too few waves)
+#ifndef ESMI_TRAIN_CHUNK_MFMA
+#define ESMI_TRAIN_CHUNK_MFMA 128   // rows per wave of the MFMA weight gradient: 64 / 128 / 256 / 512 measured 8.4 / 8.4 / 9.2 / 10.8 ms per B = 128 step
+#endif
+constexpr int kTrainChunkMfma = ESMI_TRAIN_CHUNK_MFMA;    // rows per wave of the matrix-pipe weight gradient (1024 measured slower: too few waves)
 __host__ __device__ inline long train_chunks(long rows, int chunk = kTrainChunk) { return (rows + chunk - 1) / chunk; }
 
 // dw(co, ci, j) = sum over (b, t) of dy[b, t, co] * x[b, in_pos(t, j), ci]: partial[chunk][weight element in checkpoint order]
