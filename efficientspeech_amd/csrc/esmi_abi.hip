@@ -1282,14 +1282,14 @@ int esmi_train_conv_wgrad_f32(const esmi_conv_desc* d, const float* x, const flo
         ESMI_LAUNCH(train_conv_wgrad_kernel, dim3(grid1d(nw, 64), (unsigned)chunks), dim3(64), 0, S(stream), c, x, dy, part);
     }
     if (int rc = launch_status()) return rc;
-    ESMI_LAUNCH(train_reduce_chunks_kernel, grid1d(nw, 64), dim3(1024), 1024 * sizeof(float), S(stream), part, nw, nw, chunks, dw);
+    ESMI_LAUNCH(train_reduce_chunks_kernel, grid1d(nw, 64), dim3(64 * kReduceGroups), 64 * kReduceGroups * sizeof(float), S(stream), part, nw, nw, chunks, dw);
     if (int rc = launch_status()) return rc;
     if (dbias) {
         if (!mfma && !depthwise) {
             ESMI_LAUNCH(train_colsum_kernel, dim3(grid1d(c.c_out, 64), (unsigned)chunks), dim3(64), 0, S(stream), dy, rows, c.c_out, pb);
             if (int rc = launch_status()) return rc;
         }
-        ESMI_LAUNCH(train_reduce_chunks_kernel, grid1d(c.c_out, 64), dim3(1024), 1024 * sizeof(float), S(stream), pb, (long)c.c_out, (long)c.c_out, chunks, dbias);
+        ESMI_LAUNCH(train_reduce_chunks_kernel, grid1d(c.c_out, 64), dim3(64 * kReduceGroups), 64 * kReduceGroups * sizeof(float), S(stream), pb, (long)c.c_out, (long)c.c_out, chunks, dbias);
         return launch_status();
     }
     return ESMI_OK;
@@ -1322,9 +1322,9 @@ int esmi_train_layernorm_bwd_f32(const float* x, const float* g, const float* me
         ESMI_LAUNCH(train_ln_bwd_params_kernel, dim3(grid1d(C, 64), (unsigned)chunks), dim3(64), 0, S(stream), x, mean, rstd, dy, (long)rows, C, part);
         if (int rc = launch_status()) return rc;
     }
-    ESMI_LAUNCH(train_reduce_chunks_kernel, grid1d(C, 64), dim3(1024), 1024 * sizeof(float), S(stream), part, (long)C, 2L * C, chunks, dg);   // [chunk][dg | db]
+    ESMI_LAUNCH(train_reduce_chunks_kernel, grid1d(C, 64), dim3(64 * kReduceGroups), 64 * kReduceGroups * sizeof(float), S(stream), part, (long)C, 2L * C, chunks, dg);   // [chunk][dg | db]
     if (int rc = launch_status()) return rc;
-    ESMI_LAUNCH(train_reduce_chunks_kernel, grid1d(C, 64), dim3(1024), 1024 * sizeof(float), S(stream), part + C, (long)C, 2L * C, chunks, db);
+    ESMI_LAUNCH(train_reduce_chunks_kernel, grid1d(C, 64), dim3(64 * kReduceGroups), 64 * kReduceGroups * sizeof(float), S(stream), part + C, (long)C, 2L * C, chunks, db);
     return launch_status();
 }
 int esmi_train_act_fwd_f32(const float* x, int64_t n, int kind, float* y, esmi_stream_t stream) {
@@ -1367,7 +1367,7 @@ int esmi_train_embedding_bwd_f32(const int32_t* ids, const float* dy, int64_t ro
     float* part = static_cast<float*>(workspace);
     ESMI_LAUNCH(train_embed_bwd_kernel, dim3(grid1d(n, 64), (unsigned)chunks), dim3(64), 0, S(stream), ids, dy, (long)rows, V, C, padding_idx, part);
     if (int rc = launch_status()) return rc;
-    ESMI_LAUNCH(train_reduce_chunks_kernel, grid1d(n, 64), dim3(1024), 1024 * sizeof(float), S(stream), part, n, n, chunks, dtable);
+    ESMI_LAUNCH(train_reduce_chunks_kernel, grid1d(n, 64), dim3(64 * kReduceGroups), 64 * kReduceGroups * sizeof(float), S(stream), part, n, n, chunks, dtable);
     return launch_status();
 }
 int esmi_train_mask_rows_f32(const float* x, const uint8_t* mask, int64_t rows, int C, float* y, esmi_stream_t stream) {

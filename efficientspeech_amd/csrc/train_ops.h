@@ -210,22 +210,28 @@ __global__ __launch_bounds__(256) void train_conv_wgrad_mfma_kernel(const ConvDe
     }
 }
 
-// out[e] = sum over chunks of partial[chunk * stride + e], e < n.  1024 threads = 64 elements x 16 interleaved chunk groups; the
-// sixteen group sums are added in group order (fixed order: reproducible)
-__global__ __launch_bounds__(1024) void train_reduce_chunks_kernel(const float* __restrict__ partial, long n, long stride, long chunks,
-                                                                   float* __restrict__ out) {
-    ESMI_DYN_LDS(red);   // 1024 floats
+// out[e] = sum over chunks of partial[chunk * stride + e], e < n.  64 elements x kReduceGroups interleaved chunk groups per
+// workgroup; the group sums are added in group order (fixed order: reproducible).  (The CPU simulator build uses 4 groups and
+// 8 loss workgroups: a fiber per thread makes 1024-thread workgroups the slowest thing in the test suite.)
+#ifdef ESMI_WAVESIM
+constexpr int kReduceGroups = 4;
+#else
+constexpr int kReduceGroups = 16;
+#endif
+__global__ __launch_bounds__(64 * kReduceGroups) void train_reduce_chunks_kernel(const float* __restrict__ partial, long n, long stride,
+                                                                                long chunks, float* __restrict__ out) {
+    ESMI_DYN_LDS(red);   // 64 * kReduceGroups floats
     const int ex = (int)(threadIdx.x & 63), cy = (int)(threadIdx.x >> 6);
     const long q = (long)blockIdx.x * 64 + ex;
     float acc = 0.0f;
     if (q < n)
-        for (long c = cy; c < chunks; c += 16) acc += partial[c * stride + q];
+        for (long c = cy; c < chunks; c += kReduceGroups) acc += partial[c * stride + q];
     red[cy * 64 + ex] = acc;
     __syncthreads();
     if (cy == 0 && q < n) {
         float t = red[ex];
 #pragma unroll
-        for (int u = 1; u < 16; ++u) t += red[u * 64 + ex];
+        for (int u = 1; u < kReduceGroups; ++u) t += red[u * 64 + ex];
         out[q] = t;
     }
 }
@@ -540,7 +546,11 @@ struct LossP {
     float *out, *d_mel, *d_pitch, *d_energy, *d_dur;
     float* partial;                            // [kLossBlocks][6]
 };
+#ifdef ESMI_WAVESIM
+constexpr int kLossBlocks = 8;
+#else
 constexpr int kLossBlocks = 256;
+#endif
 __device__ __forceinline__ float block_sum_256(float v, float* red) {
     const int tid = (int)threadIdx.x;
     red[tid] = v;
@@ -578,7 +588,7 @@ __global__ __launch_bounds__(256) void train_loss_final_kernel(const LossP p) {
     ESMI_DYN_LDS(red);
     float t[6];
 #pragma unroll
-    for (int e = 0; e < 6; ++e) t[e] = block_sum_256(p.partial[(long)threadIdx.x * 6 + e], red);   // kLossBlocks == blockDim
+    for (int e = 0; e < 6; ++e) t[e] = block_sum_256((int)threadIdx.x < kLossBlocks ? p.partial[(long)threadIdx.x * 6 + e] : 0.0f, red);
     if (threadIdx.x == 0) {
         const float n_el = t[0] * (float)p.n_mel, n_ph = t[1];
         const float mel_l = t[2] / n_el, l1 = t[3] / n_ph, l2 = t[4] / n_ph, l3 = t[5] / n_ph;

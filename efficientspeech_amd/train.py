@@ -533,6 +533,41 @@ class TrainStep:
         return static_out.clone()
 
 
+def lr_at_epoch(epoch, base_lr=1e-3, warmup=50, total=5000, min_lr=0.0):
+    """model.py:77-101 + :281: LambdaLR(linear warm-up over `warmup` epochs, then cosine decay to `total`), stepped once per epoch
+    by Lightning's default scheduler interval -- epoch 0 therefore trains at lr 0, as in the reference."""
+    import math
+    if epoch < warmup:
+        lam = float(epoch) / float(max(1, warmup))
+    else:
+        lam = max(min_lr, 0.5 * (1.0 + math.cos(math.pi * float(epoch - warmup) / float(max(1, total - warmup)))))
+    return base_lr * lam
+
+
+def to_device(batch, device):
+    """Move the tensors of a datamodule batch (x or y dict; x also carries the raw `text` list) to `device`."""
+    return {k: (v.to(device) if torch.is_tensor(v) else v) for k, v in batch.items()}
+
+
+def fit(step, loader, epochs, device, base_lr=None, warmup=50, total=5000, first_epoch=0, log=None):
+    """The reference's training loop (train.py:66-76 -> Lightning `trainer.fit`) reduced to what it computes: for every epoch,
+    the scheduled learning rate; for every batch of the datamodule, one `TrainStep.step`.  Returns the per-epoch mean losses."""
+    base_lr = step.lr if base_lr is None else base_lr
+    history = []
+    for epoch in range(first_epoch, first_epoch + epochs):
+        lr = lr_at_epoch(epoch, base_lr, warmup, total)
+        acc, n = None, 0
+        for x, y in loader:
+            losses = step.step(to_device(x, device), to_device(y, device), lr=lr)
+            acc = losses.clone() if acc is None else acc + losses        # five scalars per step: bookkeeping, like self.log()
+            n += 1
+        mean = (acc / max(n, 1)).cpu().tolist() if acc is not None else None
+        history.append({"epoch": epoch, "lr": lr, "losses": mean})
+        if log:
+            log(history[-1])
+    return history
+
+
 def synthetic_batch(B, T, dur, device, seed=5):
     """A seeded teacher-forced batch of the shapes datamodule.collate_fn produces (datamodule.py:29-76): no padding, D-const."""
     import numpy as np

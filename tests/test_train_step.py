@@ -204,3 +204,47 @@ def test_gpu_captured_step_equals_eager_step():
     for a, b in zip(ref, got):                               # (bias corrections: powf on the device vs on the host, ~1 ulp)
         assert torch.allclose(a, b, rtol=1e-5, atol=0), (a, b)
     assert torch.allclose(eager.flat.data, cap.flat.data, rtol=1e-4, atol=1e-6)
+
+
+def test_lr_schedule_matches_reference_lambda():
+    """model.py:77-101: linear warm-up (50 epochs) then cosine decay, evaluated per epoch."""
+    import math
+    from efficientspeech_amd.train import lr_at_epoch
+    assert lr_at_epoch(0) == 0.0 and abs(lr_at_epoch(25) - 0.5e-3) < 1e-12 and abs(lr_at_epoch(50) - 1e-3) < 1e-12
+    assert abs(lr_at_epoch(2525) - 1e-3 * 0.5 * (1 + math.cos(math.pi * 0.5))) < 1e-12 and lr_at_epoch(5000) < 1e-12
+
+
+def test_simulated_fit_over_the_datamodule(tmp_path):
+    """Loader -> training step (8f-2), end to end on the simulator: a synthetic preprocessed_data directory in the
+    reference's on-disk format, `LJSpeechDataset` + `collate_fn`, two epochs of `fit` (epoch 0 at lr 0, as the reference's
+    LambdaLR gives it, epoch 1 at the warm-up rate)."""
+    import json
+    from efficientspeech_amd import train
+    from efficientspeech_amd.data import LJSpeechDataset, collate_fn, ARPABET
+    root = tmp_path / "pre"
+    for d in ("mel", "pitch", "energy", "duration"):
+        (root / d).mkdir(parents=True)
+    rng = np.random.default_rng(0)
+    lines = []
+    for i, n in enumerate((7, 5, 6)):
+        phones = [ARPABET[j] for j in rng.integers(0, len(ARPABET), n)]
+        dur = rng.integers(1, 4, n).astype(np.int64)
+        base = f"LJ00{i}"
+        np.save(root / "duration" / f"LJSpeech-duration-{base}.npy", dur)
+        np.save(root / "pitch" / f"LJSpeech-pitch-{base}.npy", rng.normal(0, 1, n).astype(np.float32))
+        np.save(root / "energy" / f"LJSpeech-energy-{base}.npy", rng.normal(0, 1, n).astype(np.float32))
+        np.save(root / "mel" / f"LJSpeech-mel-{base}.npy", rng.normal(-5, 2, (int(dur.sum()), 80)).astype(np.float32))
+        lines.append(f"{base}|LJSpeech|{{{' '.join(phones)}}}|some text {i}")
+    (root / "train.txt").write_text("\n".join(lines) + "\n")
+    (root / "speakers.json").write_text(json.dumps({"LJSpeech": 0}))
+    cfg = {"path": {"preprocessed_path": str(root)}, "preprocessing": {"text": {"text_cleaners": ["english_cleaners"], "max_length": 4096}}}
+    ds = LJSpeechDataset("train.txt", cfg)
+    loader = torch.utils.data.DataLoader(ds, batch_size=3, shuffle=False, collate_fn=collate_fn)
+    tr, g, net, _, _ = _setup("cpu")
+    with use_sim():
+        step = tr.TrainStep(net, lr=1e-3)
+        before = step.flat.data.clone()
+        hist = train.fit(step, loader, epochs=2, device="cpu", warmup=2, total=10)
+    assert hist[0]["lr"] == 0.0 and abs(hist[1]["lr"] - 0.5e-3) < 1e-12
+    assert all(np.isfinite(h["losses"]).all() for h in hist) and hist[0]["losses"][4] > 0
+    assert not torch.equal(step.flat.data, before)                     # epoch 1 moved the weights (epoch 0 ran at lr 0: decay only)
