@@ -18,7 +18,7 @@ from tests import helpers as H
 
 pytestmark = pytest.mark.gpu
 GOLDEN = sorted(p for p in glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz"))
-                if not os.path.basename(p).startswith("hifigan_") and not p.endswith("_train_step.npz"))   # forward fixtures of the
+                if not os.path.basename(p).startswith("hifigan_") and "_train_step" not in os.path.basename(p))   # forward fixtures of the
 #                                                                 acoustic model (the vocoder and the training step have their own tests)
 DEV = "cuda:0"
 

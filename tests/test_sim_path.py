@@ -19,7 +19,7 @@ from tests.simlib import use_sim
 
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 # all tiny fixtures + a padded / teacher-forced one for the wider models (keeps the CPU suite short)
-CASES = sorted(p for p in glob.glob(os.path.join(GOLD, "tiny_*.npz")) if not p.endswith("_train_step.npz")) + \
+CASES = sorted(p for p in glob.glob(os.path.join(GOLD, "tiny_*.npz")) if "_train_step" not in os.path.basename(p)) + \
     [os.path.join(GOLD, f) for f in ("small_eval_pad_t17.npz", "small_train_tf_padtail.npz",
                                      "base_eval_pad_t17.npz", "base_eval_b1_fox.npz")]
 

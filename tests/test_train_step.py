@@ -16,11 +16,13 @@ from tests.simlib import use_sim
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLD = os.path.join(os.path.dirname(__file__), "golden", "tiny_train_step.npz")
+GOLD_B1 = os.path.join(os.path.dirname(__file__), "golden", "tiny_train_step_b1.npz")   # one utterance (the mask-free code path of
+#                                                        networks.py:338), two zero-length phonemes; a sample of the gradients
 
 
-def _setup(dev):
+def _setup(dev, gold=GOLD):
     from efficientspeech_amd import train
-    g = np.load(GOLD)
+    g = np.load(gold)
     cfg = CONFIGS["tiny"]
     net = build_phoneme2mel(cfg)
     net.load_state_dict({k: torch.from_numpy(v) for k, v in synth_state_dict(cfg, 1234).items()}, strict=True)
@@ -32,8 +34,8 @@ def _setup(dev):
     return train, g, net, x, y
 
 
-def check_loss_and_gradients(dev):
-    train, g, net, x, y = _setup(dev)
+def check_loss_and_gradients(dev, gold=GOLD):
+    train, g, net, x, y = _setup(dev, gold)
     step = train.TrainStep(net)
     step.flat.zero_grad()
     losses = train.training_loss(net, x, y)
@@ -52,7 +54,7 @@ def check_loss_and_gradients(dev):
         err = float(np.abs(mine - ref).max()) / scale
         assert err < 2e-4, (k, err, scale)
         n += 1
-    assert n == 101 and len(step.flat.names) == n                     # every parameter the reference's autograd reaches
+    assert n == (101 if gold == GOLD else 8) and len(step.flat.names) == 101   # every parameter the reference's autograd reaches
     for k in g["no_grad_params"]:
         assert str(k) not in step.flat.names, k                        # left out of the optimizer: torch's grad-is-None rule
     out = train.train_forward(net, dict(x, mel=y["mel"]))
@@ -101,8 +103,9 @@ def check_adamw_step(dev, reproducible=True):
 
 
 @pytest.mark.gpu
-def test_gpu_loss_and_gradients_match_reference():
-    check_loss_and_gradients("cuda")
+@pytest.mark.parametrize("gold", [GOLD, GOLD_B1], ids=["b2_padded", "b1_zero_durations"])
+def test_gpu_loss_and_gradients_match_reference(gold):
+    check_loss_and_gradients("cuda", gold)
 
 
 @pytest.mark.gpu
@@ -141,9 +144,10 @@ def test_simulated_loss_kernel_matches_oracle():
         check_loss_kernel_against_oracle("cpu")
 
 
-def test_simulated_loss_and_gradients_match_reference():
+@pytest.mark.parametrize("gold", [GOLD, GOLD_B1], ids=["b2_padded", "b1_zero_durations"])
+def test_simulated_loss_and_gradients_match_reference(gold):
     with use_sim():
-        check_loss_and_gradients("cpu")
+        check_loss_and_gradients("cpu", gold)
 
 
 def test_simulated_adamw_step_matches_reference():
