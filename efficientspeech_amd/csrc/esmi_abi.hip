@@ -1190,6 +1190,12 @@ int conv_desc_ok(const esmi_conv_desc* d, ConvDesc* o) {
 }
 }  // namespace
 
+namespace {
+inline bool wgrad_depthwise(const ConvDesc& c) { return !c.transposed && c.groups == c.c_in && c.c_in == c.c_out && c.k <= 8; }
+inline bool wgrad_on_mfma(const ConvDesc& c);
+inline int wgrad_chunk(const ConvDesc& c) { return wgrad_on_mfma(c) ? kTrainChunkMfma : (wgrad_depthwise(c) ? kTrainChunkDw : kTrainChunk); }
+inline bool wgrad_on_mfma(const ConvDesc& c) { return c.groups == 1 && c.c_in >= 8 && c.c_out >= 8 && (c.c_out & 3) == 0; }
+}
 // Dense convolutions (groups == 1) of the training step run on the matrix pipe through the inference path's implicit GEMM
 // (convgemm.h) when the caller gives scratch for the tap-major copy of the weight: the forward as it is, the data gradient as
 // the transposed problem -- d(Conv1d) is a ConvTranspose1d of dy with the same (Cout, Cin, k) tensor read as (Cin', Cout', k),
@@ -1231,6 +1237,10 @@ int esmi_train_conv_fwd_f32(const esmi_conv_desc* d, const float* x, const float
         if (rc != ESMI_ERR_UNSUPPORTED) return rc;
     }
     const long n = (long)c.B * c.n_out * c.c_out;
+    if (wgrad_depthwise(c) && c.stride == 1 && (c.c_out & 3) == 0) {
+        ESMI_LAUNCH(train_conv_dw_kernel, grid1d(n / 4), dim3(256), 0, S(stream), c, x, w, bias, y, 0);
+        return launch_status();
+    }
     ESMI_LAUNCH(train_conv_fwd_kernel, grid1d(n), dim3(256), 0, S(stream), c, x, w, bias, y);
     return launch_status();
 }
@@ -1244,14 +1254,12 @@ int esmi_train_conv_dgrad_f32(const esmi_conv_desc* d, const float* dy, const fl
         if (rc != ESMI_ERR_UNSUPPORTED) return rc;
     }
     const long n = (long)c.B * c.n_in * c.c_in;
+    if (wgrad_depthwise(c) && c.stride == 1 && (c.c_out & 3) == 0) {
+        ESMI_LAUNCH(train_conv_dw_kernel, grid1d(n / 4), dim3(256), 0, S(stream), c, dy, w, nullptr, dx, 1);
+        return launch_status();
+    }
     ESMI_LAUNCH(train_conv_dgrad_kernel, grid1d(n), dim3(256), 0, S(stream), c, dy, w, dx);
     return launch_status();
-}
-namespace {
-inline bool wgrad_depthwise(const ConvDesc& c) { return !c.transposed && c.groups == c.c_in && c.c_in == c.c_out && c.k <= 8; }
-inline bool wgrad_on_mfma(const ConvDesc& c);
-inline int wgrad_chunk(const ConvDesc& c) { return wgrad_on_mfma(c) ? kTrainChunkMfma : (wgrad_depthwise(c) ? kTrainChunkDw : kTrainChunk); }
-inline bool wgrad_on_mfma(const ConvDesc& c) { return c.groups == 1 && c.c_in >= 8 && c.c_out >= 8 && (c.c_out & 3) == 0; }
 }
 size_t esmi_train_conv_wgrad_workspace_bytes(const esmi_conv_desc* d) {
     ConvDesc c;
@@ -1269,30 +1277,26 @@ int esmi_train_conv_wgrad_f32(const esmi_conv_desc* d, const float* x, const flo
     const long nw = (long)(c.transposed ? c.c_in * c.c_out : c.c_out * (c.c_in / c.groups)) * c.k;
     const bool mfma = wgrad_on_mfma(c), depthwise = wgrad_depthwise(c);
     const long rows = (long)c.B * c.n_out, chunks = train_chunks(rows, wgrad_chunk(c));
-    float* part = static_cast<float*>(workspace);
-    float* pb = part + chunks * nw;
+    float* part = static_cast<float*>(workspace);   // [chunk][weight partials (nw) | bias partials (c_out)]
+    float* pb = part + nw;
+    const long ps = nw + c.c_out;
     if (mfma) {   // dense: one wave per (128 output channels x 32 input channels, tap, chunk) on the fp32 MFMA; bias partials from the tap 0, ci0 = 0 waves
         const unsigned tiles = (unsigned)(((c.c_out + 127) / 128) * ((c.c_in + 31) / 32) * c.k);
         ESMI_LAUNCH(train_conv_wgrad_mfma_kernel, dim3(tiles, (unsigned)((chunks + 3) / 4)), dim3(256), 0, S(stream), c, x, dy, part,
-                    dbias ? pb : nullptr, chunks);
+                    dbias ? pb : nullptr, chunks, ps);
     } else if (depthwise) {
         ESMI_LAUNCH(train_conv_wgrad_dw_kernel, dim3(grid1d(c.c_out, 64), (unsigned)chunks), dim3(64), 0, S(stream), c, x, dy, part,
-                    dbias ? pb : nullptr);
+                    dbias ? pb : nullptr, ps);
     } else {
-        ESMI_LAUNCH(train_conv_wgrad_kernel, dim3(grid1d(nw, 64), (unsigned)chunks), dim3(64), 0, S(stream), c, x, dy, part);
+        ESMI_LAUNCH(train_conv_wgrad_kernel, dim3(grid1d(nw, 64), (unsigned)chunks), dim3(64), 0, S(stream), c, x, dy, part, ps);
+        if (int rc = launch_status()) return rc;
+        if (dbias) ESMI_LAUNCH(train_colsum_kernel, dim3(grid1d(c.c_out, 64), (unsigned)chunks), dim3(64), 0, S(stream), dy, rows, c.c_out, pb, ps);
     }
     if (int rc = launch_status()) return rc;
-    ESMI_LAUNCH(train_reduce_chunks_kernel, grid1d(nw, 64), dim3(64 * kReduceGroups), 64 * kReduceGroups * sizeof(float), S(stream), part, nw, nw, chunks, dw);
-    if (int rc = launch_status()) return rc;
-    if (dbias) {
-        if (!mfma && !depthwise) {
-            ESMI_LAUNCH(train_colsum_kernel, dim3(grid1d(c.c_out, 64), (unsigned)chunks), dim3(64), 0, S(stream), dy, rows, c.c_out, pb);
-            if (int rc = launch_status()) return rc;
-        }
-        ESMI_LAUNCH(train_reduce_chunks_kernel, grid1d(c.c_out, 64), dim3(64 * kReduceGroups), 64 * kReduceGroups * sizeof(float), S(stream), pb, (long)c.c_out, (long)c.c_out, chunks, dbias);
-        return launch_status();
-    }
-    return ESMI_OK;
+    // weight and bias partials in ONE reduction launch: elements >= nw of a partial row are the bias sums
+    ESMI_LAUNCH(train_reduce_chunks_kernel, grid1d(dbias ? ps : nw, 64), dim3(64 * kReduceGroups), 64 * kReduceGroups * sizeof(float), S(stream),
+                part, dbias ? ps : nw, ps, chunks, dw, nw, dbias);
+    return launch_status();
 }
 int esmi_train_layernorm_fwd_f32(const float* x, const float* g, const float* b, int64_t rows, int C, float* y, float* mean,
                                  float* rstd, esmi_stream_t stream) {

@@ -57,6 +57,26 @@ __global__ void train_conv_fwd_kernel(const ConvDesc d, const float* __restrict_
     y[q] = acc;
 }
 
+// depthwise, stride 1 (MelDecoder's k = 5 convs): one thread per (row, 4 channels), 16-byte accesses; `grad` runs the data
+// gradient (the same taps mirrored: dx[t] = sum_j dy[t + pad - j] w[j]); weights (C, 1, k)
+__global__ void train_conv_dw_kernel(const ConvDesc d, const float* __restrict__ in, const float* __restrict__ w,
+                                     const float* __restrict__ bias, float* __restrict__ out, int grad) {
+    const int c4 = d.c_out >> 2;
+    const long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int n_o = grad ? d.n_in : d.n_out, n_i = grad ? d.n_out : d.n_in;
+    if (q >= (long)d.B * n_o * c4) return;
+    const int c = (int)(q % c4) * 4, t = (int)((q / c4) % n_o), b = (int)(q / ((long)c4 * n_o));
+    f32x4 acc = (bias && !grad) ? ld4(bias + c) : zero4();
+    for (int j = 0; j < d.k; ++j) {
+        const int ti = grad ? t + d.pad - j : t + j - d.pad;
+        if (ti < 0 || ti >= n_i) continue;
+        const f32x4 v = ld4(in + ((long)b * n_i + ti) * d.c_out + c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] = fmaf(v[e], w[(long)(c + e) * d.k + j], acc[e]);
+    }
+    *reinterpret_cast<f32x4*>(out + q * 4) = acc;
+}
+
 // dx[b, ti, ci] = sum over (t, j) with in_pos(t, j) == ti, and co connected to ci, of dy[b, t, co] * w(co, ci, j)
 __global__ void train_conv_dgrad_kernel(const ConvDesc d, const float* __restrict__ dy, const float* __restrict__ w,
                                         float* __restrict__ dx) {
@@ -97,7 +117,7 @@ __host__ __device__ inline long train_chunks(long rows, int chunk = kTrainChunk)
 
 // dw(co, ci, j) = sum over (b, t) of dy[b, t, co] * x[b, in_pos(t, j), ci]: partial[chunk][weight element in checkpoint order]
 __global__ void train_conv_wgrad_kernel(const ConvDesc d, const float* __restrict__ x, const float* __restrict__ dy,
-                                        float* __restrict__ partial) {
+                                        float* __restrict__ partial, long pstride) {
     const int cig = d.transposed ? d.c_out : d.c_in / d.groups;      // middle extent of the checkpoint layout
     const int outer = d.transposed ? d.c_in : d.c_out;
     const long nw = (long)outer * cig * d.k;
@@ -116,12 +136,12 @@ __global__ void train_conv_wgrad_kernel(const ConvDesc d, const float* __restric
         if (ti < 0) continue;
         acc = fmaf(dy[r * d.c_out + co], x[((long)b * d.n_in + ti) * d.c_in + ci], acc);
     }
-    partial[(long)blockIdx.y * nw + q] = acc;
+    partial[(long)blockIdx.y * pstride + q] = acc;
 }
 // depthwise (groups == C, one input channel per output channel, k <= 8): lanes across the channels (coalesced), every thread
 // keeps the k tap sums and the bias sum of its channel over the chunk's rows
 __global__ void train_conv_wgrad_dw_kernel(const ConvDesc d, const float* __restrict__ x, const float* __restrict__ dy,
-                                           float* __restrict__ partial, float* __restrict__ partial_bias) {
+                                           float* __restrict__ partial, float* __restrict__ partial_bias, long pstride) {
     const int c = (int)(blockIdx.x * blockDim.x + threadIdx.x);
     if (c >= d.c_out) return;
     const long rows = (long)d.B * d.n_out, r0 = (long)blockIdx.y * kTrainChunkDw, r1 = r0 + kTrainChunkDw < rows ? r0 + kTrainChunkDw : rows;
@@ -137,11 +157,10 @@ __global__ void train_conv_wgrad_dw_kernel(const ConvDesc d, const float* __rest
             if (ti >= 0) acc[j] = fmaf(g, x[((long)b * d.n_in + ti) * d.c_in + c], acc[j]);
         }
     }
-    const long nw = (long)d.c_out * d.k;
 #pragma unroll
     for (int j = 0; j < 8; ++j)
-        if (j < d.k) partial[(long)blockIdx.y * nw + (long)c * d.k + j] = acc[j];
-    if (partial_bias) partial_bias[(long)blockIdx.y * d.c_out + c] = bs;
+        if (j < d.k) partial[(long)blockIdx.y * pstride + (long)c * d.k + j] = acc[j];
+    if (partial_bias) partial_bias[(long)blockIdx.y * pstride + c] = bs;
 }
 
 // The same partial sums for DENSE convolutions on the matrix pipe: dW_j = dY^T X_j is a GEMM with the rows as the contraction
@@ -152,7 +171,7 @@ __global__ void train_conv_wgrad_dw_kernel(const ConvDesc d, const float* __rest
 // (input tile, output tile).  The (tap 0, first input tile) waves also sum dY's columns: the bias gradient.
 __global__ __launch_bounds__(256) void train_conv_wgrad_mfma_kernel(const ConvDesc d, const float* __restrict__ x,
                                                                     const float* __restrict__ dy, float* __restrict__ partial,
-                                                                    float* __restrict__ partial_bias, long chunks) {
+                                                                    float* __restrict__ partial_bias, long chunks, long pstride) {
     const int lane = lane_id(), i = lane & 31, kh = lane >> 5;
     const int tci = (d.c_in + 31) / 32;
     const int tile = (int)blockIdx.x, j = tile % d.k, ci0 = ((tile / d.k) % tci) * 32, cb = (tile / (d.k * tci)) * 128;
@@ -190,7 +209,6 @@ __global__ __launch_bounds__(256) void train_conv_wgrad_mfma_kernel(const ConvDe
             for (int t4 = 0; t4 < 4; ++t4) acc[t4] = mfma32(a[u][t4], bv[u], acc[t4]);
         }
     }
-    const long nw = (long)d.c_out * d.c_in * d.k;
     const int ci = ci0 + i;
 #pragma unroll
     for (int t4 = 0; t4 < 4; ++t4) {
@@ -198,14 +216,14 @@ __global__ __launch_bounds__(256) void train_conv_wgrad_mfma_kernel(const ConvDe
         for (int r = 0; r < 16; ++r) {
             const int co = cb + 4 * tile_row(r, lane) + t4;
             long wi;
-            if (co < d.c_out && ci < d.c_in && conv_w_index(d, co, ci, j, &wi)) partial[chunk * nw + wi] = acc[t4][r];
+            if (co < d.c_out && ci < d.c_in && conv_w_index(d, co, ci, j, &wi)) partial[chunk * pstride + wi] = acc[t4][r];
         }
     }
     if (partial_bias && j == 0 && ci0 == 0) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const float v = bsum[e] + shfl_xor_f(bsum[e], 32);      // even rows (kh = 0) + odd rows (kh = 1)
-            if (kh == 0 && co4 + e < d.c_out) partial_bias[chunk * d.c_out + co4 + e] = v;
+            if (kh == 0 && co4 + e < d.c_out) partial_bias[chunk * pstride + co4 + e] = v;
         }
     }
 }
@@ -219,7 +237,8 @@ constexpr int kReduceGroups = 4;
 constexpr int kReduceGroups = 16;
 #endif
 __global__ __launch_bounds__(64 * kReduceGroups) void train_reduce_chunks_kernel(const float* __restrict__ partial, long n, long stride,
-                                                                                long chunks, float* __restrict__ out) {
+                                                                                long chunks, float* __restrict__ out,
+                                                                                long n0 = -1, float* __restrict__ out1 = nullptr) {
     ESMI_DYN_LDS(red);   // 64 * kReduceGroups floats
     const int ex = (int)(threadIdx.x & 63), cy = (int)(threadIdx.x >> 6);
     const long q = (long)blockIdx.x * 64 + ex;
@@ -232,17 +251,18 @@ __global__ __launch_bounds__(64 * kReduceGroups) void train_reduce_chunks_kernel
         float t = red[ex];
 #pragma unroll
         for (int u = 1; u < kReduceGroups; ++u) t += red[u * 64 + ex];
-        out[q] = t;
+        if (out1 && q >= n0) out1[q - n0] = t;      // second segment of a partial row (e.g. the bias sums after the weight sums)
+        else out[q] = t;
     }
 }
 // partial[chunk][c] = sum over the chunk's rows of v[row, c]   (bias gradients)
-__global__ void train_colsum_kernel(const float* __restrict__ v, long rows, int C, float* __restrict__ partial) {
+__global__ void train_colsum_kernel(const float* __restrict__ v, long rows, int C, float* __restrict__ partial, long pstride) {
     const int c = (int)(blockIdx.x * blockDim.x + threadIdx.x);
     if (c >= C) return;
     const long r0 = (long)blockIdx.y * kTrainChunk, r1 = r0 + kTrainChunk < rows ? r0 + kTrainChunk : rows;
     float acc = 0.0f;
     for (long r = r0; r < r1; ++r) acc += v[r * C + c];
-    partial[(long)blockIdx.y * C + c] = acc;
+    partial[(long)blockIdx.y * pstride + c] = acc;
 }
 
 // ---- LayerNorm over the last dim (biased variance, eps inside the sqrt): one wave per row, lanes across the channels
