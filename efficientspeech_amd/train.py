@@ -434,9 +434,10 @@ class FlatParams:
     def __init__(self, net):
         named = [(k, p) for k, p in net.named_parameters() if p.requires_grad and not k.startswith(_UNREACHED)]
         self.names = [k for k, _ in named]
-        n = sum(p.numel() for _, p in named)
+        pad4 = lambda k: (k + 3) & ~3                                     # noqa: E731  every tensor starts 16-byte aligned
+        n = sum(pad4(p.numel()) for _, p in named)
         dev = named[0][1].device
-        self.data = torch.empty(n, dtype=torch.float32, device=dev)
+        self.data = torch.zeros(n, dtype=torch.float32, device=dev)          # (pad elements stay 0 under AdamW: g = 0, p = 0)
         self.grad = torch.zeros(n, dtype=torch.float32, device=dev)
         self.m, self.v = torch.zeros_like(self.data), torch.zeros_like(self.data)
         off = 0
@@ -445,7 +446,7 @@ class FlatParams:
             self.data[off:off + k].copy_(p.detach().reshape(-1))
             p.data = self.data[off:off + k].view(p.shape)
             p.grad = self.grad[off:off + k].view(p.shape)
-            off += k
+            off += pad4(k)
         self.params = [p for _, p in named]
 
     def zero_grad(self):
