@@ -245,6 +245,12 @@ def main():
             pipe, a.two_stream = alt, True
         launch_note = f"; warm-up trial: eager {t_eager * 1e3:.3f} ms/step, two-stream {t_two * 1e3:.3f} ms/step"
     dt, dec_ms, n_ev = timed_steps(pipe, net, x, a.steps, a.warmup, sync_all, a.event_every, a.graph)
+    if a.two_stream and world == 1:
+        # with the encoder side of step i+1 running beside it, the decoder's event-timed duration is not the kernel's own: time
+        # the kernel for the roofline in a short single-stream run (the step time above stays the two-stream one)
+        solo = ShardedMelPipeline(net, world_size=1, gather=False)
+        _, dec_ms, n_ev = timed_steps(solo, net, x, max(10, a.steps // 5), 3, sync_all, a.event_every, False)
+        launch_note += "; roofline kernel_ms from a single-stream run"
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
