@@ -15,6 +15,7 @@ Prints ONE JSON line (rank 0):
   decoder_only           (N=1) MelDecoder.forward alone on frame-rate features ~ N(0,1)
   allgather              (N>1) the mel all-gather timed by itself: GB/s received per rank vs 7 xGMI links x 76.8 GB/s
   without_allgather      (N>1) the same sharded steps with the exchange switched off (compute scaling next to the link-bound value)
+  b1_fox_gpu             (N=1) single-utterance latency of the forward (BASELINE configs[0] shape) with a sync per call
   vocoder                (N=1) the HiFi-GAN v2 generator on the mel the forward produced: mel-frames/s, TFLOP/s
   train_step             the training step (BASELINE configs[4]): ms/step at the reference's batch size per GPU
   cpu_baseline           (N=1) the C oracle (oracle/, fp32 accumulation, OpenMP) on this box's host cores: all cores and
@@ -373,6 +374,23 @@ def main():
                                  "frac_of_157.3": ach32 / FP32_PEAK_TFLOPS, "build_config": cfg32,
                                  "library": "efficientspeech_amd/libesmi_fp32mfma.so"}
             del net32, pipe32
+        # ---- BASELINE configs[0] shape on the GPU: one utterance (the 31-phoneme fox sentence), predicted durations replaced by
+        # D-const (random-init predictors give 0), synchronous calls: what demo.py's loop sees per sentence
+        fox = torch.tensor([FOX_IDS], dtype=torch.int32, device=dev)
+        xf = {"phoneme": fox, "duration_forced": torch.full((1, len(FOX_IDS)), a.dur, dtype=torch.int32, device=dev)}
+        with torch.no_grad():
+            for _ in range(5):
+                net(xf)
+            torch.cuda.synchronize(dev)
+            ts_ = []
+            for _ in range(50):
+                t0 = time.perf_counter()
+                net(xf)
+                torch.cuda.synchronize(dev)
+                ts_.append(time.perf_counter() - t0)
+        out["b1_fox_gpu"] = {"latency_ms_median": float(np.median(ts_) * 1e3), "frames": len(FOX_IDS) * a.dur,
+                             "mRTF": len(FOX_IDS) * a.dur * 256 / 22050 / float(np.median(ts_)),
+                             "note": "Phoneme2Mel.forward, B=1, T=31, synchronised after every call (host enqueue + kernels)"}
         # ---- the step after the path: HiFi-GAN v2 generator on the mel the forward just produced
         if not a.exact_fp32:
             from efficientspeech_amd.hifigan import HIFIGAN_CONFIGS, Generator, synth_hifigan_state_dict, flops_per_mel_frame
@@ -391,6 +409,17 @@ def main():
                     wav = voc(mel_v.transpose(1, 2))
                 torch.cuda.synchronize(dev)
                 tv = (time.perf_counter() - t0) / 5
+                for _ in range(3):
+                    voc(net(xf)[0].transpose(1, 2))
+                torch.cuda.synchronize(dev)
+                tw = []
+                for _ in range(20):
+                    t0 = time.perf_counter()
+                    wav1 = voc(net(xf)[0].transpose(1, 2))
+                    torch.cuda.synchronize(dev)
+                    tw.append(time.perf_counter() - t0)
+            out["b1_fox_gpu"]["text_to_wav_ms_median"] = float(np.median(tw) * 1e3)
+            out["b1_fox_gpu"]["text_to_wav_x_realtime"] = wav1.shape[-1] / 22050.0 / float(np.median(tw))
             vf = flops_per_mel_frame(hcfg) * vb * L / tv / 1e12
             voc_fps, am_fps = vb * L / tv, out["value"]
             out["vocoder"] = {"workload": f"hifigan_v2 generator, B={vb} x L={L} mel frames -> {L * hcfg.hop} samples each",
