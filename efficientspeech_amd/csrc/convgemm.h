@@ -51,6 +51,9 @@ struct ConvGemmP {
     float act_in_slope;
     float a_scale;       // 0 is read as 1
     int accum;           // 1: out += value (same element, same thread: no race)
+    // training step (data-gradient GEMMs): device-side power-of-two scales, [0] multiplies the A values as they are loaded,
+    // [1] the accumulated result -- keeps tiny gradients inside the binary16 range of the split products.  NULL: 1, 1
+    const float* io_scale;
 };
 
 // output positions per tile row step, and 32-row tiles per phase and batch item (see convgemm_kernel)
@@ -61,7 +64,8 @@ __host__ __device__ inline int convgemm_tiles_per_phase(const ConvGemmP& p) {
 }
 
 // input-side activation of the HiFi-GAN convolutions, applied to a loaded fragment
-__device__ __forceinline__ f32x4 conv_act_in(f32x4 v, const ConvGemmP& p) {
+__device__ __forceinline__ f32x4 conv_act_in(f32x4 v, const ConvGemmP& p, float in_s = 1.0f) {
+    if (p.io_scale) v = v * in_s;
     if (p.act_in) {
         const float sc = p.a_scale != 0.0f ? p.a_scale : 1.0f;
 #pragma unroll
@@ -78,6 +82,7 @@ __device__ __forceinline__ f32x4 conv_act_in(f32x4 v, const ConvGemmP& p) {
 template <int NT>
 __device__ __forceinline__ void convgemm_epilogue(f32x16 (&acc)[NT], const ConvGemmP& p, int b, int t0, int n0, int lane, int ts = 1) {
     const int i = lane & 31;
+    const float out_s = (ESMI_CHAIN_SPLIT ? kF16WScaleInv : 1.0f) * (p.io_scale ? p.io_scale[1] : 1.0f);
     int col[NT];
     bool cok[NT];
     float bias[NT];
@@ -94,7 +99,7 @@ __device__ __forceinline__ void convgemm_epilogue(f32x16 (&acc)[NT], const ConvG
         const long row = (long)b * p.n_out + t;
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
-            float v = apply_act(fmaf(acc[nt][r], ESMI_CHAIN_SPLIT ? kF16WScaleInv : 1.0f, bias[nt]), p.act);
+            float v = apply_act(fmaf(acc[nt][r], out_s, bias[nt]), p.act);
             if (p.res && rok && cok[nt]) v += p.res[row * p.ldr + p.r_coff + col[nt]];
             acc[nt][r] = v;
         }
@@ -153,6 +158,7 @@ __global__ __launch_bounds__(256) void convgemm_kernel(const ConvGemmP p) {
     const int i = lane & 31, h = lane >> 5;
     const int t_out = t0 + i * ts;
     const int j_first = ts > 1 ? (phase + p.pad) % ts : 0;
+    const float in_s = p.io_scale ? p.io_scale[0] : 1.0f;
 
     f32x16 acc[NT];
 #pragma unroll
@@ -212,7 +218,7 @@ __global__ __launch_bounds__(256) void convgemm_kernel(const ConvGemmP p) {
 #pragma unroll
             for (int g = 0; g < KG; ++g) {
                 const int c = 8 * (kc + g) + 4 * h;
-                av[g] = ok ? conv_act_in(ld4(arow + c), p) : zero4();
+                av[g] = ok ? conv_act_in(ld4(arow + c), p, in_s) : zero4();
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) bv[g][nt] = wok[nt] ? ld4(wrow[nt] + c) : zero4();
             }
@@ -222,7 +228,7 @@ __global__ __launch_bounds__(256) void convgemm_kernel(const ConvGemmP p) {
         for (; kc < kcs; kc += 2) {   // 8 or 16 channels left
             const int c = 8 * kc + 4 * h;
             const bool two = kc + 1 < kcs;
-            const f32x4 a0 = ok ? conv_act_in(ld4(arow + c), p) : zero4(), a1 = (ok && two) ? conv_act_in(ld4(arow + c + 8), p) : zero4();
+            const f32x4 a0 = ok ? conv_act_in(ld4(arow + c), p, in_s) : zero4(), a1 = (ok && two) ? conv_act_in(ld4(arow + c + 8), p, in_s) : zero4();
             f32x4 b0[NT], b1[NT];
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
@@ -237,7 +243,7 @@ __global__ __launch_bounds__(256) void convgemm_kernel(const ConvGemmP p) {
 #pragma unroll
             for (int g = 0; g < KG; ++g) {
                 const int c = 8 * (kc + g) + 4 * h;
-                av[g] = ok ? conv_act_in(ld4(arow + c), p) : zero4();
+                av[g] = ok ? conv_act_in(ld4(arow + c), p, in_s) : zero4();
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) bv[g][nt] = wok[nt] ? ld4(wrow[nt] + c) : zero4();
             }
@@ -252,7 +258,7 @@ __global__ __launch_bounds__(256) void convgemm_kernel(const ConvGemmP p) {
         }
         for (; kc < kcs; ++kc) {
             const int c = 8 * kc + 4 * h;
-            const f32x4 av = ok ? conv_act_in(ld4(arow + c), p) : zero4();
+            const f32x4 av = ok ? conv_act_in(ld4(arow + c), p, in_s) : zero4();
             f32x4 bv[NT];
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) bv[nt] = wok[nt] ? ld4(wrow[nt] + c) : zero4();
@@ -277,6 +283,7 @@ __global__ __launch_bounds__(256) void conv_to1_kernel(const ConvGemmP p) {
     if (q >= (long)p.B * p.n_out) return;
     const int b = (int)(q / p.n_out), t = (int)(q - (long)b * p.n_out);
     const int dil = p.dil > 0 ? p.dil : 1;
+    const float in_s = p.io_scale ? p.io_scale[0] : 1.0f;
     float acc = 0.0f;
     for (int j = 0; j < p.k; ++j) {
         const int ti = t + j * dil - p.pad;
@@ -284,12 +291,12 @@ __global__ __launch_bounds__(256) void conv_to1_kernel(const ConvGemmP p) {
         const float* arow = p.A + ((long)b * p.n_in + ti) * p.lda + p.a_coff;
         const float* wj = p.W + (long)j * p.c_in;
         for (int c = 0; c < p.c_in; c += 4) {
-            const f32x4 a = conv_act_in(ld4(arow + c), p), w = ld4(wj + c);
+            const f32x4 a = conv_act_in(ld4(arow + c), p, in_s), w = ld4(wj + c);
 #pragma unroll
             for (int e = 0; e < 4; ++e) acc = fmaf(a[e], w[e], acc);
         }
     }
-    float v = apply_act(acc + (p.bias ? p.bias[0] : 0.0f), p.act);
+    float v = apply_act(acc * (p.io_scale ? p.io_scale[1] : 1.0f) + (p.bias ? p.bias[0] : 0.0f), p.act);
     if (p.post_relu) v = fmaxf(v, 0.0f);
     float* o = p.out + ((long)b * p.n_out + t) * p.ldo + p.o_coff;
     *o = p.accum ? *o + v : v;
@@ -328,6 +335,7 @@ __global__ __launch_bounds__(256, 2) void convgemm_lds_kernel(const ConvGemmP p)
     const int kchunks = p.c_in >> 5, n_it = p.k * kchunks;
     f32x4 a_nxt[2][2], w_nxt[NT];
     f16x2p a_cur[2];
+    const float in_s = p.io_scale ? p.io_scale[0] : 1.0f;
     auto fetch = [&](int it) __attribute__((always_inline)) {   // global -> registers: A rows of this wave, W rows of the workgroup
         const int j = it / kchunks, c = (it - j * kchunks) << 5;
         const int ti = t_out + j * (p.dil > 0 ? p.dil : 1) - p.pad;
@@ -335,8 +343,8 @@ __global__ __launch_bounds__(256, 2) void convgemm_lds_kernel(const ConvGemmP p)
         const float* arow = p.A + ((long)b * p.n_in + (ok ? ti : 0)) * p.lda + p.a_coff + c + 8 * h;
 #pragma unroll
         for (int st = 0; st < 2; ++st) {
-            a_nxt[st][0] = ok ? conv_act_in(ld4(arow + 16 * st), p) : zero4();
-            a_nxt[st][1] = ok ? conv_act_in(ld4(arow + 16 * st + 4), p) : zero4();
+            a_nxt[st][0] = ok ? conv_act_in(ld4(arow + 16 * st), p, in_s) : zero4();
+            a_nxt[st][1] = ok ? conv_act_in(ld4(arow + 16 * st + 4), p, in_s) : zero4();
         }
         const float* wj = p.W + (long)j * p.c_out * p.c_in + c;
 #pragma unroll

@@ -1204,7 +1204,7 @@ inline bool wgrad_on_mfma(const ConvDesc& c) { return c.groups == 1 && c.c_in >=
 size_t esmi_train_conv_workspace_bytes(const esmi_conv_desc* d) {
     ConvDesc c;
     if (conv_desc_ok(d, &c) || c.groups != 1) return 0;
-    return align256((size_t)c.k * c.c_out * c.c_in * sizeof(float));
+    return align256((size_t)c.k * c.c_out * c.c_in * sizeof(float)) + 256;   // + the data gradient's absmax / scale slots
 }
 namespace {
 // one of the two implicit-GEMM problems of a dense conv: returns ESMI_ERR_UNSUPPORTED when the GEMM does not take the shape
@@ -1219,6 +1219,17 @@ int train_conv_gemm(const ConvDesc& c, bool grad, const float* in, const float* 
     ESMI_LAUNCH(pack_conv_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, w, wt, cout, cin, c.k, as_convT);
     if (int rc = launch_status()) return rc;
     ConvGemmP p = conv_defaults();
+    if (grad) {   // dy -> [2^9, 2^10) by a power of two chosen on the device (train_pow2_scale_kernel)
+        float* slots = reinterpret_cast<float*>(reinterpret_cast<char*>(wt) + align256((size_t)n * sizeof(float)));   // [0] absmax, [2..3] scales
+        hipError_t e = hipMemsetAsync(slots, 0, sizeof(float), st);
+        if (e != hipSuccess) return (int)e;
+        const long len = (long)c.B * c.n_out * c.c_out, blocks = (len + 256L * 8 - 1) / (256L * 8);
+        ESMI_LAUNCH(absmax_kernel, dim3((unsigned)(blocks > 1024 ? 1024 : blocks)), dim3(256), 0, st, in, len, reinterpret_cast<int*>(slots));
+        if (int rc = launch_status()) return rc;
+        ESMI_LAUNCH(train_pow2_scale_kernel, dim3(1), dim3(64), 0, st, slots, slots + 2);
+        if (int rc = launch_status()) return rc;
+        p.io_scale = slots + 2;
+    }
     p.mode = as_convT ? MODE_CONVT : MODE_CONV;
     p.k = c.k; p.stride = c.stride; p.pad = c.pad;
     p.B = c.B; p.n_in = grad ? c.n_out : c.n_in; p.n_out = grad ? c.n_in : c.n_out; p.c_in = cin; p.c_out = cout;
@@ -1426,7 +1437,7 @@ int esmi_train_adamw_f32(float* p, const float* g, float* m, float* v, int64_t n
 int esmi_train_adamw_graph_f32(float* p, const float* g, float* m, float* v, int64_t n, const float* lr_dev, float beta1, float beta2,
                                float eps, float weight_decay, int32_t* step_dev, esmi_stream_t stream) {
     if (!p || !g || !m || !v || !lr_dev || !step_dev || n <= 0) return ESMI_ERR_ARG;
-    ESMI_LAUNCH(train_bump_step_kernel, dim3(1), dim3(1), 0, S(stream), step_dev);
+    ESMI_LAUNCH(train_bump_step_kernel, dim3(1), dim3(64), 0, S(stream), step_dev);
     if (int rc = launch_status()) return rc;
     ESMI_LAUNCH(train_adamw_dev_kernel, grid1d(n), dim3(256), 0, S(stream), p, g, m, v, (long)n, lr_dev, beta1, beta2, eps, weight_decay, step_dev);
     return launch_status();

@@ -653,9 +653,23 @@ __global__ void train_adamw_kernel(float* __restrict__ p, const float* __restric
     p[q] = w;
 }
 
+// power-of-two scales that bring a tensor's largest magnitude to [2^9, 2^10): sc[0] = s, sc[1] = 1 / s (exact); the data-gradient
+// GEMMs multiply dy by s as they load it and the result by 1 / s, so gradients of any magnitude sit in the middle of the
+// binary16 range of the split products (a 1e-7 gradient would otherwise be a zero-bit f16 subnormal)
+__global__ void train_pow2_scale_kernel(const float* __restrict__ absmax, float* __restrict__ sc) {
+    if (threadIdx.x != 0) return;
+    const int bits = __builtin_bit_cast(int, absmax[0]);
+    int e = ((bits >> 23) & 255) - 127;                  // floor(log2(absmax)) for normal numbers
+    if (bits == 0 || ((bits >> 23) & 255) == 255) e = 9; // all zero / inf / nan: no scaling
+    int k = 9 - e;
+    k = k < -100 ? -100 : (k > 100 ? 100 : k);
+    sc[0] = __builtin_bit_cast(float, (127 + k) << 23);
+    sc[1] = __builtin_bit_cast(float, (127 - k) << 23);
+}
+
 // the same with the step count and the learning rate read from device memory, so that a captured hipGraph of the whole
 // training step replays correctly: hyper = {lr}; *step is advanced by train_bump_step_kernel inside the graph
-__global__ void train_bump_step_kernel(int* __restrict__ step) { step[0] += 1; }
+__global__ void train_bump_step_kernel(int* __restrict__ step) { if (threadIdx.x == 0) step[0] += 1; }
 __global__ void train_adamw_dev_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                                        long n, const float* __restrict__ lr_dev, float beta1, float beta2, float eps, float wd,
                                        const int* __restrict__ step) {

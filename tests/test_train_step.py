@@ -16,6 +16,8 @@ from tests.simlib import use_sim
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLD = os.path.join(os.path.dirname(__file__), "golden", "tiny_train_step.npz")
+GOLD_SMALL = os.path.join(os.path.dirname(__file__), "golden", "small_train_step.npz")   # 3 blocks, reduction 2; sample of gradients
+GOLD_BASE = os.path.join(os.path.dirname(__file__), "golden", "base_train_step.npz")     # heads 2/4/6, expansion 2, k = 5, depth 3
 GOLD_B1 = os.path.join(os.path.dirname(__file__), "golden", "tiny_train_step_b1.npz")   # one utterance (the mask-free code path of
 #                                                        networks.py:338), two zero-length phonemes; a sample of the gradients
 
@@ -23,7 +25,7 @@ GOLD_B1 = os.path.join(os.path.dirname(__file__), "golden", "tiny_train_step_b1.
 def _setup(dev, gold=GOLD):
     from efficientspeech_amd import train
     g = np.load(gold)
-    cfg = CONFIGS["tiny"]
+    cfg = CONFIGS[os.path.basename(gold).split("_")[0]]
     net = build_phoneme2mel(cfg)
     net.load_state_dict({k: torch.from_numpy(v) for k, v in synth_state_dict(cfg, 1234).items()}, strict=True)
     net = net.to(dev).train()
@@ -52,13 +54,17 @@ def check_loss_and_gradients(dev, gold=GOLD):
         mine = named[k[5:]].grad.detach().cpu().numpy()
         scale = max(1e-6, float(np.abs(ref).max()))
         err = float(np.abs(mine - ref).max()) / scale
-        assert err < 2e-4, (k, err, scale)
+        assert err < 5e-5, (k, err, scale)
         n += 1
-    assert n == (101 if gold == GOLD else 8) and len(step.flat.names) == 101   # every parameter the reference's autograd reaches
+    if gold == GOLD:
+        assert n == 101 and len(step.flat.names) == 101                # every parameter the reference's autograd reaches
+    else:
+        assert n >= 8                                                  # the other fixtures carry a sample of the gradients
     for k in g["no_grad_params"]:
         assert str(k) not in step.flat.names, k                        # left out of the optimizer: torch's grad-is-None rule
     out = train.train_forward(net, dict(x, mel=y["mel"]))
-    assert np.abs(out["mel"].detach().cpu().numpy() - g["mel_pred"]).max() < 1e-4
+    nf = g["mel_pred"].shape[1]                                        # (the wider configs keep the first frames only)
+    assert np.abs(out["mel"].detach().cpu().numpy()[:, :nf] - g["mel_pred"]).max() < 1e-4
     assert np.array_equal(out["mel_len"].cpu().numpy(), g["in_mel_len"])
 
 
@@ -103,7 +109,7 @@ def check_adamw_step(dev, reproducible=True):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("gold", [GOLD, GOLD_B1], ids=["b2_padded", "b1_zero_durations"])
+@pytest.mark.parametrize("gold", [GOLD, GOLD_B1, GOLD_SMALL, GOLD_BASE], ids=["b2_padded", "b1_zero_durations", "small", "base"])
 def test_gpu_loss_and_gradients_match_reference(gold):
     check_loss_and_gradients("cuda", gold)
 
@@ -144,7 +150,7 @@ def test_simulated_loss_kernel_matches_oracle():
         check_loss_kernel_against_oracle("cpu")
 
 
-@pytest.mark.parametrize("gold", [GOLD, GOLD_B1], ids=["b2_padded", "b1_zero_durations"])
+@pytest.mark.parametrize("gold", [GOLD, GOLD_B1, GOLD_SMALL], ids=["b2_padded", "b1_zero_durations", "small"])
 def test_simulated_loss_and_gradients_match_reference(gold):
     with use_sim():
         check_loss_and_gradients("cpu", gold)

@@ -36,7 +36,7 @@ def reference_loss(y_hat, mel, x):
 
 def main():
     outdir = os.path.join(G.ROOT, "tests", "golden")
-    for name, lens, T in (("tiny", [13, 9], 13), ("tiny", [11], 11)):
+    for name, lens, T in (("tiny", [13, 9], 13), ("tiny", [11], 11), ("small", [13, 9], 13), ("base", [13, 9], 13)):
         cfg = CONFIGS[name]
         net, sd = G.build_ref(cfg)
         net.train()
@@ -66,7 +66,7 @@ def main():
         rec = dict(in_phoneme=ph, in_phoneme_mask=m, in_pitch=pitch, in_energy=energy, in_duration=dur, in_mel_len=mel_len,
                    in_mel=mel, in_mel_mask=mel_mask, losses=np.array([float(v) for v in losses], np.float64),
                    total=np.array(float(total), np.float64), weights_crc=np.array(G.sd_crc(sd), dtype=np.uint32),
-                   mel_pred=y_hat["mel"].detach().numpy(), pitch_pred=y_hat["pitch"].detach().numpy(),
+                   mel_pred=y_hat["mel"].detach().numpy() if name == "tiny" else y_hat["mel"].detach().numpy()[:, :8], pitch_pred=y_hat["pitch"].detach().numpy(),
                    energy_pred=y_hat["energy"].detach().numpy(), duration_pred=y_hat["duration"].detach().numpy())
         names = [k for k, p in net.named_parameters() if p.requires_grad]
         nograd = [k for k, p in net.named_parameters() if p.requires_grad and p.grad is None]
@@ -74,17 +74,22 @@ def main():
                   "encoder.duration_decoder.conv1.0.weight", "encoder.pitch_decoder.pitch_embedding.weight",
                   "decoder.blocks.0.0.0.0.0.weight", "decoder.blocks.1.1.bias", "decoder.mel_linear.weight")
         for k, p in net.named_parameters():
-            if p.requires_grad and p.grad is not None and (B > 1 or k in sample):     # the B == 1 case keeps a sample (file size)
+            full = B > 1 and name == "tiny"                                          # every gradient for the headline config; a sample
+            small_ones = p.numel() <= 4096 and (k.endswith(".bias") or ".norm" in k or k.endswith("linear.weight"))   # elsewhere (file size)
+            keep = k in sample if name == "tiny" else (small_ones or k in ("decoder.mel_linear.weight", "encoder.encoder.embed.weight"))
+            if p.requires_grad and p.grad is not None and (full or keep):
                 rec["grad." + k] = p.grad.numpy().astype(np.float32)
         opt.step()
         keep_after = ("encoder.encoder.embed.weight", "decoder.mel_linear.weight", "decoder.mel_linear.bias",
                       "encoder.duration_decoder.linear.weight", "encoder.fuse.conv.weight")      # AdamW is elementwise: a sample
         for k, p in net.named_parameters():
-            if k in keep_after or k.endswith("norm1.bias"):
+            if (k in keep_after and name == "tiny") or k.endswith("norm1.bias"):
                 rec["after." + k] = p.detach().numpy().astype(np.float32)
         rec["param_names"] = np.array(names)
         rec["no_grad_params"] = np.array(nograd)
         path = os.path.join(outdir, f"{name}_train_step.npz" if B > 1 else f"{name}_train_step_b1.npz")
+        if name != "tiny":
+            rec.pop("in_mel_check", None)
         np.savez_compressed(path, **rec)
         print(path, os.path.getsize(path), "bytes; losses", rec["losses"], "total", float(total), "params without grad:", nograd)
 
