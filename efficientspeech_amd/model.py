@@ -52,8 +52,8 @@ def _stats_from(preprocess_config):
 class EfficientSpeech(nn.Module):
     """Drop-in for the object demo.py / synthesize.py hold (`model.phoneme2mel`, `model.hifigan`, `model(x)`).
 
-    Constructor arguments as `EfficientSpeech.__init__` (model.py:104-121); the training-only ones (lr, weight_decay,
-    max_epochs, wav_path) are accepted and ignored.  NOTE the reference's class default `decoder_kernel_size=3` differs from
+    Constructor arguments as `EfficientSpeech.__init__` (model.py:104-121); `lr` / `weight_decay` feed `make_train_step`,
+    `max_epochs` and `wav_path` are accepted and ignored.  NOTE the reference's class default `decoder_kernel_size=3` differs from
     its CLI default 5 that every published checkpoint uses: like the reference, the class keeps 3, callers
     (and `from_config`) pass what their checkpoint was trained with.
 
@@ -73,7 +73,7 @@ class EfficientSpeech(nn.Module):
         self.hifigan = hifigan
         self.hparams = dict(depth=depth, n_blocks=n_blocks, block_depth=block_depth, reduction=reduction, head=head,
                             embed_dim=embed_dim, kernel_size=kernel_size, decoder_kernel_size=decoder_kernel_size,
-                            expansion=expansion, infer_device=infer_device)
+                            expansion=expansion, infer_device=infer_device, lr=lr, weight_decay=weight_decay)
         if infer_device is not None:
             self.to(infer_device)
 
@@ -86,8 +86,44 @@ class EfficientSpeech(nn.Module):
                    expansion=cfg.expansion, **kw)
 
     def forward(self, x):
-        """model.py:155-156: the training dict when `self.training`, else `predict_step(x)`."""
-        return self.phoneme2mel(x, train=True) if self.training else self.predict_step(x)
+        """model.py:155-156: the training dict when `self.training`, else `predict_step(x)`.  With autograd enabled the training
+        dict comes from the differentiable operator path (efficientspeech_amd/train.py), so `loss(...)[...].backward()` works as
+        it does on the reference; under `torch.no_grad()` it is the inference kernels' teacher-forced forward."""
+        if not self.training:
+            return self.predict_step(x)
+        if torch.is_grad_enabled():
+            from . import train
+            out = train.train_forward(self.phoneme2mel, x)        # (pads to max(x["mel_len"]) with one .item(), as networks.py:344)
+            B, T = x["phoneme"].shape
+            return {"mel": out["mel"], "pitch": out["pitch"].reshape(B, T, 1), "energy": out["energy"].reshape(B, T, 1),
+                    "duration": out["duration"].reshape(B, T, 1), "mel_len": out["mel_len"]}
+        return self.phoneme2mel(x, train=True)
+
+    def loss(self, y_hat, y, x):
+        """model.py:167-209: (mel_loss, pitch_loss, energy_loss, duration_loss) of a training dict, differentiable."""
+        from . import train
+        from .networks import _mask_u8
+        B, T = x["phoneme"].shape
+        f = lambda t: t.contiguous().float()      # noqa: E731
+        v = train._Loss.apply(y_hat["mel"], y_hat["pitch"].reshape(B, T), y_hat["energy"].reshape(B, T), y_hat["duration"].reshape(B, T),
+                              f(y["mel"]), f(x["pitch"]), f(x["energy"]), x["duration"].to(torch.int32).contiguous(),
+                              _mask_u8(x["mel_mask"]), _mask_u8(x["phoneme_mask"]))
+        self._last_total = v[4]
+        return v[0], v[1], v[2], v[3]
+
+    def training_step(self, batch, batch_idx=0):
+        """model.py:212-226: the weighted total 10 mel + 2 pitch + 2 energy + duration (call `.backward()` on it)."""
+        x, y = batch
+        self.loss(self.forward(x), y, x)
+        return self._last_total                    # the fused loss kernel's own total: its backward seeds all four terms
+
+    def make_train_step(self, **kw):
+        """`configure_optimizers` + the step Lightning would drive (model.py:279-283): an `efficientspeech_amd.train.TrainStep`
+        over the acoustic model with this module's lr / weight_decay."""
+        from . import train
+        kw.setdefault("lr", self.hparams.get("lr", 1e-3))
+        kw.setdefault("weight_decay", self.hparams.get("weight_decay", 1e-6))
+        return train.TrainStep(self.phoneme2mel, **kw)
 
     def predict_step(self, batch, batch_idx=0, dataloader_idx=0):
         """model.py:159-164: (wav, mel_len, duration); wav = hifigan(mel.transpose(1, 2)).squeeze(1).  Without a vocoder the

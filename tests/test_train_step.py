@@ -258,3 +258,35 @@ def test_simulated_fit_over_the_datamodule(tmp_path):
     assert hist[0]["lr"] == 0.0 and abs(hist[1]["lr"] - 0.5e-3) < 1e-12
     assert all(np.isfinite(h["losses"]).all() for h in hist) and hist[0]["losses"][4] > 0
     assert not torch.equal(step.flat.data, before)                     # epoch 1 moved the weights (epoch 0 ran at lr 0: decay only)
+
+
+def check_wrapper_training_api(dev):
+    """The model.py-shaped wrapper: forward (training mode) -> dict, loss(y_hat, y, x) -> 4 losses, training_step -> total, as
+    the reference's LightningModule exposes them (model.py:155-226)."""
+    from efficientspeech_amd import EfficientSpeech
+    train, g, net, x, y = _setup(dev)
+    model = EfficientSpeech.from_config("tiny")
+    model.phoneme2mel.load_state_dict(net.state_dict())
+    model = model.to(dev).train()
+    y_hat = model(x)
+    assert set(y_hat) >= {"mel", "pitch", "energy", "duration", "mel_len"} and y_hat["pitch"].shape == (2, 13, 1)
+    losses = model.loss(y_hat, y, x)
+    assert np.allclose([float(v.detach()) for v in losses], g["losses"], rtol=2e-5)
+    total = model.training_step((x, y))
+    assert abs(float(total.detach()) - float(g["total"])) < 2e-5 * float(g["total"])
+    total.backward()
+    k = "decoder.mel_linear.bias"
+    got = dict(model.phoneme2mel.named_parameters())[k].grad.cpu().numpy()
+    assert np.abs(got - g["grad." + k]).max() < 5e-5 * np.abs(g["grad." + k]).max()
+    step = model.make_train_step()
+    assert step.lr == 1e-3 and step.wd == 1e-6
+
+
+@pytest.mark.gpu
+def test_gpu_wrapper_training_api():
+    check_wrapper_training_api("cuda")
+
+
+def test_simulated_wrapper_training_api():
+    with use_sim():
+        check_wrapper_training_api("cpu")
