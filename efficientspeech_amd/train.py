@@ -475,6 +475,35 @@ class TrainStep:
             self._step_dev = torch.zeros(1, dtype=torch.int32, device=dev)
             self._lr_dev = torch.full((1,), lr, dtype=torch.float32, device=dev)
 
+    # ---- checkpoint / resume (what Lightning's ModelCheckpoint keeps: weights under `state_dict`, AdamW moments and step count)
+    def state_dict(self):
+        """A Lightning-shaped checkpoint dict: {'state_dict': {'phoneme2mel.<key>': tensor}, 'optimizer_states': [...]}; the
+        weights load into the reference (`load_from_checkpoint`) and into `EfficientSpeech.load_from_checkpoint` here."""
+        f = self.flat
+        return {"state_dict": {"phoneme2mel." + k: v.detach().clone() for k, v in self.net.state_dict().items()},
+                "optimizer_states": [{"flat_names": list(f.names), "exp_avg": f.m.clone(), "exp_avg_sq": f.v.clone(), "step": self.t,
+                                      "lr": self.lr, "weight_decay": self.wd, "betas": tuple(self.betas), "eps": self.eps}]}
+
+    def load_state_dict(self, ckpt):
+        """Resume: weights into the flat buffer's views (in place), moments and step count into the optimizer."""
+        sd = {k[len("phoneme2mel."):]: v for k, v in ckpt["state_dict"].items() if k.startswith("phoneme2mel.")}
+        own = dict(self.net.state_dict())
+        missing = [k for k in own if k not in sd]
+        if missing:
+            raise RuntimeError(f"checkpoint lacks {missing[:3]} ...")
+        with torch.no_grad():
+            for k, t in own.items():
+                t.copy_(sd[k])                      # in place: parameters stay views of the flat buffer
+        o = ckpt["optimizer_states"][0]
+        if list(o["flat_names"]) != list(self.flat.names):
+            raise RuntimeError("optimizer state was saved for a different parameter list")
+        self.flat.m.copy_(o["exp_avg"])
+        self.flat.v.copy_(o["exp_avg_sq"])
+        self.t = int(o["step"])
+        if self.graph:
+            self._step_dev.fill_(self.t)
+        self._invalidate_packed()
+
     def _invalidate_packed(self):
         for m in self.net.modules():               # the kernel wrote the weights behind torch's version counters: drop the
             c = getattr(m, "_cache", None)         # inference path's packed copies so the next eval forward re-packs

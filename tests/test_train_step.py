@@ -290,3 +290,34 @@ def test_gpu_wrapper_training_api():
 def test_simulated_wrapper_training_api():
     with use_sim():
         check_wrapper_training_api("cpu")
+
+
+def check_checkpoint_resume(dev):
+    """Train 2 steps, save, resume in a fresh TrainStep, 1 more step == 3 uninterrupted steps (bitwise); the saved weights load
+    into the inference wrapper."""
+    from efficientspeech_amd import EfficientSpeech
+    train, g, net, x, y = _setup(dev)
+    a = train.TrainStep(net, lr=1e-3)
+    for _ in range(2):
+        a.step(x, y)
+    ckpt = a.state_dict()
+    last_a = a.step(x, y)
+    t2, g2, net2, x2, y2 = _setup(dev)
+    b = t2.TrainStep(net2, lr=1e-3)
+    b.load_state_dict(ckpt)
+    last_b = b.step(x2, y2)
+    assert torch.equal(last_a, last_b) and torch.equal(a.flat.data, b.flat.data) and b.t == 3
+    model = EfficientSpeech.load_from_checkpoint({"state_dict": a.state_dict()["state_dict"],
+                                                  "hyper_parameters": {"depth": 2, "reduction": 4, "decoder_kernel_size": 5}})
+    for k, v in model.phoneme2mel.state_dict().items():
+        assert torch.equal(v.cpu(), net.state_dict()[k].cpu()), k
+
+
+@pytest.mark.gpu
+def test_gpu_checkpoint_resume():
+    check_checkpoint_resume("cuda")
+
+
+def test_simulated_checkpoint_resume():
+    with use_sim():
+        check_checkpoint_resume("cpu")
