@@ -51,10 +51,31 @@ struct ConvGemmP {
     float act_in_slope;
     float a_scale;       // 0 is read as 1
     int accum;           // 1: out += value (same element, same thread: no race)
-    // training step (data-gradient GEMMs): device-side power-of-two scales, [0] multiplies the A values as they are loaded,
-    // [1] the accumulated result -- keeps tiny gradients inside the binary16 range of the split products.  NULL: 1, 1
+    // training step (data-gradient GEMMs): device pointer to max|A| (absmax_kernel).  The kernels derive the power of two s that
+    // puts it in [2^9, 2^10), multiply the A values by s as they are loaded and the accumulated result by 1/s (both exact) --
+    // keeps tiny gradients inside the binary16 range of the split products.  NULL: no scaling
     const float* io_scale;
 };
+// (s, 1/s) for a tensor whose largest magnitude has the bit pattern *absmax
+__device__ __forceinline__ void conv_pow2_scales(const float* absmax, float* s, float* inv) {
+    const int bits = __builtin_bit_cast(int, absmax[0]);
+    int e = ((bits >> 23) & 255) - 127;                  // floor(log2(absmax)) for normal numbers
+    if (bits == 0 || ((bits >> 23) & 255) == 255) e = 9; // all zero / inf / nan: no scaling
+    int k = 9 - e;
+    k = k < -100 ? -100 : (k > 100 ? 100 : k);
+    *s = __builtin_bit_cast(float, (127 + k) << 23);
+    *inv = __builtin_bit_cast(float, (127 - k) << 23);
+}
+__device__ __forceinline__ float conv_in_scale(const ConvGemmP& p) {
+    float s = 1.0f, inv = 1.0f;
+    if (p.io_scale) conv_pow2_scales(p.io_scale, &s, &inv);
+    return s;
+}
+__device__ __forceinline__ float conv_out_scale(const ConvGemmP& p) {
+    float s = 1.0f, inv = 1.0f;
+    if (p.io_scale) conv_pow2_scales(p.io_scale, &s, &inv);
+    return inv;
+}
 
 // output positions per tile row step, and 32-row tiles per phase and batch item (see convgemm_kernel)
 __host__ __device__ inline int convgemm_row_stride(const ConvGemmP& p) { return (p.mode == MODE_CONVT && p.stride > 1) ? p.stride : 1; }
@@ -82,7 +103,7 @@ __device__ __forceinline__ f32x4 conv_act_in(f32x4 v, const ConvGemmP& p, float 
 template <int NT>
 __device__ __forceinline__ void convgemm_epilogue(f32x16 (&acc)[NT], const ConvGemmP& p, int b, int t0, int n0, int lane, int ts = 1) {
     const int i = lane & 31;
-    const float out_s = (ESMI_CHAIN_SPLIT ? kF16WScaleInv : 1.0f) * (p.io_scale ? p.io_scale[1] : 1.0f);
+    const float out_s = (ESMI_CHAIN_SPLIT ? kF16WScaleInv : 1.0f) * conv_out_scale(p);
     int col[NT];
     bool cok[NT];
     float bias[NT];
@@ -158,7 +179,7 @@ __global__ __launch_bounds__(256) void convgemm_kernel(const ConvGemmP p) {
     const int i = lane & 31, h = lane >> 5;
     const int t_out = t0 + i * ts;
     const int j_first = ts > 1 ? (phase + p.pad) % ts : 0;
-    const float in_s = p.io_scale ? p.io_scale[0] : 1.0f;
+    const float in_s = conv_in_scale(p);
 
     f32x16 acc[NT];
 #pragma unroll
@@ -283,7 +304,7 @@ __global__ __launch_bounds__(256) void conv_to1_kernel(const ConvGemmP p) {
     if (q >= (long)p.B * p.n_out) return;
     const int b = (int)(q / p.n_out), t = (int)(q - (long)b * p.n_out);
     const int dil = p.dil > 0 ? p.dil : 1;
-    const float in_s = p.io_scale ? p.io_scale[0] : 1.0f;
+    const float in_s = conv_in_scale(p);
     float acc = 0.0f;
     for (int j = 0; j < p.k; ++j) {
         const int ti = t + j * dil - p.pad;
@@ -296,7 +317,7 @@ __global__ __launch_bounds__(256) void conv_to1_kernel(const ConvGemmP p) {
             for (int e = 0; e < 4; ++e) acc = fmaf(a[e], w[e], acc);
         }
     }
-    float v = apply_act(acc * (p.io_scale ? p.io_scale[1] : 1.0f) + (p.bias ? p.bias[0] : 0.0f), p.act);
+    float v = apply_act(acc * conv_out_scale(p) + (p.bias ? p.bias[0] : 0.0f), p.act);
     if (p.post_relu) v = fmaxf(v, 0.0f);
     float* o = p.out + ((long)b * p.n_out + t) * p.ldo + p.o_coff;
     *o = p.accum ? *o + v : v;
@@ -335,7 +356,7 @@ __global__ __launch_bounds__(256, 2) void convgemm_lds_kernel(const ConvGemmP p)
     const int kchunks = p.c_in >> 5, n_it = p.k * kchunks;
     f32x4 a_nxt[2][2], w_nxt[NT];
     f16x2p a_cur[2];
-    const float in_s = p.io_scale ? p.io_scale[0] : 1.0f;
+    const float in_s = conv_in_scale(p);
     auto fetch = [&](int it) __attribute__((always_inline)) {   // global -> registers: A rows of this wave, W rows of the workgroup
         const int j = it / kchunks, c = (it - j * kchunks) << 5;
         const int ti = t_out + j * (p.dil > 0 ? p.dil : 1) - p.pad;

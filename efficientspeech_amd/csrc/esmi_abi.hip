@@ -1216,24 +1216,25 @@ int train_conv_gemm(const ConvDesc& c, bool grad, const float* in, const float* 
     const long n = (long)c.k * c.c_out * c.c_in;
     // tap-major (k, cout, cin) of the problem: forward conv / grad of convT read the tensor as Conv1d, the other two as ConvTranspose1d
     const int as_convT = (grad != (c.transposed != 0)) ? 1 : 0;
-    ESMI_LAUNCH(pack_conv_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, w, wt, cout, cin, c.k, as_convT);
-    if (int rc = launch_status()) return rc;
+    int* amax = reinterpret_cast<int*>(reinterpret_cast<char*>(wt) + align256((size_t)n * sizeof(float)));
+    const float* wuse = wt;
+    if (c.k == 1 && !as_convT && !grad) {
+        wuse = w;                                   // a Linear's (Cout, Cin) IS its tap-major form: no copy
+    } else {
+        ESMI_LAUNCH(pack_conv_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, w, wt, cout, cin, c.k, as_convT, grad ? amax : nullptr);
+        if (int rc = launch_status()) return rc;
+    }
     ConvGemmP p = conv_defaults();
-    if (grad) {   // dy -> [2^9, 2^10) by a power of two chosen on the device (train_pow2_scale_kernel)
-        float* slots = reinterpret_cast<float*>(reinterpret_cast<char*>(wt) + align256((size_t)n * sizeof(float)));   // [0] absmax, [2..3] scales
-        hipError_t e = hipMemsetAsync(slots, 0, sizeof(float), st);
-        if (e != hipSuccess) return (int)e;
+    if (grad) {   // max|dy| on the device; the GEMM kernels derive the power-of-two scales from it (convgemm.h conv_pow2_scales)
         const long len = (long)c.B * c.n_out * c.c_out, blocks = (len + 256L * 8 - 1) / (256L * 8);
-        ESMI_LAUNCH(absmax_kernel, dim3((unsigned)(blocks > 1024 ? 1024 : blocks)), dim3(256), 0, st, in, len, reinterpret_cast<int*>(slots));
+        ESMI_LAUNCH(absmax_kernel, dim3((unsigned)(blocks > 1024 ? 1024 : blocks)), dim3(256), 0, st, in, len, amax);
         if (int rc = launch_status()) return rc;
-        ESMI_LAUNCH(train_pow2_scale_kernel, dim3(1), dim3(64), 0, st, slots, slots + 2);
-        if (int rc = launch_status()) return rc;
-        p.io_scale = slots + 2;
+        p.io_scale = reinterpret_cast<const float*>(amax);
     }
     p.mode = as_convT ? MODE_CONVT : MODE_CONV;
     p.k = c.k; p.stride = c.stride; p.pad = c.pad;
     p.B = c.B; p.n_in = grad ? c.n_out : c.n_in; p.n_out = grad ? c.n_in : c.n_out; p.c_in = cin; p.c_out = cout;
-    p.A = in; p.lda = cin; p.W = wt; p.bias = bias; p.out = out; p.ldo = cout;
+    p.A = in; p.lda = cin; p.W = wuse; p.bias = bias; p.out = out; p.ldo = cout;
     return launch_convgemm(p, st);
 }
 }  // namespace
@@ -1337,9 +1338,8 @@ int esmi_train_layernorm_bwd_f32(const float* x, const float* g, const float* me
         ESMI_LAUNCH(train_ln_bwd_params_kernel, dim3(grid1d(C, 64), (unsigned)chunks), dim3(64), 0, S(stream), x, mean, rstd, dy, (long)rows, C, part);
         if (int rc = launch_status()) return rc;
     }
-    ESMI_LAUNCH(train_reduce_chunks_kernel, grid1d(C, 64), dim3(64 * kReduceGroups), 64 * kReduceGroups * sizeof(float), S(stream), part, (long)C, 2L * C, chunks, dg);   // [chunk][dg | db]
-    if (int rc = launch_status()) return rc;
-    ESMI_LAUNCH(train_reduce_chunks_kernel, grid1d(C, 64), dim3(64 * kReduceGroups), 64 * kReduceGroups * sizeof(float), S(stream), part + C, (long)C, 2L * C, chunks, db);
+    ESMI_LAUNCH(train_reduce_chunks_kernel, grid1d(2L * C, 64), dim3(64 * kReduceGroups), 64 * kReduceGroups * sizeof(float), S(stream), part,
+                2L * C, 2L * C, chunks, dg, (long)C, db);   // partial rows are [dg (C) | db (C)]: one launch, two outputs
     return launch_status();
 }
 int esmi_train_act_fwd_f32(const float* x, int64_t n, int kind, float* y, esmi_stream_t stream) {
@@ -1354,6 +1354,14 @@ int esmi_train_act_bwd_f32(const float* saved, const float* dy, int64_t n, int k
 }
 int esmi_train_attention_fwd_f32(const float* qkv, int B, int N, int C, int h, float* P, float* ctx, esmi_stream_t stream) {
     if (!qkv || !P || !ctx || B <= 0 || N <= 0 || C <= 0 || h <= 0 || C % h) return ESMI_ERR_ARG;
+    const size_t lds = train_attn_lds_bytes(N, C);
+    if (lds <= 150 * 1024) {   // K and V of a head staged in LDS
+        static AttrOnce once;
+        if (lds > 48 * 1024)
+            if (int rc = raise_lds_limit(reinterpret_cast<const void*>(train_attn_fwd_lds_kernel), once)) return rc;
+        ESMI_LAUNCH(train_attn_fwd_lds_kernel, dim3((unsigned)(B * h)), dim3(256), lds, S(stream), qkv, B, N, C, h, 1.0f / sqrtf((float)(C / h)), P, ctx);
+        return launch_status();
+    }
     ESMI_LAUNCH(train_attn_fwd_kernel, dim3((unsigned)((long)B * h * N)), dim3(64), 0, S(stream), qkv, B, N, C, h, 1.0f / sqrtf((float)(C / h)), P, ctx);
     return launch_status();
 }
@@ -1361,7 +1369,15 @@ int esmi_train_attention_bwd_f32(const float* qkv, const float* P, const float* 
                                  float* dqkv, esmi_stream_t stream) {
     if (!qkv || !P || !dctx || !dS || !dqkv || B <= 0 || N <= 0 || C <= 0 || h <= 0 || C % h) return ESMI_ERR_ARG;
     const float scale = 1.0f / sqrtf((float)(C / h));
-    ESMI_LAUNCH(train_attn_bwd_rows_kernel, dim3((unsigned)((long)B * h * N)), dim3(64), 0, S(stream), qkv, P, dctx, B, N, C, h, scale, dS, dqkv);
+    const size_t lds = train_attn_lds_bytes(N, C);
+    if (lds <= 150 * 1024) {
+        static AttrOnce once;
+        if (lds > 48 * 1024)
+            if (int rc = raise_lds_limit(reinterpret_cast<const void*>(train_attn_bwd_rows_lds_kernel), once)) return rc;
+        ESMI_LAUNCH(train_attn_bwd_rows_lds_kernel, dim3((unsigned)(B * h)), dim3(256), lds, S(stream), qkv, P, dctx, B, N, C, h, scale, dS, dqkv);
+    } else {
+        ESMI_LAUNCH(train_attn_bwd_rows_kernel, dim3((unsigned)((long)B * h * N)), dim3(64), 0, S(stream), qkv, P, dctx, B, N, C, h, scale, dS, dqkv);
+    }
     if (int rc = launch_status()) return rc;
     ESMI_LAUNCH(train_attn_bwd_cols_kernel, grid1d((long)B * h * N * C), dim3(256), 0, S(stream), qkv, P, dS, dctx, B, N, C, h, scale, dqkv);
     return launch_status();

@@ -469,6 +469,91 @@ __global__ __launch_bounds__(64) void train_attn_bwd_rows_kernel(const float* __
         dq[c] = a * scale;
     }
 }
+// The same two kernels with the head's K and V staged once in LDS ([N][C + 1] each: a lane per key reads its row at an odd
+// stride, a lane per channel reads consecutive words -- both conflict-free), one 256-thread workgroup per (b, head), every wave
+// taking query rows w, w + 4, ...  Used whenever 2 N (C + 1) + 4 N floats fit (tiny / small ES at any realistic length); the
+// global-memory versions above remain for the rest.
+__host__ __device__ inline size_t train_attn_lds_bytes(int N, int C) { return ((size_t)2 * N * (C + 1) + 4 * (size_t)N) * sizeof(float); }
+__global__ __launch_bounds__(256) void train_attn_fwd_lds_kernel(const float* __restrict__ qkv, int B, int N, int C, int h, float scale,
+                                                                 float* __restrict__ P, float* __restrict__ ctx) {
+    ESMI_DYN_LDS(lds);
+    float* Ks = lds;
+    float* Vs = lds + (long)N * (C + 1);
+    float* prow = Vs + (long)N * (C + 1) + (long)wave_id() * N;      // this wave's softmax row
+    const int hd = (int)(blockIdx.x % h), b = (int)(blockIdx.x / h), lane = lane_id(), w = wave_id();
+    const long ld = 3L * h * C;
+    for (int e = (int)threadIdx.x; e < N * C; e += 256) {
+        const int j = e / C, c = e - j * C;
+        Ks[j * (C + 1) + c] = qkv[((long)b * N + j) * ld + (long)(h + hd) * C + c];
+        Vs[j * (C + 1) + c] = qkv[((long)b * N + j) * ld + (long)(2 * h + hd) * C + c];
+    }
+    __syncthreads();
+    for (int i = w; i < N; i += 4) {
+        const float* qi = qkv + ((long)b * N + i) * ld + (long)hd * C;
+        float* p = P + (((long)b * h + hd) * N + i) * N;
+        float mx = -3.0e38f;
+        for (int j = lane; j < N; j += 64) {
+            float s = 0.0f;
+            for (int c = 0; c < C; ++c) s = fmaf(qi[c], Ks[j * (C + 1) + c], s);
+            s *= scale;
+            prow[j] = s;
+            mx = fmaxf(mx, s);
+        }
+        mx = wave_allreduce_max(mx);
+        float sum = 0.0f;
+        for (int j = lane; j < N; j += 64) { const float e = expf(prow[j] - mx); prow[j] = e; sum += e; }
+        sum = wave_allreduce_sum(sum);
+        const float inv = 1.0f / sum;
+        for (int j = lane; j < N; j += 64) { const float v = prow[j] * inv; prow[j] = v; p[j] = v; }
+        lds_wave_sync();                               // the row is read back by other lanes of this wave
+        float* o = ctx + ((long)b * N + i) * h * C + (long)hd * C;
+        for (int c = lane; c < C; c += 64) {
+            float a = 0.0f;
+            for (int j = 0; j < N; ++j) a = fmaf(prow[j], Vs[j * (C + 1) + c], a);
+            o[c] = a;
+        }
+        lds_wave_sync();                               // before the next row overwrites prow
+    }
+}
+__global__ __launch_bounds__(256) void train_attn_bwd_rows_lds_kernel(const float* __restrict__ qkv, const float* __restrict__ P,
+                                                                      const float* __restrict__ dctx, int B, int N, int C, int h,
+                                                                      float scale, float* __restrict__ dS, float* __restrict__ dqkv) {
+    ESMI_DYN_LDS(lds);
+    float* Ks = lds;
+    float* Vs = lds + (long)N * (C + 1);
+    float* drow = Vs + (long)N * (C + 1) + (long)wave_id() * N;
+    const int hd = (int)(blockIdx.x % h), b = (int)(blockIdx.x / h), lane = lane_id(), w = wave_id();
+    const long ld = 3L * h * C;
+    for (int e = (int)threadIdx.x; e < N * C; e += 256) {
+        const int j = e / C, c = e - j * C;
+        Ks[j * (C + 1) + c] = qkv[((long)b * N + j) * ld + (long)(h + hd) * C + c];
+        Vs[j * (C + 1) + c] = qkv[((long)b * N + j) * ld + (long)(2 * h + hd) * C + c];
+    }
+    __syncthreads();
+    for (int i = w; i < N; i += 4) {
+        const float* p = P + (((long)b * h + hd) * N + i) * N;
+        float* ds = dS + (((long)b * h + hd) * N + i) * N;
+        const float* go = dctx + ((long)b * N + i) * h * C + (long)hd * C;
+        float dot = 0.0f;
+        for (int j = lane; j < N; j += 64) {
+            float a = 0.0f;
+            for (int c = 0; c < C; ++c) a = fmaf(go[c], Vs[j * (C + 1) + c], a);
+            drow[j] = a;
+            dot = fmaf(p[j], a, dot);
+        }
+        dot = wave_allreduce_sum(dot);
+        for (int j = lane; j < N; j += 64) { const float v = p[j] * (drow[j] - dot); drow[j] = v; ds[j] = v; }
+        lds_wave_sync();
+        float* dq = dqkv + ((long)b * N + i) * ld + (long)hd * C;
+        for (int c = lane; c < C; c += 64) {
+            float a = 0.0f;
+            for (int j = 0; j < N; ++j) a = fmaf(drow[j], Ks[j * (C + 1) + c], a);
+            dq[c] = a * scale;
+        }
+        lds_wave_sync();
+    }
+}
+
 // column j, channel c: dk_j = scale dS^T Q, dv_j = P^T dctx   (one thread per (b, head, j, c))
 __global__ void train_attn_bwd_cols_kernel(const float* __restrict__ qkv, const float* __restrict__ P, const float* __restrict__ dS,
                                            const float* __restrict__ dctx, int B, int N, int C, int h, float scale,
@@ -651,20 +736,6 @@ __global__ void train_adamw_kernel(float* __restrict__ p, const float* __restric
     const float denom = sqrtf(vv) / bc2_sqrt + eps;
     w -= (lr / bc1) * (mm / denom);
     p[q] = w;
-}
-
-// power-of-two scales that bring a tensor's largest magnitude to [2^9, 2^10): sc[0] = s, sc[1] = 1 / s (exact); the data-gradient
-// GEMMs multiply dy by s as they load it and the result by 1 / s, so gradients of any magnitude sit in the middle of the
-// binary16 range of the split products (a 1e-7 gradient would otherwise be a zero-bit f16 subnormal)
-__global__ void train_pow2_scale_kernel(const float* __restrict__ absmax, float* __restrict__ sc) {
-    if (threadIdx.x != 0) return;
-    const int bits = __builtin_bit_cast(int, absmax[0]);
-    int e = ((bits >> 23) & 255) - 127;                  // floor(log2(absmax)) for normal numbers
-    if (bits == 0 || ((bits >> 23) & 255) == 255) e = 9; // all zero / inf / nan: no scaling
-    int k = 9 - e;
-    k = k < -100 ? -100 : (k > 100 ? 100 : k);
-    sc[0] = __builtin_bit_cast(float, (127 + k) << 23);
-    sc[1] = __builtin_bit_cast(float, (127 - k) << 23);
 }
 
 // the same with the step count and the learning rate read from device memory, so that a captured hipGraph of the whole
