@@ -100,16 +100,17 @@ class EfficientSpeech(nn.Module):
         return self.phoneme2mel(x, train=True)
 
     def loss(self, y_hat, y, x):
-        """model.py:167-209: (mel_loss, pitch_loss, energy_loss, duration_loss) of a training dict, differentiable."""
+        """model.py:167-209: (mel_loss, pitch_loss, energy_loss, duration_loss) of a training dict.  The four values are for reporting;
+        `training_step` returns the differentiable weighted total the fused loss kernel computed alongside them."""
         from . import train
         from .networks import _mask_u8
         B, T = x["phoneme"].shape
         f = lambda t: t.contiguous().float()      # noqa: E731
-        v = train._Loss.apply(y_hat["mel"], y_hat["pitch"].reshape(B, T), y_hat["energy"].reshape(B, T), y_hat["duration"].reshape(B, T),
-                              f(y["mel"]), f(x["pitch"]), f(x["energy"]), x["duration"].to(torch.int32).contiguous(),
-                              _mask_u8(x["mel_mask"]), _mask_u8(x["phoneme_mask"]))
-        self._last_total = v[4]
-        return v[0], v[1], v[2], v[3]
+        parts, total = train._Loss.apply(y_hat["mel"], y_hat["pitch"].reshape(B, T), y_hat["energy"].reshape(B, T),
+                                         y_hat["duration"].reshape(B, T), f(y["mel"]), f(x["pitch"]), f(x["energy"]),
+                                         x["duration"].to(torch.int32).contiguous(), _mask_u8(x["mel_mask"]), _mask_u8(x["phoneme_mask"]))
+        self._last_total = total                   # the differentiable weighted sum; the four parts are reported values
+        return parts[0], parts[1], parts[2], parts[3]
 
     def training_step(self, batch, batch_idx=0):
         """model.py:212-226: the weighted total 10 mel + 2 pitch + 2 energy + duration (call `.backward()` on it)."""

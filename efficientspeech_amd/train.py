@@ -257,8 +257,9 @@ class _Repeat(torch.autograd.Function):
 
 
 class _Loss(torch.autograd.Function):
-    """model.py:167-216.  Returns the 5-vector (mel L1, pitch MSE, energy MSE, log-duration MSE, weighted total); backward
-    seeds d total / d prediction (the seed of element 4 must be 1, as `loss.backward()` gives it)."""
+    """model.py:167-216.  Returns (parts, total): the four means (mel L1, pitch MSE, energy MSE, log-duration MSE; reported, not
+    differentiable -- the reference's `loss()` values are only ever logged) and the weighted total, whose backward hands the
+    kernel's gradient seeds d total / d prediction to the four predictions, scaled by the incoming seed."""
 
     @staticmethod
     def forward(ctx, mel_pred, pitch_pred, energy_pred, dur_pred, mel, pitch, energy, dur, mel_mask, ph_mask):
@@ -274,11 +275,18 @@ class _Loss(torch.autograd.Function):
                                *[_ptr(g) for g in grads], _ptr(scratch))
         lib.esmi_train_loss_f32(C.byref(a), st)
         ctx.save_for_backward(*grads)
-        return out
+        parts, total = out[:4], out[4]
+        ctx.mark_non_differentiable(parts)
+        return parts, total
 
     @staticmethod
-    def backward(ctx, dout):
-        return tuple(ctx.saved_tensors) + (None,) * 6
+    def backward(ctx, _dparts, dtotal):
+        return tuple(g * dtotal for g in ctx.saved_tensors) + (None,) * 6     # (seed 1 from `.backward()`: four scalings, exact)
+
+
+def loss_vector(parts, total):
+    """The 5-vector (mel, pitch, energy, duration, total) for reporting."""
+    return torch.cat([parts.detach(), total.detach().reshape(1)])
 
 
 def conv(x, m, n_out=None):
@@ -410,7 +418,8 @@ def train_forward(net, x):
 
 
 def training_loss(net, x, y):
-    """training_step's forward + loss (model.py:212-216): returns the 5-vector (mel, pitch, energy, duration, total)."""
+    """training_step's forward + loss (model.py:212-216): returns (parts, total) -- the four reported means and the differentiable
+    weighted total 10 mel + 2 pitch + 2 energy + duration."""
     xx = dict(x)
     xx.setdefault("mel", y["mel"])
     out = train_forward(net, xx)
@@ -513,8 +522,9 @@ class TrainStep:
     def _body(self, x, y, lr, graph):
         f = self.flat
         f.zero_grad()
-        losses = training_loss(self.net, x, y)
-        losses[4].backward()                       # gradients accumulate straight into the flat buffer's views
+        parts, total = training_loss(self.net, x, y)
+        total.backward()                           # gradients accumulate straight into the flat buffer's views
+        losses = loss_vector(parts, total)
         if self.world > 1:
             import torch.distributed as dist
             dist.all_reduce(f.grad, op=dist.ReduceOp.SUM, group=self.group)
@@ -526,7 +536,7 @@ class TrainStep:
         else:
             lib.esmi_train_adamw_f32(_ptr(f.data), _ptr(f.grad), _ptr(f.m), _ptr(f.v), f.data.numel(), lr, self.betas[0],
                                      self.betas[1], self.eps, self.wd, self.t, st)
-        return losses.detach()
+        return losses
 
     def step(self, x, y, lr=None):
         self.t += 1

@@ -133,7 +133,8 @@ def test_loss_and_adamw_against_torch():
     d_ = torch.randint(0, 9, (B, T), generator=torch.Generator().manual_seed(3)).to(DEV).to(torch.int32)
     mm = (torch.arange(L)[None, :] >= torch.tensor([300, 250, 17, 299, 1])[:, None]).to(DEV)
     pm = (torch.arange(T)[None, :] >= torch.tensor([40, 33, 2, 39, 1])[:, None]).to(DEV)
-    got = train._Loss.apply(mel_p, pp, ep, dp, mel, p_, e_, d_, mm.view(torch.uint8), pm.view(torch.uint8))
+    parts, tot = train._Loss.apply(mel_p, pp, ep, dp, mel, p_, e_, d_, mm.view(torch.uint8), pm.view(torch.uint8))
+    got = list(parts) + [tot]
     sel, ps = ~mm[..., None], ~pm
     ref = [F.l1_loss(mel_p.masked_select(sel), mel.masked_select(sel)), F.mse_loss(pp.masked_select(ps), p_.masked_select(ps)),
            F.mse_loss(ep.masked_select(ps), e_.masked_select(ps)),

@@ -40,9 +40,9 @@ def check_loss_and_gradients(dev, gold=GOLD):
     train, g, net, x, y = _setup(dev, gold)
     step = train.TrainStep(net)
     step.flat.zero_grad()
-    losses = train.training_loss(net, x, y)
-    losses[4].backward()
-    got = losses.detach().cpu().numpy().astype(np.float64)
+    parts, total = train.training_loss(net, x, y)
+    total.backward()
+    got = train.loss_vector(parts, total).cpu().numpy().astype(np.float64)
     assert np.allclose(got[:4], g["losses"], rtol=2e-5, atol=1e-6), (got, g["losses"])
     assert abs(got[4] - float(g["total"])) < 2e-5 * abs(float(g["total"]))
     named = dict(net.named_parameters())
@@ -76,13 +76,14 @@ def check_loss_kernel_against_oracle(dev):
     B, T = g["in_pitch"].shape
     preds = [t("mel_pred").requires_grad_(), t("pitch_pred").reshape(B, T).requires_grad_(), t("energy_pred").reshape(B, T).requires_grad_(),
              t("duration_pred").reshape(B, T).requires_grad_()]
-    out = train._Loss.apply(*preds, y["mel"], x["pitch"], x["energy"], x["duration"].to(torch.int32), x["mel_mask"].view(torch.uint8),
-                            x["phoneme_mask"].view(torch.uint8))
+    parts, total = train._Loss.apply(*preds, y["mel"], x["pitch"], x["energy"], x["duration"].to(torch.int32),
+                                     x["mel_mask"].view(torch.uint8), x["phoneme_mask"].view(torch.uint8))
+    out = train.loss_vector(parts, total)
     ref, rg = oracle.training_loss(g["mel_pred"], g["in_mel"], g["in_mel_mask"], g["pitch_pred"], g["in_pitch"], g["energy_pred"],
                                    g["in_energy"], g["duration_pred"], g["in_duration"], g["in_phoneme_mask"])
-    assert np.allclose(out.detach().cpu().numpy(), ref, rtol=2e-6)
-    for a, r in zip(torch.autograd.grad(out[4], preds), rg):
-        assert np.allclose(a.cpu().numpy(), r.reshape(a.shape), rtol=1e-5, atol=1e-9)
+    assert np.allclose(out.cpu().numpy(), ref, rtol=2e-6)
+    for a, r in zip(torch.autograd.grad(0.5 * total, preds), rg):        # a seed other than 1 scales the gradients
+        assert np.allclose(a.cpu().numpy(), 0.5 * r.reshape(a.shape), rtol=1e-5, atol=1e-9)
 
 
 def check_adamw_step(dev, reproducible=True):
