@@ -9,7 +9,7 @@ import torch.nn.functional as F
 
 from efficientspeech_amd import train
 
-pytestmark = pytest.mark.gpu
+gpu = pytest.mark.gpu
 DEV = "cuda"
 
 
@@ -38,6 +38,7 @@ CONVS = [  # (c_in, c_out, k, stride, pad, groups, transposed, B, n)
 ]
 
 
+@gpu
 @pytest.mark.parametrize("cfg", CONVS, ids=[f"cin{c[0]}_cout{c[1]}_k{c[2]}_s{c[3]}_g{c[5]}_{'T' if c[6] else 'C'}" for c in CONVS])
 @pytest.mark.parametrize("matrix_pipe", [True, False])
 def test_conv_forward_and_gradients(cfg, matrix_pipe, monkeypatch):
@@ -64,6 +65,7 @@ def test_conv_forward_and_gradients(cfg, matrix_pipe, monkeypatch):
     _close(gb, rb, 5e-5, "bias grad")
 
 
+@gpu
 @pytest.mark.parametrize("rows,C", [(5000, 128), (300, 32), (77, 64)])
 def test_layernorm(rows, C):
     x = _rand(rows, C, seed=1, scale=3.0).requires_grad_()
@@ -75,6 +77,7 @@ def test_layernorm(rows, C):
         _close(a, r, 5e-5, what)
 
 
+@gpu
 @pytest.mark.parametrize("kind,fn", [(train.ACT_RELU, F.relu), (train.ACT_GELU, F.gelu), (train.ACT_TANH, torch.tanh)])
 def test_activations(kind, fn):
     x = _rand(3, 1000, 64, seed=5, scale=2.0).requires_grad_()
@@ -84,6 +87,7 @@ def test_activations(kind, fn):
     _close(torch.autograd.grad(got, x, dy)[0], torch.autograd.grad(ref, x, dy)[0], 1e-5, "backward")
 
 
+@gpu
 @pytest.mark.parametrize("B,N,C,h", [(3, 128, 32, 1), (2, 70, 64, 2), (2, 33, 128, 4)])
 def test_attention_core(B, N, C, h):
     qkv = _rand(B, N, 3 * h * C, seed=7, scale=0.5).requires_grad_()
@@ -96,6 +100,7 @@ def test_attention_core(B, N, C, h):
     _close(torch.autograd.grad(got, qkv, dy)[0], torch.autograd.grad(ref, qkv, dy)[0], 5e-5, "backward")
 
 
+@gpu
 def test_embedding_repeat_cat_mask_add():
     table = _rand(153, 128, seed=9).requires_grad_()
     ids = torch.randint(0, 153, (6, 200), generator=torch.Generator().manual_seed(1)).to(DEV)
@@ -124,6 +129,7 @@ def test_embedding_repeat_cat_mask_add():
         assert torch.equal(x_, y_)
 
 
+@gpu
 def test_loss_and_adamw_against_torch():
     B, T, L, nm = 5, 40, 300, 80
     mel_p, mel = _rand(B, L, nm, seed=1).requires_grad_(), _rand(B, L, nm, seed=2)
@@ -141,8 +147,8 @@ def test_loss_and_adamw_against_torch():
            F.mse_loss(torch.log(dp.masked_select(ps) + 1), torch.log(d_.masked_select(ps).float() + 1))]
     total = 10 * ref[0] + 2 * ref[1] + 2 * ref[2] + ref[3]
     for a, r in zip(got[:4], ref):
-        assert abs(float(a) - float(r)) < 2e-5 * abs(float(r))
-    assert abs(float(got[4]) - float(total)) < 2e-5 * abs(float(total))
+        assert abs(float(a.detach()) - float(r.detach())) < 2e-5 * abs(float(r.detach()))
+    assert abs(float(got[4].detach()) - float(total.detach())) < 2e-5 * abs(float(total.detach()))
     for a, r, what in zip(torch.autograd.grad(got[4], (mel_p, pp, ep, dp)), torch.autograd.grad(total, (mel_p, pp, ep, dp)),
                           ("d mel", "d pitch", "d energy", "d duration")):
         _close(a, r, 2e-5, what)
@@ -163,6 +169,7 @@ def test_loss_and_adamw_against_torch():
     assert float((p - ref_p.detach()).abs().max()) < 2e-6
 
 
+@gpu
 @pytest.mark.parametrize("name", ["small", "base"])
 def test_training_runs_on_the_wider_configs(name):
     """small (3 blocks, reduction 2) and base (2 / 4 heads, expansion 2, k = 5, depth 3): the loss falls and stays finite."""
@@ -178,3 +185,37 @@ def test_training_runs_on_the_wider_configs(name):
     for _ in range(8):
         last = float(step.step(x, y)[4])
     assert np.isfinite(last) and last < first, (first, last)
+
+
+# ---------------------------------------------------------------------- the same operator checks on the CPU wave simulator
+# (small shapes: a fiber per GPU thread), so the GPU-less tier also pins every training kernel to PyTorch's own op
+SIM_CONVS = [(32, 32, 3, 1, 1, 1, False, 2, 37), (32, 64, 3, 2, 1, 1, False, 2, 19), (64, 32, 3, 2, 0, 1, True, 2, 9),
+             (32, 32, 5, 1, 2, 32, False, 2, 300), (32, 1, 1, 1, 0, 1, False, 2, 21), (40, 24, 3, 1, 1, 1, False, 1, 11),
+             (128, 80, 1, 1, 0, 1, False, 1, 300)]
+
+
+def _sim_case(fn):
+    """Run a GPU-marked check body on host tensors through the simulator build."""
+    import tests.test_train_ops as me
+    from tests.simlib import use_sim
+    old = me.DEV
+    me.DEV = "cpu"
+    try:
+        with use_sim():
+            fn()
+    finally:
+        me.DEV = old
+
+
+_nogpu = pytest.mark.filterwarnings("ignore")
+
+
+@pytest.mark.parametrize("cfg", SIM_CONVS, ids=[f"cin{c[0]}_cout{c[1]}_k{c[2]}_s{c[3]}_g{c[5]}_{'T' if c[6] else 'C'}" for c in SIM_CONVS])
+def test_simulated_conv_forward_and_gradients(cfg, monkeypatch):
+    _sim_case(lambda: test_conv_forward_and_gradients(cfg, True, monkeypatch))
+
+
+def test_simulated_layernorm_attention_loss():
+    _sim_case(lambda: (test_layernorm(300, 32), test_layernorm(77, 64),
+                       test_attention_core(2, 33, 32, 2), test_activations(train.ACT_GELU, F.gelu),
+                       test_embedding_repeat_cat_mask_add(), test_loss_and_adamw_against_torch()))
