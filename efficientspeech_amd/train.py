@@ -19,6 +19,7 @@ from .networks import _ptr, _mask_u8
 
 ACT_RELU, ACT_GELU, ACT_TANH = 1, 2, 3
 USE_MATRIX_PIPE = True    # dense convolutions (forward and data gradient) through the implicit-GEMM kernels; False: plain fp32 kernels
+USE_MATRIX_PIPE_DGRAD = True   # (development) False: only the forward GEMMs on the matrix pipe
 
 
 def _rt(t):
@@ -56,7 +57,7 @@ class _Conv(torch.autograd.Function):
         lib, st = _rt(dy)
         d = ctx.d
         dx = torch.empty_like(x)
-        nws = lib.esmi_train_conv_workspace_bytes(C.byref(d)) if USE_MATRIX_PIPE else 0
+        nws = lib.esmi_train_conv_workspace_bytes(C.byref(d)) if (USE_MATRIX_PIPE and USE_MATRIX_PIPE_DGRAD) else 0
         ws = _new((nws,), w, torch.uint8) if nws else None
         lib.esmi_train_conv_dgrad_f32(C.byref(d), _ptr(dy), _ptr(w), _ptr(dx), _ptr(ws), nws, st)
         dw = torch.empty_like(w)
