@@ -15,6 +15,7 @@ Prints ONE JSON line (rank 0):
   decoder_only           (N=1) MelDecoder.forward alone on frame-rate features ~ N(0,1)
   allgather              (N>1) the mel all-gather timed by itself: GB/s received per rank vs 7 xGMI links x 76.8 GB/s
   without_allgather      (N>1) the same sharded steps with the exchange switched off (compute scaling next to the link-bound value)
+  pytorch_rocm_ops       (N=1) the same forward written with stock PyTorch-ROCm operators, same inputs / weights / GPU
   b1_fox_gpu             (N=1) single-utterance latency of the forward (BASELINE configs[0] shape) with a sync per call
   vocoder                (N=1) the HiFi-GAN v2 generator on the mel the forward produced: mel-frames/s, TFLOP/s
   train_step             the training step (BASELINE configs[4]): ms/step at the reference's batch size per GPU
@@ -374,6 +375,32 @@ def main():
                                  "frac_of_157.3": ach32 / FP32_PEAK_TFLOPS, "build_config": cfg32,
                                  "library": "efficientspeech_amd/libesmi_fp32mfma.so"}
             del net32, pipe32
+        # ---- the same forward written with stock PyTorch-ROCm operators (tests/torch_mirror.py: MIOpen / hipBLASLt convolutions,
+        # torch softmax / layer_norm / repeat_interleave -- the reference's structure incl. its per-utterance upsampling loop), on
+        # the same inputs and weights: what `--infer-device cuda` of the reference costs on this GPU, next to the CPU baseline
+        try:
+            from tests import torch_mirror as _mirror
+            with torch.no_grad():
+                m_mel = _mirror.eval_forward(net, x)[0]
+                h_mel = net(x)[0]
+                per_utt = (m_mel - h_mel).abs().amax(dim=(1, 2))
+                n_flip = int((per_utt > 1e-3).sum())         # a predicted pitch / energy within 1e-7 of a bucket edge lands in the other
+                diff = float(per_utt[per_utt <= 1e-3].max()) if n_flip < per_utt.numel() else float("nan")   # bucket: a discrete flip
+                for _ in range(2):
+                    _mirror.eval_forward(net, x)
+                torch.cuda.synchronize(dev)
+                t0 = time.perf_counter()
+                n_m = 5
+                for _ in range(n_m):
+                    _mirror.eval_forward(net, x)
+                torch.cuda.synchronize(dev)
+                tm = (time.perf_counter() - t0) / n_m
+            out["pytorch_rocm_ops"] = {"ms_per_step": tm * 1e3, "value": B * L / tm, "speedup_of_this_path": tm / (dt / a.steps),
+                                       "max_abs_diff_vs_this_path": diff, "utterances_with_a_bucket_edge_flip": n_flip, "steps": n_m,
+                                       "note": "same weights, same batch, same GPU; stock PyTorch-ROCm ops (tests/torch_mirror.py)"}
+            del m_mel, h_mel
+        except Exception as e:                     # noqa: BLE001
+            out["pytorch_rocm_ops"] = {"error": repr(e)}
         # ---- BASELINE configs[0] shape on the GPU: one utterance (the 31-phoneme fox sentence), predicted durations replaced by
         # D-const (random-init predictors give 0), synchronous calls: what demo.py's loop sees per sentence
         fox = torch.tensor([FOX_IDS], dtype=torch.int32, device=dev)

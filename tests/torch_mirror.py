@@ -36,8 +36,10 @@ def _predictor(dec, fused):
     return (F.relu(pred), _ln(y, dec.norm2)) if dec.duration else (pred, None)
 
 
-def train_forward(net, x):
+def train_forward(net, x, stop_after_predictors=False, fused=None, preds=None):
     pe, dec = net.encoder, net.decoder
+    if fused is not None:
+        return _after_encoder(net, x, fused, preds["pitch"], preds["energy"], preds["duration"], preds["dur_feat"])
     phoneme = x["phoneme"].long()
     B, T = phoneme.shape
     mask = x["phoneme_mask"] if B > 1 else None
@@ -71,6 +73,15 @@ def train_forward(net, x):
     pitch_pred, _ = _predictor(pe.pitch_decoder, fused)
     energy_pred, _ = _predictor(pe.energy_decoder, fused)
     dur_pred, dur_feat = _predictor(pe.duration_decoder, fused)
+    if stop_after_predictors:
+        return {"pitch": pitch_pred, "energy": energy_pred, "duration": dur_pred, "dur_feat": dur_feat, "fused": fused}
+    return _after_encoder(net, x, fused, pitch_pred, energy_pred, dur_pred, dur_feat)
+
+
+def _after_encoder(net, x, fused, pitch_pred, energy_pred, dur_pred, dur_feat):
+    pe, dec = net.encoder, net.decoder
+    B, T = x["phoneme"].shape
+    mask = x["phoneme_mask"] if B > 1 else None
     pf = F.embedding(torch.bucketize(x["pitch"], pe.pitch_decoder.pitch_bins), pe.pitch_decoder.pitch_embedding.weight)
     ef = F.embedding(torch.bucketize(x["energy"], pe.energy_decoder.energy_bins), pe.energy_decoder.energy_embedding.weight)
     if mask is not None:
@@ -96,6 +107,26 @@ def train_forward(net, x):
     if mask is not None:
         mel = mel.masked_fill((torch.arange(L, device=mel.device)[None, :] >= mel_len[:, None])[..., None], 0)
     return {"mel": mel, "pitch": pitch_pred, "energy": energy_pred, "duration": dur_pred, "mel_len": mel_len}
+
+
+def eval_forward(net, x):
+    """Phoneme2Mel.forward(x, train=False) with the durations given (`duration_forced`, as the benchmark injects them): predicted
+    pitch / energy are bucketised (networks.py:128-149 without targets), padding to the batch's longest utterance."""
+    pe = net.encoder
+    B, T = x["phoneme"].shape
+    xx = dict(x)
+    with torch.no_grad():
+        # run the encoder side once to get the predictions, then reuse train_forward's data flow with them as "targets"
+        dur = x["duration_forced"].long()
+        if B > 1:
+            dur = dur.masked_fill(x["phoneme_mask"], 0)
+        L = int(dur.sum(1).max())
+        xx.update(duration=dur, mel=torch.empty((B, L, 0), device=dur.device))
+        probe = dict(xx, pitch=torch.zeros((B, T), device=dur.device), energy=torch.zeros((B, T), device=dur.device))
+        first = train_forward(net, probe, stop_after_predictors=True)
+        xx.update(pitch=first["pitch"].reshape(B, T), energy=first["energy"].reshape(B, T))
+        out = train_forward(net, xx, fused=first["fused"], preds=first)
+    return out["mel"], out["mel_len"], out["duration"]
 
 
 def loss(out, x, y):
