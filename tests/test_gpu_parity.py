@@ -596,3 +596,20 @@ def test_hifigan_one_launch_resblocks_match_conv_by_conv(config, B, L):
     assert outs[0].shape == (B, 1, L * h.hop) and bool(torch.isfinite(outs[0]).all())
     assert float((outs[0] - outs[1]).abs().max()) < 2e-5
     assert float(outs[0].abs().max()) > 1e-3      # a real signal, not zeros
+
+
+def test_hip_forward_matches_stock_pytorch_ops_on_the_gpu():
+    """The HIP path against the same forward written with stock PyTorch-ROCm operators (tests/torch_mirror.py, what bench.py
+    reports as `pytorch_rocm_ops`) on the same device: a second, independent implementation next to the C oracle."""
+    from tests import torch_mirror as M
+    net, cfg, sd = H.make_net("tiny", DEV)
+    ids, mask = synth_phonemes(16, 128, 1234)
+    x = {"phoneme": torch.from_numpy(ids).to(DEV), "phoneme_mask": torch.from_numpy(mask).to(DEV),
+         "duration_forced": torch.full((16, 128), 6, dtype=torch.int32, device=DEV)}
+    with torch.no_grad():
+        mel, mel_len, _ = net(x)
+        ref, ref_len, _ = M.eval_forward(net, x)
+    assert torch.equal(mel_len.long().cpu(), ref_len.long().cpu())
+    per_utt = (mel - ref).abs().amax(dim=(1, 2))
+    assert int((per_utt > 1e-4).sum()) <= 1          # (a pitch / energy prediction on a bucket edge may flip one utterance's embedding)
+    assert float(per_utt.median()) < 2e-5

@@ -158,3 +158,23 @@ def test_oracle_training_loss_and_adamw_match_reference_fixture():
             assert np.abs(p1 - g[k]).max() < 1e-7, name
             n += 1
     assert n >= 5
+
+
+def test_torch_mirror_eval_forward_matches_oracle():
+    """tests/torch_mirror.py (the stock-PyTorch restatement bench.py times as `pytorch_rocm_ops`) against the C oracle: eval flow
+    with injected durations, padded batch."""
+    import torch
+    from efficientspeech_amd import build_phoneme2mel
+    from efficientspeech_amd.synth import synth_state_dict, synth_phonemes
+    from tests import torch_mirror as M
+    for name in ("tiny", "small"):
+        cfg = CONFIGS[name]
+        sd = synth_state_dict(cfg, 1234)
+        net = build_phoneme2mel(cfg)
+        net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+        ids, mask = synth_phonemes(3, 21, 5, [21, 13, 7])
+        dur = np.full((3, 21), 4, np.int32)
+        mel, mel_len, _ = M.eval_forward(net, {"phoneme": torch.from_numpy(ids), "phoneme_mask": torch.from_numpy(mask),
+                                               "duration_forced": torch.from_numpy(dur)})
+        o = oracle.phoneme2mel(cfg, oracle.Weights(sd), ids, mask, pitch=None, energy=None, duration=dur)
+        assert np.array_equal(mel_len.numpy(), o.mel_len) and np.abs(mel.numpy() - o.mel).max() < 2e-5
