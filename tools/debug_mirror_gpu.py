@@ -1,3 +1,5 @@
+#!/usr/bin/env python3
+"""Development: the HIP forward vs tests/torch_mirror.py (GPU and CPU) per utterance at three batch sizes -- finds bucket-edge flips."""
 import sys; sys.path.insert(0, "/root/repo")
 import numpy as np, torch
 from efficientspeech_amd import CONFIGS, build_phoneme2mel
