@@ -1193,7 +1193,12 @@ int conv_desc_ok(const esmi_conv_desc* d, ConvDesc* o) {
 namespace {
 inline bool wgrad_depthwise(const ConvDesc& c) { return !c.transposed && c.groups == c.c_in && c.c_in == c.c_out && c.k <= 8; }
 inline bool wgrad_on_mfma(const ConvDesc& c);
-inline int wgrad_chunk(const ConvDesc& c) { return wgrad_on_mfma(c) ? kTrainChunkMfma : (wgrad_depthwise(c) ? kTrainChunkDw : kTrainChunk); }
+inline int wgrad_chunk(const ConvDesc& c) {   // rows per partial sum: fewer for small weights, whose parallelism must come from the chunks
+    if (wgrad_on_mfma(c)) return kTrainChunkMfma;
+    if (wgrad_depthwise(c)) return kTrainChunkDw;
+    const long nw = (long)(c.transposed ? c.c_in * c.c_out : c.c_out * (c.c_in / c.groups)) * c.k;
+    return nw < 1024 ? 32 : kTrainChunk;
+}
 inline bool wgrad_on_mfma(const ConvDesc& c) { return c.groups == 1 && c.c_in >= 8 && c.c_out >= 8 && (c.c_out & 3) == 0; }
 }
 // Dense convolutions (groups == 1) of the training step run on the matrix pipe through the inference path's implicit GEMM
@@ -1300,9 +1305,9 @@ int esmi_train_conv_wgrad_f32(const esmi_conv_desc* d, const float* x, const flo
         ESMI_LAUNCH(train_conv_wgrad_dw_kernel, dim3(grid1d(c.c_out, 64), (unsigned)chunks), dim3(64), 0, S(stream), c, x, dy, part,
                     dbias ? pb : nullptr, ps);
     } else {
-        ESMI_LAUNCH(train_conv_wgrad_kernel, dim3(grid1d(nw, 64), (unsigned)chunks), dim3(64), 0, S(stream), c, x, dy, part, ps);
+        ESMI_LAUNCH(train_conv_wgrad_kernel, dim3(grid1d(nw, 64), (unsigned)chunks), dim3(64), 0, S(stream), c, x, dy, part, ps, wgrad_chunk(c));
         if (int rc = launch_status()) return rc;
-        if (dbias) ESMI_LAUNCH(train_colsum_kernel, dim3(grid1d(c.c_out, 64), (unsigned)chunks), dim3(64), 0, S(stream), dy, rows, c.c_out, pb, ps);
+        if (dbias) ESMI_LAUNCH(train_colsum_kernel, dim3(grid1d(c.c_out, 64), (unsigned)chunks), dim3(64), 0, S(stream), dy, rows, c.c_out, pb, ps, wgrad_chunk(c));
     }
     if (int rc = launch_status()) return rc;
     // weight and bias partials in ONE reduction launch: elements >= nw of a partial row are the bias sums

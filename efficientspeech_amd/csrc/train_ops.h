@@ -117,7 +117,7 @@ __host__ __device__ inline long train_chunks(long rows, int chunk = kTrainChunk)
 
 // dw(co, ci, j) = sum over (b, t) of dy[b, t, co] * x[b, in_pos(t, j), ci]: partial[chunk][weight element in checkpoint order]
 __global__ void train_conv_wgrad_kernel(const ConvDesc d, const float* __restrict__ x, const float* __restrict__ dy,
-                                        float* __restrict__ partial, long pstride) {
+                                        float* __restrict__ partial, long pstride, int chunk) {
     const int cig = d.transposed ? d.c_out : d.c_in / d.groups;      // middle extent of the checkpoint layout
     const int outer = d.transposed ? d.c_in : d.c_out;
     const long nw = (long)outer * cig * d.k;
@@ -127,8 +127,8 @@ __global__ void train_conv_wgrad_kernel(const ConvDesc d, const float* __restric
     int co, ci;
     if (d.transposed) { ci = out; co = mid; }
     else { co = out; ci = (co / (d.c_out / d.groups)) * cig + mid; }
-    const long rows = (long)d.B * d.n_out, r0 = (long)blockIdx.y * kTrainChunk;
-    const long r1 = r0 + kTrainChunk < rows ? r0 + kTrainChunk : rows;
+    const long rows = (long)d.B * d.n_out, r0 = (long)blockIdx.y * chunk;
+    const long r1 = r0 + chunk < rows ? r0 + chunk : rows;
     float acc = 0.0f;
     for (long r = r0; r < r1; ++r) {
         const int b = (int)(r / d.n_out), t = (int)(r - (long)b * d.n_out);
@@ -256,10 +256,10 @@ __global__ __launch_bounds__(64 * kReduceGroups) void train_reduce_chunks_kernel
     }
 }
 // partial[chunk][c] = sum over the chunk's rows of v[row, c]   (bias gradients)
-__global__ void train_colsum_kernel(const float* __restrict__ v, long rows, int C, float* __restrict__ partial, long pstride) {
+__global__ void train_colsum_kernel(const float* __restrict__ v, long rows, int C, float* __restrict__ partial, long pstride, int chunk) {
     const int c = (int)(blockIdx.x * blockDim.x + threadIdx.x);
     if (c >= C) return;
-    const long r0 = (long)blockIdx.y * kTrainChunk, r1 = r0 + kTrainChunk < rows ? r0 + kTrainChunk : rows;
+    const long r0 = (long)blockIdx.y * chunk, r1 = r0 + chunk < rows ? r0 + chunk : rows;
     float acc = 0.0f;
     for (long r = r0; r < r1; ++r) acc += v[r * C + c];
     partial[(long)blockIdx.y * pstride + c] = acc;
