@@ -30,12 +30,23 @@ def _new(shape, like, dtype=torch.float32):
     return torch.empty(shape, dtype=dtype, device=like.device)
 
 
+def _grad_buffer(param):
+    """Where an operator's backward writes a PARAMETER's gradient: straight into the flat gradient buffer when `FlatParams` owns
+    the parameter (then autograd gets None for it: no temporary, no accumulation launch), else a fresh tensor for autograd to
+    accumulate.  Valid because every parameter of this model feeds exactly one operator per step."""
+    view = getattr(param, "_esmi_grad_view", None)
+    if view is not None and param.grad is not None and param.grad.data_ptr() == view.data_ptr():   # still the buffer autograd would add to
+        return view, True
+    return torch.empty_like(param), False
+
+
 # --------------------------------------------------------------------------- operators (autograd = the tape)
 class _Conv(torch.autograd.Function):
     """Conv1d / ConvTranspose1d / Linear on channels-last (B, n, C); `w` in checkpoint layout (Linear: (Cout, Cin))."""
 
     @staticmethod
     def forward(ctx, x, w, b, stride, pad, groups, transposed, n_out):
+        w0 = w
         x, w = x.contiguous(), w.contiguous()
         lib, st = _rt(x)
         B, n_in, c_in = x.shape
@@ -47,7 +58,7 @@ class _Conv(torch.autograd.Function):
         ws = _new((nws,), x, torch.uint8) if nws else None
         lib.esmi_train_conv_fwd_f32(C.byref(d), _ptr(x), _ptr(w), _ptr(b), _ptr(y), _ptr(ws), nws, st)
         ctx.save_for_backward(x, w)
-        ctx.d, ctx.has_bias = d, b is not None
+        ctx.d, ctx.params = d, (w0, b)          # the Parameter objects themselves: their flat gradient views are the outputs
         return y
 
     @staticmethod
@@ -60,12 +71,13 @@ class _Conv(torch.autograd.Function):
         nws = lib.esmi_train_conv_workspace_bytes(C.byref(d)) if (USE_MATRIX_PIPE and USE_MATRIX_PIPE_DGRAD) else 0
         ws = _new((nws,), w, torch.uint8) if nws else None
         lib.esmi_train_conv_dgrad_f32(C.byref(d), _ptr(dy), _ptr(w), _ptr(dx), _ptr(ws), nws, st)
-        dw = torch.empty_like(w)
-        db = _new((d.c_out,), w) if ctx.has_bias else None
+        w0, b0 = ctx.params
+        dw, w_direct = _grad_buffer(w0)
+        db, b_direct = _grad_buffer(b0) if b0 is not None else (None, True)
         nws = lib.esmi_train_conv_wgrad_workspace_bytes(C.byref(d))
         ws = _new((nws,), w, torch.uint8)
         lib.esmi_train_conv_wgrad_f32(C.byref(d), _ptr(x), _ptr(dy), _ptr(dw), _ptr(db), _ptr(ws), nws, st)
-        return dx, dw, db, None, None, None, None, None
+        return dx, (None if w_direct else dw), (None if b_direct else db), None, None, None, None, None
 
 
 class _LayerNorm(torch.autograd.Function):
@@ -77,6 +89,7 @@ class _LayerNorm(torch.autograd.Function):
         y, mean, rstd = torch.empty_like(x), _new((rows,), x), _new((rows,), x)
         lib.esmi_train_layernorm_fwd_f32(_ptr(x), _ptr(g), _ptr(b), rows, Cc, _ptr(y), _ptr(mean), _ptr(rstd), st)
         ctx.save_for_backward(x, g, mean, rstd)
+        ctx.params = (g, b)
         return y
 
     @staticmethod
@@ -85,12 +98,13 @@ class _LayerNorm(torch.autograd.Function):
         dy = dy.contiguous()
         lib, st = _rt(dy)
         rows, Cc = x.numel() // x.shape[-1], x.shape[-1]
-        dx, dg, db = torch.empty_like(x), torch.empty_like(g), torch.empty_like(g)
+        dx = torch.empty_like(x)
+        (dg, g_direct), (db, b_direct) = _grad_buffer(ctx.params[0]), _grad_buffer(ctx.params[1])
         nws = lib.esmi_train_layernorm_bwd_workspace_bytes(rows, Cc)
         ws = _new((nws,), x, torch.uint8)
         lib.esmi_train_layernorm_bwd_f32(_ptr(x), _ptr(g), _ptr(mean), _ptr(rstd), _ptr(dy), rows, Cc, _ptr(dx), _ptr(dg), _ptr(db),
                                          _ptr(ws), nws, st)
-        return dx, dg, db
+        return dx, (None if g_direct else dg), (None if b_direct else db)
 
 
 class _Act(torch.autograd.Function):
@@ -149,7 +163,7 @@ class _Embedding(torch.autograd.Function):
         out = _new(tuple(ids.shape) + (Cc,), table)
         lib.esmi_train_embedding_fwd_f32(_ptr(ids), _ptr(table), ids.numel(), V, Cc, _ptr(out), st)
         ctx.save_for_backward(ids)
-        ctx.dims = (V, Cc, padding_idx)
+        ctx.dims, ctx.param = (V, Cc, padding_idx), table
         return out
 
     @staticmethod
@@ -158,11 +172,11 @@ class _Embedding(torch.autograd.Function):
         dy = dy.contiguous()
         lib, st = _rt(dy)
         V, Cc, pad = ctx.dims
-        dt = _new((V, Cc), dy)
+        dt, direct = _grad_buffer(ctx.param)
         nws = lib.esmi_train_embedding_bwd_workspace_bytes(ids.numel(), V, Cc)
         ws = _new((nws,), dy, torch.uint8)
         lib.esmi_train_embedding_bwd_f32(_ptr(ids), _ptr(dy), ids.numel(), V, Cc, pad, _ptr(dt), _ptr(ws), nws, st)
-        return None, dt, None
+        return None, (None if direct else dt), None
 
 
 class _MaskRows(torch.autograd.Function):
@@ -456,6 +470,7 @@ class FlatParams:
             self.data[off:off + k].copy_(p.detach().reshape(-1))
             p.data = self.data[off:off + k].view(p.shape)
             p.grad = self.grad[off:off + k].view(p.shape)
+            p._esmi_grad_view = p.grad              # operators' backward passes write here directly (see _grad_buffer)
             off += pad4(k)
         self.params = [p for _, p in named]
 
