@@ -54,6 +54,32 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnP p) {
         kok[kt] = 32 * kt + i < p.N;
         krow[kt] = kb + (long)(kok[kt] ? 32 * kt + i : 0) * ld;
     }
+#if ESMI_CHAIN_SPLIT
+    // split-f16x2 products (esmi_dev.h): both operands are activations, split on the fly into two binary16 pieces (no 2^8 scale:
+    // |q|, |k| are far inside the binary16 range); a k-step is 16 channels, lane half h2 holds channels 16s + 8 h2 + (0..7) of its
+    // row on BOTH sides.  Three v_mfma_f32_32x32x16_f16 per (key tile, 16 channels) instead of eight v_mfma_f32_32x32x2_f32.
+    for (int st = 0; st < (p.C >> 4); st += 2) {       // two steps (32 channels) of operands per round trip
+        f16x2p qf[2], kf[2][NKT];
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            const int c = 16 * (st + g) + 8 * h2;
+            const bool cok = st + g < (p.C >> 4);
+            qf[g] = (qok && cok) ? split_f16x2(ld4(qrow + c), ld4(qrow + c + 4)) : split_f16x2(zero4(), zero4());
+#pragma unroll
+            for (int kt = 0; kt < NKT; ++kt)
+                kf[g][kt] = (kok[kt] && cok) ? split_f16x2(ld4(krow[kt] + c), ld4(krow[kt] + c + 4)) : split_f16x2(zero4(), zero4());
+        }
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+#pragma unroll
+            for (int kt = 0; kt < NKT; ++kt) {
+                s[kt] = mfma32_f16(kf[g][kt].h2, qf[g].h1, s[kt]);
+                s[kt] = mfma32_f16(kf[g][kt].h1, qf[g].h2, s[kt]);
+                s[kt] = mfma32_f16(kf[g][kt].h1, qf[g].h1, s[kt]);
+            }
+        }
+    }
+#else
     // operands for 4 k-steps groups are fetched together (one memory round trip per 32 channels)
     for (int kc = 0; kc < (p.C >> 3); kc += 4) {
         f32x4 qv[4], kv[4][NKT];
@@ -73,6 +99,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnP p) {
             }
         }
     }
+#endif
     // ---- softmax over keys for this lane's query: in-lane over (kt, r), then the other half wave
     float mx = -INFINITY;
 #pragma unroll
@@ -108,6 +135,36 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnP p) {
         f32x16 o[4];
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) o[nt] = zero16();
+#if ESMI_CHAIN_SPLIT
+        // P V on the f16 pipe: a k-step is the 16 keys the two half waves hold in accumulator registers r8 .. r8 + 7 (half h2's eight
+        // k-slots are ITS eight keys, so the probabilities are already in place and every lane fetches the V rows of its own keys)
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt) {
+#pragma unroll
+            for (int r8 = 0; r8 < 16; r8 += 8) {
+                f32x4 pa, pb2;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { pa[e] = s[kt][r8 + e]; pb2[e] = s[kt][r8 + 4 + e]; }
+                const f16x2p pf = split_f16x2(pa, pb2);
+                float vv[8][4];
+#pragma unroll
+                for (int rr = 0; rr < 8; ++rr) {
+                    const int key = 32 * kt + tile_row(r8 + rr, lane);
+                    const bool vok = key < p.N;
+                    const float* vrow = vb + (long)(vok ? key : 0) * ld + c0 + i;
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt) vv[rr][nt] = (vok && c0 + 32 * nt + i < p.C) ? vrow[32 * nt] : 0.0f;
+                }
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) {
+                    const f16x2p vf = split_f16x2(f32x4{vv[0][nt], vv[1][nt], vv[2][nt], vv[3][nt]}, f32x4{vv[4][nt], vv[5][nt], vv[6][nt], vv[7][nt]});
+                    o[nt] = mfma32_f16(pf.h2, vf.h1, o[nt]);
+                    o[nt] = mfma32_f16(pf.h1, vf.h2, o[nt]);
+                    o[nt] = mfma32_f16(pf.h1, vf.h1, o[nt]);
+                }
+            }
+        }
+#else
 #pragma unroll
         for (int kt = 0; kt < NKT; ++kt) {
 #pragma unroll
@@ -128,6 +185,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnP p) {
                 }
             }
         }
+#endif
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int q = q0 + tile_row(r, lane);
