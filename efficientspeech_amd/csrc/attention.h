@@ -327,4 +327,158 @@ __global__ __launch_bounds__(256) void attn_long_kernel(const AttnP p) {
     }
 }
 
+#if ESMI_CHAIN_SPLIT
+// ---- the same attention with K, then V, staged ONCE per (utterance, head) in LDS as split binary16 planes.  attn_kernel
+// streams K and V from L2 for every 32-query tile (base ES block 0: 8 tiles per head -> 4 GB of L2 reads per call, which is
+// what bounds it); here one workgroup of NKT waves (= all query tiles of the head, N <= 32 NKT <= 256) shares them:
+//   stage K planes [key][C] -> scores S^T = K Q^T (A fragments: two ds_read_b128 per key tile and 16 channels, no per-use
+//   split; Q split once per wave and step) -> softmax in registers, as attn_kernel -> barrier -> stage V TRANSPOSED into the
+//   same LDS, Vt[channel][k-slot], with the k-slots permuted so that the eight keys a half wave contributes to a 16-key step
+//   are contiguous -> ctx = P V (B fragments: two ds_read_b128 per 32 channels and step).
+// Row strides 2 C + 16 / 2 N + 16 bytes: the 16-byte fragment reads of 32 consecutive rows are bank-conflict free.
+__host__ __device__ inline size_t attn_lds_bytes(int N, int C) {
+    const int nk = N <= 128 ? 128 : 256;                  // the two instantiations stage 32 NKT = 128 or 256 key rows
+    const int ck = C < 128 ? C : 128;                     // ... 128 channels at a time (K: per pass of the score loop, V: per output pass)
+    const size_t k = (size_t)2 * nk * (2 * ck + 16), v = (size_t)2 * ck * (2 * nk + 16);
+    return k > v ? k : v;
+}
+template <int NKT>
+__global__ __launch_bounds__(64 * NKT, 2) void attn_lds_kernel(const AttnP p) {
+    ESMI_DYN_LDS(lds_f);
+    char* lds = reinterpret_cast<char*>(lds_f);
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    constexpr int NK = 32 * NKT, NTHR = 64 * NKT;
+    const int lane = lane_id(), w = wave_id(), tid = (int)threadIdx.x;
+    const int hd = (int)blockIdx.x % p.h, b = (int)blockIdx.x / p.h;
+    const int i = lane & 31, h2 = lane >> 5, q0 = 32 * w;
+    const int ld = 3 * p.h * p.C, C = p.C, CK = C < 128 ? C : 128;
+    const float* base = p.qkv + (long)b * p.N * ld;
+    const float* qb = base + 0 * p.h * C + hd * C;
+    const float* kb = base + 1 * p.h * C + hd * C;
+    const float* vb = base + 2 * p.h * C + hd * C;
+    const int krs = 2 * CK + 16, kplane = NK * krs;           // K planes: [2][NK][krs bytes], CK channels per pass
+    const int vrs = 2 * NK + 16, vplane = CK * vrs;           // Vt planes: [2][CK][vrs bytes]
+
+    // ---- S^T[key][query] for this wave's 32 queries, CK channels of K staged at a time (one item = 4 channels of one key)
+    f32x16 s[NKT];
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) s[kt] = zero16();
+    const bool qok = q0 + i < p.N;
+    const float* qrow = qb + (long)(qok ? q0 + i : 0) * ld;
+    for (int cp = 0; cp < C; cp += CK) {
+        if (cp) __syncthreads();                           // the previous pass's fragments have been read
+        for (int e = tid; e < NK * (CK >> 2); e += NTHR) {
+            const int key = e / (CK >> 2), c = (e - key * (CK >> 2)) << 2;
+            const f32x4 v = key < p.N ? ld4(kb + (long)key * ld + cp + c) : zero4();
+            unsigned h1a, h2a, h1b, h2b;
+            split_f16_pair(v[0], v[1], h1a, h2a);
+            split_f16_pair(v[2], v[3], h1b, h2b);
+            char* d = lds + key * krs + c * 2;
+            *reinterpret_cast<u32x2*>(d) = u32x2{h1a, h1b};
+            *reinterpret_cast<u32x2*>(d + kplane) = u32x2{h2a, h2b};
+        }
+        __syncthreads();
+        for (int st = 0; st < (CK >> 4); ++st) {
+            const int c = 16 * st + 8 * h2;
+            const f16x2p qf = qok ? split_f16x2(ld4(qrow + cp + c), ld4(qrow + cp + c + 4)) : split_f16x2(zero4(), zero4());
+#pragma unroll
+            for (int kt = 0; kt < NKT; ++kt) {
+                const char* a = lds + opaque_i((32 * kt + i) * krs + c * 2);
+                const u32x4 k1 = *reinterpret_cast<const u32x4*>(a), k2 = *reinterpret_cast<const u32x4*>(a + kplane);
+                s[kt] = mfma32_f16(k2, qf.h1, s[kt]);
+                s[kt] = mfma32_f16(k1, qf.h2, s[kt]);
+                s[kt] = mfma32_f16(k1, qf.h1, s[kt]);
+            }
+        }
+    }
+    // ---- softmax over keys (attn_kernel's)
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = 32 * kt + tile_row(r, lane);
+            const float v = key < p.N ? s[kt][r] * p.scale : -INFINITY;
+            s[kt][r] = v;
+            mx = fmaxf(mx, v);
+        }
+    }
+    mx = fmaxf(mx, swap32_f(mx));
+    float den = 0.0f;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float e = expf(s[kt][r] - mx);
+            s[kt][r] = e;
+            den += e;
+        }
+    }
+    den += swap32_f(den);
+    const float inv = 1.0f / den;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[kt][r] *= inv;
+    }
+
+    // ---- ctx[query][c] = sum_key P[query][key] V[key][c], CK output channels per pass, V staged TRANSPOSED per pass:
+    // one item = 4 consecutive keys x 4 channels; k-slot of key 32 kt + 8 q + 4 h + e (e < 4) is 32 kt + 16 (q >> 1) + 8 h + 4 (q & 1) + e,
+    // i.e. the eight keys of (kt, step q >> 1, half h) are slots 8 h .. 8 h + 7 of that 16-key step
+    for (int c0 = 0; c0 < C; c0 += CK) {
+        __syncthreads();                                   // K (or the previous pass's V) has been read by every wave
+        for (int e = tid; e < (NK >> 2) * (CK >> 2); e += NTHR) {
+            const int g4 = e / (CK >> 2), c = (e - g4 * (CK >> 2)) << 2;
+            const int key0 = 4 * g4, kt = key0 >> 5, q = (key0 >> 3) & 3, hh = (key0 >> 2) & 1;
+            const int slot0 = 32 * kt + 16 * (q >> 1) + 8 * hh + 4 * (q & 1);
+            f32x4 v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = key0 + r < p.N ? ld4(vb + (long)(key0 + r) * ld + c0 + c) : zero4();
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) {
+                unsigned h1a, h2a, h1b, h2b;
+                split_f16_pair(v[0][cc], v[1][cc], h1a, h2a);
+                split_f16_pair(v[2][cc], v[3][cc], h1b, h2b);
+                char* d = lds + (c + cc) * vrs + slot0 * 2;
+                *reinterpret_cast<u32x2*>(d) = u32x2{h1a, h1b};
+                *reinterpret_cast<u32x2*>(d + vplane) = u32x2{h2a, h2b};
+            }
+        }
+        __syncthreads();
+        f32x16 o[4];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) o[nt] = zero16();
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt) {
+#pragma unroll
+            for (int r8 = 0; r8 < 16; r8 += 8) {
+                f32x4 pa, pb2;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { pa[e] = s[kt][r8 + e]; pb2[e] = s[kt][r8 + 4 + e]; }
+                const f16x2p pf = split_f16x2(pa, pb2);
+                const int slot = 32 * kt + 2 * r8 + 8 * h2;          // this half wave's eight k-slots of the step
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) {
+                    if (32 * nt >= CK) continue;                      // workgroup-uniform
+                    const char* a = lds + opaque_i((32 * nt + i) * vrs + slot * 2);
+                    const u32x4 v1 = *reinterpret_cast<const u32x4*>(a), v2 = *reinterpret_cast<const u32x4*>(a + vplane);
+                    o[nt] = mfma32_f16(pf.h2, v1, o[nt]);
+                    o[nt] = mfma32_f16(pf.h1, v2, o[nt]);
+                    o[nt] = mfma32_f16(pf.h1, v1, o[nt]);
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int q = q0 + tile_row(r, lane);
+            if (q >= p.N) continue;
+            float* orow = p.ctx + ((long)b * p.N + q) * (p.h * C) + hd * C + c0 + i;
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+                if (32 * nt + i < CK) orow[32 * nt] = o[nt][r];
+        }
+    }
+}
+#endif
+
 }  // namespace esmi

@@ -114,6 +114,13 @@ int launch_convgemm(ConvGemmP p, hipStream_t st) {
     return launch_status();
 }
 
+#ifndef ESMI_ATTN_LDS_MIN_HEADS
+#ifdef ESMI_WAVESIM
+#define ESMI_ATTN_LDS_MIN_HEADS 1      // (simulator: always take the LDS kernel where it applies, so the tests reach it)
+#else
+#define ESMI_ATTN_LDS_MIN_HEADS 128    // enough (utterance, head) workgroups to occupy the chip at one per CU
+#endif
+#endif
 int launch_attn(const AttnP& p, hipStream_t st) {
     if ((p.C & 31) || p.N <= 0) return ESMI_ERR_ARG;   // channel groups of 32 (4 k-steps fetched together)
     const int nkt = (p.N + 31) / 32;
@@ -129,6 +136,23 @@ int launch_attn(const AttnP& p, hipStream_t st) {
         }
         return launch_status();
     }
+#if ESMI_CHAIN_SPLIT
+    // heads with several query tiles: K and V staged once per (utterance, head) in LDS instead of once per tile from L2
+    if (nkt >= 3 && (p.C <= 128 || p.C % 128 == 0) && attn_lds_bytes(p.N, p.C) <= 150 * 1024 && (long)p.B * p.h >= ESMI_ATTN_LDS_MIN_HEADS) {
+        const size_t lds = attn_lds_bytes(p.N, p.C);
+        dim3 g2((unsigned)(p.B * p.h));
+        if (nkt <= 4) {
+            static AttrOnce once;
+            if (int rc = raise_lds_limit(reinterpret_cast<const void*>(attn_lds_kernel<4>), once)) return rc;
+            ESMI_LAUNCH((attn_lds_kernel<4>), g2, dim3(256), lds, st, p);
+        } else {
+            static AttrOnce once;
+            if (int rc = raise_lds_limit(reinterpret_cast<const void*>(attn_lds_kernel<8>), once)) return rc;
+            ESMI_LAUNCH((attn_lds_kernel<8>), g2, dim3(512), lds, st, p);
+        }
+        return launch_status();
+    }
+#endif
     if (nkt == 1) ESMI_LAUNCH((attn_kernel<1>), grid, block, 0, st, p);
     else if (nkt == 2) ESMI_LAUNCH((attn_kernel<2>), grid, block, 0, st, p);
     else if (nkt <= 4) ESMI_LAUNCH((attn_kernel<4>), grid, block, 0, st, p);

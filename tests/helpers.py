@@ -99,6 +99,22 @@ def compare_eval_with_oracle(cfg, o, enc, mel, mel_len, sd):
     return err
 
 
+def check_attention_sizes(net, cfg, sd, device, sizes=((2, 100), (1, 200), (3, 128))):
+    """SelfAttention.forward at lengths with 3 .. 8 key tiles: the (utterance, head) workgroup kernel that stages K and V in LDS
+    (csrc/attention.h attn_lds_kernel; on the GPU it needs >= 128 heads in flight, in the simulator build it always runs)."""
+    from oracle import oracle
+    rng = np.random.default_rng(11)
+    enc = net.encoder.encoder
+    for i, blk in enumerate(enc.attn_blocks):
+        pre = f"encoder.encoder.attn_blocks.{i}."
+        for B, N in sizes:
+            x = rng.standard_normal((B, N, enc.dim_outs[i])).astype(np.float32)
+            ref = oracle.self_attention(x, sd[pre + "2.qkv.weight"], sd[pre + "2.proj.weight"], sd[pre + "2.proj.bias"], enc.heads[i])
+            with torch.no_grad():
+                y, _ = blk[2](torch.from_numpy(x).to(device))
+            np.testing.assert_allclose(y.cpu().numpy(), ref, atol=PRED_TOL, rtol=0)
+
+
 def check_submodule_forwards(net, cfg, sd, device, seed=3):
     """The reference's sub-modules called on their own (SelfAttention / MixFFN / AcousticDecoder.forward, get_embedding,
     blocks.py:22-29,43-71, networks.py:128-165) against the oracle's restatement of the same functions."""

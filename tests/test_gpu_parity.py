@@ -613,3 +613,10 @@ def test_hip_forward_matches_stock_pytorch_ops_on_the_gpu():
     per_utt = (mel - ref).abs().amax(dim=(1, 2))
     assert int((per_utt > 1e-4).sum()) <= 1          # (a pitch / energy prediction on a bucket edge may flip one utterance's embedding)
     assert float(per_utt.median()) < 2e-5
+
+
+@pytest.mark.parametrize("name", ["tiny", "base"])
+def test_lds_staged_attention_at_size(name):
+    """>= 128 (utterance, head) pairs so that the GPU dispatch takes attn_lds_kernel: 3, 4, 7 and 8 key tiles, widths 32 .. 256."""
+    net, cfg, sd = H.make_net(name, DEV)
+    H.check_attention_sizes(net, cfg, sd, DEV, sizes=((128, 96), (64, 128), (40, 200), (32, 256)) if name == "tiny" else ((32, 100), (16, 250)))

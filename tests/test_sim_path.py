@@ -295,3 +295,10 @@ def test_simulated_hifigan_generator_matches_reference(fixture):
     """HiFi-GAN generator: ResBlock1 (v2) and ResBlock2 (v3) chains through esmi_hifigan_generator_f32."""
     with use_sim():
         H.check_hifigan_golden(os.path.join(GOLD, fixture), "cpu")
+
+
+def test_simulated_lds_staged_attention():
+    """attn_lds_kernel<4> / <8> (K and V staged once per head in LDS) through SelfAttention.forward, tiny ES widths 32 / 64."""
+    with use_sim():
+        net, cfg, sd = H.make_net("tiny", "cpu")
+        H.check_attention_sizes(net, cfg, sd, "cpu", sizes=((1, 100), (1, 200)))
