@@ -58,7 +58,8 @@ class EfficientSpeech(nn.Module):
     (and `from_config`) pass what their checkpoint was trained with.
 
     `hifigan`: a vocoder module mapping mel (B, 80, L) -> wav (B, 1, samples).  None (default): `predict_step` returns the
-    channels-first mel in place of the waveform -- the vocoder is not part of this repo's path."""
+    channels-first mel in place of the waveform.  `efficientspeech_amd.get_hifigan(...)` / `HifiGanGenerator` is the HIP vocoder
+    (the reference's `get_hifigan`, model.py:23-49); any module with that signature plugs in."""
 
     def __init__(self, preprocess_config=None, lr=1e-3, weight_decay=1e-6, max_epochs=5000, depth=2, n_blocks=2, block_depth=2,
                  reduction=4, head=1, embed_dim=128, kernel_size=3, decoder_kernel_size=3, expansion=1, wav_path="wavs",
