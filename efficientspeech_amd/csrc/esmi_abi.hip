@@ -179,6 +179,10 @@ int launch_enc_merge_qkv(const EncMergeP& p, int c_in, int c_out, hipStream_t st
 
 bool enc_attn_ffn_supported(int C, int N, int expansion) {
     if ((C & 31) || N > 256 || N < 1) return false;
+    // sequences of more than 128 positions: the chain kernel runs one latency chain per 32 rows against up to 256 keys; the same
+    // ops as launches (LDS-staged attention + LDS-staged GEMMs) are faster there (small ES T = 256: 2.53 vs 2.62 ms/step; base ES
+    // block 0: 1.33 vs 2.00 ms) -- `tools/debug_plan_base.py` measures the plans
+    if (N > 128) return false;
     const int nc = C / 32;
     // base ES block 0 (C = 128, expansion 2) at N = 256: the chain kernel runs one latency chain per 32 rows against 256 keys
     // (2.00 ms at B = 512); the same ops as LDS-staged GEMM launches take 1.33 ms, so that shape goes per-op
