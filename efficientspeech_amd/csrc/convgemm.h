@@ -337,16 +337,21 @@ constexpr int kGemmRowDw = 20;   // dwords per weight row and plane in LDS
 template <int NT>
 __host__ __device__ constexpr int convgemm_lds_bytes() { return 2 * 2 * 32 * NT * kGemmRowDw * 4; }
 
-template <int NT>
-__global__ __launch_bounds__(256, 2) void convgemm_lds_kernel(const ConvGemmP p) {
-    constexpr int BN = 32 * NT, PLANE = BN * kGemmRowDw;
+#ifndef ESMI_GEMM_LDS_WAVES
+#define ESMI_GEMM_LDS_WAVES 4   // waves (32 positions each) sharing one weight tile.  8 halves each wave's share of the staging work
+                                // but couples 8 waves to one barrier: measured 11.50 vs 10.45 ms/step on base ES (r02), so 4
+#endif
+template <int NT, int NWV = ESMI_GEMM_LDS_WAVES>
+__global__ __launch_bounds__(64 * NWV, 2) void convgemm_lds_kernel(const ConvGemmP p) {
+    constexpr int BN = 32 * NT, PLANE = BN * kGemmRowDw, NTHR = 64 * NWV, NU = (256 * NT) / NTHR, ROWS = 32 * NWV;
+    static_assert(NU * NTHR == 256 * NT, "staging items divide evenly");
     ESMI_DYN_LDS(lds);
     unsigned* wt = reinterpret_cast<unsigned*>(lds);   // [2 buffers][2 planes][PLANE]
     const int tid = (int)threadIdx.x, lane = lane_id(), w = wave_id();
     const int i = lane & 31, h = lane >> 5;
-    const int tiles_per_b = (p.n_out + 127) >> 7;
+    const int tiles_per_b = (p.n_out + ROWS - 1) / ROWS;
     const int b = (int)blockIdx.x / tiles_per_b;
-    const int t0 = (((int)blockIdx.x - b * tiles_per_b) << 7) + 32 * w;   // this wave's 32 positions
+    const int t0 = ((int)blockIdx.x - b * tiles_per_b) * ROWS + 32 * w;   // this wave's 32 positions
     const int n0 = (int)blockIdx.y * BN;
     const int t_out = t0 + i;
 
@@ -354,7 +359,7 @@ __global__ __launch_bounds__(256, 2) void convgemm_lds_kernel(const ConvGemmP p)
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) acc[nt] = zero16();
     const int kchunks = p.c_in >> 5, n_it = p.k * kchunks;
-    f32x4 a_nxt[2][2], w_nxt[NT];
+    f32x4 a_nxt[2][2], w_nxt[NU];
     f16x2p a_cur[2];
     const float in_s = conv_in_scale(p);
     auto fetch = [&](int it) __attribute__((always_inline)) {   // global -> registers: A rows of this wave, W rows of the workgroup
@@ -369,16 +374,16 @@ __global__ __launch_bounds__(256, 2) void convgemm_lds_kernel(const ConvGemmP p)
         }
         const float* wj = p.W + (long)j * p.c_out * p.c_in + c;
 #pragma unroll
-        for (int u = 0; u < NT; ++u) {
-            const int q = tid + 256 * u, n = n0 + (q >> 3);
+        for (int u = 0; u < NU; ++u) {
+            const int q = tid + NTHR * u, n = n0 + (q >> 3);
             w_nxt[u] = n < p.c_out ? ld4(wj + (long)n * p.c_in + 4 * (q & 7)) : zero4();
         }
     };
     auto stage = [&](int buf) __attribute__((always_inline)) {   // registers -> LDS planes (weights), A fragments split in place
         typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 #pragma unroll
-        for (int u = 0; u < NT; ++u) {
-            const int q = tid + 256 * u;
+        for (int u = 0; u < NU; ++u) {
+            const int q = tid + NTHR * u;
             const f32x4 x = w_nxt[u] * kF16WScale;
             unsigned h1a, h2a, h1b, h2b;
             split_f16_pair_rn(x[0], x[1], h1a, h2a);   // weights: nearest-rounded pieces, as the pack-time splitters

@@ -90,13 +90,14 @@ int launch_convgemm(ConvGemmP p, hipStream_t st) {
     // large plain convolutions / Linears: weight tile staged through LDS once per 128 positions (convgemm.h)
     if (p.mode == MODE_CONV && p.stride == 1 && !p.ids && (p.c_in & 31) == 0 && p.c_out > 64 && (long)p.B * p.n_out >= ESMI_GEMM_LDS_MIN_ROWS) {
         const int nl = full_row ? (nt <= 4 ? 4 : 8) : ((p.c_out & 255) == 0 ? 8 : 4);
-        dim3 g2((unsigned)(p.B * ((p.n_out + 127) / 128)), full_row ? 1 : (p.c_out + 32 * nl - 1) / (32 * nl));
+        constexpr int kRows = 32 * ESMI_GEMM_LDS_WAVES;
+        dim3 g2((unsigned)(p.B * ((p.n_out + kRows - 1) / kRows)), full_row ? 1 : (p.c_out + 32 * nl - 1) / (32 * nl));
         if (nl == 4) {
-            ESMI_LAUNCH((convgemm_lds_kernel<4>), g2, dim3(256), convgemm_lds_bytes<4>(), st, p);
+            ESMI_LAUNCH((convgemm_lds_kernel<4>), g2, dim3(64 * ESMI_GEMM_LDS_WAVES), convgemm_lds_bytes<4>(), st, p);
         } else {
             static AttrOnce once;
             if (int rc = raise_lds_limit(reinterpret_cast<const void*>(convgemm_lds_kernel<8>), once)) return rc;
-            ESMI_LAUNCH((convgemm_lds_kernel<8>), g2, dim3(256), convgemm_lds_bytes<8>(), st, p);
+            ESMI_LAUNCH((convgemm_lds_kernel<8>), g2, dim3(64 * ESMI_GEMM_LDS_WAVES), convgemm_lds_bytes<8>(), st, p);
         }
         return launch_status();
     }
