@@ -15,6 +15,7 @@
 #include "enc_merge_qkv.h"
 #include "esmi_dev.h"
 #include "mel_decoder.h"
+#include "mel_decoder_rows.h"
 #include "small_kernels.h"
 
 #ifndef ESMI_GEMM_LDS_MIN_ROWS   // rows (B * n_out) from which the per-op plan's GEMMs take the LDS-staged kernel
@@ -905,12 +906,33 @@ int esmi_mel_decoder_pack_f32(const esmi_decoder_weights* w, const esmi_decoder_
     }
     bslice(w->mel_w, L.mel_w, s->n_mel, dx2);
     vec(w->mel_b, L.mel_b, s->n_mel, dx2);
+    if (L.rows0 >= 0) {   // the row-owner form's copy (mel_decoder_rows.h)
+        auto afrag = [&](const float* src, long off, int N, int MT) {
+            const long n = 8L * MT * 2 * 256;
+            ESMI_LAUNCH(pack_rows_afrag_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src,
+                        reinterpret_cast<unsigned*>(blob + off), N, MT);
+        };
+        for (int l = 0; l < s->n_blocks * s->block_depth; ++l) {
+            const long base = L.rows0 + (long)l * L.rows_layer_stride, pr = base + 16384;
+            afrag(w->pw_w[l], base, dx2, 4);
+            ESMI_LAUNCH(pack_dw_kernel, dim3((dx2 * s->kernel + 255) / 256), dim3(256), 0, st, w->dw_w[l], blob + pr, dx2, s->kernel);
+            ESMI_LAUNCH(pack_rows_bias_kernel, dim3(2), dim3(64), 0, st, w->pw_w[l], w->dw_b[l], w->pw_b[l],
+                        blob + pr + (long)s->kernel * dx2);
+            vec(w->ln_g[l], pr + (long)(s->kernel + 1) * dx2, dx2, dx2);
+            vec(w->ln_b[l], pr + (long)(s->kernel + 2) * dx2, dx2, dx2);
+        }
+        afrag(w->mel_w, L.rows_mel, s->n_mel, 3);
+        ESMI_LAUNCH(pack_rows_padrow_kernel, dim3(1), dim3(64), 0, st, w->proj_b, w->proj_ln_g, w->proj_ln_b, blob + L.rows_pad);
+    }
     return launch_status();
 }
 
-int esmi_mel_decoder_f32(const float* blob, const esmi_decoder_shape* s, const float* x, const float* h0,
-                         const int32_t* cum, const int32_t* mel_len, const int32_t* lmax_dev, int lmax_host, int apply_mask, int B, int T,
-                         int L_out, float* mel, esmi_stream_t stream) {
+#ifndef ESMI_DEC_ROWS
+#define ESMI_DEC_ROWS 0     // 1: dx2 = 128 decoders with the phoneme-rate head take the row-owner kernel (mel_decoder_rows.h) by default.
+#endif                      // Measured on MI355X (tiny B=256 T=128): 0.316 ms vs 0.198 ms for the tile form, so 0
+static int mel_decoder_launch(const float* blob, const esmi_decoder_shape* s, const float* x, const float* h0,
+                              const int32_t* cum, const int32_t* mel_len, const int32_t* lmax_dev, int lmax_host, int apply_mask, int B, int T,
+                              int L_out, float* mel, esmi_stream_t stream, bool rows) {
     int rc = dec_check(s);
     if (rc) return rc;
     if (!blob || (!x && !h0) || !mel || B <= 0 || L_out <= 0 || !aligned16(blob) || (x && !aligned16(x))) return ESMI_ERR_ARG;
@@ -930,9 +952,27 @@ int esmi_mel_decoder_f32(const float* blob, const esmi_decoder_shape* s, const f
 #ifdef ESMI_DEC_TRACE
     p.trace = g_esmi_trace;   // development only, see tools/trace_decoder.py
 #endif
+    hipStream_t st = S(stream);
+    const bool rows_ok = h0 && p.lay.rows0 >= 0 && 4 * p.halo <= kRowsWin;
+    if (rows && !rows_ok) return ESMI_ERR_UNSUPPORTED;
+    if (rows) {
+        p.TL = kRowsWin - 2 * p.halo;
+        p.n_tiles = (L_out + p.TL - 1) / p.TL;
+        dim3 rgrid((unsigned)(p.n_tiles * ((B + 7) / 8) * 8));
+        const int lds = dec_rows_lds_floats(s->kernel) * (int)sizeof(float);
+        if (s->kernel == 5) {
+            static AttrOnce once;
+            if (int rc2 = raise_lds_limit(reinterpret_cast<const void*>(mel_decoder_rows_kernel<5>), once)) return rc2;
+            ESMI_LAUNCH((mel_decoder_rows_kernel<5>), rgrid, dim3(kRowsThreads), lds, st, p);
+        } else {
+            static AttrOnce once;
+            if (int rc2 = raise_lds_limit(reinterpret_cast<const void*>(mel_decoder_rows_kernel<3>), once)) return rc2;
+            ESMI_LAUNCH((mel_decoder_rows_kernel<3>), rgrid, dim3(kRowsThreads), lds, st, p);
+        }
+        return launch_status();
+    }
     p.n_tiles = (L_out + p.TL - 1) / p.TL;
     dim3 grid((unsigned)(p.n_tiles * ((B + 7) / 8) * 8)), block(kDecThreads);
-    hipStream_t st = S(stream);
 #ifndef ESMI_DEC_NW256
 #define ESMI_DEC_NW256 8    // waves per window of the dx2 = 256 decoder (small / base ES): 8, or 16 (measured 30 % slower: 65 spilled
                             // VGPRs at the 128-register budget and twice the weight traffic; small ES decoder 2.43 vs 1.87 ms)
@@ -950,6 +990,19 @@ int esmi_mel_decoder_f32(const float* blob, const esmi_decoder_shape* s, const f
     else ESMI_DEC_CASE(256, 3, ESMI_DEC_NW256)
 #undef ESMI_DEC_CASE
     return launch_status();
+}
+
+int esmi_mel_decoder_f32(const float* blob, const esmi_decoder_shape* s, const float* x, const float* h0,
+                         const int32_t* cum, const int32_t* mel_len, const int32_t* lmax_dev, int lmax_host, int apply_mask, int B, int T,
+                         int L_out, float* mel, esmi_stream_t stream) {
+    const bool rows = ESMI_DEC_ROWS && h0 && s && s->dx2 == 128 && ESMI_DEC_SPLIT == 2 &&
+                      4 * (s->kernel / 2) * s->n_blocks * s->block_depth <= kRowsWin;
+    return mel_decoder_launch(blob, s, x, h0, cum, mel_len, lmax_dev, lmax_host, apply_mask, B, T, L_out, mel, stream, rows);
+}
+int esmi_mel_decoder_rows_f32(const float* blob, const esmi_decoder_shape* s, const float* x, const float* h0,
+                              const int32_t* cum, const int32_t* mel_len, const int32_t* lmax_dev, int lmax_host, int apply_mask, int B,
+                              int T, int L_out, float* mel, esmi_stream_t stream) {
+    return mel_decoder_launch(blob, s, x, h0, cum, mel_len, lmax_dev, lmax_host, apply_mask, B, T, L_out, mel, stream, true);
 }
 
 // ------------------------------------------------------------------ HiFi-GAN generator

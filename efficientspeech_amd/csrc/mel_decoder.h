@@ -82,6 +82,8 @@ struct DecLayout {  // offsets in floats into the packed blob
     long l_dw, l_dwb, l_pw, l_pwb, l_g, l_b;   // relative to the layer base
     long skip0;                                // per block: gain[dx2], bias[dx2]
     long mel_w, mel_b;
+    long rows0, rows_layer_stride, rows_mel, rows_pad;   // row-owner form (mel_decoder_rows.h; dx2 = 128 split build only, else rows0 = -1):
+                                                         // per layer [A fragments 16384 | taps kd*128 | pwb' | ln_g | ln_b], mel fragments, pad row
     long total;
 };
 
@@ -104,6 +106,13 @@ inline DecLayout dec_layout(int d4, int dx2, int kd, int n_blocks, int block_dep
     L.skip0 = o; o += 2L * dx2 * n_blocks;
     L.mel_w = o; o += (long)dx2 * dx2 * kWNum / 2;   // packed like a dx2 x dx2 matrix, rows >= n_mel zero
     L.mel_b = o; o += dx2;                     // zero padded
+    L.rows0 = -1; L.rows_layer_stride = 0; L.rows_mel = 0; L.rows_pad = 0;
+    if (dx2 == 128 && ESMI_DEC_SPLIT == 2) {
+        L.rows_layer_stride = 16384 + (long)(kd + 3) * 128;
+        L.rows0 = o; o += L.rows_layer_stride * n_blocks * block_depth;
+        L.rows_mel = o; o += 12288;
+        L.rows_pad = o; o += 128;
+    }
     L.total = o;
     return L;
 }
