@@ -194,7 +194,7 @@ def bind(lib):
     lib.esmi_forward_arena_bytes.argtypes = [P(ForwardArgs)]
     lib.esmi_forward_arena_bytes.restype = sz
     lib.esmi_phoneme2mel_forward_f32.argtypes = [P(ForwardArgs), i, fp]
-    i64, f = C.c_int64, C.c_float
+    i64, f, dbl = C.c_int64, C.c_float, C.c_double
     lib.esmi_train_conv_fwd_f32.argtypes = [P(ConvDesc), fp, fp, fp, fp, fp, sz, fp]
     lib.esmi_train_conv_workspace_bytes.argtypes = [P(ConvDesc)]
     lib.esmi_train_conv_workspace_bytes.restype = sz
@@ -220,8 +220,8 @@ def bind(lib):
     lib.esmi_train_repeat_fwd_f32.argtypes = [fp, fp, i, i, i, i, fp, fp]
     lib.esmi_train_repeat_bwd_f32.argtypes = [fp, fp, i, i, i, i, fp, fp]
     lib.esmi_train_loss_f32.argtypes = [P(TrainLossArgs), fp]
-    lib.esmi_train_adamw_f32.argtypes = [fp, fp, fp, fp, i64, f, f, f, f, f, i, fp]
-    lib.esmi_train_adamw_graph_f32.argtypes = [fp, fp, fp, fp, i64, fp, f, f, f, f, fp, fp]
+    lib.esmi_train_adamw_f32.argtypes = [fp, fp, fp, fp, i64, dbl, dbl, dbl, dbl, dbl, i, fp]
+    lib.esmi_train_adamw_graph_f32.argtypes = [fp, fp, fp, fp, i64, fp, dbl, dbl, dbl, dbl, fp, fp]
     lib.esmi_pack_resblock_bytes.argtypes = [i, i]
     lib.esmi_pack_resblock_bytes.restype = sz
     lib.esmi_pack_resblock_f16.argtypes = [fp, fp, i, i, fp]

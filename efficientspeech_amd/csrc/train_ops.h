@@ -722,41 +722,50 @@ __global__ void train_loss_grad_kernel(const LossP p) {
     }
 }
 
-// ---- AdamW, torch.optim.AdamW's arithmetic (decoupled decay first, bias corrections as two scalars), over a flat buffer
-__global__ void train_adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
-                                   long n, float lr, float beta1, float beta2, float eps, float wd, float bc1, float bc2_sqrt) {
-    const long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (q >= n) return;
+// ---- AdamW, torch.optim.AdamW's arithmetic (decoupled decay first, bias corrections as two scalars), over a flat buffer.
+// Every scalar is derived in double precision (host, or one device thread for the graph variant) and rounded to fp32 once.
+struct AdamWScalars { float beta1, one_m_beta1, beta2, one_m_beta2, eps, decay /* 1 - lr wd */, step_size /* lr / bc1 */, bc2_sqrt; };
+
+__device__ __forceinline__ void adamw_update(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                             float* __restrict__ v, long q, const AdamWScalars& h) {
     const float grad = g[q];
-    float w = p[q] * (1.0f - lr * wd);
-    const float mm = beta1 * m[q] + (1.0f - beta1) * grad;
-    const float vv = beta2 * v[q] + (1.0f - beta2) * grad * grad;
+    float w = p[q] * h.decay;
+    const float mm = h.beta1 * m[q] + h.one_m_beta1 * grad;
+    const float vv = h.beta2 * v[q] + h.one_m_beta2 * grad * grad;
     m[q] = mm;
     v[q] = vv;
-    const float denom = sqrtf(vv) / bc2_sqrt + eps;
-    w -= (lr / bc1) * (mm / denom);
+    const float denom = sqrtf(vv) / h.bc2_sqrt + h.eps;
+    w -= h.step_size * (mm / denom);
     p[q] = w;
 }
 
+__global__ void train_adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                   long n, AdamWScalars h) {
+    const long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q < n) adamw_update(p, g, m, v, q, h);
+}
+
 // the same with the step count and the learning rate read from device memory, so that a captured hipGraph of the whole
-// training step replays correctly: hyper = {lr}; *step is advanced by train_bump_step_kernel inside the graph
-__global__ void train_bump_step_kernel(int* __restrict__ step) { if (threadIdx.x == 0) step[0] += 1; }
+// training step replays correctly: hyper = {lr (caller), 1 - lr wd, lr / bc1, sqrt(bc2)}; *step is advanced and the three derived
+// scalars are written by train_bump_step_kernel (one thread, double precision) inside the graph
+__global__ void train_bump_step_kernel(int* __restrict__ step, float* __restrict__ hyper, double beta1, double beta2, double wd) {
+    if (threadIdx.x != 0) return;
+    const int t = step[0] + 1;
+    step[0] = t;
+    const double lr = (double)hyper[0];
+    const double bc1 = -expm1((double)t * log(beta1)), bc2 = -expm1((double)t * log(beta2));
+    hyper[1] = (float)(1.0 - lr * wd);
+    hyper[2] = (float)(lr / bc1);
+    hyper[3] = (float)sqrt(bc2);
+}
 __global__ void train_adamw_dev_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
-                                       long n, const float* __restrict__ lr_dev, float beta1, float beta2, float eps, float wd,
-                                       const int* __restrict__ step) {
+                                       long n, AdamWScalars h, const float* __restrict__ hyper) {
     const long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= n) return;
-    const float lr = lr_dev[0], t = (float)step[0];
-    const float bc1 = 1.0f - powf(beta1, t), bc2_sqrt = sqrtf(1.0f - powf(beta2, t));
-    const float grad = g[q];
-    float w = p[q] * (1.0f - lr * wd);
-    const float mm = beta1 * m[q] + (1.0f - beta1) * grad;
-    const float vv = beta2 * v[q] + (1.0f - beta2) * grad * grad;
-    m[q] = mm;
-    v[q] = vv;
-    const float denom = sqrtf(vv) / bc2_sqrt + eps;
-    w -= (lr / bc1) * (mm / denom);
-    p[q] = w;
+    h.decay = hyper[1];
+    h.step_size = hyper[2];
+    h.bc2_sqrt = hyper[3];
+    adamw_update(p, g, m, v, q, h);
 }
 
 }  // namespace esmi

@@ -498,7 +498,7 @@ class TrainStep:
         if self.graph:
             dev = self.flat.data.device
             self._step_dev = torch.zeros(1, dtype=torch.int32, device=dev)
-            self._lr_dev = torch.full((1,), lr, dtype=torch.float32, device=dev)
+            self._lr_dev = torch.full((4,), lr, dtype=torch.float32, device=dev)   # ESMI_TRAIN_ADAMW_HYPER_FLOATS: [0] = lr
 
     # ---- checkpoint / resume (what Lightning's ModelCheckpoint keeps: weights under `state_dict`, AdamW moments and step count)
     def state_dict(self):
@@ -530,10 +530,15 @@ class TrainStep:
         self._invalidate_packed()
 
     def _invalidate_packed(self):
-        for m in self.net.modules():               # the kernel wrote the weights behind torch's version counters: drop the
-            c = getattr(m, "_cache", None)         # inference path's packed copies so the next eval forward re-packs
-            if c is not None and hasattr(c, "invalidate"):
-                c.invalidate()
+        """The optimizer kernel wrote the weights behind torch's version counters: drop EVERY packed copy the inference path
+        keeps (each module's `_PackCache` attributes, whatever their names -- the decoder has two -- and the one-call
+        forward's argument block) so that the next eval forward re-packs from the updated parameters."""
+        for m in self.net.modules():
+            for v in list(m.__dict__.values()):
+                if isinstance(v, networks._PackCache):
+                    v.invalidate()
+            if hasattr(m, "_fwd_ident"):
+                m._fwd_ident = None
 
     def _body(self, x, y, lr, graph):
         f = self.flat
@@ -561,7 +566,7 @@ class TrainStep:
             out = self._body(x, y, lr, False)
             self._invalidate_packed()
             return out
-        self._lr_dev.fill_(lr)
+        self._lr_dev[:1].fill_(lr)
         key = tuple((k, tuple(v.shape)) for k, v in sorted({**x, **{"y." + k: v for k, v in y.items()}}.items()) if torch.is_tensor(v))
         ent = self._graphs.get(key)
         if ent is None:

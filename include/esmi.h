@@ -495,13 +495,18 @@ typedef struct esmi_train_loss_args {
     float* scratch;                         /* ESMI_TRAIN_LOSS_SCRATCH_FLOATS floats (partial sums of the two-stage reduction) */
 } esmi_train_loss_args;
 int esmi_train_loss_f32(const esmi_train_loss_args* a, esmi_stream_t stream);
-/* torch.optim.AdamW's update of one flat buffer; step >= 1 */
-int esmi_train_adamw_f32(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
-                         float weight_decay, int step, esmi_stream_t stream);
-/* the same update for a captured hipGraph of the whole step: the learning rate (1 float) and the step counter (1 int32, advanced
- * by this call before the update) live in device memory, so a replay uses the current values */
-int esmi_train_adamw_graph_f32(float* p, const float* g, float* m, float* v, int64_t n, const float* lr_dev, float beta1, float beta2,
-                               float eps, float weight_decay, int32_t* step_dev, esmi_stream_t stream);
+/* torch.optim.AdamW's update of one flat buffer (model.py:279-283); step >= 1.  The hyper-parameters are doubles, as the Python
+ * scalars torch.optim.AdamW holds them: the bias corrections 1 - beta^step are evaluated in double precision on the host and
+ * every derived scalar (1 - beta, lr * weight_decay, lr / bc1, sqrt(bc2)) is rounded to fp32 once, like torch's scalar arguments */
+int esmi_train_adamw_f32(float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1, double beta2, double eps,
+                         double weight_decay, int step, esmi_stream_t stream);
+/* the same update for a captured hipGraph of the whole step: hyper_dev = ESMI_TRAIN_ADAMW_HYPER_FLOATS floats in device memory
+ * ([0] = learning rate, written by the caller before a replay; the rest is scratch of this call: the bias corrections of the
+ * current step, evaluated in double precision by one device thread) and the step counter (1 int32, advanced by this call before
+ * the update), so a replay uses the current values */
+#define ESMI_TRAIN_ADAMW_HYPER_FLOATS 4
+int esmi_train_adamw_graph_f32(float* p, const float* g, float* m, float* v, int64_t n, float* hyper_dev, double beta1, double beta2,
+                               double eps, double weight_decay, int32_t* step_dev, esmi_stream_t stream);
 
 #ifdef __cplusplus
 }

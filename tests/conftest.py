@@ -15,3 +15,15 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_collection_modifyitems(config, items):
+    """`gpu`-marked tests need a device: on a machine without one (the build container) a plain `pytest tests/` skips them
+    instead of failing with 'No HIP GPUs are available'.  `-m gpu` on the GPU box runs them all."""
+    import torch
+    if torch.cuda.is_available():
+        return
+    skip = pytest.mark.skip(reason="needs a real MI355X (no GPU visible)")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)

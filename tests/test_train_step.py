@@ -120,25 +120,45 @@ def test_gpu_adamw_step_matches_reference():
     check_adamw_step("cuda")
 
 
-@pytest.mark.gpu
-def test_gpu_training_reduces_the_loss_and_inference_sees_the_update():
-    train, g, net, x, y = _setup("cuda")
-    step = train.TrainStep(net, lr=1e-3)
-    first = float(step.step(x, y)[4])
-    for _ in range(20):
-        last = float(step.step(x, y)[4])
-    assert last < 0.9 * first, (first, last)
-    xe = {"phoneme": x["phoneme"], "phoneme_mask": x["phoneme_mask"]}
+def check_inference_sees_the_update(dev, steps):
+    """An eval forward BEFORE training fills every packed-weight cache of the inference path (encoder blocks, fuse, predictors,
+    decoder blob, the decoder HEAD the fused variance-adaptor kernel reads on tiny ES, the one-call argument block).  The AdamW
+    kernel then writes the weights through raw pointers -- no torch version counter moves -- so `TrainStep` must drop every one
+    of those copies: the eval output after training has to equal a FRESH net loaded from net.state_dict()."""
+    train, g, net, x, y = _setup(dev)
+    xe = {"phoneme": x["phoneme"], "phoneme_mask": x["phoneme_mask"], "duration_forced": x["duration"]}
     net.eval()
     with torch.no_grad():
         before = net(xe)[0].clone()
     net.train()
-    step.step(x, y)
+    step = train.TrainStep(net, lr=1e-3)
+    first = float(step.step(x, y)[4])
+    for _ in range(steps - 1):
+        last = float(step.step(x, y)[4])
     net.eval()
     with torch.no_grad():
-        after = net(xe)[0]
-    assert bool(torch.isfinite(before).all()) and after.shape[0] == before.shape[0]
-    assert not torch.equal(after[:, :8], before[:, :8])                 # the inference path re-packed the updated weights
+        after = net(xe)[0].clone()
+    cfg = CONFIGS["tiny"]
+    fresh = build_phoneme2mel(cfg)
+    fresh.load_state_dict({k: v.detach().cpu().clone() for k, v in net.state_dict().items()}, strict=True)
+    fresh = fresh.to(dev).eval()
+    with torch.no_grad():
+        want = fresh(xe)[0]
+    assert bool(torch.isfinite(before).all()) and after.shape == before.shape
+    assert float((after - before).abs().max()) > 1e-3                  # the weights moved ...
+    assert torch.equal(after, want), float((after - want).abs().max())  # ... and every packed copy followed them (same kernels, same weights: bitwise)
+    return first, last
+
+
+@pytest.mark.gpu
+def test_gpu_training_reduces_the_loss_and_inference_sees_the_update():
+    first, last = check_inference_sees_the_update("cuda", 21)
+    assert last < 0.9 * first, (first, last)
+
+
+def test_simulated_inference_sees_the_update():
+    with use_sim():
+        check_inference_sees_the_update("cpu", 3)
 
 
 @pytest.mark.gpu
@@ -344,69 +364,132 @@ def test_torch_mirror_matches_reference_fixture(gold):
             assert np.abs(mine - ref).max() < 2e-5 * max(1e-6, np.abs(ref).max()), k
 
 
-@pytest.mark.gpu
-@pytest.mark.parametrize("name,B,T", [("tiny", 6, 97), ("small", 3, 61)])
-def test_gpu_gradients_match_torch_mirror_at_size(name, B, T, monkeypatch):
-    """Every parameter gradient of the HIP training step against torch.autograd over the plain-PyTorch mirror, on a ragged batch
-    with ~100 phonemes / ~350 frames per utterance: several row chunks in every reduction, odd lengths through the stride-2
-    blocks, pooled masks, cropped ConvTranspose outputs -- what the 13-phoneme reference fixtures cannot reach."""
-    from efficientspeech_amd import train
-    from efficientspeech_amd.synth import synth_phonemes
-    from tests import torch_mirror as M
-    dev = "cuda"
+# ---------------------------------------------------------------------------------------------------------------- at size
+# Seeds of the at-size cases, chosen by tools/find_margin_seed.py so that every kink of the training graph (the predictor ReLUs,
+# the duration head's ReLU, the L1 loss's |.|) sits at least KINK_MARGIN away from zero in the fp64 reference run: SURVEY 7
+# "discrete decisions ... tests must exempt/flag elements within 1e-5 of a boundary".  Round 2's seed had an
+# energy_decoder.conv1 pre-activation 3.7e-7 from zero; two correct fp32 implementations landed on opposite sides of it and the
+# test's verdict depended on the box's MIOpen build.
+KINK_MARGIN = 2e-5
+AT_SIZE = {"tiny": (6, 97, 26), "small": (3, 61, 15)}           # name -> (B, T, seed)
+
+
+def at_size_case(name, seed=None):
+    """A ragged teacher-forced batch with ~100 phonemes / ~350 frames per utterance: several row chunks in every reduction, odd
+    lengths through the stride-2 blocks, pooled masks, cropped ConvTranspose outputs, zero-length phonemes -- what the
+    13-phoneme reference fixtures cannot reach.  -> (cfg, numpy state dict, x, y) on the CPU."""
+    B, T, seed0 = AT_SIZE[name]
+    seed = seed0 if seed is None else seed
     cfg = CONFIGS[name]
-    sd = synth_state_dict(cfg, 1234)
-    nets = []
-    for _ in range(2):
-        n = build_phoneme2mel(cfg)
-        n.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
-        nets.append(n.to(dev).train())
-    rng = np.random.default_rng(3)
+    from efficientspeech_amd.synth import synth_phonemes
+    rng = np.random.default_rng(seed)
     lens = sorted(rng.integers(T // 3, T + 1, B).tolist(), reverse=True)
     lens[0] = T
-    ids, mask = synth_phonemes(B, T, 11, lens)
+    ids, mask = synth_phonemes(B, T, 11 + seed, lens)
     dur = rng.integers(0, 7, (B, T)).astype(np.int32)
     dur[mask] = 0
     mel_len = dur.sum(1)
     L = int(mel_len.max())
-    t = lambda a: torch.from_numpy(a).to(dev)      # noqa: E731
+    t = torch.from_numpy
     x = {"phoneme": t(ids), "phoneme_mask": t(mask), "pitch": t(rng.uniform(-3, 11, (B, T)).astype(np.float32)),
          "energy": t(rng.uniform(-2, 8, (B, T)).astype(np.float32)), "duration": t(dur), "mel_len": t(mel_len.astype(np.int32)),
          "mel_mask": t(np.arange(L)[None, :] >= mel_len[:, None])}
     y = {"mel": t(rng.normal(-5, 2, (B, L, 80)).astype(np.float32))}
-    out = M.train_forward(nets[1], dict(x, mel=y["mel"]))
-    rparts, rtotal = M.loss(out, x, y)
-    rtotal.backward()
-    ref = dict(nets[1].named_parameters())
-    sd0 = {k: v.clone() for k, v in nets[0].state_dict().items()}
-    for matrix_pipe in (False, True):
-        monkeypatch.setattr(train, "USE_MATRIX_PIPE", matrix_pipe)
-        for p in nets[0].parameters():
-            p.grad = None
-        parts, total = train.training_loss(nets[0], x, y)
+    return cfg, synth_state_dict(cfg, 1234), x, y
+
+
+def fp64_reference(cfg, sd, x, y, backward=True):
+    """Loss, every parameter gradient and the kink margins of the case from the plain-PyTorch mirror on the CPU in float64:
+    deterministic on every box (no MIOpen / hipBLASLt in the checker), round-off 1e-15 -- the reference the fp32 kernels are
+    measured against.  -> (total, {name: grad or None}, {kink: min |input|})."""
+    from tests import torch_mirror as M
+    net = build_phoneme2mel(cfg)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    net = net.double().train()
+    for k, p in net.named_parameters():
+        p.requires_grad_(not k.endswith("_bins"))
+    dbl = lambda d: {k: (v.double() if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in d.items()}   # noqa: E731
+    x64, y64 = dbl(x), dbl(y)
+    M.TAPS = {}
+    try:
+        out = M.train_forward(net, dict(x64, mel=y64["mel"]))
+        _, total = M.loss(out, x64, y64)
+        taps = dict(M.TAPS)
+    finally:
+        M.TAPS = None
+    if backward:
         total.backward()
-        assert abs(float(total.detach()) - float(rtotal.detach())) < 2e-5 * float(rtotal.detach())
-        errs, dots = [], [0.0, 0.0, 0.0]
-        for k, p in nets[0].named_parameters():
-            if ref[k].grad is None:
-                assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
-                continue
-            r, m = ref[k].grad.double(), p.grad.double()
-            errs.append((float((m - r).abs().max()) / max(1e-6, float(r.abs().max())), k))
-            dots = [dots[0] + float((m * r).sum()), dots[1] + float((m * m).sum()), dots[2] + float((r * r).sum())]
-        assert len(errs) >= 100
-        if not matrix_pipe:
-            # plain fp32 kernels: every gradient agrees with torch.autograd to fp32 round-off -- the composition is exact at size
-            assert max(errs)[0] < 2e-5, max(errs)
-        else:
-            # split-f16 GEMMs round differently from PyTorch's fp32 convolutions, so a ReLU input that sits within 1e-7 of zero
-            # can take the other branch (measured: one element of 18,624 in a predictor conv); its whole contribution then moves
-            # the few gradients fed through it by ~1/rows.  Everything else agrees to 1e-5, and the full gradient vector to 1e-6.
-            errs.sort()
-            assert errs[len(errs) // 2][0] < 1e-5 and errs[int(len(errs) * 0.5)][0] < 1e-5, errs[len(errs) // 2]
-            assert max(errs)[0] < 1e-2, max(errs)
-            cos = dots[0] / (dots[1] ** 0.5 * dots[2] ** 0.5)
-            assert 1.0 - cos < 1e-6, cos
+    return float(total.detach()), {k: (None if p.grad is None else p.grad.clone()) for k, p in net.named_parameters()}, taps
+
+
+def check_gradients_at_size(dev, name, perturb=None):
+    """Every parameter gradient of the training step's kernels (both operator paths) against the fp64 mirror, per parameter,
+    relative to the parameter's largest gradient.  `perturb`: a function applied to the kernels' gradients before the
+    comparison (the self-test below shows the bounds catch a 1e-3 error in one tensor)."""
+    from efficientspeech_amd import train
+    cfg, sd, x, y = at_size_case(name)
+    rtotal, ref, taps = fp64_reference(cfg, sd, x, y)
+    assert len(taps) == 11 and min(taps.values()) > KINK_MARGIN, (
+        "the at-size case has a kink input within the margin; pick another seed with tools/find_margin_seed.py", taps)
+    net = build_phoneme2mel(cfg)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    net = net.to(dev).train()
+    xd, yd = ({k: v.to(dev) for k, v in d.items()} for d in (x, y))
+    worst = {}
+    old = train.USE_MATRIX_PIPE
+    try:
+        for matrix_pipe, bound in ((False, FP32_BOUND), (True, SPLIT_BOUND)):
+            train.USE_MATRIX_PIPE = matrix_pipe
+            for p in net.parameters():
+                p.grad = None
+            parts, total = train.training_loss(net, xd, yd)
+            total.backward()
+            assert abs(float(total.detach()) - rtotal) < 2e-5 * rtotal, (float(total.detach()), rtotal)
+            errs = []
+            for k, p in net.named_parameters():
+                if ref[k] is None:
+                    assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
+                    continue
+                m = p.grad.detach().double().cpu()
+                if perturb is not None:
+                    m = perturb(k, m)
+                errs.append((float((m - ref[k]).abs().max()) / max(1e-6, float(ref[k].abs().max())), k))
+            assert len(errs) >= 100
+            worst[matrix_pipe] = max(errs)
+            assert max(errs)[0] < bound, (matrix_pipe, sorted(errs)[-5:])
+    finally:
+        train.USE_MATRIX_PIPE = old
+    return worst
+
+
+# per-parameter bounds (max |g - g_ref| / max |g_ref|) against the fp64 reference, no kink within the margin.  Measured on the
+# simulator (tools/find_margin_seed.py --errors): plain-fp32 kernels 1.1e-6, split-f16 GEMMs 3.6e-6 (tiny); 1.4e-6 / 3.2e-6 (small).
+FP32_BOUND = 1e-5
+SPLIT_BOUND = 2e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["tiny", "small"])
+def test_gpu_gradients_match_fp64_mirror_at_size(name):
+    check_gradients_at_size("cuda", name)
+
+
+def test_simulated_gradients_match_fp64_mirror_at_size():
+    """The CPU-tier twin of the GPU test above (tiny ES, the same case, the same bounds) on the wave simulator."""
+    with use_sim():
+        check_gradients_at_size("cpu", "tiny")
+
+
+def test_at_size_check_catches_a_perturbed_gradient():
+    """The bounds are tight enough to see a kernel that is wrong by 1e-3 of one tensor's scale in one element."""
+    def perturb(k, m):
+        if k == "encoder.energy_decoder.conv1.0.weight":
+            m = m.clone()
+            m.view(-1)[7] += 1e-3 * float(m.abs().max())
+        return m
+    with use_sim():
+        with pytest.raises(AssertionError, match="energy_decoder.conv1.0.weight"):
+            check_gradients_at_size("cpu", "tiny", perturb)
 
 
 @pytest.mark.parametrize("B,T,lens", [(2, 1, [1, 1]), (1, 2, [2]), (3, 5, [5, 2, 1])], ids=["T1", "B1_T2", "ragged_T5"])

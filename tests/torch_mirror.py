@@ -5,6 +5,23 @@ reference-generated training fixtures (tests/test_train_step.py::test_torch_mirr
 import torch
 import torch.nn.functional as F
 
+# Kink margins (SURVEY 7 "discrete decisions"): when a test sets TAPS = {} before a forward, every input of a non-smooth
+# operation of the training graph -- the nine predictor ReLUs, the duration head's ReLU, |mel - target| of the L1 loss -- records
+# min |value| here.  Two correct fp32 implementations may put an element closer to zero than their own rounding on opposite
+# sides of the kink; its whole contribution to the gradients then moves (~1/rows).  A test case whose margins are below 1e-5
+# is not a test of the kernels.
+TAPS = None
+
+
+def _tap(name, t, where=None):
+    if TAPS is not None:
+        v = t.detach().abs()
+        if where is not None:
+            v = v.masked_select(where)
+        if v.numel():
+            TAPS[name] = min(TAPS.get(name, float("inf")), float(v.min()))
+    return t
+
 
 def _conv(x, m):                         # channels-last wrapper around nn.Conv1d / ConvTranspose1d parameter containers
     if isinstance(m, torch.nn.Linear):
@@ -28,12 +45,12 @@ def _pool_mask(mask, n, n_out):          # blocks.py:51-57
     return mask.reshape(mask.shape[0], -1, pool).max(dim=-1).values[:, :n_out]
 
 
-def _predictor(dec, fused):
-    y = F.relu(_conv(fused, dec.conv1[0]))
-    y = F.relu(_ln(y, dec.norm1))
-    y = F.relu(_conv(y, dec.conv2[0]))
+def _predictor(dec, fused, tag="predictor"):
+    y = F.relu(_tap(tag + ".conv1", _conv(fused, dec.conv1[0])))
+    y = F.relu(_tap(tag + ".norm1", _ln(y, dec.norm1)))
+    y = F.relu(_tap(tag + ".conv2", _conv(y, dec.conv2[0])))
     pred = _conv(y, dec.linear)
-    return (F.relu(pred), _ln(y, dec.norm2)) if dec.duration else (pred, None)
+    return (F.relu(_tap(tag + ".linear", pred)), _ln(y, dec.norm2)) if dec.duration else (pred, None)
 
 
 def train_forward(net, x, stop_after_predictors=False, fused=None, preds=None):
@@ -70,9 +87,9 @@ def train_forward(net, x, stop_after_predictors=False, fused=None, preds=None):
     fused = _conv(torch.cat(parts, -1), pe.fuse.fuse)
     if mask is not None:
         fused = fused.masked_fill(mask[..., None], 0)
-    pitch_pred, _ = _predictor(pe.pitch_decoder, fused)
-    energy_pred, _ = _predictor(pe.energy_decoder, fused)
-    dur_pred, dur_feat = _predictor(pe.duration_decoder, fused)
+    pitch_pred, _ = _predictor(pe.pitch_decoder, fused, "pitch")
+    energy_pred, _ = _predictor(pe.energy_decoder, fused, "energy")
+    dur_pred, dur_feat = _predictor(pe.duration_decoder, fused, "duration")
     if stop_after_predictors:
         return {"pitch": pitch_pred, "energy": energy_pred, "duration": dur_pred, "dur_feat": dur_feat, "fused": fused}
     return _after_encoder(net, x, fused, pitch_pred, energy_pred, dur_pred, dur_feat)
@@ -132,6 +149,7 @@ def eval_forward(net, x):
 def loss(out, x, y):
     mm, pm = ~x["mel_mask"][..., None], ~x["phoneme_mask"]
     sel = lambda t: t.reshape(pm.shape).masked_select(pm)      # noqa: E731
+    _tap("l1", out["mel"] - y["mel"], mm.expand_as(out["mel"]))
     parts = [F.l1_loss(out["mel"].masked_select(mm), y["mel"].masked_select(mm)),
              F.mse_loss(sel(out["pitch"]), x["pitch"].masked_select(pm)), F.mse_loss(sel(out["energy"]), x["energy"].masked_select(pm)),
              F.mse_loss(torch.log(sel(out["duration"]) + 1), torch.log(x["duration"].masked_select(pm).to(out["duration"].dtype) + 1))]
