@@ -299,7 +299,7 @@ __global__ __launch_bounds__(256) void convgemm_kernel(const ConvGemmP p) {
 // ---- a convolution down to ONE output channel (HiFi-GAN conv_post, hifigan/models.py:123-125: 8..32 channels -> 1, k = 7,
 // tanh): 1/32 of an MFMA tile's columns would be used, and the op is a plain read of the input (C floats per sample).
 // One thread per output position, fp32 FMAs in tap-major / channel order; neighbouring threads share their rows in L1.
-__global__ __launch_bounds__(256) void conv_to1_kernel(const ConvGemmP p) {
+static __global__ __launch_bounds__(256) void conv_to1_kernel(const ConvGemmP p) {
     const long q = (long)blockIdx.x * 256 + threadIdx.x;
     if (q >= (long)p.B * p.n_out) return;
     const int b = (int)(q / p.n_out), t = (int)(q - (long)b * p.n_out);

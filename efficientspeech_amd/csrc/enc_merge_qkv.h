@@ -29,7 +29,7 @@ struct EncMergeP {
 };
 
 // W'[j][o][i] = sum_m W1[o][m] * Wm[j][m][i]     (fp64 accumulation, once per checkpoint)
-__global__ void compose_merge_kernel(const float* __restrict__ wm, const float* __restrict__ w1, float* __restrict__ dst, int k,
+static __global__ void compose_merge_kernel(const float* __restrict__ wm, const float* __restrict__ w1, float* __restrict__ dst, int k,
                                      int cin, int cout) {
     const long n = (long)k * cout * cin;
     for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {

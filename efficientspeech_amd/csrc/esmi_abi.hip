@@ -1,273 +1,12 @@
 // esmi C-ABI: the host-side launch sequences behind include/esmi.h.
 // Built by `hipcc --offload-arch=gfx950` into libesmi.so (product) and, unchanged, by the host
 // clang++ with -DESMI_WAVESIM into libesmi_sim.so (CPU wave simulator used only by tests).
-#include "../../include/esmi.h"
-
-#include <cmath>
-#include <cstring>
-
-#include "attention.h"
-#include "convgemm.h"
-#include "hifigan_resblock.h"
-#include "train_ops.h"
-#include "enc_attn_ffn.h"
-#include "enc_fuse_va.h"
-#include "enc_merge_qkv.h"
-#include "esmi_dev.h"
-#include "mel_decoder.h"
-#include "mel_decoder_rows.h"
-#include "small_kernels.h"
-
-#ifndef ESMI_GEMM_LDS_MIN_ROWS   // rows (B * n_out) from which the per-op plan's GEMMs take the LDS-staged kernel
-#ifdef ESMI_WAVESIM
-#define ESMI_GEMM_LDS_MIN_ROWS 1   // the simulator tests are small: run them through it too
-#else
-#define ESMI_GEMM_LDS_MIN_ROWS 2048
-#endif
-#endif
+#include "launch.h"
+#include "mel_decoder.h"   // esmi_decoder_shape helpers used by the one-call forward
 
 using namespace esmi;
 
 namespace {
-
-inline hipStream_t S(esmi_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
-inline int launch_status() {
-    const hipError_t e = hipGetLastError();
-    return e == hipSuccess ? ESMI_OK : (int)e;
-}
-inline size_t align256(size_t n) { return (n + 255) & ~(size_t)255; }
-
-// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a PER-DEVICE setting: remember per (instantiation, device ordinal) that
-// it was made (once: keeps the call out of hipGraph captures).  `done` is one static table per call site.
-constexpr int kMaxDevices = 64;
-struct AttrOnce { bool done[kMaxDevices] = {}; };
-inline int raise_lds_limit(const void* fn, AttrOnce& once) {
-#ifndef ESMI_WAVESIM
-    int dev = 0;
-    hipError_t e = hipGetDevice(&dev);
-    if (e != hipSuccess) return (int)e;
-    if (dev < 0 || dev >= kMaxDevices) return ESMI_ERR_UNSUPPORTED;
-    if (!once.done[dev]) {
-        e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return (int)e;
-        once.done[dev] = true;
-    }
-#endif
-    return ESMI_OK;
-}
-inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
-
-ConvGemmP conv_defaults() {
-    ConvGemmP p;
-    memset(&p, 0, sizeof p);
-    p.k = 1; p.stride = 1; p.pad = 0; p.mode = MODE_CONV;
-    return p;
-}
-
-// full_row: the epilogue needs a whole output row inside one wave (LayerNorm / row-dot)
-int launch_convgemm(ConvGemmP p, hipStream_t st) {
-    if ((p.c_in & 7) || p.c_in <= 0 || p.c_out <= 0 || p.n_out <= 0 || p.B <= 0) return ESMI_ERR_ARG;
-    if (!p.W || !aligned16(p.W)) return ESMI_ERR_ARG;
-    if (p.ids) {
-        if (!p.table || (p.ld_table & 3) || !aligned16(p.table)) return ESMI_ERR_ARG;
-    } else if (!p.A || (p.lda & 3) || (p.a_coff & 3) || !aligned16(p.A)) return ESMI_ERR_ARG;
-    const bool full_row = p.ln_g || p.dot_out;
-    if (p.c_out == 1 && p.mode == MODE_CONV && p.stride == 1 && !p.ids && !full_row && !p.res && !p.rowmask && p.out) {
-        const long n = (long)p.B * p.n_out;
-        ESMI_LAUNCH(conv_to1_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p);
-        return launch_status();
-    }
-    int nt;
-    if (full_row) {
-        nt = (p.c_out + 31) / 32;
-        if (nt == 3) nt = 4;
-        if (nt > 4 && nt <= 8) nt = 8;
-        if (nt > 8) return ESMI_ERR_UNSUPPORTED;
-        if (p.ln_g && p.c_out != 32 * nt) return ESMI_ERR_UNSUPPORTED;  // LN width must be 32/64/128/256
-    } else {
-        nt = p.c_out > 64 ? 4 : (p.c_out > 32 ? 2 : 1);
-    }
-#if ESMI_CHAIN_SPLIT
-    // large plain convolutions / Linears: weight tile staged through LDS once per 128 positions (convgemm.h)
-    if (p.mode == MODE_CONV && p.stride == 1 && !p.ids && (p.c_in & 31) == 0 && p.c_out > 64 && (long)p.B * p.n_out >= ESMI_GEMM_LDS_MIN_ROWS) {
-        const int nl = full_row ? (nt <= 4 ? 4 : 8) : ((p.c_out & 255) == 0 ? 8 : 4);
-        constexpr int kRows = 32 * ESMI_GEMM_LDS_WAVES;
-        dim3 g2((unsigned)(p.B * ((p.n_out + kRows - 1) / kRows)), full_row ? 1 : (p.c_out + 32 * nl - 1) / (32 * nl));
-        if (nl == 4) {
-            ESMI_LAUNCH((convgemm_lds_kernel<4>), g2, dim3(64 * ESMI_GEMM_LDS_WAVES), convgemm_lds_bytes<4>(), st, p);
-        } else {
-            static AttrOnce once;
-            if (int rc = raise_lds_limit(reinterpret_cast<const void*>(convgemm_lds_kernel<8>), once)) return rc;
-            ESMI_LAUNCH((convgemm_lds_kernel<8>), g2, dim3(64 * ESMI_GEMM_LDS_WAVES), convgemm_lds_bytes<8>(), st, p);
-        }
-        return launch_status();
-    }
-#endif
-    const int tiles = p.B * convgemm_tiles_per_phase(p) * convgemm_row_stride(p);
-    dim3 grid((tiles + 3) / 4, full_row ? 1 : (p.c_out + 32 * nt - 1) / (32 * nt));
-    dim3 block(256);
-    switch (nt) {
-        case 1: ESMI_LAUNCH((convgemm_kernel<1>), grid, block, 0, st, p); break;
-        case 2: ESMI_LAUNCH((convgemm_kernel<2>), grid, block, 0, st, p); break;
-        case 4: ESMI_LAUNCH((convgemm_kernel<4>), grid, block, 0, st, p); break;
-        case 8: ESMI_LAUNCH((convgemm_kernel<8>), grid, block, 0, st, p); break;
-        default: return ESMI_ERR_UNSUPPORTED;
-    }
-    return launch_status();
-}
-
-#ifndef ESMI_ATTN_LDS_MIN_HEADS
-#ifdef ESMI_WAVESIM
-#define ESMI_ATTN_LDS_MIN_HEADS 1      // (simulator: always take the LDS kernel where it applies, so the tests reach it)
-#else
-#define ESMI_ATTN_LDS_MIN_HEADS 128    // enough (utterance, head) workgroups to occupy the chip at one per CU
-#endif
-#endif
-int launch_attn(const AttnP& p, hipStream_t st) {
-    if ((p.C & 31) || p.N <= 0) return ESMI_ERR_ARG;   // channel groups of 32 (4 k-steps fetched together)
-    const int nkt = (p.N + 31) / 32;
-    const int tiles = p.B * p.h * nkt;
-    dim3 grid((tiles + 3) / 4), block(256);
-    if (nkt > 8) {   // N > 256: key-chunked two-sweep kernel (no sequence limit, as the reference)
-        switch (p.C / 32) {
-            case 1: ESMI_LAUNCH((attn_long_kernel<1>), grid, block, 0, st, p); break;
-            case 2: ESMI_LAUNCH((attn_long_kernel<2>), grid, block, 0, st, p); break;
-            case 4: ESMI_LAUNCH((attn_long_kernel<4>), grid, block, 0, st, p); break;
-            case 8: ESMI_LAUNCH((attn_long_kernel<8>), grid, block, 0, st, p); break;
-            default: return ESMI_ERR_UNSUPPORTED;   // widths of the three published sizes: 32 .. 256
-        }
-        return launch_status();
-    }
-#if ESMI_CHAIN_SPLIT
-    // heads with several query tiles: K and V staged once per (utterance, head) in LDS instead of once per tile from L2
-    if (nkt >= 3 && (p.C <= 128 || p.C % 128 == 0) && attn_lds_bytes(p.N, p.C) <= 150 * 1024 && (long)p.B * p.h >= ESMI_ATTN_LDS_MIN_HEADS) {
-        const size_t lds = attn_lds_bytes(p.N, p.C);
-        dim3 g2((unsigned)(p.B * p.h));
-        if (nkt <= 4) {
-            static AttrOnce once;
-            if (int rc = raise_lds_limit(reinterpret_cast<const void*>(attn_lds_kernel<4>), once)) return rc;
-            ESMI_LAUNCH((attn_lds_kernel<4>), g2, dim3(256), lds, st, p);
-        } else {
-            static AttrOnce once;
-            if (int rc = raise_lds_limit(reinterpret_cast<const void*>(attn_lds_kernel<8>), once)) return rc;
-            ESMI_LAUNCH((attn_lds_kernel<8>), g2, dim3(512), lds, st, p);
-        }
-        return launch_status();
-    }
-#endif
-    if (nkt == 1) ESMI_LAUNCH((attn_kernel<1>), grid, block, 0, st, p);
-    else if (nkt == 2) ESMI_LAUNCH((attn_kernel<2>), grid, block, 0, st, p);
-    else if (nkt <= 4) ESMI_LAUNCH((attn_kernel<4>), grid, block, 0, st, p);
-    else ESMI_LAUNCH((attn_kernel<8>), grid, block, 0, st, p);
-    return launch_status();
-}
-
-inline int conv_out_len(int n, int k, int stride, int pad) { return (n + 2 * pad - k) / stride + 1; }
-
-
-// E1: merge conv + 1x1 + qkv in one launch.  Returns ESMI_ERR_UNSUPPORTED when no instantiation fits.
-int launch_enc_merge_qkv(const EncMergeP& p, int c_in, int c_out, hipStream_t st) {
-    const int nci = c_in / 32, nc = c_out / 32;
-    if ((c_in & 31) || (c_out & 31)) return ESMI_ERR_UNSUPPORTED;
-    dim3 grid(p.B * p.tiles_per_b), block(64);
-    const int lds = enc_merge_lds_floats(c_in, c_out, p.k, p.stride) * (int)sizeof(float);
-#define ESMI_E1(NCI, NC, KT, ST) \
-    if (nci == NCI && nc == NC && p.k == KT && p.stride == ST) { ESMI_LAUNCH((enc_merge_qkv_kernel<NCI, NC, KT, ST>), grid, block, lds, st, p); return launch_status(); }
-    // (Cin/32, C/32, kernel, stride) of the three published sizes: tiny, small, base (block 1 of base is not fused)
-    ESMI_E1(4, 1, 3, 1) ESMI_E1(1, 2, 1, 2) ESMI_E1(4, 2, 3, 1) ESMI_E1(2, 4, 1, 2) ESMI_E1(4, 4, 5, 1)
-#undef ESMI_E1
-    return ESMI_ERR_UNSUPPORTED;
-}
-
-bool enc_attn_ffn_supported(int C, int N, int expansion) {
-    if ((C & 31) || N > 256 || N < 1) return false;
-    // sequences of more than 128 positions: the chain kernel runs one latency chain per 32 rows against up to 256 keys; the same
-    // ops as launches (LDS-staged attention + LDS-staged GEMMs) are faster there (small ES T = 256: 2.53 vs 2.62 ms/step; base ES
-    // block 0: 1.33 vs 2.00 ms) -- `tools/debug_plan_base.py` measures the plans
-    if (N > 128) return false;
-    const int nc = C / 32;
-    // base ES block 0 (C = 128, expansion 2) at N = 256: the chain kernel runs one latency chain per 32 rows against 256 keys
-    // (2.00 ms at B = 512); the same ops as LDS-staged GEMM launches take 1.33 ms, so that shape goes per-op
-    return (expansion == 1 && (nc == 1 || nc == 2 || nc == 4)) || (expansion == 2 && nc == 4 && N <= 128);
-}
-
-// Whole encoder block (merge conv + qkv + attention + MixFFN) in one launch: sequences one workgroup covers, shapes
-// whose q/k/v tile fits in LDS.  Returns ESMI_ERR_UNSUPPORTED otherwise (-> enc_merge_qkv + enc_attn_ffn launches).
-int launch_enc_block(const EncAttnFfnP& p, int expansion, int c_in, int plan, hipStream_t st) {
-    if ((p.C & 31) || (c_in & 31) || p.N > 128) return ESMI_ERR_UNSUPPORTED;
-    const int nc = p.C / 32, nci = c_in / 32, nkt = p.N <= 64 ? 2 : 4;
-    if (p.h == 2 && nc == 2 && expansion == 1 && (plan & ESMI_FUSE_SPLIT2)) {   // two waves per row tile when rows are scarce
-        int nw, wgs, useful, halo;
-        enc_attn_ffn_split_plan(p.N, &nw, &wgs, &useful, &halo);
-        if ((long)p.B * wgs * 2 * nw <= 1024) {
-            const int lds = enc_block_split_lds_floats(p.C, p.h, expansion, c_in, p.m.k, p.m.stride, nw) * (int)sizeof(float);
-            if (halo != 0 || lds > 150 * 1024 || !(nci == 1 && p.m.k == 1 && p.m.stride == 2)) return ESMI_ERR_UNSUPPORTED;
-            EncAttnFfnP q = p;
-            q.wgs_per_b = 1; q.useful = useful; q.halo = 0;
-            dim3 grid(p.B), block(128 * nw);
-            static AttrOnce once;
-            if (int rc = raise_lds_limit(reinterpret_cast<const void*>(enc_attn_ffn_split_kernel<2, 2, 1, 1, 1, 2>), once)) return rc;
-            ESMI_LAUNCH((enc_attn_ffn_split_kernel<2, 2, 1, 1, 1, 2>), grid, block, lds, st, q);   // N <= 64 here: NKT = 2
-            return launch_status();
-        }
-    }
-    int nw, wgs, useful, halo;
-    enc_attn_ffn_plan(p.N, p.C * expansion + 4, &nw, &wgs, &useful, &halo);
-    if (halo != 0) return ESMI_ERR_UNSUPPORTED;
-    const int lds = enc_block_lds_floats(p.C, p.h, expansion, c_in, p.m.k, p.m.stride, nw) * (int)sizeof(float);
-    if (lds > 150 * 1024) return ESMI_ERR_UNSUPPORTED;
-    EncAttnFfnP q = p;
-    q.wgs_per_b = 1; q.useful = useful; q.halo = 0;
-    dim3 grid(p.B), block(64 * nw);
-#define ESMI_EB(NKT, NC, E, NCI, KT, ST) \
-    if (nkt == NKT && nc == NC && expansion == E && nci == NCI && p.m.k == KT && p.m.stride == ST) {                           \
-        static AttrOnce once; /* per instantiation */                                                                          \
-        if (int rc = raise_lds_limit(reinterpret_cast<const void*>(enc_attn_ffn_kernel<NKT, NC, E, NCI, KT, ST>), once)) return rc; \
-        ESMI_LAUNCH((enc_attn_ffn_kernel<NKT, NC, E, NCI, KT, ST>), grid, block, lds, st, q);                                  \
-        return launch_status();                                                                                                \
-    }
-    // tiny block 0 / small block 0 / tiny block 1 (when the split kernel does not apply)
-    ESMI_EB(2, 1, 1, 4, 3, 1) ESMI_EB(4, 1, 1, 4, 3, 1) ESMI_EB(2, 2, 1, 4, 3, 1) ESMI_EB(4, 2, 1, 4, 3, 1)
-    ESMI_EB(2, 2, 1, 1, 1, 2)
-#undef ESMI_EB
-    return ESMI_ERR_UNSUPPORTED;
-}
-
-// E2: attention + proj + LN1 + MixFFN + LN2 in one launch.
-int launch_enc_attn_ffn(const EncAttnFfnP& p, int expansion, int plan, hipStream_t st) {
-    if ((p.C & 31) || p.N > 256) return ESMI_ERR_UNSUPPORTED;
-    const int nc = p.C / 32, nkt = p.N <= 64 ? 2 : (p.N <= 128 ? 4 : 8);
-    int nw, wgs, useful, halo;
-    EncAttnFfnP q = p;
-    if (p.h == 2 && nc == 2 && expansion == 1 && (plan & ESMI_FUSE_SPLIT2)) {   // two waves per row tile when rows are scarce
-        enc_attn_ffn_split_plan(p.N, &nw, &wgs, &useful, &halo);
-        if ((long)p.B * wgs * 2 * nw <= 1024 && nkt <= 4) {
-            q.wgs_per_b = wgs; q.useful = useful; q.halo = halo;
-            dim3 grid(p.B * wgs), block(128 * nw);
-            const int lds = enc_attn_ffn_split_lds_floats(p.C, p.h, expansion, nw) * (int)sizeof(float);
-            if (nkt == 2) ESMI_LAUNCH((enc_attn_ffn_split_kernel<2, 2, 1>), grid, block, lds, st, q);
-            else ESMI_LAUNCH((enc_attn_ffn_split_kernel<4, 2, 1>), grid, block, lds, st, q);
-            return launch_status();
-        }
-    }
-    enc_attn_ffn_plan(p.N, p.C * expansion + 4, &nw, &wgs, &useful, &halo);
-    q.wgs_per_b = wgs; q.useful = useful; q.halo = halo;
-    dim3 grid(p.B * wgs), block(64 * nw);
-    const int lds = (32 * nw + 2) * (p.C * expansion + 4) * (int)sizeof(float);
-#define ESMI_E2(NKT, NC, E) \
-    if (nkt == NKT && nc == NC && expansion == E) {                                                                            \
-        static AttrOnce once; /* per instantiation */                                                                          \
-        if (lds > 48 * 1024)                                                                                                   \
-            if (int rc = raise_lds_limit(reinterpret_cast<const void*>(enc_attn_ffn_kernel<NKT, NC, E>), once)) return rc;     \
-        ESMI_LAUNCH((enc_attn_ffn_kernel<NKT, NC, E>), grid, block, lds, st, q);                                               \
-        return launch_status();                                                                                                \
-    }
-#define ESMI_E2K(NC, E) ESMI_E2(2, NC, E) ESMI_E2(4, NC, E) ESMI_E2(8, NC, E)
-    ESMI_E2K(1, 1) ESMI_E2K(2, 1) ESMI_E2K(4, 1) ESMI_E2K(4, 2)
-#undef ESMI_E2K
-#undef ESMI_E2
-    return ESMI_ERR_UNSUPPORTED;
-}
 
 // does the fused Fuse + variance-adaptor chain kernel serve this call?  (needs the packed weights and one of its instantiations)
 bool fuse_va_chain_ok(const esmi_fuse_weights* fw, int depth, int dim, int kernel, int n0, int T, const esmi_predictor_weights* pitch,
@@ -310,47 +49,6 @@ extern "C" void esmi_dev_set_chain_trace(long long* ptr) {
     hipMemcpyToSymbol(HIP_SYMBOL(g_chain_trace_dev), &ptr, sizeof(ptr));
 }
 #endif
-#ifdef ESMI_DEC_TRACE
-long long* g_esmi_trace = nullptr;
-extern "C" void esmi_dev_set_trace(long long* ptr) { g_esmi_trace = ptr; }
-#endif
-
-namespace {
-// One ResBlock in one launch (hifigan_resblock.h) when its packed weights are there and (channels, kernel size) has an
-// instantiation; `false` from resblock_fused_ok -> the caller runs the block conv by conv.
-template <int C, int K>
-int launch_resblock_ck(const ResblockP& p, hipStream_t st) {
-    const size_t lds = rb_lds_bytes(C, p.R);
-    const dim3 grid((unsigned)(p.B * p.tiles_per_b)), block(64 * kRbWaves);
-    if constexpr (C <= 16) {   // narrow MFMA tiles (16 channels x 16 positions): LDS <= 32 KB, no limit to raise
-        ESMI_LAUNCH((hifigan_resblock16_kernel<C, K>), grid, block, lds, st, p);
-    } else {
-        static AttrOnce once;
-        if (lds > 48 * 1024)
-            if (int rc = raise_lds_limit(reinterpret_cast<const void*>(hifigan_resblock_kernel<C, K>), once)) return rc;
-        ESMI_LAUNCH((hifigan_resblock_kernel<C, K>), grid, block, lds, st, p);
-    }
-    return launch_status();
-}
-template <int C>
-int launch_resblock_c(const ResblockP& p, hipStream_t st) {
-    switch (p.k) {
-        case 3: return launch_resblock_ck<C, 3>(p, st);
-        case 7: return launch_resblock_ck<C, 7>(p, st);
-        case 11: return launch_resblock_ck<C, 11>(p, st);
-    }
-    return ESMI_ERR_UNSUPPORTED;
-}
-int launch_resblock(const ResblockP& p, int c, hipStream_t st) {
-    switch (c) {
-        case 8: return launch_resblock_c<8>(p, st);
-        case 16: return launch_resblock_c<16>(p, st);
-        case 32: return launch_resblock_c<32>(p, st);
-        case 64: return launch_resblock_c<64>(p, st);
-    }
-    return ESMI_ERR_UNSUPPORTED;
-}
-}  // namespace
 
 extern "C" {
 
@@ -400,23 +98,6 @@ int esmi_pack_bfrag_f32(const float* src, float* dst, int n, int k, int taps, es
 #endif
     const long tot = (long)esmi_pack_bfrag_floats(n, k, taps);
     ESMI_LAUNCH(pack_bfrag_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, S(stream), src, dst, n, k, (n + 31) / 32, taps);
-    return launch_status();
-}
-
-size_t esmi_pack_resblock_bytes(int c, int k) {
-    if ((c != 8 && c != 16 && c != 32 && c != 64) || (k != 3 && k != 7 && k != 11)) return 0;
-    return rb_pack_dwords(c, k) * 4;
-}
-int esmi_pack_resblock_f16(const float* src, void* dst, int c, int k, esmi_stream_t stream) {
-    if (!src || !dst) return ESMI_ERR_ARG;
-    if (!esmi_pack_resblock_bytes(c, k)) return ESMI_ERR_UNSUPPORTED;
-    if (c <= 16) {
-        const long n16 = (long)rb_ksteps16(c, k) * 64;
-        ESMI_LAUNCH(pack_resblock16_kernel, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, S(stream), src, static_cast<unsigned*>(dst), c, k);
-        return launch_status();
-    }
-    const long n = (long)rb_mtiles(c) * rb_ksteps(c, k) * 64;
-    ESMI_LAUNCH(pack_resblock_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, S(stream), src, static_cast<unsigned*>(dst), c, k);
     return launch_status();
 }
 
@@ -677,18 +358,8 @@ int esmi_fuse_variance_adaptor_f32(const esmi_fuse_weights* fw, int depth, int d
         fuse_va_plan(T, dim, depth, &nw, &p.wgs_per_b, &p.useful, &p.halo);
         const bool scan_fused = cum && p.halo == 0;   // one workgroup sees every duration of its utterance
         p.cum = scan_fused ? cum : nullptr; p.mel_len = scan_fused ? mel_len : nullptr;
-        dim3 grid(B * p.wgs_per_b), block(64 * nw);
         if (h0) { p.head_w = head->proj_wp; p.head_b = head->proj_b; p.head_g = head->ln_g; p.head_beta = head->ln_b; p.h0 = h0; }
-        const int lds = fuse_va_lds_floats(dim, depth, nw, h0 != nullptr) * (int)sizeof(float);
-        static AttrOnce once[4];
-        const void* fns[4] = {reinterpret_cast<const void*>(enc_fuse_va_kernel<1, 3>), reinterpret_cast<const void*>(enc_fuse_va_kernel<2, 3>),
-                              reinterpret_cast<const void*>(enc_fuse_va_kernel<1, 5>), reinterpret_cast<const void*>(enc_fuse_va_kernel<2, 5>)};
-        for (int q = 0; q < 4; ++q)
-            if (int rc = raise_lds_limit(fns[q], once[q])) return rc;
-        if (dim == 32 && kernel == 3) ESMI_LAUNCH((enc_fuse_va_kernel<1, 3>), grid, block, lds, S(stream), p);
-        else if (dim == 64 && kernel == 3) ESMI_LAUNCH((enc_fuse_va_kernel<2, 3>), grid, block, lds, S(stream), p);
-        else if (dim == 32) ESMI_LAUNCH((enc_fuse_va_kernel<1, 5>), grid, block, lds, S(stream), p);
-        else ESMI_LAUNCH((enc_fuse_va_kernel<2, 5>), grid, block, lds, S(stream), p);
+        if (int rc = launch_enc_fuse_va(p, dim, kernel, nw, h0 != nullptr, S(stream))) return rc;
         if (cum && !scan_fused) ESMI_LAUNCH(length_regulate_kernel, dim3(B), dim3(64), 0, S(stream), dur, T, cum, mel_len, (int*)nullptr);
         return launch_status();
     }
@@ -848,163 +519,6 @@ int esmi_mask_rows_f32(float* x, const uint8_t* mask, int64_t rows, int C, esmi_
 }
 
 // ------------------------------------------------------------------ mel decoder
-static int dec_check(const esmi_decoder_shape* s) {
-    if (!s) return ESMI_ERR_ARG;
-    if (s->dx2 != 128 && s->dx2 != 256) return ESMI_ERR_UNSUPPORTED;
-    if (s->d4 <= 0 || s->d4 % 128) return ESMI_ERR_UNSUPPORTED;
-    if (s->kernel != 3 && s->kernel != 5) return ESMI_ERR_UNSUPPORTED;
-    if (s->n_mel <= 0 || s->n_mel > kMelCols) return ESMI_ERR_UNSUPPORTED;
-    if (s->n_blocks < 1 || s->block_depth < 1 || s->n_blocks * s->block_depth > ESMI_MAX_DEC_LAYERS) return ESMI_ERR_UNSUPPORTED;
-    if (2 * (s->kernel / 2) * s->n_blocks * s->block_depth >= kDecRows - 32) return ESMI_ERR_UNSUPPORTED;
-    return ESMI_OK;
-}
-
-size_t esmi_mel_decoder_blob_bytes(const esmi_decoder_shape* s) {
-    if (dec_check(s)) return 0;
-    return (size_t)dec_layout(s->d4, s->dx2, s->kernel, s->n_blocks, s->block_depth).total * sizeof(float);
-}
-
-int esmi_mel_decoder_pack_f32(const esmi_decoder_weights* w, const esmi_decoder_shape* s, float* blob,
-                              esmi_stream_t stream) {
-    int rc = dec_check(s);
-    if (rc) return rc;
-    if (!w || !blob) return ESMI_ERR_ARG;
-    const DecLayout L = dec_layout(s->d4, s->dx2, s->kernel, s->n_blocks, s->block_depth);
-    hipStream_t st = S(stream);
-    const int dx2 = s->dx2, ntw = dx2 / 128;
-    auto bslice = [&](const float* src, long off, int N, int K) {
-#if ESMI_DEC_SPLIT == 2
-        const long n = (long)(K / 128) * 4 * ntw * 8 * 2 * 256;
-        ESMI_LAUNCH(pack_bslice2h_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src,
-                    reinterpret_cast<unsigned*>(blob + off), N, K, ntw);
-#else
-        const long n = (long)(K / 128) * 4 * ntw * 16 * 256;
-        ESMI_LAUNCH(pack_bslice_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src, blob + off, N, K, ntw);
-#endif
-    };
-    auto vec = [&](const float* src, long off, int n, int n_pad) {
-        ESMI_LAUNCH(copy_pad_kernel, dim3((n_pad + 255) / 256), dim3(256), 0, st, src, blob + off, n, n_pad);
-    };
-    bslice(w->proj_w, L.proj_w, dx2, s->d4);
-    vec(w->proj_b, L.proj_b, dx2, dx2);
-    vec(w->proj_ln_g, L.proj_g, dx2, dx2);
-    vec(w->proj_ln_b, L.proj_beta, dx2, dx2);
-    for (int l = 0; l < s->n_blocks * s->block_depth; ++l) {
-        const long base = L.layer0 + (long)l * L.layer_stride;
-        if (!w->dw_w[l] || !w->pw_w[l]) return ESMI_ERR_ARG;
-        ESMI_LAUNCH(pack_dw_kernel, dim3((dx2 * s->kernel + 255) / 256), dim3(256), 0, st, w->dw_w[l], blob + base + L.l_dw,
-                    dx2, s->kernel);
-        vec(w->dw_b[l], base + L.l_dwb, dx2, dx2);
-        bslice(w->pw_w[l], base + L.l_pw, dx2, dx2);
-        vec(w->pw_b[l], base + L.l_pwb, dx2, dx2);
-        vec(w->ln_g[l], base + L.l_g, dx2, dx2);
-        vec(w->ln_b[l], base + L.l_b, dx2, dx2);
-    }
-    for (int b = 0; b < s->n_blocks; ++b) {
-        vec(w->skip_g[b], L.skip0 + 2L * dx2 * b, dx2, dx2);
-        vec(w->skip_b[b], L.skip0 + 2L * dx2 * b + dx2, dx2, dx2);
-    }
-    bslice(w->mel_w, L.mel_w, s->n_mel, dx2);
-    vec(w->mel_b, L.mel_b, s->n_mel, dx2);
-    if (L.rows0 >= 0) {   // the row-owner form's copy (mel_decoder_rows.h)
-        auto afrag = [&](const float* src, long off, int N, int MT) {
-            const long n = 8L * MT * 2 * 256;
-            ESMI_LAUNCH(pack_rows_afrag_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src,
-                        reinterpret_cast<unsigned*>(blob + off), N, MT);
-        };
-        for (int l = 0; l < s->n_blocks * s->block_depth; ++l) {
-            const long base = L.rows0 + (long)l * L.rows_layer_stride, pr = base + 16384;
-            afrag(w->pw_w[l], base, dx2, 4);
-            ESMI_LAUNCH(pack_dw_kernel, dim3((dx2 * s->kernel + 255) / 256), dim3(256), 0, st, w->dw_w[l], blob + pr, dx2, s->kernel);
-            ESMI_LAUNCH(pack_rows_bias_kernel, dim3(2), dim3(64), 0, st, w->pw_w[l], w->dw_b[l], w->pw_b[l],
-                        blob + pr + (long)s->kernel * dx2);
-            vec(w->ln_g[l], pr + (long)(s->kernel + 1) * dx2, dx2, dx2);
-            vec(w->ln_b[l], pr + (long)(s->kernel + 2) * dx2, dx2, dx2);
-        }
-        afrag(w->mel_w, L.rows_mel, s->n_mel, 3);
-        ESMI_LAUNCH(pack_rows_padrow_kernel, dim3(1), dim3(64), 0, st, w->proj_b, w->proj_ln_g, w->proj_ln_b, blob + L.rows_pad);
-    }
-    return launch_status();
-}
-
-#ifndef ESMI_DEC_ROWS
-#define ESMI_DEC_ROWS 0     // 1: dx2 = 128 decoders with the phoneme-rate head take the row-owner kernel (mel_decoder_rows.h) by default.
-#endif                      // Measured on MI355X (tiny B=256 T=128): 0.316 ms vs 0.198 ms for the tile form, so 0
-static int mel_decoder_launch(const float* blob, const esmi_decoder_shape* s, const float* x, const float* h0,
-                              const int32_t* cum, const int32_t* mel_len, const int32_t* lmax_dev, int lmax_host, int apply_mask, int B, int T,
-                              int L_out, float* mel, esmi_stream_t stream, bool rows) {
-    int rc = dec_check(s);
-    if (rc) return rc;
-    if (!blob || (!x && !h0) || !mel || B <= 0 || L_out <= 0 || !aligned16(blob) || (x && !aligned16(x))) return ESMI_ERR_ARG;
-    if (h0 && (!cum || !aligned16(h0))) return ESMI_ERR_ARG;   // the phoneme-rate head only exists in the fused-gather mode
-    if (!cum && lmax_dev) return ESMI_ERR_ARG;  // direct mode: L is the tensor's own length, known to the host
-    if (!lmax_dev && lmax_host == 0) return ESMI_ERR_ARG;
-    if (!lmax_dev && lmax_host < 0 && (!mel_len || !cum)) return ESMI_ERR_ARG;   // L derived from mel_len
-    MelDecP p;
-    p.blob = blob;
-    p.lay = dec_layout(s->d4, s->dx2, s->kernel, s->n_blocks, s->block_depth);
-    p.d4 = s->d4; p.n_blocks = s->n_blocks; p.block_depth = s->block_depth; p.n_mel = s->n_mel;
-    p.x = x; p.h0 = h0; p.cum = cum; p.mel_len = mel_len; p.lmax_dev = lmax_dev; p.lmax_host = lmax_host;
-    p.apply_mask = apply_mask && mel_len; p.B = B; p.T = T; p.L_out = L_out; p.mel = mel;
-    p.halo = (s->kernel / 2) * s->n_blocks * s->block_depth;
-    p.TL = kDecRows - 2 * p.halo;
-    p.trace = nullptr;
-#ifdef ESMI_DEC_TRACE
-    p.trace = g_esmi_trace;   // development only, see tools/trace_decoder.py
-#endif
-    hipStream_t st = S(stream);
-    const bool rows_ok = h0 && p.lay.rows0 >= 0 && 4 * p.halo <= kRowsWin;
-    if (rows && !rows_ok) return ESMI_ERR_UNSUPPORTED;
-    if (rows) {
-        p.TL = kRowsWin - 2 * p.halo;
-        p.n_tiles = (L_out + p.TL - 1) / p.TL;
-        dim3 rgrid((unsigned)(p.n_tiles * ((B + 7) / 8) * 8));
-        const int lds = dec_rows_lds_floats(s->kernel) * (int)sizeof(float);
-        if (s->kernel == 5) {
-            static AttrOnce once;
-            if (int rc2 = raise_lds_limit(reinterpret_cast<const void*>(mel_decoder_rows_kernel<5>), once)) return rc2;
-            ESMI_LAUNCH((mel_decoder_rows_kernel<5>), rgrid, dim3(kRowsThreads), lds, st, p);
-        } else {
-            static AttrOnce once;
-            if (int rc2 = raise_lds_limit(reinterpret_cast<const void*>(mel_decoder_rows_kernel<3>), once)) return rc2;
-            ESMI_LAUNCH((mel_decoder_rows_kernel<3>), rgrid, dim3(kRowsThreads), lds, st, p);
-        }
-        return launch_status();
-    }
-    p.n_tiles = (L_out + p.TL - 1) / p.TL;
-    dim3 grid((unsigned)(p.n_tiles * ((B + 7) / 8) * 8)), block(kDecThreads);
-#ifndef ESMI_DEC_NW256
-#define ESMI_DEC_NW256 8    // waves per window of the dx2 = 256 decoder (small / base ES): 8, or 16 (measured 30 % slower: 65 spilled
-                            // VGPRs at the 128-register budget and twice the weight traffic; small ES decoder 2.43 vs 1.87 ms)
-#endif
-#define ESMI_DEC_CASE(DX2, KD, NW)                                                                                   \
-    {                                                                                                              \
-        const int lds = dec_lds_floats<DX2>(KD) * (int)sizeof(float);                                              \
-        static AttrOnce once; /* per instantiation */                                                              \
-        if (int rc2 = raise_lds_limit(reinterpret_cast<const void*>(mel_decoder_kernel<DX2, KD, NW>), once)) return rc2; \
-        ESMI_LAUNCH((mel_decoder_kernel<DX2, KD, NW>), grid, dim3(64 * NW), lds, st, p);                           \
-    }
-    if (s->dx2 == 128 && s->kernel == 5) ESMI_DEC_CASE(128, 5, 8)
-    else if (s->dx2 == 128 && s->kernel == 3) ESMI_DEC_CASE(128, 3, 8)
-    else if (s->dx2 == 256 && s->kernel == 5) ESMI_DEC_CASE(256, 5, ESMI_DEC_NW256)
-    else ESMI_DEC_CASE(256, 3, ESMI_DEC_NW256)
-#undef ESMI_DEC_CASE
-    return launch_status();
-}
-
-int esmi_mel_decoder_f32(const float* blob, const esmi_decoder_shape* s, const float* x, const float* h0,
-                         const int32_t* cum, const int32_t* mel_len, const int32_t* lmax_dev, int lmax_host, int apply_mask, int B, int T,
-                         int L_out, float* mel, esmi_stream_t stream) {
-    const bool rows = ESMI_DEC_ROWS && h0 && s && s->dx2 == 128 && ESMI_DEC_SPLIT == 2 &&
-                      4 * (s->kernel / 2) * s->n_blocks * s->block_depth <= kRowsWin;
-    return mel_decoder_launch(blob, s, x, h0, cum, mel_len, lmax_dev, lmax_host, apply_mask, B, T, L_out, mel, stream, rows);
-}
-int esmi_mel_decoder_rows_f32(const float* blob, const esmi_decoder_shape* s, const float* x, const float* h0,
-                              const int32_t* cum, const int32_t* mel_len, const int32_t* lmax_dev, int lmax_host, int apply_mask, int B,
-                              int T, int L_out, float* mel, esmi_stream_t stream) {
-    return mel_decoder_launch(blob, s, x, h0, cum, mel_len, lmax_dev, lmax_host, apply_mask, B, T, L_out, mel, stream, true);
-}
-
 // ------------------------------------------------------------------ HiFi-GAN generator
 namespace {
 struct HgPlan {
@@ -1257,297 +771,6 @@ int esmi_phoneme2mel_forward_f32(const esmi_forward_args* a, int stage, esmi_str
         if (rc) return rc;
     }
     return ESMI_OK;
-}
-
-// ------------------------------------------------------------------ training step (csrc/train_ops.h)
-namespace {
-inline unsigned grid1d(long n, int block = 256) { return (unsigned)((n + block - 1) / block); }
-int conv_desc_ok(const esmi_conv_desc* d, ConvDesc* o) {
-    if (!d || d->B <= 0 || d->n_in <= 0 || d->n_out <= 0 || d->c_in <= 0 || d->c_out <= 0 || d->k <= 0 || d->stride <= 0 || d->pad < 0 ||
-        d->groups <= 0)
-        return ESMI_ERR_ARG;
-    if (d->groups != 1 && (d->transposed || d->c_in % d->groups || d->c_out % d->groups)) return ESMI_ERR_UNSUPPORTED;
-    *o = ConvDesc{d->B, d->n_in, d->c_in, d->n_out, d->c_out, d->k, d->stride, d->pad, d->groups, d->transposed ? 1 : 0};
-    return ESMI_OK;
-}
-}  // namespace
-
-namespace {
-inline bool wgrad_depthwise(const ConvDesc& c) { return !c.transposed && c.groups == c.c_in && c.c_in == c.c_out && c.k <= 8; }
-inline bool wgrad_on_mfma(const ConvDesc& c);
-inline int wgrad_chunk(const ConvDesc& c) {   // rows per partial sum: fewer for small weights, whose parallelism must come from the chunks
-    if (wgrad_on_mfma(c)) return kTrainChunkMfma;
-    if (wgrad_depthwise(c)) return kTrainChunkDw;
-    const long nw = (long)(c.transposed ? c.c_in * c.c_out : c.c_out * (c.c_in / c.groups)) * c.k;
-    return nw < 1024 ? 32 : kTrainChunk;
-}
-inline bool wgrad_on_mfma(const ConvDesc& c) { return c.groups == 1 && c.c_in >= 8 && c.c_out >= 8 && (c.c_out & 3) == 0; }
-}
-// Dense convolutions (groups == 1) of the training step run on the matrix pipe through the inference path's implicit GEMM
-// (convgemm.h) when the caller gives scratch for the tap-major copy of the weight: the forward as it is, the data gradient as
-// the transposed problem -- d(Conv1d) is a ConvTranspose1d of dy with the same (Cout, Cin, k) tensor read as (Cin', Cout', k),
-// d(ConvTranspose1d) is a Conv1d of dy with (Cin, Cout, k) read as (Cout', Cin', k).  Everything else (depthwise, channel
-// counts the GEMM does not take, no scratch) runs the one-thread-per-element kernels of train_ops.h.
-size_t esmi_train_conv_workspace_bytes(const esmi_conv_desc* d) {
-    ConvDesc c;
-    if (conv_desc_ok(d, &c) || c.groups != 1) return 0;
-    return align256((size_t)c.k * c.c_out * c.c_in * sizeof(float)) + 256;   // + the data gradient's absmax / scale slots
-}
-namespace {
-// one of the two implicit-GEMM problems of a dense conv: returns ESMI_ERR_UNSUPPORTED when the GEMM does not take the shape
-int train_conv_gemm(const ConvDesc& c, bool grad, const float* in, const float* w, const float* bias, float* out, float* wt,
-                    hipStream_t st) {
-    const int cin = grad ? c.c_out : c.c_in, cout = grad ? c.c_in : c.c_out;      // of the GEMM problem
-    if (c.groups != 1 || (cin & 7) || !wt) return ESMI_ERR_UNSUPPORTED;
-    if (cout == 1 && (grad != (c.transposed != 0) || c.stride != 1)) return ESMI_ERR_UNSUPPORTED;   // the one-channel kernel is a plain conv
-    const long n = (long)c.k * c.c_out * c.c_in;
-    // tap-major (k, cout, cin) of the problem: forward conv / grad of convT read the tensor as Conv1d, the other two as ConvTranspose1d
-    const int as_convT = (grad != (c.transposed != 0)) ? 1 : 0;
-    int* amax = reinterpret_cast<int*>(reinterpret_cast<char*>(wt) + align256((size_t)n * sizeof(float)));
-    const float* wuse = wt;
-    if (c.k == 1 && !as_convT && !grad) {
-        wuse = w;                                   // a Linear's (Cout, Cin) IS its tap-major form: no copy
-    } else {
-        ESMI_LAUNCH(pack_conv_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, w, wt, cout, cin, c.k, as_convT, grad ? amax : nullptr);
-        if (int rc = launch_status()) return rc;
-    }
-    ConvGemmP p = conv_defaults();
-    if (grad) {   // max|dy| on the device; the GEMM kernels derive the power-of-two scales from it (convgemm.h conv_pow2_scales)
-        const long len = (long)c.B * c.n_out * c.c_out, blocks = (len + 256L * 8 - 1) / (256L * 8);
-        ESMI_LAUNCH(absmax_kernel, dim3((unsigned)(blocks > 1024 ? 1024 : blocks)), dim3(256), 0, st, in, len, amax);
-        if (int rc = launch_status()) return rc;
-        p.io_scale = reinterpret_cast<const float*>(amax);
-    }
-    p.mode = as_convT ? MODE_CONVT : MODE_CONV;
-    p.k = c.k; p.stride = c.stride; p.pad = c.pad;
-    p.B = c.B; p.n_in = grad ? c.n_out : c.n_in; p.n_out = grad ? c.n_in : c.n_out; p.c_in = cin; p.c_out = cout;
-    p.A = in; p.lda = cin; p.W = wuse; p.bias = bias; p.out = out; p.ldo = cout;
-    return launch_convgemm(p, st);
-}
-}  // namespace
-
-int esmi_train_conv_fwd_f32(const esmi_conv_desc* d, const float* x, const float* w, const float* bias, float* y, void* workspace,
-                            size_t workspace_bytes, esmi_stream_t stream) {
-    ConvDesc c;
-    if (int rc = conv_desc_ok(d, &c)) return rc;
-    if (!x || !w || !y) return ESMI_ERR_ARG;
-    if (workspace && workspace_bytes >= esmi_train_conv_workspace_bytes(d)) {
-        const int rc = train_conv_gemm(c, false, x, w, bias, y, static_cast<float*>(workspace), S(stream));
-        if (rc != ESMI_ERR_UNSUPPORTED) return rc;
-    }
-    const long n = (long)c.B * c.n_out * c.c_out;
-    if (wgrad_depthwise(c) && c.stride == 1 && (c.c_out & 3) == 0) {
-        ESMI_LAUNCH(train_conv_dw_kernel, grid1d(n / 4), dim3(256), 0, S(stream), c, x, w, bias, y, 0);
-        return launch_status();
-    }
-    ESMI_LAUNCH(train_conv_fwd_kernel, grid1d(n), dim3(256), 0, S(stream), c, x, w, bias, y);
-    return launch_status();
-}
-int esmi_train_conv_dgrad_f32(const esmi_conv_desc* d, const float* dy, const float* w, float* dx, void* workspace,
-                              size_t workspace_bytes, esmi_stream_t stream) {
-    ConvDesc c;
-    if (int rc = conv_desc_ok(d, &c)) return rc;
-    if (!dy || !w || !dx) return ESMI_ERR_ARG;
-    if (workspace && workspace_bytes >= esmi_train_conv_workspace_bytes(d)) {
-        const int rc = train_conv_gemm(c, true, dy, w, nullptr, dx, static_cast<float*>(workspace), S(stream));
-        if (rc != ESMI_ERR_UNSUPPORTED) return rc;
-    }
-    const long n = (long)c.B * c.n_in * c.c_in;
-    if (wgrad_depthwise(c) && c.stride == 1 && (c.c_out & 3) == 0) {
-        ESMI_LAUNCH(train_conv_dw_kernel, grid1d(n / 4), dim3(256), 0, S(stream), c, dy, w, nullptr, dx, 1);
-        return launch_status();
-    }
-    ESMI_LAUNCH(train_conv_dgrad_kernel, grid1d(n), dim3(256), 0, S(stream), c, dy, w, dx);
-    return launch_status();
-}
-size_t esmi_train_conv_wgrad_workspace_bytes(const esmi_conv_desc* d) {
-    ConvDesc c;
-    if (conv_desc_ok(d, &c)) return 0;
-    const long nw = (long)(c.transposed ? c.c_in * c.c_out : c.c_out * (c.c_in / c.groups)) * c.k;
-    const long chunks = train_chunks((long)c.B * c.n_out, wgrad_chunk(c));
-    return (size_t)chunks * (size_t)(nw + c.c_out) * sizeof(float);
-}
-int esmi_train_conv_wgrad_f32(const esmi_conv_desc* d, const float* x, const float* dy, float* dw, float* dbias, void* workspace,
-                              size_t workspace_bytes, esmi_stream_t stream) {
-    ConvDesc c;
-    if (int rc = conv_desc_ok(d, &c)) return rc;
-    if (!x || !dy || !dw || !workspace) return ESMI_ERR_ARG;
-    if (workspace_bytes < esmi_train_conv_wgrad_workspace_bytes(d)) return ESMI_ERR_WORKSPACE;
-    const long nw = (long)(c.transposed ? c.c_in * c.c_out : c.c_out * (c.c_in / c.groups)) * c.k;
-    const bool mfma = wgrad_on_mfma(c), depthwise = wgrad_depthwise(c);
-    const long rows = (long)c.B * c.n_out, chunks = train_chunks(rows, wgrad_chunk(c));
-    float* part = static_cast<float*>(workspace);   // [chunk][weight partials (nw) | bias partials (c_out)]
-    float* pb = part + nw;
-    const long ps = nw + c.c_out;
-    if (mfma) {   // dense: one wave per (128 output channels x 32 input channels, tap, chunk) on the fp32 MFMA; bias partials from the tap 0, ci0 = 0 waves
-        const unsigned tiles = (unsigned)(((c.c_out + 127) / 128) * ((c.c_in + 31) / 32) * c.k);
-        ESMI_LAUNCH(train_conv_wgrad_mfma_kernel, dim3(tiles, (unsigned)((chunks + 3) / 4)), dim3(256), 0, S(stream), c, x, dy, part,
-                    dbias ? pb : nullptr, chunks, ps);
-    } else if (depthwise) {
-        ESMI_LAUNCH(train_conv_wgrad_dw_kernel, dim3(grid1d(c.c_out, 64), (unsigned)chunks), dim3(64), 0, S(stream), c, x, dy, part,
-                    dbias ? pb : nullptr, ps);
-    } else {
-        ESMI_LAUNCH(train_conv_wgrad_kernel, dim3(grid1d(nw, 64), (unsigned)chunks), dim3(64), 0, S(stream), c, x, dy, part, ps, wgrad_chunk(c));
-        if (int rc = launch_status()) return rc;
-        if (dbias) ESMI_LAUNCH(train_colsum_kernel, dim3(grid1d(c.c_out, 64), (unsigned)chunks), dim3(64), 0, S(stream), dy, rows, c.c_out, pb, ps, wgrad_chunk(c));
-    }
-    if (int rc = launch_status()) return rc;
-    // weight and bias partials in ONE reduction launch: elements >= nw of a partial row are the bias sums
-    ESMI_LAUNCH(train_reduce_chunks_kernel, grid1d(dbias ? ps : nw, 64), dim3(64 * kReduceGroups), 64 * kReduceGroups * sizeof(float), S(stream),
-                part, dbias ? ps : nw, ps, chunks, dw, nw, dbias);
-    return launch_status();
-}
-int esmi_train_layernorm_fwd_f32(const float* x, const float* g, const float* b, int64_t rows, int C, float* y, float* mean,
-                                 float* rstd, esmi_stream_t stream) {
-    if (!x || !g || !b || !y || !mean || !rstd || rows <= 0 || C <= 0) return ESMI_ERR_ARG;
-    ESMI_LAUNCH(train_ln_fwd_kernel, grid1d(rows, 4), dim3(256), 0, S(stream), x, g, b, (long)rows, C, 1e-5f, y, mean, rstd);
-    return launch_status();
-}
-size_t esmi_train_layernorm_bwd_workspace_bytes(int64_t rows, int C) {
-    if (rows <= 0 || C <= 0) return 0;
-    return (size_t)train_chunks(rows, C <= 256 ? kLnRows : kTrainChunk) * 2 * C * sizeof(float);
-}
-int esmi_train_layernorm_bwd_f32(const float* x, const float* g, const float* mean, const float* rstd, const float* dy,
-                                 int64_t rows, int C, float* dx, float* dg, float* db, void* workspace, size_t workspace_bytes,
-                                 esmi_stream_t stream) {
-    if (!x || !g || !mean || !rstd || !dy || !dx || !dg || !db || !workspace || rows <= 0 || C <= 0) return ESMI_ERR_ARG;
-    if (workspace_bytes < esmi_train_layernorm_bwd_workspace_bytes(rows, C)) return ESMI_ERR_WORKSPACE;
-    float* part = static_cast<float*>(workspace);
-    long chunks;
-    if (C <= 256) {   // dx and the parameter partials in one pass
-        chunks = train_chunks(rows, kLnRows);
-        ESMI_LAUNCH(train_ln_bwd_fused_kernel, dim3((unsigned)chunks), dim3(256), 4 * 2 * 256 * sizeof(float), S(stream), x, g, mean, rstd, dy, (long)rows, C, dx, part);
-        if (int rc = launch_status()) return rc;
-    } else {
-        chunks = train_chunks(rows);
-        ESMI_LAUNCH(train_ln_bwd_dx_kernel, grid1d(rows, 4), dim3(256), 0, S(stream), x, g, mean, rstd, dy, (long)rows, C, dx);
-        if (int rc = launch_status()) return rc;
-        ESMI_LAUNCH(train_ln_bwd_params_kernel, dim3(grid1d(C, 64), (unsigned)chunks), dim3(64), 0, S(stream), x, mean, rstd, dy, (long)rows, C, part);
-        if (int rc = launch_status()) return rc;
-    }
-    ESMI_LAUNCH(train_reduce_chunks_kernel, grid1d(2L * C, 64), dim3(64 * kReduceGroups), 64 * kReduceGroups * sizeof(float), S(stream), part,
-                2L * C, 2L * C, chunks, dg, (long)C, db);   // partial rows are [dg (C) | db (C)]: one launch, two outputs
-    return launch_status();
-}
-int esmi_train_act_fwd_f32(const float* x, int64_t n, int kind, float* y, esmi_stream_t stream) {
-    if (!x || !y || n <= 0 || kind < ACT_RELU || kind > ACT_TANH) return ESMI_ERR_ARG;
-    ESMI_LAUNCH(train_act_fwd_kernel, grid1d(n), dim3(256), 0, S(stream), x, (long)n, kind, y);
-    return launch_status();
-}
-int esmi_train_act_bwd_f32(const float* saved, const float* dy, int64_t n, int kind, float* dx, esmi_stream_t stream) {
-    if (!saved || !dy || !dx || n <= 0 || kind < ACT_RELU || kind > ACT_TANH) return ESMI_ERR_ARG;
-    ESMI_LAUNCH(train_act_bwd_kernel, grid1d(n), dim3(256), 0, S(stream), saved, dy, (long)n, kind, dx);
-    return launch_status();
-}
-int esmi_train_attention_fwd_f32(const float* qkv, int B, int N, int C, int h, float* P, float* ctx, esmi_stream_t stream) {
-    if (!qkv || !P || !ctx || B <= 0 || N <= 0 || C <= 0 || h <= 0 || C % h) return ESMI_ERR_ARG;
-    const size_t lds = train_attn_lds_bytes(N, C);
-    if (lds <= 150 * 1024) {   // K and V of a head staged in LDS
-        static AttrOnce once;
-        if (lds > 48 * 1024)
-            if (int rc = raise_lds_limit(reinterpret_cast<const void*>(train_attn_fwd_lds_kernel), once)) return rc;
-        ESMI_LAUNCH(train_attn_fwd_lds_kernel, dim3((unsigned)(B * h)), dim3(256), lds, S(stream), qkv, B, N, C, h, 1.0f / sqrtf((float)(C / h)), P, ctx);
-        return launch_status();
-    }
-    ESMI_LAUNCH(train_attn_fwd_kernel, dim3((unsigned)((long)B * h * N)), dim3(64), 0, S(stream), qkv, B, N, C, h, 1.0f / sqrtf((float)(C / h)), P, ctx);
-    return launch_status();
-}
-int esmi_train_attention_bwd_f32(const float* qkv, const float* P, const float* dctx, int B, int N, int C, int h, float* dS,
-                                 float* dqkv, esmi_stream_t stream) {
-    if (!qkv || !P || !dctx || !dS || !dqkv || B <= 0 || N <= 0 || C <= 0 || h <= 0 || C % h) return ESMI_ERR_ARG;
-    const float scale = 1.0f / sqrtf((float)(C / h));
-    const size_t lds = train_attn_lds_bytes(N, C);
-    if (lds <= 150 * 1024) {
-        static AttrOnce once;
-        if (lds > 48 * 1024)
-            if (int rc = raise_lds_limit(reinterpret_cast<const void*>(train_attn_bwd_rows_lds_kernel), once)) return rc;
-        ESMI_LAUNCH(train_attn_bwd_rows_lds_kernel, dim3((unsigned)(B * h)), dim3(256), lds, S(stream), qkv, P, dctx, B, N, C, h, scale, dS, dqkv);
-    } else {
-        ESMI_LAUNCH(train_attn_bwd_rows_kernel, dim3((unsigned)((long)B * h * N)), dim3(64), 0, S(stream), qkv, P, dctx, B, N, C, h, scale, dS, dqkv);
-    }
-    if (int rc = launch_status()) return rc;
-    ESMI_LAUNCH(train_attn_bwd_cols_kernel, grid1d((long)B * h * N * C), dim3(256), 0, S(stream), qkv, P, dS, dctx, B, N, C, h, scale, dqkv);
-    return launch_status();
-}
-int esmi_train_embedding_fwd_f32(const int32_t* ids, const float* table, int64_t rows, int V, int C, float* out, esmi_stream_t stream) {
-    if (!ids || !table || !out || rows <= 0 || V <= 0 || C <= 0) return ESMI_ERR_ARG;
-    ESMI_LAUNCH(train_embed_fwd_kernel, grid1d(rows * C), dim3(256), 0, S(stream), ids, table, (long)rows, V, C, out);
-    return launch_status();
-}
-size_t esmi_train_embedding_bwd_workspace_bytes(int64_t rows, int V, int C) {
-    return rows > 0 && V > 0 && C > 0 ? (size_t)train_chunks(rows) * V * C * sizeof(float) : 0;
-}
-int esmi_train_embedding_bwd_f32(const int32_t* ids, const float* dy, int64_t rows, int V, int C, int padding_idx, float* dtable,
-                                 void* workspace, size_t workspace_bytes, esmi_stream_t stream) {
-    if (!ids || !dy || !dtable || !workspace || rows <= 0 || V <= 0 || C <= 0) return ESMI_ERR_ARG;
-    if (workspace_bytes < esmi_train_embedding_bwd_workspace_bytes(rows, V, C)) return ESMI_ERR_WORKSPACE;
-    const long chunks = train_chunks(rows), n = (long)V * C;
-    float* part = static_cast<float*>(workspace);
-    ESMI_LAUNCH(train_embed_bwd_kernel, dim3(grid1d(n, 64), (unsigned)chunks), dim3(64), 0, S(stream), ids, dy, (long)rows, V, C, padding_idx, part);
-    if (int rc = launch_status()) return rc;
-    ESMI_LAUNCH(train_reduce_chunks_kernel, grid1d(n, 64), dim3(64 * kReduceGroups), 64 * kReduceGroups * sizeof(float), S(stream), part, n, n, chunks, dtable);
-    return launch_status();
-}
-int esmi_train_mask_rows_f32(const float* x, const uint8_t* mask, int64_t rows, int C, float* y, esmi_stream_t stream) {
-    if (!x || !mask || !y || rows <= 0 || C <= 0) return ESMI_ERR_ARG;
-    ESMI_LAUNCH(train_mask_rows_kernel, grid1d(rows * C), dim3(256), 0, S(stream), x, mask, (long)rows, C, y);
-    return launch_status();
-}
-int esmi_train_add_f32(const float* a, const float* b, int64_t n, float* y, esmi_stream_t stream) {
-    if (!a || !b || !y || n <= 0) return ESMI_ERR_ARG;
-    ESMI_LAUNCH(train_add_kernel, grid1d(n), dim3(256), 0, S(stream), a, b, (long)n, y);
-    return launch_status();
-}
-int esmi_train_copy_cols_f32(const float* src, int ld_src, int col_src, float* dst, int ld_dst, int col_dst, int64_t rows, int C,
-                             esmi_stream_t stream) {
-    if (!src || !dst || rows <= 0 || C <= 0 || col_src < 0 || col_dst < 0 || col_src + C > ld_src || col_dst + C > ld_dst) return ESMI_ERR_ARG;
-    ESMI_LAUNCH(train_copy_cols_kernel, grid1d(rows * C), dim3(256), 0, S(stream), src, ld_src, col_src, dst, ld_dst, col_dst, (long)rows, C);
-    return launch_status();
-}
-int esmi_train_repeat_fwd_f32(const float* feat, const int32_t* cum, int B, int T, int C, int L, float* out, esmi_stream_t stream) {
-    if (!feat || !cum || !out || B <= 0 || T <= 0 || C <= 0 || L <= 0) return ESMI_ERR_ARG;
-    ESMI_LAUNCH(train_repeat_fwd_kernel, grid1d((long)B * L * C), dim3(256), 0, S(stream), feat, cum, B, T, C, L, out);
-    return launch_status();
-}
-int esmi_train_repeat_bwd_f32(const float* dout, const int32_t* cum, int B, int T, int C, int L, float* dfeat, esmi_stream_t stream) {
-    if (!dout || !cum || !dfeat || B <= 0 || T <= 0 || C <= 0 || L <= 0) return ESMI_ERR_ARG;
-    ESMI_LAUNCH(train_repeat_bwd_kernel, grid1d((long)B * T * C), dim3(256), 0, S(stream), dout, cum, B, T, C, L, dfeat);
-    return launch_status();
-}
-int esmi_train_loss_f32(const esmi_train_loss_args* a, esmi_stream_t stream) {
-    if (!a || !a->mel_pred || !a->mel || !a->pitch_pred || !a->pitch || !a->energy_pred || !a->energy || !a->dur_pred || !a->dur ||
-        !a->out || !a->d_mel || !a->d_pitch || !a->d_energy || !a->d_dur || !a->scratch || a->B <= 0 || a->T <= 0 || a->L <= 0 || a->n_mel <= 0)
-        return ESMI_ERR_ARG;
-    static_assert(ESMI_TRAIN_LOSS_SCRATCH_FLOATS >= kLossBlocks * 6, "scratch size in the header");
-    LossP p = {a->mel_pred, a->mel, a->pitch_pred, a->pitch, a->energy_pred, a->energy, a->dur_pred, a->dur, a->mel_mask, a->ph_mask,
-               a->B, a->T, a->L, a->n_mel, a->out, a->d_mel, a->d_pitch, a->d_energy, a->d_dur, a->scratch};
-    ESMI_LAUNCH(train_loss_partial_kernel, dim3(kLossBlocks), dim3(256), 256 * sizeof(float), S(stream), p);
-    if (int rc = launch_status()) return rc;
-    ESMI_LAUNCH(train_loss_final_kernel, dim3(1), dim3(256), 256 * sizeof(float), S(stream), p);
-    if (int rc = launch_status()) return rc;
-    const long nm = (long)a->B * a->L * a->n_mel, np_ = (long)a->B * a->T;
-    ESMI_LAUNCH(train_loss_grad_kernel, grid1d(nm > np_ ? nm : np_), dim3(256), 0, S(stream), p);
-    return launch_status();
-}
-int esmi_train_adamw_f32(float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1, double beta2, double eps,
-                         double weight_decay, int step, esmi_stream_t stream) {
-    if (!p || !g || !m || !v || n <= 0 || step < 1) return ESMI_ERR_ARG;
-    // 1 - beta^step in double (-expm1(step * log beta)): in fp32, 1 - 0.999f^t carries ~6e-5 relative error at small t
-    const double bc1 = -expm1((double)step * log(beta1)), bc2 = -expm1((double)step * log(beta2));
-    AdamWScalars h = {(float)beta1, (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps, (float)(1.0 - lr * weight_decay),
-                      (float)(lr / bc1), (float)sqrt(bc2)};
-    ESMI_LAUNCH(train_adamw_kernel, grid1d(n), dim3(256), 0, S(stream), p, g, m, v, (long)n, h);
-    return launch_status();
-}
-
-int esmi_train_adamw_graph_f32(float* p, const float* g, float* m, float* v, int64_t n, float* hyper_dev, double beta1, double beta2,
-                               double eps, double weight_decay, int32_t* step_dev, esmi_stream_t stream) {
-    if (!p || !g || !m || !v || !hyper_dev || !step_dev || n <= 0) return ESMI_ERR_ARG;
-    ESMI_LAUNCH(train_bump_step_kernel, dim3(1), dim3(64), 0, S(stream), step_dev, hyper_dev, beta1, beta2, weight_decay);
-    if (int rc = launch_status()) return rc;
-    AdamWScalars h = {(float)beta1, (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps, 0.0f, 0.0f, 0.0f};
-    ESMI_LAUNCH(train_adamw_dev_kernel, grid1d(n), dim3(256), 0, S(stream), p, g, m, v, (long)n, h, (const float*)hyper_dev);
-    return launch_status();
 }
 
 }  // extern "C"

@@ -57,7 +57,7 @@ __host__ __device__ inline size_t rb_pack_dwords(int c, int k) { return (size_t)
 __host__ __device__ inline size_t rb_lds_bytes(int c, int R) { return (size_t)2 * R * rb_row_bytes(c); }
 
 // (k, C, C) tap-major fp32 -> A fragments, scaled by 2^8, two nearest-rounded binary16 pieces
-__global__ void pack_resblock_kernel(const float* __restrict__ w, unsigned* __restrict__ dst, int c, int k) {
+static __global__ void pack_resblock_kernel(const float* __restrict__ w, unsigned* __restrict__ dst, int c, int k) {
     const int steps = rb_ksteps(c, k);
     const long q = (long)blockIdx.x * blockDim.x + threadIdx.x;   // (mtile, step, lane)
     if (q >= (long)rb_mtiles(c) * steps * 64) return;
@@ -80,7 +80,7 @@ __global__ void pack_resblock_kernel(const float* __restrict__ w, unsigned* __re
 }
 
 // the same for the 16x16x32 tiles of C <= 16: [step][plane 2][lane 64][4 dwords], lane = (co = lane & 15, k-block = lane >> 4)
-__global__ void pack_resblock16_kernel(const float* __restrict__ w, unsigned* __restrict__ dst, int c, int k) {
+static __global__ void pack_resblock16_kernel(const float* __restrict__ w, unsigned* __restrict__ dst, int c, int k) {
     const int steps = rb_ksteps16(c, k);
     const long q = (long)blockIdx.x * blockDim.x + threadIdx.x;   // (step, lane)
     if (q >= (long)steps * 64) return;

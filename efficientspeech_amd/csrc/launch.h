@@ -1,0 +1,79 @@
+// Host-side glue shared by the translation units of libesmi.so: stream / status helpers and the internal launchers
+// (one per kernel family; each is defined in the one translation unit that instantiates that family's kernels, so the
+// families compile in parallel and a kernel edit rebuilds one file).  Not part of the C-ABI (include/esmi.h is).
+#ifndef ESMI_LAUNCH_H
+#define ESMI_LAUNCH_H
+#include "../../include/esmi.h"
+
+#include <cmath>
+#include <cstring>
+
+#include "attention.h"
+#include "convgemm.h"
+#include "hifigan_resblock.h"
+#include "enc_attn_ffn.h"
+#include "enc_fuse_va.h"
+#include "enc_merge_qkv.h"
+#include "esmi_dev.h"
+#include "small_kernels.h"
+
+namespace esmi {
+
+inline hipStream_t S(esmi_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+inline int launch_status() {
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? ESMI_OK : (int)e;
+}
+inline size_t align256(size_t n) { return (n + 255) & ~(size_t)255; }
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a PER-DEVICE setting: remember per (instantiation, device ordinal) that
+// it was made (once: keeps the call out of hipGraph captures).  `done` is one static table per call site.
+constexpr int kMaxDevices = 64;
+struct AttrOnce { bool done[kMaxDevices] = {}; };
+inline int raise_lds_limit(const void* fn, AttrOnce& once) {
+#ifndef ESMI_WAVESIM
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return (int)e;
+    if (dev < 0 || dev >= kMaxDevices) return ESMI_ERR_UNSUPPORTED;
+    if (!once.done[dev]) {
+        e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return (int)e;
+        once.done[dev] = true;
+    }
+#endif
+    return ESMI_OK;
+}
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+inline int conv_out_len(int n, int k, int stride, int pad) { return (n + 2 * pad - k) / stride + 1; }
+inline unsigned grid1d(long n, int block = 256) { return (unsigned)((n + block - 1) / block); }
+
+// tu_convgemm.hip
+ConvGemmP conv_defaults();
+int launch_convgemm(ConvGemmP p, hipStream_t st);
+// tu_attention.hip
+int launch_attn(const AttnP& p, hipStream_t st);
+// tu_enc_merge.hip / tu_enc_block.hip / tu_enc_attn_ffn.hip / tu_enc_fuse_va.hip (the encoder-side chain kernels)
+int launch_enc_merge_qkv(const EncMergeP& p, int c_in, int c_out, hipStream_t st);
+int launch_enc_block(const EncAttnFfnP& p, int expansion, int c_in, int plan, hipStream_t st);
+int launch_enc_attn_ffn(const EncAttnFfnP& p, int expansion, int plan, hipStream_t st);
+int launch_enc_fuse_va(const FuseVaP& p, int dim, int kernel, int nw, bool head, hipStream_t st);
+// tu_hifigan.hip
+int launch_resblock(const ResblockP& p, int c, hipStream_t st);
+
+inline bool enc_attn_ffn_supported(int C, int N, int expansion) {
+    if ((C & 31) || N > 256 || N < 1) return false;
+    // sequences of more than 128 positions: the chain kernel runs one latency chain per 32 rows against up to 256 keys; the same
+    // ops as launches (LDS-staged attention + LDS-staged GEMMs) are faster there (small ES T = 256: 2.53 vs 2.62 ms/step; base ES
+    // block 0: 1.33 vs 2.00 ms) -- `tools/debug_plan_base.py` measures the plans
+    if (N > 128) return false;
+    const int nc = C / 32;
+    // base ES block 0 (C = 128, expansion 2) at N = 256: the chain kernel runs one latency chain per 32 rows against 256 keys
+    // (2.00 ms at B = 512); the same ops as LDS-staged GEMM launches take 1.33 ms, so that shape goes per-op
+    return (expansion == 1 && (nc == 1 || nc == 2 || nc == 4)) || (expansion == 2 && nc == 4 && N <= 128);
+}
+
+
+}  // namespace esmi
+#endif  // ESMI_LAUNCH_H

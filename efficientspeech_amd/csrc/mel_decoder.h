@@ -82,8 +82,6 @@ struct DecLayout {  // offsets in floats into the packed blob
     long l_dw, l_dwb, l_pw, l_pwb, l_g, l_b;   // relative to the layer base
     long skip0;                                // per block: gain[dx2], bias[dx2]
     long mel_w, mel_b;
-    long rows0, rows_layer_stride, rows_mel, rows_pad;   // row-owner form (mel_decoder_rows.h; dx2 = 128 split build only, else rows0 = -1):
-                                                         // per layer [A fragments 16384 | taps kd*128 | pwb' | ln_g | ln_b], mel fragments, pad row
     long total;
 };
 
@@ -106,13 +104,6 @@ inline DecLayout dec_layout(int d4, int dx2, int kd, int n_blocks, int block_dep
     L.skip0 = o; o += 2L * dx2 * n_blocks;
     L.mel_w = o; o += (long)dx2 * dx2 * kWNum / 2;   // packed like a dx2 x dx2 matrix, rows >= n_mel zero
     L.mel_b = o; o += dx2;                     // zero padded
-    L.rows0 = -1; L.rows_layer_stride = 0; L.rows_mel = 0; L.rows_pad = 0;
-    if (dx2 == 128 && ESMI_DEC_SPLIT == 2) {
-        L.rows_layer_stride = 16384 + (long)(kd + 3) * 128;
-        L.rows0 = o; o += L.rows_layer_stride * n_blocks * block_depth;
-        L.rows_mel = o; o += 12288;
-        L.rows_pad = o; o += 128;
-    }
     L.total = o;
     return L;
 }
@@ -121,7 +112,7 @@ inline DecLayout dec_layout(int d4, int dx2, int kd, int n_blocks, int block_dep
 // workgroup whose 4 column slices are WCOLS = 32*NTW wide:
 //   dst[(((((c*4 + ns)*NTW + ntw)*16 + kc)*64 + lane)*4 + s] =
 //       W[ns*WCOLS + 32*ntw + (lane&31)][128*c + 8*kc + 4*(lane>>5) + s]      (0 for rows >= N)
-__global__ void pack_bslice_kernel(const float* __restrict__ src, float* __restrict__ dst, int N, int K, int NTW) {
+static __global__ void pack_bslice_kernel(const float* __restrict__ src, float* __restrict__ dst, int N, int K, int NTW) {
     const long n = (long)(K / 128) * 4 * NTW * 16 * 256;
     for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
         const int s = (int)(e & 3);
@@ -141,7 +132,7 @@ __global__ void pack_bslice_kernel(const float* __restrict__ src, float* __restr
 // per (chunk c, column slice ns, tile ntw, 16-channel step s, plane p) 64 lanes x 4 dwords,
 //   row = ns*32*NTW + 32*ntw + (lane&31),  k0 = 128*c + 16*s + 8*(lane>>5) + 2*w       (0 for rows >= N)
 //   dst[((((((c*4 + ns)*NTW + ntw)*8 + s)*2 + p)*64 + lane)*4 + w] = {plane_p(W[row][k0 + 1]), plane_p(W[row][k0])}
-__global__ void pack_bslice2h_kernel(const float* __restrict__ src, unsigned* __restrict__ dst, int N, int K, int NTW) {
+static __global__ void pack_bslice2h_kernel(const float* __restrict__ src, unsigned* __restrict__ dst, int N, int K, int NTW) {
     const long n = (long)(K / 128) * 4 * NTW * 8 * 2 * 256;
     for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
         const int wd = (int)(e & 3);

@@ -8,7 +8,7 @@ namespace esmi {
 
 // dst[j][o][i] = src[o][i][j]   (nn.Conv1d (Cout,Cin,k) -> tap-major)   when transposed == 0
 // dst[j][o][i] = src[i][o][j]   (nn.ConvTranspose1d (Cin,Cout,k))       when transposed == 1
-__global__ void pack_conv_kernel(const float* __restrict__ src, float* __restrict__ dst, int cout, int cin, int k,
+static __global__ void pack_conv_kernel(const float* __restrict__ src, float* __restrict__ dst, int cout, int cin, int k,
                                  int transposed, int* __restrict__ zero_slot = nullptr) {
     if (zero_slot && blockIdx.x == 0 && threadIdx.x == 0) zero_slot[0] = 0;   // (training: the absmax slot of the GEMM this pack precedes)
     const long n = (long)cout * cin * k;
@@ -22,7 +22,7 @@ __global__ void pack_conv_kernel(const float* __restrict__ src, float* __restric
 
 // MFMA B-fragment packing of `taps` row-major (N, K) matrices (wave_chain.h), NT = ceil(N/32):
 //   dst[(((t*(K/8) + kc)*NT + nt)*64 + lane)*4 + s] = src[(t*N + 32*nt + (lane&31))*K + 8*kc + 4*(lane>>5) + s]   (0 for rows >= N)
-__global__ void pack_bfrag_kernel(const float* __restrict__ src, float* __restrict__ dst, int N, int K, int NT, int taps) {
+static __global__ void pack_bfrag_kernel(const float* __restrict__ src, float* __restrict__ dst, int N, int K, int NT, int taps) {
     const long per = (long)(K / 8) * NT * 256;
     const long n = per * taps;
     for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
@@ -55,7 +55,7 @@ __global__ void pack_bfrag_kernel(const float* __restrict__ src, float* __restri
 }
 
 // depthwise weight (C,1,k) -> tap-major (k, C)
-__global__ void pack_dw_kernel(const float* __restrict__ src, float* __restrict__ dst, int C, int k) {
+static __global__ void pack_dw_kernel(const float* __restrict__ src, float* __restrict__ dst, int C, int k) {
     const int n = C * k;
     for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) {
         const int c = e % C, j = e / C;
@@ -64,13 +64,13 @@ __global__ void pack_dw_kernel(const float* __restrict__ src, float* __restrict_
 }
 
 // copy n floats, zero-fill up to n_pad
-__global__ void copy_pad_kernel(const float* __restrict__ src, float* __restrict__ dst, int n, int n_pad) {
+static __global__ void copy_pad_kernel(const float* __restrict__ src, float* __restrict__ dst, int n, int n_pad) {
     for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n_pad; e += gridDim.x * blockDim.x)
         dst[e] = e < n ? src[e] : 0.0f;
 }
 
 // blocks.py:51-57: F.pad(mask, value=True) to a multiple of pool, max over groups of pool
-__global__ void pool_mask_kernel(const unsigned char* __restrict__ mask, int B, int T, int pool,
+static __global__ void pool_mask_kernel(const unsigned char* __restrict__ mask, int B, int T, int pool,
                                  unsigned char* __restrict__ out, int n_out) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= B * n_out) return;
@@ -106,7 +106,7 @@ struct VaTailP {
 };
 
 // networks.py:349-384 minus the convolutions: one thread per (row, channel)
-__global__ void va_tail_kernel(const VaTailP p) {
+static __global__ void va_tail_kernel(const VaTailP p) {
     const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= (long)p.rows * p.dim) return;
     const int row = (int)(e / p.dim), c = (int)(e - (long)row * p.dim);
@@ -129,7 +129,7 @@ __global__ void va_tail_kernel(const VaTailP p) {
 }
 
 // networks.py:233-244 as a scan: one wave per utterance, inclusive cumsum of max(dur,0)
-__global__ __launch_bounds__(64) void length_regulate_kernel(const int* __restrict__ dur, int T, int* __restrict__ cum,
+static __global__ __launch_bounds__(64) void length_regulate_kernel(const int* __restrict__ dur, int T, int* __restrict__ cum,
                                                              int* __restrict__ mel_len, int* __restrict__ lmax) {
     const int b = blockIdx.x, lane = lane_id();
     const int per = (T + 63) / 64;
@@ -161,7 +161,7 @@ __global__ __launch_bounds__(64) void length_regulate_kernel(const int* __restri
 }
 
 // out[0] = max(v[0..n), 0): one workgroup, no atomics, no zero-initialised output needed
-__global__ __launch_bounds__(64) void max_i32_kernel(const int* __restrict__ v, int n, int* __restrict__ out) {
+static __global__ __launch_bounds__(64) void max_i32_kernel(const int* __restrict__ v, int n, int* __restrict__ out) {
     const int lane = lane_id();
     int m = 0;
     for (int j = lane; j < n; j += 64) m = max(m, v[j]);
@@ -181,7 +181,7 @@ __device__ __forceinline__ int frame_to_phoneme(const int* __restrict__ cum, int
     return lo;
 }
 
-__global__ void lr_indices_kernel(const int* __restrict__ cum, int B, int T, int L, int* __restrict__ idx) {
+static __global__ void lr_indices_kernel(const int* __restrict__ cum, int B, int T, int L, int* __restrict__ idx) {
     const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= (long)B * L) return;
     const int b = (int)(e / L), f = (int)(e - (long)b * L);
@@ -190,7 +190,7 @@ __global__ void lr_indices_kernel(const int* __restrict__ cum, int B, int T, int
 }
 
 // FeatureUpsampler output (networks.py:246-255): features (B,L,C) and masks (B,L); one float4 per thread
-__global__ void upsample_kernel(const float* __restrict__ feat, const unsigned char* __restrict__ fmask,
+static __global__ void upsample_kernel(const float* __restrict__ feat, const unsigned char* __restrict__ fmask,
                                 const int* __restrict__ cum, int B, int T, int C, int L, float* __restrict__ out,
                                 unsigned char* __restrict__ omask) {
     const int c4 = C >> 2;
@@ -207,7 +207,7 @@ __global__ void upsample_kernel(const float* __restrict__ feat, const unsigned c
 }
 
 // get_embedding, networks.py:128-149: idx = bucketize(v, bins) (right = False), out row = emb[idx]; one thread per (row, channel)
-__global__ void bucket_embed_kernel(const float* __restrict__ v, const float* __restrict__ bins, const float* __restrict__ emb,
+static __global__ void bucket_embed_kernel(const float* __restrict__ v, const float* __restrict__ bins, const float* __restrict__ emb,
                                     long rows, int dim, float* __restrict__ out, int* __restrict__ idx) {
     const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= rows * dim) return;
@@ -219,7 +219,7 @@ __global__ void bucket_embed_kernel(const float* __restrict__ v, const float* __
 }
 
 // out[0] = max(out[0], max_i |x[i]|) as the bit pattern of a non-negative float (NaN counts as +inf); out[0] zeroed by the caller
-__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, long n, int* __restrict__ out) {
+static __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, long n, int* __restrict__ out) {
     int m = 0;
     for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
         const float a = fabsf(x[e]);
@@ -232,7 +232,7 @@ __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x
     if (lane == 0 && m > 0) atomicMax(out, m);
 }
 
-__global__ void mask_rows_kernel(float* __restrict__ x, const unsigned char* __restrict__ mask, long rows, int C) {
+static __global__ void mask_rows_kernel(float* __restrict__ x, const unsigned char* __restrict__ mask, long rows, int C) {
     const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= rows * C) return;
     if (mask[e / C]) x[e] = 0.0f;

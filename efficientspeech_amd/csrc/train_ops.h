@@ -37,7 +37,7 @@ __device__ __forceinline__ int conv_in_pos(const ConvDesc& d, int t, int j) {
 }
 
 // y[b, t, co] = bias[co] + sum_j sum_ci x[b, in_pos(t, j), ci] * w(co, ci, j)
-__global__ void train_conv_fwd_kernel(const ConvDesc d, const float* __restrict__ x, const float* __restrict__ w,
+static __global__ void train_conv_fwd_kernel(const ConvDesc d, const float* __restrict__ x, const float* __restrict__ w,
                                       const float* __restrict__ bias, float* __restrict__ y) {
     const long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= (long)d.B * d.n_out * d.c_out) return;
@@ -59,7 +59,7 @@ __global__ void train_conv_fwd_kernel(const ConvDesc d, const float* __restrict_
 
 // depthwise, stride 1 (MelDecoder's k = 5 convs): one thread per (row, 4 channels), 16-byte accesses; `grad` runs the data
 // gradient (the same taps mirrored: dx[t] = sum_j dy[t + pad - j] w[j]); weights (C, 1, k)
-__global__ void train_conv_dw_kernel(const ConvDesc d, const float* __restrict__ in, const float* __restrict__ w,
+static __global__ void train_conv_dw_kernel(const ConvDesc d, const float* __restrict__ in, const float* __restrict__ w,
                                      const float* __restrict__ bias, float* __restrict__ out, int grad) {
     const int c4 = d.c_out >> 2;
     const long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -78,7 +78,7 @@ __global__ void train_conv_dw_kernel(const ConvDesc d, const float* __restrict__
 }
 
 // dx[b, ti, ci] = sum over (t, j) with in_pos(t, j) == ti, and co connected to ci, of dy[b, t, co] * w(co, ci, j)
-__global__ void train_conv_dgrad_kernel(const ConvDesc d, const float* __restrict__ dy, const float* __restrict__ w,
+static __global__ void train_conv_dgrad_kernel(const ConvDesc d, const float* __restrict__ dy, const float* __restrict__ w,
                                         float* __restrict__ dx) {
     const long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= (long)d.B * d.n_in * d.c_in) return;
@@ -116,7 +116,7 @@ constexpr int kTrainChunkMfma = ESMI_TRAIN_CHUNK_MFMA;    // rows per wave of th
 __host__ __device__ inline long train_chunks(long rows, int chunk = kTrainChunk) { return (rows + chunk - 1) / chunk; }
 
 // dw(co, ci, j) = sum over (b, t) of dy[b, t, co] * x[b, in_pos(t, j), ci]: partial[chunk][weight element in checkpoint order]
-__global__ void train_conv_wgrad_kernel(const ConvDesc d, const float* __restrict__ x, const float* __restrict__ dy,
+static __global__ void train_conv_wgrad_kernel(const ConvDesc d, const float* __restrict__ x, const float* __restrict__ dy,
                                         float* __restrict__ partial, long pstride, int chunk) {
     const int cig = d.transposed ? d.c_out : d.c_in / d.groups;      // middle extent of the checkpoint layout
     const int outer = d.transposed ? d.c_in : d.c_out;
@@ -140,7 +140,7 @@ __global__ void train_conv_wgrad_kernel(const ConvDesc d, const float* __restric
 }
 // depthwise (groups == C, one input channel per output channel, k <= 8): lanes across the channels (coalesced), every thread
 // keeps the k tap sums and the bias sum of its channel over the chunk's rows
-__global__ void train_conv_wgrad_dw_kernel(const ConvDesc d, const float* __restrict__ x, const float* __restrict__ dy,
+static __global__ void train_conv_wgrad_dw_kernel(const ConvDesc d, const float* __restrict__ x, const float* __restrict__ dy,
                                            float* __restrict__ partial, float* __restrict__ partial_bias, long pstride) {
     const int c = (int)(blockIdx.x * blockDim.x + threadIdx.x);
     if (c >= d.c_out) return;
@@ -169,7 +169,7 @@ __global__ void train_conv_wgrad_dw_kernel(const ConvDesc d, const float* __rest
 // so the 32 lanes of a half cover the whole 128-channel block, fully coalesced -- and one float of X; the four values feed four
 // MFMAs whose tiles are the channel sets {4m + t}: four MFMAs per two loads, dY read once per input tile instead of once per
 // (input tile, output tile).  The (tap 0, first input tile) waves also sum dY's columns: the bias gradient.
-__global__ __launch_bounds__(256) void train_conv_wgrad_mfma_kernel(const ConvDesc d, const float* __restrict__ x,
+static __global__ __launch_bounds__(256) void train_conv_wgrad_mfma_kernel(const ConvDesc d, const float* __restrict__ x,
                                                                     const float* __restrict__ dy, float* __restrict__ partial,
                                                                     float* __restrict__ partial_bias, long chunks, long pstride) {
     const int lane = lane_id(), i = lane & 31, kh = lane >> 5;
@@ -236,7 +236,7 @@ constexpr int kReduceGroups = 4;
 #else
 constexpr int kReduceGroups = 16;
 #endif
-__global__ __launch_bounds__(64 * kReduceGroups) void train_reduce_chunks_kernel(const float* __restrict__ partial, long n, long stride,
+static __global__ __launch_bounds__(64 * kReduceGroups) void train_reduce_chunks_kernel(const float* __restrict__ partial, long n, long stride,
                                                                                 long chunks, float* __restrict__ out,
                                                                                 long n0 = -1, float* __restrict__ out1 = nullptr) {
     ESMI_DYN_LDS(red);   // 64 * kReduceGroups floats
@@ -256,7 +256,7 @@ __global__ __launch_bounds__(64 * kReduceGroups) void train_reduce_chunks_kernel
     }
 }
 // partial[chunk][c] = sum over the chunk's rows of v[row, c]   (bias gradients)
-__global__ void train_colsum_kernel(const float* __restrict__ v, long rows, int C, float* __restrict__ partial, long pstride, int chunk) {
+static __global__ void train_colsum_kernel(const float* __restrict__ v, long rows, int C, float* __restrict__ partial, long pstride, int chunk) {
     const int c = (int)(blockIdx.x * blockDim.x + threadIdx.x);
     if (c >= C) return;
     const long r0 = (long)blockIdx.y * chunk, r1 = r0 + chunk < rows ? r0 + chunk : rows;
@@ -272,7 +272,7 @@ __device__ __forceinline__ float ln_wave_sum(float v) {
     for (int m = 32; m > 0; m >>= 1) v += shfl_xor_f(v, m);
     return v;
 }
-__global__ __launch_bounds__(256) void train_ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ g,
+static __global__ __launch_bounds__(256) void train_ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ g,
                                                            const float* __restrict__ b, long rows, int C, float eps,
                                                            float* __restrict__ y, float* __restrict__ mean, float* __restrict__ rstd) {
     const long r = (long)blockIdx.x * 4 + wave_id();
@@ -288,7 +288,7 @@ __global__ __launch_bounds__(256) void train_ln_fwd_kernel(const float* __restri
     if (lane == 0) { mean[r] = m; rstd[r] = rs; }
     for (int c = lane; c < C; c += 64) y[r * C + c] = fmaf((xr[c] - m) * rs, g[c], b[c]);
 }
-__global__ __launch_bounds__(256) void train_ln_bwd_dx_kernel(const float* __restrict__ x, const float* __restrict__ g,
+static __global__ __launch_bounds__(256) void train_ln_bwd_dx_kernel(const float* __restrict__ x, const float* __restrict__ g,
                                                               const float* __restrict__ mean, const float* __restrict__ rstd,
                                                               const float* __restrict__ dy, long rows, int C, float* __restrict__ dx) {
     const long r = (long)blockIdx.x * 4 + wave_id();
@@ -312,7 +312,7 @@ __global__ __launch_bounds__(256) void train_ln_bwd_dx_kernel(const float* __res
 // across the channels; every lane keeps dgamma / dbeta sums of its (up to four) channels over its wave's rows, the four waves'
 // sums are added in wave order through LDS -> partial[workgroup][dg (C) | db (C)]
 constexpr int kLnRows = 64;
-__global__ __launch_bounds__(256) void train_ln_bwd_fused_kernel(const float* __restrict__ x, const float* __restrict__ g,
+static __global__ __launch_bounds__(256) void train_ln_bwd_fused_kernel(const float* __restrict__ x, const float* __restrict__ g,
                                                                  const float* __restrict__ mean, const float* __restrict__ rstd,
                                                                  const float* __restrict__ dy, long rows, int C,
                                                                  float* __restrict__ dx, float* __restrict__ partial) {
@@ -362,7 +362,7 @@ __global__ __launch_bounds__(256) void train_ln_bwd_fused_kernel(const float* __
 }
 
 // partial[chunk][0][c] = sum dy * xhat, partial[chunk][1][c] = sum dy over the chunk's rows
-__global__ void train_ln_bwd_params_kernel(const float* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ rstd,
+static __global__ void train_ln_bwd_params_kernel(const float* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ rstd,
                                            const float* __restrict__ dy, long rows, int C, float* __restrict__ partial) {
     const int c = (int)(blockIdx.x * blockDim.x + threadIdx.x);
     if (c >= C) return;
@@ -378,13 +378,13 @@ __global__ void train_ln_bwd_params_kernel(const float* __restrict__ x, const fl
 }
 
 // ---- activations: kind as esmi_dev.h Act (1 ReLU, 2 GELU erf, 3 tanh); backward reads y for ReLU / tanh and x for GELU
-__global__ void train_act_fwd_kernel(const float* __restrict__ x, long n, int kind, float* __restrict__ y) {
+static __global__ void train_act_fwd_kernel(const float* __restrict__ x, long n, int kind, float* __restrict__ y) {
     const long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= n) return;
     const float v = x[q];
     y[q] = kind == ACT_RELU ? fmaxf(v, 0.0f) : (kind == ACT_GELU ? 0.5f * v * (1.0f + erff(v * 0.70710678118654752f)) : tanhf(v));
 }
-__global__ void train_act_bwd_kernel(const float* __restrict__ saved, const float* __restrict__ dy, long n, int kind,
+static __global__ void train_act_bwd_kernel(const float* __restrict__ saved, const float* __restrict__ dy, long n, int kind,
                                      float* __restrict__ dx) {
     const long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= n) return;
@@ -409,7 +409,7 @@ __device__ __forceinline__ float wave_allreduce_sum(float v) {
     for (int m = 32; m > 0; m >>= 1) v += shfl_xor_f(v, m);
     return v;
 }
-__global__ __launch_bounds__(64) void train_attn_fwd_kernel(const float* __restrict__ qkv, int B, int N, int C, int h, float scale,
+static __global__ __launch_bounds__(64) void train_attn_fwd_kernel(const float* __restrict__ qkv, int B, int N, int C, int h, float scale,
                                                             float* __restrict__ P, float* __restrict__ ctx) {
     const long q = blockIdx.x;
     const int lane = (int)threadIdx.x;
@@ -441,7 +441,7 @@ __global__ __launch_bounds__(64) void train_attn_fwd_kernel(const float* __restr
     }
 }
 // row i: dP = dctx_i . V^T, dS = P o (dP - <P, dP>), dq_i = scale dS K;  dS (B, h, N, N) kept for the column pass
-__global__ __launch_bounds__(64) void train_attn_bwd_rows_kernel(const float* __restrict__ qkv, const float* __restrict__ P,
+static __global__ __launch_bounds__(64) void train_attn_bwd_rows_kernel(const float* __restrict__ qkv, const float* __restrict__ P,
                                                                  const float* __restrict__ dctx, int B, int N, int C, int h,
                                                                  float scale, float* __restrict__ dS, float* __restrict__ dqkv) {
     const long q = blockIdx.x;
@@ -474,7 +474,7 @@ __global__ __launch_bounds__(64) void train_attn_bwd_rows_kernel(const float* __
 // taking query rows w, w + 4, ...  Used whenever 2 N (C + 1) + 4 N floats fit (tiny / small ES at any realistic length); the
 // global-memory versions above remain for the rest.
 __host__ __device__ inline size_t train_attn_lds_bytes(int N, int C) { return ((size_t)2 * N * (C + 1) + 4 * (size_t)N) * sizeof(float); }
-__global__ __launch_bounds__(256) void train_attn_fwd_lds_kernel(const float* __restrict__ qkv, int B, int N, int C, int h, float scale,
+static __global__ __launch_bounds__(256) void train_attn_fwd_lds_kernel(const float* __restrict__ qkv, int B, int N, int C, int h, float scale,
                                                                  float* __restrict__ P, float* __restrict__ ctx) {
     ESMI_DYN_LDS(lds);
     float* Ks = lds;
@@ -515,7 +515,7 @@ __global__ __launch_bounds__(256) void train_attn_fwd_lds_kernel(const float* __
         lds_wave_sync();                               // before the next row overwrites prow
     }
 }
-__global__ __launch_bounds__(256) void train_attn_bwd_rows_lds_kernel(const float* __restrict__ qkv, const float* __restrict__ P,
+static __global__ __launch_bounds__(256) void train_attn_bwd_rows_lds_kernel(const float* __restrict__ qkv, const float* __restrict__ P,
                                                                       const float* __restrict__ dctx, int B, int N, int C, int h,
                                                                       float scale, float* __restrict__ dS, float* __restrict__ dqkv) {
     ESMI_DYN_LDS(lds);
@@ -555,7 +555,7 @@ __global__ __launch_bounds__(256) void train_attn_bwd_rows_lds_kernel(const floa
 }
 
 // column j, channel c: dk_j = scale dS^T Q, dv_j = P^T dctx   (one thread per (b, head, j, c))
-__global__ void train_attn_bwd_cols_kernel(const float* __restrict__ qkv, const float* __restrict__ P, const float* __restrict__ dS,
+static __global__ void train_attn_bwd_cols_kernel(const float* __restrict__ qkv, const float* __restrict__ P, const float* __restrict__ dS,
                                            const float* __restrict__ dctx, int B, int N, int C, int h, float scale,
                                            float* __restrict__ dqkv) {
     const long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -574,7 +574,7 @@ __global__ void train_attn_bwd_cols_kernel(const float* __restrict__ qkv, const 
 
 // ---- embedding: forward gather (out-of-range ids read row 0); backward one thread per table element, rows with id ==
 // padding_idx get no gradient (nn.Embedding(padding_idx), networks.py:32)
-__global__ void train_embed_fwd_kernel(const int* __restrict__ ids, const float* __restrict__ table, long rows, int V, int C,
+static __global__ void train_embed_fwd_kernel(const int* __restrict__ ids, const float* __restrict__ table, long rows, int V, int C,
                                        float* __restrict__ out) {
     const long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= rows * C) return;
@@ -582,7 +582,7 @@ __global__ void train_embed_fwd_kernel(const int* __restrict__ ids, const float*
     if (id < 0 || id >= V) id = 0;
     out[q] = table[(long)id * C + q % C];
 }
-__global__ void train_embed_bwd_kernel(const int* __restrict__ ids, const float* __restrict__ dy, long rows, int V, int C,
+static __global__ void train_embed_bwd_kernel(const int* __restrict__ ids, const float* __restrict__ dy, long rows, int V, int C,
                                        int padding_idx, float* __restrict__ partial) {
     const long q = (long)blockIdx.x * blockDim.x + threadIdx.x;   // partial[chunk][v][c] over the chunk's rows
     if (q >= (long)V * C) return;
@@ -596,17 +596,17 @@ __global__ void train_embed_bwd_kernel(const int* __restrict__ ids, const float*
 }
 
 // ---- row masking (masked_fill(mask, 0) with a per-row mask), residual add, column-block copy (torch.cat / its gradient)
-__global__ void train_mask_rows_kernel(const float* __restrict__ x, const unsigned char* __restrict__ mask, long rows, int C,
+static __global__ void train_mask_rows_kernel(const float* __restrict__ x, const unsigned char* __restrict__ mask, long rows, int C,
                                        float* __restrict__ y) {
     const long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= rows * C) return;
     y[q] = mask[q / C] ? 0.0f : x[q];
 }
-__global__ void train_add_kernel(const float* __restrict__ a, const float* __restrict__ b, long n, float* __restrict__ y) {
+static __global__ void train_add_kernel(const float* __restrict__ a, const float* __restrict__ b, long n, float* __restrict__ y) {
     const long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (q < n) y[q] = a[q] + b[q];
 }
-__global__ void train_copy_cols_kernel(const float* __restrict__ src, int ld_src, int col_src, float* __restrict__ dst, int ld_dst,
+static __global__ void train_copy_cols_kernel(const float* __restrict__ src, int ld_src, int col_src, float* __restrict__ dst, int ld_dst,
                                        int col_dst, long rows, int C) {
     const long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= rows * C) return;
@@ -617,7 +617,7 @@ __global__ void train_copy_cols_kernel(const float* __restrict__ src, int ld_src
 
 // ---- length regulator (networks.py:233-244) forward / backward on the inclusive duration cumsum `cum` (B, T):
 // frame f of utterance b copies phoneme t with cum[t-1] <= f < cum[t]; frames >= cum[T-1] are zero padding
-__global__ void train_repeat_fwd_kernel(const float* __restrict__ feat, const int* __restrict__ cum, int B, int T, int C, int L,
+static __global__ void train_repeat_fwd_kernel(const float* __restrict__ feat, const int* __restrict__ cum, int B, int T, int C, int L,
                                         float* __restrict__ out) {
     const long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= (long)B * L * C) return;
@@ -627,7 +627,7 @@ __global__ void train_repeat_fwd_kernel(const float* __restrict__ feat, const in
     while (lo < hi) { const int mid = (lo + hi) >> 1; if (cb[mid] > f) hi = mid; else lo = mid + 1; }
     out[q] = lo < T ? feat[((long)b * T + lo) * C + c] : 0.0f;
 }
-__global__ void train_repeat_bwd_kernel(const float* __restrict__ dout, const int* __restrict__ cum, int B, int T, int C, int L,
+static __global__ void train_repeat_bwd_kernel(const float* __restrict__ dout, const int* __restrict__ cum, int B, int T, int C, int L,
                                         float* __restrict__ dfeat) {
     const long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= (long)B * T * C) return;
@@ -668,7 +668,7 @@ __device__ __forceinline__ float block_sum_256(float v, float* red) {
     __syncthreads();
     return r;
 }
-__global__ __launch_bounds__(256) void train_loss_partial_kernel(const LossP p) {
+static __global__ __launch_bounds__(256) void train_loss_partial_kernel(const LossP p) {
     ESMI_DYN_LDS(red);   // 256 floats
     const long tid = (long)blockIdx.x * 256 + threadIdx.x, nth = (long)kLossBlocks * 256;
     const long nf = (long)p.B * p.L, np_ = (long)p.B * p.T;
@@ -689,7 +689,7 @@ __global__ __launch_bounds__(256) void train_loss_partial_kernel(const LossP p) 
         if (threadIdx.x == 0) p.partial[(long)blockIdx.x * 6 + e] = t;
     }
 }
-__global__ __launch_bounds__(256) void train_loss_final_kernel(const LossP p) {
+static __global__ __launch_bounds__(256) void train_loss_final_kernel(const LossP p) {
     ESMI_DYN_LDS(red);
     float t[6];
 #pragma unroll
@@ -703,7 +703,7 @@ __global__ __launch_bounds__(256) void train_loss_final_kernel(const LossP p) {
         p.partial[1] = n_ph;
     }
 }
-__global__ void train_loss_grad_kernel(const LossP p) {
+static __global__ void train_loss_grad_kernel(const LossP p) {
     const long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const long nm = (long)p.B * p.L * p.n_mel, np_ = (long)p.B * p.T;
     const float n_el = p.partial[0], n_ph = p.partial[1];
@@ -739,7 +739,7 @@ __device__ __forceinline__ void adamw_update(float* __restrict__ p, const float*
     p[q] = w;
 }
 
-__global__ void train_adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+static __global__ void train_adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                                    long n, AdamWScalars h) {
     const long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (q < n) adamw_update(p, g, m, v, q, h);
@@ -748,7 +748,7 @@ __global__ void train_adamw_kernel(float* __restrict__ p, const float* __restric
 // the same with the step count and the learning rate read from device memory, so that a captured hipGraph of the whole
 // training step replays correctly: hyper = {lr (caller), 1 - lr wd, lr / bc1, sqrt(bc2)}; *step is advanced and the three derived
 // scalars are written by train_bump_step_kernel (one thread, double precision) inside the graph
-__global__ void train_bump_step_kernel(int* __restrict__ step, float* __restrict__ hyper, double beta1, double beta2, double wd) {
+static __global__ void train_bump_step_kernel(int* __restrict__ step, float* __restrict__ hyper, double beta1, double beta2, double wd) {
     if (threadIdx.x != 0) return;
     const int t = step[0] + 1;
     step[0] = t;
@@ -758,7 +758,7 @@ __global__ void train_bump_step_kernel(int* __restrict__ step, float* __restrict
     hyper[2] = (float)(lr / bc1);
     hyper[3] = (float)sqrt(bc2);
 }
-__global__ void train_adamw_dev_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+static __global__ void train_adamw_dev_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                                        long n, AdamWScalars h, const float* __restrict__ hyper) {
     const long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= n) return;

@@ -1,0 +1,56 @@
+// esmi C-ABI, translation unit "tu_attention.hip": stand-alone attention kernels (attention.h)
+// One of several translation units of libesmi.so (compiled in parallel by __graft_entry__.build(); the simulator build
+// tools/wavesim/build.sh compiles the same files with the host compiler).  Internal launchers are declared in launch.h.
+#include "launch.h"
+
+using namespace esmi;
+
+namespace esmi {
+
+#ifndef ESMI_ATTN_LDS_MIN_HEADS
+#ifdef ESMI_WAVESIM
+#define ESMI_ATTN_LDS_MIN_HEADS 1      // (simulator: always take the LDS kernel where it applies, so the tests reach it)
+#else
+#define ESMI_ATTN_LDS_MIN_HEADS 128    // enough (utterance, head) workgroups to occupy the chip at one per CU
+#endif
+#endif
+int launch_attn(const AttnP& p, hipStream_t st) {
+    if ((p.C & 31) || p.N <= 0) return ESMI_ERR_ARG;   // channel groups of 32 (4 k-steps fetched together)
+    const int nkt = (p.N + 31) / 32;
+    const int tiles = p.B * p.h * nkt;
+    dim3 grid((tiles + 3) / 4), block(256);
+    if (nkt > 8) {   // N > 256: key-chunked two-sweep kernel (no sequence limit, as the reference)
+        switch (p.C / 32) {
+            case 1: ESMI_LAUNCH((attn_long_kernel<1>), grid, block, 0, st, p); break;
+            case 2: ESMI_LAUNCH((attn_long_kernel<2>), grid, block, 0, st, p); break;
+            case 4: ESMI_LAUNCH((attn_long_kernel<4>), grid, block, 0, st, p); break;
+            case 8: ESMI_LAUNCH((attn_long_kernel<8>), grid, block, 0, st, p); break;
+            default: return ESMI_ERR_UNSUPPORTED;   // widths of the three published sizes: 32 .. 256
+        }
+        return launch_status();
+    }
+#if ESMI_CHAIN_SPLIT
+    // heads with several query tiles: K and V staged once per (utterance, head) in LDS instead of once per tile from L2
+    if (nkt >= 3 && (p.C <= 128 || p.C % 128 == 0) && attn_lds_bytes(p.N, p.C) <= 150 * 1024 && (long)p.B * p.h >= ESMI_ATTN_LDS_MIN_HEADS) {
+        const size_t lds = attn_lds_bytes(p.N, p.C);
+        dim3 g2((unsigned)(p.B * p.h));
+        if (nkt <= 4) {
+            static AttrOnce once;
+            if (int rc = raise_lds_limit(reinterpret_cast<const void*>(attn_lds_kernel<4>), once)) return rc;
+            ESMI_LAUNCH((attn_lds_kernel<4>), g2, dim3(256), lds, st, p);
+        } else {
+            static AttrOnce once;
+            if (int rc = raise_lds_limit(reinterpret_cast<const void*>(attn_lds_kernel<8>), once)) return rc;
+            ESMI_LAUNCH((attn_lds_kernel<8>), g2, dim3(512), lds, st, p);
+        }
+        return launch_status();
+    }
+#endif
+    if (nkt == 1) ESMI_LAUNCH((attn_kernel<1>), grid, block, 0, st, p);
+    else if (nkt == 2) ESMI_LAUNCH((attn_kernel<2>), grid, block, 0, st, p);
+    else if (nkt <= 4) ESMI_LAUNCH((attn_kernel<4>), grid, block, 0, st, p);
+    else ESMI_LAUNCH((attn_kernel<8>), grid, block, 0, st, p);
+    return launch_status();
+}
+
+}  // namespace esmi

@@ -1,0 +1,78 @@
+// esmi C-ABI, translation unit "tu_convgemm.hip": implicit-GEMM convolutions / Linears of the one-kernel-per-op plan (convgemm.h)
+// One of several translation units of libesmi.so (compiled in parallel by __graft_entry__.build(); the simulator build
+// tools/wavesim/build.sh compiles the same files with the host compiler).  Internal launchers are declared in launch.h.
+#include "launch.h"
+
+using namespace esmi;
+
+
+#ifndef ESMI_GEMM_LDS_MIN_ROWS   // rows (B * n_out) from which the per-op plan's GEMMs take the LDS-staged kernel
+#ifdef ESMI_WAVESIM
+#define ESMI_GEMM_LDS_MIN_ROWS 1   // the simulator tests are small: run them through it too
+#else
+#define ESMI_GEMM_LDS_MIN_ROWS 2048
+#endif
+#endif
+
+namespace esmi {
+
+ConvGemmP conv_defaults() {
+    ConvGemmP p;
+    memset(&p, 0, sizeof p);
+    p.k = 1; p.stride = 1; p.pad = 0; p.mode = MODE_CONV;
+    return p;
+}
+
+// full_row: the epilogue needs a whole output row inside one wave (LayerNorm / row-dot)
+int launch_convgemm(ConvGemmP p, hipStream_t st) {
+    if ((p.c_in & 7) || p.c_in <= 0 || p.c_out <= 0 || p.n_out <= 0 || p.B <= 0) return ESMI_ERR_ARG;
+    if (!p.W || !aligned16(p.W)) return ESMI_ERR_ARG;
+    if (p.ids) {
+        if (!p.table || (p.ld_table & 3) || !aligned16(p.table)) return ESMI_ERR_ARG;
+    } else if (!p.A || (p.lda & 3) || (p.a_coff & 3) || !aligned16(p.A)) return ESMI_ERR_ARG;
+    const bool full_row = p.ln_g || p.dot_out;
+    if (p.c_out == 1 && p.mode == MODE_CONV && p.stride == 1 && !p.ids && !full_row && !p.res && !p.rowmask && p.out) {
+        const long n = (long)p.B * p.n_out;
+        ESMI_LAUNCH(conv_to1_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p);
+        return launch_status();
+    }
+    int nt;
+    if (full_row) {
+        nt = (p.c_out + 31) / 32;
+        if (nt == 3) nt = 4;
+        if (nt > 4 && nt <= 8) nt = 8;
+        if (nt > 8) return ESMI_ERR_UNSUPPORTED;
+        if (p.ln_g && p.c_out != 32 * nt) return ESMI_ERR_UNSUPPORTED;  // LN width must be 32/64/128/256
+    } else {
+        nt = p.c_out > 64 ? 4 : (p.c_out > 32 ? 2 : 1);
+    }
+#if ESMI_CHAIN_SPLIT
+    // large plain convolutions / Linears: weight tile staged through LDS once per 128 positions (convgemm.h)
+    if (p.mode == MODE_CONV && p.stride == 1 && !p.ids && (p.c_in & 31) == 0 && p.c_out > 64 && (long)p.B * p.n_out >= ESMI_GEMM_LDS_MIN_ROWS) {
+        const int nl = full_row ? (nt <= 4 ? 4 : 8) : ((p.c_out & 255) == 0 ? 8 : 4);
+        constexpr int kRows = 32 * ESMI_GEMM_LDS_WAVES;
+        dim3 g2((unsigned)(p.B * ((p.n_out + kRows - 1) / kRows)), full_row ? 1 : (p.c_out + 32 * nl - 1) / (32 * nl));
+        if (nl == 4) {
+            ESMI_LAUNCH((convgemm_lds_kernel<4>), g2, dim3(64 * ESMI_GEMM_LDS_WAVES), convgemm_lds_bytes<4>(), st, p);
+        } else {
+            static AttrOnce once;
+            if (int rc = raise_lds_limit(reinterpret_cast<const void*>(convgemm_lds_kernel<8>), once)) return rc;
+            ESMI_LAUNCH((convgemm_lds_kernel<8>), g2, dim3(64 * ESMI_GEMM_LDS_WAVES), convgemm_lds_bytes<8>(), st, p);
+        }
+        return launch_status();
+    }
+#endif
+    const int tiles = p.B * convgemm_tiles_per_phase(p) * convgemm_row_stride(p);
+    dim3 grid((tiles + 3) / 4, full_row ? 1 : (p.c_out + 32 * nt - 1) / (32 * nt));
+    dim3 block(256);
+    switch (nt) {
+        case 1: ESMI_LAUNCH((convgemm_kernel<1>), grid, block, 0, st, p); break;
+        case 2: ESMI_LAUNCH((convgemm_kernel<2>), grid, block, 0, st, p); break;
+        case 4: ESMI_LAUNCH((convgemm_kernel<4>), grid, block, 0, st, p); break;
+        case 8: ESMI_LAUNCH((convgemm_kernel<8>), grid, block, 0, st, p); break;
+        default: return ESMI_ERR_UNSUPPORTED;
+    }
+    return launch_status();
+}
+
+}  // namespace esmi

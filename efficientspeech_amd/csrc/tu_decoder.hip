@@ -1,0 +1,121 @@
+// esmi C-ABI, translation unit "tu_decoder.hip": the mel decoder: blob packer and mel_decoder_kernel launches (mel_decoder.h)
+// One of several translation units of libesmi.so (compiled in parallel by __graft_entry__.build(); the simulator build
+// tools/wavesim/build.sh compiles the same files with the host compiler).  Internal launchers are declared in launch.h.
+#include "launch.h"
+#include "mel_decoder.h"
+
+using namespace esmi;
+
+namespace esmi {
+int launch_mel_decoder_128_5(const MelDecP& p, dim3 grid, hipStream_t st);
+int launch_mel_decoder_128_3(const MelDecP& p, dim3 grid, hipStream_t st);
+int launch_mel_decoder_256_5(const MelDecP& p, dim3 grid, hipStream_t st);
+int launch_mel_decoder_256_3(const MelDecP& p, dim3 grid, hipStream_t st);
+}  // namespace esmi
+
+#ifdef ESMI_DEC_TRACE
+long long* g_esmi_trace = nullptr;
+extern "C" void esmi_dev_set_trace(long long* ptr) { g_esmi_trace = ptr; }
+#endif
+
+extern "C" {
+
+static int dec_check(const esmi_decoder_shape* s) {
+    if (!s) return ESMI_ERR_ARG;
+    if (s->dx2 != 128 && s->dx2 != 256) return ESMI_ERR_UNSUPPORTED;
+    if (s->d4 <= 0 || s->d4 % 128) return ESMI_ERR_UNSUPPORTED;
+    if (s->kernel != 3 && s->kernel != 5) return ESMI_ERR_UNSUPPORTED;
+    if (s->n_mel <= 0 || s->n_mel > kMelCols) return ESMI_ERR_UNSUPPORTED;
+    if (s->n_blocks < 1 || s->block_depth < 1 || s->n_blocks * s->block_depth > ESMI_MAX_DEC_LAYERS) return ESMI_ERR_UNSUPPORTED;
+    if (2 * (s->kernel / 2) * s->n_blocks * s->block_depth >= kDecRows - 32) return ESMI_ERR_UNSUPPORTED;
+    return ESMI_OK;
+}
+
+size_t esmi_mel_decoder_blob_bytes(const esmi_decoder_shape* s) {
+    if (dec_check(s)) return 0;
+    return (size_t)dec_layout(s->d4, s->dx2, s->kernel, s->n_blocks, s->block_depth).total * sizeof(float);
+}
+
+int esmi_mel_decoder_pack_f32(const esmi_decoder_weights* w, const esmi_decoder_shape* s, float* blob,
+                              esmi_stream_t stream) {
+    int rc = dec_check(s);
+    if (rc) return rc;
+    if (!w || !blob) return ESMI_ERR_ARG;
+    const DecLayout L = dec_layout(s->d4, s->dx2, s->kernel, s->n_blocks, s->block_depth);
+    hipStream_t st = S(stream);
+    const int dx2 = s->dx2, ntw = dx2 / 128;
+    auto bslice = [&](const float* src, long off, int N, int K) {
+#if ESMI_DEC_SPLIT == 2
+        const long n = (long)(K / 128) * 4 * ntw * 8 * 2 * 256;
+        ESMI_LAUNCH(pack_bslice2h_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src,
+                    reinterpret_cast<unsigned*>(blob + off), N, K, ntw);
+#else
+        const long n = (long)(K / 128) * 4 * ntw * 16 * 256;
+        ESMI_LAUNCH(pack_bslice_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src, blob + off, N, K, ntw);
+#endif
+    };
+    auto vec = [&](const float* src, long off, int n, int n_pad) {
+        ESMI_LAUNCH(copy_pad_kernel, dim3((n_pad + 255) / 256), dim3(256), 0, st, src, blob + off, n, n_pad);
+    };
+    bslice(w->proj_w, L.proj_w, dx2, s->d4);
+    vec(w->proj_b, L.proj_b, dx2, dx2);
+    vec(w->proj_ln_g, L.proj_g, dx2, dx2);
+    vec(w->proj_ln_b, L.proj_beta, dx2, dx2);
+    for (int l = 0; l < s->n_blocks * s->block_depth; ++l) {
+        const long base = L.layer0 + (long)l * L.layer_stride;
+        if (!w->dw_w[l] || !w->pw_w[l]) return ESMI_ERR_ARG;
+        ESMI_LAUNCH(pack_dw_kernel, dim3((dx2 * s->kernel + 255) / 256), dim3(256), 0, st, w->dw_w[l], blob + base + L.l_dw,
+                    dx2, s->kernel);
+        vec(w->dw_b[l], base + L.l_dwb, dx2, dx2);
+        bslice(w->pw_w[l], base + L.l_pw, dx2, dx2);
+        vec(w->pw_b[l], base + L.l_pwb, dx2, dx2);
+        vec(w->ln_g[l], base + L.l_g, dx2, dx2);
+        vec(w->ln_b[l], base + L.l_b, dx2, dx2);
+    }
+    for (int b = 0; b < s->n_blocks; ++b) {
+        vec(w->skip_g[b], L.skip0 + 2L * dx2 * b, dx2, dx2);
+        vec(w->skip_b[b], L.skip0 + 2L * dx2 * b + dx2, dx2, dx2);
+    }
+    bslice(w->mel_w, L.mel_w, s->n_mel, dx2);
+    vec(w->mel_b, L.mel_b, s->n_mel, dx2);
+    return launch_status();
+}
+
+static int mel_decoder_launch(const float* blob, const esmi_decoder_shape* s, const float* x, const float* h0,
+                              const int32_t* cum, const int32_t* mel_len, const int32_t* lmax_dev, int lmax_host, int apply_mask, int B, int T,
+                              int L_out, float* mel, esmi_stream_t stream) {
+    int rc = dec_check(s);
+    if (rc) return rc;
+    if (!blob || (!x && !h0) || !mel || B <= 0 || L_out <= 0 || !aligned16(blob) || (x && !aligned16(x))) return ESMI_ERR_ARG;
+    if (h0 && (!cum || !aligned16(h0))) return ESMI_ERR_ARG;   // the phoneme-rate head only exists in the fused-gather mode
+    if (!cum && lmax_dev) return ESMI_ERR_ARG;  // direct mode: L is the tensor's own length, known to the host
+    if (!lmax_dev && lmax_host == 0) return ESMI_ERR_ARG;
+    if (!lmax_dev && lmax_host < 0 && (!mel_len || !cum)) return ESMI_ERR_ARG;   // L derived from mel_len
+    MelDecP p;
+    p.blob = blob;
+    p.lay = dec_layout(s->d4, s->dx2, s->kernel, s->n_blocks, s->block_depth);
+    p.d4 = s->d4; p.n_blocks = s->n_blocks; p.block_depth = s->block_depth; p.n_mel = s->n_mel;
+    p.x = x; p.h0 = h0; p.cum = cum; p.mel_len = mel_len; p.lmax_dev = lmax_dev; p.lmax_host = lmax_host;
+    p.apply_mask = apply_mask && mel_len; p.B = B; p.T = T; p.L_out = L_out; p.mel = mel;
+    p.halo = (s->kernel / 2) * s->n_blocks * s->block_depth;
+    p.TL = kDecRows - 2 * p.halo;
+    p.trace = nullptr;
+#ifdef ESMI_DEC_TRACE
+    p.trace = g_esmi_trace;   // development only, see tools/trace_decoder.py
+#endif
+    hipStream_t st = S(stream);
+    p.n_tiles = (L_out + p.TL - 1) / p.TL;
+    dim3 grid((unsigned)(p.n_tiles * ((B + 7) / 8) * 8)), block(kDecThreads);
+    // one translation unit per instantiation (tu_dec_<dx2>_<k>.hip): the kernel is by far the slowest thing to compile
+    if (s->dx2 == 128 && s->kernel == 5) return launch_mel_decoder_128_5(p, grid, st);
+    if (s->dx2 == 128 && s->kernel == 3) return launch_mel_decoder_128_3(p, grid, st);
+    if (s->dx2 == 256 && s->kernel == 5) return launch_mel_decoder_256_5(p, grid, st);
+    return launch_mel_decoder_256_3(p, grid, st);
+}
+
+int esmi_mel_decoder_f32(const float* blob, const esmi_decoder_shape* s, const float* x, const float* h0,
+                         const int32_t* cum, const int32_t* mel_len, const int32_t* lmax_dev, int lmax_host, int apply_mask, int B, int T,
+                         int L_out, float* mel, esmi_stream_t stream) {
+    return mel_decoder_launch(blob, s, x, h0, cum, mel_len, lmax_dev, lmax_host, apply_mask, B, T, L_out, mel, stream);
+}
+}  // extern "C"

@@ -1,0 +1,302 @@
+// esmi C-ABI, translation unit "tu_train.hip": the training step's operators (train_ops.h)
+// One of several translation units of libesmi.so (compiled in parallel by __graft_entry__.build(); the simulator build
+// tools/wavesim/build.sh compiles the same files with the host compiler).  Internal launchers are declared in launch.h.
+#include "launch.h"
+#include "train_ops.h"
+
+using namespace esmi;
+
+extern "C" {
+
+// ------------------------------------------------------------------ training step (csrc/train_ops.h)
+namespace {
+int conv_desc_ok(const esmi_conv_desc* d, ConvDesc* o) {
+    if (!d || d->B <= 0 || d->n_in <= 0 || d->n_out <= 0 || d->c_in <= 0 || d->c_out <= 0 || d->k <= 0 || d->stride <= 0 || d->pad < 0 ||
+        d->groups <= 0)
+        return ESMI_ERR_ARG;
+    if (d->groups != 1 && (d->transposed || d->c_in % d->groups || d->c_out % d->groups)) return ESMI_ERR_UNSUPPORTED;
+    *o = ConvDesc{d->B, d->n_in, d->c_in, d->n_out, d->c_out, d->k, d->stride, d->pad, d->groups, d->transposed ? 1 : 0};
+    return ESMI_OK;
+}
+}  // namespace
+
+namespace {
+inline bool wgrad_depthwise(const ConvDesc& c) { return !c.transposed && c.groups == c.c_in && c.c_in == c.c_out && c.k <= 8; }
+inline bool wgrad_on_mfma(const ConvDesc& c);
+inline int wgrad_chunk(const ConvDesc& c) {   // rows per partial sum: fewer for small weights, whose parallelism must come from the chunks
+    if (wgrad_on_mfma(c)) return kTrainChunkMfma;
+    if (wgrad_depthwise(c)) return kTrainChunkDw;
+    const long nw = (long)(c.transposed ? c.c_in * c.c_out : c.c_out * (c.c_in / c.groups)) * c.k;
+    return nw < 1024 ? 32 : kTrainChunk;
+}
+inline bool wgrad_on_mfma(const ConvDesc& c) { return c.groups == 1 && c.c_in >= 8 && c.c_out >= 8 && (c.c_out & 3) == 0; }
+}
+// Dense convolutions (groups == 1) of the training step run on the matrix pipe through the inference path's implicit GEMM
+// (convgemm.h) when the caller gives scratch for the tap-major copy of the weight: the forward as it is, the data gradient as
+// the transposed problem -- d(Conv1d) is a ConvTranspose1d of dy with the same (Cout, Cin, k) tensor read as (Cin', Cout', k),
+// d(ConvTranspose1d) is a Conv1d of dy with (Cin, Cout, k) read as (Cout', Cin', k).  Everything else (depthwise, channel
+// counts the GEMM does not take, no scratch) runs the one-thread-per-element kernels of train_ops.h.
+size_t esmi_train_conv_workspace_bytes(const esmi_conv_desc* d) {
+    ConvDesc c;
+    if (conv_desc_ok(d, &c) || c.groups != 1) return 0;
+    return align256((size_t)c.k * c.c_out * c.c_in * sizeof(float)) + 256;   // + the data gradient's absmax / scale slots
+}
+namespace {
+// one of the two implicit-GEMM problems of a dense conv: returns ESMI_ERR_UNSUPPORTED when the GEMM does not take the shape
+int train_conv_gemm(const ConvDesc& c, bool grad, const float* in, const float* w, const float* bias, float* out, float* wt,
+                    hipStream_t st) {
+    const int cin = grad ? c.c_out : c.c_in, cout = grad ? c.c_in : c.c_out;      // of the GEMM problem
+    if (c.groups != 1 || (cin & 7) || !wt) return ESMI_ERR_UNSUPPORTED;
+    if (cout == 1 && (grad != (c.transposed != 0) || c.stride != 1)) return ESMI_ERR_UNSUPPORTED;   // the one-channel kernel is a plain conv
+    const long n = (long)c.k * c.c_out * c.c_in;
+    // tap-major (k, cout, cin) of the problem: forward conv / grad of convT read the tensor as Conv1d, the other two as ConvTranspose1d
+    const int as_convT = (grad != (c.transposed != 0)) ? 1 : 0;
+    int* amax = reinterpret_cast<int*>(reinterpret_cast<char*>(wt) + align256((size_t)n * sizeof(float)));
+    const float* wuse = wt;
+    if (c.k == 1 && !as_convT && !grad) {
+        wuse = w;                                   // a Linear's (Cout, Cin) IS its tap-major form: no copy
+    } else {
+        ESMI_LAUNCH(pack_conv_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, w, wt, cout, cin, c.k, as_convT, grad ? amax : nullptr);
+        if (int rc = launch_status()) return rc;
+    }
+    ConvGemmP p = conv_defaults();
+    if (grad) {   // max|dy| on the device; the GEMM kernels derive the power-of-two scales from it (convgemm.h conv_pow2_scales)
+        const long len = (long)c.B * c.n_out * c.c_out, blocks = (len + 256L * 8 - 1) / (256L * 8);
+        ESMI_LAUNCH(absmax_kernel, dim3((unsigned)(blocks > 1024 ? 1024 : blocks)), dim3(256), 0, st, in, len, amax);
+        if (int rc = launch_status()) return rc;
+        p.io_scale = reinterpret_cast<const float*>(amax);
+    }
+    p.mode = as_convT ? MODE_CONVT : MODE_CONV;
+    p.k = c.k; p.stride = c.stride; p.pad = c.pad;
+    p.B = c.B; p.n_in = grad ? c.n_out : c.n_in; p.n_out = grad ? c.n_in : c.n_out; p.c_in = cin; p.c_out = cout;
+    p.A = in; p.lda = cin; p.W = wuse; p.bias = bias; p.out = out; p.ldo = cout;
+    return launch_convgemm(p, st);
+}
+}  // namespace
+
+int esmi_train_conv_fwd_f32(const esmi_conv_desc* d, const float* x, const float* w, const float* bias, float* y, void* workspace,
+                            size_t workspace_bytes, esmi_stream_t stream) {
+    ConvDesc c;
+    if (int rc = conv_desc_ok(d, &c)) return rc;
+    if (!x || !w || !y) return ESMI_ERR_ARG;
+    if (workspace && workspace_bytes >= esmi_train_conv_workspace_bytes(d)) {
+        const int rc = train_conv_gemm(c, false, x, w, bias, y, static_cast<float*>(workspace), S(stream));
+        if (rc != ESMI_ERR_UNSUPPORTED) return rc;
+    }
+    const long n = (long)c.B * c.n_out * c.c_out;
+    if (wgrad_depthwise(c) && c.stride == 1 && (c.c_out & 3) == 0) {
+        ESMI_LAUNCH(train_conv_dw_kernel, grid1d(n / 4), dim3(256), 0, S(stream), c, x, w, bias, y, 0);
+        return launch_status();
+    }
+    ESMI_LAUNCH(train_conv_fwd_kernel, grid1d(n), dim3(256), 0, S(stream), c, x, w, bias, y);
+    return launch_status();
+}
+int esmi_train_conv_dgrad_f32(const esmi_conv_desc* d, const float* dy, const float* w, float* dx, void* workspace,
+                              size_t workspace_bytes, esmi_stream_t stream) {
+    ConvDesc c;
+    if (int rc = conv_desc_ok(d, &c)) return rc;
+    if (!dy || !w || !dx) return ESMI_ERR_ARG;
+    if (workspace && workspace_bytes >= esmi_train_conv_workspace_bytes(d)) {
+        const int rc = train_conv_gemm(c, true, dy, w, nullptr, dx, static_cast<float*>(workspace), S(stream));
+        if (rc != ESMI_ERR_UNSUPPORTED) return rc;
+    }
+    const long n = (long)c.B * c.n_in * c.c_in;
+    if (wgrad_depthwise(c) && c.stride == 1 && (c.c_out & 3) == 0) {
+        ESMI_LAUNCH(train_conv_dw_kernel, grid1d(n / 4), dim3(256), 0, S(stream), c, dy, w, nullptr, dx, 1);
+        return launch_status();
+    }
+    ESMI_LAUNCH(train_conv_dgrad_kernel, grid1d(n), dim3(256), 0, S(stream), c, dy, w, dx);
+    return launch_status();
+}
+size_t esmi_train_conv_wgrad_workspace_bytes(const esmi_conv_desc* d) {
+    ConvDesc c;
+    if (conv_desc_ok(d, &c)) return 0;
+    const long nw = (long)(c.transposed ? c.c_in * c.c_out : c.c_out * (c.c_in / c.groups)) * c.k;
+    const long chunks = train_chunks((long)c.B * c.n_out, wgrad_chunk(c));
+    return (size_t)chunks * (size_t)(nw + c.c_out) * sizeof(float);
+}
+int esmi_train_conv_wgrad_f32(const esmi_conv_desc* d, const float* x, const float* dy, float* dw, float* dbias, void* workspace,
+                              size_t workspace_bytes, esmi_stream_t stream) {
+    ConvDesc c;
+    if (int rc = conv_desc_ok(d, &c)) return rc;
+    if (!x || !dy || !dw || !workspace) return ESMI_ERR_ARG;
+    if (workspace_bytes < esmi_train_conv_wgrad_workspace_bytes(d)) return ESMI_ERR_WORKSPACE;
+    const long nw = (long)(c.transposed ? c.c_in * c.c_out : c.c_out * (c.c_in / c.groups)) * c.k;
+    const bool mfma = wgrad_on_mfma(c), depthwise = wgrad_depthwise(c);
+    const long rows = (long)c.B * c.n_out, chunks = train_chunks(rows, wgrad_chunk(c));
+    float* part = static_cast<float*>(workspace);   // [chunk][weight partials (nw) | bias partials (c_out)]
+    float* pb = part + nw;
+    const long ps = nw + c.c_out;
+    if (mfma) {   // dense: one wave per (128 output channels x 32 input channels, tap, chunk) on the fp32 MFMA; bias partials from the tap 0, ci0 = 0 waves
+        const unsigned tiles = (unsigned)(((c.c_out + 127) / 128) * ((c.c_in + 31) / 32) * c.k);
+        ESMI_LAUNCH(train_conv_wgrad_mfma_kernel, dim3(tiles, (unsigned)((chunks + 3) / 4)), dim3(256), 0, S(stream), c, x, dy, part,
+                    dbias ? pb : nullptr, chunks, ps);
+    } else if (depthwise) {
+        ESMI_LAUNCH(train_conv_wgrad_dw_kernel, dim3(grid1d(c.c_out, 64), (unsigned)chunks), dim3(64), 0, S(stream), c, x, dy, part,
+                    dbias ? pb : nullptr, ps);
+    } else {
+        ESMI_LAUNCH(train_conv_wgrad_kernel, dim3(grid1d(nw, 64), (unsigned)chunks), dim3(64), 0, S(stream), c, x, dy, part, ps, wgrad_chunk(c));
+        if (int rc = launch_status()) return rc;
+        if (dbias) ESMI_LAUNCH(train_colsum_kernel, dim3(grid1d(c.c_out, 64), (unsigned)chunks), dim3(64), 0, S(stream), dy, rows, c.c_out, pb, ps, wgrad_chunk(c));
+    }
+    if (int rc = launch_status()) return rc;
+    // weight and bias partials in ONE reduction launch: elements >= nw of a partial row are the bias sums
+    ESMI_LAUNCH(train_reduce_chunks_kernel, grid1d(dbias ? ps : nw, 64), dim3(64 * kReduceGroups), 64 * kReduceGroups * sizeof(float), S(stream),
+                part, dbias ? ps : nw, ps, chunks, dw, nw, dbias);
+    return launch_status();
+}
+int esmi_train_layernorm_fwd_f32(const float* x, const float* g, const float* b, int64_t rows, int C, float* y, float* mean,
+                                 float* rstd, esmi_stream_t stream) {
+    if (!x || !g || !b || !y || !mean || !rstd || rows <= 0 || C <= 0) return ESMI_ERR_ARG;
+    ESMI_LAUNCH(train_ln_fwd_kernel, grid1d(rows, 4), dim3(256), 0, S(stream), x, g, b, (long)rows, C, 1e-5f, y, mean, rstd);
+    return launch_status();
+}
+size_t esmi_train_layernorm_bwd_workspace_bytes(int64_t rows, int C) {
+    if (rows <= 0 || C <= 0) return 0;
+    return (size_t)train_chunks(rows, C <= 256 ? kLnRows : kTrainChunk) * 2 * C * sizeof(float);
+}
+int esmi_train_layernorm_bwd_f32(const float* x, const float* g, const float* mean, const float* rstd, const float* dy,
+                                 int64_t rows, int C, float* dx, float* dg, float* db, void* workspace, size_t workspace_bytes,
+                                 esmi_stream_t stream) {
+    if (!x || !g || !mean || !rstd || !dy || !dx || !dg || !db || !workspace || rows <= 0 || C <= 0) return ESMI_ERR_ARG;
+    if (workspace_bytes < esmi_train_layernorm_bwd_workspace_bytes(rows, C)) return ESMI_ERR_WORKSPACE;
+    float* part = static_cast<float*>(workspace);
+    long chunks;
+    if (C <= 256) {   // dx and the parameter partials in one pass
+        chunks = train_chunks(rows, kLnRows);
+        ESMI_LAUNCH(train_ln_bwd_fused_kernel, dim3((unsigned)chunks), dim3(256), 4 * 2 * 256 * sizeof(float), S(stream), x, g, mean, rstd, dy, (long)rows, C, dx, part);
+        if (int rc = launch_status()) return rc;
+    } else {
+        chunks = train_chunks(rows);
+        ESMI_LAUNCH(train_ln_bwd_dx_kernel, grid1d(rows, 4), dim3(256), 0, S(stream), x, g, mean, rstd, dy, (long)rows, C, dx);
+        if (int rc = launch_status()) return rc;
+        ESMI_LAUNCH(train_ln_bwd_params_kernel, dim3(grid1d(C, 64), (unsigned)chunks), dim3(64), 0, S(stream), x, mean, rstd, dy, (long)rows, C, part);
+        if (int rc = launch_status()) return rc;
+    }
+    ESMI_LAUNCH(train_reduce_chunks_kernel, grid1d(2L * C, 64), dim3(64 * kReduceGroups), 64 * kReduceGroups * sizeof(float), S(stream), part,
+                2L * C, 2L * C, chunks, dg, (long)C, db);   // partial rows are [dg (C) | db (C)]: one launch, two outputs
+    return launch_status();
+}
+int esmi_train_act_fwd_f32(const float* x, int64_t n, int kind, float* y, esmi_stream_t stream) {
+    if (!x || !y || n <= 0 || kind < ACT_RELU || kind > ACT_TANH) return ESMI_ERR_ARG;
+    ESMI_LAUNCH(train_act_fwd_kernel, grid1d(n), dim3(256), 0, S(stream), x, (long)n, kind, y);
+    return launch_status();
+}
+int esmi_train_act_bwd_f32(const float* saved, const float* dy, int64_t n, int kind, float* dx, esmi_stream_t stream) {
+    if (!saved || !dy || !dx || n <= 0 || kind < ACT_RELU || kind > ACT_TANH) return ESMI_ERR_ARG;
+    ESMI_LAUNCH(train_act_bwd_kernel, grid1d(n), dim3(256), 0, S(stream), saved, dy, (long)n, kind, dx);
+    return launch_status();
+}
+int esmi_train_attention_fwd_f32(const float* qkv, int B, int N, int C, int h, float* P, float* ctx, esmi_stream_t stream) {
+    if (!qkv || !P || !ctx || B <= 0 || N <= 0 || C <= 0 || h <= 0 || C % h) return ESMI_ERR_ARG;
+    const size_t lds = train_attn_lds_bytes(N, C);
+    if (lds <= 150 * 1024) {   // K and V of a head staged in LDS
+        static AttrOnce once;
+        if (lds > 48 * 1024)
+            if (int rc = raise_lds_limit(reinterpret_cast<const void*>(train_attn_fwd_lds_kernel), once)) return rc;
+        ESMI_LAUNCH(train_attn_fwd_lds_kernel, dim3((unsigned)(B * h)), dim3(256), lds, S(stream), qkv, B, N, C, h, 1.0f / sqrtf((float)(C / h)), P, ctx);
+        return launch_status();
+    }
+    ESMI_LAUNCH(train_attn_fwd_kernel, dim3((unsigned)((long)B * h * N)), dim3(64), 0, S(stream), qkv, B, N, C, h, 1.0f / sqrtf((float)(C / h)), P, ctx);
+    return launch_status();
+}
+int esmi_train_attention_bwd_f32(const float* qkv, const float* P, const float* dctx, int B, int N, int C, int h, float* dS,
+                                 float* dqkv, esmi_stream_t stream) {
+    if (!qkv || !P || !dctx || !dS || !dqkv || B <= 0 || N <= 0 || C <= 0 || h <= 0 || C % h) return ESMI_ERR_ARG;
+    const float scale = 1.0f / sqrtf((float)(C / h));
+    const size_t lds = train_attn_lds_bytes(N, C);
+    if (lds <= 150 * 1024) {
+        static AttrOnce once;
+        if (lds > 48 * 1024)
+            if (int rc = raise_lds_limit(reinterpret_cast<const void*>(train_attn_bwd_rows_lds_kernel), once)) return rc;
+        ESMI_LAUNCH(train_attn_bwd_rows_lds_kernel, dim3((unsigned)(B * h)), dim3(256), lds, S(stream), qkv, P, dctx, B, N, C, h, scale, dS, dqkv);
+    } else {
+        ESMI_LAUNCH(train_attn_bwd_rows_kernel, dim3((unsigned)((long)B * h * N)), dim3(64), 0, S(stream), qkv, P, dctx, B, N, C, h, scale, dS, dqkv);
+    }
+    if (int rc = launch_status()) return rc;
+    ESMI_LAUNCH(train_attn_bwd_cols_kernel, grid1d((long)B * h * N * C), dim3(256), 0, S(stream), qkv, P, dS, dctx, B, N, C, h, scale, dqkv);
+    return launch_status();
+}
+int esmi_train_embedding_fwd_f32(const int32_t* ids, const float* table, int64_t rows, int V, int C, float* out, esmi_stream_t stream) {
+    if (!ids || !table || !out || rows <= 0 || V <= 0 || C <= 0) return ESMI_ERR_ARG;
+    ESMI_LAUNCH(train_embed_fwd_kernel, grid1d(rows * C), dim3(256), 0, S(stream), ids, table, (long)rows, V, C, out);
+    return launch_status();
+}
+size_t esmi_train_embedding_bwd_workspace_bytes(int64_t rows, int V, int C) {
+    return rows > 0 && V > 0 && C > 0 ? (size_t)train_chunks(rows) * V * C * sizeof(float) : 0;
+}
+int esmi_train_embedding_bwd_f32(const int32_t* ids, const float* dy, int64_t rows, int V, int C, int padding_idx, float* dtable,
+                                 void* workspace, size_t workspace_bytes, esmi_stream_t stream) {
+    if (!ids || !dy || !dtable || !workspace || rows <= 0 || V <= 0 || C <= 0) return ESMI_ERR_ARG;
+    if (workspace_bytes < esmi_train_embedding_bwd_workspace_bytes(rows, V, C)) return ESMI_ERR_WORKSPACE;
+    const long chunks = train_chunks(rows), n = (long)V * C;
+    float* part = static_cast<float*>(workspace);
+    ESMI_LAUNCH(train_embed_bwd_kernel, dim3(grid1d(n, 64), (unsigned)chunks), dim3(64), 0, S(stream), ids, dy, (long)rows, V, C, padding_idx, part);
+    if (int rc = launch_status()) return rc;
+    ESMI_LAUNCH(train_reduce_chunks_kernel, grid1d(n, 64), dim3(64 * kReduceGroups), 64 * kReduceGroups * sizeof(float), S(stream), part, n, n, chunks, dtable);
+    return launch_status();
+}
+int esmi_train_mask_rows_f32(const float* x, const uint8_t* mask, int64_t rows, int C, float* y, esmi_stream_t stream) {
+    if (!x || !mask || !y || rows <= 0 || C <= 0) return ESMI_ERR_ARG;
+    ESMI_LAUNCH(train_mask_rows_kernel, grid1d(rows * C), dim3(256), 0, S(stream), x, mask, (long)rows, C, y);
+    return launch_status();
+}
+int esmi_train_add_f32(const float* a, const float* b, int64_t n, float* y, esmi_stream_t stream) {
+    if (!a || !b || !y || n <= 0) return ESMI_ERR_ARG;
+    ESMI_LAUNCH(train_add_kernel, grid1d(n), dim3(256), 0, S(stream), a, b, (long)n, y);
+    return launch_status();
+}
+int esmi_train_copy_cols_f32(const float* src, int ld_src, int col_src, float* dst, int ld_dst, int col_dst, int64_t rows, int C,
+                             esmi_stream_t stream) {
+    if (!src || !dst || rows <= 0 || C <= 0 || col_src < 0 || col_dst < 0 || col_src + C > ld_src || col_dst + C > ld_dst) return ESMI_ERR_ARG;
+    ESMI_LAUNCH(train_copy_cols_kernel, grid1d(rows * C), dim3(256), 0, S(stream), src, ld_src, col_src, dst, ld_dst, col_dst, (long)rows, C);
+    return launch_status();
+}
+int esmi_train_repeat_fwd_f32(const float* feat, const int32_t* cum, int B, int T, int C, int L, float* out, esmi_stream_t stream) {
+    if (!feat || !cum || !out || B <= 0 || T <= 0 || C <= 0 || L <= 0) return ESMI_ERR_ARG;
+    ESMI_LAUNCH(train_repeat_fwd_kernel, grid1d((long)B * L * C), dim3(256), 0, S(stream), feat, cum, B, T, C, L, out);
+    return launch_status();
+}
+int esmi_train_repeat_bwd_f32(const float* dout, const int32_t* cum, int B, int T, int C, int L, float* dfeat, esmi_stream_t stream) {
+    if (!dout || !cum || !dfeat || B <= 0 || T <= 0 || C <= 0 || L <= 0) return ESMI_ERR_ARG;
+    ESMI_LAUNCH(train_repeat_bwd_kernel, grid1d((long)B * T * C), dim3(256), 0, S(stream), dout, cum, B, T, C, L, dfeat);
+    return launch_status();
+}
+int esmi_train_loss_f32(const esmi_train_loss_args* a, esmi_stream_t stream) {
+    if (!a || !a->mel_pred || !a->mel || !a->pitch_pred || !a->pitch || !a->energy_pred || !a->energy || !a->dur_pred || !a->dur ||
+        !a->out || !a->d_mel || !a->d_pitch || !a->d_energy || !a->d_dur || !a->scratch || a->B <= 0 || a->T <= 0 || a->L <= 0 || a->n_mel <= 0)
+        return ESMI_ERR_ARG;
+    static_assert(ESMI_TRAIN_LOSS_SCRATCH_FLOATS >= kLossBlocks * 6, "scratch size in the header");
+    LossP p = {a->mel_pred, a->mel, a->pitch_pred, a->pitch, a->energy_pred, a->energy, a->dur_pred, a->dur, a->mel_mask, a->ph_mask,
+               a->B, a->T, a->L, a->n_mel, a->out, a->d_mel, a->d_pitch, a->d_energy, a->d_dur, a->scratch};
+    ESMI_LAUNCH(train_loss_partial_kernel, dim3(kLossBlocks), dim3(256), 256 * sizeof(float), S(stream), p);
+    if (int rc = launch_status()) return rc;
+    ESMI_LAUNCH(train_loss_final_kernel, dim3(1), dim3(256), 256 * sizeof(float), S(stream), p);
+    if (int rc = launch_status()) return rc;
+    const long nm = (long)a->B * a->L * a->n_mel, np_ = (long)a->B * a->T;
+    ESMI_LAUNCH(train_loss_grad_kernel, grid1d(nm > np_ ? nm : np_), dim3(256), 0, S(stream), p);
+    return launch_status();
+}
+int esmi_train_adamw_f32(float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1, double beta2, double eps,
+                         double weight_decay, int step, esmi_stream_t stream) {
+    if (!p || !g || !m || !v || n <= 0 || step < 1) return ESMI_ERR_ARG;
+    // 1 - beta^step in double (-expm1(step * log beta)): in fp32, 1 - 0.999f^t carries ~6e-5 relative error at small t
+    const double bc1 = -expm1((double)step * log(beta1)), bc2 = -expm1((double)step * log(beta2));
+    AdamWScalars h = {(float)beta1, (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps, (float)(1.0 - lr * weight_decay),
+                      (float)(lr / bc1), (float)sqrt(bc2)};
+    ESMI_LAUNCH(train_adamw_kernel, grid1d(n), dim3(256), 0, S(stream), p, g, m, v, (long)n, h);
+    return launch_status();
+}
+
+int esmi_train_adamw_graph_f32(float* p, const float* g, float* m, float* v, int64_t n, float* hyper_dev, double beta1, double beta2,
+                               double eps, double weight_decay, int32_t* step_dev, esmi_stream_t stream) {
+    if (!p || !g || !m || !v || !hyper_dev || !step_dev || n <= 0) return ESMI_ERR_ARG;
+    ESMI_LAUNCH(train_bump_step_kernel, dim3(1), dim3(64), 0, S(stream), step_dev, hyper_dev, beta1, beta2, weight_decay);
+    if (int rc = launch_status()) return rc;
+    AdamWScalars h = {(float)beta1, (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps, 0.0f, 0.0f, 0.0f};
+    ESMI_LAUNCH(train_adamw_dev_kernel, grid1d(n), dim3(256), 0, S(stream), p, g, m, v, (long)n, h, (const float*)hyper_dev);
+    return launch_status();
+}
+
+
+}  // extern "C"

@@ -515,7 +515,6 @@ class MelDecoder(_PackedModule):
         self.timing = None      # bench.py sets this to a list to collect (start, end) HIP events per timed launch
         self.timing_every = 1   # ... on every n-th launch only (an event pair costs ~10 us of pipeline drain per step)
         self._launches = 0
-        self.rows_form = False  # True: per-stage fused calls with h0 take esmi_mel_decoder_rows_f32 (the row-owner kernel; tests / A-B runs)
 
     def _shape(self):
         return _lib.DecoderShape(self.dim_x4, self.dim_x2, self.kernel_size, self.n_blocks, self.block_depth,
@@ -597,8 +596,7 @@ class MelDecoder(_PackedModule):
             if self.timing is not None and feat.is_cuda and self._launches % self.timing_every == 0:   # events on the launch stream
                 ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
                 ev[0].record()
-            fn = lib.esmi_mel_decoder_rows_f32 if (self.rows_form and h0 is not None) else lib.esmi_mel_decoder_f32
-            fn(_ptr(blob), C.byref(shape), _ptr(feat), _ptr(h0), _ptr(cum), _ptr(mel_len), _ptr(lmax_dev),
+            lib.esmi_mel_decoder_f32(_ptr(blob), C.byref(shape), _ptr(feat), _ptr(h0), _ptr(cum), _ptr(mel_len), _ptr(lmax_dev),
                int(lmax_host), int(apply_mask), B, T, L_out, _ptr(mel), stream)
             if ev is not None:
                 ev[1].record()

@@ -333,15 +333,6 @@ int esmi_mel_decoder_f32(const float* blob, const esmi_decoder_shape* s, const f
                          const float* h0, /* optional, fused mode only: (B,T,dx2) = LN(tanh(proj(x))), see esmi_decoder_head */
                          const int32_t* cum, const int32_t* mel_len, const int32_t* lmax_dev, int lmax_host, int apply_mask, int B,
                          int T, int L_out, float* mel, esmi_stream_t stream);
-/* The same function on the row-owner kernel (csrc/mel_decoder_rows.h: a wave keeps 32 frames x all channels in registers through
- * every layer, the depthwise conv runs along the lanes by DPP, weights stream from an LDS copy).  dx2 = 128 split build, fused
- * mode with h0 only (ESMI_ERR_UNSUPPORTED otherwise).  Parity-equal to esmi_mel_decoder_f32 and measured SLOWER on MI355X
- * (0.316 vs 0.198 ms, tiny ES B=256 T=128) -- exported for the tests and as the starting point it is, not the
- * default route.                                                                                                             */
-int esmi_mel_decoder_rows_f32(const float* blob, const esmi_decoder_shape* s, const float* x, const float* h0,
-                              const int32_t* cum, const int32_t* mel_len, const int32_t* lmax_dev, int lmax_host, int apply_mask,
-                              int B, int T, int L_out, float* mel, esmi_stream_t stream);
-
 /* ------------------------------------------------------------------ whole inference forward in ONE call
  * Phoneme2Mel.forward (eval), layers/networks.py:415-434 = Encoder blocks -> Fuse + variance adaptor (+ length-regulator scan,
  * + the decoder's phoneme-rate first stage when the fused kernel serves the shape) -> fused mel decoder, enqueued by a C

@@ -283,43 +283,3 @@ def check_hifigan_golden(path, device):
         errs.append(float(np.abs(wav[:, 0].cpu().numpy() - g["wav"]).max()))
         assert errs[-1] < 5e-5, (fused, errs)
     return max(errs)
-
-
-def check_decoder_rows_form(net, cfg, device, cases, seed=7):
-    """esmi_mel_decoder_rows_f32 (row-owner kernel) against esmi_mel_decoder_f32 (the tile kernel, itself pinned to the oracle /
-    golden vectors by the other tests) on the same random phoneme-rate inputs: ragged lengths, zero durations, padding frames,
-    L_out > L, with and without the final mask.  cases: (B, T, max_dur, extra_out)."""
-    rng = np.random.default_rng(seed)
-    dec = net.decoder
-    worst = 0.0
-    for B, T, dmax, extra in cases:
-        dur = rng.integers(0, dmax + 1, size=(B, T)).astype(np.int32)
-        dur[rng.random((B, T)) < 0.15] = 0
-        if B > 1:
-            dur[-1, T // 2:] = 0                       # one short utterance: padding frames up to L
-        dur[0, 0] = max(dur[0, 0], 1)
-        cum_np = np.cumsum(dur, 1).astype(np.int32)
-        L = int(cum_np[:, -1].max())
-        cum = torch.from_numpy(cum_np).to(device)
-        mel_len = torch.from_numpy(cum_np[:, -1].copy()).to(device)
-        feat = torch.from_numpy(rng.standard_normal((B, T, cfg.d4)).astype(np.float32)).to(device)
-        h0 = torch.from_numpy(rng.standard_normal((B, T, cfg.dx2)).astype(np.float32)).to(device)
-        for apply_mask in (True, False):
-            outs = []
-            for rows in (False, True):
-                dec.rows_form = rows
-                try:
-                    with torch.no_grad():
-                        outs.append(dec._fused(feat, cum, mel_len, None, L, apply_mask, L + extra, h0=h0).cpu().numpy())
-                finally:
-                    dec.rows_form = False
-            a, b = outs
-            assert a.shape == b.shape == (B, L + extra, cfg.n_mel_channels)
-            assert np.isfinite(b).all()
-            assert not b[:, L:].any()                                   # rows in [L, L_out) are zero
-            if apply_mask:
-                for i in range(B):
-                    assert not b[i, int(cum_np[i, -1]):].any()          # final masked_fill
-            worst = max(worst, float(np.abs(a - b).max()))
-            assert np.abs(a - b).max() < 2e-5, (B, T, L, apply_mask, np.abs(a - b).max())
-    return worst

@@ -11,9 +11,8 @@ import subprocess
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SIM_SO = os.path.join(ROOT, "tools", "wavesim", "_build", "libesmi_sim.so")
-_SRCS = [os.path.join(ROOT, "efficientspeech_amd", "csrc", f) for f in
-         ("esmi_abi.hip", "convgemm.h", "attention.h", "mel_decoder.h", "small_kernels.h", "esmi_dev.h", "wave_chain.h",
-          "enc_merge_qkv.h", "enc_attn_ffn.h", "enc_fuse_va.h", "hifigan_resblock.h", "train_ops.h", "mel_decoder_rows.h")] + \
+_CSRC = os.path.join(ROOT, "efficientspeech_amd", "csrc")
+_SRCS = [os.path.join(_CSRC, f) for f in os.listdir(_CSRC) if f.endswith((".hip", ".h"))] + \
         [os.path.join(ROOT, "tools", "wavesim", f) for f in ("wavesim.h", "wavesim.cpp")] + \
         [os.path.join(ROOT, "include", "esmi.h")]
 _handle = None

@@ -620,24 +620,3 @@ def test_lds_staged_attention_at_size(name):
     """>= 128 (utterance, head) pairs so that the GPU dispatch takes attn_lds_kernel: 3, 4, 7 and 8 key tiles, widths 32 .. 256."""
     net, cfg, sd = H.make_net(name, DEV)
     H.check_attention_sizes(net, cfg, sd, DEV, sizes=((128, 96), (64, 128), (40, 200), (32, 256)) if name == "tiny" else ((32, 100), (16, 250)))
-
-
-def test_decoder_rows_form_matches_tile_form(nets):
-    """The row-owner decoder kernel (mel_decoder_rows.h; not the default route: measured slower) computes the same
-    function: single window, several windows with a partly dead last one, B = 1, L_out beyond L."""
-    net, cfg, sd = nets("tiny")
-    if "dec_gemm=split-f16x2" not in _lib.load().esmi_build_config().decode():   # the exact-fp32 build has no row-owner instantiation
-        with pytest.raises(_lib.Unsupported):
-            H.check_decoder_rows_form(net, cfg, DEV, [(1, 11, 4, 3)])
-        return
-    worst = H.check_decoder_rows_form(net, cfg, DEV, [(5, 40, 9, 0), (3, 128, 6, 7), (1, 11, 4, 3), (9, 100, 12, 0)])
-    assert worst < 2e-5
-    net_s, cfg_s, _ = nets("small")     # dx2 = 256: no row-owner instantiation
-    feat = torch.zeros((1, 4, cfg_s.d4), device=DEV)
-    cum = torch.tensor([[1, 2, 3, 4]], dtype=torch.int32, device=DEV)
-    net_s.decoder.rows_form = True
-    try:
-        with pytest.raises(_lib.Unsupported):
-            net_s.decoder._fused(feat, cum, cum[:, -1].contiguous(), None, 4, True, 4, h0=torch.zeros((1, 4, cfg_s.dx2), device=DEV))
-    finally:
-        net_s.decoder.rows_form = False

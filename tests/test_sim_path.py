@@ -302,11 +302,3 @@ def test_simulated_lds_staged_attention():
     with use_sim():
         net, cfg, sd = H.make_net("tiny", "cpu")
         H.check_attention_sizes(net, cfg, sd, "cpu", sizes=((1, 100), (1, 200)))
-
-
-def test_simulated_decoder_rows_form(nets):
-    """Row-owner decoder kernel on the lane-level simulator against the tile kernel (one and two windows)."""
-    net, cfg, sd = nets("tiny")
-    with use_sim():
-        worst = H.check_decoder_rows_form(net, cfg, "cpu", [(2, 12, 5, 2), (1, 50, 9, 0)])
-    assert worst < 2e-5

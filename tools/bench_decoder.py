@@ -11,7 +11,7 @@ from efficientspeech_amd.synth import synth_state_dict
 ap = argparse.ArgumentParser()
 ap.add_argument("--config", default="tiny"); ap.add_argument("--batch", type=int, default=256)
 ap.add_argument("--phonemes", type=int, default=128); ap.add_argument("--dur", type=int, default=6)
-ap.add_argument("--iters", type=int, default=30); ap.add_argument("--h0", action="store_true", help="phoneme-rate first stage supplied (what the full forward does for tiny, T <= 128)"); ap.add_argument("--rows", action="store_true", help="with --h0: the row-owner kernel (esmi_mel_decoder_rows_f32) instead of the tile kernel"); ap.add_argument("--burst", type=int, default=20, help="launches per timed burst (back-to-back, one event pair)"); ap.add_argument("--libs", nargs="*", default=[_lib.LIB_PATH])
+ap.add_argument("--iters", type=int, default=30); ap.add_argument("--h0", action="store_true", help="phoneme-rate first stage supplied (what the full forward does for tiny, T <= 128)"); ap.add_argument("--burst", type=int, default=20, help="launches per timed burst (back-to-back, one event pair)"); ap.add_argument("--libs", nargs="*", default=[_lib.LIB_PATH])
 a = ap.parse_args()
 cfg = CONFIGS[a.config]
 B, T, L = a.batch, a.phonemes, a.phonemes * a.dur
@@ -25,7 +25,6 @@ for path in a.libs:
     cum = (torch.arange(1, T + 1, device="cuda", dtype=torch.int32) * a.dur).repeat(B, 1).contiguous()
     mel_len = torch.full((B,), L, dtype=torch.int32, device="cuda")
     dec = net.decoder
-    dec.rows_form = a.rows
     h0 = torch.randn((B, T, cfg.dx2), device="cuda", generator=g) if a.h0 else None
     for _ in range(5):
         mel = dec._fused(feat, cum, mel_len, None, L, True, L, h0=h0)

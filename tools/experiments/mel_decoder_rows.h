@@ -46,7 +46,7 @@ __host__ __device__ constexpr int dec_rows_lds_floats(int kd) {
 // binary16 planes of 2^8 W (round to nearest), MT = ceil(N / 32) M tiles:
 //   dst[((((s*MT + tt)*2 + pl)*64 + lane)*4 + w] = {plane(W[m][cin(2w+1)]), plane(W[m][cin(2w)])},
 //   m = 32 tt + (lane & 31),  cin(e) = 16 s + 8 (e >> 2) + 4 (lane >> 5) + (e & 3)          (0 for m >= N)
-__global__ void pack_rows_afrag_kernel(const float* __restrict__ src, unsigned* __restrict__ dst, int N, int MT) {
+static __global__ void pack_rows_afrag_kernel(const float* __restrict__ src, unsigned* __restrict__ dst, int N, int MT) {
     const long n = 8L * MT * 2 * 256;
     for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
         const int wd = (int)(e & 3), lane = (int)((e >> 2) & 63);
@@ -65,7 +65,7 @@ __global__ void pack_rows_afrag_kernel(const float* __restrict__ src, unsigned* 
     }
 }
 // the depthwise conv's bias goes through the pointwise conv: pwb'[m] = pwb[m] + sum_k W[m][k] dwb[k]   (C = 128)
-__global__ void pack_rows_bias_kernel(const float* __restrict__ w, const float* __restrict__ dwb, const float* __restrict__ pwb,
+static __global__ void pack_rows_bias_kernel(const float* __restrict__ w, const float* __restrict__ dwb, const float* __restrict__ pwb,
                                       float* __restrict__ dst) {
     const int m = (int)(blockIdx.x * blockDim.x + threadIdx.x);
     if (m >= 128) return;
@@ -74,7 +74,7 @@ __global__ void pack_rows_bias_kernel(const float* __restrict__ w, const float* 
     dst[m] = pwb[m] + a;
 }
 // the first stage's output for a padding frame (zero input row): LN(tanh(proj_b))
-__global__ void pack_rows_padrow_kernel(const float* __restrict__ b, const float* __restrict__ g, const float* __restrict__ be,
+static __global__ void pack_rows_padrow_kernel(const float* __restrict__ b, const float* __restrict__ g, const float* __restrict__ be,
                                         float* __restrict__ dst) {
     if (blockIdx.x != 0 || threadIdx.x != 0) return;
     float mean = 0.0f;
