@@ -477,6 +477,9 @@ __device__ __forceinline__ f32x4 buf_ld4(const BufRsrc& r, unsigned off) {
 __device__ __forceinline__ unsigned buf_ld_u8(const BufRsrc& r, unsigned off) {
     return off < r.bytes ? (unsigned)*reinterpret_cast<const unsigned char*>(r.base + off) : 0u;
 }
+// 16 bytes at byte offset voff (per lane) + soff (wave-uniform): the uniform part travels in an SGPR, so one lane-offset VGPR
+// serves every access of a kernel to the same buffer (no 64-bit per-lane pointers kept alive across loops)
+__device__ __forceinline__ f32x4 buf_ld4s(const BufRsrc& r, unsigned voff, unsigned soff) { return buf_ld4(r, voff + soff); }
 __device__ __forceinline__ void buf_st(const BufRsrc& r, unsigned off, float v) {
     if (off < r.bytes && off + 4u <= r.bytes) *reinterpret_cast<float*>(const_cast<char*>(r.base) + off) = v;
 }
@@ -498,6 +501,11 @@ __device__ __forceinline__ f32x4 buf_ld4(BufRsrc r, unsigned off) {
 }
 __device__ __forceinline__ unsigned buf_ld_u8(BufRsrc r, unsigned off) {
     return (unsigned)__builtin_amdgcn_raw_buffer_load_b8(r, (int)off, 0, 0);
+}
+// 16 bytes at byte offset voff (per lane) + soff (wave-uniform): the uniform part travels in an SGPR, so one lane-offset VGPR
+// serves every access of a kernel to the same buffer (no 64-bit per-lane pointers kept alive across loops)
+__device__ __forceinline__ f32x4 buf_ld4s(BufRsrc r, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, __builtin_amdgcn_readfirstlane((int)soff), 0));
 }
 #ifndef ESMI_ST_AUX
 #define ESMI_ST_AUX 0   // cache policy bits of the tensor-output stores (gfx94x: 1 = sc0, 2 = nt, 16 = sc1)

@@ -258,7 +258,11 @@ __global__ __launch_bounds__(64 * NW, (DX2 <= 128 ? ESMI_DEC_WPS : NW / 4)) void
     if (w >= 4) __builtin_amdgcn_s_setprio(ESMI_DEC_YOUNG_PRIO);
 #endif
     const int n_layers = p.n_blocks * p.block_depth;
-    const f32x4* blob4 = reinterpret_cast<const f32x4*>(p.blob);
+    // every read of the packed blob is a buffer load: resource + wave-uniform byte offset in SGPRs, one lane-offset VGPR for all of
+    // them (64-bit per-lane pointers into the blob, live across the layer loop, were most of the kernel's register spills)
+    const BufRsrc brs = make_rsrc(p.blob, p.lay.total * (long)sizeof(float));
+    const unsigned tid16 = (unsigned)tid * 16u, lane16 = (unsigned)lane * 16u;
+    auto blob_ld = [&](long float_off, unsigned voff) __attribute__((always_inline)) { return buf_ld4s(brs, voff, (unsigned)(float_off * 4)); };
 #ifdef ESMI_DEC_TRACE
     int tr_n = 0;
     const bool tr_on = p.trace && tile == 3 && b == p.B / 2 + 5 && lane == 0;
@@ -267,32 +271,42 @@ __global__ __launch_bounds__(64 * NW, (DX2 <= 128 ? ESMI_DEC_WPS : NW / 4)) void
 #define ESMI_STAMP() do {} while (0)
 #endif
 
-    // ---- parameter staging: fetch (global -> register) at the start of a phase, commit (register -> LDS) at its end.
-    // "layer" n_layers is the mel Linear (group B = its bias only).
-    f32x4 pst = zero4();
-    auto fetch_A = [&](int l) __attribute__((always_inline)) {
-        if (l < n_layers && tid < NA4) pst = blob4[((p.lay.layer0 + (long)l * p.lay.layer_stride) >> 2) + tid];
+    // ---- parameter staging by LDS-DMA (global_load_lds_dwordx4: memory -> LDS, 16 bytes per lane, no staging registers): issued
+    // when the last reader of the slots' old contents has passed a barrier, drained by the barrier in front of the first reader of
+    // the new ones.  "layer" n_layers is the mel Linear (its bias goes to the group A slots, unused by then).
+    auto stage = [&](long float_off, float* dst, int n4) __attribute__((always_inline)) {   // n4 float4 from blob + float_off to dst, thread tid -> dst + 4 tid
+        if (tid < n4) {
+#ifdef ESMI_WAVESIM
+            reinterpret_cast<f32x4*>(dst)[tid] = blob_ld(float_off, tid16);
+#else
+            // (opaque: the per-lane source pointer is formed here, not hoisted out of the layer loop as a live 64-bit register pair)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.blob + float_off + opaque_i(4 * tid)),
+                                             (__attribute__((address_space(3))) void*)(dst + 256 * w), 16, 0, 0);
+#endif
+        }
     };
-    auto commit_A = [&](int l) __attribute__((always_inline)) {
-        if (l < n_layers && tid < NA4) reinterpret_cast<f32x4*>(pbuf)[tid] = pst;
+    auto fetch_A = [&](int l) __attribute__((always_inline)) {
+        if (l < n_layers) stage(p.lay.layer0 + (long)l * p.lay.layer_stride, pbuf, NA4);
     };
     auto fetch_B = [&](int l) __attribute__((always_inline)) {
         if (l < n_layers) {
-            if (tid < NB4) pst = blob4[((p.lay.layer0 + (long)l * p.lay.layer_stride + p.lay.l_pwb) >> 2) + tid];
-            else if (((l + 1) % p.block_depth) == 0 && tid < NB4 + DX2 / 2)   // block end: skip LN params
-                pst = blob4[((p.lay.skip0 + (long)(l / p.block_depth) * 2 * DX2) >> 2) + tid - NB4];
-        } else if (tid < DX2 / 4) {
-            pst = blob4[(p.lay.mel_b >> 2) + tid];
+            stage(p.lay.layer0 + (long)l * p.lay.layer_stride + p.lay.l_pwb, pbuf + P_PWB, NB4);
+            if (((l + 1) % p.block_depth) == 0) {   // block end: skip LN params, threads NB4 .. NB4 + DX2/2 (whole waves: NB4 is a multiple of 64 floats4? no -- see below)
+                if (tid >= NB4 && tid < NB4 + DX2 / 2) {
+#ifdef ESMI_WAVESIM
+                    reinterpret_cast<f32x4*>(pbuf + P_PWB)[tid] = blob_ld(p.lay.skip0 + (long)(l / p.block_depth) * 2 * DX2 - 4 * NB4, tid16);
+#else
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.blob + p.lay.skip0 + (long)(l / p.block_depth) * 2 * DX2 + opaque_i(4 * (tid - NB4))),
+                                                     (__attribute__((address_space(3))) void*)(pbuf + P_PWB + 256 * w), 16, 0, 0);
+#endif
+                }
+            }
+        } else {
+            stage(p.lay.mel_b, pbuf, DX2 / 4);
         }
     };
-    auto commit_B = [&](int l) __attribute__((always_inline)) {
-        f32x4* d4 = reinterpret_cast<f32x4*>(pbuf + P_PWB);
-        if (l < n_layers) {
-            if (tid < NB4 || (((l + 1) % p.block_depth) == 0 && tid < NB4 + DX2 / 2)) d4[tid] = pst;
-        } else if (tid < DX2 / 4) {
-            d4[tid] = pst;
-        }
-    };
+    auto commit_A = [&](int) __attribute__((always_inline)) {};
+    auto commit_B = [&](int) __attribute__((always_inline)) {};
 
     // ---- phase 0: source row of every window row, zero the LDS pad rows, stage proj + layer-0 params
     if (tid < kDecRows) {
@@ -313,7 +327,7 @@ __global__ __launch_bounds__(64 * NW, (DX2 <= 128 ? ESMI_DEC_WPS : NW / 4)) void
         xs[rr * LDSROW + c] = 0.0f;
     }
     if (tid < NB4)                                                     // proj_b, proj_g, proj_beta -> group B
-        reinterpret_cast<f32x4*>(pbuf + P_PWB)[tid] = blob4[(p.lay.proj_b >> 2) + tid];
+        reinterpret_cast<f32x4*>(pbuf + P_PWB)[tid] = blob_ld(p.lay.proj_b, tid16);
     fetch_A(0);
     commit_A(0);
     __syncthreads();
@@ -356,14 +370,14 @@ __global__ __launch_bounds__(64 * NW, (DX2 <= 128 ? ESMI_DEC_WPS : NW / 4)) void
 #if ESMI_DEC_SPLIT
     constexpr int KS16 = KSUB / 2;
     u32x4 bf[NTW][KS16][2];
-    auto load_b = [&](const f32x4* wsl, int k0) __attribute__((always_inline)) {
-        const u32x4* w3 = reinterpret_cast<const u32x4*>(wsl);
+    auto load_b = [&](long wsl, int k0) __attribute__((always_inline)) {   // wsl: float offset of the wave's weight slice in the blob
 #pragma unroll
         for (int t = 0; t < NTW; ++t) {
 #pragma unroll
             for (int st = 0; st < KS16; ++st) {
 #pragma unroll
-                for (int pl = 0; pl < 2; ++pl) bf[t][st][pl] = w3[((t * 8 + (k0 >> 1) + st) * 2 + pl) * 64];
+                for (int pl = 0; pl < 2; ++pl)
+                    bf[t][st][pl] = __builtin_bit_cast(u32x4, blob_ld(wsl + ((t * 8 + (k0 >> 1) + st) * 2 + pl) * 256, lane16));
             }
         }
     };
@@ -382,7 +396,7 @@ __global__ __launch_bounds__(64 * NW, (DX2 <= 128 ? ESMI_DEC_WPS : NW / 4)) void
         }
     };
     // slice pointer of chunk c of the matrix at float offset `off` (planes: 8 steps x 2 planes x 64 lanes x 16 B per tile)
-    auto wslice = [&](long off, int c) __attribute__((always_inline)) { return blob4 + (off >> 2) + (long)(c * (DX2 / 32) + ns * NTW) * 8 * 2 * 64 + lane; };
+    auto wslice = [&](long off, int c) __attribute__((always_inline)) { return off + (long)(c * (DX2 / 32) + ns * NTW) * 8 * 2 * 256; };
 
     // The A operand rows already stored as the two f16 planes (row = [DX2 halves h1 | DX2 halves h2 | pad], written by the
     // depthwise phase / the last LayerNorm): per (16-channel step, row tile) two ds_read_b128 + 3*NTW MFMAs.
@@ -420,11 +434,11 @@ __global__ __launch_bounds__(64 * NW, (DX2 <= 128 ? ESMI_DEC_WPS : NW / 4)) void
     static_assert(WD >= 1 && WD <= NSTEP && AD >= 1 && AD <= NITEM, "ring depths");
     u32x4 wr[WD][NTW][2];
     auto w_fetch = [&](long off, int s, int slot) __attribute__((always_inline)) {
-        const u32x4* w3 = reinterpret_cast<const u32x4*>(wslice(off, s >> 3));
+        const long wsl = wslice(off, s >> 3);
 #pragma unroll
         for (int t = 0; t < NTW; ++t) {
 #pragma unroll
-            for (int pl = 0; pl < 2; ++pl) wr[slot][t][pl] = w3[((t * 8 + (s & 7)) * 2 + pl) * 64];
+            for (int pl = 0; pl < 2; ++pl) wr[slot][t][pl] = __builtin_bit_cast(u32x4, blob_ld(wsl + ((t * 8 + (s & 7)) * 2 + pl) * 256, lane16));
         }
     };
     // the first WD weight steps of the matrix at `off` (issued ahead of the barrier that precedes the K loop: the L2 round
@@ -459,11 +473,11 @@ __global__ __launch_bounds__(64 * NW, (DX2 <= 128 ? ESMI_DEC_WPS : NW / 4)) void
 #endif
 #else
     f32x4 bf[NTW][KSUB];
-    auto load_b = [&](const f32x4* wsl, int k0) __attribute__((always_inline)) {
+    auto load_b = [&](long wsl, int k0) __attribute__((always_inline)) {   // wsl: float offset of the wave's weight slice in the blob
 #pragma unroll
         for (int t = 0; t < NTW; ++t) {
 #pragma unroll
-            for (int kc = 0; kc < KSUB; ++kc) bf[t][kc] = wsl[(t * 16 + k0 + kc) * 64];
+            for (int kc = 0; kc < KSUB; ++kc) bf[t][kc] = blob_ld(wsl + (t * 16 + k0 + kc) * 256, lane16);
         }
     };
     auto mma_sub = [&](int a_col0, int k0) __attribute__((always_inline)) {
@@ -482,7 +496,7 @@ __global__ __launch_bounds__(64 * NW, (DX2 <= 128 ? ESMI_DEC_WPS : NW / 4)) void
         }
     };
     // slice pointer of chunk c of the matrix at float offset `off`
-    auto wslice = [&](long off, int c) __attribute__((always_inline)) { return blob4 + (off >> 2) + (long)(c * (DX2 / 32) + ns * NTW) * 16 * 64 + lane; };
+    auto wslice = [&](long off, int c) __attribute__((always_inline)) { return off + (long)(c * (DX2 / 32) + ns * NTW) * 16 * 256; };
     auto gemm_prefetch = [&](long) __attribute__((always_inline)) {};
     auto gemm_planes = [&](long) __attribute__((always_inline)) {};
 #endif
@@ -763,7 +777,7 @@ __global__ __launch_bounds__(64 * NW, (DX2 <= 128 ? ESMI_DEC_WPS : NW / 4)) void
         __syncthreads();
         ESMI_STAMP();   // 8: barrier
         // 4. LayerNorm (+ block-end skip LayerNorm) by row owners; the last one writes the mel Linear's operand planes
-        if (l + 1 == n_layers) fetch_B(n_layers);   // mel bias (pst is free: group A of a non-existent layer was not fetched)
+        if (l + 1 == n_layers) fetch_B(n_layers);   // mel bias -> group A slots (taps: last read by this layer's depthwise phase)
         if (SPLIT && l + 1 == n_layers) {
             if (block_end) ln_pass(pb, TrueC{}, TrueC{});
             else ln_pass(pb, FalseC{}, TrueC{});
@@ -772,10 +786,7 @@ __global__ __launch_bounds__(64 * NW, (DX2 <= 128 ? ESMI_DEC_WPS : NW / 4)) void
             else ln_pass(pb, FalseC{}, FalseC{});
         }
         ESMI_STAMP();   // 9: LN done
-        if (l + 1 == n_layers) {   // the LayerNorm's reads of group B are done only after the barrier: the mel bias goes to the (now unused) group A slots
-            if (tid < DX2 / 4) reinterpret_cast<f32x4*>(pbuf)[tid] = pst;
-            gemm_prefetch(p.lay.mel_w);
-        }
+        if (l + 1 == n_layers) gemm_prefetch(p.lay.mel_w);   // (the mel bias went to the unused group A slots by LDS-DMA above)
         __syncthreads();
         ESMI_STAMP();   // 10: barrier
     }
@@ -783,7 +794,6 @@ __global__ __launch_bounds__(64 * NW, (DX2 <= 128 ? ESMI_DEC_WPS : NW / 4)) void
     // ---- mel Linear(dx2, n_mel) on skip (held in the tile), masked store
     if (n_layers == 0) {   // (degenerate: proj output straight into the mel Linear, fp32 rows)
         fetch_B(0);
-        if (tid < DX2 / 4) reinterpret_cast<f32x4*>(pbuf)[tid] = pst;
         __syncthreads();
     }
     if (ns * WCOLS < p.n_mel) {   // wave-uniform: column slices beyond n_mel have nothing to do
