@@ -88,8 +88,10 @@ def _omp_threads(n):
 
 
 def cpu_baseline(cfg, sd, T, dur):
-    """Time the oracle (fp32-accumulating build) on bounded samples of the same workload: all host cores, n = 24 threads (the
-    reference's --threads default, utils/tools.py:324), and the B = 1 fox sentence (BASELINE configs[0])."""
+    """Time the oracle (fp32-accumulating build) on bounded samples of the same workload: n = 24 threads (the reference's
+    --threads default, utils/tools.py:324 -- and the fastest setting for this port) and the B = 1 fox sentence (BASELINE
+    configs[0]).  (Round 2 also printed an all-hardware-threads figure: 1.3e3 frames/s at 256 threads, a fork/join pathology of
+    the port's one-parallel-region-per-layer structure and not a baseline of anything; it is gone.)"""
     from oracle import oracle
     from efficientspeech_amd.synth import synth_phonemes
     w = oracle.Weights(sd)
@@ -113,18 +115,13 @@ def cpu_baseline(cfg, sd, T, dur):
         return r[0][0], sum(x[1] for x in r) / len(r)
     # n = 24: the reference's --threads default -- and the fastest setting for this port (its OpenMP regions are one layer
     # each: beyond ~32 threads the fork/join cost dominates; measured on the MI355X box's 256 hardware threads, B = 64:
-    # 24 threads 8.7e5 frames/s, 64: 4.0e5, 128: 1.6e5, 256: 5e3).  `value` is the n = 24 number; all cores is reported beside it.
+    # 24 threads 8.7e5 frames/s, 64: 4.0e5, 128: 1.6e5, 256: 5e3).  `value` is the n = 24 number.
     n24 = min(24, cores)
     b24 = 256 if cfg.name == "tiny" else 64
     frames, dt = sample(n24, b24, 3)
     out = {"value": frames / dt, "unit": "mel-frames/s", "cores": n24, "kind": "port",
            "sample": f"oracle/es_oracle.c (fp32 accumulate, OpenMP {n24} threads = the reference's --threads default), {cfg.name} ES "
                      f"full forward, B={b24} T={T} D-const {dur}: {frames} frames in {dt:.2f} s (mean of 3 runs)"}
-    b_all = 16
-    f_all, dt_all = sample(cores, b_all, 1)
-    out["all_cores"] = {"value": f_all / dt_all, "cores": cores,
-                        "sample": f"same code, OpenMP {cores} threads (every hardware thread of the box), B={b_all}: {f_all} frames in "
-                                  f"{dt_all:.2f} s -- slower than n = 24: one parallel region per layer, fork/join bound"}
     fox = np.asarray([FOX_IDS], np.int32)
     for threads, key in ((n24, "b1_fox_latency_ms_n24"), (1, "b1_fox_latency_ms_n1")):
         _omp_threads(threads)
@@ -272,6 +269,11 @@ def main():
     # pipe (dense peak 2500 TFLOP/s, MI355X_MICROARCH.md), or one on the fp32 MFMA path (157.3)
     peak_tf = F16_PEAK_TFLOPS / split if split else FP32_PEAK_TFLOPS
     ach_tf = flops * B * L / (dec_ms * 1e-3) / 1e12
+    # algorithmic HBM bytes per valid frame of the variant that RUNS: the decoder gathers its input rows at phoneme rate
+    # through the duration scan -- dx2 floats of h0 per phoneme when its first stage ran in the variance-adaptor kernel, else d4
+    # floats of features -- and writes 80 floats of mel per frame: 405 / 491 / 661 B per frame at D-const 6 (tiny / small / base).
+    # (832 / 1344 / 2368 B is the stand-alone MelDecoder.forward on frame-rate features: the `decoder_only` leg.)
+    exec_bytes = 4.0 * cfg.n_mel_channels + 4.0 * (cfg.dx2 if head_moved else cfg.d4) / a.dur
     traffic, traffic_src, mfma_util = (None, None, None) if a.exact_fp32 else pmc_traffic(a.config, B, T, a.dur)
     out = {
         "metric": "mel-frames/sec (whole node), full Phoneme2Mel forward", "value": value, "unit": "mel-frames/s",
@@ -291,17 +293,21 @@ def main():
                      "unit": "TFLOP/s", "frac": ach_tf / peak_tf,
                      "peak_is": (f"dense 16-bit MFMA peak {F16_PEAK_TFLOPS:.0f} TFLOP/s / {split} products per fp32-accurate product"
                                  if split else "v_mfma_f32_32x32x2_f32 peak"),
-                     "traffic": traffic, "traffic_unit": "HBM bytes per launch (rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE)",
+                     "traffic": traffic, "traffic_unit": "HBM bytes per launch (rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE; both "
+                                                         "calibrated on known byte counts in this kernel's access pattern: profiles/r03_probes/pmc_calibration.md)",
                      "traffic_source": traffic_src, "mfma_pipe_utilisation_pmc": mfma_util,
-                     "algorithmic_bytes_per_launch": nbytes * B * L, "algorithmic_flops_per_frame": flops,
-                     "algorithmic_bytes_per_frame": nbytes,
+                     "algorithmic_bytes_per_launch": exec_bytes * B * L, "algorithmic_bytes_per_frame": exec_bytes,
+                     "traffic_ratio": (traffic / (exec_bytes * B * L)) if traffic else None,
+                     "algorithmic_bytes_note": "the executed variant: input rows gathered at phoneme rate (SURVEY 8d: 405 / 491 / 661 B per "
+                                               "frame); the frame-rate-input figure (832 / 1344 / 2368) belongs to `decoder_only`",
+                     "algorithmic_flops_per_frame": flops,
                      "kernel_ms": dec_ms, "kernel_ms_samples": n_ev, "build_config": build_cfg,
                      "contraction": ((f"{split_txt}; measured error <= that of an fp32 FMA chain (DESIGN.md 3); `peak` is the 16-bit "
                                       "matrix-pipe peak divided by the products per fp32-accurate product; `exact_fp32` below is the "
                                       "same step on the v_mfma_f32_32x32x2_f32 build") if split else "v_mfma_f32_32x32x2_f32 (exact fp32)"),
                      "proj_stage_at_phoneme_rate": head_moved, "kernel_flops_per_frame": kernel_flops,
                      "frac_kernel_flops": kernel_flops * B * L / (dec_ms * 1e-3) / 1e12 / peak_tf,
-                     "hbm_frac": nbytes * B * L / (dec_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                     "hbm_frac": exec_bytes * B * L / (dec_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                      "note": "MFMA bound (228 FLOP/B >> machine balance); hbm_frac reported because north_star quotes the HBM "
                              "roofline.  achieved/frac use SURVEY 8d's algorithmic FLOP per frame; frac_kernel_flops counts only what "
                              "the decoder kernel still computes per frame (its row-wise first stage runs once per phoneme in "
