@@ -99,36 +99,46 @@ class LJSpeechDataset(torch.utils.data.Dataset):
         return x, {"mel": self._load("mel", idx)}
 
     def process_meta(self, filename):
-        """`basename|speaker|{phones}|raw text` per line; lines whose raw text exceeds max_length are dropped (:172-186)"""
-        name, speaker, text, raw = [], [], [], []
-        with open(os.path.join(self.preprocessed_path, filename), "r", encoding="utf-8") as f:
-            for line in f.readlines():
-                n, s, t, r = line.strip("\n").split("|")
-                if len(r) > self.max_text_length:
-                    continue
-                name.append(n); speaker.append(s); text.append(t); raw.append(r)
-        return name, speaker, text, raw
+        """The metadata file: one utterance per line, four fields separated by the pipe character -- basename, speaker, phone string,
+        raw text.  Utterances whose raw text is longer than `max_length` characters are left out (datamodule.py:172-186).
+        -> four parallel lists (basenames, speakers, phone strings, raw texts)."""
+        path = os.path.join(self.preprocessed_path, filename)
+        with open(path, "r", encoding="utf-8") as f:
+            records = [line.rstrip("\n").split("|") for line in f]
+        for rec in records:
+            if len(rec) != 4:
+                raise ValueError(f"{path}: expected 4 fields per line, got {len(rec)}")       # (the reference's unpacking raises too)
+        kept = [rec for rec in records if len(rec[3]) <= self.max_text_length]
+        columns = list(zip(*kept)) if kept else [(), (), (), ()]
+        return tuple(list(c) for c in columns)
 
 
 def collate_fn(batch):
-    """datamodule.py:29-79: sort by phoneme length (descending, NumPy argsort of the negated lengths), pad, build masks."""
-    x, y = zip(*batch)
-    len_arr = np.array([d["phoneme"].shape[0] for d in x])
-    idxs = np.argsort(-len_arr).tolist()
-    phonemes = [x[i]["phoneme"] for i in idxs]
-    mels = [y[i]["mel"] for i in idxs]
-    phoneme_lens = torch.from_numpy(np.array([p.shape[0] for p in phonemes])).int()
-    mel_lens = torch.from_numpy(np.array([m.shape[0] for m in mels])).int()
-    out_x = {"phoneme": torch.from_numpy(pad_1D(phonemes)).int(),
-             "phoneme_len": phoneme_lens,
-             "phoneme_mask": get_mask_from_lengths(phoneme_lens, int(torch.max(phoneme_lens).item())),
-             "text": [x[i]["text"] for i in idxs],
-             "mel_len": mel_lens,
-             "mel_mask": get_mask_from_lengths(mel_lens, int(torch.max(mel_lens).item())),
-             "pitch": torch.from_numpy(pad_1D([x[i]["pitch"] for i in idxs])).float(),
-             "energy": torch.from_numpy(pad_1D([x[i]["energy"] for i in idxs])).float(),
-             "duration": torch.from_numpy(pad_1D([x[i]["duration"] for i in idxs])).int()}
-    return out_x, {"mel": torch.from_numpy(pad_2D(mels)).float()}
+    """A list of dataset items -> the padded training batch (x, y) of datamodule.py:29-79: utterances ordered by phoneme count,
+    longest first -- the order NumPy's default argsort gives the negated counts, which is what decides between utterances of
+    equal length -- every per-utterance array zero-padded to the batch maximum, boolean masks that are True on the padding."""
+    xs = [item[0] for item in batch]
+    ys = [item[1] for item in batch]
+    order = np.argsort(-np.array([x["phoneme"].shape[0] for x in xs])).tolist()
+    xs, ys = [xs[j] for j in order], [ys[j] for j in order]
+
+    def lengths(arrays):
+        return torch.from_numpy(np.array([a.shape[0] for a in arrays])).int()
+
+    def padded(key):
+        return torch.from_numpy(pad_1D([x[key] for x in xs]))
+
+    phoneme_len, mel_len = lengths([x["phoneme"] for x in xs]), lengths([y["mel"] for y in ys])
+    x = {"phoneme": padded("phoneme").int(),
+         "phoneme_len": phoneme_len,
+         "phoneme_mask": get_mask_from_lengths(phoneme_len, int(phoneme_len.max())),
+         "text": [x["text"] for x in xs],
+         "mel_len": mel_len,
+         "mel_mask": get_mask_from_lengths(mel_len, int(mel_len.max())),
+         "pitch": padded("pitch").float(),
+         "energy": padded("energy").float(),
+         "duration": padded("duration").int()}
+    return x, {"mel": torch.from_numpy(pad_2D([y["mel"] for y in ys])).float()}
 
 
 class LJSpeechDataModule:

@@ -99,3 +99,79 @@ def test_collated_batch_is_the_training_input_dict():
         assert k in X
     assert X["phoneme_mask"].dtype == torch.bool and X["mel_len"].dtype == torch.int32
     assert int(X["mel_len"].max()) == Y["mel"].shape[1]
+
+
+def _tree_from_fixture(root):
+    """Rebuild the preprocessed_data directory the fixture was generated from (tools/gen_golden_data.py stores the tree itself)."""
+    g = np.load(os.path.join(GOLD, "data_loader.npz"))
+    for d in ("mel", "pitch", "energy", "duration"):
+        os.makedirs(os.path.join(root, d))
+    for k in g.files:
+        if k.startswith("tree/"):
+            np.save(os.path.join(root, k[5:]), g[k])
+    open(os.path.join(root, "train.txt"), "w", encoding="utf-8").write("\n".join(str(v) for v in g["meta_lines"]) + "\n")
+    json.dump({"LJSpeech": 0}, open(os.path.join(root, "speakers.json"), "w"))
+    cfg = {"dataset": "LJSpeech", "path": {"preprocessed_path": root},
+           "preprocessing": {"text": {"text_cleaners": ["english_cleaners"], "max_length": 100}}}
+    return g, cfg
+
+
+def test_dataset_and_collate_match_reference_generated_fixture(tmp_path):
+    """What the reference's own LJSpeechDataset.__getitem__ and collate_fn returned for this tree (datamodule.py:29-79, 113-186;
+    generated by tools/gen_golden_data.py in the build container): item arrays, the max_length filter, the sort order of
+    equal-length utterances, padding, masks, dtypes -- all exact."""
+    g, cfg = _tree_from_fixture(str(tmp_path / "pre"))
+    ds = LJSpeechDataset("train.txt", cfg)
+    assert len(ds) == int(g["n_items"]) == 6 and ds.basename == [str(v) for v in g["basenames"]]
+    items = [ds[j] for j in range(len(ds))]
+    for j, (x, y) in enumerate(items):
+        assert x["phoneme"].tolist() == g[f"item{j}/phoneme"].tolist() and x["text"] == str(g[f"item{j}/text"])
+        for k in ("pitch", "energy", "duration"):
+            assert np.array_equal(x[k], g[f"item{j}/{k}"]) and x[k].dtype == g[f"item{j}/{k}"].dtype, (j, k)
+        assert np.array_equal(y["mel"], g[f"item{j}/mel"])
+    for name in ("all", "first4", "ties"):
+        idxs = g[f"batch_{name}/indices"].tolist()
+        X, Y = collate_fn([items[j] for j in idxs])
+        assert X["text"] == [str(v) for v in g[f"batch_{name}/text"]]
+        for k in ("phoneme", "phoneme_len", "phoneme_mask", "mel_len", "mel_mask", "pitch", "energy", "duration"):
+            ref = g[f"batch_{name}/{k}"]
+            assert str(X[k].dtype) == str(g[f"batch_{name}/{k}.dtype"]), (name, k, X[k].dtype)
+            assert X[k].shape == ref.shape and np.array_equal(X[k].numpy(), ref), (name, k)
+        assert np.array_equal(Y["mel"].numpy(), g[f"batch_{name}/mel"]) and Y["mel"].dtype == torch.float32
+        assert set(X) == {"phoneme", "phoneme_len", "phoneme_mask", "text", "mel_len", "mel_mask", "pitch", "energy", "duration"}
+
+
+def check_loader_batch_trains(dev, tmp_path):
+    """Loader -> training step on the device: a batch collated from the reference-format tree goes through TrainStep.step."""
+    from efficientspeech_amd import CONFIGS, build_phoneme2mel, train
+    from efficientspeech_amd.synth import synth_state_dict
+    g, cfg = _tree_from_fixture(str(tmp_path / "pre"))
+    ds = LJSpeechDataset("train.txt", cfg)
+    loader = torch.utils.data.DataLoader(ds, batch_size=3, shuffle=False, collate_fn=collate_fn)
+    mcfg = CONFIGS["tiny"]
+    net = build_phoneme2mel(mcfg)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in synth_state_dict(mcfg, 1234).items()}, strict=True)
+    net = net.to(dev).train()
+    step = train.TrainStep(net, lr=1e-3)
+    losses = []
+    for epoch in range(3):
+        for x, y in loader:
+            losses.append(step.step(train.to_device(x, dev), train.to_device(y, dev)).cpu().numpy())
+    losses = np.array(losses)
+    assert np.isfinite(losses).all() and losses.shape == (6, 5)
+    assert losses[4:, 4].mean() < losses[:2, 4].mean()                # the same two batches, two epochs later: the loss fell
+    return losses
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.gpu
+def test_gpu_loader_batch_through_the_training_step(tmp_path):
+    check_loader_batch_trains("cuda", tmp_path)
+
+
+def test_simulated_loader_batch_through_the_training_step(tmp_path):
+    from tests.simlib import use_sim
+    with use_sim():
+        check_loader_batch_trains("cpu", tmp_path)

@@ -61,3 +61,63 @@ def test_shard_batch_splits_every_batch_leading_tensor():
     x = {"phoneme": torch.arange(12).reshape(6, 2), "phoneme_mask": torch.zeros(6, 2, dtype=torch.bool), "max_mel_len": 7}
     s = shard_batch(x, 2, 3)
     assert s["phoneme"].tolist() == [[8, 9], [10, 11]] and s["phoneme_mask"].shape == (2, 2) and s["max_mel_len"] == 7
+
+
+# ------------------------------------------------------------------------------------------------ the serving loop, N > 1, on one GPU
+def _pipeline_worker(rank, world, port, out_path):
+    """Two ranks share cuda:0 (process group `gloo`: RCCL refuses two ranks on one device; gloo carries CUDA tensors) and run
+    `ShardedMelPipeline` -- the loop `bench.py --gpus N` times -- with a different batch every step: side-stream all-gather,
+    MAX-reduce of the padded length, `_masked_path_inputs`, the two-stream hand-over.  Rank 0 compares every gathered step with the
+    single-process forward of the whole batch."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from tests import helpers as H
+    from efficientspeech_amd.sharded import ShardedMelPipeline, shard_batch
+    from efficientspeech_amd.synth import synth_phonemes
+    net, cfg, sd = H.make_net("tiny", "cuda")
+    results = {}
+    rng = np.random.default_rng(5)
+    # (name, B, T, lengths, forced durations?, two_stream)
+    cases = [("plain", 6, 40, [40, 33, 21, 8, 40, 17], False, False),
+             ("two_stream", 6, 40, [40, 33, 21, 8, 40, 17], False, True),
+             ("one_utterance_shard", 2, 23, [23, 11], False, False),
+             ("one_utterance_shard_two_stream", 2, 23, [23, 11], False, True),
+             ("forced_exact_length", 4, 32, [32, 32, 32, 32], True, False),
+             ("forced_exact_length_two_stream", 4, 32, [32, 32, 32, 32], True, True)]
+    with torch.no_grad():
+        for name, B, T, lens, forced, two in cases:
+            pipe = ShardedMelPipeline(net, world_size=world, gather=True, two_stream=two)
+            steps, fulls = [], []
+            for s in range(3):                                   # a different batch every step
+                ids, mask = synth_phonemes(B, T, 100 + 7 * s + len(name), lens)
+                x = {"phoneme": torch.from_numpy(ids).cuda(), "phoneme_mask": torch.from_numpy(mask).cuda()}
+                if forced:
+                    x.update(duration_forced=torch.full((B, T), 3 + s, dtype=torch.int32, device="cuda"), max_mel_len=T * (3 + s),
+                             max_mel_len_exact=True)
+                steps.append(x)
+                full, lens_g = pipe.step(shard_batch(x, rank, world))
+                fulls.append((full, lens_g, pipe.last_ready))    # (kept alive; read after the flush)
+            pipe.flush()
+            torch.cuda.synchronize()
+            if rank == 0:
+                ok = True
+                for x, (full, lens_g, _) in zip(steps, fulls):
+                    ref_mel, ref_len, _ = net(x)
+                    ok = ok and full.shape == ref_mel.shape and torch.equal(full, ref_mel) and torch.equal(lens_g, ref_len)
+                results[name] = int(ok)
+            dist.barrier()
+    if rank == 0:
+        np.save(out_path, np.array([results[c[0]] for c in cases]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_gpu_two_rank_serving_loop_on_one_device(tmp_path):
+    """`ShardedMelPipeline` with world_size 2 (both ranks on cuda:0): every gathered step bit-identical to the whole batch in one
+    process -- plain, two-stream, 1-utterance shards (duplicated to stay on the reference's masked B > 1 path), caller-vouched length."""
+    out = str(tmp_path / "pipe.npy")
+    mp.spawn(_pipeline_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    assert np.load(out).tolist() == [1, 1, 1, 1, 1, 1]
