@@ -52,11 +52,14 @@
 #define ESMI_DEC_KSUB (ESMI_DEC_SPLIT ? 4 : 8)   // un-pipelined contractions (fp32 build, in-kernel proj stage): k-steps (of 8 channels) of weights in registers at a time
 #endif
 #ifndef ESMI_DEC_WD
-#define ESMI_DEC_WD 0       // > 0: hand-pipelined K loop with this many 16-channel steps of weight fragments in flight (global/L2 ->
-#endif                      //      VGPR ring).  Measured on MI355X (tiny B=256 T=128): 0 (weights per sub-block, A fragments where used)
-#ifndef ESMI_DEC_AD         //      178 us; WD/AD = 1/1 181, 2/2 188, 3/2 215, 4/2 228, 4/3 236 us (ring registers spill at the 128-VGPR budget);
-#define ESMI_DEC_AD 1       //      256 VGPRs + 4/4: 228 us -- with four waves per SIMD the other waves already cover the round trips.
-#endif                      // A fragments in flight, in (step, row tile) items (LDS -> VGPR ring), WD > 0 only
+#define ESMI_DEC_WD 0       // weight-fragment ring depth (16-channel steps) of the dx2 = 128 kernel's K loop; 0 = no hand pipelining
+#endif
+#ifndef ESMI_DEC_WD256
+#define ESMI_DEC_WD256 2    // the same for the dx2 = 256 kernel (small / base ES: one workgroup per CU)
+#endif
+#ifndef ESMI_DEC_AD
+#define ESMI_DEC_AD 1       // A fragments in flight, in (step, row tile) items (LDS -> VGPR ring), ring form only
+#endif
 #ifndef ESMI_DEC_LN_SPREAD
 #define ESMI_DEC_LN_SPREAD 1
 #endif
@@ -400,39 +403,16 @@ __global__ __launch_bounds__(64 * NW, (DX2 <= 128 ? ESMI_DEC_WPS : NW / 4)) void
 
     // The A operand rows already stored as the two f16 planes (row = [DX2 halves h1 | DX2 halves h2 | pad], written by the
     // depthwise phase / the last LayerNorm): per (16-channel step, row tile) two ds_read_b128 + 3*NTW MFMAs.
-#if ESMI_DEC_WD == 0
-    auto gemm_prefetch = [&](long) __attribute__((always_inline)) {};
-    auto gemm_planes = [&](long off) __attribute__((always_inline)) {
-        const unsigned* a_base = reinterpret_cast<const unsigned*>(xs) + opaque_i((kDecPadRows + 32 * MT * mh + i) * LDSROW + 4 * h);
-#pragma unroll
-        for (int c = 0; c < KCH; ++c) {
-#pragma unroll
-            for (int k0 = 0; k0 < 16; k0 += KSUB) {
-                load_b(wslice(off, c), k0);
-#pragma unroll
-                for (int st = 0; st < KS16; ++st) {
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) {
-                        const unsigned* ap = a_base + 32 * mt * LDSROW + 64 * c + 4 * k0 + 8 * st;
-                        f16x2p a2;
-                        a2.h1 = *reinterpret_cast<const u32x4*>(ap);
-                        a2.h2 = *reinterpret_cast<const u32x4*>(ap + DX2 / 2);
-#pragma unroll
-                        for (int t = 0; t < NTW; ++t) acc[mt][t] = mfma32_split2_wx(bf[t][st][0], bf[t][st][1], a2, acc[mt][t]);
-                    }
-                }
-            }
-        }
-    };
-#else
-    // Hand-pipelined form (measured slower, see the knob): an item = (16-channel step s, row tile mt); weight fragments of step s + WD and A fragments of item q + AD are requested
-    // while item q's MFMAs run (VGPR rings; scheduling fences keep hipcc from sinking the loads back to their first use --
-    // left to itself it emits `ds_read; s_waitcnt lgkmcnt(0); v_mfma` per product and the matrix pipe idles through every LDS
-    // and L2 round trip: measured 4.3-9k cycles per K loop against 1.5k of MFMA issue).
-    constexpr int WD = ESMI_DEC_WD, AD = ESMI_DEC_AD;
+    // Two forms.  WD == 0 (dx2 = 128, two workgroups per CU): the weights of KSUB k-steps are loaded, then used -- the compiler
+    // keeps one or two fragments in flight and the neighbour workgroup's VALU phases fill the L2 round trips (a ring that
+    // pipelines the loop measured slower there: profiles/r03_probes/decoder_round3_experiments.md).  WD > 0 (dx2 = 256, ONE workgroup
+    // per CU, nobody to fill the gaps): hand-pipelined -- an item = (16-channel step s, row tile mt); weight fragments of step s + WD
+    // and A fragments of item q + AD are requested while item q's MFMAs run (VGPR rings; scheduling fences keep hipcc from sinking
+    // the loads back to their first use).  small ES decoder 1774 -> 1687 us with WD = 2; WD = 4 spills (1736), 6: 1976.
+    constexpr int WD = DX2 > 128 ? ESMI_DEC_WD256 : ESMI_DEC_WD, AD = ESMI_DEC_AD;
     constexpr int NSTEP = 8 * KCH, NITEM = NSTEP * MT;
-    static_assert(WD >= 1 && WD <= NSTEP && AD >= 1 && AD <= NITEM, "ring depths");
-    u32x4 wr[WD][NTW][2];
+    static_assert(WD >= 0 && WD <= NSTEP && AD >= 1 && AD <= NITEM, "ring depths");
+    u32x4 wr[WD > 0 ? WD : 1][NTW][2];
     auto w_fetch = [&](long off, int s, int slot) __attribute__((always_inline)) {
         const long wsl = wslice(off, s >> 3);
 #pragma unroll
@@ -444,33 +424,57 @@ __global__ __launch_bounds__(64 * NW, (DX2 <= 128 ? ESMI_DEC_WPS : NW / 4)) void
     // the first WD weight steps of the matrix at `off` (issued ahead of the barrier that precedes the K loop: the L2 round
     // trip then overlaps the barrier wait)
     auto gemm_prefetch = [&](long off) __attribute__((always_inline)) {
+        if constexpr (WD > 0) {
 #pragma unroll
-        for (int s = 0; s < WD; ++s) w_fetch(off, s, s);
-        sched_fence();
-    };
-    auto gemm_planes = [&](long off) __attribute__((always_inline)) {
-        const unsigned* a_base = reinterpret_cast<const unsigned*>(xs) + opaque_i((kDecPadRows + 32 * MT * mh + i) * LDSROW + 4 * h);
-        f16x2p ar[AD];
-        auto a_fetch = [&](int q, int slot) __attribute__((always_inline)) {
-            const int s = q / MT, mt = q % MT;
-            const unsigned* ap = a_base + 32 * mt * LDSROW + 64 * (s >> 3) + 8 * (s & 7);
-            ar[slot].h1 = *reinterpret_cast<const u32x4*>(ap);
-            ar[slot].h2 = *reinterpret_cast<const u32x4*>(ap + DX2 / 2);
-        };
-#pragma unroll
-        for (int q = 0; q < AD; ++q) a_fetch(q, q);
-        sched_fence();
-#pragma unroll
-        for (int q = 0; q < NITEM; ++q) {
-            const int s = q / MT, mt = q % MT;
-#pragma unroll
-            for (int t = 0; t < NTW; ++t) acc[mt][t] = mfma32_split2_wx(wr[s % WD][t][0], wr[s % WD][t][1], ar[q % AD], acc[mt][t]);
-            if (q + AD < NITEM) a_fetch(q + AD, q % AD);
-            if (mt == MT - 1 && s + WD < NSTEP) w_fetch(off, s + WD, s % WD);
+            for (int s = 0; s < WD; ++s) w_fetch(off, s, s);
             sched_fence();
         }
     };
-#endif
+    auto gemm_planes = [&](long off) __attribute__((always_inline)) {
+        const unsigned* a_base = reinterpret_cast<const unsigned*>(xs) + opaque_i((kDecPadRows + 32 * MT * mh + i) * LDSROW + 4 * h);
+        if constexpr (WD == 0) {
+#pragma unroll
+            for (int c = 0; c < KCH; ++c) {
+#pragma unroll
+                for (int k0 = 0; k0 < 16; k0 += KSUB) {
+                    load_b(wslice(off, c), k0);
+#pragma unroll
+                    for (int st = 0; st < KS16; ++st) {
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt) {
+                            const unsigned* ap = a_base + 32 * mt * LDSROW + 64 * c + 4 * k0 + 8 * st;
+                            f16x2p a2;
+                            a2.h1 = *reinterpret_cast<const u32x4*>(ap);
+                            a2.h2 = *reinterpret_cast<const u32x4*>(ap + DX2 / 2);
+#pragma unroll
+                            for (int t = 0; t < NTW; ++t) acc[mt][t] = mfma32_split2_wx(bf[t][st][0], bf[t][st][1], a2, acc[mt][t]);
+                        }
+                    }
+                }
+            }
+        } else {
+            f16x2p ar[AD];
+            auto a_fetch = [&](int q, int slot) __attribute__((always_inline)) {
+                const int s = q / MT, mt = q % MT;
+                const unsigned* ap = a_base + 32 * mt * LDSROW + 64 * (s >> 3) + 8 * (s & 7);
+                ar[slot].h1 = *reinterpret_cast<const u32x4*>(ap);
+                ar[slot].h2 = *reinterpret_cast<const u32x4*>(ap + DX2 / 2);
+            };
+#pragma unroll
+            for (int q = 0; q < AD; ++q) a_fetch(q, q);
+            sched_fence();
+#pragma unroll
+            for (int q = 0; q < NITEM; ++q) {
+                const int s = q / MT, mt = q % MT;
+#pragma unroll
+                for (int t = 0; t < NTW; ++t)
+                    acc[mt][t] = mfma32_split2_wx(wr[s % (WD > 0 ? WD : 1)][t][0], wr[s % (WD > 0 ? WD : 1)][t][1], ar[q % AD], acc[mt][t]);
+                if (q + AD < NITEM) a_fetch(q + AD, q % AD);
+                if (mt == MT - 1 && s + WD < NSTEP) w_fetch(off, s + WD, s % (WD > 0 ? WD : 1));
+                sched_fence();
+            }
+        }
+    };
 #else
     f32x4 bf[NTW][KSUB];
     auto load_b = [&](long wsl, int k0) __attribute__((always_inline)) {   // wsl: float offset of the wave's weight slice in the blob

@@ -71,6 +71,17 @@ class EfficientSpeech(nn.Module):
         decoder = MelDecoder(dim=embed_dim // reduction, kernel_size=decoder_kernel_size, n_blocks=n_blocks,
                              block_depth=block_depth)
         self.phoneme2mel = Phoneme2Mel(encoder=encoder, decoder=decoder)
+        # model.py:148: the reference always builds its vocoder from `hifigan_checkpoint`.  Here an explicitly plugged-in module wins;
+        # else a checkpoint path that exists is loaded through the HIP generator; a path that does not exist (a Lightning checkpoint
+        # written on another machine carries one in its hyper_parameters) leaves the slot empty -- `load_from_checkpoint` then
+        # rebuilds the vocoder from the checkpoint's own `hifigan.*` weights.
+        if hifigan is None and hifigan_checkpoint is not None:
+            if os.path.exists(hifigan_checkpoint):
+                from .hifigan import get_hifigan
+                hifigan = get_hifigan(hifigan_checkpoint, infer_device=infer_device, verbose=verbose)
+            else:
+                import warnings
+                warnings.warn(f"hifigan_checkpoint {hifigan_checkpoint!r} not found: no vocoder attached (predict_step returns the mel)")
         self.hifigan = hifigan
         self.hparams = dict(depth=depth, n_blocks=n_blocks, block_depth=block_depth, reduction=reduction, head=head,
                             embed_dim=embed_dim, kernel_size=kernel_size, decoder_kernel_size=decoder_kernel_size,
@@ -141,7 +152,8 @@ class EfficientSpeech(nn.Module):
         """`checkpoint`: path of a Lightning .ckpt (torch.load) or the already-loaded dict
         {'state_dict': {'phoneme2mel.*', 'hifigan.*'}, 'hyper_parameters': {...}}.  Constructor arguments come from
         `hparams`, falling back to the checkpoint's own `hyper_parameters` (as Lightning does, synthesize.py:103-119).
-        `phoneme2mel.*` loads strict; `hifigan.*` goes to the plugged-in vocoder when there is one, else it is ignored."""
+        `phoneme2mel.*` loads strict; `hifigan.*` goes to the attached vocoder, and when none is attached the HIP generator is built
+        from those weights (v1 / v2 / v3 recognised by conv_pre's width), so `predict_step` returns waveforms as on the reference."""
         ckpt = torch.load(checkpoint, map_location=map_location or "cpu") if isinstance(checkpoint, (str, os.PathLike)) else checkpoint
         hp = dict(ckpt.get("hyper_parameters", {}))
         hp.update(hparams)
@@ -151,6 +163,18 @@ class EfficientSpeech(nn.Module):
         model.phoneme2mel.load_state_dict({k[len("phoneme2mel."):]: v for k, v in sd.items() if k.startswith("phoneme2mel.")},
                                           strict=strict)
         voc = {k[len("hifigan."):]: v for k, v in sd.items() if k.startswith("hifigan.")}
-        if voc and model.hifigan is not None and hasattr(model.hifigan, "load_state_dict"):
+        if voc and model.hifigan is None:
+            # the checkpoint owns a vocoder (the reference's module does, model.py:148) and none is attached: rebuild the generator
+            # from the weights themselves -- v1 / v2 / v3 differ in conv_pre's width (512 / 128 / 256 channels)
+            from .hifigan import HIFIGAN_CONFIGS, Generator
+            width = int(voc["conv_pre.weight"].shape[0])
+            name = {512: "v1", 128: "v2", 256: "v3"}.get(width)
+            if name is None:
+                raise RuntimeError(f"hifigan.* weights of an unknown generator (conv_pre width {width})")
+            model.hifigan = Generator(HIFIGAN_CONFIGS[name])
+            dev = hp.get("infer_device")
+            if dev is not None:
+                model.hifigan.to(dev)
+        if voc and hasattr(model.hifigan, "load_state_dict"):
             model.hifigan.load_state_dict(voc, strict=strict)
         return model.eval()

@@ -30,12 +30,17 @@ def _new(shape, like, dtype=torch.float32):
     return torch.empty(shape, dtype=dtype, device=like.device)
 
 
+_DIRECT_GRADS = False     # True only while TrainStep._body runs: ONE backward per zeroed buffer, so overwriting == accumulating
+
+
 def _grad_buffer(param):
     """Where an operator's backward writes a PARAMETER's gradient: straight into the flat gradient buffer when `FlatParams` owns
-    the parameter (then autograd gets None for it: no temporary, no accumulation launch), else a fresh tensor for autograd to
-    accumulate.  Valid because every parameter of this model feeds exactly one operator per step."""
+    the parameter AND a `TrainStep` is driving the step (then autograd gets None for it: no temporary, no accumulation launch),
+    else a fresh tensor for autograd to accumulate -- so `training_step(...).backward()` called twice before an optimizer step
+    (gradient accumulation through the wrapper's public route) adds up as torch semantics require.  The direct write is valid
+    inside `TrainStep` because the buffer is zeroed per step and every parameter of this model feeds exactly one operator."""
     view = getattr(param, "_esmi_grad_view", None)
-    if view is not None and param.grad is not None and param.grad.data_ptr() == view.data_ptr():   # still the buffer autograd would add to
+    if _DIRECT_GRADS and view is not None and param.grad is not None and param.grad.data_ptr() == view.data_ptr():   # still the buffer autograd would add to
         return view, True
     return torch.empty_like(param), False
 
@@ -500,17 +505,49 @@ class TrainStep:
             self._step_dev = torch.zeros(1, dtype=torch.int32, device=dev)
             self._lr_dev = torch.full((4,), lr, dtype=torch.float32, device=dev)   # ESMI_TRAIN_ADAMW_HYPER_FLOATS: [0] = lr
 
-    # ---- checkpoint / resume (what Lightning's ModelCheckpoint keeps: weights under `state_dict`, AdamW moments and step count)
-    def state_dict(self):
-        """A Lightning-shaped checkpoint dict: {'state_dict': {'phoneme2mel.<key>': tensor}, 'optimizer_states': [...]}; the
-        weights load into the reference (`load_from_checkpoint`) and into `EfficientSpeech.load_from_checkpoint` here."""
+    # ---- checkpoint / resume (what Lightning's ModelCheckpoint keeps: weights, hyper-parameters, the optimizer's state_dict)
+    def hyper_parameters(self):
+        """The constructor arguments of the reference's LightningModule (model.py:104-121) that describe this network: what
+        `load_from_checkpoint` needs next to the weights."""
+        pe, dec = self.net.encoder, self.net.decoder
+        e = pe.encoder
+        return {"depth": e.depth, "reduction": e.embed_dim // pe.dim, "head": e.heads[0], "embed_dim": e.embed_dim,
+                "kernel_size": e.kernels[0], "expansion": e.expansion, "n_blocks": dec.n_blocks, "block_depth": dec.block_depth,
+                "decoder_kernel_size": dec.kernel_size, "lr": self.lr, "weight_decay": self.wd}
+
+    def optimizer_state_dict(self):
+        """`torch.optim.AdamW(net.parameters()).state_dict()` as the reference's optimizer would hold it after `self.t` steps:
+        per-parameter `step` / `exp_avg` / `exp_avg_sq` (views of the flat moment buffers, cloned), indexed by the parameter's
+        position in `net.parameters()`; parameters that never received a gradient (the bins, the two unreached LayerNorms) have
+        no state, as in torch."""
         f = self.flat
+        index = {id(p): j for j, p in enumerate(self.net.parameters())}
+        state, off = {}, 0
+        for p in f.params:
+            k = p.numel()
+            if self.t > 0:
+                state[index[id(p)]] = {"step": torch.tensor(float(self.t)), "exp_avg": f.m[off:off + k].view(p.shape).clone(),
+                                       "exp_avg_sq": f.v[off:off + k].view(p.shape).clone()}
+            off += (k + 3) & ~3
+        group = {"lr": self.lr, "betas": tuple(self.betas), "eps": self.eps, "weight_decay": self.wd, "amsgrad": False,
+                 "maximize": False, "foreach": None, "capturable": False, "differentiable": False, "fused": None,
+                 "decoupled_weight_decay": True, "params": list(range(len(index)))}
+        return {"state": state, "param_groups": [group]}
+
+    def state_dict(self):
+        """A Lightning-shaped checkpoint dict: `state_dict` ('phoneme2mel.<key>' weights), `hyper_parameters` (what
+        `EfficientSpeech.load_from_checkpoint` / the reference's constructor need), `optimizer_states` = [a torch AdamW
+        state_dict] (loads into `torch.optim.AdamW(net.parameters())`), `global_step`.  The reference's own
+        `load_from_checkpoint` additionally expects `hifigan.*` weights (its module owns the vocoder, model.py:148) and a
+        `preprocess_config` argument: pass `strict=False, preprocess_config=...` there, or attach the vocoder's weights under
+        `hifigan.` before saving."""
         return {"state_dict": {"phoneme2mel." + k: v.detach().clone() for k, v in self.net.state_dict().items()},
-                "optimizer_states": [{"flat_names": list(f.names), "exp_avg": f.m.clone(), "exp_avg_sq": f.v.clone(), "step": self.t,
-                                      "lr": self.lr, "weight_decay": self.wd, "betas": tuple(self.betas), "eps": self.eps}]}
+                "hyper_parameters": self.hyper_parameters(), "optimizer_states": [self.optimizer_state_dict()],
+                "global_step": self.t}
 
     def load_state_dict(self, ckpt):
-        """Resume: weights into the flat buffer's views (in place), moments and step count into the optimizer."""
+        """Resume: weights into the flat buffer's views (in place), the AdamW moments and step count from the optimizer state
+        (torch's AdamW state_dict layout, as `state_dict()` writes it)."""
         sd = {k[len("phoneme2mel."):]: v for k, v in ckpt["state_dict"].items() if k.startswith("phoneme2mel.")}
         own = dict(self.net.state_dict())
         missing = [k for k in own if k not in sd]
@@ -520,11 +557,26 @@ class TrainStep:
             for k, t in own.items():
                 t.copy_(sd[k])                      # in place: parameters stay views of the flat buffer
         o = ckpt["optimizer_states"][0]
-        if list(o["flat_names"]) != list(self.flat.names):
+        f = self.flat
+        index = {id(p): j for j, p in enumerate(self.net.parameters())}
+        if len(o["param_groups"][0]["params"]) != len(index):
             raise RuntimeError("optimizer state was saved for a different parameter list")
-        self.flat.m.copy_(o["exp_avg"])
-        self.flat.v.copy_(o["exp_avg_sq"])
-        self.t = int(o["step"])
+        f.m.zero_()
+        f.v.zero_()
+        steps, off = set(), 0
+        for p in f.params:
+            k = p.numel()
+            st = o["state"].get(index[id(p)])
+            if st is not None:
+                f.m[off:off + k].copy_(st["exp_avg"].reshape(-1))
+                f.v[off:off + k].copy_(st["exp_avg_sq"].reshape(-1))
+                steps.add(int(st["step"]))
+            off += (k + 3) & ~3
+        if len(steps) > 1:
+            raise RuntimeError(f"per-parameter step counts differ: {sorted(steps)}")
+        self.t = steps.pop() if steps else 0
+        g = o["param_groups"][0]
+        self.lr, self.wd, self.betas, self.eps = g["lr"], g["weight_decay"], tuple(g["betas"]), g["eps"]
         if self.graph:
             self._step_dev.fill_(self.t)
         self._invalidate_packed()
@@ -541,10 +593,15 @@ class TrainStep:
                 m._fwd_ident = None
 
     def _body(self, x, y, lr, graph):
+        global _DIRECT_GRADS
         f = self.flat
         f.zero_grad()
         parts, total = training_loss(self.net, x, y)
-        total.backward()                           # gradients accumulate straight into the flat buffer's views
+        _DIRECT_GRADS = True                       # one backward on a zeroed buffer: operators write parameter gradients in place
+        try:
+            total.backward()
+        finally:
+            _DIRECT_GRADS = False
         losses = loss_vector(parts, total)
         if self.world > 1:
             import torch.distributed as dist

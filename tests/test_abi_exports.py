@@ -161,3 +161,29 @@ def test_bucket_plan_covers_every_request_once():
         assert 0.0 <= waste < g / (np.mean(lens) + g) + 1e-9 if g > 1 else waste == 0.0
     # one big padded batch, for comparison: what the reference does with a ragged batch
     assert BucketedSynthesizer.padding_waste(lens, [(list(range(500)), max(lens))]) > 0.3
+
+
+def test_wrapper_attaches_the_vocoder_a_checkpoint_carries(tmp_path):
+    """model.py:148 builds the vocoder inside the module, so a reference checkpoint holds `hifigan.*` weights and a
+    `hifigan_checkpoint` path from the machine that wrote it: loading it here must end with a vocoder attached (built from the
+    weights when the path does not exist) -- not silently with `hifigan = None`.  (Host-side only: no kernels run.)"""
+    import warnings
+    import torch
+    from efficientspeech_amd import CONFIGS, EfficientSpeech, build_phoneme2mel
+    from efficientspeech_amd.hifigan import HIFIGAN_CONFIGS, Generator, synth_hifigan_state_dict
+    from efficientspeech_amd.synth import synth_state_dict
+    sd = {"phoneme2mel." + k: torch.from_numpy(v) for k, v in synth_state_dict(CONFIGS["tiny"], 1234).items()}
+    vsd = {k: torch.from_numpy(v) for k, v in synth_hifigan_state_dict(HIFIGAN_CONFIGS["v2"], 7).items()}
+    sd.update({"hifigan." + k: v for k, v in vsd.items()})
+    ckpt = {"state_dict": sd, "hyper_parameters": {"depth": 2, "reduction": 4, "decoder_kernel_size": 5,
+                                                   "hifigan_checkpoint": "hifigan/LJ_V2/generator_v2"}}
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        model = EfficientSpeech.load_from_checkpoint(ckpt)
+    assert any("not found" in str(m.message) for m in w)
+    assert isinstance(model.hifigan, Generator) and model.hifigan.h.upsample_initial_channel == 128
+    for k, v in model.hifigan.state_dict().items():
+        assert torch.equal(v, vsd[k]), k
+    plugged = Generator(HIFIGAN_CONFIGS["v2"])
+    model2 = EfficientSpeech.load_from_checkpoint(ckpt, hifigan=plugged)       # an explicitly plugged-in module wins and is loaded
+    assert model2.hifigan is plugged and torch.equal(plugged.state_dict()["conv_pre.weight"], vsd["conv_pre.weight"])

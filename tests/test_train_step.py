@@ -301,6 +301,14 @@ def check_wrapper_training_api(dev):
     assert np.abs(got - g["grad." + k]).max() < 5e-5 * np.abs(g["grad." + k]).max()
     step = model.make_train_step()
     assert step.lr == 1e-3 and step.wd == 1e-6
+    # gradient accumulation through the public route: two backwards before an optimizer step add up (torch semantics), also
+    # after make_train_step re-homed the gradients in the flat buffer
+    p = dict(model.phoneme2mel.named_parameters())[k]
+    step.flat.zero_grad()
+    model.training_step((x, y)).backward()
+    once = p.grad.detach().clone()
+    model.training_step((x, y)).backward()
+    assert torch.allclose(p.grad, 2 * once, rtol=1e-6, atol=0)
 
 
 @pytest.mark.gpu
@@ -328,10 +336,33 @@ def check_checkpoint_resume(dev):
     b.load_state_dict(ckpt)
     last_b = b.step(x2, y2)
     assert torch.equal(last_a, last_b) and torch.equal(a.flat.data, b.flat.data) and b.t == 3
-    model = EfficientSpeech.load_from_checkpoint({"state_dict": a.state_dict()["state_dict"],
-                                                  "hyper_parameters": {"depth": 2, "reduction": 4, "decoder_kernel_size": 5}})
+    model = EfficientSpeech.load_from_checkpoint(a.state_dict())     # (its own hyper_parameters describe the network)
     for k, v in model.phoneme2mel.state_dict().items():
         assert torch.equal(v.cpu(), net.state_dict()[k].cpu()), k
+    # the optimizer state is a torch AdamW state_dict: it loads into torch.optim.AdamW over the same parameter list, and one
+    # torch step from there equals one step of the AdamW kernel (same gradients) to round-off
+    ck = a.state_dict()
+    ref_net = build_phoneme2mel(CONFIGS["tiny"])
+    ref_net.load_state_dict({k[len("phoneme2mel."):]: v.cpu() for k, v in ck["state_dict"].items()})
+    opt = torch.optim.AdamW(ref_net.parameters(), lr=1e-3, weight_decay=1e-6)
+    opt.load_state_dict({"state": {j: {k: v.cpu() if torch.is_tensor(v) else v for k, v in st.items()}
+                                   for j, st in ck["optimizer_states"][0]["state"].items()},
+                         "param_groups": ck["optimizer_states"][0]["param_groups"]})
+    assert len(opt.state) == len(a.flat.names) and ck["global_step"] == 3
+    named, mine = dict(ref_net.named_parameters()), dict(net.named_parameters())
+    a.flat.zero_grad()
+    _, total = train.training_loss(net, x, y)
+    total.backward()
+    for k in a.flat.names:
+        named[k].grad = mine[k].grad.detach().cpu().clone()
+    opt.step()
+    a.t += 1
+    lib, st = train._rt(a.flat.data)
+    f = a.flat
+    lib.esmi_train_adamw_f32(train._ptr(f.data), train._ptr(f.grad), train._ptr(f.m), train._ptr(f.v), f.data.numel(), a.lr, a.betas[0],
+                             a.betas[1], a.eps, a.wd, a.t, st)
+    for k in a.flat.names:
+        assert torch.allclose(mine[k].detach().cpu(), named[k].detach(), rtol=0, atol=2e-7), k
 
 
 @pytest.mark.gpu
