@@ -77,7 +77,7 @@ class HifiGanShape(C.Structure):
 
 class ConvDesc(C.Structure):
     """esmi_conv_desc (include/esmi.h): one convolution of the training step, checkpoint weight layout."""
-    _fields_ = [(n, C.c_int) for n in ("B", "n_in", "c_in", "n_out", "c_out", "k", "stride", "pad", "groups", "transposed")]
+    _fields_ = [(n, C.c_int) for n in ("B", "n_in", "c_in", "n_out", "c_out", "k", "stride", "pad", "groups", "transposed", "precision")]
 
 
 class TrainLossArgs(C.Structure):
@@ -219,7 +219,7 @@ def bind(lib):
     lib.esmi_train_repeat_fwd_f32.argtypes = [fp, fp, i, i, i, i, fp, fp]
     lib.esmi_train_repeat_bwd_f32.argtypes = [fp, fp, i, i, i, i, fp, fp]
     lib.esmi_train_loss_f32.argtypes = [P(TrainLossArgs), fp]
-    lib.esmi_train_adamw_f32.argtypes = [fp, fp, fp, fp, i64, dbl, dbl, dbl, dbl, dbl, i, fp]
+    lib.esmi_train_adamw_f32.argtypes = [fp, fp, fp, fp, i64, dbl, dbl, dbl, dbl, dbl, i, dbl, fp]
     lib.esmi_train_adamw_graph_f32.argtypes = [fp, fp, fp, fp, i64, fp, dbl, dbl, dbl, dbl, fp, fp]
     lib.esmi_pack_resblock_bytes.argtypes = [i, i]
     lib.esmi_pack_resblock_bytes.restype = sz

@@ -55,6 +55,10 @@ struct ConvGemmP {
     // puts it in [2^9, 2^10), multiply the A values by s as they are loaded and the accumulated result by 1/s (both exact) --
     // keeps tiny gradients inside the binary16 range of the split products.  NULL: no scaling
     const float* io_scale;
+    // training with `precision=16` (the reference's default, utils/tools.py:326-327 -> torch.autocast): 1 = both operands are rounded
+    // to binary16 (nearest) and the contraction is ONE v_mfma_f32_32x32x16_f16 per 16 channels instead of the three products of
+    // the fp32-accurate split; fp32 accumulation, fp32 in / out (master weights and activations stay fp32 in memory)
+    int amp;
 };
 // (s, 1/s) for a tensor whose largest magnitude has the bit pattern *absmax
 __device__ __forceinline__ void conv_pow2_scales(const float* absmax, float* s, float* inv) {
@@ -227,6 +231,12 @@ __global__ __launch_bounds__(256) void convgemm_kernel(const ConvGemmP p) {
         // out again): this plan takes the weights exactly as stored, there is no pre-split copy.  A lane's 8 k-slots of a step are
         // the channels 8kc + 4h + (0..3) and 8(kc+1) + 4h + (0..3) on BOTH sides, i.e. a fixed permutation of the 16 channels.
         auto step16 = [&](const f32x4& a0, const f32x4& a1, const f32x4 (&b0)[NT], const f32x4 (&b1)[NT]) __attribute__((always_inline)) {
+            if (p.amp) {   // wave-uniform: binary16 operands, one product
+                const u32x4 ah = round_f16x8(a0, a1);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc[nt] = mfma32_f16(ah, round_f16x8(b0[nt] * kF16WScale, b1[nt] * kF16WScale), acc[nt]);
+                return;
+            }
             const f16x2p a2 = split_f16x2(a0, a1);
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
@@ -393,7 +403,10 @@ __global__ __launch_bounds__(64 * NWV, 2) void convgemm_lds_kernel(const ConvGem
             *reinterpret_cast<u32x2*>(d + PLANE) = u32x2{h2a, h2b};
         }
 #pragma unroll
-        for (int st = 0; st < 2; ++st) a_cur[st] = split_f16x2(a_nxt[st][0], a_nxt[st][1]);
+        for (int st = 0; st < 2; ++st) {
+            if (p.amp) a_cur[st].h1 = round_f16x8(a_nxt[st][0], a_nxt[st][1]);   // (nearest-rounded single piece; h2 unused)
+            else a_cur[st] = split_f16x2(a_nxt[st][0], a_nxt[st][1]);
+        }
     };
     fetch(0);
     stage(0);
@@ -409,6 +422,10 @@ __global__ __launch_bounds__(64 * NWV, 2) void convgemm_lds_kernel(const ConvGem
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 const u32x4 b1 = *reinterpret_cast<const u32x4*>(bp + 32 * nt * kGemmRowDw + 8 * st);
+                if (p.amp) {   // the first plane of the staged weights IS round-to-nearest binary16 of 2^8 W
+                    acc[nt] = mfma32_f16(a_use[st].h1, b1, acc[nt]);
+                    continue;
+                }
                 const u32x4 b2 = *reinterpret_cast<const u32x4*>(bp + PLANE + 32 * nt * kGemmRowDw + 8 * st);
                 acc[nt] = mfma32_split2(a_use[st], b1, b2, acc[nt]);
             }

@@ -179,6 +179,23 @@ __device__ __forceinline__ f16x2p split_f16x2(const f32x4& x0, const f32x4& x1) 
     }
     return o;
 }
+// 8 consecutive k of one row rounded to binary16 (nearest even), in the k-slot order of split_f16x2: the single-piece operand of the
+// `precision=16` training GEMMs
+__device__ __forceinline__ u32x4 round_f16x8(const f32x4& x0, const f32x4& x1) {
+    u32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float a = j < 2 ? x0[2 * j] : x1[2 * j - 4], b = j < 2 ? x0[2 * j + 1] : x1[2 * j - 3];
+#ifdef ESMI_WAVESIM
+        o[j] = f32_to_f16_bits(a, false) | (f32_to_f16_bits(b, false) << 16);
+#else
+        typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+        const f16x2_t h = {(_Float16)a, (_Float16)b};
+        o[j] = __builtin_bit_cast(unsigned, h);
+#endif
+    }
+    return o;
+}
 __device__ __forceinline__ f32x16 mfma32_f16(const u32x4& a, const u32x4& b, f32x16 c) {
 #ifdef ESMI_WAVESIM
     return wavesim::mfma_32x32x16_f16(a, b, c);

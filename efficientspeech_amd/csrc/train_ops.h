@@ -11,7 +11,7 @@
 
 namespace esmi {
 
-struct ConvDesc {   // mirrors esmi_conv_desc (include/esmi.h)
+struct ConvDesc {   // mirrors esmi_conv_desc (include/esmi.h), without its trailing `precision` (a property of the GEMM launch)
     int B, n_in, c_in, n_out, c_out, k, stride, pad, groups, transposed;
 };
 
@@ -724,11 +724,11 @@ static __global__ void train_loss_grad_kernel(const LossP p) {
 
 // ---- AdamW, torch.optim.AdamW's arithmetic (decoupled decay first, bias corrections as two scalars), over a flat buffer.
 // Every scalar is derived in double precision (host, or one device thread for the graph variant) and rounded to fp32 once.
-struct AdamWScalars { float beta1, one_m_beta1, beta2, one_m_beta2, eps, decay /* 1 - lr wd */, step_size /* lr / bc1 */, bc2_sqrt; };
+struct AdamWScalars { float beta1, one_m_beta1, beta2, one_m_beta2, eps, decay /* 1 - lr wd */, step_size /* lr / bc1 */, bc2_sqrt, gscale; };
 
 __device__ __forceinline__ void adamw_update(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                              float* __restrict__ v, long q, const AdamWScalars& h) {
-    const float grad = g[q];
+    const float grad = g[q] * h.gscale;
     float w = p[q] * h.decay;
     const float mm = h.beta1 * m[q] + h.one_m_beta1 * grad;
     const float vv = h.beta2 * v[q] + h.one_m_beta2 * grad * grad;

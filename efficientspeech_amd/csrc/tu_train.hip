@@ -11,6 +11,7 @@ extern "C" {
 // ------------------------------------------------------------------ training step (csrc/train_ops.h)
 namespace {
 int conv_desc_ok(const esmi_conv_desc* d, ConvDesc* o) {
+    if (d && d->precision != 0 && d->precision != 16 && d->precision != 32) return ESMI_ERR_ARG;
     if (!d || d->B <= 0 || d->n_in <= 0 || d->n_out <= 0 || d->c_in <= 0 || d->c_out <= 0 || d->k <= 0 || d->stride <= 0 || d->pad < 0 ||
         d->groups <= 0)
         return ESMI_ERR_ARG;
@@ -44,7 +45,7 @@ size_t esmi_train_conv_workspace_bytes(const esmi_conv_desc* d) {
 namespace {
 // one of the two implicit-GEMM problems of a dense conv: returns ESMI_ERR_UNSUPPORTED when the GEMM does not take the shape
 int train_conv_gemm(const ConvDesc& c, bool grad, const float* in, const float* w, const float* bias, float* out, float* wt,
-                    hipStream_t st) {
+                    bool amp, hipStream_t st) {
     const int cin = grad ? c.c_out : c.c_in, cout = grad ? c.c_in : c.c_out;      // of the GEMM problem
     if (c.groups != 1 || (cin & 7) || !wt) return ESMI_ERR_UNSUPPORTED;
     if (cout == 1 && (grad != (c.transposed != 0) || c.stride != 1)) return ESMI_ERR_UNSUPPORTED;   // the one-channel kernel is a plain conv
@@ -70,6 +71,7 @@ int train_conv_gemm(const ConvDesc& c, bool grad, const float* in, const float* 
     p.k = c.k; p.stride = c.stride; p.pad = c.pad;
     p.B = c.B; p.n_in = grad ? c.n_out : c.n_in; p.n_out = grad ? c.n_in : c.n_out; p.c_in = cin; p.c_out = cout;
     p.A = in; p.lda = cin; p.W = wuse; p.bias = bias; p.out = out; p.ldo = cout;
+    p.amp = amp ? 1 : 0;
     return launch_convgemm(p, st);
 }
 }  // namespace
@@ -80,7 +82,7 @@ int esmi_train_conv_fwd_f32(const esmi_conv_desc* d, const float* x, const float
     if (int rc = conv_desc_ok(d, &c)) return rc;
     if (!x || !w || !y) return ESMI_ERR_ARG;
     if (workspace && workspace_bytes >= esmi_train_conv_workspace_bytes(d)) {
-        const int rc = train_conv_gemm(c, false, x, w, bias, y, static_cast<float*>(workspace), S(stream));
+        const int rc = train_conv_gemm(c, false, x, w, bias, y, static_cast<float*>(workspace), d->precision == 16, S(stream));
         if (rc != ESMI_ERR_UNSUPPORTED) return rc;
     }
     const long n = (long)c.B * c.n_out * c.c_out;
@@ -97,7 +99,7 @@ int esmi_train_conv_dgrad_f32(const esmi_conv_desc* d, const float* dy, const fl
     if (int rc = conv_desc_ok(d, &c)) return rc;
     if (!dy || !w || !dx) return ESMI_ERR_ARG;
     if (workspace && workspace_bytes >= esmi_train_conv_workspace_bytes(d)) {
-        const int rc = train_conv_gemm(c, true, dy, w, nullptr, dx, static_cast<float*>(workspace), S(stream));
+        const int rc = train_conv_gemm(c, true, dy, w, nullptr, dx, static_cast<float*>(workspace), d->precision == 16, S(stream));
         if (rc != ESMI_ERR_UNSUPPORTED) return rc;
     }
     const long n = (long)c.B * c.n_in * c.c_in;
@@ -278,12 +280,12 @@ int esmi_train_loss_f32(const esmi_train_loss_args* a, esmi_stream_t stream) {
     return launch_status();
 }
 int esmi_train_adamw_f32(float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1, double beta2, double eps,
-                         double weight_decay, int step, esmi_stream_t stream) {
-    if (!p || !g || !m || !v || n <= 0 || step < 1) return ESMI_ERR_ARG;
+                         double weight_decay, int step, double grad_scale, esmi_stream_t stream) {
+    if (!p || !g || !m || !v || n <= 0 || step < 1 || !(grad_scale > 0.0)) return ESMI_ERR_ARG;
     // 1 - beta^step in double (-expm1(step * log beta)): in fp32, 1 - 0.999f^t carries ~6e-5 relative error at small t
     const double bc1 = -expm1((double)step * log(beta1)), bc2 = -expm1((double)step * log(beta2));
     AdamWScalars h = {(float)beta1, (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps, (float)(1.0 - lr * weight_decay),
-                      (float)(lr / bc1), (float)sqrt(bc2)};
+                      (float)(lr / bc1), (float)sqrt(bc2), (float)grad_scale};
     ESMI_LAUNCH(train_adamw_kernel, grid1d(n), dim3(256), 0, S(stream), p, g, m, v, (long)n, h);
     return launch_status();
 }
@@ -293,7 +295,7 @@ int esmi_train_adamw_graph_f32(float* p, const float* g, float* m, float* v, int
     if (!p || !g || !m || !v || !hyper_dev || !step_dev || n <= 0) return ESMI_ERR_ARG;
     ESMI_LAUNCH(train_bump_step_kernel, dim3(1), dim3(64), 0, S(stream), step_dev, hyper_dev, beta1, beta2, weight_decay);
     if (int rc = launch_status()) return rc;
-    AdamWScalars h = {(float)beta1, (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps, 0.0f, 0.0f, 0.0f};
+    AdamWScalars h = {(float)beta1, (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps, 0.0f, 0.0f, 0.0f, 1.0f};
     ESMI_LAUNCH(train_adamw_dev_kernel, grid1d(n), dim3(256), 0, S(stream), p, g, m, v, (long)n, h, (const float*)hyper_dev);
     return launch_status();
 }

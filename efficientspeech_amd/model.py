@@ -163,7 +163,7 @@ class EfficientSpeech(nn.Module):
         model.phoneme2mel.load_state_dict({k[len("phoneme2mel."):]: v for k, v in sd.items() if k.startswith("phoneme2mel.")},
                                           strict=strict)
         voc = {k[len("hifigan."):]: v for k, v in sd.items() if k.startswith("hifigan.")}
-        if voc and model.hifigan is None:
+        if "conv_pre.weight" in voc and model.hifigan is None:
             # the checkpoint owns a vocoder (the reference's module does, model.py:148) and none is attached: rebuild the generator
             # from the weights themselves -- v1 / v2 / v3 differ in conv_pre's width (512 / 128 / 256 channels)
             from .hifigan import HIFIGAN_CONFIGS, Generator

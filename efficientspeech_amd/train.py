@@ -20,6 +20,8 @@ from .networks import _ptr, _mask_u8
 ACT_RELU, ACT_GELU, ACT_TANH = 1, 2, 3
 USE_MATRIX_PIPE = True    # dense convolutions (forward and data gradient) through the implicit-GEMM kernels; False: plain fp32 kernels
 USE_MATRIX_PIPE_DGRAD = True   # (development) False: only the forward GEMMs on the matrix pipe
+PRECISION = 32            # 16: the reference's `--precision 16` -- the dense GEMMs (forward, data gradient) round their operands to
+#                           binary16 (one MFMA product instead of three); set by TrainStep(precision=16) around its step
 
 
 def _rt(t):
@@ -57,7 +59,7 @@ class _Conv(torch.autograd.Function):
         B, n_in, c_in = x.shape
         w3 = w if w.dim() == 3 else w.unsqueeze(-1)
         c_out, k = (w3.shape[1] if transposed else w3.shape[0]), w3.shape[2]
-        d = _lib.ConvDesc(B, n_in, c_in, n_out, c_out, k, stride, pad, groups, 1 if transposed else 0)
+        d = _lib.ConvDesc(B, n_in, c_in, n_out, c_out, k, stride, pad, groups, 1 if transposed else 0, 16 if PRECISION == 16 else 0)
         y = _new((B, n_out, c_out), x)
         nws = lib.esmi_train_conv_workspace_bytes(C.byref(d)) if USE_MATRIX_PIPE else 0
         ws = _new((nws,), x, torch.uint8) if nws else None
@@ -493,12 +495,21 @@ class TrainStep:
     every later batch of that shape (inputs are copied into the graph's static buffers; step count and learning rate live in
     device memory).  Single-GPU only: the gradient all-reduce stays outside a graph."""
 
-    def __init__(self, net, lr=1e-3, weight_decay=1e-6, betas=(0.9, 0.999), eps=1e-8, group=None, world_size=1, graph=False):
+    def __init__(self, net, lr=1e-3, weight_decay=1e-6, betas=(0.9, 0.999), eps=1e-8, group=None, world_size=1, graph=False,
+                 precision=32, init_scale=65536.0, growth_factor=2.0, backoff_factor=0.5, growth_interval=2000):
         self.net, self.flat = net, FlatParams(net)
         self.lr, self.wd, self.betas, self.eps = lr, weight_decay, betas, eps
         self.group, self.world = group, world_size
         self.t = 0
-        self.graph = bool(graph) and world_size == 1
+        # precision 16 = what Lightning's `precision=16` does around the reference's step (train.py:66-70): autocast-class GEMMs
+        # (binary16 operands, fp32 accumulate, fp32 master weights) + torch.amp.GradScaler's dynamic loss scaling: the backward
+        # is seeded with `scale`, a step whose gradients hold inf / nan is skipped and halves the scale, `growth_interval` clean
+        # steps in a row double it.  `skipped` counts the skipped steps (they do not advance the optimizer's step count).
+        assert precision in (16, 32), precision
+        self.precision = precision
+        self.scale, self.growth_factor, self.backoff_factor, self.growth_interval = float(init_scale), growth_factor, backoff_factor, growth_interval
+        self._good_steps, self.skipped = 0, 0
+        self.graph = bool(graph) and world_size == 1 and precision == 32
         self._graphs = {}
         if self.graph:
             dev = self.flat.data.device
@@ -593,27 +604,53 @@ class TrainStep:
                 m._fwd_ident = None
 
     def _body(self, x, y, lr, graph):
-        global _DIRECT_GRADS
+        global _DIRECT_GRADS, PRECISION
         f = self.flat
         f.zero_grad()
-        parts, total = training_loss(self.net, x, y)
-        _DIRECT_GRADS = True                       # one backward on a zeroed buffer: operators write parameter gradients in place
+        amp = self.precision == 16
+        old_precision, PRECISION = PRECISION, self.precision
         try:
-            total.backward()
+            parts, total = training_loss(self.net, x, y)
+            _DIRECT_GRADS = True                   # one backward on a zeroed buffer: operators write parameter gradients in place
+            if amp:
+                total.backward(gradient=torch.full_like(total, self.scale))     # GradScaler.scale(loss).backward()
+            else:
+                total.backward()
         finally:
             _DIRECT_GRADS = False
+            PRECISION = old_precision
         losses = loss_vector(parts, total)
         if self.world > 1:
             import torch.distributed as dist
             dist.all_reduce(f.grad, op=dist.ReduceOp.SUM, group=self.group)
             f.grad.div_(self.world)                # DDP averages (train.py:66-70 runs Lightning's default DDP strategy)
         lib, st = _rt(f.data)
+        if amp:
+            # GradScaler.step: inf / nan anywhere in the (still scaled) gradients -> skip the update, back the scale off; the check
+            # is one reduction launch + a 4-byte read (GradScaler reads its found_inf flag on the host too).  absmax's integer
+            # max orders inf and nan above every finite magnitude.
+            amax = torch.zeros(1, dtype=torch.float32, device=f.grad.device)
+            lib.esmi_absmax_f32(_ptr(f.grad), f.grad.numel(), _ptr(amax), st)
+            finite = bool(torch.isfinite(amax).item())
+            if not finite:
+                self.scale *= self.backoff_factor
+                self._good_steps = 0
+                self.skipped += 1
+                self.t -= 1                        # (the skipped step does not count for the bias corrections)
+                return losses
+            lib.esmi_train_adamw_f32(_ptr(f.data), _ptr(f.grad), _ptr(f.m), _ptr(f.v), f.data.numel(), lr, self.betas[0],
+                                     self.betas[1], self.eps, self.wd, self.t, 1.0 / self.scale, st)
+            self._good_steps += 1
+            if self._good_steps >= self.growth_interval:
+                self.scale *= self.growth_factor
+                self._good_steps = 0
+            return losses
         if graph:
             lib.esmi_train_adamw_graph_f32(_ptr(f.data), _ptr(f.grad), _ptr(f.m), _ptr(f.v), f.data.numel(), _ptr(self._lr_dev),
                                            self.betas[0], self.betas[1], self.eps, self.wd, _ptr(self._step_dev), st)
         else:
             lib.esmi_train_adamw_f32(_ptr(f.data), _ptr(f.grad), _ptr(f.m), _ptr(f.v), f.data.numel(), lr, self.betas[0],
-                                     self.betas[1], self.eps, self.wd, self.t, st)
+                                     self.betas[1], self.eps, self.wd, self.t, 1.0, st)
         return losses
 
     def step(self, x, y, lr=None):
@@ -669,7 +706,9 @@ def to_device(batch, device):
 
 def fit(step, loader, epochs, device, base_lr=None, warmup=50, total=5000, first_epoch=0, log=None):
     """The reference's training loop (train.py:66-76 -> Lightning `trainer.fit`) reduced to what it computes: for every epoch,
-    the scheduled learning rate; for every batch of the datamodule, one `TrainStep.step`.  Returns the per-epoch mean losses."""
+    the scheduled learning rate; for every batch of the datamodule, one `TrainStep.step`; at the end of the epoch the means of the
+    five losses over the epoch's steps, averaged over the data-parallel ranks (model.py:227-242: `on_train_epoch_end` logs them
+    with `sync_dist=True`) -- one 5-float all-reduce per epoch on `step.group`.  Returns the per-epoch records."""
     base_lr = step.lr if base_lr is None else base_lr
     history = []
     for epoch in range(first_epoch, first_epoch + epochs):
@@ -679,8 +718,12 @@ def fit(step, loader, epochs, device, base_lr=None, warmup=50, total=5000, first
             losses = step.step(to_device(x, device), to_device(y, device), lr=lr)
             acc = losses.clone() if acc is None else acc + losses        # five scalars per step: bookkeeping, like self.log()
             n += 1
-        mean = (acc / max(n, 1)).cpu().tolist() if acc is not None else None
-        history.append({"epoch": epoch, "lr": lr, "losses": mean})
+        mean = acc / max(n, 1) if acc is not None else None
+        if mean is not None and step.world > 1:
+            import torch.distributed as dist
+            dist.all_reduce(mean, op=dist.ReduceOp.SUM, group=step.group)
+            mean = mean / step.world
+        history.append({"epoch": epoch, "lr": lr, "losses": mean.cpu().tolist() if mean is not None else None})
         if log:
             log(history[-1])
     return history

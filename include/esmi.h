@@ -431,6 +431,9 @@ typedef struct esmi_conv_desc {
     int B, n_in, c_in, n_out, c_out, k, stride, pad;
     int groups;       /* 1, or c_in == c_out == groups (depthwise, MelDecoder networks.py:275) */
     int transposed;   /* 1: nn.ConvTranspose1d (Fuse, networks.py:185), groups must be 1 */
+    int precision;    /* 0 / 32: fp32-accurate contractions.  16: the reference's `--precision 16` (utils/tools.py:326-327, Lightning ->
+                       * torch.autocast): the forward and data-gradient GEMMs round both operands to binary16 and run ONE MFMA product
+                       * per 16 channels (fp32 accumulate, fp32 tensors in memory, fp32 master weights); weight gradients stay fp32 */
 } esmi_conv_desc;
 /* workspace (esmi_train_conv_workspace_bytes, may be NULL): scratch for the tap-major weight copy; with it, dense convolutions
  * run on the matrix pipe through the inference path's implicit GEMM (split-f16 products in libesmi.so, fp32 MFMA in
@@ -490,7 +493,8 @@ int esmi_train_loss_f32(const esmi_train_loss_args* a, esmi_stream_t stream);
  * scalars torch.optim.AdamW holds them: the bias corrections 1 - beta^step are evaluated in double precision on the host and
  * every derived scalar (1 - beta, lr * weight_decay, lr / bc1, sqrt(bc2)) is rounded to fp32 once, like torch's scalar arguments */
 int esmi_train_adamw_f32(float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1, double beta2, double eps,
-                         double weight_decay, int step, esmi_stream_t stream);
+                         double weight_decay, int step, double grad_scale /* gradients are g * grad_scale: 1 / loss scale under
+                         precision 16 (torch.amp.GradScaler's unscale_), else 1 */, esmi_stream_t stream);
 /* the same update for a captured hipGraph of the whole step: hyper_dev = ESMI_TRAIN_ADAMW_HYPER_FLOATS floats in device memory
  * ([0] = learning rate, written by the caller before a replay; the rest is scratch of this call: the bias corrections of the
  * current step, evaluated in double precision by one device thread) and the step counter (1 int32, advanced by this call before

@@ -165,7 +165,7 @@ def test_loss_and_adamw_against_torch():
         g = _rand(n, seed=30 + t)
         ref_p.grad = g.clone()
         opt.step()
-        lib.esmi_train_adamw_f32(_ptr(p), _ptr(g), _ptr(m), _ptr(v), n, 1e-3, 0.9, 0.999, 1e-8, 1e-2, t, st)
+        lib.esmi_train_adamw_f32(_ptr(p), _ptr(g), _ptr(m), _ptr(v), n, 1e-3, 0.9, 0.999, 1e-8, 1e-2, t, 1.0, st)
     assert float((p - ref_p.detach()).abs().max()) < 2e-6
 
 

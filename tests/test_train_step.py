@@ -207,9 +207,14 @@ def _ddp_worker(rank, world, port, out_path):
         dist.all_gather(gather, flat)
         lg = [torch.empty_like(losses) for _ in range(world)]
         dist.all_gather(lg, losses)
+        # epoch-level means are averaged over the ranks (model.py:227-242, sync_dist=True): one epoch of one batch per rank
+        hist = train.fit(step, [(cut(x), cut(y))], epochs=1, device="cpu", first_epoch=60)
+        ep = torch.tensor(hist[0]["losses"])
+        eg = [torch.empty_like(ep) for _ in range(world)]
+        dist.all_gather(eg, ep)
     if rank == 0:
         np.save(out_path, np.array([int(torch.equal(gather[0], gather[1])), int(not torch.equal(lg[0], lg[1])),
-                                    int(bool(torch.isfinite(flat).all()))]))
+                                    int(bool(torch.isfinite(flat).all())), int(torch.equal(eg[0], eg[1]))]))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -219,8 +224,8 @@ def test_two_rank_data_parallel_step_keeps_replicas_identical(tmp_path):
     import torch.multiprocessing as mp
     out = str(tmp_path / "ddp.npy")
     mp.spawn(_ddp_worker, args=(2, _free_port(), out), nprocs=2, join=True)
-    same_params, different_losses, finite = np.load(out)
-    assert same_params == 1 and different_losses == 1 and finite == 1
+    same_params, different_losses, finite, same_epoch_means = np.load(out)
+    assert same_params == 1 and different_losses == 1 and finite == 1 and same_epoch_means == 1
 
 
 @pytest.mark.gpu
@@ -360,7 +365,7 @@ def check_checkpoint_resume(dev):
     lib, st = train._rt(a.flat.data)
     f = a.flat
     lib.esmi_train_adamw_f32(train._ptr(f.data), train._ptr(f.grad), train._ptr(f.m), train._ptr(f.v), f.data.numel(), a.lr, a.betas[0],
-                             a.betas[1], a.eps, a.wd, a.t, st)
+                             a.betas[1], a.eps, a.wd, a.t, 1.0, st)
     for k in a.flat.names:
         assert torch.allclose(mine[k].detach().cpu(), named[k].detach(), rtol=0, atol=2e-7), k
 
@@ -393,6 +398,72 @@ def test_torch_mirror_matches_reference_fixture(gold):
         if k.startswith("grad."):
             ref, mine = g[k], named[k[5:]].grad.numpy()
             assert np.abs(mine - ref).max() < 2e-5 * max(1e-6, np.abs(ref).max()), k
+
+
+# ------------------------------------------------------------------------------------------------------- precision 16 (AMP)
+GOLD_AMP = os.path.join(os.path.dirname(__file__), "golden", "tiny_train_step_amp16.npz")   # tools/gen_golden_train.py --amp
+
+
+def check_precision16_step(dev):
+    """TrainStep(precision=16) -- binary16 GEMM operands, fp32 master weights, GradScaler-style dynamic loss scaling -- against the
+    reference's own step under torch.autocast(float16) + torch.amp.GradScaler (what its default `--precision 16` runs).  Half
+    precision is noisy by construction: the reference's fp16 gradients differ from its own fp32 gradients by 1.7e-2 (median
+    tensor) to 0.30 (worst) of each tensor's scale on this batch, so the bar is statistical -- losses to 1e-3, every tensor's
+    gradient aligned with the reference's (cosine), our error vs the fp16 reference no larger than the fp16 reference's own
+    distance from fp32 -- plus the exact mechanics: the scaled seed, the unscale inside AdamW, skip + back-off on overflow."""
+    train, g, net, x, y = _setup(dev, GOLD_AMP)
+    f32 = np.load(GOLD)
+    step = train.TrainStep(net, lr=1e-3, weight_decay=1e-6, precision=16, init_scale=2048.0)
+    before = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    losses = step.step(x, y).cpu().numpy().astype(np.float64)
+    assert np.allclose(losses[:4], g["losses"], rtol=1e-3, atol=1e-5), (losses, g["losses"])
+    assert abs(losses[4] - float(g["total"])) < 1e-3 * float(g["total"])
+    assert step.skipped == 0 and step.scale == 2048.0 and step.t == 1
+    named = dict(net.named_parameters())
+    n, worse = 0, []
+    for k in g.files:
+        if not k.startswith("grad."):
+            continue
+        ref16 = g[k].astype(np.float64).ravel()
+        mine = (named[k[5:]].grad.detach().cpu().numpy().astype(np.float64) / 2048.0).ravel()      # the buffer holds scaled gradients
+        scale = max(1e-9, np.abs(ref16).max())
+        if ref16.size >= 32 and np.linalg.norm(ref16) > 1e-6 * ref16.size ** 0.5:
+            cos = float(mine @ ref16 / (np.linalg.norm(mine) * np.linalg.norm(ref16) + 1e-30))
+            assert cos > 0.98, (k, cos)
+        if k in f32.files:
+            ref32 = f32[k].astype(np.float64).ravel()
+            d_mine, d_ref = np.abs(mine - ref16).max() / scale, np.abs(ref16 - ref32).max() / scale
+            worse.append((d_mine - max(d_ref, 2e-3), k))      # ours vs fp16 reference, against the fp16 reference's own noise
+        n += 1
+    assert n >= 60
+    assert max(worse)[0] < 0.05, sorted(worse)[-3:]
+    for k in g.files:                                           # the update itself: AdamW on the unscaled gradients
+        if k.startswith("after."):
+            mine, ref = named[k[6:]].detach().cpu().numpy(), g[k]
+            assert np.abs(mine - ref).max() < 2.5e-3, k         # (lr 1e-3: a first AdamW step moves every weight by <= 1e-3; the sign
+            #                                                      of a near-zero fp16 gradient may differ)
+            moved = np.abs(mine - before[k[6:]].cpu().numpy()).max()
+            assert 0.5e-3 < moved < 1.5e-3, (k, moved)
+    # overflow: an inf in the scaled gradients skips the update and halves the scale; the optimizer's step count stays
+    snap = step.flat.data.clone()
+    xb = dict(x, pitch=x["pitch"].clone())
+    xb["pitch"][0, 0] = float("inf")
+    step.step(xb, y)
+    assert step.skipped == 1 and step.scale == 1024.0 and step.t == 1 and torch.equal(step.flat.data, snap)
+    step.growth_interval = 2
+    step.step(x, y)
+    step.step(x, y)
+    assert step.scale == 2048.0 and step.t == 3                 # two clean steps in a row: the scale doubles
+
+
+@pytest.mark.gpu
+def test_gpu_precision16_step_matches_reference_amp():
+    check_precision16_step("cuda")
+
+
+def test_simulated_precision16_step_matches_reference_amp():
+    with use_sim():
+        check_precision16_step("cpu")
 
 
 # ---------------------------------------------------------------------------------------------------------------- at size
