@@ -140,7 +140,8 @@ EXPORTS = (
     "esmi_train_layernorm_bwd_f32", "esmi_train_act_fwd_f32", "esmi_train_act_bwd_f32", "esmi_train_attention_fwd_f32",
     "esmi_train_attention_bwd_f32", "esmi_train_embedding_fwd_f32", "esmi_train_embedding_bwd_f32", "esmi_train_mask_rows_f32",
     "esmi_train_add_f32", "esmi_train_copy_cols_f32", "esmi_train_repeat_fwd_f32", "esmi_train_repeat_bwd_f32",
-    "esmi_train_loss_f32", "esmi_train_adamw_f32", "esmi_train_adamw_graph_f32",
+    "esmi_train_loss_f32", "esmi_train_adamw_f32", "esmi_train_adamw_graph_f32", "esmi_train_conv_bwd_workspace_bytes",
+    "esmi_train_conv_bwd_f32",
 )
 
 
@@ -201,6 +202,9 @@ def bind(lib):
     lib.esmi_train_conv_wgrad_f32.argtypes = [P(ConvDesc), fp, fp, fp, fp, fp, sz, fp]
     lib.esmi_train_conv_wgrad_workspace_bytes.argtypes = [P(ConvDesc)]
     lib.esmi_train_conv_wgrad_workspace_bytes.restype = sz
+    lib.esmi_train_conv_bwd_workspace_bytes.argtypes = [P(ConvDesc)]
+    lib.esmi_train_conv_bwd_workspace_bytes.restype = sz
+    lib.esmi_train_conv_bwd_f32.argtypes = [P(ConvDesc), fp, fp, fp, fp, fp, fp, fp, sz, fp]
     lib.esmi_train_layernorm_bwd_workspace_bytes.argtypes = [i64, i]
     lib.esmi_train_layernorm_bwd_workspace_bytes.restype = sz
     lib.esmi_train_layernorm_fwd_f32.argtypes = [fp, fp, fp, i64, i, fp, fp, fp, fp]
@@ -220,7 +224,7 @@ def bind(lib):
     lib.esmi_train_repeat_bwd_f32.argtypes = [fp, fp, i, i, i, i, fp, fp]
     lib.esmi_train_loss_f32.argtypes = [P(TrainLossArgs), fp]
     lib.esmi_train_adamw_f32.argtypes = [fp, fp, fp, fp, i64, dbl, dbl, dbl, dbl, dbl, i, dbl, fp]
-    lib.esmi_train_adamw_graph_f32.argtypes = [fp, fp, fp, fp, i64, fp, dbl, dbl, dbl, dbl, fp, fp]
+    lib.esmi_train_adamw_graph_f32.argtypes = [fp, fp, fp, fp, i64, fp, dbl, dbl, dbl, dbl, fp, fp, fp, fp]
     lib.esmi_pack_resblock_bytes.argtypes = [i, i]
     lib.esmi_pack_resblock_bytes.restype = sz
     lib.esmi_pack_resblock_f16.argtypes = [fp, fp, i, i, fp]

@@ -171,7 +171,11 @@ static __global__ void train_conv_wgrad_dw_kernel(const ConvDesc d, const float*
 // (input tile, output tile).  The (tap 0, first input tile) waves also sum dY's columns: the bias gradient.
 static __global__ __launch_bounds__(256) void train_conv_wgrad_mfma_kernel(const ConvDesc d, const float* __restrict__ x,
                                                                     const float* __restrict__ dy, float* __restrict__ partial,
-                                                                    float* __restrict__ partial_bias, long chunks, long pstride) {
+                                                                    float* __restrict__ partial_bias, long chunks, long pstride,
+                                                                    int* __restrict__ dy_absmax = nullptr) {
+    // dy_absmax (optional): max |dy| as a by-product -- the (tap 0, first input tile) waves read every element of dY exactly once;
+    // an integer atomicMax of the magnitude's bit pattern is order-independent (the data-gradient GEMM that follows derives its
+    // power-of-two operand scale from it: no separate pass over dY)
     const int lane = lane_id(), i = lane & 31, kh = lane >> 5;
     const int tci = (d.c_in + 31) / 32;
     const int tile = (int)blockIdx.x, j = tile % d.k, ci0 = ((tile / d.k) % tci) * 32, cb = (tile / (d.k * tci)) * 128;
@@ -182,6 +186,7 @@ static __global__ __launch_bounds__(256) void train_conv_wgrad_mfma_kernel(const
     const bool vec_ok = co4 + 3 < d.c_out, ci_ok = ci0 + i < d.c_in;
     f32x16 acc[4] = {zero16(), zero16(), zero16(), zero16()};
     f32x4 bsum = zero4();
+    float amax_f = 0.0f;
     for (long r = r0; r < r1; r += 8) {                 // 8 rows per trip: all eight loads in flight before the 16 MFMAs
         f32x4 a[4];
         float bv[4];
@@ -204,6 +209,8 @@ static __global__ __launch_bounds__(256) void train_conv_wgrad_mfma_kernel(const
         sched_fence();
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) amax_f = fmaxf(amax_f, fabsf(a[u][e]));    // (NaN-transparent enough: a NaN gradient shows up as NaN weights anyway)
             bsum = bsum + a[u];
 #pragma unroll
             for (int t4 = 0; t4 < 4; ++t4) acc[t4] = mfma32(a[u][t4], bv[u], acc[t4]);
@@ -225,6 +232,12 @@ static __global__ __launch_bounds__(256) void train_conv_wgrad_mfma_kernel(const
             const float v = bsum[e] + shfl_xor_f(bsum[e], 32);      // even rows (kh = 0) + odd rows (kh = 1)
             if (kh == 0 && co4 + e < d.c_out) partial_bias[chunk * pstride + co4 + e] = v;
         }
+    }
+    if (dy_absmax && j == 0 && ci0 == 0) {
+        int m = __builtin_bit_cast(int, amax_f) & 0x7FFFFFFF;
+#pragma unroll
+        for (int dd = 32; dd >= 1; dd >>= 1) m = max(m, shfl_i(m, lane ^ dd));
+        if (lane == 0 && m > 0) atomicMax(dy_absmax, m);
     }
 }
 
@@ -746,10 +759,34 @@ static __global__ void train_adamw_kernel(float* __restrict__ p, const float* __
 }
 
 // the same with the step count and the learning rate read from device memory, so that a captured hipGraph of the whole
-// training step replays correctly: hyper = {lr (caller), 1 - lr wd, lr / bc1, sqrt(bc2)}; *step is advanced and the three derived
-// scalars are written by train_bump_step_kernel (one thread, double precision) inside the graph
-static __global__ void train_bump_step_kernel(int* __restrict__ step, float* __restrict__ hyper, double beta1, double beta2, double wd) {
+// training step replays correctly -- and so that `precision=16`'s dynamic loss scaling needs no host round trip:
+//   hyper  = {lr (caller), 1 - lr wd, lr / bc1, sqrt(bc2), skip flag, gradient scale}  (all but [0] written by train_bump_step_kernel)
+//   scaler = NULL, or torch.amp.GradScaler's state {scale, growth_factor, backoff_factor, growth_interval, clean steps in a row,
+//            skipped steps}: an inf / nan in the (scaled) gradients -- `grad_absmax` holds max|g| with nan ordered as inf -- skips the
+//            update (the step counter does not advance), multiplies the scale by backoff_factor; growth_interval clean steps in a
+//            row multiply it by growth_factor (GradScaler.step + .update, torch/amp/grad_scaler.py)
+static __global__ void train_bump_step_kernel(int* __restrict__ step, float* __restrict__ hyper, double beta1, double beta2, double wd,
+                                              const float* __restrict__ grad_absmax, float* __restrict__ scaler) {
     if (threadIdx.x != 0) return;
+    bool skip = false;
+    float gscale = 1.0f;
+    if (scaler) {
+        const float amax = grad_absmax[0], scale = scaler[0];
+        if (!(amax <= 3.4028234663852886e38f)) {       // inf or nan
+            skip = true;
+            scaler[0] = scale * scaler[2];
+            scaler[4] = 0.0f;
+            scaler[5] += 1.0f;
+        } else {
+            gscale = 1.0f / scale;
+            float good = scaler[4] + 1.0f;
+            if (good >= scaler[3]) { scaler[0] = scale * scaler[1]; good = 0.0f; }
+            scaler[4] = good;
+        }
+    }
+    hyper[4] = skip ? 1.0f : 0.0f;
+    hyper[5] = gscale;
+    if (skip) return;
     const int t = step[0] + 1;
     step[0] = t;
     const double lr = (double)hyper[0];
@@ -761,10 +798,11 @@ static __global__ void train_bump_step_kernel(int* __restrict__ step, float* __r
 static __global__ void train_adamw_dev_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                                        long n, AdamWScalars h, const float* __restrict__ hyper) {
     const long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (q >= n) return;
+    if (q >= n || hyper[4] != 0.0f) return;
     h.decay = hyper[1];
     h.step_size = hyper[2];
     h.bc2_sqrt = hyper[3];
+    h.gscale = hyper[5];
     adamw_update(p, g, m, v, q, h);
 }
 

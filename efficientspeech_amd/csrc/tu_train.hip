@@ -44,8 +44,9 @@ size_t esmi_train_conv_workspace_bytes(const esmi_conv_desc* d) {
 }
 namespace {
 // one of the two implicit-GEMM problems of a dense conv: returns ESMI_ERR_UNSUPPORTED when the GEMM does not take the shape
+// (have_absmax: max|in| already sits in the workspace's absmax slot -- the weight-gradient pass of esmi_train_conv_bwd_f32 left it)
 int train_conv_gemm(const ConvDesc& c, bool grad, const float* in, const float* w, const float* bias, float* out, float* wt,
-                    bool amp, hipStream_t st) {
+                    bool amp, hipStream_t st, bool have_absmax = false, bool pack_only = false) {
     const int cin = grad ? c.c_out : c.c_in, cout = grad ? c.c_in : c.c_out;      // of the GEMM problem
     if (c.groups != 1 || (cin & 7) || !wt) return ESMI_ERR_UNSUPPORTED;
     if (cout == 1 && (grad != (c.transposed != 0) || c.stride != 1)) return ESMI_ERR_UNSUPPORTED;   // the one-channel kernel is a plain conv
@@ -57,11 +58,16 @@ int train_conv_gemm(const ConvDesc& c, bool grad, const float* in, const float* 
     if (c.k == 1 && !as_convT && !grad) {
         wuse = w;                                   // a Linear's (Cout, Cin) IS its tap-major form: no copy
     } else {
-        ESMI_LAUNCH(pack_conv_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, w, wt, cout, cin, c.k, as_convT, grad ? amax : nullptr);
-        if (int rc = launch_status()) return rc;
+        if (!have_absmax) {   // (with have_absmax the pack ran in the pack_only call that preceded the weight-gradient pass)
+            ESMI_LAUNCH(pack_conv_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, w, wt, cout, cin, c.k, as_convT, grad ? amax : nullptr);
+            if (int rc = launch_status()) return rc;
+        }
     }
+    if (pack_only) return ESMI_OK;
     ConvGemmP p = conv_defaults();
-    if (grad) {   // max|dy| on the device; the GEMM kernels derive the power-of-two scales from it (convgemm.h conv_pow2_scales)
+    if (grad && have_absmax) {
+        p.io_scale = reinterpret_cast<const float*>(amax);
+    } else if (grad) {   // max|dy| on the device; the GEMM kernels derive the power-of-two scales from it (convgemm.h conv_pow2_scales)
         const long len = (long)c.B * c.n_out * c.c_out, blocks = (len + 256L * 8 - 1) / (256L * 8);
         ESMI_LAUNCH(absmax_kernel, dim3((unsigned)(blocks > 1024 ? 1024 : blocks)), dim3(256), 0, st, in, len, amax);
         if (int rc = launch_status()) return rc;
@@ -146,6 +152,41 @@ int esmi_train_conv_wgrad_f32(const esmi_conv_desc* d, const float* x, const flo
     ESMI_LAUNCH(train_reduce_chunks_kernel, grid1d(dbias ? ps : nw, 64), dim3(64 * kReduceGroups), 64 * kReduceGroups * sizeof(float), S(stream),
                 part, dbias ? ps : nw, ps, chunks, dw, nw, dbias);
     return launch_status();
+}
+size_t esmi_train_conv_bwd_workspace_bytes(const esmi_conv_desc* d) {
+    return align256(esmi_train_conv_wgrad_workspace_bytes(d)) + esmi_train_conv_workspace_bytes(d);
+}
+int esmi_train_conv_bwd_f32(const esmi_conv_desc* d, const float* x, const float* dy, const float* w, float* dx, float* dw, float* dbias,
+                            void* workspace, size_t workspace_bytes, esmi_stream_t stream) {
+    ConvDesc c;
+    if (int rc = conv_desc_ok(d, &c)) return rc;
+    if (!x || !dy || !w || !dx || !dw || !workspace) return ESMI_ERR_ARG;
+    if (workspace_bytes < esmi_train_conv_bwd_workspace_bytes(d)) return ESMI_ERR_WORKSPACE;
+    const size_t wg_bytes = align256(esmi_train_conv_wgrad_workspace_bytes(d)), gemm_bytes = esmi_train_conv_workspace_bytes(d);
+    char* ws = static_cast<char*>(workspace);
+    float* wt = reinterpret_cast<float*>(ws + wg_bytes);
+    // dense shapes whose two gradients both run on the matrix pipe: tap-major weight copy (zeroes the absmax slot) -> weight gradient
+    // (leaves max|dy| in the slot) -> data-gradient GEMM scaled by it.  Everything else: the two stand-alone entry points.
+    const bool fused = gemm_bytes > 0 && wgrad_on_mfma(c) &&
+                       train_conv_gemm(c, true, dy, w, nullptr, dx, wt, d->precision == 16, S(stream), false, true) == ESMI_OK;
+    if (!fused) {
+        if (int rc = esmi_train_conv_dgrad_f32(d, dy, w, dx, gemm_bytes ? wt : nullptr, gemm_bytes, stream)) return rc;
+        return esmi_train_conv_wgrad_f32(d, x, dy, dw, dbias, workspace, wg_bytes, stream);
+    }
+    const long nw = (long)(c.transposed ? c.c_in * c.c_out : c.c_out * (c.c_in / c.groups)) * c.k;
+    int* amax = reinterpret_cast<int*>(reinterpret_cast<char*>(wt) + align256((size_t)nw * sizeof(float)));
+    const long rows = (long)c.B * c.n_out, chunks = train_chunks(rows, wgrad_chunk(c));
+    float* part = reinterpret_cast<float*>(ws);
+    float* pb = part + nw;
+    const long ps = nw + c.c_out;
+    const unsigned tiles = (unsigned)(((c.c_out + 127) / 128) * ((c.c_in + 31) / 32) * c.k);
+    ESMI_LAUNCH(train_conv_wgrad_mfma_kernel, dim3(tiles, (unsigned)((chunks + 3) / 4)), dim3(256), 0, S(stream), c, x, dy, part,
+                dbias ? pb : nullptr, chunks, ps, amax);
+    if (int rc = launch_status()) return rc;
+    ESMI_LAUNCH(train_reduce_chunks_kernel, grid1d(dbias ? ps : nw, 64), dim3(64 * kReduceGroups), 64 * kReduceGroups * sizeof(float), S(stream),
+                part, dbias ? ps : nw, ps, chunks, dw, nw, dbias);
+    if (int rc = launch_status()) return rc;
+    return train_conv_gemm(c, true, dy, w, nullptr, dx, wt, d->precision == 16, S(stream), true);
 }
 int esmi_train_layernorm_fwd_f32(const float* x, const float* g, const float* b, int64_t rows, int C, float* y, float* mean,
                                  float* rstd, esmi_stream_t stream) {
@@ -291,14 +332,15 @@ int esmi_train_adamw_f32(float* p, const float* g, float* m, float* v, int64_t n
 }
 
 int esmi_train_adamw_graph_f32(float* p, const float* g, float* m, float* v, int64_t n, float* hyper_dev, double beta1, double beta2,
-                               double eps, double weight_decay, int32_t* step_dev, esmi_stream_t stream) {
-    if (!p || !g || !m || !v || !hyper_dev || !step_dev || n <= 0) return ESMI_ERR_ARG;
-    ESMI_LAUNCH(train_bump_step_kernel, dim3(1), dim3(64), 0, S(stream), step_dev, hyper_dev, beta1, beta2, weight_decay);
+                               double eps, double weight_decay, int32_t* step_dev, const float* grad_absmax, float* scaler_state,
+                               esmi_stream_t stream) {
+    if (!p || !g || !m || !v || !hyper_dev || !step_dev || n <= 0 || ((scaler_state != nullptr) != (grad_absmax != nullptr))) return ESMI_ERR_ARG;
+    ESMI_LAUNCH(train_bump_step_kernel, dim3(1), dim3(64), 0, S(stream), step_dev, hyper_dev, beta1, beta2, weight_decay, grad_absmax,
+                scaler_state);
     if (int rc = launch_status()) return rc;
     AdamWScalars h = {(float)beta1, (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps, 0.0f, 0.0f, 0.0f, 1.0f};
     ESMI_LAUNCH(train_adamw_dev_kernel, grid1d(n), dim3(256), 0, S(stream), p, g, m, v, (long)n, h, (const float*)hyper_dev);
     return launch_status();
 }
-
 
 }  // extern "C"

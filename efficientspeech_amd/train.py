@@ -75,15 +75,19 @@ class _Conv(torch.autograd.Function):
         lib, st = _rt(dy)
         d = ctx.d
         dx = torch.empty_like(x)
-        nws = lib.esmi_train_conv_workspace_bytes(C.byref(d)) if (USE_MATRIX_PIPE and USE_MATRIX_PIPE_DGRAD) else 0
-        ws = _new((nws,), w, torch.uint8) if nws else None
-        lib.esmi_train_conv_dgrad_f32(C.byref(d), _ptr(dy), _ptr(w), _ptr(dx), _ptr(ws), nws, st)
         w0, b0 = ctx.params
         dw, w_direct = _grad_buffer(w0)
         db, b_direct = _grad_buffer(b0) if b0 is not None else (None, True)
-        nws = lib.esmi_train_conv_wgrad_workspace_bytes(C.byref(d))
-        ws = _new((nws,), w, torch.uint8)
-        lib.esmi_train_conv_wgrad_f32(C.byref(d), _ptr(x), _ptr(dy), _ptr(dw), _ptr(db), _ptr(ws), nws, st)
+        if USE_MATRIX_PIPE and USE_MATRIX_PIPE_DGRAD:
+            # one call for both gradients: the weight-gradient pass leaves max|dy| behind for the data-gradient GEMM's operand scale
+            nws = lib.esmi_train_conv_bwd_workspace_bytes(C.byref(d))
+            ws = _new((nws,), w, torch.uint8)
+            lib.esmi_train_conv_bwd_f32(C.byref(d), _ptr(x), _ptr(dy), _ptr(w), _ptr(dx), _ptr(dw), _ptr(db), _ptr(ws), nws, st)
+        else:
+            lib.esmi_train_conv_dgrad_f32(C.byref(d), _ptr(dy), _ptr(w), _ptr(dx), None, 0, st)
+            nws = lib.esmi_train_conv_wgrad_workspace_bytes(C.byref(d))
+            ws = _new((nws,), w, torch.uint8)
+            lib.esmi_train_conv_wgrad_f32(C.byref(d), _ptr(x), _ptr(dy), _ptr(dw), _ptr(db), _ptr(ws), nws, st)
         return dx, (None if w_direct else dw), (None if b_direct else db), None, None, None, None, None
 
 
@@ -500,21 +504,51 @@ class TrainStep:
         self.net, self.flat = net, FlatParams(net)
         self.lr, self.wd, self.betas, self.eps = lr, weight_decay, betas, eps
         self.group, self.world = group, world_size
-        self.t = 0
+        self._t = 0
         # precision 16 = what Lightning's `precision=16` does around the reference's step (train.py:66-70): autocast-class GEMMs
         # (binary16 operands, fp32 accumulate, fp32 master weights) + torch.amp.GradScaler's dynamic loss scaling: the backward
         # is seeded with `scale`, a step whose gradients hold inf / nan is skipped and halves the scale, `growth_interval` clean
         # steps in a row double it.  `skipped` counts the skipped steps (they do not advance the optimizer's step count).
         assert precision in (16, 32), precision
         self.precision = precision
-        self.scale, self.growth_factor, self.backoff_factor, self.growth_interval = float(init_scale), growth_factor, backoff_factor, growth_interval
-        self._good_steps, self.skipped = 0, 0
-        self.graph = bool(graph) and world_size == 1 and precision == 32
+        self.graph = bool(graph) and world_size == 1
+        dev = self.flat.data.device
+        if precision == 16:
+            # the scaler's state and the optimizer's step count live in device memory: the step never waits for the host.
+            # {scale, growth_factor, backoff_factor, growth_interval, clean steps in a row, skipped steps, -, -}
+            self._scaler = torch.tensor([init_scale, growth_factor, backoff_factor, growth_interval, 0, 0, 0, 0], dtype=torch.float32, device=dev)
+            self._absmax = torch.zeros(1, dtype=torch.float32, device=dev)
         self._graphs = {}
-        if self.graph:
-            dev = self.flat.data.device
+        if self.graph or precision == 16:
             self._step_dev = torch.zeros(1, dtype=torch.int32, device=dev)
-            self._lr_dev = torch.full((4,), lr, dtype=torch.float32, device=dev)   # ESMI_TRAIN_ADAMW_HYPER_FLOATS: [0] = lr
+            self._lr_dev = torch.full((8,), lr, dtype=torch.float32, device=dev)   # ESMI_TRAIN_ADAMW_HYPER_FLOATS: [0] = lr
+
+    # precision 16: read-outs of the device-side state (each is one small device -> host copy; the step itself never reads them)
+    @property
+    def scale(self):
+        return float(self._scaler[0].item()) if self.precision == 16 else 1.0
+
+    @property
+    def skipped(self):
+        return int(self._scaler[5].item()) if self.precision == 16 else 0
+
+    @property
+    def growth_interval(self):
+        return int(self._scaler[3].item())
+
+    @growth_interval.setter
+    def growth_interval(self, n):
+        self._scaler[3] = float(n)
+
+    @property
+    def t(self):
+        return int(self._step_dev.item()) if self.precision == 16 else self._t
+
+    @t.setter
+    def t(self, v):
+        self._t = int(v)
+        if self.precision == 16 and hasattr(self, "_step_dev"):
+            self._step_dev.fill_(int(v))
 
     # ---- checkpoint / resume (what Lightning's ModelCheckpoint keeps: weights, hyper-parameters, the optimizer's state_dict)
     def hyper_parameters(self):
@@ -552,9 +586,14 @@ class TrainStep:
         `load_from_checkpoint` additionally expects `hifigan.*` weights (its module owns the vocoder, model.py:148) and a
         `preprocess_config` argument: pass `strict=False, preprocess_config=...` there, or attach the vocoder's weights under
         `hifigan.` before saving."""
-        return {"state_dict": {"phoneme2mel." + k: v.detach().clone() for k, v in self.net.state_dict().items()},
-                "hyper_parameters": self.hyper_parameters(), "optimizer_states": [self.optimizer_state_dict()],
-                "global_step": self.t}
+        ck = {"state_dict": {"phoneme2mel." + k: v.detach().clone() for k, v in self.net.state_dict().items()},
+              "hyper_parameters": self.hyper_parameters(), "optimizer_states": [self.optimizer_state_dict()],
+              "global_step": self.t}
+        if self.precision == 16:                   # torch.amp.GradScaler.state_dict()'s keys (Lightning stores it next to the optimizer)
+            sc = self._scaler.cpu().tolist()
+            ck["scaler"] = {"scale": sc[0], "growth_factor": sc[1], "backoff_factor": sc[2], "growth_interval": int(sc[3]),
+                            "_growth_tracker": int(sc[4])}
+        return ck
 
     def load_state_dict(self, ckpt):
         """Resume: weights into the flat buffer's views (in place), the AdamW moments and step count from the optimizer state
@@ -588,8 +627,12 @@ class TrainStep:
         self.t = steps.pop() if steps else 0
         g = o["param_groups"][0]
         self.lr, self.wd, self.betas, self.eps = g["lr"], g["weight_decay"], tuple(g["betas"]), g["eps"]
-        if self.graph:
+        if self.graph and self.precision != 16:
             self._step_dev.fill_(self.t)
+        if self.precision == 16 and "scaler" in ckpt:
+            sc = ckpt["scaler"]
+            self._scaler[:5] = torch.tensor([sc["scale"], sc["growth_factor"], sc["backoff_factor"], sc["growth_interval"],
+                                             sc["_growth_tracker"]], dtype=torch.float32)
         self._invalidate_packed()
 
     def _invalidate_packed(self):
@@ -613,7 +656,7 @@ class TrainStep:
             parts, total = training_loss(self.net, x, y)
             _DIRECT_GRADS = True                   # one backward on a zeroed buffer: operators write parameter gradients in place
             if amp:
-                total.backward(gradient=torch.full_like(total, self.scale))     # GradScaler.scale(loss).backward()
+                total.backward(gradient=self._scaler[0].reshape(total.shape))     # GradScaler.scale(loss).backward(): the seed is the device-side scale
             else:
                 total.backward()
         finally:
@@ -626,35 +669,27 @@ class TrainStep:
             f.grad.div_(self.world)                # DDP averages (train.py:66-70 runs Lightning's default DDP strategy)
         lib, st = _rt(f.data)
         if amp:
-            # GradScaler.step: inf / nan anywhere in the (still scaled) gradients -> skip the update, back the scale off; the check
-            # is one reduction launch + a 4-byte read (GradScaler reads its found_inf flag on the host too).  absmax's integer
-            # max orders inf and nan above every finite magnitude.
-            amax = torch.zeros(1, dtype=torch.float32, device=f.grad.device)
-            lib.esmi_absmax_f32(_ptr(f.grad), f.grad.numel(), _ptr(amax), st)
-            finite = bool(torch.isfinite(amax).item())
-            if not finite:
-                self.scale *= self.backoff_factor
-                self._good_steps = 0
-                self.skipped += 1
-                self.t -= 1                        # (the skipped step does not count for the bias corrections)
-                return losses
-            lib.esmi_train_adamw_f32(_ptr(f.data), _ptr(f.grad), _ptr(f.m), _ptr(f.v), f.data.numel(), lr, self.betas[0],
-                                     self.betas[1], self.eps, self.wd, self.t, 1.0 / self.scale, st)
-            self._good_steps += 1
-            if self._good_steps >= self.growth_interval:
-                self.scale *= self.growth_factor
-                self._good_steps = 0
+            # GradScaler.step + .update on the device: max|g| of the (still scaled) gradients -- absmax's integer max orders inf and
+            # nan above every finite magnitude -- decides inside the optimizer launch whether the update runs (on g / scale) or is
+            # skipped with the scale backed off; nothing is read back.
+            if not graph:                          # (graph mode: step() wrote it before the replay)
+                self._lr_dev[:1].fill_(lr)
+            lib.esmi_absmax_f32(_ptr(f.grad), f.grad.numel(), _ptr(self._absmax), st)
+            lib.esmi_train_adamw_graph_f32(_ptr(f.data), _ptr(f.grad), _ptr(f.m), _ptr(f.v), f.data.numel(), _ptr(self._lr_dev),
+                                           self.betas[0], self.betas[1], self.eps, self.wd, _ptr(self._step_dev), _ptr(self._absmax),
+                                           _ptr(self._scaler), st)
             return losses
         if graph:
             lib.esmi_train_adamw_graph_f32(_ptr(f.data), _ptr(f.grad), _ptr(f.m), _ptr(f.v), f.data.numel(), _ptr(self._lr_dev),
-                                           self.betas[0], self.betas[1], self.eps, self.wd, _ptr(self._step_dev), st)
+                                           self.betas[0], self.betas[1], self.eps, self.wd, _ptr(self._step_dev), None, None, st)
         else:
             lib.esmi_train_adamw_f32(_ptr(f.data), _ptr(f.grad), _ptr(f.m), _ptr(f.v), f.data.numel(), lr, self.betas[0],
                                      self.betas[1], self.eps, self.wd, self.t, 1.0, st)
         return losses
 
     def step(self, x, y, lr=None):
-        self.t += 1
+        if self.precision != 16:
+            self._t += 1                           # (precision 16 counts on the device: a skipped step does not advance it)
         lr = self.lr if lr is None else lr
         if not self.graph:
             out = self._body(x, y, lr, False)

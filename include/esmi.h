@@ -447,6 +447,12 @@ int esmi_train_conv_dgrad_f32(const esmi_conv_desc* d, const float* dy, const fl
 size_t esmi_train_conv_wgrad_workspace_bytes(const esmi_conv_desc* d);
 int esmi_train_conv_wgrad_f32(const esmi_conv_desc* d, const float* x, const float* dy, float* dw, float* dbias /* or NULL */,
                               void* workspace, size_t workspace_bytes, esmi_stream_t stream);
+/* both gradients of one convolution in one call (what autograd's backward of the op needs): the weight-gradient pass leaves max|dy|
+ * behind as a by-product and the data-gradient GEMM takes its operand scale from it -- no separate pass over dy.  Shapes that do not
+ * run on the matrix pipe fall back to the two entry points above. */
+size_t esmi_train_conv_bwd_workspace_bytes(const esmi_conv_desc* d);
+int esmi_train_conv_bwd_f32(const esmi_conv_desc* d, const float* x, const float* dy, const float* w, float* dx, float* dw,
+                            float* dbias /* or NULL */, void* workspace, size_t workspace_bytes, esmi_stream_t stream);
 /* nn.LayerNorm over the last dim (eps 1e-5); mean / rstd (rows) are kept for the backward */
 int esmi_train_layernorm_fwd_f32(const float* x, const float* g, const float* b, int64_t rows, int C, float* y, float* mean,
                                  float* rstd, esmi_stream_t stream);
@@ -495,13 +501,19 @@ int esmi_train_loss_f32(const esmi_train_loss_args* a, esmi_stream_t stream);
 int esmi_train_adamw_f32(float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1, double beta2, double eps,
                          double weight_decay, int step, double grad_scale /* gradients are g * grad_scale: 1 / loss scale under
                          precision 16 (torch.amp.GradScaler's unscale_), else 1 */, esmi_stream_t stream);
-/* the same update for a captured hipGraph of the whole step: hyper_dev = ESMI_TRAIN_ADAMW_HYPER_FLOATS floats in device memory
- * ([0] = learning rate, written by the caller before a replay; the rest is scratch of this call: the bias corrections of the
- * current step, evaluated in double precision by one device thread) and the step counter (1 int32, advanced by this call before
- * the update), so a replay uses the current values */
-#define ESMI_TRAIN_ADAMW_HYPER_FLOATS 4
+/* the same update with its bookkeeping in device memory -- for a captured hipGraph of the whole step, and for `precision=16` without a
+ * host round trip: hyper_dev = ESMI_TRAIN_ADAMW_HYPER_FLOATS floats ([0] = learning rate, written by the caller before a replay;
+ * the rest is scratch of this call: the bias corrections of the current step, evaluated in double precision by one device thread,
+ * the skip flag and the gradient scale), step_dev = the step counter (1 int32, advanced by this call before the update).
+ * grad_absmax + scaler_state (both NULL, or both given): torch.amp.GradScaler on the device -- grad_absmax = max|g| of the (scaled)
+ * gradient buffer with nan ordered as inf (esmi_absmax_f32), scaler_state = ESMI_TRAIN_SCALER_FLOATS floats {scale, growth_factor,
+ * backoff_factor, growth_interval, clean steps in a row, skipped steps}: an overflow skips the update (step_dev stays) and backs
+ * the scale off; otherwise the update runs on g / scale and the growth counter advances */
+#define ESMI_TRAIN_ADAMW_HYPER_FLOATS 8
+#define ESMI_TRAIN_SCALER_FLOATS 8
 int esmi_train_adamw_graph_f32(float* p, const float* g, float* m, float* v, int64_t n, float* hyper_dev, double beta1, double beta2,
-                               double eps, double weight_decay, int32_t* step_dev, esmi_stream_t stream);
+                               double eps, double weight_decay, int32_t* step_dev, const float* grad_absmax /* or NULL */,
+                               float* scaler_state /* or NULL */, esmi_stream_t stream);
 
 #ifdef __cplusplus
 }

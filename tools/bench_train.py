@@ -12,7 +12,7 @@ from efficientspeech_amd.synth import synth_state_dict
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--config", default="tiny"); ap.add_argument("--batch", type=int, default=32)
-    ap.add_argument("--phonemes", type=int, default=128); ap.add_argument("--dur", type=int, default=6); ap.add_argument("--iters", type=int, default=5); ap.add_argument("--graph", action="store_true"); ap.add_argument("--torch-mirror", action="store_true", help="time plain PyTorch-ROCm ops (tests/torch_mirror.py + torch.optim.AdamW) on the same batch instead")
+    ap.add_argument("--phonemes", type=int, default=128); ap.add_argument("--dur", type=int, default=6); ap.add_argument("--iters", type=int, default=5); ap.add_argument("--graph", action="store_true"); ap.add_argument("--precision", type=int, default=32); ap.add_argument("--torch-mirror", action="store_true", help="time plain PyTorch-ROCm ops (tests/torch_mirror.py + torch.optim.AdamW) on the same batch instead")
     a = ap.parse_args()
     cfg = CONFIGS[a.config]
     net = build_phoneme2mel(cfg)
@@ -34,7 +34,7 @@ if __name__ == "__main__":
                 return torch.stack([*[p.detach() for p in parts], total.detach()])
         step = _S()
     else:
-        step = train.TrainStep(net, graph=a.graph)
+        step = train.TrainStep(net, graph=a.graph, precision=a.precision, init_scale=2048.0)
     for _ in range(3):
         l0 = step.step(x, y)
     torch.cuda.synchronize(); t0 = time.perf_counter()
