@@ -424,6 +424,34 @@ def main():
         out["b1_fox_gpu"] = {"latency_ms_median": float(np.median(ts_) * 1e3), "frames": len(FOX_IDS) * a.dur,
                              "mRTF": len(FOX_IDS) * a.dur * 256 / 22050 / float(np.median(ts_)),
                              "note": "Phoneme2Mel.forward, B=1, T=31, synchronised after every call (host enqueue + kernels)"}
+        # ---- robustness workload D-rand: durations uniform in [1, 11] (seed 1234, mean 6), ragged mel lengths, the
+        # padded length derived on the device (no caller-vouched L): frame -> phoneme search, padding frames and the final mask all
+        # take part.  Valid frames only are counted.
+        try:
+            rng = np.random.default_rng(1234)
+            d_rand = rng.integers(1, 12, size=(B, T)).astype(np.int32)
+            L_rand = int(d_rand.sum(1).max())
+            xr = {"phoneme": x["phoneme"], "phoneme_mask": x["phoneme_mask"], "duration_forced": torch.from_numpy(d_rand).to(dev),
+                  "max_mel_len": L_rand}
+            with torch.no_grad():
+                for _ in range(5):
+                    net(xr)
+                torch.cuda.synchronize(dev)
+                t0 = time.perf_counter()
+                n_r = 30
+                for _ in range(n_r):
+                    mel_r, len_r, _ = net(xr)
+                torch.cuda.synchronize(dev)
+                tr_ = (time.perf_counter() - t0) / n_r
+            valid = int(d_rand.sum())
+            out["d_rand"] = {"ms_per_step": tr_ * 1e3, "valid_frames_per_step": valid, "padded_length": L_rand,
+                             "value": valid / tr_, "padding_fraction": 1.0 - valid / float(B * L_rand),
+                             "mel_len_matches": bool(np.array_equal(len_r.cpu().numpy(), d_rand.sum(1))),
+                             "note": "SURVEY 8d robustness workload: durations U[1, 11] seed 1234, same phoneme batch; frames/s counts "
+                                     "valid frames only (windows that are all padding are skipped by the decoder, partly padded ones "
+                                     "are computed as the reference computes them)"}
+        except Exception as e:                     # noqa: BLE001
+            out["d_rand"] = {"error": repr(e)}
         # ---- the step after the path: HiFi-GAN v2 generator on the mel the forward just produced
         if not a.exact_fp32:
             from efficientspeech_amd.hifigan import HIFIGAN_CONFIGS, Generator, synth_hifigan_state_dict, flops_per_mel_frame
@@ -488,8 +516,32 @@ def main():
         if world > 1:
             dist.all_reduce(ttr, op=dist.ReduceOp.MAX)
         ttr = float(ttr.item())
+        # algorithmic work of one step: the forward's matmul-class FLOPs (decoder per frame + encoder side per phoneme) once
+        # forward, twice backward (data gradient + weight gradient of every contraction); the decoder runs at frame rate in train mode
+        enc_flops = {"tiny": 262_336, "small": 737_664, "base": 4_489_984}[a.config]
+        step_flops = 3.0 * tb * tt * (a.dur * DECODER_WORK[a.config][0] + enc_flops)
+        t16 = None
+        if world == 1:
+            ts16 = _train.TrainStep(make_net(cfg, sd, dev).train(), precision=16, init_scale=2048.0)
+            for _ in range(3):
+                ts16.step(tx, ty)
+            sync_all()
+            t0 = time.perf_counter()
+            for _ in range(n_tr):
+                ts16.step(tx, ty)
+            sync_all()
+            t16 = (time.perf_counter() - t0) / n_tr
+            del ts16
         out["train_step"] = {"ms_per_step": ttr * 1e3, "mel_frames_per_s": tb * tt * a.dur * world / ttr, "steps": n_tr,
                              "per_gpu_batch": tb, "phonemes": tt, "frames_per_utterance": tt * a.dur,
+                             "precision16_ms_per_step": None if t16 is None else t16 * 1e3,
+                             "roofline": {"bound": "mfma", "algorithmic_flops_per_step": step_flops,
+                                          "achieved": step_flops / ttr / 1e12, "peak": F16_PEAK_TFLOPS / 3.0, "unit": "TFLOP/s",
+                                          "frac": step_flops / ttr / 1e12 / (F16_PEAK_TFLOPS / 3.0),
+                                          "note": "whole step (several hundred launches, no dominant kernel): 3 x the forward's "
+                                                  "contraction FLOPs over the step time against the split-f16 bound; the step is "
+                                                  "bound by launch count and by the partial-sum traffic of the deterministic "
+                                                  "weight-gradient reductions, not by the matrix pipe (DESIGN.md 3.6)"},
                              "loss_first_last": [float(tl0[4]), float(tl1[4])],
                              "allreduce_bytes_per_step": int(ts.flat.grad.numel() * 4) if world > 1 else 0,
                              "note": "SURVEY 8f-2 / BASELINE configs[4]: train=True forward, masked L1 + 3 MSE loss, backward, AdamW "
