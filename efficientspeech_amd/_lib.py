@@ -18,7 +18,8 @@ MAX_DEC_LAYERS = 16
 ESMI_OK = 0
 _ERRS = {-1: "ESMI_ERR_ARG (null pointer / bad size / misaligned)",
          -2: "ESMI_ERR_UNSUPPORTED (shape outside what the kernels are built for)",
-         -3: "ESMI_ERR_WORKSPACE (workspace too small)"}
+         -3: "ESMI_ERR_WORKSPACE (workspace too small)",
+         -4: "ESMI_ERR_RANGE (an activation left the binary16 range of the split contractions)"}
 
 fp = C.c_void_p  # device pointers travel as integers
 
@@ -96,7 +97,7 @@ class ForwardArgs(C.Structure):
                 ("ids", fp), ("mask", fp), ("dur_forced", fp),
                 ("duration_pred", fp), ("mel_len", fp), ("mel", fp), ("L_out", C.c_int), ("lmax_host", C.c_int), ("lmax_dev", fp),
                 ("pitch_pred", fp), ("energy_pred", fp), ("pitch_idx", fp), ("energy_idx", fp), ("dur", fp), ("cum", fp),
-                ("arena", fp), ("arena_bytes", C.c_size_t)]
+                ("arena", fp), ("arena_bytes", C.c_size_t), ("range_flag", fp)]
 
 
 # launch-plan bits (include/esmi.h ESMI_FUSE_*): passed per call, the library keeps no state
@@ -238,6 +239,10 @@ def bind(lib):
     return lib
 
 
+class ActivationRange(ValueError):
+    """ESMI_ERR_RANGE (checked build): a value entering a split-f16 contraction was outside the binary16 range."""
+
+
 class Unsupported(RuntimeError):
     """ESMI_ERR_UNSUPPORTED: the shape is outside what this entry point's kernels are built for."""
 
@@ -246,6 +251,9 @@ def _make_check(name):
     def check(rc, func, args):
         if rc == -2:
             raise Unsupported(f"{name}: shape not supported")
+        if rc == -4:
+            raise ActivationRange(f"{name}: an activation is outside the binary16 range (|a| >= 65504) of the fp32-accurate split "
+                                  "contractions; run this checkpoint on libesmi_fp32mfma.so (ESMI_LIB=...), which has no range limit")
         if rc != ESMI_OK:
             what = _ERRS.get(rc, f"hipError_t {rc}" if rc > 0 else f"error {rc}")
             raise RuntimeError(f"{name} failed: {what}")

@@ -5,6 +5,7 @@
 #include "mel_decoder.h"   // esmi_decoder_shape helpers used by the one-call forward
 
 using namespace esmi;
+ESMI_TU_RANGE_SETTER(abi)
 
 namespace {
 
@@ -67,10 +68,15 @@ const char* esmi_build_config(void) {
 #else
 #define ESMI_CFG_ENC_ ",enc_gemm=fp32-mfma"
 #endif
-#if ESMI_DEC_SPLIT == 2
-    return "dec_gemm=split-f16x2" ESMI_CFG_ENC_;
+#if ESMI_RANGE_CHECK
+#define ESMI_CFG_RC_ ",range_check=1"
 #else
-    return "dec_gemm=fp32-mfma" ESMI_CFG_ENC_;
+#define ESMI_CFG_RC_ ""
+#endif
+#if ESMI_DEC_SPLIT == 2
+    return "dec_gemm=split-f16x2" ESMI_CFG_ENC_ ESMI_CFG_RC_;
+#else
+    return "dec_gemm=fp32-mfma" ESMI_CFG_ENC_ ESMI_CFG_RC_;
 #endif
 }
 
@@ -710,7 +716,38 @@ size_t esmi_forward_arena_bytes(const esmi_forward_args* a) {
     return fwd_arena(a, &o) == ESMI_OK ? o.total : 0;
 }
 
+static int forward_impl(const esmi_forward_args* a, int stage, esmi_stream_t stream);
 int esmi_phoneme2mel_forward_f32(const esmi_forward_args* a, int stage, esmi_stream_t stream) {
+    if (!a) return ESMI_ERR_ARG;
+    if (!a->range_flag) return forward_impl(a, stage, stream);
+#if ESMI_RANGE_CHECK
+    // validation mode: clear the word, point every translation unit's kernels at it, run, wait, read it back
+    hipError_t e = hipMemsetAsync(a->range_flag, 0, sizeof(int32_t), S(stream));
+    if (e != hipSuccess) return (int)e;
+    int (*const setters[])(int*) = {set_range_flag_abi, set_range_flag_convgemm, set_range_flag_attention, set_range_flag_enc_merge,
+                                    set_range_flag_enc_block, set_range_flag_enc_attn_ffn, set_range_flag_enc_fuse_va,
+                                    set_range_flag_decoder, set_range_flag_dec_128_5, set_range_flag_dec_128_3, set_range_flag_dec_256_5,
+                                    set_range_flag_dec_256_3, set_range_flag_hifigan, set_range_flag_train};
+    for (auto set : setters)
+        if (int rc = set(reinterpret_cast<int*>(a->range_flag))) return rc;
+    int rc = forward_impl(a, stage, stream);
+    int32_t flag = 0;
+#ifdef ESMI_WAVESIM
+    flag = *a->range_flag;
+#else
+    if (!rc) {
+        e = hipStreamSynchronize(S(stream));
+        if (e == hipSuccess) e = hipMemcpy(&flag, a->range_flag, sizeof flag, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) rc = (int)e;
+    }
+#endif
+    for (auto set : setters) set(nullptr);
+    return rc ? rc : (flag ? ESMI_ERR_RANGE : ESMI_OK);
+#else
+    return ESMI_ERR_UNSUPPORTED;   // this library was built without the range check (libesmi_checked.so has it)
+#endif
+}
+static int forward_impl(const esmi_forward_args* a, int stage, esmi_stream_t stream) {
     FwdArena o;
     int rc = fwd_arena(a, &o);
     if (rc) return rc;

@@ -105,6 +105,30 @@ __device__ __forceinline__ f32x16 mfma32_split_wx(const u32x4& bh, const u32x4& 
 // for sequential fp32 accumulation).  Operands must be inside the binary16 range: |a| < 65504 and
 // |w| < 255 (2^8 scale keeps the second piece of weights down to 5e-4 a normal number; smaller ones lose nothing that
 // matters: absolute error < 2.4e-10 per weight).  Layout as for v_mfma_f32_32x32x16_bf16.
+// ---- activation-range check (the `libesmi_checked.so` build, -DESMI_RANGE_CHECK=1): the split-f16 contractions need their operands
+// inside the binary16 range (|a| < 65504; the first piece saturates there, so larger values are silently wrong, not inf).  Trained
+// networks are orders of magnitude inside it (LayerNorm / tanh / GELU outputs, O(1) embeddings), so the product kernels do not pay
+// for a test; the checked build ORs a device word whenever a value entering a split is out of range, and
+// esmi_phoneme2mel_forward_f32 turns that into ESMI_ERR_RANGE.  One flag pointer per translation unit (no relocatable device code).
+#ifndef ESMI_RANGE_CHECK
+#define ESMI_RANGE_CHECK 0
+#endif
+#if ESMI_RANGE_CHECK
+#ifdef ESMI_WAVESIM
+static int* g_esmi_range_flag = nullptr;
+#else
+static __device__ int* g_esmi_range_flag = nullptr;
+#endif
+__device__ __forceinline__ void range_note(float a) {
+    if (!(fabsf(a) < 65504.0f)) {       // also true for nan
+        int* f = g_esmi_range_flag;
+        if (f) *f = 1;                  // (a plain store of the same value from any number of lanes: no atomic needed)
+    }
+}
+#else
+__device__ __forceinline__ void range_note(float) {}
+#endif
+
 struct f16x2p { u32x4 h1, h2; };
 #ifndef ESMI_CHAIN_SPLIT
 #define ESMI_CHAIN_SPLIT 1   // weight GEMMs of the encoder-side chain kernels: 1 = split-f16x2 (3 f16 MFMAs per 16 channels), 0 = fp32 MFMA
@@ -136,6 +160,8 @@ __host__ __device__ inline float f16_bits_to_f32(unsigned h) {
     return __builtin_bit_cast(float, sign | ((e + 112u) << 23) | (m << 13));
 }
 __device__ __forceinline__ void split_f16_pair(float a, float b, unsigned& h1, unsigned& h2) {   // {b, a} pieces, a in the low half
+    range_note(a);
+    range_note(b);
 #ifdef ESMI_WAVESIM
     const unsigned ha = f32_to_f16_bits(a, true), hb = f32_to_f16_bits(b, true);
     const float ra = a - f16_bits_to_f32(ha), rb = b - f16_bits_to_f32(hb);
@@ -153,6 +179,8 @@ __device__ __forceinline__ void split_f16_pair(float a, float b, unsigned& h1, u
 // the same with both pieces rounded to nearest (what the weight packers do): one bit more than the truncating form, three
 // conversions instead of one packed one -- used where a value is split once and read many times (weight staging)
 __device__ __forceinline__ void split_f16_pair_rn(float a, float b, unsigned& h1, unsigned& h2) {
+    range_note(a);
+    range_note(b);
 #ifdef ESMI_WAVESIM
     const unsigned ha = f32_to_f16_bits(a, false), hb = f32_to_f16_bits(b, false);
     const float ra = a - f16_bits_to_f32(ha), rb = b - f16_bits_to_f32(hb);
@@ -186,6 +214,8 @@ __device__ __forceinline__ u32x4 round_f16x8(const f32x4& x0, const f32x4& x1) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const float a = j < 2 ? x0[2 * j] : x1[2 * j - 4], b = j < 2 ? x0[2 * j + 1] : x1[2 * j - 3];
+        range_note(a);
+        range_note(b);
 #ifdef ESMI_WAVESIM
         o[j] = f32_to_f16_bits(a, false) | (f32_to_f16_bits(b, false) << 16);
 #else

@@ -75,5 +75,31 @@ inline bool enc_attn_ffn_supported(int C, int N, int expansion) {
 }
 
 
+
+// ---- activation-range check (esmi_dev.h, the ESMI_RANGE_CHECK build): every translation unit owns a copy of the device-side flag
+// pointer and defines its setter with ESMI_TU_RANGE_SETTER(<unit>); `set_range_flag_all` (esmi_abi.hip) calls them all.
+int set_range_flag_abi(int* flag);
+int set_range_flag_convgemm(int* flag);
+int set_range_flag_attention(int* flag);
+int set_range_flag_enc_merge(int* flag);
+int set_range_flag_enc_block(int* flag);
+int set_range_flag_enc_attn_ffn(int* flag);
+int set_range_flag_enc_fuse_va(int* flag);
+int set_range_flag_decoder(int* flag);
+int set_range_flag_dec_128_5(int* flag);
+int set_range_flag_dec_128_3(int* flag);
+int set_range_flag_dec_256_5(int* flag);
+int set_range_flag_dec_256_3(int* flag);
+int set_range_flag_hifigan(int* flag);
+int set_range_flag_train(int* flag);
+#if ESMI_RANGE_CHECK && !defined(ESMI_WAVESIM)
+#define ESMI_TU_RANGE_SETTER(tu) namespace esmi { int set_range_flag_##tu(int* flag) { \
+    const hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(g_esmi_range_flag), &flag, sizeof(flag)); return e == hipSuccess ? ESMI_OK : (int)e; } }
+#elif ESMI_RANGE_CHECK
+#define ESMI_TU_RANGE_SETTER(tu) namespace esmi { int set_range_flag_##tu(int* flag) { g_esmi_range_flag = flag; return ESMI_OK; } }
+#else
+#define ESMI_TU_RANGE_SETTER(tu) namespace esmi { int set_range_flag_##tu(int*) { return ESMI_OK; } }
+#endif
+
 }  // namespace esmi
 #endif  // ESMI_LAUNCH_H

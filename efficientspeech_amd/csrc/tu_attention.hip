@@ -4,6 +4,7 @@
 #include "launch.h"
 
 using namespace esmi;
+ESMI_TU_RANGE_SETTER(attention)
 
 namespace esmi {
 

@@ -4,6 +4,7 @@
 #include "launch.h"
 
 using namespace esmi;
+ESMI_TU_RANGE_SETTER(convgemm)
 
 
 #ifndef ESMI_GEMM_LDS_MIN_ROWS   // rows (B * n_out) from which the per-op plan's GEMMs take the LDS-staged kernel

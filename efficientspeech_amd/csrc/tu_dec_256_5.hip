@@ -7,6 +7,8 @@
 #define ESMI_DEC_NW256 8    // waves per window of the dx2 = 256 decoder (small / base ES): 8, or 16 (measured 30 % slower: 65 spilled
 #endif                      // VGPRs at the 128-register budget and twice the weight traffic; small ES decoder 2.43 vs 1.87 ms)
 
+ESMI_TU_RANGE_SETTER(dec_256_5)
+
 namespace esmi {
 
 int launch_mel_decoder_256_5(const MelDecP& p, dim3 grid, hipStream_t st) {

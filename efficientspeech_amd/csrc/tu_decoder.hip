@@ -5,6 +5,7 @@
 #include "mel_decoder.h"
 
 using namespace esmi;
+ESMI_TU_RANGE_SETTER(decoder)
 
 namespace esmi {
 int launch_mel_decoder_128_5(const MelDecP& p, dim3 grid, hipStream_t st);

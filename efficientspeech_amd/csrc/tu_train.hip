@@ -5,6 +5,7 @@
 #include "train_ops.h"
 
 using namespace esmi;
+ESMI_TU_RANGE_SETTER(train)
 
 extern "C" {
 

@@ -9,7 +9,9 @@ are used purely as parameter containers; PyTorch supplies device memory and stre
 
 There is no CPU fallback: tensors must live on the MI355X and libesmi.so must be built.
 """
+import contextlib
 import ctypes as C
+import os
 
 import torch
 from torch import nn
@@ -754,6 +756,25 @@ class Phoneme2Mel(nn.Module):
         st = self._launch(x)
         return st.mel, st.mel_len, st.duration
 
+    def check_activation_range(self, x):
+        """Validation of a (new) checkpoint on a sample batch: run the inference forward on the range-checked build of the library
+        (`libesmi_checked.so`: every value entering a split-f16 contraction is tested against |a| < 65504) and raise
+        `_lib.ActivationRange` if one is outside -- the product build would saturate it silently.  Costs a device sync; not for
+        serving.  Returns the forward's (mel, mel_len, duration) when everything is in range."""
+        w = self.decoder.mel_linear.weight
+        checked = os.path.join(os.path.dirname(_lib.LIB_PATH), "libesmi_checked.so")
+        ctx = _lib.use_library(checked) if (w.is_cuda and os.path.exists(checked)) else contextlib.nullcontext()
+        if w.is_cuda and not os.path.exists(checked):
+            raise RuntimeError(f"{checked} not built (python -c 'import __graft_entry__ as g; g.build()')")
+        with ctx:
+            self._range_flag = torch.zeros(1, dtype=torch.int32, device=w.device)
+            try:
+                with torch.no_grad():
+                    st = self._launch(x)
+                return st.mel, st.mel_len, st.duration
+            finally:
+                self._range_flag = None
+
     # ------------------------------------------------------------------ one-call forward
     def _static_args(self, lib, stream):
         """The checkpoint-dependent part of esmi_forward_args (packed weights, shapes), rebuilt only when a packed cache was."""
@@ -820,6 +841,8 @@ class Phoneme2Mel(nn.Module):
             nbytes = lib.esmi_forward_arena_bytes(C.byref(a))
             st.arena = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         a.arena, a.arena_bytes = _ptr(st.arena), st.arena.numel()
+        rf = getattr(self, "_range_flag", None)                       # validation mode only (check_activation_range)
+        a.range_flag = _ptr(rf)
         dec = self.decoder
         timed = False
         if stage != 1 and dec.timing is not None:                     # bench.py: HIP events around the decoder launch only

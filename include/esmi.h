@@ -38,6 +38,7 @@ extern "C" {
 #define ESMI_ERR_ARG (-1)         /* null pointer / bad size */
 #define ESMI_ERR_UNSUPPORTED (-2) /* shape outside what the kernels are built for */
 #define ESMI_ERR_WORKSPACE (-3)   /* workspace too small */
+#define ESMI_ERR_RANGE (-4)       /* range-checked build only: an activation left the binary16 range of the split contractions */
 
 typedef void* esmi_stream_t; /* hipStream_t */
 
@@ -366,6 +367,11 @@ typedef struct esmi_forward_args {
     /* optional taps (NULL to skip): what PhonemeEncoder._encode exposes to tests / training-style callers */
     float* pitch_pred; float* energy_pred; int32_t* pitch_idx; int32_t* energy_idx; int32_t* dur; int32_t* cum;
     void* arena; size_t arena_bytes;
+    int32_t* range_flag;   /* NULL (normal operation), or a device word: ask for the activation-range check.  Only the checked build
+                            * (libesmi_checked.so, -DESMI_RANGE_CHECK=1) honours it: every value that enters a split-f16 contraction is
+                            * tested against the binary16 range (|a| < 65504), the call then WAITS for the stream and returns
+                            * ESMI_ERR_RANGE when one was outside -- a validation mode for new checkpoints, not for serving.  The
+                            * unchecked libraries return ESMI_ERR_UNSUPPORTED when the field is set */
 } esmi_forward_args;
 size_t esmi_forward_arena_bytes(const esmi_forward_args* a);
 /* stage = 0: everything; 1: encoder side only (up to cum / mel_len / lmax_dev / h0, kept in the arena); 2: mel decoder only,

@@ -302,3 +302,46 @@ def test_simulated_lds_staged_attention():
     with use_sim():
         net, cfg, sd = H.make_net("tiny", "cpu")
         H.check_attention_sizes(net, cfg, sd, "cpu", sizes=((1, 100), (1, 200)))
+
+
+def check_activation_range_guard(dev):
+    """ESMI_ERR_RANGE (include/esmi.h): on the range-checked build a value that enters a split-f16 contraction outside the binary16
+    range is reported by esmi_phoneme2mel_forward_f32 -- the product build would saturate it silently.  In-range checkpoints pass
+    (and give the product build's output); embedding rows x 1e5 push the first convolution's operands to ~4e5 and are refused."""
+    from efficientspeech_amd import _lib
+    net, cfg, sd = H.make_net("tiny", dev)
+    ids, mask = synth_phonemes(3, 24, 5, [24, 17, 9])
+    x = {"phoneme": torch.from_numpy(ids).to(dev), "phoneme_mask": torch.from_numpy(mask).to(dev)}
+    with torch.no_grad():
+        ref = net(x)[0]
+    mel, mel_len, _ = net.check_activation_range(x)
+    assert torch.equal(mel, ref)                                   # same kernels, same arithmetic: the check only observes
+    sd2 = {k: v.copy() for k, v in sd.items()}
+    sd2["encoder.encoder.embed.weight"] = sd2["encoder.encoder.embed.weight"] * np.float32(1e5)
+    bad = H.build_phoneme2mel(cfg)
+    H.load_numpy_state_dict(bad, sd2)
+    bad = bad.to(dev)
+    with pytest.raises(_lib.ActivationRange):
+        bad.check_activation_range(x)
+    net.check_activation_range(x)                                  # the flag pointer was cleared again: a good network still passes
+
+
+def test_simulated_activation_range_guard():
+    with use_sim():
+        check_activation_range_guard("cpu")
+
+
+@pytest.mark.gpu
+def test_gpu_activation_range_guard():
+    check_activation_range_guard("cuda")
+    # the product library refuses the request instead of ignoring it
+    from efficientspeech_amd import _lib
+    net, cfg, sd = H.make_net("tiny", "cuda")
+    ids, mask = synth_phonemes(2, 8, 5)
+    x = {"phoneme": torch.from_numpy(ids).cuda(), "phoneme_mask": torch.from_numpy(mask).cuda()}
+    net._range_flag = torch.zeros(1, dtype=torch.int32, device="cuda")
+    try:
+        with pytest.raises(_lib.Unsupported):
+            net(x)
+    finally:
+        net._range_flag = None

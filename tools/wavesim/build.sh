@@ -7,7 +7,7 @@ ROOT="$(cd "$HERE/../.." && pwd)"
 CXX=${CXX:-/opt/rocm/lib/llvm/bin/clang++}
 OBJ="$HERE/_build/obj"
 mkdir -p "$OBJ"
-FLAGS="-std=c++17 -O2 -g0 -DESMI_WAVESIM -I$HERE -I$ROOT/efficientspeech_amd/csrc -fPIC -Wno-unused-value -Wno-pass-failed"
+FLAGS="-std=c++17 -O2 -g0 -DESMI_WAVESIM -DESMI_RANGE_CHECK=1 -I$HERE -I$ROOT/efficientspeech_amd/csrc -fPIC -Wno-unused-value -Wno-pass-failed"
 pids=()
 for src in "$ROOT"/efficientspeech_amd/csrc/*.hip "$HERE/wavesim.cpp"; do
     "$CXX" -x c++ $FLAGS -c "$src" -o "$OBJ/$(basename "$src").o" &
