@@ -115,9 +115,6 @@ __device__ __forceinline__ f32x4 lrelu4(const f32x4& v, float slope) {   // 0 <=
 #ifndef ESMI_RB_PD
 #define ESMI_RB_PD 1    // weight fragments are fetched this many k-steps ahead
 #endif
-#ifndef ESMI_RB_XPF
-#define ESMI_RB_XPF 0   // 1: the next step's B fragments are read from LDS under this step's MFMAs (16 more VGPRs)
-#endif
 
 template <int C, int K>
 __global__ __launch_bounds__(64 * kRbWaves, ESMI_RB_WPS) void hifigan_resblock_kernel(const ResblockP p) {
@@ -206,11 +203,8 @@ __global__ __launch_bounds__(64 * kRbWaves, ESMI_RB_WPS) void hifigan_resblock_k
 #pragma unroll
             for (int s = 0; s < STEPS; ++s) {
                 const u32x4 wh = wq[s % PD][0], wl = wq[s % PD][1];
-                u32x4 nh = wh, nl = wl, n1[2] = {x1[0], x1[1]}, n2[2] = {x2[0], x2[1]};
+                u32x4 nh = wh, nl = wl;
                 wfetch(ci, s + PD, nh, nl);                        // in flight under PD steps of MFMAs (and the epilogue)
-#if ESMI_RB_XPF
-                if (s + 1 < STEPS) xfetch(s + 1, dil, n1, n2);     // next step's B fragments under this step's MFMAs
-#endif
                 sched_fence();
 #pragma unroll
                 for (int tt = 0; tt < 2; ++tt) {
@@ -220,12 +214,7 @@ __global__ __launch_bounds__(64 * kRbWaves, ESMI_RB_WPS) void hifigan_resblock_k
                 }
                 wq[s % PD][0] = nh;
                 wq[s % PD][1] = nl;
-#if ESMI_RB_XPF
-#pragma unroll
-                for (int tt = 0; tt < 2; ++tt) { x1[tt] = n1[tt]; x2[tt] = n2[tt]; }
-#else
                 if (s + 1 < STEPS) xfetch(s + 1, dil, x1, x2);
-#endif
             }
             // bias, residual, zero outside the sequence; the last conv's result goes straight out
             const float* bias = p.conv[ci].bias + 32 * mt + 4 * h;

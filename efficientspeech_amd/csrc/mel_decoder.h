@@ -60,15 +60,6 @@
 #ifndef ESMI_DEC_AD
 #define ESMI_DEC_AD 1       // A fragments in flight, in (step, row tile) items (LDS -> VGPR ring), ring form only
 #endif
-#ifndef ESMI_DEC_LN_SPREAD
-#define ESMI_DEC_LN_SPREAD 1
-#endif
-#ifndef ESMI_DEC_ST_NT
-#define ESMI_DEC_ST_NT 0   // 1: the mel rows leave with nontemporal stores (tried against the ~6 us bubble either side of the kernel: 0.283 vs 0.278 ms/step, no gain)
-#endif
-#ifndef ESMI_DEC_YOUNG_PRIO
-#define ESMI_DEC_YOUNG_PRIO 0   // static s_setprio for waves 4-7 (the arbitration losers of every phase on their SIMD)
-#endif
 #define ESMI_DEC_TANH tanh_fast_f32
 #define ESMI_DEC_RSQRT rsqrt_fast_f32   // v_rsq_f32 (1 ulp)
 
@@ -257,9 +248,6 @@ __global__ __launch_bounds__(64 * NW, (DX2 <= 128 ? ESMI_DEC_WPS : NW / 4)) void
         for (int e = tid; e < n; e += kDecThreads) o[e] = 0.0f;
         return;
     }
-#if ESMI_DEC_YOUNG_PRIO && !defined(ESMI_WAVESIM)
-    if (w >= 4) __builtin_amdgcn_s_setprio(ESMI_DEC_YOUNG_PRIO);
-#endif
     const int n_layers = p.n_blocks * p.block_depth;
     // every read of the packed blob is a buffer load: resource + wave-uniform byte offset in SGPRs, one lane-offset VGPR for all of
     // them (64-bit per-lane pointers into the blob, live across the layer loop, were most of the kernel's register spills)
@@ -340,12 +328,8 @@ __global__ __launch_bounds__(64 * NW, (DX2 <= 128 ? ESMI_DEC_WPS : NW / 4)) void
     // 16-byte access is 4*(row + c) mod 64, so rows that agree mod 16 make every ds_read_b128 / ds_write_b128 of the pass
     // conflict-free; in general rows 64(w / LNPER) + 16rg + RPT(w % LNPER) + j (with four CONSECUTIVE row quadruples per wave, lanes of neighbouring groups met in the same banks:
     // 17.8 % of the kernel's LDS cycles were bank conflicts, profiles/r01_l).
-#if ESMI_DEC_LN_SPREAD
     constexpr int LNPER = 16 / RPT;         // waves that share one residue class of rows mod 16
     const int ln_c = lane & (TPR - 1), ln_row0 = 64 * (w / LNPER) + 16 * (lane / TPR) + RPT * (w % LNPER);
-#else
-    const int ln_c = lane & (TPR - 1), ln_row0 = (64 / TPR) * RPT * w + RPT * (lane / TPR);
-#endif
     const bool edge_window = f0 < 0 || f0 + kDecRows > L;   // some window rows lie outside [0, L) (SGPR: a scalar branch)
     unsigned ln_inside = 0;                 // bit j: row ln_row0 + j exists in the reference (inside [0, L))
 #pragma unroll
@@ -520,20 +504,36 @@ __global__ __launch_bounds__(64 * NW, (DX2 <= 128 ? ESMI_DEC_WPS : NW / 4)) void
     // accumulators (+ bias, tanh) -> tile.  The products are computed TRANSPOSED (weights as the first MFMA operand): lane
     // (i, h) holds frame i of the tile and, per register quad g = r >> 2, the four consecutive channels 8g + 4h .. + 3 --
     // one ds_write_b128 per quad instead of four ds_write_b32 (and float4 global stores for the mel rows).
-    auto store_tanh = [&](const float* bias) __attribute__((always_inline)) {
+    // Two steps: `tanh_acc` turns the accumulators into tanh(acc + bias) IN PLACE -- it touches no tile row, so it runs right behind
+    // the K loop, before the barrier that waits for the last reader of the operand planes: a wave that is through its MFMAs spends the
+    // transcendental-heavy part of the epilogue while the other waves of its SIMD still feed the matrix pipe -- and `store_acc`
+    // writes them to the tile after that barrier.
+    auto tanh_acc = [&](const float* bias) __attribute__((always_inline)) {
 #pragma unroll
         for (int t = 0; t < NTW; ++t) {
-            const int col = ns * WCOLS + 32 * t + 4 * h;
-            const float* bp = bias + opaque_i(col);
-            float* base = xs + opaque_i((kDecPadRows + 32 * MT * mh + i) * LDSROW + col);
+            const float* bp = bias + opaque_i(ns * WCOLS + 32 * t + 4 * h);
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const f32x4 bc = *reinterpret_cast<const f32x4*>(bp + 8 * g) * kTanhExpScale;   // the exponent's 2 log2(e) goes into the bias and the scale of the fma
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[mt][t][4 * g + e] = tanh_fast_fma_f32(acc[mt][t][4 * g + e], WSI * kTanhExpScale, bc[e]);
+                }
+            }
+        }
+    };
+    auto store_acc = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) {
+            float* base = xs + opaque_i((kDecPadRows + 32 * MT * mh + i) * LDSROW + ns * WCOLS + 32 * t + 4 * h);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
                     f32x4 v;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = tanh_fast_fma_f32(acc[mt][t][4 * g + e], WSI * kTanhExpScale, bc[e]);
+                    for (int e = 0; e < 4; ++e) v[e] = acc[mt][t][4 * g + e];
                     *reinterpret_cast<f32x4*>(base + 32 * mt * LDSROW + 8 * g) = v;
                 }
             }
@@ -693,8 +693,9 @@ __global__ __launch_bounds__(64 * NW, (DX2 <= 128 ? ESMI_DEC_WPS : NW / 4)) void
                 mma_sub(0, k0);
             }
         }
+        tanh_acc(pbuf + P_PWB);
         __syncthreads();  // every wave finished reading the staged input
-        store_tanh(pbuf + P_PWB);
+        store_acc();
         __syncthreads();
         {   // LN(tanh(proj)); skip = the stage's output
             const float* pb = pbuf + opaque_i(4 * ln_c);
@@ -771,11 +772,12 @@ __global__ __launch_bounds__(64 * NW, (DX2 <= 128 ? ESMI_DEC_WPS : NW / 4)) void
         if (SPLIT) gemm_planes(lbase + p.lay.l_pw);
         else gemm_rows(lbase + p.lay.l_pw);
         ESMI_STAMP();   // 5: K loop issued
-        fetch_A(l + 1);      // next layer's taps: in flight during the tanh phase
+        // 3. bias + tanh on the accumulators (no tile access: ahead of the barrier), then -> tile
+        tanh_acc(pb + P_PWB);
+        fetch_A(l + 1);      // next layer's taps (their slots were last read by this layer's depthwise phase)
         __syncthreads();  // all reads of the filtered tile done
         ESMI_STAMP();   // 6: barrier
-        // 3. bias + tanh -> tile
-        store_tanh(pb + P_PWB);
+        store_acc();
         commit_A(l + 1);     // (the taps' LDS slots were last read by this layer's depthwise phase)
         ESMI_STAMP();   // 7: tanh stored
         __syncthreads();
@@ -823,11 +825,7 @@ __global__ __launch_bounds__(64 * NW, (DX2 <= 128 ? ESMI_DEC_WPS : NW / 4)) void
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = live ? fmaf(acc[mt][t][4 * g + e], WSI, bc[e]) : 0.0f;
                     if (vec_ok) {
-#if ESMI_DEC_ST_NT && !defined(ESMI_WAVESIM)
-                        __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(orow + col));
-#else
                         *reinterpret_cast<f32x4*>(orow + col) = v;
-#endif
                     } else {
 #pragma unroll
                         for (int e = 0; e < 4; ++e)

@@ -82,11 +82,7 @@ __device__ __forceinline__ void wave_fetch_b(WaveGrp<NT>& gq, const float* wl, i
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             const int ntc = nt0 + nt < ntw ? nt : ntw - 1 - nt0;   // wave-uniform clamp, no branch around the load
-#ifdef ESMI_ABL_NOB
-            gq.b[q][nt] = ld4(wl + ntc * 256);      // ablation probe: always the same 1 KiB
-#else
             gq.b[q][nt] = ld4(wg + (q * ntw + ntc) * 256);
-#endif
         }
     }
 }
@@ -95,11 +91,7 @@ template <int NT, bool MASKED>
 __device__ __forceinline__ void wave_fetch_a(WaveGrp<NT>& gq, const float* ar, bool ok, int g) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-#ifdef ESMI_ABL_NOA
-        gq.a[q] = ld4(ar);                           // ablation probe: always the same 16 bytes per lane
-#else
         gq.a[q] = ld4(ar + 32 * g + 8 * q);
-#endif
         if (MASKED && !ok) gq.a[q] = zero4();
     }
 }
