@@ -138,7 +138,9 @@ int esmi_train_conv_wgrad_f32(const esmi_conv_desc* d, const float* x, const flo
     const long ps = nw + c.c_out;
     if (mfma) {   // dense: one wave per (128 output channels x 32 input channels, tap, chunk) on the fp32 MFMA; bias partials from the tap 0, ci0 = 0 waves
         const unsigned tiles = (unsigned)(((c.c_out + 127) / 128) * ((c.c_in + 31) / 32) * c.k);
-        ESMI_LAUNCH(train_conv_wgrad_mfma_kernel, dim3(tiles, (unsigned)((chunks + 3) / 4)), dim3(256), 0, S(stream), c, x, dy, part,
+        static AttrOnce once;
+        if (int rc = raise_lds_limit(reinterpret_cast<const void*>(train_conv_wgrad_mfma_kernel), once)) return rc;
+        ESMI_LAUNCH(train_conv_wgrad_mfma_kernel, dim3(tiles, (unsigned)((chunks + 3) / 4)), dim3(256), kWgradLdsBytes, S(stream), c, x, dy, part,
                     dbias ? pb : nullptr, chunks, ps);
     } else if (depthwise) {
         ESMI_LAUNCH(train_conv_wgrad_dw_kernel, dim3(grid1d(c.c_out, 64), (unsigned)chunks), dim3(64), 0, S(stream), c, x, dy, part,
@@ -150,8 +152,9 @@ int esmi_train_conv_wgrad_f32(const esmi_conv_desc* d, const float* x, const flo
     }
     if (int rc = launch_status()) return rc;
     // weight and bias partials in ONE reduction launch: elements >= nw of a partial row are the bias sums
+    // (the matrix-pipe kernel already summed its four waves: one partial row per workgroup)
     ESMI_LAUNCH(train_reduce_chunks_kernel, grid1d(dbias ? ps : nw, 64), dim3(64 * kReduceGroups), 64 * kReduceGroups * sizeof(float), S(stream),
-                part, dbias ? ps : nw, ps, chunks, dw, nw, dbias);
+                part, dbias ? ps : nw, ps, mfma ? (chunks + 3) / 4 : chunks, dw, nw, dbias);
     return launch_status();
 }
 size_t esmi_train_conv_bwd_workspace_bytes(const esmi_conv_desc* d) {
@@ -181,11 +184,13 @@ int esmi_train_conv_bwd_f32(const esmi_conv_desc* d, const float* x, const float
     float* pb = part + nw;
     const long ps = nw + c.c_out;
     const unsigned tiles = (unsigned)(((c.c_out + 127) / 128) * ((c.c_in + 31) / 32) * c.k);
-    ESMI_LAUNCH(train_conv_wgrad_mfma_kernel, dim3(tiles, (unsigned)((chunks + 3) / 4)), dim3(256), 0, S(stream), c, x, dy, part,
+    static AttrOnce once;
+    if (int rc = raise_lds_limit(reinterpret_cast<const void*>(train_conv_wgrad_mfma_kernel), once)) return rc;
+    ESMI_LAUNCH(train_conv_wgrad_mfma_kernel, dim3(tiles, (unsigned)((chunks + 3) / 4)), dim3(256), kWgradLdsBytes, S(stream), c, x, dy, part,
                 dbias ? pb : nullptr, chunks, ps, amax);
     if (int rc = launch_status()) return rc;
     ESMI_LAUNCH(train_reduce_chunks_kernel, grid1d(dbias ? ps : nw, 64), dim3(64 * kReduceGroups), 64 * kReduceGroups * sizeof(float), S(stream),
-                part, dbias ? ps : nw, ps, chunks, dw, nw, dbias);
+                part, dbias ? ps : nw, ps, (chunks + 3) / 4, dw, nw, dbias);
     if (int rc = launch_status()) return rc;
     return train_conv_gemm(c, true, dy, w, nullptr, dx, wt, d->precision == 16, S(stream), true);
 }

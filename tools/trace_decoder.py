@@ -8,7 +8,8 @@ from efficientspeech_amd import CONFIGS, _lib, build_phoneme2mel, load_numpy_sta
 from efficientspeech_amd.synth import synth_state_dict
 lib = C.CDLL(os.path.abspath(sys.argv[1]))
 _lib._LIB = _lib.bind(lib)
-cfg = CONFIGS["tiny"]; B, T, D = 256, 128, 6; L = T * D
+cname = sys.argv[sys.argv.index("--config") + 1] if "--config" in sys.argv else "tiny"
+cfg = CONFIGS[cname]; B, T, D = (256, 128, 6) if cname == "tiny" else (256 if cname == "small" else 512, 256, 6); L = T * D
 net = build_phoneme2mel(cfg); load_numpy_state_dict(net, synth_state_dict(cfg)); net = net.cuda()
 feat = torch.randn((B, T, cfg.d4), device="cuda")
 cum = (torch.arange(1, T + 1, device="cuda", dtype=torch.int32) * D).repeat(B, 1).contiguous()
@@ -23,7 +24,7 @@ net.decoder._fused(feat, cum, mel_len, None, L, True, L, h0=h0)
 torch.cuda.synchronize()
 t = tr.cpu().numpy()
 names = ["dw window load", "barrier", "dw compute+write", "barrier", "K loop (MFMA)", "barrier", "bias+tanh store", "barrier", "LayerNorm", "barrier"]
-nl = cfg.n_blocks * cfg.block_depth
+nl = min(cfg.n_blocks * cfg.block_depth, 5)      # (64 stamp slots per wave = 5 layers of 11 stamps)
 for w in (0, 3, 7):
     print(f"wave {w}: total layer-loop cycles {t[w, 11 * nl - 1] - t[w, 0]}")
     for l in range(nl):
