@@ -166,7 +166,7 @@ __device__ __forceinline__ void convgemm_epilogue(f32x16 (&acc)[NT], const ConvG
     }
 }
 
-template <int NT>
+template <int NT, bool AMP = false>     // AMP: ConvGemmP::amp as a compile-time constant (a run-time branch in the K loop broke its software pipeline: base ES +35 %)
 __global__ __launch_bounds__(256) void convgemm_kernel(const ConvGemmP p) {
     const int lane = lane_id();
     // A strided ConvTranspose1d tile holds 32 positions of ONE phase (t mod stride): only the k/stride taps of that phase are
@@ -231,17 +231,17 @@ __global__ __launch_bounds__(256) void convgemm_kernel(const ConvGemmP p) {
         // out again): this plan takes the weights exactly as stored, there is no pre-split copy.  A lane's 8 k-slots of a step are
         // the channels 8kc + 4h + (0..3) and 8(kc+1) + 4h + (0..3) on BOTH sides, i.e. a fixed permutation of the 16 channels.
         auto step16 = [&](const f32x4& a0, const f32x4& a1, const f32x4 (&b0)[NT], const f32x4 (&b1)[NT]) __attribute__((always_inline)) {
-            if (p.amp) {   // wave-uniform: binary16 operands, one product
+            if constexpr (AMP) {   // binary16 operands, one product
                 const u32x4 ah = round_f16x8(a0, a1);
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) acc[nt] = mfma32_f16(ah, round_f16x8(b0[nt] * kF16WScale, b1[nt] * kF16WScale), acc[nt]);
-                return;
-            }
-            const f16x2p a2 = split_f16x2(a0, a1);
+            } else {
+                const f16x2p a2 = split_f16x2(a0, a1);
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                const f16x2p w2 = split_f16x2(b0[nt] * kF16WScale, b1[nt] * kF16WScale);
-                acc[nt] = mfma32_split2(a2, w2.h1, w2.h2, acc[nt]);
+                for (int nt = 0; nt < NT; ++nt) {
+                    const f16x2p w2 = split_f16x2(b0[nt] * kF16WScale, b1[nt] * kF16WScale);
+                    acc[nt] = mfma32_split2(a2, w2.h1, w2.h2, acc[nt]);
+                }
             }
         };
         for (; kc + KG <= kcs; kc += KG) {
@@ -351,7 +351,7 @@ __host__ __device__ constexpr int convgemm_lds_bytes() { return 2 * 2 * 32 * NT 
 #define ESMI_GEMM_LDS_WAVES 4   // waves (32 positions each) sharing one weight tile.  8 halves each wave's share of the staging work
                                 // but couples 8 waves to one barrier: measured 11.50 vs 10.45 ms/step on base ES (r02), so 4
 #endif
-template <int NT, int NWV = ESMI_GEMM_LDS_WAVES>
+template <int NT, int NWV = ESMI_GEMM_LDS_WAVES, bool AMP = false>
 __global__ __launch_bounds__(64 * NWV, 2) void convgemm_lds_kernel(const ConvGemmP p) {
     constexpr int BN = 32 * NT, PLANE = BN * kGemmRowDw, NTHR = 64 * NWV, NU = (256 * NT) / NTHR, ROWS = 32 * NWV;
     static_assert(NU * NTHR == 256 * NT, "staging items divide evenly");
@@ -404,7 +404,7 @@ __global__ __launch_bounds__(64 * NWV, 2) void convgemm_lds_kernel(const ConvGem
         }
 #pragma unroll
         for (int st = 0; st < 2; ++st) {
-            if (p.amp) a_cur[st].h1 = round_f16x8(a_nxt[st][0], a_nxt[st][1]);   // (nearest-rounded single piece; h2 unused)
+            if constexpr (AMP) a_cur[st].h1 = round_f16x8(a_nxt[st][0], a_nxt[st][1]);   // (nearest-rounded single piece; h2 unused)
             else a_cur[st] = split_f16x2(a_nxt[st][0], a_nxt[st][1]);
         }
     };
@@ -413,7 +413,9 @@ __global__ __launch_bounds__(64 * NWV, 2) void convgemm_lds_kernel(const ConvGem
     __syncthreads();
     for (int it = 0; it < n_it; ++it) {
         const bool more = it + 1 < n_it;
-        f16x2p a_use[2] = {a_cur[0], a_cur[1]};
+        f16x2p a_use[2];
+        a_use[0].h1 = a_cur[0].h1; a_use[1].h1 = a_cur[1].h1;
+        if constexpr (!AMP) { a_use[0].h2 = a_cur[0].h2; a_use[1].h2 = a_cur[1].h2; }
         if (more) fetch(it + 1);                   // in flight under this chunk's MFMAs
         sched_fence();
         const unsigned* bp = wt + ((it & 1) * 2) * PLANE + opaque_i(i * kGemmRowDw + 4 * h);
@@ -422,12 +424,12 @@ __global__ __launch_bounds__(64 * NWV, 2) void convgemm_lds_kernel(const ConvGem
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 const u32x4 b1 = *reinterpret_cast<const u32x4*>(bp + 32 * nt * kGemmRowDw + 8 * st);
-                if (p.amp) {   // the first plane of the staged weights IS round-to-nearest binary16 of 2^8 W
+                if constexpr (AMP) {   // the first plane of the staged weights IS round-to-nearest binary16 of 2^8 W
                     acc[nt] = mfma32_f16(a_use[st].h1, b1, acc[nt]);
-                    continue;
+                } else {
+                    const u32x4 b2 = *reinterpret_cast<const u32x4*>(bp + PLANE + 32 * nt * kGemmRowDw + 8 * st);
+                    acc[nt] = mfma32_split2(a_use[st], b1, b2, acc[nt]);
                 }
-                const u32x4 b2 = *reinterpret_cast<const u32x4*>(bp + PLANE + 32 * nt * kGemmRowDw + 8 * st);
-                acc[nt] = mfma32_split2(a_use[st], b1, b2, acc[nt]);
             }
         }
         if (more) stage((it + 1) & 1);             // the other buffer: last read one iteration ago, before the barrier below

@@ -53,12 +53,19 @@ int launch_convgemm(ConvGemmP p, hipStream_t st) {
         const int nl = full_row ? (nt <= 4 ? 4 : 8) : ((p.c_out & 255) == 0 ? 8 : 4);
         constexpr int kRows = 32 * ESMI_GEMM_LDS_WAVES;
         dim3 g2((unsigned)(p.B * ((p.n_out + kRows - 1) / kRows)), full_row ? 1 : (p.c_out + 32 * nl - 1) / (32 * nl));
-        if (nl == 4) {
-            ESMI_LAUNCH((convgemm_lds_kernel<4>), g2, dim3(64 * ESMI_GEMM_LDS_WAVES), convgemm_lds_bytes<4>(), st, p);
+        constexpr int NWV = ESMI_GEMM_LDS_WAVES;
+        if (nl == 4 && !p.amp) {
+            ESMI_LAUNCH((convgemm_lds_kernel<4, NWV, false>), g2, dim3(64 * NWV), convgemm_lds_bytes<4>(), st, p);
+        } else if (nl == 4) {
+            ESMI_LAUNCH((convgemm_lds_kernel<4, NWV, true>), g2, dim3(64 * NWV), convgemm_lds_bytes<4>(), st, p);
+        } else if (!p.amp) {
+            static AttrOnce once;
+            if (int rc = raise_lds_limit(reinterpret_cast<const void*>(convgemm_lds_kernel<8, NWV, false>), once)) return rc;
+            ESMI_LAUNCH((convgemm_lds_kernel<8, NWV, false>), g2, dim3(64 * NWV), convgemm_lds_bytes<8>(), st, p);
         } else {
             static AttrOnce once;
-            if (int rc = raise_lds_limit(reinterpret_cast<const void*>(convgemm_lds_kernel<8>), once)) return rc;
-            ESMI_LAUNCH((convgemm_lds_kernel<8>), g2, dim3(64 * ESMI_GEMM_LDS_WAVES), convgemm_lds_bytes<8>(), st, p);
+            if (int rc = raise_lds_limit(reinterpret_cast<const void*>(convgemm_lds_kernel<8, NWV, true>), once)) return rc;
+            ESMI_LAUNCH((convgemm_lds_kernel<8, NWV, true>), g2, dim3(64 * NWV), convgemm_lds_bytes<8>(), st, p);
         }
         return launch_status();
     }
@@ -66,12 +73,22 @@ int launch_convgemm(ConvGemmP p, hipStream_t st) {
     const int tiles = p.B * convgemm_tiles_per_phase(p) * convgemm_row_stride(p);
     dim3 grid((tiles + 3) / 4, full_row ? 1 : (p.c_out + 32 * nt - 1) / (32 * nt));
     dim3 block(256);
-    switch (nt) {
-        case 1: ESMI_LAUNCH((convgemm_kernel<1>), grid, block, 0, st, p); break;
-        case 2: ESMI_LAUNCH((convgemm_kernel<2>), grid, block, 0, st, p); break;
-        case 4: ESMI_LAUNCH((convgemm_kernel<4>), grid, block, 0, st, p); break;
-        case 8: ESMI_LAUNCH((convgemm_kernel<8>), grid, block, 0, st, p); break;
-        default: return ESMI_ERR_UNSUPPORTED;
+    if (!p.amp) {
+        switch (nt) {
+            case 1: ESMI_LAUNCH((convgemm_kernel<1, false>), grid, block, 0, st, p); break;
+            case 2: ESMI_LAUNCH((convgemm_kernel<2, false>), grid, block, 0, st, p); break;
+            case 4: ESMI_LAUNCH((convgemm_kernel<4, false>), grid, block, 0, st, p); break;
+            case 8: ESMI_LAUNCH((convgemm_kernel<8, false>), grid, block, 0, st, p); break;
+            default: return ESMI_ERR_UNSUPPORTED;
+        }
+    } else {
+        switch (nt) {
+            case 1: ESMI_LAUNCH((convgemm_kernel<1, true>), grid, block, 0, st, p); break;
+            case 2: ESMI_LAUNCH((convgemm_kernel<2, true>), grid, block, 0, st, p); break;
+            case 4: ESMI_LAUNCH((convgemm_kernel<4, true>), grid, block, 0, st, p); break;
+            case 8: ESMI_LAUNCH((convgemm_kernel<8, true>), grid, block, 0, st, p); break;
+            default: return ESMI_ERR_UNSUPPORTED;
+        }
     }
     return launch_status();
 }
