@@ -314,7 +314,8 @@ int esmi_variance_adaptor_f32(const esmi_predictor_weights* pitch, const esmi_pr
     v.pbins = pitch->bins; v.ebins = energy->bins; v.pemb = pitch->emb; v.eemb = energy->emb;
     v.feat = feat; v.pitch_idx = pitch_idx; v.energy_idx = energy_idx; v.dur = dur;
     if (!v.pbins || !v.ebins || !v.pemb || !v.eemb) return ESMI_ERR_ARG;
-    const long n = (long)B * T * dim;
+    if (dim & 3) return ESMI_ERR_UNSUPPORTED;                  // (dim = embed_dim // reduction: 32 / 64 / 128 for the published sizes)
+    const long n = (long)B * T * (dim >> 2);                   // one thread per four channels
     ESMI_LAUNCH(va_tail_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, v);
     return launch_status();
 }

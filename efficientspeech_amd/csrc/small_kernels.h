@@ -106,16 +106,18 @@ struct VaTailP {
 };
 
 // networks.py:349-384 minus the convolutions: one thread per (row, channel)
-static __global__ void va_tail_kernel(const VaTailP p) {
+static __global__ void va_tail_kernel(const VaTailP p) {   // one thread = (row, four consecutive channels); dim % 4 == 0
+    const int q4 = p.dim >> 2;
     const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= (long)p.rows * p.dim) return;
-    const int row = (int)(e / p.dim), c = (int)(e - (long)row * p.dim);
+    if (e >= (long)p.rows * q4) return;
+    const int row = (int)(e / q4), c = 4 * (int)(e - (long)row * q4);
     const bool pad = p.mask && p.mask[row];
     const int pi = bucketize_left(p.pitch_t ? p.pitch_t[row] : p.pitch_pred[row], p.pbins, p.dim - 1);
     const int ei = bucketize_left(p.energy_t ? p.energy_t[row] : p.energy_pred[row], p.ebins, p.dim - 1);
     float* fr = p.feat + (long)row * 4 * p.dim;
-    fr[p.dim + c] = pad ? 0.0f : p.pemb[pi * p.dim + c];
-    fr[2 * p.dim + c] = pad ? 0.0f : p.eemb[ei * p.dim + c];
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    *reinterpret_cast<f32x4*>(fr + p.dim + c) = pad ? z : *reinterpret_cast<const f32x4*>(p.pemb + (long)pi * p.dim + c);
+    *reinterpret_cast<f32x4*>(fr + 2 * p.dim + c) = pad ? z : *reinterpret_cast<const f32x4*>(p.eemb + (long)ei * p.dim + c);
     if (c == 0) {
         if (p.pitch_idx) p.pitch_idx[row] = pi;
         if (p.energy_idx) p.energy_idx[row] = ei;
