@@ -529,7 +529,9 @@ static __global__ __launch_bounds__(256) void train_attn_fwd_lds_kernel(const fl
         Vs[j * (C + 1) + c] = qkv[((long)b * N + j) * ld + (long)(2 * h + hd) * C + c];
     }
     __syncthreads();
-    for (int i = w; i < N; i += 4) {
+    // gridDim.y row segments per (utterance, head): B * h workgroups alone leave most of the chip idle at the reference's batch size
+    const int seg = (N + (int)gridDim.y - 1) / (int)gridDim.y, i_lo = (int)blockIdx.y * seg, i_hi = i_lo + seg < N ? i_lo + seg : N;
+    for (int i = i_lo + w; i < i_hi; i += 4) {
         const float* qi = qkv + ((long)b * N + i) * ld + (long)hd * C;
         float* p = P + (((long)b * h + hd) * N + i) * N;
         float mx = -3.0e38f;
@@ -571,7 +573,9 @@ static __global__ __launch_bounds__(256) void train_attn_bwd_rows_lds_kernel(con
         Vs[j * (C + 1) + c] = qkv[((long)b * N + j) * ld + (long)(2 * h + hd) * C + c];
     }
     __syncthreads();
-    for (int i = w; i < N; i += 4) {
+    // gridDim.y row segments per (utterance, head): B * h workgroups alone leave most of the chip idle at the reference's batch size
+    const int seg = (N + (int)gridDim.y - 1) / (int)gridDim.y, i_lo = (int)blockIdx.y * seg, i_hi = i_lo + seg < N ? i_lo + seg : N;
+    for (int i = i_lo + w; i < i_hi; i += 4) {
         const float* p = P + (((long)b * h + hd) * N + i) * N;
         float* ds = dS + (((long)b * h + hd) * N + i) * N;
         const float* go = dctx + ((long)b * N + i) * h * C + (long)hd * C;

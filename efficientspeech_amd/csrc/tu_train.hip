@@ -236,6 +236,15 @@ int esmi_train_act_bwd_f32(const float* saved, const float* dy, int64_t n, int k
     ESMI_LAUNCH(train_act_bwd_kernel, grid1d(n), dim3(256), 0, S(stream), saved, dy, (long)n, kind, dx);
     return launch_status();
 }
+namespace {
+// row segments per (utterance, head) of the LDS-staged attention kernels: enough workgroups for ~4 per CU, at least 4 rows per wave
+inline unsigned attn_row_segments(int heads_total, int N) {
+    int rs = (1024 + heads_total - 1) / heads_total;
+    const int max_rs = (N + 15) / 16;
+    if (rs > max_rs) rs = max_rs;
+    return (unsigned)(rs < 1 ? 1 : rs);
+}
+}  // namespace
 int esmi_train_attention_fwd_f32(const float* qkv, int B, int N, int C, int h, float* P, float* ctx, esmi_stream_t stream) {
     if (!qkv || !P || !ctx || B <= 0 || N <= 0 || C <= 0 || h <= 0 || C % h) return ESMI_ERR_ARG;
     const size_t lds = train_attn_lds_bytes(N, C);
@@ -243,7 +252,8 @@ int esmi_train_attention_fwd_f32(const float* qkv, int B, int N, int C, int h, f
         static AttrOnce once;
         if (lds > 48 * 1024)
             if (int rc = raise_lds_limit(reinterpret_cast<const void*>(train_attn_fwd_lds_kernel), once)) return rc;
-        ESMI_LAUNCH(train_attn_fwd_lds_kernel, dim3((unsigned)(B * h)), dim3(256), lds, S(stream), qkv, B, N, C, h, 1.0f / sqrtf((float)(C / h)), P, ctx);
+        ESMI_LAUNCH(train_attn_fwd_lds_kernel, dim3((unsigned)(B * h), attn_row_segments(B * h, N)), dim3(256), lds, S(stream), qkv, B, N, C, h,
+                    1.0f / sqrtf((float)(C / h)), P, ctx);
         return launch_status();
     }
     ESMI_LAUNCH(train_attn_fwd_kernel, dim3((unsigned)((long)B * h * N)), dim3(64), 0, S(stream), qkv, B, N, C, h, 1.0f / sqrtf((float)(C / h)), P, ctx);
@@ -258,7 +268,8 @@ int esmi_train_attention_bwd_f32(const float* qkv, const float* P, const float* 
         static AttrOnce once;
         if (lds > 48 * 1024)
             if (int rc = raise_lds_limit(reinterpret_cast<const void*>(train_attn_bwd_rows_lds_kernel), once)) return rc;
-        ESMI_LAUNCH(train_attn_bwd_rows_lds_kernel, dim3((unsigned)(B * h)), dim3(256), lds, S(stream), qkv, P, dctx, B, N, C, h, scale, dS, dqkv);
+        ESMI_LAUNCH(train_attn_bwd_rows_lds_kernel, dim3((unsigned)(B * h), attn_row_segments(B * h, N)), dim3(256), lds, S(stream), qkv, P, dctx,
+                    B, N, C, h, scale, dS, dqkv);
     } else {
         ESMI_LAUNCH(train_attn_bwd_rows_kernel, dim3((unsigned)((long)B * h * N)), dim3(64), 0, S(stream), qkv, P, dctx, B, N, C, h, scale, dS, dqkv);
     }
