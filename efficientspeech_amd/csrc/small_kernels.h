@@ -9,14 +9,15 @@ namespace esmi {
 // dst[j][o][i] = src[o][i][j]   (nn.Conv1d (Cout,Cin,k) -> tap-major)   when transposed == 0
 // dst[j][o][i] = src[i][o][j]   (nn.ConvTranspose1d (Cin,Cout,k))       when transposed == 1
 static __global__ void pack_conv_kernel(const float* __restrict__ src, float* __restrict__ dst, int cout, int cin, int k,
-                                 int transposed, int* __restrict__ zero_slot = nullptr) {
+                                 int transposed, int* __restrict__ zero_slot = nullptr, int flip = 0) {
     if (zero_slot && blockIdx.x == 0 && threadIdx.x == 0) zero_slot[0] = 0;   // (training: the absmax slot of the GEMM this pack precedes)
     const long n = (long)cout * cin * k;
     for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
         const int i = (int)(e % cin);
         const int o = (int)((e / cin) % cout);
         const int j = (int)(e / ((long)cin * cout));
-        dst[e] = transposed ? src[((long)i * cout + o) * k + j] : src[((long)o * cin + i) * k + j];
+        const int js = flip ? k - 1 - j : j;     // flip: taps reversed (a stride-1 transposed convolution AS a plain one, padding k - 1 - pad)
+        dst[e] = transposed ? src[((long)i * cout + o) * k + js] : src[((long)o * cin + i) * k + js];
     }
 }
 

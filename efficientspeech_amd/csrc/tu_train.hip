@@ -54,13 +54,17 @@ int train_conv_gemm(const ConvDesc& c, bool grad, const float* in, const float* 
     const long n = (long)c.k * c.c_out * c.c_in;
     // tap-major (k, cout, cin) of the problem: forward conv / grad of convT read the tensor as Conv1d, the other two as ConvTranspose1d
     const int as_convT = (grad != (c.transposed != 0)) ? 1 : 0;
+    // a stride-1 transposed convolution is a plain convolution with the taps reversed and padding k - 1 - pad: packed that way it
+    // takes the LDS-staged GEMM kernel (MODE_CONV only) like the forward problem does
+    const bool as_flipped_conv = as_convT && c.stride == 1 && c.k - 1 - c.pad >= 0;
     int* amax = reinterpret_cast<int*>(reinterpret_cast<char*>(wt) + align256((size_t)n * sizeof(float)));
     const float* wuse = wt;
     if (c.k == 1 && !as_convT && !grad) {
         wuse = w;                                   // a Linear's (Cout, Cin) IS its tap-major form: no copy
     } else {
         if (!have_absmax) {   // (with have_absmax the pack ran in the pack_only call that preceded the weight-gradient pass)
-            ESMI_LAUNCH(pack_conv_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, w, wt, cout, cin, c.k, as_convT, grad ? amax : nullptr);
+            ESMI_LAUNCH(pack_conv_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, w, wt, cout, cin, c.k, as_convT, grad ? amax : nullptr,
+                        as_flipped_conv ? 1 : 0);
             if (int rc = launch_status()) return rc;
         }
     }
@@ -74,8 +78,8 @@ int train_conv_gemm(const ConvDesc& c, bool grad, const float* in, const float* 
         if (int rc = launch_status()) return rc;
         p.io_scale = reinterpret_cast<const float*>(amax);
     }
-    p.mode = as_convT ? MODE_CONVT : MODE_CONV;
-    p.k = c.k; p.stride = c.stride; p.pad = c.pad;
+    p.mode = (as_convT && !as_flipped_conv) ? MODE_CONVT : MODE_CONV;
+    p.k = c.k; p.stride = c.stride; p.pad = as_flipped_conv ? c.k - 1 - c.pad : c.pad;
     p.B = c.B; p.n_in = grad ? c.n_out : c.n_in; p.n_out = grad ? c.n_in : c.n_out; p.c_in = cin; p.c_out = cout;
     p.A = in; p.lda = cin; p.W = wuse; p.bias = bias; p.out = out; p.ldo = cout;
     p.amp = amp ? 1 : 0;
