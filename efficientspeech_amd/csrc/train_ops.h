@@ -192,6 +192,48 @@ static __global__ __launch_bounds__(256) void train_conv_wgrad_mfma_kernel(const
     f32x16 acc[4] = {zero16(), zero16(), zero16(), zero16()};
     f32x4 bsum = zero4();
     float amax_f = 0.0f;
+#if ESMI_CHAIN_SPLIT
+    // fp32-accurate split products on the bf16 matrix pipe (esmi_dev.h split_bf16x3: three 8-bit pieces per value = all 24 significand
+    // bits, six products, bf16's exponent range -- gradients as small as 1e-30 lose nothing, which binary16 pieces would need a scale
+    // for): the contraction runs over the ROWS, so a lane's eight k-slots of a 16-row step are eight consecutive rows -- lane (i, kh)
+    // loads dY channels 4i .. 4i+3 and X channel ci0 + i of rows r + 8 kh + (0..7); each of the four dY channels is the A operand of
+    // one of four MFMA tiles (channel sets {4m + t}).  24 v_mfma_f32_32x32x16_bf16 (768 cycles) per 16 rows instead of 32
+    // v_mfma_f32_32x32x2_f32 (2048 cycles).
+    for (long r = r0; r < r1; r += 16) {                // (chunk >= chunks: no trip)
+        f32x4 a[8];
+        float bv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const long rr = r + 8 * kh + u;
+            a[u] = zero4();
+            bv[u] = 0.0f;
+            if (rr < r1) {
+                const int b = (int)(rr / d.n_out), t = (int)(rr - (long)b * d.n_out);
+                const int ti = conv_in_pos(d, t, j);
+                const float* dr = dy + rr * d.c_out + co4;
+                if (vec_ok) a[u] = ld4(dr);
+                else
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) if (co4 + e < d.c_out) a[u][e] = dr[e];
+                if (ci_ok && ti >= 0) bv[u] = x[((long)b * d.n_in + ti) * d.c_in + ci0 + i];
+            }
+        }
+        sched_fence();
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) amax_f = fmaxf(amax_f, fabsf(a[u][e]));    // (NaN-transparent enough: a NaN gradient shows up as NaN weights anyway)
+            bsum = bsum + a[u];
+        }
+        const f32x4 b0 = {bv[0], bv[1], bv[2], bv[3]}, b1 = {bv[4], bv[5], bv[6], bv[7]};
+        const bf16x3 b3 = split_bf16x3(b0, b1);
+#pragma unroll
+        for (int t4 = 0; t4 < 4; ++t4) {
+            const f32x4 a0 = {a[0][t4], a[1][t4], a[2][t4], a[3][t4]}, a1 = {a[4][t4], a[5][t4], a[6][t4], a[7][t4]};
+            acc[t4] = mfma32_split(split_bf16x3(a0, a1), b3.hi, b3.mid, b3.lo, acc[t4]);
+        }
+    }
+#else
     for (long r = r0; r < r1; r += 8) {                 // 8 rows per trip: all eight loads in flight before the 16 MFMAs  (chunk >= chunks: no trip)
         f32x4 a[4];
         float bv[4];
@@ -221,6 +263,7 @@ static __global__ __launch_bounds__(256) void train_conv_wgrad_mfma_kernel(const
             for (int t4 = 0; t4 < 4; ++t4) acc[t4] = mfma32(a[u][t4], bv[u], acc[t4]);
         }
     }
+#endif
     if (dy_absmax && j == 0 && ci0 == 0) {
         int m = __builtin_bit_cast(int, amax_f) & 0x7FFFFFFF;
 #pragma unroll
