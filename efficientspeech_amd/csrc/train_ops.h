@@ -110,7 +110,7 @@ static __global__ void train_conv_dgrad_kernel(const ConvDesc d, const float* __
 constexpr int kTrainChunk = 256;
 constexpr int kTrainChunkDw = 32;      // rows per thread of the depthwise weight gradient (few channels: parallelism from the chunks)
 #ifndef ESMI_TRAIN_CHUNK_MFMA
-#define ESMI_TRAIN_CHUNK_MFMA 128   // rows per wave of the MFMA weight gradient: 64 / 128 / 256 / 512 measured 8.4 / 8.4 / 9.2 / 10.8 ms per B = 128 step
+#define ESMI_TRAIN_CHUNK_MFMA 96    // rows per wave of the MFMA weight gradient (a multiple of 16).  Round 3 (four waves summed in LDS, split-bf16 products): 48 / 80 / 96 / 128 / 160 / 192 rows -> 5.2-5.3 / 5.3 / 5.3-5.4 / 5.5 / 5.5 / 5.7 ms per B = 128 step (+-0.3 ms run to run)
 #endif
 constexpr int kTrainChunkMfma = ESMI_TRAIN_CHUNK_MFMA;    // rows per wave of the matrix-pipe weight gradient (1024 measured slower: too few waves)
 __host__ __device__ inline long train_chunks(long rows, int chunk = kTrainChunk) { return (rows + chunk - 1) / chunk; }
