@@ -503,7 +503,9 @@ def main():
         tb, tt = 128, 100
         tnet = make_net(cfg, sd, dev).train()
         tx, ty = _train.synthetic_batch(tb, tt, a.dur, dev, seed=77 + rank)
-        ts = _train.TrainStep(tnet, world_size=world)
+        # hipGraph replay of the step (N = 1: the whole step; N > 1: forward + loss + backward, then the all-reduce and the optimizer
+        # launch eagerly): ~330 launches per step make the eager step host-bound
+        ts = _train.TrainStep(tnet, world_size=world, graph=True)
         for _ in range(3):
             tl0 = ts.step(tx, ty)
         sync_all()
@@ -520,9 +522,19 @@ def main():
         # forward, twice backward (data gradient + weight gradient of every contraction); the decoder runs at frame rate in train mode
         enc_flops = {"tiny": 262_336, "small": 737_664, "base": 4_489_984}[a.config]
         step_flops = 3.0 * tb * tt * (a.dur * DECODER_WORK[a.config][0] + enc_flops)
-        t16 = None
+        t16 = t_eager = None
         if world == 1:
-            ts16 = _train.TrainStep(make_net(cfg, sd, dev).train(), precision=16, init_scale=2048.0)
+            tse = _train.TrainStep(make_net(cfg, sd, dev).train())
+            for _ in range(3):
+                tse.step(tx, ty)
+            sync_all()
+            t0 = time.perf_counter()
+            for _ in range(n_tr):
+                tse.step(tx, ty)
+            sync_all()
+            t_eager = (time.perf_counter() - t0) / n_tr
+            del tse
+            ts16 = _train.TrainStep(make_net(cfg, sd, dev).train(), precision=16, init_scale=2048.0, graph=True)
             for _ in range(3):
                 ts16.step(tx, ty)
             sync_all()
@@ -535,6 +547,8 @@ def main():
         out["train_step"] = {"ms_per_step": ttr * 1e3, "mel_frames_per_s": tb * tt * a.dur * world / ttr, "steps": n_tr,
                              "per_gpu_batch": tb, "phonemes": tt, "frames_per_utterance": tt * a.dur,
                              "precision16_ms_per_step": None if t16 is None else t16 * 1e3,
+                             "eager_ms_per_step": None if t_eager is None else t_eager * 1e3,
+                             "launch": "hipGraph replay per batch shape" + ("" if world == 1 else " of forward + loss + backward; all-reduce and optimizer eager"),
                              "roofline": {"bound": "mfma", "algorithmic_flops_per_step": step_flops,
                                           "achieved": step_flops / ttr / 1e12, "peak": F16_PEAK_TFLOPS / 3.0, "unit": "TFLOP/s",
                                           "frac": step_flops / ttr / 1e12 / (F16_PEAK_TFLOPS / 3.0),

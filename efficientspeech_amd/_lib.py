@@ -81,6 +81,15 @@ class ConvDesc(C.Structure):
     _fields_ = [(n, C.c_int) for n in ("B", "n_in", "c_in", "n_out", "c_out", "k", "stride", "pad", "groups", "transposed", "precision")]
 
 
+class ReduceItem(C.Structure):
+    _fields_ = [("partial", fp), ("n", C.c_int64), ("stride", C.c_int64), ("chunks", C.c_int64), ("out", fp), ("n0", C.c_int64), ("out1", fp)]
+
+
+class ReduceQueue(C.Structure):
+    """esmi_reduce_queue (include/esmi.h): the queued second stages of a training step's chunked reductions."""
+    _fields_ = [("count", C.c_int32), ("items", ReduceItem * 48)]
+
+
 class TrainLossArgs(C.Structure):
     """esmi_train_loss_args (include/esmi.h): model.py:167-216."""
     _fields_ = [(n, fp) for n in ("mel_pred", "mel", "pitch_pred", "pitch", "energy_pred", "energy", "dur_pred", "dur", "mel_mask",
@@ -142,7 +151,7 @@ EXPORTS = (
     "esmi_train_attention_bwd_f32", "esmi_train_embedding_fwd_f32", "esmi_train_embedding_bwd_f32", "esmi_train_mask_rows_f32",
     "esmi_train_add_f32", "esmi_train_copy_cols_f32", "esmi_train_repeat_fwd_f32", "esmi_train_repeat_bwd_f32",
     "esmi_train_loss_f32", "esmi_train_adamw_f32", "esmi_train_adamw_graph_f32", "esmi_train_conv_bwd_workspace_bytes",
-    "esmi_train_conv_bwd_f32",
+    "esmi_train_conv_bwd_f32", "esmi_train_reduce_flush_f32",
 )
 
 
@@ -205,17 +214,18 @@ def bind(lib):
     lib.esmi_train_conv_wgrad_workspace_bytes.restype = sz
     lib.esmi_train_conv_bwd_workspace_bytes.argtypes = [P(ConvDesc)]
     lib.esmi_train_conv_bwd_workspace_bytes.restype = sz
-    lib.esmi_train_conv_bwd_f32.argtypes = [P(ConvDesc), fp, fp, fp, fp, fp, fp, fp, sz, fp]
+    lib.esmi_train_conv_bwd_f32.argtypes = [P(ConvDesc), fp, fp, fp, fp, fp, fp, fp, sz, P(ReduceQueue), fp]
+    lib.esmi_train_reduce_flush_f32.argtypes = [P(ReduceQueue), fp]
     lib.esmi_train_layernorm_bwd_workspace_bytes.argtypes = [i64, i]
     lib.esmi_train_layernorm_bwd_workspace_bytes.restype = sz
     lib.esmi_train_layernorm_fwd_f32.argtypes = [fp, fp, fp, i64, i, fp, fp, fp, fp]
-    lib.esmi_train_layernorm_bwd_f32.argtypes = [fp, fp, fp, fp, fp, i64, i, fp, fp, fp, fp, sz, fp]
+    lib.esmi_train_layernorm_bwd_f32.argtypes = [fp, fp, fp, fp, fp, i64, i, fp, fp, fp, fp, sz, P(ReduceQueue), fp]
     lib.esmi_train_act_fwd_f32.argtypes = [fp, i64, i, fp, fp]
     lib.esmi_train_act_bwd_f32.argtypes = [fp, fp, i64, i, fp, fp]
     lib.esmi_train_attention_fwd_f32.argtypes = [fp, i, i, i, i, fp, fp, fp]
     lib.esmi_train_attention_bwd_f32.argtypes = [fp, fp, fp, i, i, i, i, fp, fp, fp]
     lib.esmi_train_embedding_fwd_f32.argtypes = [fp, fp, i64, i, i, fp, fp]
-    lib.esmi_train_embedding_bwd_f32.argtypes = [fp, fp, i64, i, i, i, fp, fp, sz, fp]
+    lib.esmi_train_embedding_bwd_f32.argtypes = [fp, fp, i64, i, i, i, fp, fp, sz, P(ReduceQueue), fp]
     lib.esmi_train_embedding_bwd_workspace_bytes.argtypes = [i64, i, i]
     lib.esmi_train_embedding_bwd_workspace_bytes.restype = sz
     lib.esmi_train_mask_rows_f32.argtypes = [fp, fp, i64, i, fp, fp]

@@ -339,6 +339,29 @@ static __global__ __launch_bounds__(64 * kReduceGroups) void train_reduce_chunks
         else out[q] = t;
     }
 }
+// the same for a batch of independent reductions in one launch (blockIdx.y = item): the queued second stages of a training step
+struct ReduceItem { const float* partial; long n, stride, chunks; float* out; long n0; float* out1; };
+constexpr int kReduceBatch = 48;
+struct ReduceBatch { int count; ReduceItem items[kReduceBatch]; };
+static __global__ __launch_bounds__(64 * kReduceGroups) void train_reduce_batch_kernel(const ReduceBatch b) {
+    ESMI_DYN_LDS(red);   // 64 * kReduceGroups floats
+    const ReduceItem& it = b.items[blockIdx.y];
+    const int ex = (int)(threadIdx.x & 63), cy = (int)(threadIdx.x >> 6);
+    const long q = (long)blockIdx.x * 64 + ex;
+    if ((long)blockIdx.x * 64 >= it.n) return;            // (workgroup-uniform: the grid is sized for the largest item)
+    float acc = 0.0f;
+    if (q < it.n)
+        for (long c = cy; c < it.chunks; c += kReduceGroups) acc += it.partial[c * it.stride + q];
+    red[cy * 64 + ex] = acc;
+    __syncthreads();
+    if (cy == 0 && q < it.n) {
+        float t = red[ex];
+#pragma unroll
+        for (int u = 1; u < kReduceGroups; ++u) t += red[u * 64 + ex];
+        if (it.out1 && q >= it.n0) it.out1[q - it.n0] = t;
+        else it.out[q] = t;
+    }
+}
 // partial[chunk][c] = sum over the chunk's rows of v[row, c]   (bias gradients)
 static __global__ void train_colsum_kernel(const float* __restrict__ v, long rows, int C, float* __restrict__ partial, long pstride, int chunk) {
     const int c = (int)(blockIdx.x * blockDim.x + threadIdx.x);

@@ -23,6 +23,33 @@ int conv_desc_ok(const esmi_conv_desc* d, ConvDesc* o) {
 }  // namespace
 
 namespace {
+int reduce_flush(esmi_reduce_queue* q, hipStream_t st) {
+    if (!q || q->count <= 0) return ESMI_OK;
+    if (q->count > ESMI_REDUCE_QUEUE_ITEMS) return ESMI_ERR_ARG;
+    ReduceBatch b;
+    b.count = q->count;
+    long nmax = 0;
+    for (int i = 0; i < q->count; ++i) {
+        const esmi_reduce_item& s = q->items[i];
+        b.items[i] = ReduceItem{s.partial, (long)s.n, (long)s.stride, (long)s.chunks, s.out, (long)s.n0, s.out1};
+        nmax = s.n > nmax ? (long)s.n : nmax;
+    }
+    ESMI_LAUNCH(train_reduce_batch_kernel, dim3(grid1d(nmax, 64), (unsigned)q->count), dim3(64 * kReduceGroups), 64 * kReduceGroups * sizeof(float), st, b);
+    q->count = 0;
+    return launch_status();
+}
+// second stage of a chunked reduction: now (one launch), or queued for the step's single flush
+int reduce_or_defer(esmi_reduce_queue* q, const float* part, long n, long stride, long chunks, float* out, long n0, float* out1, hipStream_t st) {
+    if (!q) {
+        ESMI_LAUNCH(train_reduce_chunks_kernel, grid1d(n, 64), dim3(64 * kReduceGroups), 64 * kReduceGroups * sizeof(float), st, part, n, stride, chunks,
+                    out, n0, out1);
+        return launch_status();
+    }
+    if (q->count >= ESMI_REDUCE_QUEUE_ITEMS)
+        if (int rc = reduce_flush(q, st)) return rc;
+    q->items[q->count++] = esmi_reduce_item{part, n, stride, chunks, out, n0, out1};
+    return ESMI_OK;
+}
 inline bool wgrad_depthwise(const ConvDesc& c) { return !c.transposed && c.groups == c.c_in && c.c_in == c.c_out && c.k <= 8; }
 inline bool wgrad_on_mfma(const ConvDesc& c);
 inline int wgrad_chunk(const ConvDesc& c) {   // rows per partial sum: fewer for small weights, whose parallelism must come from the chunks
@@ -128,8 +155,8 @@ size_t esmi_train_conv_wgrad_workspace_bytes(const esmi_conv_desc* d) {
     const long chunks = train_chunks((long)c.B * c.n_out, wgrad_chunk(c));
     return (size_t)chunks * (size_t)(nw + c.c_out) * sizeof(float);
 }
-int esmi_train_conv_wgrad_f32(const esmi_conv_desc* d, const float* x, const float* dy, float* dw, float* dbias, void* workspace,
-                              size_t workspace_bytes, esmi_stream_t stream) {
+static int conv_wgrad_impl(const esmi_conv_desc* d, const float* x, const float* dy, float* dw, float* dbias, void* workspace,
+                           size_t workspace_bytes, esmi_reduce_queue* defer, esmi_stream_t stream) {
     ConvDesc c;
     if (int rc = conv_desc_ok(d, &c)) return rc;
     if (!x || !dy || !dw || !workspace) return ESMI_ERR_ARG;
@@ -155,17 +182,23 @@ int esmi_train_conv_wgrad_f32(const esmi_conv_desc* d, const float* x, const flo
         if (dbias) ESMI_LAUNCH(train_colsum_kernel, dim3(grid1d(c.c_out, 64), (unsigned)chunks), dim3(64), 0, S(stream), dy, rows, c.c_out, pb, ps, wgrad_chunk(c));
     }
     if (int rc = launch_status()) return rc;
-    // weight and bias partials in ONE reduction launch: elements >= nw of a partial row are the bias sums
+    // weight and bias partials in ONE reduction: elements >= nw of a partial row are the bias sums
     // (the matrix-pipe kernel already summed its four waves: one partial row per workgroup)
-    ESMI_LAUNCH(train_reduce_chunks_kernel, grid1d(dbias ? ps : nw, 64), dim3(64 * kReduceGroups), 64 * kReduceGroups * sizeof(float), S(stream),
-                part, dbias ? ps : nw, ps, mfma ? (chunks + 3) / 4 : chunks, dw, nw, dbias);
-    return launch_status();
+    return reduce_or_defer(defer, part, dbias ? ps : nw, ps, mfma ? (chunks + 3) / 4 : chunks, dw, nw, dbias, S(stream));
+}
+int esmi_train_conv_wgrad_f32(const esmi_conv_desc* d, const float* x, const float* dy, float* dw, float* dbias, void* workspace,
+                              size_t workspace_bytes, esmi_stream_t stream) {
+    return conv_wgrad_impl(d, x, dy, dw, dbias, workspace, workspace_bytes, nullptr, stream);
+}
+int esmi_train_reduce_flush_f32(esmi_reduce_queue* q, esmi_stream_t stream) {
+    if (!q) return ESMI_ERR_ARG;
+    return reduce_flush(q, S(stream));
 }
 size_t esmi_train_conv_bwd_workspace_bytes(const esmi_conv_desc* d) {
     return align256(esmi_train_conv_wgrad_workspace_bytes(d)) + esmi_train_conv_workspace_bytes(d);
 }
 int esmi_train_conv_bwd_f32(const esmi_conv_desc* d, const float* x, const float* dy, const float* w, float* dx, float* dw, float* dbias,
-                            void* workspace, size_t workspace_bytes, esmi_stream_t stream) {
+                            void* workspace, size_t workspace_bytes, esmi_reduce_queue* defer, esmi_stream_t stream) {
     ConvDesc c;
     if (int rc = conv_desc_ok(d, &c)) return rc;
     if (!x || !dy || !w || !dx || !dw || !workspace) return ESMI_ERR_ARG;
@@ -179,7 +212,7 @@ int esmi_train_conv_bwd_f32(const esmi_conv_desc* d, const float* x, const float
                        train_conv_gemm(c, true, dy, w, nullptr, dx, wt, d->precision == 16, S(stream), false, true) == ESMI_OK;
     if (!fused) {
         if (int rc = esmi_train_conv_dgrad_f32(d, dy, w, dx, gemm_bytes ? wt : nullptr, gemm_bytes, stream)) return rc;
-        return esmi_train_conv_wgrad_f32(d, x, dy, dw, dbias, workspace, wg_bytes, stream);
+        return conv_wgrad_impl(d, x, dy, dw, dbias, workspace, wg_bytes, defer, stream);
     }
     const long nw = (long)(c.transposed ? c.c_in * c.c_out : c.c_out * (c.c_in / c.groups)) * c.k;
     int* amax = reinterpret_cast<int*>(reinterpret_cast<char*>(wt) + align256((size_t)nw * sizeof(float)));
@@ -193,9 +226,7 @@ int esmi_train_conv_bwd_f32(const esmi_conv_desc* d, const float* x, const float
     ESMI_LAUNCH(train_conv_wgrad_mfma_kernel, dim3(tiles, (unsigned)((chunks + 3) / 4)), dim3(256), kWgradLdsBytes, S(stream), c, x, dy, part,
                 dbias ? pb : nullptr, chunks, ps, amax);
     if (int rc = launch_status()) return rc;
-    ESMI_LAUNCH(train_reduce_chunks_kernel, grid1d(dbias ? ps : nw, 64), dim3(64 * kReduceGroups), 64 * kReduceGroups * sizeof(float), S(stream),
-                part, dbias ? ps : nw, ps, (chunks + 3) / 4, dw, nw, dbias);
-    if (int rc = launch_status()) return rc;
+    if (int rc = reduce_or_defer(defer, part, dbias ? ps : nw, ps, (chunks + 3) / 4, dw, nw, dbias, S(stream))) return rc;
     return train_conv_gemm(c, true, dy, w, nullptr, dx, wt, d->precision == 16, S(stream), true);
 }
 int esmi_train_layernorm_fwd_f32(const float* x, const float* g, const float* b, int64_t rows, int C, float* y, float* mean,
@@ -210,7 +241,7 @@ size_t esmi_train_layernorm_bwd_workspace_bytes(int64_t rows, int C) {
 }
 int esmi_train_layernorm_bwd_f32(const float* x, const float* g, const float* mean, const float* rstd, const float* dy,
                                  int64_t rows, int C, float* dx, float* dg, float* db, void* workspace, size_t workspace_bytes,
-                                 esmi_stream_t stream) {
+                                 esmi_reduce_queue* defer, esmi_stream_t stream) {
     if (!x || !g || !mean || !rstd || !dy || !dx || !dg || !db || !workspace || rows <= 0 || C <= 0) return ESMI_ERR_ARG;
     if (workspace_bytes < esmi_train_layernorm_bwd_workspace_bytes(rows, C)) return ESMI_ERR_WORKSPACE;
     float* part = static_cast<float*>(workspace);
@@ -226,9 +257,7 @@ int esmi_train_layernorm_bwd_f32(const float* x, const float* g, const float* me
         ESMI_LAUNCH(train_ln_bwd_params_kernel, dim3(grid1d(C, 64), (unsigned)chunks), dim3(64), 0, S(stream), x, mean, rstd, dy, (long)rows, C, part);
         if (int rc = launch_status()) return rc;
     }
-    ESMI_LAUNCH(train_reduce_chunks_kernel, grid1d(2L * C, 64), dim3(64 * kReduceGroups), 64 * kReduceGroups * sizeof(float), S(stream), part,
-                2L * C, 2L * C, chunks, dg, (long)C, db);   // partial rows are [dg (C) | db (C)]: one launch, two outputs
-    return launch_status();
+    return reduce_or_defer(defer, part, 2L * C, 2L * C, chunks, dg, (long)C, db, S(stream));   // partial rows are [dg (C) | db (C)]: two outputs
 }
 int esmi_train_act_fwd_f32(const float* x, int64_t n, int kind, float* y, esmi_stream_t stream) {
     if (!x || !y || n <= 0 || kind < ACT_RELU || kind > ACT_TANH) return ESMI_ERR_ARG;
@@ -290,15 +319,14 @@ size_t esmi_train_embedding_bwd_workspace_bytes(int64_t rows, int V, int C) {
     return rows > 0 && V > 0 && C > 0 ? (size_t)train_chunks(rows) * V * C * sizeof(float) : 0;
 }
 int esmi_train_embedding_bwd_f32(const int32_t* ids, const float* dy, int64_t rows, int V, int C, int padding_idx, float* dtable,
-                                 void* workspace, size_t workspace_bytes, esmi_stream_t stream) {
+                                 void* workspace, size_t workspace_bytes, esmi_reduce_queue* defer, esmi_stream_t stream) {
     if (!ids || !dy || !dtable || !workspace || rows <= 0 || V <= 0 || C <= 0) return ESMI_ERR_ARG;
     if (workspace_bytes < esmi_train_embedding_bwd_workspace_bytes(rows, V, C)) return ESMI_ERR_WORKSPACE;
     const long chunks = train_chunks(rows), n = (long)V * C;
     float* part = static_cast<float*>(workspace);
     ESMI_LAUNCH(train_embed_bwd_kernel, dim3(grid1d(n, 64), (unsigned)chunks), dim3(64), 0, S(stream), ids, dy, (long)rows, V, C, padding_idx, part);
     if (int rc = launch_status()) return rc;
-    ESMI_LAUNCH(train_reduce_chunks_kernel, grid1d(n, 64), dim3(64 * kReduceGroups), 64 * kReduceGroups * sizeof(float), S(stream), part, n, n, chunks, dtable);
-    return launch_status();
+    return reduce_or_defer(defer, part, n, n, chunks, dtable, -1, nullptr, S(stream));
 }
 int esmi_train_mask_rows_f32(const float* x, const uint8_t* mask, int64_t rows, int C, float* y, esmi_stream_t stream) {
     if (!x || !mask || !y || rows <= 0 || C <= 0) return ESMI_ERR_ARG;

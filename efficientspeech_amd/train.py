@@ -32,6 +32,19 @@ def _new(shape, like, dtype=torch.float32):
     return torch.empty(shape, dtype=dtype, device=like.device)
 
 
+_REDUCE_Q = None          # (esmi_reduce_queue, [workspaces kept alive]) while TrainStep's backward runs: the second stages of the chunked
+#                           parameter-gradient reductions are queued and run as ONE launch before the optimizer (62 launches otherwise)
+
+
+def _defer(ws, *direct):
+    """The queue to hand to an operator's backward, or None: only gradients that go straight into the flat buffer may be late
+    (autograd would read a returned tensor at once); the partial sums in `ws` must outlive the flush."""
+    if _REDUCE_Q is None or not all(direct):
+        return None
+    _REDUCE_Q[1].append(ws)
+    return C.byref(_REDUCE_Q[0])
+
+
 _DIRECT_GRADS = False     # True only while TrainStep._body runs: ONE backward per zeroed buffer, so overwriting == accumulating
 
 
@@ -82,7 +95,8 @@ class _Conv(torch.autograd.Function):
             # one call for both gradients: the weight-gradient pass leaves max|dy| behind for the data-gradient GEMM's operand scale
             nws = lib.esmi_train_conv_bwd_workspace_bytes(C.byref(d))
             ws = _new((nws,), w, torch.uint8)
-            lib.esmi_train_conv_bwd_f32(C.byref(d), _ptr(x), _ptr(dy), _ptr(w), _ptr(dx), _ptr(dw), _ptr(db), _ptr(ws), nws, st)
+            lib.esmi_train_conv_bwd_f32(C.byref(d), _ptr(x), _ptr(dy), _ptr(w), _ptr(dx), _ptr(dw), _ptr(db), _ptr(ws), nws,
+                                        _defer(ws, w_direct, b_direct), st)
         else:
             lib.esmi_train_conv_dgrad_f32(C.byref(d), _ptr(dy), _ptr(w), _ptr(dx), None, 0, st)
             nws = lib.esmi_train_conv_wgrad_workspace_bytes(C.byref(d))
@@ -114,7 +128,7 @@ class _LayerNorm(torch.autograd.Function):
         nws = lib.esmi_train_layernorm_bwd_workspace_bytes(rows, Cc)
         ws = _new((nws,), x, torch.uint8)
         lib.esmi_train_layernorm_bwd_f32(_ptr(x), _ptr(g), _ptr(mean), _ptr(rstd), _ptr(dy), rows, Cc, _ptr(dx), _ptr(dg), _ptr(db),
-                                         _ptr(ws), nws, st)
+                                         _ptr(ws), nws, _defer(ws, g_direct, b_direct), st)
         return dx, (None if g_direct else dg), (None if b_direct else db)
 
 
@@ -186,7 +200,7 @@ class _Embedding(torch.autograd.Function):
         dt, direct = _grad_buffer(ctx.param)
         nws = lib.esmi_train_embedding_bwd_workspace_bytes(ids.numel(), V, Cc)
         ws = _new((nws,), dy, torch.uint8)
-        lib.esmi_train_embedding_bwd_f32(_ptr(ids), _ptr(dy), ids.numel(), V, Cc, pad, _ptr(dt), _ptr(ws), nws, st)
+        lib.esmi_train_embedding_bwd_f32(_ptr(ids), _ptr(dy), ids.numel(), V, Cc, pad, _ptr(dt), _ptr(ws), nws, _defer(ws, direct), st)
         return None, (None if direct else dt), None
 
 
@@ -495,9 +509,11 @@ class TrainStep:
     step(x, y): forward + loss + backward on this rank's batch, ONE all-reduce (mean) of the flat gradient buffer over `group`
     (RCCL when the process group is `nccl`), one AdamW launch.  lr follows torch.optim.AdamW's defaults as model.py sets them.
 
-    graph=True captures the whole step (≈ 650 launches) into one hipGraph the first time a batch SHAPE is seen and replays it for
-    every later batch of that shape (inputs are copied into the graph's static buffers; step count and learning rate live in
-    device memory).  Single-GPU only: the gradient all-reduce stays outside a graph."""
+    graph=True captures the step into one hipGraph the first time a batch SHAPE is seen and replays it for every later batch of
+    that shape (inputs are copied into the graph's static buffers; step count, learning rate and the loss scaler live in device
+    memory): the whole step on one GPU, everything up to the gradient all-reduce when data-parallel (the collective and the
+    optimizer launch then follow eagerly).  With ~330 launches per step the eager step is bound by the host's dispatch (5.6 ms at
+    B = 128); the replay runs at the kernels' own pace (4.9 ms)."""
 
     def __init__(self, net, lr=1e-3, weight_decay=1e-6, betas=(0.9, 0.999), eps=1e-8, group=None, world_size=1, graph=False,
                  precision=32, init_scale=65536.0, growth_factor=2.0, backoff_factor=0.5, growth_interval=2000):
@@ -511,7 +527,7 @@ class TrainStep:
         # steps in a row double it.  `skipped` counts the skipped steps (they do not advance the optimizer's step count).
         assert precision in (16, 32), precision
         self.precision = precision
-        self.graph = bool(graph) and world_size == 1
+        self.graph = bool(graph)
         dev = self.flat.data.device
         if precision == 16:
             # the scaler's state and the optimizer's step count live in device memory: the step never waits for the host.
@@ -646,56 +662,77 @@ class TrainStep:
             if hasattr(m, "_fwd_ident"):
                 m._fwd_ident = None
 
-    def _body(self, x, y, lr, graph):
-        global _DIRECT_GRADS, PRECISION
+    def _fwd_bwd(self, x, y):
+        """Forward, loss, backward, and the one launch that finishes every parameter gradient: everything up to the exchange.
+        Capturable as a hipGraph (no host reads, no collectives)."""
+        global _DIRECT_GRADS, PRECISION, _REDUCE_Q
         f = self.flat
         f.zero_grad()
+        rq = (_lib.ReduceQueue(), [])
         amp = self.precision == 16
         old_precision, PRECISION = PRECISION, self.precision
         try:
             parts, total = training_loss(self.net, x, y)
             _DIRECT_GRADS = True                   # one backward on a zeroed buffer: operators write parameter gradients in place
+            _REDUCE_Q = rq
             if amp:
                 total.backward(gradient=self._scaler[0].reshape(total.shape))     # GradScaler.scale(loss).backward(): the seed is the device-side scale
             else:
                 total.backward()
         finally:
             _DIRECT_GRADS = False
+            _REDUCE_Q = None
             PRECISION = old_precision
-        losses = loss_vector(parts, total)
+        lib0, st0 = _rt(f.data)
+        lib0.esmi_train_reduce_flush_f32(C.byref(rq[0]), st0)      # every queued parameter-gradient reduction in one launch
+        rq[1].clear()
+        return loss_vector(parts, total)
+
+    def _optimize(self, lr, on_device):
+        """The exchange (one all-reduce of the flat gradient buffer when data-parallel) and the optimizer launch.  `on_device`: step
+        count / learning rate (/ the loss scaler's state) are read from device memory (graph replay, precision 16)."""
+        f = self.flat
         if self.world > 1:
             import torch.distributed as dist
             dist.all_reduce(f.grad, op=dist.ReduceOp.SUM, group=self.group)
             f.grad.div_(self.world)                # DDP averages (train.py:66-70 runs Lightning's default DDP strategy)
         lib, st = _rt(f.data)
-        if amp:
+        if self.precision == 16:
             # GradScaler.step + .update on the device: max|g| of the (still scaled) gradients -- absmax's integer max orders inf and
             # nan above every finite magnitude -- decides inside the optimizer launch whether the update runs (on g / scale) or is
             # skipped with the scale backed off; nothing is read back.
-            if not graph:                          # (graph mode: step() wrote it before the replay)
-                self._lr_dev[:1].fill_(lr)
             lib.esmi_absmax_f32(_ptr(f.grad), f.grad.numel(), _ptr(self._absmax), st)
             lib.esmi_train_adamw_graph_f32(_ptr(f.data), _ptr(f.grad), _ptr(f.m), _ptr(f.v), f.data.numel(), _ptr(self._lr_dev),
                                            self.betas[0], self.betas[1], self.eps, self.wd, _ptr(self._step_dev), _ptr(self._absmax),
                                            _ptr(self._scaler), st)
-            return losses
-        if graph:
+        elif on_device:
             lib.esmi_train_adamw_graph_f32(_ptr(f.data), _ptr(f.grad), _ptr(f.m), _ptr(f.v), f.data.numel(), _ptr(self._lr_dev),
                                            self.betas[0], self.betas[1], self.eps, self.wd, _ptr(self._step_dev), None, None, st)
         else:
             lib.esmi_train_adamw_f32(_ptr(f.data), _ptr(f.grad), _ptr(f.m), _ptr(f.v), f.data.numel(), lr, self.betas[0],
                                      self.betas[1], self.eps, self.wd, self.t, 1.0, st)
+
+    def _body(self, x, y, lr, graph):
+        losses = self._fwd_bwd(x, y)
+        self._optimize(lr, graph)
         return losses
 
     def step(self, x, y, lr=None):
+        """One training step.  graph=True: a hipGraph per batch SHAPE replays the step (inputs are copied into its static buffers) --
+        the whole step on one GPU; data-parallel, everything up to the gradient all-reduce (the collective and the optimizer launch
+        follow eagerly)."""
         if self.precision != 16:
             self._t += 1                           # (precision 16 counts on the device: a skipped step does not advance it)
         lr = self.lr if lr is None else lr
+        on_device = self.graph or self.precision == 16
+        if on_device:
+            self._lr_dev[:1].fill_(lr)
         if not self.graph:
             out = self._body(x, y, lr, False)
             self._invalidate_packed()
             return out
-        self._lr_dev[:1].fill_(lr)
+        whole = self.world == 1                    # the collective stays outside a graph
+        captured = self._body if whole else (lambda sx, sy, lr_, g_: self._fwd_bwd(sx, sy))
         key = tuple((k, tuple(v.shape)) for k, v in sorted({**x, **{"y." + k: v for k, v in y.items()}}.items()) if torch.is_tensor(v))
         ent = self._graphs.get(key)
         if ent is None:
@@ -708,7 +745,7 @@ class TrainStep:
             torch.cuda.current_stream().wait_stream(side)
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
-                static_out = self._body(sx, sy, lr, True)
+                static_out = captured(sx, sy, lr, True)
             self._graphs[key] = (g, sx, sy, static_out)
             self._invalidate_packed()
             return out.clone()                     # (the capture itself does not execute: this batch's step ran eagerly above)
@@ -719,6 +756,8 @@ class TrainStep:
         for k, v in y.items():
             sy[k].copy_(v)
         g.replay()
+        if not whole:
+            self._optimize(lr, True)
         self._invalidate_packed()
         return static_out.clone()
 

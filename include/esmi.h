@@ -453,19 +453,30 @@ int esmi_train_conv_dgrad_f32(const esmi_conv_desc* d, const float* dy, const fl
 size_t esmi_train_conv_wgrad_workspace_bytes(const esmi_conv_desc* d);
 int esmi_train_conv_wgrad_f32(const esmi_conv_desc* d, const float* x, const float* dy, float* dw, float* dbias /* or NULL */,
                               void* workspace, size_t workspace_bytes, esmi_stream_t stream);
+/* Deferred second stage of the two-stage (fixed-order, reproducible) reductions: parameter gradients are only read by the optimizer at
+ * the end of the step, so the callers below may queue their "sum the partial rows" stage instead of launching it; ONE launch
+ * (esmi_train_reduce_flush_f32) then runs every queued reduction.  The queue is a caller-owned host struct (the library keeps no
+ * state); the partial buffers (workspaces) must stay alive until the flush.  A full queue is flushed by the call that finds it full. */
+typedef struct esmi_reduce_item {
+    const float* partial; int64_t n, stride, chunks; float* out; int64_t n0; float* out1;   /* out[e] (e < n0 or no out1) / out1[e - n0] = sum_c partial[c * stride + e] */
+} esmi_reduce_item;
+#define ESMI_REDUCE_QUEUE_ITEMS 48
+typedef struct esmi_reduce_queue { int32_t count; esmi_reduce_item items[ESMI_REDUCE_QUEUE_ITEMS]; } esmi_reduce_queue;
+int esmi_train_reduce_flush_f32(esmi_reduce_queue* q, esmi_stream_t stream);
 /* both gradients of one convolution in one call (what autograd's backward of the op needs): the weight-gradient pass leaves max|dy|
  * behind as a by-product and the data-gradient GEMM takes its operand scale from it -- no separate pass over dy.  Shapes that do not
  * run on the matrix pipe fall back to the two entry points above. */
 size_t esmi_train_conv_bwd_workspace_bytes(const esmi_conv_desc* d);
 int esmi_train_conv_bwd_f32(const esmi_conv_desc* d, const float* x, const float* dy, const float* w, float* dx, float* dw,
-                            float* dbias /* or NULL */, void* workspace, size_t workspace_bytes, esmi_stream_t stream);
+                            float* dbias /* or NULL */, void* workspace, size_t workspace_bytes, esmi_reduce_queue* defer /* or NULL */,
+                            esmi_stream_t stream);
 /* nn.LayerNorm over the last dim (eps 1e-5); mean / rstd (rows) are kept for the backward */
 int esmi_train_layernorm_fwd_f32(const float* x, const float* g, const float* b, int64_t rows, int C, float* y, float* mean,
                                  float* rstd, esmi_stream_t stream);
 size_t esmi_train_layernorm_bwd_workspace_bytes(int64_t rows, int C);
 int esmi_train_layernorm_bwd_f32(const float* x, const float* g, const float* mean, const float* rstd, const float* dy,
                                  int64_t rows, int C, float* dx, float* dg, float* db, void* workspace, size_t workspace_bytes,
-                                 esmi_stream_t stream);
+                                 esmi_reduce_queue* defer /* or NULL */, esmi_stream_t stream);
 /* kind: 1 ReLU, 2 GELU (erf), 3 tanh.  Backward reads the OUTPUT for ReLU / tanh and the INPUT for GELU as `saved`. */
 int esmi_train_act_fwd_f32(const float* x, int64_t n, int kind, float* y, esmi_stream_t stream);
 int esmi_train_act_bwd_f32(const float* saved, const float* dy, int64_t n, int kind, float* dx, esmi_stream_t stream);
@@ -478,7 +489,7 @@ int esmi_train_attention_bwd_f32(const float* qkv, const float* P, const float* 
 int esmi_train_embedding_fwd_f32(const int32_t* ids, const float* table, int64_t rows, int V, int C, float* out, esmi_stream_t stream);
 size_t esmi_train_embedding_bwd_workspace_bytes(int64_t rows, int V, int C);
 int esmi_train_embedding_bwd_f32(const int32_t* ids, const float* dy, int64_t rows, int V, int C, int padding_idx, float* dtable,
-                                 void* workspace, size_t workspace_bytes, esmi_stream_t stream);
+                                 void* workspace, size_t workspace_bytes, esmi_reduce_queue* defer /* or NULL */, esmi_stream_t stream);
 int esmi_train_mask_rows_f32(const float* x, const uint8_t* mask, int64_t rows, int C, float* y, esmi_stream_t stream);
 int esmi_train_add_f32(const float* a, const float* b, int64_t n, float* y, esmi_stream_t stream);
 /* dst[r, col_dst + c] = src[r, col_src + c], c < C: torch.cat along channels and its gradient */

@@ -631,3 +631,41 @@ def test_simulated_edge_shapes_match_torch_mirror(B, T, lens):
     bad = [k for k, p in nets[0].named_parameters() if ref[k].grad is not None and
            float((p.grad - ref[k].grad).abs().max()) > 1e-4 * max(1e-6, float(ref[k].grad.abs().max()))]
     assert len(bad) <= 2, bad          # (a ReLU input on zero may take the other branch: see the at-size GPU test)
+
+
+def _ddp_gpu_worker(rank, world, port, out_path):
+    """Two data-parallel ranks on cuda:0 (gloo carries device tensors): the hipGraph-replayed step (forward + loss + backward captured,
+    all-reduce + optimizer eager) against the eager step, different batches per rank."""
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    res = {}
+    for mode in ("eager", "graph"):
+        train, g, net, x, y = _setup("cuda")
+        sel = slice(rank, rank + 1)
+        cut = lambda d: {k: (torch.cat([v[sel], v[sel]]) if torch.is_tensor(v) and v.dim() > 0 and v.shape[0] == 2 else v)   # noqa: E731
+                         for k, v in d.items()}
+        step = train.TrainStep(net, world_size=world, graph=(mode == "graph"))
+        losses = [step.step(cut(x), cut(y)).clone() for _ in range(4)]
+        res[mode] = (step.flat.data.clone(), torch.stack(losses))
+        flat = step.flat.data
+        gather = [torch.empty_like(flat) for _ in range(world)]
+        dist.all_gather(gather, flat)
+        res[mode + "_same"] = torch.equal(gather[0], gather[1])
+    if rank == 0:
+        ok_params = torch.allclose(res["eager"][0], res["graph"][0], rtol=1e-4, atol=1e-6)
+        ok_losses = torch.allclose(res["eager"][1], res["graph"][1], rtol=1e-5, atol=0)
+        np.save(out_path, np.array([int(res["eager_same"]), int(res["graph_same"]), int(ok_params), int(ok_losses)]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_gpu_two_rank_captured_step_equals_eager_step(tmp_path):
+    """Data-parallel + hipGraph: replicas stay identical and the replayed steps equal the eager ones."""
+    import torch.multiprocessing as mp
+    out = str(tmp_path / "ddp_graph.npy")
+    mp.spawn(_ddp_gpu_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    assert np.load(out).tolist() == [1, 1, 1, 1]
