@@ -59,6 +59,10 @@ struct ConvGemmP {
     // to binary16 (nearest) and the contraction is ONE v_mfma_f32_32x32x16_f16 per 16 channels instead of the three products of
     // the fp32-accurate split; fp32 accumulation, fp32 in / out (master weights and activations stay fp32 in memory)
     int amp;
+    // optional: the same weights in MFMA B-fragment order with pre-split binary16 pieces (esmi_pack_bfrag_f32 of W, taps = k; the
+    // `*_wp` fields of include/esmi.h).  convgemm_dma_kernel then brings its weight tile in by LDS-DMA -- each 1 KiB block of the
+    // blob IS one (32-channel tile, 16-k step, piece) operand fragment in lane order -- instead of splitting fp32 rows per workgroup
+    const float* Wp;
 };
 // (s, 1/s) for a tensor whose largest magnitude has the bit pattern *absmax
 __device__ __forceinline__ void conv_pow2_scales(const float* absmax, float* s, float* inv) {
@@ -105,7 +109,8 @@ __device__ __forceinline__ f32x4 conv_act_in(f32x4 v, const ConvGemmP& p, float 
 // Fused epilogue of the implicit-GEMM kernels, in the MFMA C/D layout (row = tile_row(r), col = n0 + 32*nt + (lane&31)):
 //   out = mask( post_relu( LN( act(acc * s + bias) + residual ) ) ), optional row-dot side output on the pre-LN value.
 template <int NT>
-__device__ __forceinline__ void convgemm_epilogue(f32x16 (&acc)[NT], const ConvGemmP& p, int b, int t0, int n0, int lane, int ts = 1) {
+__device__ __forceinline__ void convgemm_epilogue(f32x16 (&acc)[NT], const ConvGemmP& p, int b, int t0, int n0, int lane, int ts = 1, int flat_rows = 0) {
+    const int n_out = flat_rows ? flat_rows : p.n_out;   // (flat_rows: the caller's rows are b * n_out + t with b = 0)
     const int i = lane & 31;
     const float out_s = (ESMI_CHAIN_SPLIT ? kF16WScaleInv : 1.0f) * conv_out_scale(p);
     int col[NT];
@@ -120,8 +125,8 @@ __device__ __forceinline__ void convgemm_epilogue(f32x16 (&acc)[NT], const ConvG
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int t = t0 + tile_row(r, lane) * ts;
-        const bool rok = t < p.n_out;
-        const long row = (long)b * p.n_out + t;
+        const bool rok = t < n_out;
+        const long row = (long)b * n_out + t;
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             float v = apply_act(fmaf(acc[nt][r], out_s, bias[nt]), p.act);
@@ -142,7 +147,7 @@ __device__ __forceinline__ void convgemm_epilogue(f32x16 (&acc)[NT], const ConvG
             s = row_sum32(s) + db;
             if (p.dot_relu) s = fmaxf(s, 0.0f);
             const int t = t0 + tile_row(r, lane) * ts;
-            if (i == 0 && t < p.n_out) p.dot_out[(long)b * p.n_out + t] = s;
+            if (i == 0 && t < n_out) p.dot_out[(long)b * n_out + t] = s;
         }
     }
     if (!p.out) return;
@@ -150,8 +155,8 @@ __device__ __forceinline__ void convgemm_epilogue(f32x16 (&acc)[NT], const ConvG
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int t = t0 + tile_row(r, lane) * ts;
-        if (t >= p.n_out) continue;
-        const long row = (long)b * p.n_out + t;
+        if (t >= n_out) continue;
+        const long row = (long)b * n_out + t;
         const bool masked = p.rowmask && p.rowmask[row];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
@@ -351,36 +356,51 @@ __host__ __device__ constexpr int convgemm_lds_bytes() { return 2 * 2 * 32 * NT 
 #define ESMI_GEMM_LDS_WAVES 4   // waves (32 positions each) sharing one weight tile.  8 halves each wave's share of the staging work
                                 // but couples 8 waves to one barrier: measured 11.50 vs 10.45 ms/step on base ES (r02), so 4
 #endif
-template <int NT, int NWV = ESMI_GEMM_LDS_WAVES, bool AMP = false>
+// MT = 32-row tiles per wave.  The B fragments are the LDS traffic of this kernel (one 16-byte read per lane and plane feeds
+// 3 MT products): with MT = 1 eight waves of a CU ask LDS for ~85 B/clk of its 128 to keep the matrix pipe full, and the counters
+// show the waves parked half of the time (profiles/r03_probes/gemm_lds_counters.md); MT = 2 halves the reads per product and the
+// staging work per output.  Rows are the FLAT index b * n_out + t (a tile may span utterances; each lane derives its own (b, t)
+// once), so short sequences (base block 2: 64 positions) still fill 64 * NWV-row workgroup tiles.
+template <int NT, int MT = 1, int NWV = ESMI_GEMM_LDS_WAVES, bool AMP = false>
 __global__ __launch_bounds__(64 * NWV, 2) void convgemm_lds_kernel(const ConvGemmP p) {
-    constexpr int BN = 32 * NT, PLANE = BN * kGemmRowDw, NTHR = 64 * NWV, NU = (256 * NT) / NTHR, ROWS = 32 * NWV;
+    constexpr int BN = 32 * NT, PLANE = BN * kGemmRowDw, NTHR = 64 * NWV, NU = (256 * NT) / NTHR, WROWS = 32 * MT, ROWS = WROWS * NWV;
     static_assert(NU * NTHR == 256 * NT, "staging items divide evenly");
     ESMI_DYN_LDS(lds);
     unsigned* wt = reinterpret_cast<unsigned*>(lds);   // [2 buffers][2 planes][PLANE]
     const int tid = (int)threadIdx.x, lane = lane_id(), w = wave_id();
     const int i = lane & 31, h = lane >> 5;
-    const int tiles_per_b = (p.n_out + ROWS - 1) / ROWS;
-    const int b = (int)blockIdx.x / tiles_per_b;
-    const int t0 = ((int)blockIdx.x - b * tiles_per_b) * ROWS + 32 * w;   // this wave's 32 positions
+    const long n_rows = (long)p.B * p.n_out;
+    const long r0 = (long)blockIdx.x * ROWS + WROWS * w;   // this wave's first flat row
     const int n0 = (int)blockIdx.y * BN;
-    const int t_out = t0 + i;
-
-    f32x16 acc[NT];
+    int rb[MT], rt[MT];       // (utterance, position) of this lane's row in each of the wave's tiles
+    bool rok[MT];
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) acc[nt] = zero16();
+    for (int mt = 0; mt < MT; ++mt) {
+        const long r = r0 + 32 * mt + i;
+        rok[mt] = r < n_rows;
+        rb[mt] = rok[mt] ? (int)(r / p.n_out) : 0;
+        rt[mt] = rok[mt] ? (int)(r - (long)rb[mt] * p.n_out) : 0;
+    }
+
+    f32x16 acc[MT * NT];   // tile (mt, nt) at mt * NT + nt
+#pragma unroll
+    for (int q = 0; q < MT * NT; ++q) acc[q] = zero16();
     const int kchunks = p.c_in >> 5, n_it = p.k * kchunks;
-    f32x4 a_nxt[2][2], w_nxt[NU];
-    f16x2p a_cur[2];
+    f32x4 a_nxt[MT][2][2], w_nxt[NU];
+    f16x2p a_cur[MT][2];
     const float in_s = conv_in_scale(p);
     auto fetch = [&](int it) __attribute__((always_inline)) {   // global -> registers: A rows of this wave, W rows of the workgroup
         const int j = it / kchunks, c = (it - j * kchunks) << 5;
-        const int ti = t_out + j * (p.dil > 0 ? p.dil : 1) - p.pad;
-        const bool ok = t_out < p.n_out && ti >= 0 && ti < p.n_in;
-        const float* arow = p.A + ((long)b * p.n_in + (ok ? ti : 0)) * p.lda + p.a_coff + c + 8 * h;
 #pragma unroll
-        for (int st = 0; st < 2; ++st) {
-            a_nxt[st][0] = ok ? conv_act_in(ld4(arow + 16 * st), p, in_s) : zero4();
-            a_nxt[st][1] = ok ? conv_act_in(ld4(arow + 16 * st + 4), p, in_s) : zero4();
+        for (int mt = 0; mt < MT; ++mt) {
+            const int ti = rt[mt] + j * (p.dil > 0 ? p.dil : 1) - p.pad;
+            const bool ok = rok[mt] && ti >= 0 && ti < p.n_in;
+            const float* arow = p.A + ((long)rb[mt] * p.n_in + (ok ? ti : 0)) * p.lda + p.a_coff + c + 8 * h;
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+                a_nxt[mt][st][0] = ok ? conv_act_in(ld4(arow + 16 * st), p, in_s) : zero4();
+                a_nxt[mt][st][1] = ok ? conv_act_in(ld4(arow + 16 * st + 4), p, in_s) : zero4();
+            }
         }
         const float* wj = p.W + (long)j * p.c_out * p.c_in + c;
 #pragma unroll
@@ -403,19 +423,26 @@ __global__ __launch_bounds__(64 * NWV, 2) void convgemm_lds_kernel(const ConvGem
             *reinterpret_cast<u32x2*>(d + PLANE) = u32x2{h2a, h2b};
         }
 #pragma unroll
-        for (int st = 0; st < 2; ++st) {
-            if constexpr (AMP) a_cur[st].h1 = round_f16x8(a_nxt[st][0], a_nxt[st][1]);   // (nearest-rounded single piece; h2 unused)
-            else a_cur[st] = split_f16x2(a_nxt[st][0], a_nxt[st][1]);
-        }
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+                if constexpr (AMP) a_cur[mt][st].h1 = round_f16x8(a_nxt[mt][st][0], a_nxt[mt][st][1]);   // (nearest-rounded single piece; h2 unused)
+                else a_cur[mt][st] = split_f16x2(a_nxt[mt][st][0], a_nxt[mt][st][1]);
+            }
     };
     fetch(0);
     stage(0);
     __syncthreads();
     for (int it = 0; it < n_it; ++it) {
         const bool more = it + 1 < n_it;
-        f16x2p a_use[2];
-        a_use[0].h1 = a_cur[0].h1; a_use[1].h1 = a_cur[1].h1;
-        if constexpr (!AMP) { a_use[0].h2 = a_cur[0].h2; a_use[1].h2 = a_cur[1].h2; }
+        f16x2p a_use[MT][2];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+                a_use[mt][st].h1 = a_cur[mt][st].h1;
+                if constexpr (!AMP) a_use[mt][st].h2 = a_cur[mt][st].h2;
+            }
         if (more) fetch(it + 1);                   // in flight under this chunk's MFMAs
         sched_fence();
         const unsigned* bp = wt + ((it & 1) * 2) * PLANE + opaque_i(i * kGemmRowDw + 4 * h);
@@ -425,17 +452,285 @@ __global__ __launch_bounds__(64 * NWV, 2) void convgemm_lds_kernel(const ConvGem
             for (int nt = 0; nt < NT; ++nt) {
                 const u32x4 b1 = *reinterpret_cast<const u32x4*>(bp + 32 * nt * kGemmRowDw + 8 * st);
                 if constexpr (AMP) {   // the first plane of the staged weights IS round-to-nearest binary16 of 2^8 W
-                    acc[nt] = mfma32_f16(a_use[st].h1, b1, acc[nt]);
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) acc[mt * NT + nt] = mfma32_f16(a_use[mt][st].h1, b1, acc[mt * NT + nt]);
                 } else {
                     const u32x4 b2 = *reinterpret_cast<const u32x4*>(bp + PLANE + 32 * nt * kGemmRowDw + 8 * st);
-                    acc[nt] = mfma32_split2(a_use[st], b1, b2, acc[nt]);
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) acc[mt * NT + nt] = mfma32_split2(a_use[mt][st], b1, b2, acc[mt * NT + nt]);
                 }
             }
         }
         if (more) stage((it + 1) & 1);             // the other buffer: last read one iteration ago, before the barrier below
         __syncthreads();
     }
-    if (t0 < p.n_out) convgemm_epilogue<NT>(acc, p, b, t0, n0, lane);
+    // the epilogue in flat rows: one "utterance" of B * n_out positions (written out per tile: hipcc refuses to unroll a loop around it)
+    static_assert(MT <= 2, "epilogue calls below");
+    if (r0 < n_rows) convgemm_epilogue<NT>(*reinterpret_cast<f32x16(*)[NT]>(&acc[0]), p, 0, (int)r0, n0, lane, 1, (int)n_rows);
+    if constexpr (MT > 1) {
+        if (r0 + 32 < n_rows) convgemm_epilogue<NT>(*reinterpret_cast<f32x16(*)[NT]>(&acc[NT]), p, 0, (int)r0 + 32, n0, lane, 1, (int)n_rows);
+    }
+}
+
+#ifdef ESMI_GEMM_TRACE
+extern __device__ long long* g_gemm_trace_dev;
+#endif
+// ---- convgemm_dma_kernel: the LDS-staged GEMM above with the INPUT rows brought in by LDS-DMA.
+// Ablations on the register-path kernel (base ES block-1 MixFFN, profiles/r03_probes/gemm_lds_ablation.md) put its time in the A
+// loads: a lane of the MFMA operand layout owns 32 contiguous bytes of ITS OWN row, so every global_load_dwordx4 of a wave
+// touches 32 different cache lines for 16 bytes each and the vector-memory pipe -- not LDS, the barrier or the matrix pipe --
+// paces the loop (no A loads: -30 %; no weight loads: -8 %; no barrier: -3 %).  Here eight lanes fetch one whole 128-byte row
+// chunk (8 lines per instruction instead of 32) with global_load_lds_dwordx4 -- memory -> LDS, no staging registers -- into a
+// wave-PRIVATE fp32 tile, and the operand fragments are read back with ds_read_b128.  LDS-DMA writes lane l's 16 bytes at
+// base + 16 l, so the tile is plain row-major [row][8 pieces]; the bank spread comes from WHICH piece a lane fetches instead:
+// slot s of row r holds piece s ^ ((r >> 1) & 7), and 16 consecutive rows reading the same piece hit 16 different 16-byte bank
+// groups.  The tile is single-buffered: a wave reads its fragments of chunk c into registers, waits for them (lgkmcnt), and only
+// then issues the DMA of chunk c + 1 into the same rows -- no other wave touches them.  Rows whose tap falls outside the
+// utterance (or past the last row) are fetched from a clamped in-range address and zeroed by the reader, which knows its own
+// row's position.  Restriction on top of convgemm_lds_kernel's: the input tensor spans < 2^31 elements (32-bit lane offsets).
+// Convolution taps re-use the rows: when the taps' reach (k - 1) * dil is at most kGemmHaloMax rows the wave's tile carries that
+// many extra rows, the K loop runs channel chunk OUTER / tap INNER, and one DMA per chunk serves all k taps (tap j reads the
+// fragments j * dil rows further down) -- a third of the input traffic of a k = 3 convolution.  Otherwise (long dilated HiFi-GAN
+// taps) each tap fetches its own shifted rows, tap outer.  Workgroups are numbered so that the c_out / BN column tiles of one row
+// tile are neighbours ON THE SAME XCD (ids congruent mod 8 share an XCD and its L2): they sweep the same input rows at the same
+// time and three of four fetches hit L2 instead of going out to the Infinity Cache.
+constexpr int kGemmHaloMax = 16;
+__host__ __device__ inline int convgemm_dma_tile_rows(int mt, int k, int dil) {   // LDS rows of one wave's input tile
+    const int reach = (k - 1) * (dil > 0 ? dil : 1);
+    return 32 * mt + (reach <= kGemmHaloMax ? (reach + 7) / 8 * 8 : 0);
+}
+template <int NT>
+__host__ __device__ inline int convgemm_dma_bytes(int mt, int k, int dil, bool pre, int nwv = ESMI_GEMM_LDS_WAVES) {
+    return (pre ? 2 * 4 * NT * 1024 : convgemm_lds_bytes<NT>()) + nwv * convgemm_dma_tile_rows(mt, k, dil) * 128;
+}
+
+template <int NT, int MT, int NWV = ESMI_GEMM_LDS_WAVES, bool AMP = false, bool PRE = false>
+__global__ __launch_bounds__(64 * NWV, 2) void convgemm_dma_kernel(const ConvGemmP p, int nx, int ny) {
+    constexpr int BN = 32 * NT, PLANE = BN * kGemmRowDw, NTHR = 64 * NWV, NU = (256 * NT) / NTHR, WROWS = 32 * MT, ROWS = WROWS * NWV;
+    static_assert(NU * NTHR == 256 * NT, "staging items divide evenly");
+    static_assert(MT <= 2, "epilogue calls below");
+    // workgroup id -> (row tile bx, column tile by): id = 8 * (ny * xs + by) + xcd, bx = 8 * xs + xcd
+    const int xcd = (int)blockIdx.x & 7, nq = (int)blockIdx.x >> 3;
+    const int by = nq % ny, bx = (nq / ny) * 8 + xcd;
+    if (bx >= nx) return;                              // (the grid is padded to whole groups of 8 row tiles)
+    ESMI_DYN_LDS(lds);
+    unsigned* wt = reinterpret_cast<unsigned*>(lds);   // [2 buffers][2 planes][PLANE]
+    const int tid = (int)threadIdx.x, lane = lane_id(), w = wave_id();
+    const int dil = p.dil > 0 ? p.dil : 1;
+    const int reach = (p.k - 1) * dil;
+    const bool halo = reach <= kGemmHaloMax;           // taps share one fetch per channel chunk
+    const int trows = convgemm_dma_tile_rows(MT, p.k, dil), nd = trows >> 3;
+    float* at = lds + (PRE ? 8 * NT * 256 : 4 * PLANE) + w * (trows * 32);    // this wave's input rows: [trows][8 pieces of 4 floats, swizzled]
+    const int i = lane & 31, h = lane >> 5;
+    const long n_rows = (long)p.B * p.n_out;           // == B * n_in (the launcher checks n_in == n_out): input row = output row + tap offset
+    const long r0 = (long)bx * ROWS + WROWS * w;       // this wave's first flat row b * n_out + t
+    const int n0 = by * BN;
+    constexpr int WBLK = 256, WBUF = PRE ? 4 * NT * WBLK : 2 * PLANE;   // dwords: one fragment block / one weight buffer
+    (void)WBUF;
+    // reader role: MFMA operand layout, lane (i, h) <-> row 32 mt + i, channels 8 h + 16 st + (0..7)
+    int rt[MT];
+    bool rok[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const long r = r0 + 32 * mt + i;
+        rok[mt] = r < n_rows;
+        rt[mt] = rok[mt] ? (int)(r % p.n_out) : 0;
+    }
+    // loader role: DMA instruction d, lane l <-> tile row 8 d + (l >> 3), LDS slot l & 7, which holds piece (l & 7) ^ ((row >> 1) & 7)
+    const int l_row = lane >> 3;
+    const int piece_e = (lane & 7) ^ (lane >> 4), piece_o = piece_e ^ 4;   // d even / odd
+    const int lbase = ((int)r0 + l_row) * p.lda + p.a_coff;                // (32-bit: the launcher checks the tensor's span)
+    const int max_off = ((int)n_rows - 1) * p.lda + p.a_coff + p.c_in - 4;
+
+    f32x16 acc[MT * NT];   // tile (mt, nt) at mt * NT + nt
+#pragma unroll
+    for (int q = 0; q < MT * NT; ++q) acc[q] = zero16();
+    const int kchunks = p.c_in >> 5, n_it = p.k * kchunks;
+    f32x4 w_nxt[NU];
+    const float in_s = conv_in_scale(p);
+    // iteration -> (tap j, channel chunk c): halo mode runs the taps innermost
+    int nj = 0, nc = 0;   // the NEXT iteration's (plain loop-carried scalars: behind a by-reference lambda they ended up in scratch)
+    // input rows of tap j / chunk c: memory -> LDS (DMA instruction d, lane l: tile row 8 d + (l >> 3))
+    auto fetch_a = [&](int j, int c) __attribute__((always_inline)) {
+        const int shift = halo ? -p.pad : j * dil - p.pad;    // first tile row, relative to the wave's first output row
+        const int off0 = lbase + shift * p.lda + (c << 5);
+        for (int d = 0; d < nd; ++d) {
+            int off = off0 + 8 * d * p.lda + 4 * ((d & 1) ? piece_o : piece_e);
+            off = off < 0 ? 0 : (off > max_off ? max_off : off);
+#ifdef ESMI_WAVESIM
+            reinterpret_cast<f32x4*>(at + 8 * d * 32)[lane] = ld4(p.A + off);
+#else
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.A + off),
+                                             (__attribute__((address_space(3))) void*)(at + 8 * d * 32), 16, 0, 0);
+#endif
+        }
+    };
+    const int ntw = (p.c_out + 31) >> 5;
+    // weight tile of the workgroup for tap j / chunk c into buffer `buf`
+    auto fetch_w = [&](int j, int c, int buf) __attribute__((always_inline)) {
+        if constexpr (PRE) {   // blob -> LDS: blocks [16-k step st][piece][tile nt] of 64 lanes x 16 bytes, lane order
+            constexpr int P = AMP ? 1 : 2, NB = 2 * P * NT;
+            const long blk0 = ((long)j * (p.c_in >> 3) + 4 * c) * ntw + (n0 >> 5);
+            unsigned* dstb = wt + buf * WBUF;
+#pragma unroll
+            for (int v0 = 0; v0 < NB; v0 += NWV) {
+                const int v = v0 + w;                      // (wave-uniform)
+                if (v < NB) {
+                    const int st = v / (P * NT), pl = (v / NT) % P, nt = v % NT;
+                    unsigned* d = dstb + ((st * 2 + pl) * NT + nt) * WBLK;
+                    if ((n0 >> 5) + nt < ntw) {
+                        const float* src = p.Wp + ((blk0 + (long)(2 * st + pl) * ntw + nt) * 64 + lane) * 4;
+#ifdef ESMI_WAVESIM
+                        reinterpret_cast<f32x4*>(d)[lane] = ld4(src);
+#else
+                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                         (__attribute__((address_space(3))) void*)d, 16, 0, 0);
+#endif
+                    } else {
+                        reinterpret_cast<u32x4*>(d)[lane] = u32x4{0u, 0u, 0u, 0u};   // column tile past c_out
+                    }
+                }
+            }
+        } else {               // fp32 rows -> registers (split and written to LDS by stage())
+            const float* wj = p.W + (long)j * p.c_out * p.c_in + (c << 5);
+#pragma unroll
+            for (int u = 0; u < NU; ++u) {
+                const int q = tid + NTHR * u, n = n0 + (q >> 3);
+                w_nxt[u] = n < p.c_out ? ld4(wj + (long)n * p.c_in + 4 * (q & 7)) : zero4();
+            }
+        }
+    };
+    auto stage = [&](int buf) __attribute__((always_inline)) {   // registers -> LDS planes (weights)
+        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+        if constexpr (PRE) return;
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            const int q = tid + NTHR * u;
+            const f32x4 x = w_nxt[u] * kF16WScale;
+            unsigned h1a, h2a, h1b, h2b;
+            split_f16_pair_rn(x[0], x[1], h1a, h2a);   // weights: nearest-rounded pieces, as the pack-time splitters
+            split_f16_pair_rn(x[2], x[3], h1b, h2b);
+            unsigned* d = wt + (buf * 2) * PLANE + (q >> 3) * kGemmRowDw + 2 * (q & 7);
+            *reinterpret_cast<u32x2*>(d) = u32x2{h1a, h1b};
+            *reinterpret_cast<u32x2*>(d + PLANE) = u32x2{h2a, h2b};
+        }
+    };
+#ifdef ESMI_GEMM_TRACE   // development: shader-clock stamps of one mid-grid workgroup, 7 per K chunk (tools/trace_gemm.py)
+    const bool tr_on = g_gemm_trace_dev && p.k == 3 && p.c_in == 512 && bx == nx / 2 && by == 0 && lane == 0;
+    int tr_n = 0;
+#define ESMI_GT() do { if (tr_on && tr_n < 512) g_gemm_trace_dev[w * 512 + tr_n] = (long long)__builtin_amdgcn_s_memtime(); ++tr_n; } while (0)
+#else
+#define ESMI_GT() do {} while (0)
+#endif
+    fetch_a(0, 0);
+    fetch_w(0, 0, 0);
+    stage(0);
+    __syncthreads();
+    for (int it = 0; it < n_it; ++it) {
+        const int tj = nj;                             // this iteration's tap; (nj, nc) := the next iteration's
+        if (halo) { const bool wrap = nj + 1 == p.k; nj = wrap ? 0 : nj + 1; nc += wrap ? 1 : 0; }
+        else { const bool wrap = nc + 1 == kchunks; nc = wrap ? 0 : nc + 1; nj += wrap ? 1 : 0; }
+        const bool more = it + 1 < n_it;
+        const bool more_a = more && (!halo || nj == 0);   // halo mode: new rows only when the next iteration starts a chunk
+        f16x2p a_use[MT][2];
+        ESMI_GT();   // 0: top
+        {   // this chunk's operand fragments: all LDS reads first, ONE wait, then zero the rows outside the utterance and split
+            const int tap = tj * dil - p.pad;
+            const int row_l = i + (halo ? tap + p.pad : 0);             // tile row of this lane's first fragment row
+            const float* ap = at + row_l * 32;
+            const int swz = (row_l >> 1) & 7;
+            f32x4 raw[MT][2][2];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int st = 0; st < 2; ++st) {
+                    // k-slots of a lane: channels 16 st + 8 h + (0..7) against weights split in this kernel, 16 st + 4 h + (0..3)
+                    // and + 8 against the packed blob (the order esmi_pack_bfrag_f32 writes)
+                    const int s0 = (PRE ? 4 * st + h : 4 * st + 2 * h) ^ swz;   // (32 mt rows further: same (row >> 1) & 7)
+                    raw[mt][st][0] = *reinterpret_cast<const f32x4*>(ap + 32 * mt * 32 + 4 * s0);
+                    raw[mt][st][1] = *reinterpret_cast<const f32x4*>(ap + 32 * mt * 32 + 4 * (s0 ^ (PRE ? 2 : 1)));
+                }
+            sched_fence();
+            const bool plain = !p.act_in && !p.io_scale;   // (wave-uniform)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const int ti = rt[mt] + tap;
+                const unsigned keep = (rok[mt] && ti >= 0 && ti < p.n_in) ? 0xffffffffu : 0u;
+#pragma unroll
+                for (int st = 0; st < 2; ++st) {
+                    f32x4 lo = raw[mt][st][0], hi = raw[mt][st][1];
+                    if (!plain) { lo = conv_act_in(lo, p, in_s); hi = conv_act_in(hi, p, in_s); }
+                    lo = __builtin_bit_cast(f32x4, __builtin_bit_cast(u32x4, lo) & keep);
+                    hi = __builtin_bit_cast(f32x4, __builtin_bit_cast(u32x4, hi) & keep);
+                    if constexpr (AMP) a_use[mt][st].h1 = round_f16x8(lo, hi);
+                    else a_use[mt][st] = split_f16x2(lo, hi);
+                }
+            }
+        }
+        lds_wave_sync();                           // the fragment reads have returned: the rows may be overwritten
+        sched_fence();
+        ESMI_GT();   // 1: A fragments read + split
+        if (more_a) fetch_a(nj, nc);               // the next iteration's loads: in flight under this iteration's products
+        if (more) fetch_w(nj, nc, (it + 1) & 1);
+        sched_fence();
+        ESMI_GT();   // 2: loads issued
+        const unsigned* bp = PRE ? wt + (it & 1) * WBUF + opaque_i(4 * lane) : wt + ((it & 1) * 2) * PLANE + opaque_i(i * kGemmRowDw + 4 * h);
+        // B fragments in groups of two 32-channel tiles, one group ahead of the products that use them (hipcc on its own issues
+        // each pair of reads right in front of its products and waits for the full LDS round trip every time)
+        constexpr int NG = NT;   // 2 k-halves x NT / 2 tile pairs
+        u32x4 bf[2][2][2];       // [group parity][tile of the pair][plane]
+        auto ld_b = [&](int g) __attribute__((always_inline)) {
+            const int st = g / (NT / 2), np = g % (NT / 2);
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const unsigned* src = PRE ? bp + (st * 2 * NT + 2 * np + q) * WBLK : bp + 32 * (2 * np + q) * kGemmRowDw + 8 * st;
+                bf[g & 1][q][0] = *reinterpret_cast<const u32x4*>(src);
+                if constexpr (!AMP) bf[g & 1][q][1] = *reinterpret_cast<const u32x4*>(src + (PRE ? NT * WBLK : PLANE));
+            }
+        };
+        ld_b(0);
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            if (g + 1 < NG) ld_b(g + 1);
+            sched_fence();
+            const int st = g / (NT / 2), np = g % (NT / 2);
+            if constexpr (AMP) {
+#pragma unroll
+                for (int q = 0; q < 2; ++q)
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) {
+                        f32x16& c = acc[mt * NT + 2 * np + q];
+                        c = mfma32_f16(a_use[mt][st].h1, bf[g & 1][q][0], c);
+                    }
+            } else {
+                // the three products of a tile are a dependent chain on its accumulator: run the 2 MT chains side by side
+#pragma unroll
+                for (int pr = 0; pr < 3; ++pr)
+#pragma unroll
+                    for (int q = 0; q < 2; ++q)
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt) {
+                            f32x16& c = acc[mt * NT + 2 * np + q];
+                            const f16x2p& a = a_use[mt][st];
+                            c = pr == 0 ? mfma32_f16(a.h2, bf[g & 1][q][0], c) : pr == 1 ? mfma32_f16(a.h1, bf[g & 1][q][1], c) : mfma32_f16(a.h1, bf[g & 1][q][0], c);
+                        }
+            }
+            sched_fence();
+        }
+        ESMI_GT();   // 3: products issued
+#ifdef ESMI_GEMM_TRACE
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        ESMI_GT();   // 4: weight rows + DMA arrived
+#endif
+        if (more) stage((it + 1) & 1);             // the other buffer: last read one iteration ago, before the barrier below
+        ESMI_GT();   // 5: weights staged
+        __syncthreads();                           // (its fence also drains this wave's DMA: vmcnt(0))
+        ESMI_GT();   // 6: barrier passed
+    }
+    if (r0 < n_rows) convgemm_epilogue<NT>(*reinterpret_cast<f32x16(*)[NT]>(&acc[0]), p, 0, (int)r0, n0, lane, 1, (int)n_rows);
+    if constexpr (MT > 1) {
+        if (r0 + 32 < n_rows) convgemm_epilogue<NT>(*reinterpret_cast<f32x16(*)[NT]>(&acc[NT]), p, 0, (int)r0 + 32, n0, lane, 1, (int)n_rows);
+    }
 }
 #endif
 

@@ -191,7 +191,7 @@ int esmi_encoder_block_f32(const esmi_encoder_block_weights* w, const esmi_encod
         // qkv Linear (bias-free), blocks.py:44
         p = conv_defaults();
         p.B = B; p.n_in = n; p.c_in = C; p.n_out = n; p.c_out = 3 * h * C;
-        p.A = x_mid; p.lda = C; p.W = w->qkv_w; p.out = qkv; p.ldo = 3 * h * C;
+        p.A = x_mid; p.lda = C; p.W = w->qkv_w; p.Wp = w->qkv_wp; p.out = qkv; p.ldo = 3 * h * C;
         if ((rc = launch_convgemm(p, st))) return rc;
     }
     if (fused2) {   // E2: attention + proj + LN1 + MixFFN + LN2 as one wave-chain kernel
@@ -210,23 +210,23 @@ int esmi_encoder_block_f32(const esmi_encoder_block_weights* w, const esmi_encod
     // proj + residual + LN1 + mask, blocks.py:65 + networks.py:73-75
     p = conv_defaults();
     p.B = B; p.n_in = n; p.c_in = h * C; p.n_out = n; p.c_out = C;
-    p.A = ctx; p.lda = h * C; p.W = w->proj_w; p.bias = w->proj_b;
+    p.A = ctx; p.lda = h * C; p.W = w->proj_w; p.Wp = w->proj_wp; p.bias = w->proj_b;
     p.res = x_out; p.ldr = C; p.ln_g = w->ln1_g; p.ln_b = w->ln1_b; p.rowmask = mask;
     p.out = y1; p.ldo = C;
     if ((rc = launch_convgemm(p, st))) return rc;
     // MixFFN, blocks.py:22-29
     p = conv_defaults();
     p.B = B; p.n_in = n; p.c_in = C; p.n_out = n; p.c_out = E;
-    p.A = y1; p.lda = C; p.W = w->mlp1_w; p.bias = w->mlp1_b; p.out = m1; p.ldo = E;
+    p.A = y1; p.lda = C; p.W = w->mlp1_w; p.Wp = w->mlp1_wp; p.bias = w->mlp1_b; p.out = m1; p.ldo = E;
     if ((rc = launch_convgemm(p, st))) return rc;
     p = conv_defaults();
     p.B = B; p.n_in = n; p.c_in = E; p.n_out = n; p.c_out = E; p.k = 3; p.pad = 1;
-    p.A = m1; p.lda = E; p.W = w->conv_w; p.bias = w->conv_b; p.act = ACT_GELU; p.out = m2; p.ldo = E;
+    p.A = m1; p.lda = E; p.W = w->conv_w; p.Wp = w->conv_wp; p.bias = w->conv_b; p.act = ACT_GELU; p.out = m2; p.ldo = E;
     if ((rc = launch_convgemm(p, st))) return rc;
     // mlp2 + residual + LN2 + mask, networks.py:80-83
     p = conv_defaults();
     p.B = B; p.n_in = n; p.c_in = E; p.n_out = n; p.c_out = C;
-    p.A = m2; p.lda = E; p.W = w->mlp2_w; p.bias = w->mlp2_b;
+    p.A = m2; p.lda = E; p.W = w->mlp2_w; p.Wp = w->mlp2_wp; p.bias = w->mlp2_b;
     p.res = y1; p.ldr = C; p.ln_g = w->ln2_g; p.ln_b = w->ln2_b; p.rowmask = mask;
     p.out = x_out; p.ldo = C;
     return launch_convgemm(p, st);
@@ -249,7 +249,7 @@ int esmi_fuse_f32(const esmi_fuse_weights* w, int depth, int dim, int kernel, in
         const int ci = dim << i, s = 1 << i;
         ConvGemmP p = conv_defaults();  // Linear(dim*2^i, dim), networks.py:197
         p.B = B; p.n_in = n_i[i]; p.c_in = ci; p.n_out = n_i[i]; p.c_out = dim;
-        p.A = feats[i]; p.lda = ci; p.W = w->mlp_w[i]; p.bias = w->mlp_b[i];
+        p.A = feats[i]; p.lda = ci; p.W = w->mlp_w[i]; p.Wp = w->mlp_wp[i]; p.bias = w->mlp_b[i];
         if (i == 0) {
             if (n_i[0] != T) return ESMI_ERR_ARG;
             p.out = cat; p.ldo = dim * depth; p.o_coff = 0;
@@ -268,7 +268,7 @@ int esmi_fuse_f32(const esmi_fuse_weights* w, int depth, int dim, int kernel, in
     }
     ConvGemmP p = conv_defaults();  // Linear(depth*dim, dim) + masked_fill, networks.py:215-217
     p.B = B; p.n_in = T; p.c_in = dim * depth; p.n_out = T; p.c_out = dim;
-    p.A = cat; p.lda = dim * depth; p.W = w->fuse_w; p.bias = w->fuse_b; p.rowmask = mask;
+    p.A = cat; p.lda = dim * depth; p.W = w->fuse_w; p.Wp = w->fuse_wp; p.bias = w->fuse_b; p.rowmask = mask;
     p.out = out; p.ldo = ld_out;
     return launch_convgemm(p, st);
 }
@@ -293,13 +293,13 @@ int esmi_variance_adaptor_f32(const esmi_predictor_weights* pitch, const esmi_pr
         // conv1 + ReLU -> LN1 -> ReLU, networks.py:152-155
         ConvGemmP p = conv_defaults();
         p.B = B; p.n_in = T; p.c_in = dim; p.n_out = T; p.c_out = dim; p.k = 3; p.pad = 1;
-        p.A = feat; p.lda = 4 * dim; p.a_coff = 0; p.W = pw[q]->conv1_w; p.bias = pw[q]->conv1_b; p.act = ACT_RELU;
+        p.A = feat; p.lda = 4 * dim; p.a_coff = 0; p.W = pw[q]->conv1_w; p.Wp = pw[q]->conv1_wp; p.bias = pw[q]->conv1_b; p.act = ACT_RELU;
         p.ln_g = pw[q]->ln1_g; p.ln_b = pw[q]->ln1_b; p.post_relu = 1; p.out = t1; p.ldo = dim;
         if ((rc = launch_convgemm(p, st))) return rc;
         // conv2 + ReLU; pred = Linear(dim,1) on the PRE-norm2 tensor (:157-160); duration: ReLU + features = LN2
         p = conv_defaults();
         p.B = B; p.n_in = T; p.c_in = dim; p.n_out = T; p.c_out = dim; p.k = 3; p.pad = 1;
-        p.A = t1; p.lda = dim; p.W = pw[q]->conv2_w; p.bias = pw[q]->conv2_b; p.act = ACT_RELU;
+        p.A = t1; p.lda = dim; p.W = pw[q]->conv2_w; p.Wp = pw[q]->conv2_wp; p.bias = pw[q]->conv2_b; p.act = ACT_RELU;
         p.dot_w = pw[q]->lin_w; p.dot_b = pw[q]->lin_b; p.dot_out = preds[q]; p.dot_relu = q == 2;
         if (q == 2) {
             p.ln_g = pw[q]->ln2_g; p.ln_b = pw[q]->ln2_b; p.rowmask = mask;   // :366-368
@@ -467,13 +467,13 @@ int esmi_acoustic_decoder_f32(const esmi_predictor_weights* w, int dim, int B, i
     hipStream_t st = S(stream);
     ConvGemmP p = conv_defaults();   // conv1 + ReLU -> LN1 -> ReLU, networks.py:152-155
     p.B = B; p.n_in = T; p.c_in = dim; p.n_out = T; p.c_out = dim; p.k = 3; p.pad = 1;
-    p.A = x; p.lda = ldx; p.W = w->conv1_w; p.bias = w->conv1_b; p.act = ACT_RELU;
+    p.A = x; p.lda = ldx; p.W = w->conv1_w; p.Wp = w->conv1_wp; p.bias = w->conv1_b; p.act = ACT_RELU;
     p.ln_g = w->ln1_g; p.ln_b = w->ln1_b; p.post_relu = 1; p.out = t1; p.ldo = dim;
     int rc = launch_convgemm(p, st);
     if (rc) return rc;
     p = conv_defaults();              // conv2 + ReLU; y = Linear(dim,1) on the PRE-norm2 tensor (:157-160); duration: ReLU + features = LN2
     p.B = B; p.n_in = T; p.c_in = dim; p.n_out = T; p.c_out = dim; p.k = 3; p.pad = 1;
-    p.A = t1; p.lda = dim; p.W = w->conv2_w; p.bias = w->conv2_b; p.act = ACT_RELU;
+    p.A = t1; p.lda = dim; p.W = w->conv2_w; p.Wp = w->conv2_wp; p.bias = w->conv2_b; p.act = ACT_RELU;
     p.dot_w = w->lin_w; p.dot_b = w->lin_b; p.dot_out = pred; p.dot_relu = duration != 0;
     if (duration) { p.ln_g = w->ln2_g; p.ln_b = w->ln2_b; p.out = features; p.ldo = dim; }
     return launch_convgemm(p, st);

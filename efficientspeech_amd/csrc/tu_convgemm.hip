@@ -15,6 +15,11 @@ ESMI_TU_RANGE_SETTER(convgemm)
 #endif
 #endif
 
+#ifdef ESMI_GEMM_TRACE
+namespace esmi { __device__ long long* g_gemm_trace_dev = nullptr; }
+extern "C" void esmi_dev_set_gemm_trace(long long* ptr) { hipMemcpyToSymbol(HIP_SYMBOL(esmi::g_gemm_trace_dev), &ptr, sizeof(ptr)); }
+#endif
+
 namespace esmi {
 
 ConvGemmP conv_defaults() {
@@ -50,22 +55,46 @@ int launch_convgemm(ConvGemmP p, hipStream_t st) {
 #if ESMI_CHAIN_SPLIT
     // large plain convolutions / Linears: weight tile staged through LDS once per 128 positions (convgemm.h)
     if (p.mode == MODE_CONV && p.stride == 1 && !p.ids && (p.c_in & 31) == 0 && p.c_out > 64 && (long)p.B * p.n_out >= ESMI_GEMM_LDS_MIN_ROWS) {
-        const int nl = full_row ? (nt <= 4 ? 4 : 8) : ((p.c_out & 255) == 0 ? 8 : 4);
-        constexpr int kRows = 32 * ESMI_GEMM_LDS_WAVES;
-        dim3 g2((unsigned)(p.B * ((p.n_out + kRows - 1) / kRows)), full_row ? 1 : (p.c_out + 32 * nl - 1) / (32 * nl));
+        // tile: 64 rows x 128 channels per wave (MT = 2, NT = 4) unless a LayerNorm / row-dot epilogue needs 256 channels in one wave
+        const bool wide = full_row && nt > 4;
+        if ((long)p.B * p.n_out >= (1L << 31)) return ESMI_ERR_ARG;
         constexpr int NWV = ESMI_GEMM_LDS_WAVES;
-        if (nl == 4 && !p.amp) {
-            ESMI_LAUNCH((convgemm_lds_kernel<4, NWV, false>), g2, dim3(64 * NWV), convgemm_lds_bytes<4>(), st, p);
-        } else if (nl == 4) {
-            ESMI_LAUNCH((convgemm_lds_kernel<4, NWV, true>), g2, dim3(64 * NWV), convgemm_lds_bytes<4>(), st, p);
+        const long rows = (long)p.B * p.n_out, wg_rows = (wide ? 32 : 64) * NWV;
+        dim3 g2((unsigned)((rows + wg_rows - 1) / wg_rows), full_row ? 1 : (p.c_out + 127) / 128);
+#ifndef ESMI_GEMM_MT
+#define ESMI_GEMM_MT 2
+#endif
+        constexpr int MT = ESMI_GEMM_MT;
+        const bool dma = !wide && p.n_in == p.n_out && ((long)p.B * p.n_in * p.lda + p.a_coff + p.c_in) < (1L << 31);   // LDS-DMA input rows
+        if (dma) {
+            const long wr = 32 * MT * NWV;
+            const int nx = (int)((rows + wr - 1) / wr), ny = full_row ? 1 : (p.c_out + 127) / 128;
+            dim3 g1((unsigned)((nx + 7) / 8 * 8 * ny));
+            const bool pre = p.Wp != nullptr && aligned16(p.Wp);
+            const int lds_bytes = convgemm_dma_bytes<4>(MT, p.k, p.dil, pre);
+            static AttrOnce once[4];
+#define ESMI_DMA_CASE(AMP_, PRE_, slot)                                                                                        \
+    do {                                                                                                                       \
+        if (int rc = raise_lds_limit(reinterpret_cast<const void*>(convgemm_dma_kernel<4, MT, NWV, AMP_, PRE_>), once[slot])) return rc; \
+        ESMI_LAUNCH((convgemm_dma_kernel<4, MT, NWV, AMP_, PRE_>), g1, dim3(64 * NWV), lds_bytes, st, p, nx, ny);              \
+    } while (0)
+            if (!p.amp && !pre) ESMI_DMA_CASE(false, false, 0);
+            else if (!p.amp) ESMI_DMA_CASE(false, true, 1);
+            else if (!pre) ESMI_DMA_CASE(true, false, 2);
+            else ESMI_DMA_CASE(true, true, 3);
+#undef ESMI_DMA_CASE
+        } else if (!wide && !p.amp) {
+            ESMI_LAUNCH((convgemm_lds_kernel<4, 2, NWV, false>), g2, dim3(64 * NWV), convgemm_lds_bytes<4>(), st, p);
+        } else if (!wide) {
+            ESMI_LAUNCH((convgemm_lds_kernel<4, 2, NWV, true>), g2, dim3(64 * NWV), convgemm_lds_bytes<4>(), st, p);
         } else if (!p.amp) {
             static AttrOnce once;
-            if (int rc = raise_lds_limit(reinterpret_cast<const void*>(convgemm_lds_kernel<8, NWV, false>), once)) return rc;
-            ESMI_LAUNCH((convgemm_lds_kernel<8, NWV, false>), g2, dim3(64 * NWV), convgemm_lds_bytes<8>(), st, p);
+            if (int rc = raise_lds_limit(reinterpret_cast<const void*>(convgemm_lds_kernel<8, 1, NWV, false>), once)) return rc;
+            ESMI_LAUNCH((convgemm_lds_kernel<8, 1, NWV, false>), g2, dim3(64 * NWV), convgemm_lds_bytes<8>(), st, p);
         } else {
             static AttrOnce once;
-            if (int rc = raise_lds_limit(reinterpret_cast<const void*>(convgemm_lds_kernel<8, NWV, true>), once)) return rc;
-            ESMI_LAUNCH((convgemm_lds_kernel<8, NWV, true>), g2, dim3(64 * NWV), convgemm_lds_bytes<8>(), st, p);
+            if (int rc = raise_lds_limit(reinterpret_cast<const void*>(convgemm_lds_kernel<8, 1, NWV, true>), once)) return rc;
+            ESMI_LAUNCH((convgemm_lds_kernel<8, 1, NWV, true>), g2, dim3(64 * NWV), convgemm_lds_bytes<8>(), st, p);
         }
         return launch_status();
     }
