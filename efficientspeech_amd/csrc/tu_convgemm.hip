@@ -61,27 +61,33 @@ int launch_convgemm(ConvGemmP p, hipStream_t st) {
         constexpr int NWV = ESMI_GEMM_LDS_WAVES;
         const long rows = (long)p.B * p.n_out, wg_rows = (wide ? 32 : 64) * NWV;
         dim3 g2((unsigned)((rows + wg_rows - 1) / wg_rows), full_row ? 1 : (p.c_out + 127) / 128);
-#ifndef ESMI_GEMM_MT
-#define ESMI_GEMM_MT 2
-#endif
-        constexpr int MT = ESMI_GEMM_MT;
         const bool dma = !wide && p.n_in == p.n_out && ((long)p.B * p.n_in * p.lda + p.a_coff + p.c_in) < (1L << 31);   // LDS-DMA input rows
         if (dma) {
-            const long wr = 32 * MT * NWV;
-            const int nx = (int)((rows + wr - 1) / wr), ny = full_row ? 1 : (p.c_out + 127) / 128;
+            // 64 rows per wave when that still gives every CU its two workgroups, else 32 (training at phoneme rate: 12,800 rows)
+            const int ny = full_row ? 1 : (p.c_out + 127) / 128;
+            const int mt = ((rows + 64 * NWV - 1) / (64 * NWV)) * ny >= 512 ? 2 : 1;
+            const long wr = 32 * mt * NWV;
+            const int nx = (int)((rows + wr - 1) / wr);
             dim3 g1((unsigned)((nx + 7) / 8 * 8 * ny));
             const bool pre = p.Wp != nullptr && aligned16(p.Wp);
-            const int lds_bytes = convgemm_dma_bytes<4>(MT, p.k, p.dil, pre);
-            static AttrOnce once[4];
-#define ESMI_DMA_CASE(AMP_, PRE_, slot)                                                                                        \
+            const int lds_bytes = convgemm_dma_bytes<4>(mt, p.k, p.dil, pre);
+            static AttrOnce once[8];
+#define ESMI_DMA_CASE(MT_, AMP_, PRE_, slot)                                                                                   \
     do {                                                                                                                       \
-        if (int rc = raise_lds_limit(reinterpret_cast<const void*>(convgemm_dma_kernel<4, MT, NWV, AMP_, PRE_>), once[slot])) return rc; \
-        ESMI_LAUNCH((convgemm_dma_kernel<4, MT, NWV, AMP_, PRE_>), g1, dim3(64 * NWV), lds_bytes, st, p, nx, ny);              \
+        if (int rc = raise_lds_limit(reinterpret_cast<const void*>(convgemm_dma_kernel<4, MT_, NWV, AMP_, PRE_>), once[slot])) return rc; \
+        ESMI_LAUNCH((convgemm_dma_kernel<4, MT_, NWV, AMP_, PRE_>), g1, dim3(64 * NWV), lds_bytes, st, p, nx, ny);             \
     } while (0)
-            if (!p.amp && !pre) ESMI_DMA_CASE(false, false, 0);
-            else if (!p.amp) ESMI_DMA_CASE(false, true, 1);
-            else if (!pre) ESMI_DMA_CASE(true, false, 2);
-            else ESMI_DMA_CASE(true, true, 3);
+            const int variant = (mt == 2 ? 4 : 0) + (p.amp ? 2 : 0) + (pre ? 1 : 0);
+            switch (variant) {
+                case 0: ESMI_DMA_CASE(1, false, false, 0); break;
+                case 1: ESMI_DMA_CASE(1, false, true, 1); break;
+                case 2: ESMI_DMA_CASE(1, true, false, 2); break;
+                case 3: ESMI_DMA_CASE(1, true, true, 3); break;
+                case 4: ESMI_DMA_CASE(2, false, false, 4); break;
+                case 5: ESMI_DMA_CASE(2, false, true, 5); break;
+                case 6: ESMI_DMA_CASE(2, true, false, 6); break;
+                default: ESMI_DMA_CASE(2, true, true, 7); break;
+            }
 #undef ESMI_DMA_CASE
         } else if (!wide && !p.amp) {
             ESMI_LAUNCH((convgemm_lds_kernel<4, 2, NWV, false>), g2, dim3(64 * NWV), convgemm_lds_bytes<4>(), st, p);
