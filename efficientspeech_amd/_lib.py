@@ -78,7 +78,8 @@ class HifiGanShape(C.Structure):
 
 class ConvDesc(C.Structure):
     """esmi_conv_desc (include/esmi.h): one convolution of the training step, checkpoint weight layout."""
-    _fields_ = [(n, C.c_int) for n in ("B", "n_in", "c_in", "n_out", "c_out", "k", "stride", "pad", "groups", "transposed", "precision")]
+    _fields_ = [(n, C.c_int) for n in ("B", "n_in", "c_in", "n_out", "c_out", "k", "stride", "pad", "groups", "transposed", "precision", "act")] + \
+               [("packed_fwd", C.c_void_p), ("packed_grad", C.c_void_p)]
 
 
 class ReduceItem(C.Structure):
@@ -151,7 +152,7 @@ EXPORTS = (
     "esmi_train_attention_bwd_f32", "esmi_train_embedding_fwd_f32", "esmi_train_embedding_bwd_f32", "esmi_train_mask_rows_f32",
     "esmi_train_add_f32", "esmi_train_copy_cols_f32", "esmi_train_repeat_fwd_f32", "esmi_train_repeat_bwd_f32",
     "esmi_train_loss_f32", "esmi_train_adamw_f32", "esmi_train_adamw_graph_f32", "esmi_train_conv_bwd_workspace_bytes",
-    "esmi_train_conv_bwd_f32", "esmi_train_reduce_flush_f32",
+    "esmi_train_conv_bwd_f32", "esmi_train_reduce_flush_f32", "esmi_train_pack_weights_f32",
 )
 
 
@@ -216,10 +217,11 @@ def bind(lib):
     lib.esmi_train_conv_bwd_workspace_bytes.restype = sz
     lib.esmi_train_conv_bwd_f32.argtypes = [P(ConvDesc), fp, fp, fp, fp, fp, fp, fp, sz, P(ReduceQueue), fp]
     lib.esmi_train_reduce_flush_f32.argtypes = [P(ReduceQueue), fp]
+    lib.esmi_train_pack_weights_f32.argtypes = [P(ConvDesc), P(C.c_void_p), i, fp]
     lib.esmi_train_layernorm_bwd_workspace_bytes.argtypes = [i64, i]
     lib.esmi_train_layernorm_bwd_workspace_bytes.restype = sz
-    lib.esmi_train_layernorm_fwd_f32.argtypes = [fp, fp, fp, i64, i, fp, fp, fp, fp]
-    lib.esmi_train_layernorm_bwd_f32.argtypes = [fp, fp, fp, fp, fp, i64, i, fp, fp, fp, fp, sz, P(ReduceQueue), fp]
+    lib.esmi_train_layernorm_fwd_f32.argtypes = [fp, fp, fp, i64, i, fp, fp, fp, fp, fp, fp, fp]
+    lib.esmi_train_layernorm_bwd_f32.argtypes = [fp, fp, fp, fp, fp, i64, i, fp, fp, fp, fp, sz, P(ReduceQueue), fp, fp]
     lib.esmi_train_act_fwd_f32.argtypes = [fp, i64, i, fp, fp]
     lib.esmi_train_act_bwd_f32.argtypes = [fp, fp, i64, i, fp, fp]
     lib.esmi_train_attention_fwd_f32.argtypes = [fp, i, i, i, i, fp, fp, fp]

@@ -339,6 +339,22 @@ static __global__ __launch_bounds__(64 * kReduceGroups) void train_reduce_chunks
         else out[q] = t;
     }
 }
+// tap-major GEMM copies of many weights in one launch (blockIdx.y = item): what pack_conv_kernel does per convolution
+struct PackItem { const float* src; float* dst; int* zero_slot; int cout, cin, k, transposed, flip; };
+constexpr int kPackBatch = 64;
+struct PackBatch { int count; PackItem items[kPackBatch]; };
+static __global__ void train_pack_batch_kernel(const PackBatch b) {
+    const PackItem& it = b.items[blockIdx.y];
+    if (it.zero_slot && blockIdx.x == 0 && threadIdx.x == 0) it.zero_slot[0] = 0;
+    const long n = (long)it.cout * it.cin * it.k;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
+        const int i = (int)(e % it.cin);
+        const int o = (int)((e / it.cin) % it.cout);
+        const int j = (int)(e / ((long)it.cin * it.cout));
+        const int js = it.flip ? it.k - 1 - j : j;
+        it.dst[e] = it.transposed ? it.src[((long)i * it.cout + o) * it.k + js] : it.src[((long)o * it.cin + i) * it.k + js];
+    }
+}
 // the same for a batch of independent reductions in one launch (blockIdx.y = item): the queued second stages of a training step
 struct ReduceItem { const float* partial; long n, stride, chunks; float* out; long n0; float* out1; };
 constexpr int kReduceBatch = 48;
@@ -379,28 +395,43 @@ __device__ __forceinline__ float ln_wave_sum(float v) {
     for (int m = 32; m > 0; m >>= 1) v += shfl_xor_f(v, m);
     return v;
 }
+// res != NULL: the normalised tensor is x + res, written to `xsum` for the backward (LN(f(x) + x), networks.py:75,83,301);
+// rowmask[r] != 0: the output row is zero (masked_fill after the norm, networks.py:76,84) -- the backward kernels take the same mask
 static __global__ __launch_bounds__(256) void train_ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ g,
                                                            const float* __restrict__ b, long rows, int C, float eps,
-                                                           float* __restrict__ y, float* __restrict__ mean, float* __restrict__ rstd) {
+                                                           float* __restrict__ y, float* __restrict__ mean, float* __restrict__ rstd,
+                                                           const float* __restrict__ res, float* __restrict__ xsum,
+                                                           const unsigned char* __restrict__ rowmask) {
     const long r = (long)blockIdx.x * 4 + wave_id();
     if (r >= rows) return;
     const int lane = lane_id();
     const float* xr = x + r * C;
     float m = 0.0f;
-    for (int c = lane; c < C; c += 64) m += xr[c];
+    if (res) {   // this lane re-reads only what it wrote
+        for (int c = lane; c < C; c += 64) { const float v = xr[c] + res[r * C + c]; xsum[r * C + c] = v; m += v; }
+        xr = xsum + r * C;
+    } else {
+        for (int c = lane; c < C; c += 64) m += xr[c];
+    }
     m = ln_wave_sum(m) / (float)C;
     float v = 0.0f;
     for (int c = lane; c < C; c += 64) { const float dlt = xr[c] - m; v = fmaf(dlt, dlt, v); }
     const float rs = 1.0f / sqrtf(ln_wave_sum(v) / (float)C + eps);
     if (lane == 0) { mean[r] = m; rstd[r] = rs; }
-    for (int c = lane; c < C; c += 64) y[r * C + c] = fmaf((xr[c] - m) * rs, g[c], b[c]);
+    const bool masked = rowmask && rowmask[r];
+    for (int c = lane; c < C; c += 64) y[r * C + c] = masked ? 0.0f : fmaf((xr[c] - m) * rs, g[c], b[c]);
 }
 static __global__ __launch_bounds__(256) void train_ln_bwd_dx_kernel(const float* __restrict__ x, const float* __restrict__ g,
                                                               const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                              const float* __restrict__ dy, long rows, int C, float* __restrict__ dx) {
+                                                              const float* __restrict__ dy, long rows, int C, float* __restrict__ dx,
+                                                              const unsigned char* __restrict__ rowmask) {
     const long r = (long)blockIdx.x * 4 + wave_id();
     if (r >= rows) return;
     const int lane = lane_id();
+    if (rowmask && rowmask[r]) {   // the forward zeroed this row: no gradient passes
+        for (int c = lane; c < C; c += 64) dx[r * C + c] = 0.0f;
+        return;
+    }
     const float m = mean[r], rs = rstd[r];
     float s1 = 0.0f, s2 = 0.0f;
     for (int c = lane; c < C; c += 64) {
@@ -422,7 +453,8 @@ constexpr int kLnRows = 64;
 static __global__ __launch_bounds__(256) void train_ln_bwd_fused_kernel(const float* __restrict__ x, const float* __restrict__ g,
                                                                  const float* __restrict__ mean, const float* __restrict__ rstd,
                                                                  const float* __restrict__ dy, long rows, int C,
-                                                                 float* __restrict__ dx, float* __restrict__ partial) {
+                                                                 float* __restrict__ dx, float* __restrict__ partial,
+                                                                 const unsigned char* __restrict__ rowmask) {
     ESMI_DYN_LDS(red);   // [4 waves][2][256] floats
     const long chunk = blockIdx.x;
     const int lane = lane_id(), w = wave_id();
@@ -434,12 +466,13 @@ static __global__ __launch_bounds__(256) void train_ln_bwd_fused_kernel(const fl
     for (int u = 0; u < 4; ++u) gg[u] = lane + 64 * u < C ? g[lane + 64 * u] : 0.0f;
     for (long r = r0; r < r1; ++r) {
         const float m = mean[r], rs = rstd[r];
+        const bool masked = rowmask && rowmask[r];   // (a zero dy row: dx = 0, no contribution to dgamma / dbeta)
         float xh[4], dh[4], s1 = 0.0f, s2 = 0.0f;
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int c = lane + 64 * u;
             const bool ok = c < C;
-            const float d = ok ? dy[r * C + c] : 0.0f;
+            const float d = (ok && !masked) ? dy[r * C + c] : 0.0f;
             xh[u] = ok ? (x[r * C + c] - m) * rs : 0.0f;
             dh[u] = d * gg[u];
             s1 += dh[u];
@@ -470,13 +503,14 @@ static __global__ __launch_bounds__(256) void train_ln_bwd_fused_kernel(const fl
 
 // partial[chunk][0][c] = sum dy * xhat, partial[chunk][1][c] = sum dy over the chunk's rows
 static __global__ void train_ln_bwd_params_kernel(const float* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ rstd,
-                                           const float* __restrict__ dy, long rows, int C, float* __restrict__ partial) {
+                                           const float* __restrict__ dy, long rows, int C, float* __restrict__ partial,
+                                           const unsigned char* __restrict__ rowmask) {
     const int c = (int)(blockIdx.x * blockDim.x + threadIdx.x);
     if (c >= C) return;
     const long r0 = (long)blockIdx.y * kTrainChunk, r1 = r0 + kTrainChunk < rows ? r0 + kTrainChunk : rows;
     float a = 0.0f, s = 0.0f;
     for (long r = r0; r < r1; ++r) {
-        const float d = dy[r * C + c];
+        const float d = (rowmask && rowmask[r]) ? 0.0f : dy[r * C + c];
         a = fmaf(d, (x[r * C + c] - mean[r]) * rstd[r], a);
         s += d;
     }

@@ -71,29 +71,38 @@ size_t esmi_train_conv_workspace_bytes(const esmi_conv_desc* d) {
     return align256((size_t)c.k * c.c_out * c.c_in * sizeof(float)) + 256;   // + the data gradient's absmax / scale slots
 }
 namespace {
-// one of the two implicit-GEMM problems of a dense conv: returns ESMI_ERR_UNSUPPORTED when the GEMM does not take the shape
-// (have_absmax: max|in| already sits in the workspace's absmax slot -- the weight-gradient pass of esmi_train_conv_bwd_f32 left it)
-int train_conv_gemm(const ConvDesc& c, bool grad, const float* in, const float* w, const float* bias, float* out, float* wt,
-                    bool amp, hipStream_t st, bool have_absmax = false, bool pack_only = false) {
-    const int cin = grad ? c.c_out : c.c_in, cout = grad ? c.c_in : c.c_out;      // of the GEMM problem
-    if (c.groups != 1 || (cin & 7) || !wt) return ESMI_ERR_UNSUPPORTED;
-    if (cout == 1 && (grad != (c.transposed != 0) || c.stride != 1)) return ESMI_ERR_UNSUPPORTED;   // the one-channel kernel is a plain conv
-    const long n = (long)c.k * c.c_out * c.c_in;
+// how the GEMM of one direction reads the weight tensor: (supported, needs a copy, read as ConvTranspose1d, taps flipped)
+struct GemmWeight { bool ok, copy; int as_convT; bool flipped; int cin, cout; };
+GemmWeight gemm_weight(const ConvDesc& c, bool grad) {
+    GemmWeight g;
+    g.cin = grad ? c.c_out : c.c_in; g.cout = grad ? c.c_in : c.c_out;      // of the GEMM problem
+    g.ok = c.groups == 1 && !(g.cin & 7) && !(g.cout == 1 && (grad != (c.transposed != 0) || c.stride != 1));   // the one-channel kernel is a plain conv
     // tap-major (k, cout, cin) of the problem: forward conv / grad of convT read the tensor as Conv1d, the other two as ConvTranspose1d
-    const int as_convT = (grad != (c.transposed != 0)) ? 1 : 0;
+    g.as_convT = (grad != (c.transposed != 0)) ? 1 : 0;
     // a stride-1 transposed convolution is a plain convolution with the taps reversed and padding k - 1 - pad: packed that way it
     // takes the LDS-staged GEMM kernel (MODE_CONV only) like the forward problem does
-    const bool as_flipped_conv = as_convT && c.stride == 1 && c.k - 1 - c.pad >= 0;
+    g.flipped = g.as_convT && c.stride == 1 && c.k - 1 - c.pad >= 0;
+    g.copy = !(c.k == 1 && !g.as_convT && !grad);   // a Linear's (Cout, Cin) IS its tap-major form
+    return g;
+}
+// one of the two implicit-GEMM problems of a dense conv: returns ESMI_ERR_UNSUPPORTED when the GEMM does not take the shape
+// (have_absmax: max|in| already sits in the workspace's absmax slot -- the weight-gradient pass of esmi_train_conv_bwd_f32 left it)
+// prepacked: `wt` already holds this step's copy (esmi_train_pack_weights_f32, which also cleared the absmax slot)
+int train_conv_gemm(const ConvDesc& c, bool grad, const float* in, const float* w, const float* bias, float* out, float* wt,
+                    bool amp, hipStream_t st, bool have_absmax = false, bool pack_only = false, bool prepacked = false, int act = 0) {
+    const GemmWeight g = gemm_weight(c, grad);
+    if (!g.ok || !wt) return ESMI_ERR_UNSUPPORTED;
+    const int cin = g.cin, cout = g.cout, as_convT = g.as_convT;
+    const bool as_flipped_conv = g.flipped;
+    const long n = (long)c.k * c.c_out * c.c_in;
     int* amax = reinterpret_cast<int*>(reinterpret_cast<char*>(wt) + align256((size_t)n * sizeof(float)));
     const float* wuse = wt;
-    if (c.k == 1 && !as_convT && !grad) {
-        wuse = w;                                   // a Linear's (Cout, Cin) IS its tap-major form: no copy
-    } else {
-        if (!have_absmax) {   // (with have_absmax the pack ran in the pack_only call that preceded the weight-gradient pass)
-            ESMI_LAUNCH(pack_conv_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, w, wt, cout, cin, c.k, as_convT, grad ? amax : nullptr,
-                        as_flipped_conv ? 1 : 0);
-            if (int rc = launch_status()) return rc;
-        }
+    if (!g.copy) {
+        wuse = w;                                   // no copy
+    } else if (!have_absmax && !prepacked) {   // (with have_absmax the pack ran in the pack_only call that preceded the weight-gradient pass)
+        ESMI_LAUNCH(pack_conv_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, w, wt, cout, cin, c.k, as_convT, grad ? amax : nullptr,
+                    as_flipped_conv ? 1 : 0);
+        if (int rc = launch_status()) return rc;
     }
     if (pack_only) return ESMI_OK;
     ConvGemmP p = conv_defaults();
@@ -110,34 +119,74 @@ int train_conv_gemm(const ConvDesc& c, bool grad, const float* in, const float* 
     p.B = c.B; p.n_in = grad ? c.n_out : c.n_in; p.n_out = grad ? c.n_in : c.n_out; p.c_in = cin; p.c_out = cout;
     p.A = in; p.lda = cin; p.W = wuse; p.bias = bias; p.out = out; p.ldo = cout;
     p.amp = amp ? 1 : 0;
+    p.act = act;
     return launch_convgemm(p, st);
 }
 }  // namespace
 
+int esmi_train_pack_weights_f32(const esmi_conv_desc* descs, const float* const* weights, int n, esmi_stream_t stream) {
+    if (n < 0 || (n > 0 && (!descs || !weights))) return ESMI_ERR_ARG;
+    PackBatch b;
+    b.count = 0;
+    long nmax = 0;
+    auto flush = [&]() -> int {
+        if (!b.count) return ESMI_OK;
+        const long blocks = (nmax + 255) / 256;
+        ESMI_LAUNCH(train_pack_batch_kernel, dim3((unsigned)(blocks > 256 ? 256 : blocks), (unsigned)b.count), dim3(256), 0, S(stream), b);
+        b.count = 0; nmax = 0;
+        return launch_status();
+    };
+    for (int i = 0; i < n; ++i) {
+        ConvDesc c;
+        esmi_conv_desc d = descs[i];
+        d.B = d.n_in = d.n_out = 1;                 // (only the weight's shape matters here)
+        if (int rc = conv_desc_ok(&d, &c)) return rc;
+        if (!weights[i]) return ESMI_ERR_ARG;
+        const long nw = (long)c.k * c.c_out * c.c_in;
+        for (int grad = 0; grad < 2; ++grad) {
+            float* dst = grad ? d.packed_grad : d.packed_fwd;
+            if (!dst) continue;
+            const GemmWeight g = gemm_weight(c, grad != 0);
+            if (!g.ok || !g.copy) continue;         // the direction does not run as a GEMM / reads the tensor as it is
+            int* amax = reinterpret_cast<int*>(reinterpret_cast<char*>(dst) + align256((size_t)nw * sizeof(float)));
+            b.items[b.count++] = PackItem{weights[i], dst, grad ? amax : nullptr, g.cout, g.cin, c.k, g.as_convT, g.flipped ? 1 : 0};
+            nmax = nw > nmax ? nw : nmax;
+            if (b.count == kPackBatch) if (int rc = flush()) return rc;
+        }
+    }
+    return flush();
+}
 int esmi_train_conv_fwd_f32(const esmi_conv_desc* d, const float* x, const float* w, const float* bias, float* y, void* workspace,
                             size_t workspace_bytes, esmi_stream_t stream) {
     ConvDesc c;
     if (int rc = conv_desc_ok(d, &c)) return rc;
-    if (!x || !w || !y) return ESMI_ERR_ARG;
-    if (workspace && workspace_bytes >= esmi_train_conv_workspace_bytes(d)) {
-        const int rc = train_conv_gemm(c, false, x, w, bias, y, static_cast<float*>(workspace), d->precision == 16, S(stream));
+    if (!x || !w || !y || d->act < 0 || d->act > ACT_TANH) return ESMI_ERR_ARG;
+    if (d->packed_fwd || (workspace && workspace_bytes >= esmi_train_conv_workspace_bytes(d))) {
+        float* wt = d->packed_fwd ? d->packed_fwd : static_cast<float*>(workspace);
+        const int rc = train_conv_gemm(c, false, x, w, bias, y, wt, d->precision == 16, S(stream), false, false, d->packed_fwd != nullptr, d->act);
         if (rc != ESMI_ERR_UNSUPPORTED) return rc;
     }
     const long n = (long)c.B * c.n_out * c.c_out;
     if (wgrad_depthwise(c) && c.stride == 1 && (c.c_out & 3) == 0) {
         ESMI_LAUNCH(train_conv_dw_kernel, grid1d(n / 4), dim3(256), 0, S(stream), c, x, w, bias, y, 0);
+    } else {
+        ESMI_LAUNCH(train_conv_fwd_kernel, grid1d(n), dim3(256), 0, S(stream), c, x, w, bias, y);
+    }
+    if (int rc = launch_status()) return rc;
+    if (d->act) {   // the plain kernels have no epilogue: the activation as its own launch, in place
+        ESMI_LAUNCH(train_act_fwd_kernel, grid1d(n), dim3(256), 0, S(stream), y, n, d->act, y);
         return launch_status();
     }
-    ESMI_LAUNCH(train_conv_fwd_kernel, grid1d(n), dim3(256), 0, S(stream), c, x, w, bias, y);
-    return launch_status();
+    return ESMI_OK;
 }
 int esmi_train_conv_dgrad_f32(const esmi_conv_desc* d, const float* dy, const float* w, float* dx, void* workspace,
                               size_t workspace_bytes, esmi_stream_t stream) {
     ConvDesc c;
     if (int rc = conv_desc_ok(d, &c)) return rc;
     if (!dy || !w || !dx) return ESMI_ERR_ARG;
-    if (workspace && workspace_bytes >= esmi_train_conv_workspace_bytes(d)) {
-        const int rc = train_conv_gemm(c, true, dy, w, nullptr, dx, static_cast<float*>(workspace), d->precision == 16, S(stream));
+    if (d->packed_grad || (workspace && workspace_bytes >= esmi_train_conv_workspace_bytes(d))) {
+        float* wt = d->packed_grad ? d->packed_grad : static_cast<float*>(workspace);
+        const int rc = train_conv_gemm(c, true, dy, w, nullptr, dx, wt, d->precision == 16, S(stream), false, false, d->packed_grad != nullptr);
         if (rc != ESMI_ERR_UNSUPPORTED) return rc;
     }
     const long n = (long)c.B * c.n_in * c.c_in;
@@ -205,11 +254,12 @@ int esmi_train_conv_bwd_f32(const esmi_conv_desc* d, const float* x, const float
     if (workspace_bytes < esmi_train_conv_bwd_workspace_bytes(d)) return ESMI_ERR_WORKSPACE;
     const size_t wg_bytes = align256(esmi_train_conv_wgrad_workspace_bytes(d)), gemm_bytes = esmi_train_conv_workspace_bytes(d);
     char* ws = static_cast<char*>(workspace);
-    float* wt = reinterpret_cast<float*>(ws + wg_bytes);
+    const bool pre = d->packed_grad != nullptr;
+    float* wt = pre ? d->packed_grad : reinterpret_cast<float*>(ws + wg_bytes);
     // dense shapes whose two gradients both run on the matrix pipe: tap-major weight copy (zeroes the absmax slot) -> weight gradient
     // (leaves max|dy| in the slot) -> data-gradient GEMM scaled by it.  Everything else: the two stand-alone entry points.
     const bool fused = gemm_bytes > 0 && wgrad_on_mfma(c) &&
-                       train_conv_gemm(c, true, dy, w, nullptr, dx, wt, d->precision == 16, S(stream), false, true) == ESMI_OK;
+                       train_conv_gemm(c, true, dy, w, nullptr, dx, wt, d->precision == 16, S(stream), false, true, pre) == ESMI_OK;
     if (!fused) {
         if (int rc = esmi_train_conv_dgrad_f32(d, dy, w, dx, gemm_bytes ? wt : nullptr, gemm_bytes, stream)) return rc;
         return conv_wgrad_impl(d, x, dy, dw, dbias, workspace, wg_bytes, defer, stream);
@@ -227,12 +277,12 @@ int esmi_train_conv_bwd_f32(const esmi_conv_desc* d, const float* x, const float
                 dbias ? pb : nullptr, chunks, ps, amax);
     if (int rc = launch_status()) return rc;
     if (int rc = reduce_or_defer(defer, part, dbias ? ps : nw, ps, (chunks + 3) / 4, dw, nw, dbias, S(stream))) return rc;
-    return train_conv_gemm(c, true, dy, w, nullptr, dx, wt, d->precision == 16, S(stream), true);
+    return train_conv_gemm(c, true, dy, w, nullptr, dx, wt, d->precision == 16, S(stream), true, false, pre);
 }
 int esmi_train_layernorm_fwd_f32(const float* x, const float* g, const float* b, int64_t rows, int C, float* y, float* mean,
-                                 float* rstd, esmi_stream_t stream) {
-    if (!x || !g || !b || !y || !mean || !rstd || rows <= 0 || C <= 0) return ESMI_ERR_ARG;
-    ESMI_LAUNCH(train_ln_fwd_kernel, grid1d(rows, 4), dim3(256), 0, S(stream), x, g, b, (long)rows, C, 1e-5f, y, mean, rstd);
+                                 float* rstd, const float* res, float* xsum, const uint8_t* rowmask, esmi_stream_t stream) {
+    if (!x || !g || !b || !y || !mean || !rstd || rows <= 0 || C <= 0 || (res && !xsum)) return ESMI_ERR_ARG;
+    ESMI_LAUNCH(train_ln_fwd_kernel, grid1d(rows, 4), dim3(256), 0, S(stream), x, g, b, (long)rows, C, 1e-5f, y, mean, rstd, res, xsum, rowmask);
     return launch_status();
 }
 size_t esmi_train_layernorm_bwd_workspace_bytes(int64_t rows, int C) {
@@ -241,20 +291,20 @@ size_t esmi_train_layernorm_bwd_workspace_bytes(int64_t rows, int C) {
 }
 int esmi_train_layernorm_bwd_f32(const float* x, const float* g, const float* mean, const float* rstd, const float* dy,
                                  int64_t rows, int C, float* dx, float* dg, float* db, void* workspace, size_t workspace_bytes,
-                                 esmi_reduce_queue* defer, esmi_stream_t stream) {
+                                 esmi_reduce_queue* defer, const uint8_t* rowmask, esmi_stream_t stream) {
     if (!x || !g || !mean || !rstd || !dy || !dx || !dg || !db || !workspace || rows <= 0 || C <= 0) return ESMI_ERR_ARG;
     if (workspace_bytes < esmi_train_layernorm_bwd_workspace_bytes(rows, C)) return ESMI_ERR_WORKSPACE;
     float* part = static_cast<float*>(workspace);
     long chunks;
     if (C <= 256) {   // dx and the parameter partials in one pass
         chunks = train_chunks(rows, kLnRows);
-        ESMI_LAUNCH(train_ln_bwd_fused_kernel, dim3((unsigned)chunks), dim3(256), 4 * 2 * 256 * sizeof(float), S(stream), x, g, mean, rstd, dy, (long)rows, C, dx, part);
+        ESMI_LAUNCH(train_ln_bwd_fused_kernel, dim3((unsigned)chunks), dim3(256), 4 * 2 * 256 * sizeof(float), S(stream), x, g, mean, rstd, dy, (long)rows, C, dx, part, rowmask);
         if (int rc = launch_status()) return rc;
     } else {
         chunks = train_chunks(rows);
-        ESMI_LAUNCH(train_ln_bwd_dx_kernel, grid1d(rows, 4), dim3(256), 0, S(stream), x, g, mean, rstd, dy, (long)rows, C, dx);
+        ESMI_LAUNCH(train_ln_bwd_dx_kernel, grid1d(rows, 4), dim3(256), 0, S(stream), x, g, mean, rstd, dy, (long)rows, C, dx, rowmask);
         if (int rc = launch_status()) return rc;
-        ESMI_LAUNCH(train_ln_bwd_params_kernel, dim3(grid1d(C, 64), (unsigned)chunks), dim3(64), 0, S(stream), x, mean, rstd, dy, (long)rows, C, part);
+        ESMI_LAUNCH(train_ln_bwd_params_kernel, dim3(grid1d(C, 64), (unsigned)chunks), dim3(64), 0, S(stream), x, mean, rstd, dy, (long)rows, C, part, rowmask);
         if (int rc = launch_status()) return rc;
     }
     return reduce_or_defer(defer, part, 2L * C, 2L * C, chunks, dg, (long)C, db, S(stream));   // partial rows are [dg (C) | db (C)]: two outputs

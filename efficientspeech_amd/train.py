@@ -46,6 +46,7 @@ def _defer(ws, *direct):
 
 
 _DIRECT_GRADS = False     # True only while TrainStep._body runs: ONE backward per zeroed buffer, so overwriting == accumulating
+_PACKED_VALID = False     # True only while TrainStep._fwd_bwd runs, after its pack launch: `param._esmi_packed` holds this step's GEMM copies
 
 
 def _grad_buffer(param):
@@ -65,28 +66,38 @@ class _Conv(torch.autograd.Function):
     """Conv1d / ConvTranspose1d / Linear on channels-last (B, n, C); `w` in checkpoint layout (Linear: (Cout, Cin))."""
 
     @staticmethod
-    def forward(ctx, x, w, b, stride, pad, groups, transposed, n_out):
+    def forward(ctx, x, w, b, stride, pad, groups, transposed, n_out, act=0):
+        """act: ReLU / tanh applied to the result inside the convolution's launch (`esmi_conv_desc.act`); their derivatives come
+        from the saved output, so the backward is act' then the convolution's."""
+        assert act in (0, ACT_RELU, ACT_TANH)
         w0 = w
         x, w = x.contiguous(), w.contiguous()
         lib, st = _rt(x)
         B, n_in, c_in = x.shape
         w3 = w if w.dim() == 3 else w.unsqueeze(-1)
         c_out, k = (w3.shape[1] if transposed else w3.shape[0]), w3.shape[2]
-        d = _lib.ConvDesc(B, n_in, c_in, n_out, c_out, k, stride, pad, groups, 1 if transposed else 0, 16 if PRECISION == 16 else 0)
+        d = _lib.ConvDesc(B, n_in, c_in, n_out, c_out, k, stride, pad, groups, 1 if transposed else 0, 16 if PRECISION == 16 else 0, act)
+        packed = getattr(w0, "_esmi_packed", None) if (_PACKED_VALID and USE_MATRIX_PIPE) else None
+        if packed is not None:                  # this step's GEMM copies, made by TrainStep's one pack launch
+            d.packed_fwd, d.packed_grad = _ptr(packed[0]), (_ptr(packed[1]) if USE_MATRIX_PIPE_DGRAD else None)
         y = _new((B, n_out, c_out), x)
-        nws = lib.esmi_train_conv_workspace_bytes(C.byref(d)) if USE_MATRIX_PIPE else 0
+        nws = lib.esmi_train_conv_workspace_bytes(C.byref(d)) if (USE_MATRIX_PIPE and packed is None) else 0
         ws = _new((nws,), x, torch.uint8) if nws else None
         lib.esmi_train_conv_fwd_f32(C.byref(d), _ptr(x), _ptr(w), _ptr(b), _ptr(y), _ptr(ws), nws, st)
-        ctx.save_for_backward(x, w)
+        ctx.save_for_backward(x, w, *((y,) if act else ()))
         ctx.d, ctx.params = d, (w0, b)          # the Parameter objects themselves: their flat gradient views are the outputs
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, w = ctx.saved_tensors
+        x, w = ctx.saved_tensors[:2]
         dy = dy.contiguous()
         lib, st = _rt(dy)
         d = ctx.d
+        if d.act:
+            da = torch.empty_like(dy)
+            lib.esmi_train_act_bwd_f32(_ptr(ctx.saved_tensors[2]), _ptr(dy), dy.numel(), d.act, _ptr(da), st)
+            dy = da
         dx = torch.empty_like(x)
         w0, b0 = ctx.params
         dw, w_direct = _grad_buffer(w0)
@@ -102,24 +113,32 @@ class _Conv(torch.autograd.Function):
             nws = lib.esmi_train_conv_wgrad_workspace_bytes(C.byref(d))
             ws = _new((nws,), w, torch.uint8)
             lib.esmi_train_conv_wgrad_f32(C.byref(d), _ptr(x), _ptr(dy), _ptr(dw), _ptr(db), _ptr(ws), nws, st)
-        return dx, (None if w_direct else dw), (None if b_direct else db), None, None, None, None, None
+        return dx, (None if w_direct else dw), (None if b_direct else db), None, None, None, None, None, None
 
 
 class _LayerNorm(torch.autograd.Function):
+    """LayerNorm over the last dim -- optionally of x + res (both summands get the backward's dx) and with padded rows zeroed
+    afterwards (`mask` (rows) uint8; those rows pass no gradient): the add and the masked_fill ride in the norm's launches."""
+
     @staticmethod
-    def forward(ctx, x, g, b):
+    def forward(ctx, x, g, b, res=None, mask=None):
         x = x.contiguous()
         lib, st = _rt(x)
         rows, Cc = x.numel() // x.shape[-1], x.shape[-1]
         y, mean, rstd = torch.empty_like(x), _new((rows,), x), _new((rows,), x)
-        lib.esmi_train_layernorm_fwd_f32(_ptr(x), _ptr(g), _ptr(b), rows, Cc, _ptr(y), _ptr(mean), _ptr(rstd), st)
-        ctx.save_for_backward(x, g, mean, rstd)
-        ctx.params = (g, b)
+        xs = x
+        if res is not None:
+            res, xs = res.contiguous(), torch.empty_like(x)
+        lib.esmi_train_layernorm_fwd_f32(_ptr(x), _ptr(g), _ptr(b), rows, Cc, _ptr(y), _ptr(mean), _ptr(rstd), _ptr(res),
+                                         _ptr(xs) if res is not None else None, _ptr(mask), st)
+        ctx.save_for_backward(xs, g, mean, rstd, *((mask,) if mask is not None else ()))
+        ctx.params, ctx.has_res = (g, b), res is not None
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, g, mean, rstd = ctx.saved_tensors
+        x, g, mean, rstd = ctx.saved_tensors[:4]
+        mask = ctx.saved_tensors[4] if len(ctx.saved_tensors) > 4 else None
         dy = dy.contiguous()
         lib, st = _rt(dy)
         rows, Cc = x.numel() // x.shape[-1], x.shape[-1]
@@ -128,8 +147,8 @@ class _LayerNorm(torch.autograd.Function):
         nws = lib.esmi_train_layernorm_bwd_workspace_bytes(rows, Cc)
         ws = _new((nws,), x, torch.uint8)
         lib.esmi_train_layernorm_bwd_f32(_ptr(x), _ptr(g), _ptr(mean), _ptr(rstd), _ptr(dy), rows, Cc, _ptr(dx), _ptr(dg), _ptr(db),
-                                         _ptr(ws), nws, _defer(ws, g_direct, b_direct), st)
-        return dx, (None if g_direct else dg), (None if b_direct else db)
+                                         _ptr(ws), nws, _defer(ws, g_direct, b_direct), _ptr(mask), st)
+        return dx, (None if g_direct else dg), (None if b_direct else db), (dx if ctx.has_res else None), None
 
 
 class _Act(torch.autograd.Function):
@@ -329,18 +348,18 @@ def loss_vector(parts, total):
     return torch.cat([parts.detach(), total.detach().reshape(1)])
 
 
-def conv(x, m, n_out=None):
-    """Apply an nn.Conv1d / nn.ConvTranspose1d / nn.Linear parameter container to channels-last x."""
+def conv(x, m, n_out=None, act=0):
+    """Apply an nn.Conv1d / nn.ConvTranspose1d / nn.Linear parameter container to channels-last x (+ ReLU / tanh in the same launch)."""
     if isinstance(m, torch.nn.Linear):
-        return _Conv.apply(x, m.weight, m.bias, 1, 0, 1, False, x.shape[1])
+        return _Conv.apply(x, m.weight, m.bias, 1, 0, 1, False, x.shape[1], act)
     tr = isinstance(m, torch.nn.ConvTranspose1d)
     k, s, p = m.kernel_size[0], m.stride[0], m.padding[0]
     full = (x.shape[1] - 1) * s - 2 * p + k if tr else (x.shape[1] + 2 * p - k) // s + 1
-    return _Conv.apply(x, m.weight, m.bias, s, p, m.groups, tr, full if n_out is None else min(full, n_out))
+    return _Conv.apply(x, m.weight, m.bias, s, p, m.groups, tr, full if n_out is None else min(full, n_out), act)
 
 
-def layer_norm(x, m):
-    return _LayerNorm.apply(x, m.weight, m.bias)
+def layer_norm(x, m, res=None, mask=None):
+    return _LayerNorm.apply(x, m.weight, m.bias, res, mask)
 
 
 def act(x, kind):
@@ -368,13 +387,9 @@ def encoder_forward(enc, phoneme, mask_u8):
         x = conv(conv(x, merge3), merge1)
         m = _pooled_mask(mask_u8, T, T, x.shape[1]) if mask_u8 is not None else None
         y = conv(_AttnCore.apply(conv(x, attn.qkv), attn.num_heads), attn.proj)
-        x = layer_norm(_Add.apply(y, x), norm1)
-        if m is not None:
-            x = _MaskRows.apply(x, m)
+        x = layer_norm(y, norm1, res=x, mask=m)                  # LN(attn(x) + x), padded positions zeroed: one launch
         y = conv(act(conv(conv(x, ffn.mlp1), ffn.conv), ACT_GELU), ffn.mlp2)
-        x = layer_norm(_Add.apply(y, x), norm2)
-        if m is not None:
-            x = _MaskRows.apply(x, m)
+        x = layer_norm(y, norm2, res=x, mask=m)
         feats.append(x)
     return feats
 
@@ -394,12 +409,12 @@ def fuse_forward(fuse, feats, mask_u8):
 
 def predictor_forward(dec, fused):
     """AcousticDecoder.forward, networks.py:151-165 -> (pred (B, T, 1), features (B, T, dim))."""
-    y = act(conv(fused, dec.conv1[0]), ACT_RELU)
+    y = conv(fused, dec.conv1[0], act=ACT_RELU)
     y = act(layer_norm(y, dec.norm1), ACT_RELU)
-    y = act(conv(y, dec.conv2[0]), ACT_RELU)
-    pred = conv(y, dec.linear)
+    y = conv(y, dec.conv2[0], act=ACT_RELU)
     if dec.duration:
-        return act(pred, ACT_RELU), layer_norm(y, dec.norm2)
+        return conv(y, dec.linear, act=ACT_RELU), layer_norm(y, dec.norm2)
+    pred = conv(y, dec.linear)
     return pred, None
 
 
@@ -417,12 +432,12 @@ def _bucket_embedding(dec, target):
 
 def decoder_forward(dec, features):
     """MelDecoder.forward, networks.py:291-304."""
-    skip = layer_norm(act(conv(features, dec.proj[0]), ACT_TANH), dec.proj[2])
+    skip = layer_norm(conv(features, dec.proj[0], act=ACT_TANH), dec.proj[2])
     for convs, skip_norm in dec.blocks:
         x = skip
         for seq, norm in convs:
-            x = layer_norm(act(conv(conv(x, seq[0]), seq[1]), ACT_TANH), norm)
-        skip = layer_norm(_Add.apply(x, skip), skip_norm)
+            x = layer_norm(conv(conv(x, seq[0]), seq[1], act=ACT_TANH), norm)
+        skip = layer_norm(x, skip_norm, res=skip)
     return conv(skip, dec.mel_linear)
 
 
@@ -535,6 +550,7 @@ class TrainStep:
             self._scaler = torch.tensor([init_scale, growth_factor, backoff_factor, growth_interval, 0, 0, 0, 0], dtype=torch.float32, device=dev)
             self._absmax = torch.zeros(1, dtype=torch.float32, device=dev)
         self._graphs = {}
+        self._build_pack_list()
         if self.graph or precision == 16:
             self._step_dev = torch.zeros(1, dtype=torch.int32, device=dev)
             self._lr_dev = torch.full((8,), lr, dtype=torch.float32, device=dev)   # ESMI_TRAIN_ADAMW_HYPER_FLOATS: [0] = lr
@@ -662,16 +678,42 @@ class TrainStep:
             if hasattr(m, "_fwd_ident"):
                 m._fwd_ident = None
 
+    def _build_pack_list(self):
+        """Persistent GEMM copies (forward layout, data-gradient layout) of every dense convolution / Linear weight, re-made by ONE
+        launch per step (esmi_train_pack_weights_f32) instead of one pack launch per operator call (40 per step)."""
+        mods = [m for m in self.net.modules() if isinstance(m, (torch.nn.Conv1d, torch.nn.ConvTranspose1d, torch.nn.Linear))
+                and getattr(m, "groups", 1) == 1 and getattr(m.weight, "_esmi_grad_view", None) is not None]
+        self._pack_n = len(mods)
+        self._pack_descs = (_lib.ConvDesc * max(1, len(mods)))()
+        self._pack_w = (C.c_void_p * max(1, len(mods)))()
+        lib = _lib.load()
+        for j, m in enumerate(mods):
+            w = m.weight
+            tr = isinstance(m, torch.nn.ConvTranspose1d)
+            w3 = w if w.dim() == 3 else w.unsqueeze(-1)
+            c_in, c_out, k = (w3.shape[0], w3.shape[1], w3.shape[2]) if tr else (w3.shape[1], w3.shape[0], w3.shape[2])
+            stride, pad = (m.stride[0], m.padding[0]) if w.dim() == 3 else (1, 0)
+            d = _lib.ConvDesc(1, 1, c_in, 1, c_out, k, stride, pad, 1, 1 if tr else 0, 0)
+            nb = lib.esmi_train_conv_workspace_bytes(C.byref(d))
+            w._esmi_packed = (torch.zeros(nb, dtype=torch.uint8, device=w.device), torch.zeros(nb, dtype=torch.uint8, device=w.device))
+            d.packed_fwd, d.packed_grad = _ptr(w._esmi_packed[0]), _ptr(w._esmi_packed[1])
+            self._pack_descs[j] = d
+            self._pack_w[j] = w.data_ptr()
+
     def _fwd_bwd(self, x, y):
         """Forward, loss, backward, and the one launch that finishes every parameter gradient: everything up to the exchange.
         Capturable as a hipGraph (no host reads, no collectives)."""
-        global _DIRECT_GRADS, PRECISION, _REDUCE_Q
+        global _DIRECT_GRADS, PRECISION, _REDUCE_Q, _PACKED_VALID
         f = self.flat
         f.zero_grad()
         rq = (_lib.ReduceQueue(), [])
         amp = self.precision == 16
         old_precision, PRECISION = PRECISION, self.precision
+        lib0, st0 = _rt(f.data)
         try:
+            if USE_MATRIX_PIPE and self._pack_n:   # every operator of this step reads these copies of the current weights
+                lib0.esmi_train_pack_weights_f32(self._pack_descs, self._pack_w, self._pack_n, st0)
+                _PACKED_VALID = True
             parts, total = training_loss(self.net, x, y)
             _DIRECT_GRADS = True                   # one backward on a zeroed buffer: operators write parameter gradients in place
             _REDUCE_Q = rq
@@ -682,8 +724,8 @@ class TrainStep:
         finally:
             _DIRECT_GRADS = False
             _REDUCE_Q = None
+            _PACKED_VALID = False
             PRECISION = old_precision
-        lib0, st0 = _rt(f.data)
         lib0.esmi_train_reduce_flush_f32(C.byref(rq[0]), st0)      # every queued parameter-gradient reduction in one launch
         rq[1].clear()
         return loss_vector(parts, total)

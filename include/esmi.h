@@ -440,11 +440,23 @@ typedef struct esmi_conv_desc {
     int precision;    /* 0 / 32: fp32-accurate contractions.  16: the reference's `--precision 16` (utils/tools.py:326-327, Lightning ->
                        * torch.autocast): the forward and data-gradient GEMMs round both operands to binary16 and run ONE MFMA product
                        * per 16 channels (fp32 accumulate, fp32 tensors in memory, fp32 master weights); weight gradients stay fp32 */
+    int act;          /* forward only: 0, or 1 ReLU / 2 GELU (erf) / 3 tanh applied to the result (in the GEMM's epilogue when the shape runs
+                       * on the matrix pipe, else as a second launch); the backward entry points ignore it -- the caller applies
+                       * esmi_train_act_bwd_f32 to dy first (ReLU / tanh from the saved OUTPUT) */
+    /* optional (NULL: the GEMM copy of the weight is made per call, in the workspace): persistent copies of THIS step's weight for
+     * the forward / the data-gradient problem, esmi_train_conv_workspace_bytes(d) each, filled by esmi_train_pack_weights_f32
+     * after the optimizer's last update -- one launch for every convolution of the model instead of one per call */
+    float* packed_fwd;
+    float* packed_grad;
 } esmi_conv_desc;
 /* workspace (esmi_train_conv_workspace_bytes, may be NULL): scratch for the tap-major weight copy; with it, dense convolutions
  * run on the matrix pipe through the inference path's implicit GEMM (split-f16 products in libesmi.so, fp32 MFMA in
  * libesmi_fp32mfma.so) -- the data gradient as the transposed problem; without it every shape takes the plain fp32 kernels */
 size_t esmi_train_conv_workspace_bytes(const esmi_conv_desc* d);
+/* the GEMM copies of n weights in ONE launch (per 64): descs[i].packed_fwd / packed_grad (each may be NULL) <- weights[i] in the layout
+ * the forward / data-gradient GEMM of descs[i] reads; also clears the operand-scale slot behind each data-gradient copy.  Only the
+ * channel / tap / stride / padding / transposed fields of a descriptor matter here.  Call it once per step, before the forward. */
+int esmi_train_pack_weights_f32(const esmi_conv_desc* descs, const float* const* weights, int n, esmi_stream_t stream);
 int esmi_train_conv_fwd_f32(const esmi_conv_desc* d, const float* x, const float* w, const float* bias /* or NULL */, float* y,
                             void* workspace, size_t workspace_bytes, esmi_stream_t stream);
 int esmi_train_conv_dgrad_f32(const esmi_conv_desc* d, const float* dy, const float* w, float* dx, void* workspace,
@@ -470,13 +482,17 @@ size_t esmi_train_conv_bwd_workspace_bytes(const esmi_conv_desc* d);
 int esmi_train_conv_bwd_f32(const esmi_conv_desc* d, const float* x, const float* dy, const float* w, float* dx, float* dw,
                             float* dbias /* or NULL */, void* workspace, size_t workspace_bytes, esmi_reduce_queue* defer /* or NULL */,
                             esmi_stream_t stream);
-/* nn.LayerNorm over the last dim (eps 1e-5); mean / rstd (rows) are kept for the backward */
+/* nn.LayerNorm over the last dim (eps 1e-5); mean / rstd (rows) are kept for the backward.  The steps the reference runs around it
+ * ride in the same launch: res (or NULL) -- the normalised tensor is x + res, written to xsum for the backward (networks.py:75,83,301:
+ * LN(f(x) + x); the gradient of both summands is the backward's dx); rowmask (or NULL, rows bytes) -- rows with a nonzero byte come
+ * out zero (the masked_fill of networks.py:76,84) and pass no gradient: give the backward the same mask. */
 int esmi_train_layernorm_fwd_f32(const float* x, const float* g, const float* b, int64_t rows, int C, float* y, float* mean,
-                                 float* rstd, esmi_stream_t stream);
+                                 float* rstd, const float* res /* or NULL */, float* xsum /* with res */,
+                                 const uint8_t* rowmask /* or NULL */, esmi_stream_t stream);
 size_t esmi_train_layernorm_bwd_workspace_bytes(int64_t rows, int C);
 int esmi_train_layernorm_bwd_f32(const float* x, const float* g, const float* mean, const float* rstd, const float* dy,
                                  int64_t rows, int C, float* dx, float* dg, float* db, void* workspace, size_t workspace_bytes,
-                                 esmi_reduce_queue* defer /* or NULL */, esmi_stream_t stream);
+                                 esmi_reduce_queue* defer /* or NULL */, const uint8_t* rowmask /* or NULL */, esmi_stream_t stream);
 /* kind: 1 ReLU, 2 GELU (erf), 3 tanh.  Backward reads the OUTPUT for ReLU / tanh and the INPUT for GELU as `saved`. */
 int esmi_train_act_fwd_f32(const float* x, int64_t n, int kind, float* y, esmi_stream_t stream);
 int esmi_train_act_bwd_f32(const float* saved, const float* dy, int64_t n, int kind, float* dx, esmi_stream_t stream);

@@ -78,6 +78,43 @@ def test_layernorm(rows, C):
 
 
 @gpu
+@pytest.mark.parametrize("rows,C", [(300, 32), (130, 128), (40, 320)])
+def test_layernorm_with_residual_and_row_mask(rows, C):
+    """LN(x + res) with padded rows zeroed, in the norm's own launches (networks.py:75-76, 83-84, 301): forward, both summands'
+    gradients, and the parameter gradients -- masked rows contribute nothing."""
+    x, res = _rand(rows, C, seed=11, scale=2.0).requires_grad_(), _rand(rows, C, seed=12, scale=2.0).requires_grad_()
+    g, b = (_rand(C, seed=13) + 1.0).requires_grad_(), _rand(C, seed=14).requires_grad_()
+    mask = (torch.arange(rows, device=x.device) % 7 == 3) | (torch.arange(rows, device=x.device) >= rows - 5)
+    m8 = mask.to(torch.uint8).contiguous()
+    dy = _rand(rows, C, seed=15)
+    for use_res, use_mask in ((True, True), (True, False), (False, True)):
+        got = train._LayerNorm.apply(x, g, b, res if use_res else None, m8 if use_mask else None)
+        ref = F.layer_norm(x + res if use_res else x, (C,), g, b)
+        if use_mask:
+            ref = ref.masked_fill(mask[:, None], 0.0)
+        _close(got, ref, 1e-5, "forward")
+        ins = (x, res, g, b) if use_res else (x, g, b)
+        names = ("dx", "dres", "dgamma", "dbeta") if use_res else ("dx", "dgamma", "dbeta")
+        for a, r, what in zip(torch.autograd.grad(got, ins, dy), torch.autograd.grad(ref, ins, dy), names):
+            _close(a, r, 5e-5, what)
+
+
+@gpu
+def test_conv_with_fused_activation():
+    """ReLU / tanh inside the convolution's launch (esmi_conv_desc.act): GEMM shapes, the one-channel Linear and a plain-kernel shape."""
+    for (cin, cout, k, kind, fn) in ((64, 128, 3, train.ACT_RELU, F.relu), (128, 128, 1, train.ACT_TANH, torch.tanh),
+                                     (128, 1, 1, train.ACT_RELU, F.relu), (6, 10, 3, train.ACT_TANH, torch.tanh)):
+        x = _rand(3, 90, cin, seed=21, scale=1.0).requires_grad_()
+        w, b = (_rand(cout, cin, k, seed=22, scale=0.2)).requires_grad_(), _rand(cout, seed=23).requires_grad_()
+        got = train._Conv.apply(x, w, b, 1, k // 2, 1, False, 90, kind)
+        ref = fn(F.conv1d(x.transpose(1, 2), w, b, padding=k // 2).transpose(1, 2))
+        _close(got, ref, 2e-5, f"forward {cin}->{cout} k{k}")
+        dy = _rand(3, 90, cout, seed=24)
+        for a, r, what in zip(torch.autograd.grad(got, (x, w, b), dy), torch.autograd.grad(ref, (x, w, b), dy), ("dx", "dw", "db")):
+            _close(a, r, 1e-4, f"{what} {cin}->{cout} k{k}")
+
+
+@gpu
 @pytest.mark.parametrize("kind,fn", [(train.ACT_RELU, F.relu), (train.ACT_GELU, F.gelu), (train.ACT_TANH, torch.tanh)])
 def test_activations(kind, fn):
     x = _rand(3, 1000, 64, seed=5, scale=2.0).requires_grad_()
@@ -216,6 +253,7 @@ def test_simulated_conv_forward_and_gradients(cfg, monkeypatch):
 
 
 def test_simulated_layernorm_attention_loss():
-    _sim_case(lambda: (test_layernorm(300, 32), test_layernorm(77, 64),
+    _sim_case(lambda: (test_layernorm(300, 32), test_layernorm(77, 64), test_layernorm_with_residual_and_row_mask(130, 128),
+                       test_layernorm_with_residual_and_row_mask(40, 320), test_conv_with_fused_activation(),
                        test_attention_core(2, 33, 32, 2), test_activations(train.ACT_GELU, F.gelu),
                        test_embedding_repeat_cat_mask_add(), test_loss_and_adamw_against_torch()))
