@@ -152,7 +152,7 @@ EXPORTS = (
     "esmi_train_attention_bwd_f32", "esmi_train_embedding_fwd_f32", "esmi_train_embedding_bwd_f32", "esmi_train_mask_rows_f32",
     "esmi_train_add_f32", "esmi_train_copy_cols_f32", "esmi_train_repeat_fwd_f32", "esmi_train_repeat_bwd_f32",
     "esmi_train_loss_f32", "esmi_train_adamw_f32", "esmi_train_adamw_graph_f32", "esmi_train_conv_bwd_workspace_bytes",
-    "esmi_train_conv_bwd_f32", "esmi_train_reduce_flush_f32", "esmi_train_pack_weights_f32",
+    "esmi_train_conv_bwd_f32", "esmi_train_reduce_flush_f32", "esmi_train_pack_weights_f32", "esmi_train_cat_f32",
 )
 
 
@@ -218,10 +218,11 @@ def bind(lib):
     lib.esmi_train_conv_bwd_f32.argtypes = [P(ConvDesc), fp, fp, fp, fp, fp, fp, fp, sz, P(ReduceQueue), fp]
     lib.esmi_train_reduce_flush_f32.argtypes = [P(ReduceQueue), fp]
     lib.esmi_train_pack_weights_f32.argtypes = [P(ConvDesc), P(C.c_void_p), i, fp]
+    lib.esmi_train_cat_f32.argtypes = [P(C.c_void_p), P(i), i, i64, fp, fp, C.c_uint, i, fp]
     lib.esmi_train_layernorm_bwd_workspace_bytes.argtypes = [i64, i]
     lib.esmi_train_layernorm_bwd_workspace_bytes.restype = sz
     lib.esmi_train_layernorm_fwd_f32.argtypes = [fp, fp, fp, i64, i, fp, fp, fp, fp, fp, fp, fp]
-    lib.esmi_train_layernorm_bwd_f32.argtypes = [fp, fp, fp, fp, fp, i64, i, fp, fp, fp, fp, sz, P(ReduceQueue), fp, fp]
+    lib.esmi_train_layernorm_bwd_f32.argtypes = [fp, fp, fp, fp, fp, i64, i, fp, fp, fp, fp, sz, P(ReduceQueue), fp, i, fp]
     lib.esmi_train_act_fwd_f32.argtypes = [fp, i64, i, fp, fp]
     lib.esmi_train_act_bwd_f32.argtypes = [fp, fp, i64, i, fp, fp]
     lib.esmi_train_attention_fwd_f32.argtypes = [fp, i, i, i, i, fp, fp, fp]

@@ -421,10 +421,16 @@ static __global__ __launch_bounds__(256) void train_ln_fwd_kernel(const float* _
     const bool masked = rowmask && rowmask[r];
     for (int c = lane; c < C; c += 64) y[r * C + c] = masked ? 0.0f : fmaf((xr[c] - m) * rs, g[c], b[c]);
 }
+// derivative of ReLU / tanh from the activation's OUTPUT y (kind as esmi_dev.h Act; 0: 1)
+__device__ __forceinline__ float act_grad_from_output(int kind, float y) {
+    return kind == ACT_RELU ? (y > 0.0f ? 1.0f : 0.0f) : (kind == ACT_TANH ? 1.0f - y * y : 1.0f);
+}
+// in_act: x is the output of that activation (LN(tanh(conv)), networks.py:298; LN(relu(conv)), :152-153) and dx is returned for the
+// PRE-activation tensor -- the activation's backward rides in this launch
 static __global__ __launch_bounds__(256) void train_ln_bwd_dx_kernel(const float* __restrict__ x, const float* __restrict__ g,
                                                               const float* __restrict__ mean, const float* __restrict__ rstd,
                                                               const float* __restrict__ dy, long rows, int C, float* __restrict__ dx,
-                                                              const unsigned char* __restrict__ rowmask) {
+                                                              const unsigned char* __restrict__ rowmask, int in_act) {
     const long r = (long)blockIdx.x * 4 + wave_id();
     if (r >= rows) return;
     const int lane = lane_id();
@@ -442,8 +448,8 @@ static __global__ __launch_bounds__(256) void train_ln_bwd_dx_kernel(const float
     s1 = ln_wave_sum(s1) / (float)C;
     s2 = ln_wave_sum(s2) / (float)C;
     for (int c = lane; c < C; c += 64) {
-        const float xh = (x[r * C + c] - m) * rs, dh = dy[r * C + c] * g[c];
-        dx[r * C + c] = rs * (dh - s1 - xh * s2);
+        const float xv = x[r * C + c], xh = (xv - m) * rs, dh = dy[r * C + c] * g[c];
+        dx[r * C + c] = rs * (dh - s1 - xh * s2) * act_grad_from_output(in_act, xv);
     }
 }
 // dx and the parameter-gradient partials in one pass (C <= 256): a 4-wave workgroup per kLnRows rows, one wave per quarter, lanes
@@ -454,7 +460,7 @@ static __global__ __launch_bounds__(256) void train_ln_bwd_fused_kernel(const fl
                                                                  const float* __restrict__ mean, const float* __restrict__ rstd,
                                                                  const float* __restrict__ dy, long rows, int C,
                                                                  float* __restrict__ dx, float* __restrict__ partial,
-                                                                 const unsigned char* __restrict__ rowmask) {
+                                                                 const unsigned char* __restrict__ rowmask, int in_act) {
     ESMI_DYN_LDS(red);   // [4 waves][2][256] floats
     const long chunk = blockIdx.x;
     const int lane = lane_id(), w = wave_id();
@@ -467,13 +473,14 @@ static __global__ __launch_bounds__(256) void train_ln_bwd_fused_kernel(const fl
     for (long r = r0; r < r1; ++r) {
         const float m = mean[r], rs = rstd[r];
         const bool masked = rowmask && rowmask[r];   // (a zero dy row: dx = 0, no contribution to dgamma / dbeta)
-        float xh[4], dh[4], s1 = 0.0f, s2 = 0.0f;
+        float xv[4], xh[4], dh[4], s1 = 0.0f, s2 = 0.0f;
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int c = lane + 64 * u;
             const bool ok = c < C;
             const float d = (ok && !masked) ? dy[r * C + c] : 0.0f;
-            xh[u] = ok ? (x[r * C + c] - m) * rs : 0.0f;
+            xv[u] = ok ? x[r * C + c] : 0.0f;
+            xh[u] = ok ? (xv[u] - m) * rs : 0.0f;
             dh[u] = d * gg[u];
             s1 += dh[u];
             s2 = fmaf(dh[u], xh[u], s2);
@@ -485,7 +492,7 @@ static __global__ __launch_bounds__(256) void train_ln_bwd_fused_kernel(const fl
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int c = lane + 64 * u;
-            if (c < C) dx[r * C + c] = rs * (dh[u] - s1 - xh[u] * s2);
+            if (c < C) dx[r * C + c] = rs * (dh[u] - s1 - xh[u] * s2) * act_grad_from_output(in_act, xv[u]);
         }
     }
 #pragma unroll
@@ -758,6 +765,27 @@ static __global__ void train_copy_cols_kernel(const float* __restrict__ src, int
     const long r = q / C;
     const int c = (int)(q % C);
     dst[r * ld_dst + col_dst + c] = src[r * ld_src + col_src + c];
+}
+
+// torch.cat(parts, dim=-1) of up to 8 row-major parts in ONE launch, or its backward (the slices of dcat back into the parts);
+// parts whose bit is set in `masked` are taken as zero on rows with rowmask[r] != 0 (x.masked_fill(mask, 0) before the cat,
+// networks.py:366-368) -- the same mask zeroes those rows of their gradient
+struct CatArgs { float* part[8]; int width[8]; int col[8]; int n, tot; long rows; float* cat; const unsigned char* rowmask; unsigned masked; int backward; };
+static __global__ void train_cat_kernel(const CatArgs a) {
+    const long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= a.rows * a.tot) return;
+    const long r = q / a.tot;
+    const int c = (int)(q - r * a.tot);
+    int pi = 0;
+#pragma unroll
+    for (int j = 1; j < 8; ++j) pi += (j < a.n && c >= a.col[j]) ? 1 : 0;
+    float* part = a.part[0];
+    int w = a.width[0], c0 = a.col[0];
+#pragma unroll
+    for (int j = 1; j < 8; ++j) if (pi == j) { part = a.part[j]; w = a.width[j]; c0 = a.col[j]; }
+    const bool zero = ((a.masked >> pi) & 1u) && a.rowmask && a.rowmask[r];
+    if (a.backward) part[r * w + (c - c0)] = zero ? 0.0f : a.cat[q];
+    else a.cat[q] = zero ? 0.0f : part[r * w + (c - c0)];
 }
 
 // ---- length regulator (networks.py:233-244) forward / backward on the inclusive duration cumsum `cum` (B, T):

@@ -291,18 +291,19 @@ size_t esmi_train_layernorm_bwd_workspace_bytes(int64_t rows, int C) {
 }
 int esmi_train_layernorm_bwd_f32(const float* x, const float* g, const float* mean, const float* rstd, const float* dy,
                                  int64_t rows, int C, float* dx, float* dg, float* db, void* workspace, size_t workspace_bytes,
-                                 esmi_reduce_queue* defer, const uint8_t* rowmask, esmi_stream_t stream) {
+                                 esmi_reduce_queue* defer, const uint8_t* rowmask, int in_act, esmi_stream_t stream) {
     if (!x || !g || !mean || !rstd || !dy || !dx || !dg || !db || !workspace || rows <= 0 || C <= 0) return ESMI_ERR_ARG;
+    if (in_act != 0 && in_act != ACT_RELU && in_act != ACT_TANH) return ESMI_ERR_ARG;
     if (workspace_bytes < esmi_train_layernorm_bwd_workspace_bytes(rows, C)) return ESMI_ERR_WORKSPACE;
     float* part = static_cast<float*>(workspace);
     long chunks;
     if (C <= 256) {   // dx and the parameter partials in one pass
         chunks = train_chunks(rows, kLnRows);
-        ESMI_LAUNCH(train_ln_bwd_fused_kernel, dim3((unsigned)chunks), dim3(256), 4 * 2 * 256 * sizeof(float), S(stream), x, g, mean, rstd, dy, (long)rows, C, dx, part, rowmask);
+        ESMI_LAUNCH(train_ln_bwd_fused_kernel, dim3((unsigned)chunks), dim3(256), 4 * 2 * 256 * sizeof(float), S(stream), x, g, mean, rstd, dy, (long)rows, C, dx, part, rowmask, in_act);
         if (int rc = launch_status()) return rc;
     } else {
         chunks = train_chunks(rows);
-        ESMI_LAUNCH(train_ln_bwd_dx_kernel, grid1d(rows, 4), dim3(256), 0, S(stream), x, g, mean, rstd, dy, (long)rows, C, dx, rowmask);
+        ESMI_LAUNCH(train_ln_bwd_dx_kernel, grid1d(rows, 4), dim3(256), 0, S(stream), x, g, mean, rstd, dy, (long)rows, C, dx, rowmask, in_act);
         if (int rc = launch_status()) return rc;
         ESMI_LAUNCH(train_ln_bwd_params_kernel, dim3(grid1d(C, 64), (unsigned)chunks), dim3(64), 0, S(stream), x, mean, rstd, dy, (long)rows, C, part, rowmask);
         if (int rc = launch_status()) return rc;
@@ -392,6 +393,21 @@ int esmi_train_copy_cols_f32(const float* src, int ld_src, int col_src, float* d
                              esmi_stream_t stream) {
     if (!src || !dst || rows <= 0 || C <= 0 || col_src < 0 || col_dst < 0 || col_src + C > ld_src || col_dst + C > ld_dst) return ESMI_ERR_ARG;
     ESMI_LAUNCH(train_copy_cols_kernel, grid1d(rows * C), dim3(256), 0, S(stream), src, ld_src, col_src, dst, ld_dst, col_dst, (long)rows, C);
+    return launch_status();
+}
+int esmi_train_cat_f32(float* const* parts, const int* widths, int n, int64_t rows, float* cat, const uint8_t* rowmask,
+                       unsigned masked_parts, int backward, esmi_stream_t stream) {
+    if (!parts || !widths || n <= 0 || n > 8 || rows <= 0 || !cat || (masked_parts && !rowmask)) return ESMI_ERR_ARG;
+    CatArgs a;
+    memset(&a, 0, sizeof a);
+    int col = 0;
+    for (int j = 0; j < n; ++j) {
+        if (!parts[j] || widths[j] <= 0) return ESMI_ERR_ARG;
+        a.part[j] = parts[j]; a.width[j] = widths[j]; a.col[j] = col;
+        col += widths[j];
+    }
+    a.n = n; a.tot = col; a.rows = (long)rows; a.cat = cat; a.rowmask = rowmask; a.masked = masked_parts; a.backward = backward ? 1 : 0;
+    ESMI_LAUNCH(train_cat_kernel, grid1d((long)rows * col), dim3(256), 0, S(stream), a);
     return launch_status();
 }
 int esmi_train_repeat_fwd_f32(const float* feat, const int32_t* cum, int B, int T, int C, int L, float* out, esmi_stream_t stream) {

@@ -66,10 +66,12 @@ class _Conv(torch.autograd.Function):
     """Conv1d / ConvTranspose1d / Linear on channels-last (B, n, C); `w` in checkpoint layout (Linear: (Cout, Cin))."""
 
     @staticmethod
-    def forward(ctx, x, w, b, stride, pad, groups, transposed, n_out, act=0):
+    def forward(ctx, x, w, b, stride, pad, groups, transposed, n_out, act=0, act_grad_downstream=False):
         """act: ReLU / tanh applied to the result inside the convolution's launch (`esmi_conv_desc.act`); their derivatives come
-        from the saved output, so the backward is act' then the convolution's."""
+        from the saved output, so the backward is act' then the convolution's -- unless the one consumer of the result takes care of
+        act' in its own backward (`act_grad_downstream`: the LayerNorm that follows, `in_act`)."""
         assert act in (0, ACT_RELU, ACT_TANH)
+        ctx.act_here = bool(act) and not act_grad_downstream
         w0 = w
         x, w = x.contiguous(), w.contiguous()
         lib, st = _rt(x)
@@ -84,7 +86,7 @@ class _Conv(torch.autograd.Function):
         nws = lib.esmi_train_conv_workspace_bytes(C.byref(d)) if (USE_MATRIX_PIPE and packed is None) else 0
         ws = _new((nws,), x, torch.uint8) if nws else None
         lib.esmi_train_conv_fwd_f32(C.byref(d), _ptr(x), _ptr(w), _ptr(b), _ptr(y), _ptr(ws), nws, st)
-        ctx.save_for_backward(x, w, *((y,) if act else ()))
+        ctx.save_for_backward(x, w, *((y,) if ctx.act_here else ()))
         ctx.d, ctx.params = d, (w0, b)          # the Parameter objects themselves: their flat gradient views are the outputs
         return y
 
@@ -94,7 +96,7 @@ class _Conv(torch.autograd.Function):
         dy = dy.contiguous()
         lib, st = _rt(dy)
         d = ctx.d
-        if d.act:
+        if ctx.act_here:
             da = torch.empty_like(dy)
             lib.esmi_train_act_bwd_f32(_ptr(ctx.saved_tensors[2]), _ptr(dy), dy.numel(), d.act, _ptr(da), st)
             dy = da
@@ -113,15 +115,18 @@ class _Conv(torch.autograd.Function):
             nws = lib.esmi_train_conv_wgrad_workspace_bytes(C.byref(d))
             ws = _new((nws,), w, torch.uint8)
             lib.esmi_train_conv_wgrad_f32(C.byref(d), _ptr(x), _ptr(dy), _ptr(dw), _ptr(db), _ptr(ws), nws, st)
-        return dx, (None if w_direct else dw), (None if b_direct else db), None, None, None, None, None, None
+        return dx, (None if w_direct else dw), (None if b_direct else db), None, None, None, None, None, None, None
 
 
 class _LayerNorm(torch.autograd.Function):
     """LayerNorm over the last dim -- optionally of x + res (both summands get the backward's dx) and with padded rows zeroed
-    afterwards (`mask` (rows) uint8; those rows pass no gradient): the add and the masked_fill ride in the norm's launches."""
+    afterwards (`mask` (rows) uint8; those rows pass no gradient): the add and the masked_fill ride in the norm's launches.
+    in_act: x is the output of that ReLU / tanh and has no other consumer -- the backward returns the gradient of the activation's
+    INPUT, so the producer (`conv(..., act=kind, act_grad_downstream=True)`) must not apply the activation's backward again."""
 
     @staticmethod
-    def forward(ctx, x, g, b, res=None, mask=None):
+    def forward(ctx, x, g, b, res=None, mask=None, in_act=0):
+        assert in_act in (0, ACT_RELU, ACT_TANH) and not (in_act and res is not None)
         x = x.contiguous()
         lib, st = _rt(x)
         rows, Cc = x.numel() // x.shape[-1], x.shape[-1]
@@ -132,7 +137,7 @@ class _LayerNorm(torch.autograd.Function):
         lib.esmi_train_layernorm_fwd_f32(_ptr(x), _ptr(g), _ptr(b), rows, Cc, _ptr(y), _ptr(mean), _ptr(rstd), _ptr(res),
                                          _ptr(xs) if res is not None else None, _ptr(mask), st)
         ctx.save_for_backward(xs, g, mean, rstd, *((mask,) if mask is not None else ()))
-        ctx.params, ctx.has_res = (g, b), res is not None
+        ctx.params, ctx.has_res, ctx.in_act = (g, b), res is not None, in_act
         return y
 
     @staticmethod
@@ -147,8 +152,8 @@ class _LayerNorm(torch.autograd.Function):
         nws = lib.esmi_train_layernorm_bwd_workspace_bytes(rows, Cc)
         ws = _new((nws,), x, torch.uint8)
         lib.esmi_train_layernorm_bwd_f32(_ptr(x), _ptr(g), _ptr(mean), _ptr(rstd), _ptr(dy), rows, Cc, _ptr(dx), _ptr(dg), _ptr(db),
-                                         _ptr(ws), nws, _defer(ws, g_direct, b_direct), _ptr(mask), st)
-        return dx, (None if g_direct else dg), (None if b_direct else db), (dx if ctx.has_res else None), None
+                                         _ptr(ws), nws, _defer(ws, g_direct, b_direct), _ptr(mask), ctx.in_act, st)
+        return dx, (None if g_direct else dg), (None if b_direct else db), (dx if ctx.has_res else None), None, None
 
 
 class _Act(torch.autograd.Function):
@@ -260,34 +265,35 @@ class _Add(torch.autograd.Function):
 
 
 class _Cat(torch.autograd.Function):
-    """torch.cat(parts, dim=-1)."""
+    """torch.cat(parts, dim=-1) in one launch; parts whose bit is set in `masked` are first zeroed on the rows of the (rows) uint8
+    `mask` (x.masked_fill(mask[..., None], 0) in front of the cat), gradients likewise."""
 
     @staticmethod
-    def forward(ctx, *parts):
+    def _run(lib, st, parts, widths, rows, cat, mask, masked, backward):
+        ptrs = (C.c_void_p * len(parts))(*[_ptr(p) for p in parts])
+        lib.esmi_train_cat_f32(ptrs, (C.c_int * len(parts))(*widths), len(parts), rows, _ptr(cat), _ptr(mask), masked, backward, st)
+
+    @staticmethod
+    def forward(ctx, mask, masked, *parts):
         parts = [p.contiguous() for p in parts]
         lib, st = _rt(parts[0])
         widths = [p.shape[-1] for p in parts]
         rows, tot = parts[0].numel() // widths[0], sum(widths)
         y = _new(tuple(parts[0].shape[:-1]) + (tot,), parts[0])
-        col = 0
-        for p, w in zip(parts, widths):
-            lib.esmi_train_copy_cols_f32(_ptr(p), w, 0, _ptr(y), tot, col, rows, w, st)
-            col += w
-        ctx.widths = widths
+        masked = masked if mask is not None else 0
+        _Cat._run(lib, st, parts, widths, rows, y, mask, masked, 0)
+        ctx.widths, ctx.masked = widths, masked
+        ctx.save_for_backward(*((mask,) if masked else ()))
         return y
 
     @staticmethod
     def backward(ctx, dy):
         dy = dy.contiguous()
         lib, st = _rt(dy)
-        tot, rows = dy.shape[-1], dy.numel() // dy.shape[-1]
-        outs, col = [], 0
-        for w in ctx.widths:
-            g = _new(tuple(dy.shape[:-1]) + (w,), dy)
-            lib.esmi_train_copy_cols_f32(_ptr(dy), tot, col, _ptr(g), w, 0, rows, w, st)
-            outs.append(g)
-            col += w
-        return tuple(outs)
+        rows = dy.numel() // dy.shape[-1]
+        outs = [_new(tuple(dy.shape[:-1]) + (w,), dy) for w in ctx.widths]
+        _Cat._run(lib, st, outs, ctx.widths, rows, dy, ctx.saved_tensors[0] if ctx.masked else None, ctx.masked, 1)
+        return (None, None) + tuple(outs)
 
 
 class _Repeat(torch.autograd.Function):
@@ -348,18 +354,18 @@ def loss_vector(parts, total):
     return torch.cat([parts.detach(), total.detach().reshape(1)])
 
 
-def conv(x, m, n_out=None, act=0):
+def conv(x, m, n_out=None, act=0, act_grad_downstream=False):
     """Apply an nn.Conv1d / nn.ConvTranspose1d / nn.Linear parameter container to channels-last x (+ ReLU / tanh in the same launch)."""
     if isinstance(m, torch.nn.Linear):
-        return _Conv.apply(x, m.weight, m.bias, 1, 0, 1, False, x.shape[1], act)
+        return _Conv.apply(x, m.weight, m.bias, 1, 0, 1, False, x.shape[1], act, act_grad_downstream)
     tr = isinstance(m, torch.nn.ConvTranspose1d)
     k, s, p = m.kernel_size[0], m.stride[0], m.padding[0]
     full = (x.shape[1] - 1) * s - 2 * p + k if tr else (x.shape[1] + 2 * p - k) // s + 1
-    return _Conv.apply(x, m.weight, m.bias, s, p, m.groups, tr, full if n_out is None else min(full, n_out), act)
+    return _Conv.apply(x, m.weight, m.bias, s, p, m.groups, tr, full if n_out is None else min(full, n_out), act, act_grad_downstream)
 
 
-def layer_norm(x, m, res=None, mask=None):
-    return _LayerNorm.apply(x, m.weight, m.bias, res, mask)
+def layer_norm(x, m, res=None, mask=None, in_act=0):
+    return _LayerNorm.apply(x, m.weight, m.bias, res, mask, in_act)
 
 
 def act(x, kind):
@@ -403,14 +409,14 @@ def fuse_forward(fuse, feats, mask_u8):
         if isinstance(up, torch.nn.ConvTranspose1d):
             x = conv(x, up, n_out=T)
         parts.append(x)
-    x = conv(_Cat.apply(*parts), fuse.fuse)
+    x = conv(_Cat.apply(None, 0, *parts), fuse.fuse)
     return _MaskRows.apply(x, mask_u8) if mask_u8 is not None else x
 
 
 def predictor_forward(dec, fused):
     """AcousticDecoder.forward, networks.py:151-165 -> (pred (B, T, 1), features (B, T, dim))."""
-    y = conv(fused, dec.conv1[0], act=ACT_RELU)
-    y = act(layer_norm(y, dec.norm1), ACT_RELU)
+    y = conv(fused, dec.conv1[0], act=ACT_RELU, act_grad_downstream=True)
+    y = act(layer_norm(y, dec.norm1, in_act=ACT_RELU), ACT_RELU)
     y = conv(y, dec.conv2[0], act=ACT_RELU)
     if dec.duration:
         return conv(y, dec.linear, act=ACT_RELU), layer_norm(y, dec.norm2)
@@ -432,11 +438,11 @@ def _bucket_embedding(dec, target):
 
 def decoder_forward(dec, features):
     """MelDecoder.forward, networks.py:291-304."""
-    skip = layer_norm(conv(features, dec.proj[0], act=ACT_TANH), dec.proj[2])
+    skip = layer_norm(conv(features, dec.proj[0], act=ACT_TANH, act_grad_downstream=True), dec.proj[2], in_act=ACT_TANH)
     for convs, skip_norm in dec.blocks:
         x = skip
         for seq, norm in convs:
-            x = layer_norm(conv(conv(x, seq[0]), seq[1], act=ACT_TANH), norm)
+            x = layer_norm(conv(conv(x, seq[0]), seq[1], act=ACT_TANH, act_grad_downstream=True), norm, in_act=ACT_TANH)
         skip = layer_norm(x, skip_norm, res=skip)
     return conv(skip, dec.mel_linear)
 
@@ -453,9 +459,7 @@ def train_forward(net, x):
     energy_pred, _ = predictor_forward(pe.energy_decoder, fused)
     dur_pred, dur_feat = predictor_forward(pe.duration_decoder, fused)
     pf, ef = _bucket_embedding(pe.pitch_decoder, x["pitch"]), _bucket_embedding(pe.energy_decoder, x["energy"])
-    if ph_mask is not None:
-        pf, ef, dur_feat = _MaskRows.apply(pf, ph_mask), _MaskRows.apply(ef, ph_mask), _MaskRows.apply(dur_feat, ph_mask)
-    feat4 = _Cat.apply(fused, pf, ef, dur_feat)
+    feat4 = _Cat.apply(ph_mask, 0b1110, fused, pf, ef, dur_feat)     # the three masked_fills (networks.py:366-368) inside the cat's launch
     # length regulator on the TARGET durations (masked, clamped at 0), padded to the batch's longest target mel
     lib, st = _rt(feat4)
     dur = x["duration"].to(torch.int32).contiguous()

@@ -492,7 +492,9 @@ int esmi_train_layernorm_fwd_f32(const float* x, const float* g, const float* b,
 size_t esmi_train_layernorm_bwd_workspace_bytes(int64_t rows, int C);
 int esmi_train_layernorm_bwd_f32(const float* x, const float* g, const float* mean, const float* rstd, const float* dy,
                                  int64_t rows, int C, float* dx, float* dg, float* db, void* workspace, size_t workspace_bytes,
-                                 esmi_reduce_queue* defer /* or NULL */, const uint8_t* rowmask /* or NULL */, esmi_stream_t stream);
+                                 esmi_reduce_queue* defer /* or NULL */, const uint8_t* rowmask /* or NULL */,
+                                 int in_act /* 0, or 1 ReLU / 3 tanh: x is that activation's output and dx is returned for its INPUT */,
+                                 esmi_stream_t stream);
 /* kind: 1 ReLU, 2 GELU (erf), 3 tanh.  Backward reads the OUTPUT for ReLU / tanh and the INPUT for GELU as `saved`. */
 int esmi_train_act_fwd_f32(const float* x, int64_t n, int kind, float* y, esmi_stream_t stream);
 int esmi_train_act_bwd_f32(const float* saved, const float* dy, int64_t n, int kind, float* dx, esmi_stream_t stream);
@@ -507,6 +509,11 @@ size_t esmi_train_embedding_bwd_workspace_bytes(int64_t rows, int V, int C);
 int esmi_train_embedding_bwd_f32(const int32_t* ids, const float* dy, int64_t rows, int V, int C, int padding_idx, float* dtable,
                                  void* workspace, size_t workspace_bytes, esmi_reduce_queue* defer /* or NULL */, esmi_stream_t stream);
 int esmi_train_mask_rows_f32(const float* x, const uint8_t* mask, int64_t rows, int C, float* y, esmi_stream_t stream);
+/* torch.cat(parts, dim=-1) of n <= 8 row-major (rows, widths[j]) parts into cat (rows, sum widths) in one launch -- backward = 1: the
+ * slices of `cat` (then the gradient) back into the parts.  Parts whose bit is set in masked_parts count as zero on rows with
+ * rowmask[r] != 0 (the masked_fill in front of the cat, networks.py:366-368), in both directions. */
+int esmi_train_cat_f32(float* const* parts, const int* widths, int n, int64_t rows, float* cat, const uint8_t* rowmask /* or NULL */,
+                       unsigned masked_parts, int backward, esmi_stream_t stream);
 int esmi_train_add_f32(const float* a, const float* b, int64_t n, float* y, esmi_stream_t stream);
 /* dst[r, col_dst + c] = src[r, col_src + c], c < C: torch.cat along channels and its gradient */
 int esmi_train_copy_cols_f32(const float* src, int ld_src, int col_src, float* dst, int ld_dst, int col_dst, int64_t rows, int C,

@@ -100,6 +100,22 @@ def test_layernorm_with_residual_and_row_mask(rows, C):
 
 
 @gpu
+def test_conv_activation_layernorm_chain():
+    """LN(tanh(conv(x))) / LN(relu(conv(x))) with the activation in the convolution's launch and its backward in the LayerNorm's."""
+    for kind, fn in ((train.ACT_TANH, torch.tanh), (train.ACT_RELU, F.relu)):
+        x = _rand(2, 150, 128, seed=31).requires_grad_()
+        w, b = _rand(128, 128, 1, seed=32, scale=0.15).requires_grad_(), _rand(128, seed=33).requires_grad_()
+        g, beta = (_rand(128, seed=34) + 1.0).requires_grad_(), _rand(128, seed=35).requires_grad_()
+        got = train._LayerNorm.apply(train._Conv.apply(x, w, b, 1, 0, 1, False, 150, kind, True), g, beta, None, None, kind)
+        ref = F.layer_norm(fn(F.conv1d(x.transpose(1, 2), w, b).transpose(1, 2)), (128,), g, beta)
+        _close(got, ref, 3e-5, "forward")
+        dy = _rand(2, 150, 128, seed=36)
+        for a, r, what in zip(torch.autograd.grad(got, (x, w, b, g, beta), dy), torch.autograd.grad(ref, (x, w, b, g, beta), dy),
+                              ("dx", "dw", "db", "dgamma", "dbeta")):
+            _close(a, r, 1e-4, what)
+
+
+@gpu
 def test_conv_with_fused_activation():
     """ReLU / tanh inside the convolution's launch (esmi_conv_desc.act): GEMM shapes, the one-channel Linear and a plain-kernel shape."""
     for (cin, cout, k, kind, fn) in ((64, 128, 3, train.ACT_RELU, F.relu), (128, 128, 1, train.ACT_TANH, torch.tanh),
@@ -158,11 +174,20 @@ def test_embedding_repeat_cat_mask_add():
     # cat / mask / add
     a, b = _rand(4, 30, 8, seed=13).requires_grad_(), _rand(4, 30, 24, seed=14).requires_grad_()
     m = (torch.arange(30)[None, :] >= torch.tensor([30, 12, 1, 29])[:, None]).to(DEV)
-    got = train._MaskRows.apply(train._Cat.apply(a, train._Add.apply(b, b)), m.view(torch.uint8) if m.dtype != torch.uint8 else m)
+    m8 = m.view(torch.uint8) if m.dtype != torch.uint8 else m
+    got = train._MaskRows.apply(train._Cat.apply(None, 0, a, train._Add.apply(b, b)), m8)
     ref = torch.cat([a, b + b], -1).masked_fill(m[..., None], 0)
     assert torch.equal(got, ref)
     dy = _rand(4, 30, 32, seed=15)
     for x_, y_ in zip(torch.autograd.grad(got, (a, b), dy), torch.autograd.grad(ref, (a, b), dy)):
+        assert torch.equal(x_, y_)
+    # the cat that masks some of its parts itself (networks.py:366-368: three of the four parts are masked_fill'ed first)
+    c = _rand(4, 30, 5, seed=16).requires_grad_()
+    got = train._Cat.apply(m8, 0b110, a, b, c)
+    ref = torch.cat([a, b.masked_fill(m[..., None], 0), c.masked_fill(m[..., None], 0)], -1)
+    assert torch.equal(got, ref)
+    dy = _rand(4, 30, 37, seed=17)
+    for x_, y_ in zip(torch.autograd.grad(got, (a, b, c), dy), torch.autograd.grad(ref, (a, b, c), dy)):
         assert torch.equal(x_, y_)
 
 
@@ -255,5 +280,6 @@ def test_simulated_conv_forward_and_gradients(cfg, monkeypatch):
 def test_simulated_layernorm_attention_loss():
     _sim_case(lambda: (test_layernorm(300, 32), test_layernorm(77, 64), test_layernorm_with_residual_and_row_mask(130, 128),
                        test_layernorm_with_residual_and_row_mask(40, 320), test_conv_with_fused_activation(),
+                       test_conv_activation_layernorm_chain(),
                        test_attention_core(2, 33, 32, 2), test_activations(train.ACT_GELU, F.gelu),
                        test_embedding_repeat_cat_mask_add(), test_loss_and_adamw_against_torch()))
