@@ -95,7 +95,7 @@ class TrainLossArgs(C.Structure):
     """esmi_train_loss_args (include/esmi.h): model.py:167-216."""
     _fields_ = [(n, fp) for n in ("mel_pred", "mel", "pitch_pred", "pitch", "energy_pred", "energy", "dur_pred", "dur", "mel_mask",
                                   "ph_mask")] + [(n, C.c_int) for n in ("B", "T", "L", "n_mel")] + \
-               [(n, fp) for n in ("out", "d_mel", "d_pitch", "d_energy", "d_dur", "scratch")]
+               [(n, fp) for n in ("out", "d_mel", "d_pitch", "d_energy", "d_dur", "scratch", "grad_seed")]
 
 
 class ForwardArgs(C.Structure):
@@ -221,8 +221,8 @@ def bind(lib):
     lib.esmi_train_cat_f32.argtypes = [P(C.c_void_p), P(i), i, i64, fp, fp, C.c_uint, i, fp]
     lib.esmi_train_layernorm_bwd_workspace_bytes.argtypes = [i64, i]
     lib.esmi_train_layernorm_bwd_workspace_bytes.restype = sz
-    lib.esmi_train_layernorm_fwd_f32.argtypes = [fp, fp, fp, i64, i, fp, fp, fp, fp, fp, fp, fp]
-    lib.esmi_train_layernorm_bwd_f32.argtypes = [fp, fp, fp, fp, fp, i64, i, fp, fp, fp, fp, sz, P(ReduceQueue), fp, i, fp]
+    lib.esmi_train_layernorm_fwd_f32.argtypes = [fp, fp, fp, i64, i, fp, fp, fp, fp, fp, fp, i, fp]
+    lib.esmi_train_layernorm_bwd_f32.argtypes = [fp, fp, fp, fp, fp, i64, i, fp, fp, fp, fp, sz, P(ReduceQueue), fp, i, fp, fp]
     lib.esmi_train_act_fwd_f32.argtypes = [fp, i64, i, fp, fp]
     lib.esmi_train_act_bwd_f32.argtypes = [fp, fp, i64, i, fp, fp]
     lib.esmi_train_attention_fwd_f32.argtypes = [fp, i, i, i, i, fp, fp, fp]

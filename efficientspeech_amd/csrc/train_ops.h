@@ -401,7 +401,7 @@ static __global__ __launch_bounds__(256) void train_ln_fwd_kernel(const float* _
                                                            const float* __restrict__ b, long rows, int C, float eps,
                                                            float* __restrict__ y, float* __restrict__ mean, float* __restrict__ rstd,
                                                            const float* __restrict__ res, float* __restrict__ xsum,
-                                                           const unsigned char* __restrict__ rowmask) {
+                                                           const unsigned char* __restrict__ rowmask, int relu_out) {
     const long r = (long)blockIdx.x * 4 + wave_id();
     if (r >= rows) return;
     const int lane = lane_id();
@@ -419,7 +419,10 @@ static __global__ __launch_bounds__(256) void train_ln_fwd_kernel(const float* _
     const float rs = 1.0f / sqrtf(ln_wave_sum(v) / (float)C + eps);
     if (lane == 0) { mean[r] = m; rstd[r] = rs; }
     const bool masked = rowmask && rowmask[r];
-    for (int c = lane; c < C; c += 64) y[r * C + c] = masked ? 0.0f : fmaf((xr[c] - m) * rs, g[c], b[c]);
+    for (int c = lane; c < C; c += 64) {
+        const float v = fmaf((xr[c] - m) * rs, g[c], b[c]);
+        y[r * C + c] = masked ? 0.0f : (relu_out ? fmaxf(v, 0.0f) : v);
+    }
 }
 // derivative of ReLU / tanh from the activation's OUTPUT y (kind as esmi_dev.h Act; 0: 1)
 __device__ __forceinline__ float act_grad_from_output(int kind, float y) {
@@ -430,7 +433,8 @@ __device__ __forceinline__ float act_grad_from_output(int kind, float y) {
 static __global__ __launch_bounds__(256) void train_ln_bwd_dx_kernel(const float* __restrict__ x, const float* __restrict__ g,
                                                               const float* __restrict__ mean, const float* __restrict__ rstd,
                                                               const float* __restrict__ dy, long rows, int C, float* __restrict__ dx,
-                                                              const unsigned char* __restrict__ rowmask, int in_act) {
+                                                              const unsigned char* __restrict__ rowmask, int in_act,
+                                                              const float* __restrict__ y_relu) {
     const long r = (long)blockIdx.x * 4 + wave_id();
     if (r >= rows) return;
     const int lane = lane_id();
@@ -441,14 +445,16 @@ static __global__ __launch_bounds__(256) void train_ln_bwd_dx_kernel(const float
     const float m = mean[r], rs = rstd[r];
     float s1 = 0.0f, s2 = 0.0f;
     for (int c = lane; c < C; c += 64) {
-        const float xh = (x[r * C + c] - m) * rs, dh = dy[r * C + c] * g[c];
+        const float dyv = (y_relu && !(y_relu[r * C + c] > 0.0f)) ? 0.0f : dy[r * C + c];
+        const float xh = (x[r * C + c] - m) * rs, dh = dyv * g[c];
         s1 += dh;
         s2 = fmaf(dh, xh, s2);
     }
     s1 = ln_wave_sum(s1) / (float)C;
     s2 = ln_wave_sum(s2) / (float)C;
     for (int c = lane; c < C; c += 64) {
-        const float xv = x[r * C + c], xh = (xv - m) * rs, dh = dy[r * C + c] * g[c];
+        const float dyv = (y_relu && !(y_relu[r * C + c] > 0.0f)) ? 0.0f : dy[r * C + c];
+        const float xv = x[r * C + c], xh = (xv - m) * rs, dh = dyv * g[c];
         dx[r * C + c] = rs * (dh - s1 - xh * s2) * act_grad_from_output(in_act, xv);
     }
 }
@@ -460,7 +466,8 @@ static __global__ __launch_bounds__(256) void train_ln_bwd_fused_kernel(const fl
                                                                  const float* __restrict__ mean, const float* __restrict__ rstd,
                                                                  const float* __restrict__ dy, long rows, int C,
                                                                  float* __restrict__ dx, float* __restrict__ partial,
-                                                                 const unsigned char* __restrict__ rowmask, int in_act) {
+                                                                 const unsigned char* __restrict__ rowmask, int in_act,
+                                                                 const float* __restrict__ y_relu) {
     ESMI_DYN_LDS(red);   // [4 waves][2][256] floats
     const long chunk = blockIdx.x;
     const int lane = lane_id(), w = wave_id();
@@ -478,7 +485,7 @@ static __global__ __launch_bounds__(256) void train_ln_bwd_fused_kernel(const fl
         for (int u = 0; u < 4; ++u) {
             const int c = lane + 64 * u;
             const bool ok = c < C;
-            const float d = (ok && !masked) ? dy[r * C + c] : 0.0f;
+            const float d = (ok && !masked && !(y_relu && !(y_relu[r * C + c] > 0.0f))) ? dy[r * C + c] : 0.0f;
             xv[u] = ok ? x[r * C + c] : 0.0f;
             xh[u] = ok ? (xv[u] - m) * rs : 0.0f;
             dh[u] = d * gg[u];
@@ -511,13 +518,13 @@ static __global__ __launch_bounds__(256) void train_ln_bwd_fused_kernel(const fl
 // partial[chunk][0][c] = sum dy * xhat, partial[chunk][1][c] = sum dy over the chunk's rows
 static __global__ void train_ln_bwd_params_kernel(const float* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ rstd,
                                            const float* __restrict__ dy, long rows, int C, float* __restrict__ partial,
-                                           const unsigned char* __restrict__ rowmask) {
+                                           const unsigned char* __restrict__ rowmask, const float* __restrict__ y_relu) {
     const int c = (int)(blockIdx.x * blockDim.x + threadIdx.x);
     if (c >= C) return;
     const long r0 = (long)blockIdx.y * kTrainChunk, r1 = r0 + kTrainChunk < rows ? r0 + kTrainChunk : rows;
     float a = 0.0f, s = 0.0f;
     for (long r = r0; r < r1; ++r) {
-        const float d = (rowmask && rowmask[r]) ? 0.0f : dy[r * C + c];
+        const float d = ((rowmask && rowmask[r]) || (y_relu && !(y_relu[r * C + c] > 0.0f))) ? 0.0f : dy[r * C + c];
         a = fmaf(d, (x[r * C + c] - mean[r]) * rstd[r], a);
         s += d;
     }
@@ -823,6 +830,7 @@ struct LossP {
     int B, T, L, n_mel;
     float *out, *d_mel, *d_pitch, *d_energy, *d_dur;
     float* partial;                            // [kLossBlocks][6]
+    const float* grad_seed;                    // NULL or one float: multiplies every gradient
 };
 #ifdef ESMI_WAVESIM
 constexpr int kLossBlocks = 8;
@@ -880,18 +888,19 @@ static __global__ void train_loss_grad_kernel(const LossP p) {
     const long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const long nm = (long)p.B * p.L * p.n_mel, np_ = (long)p.B * p.T;
     const float n_el = p.partial[0], n_ph = p.partial[1];
+    const float seed = p.grad_seed ? p.grad_seed[0] : 1.0f;
     if (q < nm) {
         const bool ok = !(p.mel_mask && p.mel_mask[q / p.n_mel]);
         const float d = p.mel_pred[q] - p.mel[q];
-        p.d_mel[q] = ok ? 10.0f * (d > 0.0f ? 1.0f : (d < 0.0f ? -1.0f : 0.0f)) / n_el : 0.0f;
+        p.d_mel[q] = ok ? (10.0f * (d > 0.0f ? 1.0f : (d < 0.0f ? -1.0f : 0.0f)) / n_el) * seed : 0.0f;
     }
     if (q < np_) {
         const bool ok = !(p.ph_mask && p.ph_mask[q]);
         const float d1 = p.pitch_pred[q] - p.pitch[q], d2 = p.energy_pred[q] - p.energy[q];
         const float d3 = logf(p.dur_pred[q] + 1.0f) - logf((float)p.dur[q] + 1.0f);
-        p.d_pitch[q] = ok ? 2.0f * 2.0f * d1 / n_ph : 0.0f;
-        p.d_energy[q] = ok ? 2.0f * 2.0f * d2 / n_ph : 0.0f;
-        p.d_dur[q] = ok ? 2.0f * d3 / (p.dur_pred[q] + 1.0f) / n_ph : 0.0f;
+        p.d_pitch[q] = ok ? (2.0f * 2.0f * d1 / n_ph) * seed : 0.0f;
+        p.d_energy[q] = ok ? (2.0f * 2.0f * d2 / n_ph) * seed : 0.0f;
+        p.d_dur[q] = ok ? (2.0f * d3 / (p.dur_pred[q] + 1.0f) / n_ph) * seed : 0.0f;
     }
 }
 

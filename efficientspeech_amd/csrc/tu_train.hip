@@ -280,9 +280,9 @@ int esmi_train_conv_bwd_f32(const esmi_conv_desc* d, const float* x, const float
     return train_conv_gemm(c, true, dy, w, nullptr, dx, wt, d->precision == 16, S(stream), true, false, pre);
 }
 int esmi_train_layernorm_fwd_f32(const float* x, const float* g, const float* b, int64_t rows, int C, float* y, float* mean,
-                                 float* rstd, const float* res, float* xsum, const uint8_t* rowmask, esmi_stream_t stream) {
+                                 float* rstd, const float* res, float* xsum, const uint8_t* rowmask, int relu_out, esmi_stream_t stream) {
     if (!x || !g || !b || !y || !mean || !rstd || rows <= 0 || C <= 0 || (res && !xsum)) return ESMI_ERR_ARG;
-    ESMI_LAUNCH(train_ln_fwd_kernel, grid1d(rows, 4), dim3(256), 0, S(stream), x, g, b, (long)rows, C, 1e-5f, y, mean, rstd, res, xsum, rowmask);
+    ESMI_LAUNCH(train_ln_fwd_kernel, grid1d(rows, 4), dim3(256), 0, S(stream), x, g, b, (long)rows, C, 1e-5f, y, mean, rstd, res, xsum, rowmask, relu_out ? 1 : 0);
     return launch_status();
 }
 size_t esmi_train_layernorm_bwd_workspace_bytes(int64_t rows, int C) {
@@ -291,7 +291,7 @@ size_t esmi_train_layernorm_bwd_workspace_bytes(int64_t rows, int C) {
 }
 int esmi_train_layernorm_bwd_f32(const float* x, const float* g, const float* mean, const float* rstd, const float* dy,
                                  int64_t rows, int C, float* dx, float* dg, float* db, void* workspace, size_t workspace_bytes,
-                                 esmi_reduce_queue* defer, const uint8_t* rowmask, int in_act, esmi_stream_t stream) {
+                                 esmi_reduce_queue* defer, const uint8_t* rowmask, int in_act, const float* y_relu, esmi_stream_t stream) {
     if (!x || !g || !mean || !rstd || !dy || !dx || !dg || !db || !workspace || rows <= 0 || C <= 0) return ESMI_ERR_ARG;
     if (in_act != 0 && in_act != ACT_RELU && in_act != ACT_TANH) return ESMI_ERR_ARG;
     if (workspace_bytes < esmi_train_layernorm_bwd_workspace_bytes(rows, C)) return ESMI_ERR_WORKSPACE;
@@ -299,13 +299,13 @@ int esmi_train_layernorm_bwd_f32(const float* x, const float* g, const float* me
     long chunks;
     if (C <= 256) {   // dx and the parameter partials in one pass
         chunks = train_chunks(rows, kLnRows);
-        ESMI_LAUNCH(train_ln_bwd_fused_kernel, dim3((unsigned)chunks), dim3(256), 4 * 2 * 256 * sizeof(float), S(stream), x, g, mean, rstd, dy, (long)rows, C, dx, part, rowmask, in_act);
+        ESMI_LAUNCH(train_ln_bwd_fused_kernel, dim3((unsigned)chunks), dim3(256), 4 * 2 * 256 * sizeof(float), S(stream), x, g, mean, rstd, dy, (long)rows, C, dx, part, rowmask, in_act, y_relu);
         if (int rc = launch_status()) return rc;
     } else {
         chunks = train_chunks(rows);
-        ESMI_LAUNCH(train_ln_bwd_dx_kernel, grid1d(rows, 4), dim3(256), 0, S(stream), x, g, mean, rstd, dy, (long)rows, C, dx, rowmask, in_act);
+        ESMI_LAUNCH(train_ln_bwd_dx_kernel, grid1d(rows, 4), dim3(256), 0, S(stream), x, g, mean, rstd, dy, (long)rows, C, dx, rowmask, in_act, y_relu);
         if (int rc = launch_status()) return rc;
-        ESMI_LAUNCH(train_ln_bwd_params_kernel, dim3(grid1d(C, 64), (unsigned)chunks), dim3(64), 0, S(stream), x, mean, rstd, dy, (long)rows, C, part, rowmask);
+        ESMI_LAUNCH(train_ln_bwd_params_kernel, dim3(grid1d(C, 64), (unsigned)chunks), dim3(64), 0, S(stream), x, mean, rstd, dy, (long)rows, C, part, rowmask, y_relu);
         if (int rc = launch_status()) return rc;
     }
     return reduce_or_defer(defer, part, 2L * C, 2L * C, chunks, dg, (long)C, db, S(stream));   // partial rows are [dg (C) | db (C)]: two outputs
@@ -426,7 +426,7 @@ int esmi_train_loss_f32(const esmi_train_loss_args* a, esmi_stream_t stream) {
         return ESMI_ERR_ARG;
     static_assert(ESMI_TRAIN_LOSS_SCRATCH_FLOATS >= kLossBlocks * 6, "scratch size in the header");
     LossP p = {a->mel_pred, a->mel, a->pitch_pred, a->pitch, a->energy_pred, a->energy, a->dur_pred, a->dur, a->mel_mask, a->ph_mask,
-               a->B, a->T, a->L, a->n_mel, a->out, a->d_mel, a->d_pitch, a->d_energy, a->d_dur, a->scratch};
+               a->B, a->T, a->L, a->n_mel, a->out, a->d_mel, a->d_pitch, a->d_energy, a->d_dur, a->scratch, a->grad_seed};
     ESMI_LAUNCH(train_loss_partial_kernel, dim3(kLossBlocks), dim3(256), 256 * sizeof(float), S(stream), p);
     if (int rc = launch_status()) return rc;
     ESMI_LAUNCH(train_loss_final_kernel, dim3(1), dim3(256), 256 * sizeof(float), S(stream), p);

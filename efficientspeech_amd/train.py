@@ -46,6 +46,8 @@ def _defer(ws, *direct):
 
 
 _DIRECT_GRADS = False     # True only while TrainStep._body runs: ONE backward per zeroed buffer, so overwriting == accumulating
+_LOSS_SEED = None         # while TrainStep's step runs: False = the backward is seeded with 1, or the device scalar it is seeded with (the loss
+#                           scale): the loss kernel writes its gradients already multiplied by it and `_Loss.backward` passes them on as they are
 _PACKED_VALID = False     # True only while TrainStep._fwd_bwd runs, after its pack launch: `param._esmi_packed` holds this step's GEMM copies
 
 
@@ -125,7 +127,8 @@ class _LayerNorm(torch.autograd.Function):
     INPUT, so the producer (`conv(..., act=kind, act_grad_downstream=True)`) must not apply the activation's backward again."""
 
     @staticmethod
-    def forward(ctx, x, g, b, res=None, mask=None, in_act=0):
+    def forward(ctx, x, g, b, res=None, mask=None, in_act=0, relu_out=False):
+        """relu_out: y = relu(LN(.)) in the same launch (networks.py:153-154); the backward gates dy with the saved output."""
         assert in_act in (0, ACT_RELU, ACT_TANH) and not (in_act and res is not None)
         x = x.contiguous()
         lib, st = _rt(x)
@@ -135,15 +138,14 @@ class _LayerNorm(torch.autograd.Function):
         if res is not None:
             res, xs = res.contiguous(), torch.empty_like(x)
         lib.esmi_train_layernorm_fwd_f32(_ptr(x), _ptr(g), _ptr(b), rows, Cc, _ptr(y), _ptr(mean), _ptr(rstd), _ptr(res),
-                                         _ptr(xs) if res is not None else None, _ptr(mask), st)
-        ctx.save_for_backward(xs, g, mean, rstd, *((mask,) if mask is not None else ()))
+                                         _ptr(xs) if res is not None else None, _ptr(mask), 1 if relu_out else 0, st)
+        ctx.save_for_backward(xs, g, mean, rstd, mask, y if relu_out else None)
         ctx.params, ctx.has_res, ctx.in_act = (g, b), res is not None, in_act
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, g, mean, rstd = ctx.saved_tensors[:4]
-        mask = ctx.saved_tensors[4] if len(ctx.saved_tensors) > 4 else None
+        x, g, mean, rstd, mask, y_relu = ctx.saved_tensors
         dy = dy.contiguous()
         lib, st = _rt(dy)
         rows, Cc = x.numel() // x.shape[-1], x.shape[-1]
@@ -152,8 +154,8 @@ class _LayerNorm(torch.autograd.Function):
         nws = lib.esmi_train_layernorm_bwd_workspace_bytes(rows, Cc)
         ws = _new((nws,), x, torch.uint8)
         lib.esmi_train_layernorm_bwd_f32(_ptr(x), _ptr(g), _ptr(mean), _ptr(rstd), _ptr(dy), rows, Cc, _ptr(dx), _ptr(dg), _ptr(db),
-                                         _ptr(ws), nws, _defer(ws, g_direct, b_direct), _ptr(mask), ctx.in_act, st)
-        return dx, (None if g_direct else dg), (None if b_direct else db), (dx if ctx.has_res else None), None, None
+                                         _ptr(ws), nws, _defer(ws, g_direct, b_direct), _ptr(mask), ctx.in_act, _ptr(y_relu), st)
+        return dx, (None if g_direct else dg), (None if b_direct else db), (dx if ctx.has_res else None), None, None, None
 
 
 class _Act(torch.autograd.Function):
@@ -335,17 +337,21 @@ class _Loss(torch.autograd.Function):
         out = _new((5,), mel_pred)
         grads = [torch.empty_like(t) for t in (mel_pred, pitch_pred, energy_pred, dur_pred)]
         scratch = _new((1536,), mel_pred)          # ESMI_TRAIN_LOSS_SCRATCH_FLOATS; held until the call has been enqueued
+        seed = _LOSS_SEED                          # None: unknown here (scaled in backward); False: 1; else the device scalar
         a = _lib.TrainLossArgs(_ptr(mel_pred), _ptr(mel), _ptr(pitch_pred), _ptr(pitch), _ptr(energy_pred), _ptr(energy),
                                _ptr(dur_pred), _ptr(dur), _ptr(mel_mask), _ptr(ph_mask), B, T, L, nm, _ptr(out),
-                               *[_ptr(g) for g in grads], _ptr(scratch))
+                               *[_ptr(g) for g in grads], _ptr(scratch), _ptr(seed) if torch.is_tensor(seed) else None)
         lib.esmi_train_loss_f32(C.byref(a), st)
         ctx.save_for_backward(*grads)
+        ctx.prescaled = seed is not None
         parts, total = out[:4], out[4]
         ctx.mark_non_differentiable(parts)
         return parts, total
 
     @staticmethod
     def backward(ctx, _dparts, dtotal):
+        if ctx.prescaled:                          # TrainStep told the forward what this backward is seeded with
+            return tuple(ctx.saved_tensors) + (None,) * 6
         return tuple(g * dtotal for g in ctx.saved_tensors) + (None,) * 6     # (seed 1 from `.backward()`: four scalings, exact)
 
 
@@ -364,8 +370,8 @@ def conv(x, m, n_out=None, act=0, act_grad_downstream=False):
     return _Conv.apply(x, m.weight, m.bias, s, p, m.groups, tr, full if n_out is None else min(full, n_out), act, act_grad_downstream)
 
 
-def layer_norm(x, m, res=None, mask=None, in_act=0):
-    return _LayerNorm.apply(x, m.weight, m.bias, res, mask, in_act)
+def layer_norm(x, m, res=None, mask=None, in_act=0, relu_out=False):
+    return _LayerNorm.apply(x, m.weight, m.bias, res, mask, in_act, relu_out)
 
 
 def act(x, kind):
@@ -416,7 +422,7 @@ def fuse_forward(fuse, feats, mask_u8):
 def predictor_forward(dec, fused):
     """AcousticDecoder.forward, networks.py:151-165 -> (pred (B, T, 1), features (B, T, dim))."""
     y = conv(fused, dec.conv1[0], act=ACT_RELU, act_grad_downstream=True)
-    y = act(layer_norm(y, dec.norm1, in_act=ACT_RELU), ACT_RELU)
+    y = layer_norm(y, dec.norm1, in_act=ACT_RELU, relu_out=True)
     y = conv(y, dec.conv2[0], act=ACT_RELU)
     if dec.duration:
         return conv(y, dec.linear, act=ACT_RELU), layer_norm(y, dec.norm2)
@@ -447,7 +453,7 @@ def decoder_forward(dec, features):
     return conv(skip, dec.mel_linear)
 
 
-def train_forward(net, x):
+def train_forward(net, x, mask_mel=True):
     """Phoneme2Mel.forward(x, train=True), networks.py:336-434 -> dict(mel, pitch, energy, duration, mel_len)."""
     pe = net.encoder
     phoneme = x["phoneme"]
@@ -470,7 +476,7 @@ def train_forward(net, x):
     L = int(x["mel"].shape[1]) if "mel" in x else int(torch.max(x["mel_len"]).item())
     features = _Repeat.apply(feat4, cum, L)
     mel = decoder_forward(net.decoder, features)
-    if ph_mask is not None:
+    if ph_mask is not None and mask_mel:
         frames = torch.arange(L, device=mel.device)[None, :] >= mel_len[:, None]        # FeatureUpsampler's masks, one bit per frame
         mel = _MaskRows.apply(mel, _mask_u8(frames))
     return {"mel": mel, "pitch": pitch_pred, "energy": energy_pred, "duration": dur_pred, "mel_len": mel_len}
@@ -481,7 +487,9 @@ def training_loss(net, x, y):
     weighted total 10 mel + 2 pitch + 2 energy + duration."""
     xx = dict(x)
     xx.setdefault("mel", y["mel"])
-    out = train_forward(net, xx)
+    # (the masked_fill of the padded mel frames, networks.py:423-424, is skipped here: the loss leaves those frames out and
+    #  gives them a zero gradient either way)
+    out = train_forward(net, xx, mask_mel=False)
     B, T = x["phoneme"].shape
     ph_mask = _mask_u8(x["phoneme_mask"]) if x.get("phoneme_mask") is not None else None
     mel_mask = _mask_u8(x["mel_mask"]) if x.get("mel_mask") is not None else None
@@ -554,6 +562,7 @@ class TrainStep:
             self._scaler = torch.tensor([init_scale, growth_factor, backoff_factor, growth_interval, 0, 0, 0, 0], dtype=torch.float32, device=dev)
             self._absmax = torch.zeros(1, dtype=torch.float32, device=dev)
         self._graphs = {}
+        self._one = torch.ones(1, dtype=torch.float32, device=dev)
         self._build_pack_list()
         if self.graph or precision == 16:
             self._step_dev = torch.zeros(1, dtype=torch.int32, device=dev)
@@ -707,7 +716,7 @@ class TrainStep:
     def _fwd_bwd(self, x, y):
         """Forward, loss, backward, and the one launch that finishes every parameter gradient: everything up to the exchange.
         Capturable as a hipGraph (no host reads, no collectives)."""
-        global _DIRECT_GRADS, PRECISION, _REDUCE_Q, _PACKED_VALID
+        global _DIRECT_GRADS, PRECISION, _REDUCE_Q, _PACKED_VALID, _LOSS_SEED
         f = self.flat
         f.zero_grad()
         rq = (_lib.ReduceQueue(), [])
@@ -718,17 +727,19 @@ class TrainStep:
             if USE_MATRIX_PIPE and self._pack_n:   # every operator of this step reads these copies of the current weights
                 lib0.esmi_train_pack_weights_f32(self._pack_descs, self._pack_w, self._pack_n, st0)
                 _PACKED_VALID = True
+            _LOSS_SEED = self._scaler[:1] if amp else False
             parts, total = training_loss(self.net, x, y)
             _DIRECT_GRADS = True                   # one backward on a zeroed buffer: operators write parameter gradients in place
             _REDUCE_Q = rq
             if amp:
                 total.backward(gradient=self._scaler[0].reshape(total.shape))     # GradScaler.scale(loss).backward(): the seed is the device-side scale
             else:
-                total.backward()
+                total.backward(gradient=self._one.reshape(total.shape))
         finally:
             _DIRECT_GRADS = False
             _REDUCE_Q = None
             _PACKED_VALID = False
+            _LOSS_SEED = None
             PRECISION = old_precision
         lib0.esmi_train_reduce_flush_f32(C.byref(rq[0]), st0)      # every queued parameter-gradient reduction in one launch
         rq[1].clear()

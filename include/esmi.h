@@ -488,12 +488,14 @@ int esmi_train_conv_bwd_f32(const esmi_conv_desc* d, const float* x, const float
  * out zero (the masked_fill of networks.py:76,84) and pass no gradient: give the backward the same mask. */
 int esmi_train_layernorm_fwd_f32(const float* x, const float* g, const float* b, int64_t rows, int C, float* y, float* mean,
                                  float* rstd, const float* res /* or NULL */, float* xsum /* with res */,
-                                 const uint8_t* rowmask /* or NULL */, esmi_stream_t stream);
+                                 const uint8_t* rowmask /* or NULL */, int relu_out /* 1: y = relu(LN(.)), networks.py:153-154 */,
+                                 esmi_stream_t stream);
 size_t esmi_train_layernorm_bwd_workspace_bytes(int64_t rows, int C);
 int esmi_train_layernorm_bwd_f32(const float* x, const float* g, const float* mean, const float* rstd, const float* dy,
                                  int64_t rows, int C, float* dx, float* dg, float* db, void* workspace, size_t workspace_bytes,
                                  esmi_reduce_queue* defer /* or NULL */, const uint8_t* rowmask /* or NULL */,
                                  int in_act /* 0, or 1 ReLU / 3 tanh: x is that activation's output and dx is returned for its INPUT */,
+                                 const float* y_relu /* NULL, or the forward's output when it ran with relu_out: dy counts only where y > 0 */,
                                  esmi_stream_t stream);
 /* kind: 1 ReLU, 2 GELU (erf), 3 tanh.  Backward reads the OUTPUT for ReLU / tanh and the INPUT for GELU as `saved`. */
 int esmi_train_act_fwd_f32(const float* x, int64_t n, int kind, float* y, esmi_stream_t stream);
@@ -533,6 +535,7 @@ typedef struct esmi_train_loss_args {
     int B, T, L, n_mel;
     float *out, *d_mel, *d_pitch, *d_energy, *d_dur;
     float* scratch;                         /* ESMI_TRAIN_LOSS_SCRATCH_FLOATS floats (partial sums of the two-stage reduction) */
+    const float* grad_seed;                 /* NULL, or one device float every d_* is multiplied by (the backward's seed: the loss scale) */
 } esmi_train_loss_args;
 int esmi_train_loss_f32(const esmi_train_loss_args* a, esmi_stream_t stream);
 /* torch.optim.AdamW's update of one flat buffer (model.py:279-283); step >= 1.  The hyper-parameters are doubles, as the Python

@@ -100,6 +100,26 @@ def test_layernorm_with_residual_and_row_mask(rows, C):
 
 
 @gpu
+def test_layernorm_with_relu_output():
+    """relu(LN(relu(conv))) as the predictors run it (networks.py:152-154): the first ReLU in the convolution's launch with its backward
+    in the LayerNorm's, the second in the LayerNorm's forward with dy gated by the saved output."""
+    x = _rand(2, 90, 128, seed=41).requires_grad_()
+    w, b = _rand(128, 128, 3, seed=42, scale=0.1).requires_grad_(), _rand(128, seed=43).requires_grad_()
+    g, beta = (_rand(128, seed=44) + 1.0).requires_grad_(), _rand(128, seed=45).requires_grad_()
+    m = (torch.arange(90)[None, :] >= torch.tensor([90, 31])[:, None]).to(DEV)
+    for mask in (None, m.view(torch.uint8).contiguous()):
+        got = train._LayerNorm.apply(train._Conv.apply(x, w, b, 1, 1, 1, False, 90, train.ACT_RELU, True), g, beta, None, mask, train.ACT_RELU, True)
+        ref = F.relu(F.layer_norm(F.relu(F.conv1d(x.transpose(1, 2), w, b, padding=1).transpose(1, 2)), (128,), g, beta))
+        if mask is not None:
+            ref = ref.masked_fill(m[..., None], 0.0)
+        _close(got, ref, 3e-5, "forward")
+        dy = _rand(2, 90, 128, seed=46)
+        for a, r, what in zip(torch.autograd.grad(got, (x, w, b, g, beta), dy), torch.autograd.grad(ref, (x, w, b, g, beta), dy),
+                              ("dx", "dw", "db", "dgamma", "dbeta")):
+            _close(a, r, 1e-4, what)
+
+
+@gpu
 def test_conv_activation_layernorm_chain():
     """LN(tanh(conv(x))) / LN(relu(conv(x))) with the activation in the convolution's launch and its backward in the LayerNorm's."""
     for kind, fn in ((train.ACT_TANH, torch.tanh), (train.ACT_RELU, F.relu)):
@@ -280,6 +300,6 @@ def test_simulated_conv_forward_and_gradients(cfg, monkeypatch):
 def test_simulated_layernorm_attention_loss():
     _sim_case(lambda: (test_layernorm(300, 32), test_layernorm(77, 64), test_layernorm_with_residual_and_row_mask(130, 128),
                        test_layernorm_with_residual_and_row_mask(40, 320), test_conv_with_fused_activation(),
-                       test_conv_activation_layernorm_chain(),
+                       test_conv_activation_layernorm_chain(), test_layernorm_with_relu_output(),
                        test_attention_core(2, 33, 32, 2), test_activations(train.ACT_GELU, F.gelu),
                        test_embedding_repeat_cat_mask_add(), test_loss_and_adamw_against_torch()))
