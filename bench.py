@@ -504,7 +504,7 @@ def main():
         tnet = make_net(cfg, sd, dev).train()
         tx, ty = _train.synthetic_batch(tb, tt, a.dur, dev, seed=77 + rank)
         # hipGraph replay of the step (N = 1: the whole step; N > 1: forward + loss + backward, then the all-reduce and the optimizer
-        # launch eagerly): ~330 launches per step make the eager step host-bound
+        # launch eagerly): 200 launches per step; the replay takes the host out of the loop
         ts = _train.TrainStep(tnet, world_size=world, graph=True)
         for _ in range(3):
             tl0 = ts.step(tx, ty)
@@ -552,7 +552,7 @@ def main():
                              "roofline": {"bound": "mfma", "algorithmic_flops_per_step": step_flops,
                                           "achieved": step_flops / ttr / 1e12, "peak": F16_PEAK_TFLOPS / 3.0, "unit": "TFLOP/s",
                                           "frac": step_flops / ttr / 1e12 / (F16_PEAK_TFLOPS / 3.0),
-                                          "note": "whole step (several hundred launches, no dominant kernel): 3 x the forward's "
+                                          "note": "whole step (200 launches, no dominant kernel): 3 x the forward's "
                                                   "contraction FLOPs over the step time against the split-f16 bound; the step is "
                                                   "bound by launch count and by the partial-sum traffic of the deterministic "
                                                   "weight-gradient reductions, not by the matrix pipe (DESIGN.md 3.6)"},
