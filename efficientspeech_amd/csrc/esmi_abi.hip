@@ -44,10 +44,16 @@ EncWs enc_ws(const esmi_encoder_block_shape* s) {
 
 }  // namespace
 
-#ifdef ESMI_CHAIN_TRACE
-__device__ long long* g_chain_trace_dev = nullptr;
-extern "C" void esmi_dev_set_chain_trace(long long* ptr) {
-    hipMemcpyToSymbol(HIP_SYMBOL(g_chain_trace_dev), &ptr, sizeof(ptr));
+#ifdef ESMI_CHAIN_TRACE   // development: tools/trace_chain.py
+extern "C" {
+void esmi_dev_set_chain_trace_enc_attn_ffn(long long*);
+void esmi_dev_set_chain_trace_enc_block(long long*);
+void esmi_dev_set_chain_trace_enc_fuse_va(long long*);
+void esmi_dev_set_chain_trace_enc_merge(long long*);
+void esmi_dev_set_chain_trace(long long* ptr) {
+    esmi_dev_set_chain_trace_enc_attn_ffn(ptr); esmi_dev_set_chain_trace_enc_block(ptr);
+    esmi_dev_set_chain_trace_enc_fuse_va(ptr); esmi_dev_set_chain_trace_enc_merge(ptr);
+}
 }
 #endif
 

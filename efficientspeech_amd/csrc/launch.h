@@ -92,6 +92,13 @@ int set_range_flag_dec_256_5(int* flag);
 int set_range_flag_dec_256_3(int* flag);
 int set_range_flag_hifigan(int* flag);
 int set_range_flag_train(int* flag);
+// development (-DESMI_CHAIN_TRACE): every translation unit with chain kernels owns a copy of the trace pointer
+#ifdef ESMI_CHAIN_TRACE
+#define ESMI_TU_CHAIN_TRACE_SETTER(tu) extern "C" void esmi_dev_set_chain_trace_##tu(long long* ptr) { \
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_chain_trace_dev), &ptr, sizeof(ptr)); }
+#else
+#define ESMI_TU_CHAIN_TRACE_SETTER(tu)
+#endif
 #if ESMI_RANGE_CHECK && !defined(ESMI_WAVESIM)
 #define ESMI_TU_RANGE_SETTER(tu) namespace esmi { int set_range_flag_##tu(int* flag) { \
     const hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(g_esmi_range_flag), &flag, sizeof(flag)); return e == hipSuccess ? ESMI_OK : (int)e; } }

@@ -5,6 +5,7 @@
 
 using namespace esmi;
 ESMI_TU_RANGE_SETTER(enc_attn_ffn)
+ESMI_TU_CHAIN_TRACE_SETTER(enc_attn_ffn)
 
 namespace esmi {
 

@@ -5,6 +5,7 @@
 
 using namespace esmi;
 ESMI_TU_RANGE_SETTER(enc_block)
+ESMI_TU_CHAIN_TRACE_SETTER(enc_block)
 
 namespace esmi {
 

@@ -5,6 +5,7 @@
 
 using namespace esmi;
 ESMI_TU_RANGE_SETTER(enc_merge)
+ESMI_TU_CHAIN_TRACE_SETTER(enc_merge)
 
 namespace esmi {
 

@@ -20,7 +20,7 @@
 #define ESMI_CT_THREAD 0
 #endif
 // development only: shader-clock stamps of workgroup 7 of each chain kernel -> g_chain_trace[kernel_slot*64 + n]
-extern __device__ long long* g_chain_trace_dev;
+static __device__ long long* g_chain_trace_dev = nullptr;   // one per translation unit (ESMI_TU_CHAIN_TRACE_SETTER, launch.h)
 #define ESMI_CT_INIT(slot) int ct_n_ = 0; const bool ct_on_ = blockIdx.x == ESMI_CT_BLOCK && threadIdx.x == ESMI_CT_THREAD; const int ct_slot_ = (slot)
 #define ESMI_CT() do { if (ct_on_ && g_chain_trace_dev) g_chain_trace_dev[ct_slot_ * 64 + ct_n_] = (long long)ESMI_CT_CLOCK(); ++ct_n_; } while (0)
 #else
