@@ -6,6 +6,7 @@ or fails to load, `load()` raises.  (tests/ may bind the wave-simulator build of
 same sources through `bind()`; nothing in this package does.)
 """
 import contextlib
+import itertools
 import ctypes as C
 import os
 import threading
@@ -156,8 +157,12 @@ EXPORTS = (
 )
 
 
+_BIND_COUNT = itertools.count(1)
+
+
 def bind(lib):
     """Declare argument / return types of every entry point of include/esmi.h on `lib`."""
+    lib._esmi_generation = next(_BIND_COUNT)      # identity of this binding: packed weight blobs are only valid for the build that made them
     i, sz, P = C.c_int, C.c_size_t, C.POINTER
     lib.esmi_version.restype = i
     lib.esmi_backend.restype = C.c_char_p
@@ -293,7 +298,8 @@ def load():
 @contextlib.contextmanager
 def use_library(path):
     """Bind another build of the SAME ABI (e.g. libesmi_fp32mfma.so) for the duration of the block.  Packed weight blobs are
-    only valid for the library that made them: build the modules used inside the block inside the block."""
+    only valid for the build that made them (the split-f16 and the exact-fp32 build store different blobs): the modules' pack caches
+    key on the binding (`generation()`), so a module used on both sides of the switch re-packs."""
     global _LIB
     old = _LIB
     _LIB = bind(C.CDLL(os.path.abspath(path)))
@@ -301,6 +307,11 @@ def use_library(path):
         yield _LIB
     finally:
         _LIB = old
+
+
+def generation():
+    """Identity of the currently bound library (changes with `use_library`)."""
+    return load()._esmi_generation
 
 
 def backend(lib=None):

@@ -113,7 +113,7 @@ class _PackCache:
         `invalidate()` (the module mirrors call it from `_apply` and after `load_state_dict`)."""
         if self.plist is None:
             self.plist = list(params())
-        key = tuple((p.data_ptr(), p._version) for p in self.plist)
+        key = (_lib.generation(),) + tuple((p.data_ptr(), p._version) for p in self.plist)
         if key != self.key:
             self.val = build()
             self.key = key
