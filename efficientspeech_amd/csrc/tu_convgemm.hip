@@ -53,55 +53,44 @@ int launch_convgemm(ConvGemmP p, hipStream_t st) {
         nt = p.c_out > 64 ? 4 : (p.c_out > 32 ? 2 : 1);
     }
 #if ESMI_CHAIN_SPLIT
-    // large plain convolutions / Linears: weight tile staged through LDS once per 128 positions (convgemm.h)
-    if (p.mode == MODE_CONV && p.stride == 1 && !p.ids && (p.c_in & 31) == 0 && p.c_out > 64 && (long)p.B * p.n_out >= ESMI_GEMM_LDS_MIN_ROWS) {
-        // tile: 64 rows x 128 channels per wave (MT = 2, NT = 4) unless a LayerNorm / row-dot epilogue needs 256 channels in one wave
-        const bool wide = full_row && nt > 4;
-        if ((long)p.B * p.n_out >= (1L << 31)) return ESMI_ERR_ARG;
+    // large plain convolutions / Linears: operands staged through LDS by convgemm_dma_kernel (convgemm.h) -- needs input rows ==
+    // output rows (flat-row addressing) and an input tensor of < 2^31 elements (32-bit lane offsets); anything else streams from L2 below
+    if (p.mode == MODE_CONV && p.stride == 1 && !p.ids && (p.c_in & 31) == 0 && p.c_out > 64 && (long)p.B * p.n_out >= ESMI_GEMM_LDS_MIN_ROWS &&
+        p.n_in == p.n_out && ((long)p.B * p.n_in * p.lda + p.a_coff + p.c_in) < (1L << 31)) {
         constexpr int NWV = ESMI_GEMM_LDS_WAVES;
-        const long rows = (long)p.B * p.n_out, wg_rows = (wide ? 32 : 64) * NWV;
-        dim3 g2((unsigned)((rows + wg_rows - 1) / wg_rows), full_row ? 1 : (p.c_out + 127) / 128);
-        const bool dma = !wide && p.n_in == p.n_out && ((long)p.B * p.n_in * p.lda + p.a_coff + p.c_in) < (1L << 31);   // LDS-DMA input rows
-        if (dma) {
-            // 64 rows per wave when that still gives every CU its two workgroups, else 32 (training at phoneme rate: 12,800 rows)
-            const int ny = full_row ? 1 : (p.c_out + 127) / 128;
-            const int mt = ((rows + 64 * NWV - 1) / (64 * NWV)) * ny >= 512 ? 2 : 1;
-            const long wr = 32 * mt * NWV;
-            const int nx = (int)((rows + wr - 1) / wr);
-            dim3 g1((unsigned)((nx + 7) / 8 * 8 * ny));
-            const bool pre = p.Wp != nullptr && aligned16(p.Wp);
-            const int lds_bytes = convgemm_dma_bytes<4>(mt, p.k, p.dil, pre);
-            static AttrOnce once[8];
-#define ESMI_DMA_CASE(MT_, AMP_, PRE_, slot)                                                                                   \
+        const long rows = (long)p.B * p.n_out;
+        // a LayerNorm / row-dot epilogue over 129..256 channels needs them all in one wave: 32 rows x 256 channels per wave; else
+        // 128 channels per wave and 64 rows when that still gives every CU its two workgroups, 32 otherwise (training at phoneme rate)
+        const bool wide = full_row && nt > 4;
+        const int ny = full_row ? 1 : (p.c_out + 127) / 128;
+        const int mt = (!wide && ((rows + 64 * NWV - 1) / (64 * NWV)) * ny >= 512) ? 2 : 1;
+        const long wr = 32 * mt * NWV;
+        const int nx = (int)((rows + wr - 1) / wr);
+        dim3 g1((unsigned)((nx + 7) / 8 * 8 * ny));
+        const bool pre = p.Wp != nullptr && aligned16(p.Wp);
+        const int lds_bytes = wide ? convgemm_dma_bytes<8>(1, p.k, p.dil, pre) : convgemm_dma_bytes<4>(mt, p.k, p.dil, pre);
+        static AttrOnce once[12];
+#define ESMI_DMA_CASE(NT_, MT_, AMP_, PRE_, slot)                                                                              \
     do {                                                                                                                       \
-        if (int rc = raise_lds_limit(reinterpret_cast<const void*>(convgemm_dma_kernel<4, MT_, NWV, AMP_, PRE_>), once[slot])) return rc; \
-        ESMI_LAUNCH((convgemm_dma_kernel<4, MT_, NWV, AMP_, PRE_>), g1, dim3(64 * NWV), lds_bytes, st, p, nx, ny);             \
+        if (int rc = raise_lds_limit(reinterpret_cast<const void*>(convgemm_dma_kernel<NT_, MT_, NWV, AMP_, PRE_>), once[slot])) return rc; \
+        ESMI_LAUNCH((convgemm_dma_kernel<NT_, MT_, NWV, AMP_, PRE_>), g1, dim3(64 * NWV), lds_bytes, st, p, nx, ny);           \
     } while (0)
-            const int variant = (mt == 2 ? 4 : 0) + (p.amp ? 2 : 0) + (pre ? 1 : 0);
-            switch (variant) {
-                case 0: ESMI_DMA_CASE(1, false, false, 0); break;
-                case 1: ESMI_DMA_CASE(1, false, true, 1); break;
-                case 2: ESMI_DMA_CASE(1, true, false, 2); break;
-                case 3: ESMI_DMA_CASE(1, true, true, 3); break;
-                case 4: ESMI_DMA_CASE(2, false, false, 4); break;
-                case 5: ESMI_DMA_CASE(2, false, true, 5); break;
-                case 6: ESMI_DMA_CASE(2, true, false, 6); break;
-                default: ESMI_DMA_CASE(2, true, true, 7); break;
-            }
-#undef ESMI_DMA_CASE
-        } else if (!wide && !p.amp) {
-            ESMI_LAUNCH((convgemm_lds_kernel<4, 2, NWV, false>), g2, dim3(64 * NWV), convgemm_lds_bytes<4>(), st, p);
-        } else if (!wide) {
-            ESMI_LAUNCH((convgemm_lds_kernel<4, 2, NWV, true>), g2, dim3(64 * NWV), convgemm_lds_bytes<4>(), st, p);
-        } else if (!p.amp) {
-            static AttrOnce once;
-            if (int rc = raise_lds_limit(reinterpret_cast<const void*>(convgemm_lds_kernel<8, 1, NWV, false>), once)) return rc;
-            ESMI_LAUNCH((convgemm_lds_kernel<8, 1, NWV, false>), g2, dim3(64 * NWV), convgemm_lds_bytes<8>(), st, p);
-        } else {
-            static AttrOnce once;
-            if (int rc = raise_lds_limit(reinterpret_cast<const void*>(convgemm_lds_kernel<8, 1, NWV, true>), once)) return rc;
-            ESMI_LAUNCH((convgemm_lds_kernel<8, 1, NWV, true>), g2, dim3(64 * NWV), convgemm_lds_bytes<8>(), st, p);
+        const int variant = (wide ? 8 : (mt == 2 ? 4 : 0)) + (p.amp ? 2 : 0) + (pre ? 1 : 0);
+        switch (variant) {
+            case 0: ESMI_DMA_CASE(4, 1, false, false, 0); break;
+            case 1: ESMI_DMA_CASE(4, 1, false, true, 1); break;
+            case 2: ESMI_DMA_CASE(4, 1, true, false, 2); break;
+            case 3: ESMI_DMA_CASE(4, 1, true, true, 3); break;
+            case 4: ESMI_DMA_CASE(4, 2, false, false, 4); break;
+            case 5: ESMI_DMA_CASE(4, 2, false, true, 5); break;
+            case 6: ESMI_DMA_CASE(4, 2, true, false, 6); break;
+            case 7: ESMI_DMA_CASE(4, 2, true, true, 7); break;
+            case 8: ESMI_DMA_CASE(8, 1, false, false, 8); break;
+            case 9: ESMI_DMA_CASE(8, 1, false, true, 9); break;
+            case 10: ESMI_DMA_CASE(8, 1, true, false, 10); break;
+            default: ESMI_DMA_CASE(8, 1, true, true, 11); break;
         }
+#undef ESMI_DMA_CASE
         return launch_status();
     }
 #endif

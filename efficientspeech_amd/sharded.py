@@ -245,6 +245,14 @@ class ShardedMelPipeline:
             mel, mel_len = self._compute(x)
         self.last_ready = done
         if not self.gather:
+            if done is not None:
+                # bound the host's run-ahead in two-stream mode: every step's buffers are shared between two streams
+                # (record_stream), so the allocator cannot hand them out again until the GPU has passed them -- a host 100 steps
+                # ahead of a 9 ms step (base ES: 252 MB of mel per step) was found allocating fresh blocks for every step,
+                # 22-36 ms per step instead of 9.1 (profiles/r03_probes/two_stream_runahead.md)
+                self.inflight.append((done, None, None))
+                while len(self.inflight) > self.depth + 1:
+                    self.inflight.pop(0)[0].synchronize()
             self.last = (mel, mel_len)
             return self.last
         if self.comm is None:
