@@ -339,161 +339,46 @@ static __global__ __launch_bounds__(256) void conv_to1_kernel(const ConvGemmP p)
 }
 
 #if ESMI_CHAIN_SPLIT
-// ---- the same implicit GEMM with the WEIGHT tile staged through LDS (large shapes of the per-op plan: base ES block 1,
-// long sequences).  convgemm_kernel streams both operands from L2 per wave: at 65536 rows x 3072 columns (base qkv) every
-// wave re-reads its 128 weight rows for each of its row tiles, and the kernel sits at ~8 % of the matrix pipe behind L2
-// latency.  Here a 256-thread workgroup owns 128 positions x BN = 32*NT channels: each wave keeps its own 32 rows (so the
-// LayerNorm / row-dot epilogues stay in-wave) and reads its A fragments straight from global memory one chunk ahead, while
-// the BN x 32-channel weight chunk is fetched ONCE per workgroup, split into the two f16 planes of 2^8 W once (not once per
-// wave), and double-buffered in LDS: [buffer][plane][BN rows][16 data + 4 pad dwords] -- the 80-byte row stride makes both the
-// ds_write_b64 of the staging threads and the 16-byte B-fragment reads (lane = weight row) bank-conflict free.
-// Restrictions (the launcher falls back to convgemm_kernel otherwise): MODE_CONV, stride 1, no embedding gather, Cin % 32 == 0.
-constexpr int kGemmRowDw = 20;   // dwords per weight row and plane in LDS
+// ---- convgemm_dma_kernel: the same implicit GEMM with BOTH operands staged through LDS (large shapes of the per-op plan: base ES
+// block 1, long sequences, the training step's GEMMs).  convgemm_kernel streams both operands from L2 per wave: at 65536 rows x
+// 3072 columns (base qkv) every wave re-reads its 128 weight rows for each of its row tiles, and the kernel sits at ~8 % of the
+// matrix pipe behind L2 latency.  Here a 256-thread workgroup owns 32 MT x 4 rows (the FLAT index b * n_out + t: a tile may span
+// utterances, so 64-position sequences still fill it) x BN = 32 NT channels; each wave keeps its own 32 MT rows, so the LayerNorm /
+// row-dot epilogues stay in-wave (NT = 8, MT = 1 when they span 256 channels; else NT = 4 and MT = 2 when the grid is large enough).
+//  * weight tile, double-buffered: either split per workgroup from the fp32 rows into the two f16 planes of 2^8 W
+//    ([buffer][plane][BN rows][16 data + 4 pad dwords]: the 80-byte row stride keeps the staging ds_write_b64 and the 16-byte
+//    B-fragment reads conflict-free), or -- when the caller has the esmi_pack_bfrag_f32 blob (`Wp`) -- copied by LDS-DMA: each 1 KiB
+//    block of the blob IS one (tile, 16-k step, piece) fragment in lane order.
+//  * input rows by LDS-DMA.  Round 2's version read the A fragments from global memory into registers; ablations on it
+//    (profiles/r03_probes/gemm_lds_ablation.md) put its time there: a lane of the MFMA operand layout owns 32 contiguous bytes of
+//    ITS OWN row, so every global_load_dwordx4 of a wave touched 32 different cache lines for 16 bytes each (no A loads: -30 %; no
+//    weight loads: -8 %; no barrier: -3 %).  Now eight lanes fetch one whole 128-byte row chunk (8 lines per instruction) with
+//    global_load_lds_dwordx4 -- memory -> LDS, no staging registers -- into a wave-PRIVATE fp32 tile, and the fragments are read
+//    back with ds_read_b128.  LDS-DMA writes lane l's 16 bytes at base + 16 l, so the tile is plain row-major [row][8 pieces]; the
+//    bank spread comes from WHICH piece a lane fetches instead: slot s of row r holds piece s ^ ((r >> 1) & 7), and 16 consecutive
+//    rows reading the same piece hit 16 different 16-byte bank groups.  The tile is single-buffered: a wave reads its fragments of
+//    chunk c into registers, waits for them (lgkmcnt), and only then issues the DMA of chunk c + 1 into the same rows -- no other
+//    wave touches them.  Rows whose tap falls outside the utterance (or past the last row) are fetched from a clamped in-range
+//    address and zeroed by the reader, which knows its own row's position.
+//  * convolution taps re-use the rows: when the taps' reach (k - 1) * dil is at most kGemmHaloMax rows the wave's tile carries that
+//    many extra rows, the K loop runs channel chunk OUTER / tap INNER, and one DMA per chunk serves all k taps (tap j reads the
+//    fragments j * dil rows further down) -- a third of the input traffic of a k = 3 convolution.  Otherwise (long dilated HiFi-GAN
+//    taps) each tap fetches its own shifted rows, tap outer.
+//  * workgroups are numbered so that the c_out / BN column tiles of one row tile are neighbours ON THE SAME XCD (ids congruent
+//    mod 8 share an XCD and its L2): they sweep the same input rows at the same time and three of four fetches hit L2.
+// Restrictions (the launcher falls back to convgemm_kernel otherwise): MODE_CONV, stride 1, n_in == n_out, no embedding gather,
+// Cin % 32 == 0, an input tensor of < 2^31 elements (32-bit lane offsets).
+constexpr int kGemmRowDw = 20;   // dwords per weight row and plane in LDS (weights split in the kernel)
 template <int NT>
 __host__ __device__ constexpr int convgemm_lds_bytes() { return 2 * 2 * 32 * NT * kGemmRowDw * 4; }
 
 #ifndef ESMI_GEMM_LDS_WAVES
-#define ESMI_GEMM_LDS_WAVES 4   // waves (32 positions each) sharing one weight tile.  8 halves each wave's share of the staging work
-                                // but couples 8 waves to one barrier: measured 11.50 vs 10.45 ms/step on base ES (r02), so 4
+#define ESMI_GEMM_LDS_WAVES 4   // waves sharing one weight tile.  8 halves each wave's share of the staging work but couples 8 waves
+                                // to one barrier: 11.50 vs 10.45 ms/step on base ES in round 2, +2 % on the round-3 kernel: 4
 #endif
-// MT = 32-row tiles per wave.  The B fragments are the LDS traffic of this kernel (one 16-byte read per lane and plane feeds
-// 3 MT products): with MT = 1 eight waves of a CU ask LDS for ~85 B/clk of its 128 to keep the matrix pipe full, and the counters
-// show the waves parked half of the time (profiles/r03_probes/gemm_lds_counters.md); MT = 2 halves the reads per product and the
-// staging work per output.  Rows are the FLAT index b * n_out + t (a tile may span utterances; each lane derives its own (b, t)
-// once), so short sequences (base block 2: 64 positions) still fill 64 * NWV-row workgroup tiles.
-template <int NT, int MT = 1, int NWV = ESMI_GEMM_LDS_WAVES, bool AMP = false>
-__global__ __launch_bounds__(64 * NWV, 2) void convgemm_lds_kernel(const ConvGemmP p) {
-    constexpr int BN = 32 * NT, PLANE = BN * kGemmRowDw, NTHR = 64 * NWV, NU = (256 * NT) / NTHR, WROWS = 32 * MT, ROWS = WROWS * NWV;
-    static_assert(NU * NTHR == 256 * NT, "staging items divide evenly");
-    ESMI_DYN_LDS(lds);
-    unsigned* wt = reinterpret_cast<unsigned*>(lds);   // [2 buffers][2 planes][PLANE]
-    const int tid = (int)threadIdx.x, lane = lane_id(), w = wave_id();
-    const int i = lane & 31, h = lane >> 5;
-    const long n_rows = (long)p.B * p.n_out;
-    const long r0 = (long)blockIdx.x * ROWS + WROWS * w;   // this wave's first flat row
-    const int n0 = (int)blockIdx.y * BN;
-    int rb[MT], rt[MT];       // (utterance, position) of this lane's row in each of the wave's tiles
-    bool rok[MT];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-        const long r = r0 + 32 * mt + i;
-        rok[mt] = r < n_rows;
-        rb[mt] = rok[mt] ? (int)(r / p.n_out) : 0;
-        rt[mt] = rok[mt] ? (int)(r - (long)rb[mt] * p.n_out) : 0;
-    }
-
-    f32x16 acc[MT * NT];   // tile (mt, nt) at mt * NT + nt
-#pragma unroll
-    for (int q = 0; q < MT * NT; ++q) acc[q] = zero16();
-    const int kchunks = p.c_in >> 5, n_it = p.k * kchunks;
-    f32x4 a_nxt[MT][2][2], w_nxt[NU];
-    f16x2p a_cur[MT][2];
-    const float in_s = conv_in_scale(p);
-    auto fetch = [&](int it) __attribute__((always_inline)) {   // global -> registers: A rows of this wave, W rows of the workgroup
-        const int j = it / kchunks, c = (it - j * kchunks) << 5;
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            const int ti = rt[mt] + j * (p.dil > 0 ? p.dil : 1) - p.pad;
-            const bool ok = rok[mt] && ti >= 0 && ti < p.n_in;
-            const float* arow = p.A + ((long)rb[mt] * p.n_in + (ok ? ti : 0)) * p.lda + p.a_coff + c + 8 * h;
-#pragma unroll
-            for (int st = 0; st < 2; ++st) {
-                a_nxt[mt][st][0] = ok ? conv_act_in(ld4(arow + 16 * st), p, in_s) : zero4();
-                a_nxt[mt][st][1] = ok ? conv_act_in(ld4(arow + 16 * st + 4), p, in_s) : zero4();
-            }
-        }
-        const float* wj = p.W + (long)j * p.c_out * p.c_in + c;
-#pragma unroll
-        for (int u = 0; u < NU; ++u) {
-            const int q = tid + NTHR * u, n = n0 + (q >> 3);
-            w_nxt[u] = n < p.c_out ? ld4(wj + (long)n * p.c_in + 4 * (q & 7)) : zero4();
-        }
-    };
-    auto stage = [&](int buf) __attribute__((always_inline)) {   // registers -> LDS planes (weights), A fragments split in place
-        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-#pragma unroll
-        for (int u = 0; u < NU; ++u) {
-            const int q = tid + NTHR * u;
-            const f32x4 x = w_nxt[u] * kF16WScale;
-            unsigned h1a, h2a, h1b, h2b;
-            split_f16_pair_rn(x[0], x[1], h1a, h2a);   // weights: nearest-rounded pieces, as the pack-time splitters
-            split_f16_pair_rn(x[2], x[3], h1b, h2b);
-            unsigned* d = wt + (buf * 2) * PLANE + (q >> 3) * kGemmRowDw + 2 * (q & 7);
-            *reinterpret_cast<u32x2*>(d) = u32x2{h1a, h1b};
-            *reinterpret_cast<u32x2*>(d + PLANE) = u32x2{h2a, h2b};
-        }
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int st = 0; st < 2; ++st) {
-                if constexpr (AMP) a_cur[mt][st].h1 = round_f16x8(a_nxt[mt][st][0], a_nxt[mt][st][1]);   // (nearest-rounded single piece; h2 unused)
-                else a_cur[mt][st] = split_f16x2(a_nxt[mt][st][0], a_nxt[mt][st][1]);
-            }
-    };
-    fetch(0);
-    stage(0);
-    __syncthreads();
-    for (int it = 0; it < n_it; ++it) {
-        const bool more = it + 1 < n_it;
-        f16x2p a_use[MT][2];
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int st = 0; st < 2; ++st) {
-                a_use[mt][st].h1 = a_cur[mt][st].h1;
-                if constexpr (!AMP) a_use[mt][st].h2 = a_cur[mt][st].h2;
-            }
-        if (more) fetch(it + 1);                   // in flight under this chunk's MFMAs
-        sched_fence();
-        const unsigned* bp = wt + ((it & 1) * 2) * PLANE + opaque_i(i * kGemmRowDw + 4 * h);
-#pragma unroll
-        for (int st = 0; st < 2; ++st) {
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                const u32x4 b1 = *reinterpret_cast<const u32x4*>(bp + 32 * nt * kGemmRowDw + 8 * st);
-                if constexpr (AMP) {   // the first plane of the staged weights IS round-to-nearest binary16 of 2^8 W
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) acc[mt * NT + nt] = mfma32_f16(a_use[mt][st].h1, b1, acc[mt * NT + nt]);
-                } else {
-                    const u32x4 b2 = *reinterpret_cast<const u32x4*>(bp + PLANE + 32 * nt * kGemmRowDw + 8 * st);
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) acc[mt * NT + nt] = mfma32_split2(a_use[mt][st], b1, b2, acc[mt * NT + nt]);
-                }
-            }
-        }
-        if (more) stage((it + 1) & 1);             // the other buffer: last read one iteration ago, before the barrier below
-        __syncthreads();
-    }
-    // the epilogue in flat rows: one "utterance" of B * n_out positions (written out per tile: hipcc refuses to unroll a loop around it)
-    static_assert(MT <= 2, "epilogue calls below");
-    if (r0 < n_rows) convgemm_epilogue<NT>(*reinterpret_cast<f32x16(*)[NT]>(&acc[0]), p, 0, (int)r0, n0, lane, 1, (int)n_rows);
-    if constexpr (MT > 1) {
-        if (r0 + 32 < n_rows) convgemm_epilogue<NT>(*reinterpret_cast<f32x16(*)[NT]>(&acc[NT]), p, 0, (int)r0 + 32, n0, lane, 1, (int)n_rows);
-    }
-}
-
 #ifdef ESMI_GEMM_TRACE
 extern __device__ long long* g_gemm_trace_dev;
 #endif
-// ---- convgemm_dma_kernel: the LDS-staged GEMM above with the INPUT rows brought in by LDS-DMA.
-// Ablations on the register-path kernel (base ES block-1 MixFFN, profiles/r03_probes/gemm_lds_ablation.md) put its time in the A
-// loads: a lane of the MFMA operand layout owns 32 contiguous bytes of ITS OWN row, so every global_load_dwordx4 of a wave
-// touches 32 different cache lines for 16 bytes each and the vector-memory pipe -- not LDS, the barrier or the matrix pipe --
-// paces the loop (no A loads: -30 %; no weight loads: -8 %; no barrier: -3 %).  Here eight lanes fetch one whole 128-byte row
-// chunk (8 lines per instruction instead of 32) with global_load_lds_dwordx4 -- memory -> LDS, no staging registers -- into a
-// wave-PRIVATE fp32 tile, and the operand fragments are read back with ds_read_b128.  LDS-DMA writes lane l's 16 bytes at
-// base + 16 l, so the tile is plain row-major [row][8 pieces]; the bank spread comes from WHICH piece a lane fetches instead:
-// slot s of row r holds piece s ^ ((r >> 1) & 7), and 16 consecutive rows reading the same piece hit 16 different 16-byte bank
-// groups.  The tile is single-buffered: a wave reads its fragments of chunk c into registers, waits for them (lgkmcnt), and only
-// then issues the DMA of chunk c + 1 into the same rows -- no other wave touches them.  Rows whose tap falls outside the
-// utterance (or past the last row) are fetched from a clamped in-range address and zeroed by the reader, which knows its own
-// row's position.  Restriction on top of convgemm_lds_kernel's: the input tensor spans < 2^31 elements (32-bit lane offsets).
-// Convolution taps re-use the rows: when the taps' reach (k - 1) * dil is at most kGemmHaloMax rows the wave's tile carries that
-// many extra rows, the K loop runs channel chunk OUTER / tap INNER, and one DMA per chunk serves all k taps (tap j reads the
-// fragments j * dil rows further down) -- a third of the input traffic of a k = 3 convolution.  Otherwise (long dilated HiFi-GAN
-// taps) each tap fetches its own shifted rows, tap outer.  Workgroups are numbered so that the c_out / BN column tiles of one row
-// tile are neighbours ON THE SAME XCD (ids congruent mod 8 share an XCD and its L2): they sweep the same input rows at the same
-// time and three of four fetches hit L2 instead of going out to the Infinity Cache.
 constexpr int kGemmHaloMax = 16;
 __host__ __device__ inline int convgemm_dma_tile_rows(int mt, int k, int dil) {   // LDS rows of one wave's input tile
     const int reach = (k - 1) * (dil > 0 ? dil : 1);
