@@ -68,7 +68,7 @@ def parse():
                          "v_mfma_f32_32x32x2_f32) instead of the split-f16 default build")
     ap.add_argument("--no-auto-launch", action="store_true",
                     help="N=1 only: do not try the two-stream pipeline during warm-up (default: warm up both launch modes and "
-                         "keep two-stream only if it is >= 5 %% faster -- it is on boxes whose GPU drops to a low sclk state "
+                         "keep two-stream only if it is >= 3 %% faster -- it is on boxes whose GPU drops to a low sclk state "
                          "during the light encoder-side kernels, and ~3 %% slower elsewhere)")
     ap.add_argument("--graph", action="store_true",
                     help="replay the forward as two hipGraphs per step instead of eager launches")
@@ -239,8 +239,10 @@ def main():
                 pl.flush(); torch.cuda.synchronize(dev)
             return (time.perf_counter() - t) / n
         n_try = max(10, a.warmup)
+        # two alternating rounds, the better of each mode: the first trial on a cold box (clocks, page cache) is not the mode's speed
         t_eager, t_two = trial(pipe, n_try), trial(alt, n_try)
-        if t_two < 0.95 * t_eager:
+        t_eager, t_two = min(t_eager, trial(pipe, n_try)), min(t_two, trial(alt, n_try))
+        if t_two < 0.97 * t_eager:
             pipe, a.two_stream = alt, True
         launch_note = f"; warm-up trial: eager {t_eager * 1e3:.3f} ms/step, two-stream {t_two * 1e3:.3f} ms/step"
     dt, dec_ms, n_ev = timed_steps(pipe, net, x, a.steps, a.warmup, sync_all, a.event_every, a.graph)
