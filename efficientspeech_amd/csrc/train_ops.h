@@ -57,24 +57,48 @@ static __global__ void train_conv_fwd_kernel(const ConvDesc d, const float* __re
     y[q] = acc;
 }
 
-// depthwise, stride 1 (MelDecoder's k = 5 convs): one thread per (row, 4 channels), 16-byte accesses; `grad` runs the data
-// gradient (the same taps mirrored: dx[t] = sum_j dy[t + pad - j] w[j]); weights (C, 1, k)
+// depthwise, stride 1 (MelDecoder's k = 5 convs): one thread per (kDwRows consecutive rows, 4 channels), 16-byte accesses -- the rows
+// slide through registers (kDwRows + k - 1 loads for kDwRows outputs instead of k each), the k x 4 weights are read once.  `grad`
+// runs the data gradient: dx[t] = sum_j dy[t + pad - j] w[j] = the same correlation with the taps reversed and padding k - 1 - pad.
+// Requires k <= 8; weights (C, 1, k)
+constexpr int kDwRows = 8;
 static __global__ void train_conv_dw_kernel(const ConvDesc d, const float* __restrict__ in, const float* __restrict__ w,
                                      const float* __restrict__ bias, float* __restrict__ out, int grad) {
     const int c4 = d.c_out >> 2;
-    const long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const int n_o = grad ? d.n_in : d.n_out, n_i = grad ? d.n_out : d.n_in;
-    if (q >= (long)d.B * n_o * c4) return;
-    const int c = (int)(q % c4) * 4, t = (int)((q / c4) % n_o), b = (int)(q / ((long)c4 * n_o));
-    f32x4 acc = (bias && !grad) ? ld4(bias + c) : zero4();
-    for (int j = 0; j < d.k; ++j) {
-        const int ti = grad ? t + d.pad - j : t + j - d.pad;
-        if (ti < 0 || ti >= n_i) continue;
-        const f32x4 v = ld4(in + ((long)b * n_i + ti) * d.c_out + c);
+    const int tb = (n_o + kDwRows - 1) / kDwRows;
+    const long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= (long)d.B * tb * c4) return;
+    const int c = (int)(q % c4) * 4, t0 = (int)((q / c4) % tb) * kDwRows, b = (int)(q / ((long)c4 * tb));
+    const int pad = grad ? d.k - 1 - d.pad : d.pad;
+    f32x4 wt[8];                                       // wt[j][e]: tap j of channel c + e, in correlation order
 #pragma unroll
-        for (int e = 0; e < 4; ++e) acc[e] = fmaf(v[e], w[(long)(c + e) * d.k + j], acc[e]);
+    for (int j = 0; j < 8; ++j) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) wt[j][e] = j < d.k ? w[(long)(c + e) * d.k + (grad ? d.k - 1 - j : j)] : 0.0f;
     }
-    *reinterpret_cast<f32x4*>(out + q * 4) = acc;
+    const f32x4 b4 = (bias && !grad) ? ld4(bias + c) : zero4();
+    f32x4 acc[kDwRows];
+#pragma unroll
+    for (int o = 0; o < kDwRows; ++o) acc[o] = b4;
+    const float* base = in + (long)b * n_i * d.c_out + c;
+#pragma unroll
+    for (int r = 0; r < kDwRows + 7; ++r) {            // input row t0 - pad + r feeds output o through tap j = r - o
+        if (r >= kDwRows + d.k - 1) break;
+        const int ti = t0 - pad + r;
+        const f32x4 v = (ti >= 0 && ti < n_i) ? ld4(base + (long)ti * d.c_out) : zero4();
+#pragma unroll
+        for (int o = 0; o < kDwRows; ++o) {
+            const int j = r - o;
+            if (j >= 0 && j < 8) {                     // (compile-time after unrolling; taps >= k hold zero weights)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[o][e] = fmaf(v[e], wt[j][e], acc[o][e]);
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 0; o < kDwRows; ++o)
+        if (t0 + o < n_o) *reinterpret_cast<f32x4*>(out + ((long)b * n_o + t0 + o) * d.c_out + c) = acc[o];
 }
 
 // dx[b, ti, ci] = sum over (t, j) with in_pos(t, j) == ti, and co connected to ci, of dy[b, t, co] * w(co, ci, j)

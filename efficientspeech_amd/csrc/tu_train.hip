@@ -168,7 +168,7 @@ int esmi_train_conv_fwd_f32(const esmi_conv_desc* d, const float* x, const float
     }
     const long n = (long)c.B * c.n_out * c.c_out;
     if (wgrad_depthwise(c) && c.stride == 1 && (c.c_out & 3) == 0) {
-        ESMI_LAUNCH(train_conv_dw_kernel, grid1d(n / 4), dim3(256), 0, S(stream), c, x, w, bias, y, 0);
+        ESMI_LAUNCH(train_conv_dw_kernel, grid1d((long)c.B * ((c.n_out + kDwRows - 1) / kDwRows) * (c.c_out / 4)), dim3(256), 0, S(stream), c, x, w, bias, y, 0);
     } else {
         ESMI_LAUNCH(train_conv_fwd_kernel, grid1d(n), dim3(256), 0, S(stream), c, x, w, bias, y);
     }
@@ -191,7 +191,7 @@ int esmi_train_conv_dgrad_f32(const esmi_conv_desc* d, const float* dy, const fl
     }
     const long n = (long)c.B * c.n_in * c.c_in;
     if (wgrad_depthwise(c) && c.stride == 1 && (c.c_out & 3) == 0) {
-        ESMI_LAUNCH(train_conv_dw_kernel, grid1d(n / 4), dim3(256), 0, S(stream), c, dy, w, nullptr, dx, 1);
+        ESMI_LAUNCH(train_conv_dw_kernel, grid1d((long)c.B * ((c.n_in + kDwRows - 1) / kDwRows) * (c.c_in / 4)), dim3(256), 0, S(stream), c, dy, w, nullptr, dx, 1);
         return launch_status();
     }
     ESMI_LAUNCH(train_conv_dgrad_kernel, grid1d(n), dim3(256), 0, S(stream), c, dy, w, dx);
