@@ -132,7 +132,7 @@ static __global__ void train_conv_dgrad_kernel(const ConvDesc d, const float* __
 // Reductions over the rows (B * n positions) run in two deterministic stages: stage 1 gives every (output element, chunk of
 // kTrainChunk rows) its own thread and writes a partial sum, stage 2 adds the partials of an element in chunk order.
 constexpr int kTrainChunk = 256;
-constexpr int kTrainChunkDw = 32;      // rows per thread of the depthwise weight gradient (few channels: parallelism from the chunks)
+constexpr int kTrainChunkDw = 256;     // rows per workgroup of the depthwise weight gradient (8 sub-chunks of 32 rows, summed in LDS)
 #ifndef ESMI_TRAIN_CHUNK_MFMA
 #define ESMI_TRAIN_CHUNK_MFMA 96    // rows per wave of the MFMA weight gradient (a multiple of 16).  Round 3 (four waves summed in LDS, split-bf16 products): 48 / 80 / 96 / 128 / 160 / 192 rows -> 5.2-5.3 / 5.3 / 5.3-5.4 / 5.5 / 5.5 / 5.7 ms per B = 128 step (+-0.3 ms run to run)
 #endif
@@ -185,6 +185,76 @@ static __global__ void train_conv_wgrad_dw_kernel(const ConvDesc d, const float*
     for (int j = 0; j < 8; ++j)
         if (j < d.k) partial[(long)blockIdx.y * pstride + (long)c * d.k + j] = acc[j];
     if (partial_bias) partial_bias[(long)blockIdx.y * pstride + c] = bs;
+}
+
+// The same for C % 4 == 0, stride 1, n_in == n_out (every depthwise convolution of the model): a 256-thread workgroup = 32 channel
+// quads x kDwSub row sub-chunks of one chunk.  A thread walks its 32 rows in groups of 8: 8 rows of dY and 8 + k - 1 rows of X
+// (16-byte loads; the input row of tap j for flat row r is flat row r + j - pad) feed 8 k fused multiply-adds per channel -- 2.5 loads
+// per row instead of 6 scalar ones; a group that touches an utterance edge takes the tap-by-tap path.  The sub-chunks' sums are
+// added in LDS in sub-chunk order (fixed: reproducible) and one partial row per workgroup goes out.
+constexpr int kDwSub = 8;
+static __global__ __launch_bounds__(256) void train_conv_wgrad_dw4_kernel(const ConvDesc d, const float* __restrict__ x, const float* __restrict__ dy,
+                                                                   float* __restrict__ partial, float* __restrict__ partial_bias, long pstride) {
+    ESMI_DYN_LDS(red);   // [kDwSub][9][128]: sub-chunk, tap (8 = bias), channel within the workgroup's 128
+    const int lq = (int)threadIdx.x & 31, sub = (int)threadIdx.x >> 5;
+    const int c = ((int)blockIdx.x * 32 + lq) * 4;
+    const long rows = (long)d.B * d.n_out;
+    const long c0 = (long)blockIdx.y * kTrainChunkDw + sub * (kTrainChunkDw / kDwSub);
+    const long c1 = c0 + kTrainChunkDw / kDwSub < rows ? c0 + kTrainChunkDw / kDwSub : rows;
+    f32x4 acc[8], bs = zero4();
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = zero4();
+    if (c < d.c_out) {
+        const int n = d.n_out, reach = d.k - 1 - d.pad;
+        for (long g0 = c0; g0 < c1; g0 += 8) {
+            const int t0 = (int)(g0 % n);
+            if (g0 + 8 <= c1 && t0 >= d.pad && t0 + 7 + reach < n) {     // the whole group and all its taps inside one utterance
+                f32x4 v[15], g[8];
+#pragma unroll
+                for (int r = 0; r < 15; ++r) v[r] = r < 8 + d.k - 1 ? ld4(x + (g0 - d.pad + r) * d.c_in + c) : zero4();
+#pragma unroll
+                for (int o = 0; o < 8; ++o) { g[o] = ld4(dy + (g0 + o) * d.c_out + c); bs += g[o]; }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    if (j >= d.k) break;
+#pragma unroll
+                    for (int o = 0; o < 8; ++o)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[j][e] = fmaf(g[o][e], v[o + j][e], acc[j][e]);
+                }
+            } else {
+                const long ge = g0 + 8 < c1 ? g0 + 8 : c1;
+                for (long r = g0; r < ge; ++r) {
+                    const int t = (int)(r % n);
+                    const f32x4 gg = ld4(dy + r * d.c_out + c);
+                    bs += gg;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        if (j >= d.k) break;
+                        const int ti = t + j - d.pad;
+                        if (ti < 0 || ti >= n) continue;
+                        const f32x4 xv = ld4(x + (r + j - d.pad) * d.c_in + c);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[j][e] = fmaf(gg[e], xv[e], acc[j][e]);
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) *reinterpret_cast<f32x4*>(red + ((sub * 9 + j) * 32 + lq) * 4) = acc[j];
+    *reinterpret_cast<f32x4*>(red + ((sub * 9 + 8) * 32 + lq) * 4) = bs;
+    __syncthreads();
+    // thread -> (tap or bias, channel): 9 x 128 sums over the 8 sub-chunks
+    for (int q = (int)threadIdx.x; q < 9 * 128; q += 256) {
+        const int j = q >> 7, cc = q & 127, ch = (int)blockIdx.x * 128 + cc;
+        if (ch >= d.c_out || (j < 8 && j >= d.k)) continue;
+        float sum = 0.0f;
+#pragma unroll
+        for (int s2 = 0; s2 < kDwSub; ++s2) sum += red[(s2 * 9 + j) * 128 + cc];
+        if (j < 8) partial[(long)blockIdx.y * pstride + (long)ch * d.k + j] = sum;
+        else if (partial_bias) partial_bias[(long)blockIdx.y * pstride + ch] = sum;
+    }
 }
 
 // The same partial sums for DENSE convolutions on the matrix pipe: dW_j = dY^T X_j is a GEMM with the rows as the contraction

@@ -222,6 +222,9 @@ static int conv_wgrad_impl(const esmi_conv_desc* d, const float* x, const float*
         if (int rc = raise_lds_limit(reinterpret_cast<const void*>(train_conv_wgrad_mfma_kernel), once)) return rc;
         ESMI_LAUNCH(train_conv_wgrad_mfma_kernel, dim3(tiles, (unsigned)((chunks + 3) / 4)), dim3(256), kWgradLdsBytes, S(stream), c, x, dy, part,
                     dbias ? pb : nullptr, chunks, ps);
+    } else if (depthwise && (c.c_out & 3) == 0 && c.stride == 1 && c.n_in == c.n_out) {
+        ESMI_LAUNCH(train_conv_wgrad_dw4_kernel, dim3((unsigned)((c.c_out + 127) / 128), (unsigned)chunks), dim3(256), kDwSub * 9 * 128 * sizeof(float),
+                    S(stream), c, x, dy, part, dbias ? pb : nullptr, ps);
     } else if (depthwise) {
         ESMI_LAUNCH(train_conv_wgrad_dw_kernel, dim3(grid1d(c.c_out, 64), (unsigned)chunks), dim3(64), 0, S(stream), c, x, dy, part,
                     dbias ? pb : nullptr, ps);
