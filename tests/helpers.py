@@ -115,6 +115,25 @@ def check_attention_sizes(net, cfg, sd, device, sizes=((2, 100), (1, 200), (3, 1
             np.testing.assert_allclose(y.cpu().numpy(), ref, atol=PRED_TOL, rtol=0)
 
 
+def check_lds_gemm_edges(device, cases):
+    """MixFFN.forward = three launches of the per-op plan's LDS-staged GEMM (convgemm_dma_kernel; a k = 3 convolution in the middle)
+    against a torch fp64 restatement (blocks.py:22-29) on shapes at the kernel's edges: one-position utterances, utterances shorter
+    than the taps' reach, row counts off the 128 / 256-row workgroup tile, channel counts off the 128-column tile."""
+    import torch.nn.functional as F
+    from efficientspeech_amd.networks import MixFFN
+    torch.manual_seed(0)
+    for B, N, Cc, E in cases:
+        m = MixFFN(Cc, E).to(device)
+        x = torch.randn(B, N, Cc).to(device)
+        with torch.no_grad():
+            y = m(x)
+            h = F.linear(x.double(), m.mlp1.weight.double(), m.mlp1.bias.double())
+            h = F.gelu(F.conv1d(h.transpose(1, 2), m.conv.weight.double(), m.conv.bias.double(), padding=1).transpose(1, 2))
+            ref = F.linear(h, m.mlp2.weight.double(), m.mlp2.bias.double())
+        err = float((y.double() - ref).abs().max()) / float(ref.abs().max())
+        assert torch.isfinite(y).all() and err < 5e-6, (B, N, Cc, E, err)
+
+
 def check_submodule_forwards(net, cfg, sd, device, seed=3):
     """The reference's sub-modules called on their own (SelfAttention / MixFFN / AcousticDecoder.forward, get_embedding,
     blocks.py:22-29,43-71, networks.py:128-165) against the oracle's restatement of the same functions."""

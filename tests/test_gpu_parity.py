@@ -620,3 +620,10 @@ def test_lds_staged_attention_at_size(name):
     """>= 128 (utterance, head) pairs so that the GPU dispatch takes attn_lds_kernel: 3, 4, 7 and 8 key tiles, widths 32 .. 256."""
     net, cfg, sd = H.make_net(name, DEV)
     H.check_attention_sizes(net, cfg, sd, DEV, sizes=((128, 96), (64, 128), (40, 200), (32, 256)) if name == "tiny" else ((32, 100), (16, 250)))
+
+
+def test_lds_gemm_edge_shapes():
+    """>= 2048 rows each (the launcher's threshold for the LDS-staged kernel)."""
+    H.check_lds_gemm_edges(DEV, [(2048, 1, 128, 1), (1100, 2, 128, 2), (700, 3, 160, 1), (300, 7, 128, 2), (63, 33, 256, 1),
+                                 (33, 64, 96, 2), (9, 255, 160, 2), (5, 513, 128, 1), (4100, 1, 96, 1), (17, 129, 224, 1)])
+

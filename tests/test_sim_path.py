@@ -304,6 +304,12 @@ def test_simulated_lds_staged_attention():
         H.check_attention_sizes(net, cfg, sd, "cpu", sizes=((1, 100), (1, 200)))
 
 
+def test_simulated_lds_gemm_edge_shapes():
+    """(the simulator build sends every row count through the LDS-staged kernel)"""
+    with use_sim():
+        H.check_lds_gemm_edges("cpu", [(5, 1, 96, 1), (3, 2, 128, 1), (2, 7, 96, 2), (1, 70, 128, 1)])
+
+
 def check_activation_range_guard(dev):
     """ESMI_ERR_RANGE (include/esmi.h): on the range-checked build a value that enters a split-f16 contraction outside the binary16
     range is reported by esmi_phoneme2mel_forward_f32 -- the product build would saturate it silently.  In-range checkpoints pass
