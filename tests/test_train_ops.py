@@ -32,6 +32,8 @@ CONVS = [  # (c_in, c_out, k, stride, pad, groups, transposed, B, n)
     (128, 128, 3, 2, 1, 1, False, 4, 131),      # strided merge conv, odd length
     (32, 64, 1, 1, 0, 1, False, 4, 65),
     (128, 128, 5, 1, 2, 128, False, 3, 500),    # depthwise k5
+    (64, 64, 3, 1, 1, 64, False, 5, 13),        # depthwise k3, utterances shorter than two 8-row groups
+    (128, 128, 5, 1, 2, 128, False, 2, 7),      # depthwise k5, utterances shorter than one group
     (128, 128, 3, 2, 0, 1, True, 4, 64),        # Fuse upsample (ConvTranspose1d, cropped to 2n)
     (128, 1, 1, 1, 0, 1, False, 4, 300),        # predictor output Linear
     (40, 24, 3, 1, 1, 1, False, 2, 50),         # channel counts the GEMM path does not take
