@@ -32,7 +32,10 @@
 extern "C" {
 #endif
 
-#define ESMI_VERSION 200 /* 0.2.0: launch plan per call (no process-global state), module-level entry points, range guard */
+#define ESMI_VERSION 300 /* 0.3.0: training entry points changed shape (esmi_conv_desc: act / packed_fwd / packed_grad; LayerNorm with
+                          * residual / row mask / activation arguments; esmi_train_loss_args.grad_seed; esmi_train_pack_weights_f32,
+                          * esmi_train_cat_f32, esmi_reduce_queue); activation-range flag.  0.2.0: launch plan per call (no
+                          * process-global state), module-level entry points, weight range guard */
 
 #define ESMI_OK 0
 #define ESMI_ERR_ARG (-1)         /* null pointer / bad size */
