@@ -108,20 +108,23 @@ def cpu_baseline(cfg, sd, T, dur):
         o = oracle.phoneme2mel(cfg, w, ids, mask, pitch=None, energy=None, duration=d, f32=True)
         return int(o.mel_len.sum()), time.perf_counter() - t0
 
-    def sample(threads, b, reps):
+    def sample(threads, b, reps, seconds=8.0):
+        """at least `reps` runs, and as many as fit into ~`seconds` of wall time (x threads = the CPU work the number rests on)"""
         _omp_threads(threads)
         run(4)                                   # spin up the OpenMP pool at this width
-        r = [run(b) for _ in range(reps)]
-        return r[0][0], sum(x[1] for x in r) / len(r)
+        r = []
+        while len(r) < reps or (sum(x[1] for x in r) < seconds and len(r) < 200):
+            r.append(run(b))
+        return r[0][0], sum(x[1] for x in r) / len(r), len(r)
     # n = 24: the reference's --threads default -- and the fastest setting for this port (its OpenMP regions are one layer
     # each: beyond ~32 threads the fork/join cost dominates; measured on the MI355X box's 256 hardware threads, B = 64:
     # 24 threads 8.7e5 frames/s, 64: 4.0e5, 128: 1.6e5, 256: 5e3).  `value` is the n = 24 number.
     n24 = min(24, cores)
     b24 = 256 if cfg.name == "tiny" else 64
-    frames, dt = sample(n24, b24, 3)
+    frames, dt, n_runs = sample(n24, b24, 3)
     out = {"value": frames / dt, "unit": "mel-frames/s", "cores": n24, "kind": "port",
            "sample": f"oracle/es_oracle.c (fp32 accumulate, OpenMP {n24} threads = the reference's --threads default), {cfg.name} ES "
-                     f"full forward, B={b24} T={T} D-const {dur}: {frames} frames in {dt:.2f} s (mean of 3 runs)"}
+                     f"full forward, B={b24} T={T} D-const {dur}: {frames} frames in {dt:.2f} s (mean of {n_runs} runs = {n_runs * dt:.1f} s x {n24} threads of CPU work)"}
     fox = np.asarray([FOX_IDS], np.int32)
     for threads, key in ((n24, "b1_fox_latency_ms_n24"), (1, "b1_fox_latency_ms_n1")):
         _omp_threads(threads)
