@@ -121,3 +121,29 @@ def test_gpu_two_rank_serving_loop_on_one_device(tmp_path):
     out = str(tmp_path / "pipe.npy")
     mp.spawn(_pipeline_worker, args=(2, _free_port(), out), nprocs=2, join=True)
     assert np.load(out).tolist() == [1, 1, 1, 1, 1, 1]
+
+
+@pytest.mark.gpu
+def test_gpu_two_stream_loop_bounds_its_run_ahead_and_matches_the_plain_loop():
+    """The single-GPU two-stream pipeline (encoder side of step i+1 beside the decoder of step i): every step's result equals the
+    plain forward's bit for bit, and the host never has more than depth + 1 steps in flight (unbounded, the allocator had to find
+    fresh blocks for every step: 22-36 ms per base-ES step instead of 9, profiles/r03_probes/two_stream_runahead.md)."""
+    from tests import helpers as H
+    from efficientspeech_amd.sharded import ShardedMelPipeline
+    from efficientspeech_amd.synth import synth_phonemes
+    net, cfg, sd = H.make_net("tiny", "cuda:0")
+    pipe = ShardedMelPipeline(net, world_size=1, gather=False, two_stream=True)
+    with torch.no_grad():
+        for step in range(12):
+            ids, mask = synth_phonemes(6, 40, 100 + step, [40, 33, 21, 40, 9, 17])
+            x = {"phoneme": torch.from_numpy(ids).cuda(), "phoneme_mask": torch.from_numpy(mask).cuda(),
+                 "duration_forced": torch.full((6, 40), 3 + step % 3, dtype=torch.int32, device="cuda"),
+                 "max_mel_len": 40 * 5, "max_mel_len_exact": False}
+            mel, mel_len = pipe.step(x)
+            assert len(pipe.inflight) <= pipe.depth + 1
+            pipe.wait_last()
+            ref, ref_len, _ = net(x)
+            torch.cuda.synchronize()
+            assert torch.equal(mel_len, ref_len) and torch.equal(mel, ref), step
+    pipe.flush()
+    assert not pipe.inflight
