@@ -11,7 +11,7 @@ from efficientspeech_amd.synth import synth_state_dict
 ap = argparse.ArgumentParser()
 ap.add_argument("--config", default="tiny"); ap.add_argument("--batch", type=int, default=256)
 ap.add_argument("--phonemes", type=int, default=128); ap.add_argument("--dur", type=int, default=6)
-ap.add_argument("--iters", type=int, default=30); ap.add_argument("--h0", action="store_true", help="phoneme-rate first stage supplied (what the full forward does for tiny, T <= 128)"); ap.add_argument("--burst", type=int, default=20, help="launches per timed burst (back-to-back, one event pair)"); ap.add_argument("--libs", nargs="*", default=[_lib.LIB_PATH])
+ap.add_argument("--zeros", action="store_true", help="zero activations (DVFS probe: same instruction stream, less switching power)"); ap.add_argument("--iters", type=int, default=30); ap.add_argument("--h0", action="store_true", help="phoneme-rate first stage supplied (what the full forward does for tiny, T <= 128)"); ap.add_argument("--burst", type=int, default=20, help="launches per timed burst (back-to-back, one event pair)"); ap.add_argument("--libs", nargs="*", default=[_lib.LIB_PATH])
 a = ap.parse_args()
 cfg = CONFIGS[a.config]
 B, T, L = a.batch, a.phonemes, a.phonemes * a.dur
@@ -26,6 +26,9 @@ for path in a.libs:
     mel_len = torch.full((B,), L, dtype=torch.int32, device="cuda")
     dec = net.decoder
     h0 = torch.randn((B, T, cfg.dx2), device="cuda", generator=g) if a.h0 else None
+    if a.zeros:
+        feat.zero_()
+        if h0 is not None: h0.zero_()
     for _ in range(5):
         mel = dec._fused(feat, cum, mel_len, None, L, True, L, h0=h0)
     torch.cuda.synchronize()
