@@ -2,7 +2,7 @@
 // Built by `hipcc --offload-arch=gfx950` into libesmi.so (product) and, unchanged, by the host
 // clang++ with -DESMI_WAVESIM into libesmi_sim.so (CPU wave simulator used only by tests).
 #include "launch.h"
-#include "mel_decoder_any.h"   // esmi_decoder_shape helpers used by the one-call forward
+#include "mel_decoder.h"   // esmi_decoder_shape helpers used by the one-call forward
 
 using namespace esmi;
 ESMI_TU_RANGE_SETTER(abi)
@@ -734,7 +734,7 @@ int esmi_phoneme2mel_forward_f32(const esmi_forward_args* a, int stage, esmi_str
     int (*const setters[])(int*) = {set_range_flag_abi, set_range_flag_convgemm, set_range_flag_attention, set_range_flag_enc_merge,
                                     set_range_flag_enc_block, set_range_flag_enc_attn_ffn, set_range_flag_enc_fuse_va,
                                     set_range_flag_decoder, set_range_flag_dec_128_5, set_range_flag_dec_128_3, set_range_flag_dec_256_5,
-                                    set_range_flag_dec_256_3, set_range_flag_dec_pp, set_range_flag_hifigan, set_range_flag_train};
+                                    set_range_flag_dec_256_3, set_range_flag_hifigan, set_range_flag_train};
     for (auto set : setters)
         if (int rc = set(reinterpret_cast<int*>(a->range_flag))) return rc;
     int rc = forward_impl(a, stage, stream);

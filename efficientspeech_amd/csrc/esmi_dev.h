@@ -534,11 +534,6 @@ __device__ __forceinline__ void buf_st_i(const BufRsrc& r, unsigned off, int v) 
     if (off < r.bytes && off + 4u <= r.bytes) *reinterpret_cast<int*>(const_cast<char*>(r.base) + off) = v;
 }
 __device__ __forceinline__ void lds_wave_sync() { wavesim::shfl_i(0, 0); }   // a wave-level collective: all 64 fibers arrive
-// Marks a point where the code relies on the lanes of a wave executing in lockstep (an LDS read by all lanes in one instruction
-// precedes a later instruction's LDS write by any lane).  The hardware gives that for free; the simulator's fibers meet here.
-__device__ __forceinline__ void wave_lockstep() { wavesim::shfl_i(0, 0); }
-// workgroup barrier that orders LDS traffic only (see the hardware form below)
-__device__ __forceinline__ void lds_barrier() { __syncthreads(); }
 #else
 typedef __amdgpu_buffer_rsrc_t BufRsrc;
 __device__ __forceinline__ BufRsrc make_rsrc(const void* p, long bytes) {
@@ -572,11 +567,6 @@ __device__ __forceinline__ void buf_st_i(BufRsrc r, unsigned off, int v) {
 // in issue order, so only the compiler has to be kept from reordering; no s_barrier, and global loads in flight
 // (weight prefetches) stay in flight.
 __device__ __forceinline__ void lds_wave_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
-__device__ __forceinline__ void wave_lockstep() {}
-// Workgroup barrier for kernels whose waves exchange data through LDS only: waits for this wave's LDS operations, not for its global
-// loads (`__syncthreads()` drains vmcnt too: a register prefetch in flight across the barrier -- the next step's weights -- would
-// stall every wave of the workgroup for an L2 round trip).
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 #endif
 
 // Pin the instruction order at this point.  hipcc's scheduler sinks prefetch loads down to their first use to shorten

@@ -90,7 +90,6 @@ int set_range_flag_dec_128_5(int* flag);
 int set_range_flag_dec_128_3(int* flag);
 int set_range_flag_dec_256_5(int* flag);
 int set_range_flag_dec_256_3(int* flag);
-int set_range_flag_dec_pp(int* flag);
 int set_range_flag_hifigan(int* flag);
 int set_range_flag_train(int* flag);
 // development (-DESMI_CHAIN_TRACE): every translation unit with chain kernels owns a copy of the trace pointer

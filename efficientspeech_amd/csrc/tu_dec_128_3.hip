@@ -1,7 +1,7 @@
 // esmi C-ABI, translation unit "tu_dec_128_3.hip": mel_decoder_kernel<128, 3, NW> (mel_decoder.h) and its launcher -- one
 // instantiation per file: this kernel dominates the library's compile time, so the four build side by side.
 #include "launch.h"
-#include "mel_decoder_any.h"
+#include "mel_decoder.h"
 
 #ifndef ESMI_DEC_NW256
 #define ESMI_DEC_NW256 8    // waves per window of the dx2 = 256 decoder (small / base ES): 8, or 16 (measured 30 % slower: 65 spilled

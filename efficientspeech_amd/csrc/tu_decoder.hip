@@ -2,7 +2,7 @@
 // One of several translation units of libesmi.so (compiled in parallel by __graft_entry__.build(); the simulator build
 // tools/wavesim/build.sh compiles the same files with the host compiler).  Internal launchers are declared in launch.h.
 #include "launch.h"
-#include "mel_decoder_any.h"
+#include "mel_decoder.h"
 
 using namespace esmi;
 ESMI_TU_RANGE_SETTER(decoder)
@@ -12,11 +12,7 @@ int launch_mel_decoder_128_5(const MelDecP& p, dim3 grid, hipStream_t st);
 int launch_mel_decoder_128_3(const MelDecP& p, dim3 grid, hipStream_t st);
 int launch_mel_decoder_256_5(const MelDecP& p, dim3 grid, hipStream_t st);
 int launch_mel_decoder_256_3(const MelDecP& p, dim3 grid, hipStream_t st);
-int launch_mel_decoder_pp(const MelDecP& p, int kernel, hipStream_t st);
 }  // namespace esmi
-#ifndef ESMI_DEC_PP
-#define ESMI_DEC_PP 1      // dx2 = 128 with a supplied first stage: the role-alternating kernel (mel_decoder_pp.h); 0: the window form (A/B)
-#endif
 
 #ifdef ESMI_DEC_TRACE
 long long* g_esmi_trace = nullptr;
@@ -41,68 +37,6 @@ size_t esmi_mel_decoder_blob_bytes(const esmi_decoder_shape* s) {
     return (size_t)dec_layout(s->d4, s->dx2, s->kernel, s->n_blocks, s->block_depth).total * sizeof(float);
 }
 
-#if ESMI_DEC_FOLD
-int esmi_mel_decoder_pack_f32(const esmi_decoder_weights* w, const esmi_decoder_shape* s, float* blob,
-                              esmi_stream_t stream) {
-    int rc = dec_check(s);
-    if (rc) return rc;
-    if (!w || !blob) return ESMI_ERR_ARG;
-    const DecLayout L = dec_layout(s->d4, s->dx2, s->kernel, s->n_blocks, s->block_depth);
-    hipStream_t st = S(stream);
-    const int dx2 = s->dx2, ntw = dx2 / 128, n_layers = s->n_blocks * s->block_depth;
-    // cs: per-input-channel scale folded into the matrix (the gain of the LayerNorm that feeds it), or NULL
-    auto bslice = [&](const float* src, const float* cs, long off, int N, int K) {
-#if ESMI_DEC_SPLIT == 2
-        const long n = (long)(K / 128) * 4 * ntw * 8 * 2 * 256;
-        ESMI_LAUNCH(pack_bslice2h_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src, cs,
-                    reinterpret_cast<unsigned*>(blob + off), N, K, ntw);
-#else
-        const long n = (long)(K / 128) * 4 * ntw * 16 * 256;
-        ESMI_LAUNCH(pack_bslice_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src, cs, blob + off, N, K, ntw);
-#endif
-    };
-    auto vec = [&](const float* src, long off, int n, int n_pad) {
-        ESMI_LAUNCH(copy_pad_kernel, dim3((n_pad + 255) / 256), dim3(256), 0, st, src, blob + off, n, n_pad);
-    };
-    // group A of a conv layer: taps / shift folded with the LayerNorm (g, b) that produces the layer's input (mel_decoder_fold.h)
-    auto group_a = [&](int l, const float* g, const float* b, long off) {
-        ESMI_LAUNCH(pack_dw_fold_kernel, dim3((dx2 + 127) / 128), dim3(128), 0, st, w->dw_w[l], w->dw_b[l], g, b, blob + off, dx2, s->kernel);
-    };
-    bslice(w->proj_w, nullptr, L.proj_w, dx2, s->d4);
-    vec(w->proj_b, L.proj_b, dx2, dx2);
-    auto gain = [&](const float* src, long off) {
-        ESMI_LAUNCH(copy_gain_kernel, dim3((dx2 + 255) / 256), dim3(256), 0, st, src, blob + off, dx2);
-    };
-    gain(w->proj_ln_g, L.proj_g);
-    vec(w->proj_ln_b, L.proj_beta, dx2, dx2);
-    ESMI_LAUNCH(pack_h0_pad_kernel, dim3(1), dim3(64), 0, st, w->proj_b, w->proj_ln_g, w->proj_ln_b, blob + L.h0_pad, dx2);
-    for (int l = 0; l < n_layers; ++l) {
-        const long base = L.layer0 + (long)l * L.layer_stride;
-        if (!w->dw_w[l] || !w->pw_w[l]) return ESMI_ERR_ARG;
-        // the LayerNorm in front of layer l: the first stage's (l = 0), the previous block's skip LN (first layer of a block), else layer l-1's
-        const float *gin, *bin;
-        if (l == 0) { gin = w->proj_ln_g; bin = w->proj_ln_b; }
-        else if (l % s->block_depth == 0) { gin = w->skip_g[l / s->block_depth - 1]; bin = w->skip_b[l / s->block_depth - 1]; }
-        else { gin = w->ln_g[l - 1]; bin = w->ln_b[l - 1]; }
-        group_a(l, gin, bin, base + L.l_taps);
-        vec(w->pw_b[l], base + L.l_pwb, dx2, dx2);
-        gain(w->ln_g[l], base + L.l_g);
-        vec(w->ln_b[l], base + L.l_b, dx2, dx2);
-        if ((l + 1) % s->block_depth == 0) {
-            gain(w->skip_g[l / s->block_depth], base + L.l_sg);
-            vec(w->skip_b[l / s->block_depth], base + L.l_sb, dx2, dx2);
-        } else {
-            vec(w->ln_g[l], base + L.l_sg, 0, 2 * dx2);      // (zeros: never read)
-        }
-        bslice(w->pw_w[l], nullptr, base + L.l_pw, dx2, dx2);
-    }
-    group_a(0, nullptr, nullptr, L.layer0_h0);              // layer 0 behind a supplied h0: its input is already normalised
-    bslice(w->mel_w, w->skip_g[s->n_blocks - 1], L.mel_w, s->n_mel, dx2);
-    ESMI_LAUNCH(pack_mel_bias_kernel, dim3((dx2 + 127) / 128), dim3(128), 0, st, w->mel_w, w->mel_b, w->skip_b[s->n_blocks - 1],
-                blob + L.mel_b, s->n_mel, dx2, dx2);
-    return launch_status();
-}
-#else
 int esmi_mel_decoder_pack_f32(const esmi_decoder_weights* w, const esmi_decoder_shape* s, float* blob,
                               esmi_stream_t stream) {
     int rc = dec_check(s);
@@ -148,8 +82,6 @@ int esmi_mel_decoder_pack_f32(const esmi_decoder_weights* w, const esmi_decoder_
     return launch_status();
 }
 
-#endif
-
 static int mel_decoder_launch(const float* blob, const esmi_decoder_shape* s, const float* x, const float* h0,
                               const int32_t* cum, const int32_t* mel_len, const int32_t* lmax_dev, int lmax_host, int apply_mask, int B, int T,
                               int L_out, float* mel, esmi_stream_t stream) {
@@ -175,9 +107,6 @@ static int mel_decoder_launch(const float* blob, const esmi_decoder_shape* s, co
     hipStream_t st = S(stream);
     p.n_tiles = (L_out + p.TL - 1) / p.TL;
     dim3 grid((unsigned)(p.n_tiles * ((B + 7) / 8) * 8)), block(kDecThreads);
-#if ESMI_DEC_FOLD && ESMI_DEC_SPLIT == 2 && ESMI_DEC_PP
-    if (s->dx2 == 128 && h0) return launch_mel_decoder_pp(p, s->kernel, st);
-#endif
     // one translation unit per instantiation (tu_dec_<dx2>_<k>.hip): the kernel is by far the slowest thing to compile
     if (s->dx2 == 128 && s->kernel == 5) return launch_mel_decoder_128_5(p, grid, st);
     if (s->dx2 == 128 && s->kernel == 3) return launch_mel_decoder_128_3(p, grid, st);

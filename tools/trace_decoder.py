@@ -23,14 +23,10 @@ lib.esmi_dev_set_trace(tr.data_ptr())
 net.decoder._fused(feat, cum, mel_len, None, L, True, L, h0=h0)
 torch.cuda.synchronize()
 t = tr.cpu().numpy()
-if "--rowln" in sys.argv:
-    names = ["dw window load", "barrier", "dw compute+write", "barrier", "K loop (MFMA)", "barrier", "bias+tanh store", "barrier", "LayerNorm", "barrier"]
-else:   # the LayerNorm-folded form (mel_decoder_fold.h): 10 stamps per layer
-    names = ["merge stats+halo load", "barrier", "dw stream+write", "barrier", "K loop (MFMA)", "tanh+stats", "barrier", "store (+block end)", "barrier"]
-ns = len(names) + 1
-nl = min(cfg.n_blocks * cfg.block_depth, 64 // ns)      # (64 stamp slots per wave)
+names = ["dw window load", "barrier", "dw compute+write", "barrier", "K loop (MFMA)", "barrier", "bias+tanh store", "barrier", "LayerNorm", "barrier"]
+nl = min(cfg.n_blocks * cfg.block_depth, 5)      # (64 stamp slots per wave = 5 layers of 11 stamps)
 for w in (0, 3, 7):
-    print(f"wave {w}: total layer-loop cycles {t[w, ns * nl - 1] - t[w, 0]}")
+    print(f"wave {w}: total layer-loop cycles {t[w, 11 * nl - 1] - t[w, 0]}")
     for l in range(nl):
-        d = np.diff(t[w, ns * l: ns * l + ns])
+        d = np.diff(t[w, 11 * l: 11 * l + 11])
         print(f"  layer {l}: " + "  ".join(f"{n}={int(x)}" for n, x in zip(names, d)))
