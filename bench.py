@@ -14,6 +14,9 @@ Prints ONE JSON line (rank 0):
                          v_mfma_f32_32x32x2_f32, with its own kernel time and fraction of the 157.3 TFLOP/s fp32-MFMA peak
   decoder_only           (N=1) MelDecoder.forward alone on frame-rate features ~ N(0,1)
   allgather              (N>1) the mel all-gather timed by itself: GB/s received per rank vs 7 xGMI links x 76.8 GB/s
+  strong                 (N>1) the same model with the GLOBAL batch of the headline (256 utterances) sharded over the ranks
+  base_strong            (N>1) BASELINE configs[3]: base ES, global B=512 x T=256, batch-sharded over the ranks, mel all-gather
+  base                   (N=1) base ES B=512 T=256 on one GPU: ms/step, decoder kernel roofline, D-rand, exact-fp32 build
   without_allgather      (N>1) the same sharded steps with the exchange switched off (compute scaling next to the link-bound value)
   pytorch_rocm_ops       (N=1) the same forward written with stock PyTorch-ROCm operators, same inputs / weights / GPU
   b1_fox_gpu             (N=1) single-utterance latency of the forward (BASELINE configs[0] shape) with a sync per call
@@ -125,6 +128,19 @@ def cpu_baseline(cfg, sd, T, dur):
     out = {"value": frames / dt, "unit": "mel-frames/s", "cores": n24, "kind": "port",
            "sample": f"oracle/es_oracle.c (fp32 accumulate, OpenMP {n24} threads = the reference's --threads default), {cfg.name} ES "
                      f"full forward, B={b24} T={T} D-const {dur}: {frames} frames in {dt:.2f} s (mean of {n_runs} runs = {n_runs * dt:.1f} s x {n24} threads of CPU work)"}
+    # n = all physical cores.  The port's OpenMP regions are one per layer, so its intra-op scaling stops at a few
+    # dozen threads; utterances are independent, though, so the all-cores figure shards the BATCH instead: one worker process
+    # per core, each running the whole forward of its utterances with single-threaded layers.  Same arithmetic, same total work, one "parallel region" per forward.
+    try:
+        phys = _physical_cores()
+        nall = max(1, min(phys, cores, b24))
+        out["all_cores"] = _utterance_parallel_sample(run_chunk=lambda ids_, mask_: oracle.phoneme2mel(
+            cfg, w, ids_, mask_, pitch=None, energy=None, duration=np.full(ids_.shape, dur, np.int32), f32=True),
+            b=b24, t=T, threads=nall)
+        out["all_cores"]["sample"] = (f"the same forward, B={b24} sharded by utterance over {nall} forked worker processes (one per physical core: "
+                                      f"{phys} cores / {cores} hardware threads visible), layers single-threaded inside a worker")
+    except Exception as e:                         # noqa: BLE001
+        out["all_cores"] = {"error": repr(e)}
     fox = np.asarray([FOX_IDS], np.int32)
     for threads, key in ((n24, "b1_fox_latency_ms_n24"), (1, "b1_fox_latency_ms_n1")):
         _omp_threads(threads)
@@ -135,6 +151,60 @@ def cpu_baseline(cfg, sd, T, dur):
                           "median of 5")
     _omp_threads(cores)
     return out
+
+
+def _physical_cores():
+    """Physical cores among the CPUs this process may run on (unique (package, core) pairs of /proc/cpuinfo)."""
+    allowed = os.sched_getaffinity(0)
+    seen, cpu, pkg = set(), None, 0
+    try:
+        for line in open("/proc/cpuinfo"):
+            k, _, v = line.partition(":")
+            k = k.strip()
+            if k == "processor":
+                cpu = int(v)
+            elif k == "physical id":
+                pkg = int(v)
+            elif k == "core id" and cpu in allowed:
+                seen.add((pkg, int(v)))
+    except OSError:
+        pass
+    return len(seen) or max(1, len(allowed) // 2)
+
+
+_UP_STATE = {}
+
+
+def _up_work(i):
+    """One worker's chunk (forked process: the batch and the closure are inherited through _UP_STATE)."""
+    run_chunk, chunks = _UP_STATE["run"], _UP_STATE["chunks"]
+    _omp_threads(1)                                     # every worker's layers run on its own core only
+    c = chunks[i]
+    if c[0].shape[0] == 1:                              # a 1-utterance chunk must stay on the masked (B > 1) path like its batch
+        o = run_chunk(np.concatenate([c[0], c[0]]), np.concatenate([c[1], c[1]]))
+        return int(o.mel_len[0])
+    return int(run_chunk(c[0], c[1]).mel_len.sum())
+
+
+def _utterance_parallel_sample(run_chunk, b, t, threads, seconds=6.0):
+    """frames/s of `run_chunk` over a batch of b utterances split into `threads` contiguous chunks, one forked worker process each
+    (Python threads would serialise on the GIL in the glue between the C calls: 128 threads measured 1.14x of 24)."""
+    import multiprocessing as mp
+    from efficientspeech_amd.synth import synth_phonemes
+    ids, mask = synth_phonemes(b, t, 99)
+    bounds = np.linspace(0, b, threads + 1).astype(int)
+    chunks = [(ids[lo:hi], mask[lo:hi]) for lo, hi in zip(bounds[:-1], bounds[1:]) if hi > lo]
+    _UP_STATE.update(run=run_chunk, chunks=chunks)
+    idx = list(range(len(chunks)))
+    with mp.get_context("fork").Pool(len(chunks)) as pool:     # (the children never touch the GPU runtime)
+        pool.map(_up_work, idx, chunksize=1)            # warm the workers
+        times, frames = [], 0
+        while len(times) < 2 or (sum(times) < seconds and len(times) < 50):
+            t0 = time.perf_counter()
+            frames = sum(pool.map(_up_work, idx, chunksize=1))
+            times.append(time.perf_counter() - t0)
+    dt = sum(times) / len(times)
+    return {"value": frames / dt, "unit": "mel-frames/s", "cores": len(chunks), "runs": len(times), "seconds_per_run": dt}
 
 
 def pmc_traffic(config, B, T, dur):
@@ -182,8 +252,38 @@ def timed_steps(pipe, net, x, steps, warmup, sync_all, event_every, graph):
     return dt, dec_ms, len(ev)
 
 
+def _self_launch(n):
+    """`python bench.py --gpus N` without a launcher (no WORLD_SIZE in the environment): become
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py <same arguments>` -- one rank per
+    GPU over RCCL, like the reference's single flag (`train.py --devices N`)."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # dmabuf IPC (the host driver's only mode): RCCL needs it
+    os.execv(sys.executable, [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+                              "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:])
+
+
+def trace_kernel_us(config):
+    """Average duration (us) of the mel decoder kernel in the newest committed `rocprofv3 --kernel-trace --stats` summary of this
+    config (profiles/*kernel_stats.md; tiny has no config tag in the file name) -> (us, file) or (None, None)."""
+    import glob
+    import re
+    tag = "" if config == "tiny" else config + "_"
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r??_?_{tag}kernel_stats.md")), reverse=True):
+        for line in open(path):
+            m = re.match(r"\| `void esmi::mel_decoder_kernel<.*\| (\d+) \| ([\d.]+) \| ([\d.]+) \|", line)
+            if m:
+                return float(m.group(3)), os.path.basename(path)
+    return None, None
+
+
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        _self_launch(a.gpus)
     fp32_lib = os.path.join(ROOT, "efficientspeech_amd", "libesmi_fp32mfma.so")
     if a.exact_fp32:
         os.environ["ESMI_LIB"] = fp32_lib
@@ -206,8 +306,7 @@ def main():
     cfg = CONFIGS[a.config]
     B_arg = a.batch or DEFAULT_BATCH[a.config]
     if a.scaling == "strong":
-        assert B_arg % world == 0, f"global batch {B_arg} not divisible by {world} ranks"
-        B = B_arg // world
+        B = -(-B_arg // world)      # equal shards of ceil(B / N): a ragged split computes copies of real utterances (sharded.shard_batch)
     else:
         B = B_arg
     T = a.phonemes or DEFAULT_PHONEMES[a.config]
@@ -259,7 +358,8 @@ def main():
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-    frames_per_step = B * L * world                       # every frame valid under D-const, no padding
+    # every frame valid under D-const, no padding; a ragged strong split counts the real utterances only
+    frames_per_step = (B_arg if a.scaling == "strong" else B * world) * L
     value = frames_per_step * a.steps / dt
     flops, nbytes = DECODER_WORK[a.config]
     # MelDecoder's first stage (proj Linear + Tanh + LN) is row-wise and runs at PHONEME rate inside the fused
@@ -280,6 +380,7 @@ def main():
     # (832 / 1344 / 2368 B is the stand-alone MelDecoder.forward on frame-rate features: the `decoder_only` leg.)
     exec_bytes = 4.0 * cfg.n_mel_channels + 4.0 * (cfg.dx2 if head_moved else cfg.d4) / a.dur
     traffic, traffic_src, mfma_util = (None, None, None) if a.exact_fp32 else pmc_traffic(a.config, B, T, a.dur)
+    tr_us, tr_src = (None, None) if a.exact_fp32 or (B, T) != (DEFAULT_BATCH[a.config], DEFAULT_PHONEMES[a.config]) else trace_kernel_us(a.config)
     out = {
         "metric": "mel-frames/sec (whole node), full Phoneme2Mel forward", "value": value, "unit": "mel-frames/s",
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
@@ -290,7 +391,7 @@ def main():
         "config": {"workload": f"{a.config} ES ({sum(v.size for v in sd.values())} params, seeded random weights), "
                                f"synthetic phoneme batch B={B} T={T} per GPU, injected durations D-const {a.dur} "
                                f"(L={L}), eval path, mel all-gather over RCCL when N>1",
-                   "global_batch": B * world, "per_gpu_batch": B, "phonemes": T, "frames_per_step": frames_per_step,
+                   "global_batch": (B_arg if a.scaling == "strong" else B * world), "per_gpu_batch": B, "phonemes": T, "frames_per_step": frames_per_step,
                    "parallelism": f"batch-shard x{world}",
                    "launch": ("hipGraph replay (encoder graph + decoder graph per step)" if a.graph else "eager")
                              + (", encoder/decoder on two streams (steps software-pipelined)" if a.two_stream else "") + launch_note},
@@ -307,6 +408,11 @@ def main():
                                                "frame); the frame-rate-input figure (832 / 1344 / 2368) belongs to `decoder_only`",
                      "algorithmic_flops_per_frame": flops,
                      "kernel_ms": dec_ms, "kernel_ms_samples": n_ev, "build_config": build_cfg,
+                     "frac_is": "event-timed (kernel_ms: live HIP events on the launch stream, this run)",
+                     "trace_kernel_us": tr_us, "trace_source": tr_src,
+                     "frac_trace": (flops * B * L / (tr_us * 1e-6) / 1e12 / peak_tf) if tr_us else None,
+                     "frac_trace_is": "the same FLOPs over the committed rocprofv3 --kernel-trace --stats average of this kernel (tracer "
+                                      "overhead included; a different run and box than kernel_ms)",
                      "contraction": ((f"{split_txt}; measured error <= that of an fp32 FMA chain (DESIGN.md 3); `peak` is the 16-bit "
                                       "matrix-pipe peak divided by the products per fp32-accurate product; `exact_fp32` below is the "
                                       "same step on the v_mfma_f32_32x32x2_f32 build") if split else "v_mfma_f32_32x32x2_f32 (exact fp32)"),
@@ -352,6 +458,102 @@ def main():
         out["without_allgather"] = {"value": frames_per_step * steps2 / dt2, "ms_per_step": dt2 / steps2 * 1e3, "steps": steps2,
                                     "note": "same shards, same barrier/max-over-ranks timing, mels left on the rank that made them"}
         del pipe_ng
+
+
+    def _forward_leg(config, b_global, t_ph, steps_, warm_, gather, lib=None, events=False):
+        """The same timed loop for another model / batch: `b_global` utterances sharded over the ranks (strong), D-const durations.
+        -> dict(ms_per_step, value [real frames/s, whole job], per_gpu_batch, kernel_ms)"""
+        cfg2 = CONFIGS[config]
+        b_rank = -(-b_global // world)
+        sd2 = synth_state_dict(cfg2, 1234)
+        ctx = _lib.use_library(lib) if lib else None
+        if ctx:
+            ctx.__enter__()
+        try:
+            net2 = make_net(cfg2, sd2, dev)
+            ids2, mask2 = synth_phonemes(b_rank, t_ph, 4321 + rank)
+            l2 = t_ph * a.dur
+            x2 = {"phoneme": torch.from_numpy(ids2).to(dev), "phoneme_mask": torch.from_numpy(mask2).to(dev),
+                  "duration_forced": torch.full((b_rank, t_ph), a.dur, dtype=torch.int32, device=dev), "max_mel_len": l2,
+                  "max_mel_len_exact": True}
+            pipe2 = ShardedMelPipeline(net2, world_size=world, gather=(gather and world > 1))
+            dt2, dec2, n2 = timed_steps(pipe2, net2, x2, steps_, warm_, sync_all, a.event_every if events else 1 << 30, False)
+            if world > 1:
+                t2 = torch.tensor([dt2], dtype=torch.float64, device=dev)
+                dist.all_reduce(t2, op=dist.ReduceOp.MAX)
+                dt2 = float(t2.item())
+        finally:
+            if ctx:
+                ctx.__exit__(None, None, None)
+        res = {"ms_per_step": dt2 / steps_ * 1e3, "value": b_global * l2 * steps_ / dt2, "steps": steps_, "global_batch": b_global,
+               "per_gpu_batch": b_rank, "phonemes": t_ph, "frames_per_step": b_global * l2}
+        if events and n2:
+            f2 = DECODER_WORK[config][0]
+            res.update(kernel_ms=dec2, kernel_ms_samples=n2, achieved_tflops=f2 * b_rank * l2 / (dec2 * 1e-3) / 1e12)
+        return res, net2, x2, cfg2, sd2
+
+    if world > 1 and not a.no_extras and a.config == "tiny" and a.scaling == "weak":
+        # north_star asks for both: the headline above is weak scaling (B per GPU fixed); here the headline's GLOBAL batch is split
+        # over the ranks (32 utterances per GPU at N = 8: bounded by the encoder side's latency chain), and BASELINE configs[3]
+        # (base ES, B = 512 x T = 256 over the node).  Collectives inside: every rank runs them or none does.
+        for key, (c2, b2, t2) in (("strong", ("tiny", DEFAULT_BATCH["tiny"], DEFAULT_PHONEMES["tiny"])),
+                                  ("base_strong", ("base", DEFAULT_BATCH["base"], DEFAULT_PHONEMES["base"]))):
+            ok = torch.ones(1, device=dev)
+            try:
+                res, n2_, x2_, _, _ = _forward_leg(c2, b2, t2, max(10, a.steps // 2), max(5, a.warmup // 2), gather=pipe.gather)
+                del n2_, x2_
+            except Exception as e:          # noqa: BLE001
+                res, ok = {"error": repr(e)}, torch.zeros(1, device=dev)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)          # a rank-local failure must not leave the others in a collective
+            if float(ok.item()) == 0.0 and "error" not in res:
+                res = {"error": "another rank failed"}
+            res["note"] = (f"{c2} ES, GLOBAL batch {b2} x T={t2} sharded over {world} ranks (strong scaling), D-const {a.dur}, "
+                           "mel all-gather one step behind; frames/s counts the real utterances")
+            out[key] = res
+
+    def _base_leg():
+        # ---- BASELINE configs[3] on ONE GPU (the 8-GPU run shards exactly this batch): base ES, B = 512, T = 256
+        steps2, warm2 = max(10, a.steps // 5), max(3, a.warmup // 4)
+        res, netb, xb, cfgb, sdb = _forward_leg("base", DEFAULT_BATCH["base"], DEFAULT_PHONEMES["base"], steps2, warm2, gather=False, events=True)
+        fb = DECODER_WORK["base"][0]
+        bb, tb_ = DEFAULT_BATCH["base"], DEFAULT_PHONEMES["base"]
+        lb = tb_ * a.dur
+        if "achieved_tflops" in res:
+            res["roofline"] = {"kernel": "mel_decoder_kernel<256,5,8>", "bound": "mfma", "achieved": res["achieved_tflops"], "peak": peak_tf,
+                               "unit": "TFLOP/s", "frac": res["achieved_tflops"] / peak_tf, "algorithmic_flops_per_frame": fb}
+            tr_b, tr_bsrc = trace_kernel_us("base")
+            if tr_b:
+                res["roofline"].update(trace_kernel_us=tr_b, trace_source=tr_bsrc, frac_trace=fb * bb * lb / (tr_b * 1e-6) / 1e12 / peak_tf)
+            trf, trf_src, _ = pmc_traffic("base", bb, tb_, a.dur)
+            if trf:
+                eb = 4.0 * cfgb.n_mel_channels + 4.0 * cfgb.d4 / a.dur
+                res["roofline"].update(traffic=trf, traffic_source=trf_src, traffic_ratio=trf / (eb * bb * lb))
+        # D-rand on base
+        rng = np.random.default_rng(1234)
+        d_rand = rng.integers(1, 12, size=(bb, tb_)).astype(np.int32)
+        l_rand = int(d_rand.sum(1).max())
+        xr = {"phoneme": xb["phoneme"], "phoneme_mask": xb["phoneme_mask"], "duration_forced": torch.from_numpy(d_rand).to(dev),
+              "max_mel_len": l_rand}
+        with torch.no_grad():
+            for _ in range(3):
+                netb(xr)
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for _ in range(10):
+                _, len_r, _ = netb(xr)
+            torch.cuda.synchronize(dev)
+            tr_ = (time.perf_counter() - t0) / 10
+        res["d_rand"] = {"ms_per_step": tr_ * 1e3, "valid_frames_per_step": int(d_rand.sum()), "padded_length": l_rand,
+                         "value": int(d_rand.sum()) / tr_, "mel_len_matches": bool(np.array_equal(len_r.cpu().numpy(), d_rand.sum(1)))}
+        del netb
+        if not a.exact_fp32 and os.path.exists(fp32_lib):
+            r32, n32_, _, _, _ = _forward_leg("base", bb, tb_, max(5, steps2 // 2), 2, gather=False, lib=fp32_lib, events=True)
+            del n32_
+            res["exact_fp32"] = {k: r32[k] for k in ("ms_per_step", "value", "steps", "kernel_ms", "achieved_tflops") if k in r32}
+            if "achieved_tflops" in r32:
+                res["exact_fp32"]["frac_of_157.3"] = r32["achieved_tflops"] / FP32_PEAK_TFLOPS
+        res["note"] = "BASELINE configs[3] on one GPU: base ES (3.95 M params), B=512 T=256 D-const, full Phoneme2Mel forward"
+        out["base"] = res
 
     def _single_gpu_extras():
         steps2, warm2 = max(10, a.steps // 2), max(5, a.warmup // 2)
@@ -501,6 +703,11 @@ def main():
             _single_gpu_extras()
         except Exception as e:                 # noqa: BLE001
             out["extras_error"] = repr(e)
+        if a.config == "tiny" and not a.exact_fp32:
+            try:
+                _base_leg()
+            except Exception as e:             # noqa: BLE001
+                out["base"] = {"error": repr(e)}
     def _train_leg():
         # ---- BASELINE configs[4]: the training step (forward + loss + backward + AdamW; N > 1: one RCCL all-reduce of the flat
         # gradient buffer per step), tiny-ES-shaped synthetic teacher-forced batch of the reference's default batch size per GPU
@@ -575,10 +782,32 @@ def main():
             except Exception as e:             # noqa: BLE001
                 out["train_step_error"] = repr(e)
         else:
-            try:                               # collectives inside: a failure is the same on every rank (same code, same shapes), so
-                _train_leg()                   # every rank lands here together; the headline line is printed either way
+            # collectives inside.  A failure in the step CONSTRUCTION is the same on every rank; a rank-local one inside the timed
+            # loop (OOM, a RCCL error) would leave the others waiting in an all-reduce -- so the leg runs under a watchdog thread
+            # that ends the process group's wait by aborting this rank's process after a generous bound instead of hanging the
+            # benchmark, and the ranks agree on an ok-flag before anyone goes on
+            import threading
+            done_evt = threading.Event()
+
+            def _watchdog():
+                if not done_evt.wait(600.0):
+                    if rank == 0:
+                        out["train_step_error"] = "train leg timed out (a rank failed inside a collective?)"
+                        print(json.dumps(out), flush=True)
+                    os._exit(3)
+            threading.Thread(target=_watchdog, daemon=True).start()
+            ok = torch.ones(1, device=dev)
+            try:
+                _train_leg()
             except Exception as e:             # noqa: BLE001
                 out["train_step_error"] = repr(e)
+                ok.zero_()
+            try:
+                dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+                if float(ok.item()) == 0.0 and "train_step_error" not in out:
+                    out["train_step_error"] = "another rank failed"
+            finally:
+                done_evt.set()
     if rank == 0:
         if world == 1 and not a.no_cpu_baseline:
             try:

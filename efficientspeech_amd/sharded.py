@@ -26,15 +26,38 @@ def _encode_with_head(net, x, need_lmax=True):
     return net.encoder._encode(x, train=False, need_lmax=need_lmax, head=net.decoder._head(lib, stream))
 
 
+def shard_rows(B, rank, world):
+    """Rows [lo, hi) of a batch of B utterances that rank `rank` of `world` owns, and the common shard size: contiguous
+    shards of ceil(B / world) utterances -- the last ranks own fewer (possibly none) when world does not divide B."""
+    per = -(-B // world)
+    lo = min(rank * per, B)
+    return lo, min(lo + per, B), per
+
+
 def shard_batch(x, rank, world):
-    """Contiguous utterance shard of every batch-leading tensor in the input dict."""
+    """Contiguous utterance shard of every batch-leading tensor in the input dict.  A ragged last batch (world does not divide
+    B) is padded, not refused: every rank gets ceil(B / world) utterances (equal shards are what all_gather_into_tensor needs),
+    the missing ones being copies of the shard's last utterance -- or of the batch's last one for a rank that owns none.  The
+    copies only cost their compute: they are duplicates of real utterances, so they cannot change the batch's padded length, and
+    `unpad_gathered` drops their rows (they sit behind the B real ones in the gathered tensors)."""
     B = x["phoneme"].shape[0]
-    assert B % world == 0, f"batch {B} not divisible by world size {world}"
-    per = B // world
+    lo, hi, per = shard_rows(B, rank, world)
     out = {}
     for k, v in x.items():
-        out[k] = v[rank * per:(rank + 1) * per] if torch.is_tensor(v) and v.dim() > 0 and v.shape[0] == B else v
+        if torch.is_tensor(v) and v.dim() > 0 and v.shape[0] == B:
+            part = v[lo:hi]
+            if hi - lo < per:
+                fill = (part[-1:] if hi > lo else v[B - 1:B]).expand((per - (hi - lo),) + tuple(v.shape[1:]))
+                part = torch.cat([part, fill])
+            out[k] = part
+        else:
+            out[k] = v
     return out
+
+
+def unpad_gathered(t, B):
+    """Rows of the real utterances of an all-gathered tensor: with contiguous shards the padding copies are the rows behind B."""
+    return t if t.shape[0] == B else t[:B]
 
 
 def _masked_path_inputs(x):
@@ -77,7 +100,7 @@ def sharded_forward(net, x_full, group=None):
     for t in (mel.contiguous(), mel_len.contiguous(), dur.contiguous()):
         full = torch.empty((t.shape[0] * world,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
         dist.all_gather_into_tensor(full, t, group=group)
-        outs.append(full)
+        outs.append(unpad_gathered(full, x_full["phoneme"].shape[0]))
     return tuple(outs)
 
 

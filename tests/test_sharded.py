@@ -63,6 +63,50 @@ def test_shard_batch_splits_every_batch_leading_tensor():
     assert s["phoneme"].tolist() == [[8, 9], [10, 11]] and s["phoneme_mask"].shape == (2, 2) and s["max_mel_len"] == 7
 
 
+def test_shard_batch_pads_a_ragged_batch_and_unpad_drops_the_copies():
+    """world does not divide B: equal shards of ceil(B / world), copies of real utterances behind the real ones (a
+    ragged last batch must not kill a multi-GPU serving loop)."""
+    from efficientspeech_amd.sharded import shard_batch, shard_rows, unpad_gathered
+    x = {"phoneme": torch.arange(10).reshape(5, 2), "max_mel_len": 7}
+    shards = [shard_batch(x, r, 4)["phoneme"] for r in range(4)]
+    assert [tuple(t.shape) for t in shards] == [(2, 2)] * 4
+    assert shards[0].tolist() == [[0, 1], [2, 3]] and shards[1].tolist() == [[4, 5], [6, 7]]
+    assert shards[2].tolist() == [[8, 9], [8, 9]]          # one real utterance + its copy
+    assert shards[3].tolist() == [[8, 9], [8, 9]]          # owns none: copies of the batch's last utterance
+    assert [shard_rows(5, r, 4) for r in range(4)] == [(0, 2, 2), (2, 4, 2), (4, 5, 2), (5, 5, 2)]
+    assert torch.equal(unpad_gathered(torch.cat(shards), 5), x["phoneme"])
+
+
+def _ragged_worker(rank, world, port, out_path):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WAVESIM_THREADS="2")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from tests import helpers as H
+    from tests.simlib import use_sim
+    from efficientspeech_amd.sharded import sharded_forward
+    from efficientspeech_amd.synth import synth_phonemes
+    net, cfg, sd = H.make_net("tiny", "cpu")
+    ids, mask = synth_phonemes(3, 18, 33, [18, 7, 12])
+    x = {"phoneme": torch.from_numpy(ids), "phoneme_mask": torch.from_numpy(mask)}
+    with use_sim(), torch.no_grad():
+        mel, mel_len, dur = sharded_forward(net, x)
+        if rank == 0:
+            ref_mel, ref_len, ref_dur = net(x)
+            ok = mel.shape == ref_mel.shape and torch.equal(mel, ref_mel) and torch.equal(mel_len, ref_len) and torch.equal(dur, ref_dur)
+            np.save(out_path, np.array([int(ok), mel.shape[0]]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_ragged_batch_is_bit_identical(tmp_path):
+    """B = 3 on two ranks: shards of 2 (rank 1: one real utterance + its copy); the gathered result is the 3 real utterances,
+    bit-identical to the single-process forward."""
+    out = str(tmp_path / "res.npy")
+    mp.spawn(_ragged_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    ok, B = np.load(out)
+    assert ok == 1 and B == 3
+
+
 # ------------------------------------------------------------------------------------------------ the serving loop, N > 1, on one GPU
 def _pipeline_worker(rank, world, port, out_path):
     """Two ranks share cuda:0 (process group `gloo`: RCCL refuses two ranks on one device; gloo carries CUDA tensors) and run
@@ -147,3 +191,33 @@ def test_gpu_two_stream_loop_bounds_its_run_ahead_and_matches_the_plain_loop():
             assert torch.equal(mel_len, ref_len) and torch.equal(mel, ref), step
     pipe.flush()
     assert not pipe.inflight
+
+
+@pytest.mark.gpu
+def test_gpu_bench_self_launches_two_ranks_on_one_device():
+    """`python bench.py --gpus 2` with no launcher in front of it: it re-executes itself under torch.distributed.run (one rank
+    per GPU; here both ranks on cuda:0 over gloo -- RCCL refuses two ranks on one device), runs the sharded serving loop with the
+    side-stream all-gather and prints the one JSON line the driver parses (the plain form used to die on an assert)."""
+    import json
+    import subprocess
+    env = dict(os.environ, ESMI_BENCH_ONE_DEVICE="1", ESMI_BENCH_BACKEND="gloo")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2", "--batch", "8",
+                        "--phonemes", "32", "--event-every", "1", "--no-extras", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 4 and out["scaling"] == "weak"
+    assert out["config"]["global_batch"] == 16 and out["config"]["frames_per_step"] == 16 * 32 * 6
+    assert out["value"] > 0 and abs(out["value"] - out["config"]["frames_per_step"] / (out["ms_per_step"] * 1e-3)) < 1e-6 * out["value"]
+    assert out["allgather"]["bytes_received_per_rank"] == 8 * 32 * 6 * 80 * 4 and out["allgather"]["GBps_received_per_rank"] > 0
+    assert out["without_allgather"]["value"] > 0 and out["roofline"]["kernel_ms"] > 0
+    # strong scaling with a ragged split: 7 utterances over 2 ranks -> shards of 4, 7 real utterances counted
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "7",
+                        "--phonemes", "32", "--scaling", "strong", "--no-extras", "--no-cpu-baseline"], env=env, capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert out["scaling"] == "strong" and out["config"]["per_gpu_batch"] == 4 and out["config"]["frames_per_step"] == 7 * 32 * 6
