@@ -54,9 +54,12 @@ int launch_convgemm(ConvGemmP p, hipStream_t st) {
     }
 #if ESMI_CHAIN_SPLIT
     // large plain convolutions / Linears: operands staged through LDS by convgemm_dma_kernel (convgemm.h) -- needs input rows ==
-    // output rows (flat-row addressing) and an input tensor of < 2^31 elements (32-bit lane offsets); anything else streams from L2 below
+    // output rows (flat-row addressing) and 32-bit lane offsets: the kernel forms (row + tile rows + halo) * lda BEFORE it clamps, so
+    // the bound covers the last workgroup's padded rows and the taps' reach, not just the tensor (the pre-clamp product
+    // must not overflow); anything else streams from L2 below
     if (p.mode == MODE_CONV && p.stride == 1 && !p.ids && (p.c_in & 31) == 0 && p.c_out > 64 && (long)p.B * p.n_out >= ESMI_GEMM_LDS_MIN_ROWS &&
-        p.n_in == p.n_out && ((long)p.B * p.n_in * p.lda + p.a_coff + p.c_in) < (1L << 31)) {
+        p.n_in == p.n_out &&
+        (((long)p.B * p.n_in + 64L * ESMI_GEMM_LDS_WAVES + 2L * kGemmHaloMax + 8) * p.lda + p.a_coff + p.c_in) < (1L << 31)) {
         constexpr int NWV = ESMI_GEMM_LDS_WAVES;
         const long rows = (long)p.B * p.n_out;
         // a LayerNorm / row-dot epilogue over 129..256 channels needs them all in one wave: 32 rows x 256 channels per wave; else

@@ -613,13 +613,14 @@ class TrainStep:
         f = self.flat
         index = {id(p): j for j, p in enumerate(self.net.parameters())}
         state, off = {}, 0
+        t_now = self.t                          # (precision 16: a device read -- once, not per parameter)
         for p in f.params:
             k = p.numel()
-            if self.t > 0:
-                state[index[id(p)]] = {"step": torch.tensor(float(self.t)), "exp_avg": f.m[off:off + k].view(p.shape).clone(),
+            if t_now > 0:
+                state[index[id(p)]] = {"step": torch.tensor(float(t_now)), "exp_avg": f.m[off:off + k].view(p.shape).clone(),
                                        "exp_avg_sq": f.v[off:off + k].view(p.shape).clone()}
             off += (k + 3) & ~3
-        group = {"lr": self.lr, "betas": tuple(self.betas), "eps": self.eps, "weight_decay": self.wd, "amsgrad": False,
+        group = {"lr": self.lr, "initial_lr": self.lr, "betas": tuple(self.betas), "eps": self.eps, "weight_decay": self.wd, "amsgrad": False,
                  "maximize": False, "foreach": None, "capturable": False, "differentiable": False, "fused": None,
                  "decoupled_weight_decay": True, "params": list(range(len(index)))}
         return {"state": state, "param_groups": [group]}
@@ -633,7 +634,7 @@ class TrainStep:
         `hifigan.` before saving."""
         ck = {"state_dict": {"phoneme2mel." + k: v.detach().clone() for k, v in self.net.state_dict().items()},
               "hyper_parameters": self.hyper_parameters(), "optimizer_states": [self.optimizer_state_dict()],
-              "global_step": self.t}
+              "global_step": self.t, "epoch": int(getattr(self, "epoch", 0))}
         if self.precision == 16:                   # torch.amp.GradScaler.state_dict()'s keys (Lightning stores it next to the optimizer)
             sc = self._scaler.cpu().tolist()
             ck["scaler"] = {"scale": sc[0], "growth_factor": sc[1], "backoff_factor": sc[2], "growth_interval": int(sc[3]),
@@ -642,7 +643,10 @@ class TrainStep:
 
     def load_state_dict(self, ckpt):
         """Resume: weights into the flat buffer's views (in place), the AdamW moments and step count from the optimizer state
-        (torch's AdamW state_dict layout, as `state_dict()` writes it)."""
+        (torch's AdamW state_dict layout, as `state_dict()` writes it).  Only optimizer states written by `TrainStep.state_dict()` --
+        i.e. over `net.parameters()` of the acoustic model alone -- load: the reference's own optimizer also owns the vocoder's
+        parameters (model.py:148, 279-283), so its state has a different parameter list and is refused below.  `ckpt['epoch']`
+        (when present) is returned so that the caller can pass it to `fit(first_epoch=...)`."""
         sd = {k[len("phoneme2mel."):]: v for k, v in ckpt["state_dict"].items() if k.startswith("phoneme2mel.")}
         own = dict(self.net.state_dict())
         missing = [k for k in own if k not in sd]
@@ -671,7 +675,9 @@ class TrainStep:
             raise RuntimeError(f"per-parameter step counts differ: {sorted(steps)}")
         self.t = steps.pop() if steps else 0
         g = o["param_groups"][0]
-        self.lr, self.wd, self.betas, self.eps = g["lr"], g["weight_decay"], tuple(g["betas"]), g["eps"]
+        # the BASE learning rate: under a scheduler torch stores it as `initial_lr` and keeps the scheduled value in `lr` (0 at the
+        # first step of the reference's LambdaLR warm-up) -- `fit` derives every step's rate from the base one
+        self.lr, self.wd, self.betas, self.eps = g.get("initial_lr", g["lr"]), g["weight_decay"], tuple(g["betas"]), g["eps"]
         if self.graph and self.precision != 16:
             self._step_dev.fill_(self.t)
         if self.precision == 16 and "scaler" in ckpt:
@@ -679,17 +685,25 @@ class TrainStep:
             self._scaler[:5] = torch.tensor([sc["scale"], sc["growth_factor"], sc["backoff_factor"], sc["growth_interval"],
                                              sc["_growth_tracker"]], dtype=torch.float32)
         self._invalidate_packed()
+        self.epoch = int(ckpt.get("epoch", 0))
+        return self.epoch
 
     def _invalidate_packed(self):
         """The optimizer kernel wrote the weights behind torch's version counters: drop EVERY packed copy the inference path
         keeps (each module's `_PackCache` attributes, whatever their names -- the decoder has two -- and the one-call
         forward's argument block) so that the next eval forward re-packs from the updated parameters."""
-        for m in self.net.modules():
-            for v in list(m.__dict__.values()):
-                if isinstance(v, networks._PackCache):
-                    v.invalidate()
-            if hasattr(m, "_fwd_ident"):
-                m._fwd_ident = None
+        caches = getattr(self, "_pack_caches", None)
+        if caches is None or self._pack_caches_n != sum(1 for _ in self.net.modules()):
+            # collected once (and again only if the module tree changed): this runs every step, graph replays included, and walking
+            # every module's __dict__ was pure host time in a loop that is host-dispatch bound
+            mods = list(self.net.modules())
+            self._pack_caches_n = len(mods)
+            self._pack_owners = [m for m in mods if hasattr(m, "_launch")]      # the one-call forward keeps an argument block (lazily created)
+            caches = self._pack_caches = [v for m in mods for v in m.__dict__.values() if isinstance(v, networks._PackCache)]
+        for v in caches:
+            v.invalidate()
+        for m in self._pack_owners:
+            m._fwd_ident = None
 
     def _build_pack_list(self):
         """Persistent GEMM copies (forward layout, data-gradient layout) of every dense convolution / Linear weight, re-made by ONE
