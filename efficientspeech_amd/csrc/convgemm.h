@@ -442,12 +442,7 @@ __global__ __launch_bounds__(64 * NWV, 2) void convgemm_dma_kernel(const ConvGem
         for (int d = 0; d < nd; ++d) {
             int off = off0 + 8 * d * p.lda + 4 * ((d & 1) ? piece_o : piece_e);
             off = off < 0 ? 0 : (off > max_off ? max_off : off);
-#ifdef ESMI_WAVESIM
-            reinterpret_cast<f32x4*>(at + 8 * d * 32)[lane] = ld4(p.A + off);
-#else
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.A + off),
-                                             (__attribute__((address_space(3))) void*)(at + 8 * d * 32), 16, 0, 0);
-#endif
+            lds_dma16(p.A + off, at + 8 * d * 32, lane);
         }
     };
     const int ntw = (p.c_out + 31) >> 5;
@@ -465,12 +460,7 @@ __global__ __launch_bounds__(64 * NWV, 2) void convgemm_dma_kernel(const ConvGem
                     unsigned* d = dstb + ((st * 2 + pl) * NT + nt) * WBLK;
                     if ((n0 >> 5) + nt < ntw) {
                         const float* src = p.Wp + ((blk0 + (long)(2 * st + pl) * ntw + nt) * 64 + lane) * 4;
-#ifdef ESMI_WAVESIM
-                        reinterpret_cast<f32x4*>(d)[lane] = ld4(src);
-#else
-                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                                         (__attribute__((address_space(3))) void*)d, 16, 0, 0);
-#endif
+                        lds_dma16(src, d, lane);
                     } else {
                         reinterpret_cast<u32x4*>(d)[lane] = u32x4{0u, 0u, 0u, 0u};   // column tile past c_out
                     }

@@ -60,13 +60,7 @@ void esmi_dev_set_chain_trace(long long* ptr) {
 extern "C" {
 
 int esmi_version(void) { return ESMI_VERSION; }
-const char* esmi_backend(void) {
-#ifdef ESMI_WAVESIM
-    return "wavesim";
-#else
-    return "hip:gfx950";
-#endif
-}
+const char* esmi_backend(void) { return kBackendName; }
 
 const char* esmi_build_config(void) {
 #if ESMI_CHAIN_SPLIT
@@ -739,15 +733,7 @@ int esmi_phoneme2mel_forward_f32(const esmi_forward_args* a, int stage, esmi_str
         if (int rc = set(reinterpret_cast<int*>(a->range_flag))) return rc;
     int rc = forward_impl(a, stage, stream);
     int32_t flag = 0;
-#ifdef ESMI_WAVESIM
-    flag = *a->range_flag;
-#else
-    if (!rc) {
-        e = hipStreamSynchronize(S(stream));
-        if (e == hipSuccess) e = hipMemcpy(&flag, a->range_flag, sizeof flag, hipMemcpyDeviceToHost);
-        if (e != hipSuccess) rc = (int)e;
-    }
-#endif
+    if (!rc) rc = read_device_flag(a->range_flag, S(stream), &flag);
     for (auto set : setters) set(nullptr);
     return rc ? rc : (flag ? ESMI_ERR_RANGE : ESMI_OK);
 #else

@@ -31,17 +31,13 @@ inline size_t align256(size_t n) { return (n + 255) & ~(size_t)255; }
 constexpr int kMaxDevices = 64;
 struct AttrOnce { bool done[kMaxDevices] = {}; };
 inline int raise_lds_limit(const void* fn, AttrOnce& once) {
-#ifndef ESMI_WAVESIM
-    int dev = 0;
-    hipError_t e = hipGetDevice(&dev);
-    if (e != hipSuccess) return (int)e;
-    if (dev < 0 || dev >= kMaxDevices) return ESMI_ERR_UNSUPPORTED;
+    const int dev = current_device();
+    if (dev < 0) return -dev;
+    if (dev >= kMaxDevices) return ESMI_ERR_UNSUPPORTED;
     if (!once.done[dev]) {
-        e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return (int)e;
+        if (int rc = set_max_dynamic_lds(fn, 160 * 1024)) return rc;
         once.done[dev] = true;
     }
-#endif
     return ESMI_OK;
 }
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
@@ -99,11 +95,8 @@ int set_range_flag_train(int* flag);
 #else
 #define ESMI_TU_CHAIN_TRACE_SETTER(tu)
 #endif
-#if ESMI_RANGE_CHECK && !defined(ESMI_WAVESIM)
-#define ESMI_TU_RANGE_SETTER(tu) namespace esmi { int set_range_flag_##tu(int* flag) { \
-    const hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(g_esmi_range_flag), &flag, sizeof(flag)); return e == hipSuccess ? ESMI_OK : (int)e; } }
-#elif ESMI_RANGE_CHECK
-#define ESMI_TU_RANGE_SETTER(tu) namespace esmi { int set_range_flag_##tu(int* flag) { g_esmi_range_flag = flag; return ESMI_OK; } }
+#if ESMI_RANGE_CHECK
+#define ESMI_TU_RANGE_SETTER(tu) namespace esmi { int set_range_flag_##tu(int* flag) { return store_range_flag_pointer(flag); } }
 #else
 #define ESMI_TU_RANGE_SETTER(tu) namespace esmi { int set_range_flag_##tu(int*) { return ESMI_OK; } }
 #endif

@@ -38,28 +38,19 @@
 #include "esmi_dev.h"
 #include "small_kernels.h"
 
-// Build knobs (defaults = the measured best on MI355X, tiny ES B=256 T=128; history in DESIGN.md 3.1)
+// Build knob: the contraction form (two libraries of one ABI are built from it, __graft_entry__.py)
 #ifndef ESMI_DEC_SPLIT      // contraction of the pointwise GEMMs (esmi_dev.h):
 #define ESMI_DEC_SPLIT 2    //   0: v_mfma_f32_32x32x2_f32 (exact fp32; the libesmi_fp32mfma.so build)
 #endif                      //   2: fp32 split into 2 f16 (weights pre-scaled by 2^8), 3 products on v_mfma_f32_32x32x16_f16
 #if ESMI_DEC_SPLIT != 0 && ESMI_DEC_SPLIT != 2
 #error "ESMI_DEC_SPLIT must be 0 (fp32 MFMA) or 2 (split f16x2)"
 #endif
-#ifndef ESMI_DEC_WPS
-#define ESMI_DEC_WPS 4      // __launch_bounds__ waves/SIMD of the dx2 = 128 kernel (512-thread workgroups: 4 -> 128 VGPRs, two workgroups per CU)
-#endif
-#ifndef ESMI_DEC_KSUB
-#define ESMI_DEC_KSUB (ESMI_DEC_SPLIT ? 4 : 8)   // un-pipelined contractions (fp32 build, in-kernel proj stage): k-steps (of 8 channels) of weights in registers at a time
-#endif
-#ifndef ESMI_DEC_WD
-#define ESMI_DEC_WD 0       // weight-fragment ring depth (16-channel steps) of the dx2 = 128 kernel's K loop; 0 = no hand pipelining
-#endif
-#ifndef ESMI_DEC_WD256
-#define ESMI_DEC_WD256 2    // the same for the dx2 = 256 kernel (small / base ES: one workgroup per CU)
-#endif
-#ifndef ESMI_DEC_AD
-#define ESMI_DEC_AD 1       // A fragments in flight, in (step, row tile) items (LDS -> VGPR ring), ring form only
-#endif
+// Fixed choices (each the measured best on MI355X; the alternatives and their times are in DESIGN.md 3.1, not in the build):
+//  * dx2 = 128: 4 waves per SIMD (128 VGPRs, two workgroups per CU); weight slices of 4 k-steps (split build) / 8 (fp32 build) loaded then
+//    used, no hand-pipelined ring (a ring measured 169 -> 172 / 174 us: the neighbour workgroup already fills the L2 round trips);
+//  * dx2 = 256 (one workgroup per CU, nobody fills the gaps): the K loop's weight fragments run 2 steps ahead in a VGPR ring
+//    (small ES decoder 1774 -> 1687 us; depth 4 spills: 1736), the A fragments one item ahead; 8 waves per window (16: 2.43 vs 1.87 ms).
+constexpr int kDecWps128 = 4, kDecWeightRing256 = 2, kDecARing = 1;
 #define ESMI_DEC_TANH tanh_fast_f32
 #define ESMI_DEC_RSQRT rsqrt_fast_f32   // v_rsq_f32 (1 ulp)
 
@@ -180,18 +171,14 @@ __device__ __forceinline__ int batch_max_len(const int* __restrict__ mel_len, in
     for (int j = lane; j < B; j += 64) v = max(v, mel_len[j]);
     float f = row_max32((float)v);      // lengths are far below 2^24: exact in fp32
     f = fmaxf(f, swap32_f(f));
-#ifdef ESMI_WAVESIM
-    return (int)f;
-#else
-    return __builtin_amdgcn_readfirstlane((int)f);
-#endif
+    return uniform_i((int)f);
 }
 
 // NW waves per window (8 or 16): wave (mh = w>>2, ns = w&3) owns rows [128/MH*mh, +128/MH) x columns [ns*DX2/4, +DX2/4).
 // NW = 16 (dx2 = 256, one workgroup per CU either way): four waves per SIMD instead of two inside every barrier-separated
 // phase -- the phases are latency-bound, so the extra waves are what hides it -- at 128 VGPRs (one 32-row tile per wave).
 template <int DX2, int KD, int NW>
-__global__ __launch_bounds__(64 * NW, (DX2 <= 128 ? ESMI_DEC_WPS : NW / 4)) void mel_decoder_kernel(const MelDecP p) {
+__global__ __launch_bounds__(64 * NW, (DX2 <= 128 ? kDecWps128 : NW / 4)) void mel_decoder_kernel(const MelDecP p) {
     constexpr int kDecThreads = 64 * NW;    // shadows the namespace constant inside this kernel
     constexpr int NS = 4;                   // column slices per workgroup
     constexpr int MH = NW / NS;             // row groups (2 or 4)
@@ -266,15 +253,8 @@ __global__ __launch_bounds__(64 * NW, (DX2 <= 128 ? ESMI_DEC_WPS : NW / 4)) void
     // when the last reader of the slots' old contents has passed a barrier, drained by the barrier in front of the first reader of
     // the new ones.  "layer" n_layers is the mel Linear (its bias goes to the group A slots, unused by then).
     auto stage = [&](long float_off, float* dst, int n4) __attribute__((always_inline)) {   // n4 float4 from blob + float_off to dst, thread tid -> dst + 4 tid
-        if (tid < n4) {
-#ifdef ESMI_WAVESIM
-            reinterpret_cast<f32x4*>(dst)[tid] = blob_ld(float_off, tid16);
-#else
-            // (opaque: the per-lane source pointer is formed here, not hoisted out of the layer loop as a live 64-bit register pair)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.blob + float_off + opaque_i(4 * tid)),
-                                             (__attribute__((address_space(3))) void*)(dst + 256 * w), 16, 0, 0);
-#endif
-        }
+        // (opaque: the per-lane source pointer is formed here, not hoisted out of the layer loop as a live 64-bit register pair)
+        if (tid < n4) lds_dma16(p.blob + float_off + opaque_i(4 * tid), dst + 256 * w, lane);
     };
     auto fetch_A = [&](int l) __attribute__((always_inline)) {
         if (l < n_layers) stage(p.lay.layer0 + (long)l * p.lay.layer_stride, pbuf, NA4);
@@ -283,14 +263,8 @@ __global__ __launch_bounds__(64 * NW, (DX2 <= 128 ? ESMI_DEC_WPS : NW / 4)) void
         if (l < n_layers) {
             stage(p.lay.layer0 + (long)l * p.lay.layer_stride + p.lay.l_pwb, pbuf + P_PWB, NB4);
             if (((l + 1) % p.block_depth) == 0) {   // block end: skip LN params, threads NB4 .. NB4 + DX2/2 (whole waves: NB4 is a multiple of 64 floats4? no -- see below)
-                if (tid >= NB4 && tid < NB4 + DX2 / 2) {
-#ifdef ESMI_WAVESIM
-                    reinterpret_cast<f32x4*>(pbuf + P_PWB)[tid] = blob_ld(p.lay.skip0 + (long)(l / p.block_depth) * 2 * DX2 - 4 * NB4, tid16);
-#else
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.blob + p.lay.skip0 + (long)(l / p.block_depth) * 2 * DX2 + opaque_i(4 * (tid - NB4))),
-                                                     (__attribute__((address_space(3))) void*)(pbuf + P_PWB + 256 * w), 16, 0, 0);
-#endif
-                }
+                if (tid >= NB4 && tid < NB4 + DX2 / 2)
+                    lds_dma16(p.blob + p.lay.skip0 + (long)(l / p.block_depth) * 2 * DX2 + opaque_i(4 * (tid - NB4)), pbuf + P_PWB + 256 * w, lane);
             }
         } else {
             stage(p.lay.mel_b, pbuf, DX2 / 4);
@@ -353,7 +327,7 @@ __global__ __launch_bounds__(64 * NW, (DX2 <= 128 ? ESMI_DEC_WPS : NW / 4)) void
     // ================================================================== contractions
     // Un-pipelined form (exact-fp32 build; in-kernel proj stage of the split build): the wave's weight slice for KSUB k-steps
     // is loaded, then the A fragments of its rows stream from LDS.
-    constexpr int KSUB = DX2 <= 128 ? ESMI_DEC_KSUB / NTW : (NW > 8 ? 2 : 8);   // k-steps (of 8 channels) of weights in registers at a time
+    constexpr int KSUB = DX2 <= 128 ? (SPLIT ? 4 : 8) / NTW : (NW > 8 ? 2 : 8);   // k-steps (of 8 channels) of weights in registers at a time
 #if ESMI_DEC_SPLIT
     constexpr int KS16 = KSUB / 2;
     u32x4 bf[NTW][KS16][2];
@@ -393,7 +367,7 @@ __global__ __launch_bounds__(64 * NW, (DX2 <= 128 ? ESMI_DEC_WPS : NW / 4)) void
     // per CU, nobody to fill the gaps): hand-pipelined -- an item = (16-channel step s, row tile mt); weight fragments of step s + WD
     // and A fragments of item q + AD are requested while item q's MFMAs run (VGPR rings; scheduling fences keep hipcc from sinking
     // the loads back to their first use).  small ES decoder 1774 -> 1687 us with WD = 2; WD = 4 spills (1736), 6: 1976.
-    constexpr int WD = DX2 > 128 ? ESMI_DEC_WD256 : ESMI_DEC_WD, AD = ESMI_DEC_AD;
+    constexpr int WD = DX2 > 128 ? kDecWeightRing256 : 0, AD = kDecARing;
     constexpr int NSTEP = 8 * KCH, NITEM = NSTEP * MT;
     static_assert(WD >= 0 && WD <= NSTEP && AD >= 1 && AD <= NITEM, "ring depths");
     u32x4 wr[WD > 0 ? WD : 1][NTW][2];

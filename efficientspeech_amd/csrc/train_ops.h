@@ -409,11 +409,7 @@ static __global__ __launch_bounds__(256) void train_conv_wgrad_mfma_kernel(const
 // out[e] = sum over chunks of partial[chunk * stride + e], e < n.  64 elements x kReduceGroups interleaved chunk groups per
 // workgroup; the group sums are added in group order (fixed order: reproducible).  (The CPU simulator build uses 4 groups and
 // 8 loss workgroups: a fiber per thread makes 1024-thread workgroups the slowest thing in the test suite.)
-#ifdef ESMI_WAVESIM
-constexpr int kReduceGroups = 4;
-#else
-constexpr int kReduceGroups = 16;
-#endif
+// (kReduceGroups: wavesim_shim.h)
 static __global__ __launch_bounds__(64 * kReduceGroups) void train_reduce_chunks_kernel(const float* __restrict__ partial, long n, long stride,
                                                                                 long chunks, float* __restrict__ out,
                                                                                 long n0 = -1, float* __restrict__ out1 = nullptr) {
@@ -926,11 +922,7 @@ struct LossP {
     float* partial;                            // [kLossBlocks][6]
     const float* grad_seed;                    // NULL or one float: multiplies every gradient
 };
-#ifdef ESMI_WAVESIM
-constexpr int kLossBlocks = 8;
-#else
-constexpr int kLossBlocks = 256;
-#endif
+// (kLossBlocks: wavesim_shim.h)
 __device__ __forceinline__ float block_sum_256(float v, float* red) {
     const int tid = (int)threadIdx.x;
     red[tid] = v;

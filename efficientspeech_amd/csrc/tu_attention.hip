@@ -9,11 +9,7 @@ ESMI_TU_RANGE_SETTER(attention)
 namespace esmi {
 
 #ifndef ESMI_ATTN_LDS_MIN_HEADS
-#ifdef ESMI_WAVESIM
-#define ESMI_ATTN_LDS_MIN_HEADS 1      // (simulator: always take the LDS kernel where it applies, so the tests reach it)
-#else
-#define ESMI_ATTN_LDS_MIN_HEADS 128    // enough (utterance, head) workgroups to occupy the chip at one per CU
-#endif
+#define ESMI_ATTN_LDS_MIN_HEADS kAttnLdsMinHeadsDefault    // (wavesim_shim.h: 128 on the GPU, 1 in the simulator)
 #endif
 int launch_attn(const AttnP& p, hipStream_t st) {
     if ((p.C & 31) || p.N <= 0) return ESMI_ERR_ARG;   // channel groups of 32 (4 k-steps fetched together)

@@ -8,11 +8,7 @@ ESMI_TU_RANGE_SETTER(convgemm)
 
 
 #ifndef ESMI_GEMM_LDS_MIN_ROWS   // rows (B * n_out) from which the per-op plan's GEMMs take the LDS-staged kernel
-#ifdef ESMI_WAVESIM
-#define ESMI_GEMM_LDS_MIN_ROWS 1   // the simulator tests are small: run them through it too
-#else
-#define ESMI_GEMM_LDS_MIN_ROWS 2048
-#endif
+#define ESMI_GEMM_LDS_MIN_ROWS kGemmLdsMinRowsDefault   // (wavesim_shim.h: 2048 on the GPU, 1 in the simulator)
 #endif
 
 #ifdef ESMI_GEMM_TRACE

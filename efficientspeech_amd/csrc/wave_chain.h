@@ -283,9 +283,7 @@ __device__ __forceinline__ void wave_gemm(f32x16 (&acc)[NT], WaveGrp<NT>& g0, co
 template <int NT>
 __device__ __forceinline__ void tile_store(float* tile, int ld, int col0, const f32x16 (&v)[NT], int lane) {
     const int i = lane & 31;
-#ifndef ESMI_WAVESIM
-    asm volatile("" : "+v"(ld));
-#endif
+    ld = opaque_i(ld);
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
 #pragma unroll
