@@ -437,13 +437,36 @@ def check_precision16_step(dev):
         n += 1
     assert n >= 60
     assert max(worse)[0] < 0.05, sorted(worse)[-3:]
-    for k in g.files:                                           # the update itself: AdamW on the unscaled gradients
-        if k.startswith("after."):
-            mine, ref = named[k[6:]].detach().cpu().numpy(), g[k]
-            assert np.abs(mine - ref).max() < 2.5e-3, k         # (lr 1e-3: a first AdamW step moves every weight by <= 1e-3; the sign
-            #                                                      of a near-zero fp16 gradient may differ)
-            moved = np.abs(mine - before[k[6:]].cpu().numpy()).max()
-            assert 0.5e-3 < moved < 1.5e-3, (k, moved)
+    # the update itself: AdamW on the unscaled gradients.  A FIRST AdamW step moves a weight by -lr g / (|g| + eps) (+ lr wd w): every
+    # element whose gradient is clear of zero moves by -lr sign(g).  So the check is the SIGN PATTERN of the update on the elements
+    # whose reference gradient exceeds what half precision can blur (the fp16 reference's own distance from fp32 on that tensor, plus
+    # the slack granted to our gradients above), and there |delta_mine - delta_ref| against lr; elements with a near-zero gradient
+    # (either sign is legitimate) are exempt.  (Round 3 bounded |after_mine - after_ref| by 2.5e-3 at lr 1e-3: it could not fail.)
+    lr, checked, total = 1e-3, 0, 0
+    for k in g.files:
+        if not k.startswith("after."):
+            continue
+        name = k[6:]
+        b4 = before[name].cpu().numpy().astype(np.float64)
+        d_mine = named[name].detach().cpu().numpy().astype(np.float64) - b4
+        d_ref = g[k].astype(np.float64) - b4
+        moved = np.abs(d_mine).max()
+        assert 0.5 * lr < moved < 1.5 * lr, (k, moved)
+        total += d_ref.size
+        gk = "grad." + name
+        if gk not in g.files:
+            continue
+        ref16 = g[gk].astype(np.float64)
+        scale = max(1e-9, np.abs(ref16).max())
+        blur = (np.abs(ref16 - f32[gk].astype(np.float64)).max() if gk in f32.files else 2e-3 * scale) + 0.06 * scale
+        clear = np.abs(ref16) > 2.0 * blur
+        if not clear.any():
+            continue
+        checked += int(clear.sum())
+        assert np.array_equal(np.sign(d_mine[clear]), np.sign(d_ref[clear])), (k, "update sign pattern differs")
+        assert np.array_equal(np.sign(d_ref[clear]), -np.sign(ref16[clear])), k          # (the reference itself: -lr sign(g))
+        assert np.abs(d_mine[clear] - d_ref[clear]).max() < 0.02 * lr, (k, np.abs(d_mine[clear] - d_ref[clear]).max())
+    assert checked > 0.05 * total, (checked, total)            # the exemption must not swallow the test
     # overflow: an inf in the scaled gradients skips the update and halves the scale; the optimizer's step count stays
     snap = step.flat.data.clone()
     xb = dict(x, pitch=x["pitch"].clone())
