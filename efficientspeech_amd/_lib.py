@@ -48,7 +48,7 @@ class PredictorWeights(C.Structure):
 
 
 class DecoderHead(C.Structure):
-    _fields_ = [("proj_wp", fp), ("proj_b", fp), ("ln_g", fp), ("ln_b", fp), ("d4", C.c_int), ("dx2", C.c_int)]
+    _fields_ = [("proj_wp", fp), ("proj_b", fp), ("ln_g", fp), ("ln_b", fp), ("d4", C.c_int), ("dx2", C.c_int), ("proj_w", fp)]
 
 
 class DecoderWeights(C.Structure):
@@ -136,7 +136,7 @@ def launch_plan(mask):
 
 EXPORTS = (
     "esmi_version", "esmi_backend", "esmi_build_config", "esmi_fuse_variance_adaptor_workspace_bytes",
-    "esmi_fuse_variance_adaptor_f32", "esmi_pack_conv_weight_f32", "esmi_pack_convT_weight_f32",
+    "esmi_fuse_variance_adaptor_f32", "esmi_decoder_head_f32", "esmi_pack_conv_weight_f32", "esmi_pack_convT_weight_f32",
     "esmi_encoder_block_workspace_bytes", "esmi_encoder_block_f32", "esmi_pool_mask_u8",
     "esmi_fuse_workspace_bytes", "esmi_fuse_f32", "esmi_variance_adaptor_workspace_bytes",
     "esmi_variance_adaptor_f32", "esmi_length_regulate_i32", "esmi_length_regulator_indices_i32",
@@ -187,6 +187,7 @@ def bind(lib):
     lib.esmi_fuse_variance_adaptor_workspace_bytes.restype = sz
     lib.esmi_fuse_variance_adaptor_f32.argtypes = [P(FuseWeights), i, i, i, i, i, P(fp), P(i)] + [P(PredictorWeights)] * 3 + \
         [fp] * 13 + [P(DecoderHead), fp, i] + [fp, sz, fp]
+    lib.esmi_decoder_head_f32.argtypes = [P(DecoderHead), C.c_long, fp, fp, fp]
     lib.esmi_max_i32.argtypes = [fp, i, fp, fp]
     lib.esmi_length_regulate_i32.argtypes = [fp, i, i, fp, fp, fp, fp]
     lib.esmi_length_regulator_indices_i32.argtypes = [fp, i, i, i, fp, fp]

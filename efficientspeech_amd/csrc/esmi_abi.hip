@@ -22,6 +22,11 @@ bool fuse_va_chain_ok(const esmi_fuse_weights* fw, int depth, int dim, int kerne
 bool fuse_va_head_ok(bool chain, int dim, const esmi_decoder_head* head) {
     return chain && head && head->proj_wp && dim == 32 && head->d4 == 128 && head->dx2 == 128;
 }
+// ... or can the stage run as its own phoneme-rate GEMM launch (esmi_decoder_head_f32) behind the variance adaptor?
+bool head_gemm_ok(const esmi_decoder_head* head) {
+    return head && head->proj_w && head->proj_b && head->ln_g && head->ln_b && head->d4 > 0 && (head->d4 & 7) == 0 &&
+           (head->dx2 == 32 || head->dx2 == 64 || head->dx2 == 128 || head->dx2 == 256);
+}
 
 struct EncWs {
     size_t t_merge, qkv, ctx, y1, m1, m2, pmask, total;
@@ -333,12 +338,13 @@ int esmi_fuse_variance_adaptor_f32(const esmi_fuse_weights* fw, int depth, int d
                                    int32_t* cum, int32_t* mel_len, const esmi_decoder_head* head, float* h0, int plan,
                                    void* workspace, size_t workspace_bytes, esmi_stream_t stream) {
     if ((cum == nullptr) != (mel_len == nullptr)) return ESMI_ERR_ARG;
-    if (h0 && (!head || !head->proj_wp || !head->proj_b || !head->ln_g || !head->ln_b)) return ESMI_ERR_ARG;
+    if (h0 && (!head || (!head->proj_wp && !head->proj_w) || !head->proj_b || !head->ln_g || !head->ln_b)) return ESMI_ERR_ARG;
     if (!fw || !feats || !n_i || !pitch || !energy || !duration || !feat || !pitch_pred || !energy_pred ||
         !duration_pred || !dur || depth < 1 || depth > ESMI_MAX_DEPTH)
         return ESMI_ERR_ARG;
     const bool chain = fuse_va_chain_ok(fw, depth, dim, kernel, n_i[0], T, pitch, energy, duration, plan);
-    if (h0 && !fuse_va_head_ok(chain, dim, head)) return ESMI_ERR_UNSUPPORTED;
+    const bool head_in_chain = h0 && fuse_va_head_ok(chain, dim, head);
+    if (h0 && !head_in_chain && !(head_gemm_ok(head) && head->d4 == 4 * dim)) return ESMI_ERR_UNSUPPORTED;
     for (int i = 1; i < depth && chain; ++i)
         if ((n_i[i] - 1) * (1 << i) + kernel < T) return ESMI_ERR_UNSUPPORTED;   // torch.cat would raise in the reference
     if (chain) {
@@ -365,9 +371,10 @@ int esmi_fuse_variance_adaptor_f32(const esmi_fuse_weights* fw, int depth, int d
         fuse_va_plan(T, dim, depth, &nw, &p.wgs_per_b, &p.useful, &p.halo);
         const bool scan_fused = cum && p.halo == 0;   // one workgroup sees every duration of its utterance
         p.cum = scan_fused ? cum : nullptr; p.mel_len = scan_fused ? mel_len : nullptr;
-        if (h0) { p.head_w = head->proj_wp; p.head_b = head->proj_b; p.head_g = head->ln_g; p.head_beta = head->ln_b; p.h0 = h0; }
-        if (int rc = launch_enc_fuse_va(p, dim, kernel, nw, h0 != nullptr, S(stream))) return rc;
+        if (head_in_chain) { p.head_w = head->proj_wp; p.head_b = head->proj_b; p.head_g = head->ln_g; p.head_beta = head->ln_b; p.h0 = h0; }
+        if (int rc = launch_enc_fuse_va(p, dim, kernel, nw, head_in_chain, S(stream))) return rc;
         if (cum && !scan_fused) ESMI_LAUNCH(length_regulate_kernel, dim3(B), dim3(64), 0, S(stream), dur, T, cum, mel_len, (int*)nullptr);
+        if (h0 && !head_in_chain) return esmi_decoder_head_f32(head, (long)B * T, feat, h0, stream);
         return launch_status();
     }
     if (!workspace || workspace_bytes < esmi_fuse_variance_adaptor_workspace_bytes(B, T, dim, depth)) return ESMI_ERR_WORKSPACE;
@@ -377,9 +384,21 @@ int esmi_fuse_variance_adaptor_f32(const esmi_fuse_weights* fw, int depth, int d
     rc = esmi_variance_adaptor_f32(pitch, energy, duration, dim, B, T, mask, pitch_target, energy_target,
                                    duration_target, feat, pitch_pred, energy_pred, duration_pred, pitch_idx, energy_idx,
                                    dur, static_cast<char*>(workspace) + fws, workspace_bytes - fws, stream);
-    if (rc || !cum) return rc;
-    ESMI_LAUNCH(length_regulate_kernel, dim3(B), dim3(64), 0, S(stream), dur, T, cum, mel_len, (int*)nullptr);
+    if (rc) return rc;
+    if (cum) ESMI_LAUNCH(length_regulate_kernel, dim3(B), dim3(64), 0, S(stream), dur, T, cum, mel_len, (int*)nullptr);
+    if (h0) return esmi_decoder_head_f32(head, (long)B * T, feat, h0, stream);
     return launch_status();
+}
+
+// MelDecoder's first stage at phoneme rate as one launch: GEMM (k = 1) + bias + tanh + LayerNorm in the epilogue (networks.py:291-293)
+int esmi_decoder_head_f32(const esmi_decoder_head* head, long rows, const float* feat, float* h0, esmi_stream_t stream) {
+    if (!head_gemm_ok(head) || !feat || !h0 || rows <= 0 || rows > 0x7fffffffL) return head_gemm_ok(head) ? ESMI_ERR_ARG : ESMI_ERR_UNSUPPORTED;
+    ConvGemmP p = conv_defaults();
+    p.B = 1; p.n_in = p.n_out = (int)rows; p.c_in = head->d4; p.c_out = head->dx2;
+    p.A = feat; p.lda = head->d4; p.W = head->proj_w; p.bias = head->proj_b; p.act = ACT_TANH;
+    p.ln_g = head->ln_g; p.ln_b = head->ln_b; p.out = h0; p.ldo = head->dx2;
+    p.Wp = head->proj_wp;            // (optional) pre-split fragments: the LDS-staged kernel then brings the weight tiles in by LDS-DMA
+    return launch_convgemm(p, S(stream));
 }
 
 float esmi_split_weight_limit(void) {
@@ -706,7 +725,7 @@ int fwd_arena(const esmi_forward_args* a, FwdArena* o) {
     for (int q = 0; q < 2; ++q) { o->idx[q] = off; off += align256(rows * 4); }
     o->dur = off; off += align256(rows * 4);
     o->cum = off; off += align256(rows * 4);
-    o->h0 = off; off += a->head.proj_wp ? align256(rows * a->head.dx2 * 4) : 0;
+    o->h0 = off; off += (a->head.proj_wp || a->head.proj_w) ? align256(rows * a->head.dx2 * 4) : 0;
     o->total = off;
     return ESMI_OK;
 }
@@ -752,7 +771,7 @@ static int forward_impl(const esmi_forward_args* a, int stage, esmi_stream_t str
     const int B = a->B, T = a->T, plan = a->plan & ESMI_FUSE_ALL;
     float* feat = F(o.feat);
     int32_t* cum = a->cum ? a->cum : I(o.cum);
-    float* h0 = a->head.proj_wp ? F(o.h0) : nullptr;
+    float* h0 = (a->head.proj_wp || a->head.proj_w) ? F(o.h0) : nullptr;
     const uint8_t* mask = a->mask;
     if (stage != 2) {
         const float* x_in = nullptr;
@@ -781,7 +800,8 @@ static int forward_impl(const esmi_forward_args* a, int stage, esmi_stream_t str
         int32_t* dur = a->dur ? a->dur : I(o.dur);
         const size_t wsb = esmi_fuse_variance_adaptor_workspace_bytes(B, T, a->dim, a->depth);
         const bool head_ok = fuse_va_head_ok(fuse_va_chain_ok(&a->fuse, a->depth, a->dim, a->fuse_kernel, o.n[0], T, &a->pitch, &a->energy,
-                                                              &a->duration, plan), a->dim, &a->head);
+                                                              &a->duration, plan), a->dim, &a->head) ||
+                             (head_gemm_ok(&a->head) && a->head.d4 == 4 * a->dim && a->head.dx2 == a->dec_shape.dx2);
         rc = esmi_fuse_variance_adaptor_f32(&a->fuse, a->depth, a->dim, a->fuse_kernel, B, T, feats, o.n, &a->pitch, &a->energy,
                                             &a->duration, mask, nullptr, nullptr, a->dur_forced, feat, pp, ep, a->duration_pred,
                                             pi, ei, dur, cum, a->mel_len, head_ok ? &a->head : nullptr, head_ok ? h0 : nullptr, plan,
@@ -794,7 +814,8 @@ static int forward_impl(const esmi_forward_args* a, int stage, esmi_stream_t str
         if (!a->mel || !a->dec_blob) return ESMI_ERR_ARG;
         // (a stage-2 call re-derives whether stage 1 produced the phoneme-rate head: the same static test)
         const bool head_ok = fuse_va_head_ok(fuse_va_chain_ok(&a->fuse, a->depth, a->dim, a->fuse_kernel, o.n[0], T, &a->pitch, &a->energy,
-                                                              &a->duration, plan), a->dim, &a->head);
+                                                              &a->duration, plan), a->dim, &a->head) ||
+                             (head_gemm_ok(&a->head) && a->head.d4 == 4 * a->dim && a->head.dx2 == a->dec_shape.dx2);
         rc = esmi_mel_decoder_f32(a->dec_blob, &a->dec_shape, feat, head_ok ? h0 : nullptr, cum, a->mel_len,
                                   a->lmax_host < 0 ? a->lmax_dev : nullptr, a->lmax_host, mask != nullptr && B > 1, B, T, a->L_out,
                                   a->mel, stream);

@@ -573,14 +573,18 @@ class MelDecoder(_PackedModule):
         return mel
 
     def _head(self, lib, stream):
-        """The decoder's first stage (proj Linear + Tanh + LN) as the fused variance-adaptor kernel takes it: it is
-        row-wise, so it runs once per PHONEME there and the decoder only gathers.  None when the shape is not served."""
-        if self.dim_x4 != 128 or self.dim_x2 != 128:
+        """The decoder's first stage (proj Linear + Tanh + LN) for the encoder side: it is row-wise, so it runs once per
+        PHONEME there -- inside the fused variance-adaptor kernel (tiny ES: `proj_wp`) or as one GEMM launch behind it (every
+        other size: `proj_w`) -- and the decoder only gathers.  None when the width is not one the GEMM's LayerNorm epilogue serves."""
+        if self.dim_x2 not in (32, 64, 128, 256):
             return None
+        if os.environ.get("ESMI_HEAD_GEMM", "1") == "0" and not (self.dim_x4 == 128 and self.dim_x2 == 128):
+            return None                      # (development A/B: the decoder runs its first stage itself, at frame rate)
 
         def build():
-            t = dict(proj_wp=_pack_bfrag(lib, stream, self.proj[0].weight), proj_b=_f32(self.proj[0].bias),
-                     ln_g=_f32(self.proj[2].weight), ln_b=_f32(self.proj[2].bias))
+            t = dict(proj_b=_f32(self.proj[0].bias), ln_g=_f32(self.proj[2].weight), ln_b=_f32(self.proj[2].bias),
+                     proj_w=_f32(self.proj[0].weight))
+            t["proj_wp"] = _pack_bfrag(lib, stream, self.proj[0].weight)     # (the chain kernel's operand order = the GEMM's pre-split form)
             return _lib.DecoderHead(d4=self.dim_x4, dx2=self.dim_x2, **{k: _ptr(v) for k, v in t.items()}), list(t.values())
         return self._head_cache.get(lambda: list(self.proj.parameters()), build)
 

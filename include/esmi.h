@@ -32,7 +32,8 @@
 extern "C" {
 #endif
 
-#define ESMI_VERSION 300 /* 0.3.0: training entry points changed shape (esmi_conv_desc: act / packed_fwd / packed_grad; LayerNorm with
+#define ESMI_VERSION 400 /* 0.4.0: esmi_decoder_head.proj_w (the decoder's first stage at phoneme rate for every model size:
+                          * esmi_decoder_head_f32).  0.3.0: training entry points changed shape (esmi_conv_desc: act / packed_fwd / packed_grad; LayerNorm with
                           * residual / row mask / activation arguments; esmi_train_loss_args.grad_seed; esmi_train_pack_weights_f32,
                           * esmi_train_cat_f32, esmi_reduce_queue); activation-range flag.  0.2.0: launch plan per call (no
                           * process-global state), module-level entry points, weight range guard */
@@ -219,7 +220,14 @@ typedef struct esmi_decoder_head {
     const float* ln_g;      /* decoder.proj.2.{weight,bias} */
     const float* ln_b;
     int d4, dx2;
+    const float* proj_w;    /* decoder.proj.0.weight itself (dx2, 4*dim), or NULL: lets shapes the fused kernel does not serve (small /
+                             * base ES, long sequences) run the stage as ONE phoneme-rate GEMM launch (esmi_decoder_head_f32)           */
 } esmi_decoder_head;
+
+/* h0 = LayerNorm(tanh(Linear(4*dim, dx2)(feat))) -- MelDecoder's first stage (layers/networks.py:291-293: proj = Linear + Tanh,
+ * then LayerNorm) on `rows` rows of phoneme-rate features (rows, 4*dim) -> (rows, dx2).  One GEMM launch with the activation and the
+ * LayerNorm in its epilogue; dx2 must be 32, 64, 128 or 256 (one output row per wave).  Needs head->proj_w.                       */
+int esmi_decoder_head_f32(const esmi_decoder_head* head, long rows, const float* feat, float* h0, esmi_stream_t stream);
 
 size_t esmi_fuse_variance_adaptor_workspace_bytes(int B, int T, int dim, int depth);
 int esmi_fuse_variance_adaptor_f32(const esmi_fuse_weights* fuse, int depth, int dim, int kernel, int B, int T,
@@ -229,9 +237,10 @@ int esmi_fuse_variance_adaptor_f32(const esmi_fuse_weights* fuse, int depth, int
                                    const int32_t* duration_target, float* feat, float* pitch_pred, float* energy_pred,
                                    float* duration_pred, int32_t* pitch_idx, int32_t* energy_idx, int32_t* dur,
                                    int32_t* cum, int32_t* mel_len, /* (B,T), (B) or NULL, NULL                  */
-                                   const esmi_decoder_head* head, float* h0, /* (B,T,dx2) or NULL, NULL; returns
-                                      ESMI_ERR_UNSUPPORTED (nothing launched) when h0 is requested for a shape the
-                                      fused kernel cannot serve: call again without it                            */
+                                   const esmi_decoder_head* head, float* h0, /* (B,T,dx2) or NULL, NULL: computed inside
+                                      the fused kernel when it serves the shape (dim 32), else by one more launch
+                                      (esmi_decoder_head_f32; needs head->proj_w -- without it ESMI_ERR_UNSUPPORTED,
+                                      nothing launched: call again without h0)                                     */
                                    int plan,                                 /* ESMI_FUSE_* bits of this call     */
                                    void* workspace, size_t workspace_bytes, esmi_stream_t stream);
 

@@ -184,6 +184,37 @@ def check_submodule_forwards(net, cfg, sd, device, seed=3):
     assert net.encoder.duration_decoder.get_embedding(None, None, None) is None
 
 
+def check_decoder_head(net, cfg, device, seed=11):
+    """MelDecoder's first stage at PHONEME rate (esmi_decoder_head_f32: GEMM + tanh + LayerNorm in one launch) against plain torch
+    fp32 on the same weights, and the decoder fed with it (h0) against the decoder running the stage itself at frame rate."""
+    import ctypes as C
+    from efficientspeech_amd import networks
+    dec = net.decoder
+    rng = np.random.default_rng(seed)
+    B, T, D = 3, 21, 4
+    feat = torch.from_numpy(rng.standard_normal((B, T, cfg.d4)).astype(np.float32)).to(device)
+    lib, stream = networks._runtime(feat)
+    head = dec._head(lib, stream)
+    assert head is not None and head[0].proj_w
+    h0 = torch.empty((B, T, cfg.dx2), dtype=torch.float32, device=device)
+    lib.esmi_decoder_head_f32(C.byref(head[0]), B * T, feat.data_ptr(), h0.data_ptr(), stream)
+    with torch.no_grad():
+        ref = torch.nn.functional.layer_norm(torch.tanh(torch.nn.functional.linear(feat.cpu(), dec.proj[0].weight.cpu(), dec.proj[0].bias.cpu())),
+                                             (cfg.dx2,), dec.proj[2].weight.cpu(), dec.proj[2].bias.cpu(), 1e-5)
+        err = float((h0.cpu() - ref).abs().max())
+        assert err < 2e-5, err
+        # the decoder gathering h0 == the decoder computing its first stage per frame (ragged lengths: padding frames, the final mask)
+        dur = torch.from_numpy(rng.integers(0, D + 3, size=(B, T)).astype(np.int32)).to(device)
+        dur[1, 15:] = 0
+        cum = torch.cumsum(dur, 1).to(torch.int32).contiguous()
+        mel_len = cum[:, -1].contiguous()
+        L = int(mel_len.max())
+        a = dec._fused(feat, cum, mel_len, None, L, True, L, h0=h0)
+        b = dec._fused(feat, cum, mel_len, None, L, True, L, h0=None)
+        d = float((a - b).abs().max())
+        assert d < 2e-5, d
+
+
 def check_wrapper_and_scheduler(device):
     """model.py-shaped wrapper (`.phoneme2mel`, `.hifigan`, `model(x)`, `predict_step`, Lightning-dict load; model.py:155-164,
     demo.py:66-67) on a padded B > 1 batch and a B == 1 call, and the length-bucketed scheduler, against the oracle."""

@@ -449,6 +449,14 @@ def test_submodule_forwards(name, nets):
     H.check_submodule_forwards(net, cfg, sd, DEV)
 
 
+@pytest.mark.parametrize("name", ["tiny", "small", "base"])
+def test_decoder_head_at_phoneme_rate(name, nets):
+    """esmi_decoder_head_f32 vs torch fp32, and the h0-gathering decoder vs the decoder that runs its first stage per frame
+    (dx2 = 128 and 256)."""
+    net, cfg, sd = nets(name)
+    H.check_decoder_head(net, cfg, DEV)
+
+
 def test_split_range_guard_and_encoder_operand_scales():
     """(1) a weight outside the split-f16 range is refused at pack time; (2) encoder-side operands far from O(1): embedding
     rows x 40 (the un-normalised conv output that feeds qkv grows with them), merge / qkv / MixFFN weights x 0.05 .. x 6."""

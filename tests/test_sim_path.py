@@ -248,6 +248,13 @@ def test_simulated_submodule_forwards(name, nets):
         H.check_submodule_forwards(net, cfg, sd, "cpu")
 
 
+@pytest.mark.parametrize("name", ["small", "base"])
+def test_simulated_decoder_head_at_phoneme_rate(name, nets):
+    net, cfg, sd = nets(name)
+    with use_sim():
+        H.check_decoder_head(net, cfg, "cpu")
+
+
 def test_simulated_split_range_guard(nets):
     """A weight outside the split-f16 operand range is refused at pack time (ValueError naming the fp32 build), not
     silently turned into inf."""
