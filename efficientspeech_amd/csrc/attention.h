@@ -17,7 +17,12 @@
 namespace esmi {
 
 struct AttnP {
-    const float* qkv;  // (B, N, 3, h, C)
+    const float* qkv;  // (B, N, 3, h, C), or NULL with q / k / v given
+    // the three operands on their own (launch_attn derives them from `qkv` when q is NULL): row b*N + n of head hd starts at
+    // ptr + (b*N + n) * ld + hd * hs.  hs = 0 shares one tensor between the heads -- the weight-folded attention of the per-op
+    // encoder plan has q = x (Wq_h^T Wk_h) per head and k = v = x for every head (esmi_encoder_block_weights.qk_w)
+    const float *q, *k, *v;
+    int ldq, ldk, ldv, hsq, hsk, hsv;
     int B, N, C, h;
     float scale;
     float* ctx;  // (B, N, h*C), head-major channels (blocks.py:64 transpose(1,2).reshape)
@@ -35,24 +40,23 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnP p) {
     const int hd = rem / qtiles;
     const int q0 = (rem - hd * qtiles) << 5;
     const int i = lane & 31, h2 = lane >> 5;
-    const int ld = 3 * p.h * p.C;
-    const float* base = p.qkv + (long)b * p.N * ld;
-    const float* qb = base + 0 * p.h * p.C + hd * p.C;
-    const float* kb = base + 1 * p.h * p.C + hd * p.C;
-    const float* vb = base + 2 * p.h * p.C + hd * p.C;
+    const int ldq = p.ldq, ldk = p.ldk, ldv = p.ldv;
+    const float* qb = p.q + (long)b * p.N * ldq + hd * p.hsq;
+    const float* kb = p.k + (long)b * p.N * ldk + hd * p.hsk;
+    const float* vb = p.v + (long)b * p.N * ldv + hd * p.hsv;
 
     // ---- S^T[key][query] = sum_c K[key][c] Q[query][c]
     f32x16 s[NKT];
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt) s[kt] = zero16();
     const bool qok = q0 + i < p.N;
-    const float* qrow = qb + (long)(qok ? q0 + i : 0) * ld;
+    const float* qrow = qb + (long)(qok ? q0 + i : 0) * ldq;
     const float* krow[NKT];
     bool kok[NKT];
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt) {
         kok[kt] = 32 * kt + i < p.N;
-        krow[kt] = kb + (long)(kok[kt] ? 32 * kt + i : 0) * ld;
+        krow[kt] = kb + (long)(kok[kt] ? 32 * kt + i : 0) * ldk;
     }
 #if ESMI_CHAIN_SPLIT
     // split-f16x2 products (esmi_dev.h): both operands are activations, split on the fly into two binary16 pieces (no 2^8 scale:
@@ -151,7 +155,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnP p) {
                 for (int rr = 0; rr < 8; ++rr) {
                     const int key = 32 * kt + tile_row(r8 + rr, lane);
                     const bool vok = key < p.N;
-                    const float* vrow = vb + (long)(vok ? key : 0) * ld + c0 + i;
+                    const float* vrow = vb + (long)(vok ? key : 0) * ldv + c0 + i;
 #pragma unroll
                     for (int nt = 0; nt < 4; ++nt) vv[rr][nt] = (vok && c0 + 32 * nt + i < p.C) ? vrow[32 * nt] : 0.0f;
                 }
@@ -174,7 +178,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnP p) {
                 for (int rr = 0; rr < 4; ++rr) {
                     const int key = 32 * kt + tile_row(r4 + rr, lane);  // differs between the half waves: that IS the k index
                     const bool vok = key < p.N;
-                    const float* vrow = vb + (long)(vok ? key : 0) * ld + c0 + i;
+                    const float* vrow = vb + (long)(vok ? key : 0) * ldv + c0 + i;
 #pragma unroll
                     for (int nt = 0; nt < 4; ++nt) vv[rr][nt] = (vok && c0 + 32 * nt + i < p.C) ? vrow[32 * nt] : 0.0f;
                 }
@@ -215,13 +219,12 @@ __global__ __launch_bounds__(256) void attn_long_kernel(const AttnP p) {
     const int hd = rem / qtiles;
     const int q0 = (rem - hd * qtiles) << 5;
     const int i = lane & 31, h2 = lane >> 5;
-    const int ld = 3 * p.h * p.C;
-    const float* base = p.qkv + (long)b * p.N * ld;
-    const float* qb = base + 0 * p.h * p.C + hd * p.C;
-    const float* kb = base + 1 * p.h * p.C + hd * p.C;
-    const float* vb = base + 2 * p.h * p.C + hd * p.C;
+    const int ldq = p.ldq, ldk = p.ldk, ldv = p.ldv;
+    const float* qb = p.q + (long)b * p.N * ldq + hd * p.hsq;
+    const float* kb = p.k + (long)b * p.N * ldk + hd * p.hsk;
+    const float* vb = p.v + (long)b * p.N * ldv + hd * p.hsv;
     const bool qok = q0 + i < p.N;
-    const float* qrow = qb + (long)(qok ? q0 + i : 0) * ld;
+    const float* qrow = qb + (long)(qok ? q0 + i : 0) * ldq;
 
     f32x16 s[NKT];
     // scores of key chunk [k0, k0 + 128) for this lane's query, scaled; keys >= N -> -inf
@@ -233,7 +236,7 @@ __global__ __launch_bounds__(256) void attn_long_kernel(const AttnP p) {
 #pragma unroll
         for (int kt = 0; kt < NKT; ++kt) {
             kok[kt] = k0 + 32 * kt + i < p.N;
-            krow[kt] = kb + (long)(kok[kt] ? k0 + 32 * kt + i : 0) * ld;
+            krow[kt] = kb + (long)(kok[kt] ? k0 + 32 * kt + i : 0) * ldk;
         }
         for (int kc = 0; kc < (p.C >> 3); kc += 4) {
             f32x4 qv[4], kv[4][NKT];
@@ -305,7 +308,7 @@ __global__ __launch_bounds__(256) void attn_long_kernel(const AttnP p) {
                 for (int rr = 0; rr < 4; ++rr) {
                     const int key = k0 + 32 * kt + tile_row(r4 + rr, lane);
                     const bool vok = key < p.N;
-                    const float* vrow = vb + (long)(vok ? key : 0) * ld + i;
+                    const float* vrow = vb + (long)(vok ? key : 0) * ldv + i;
 #pragma unroll
                     for (int nt = 0; nt < NC; ++nt) vv[rr][nt] = vok ? vrow[32 * nt] : 0.0f;
                 }
@@ -351,11 +354,10 @@ __global__ __launch_bounds__(64 * NKT, 2) void attn_lds_kernel(const AttnP p) {
     const int lane = lane_id(), w = wave_id(), tid = (int)threadIdx.x;
     const int hd = (int)blockIdx.x % p.h, b = (int)blockIdx.x / p.h;
     const int i = lane & 31, h2 = lane >> 5, q0 = 32 * w;
-    const int ld = 3 * p.h * p.C, C = p.C, CK = C < 128 ? C : 128;
-    const float* base = p.qkv + (long)b * p.N * ld;
-    const float* qb = base + 0 * p.h * C + hd * C;
-    const float* kb = base + 1 * p.h * C + hd * C;
-    const float* vb = base + 2 * p.h * C + hd * C;
+    const int ldq = p.ldq, ldk = p.ldk, ldv = p.ldv, C = p.C, CK = C < 128 ? C : 128;
+    const float* qb = p.q + (long)b * p.N * ldq + hd * p.hsq;
+    const float* kb = p.k + (long)b * p.N * ldk + hd * p.hsk;
+    const float* vb = p.v + (long)b * p.N * ldv + hd * p.hsv;
     const int krs = 2 * CK + 16, kplane = NK * krs;           // K planes: [2][NK][krs bytes], CK channels per pass
     const int vrs = 2 * NK + 16, vplane = CK * vrs;           // Vt planes: [2][CK][vrs bytes]
 
@@ -364,12 +366,12 @@ __global__ __launch_bounds__(64 * NKT, 2) void attn_lds_kernel(const AttnP p) {
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt) s[kt] = zero16();
     const bool qok = q0 + i < p.N;
-    const float* qrow = qb + (long)(qok ? q0 + i : 0) * ld;
+    const float* qrow = qb + (long)(qok ? q0 + i : 0) * ldq;
     for (int cp = 0; cp < C; cp += CK) {
         if (cp) __syncthreads();                           // the previous pass's fragments have been read
         for (int e = tid; e < NK * (CK >> 2); e += NTHR) {
             const int key = e / (CK >> 2), c = (e - key * (CK >> 2)) << 2;
-            const f32x4 v = key < p.N ? ld4(kb + (long)key * ld + cp + c) : zero4();
+            const f32x4 v = key < p.N ? ld4(kb + (long)key * ldk + cp + c) : zero4();
             unsigned h1a, h2a, h1b, h2b;
             split_f16_pair(v[0], v[1], h1a, h2a);
             split_f16_pair(v[2], v[3], h1b, h2b);
@@ -433,7 +435,7 @@ __global__ __launch_bounds__(64 * NKT, 2) void attn_lds_kernel(const AttnP p) {
             const int slot0 = 32 * kt + 16 * (q >> 1) + 8 * hh + 4 * (q & 1);
             f32x4 v[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = key0 + r < p.N ? ld4(vb + (long)(key0 + r) * ld + c0 + c) : zero4();
+            for (int r = 0; r < 4; ++r) v[r] = key0 + r < p.N ? ld4(vb + (long)(key0 + r) * ldv + c0 + c) : zero4();
 #pragma unroll
             for (int cc = 0; cc < 4; ++cc) {
                 unsigned h1a, h2a, h1b, h2b;

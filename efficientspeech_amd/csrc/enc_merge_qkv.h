@@ -24,7 +24,8 @@ struct EncMergeP {
     const float* merge_w;  // (k, C, Cin) composed merge conv  } both in MFMA B-fragment order
     const float* qkv_w;    // (3*h*C, C)                        } (esmi_pack_bfrag_f32, see wave_chain.h)
     float* x_out;          // (B, n_out, C)
-    float* qkv;            // (B, n_out, 3*h*C)
+    float* qkv;            // (B, n_out, 3*h*C)  [nq_override > 0: (B, n_out, nq_override), with qkv_w (nq_override, C)]
+    int nq_override;       // 0, or the width of the Linear behind the merge convs when it is not the reference's qkv (folded attention: h*C)
     int tiles_per_b;       // ceil(n_out / 32)
 };
 
@@ -118,7 +119,7 @@ __global__ __launch_bounds__(64, ESMI_E1_WPS) void enc_merge_qkv_kernel(const En
     const float* a_row = buf + i * LD + 4 * h2;
     f32x16 x[NC];
     merge_conv_tile<NCI, NC, KT, STRIDE>(p, b, t0, buf, lane, x);
-    const int nq = 3 * p.h * C, ntq = nq >> 5;
+    const int nq = p.nq_override > 0 ? p.nq_override : 3 * p.h * C, ntq = nq >> 5;
     WaveGrp<4> gq;
     wave_prefetch<4>(gq, p.qkv_w, ntq, 0, 0, lane);
     ESMI_CT();

@@ -154,11 +154,15 @@ int esmi_encoder_block_f32(const esmi_encoder_block_weights* w, const esmi_encod
     const bool packed = w->merge_cwp && w->qkv_wp && w->proj_wp && w->mlp1_wp && w->conv_wp && w->mlp2_wp;
     const bool fused2 = packed && (plan & ESMI_FUSE_ATTN_FFN) && enc_attn_ffn_supported(C, n, s->expansion);
     float* x_mid = fused2 ? y1 : x_out;
+    // one-kernel-per-op attention with folded weights (esmi.h): the Linear behind the merge convs is x M (h*C wide) instead of qkv
+    const bool folded = !fused2 && w->qk_w && w->qk_wp && w->vo_w && w->vo_wp;
+    const int nq = folded ? h * C : 3 * h * C;
     EncMergeP m;
     memset(&m, 0, sizeof m);
     m.ids = ids; m.table = embed; m.vocab = s->vocab; m.x_in = ids ? nullptr : x_in;
     m.B = B; m.n_in = s->n_in; m.n_out = n; m.k = s->kernel; m.stride = s->stride; m.pad = s->kernel / 2; m.h = h;
-    m.merge_w = w->merge_cwp; m.qkv_w = w->qkv_wp; m.x_out = x_mid; m.qkv = qkv;
+    m.merge_w = w->merge_cwp; m.qkv_w = folded ? w->qk_wp : w->qkv_wp; m.x_out = x_mid; m.qkv = qkv;
+    m.nq_override = folded ? nq : 0;
     m.tiles_per_b = (n + 31) / 32;
     EncAttnFfnP f;
     memset(&f, 0, sizeof f);
@@ -195,8 +199,8 @@ int esmi_encoder_block_f32(const esmi_encoder_block_weights* w, const esmi_encod
         if ((rc = launch_convgemm(p, st))) return rc;
         // qkv Linear (bias-free), blocks.py:44
         p = conv_defaults();
-        p.B = B; p.n_in = n; p.c_in = C; p.n_out = n; p.c_out = 3 * h * C;
-        p.A = x_mid; p.lda = C; p.W = w->qkv_w; p.Wp = w->qkv_wp; p.out = qkv; p.ldo = 3 * h * C;
+        p.B = B; p.n_in = n; p.c_in = C; p.n_out = n; p.c_out = nq;
+        p.A = x_mid; p.lda = C; p.W = folded ? w->qk_w : w->qkv_w; p.Wp = folded ? w->qk_wp : w->qkv_wp; p.out = qkv; p.ldo = nq;
         if ((rc = launch_convgemm(p, st))) return rc;
     }
     if (fused2) {   // E2: attention + proj + LN1 + MixFFN + LN2 as one wave-chain kernel
@@ -208,14 +212,20 @@ int esmi_encoder_block_f32(const esmi_encoder_block_weights* w, const esmi_encod
         mask = pm;
     }
     // softmax(q k^T scale) v, blocks.py:49-64
-    AttnP a;
-    a.qkv = qkv; a.B = B; a.N = n; a.C = C; a.h = h; a.ctx = ctx;
+    AttnP a = {};
+    a.B = B; a.N = n; a.C = C; a.h = h; a.ctx = ctx;
     a.scale = 1.0f / sqrtf((float)(C / h));
+    if (folded) {   // q_h = x M_h (the `qkv` buffer, h*C wide); keys = values = x, shared by the heads
+        a.q = qkv; a.ldq = h * C; a.hsq = C;
+        a.k = a.v = x_out; a.ldk = a.ldv = C; a.hsk = a.hsv = 0;
+    } else {
+        a.qkv = qkv;
+    }
     if ((rc = launch_attn(a, st))) return rc;
-    // proj + residual + LN1 + mask, blocks.py:65 + networks.py:73-75
+    // proj + residual + LN1 + mask, blocks.py:65 + networks.py:73-75  (folded: ctx holds P_h x, the matrix is [O_h])
     p = conv_defaults();
     p.B = B; p.n_in = n; p.c_in = h * C; p.n_out = n; p.c_out = C;
-    p.A = ctx; p.lda = h * C; p.W = w->proj_w; p.Wp = w->proj_wp; p.bias = w->proj_b;
+    p.A = ctx; p.lda = h * C; p.W = folded ? w->vo_w : w->proj_w; p.Wp = folded ? w->vo_wp : w->proj_wp; p.bias = w->proj_b;
     p.res = x_out; p.ldr = C; p.ln_g = w->ln1_g; p.ln_b = w->ln1_b; p.rowmask = mask;
     p.out = y1; p.ldo = C;
     if ((rc = launch_convgemm(p, st))) return rc;
@@ -437,7 +447,7 @@ int esmi_self_attention_f32(const float* qkv_w, const float* proj_w, const float
     p.B = B; p.n_in = N; p.c_in = C; p.n_out = N; p.c_out = 3 * heads * C;
     p.A = x; p.lda = C; p.W = qkv_w; p.out = qkv; p.ldo = 3 * heads * C;
     if ((rc = launch_convgemm(p, st))) return rc;
-    AttnP a;                          // softmax(q k^T scale) v, blocks.py:49-64 (scores not masked)
+    AttnP a = {};                     // softmax(q k^T scale) v, blocks.py:49-64 (scores not masked)
     a.qkv = qkv; a.B = B; a.N = N; a.C = C; a.h = heads; a.ctx = ctx;
     a.scale = 1.0f / sqrtf((float)(C / heads));
     if ((rc = launch_attn(a, st))) return rc;

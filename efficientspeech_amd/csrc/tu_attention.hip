@@ -11,7 +11,16 @@ namespace esmi {
 #ifndef ESMI_ATTN_LDS_MIN_HEADS
 #define ESMI_ATTN_LDS_MIN_HEADS kAttnLdsMinHeadsDefault    // (wavesim_shim.h: 128 on the GPU, 1 in the simulator)
 #endif
-int launch_attn(const AttnP& p, hipStream_t st) {
+int launch_attn(const AttnP& p_in, hipStream_t st) {
+    AttnP p = p_in;
+    if (!p.q) {                        // the reference's layout: one (B, N, 3, h, C) tensor
+        if (!p.qkv) return ESMI_ERR_ARG;
+        const int hc = p.h * p.C;
+        p.q = p.qkv; p.k = p.qkv + hc; p.v = p.qkv + 2 * hc;
+        p.ldq = p.ldk = p.ldv = 3 * hc;
+        p.hsq = p.hsk = p.hsv = p.C;
+    }
+    if (!p.k || !p.v || (p.ldq & 3) || (p.ldk & 3) || (p.ldv & 3) || (p.hsq & 3) || (p.hsk & 3) || (p.hsv & 3)) return ESMI_ERR_ARG;
     if ((p.C & 31) || p.N <= 0) return ESMI_ERR_ARG;   // channel groups of 32 (4 k-steps fetched together)
     const int nkt = (p.N + 31) / 32;
     const int tiles = p.B * p.h * nkt;

@@ -276,14 +276,26 @@ class Encoder(_PackedModule):
                          mlp1_w=_f32(ffn.mlp1.weight), mlp1_b=_f32(ffn.mlp1.bias), conv_w=cw,
                          conv_b=_f32(ffn.conv.bias), mlp2_w=_f32(ffn.mlp2.weight), mlp2_b=_f32(ffn.mlp2.bias),
                          ln1_g=_f32(n1.weight), ln1_b=_f32(n1.bias), ln2_g=_f32(n2.weight), ln2_b=_f32(n2.bias))
-                for name in ("qkv_w", "proj_w", "mlp1_w", "conv_w", "mlp2_w"):
+                # weight-folded attention for the one-kernel-per-op plan (include/esmi.h): M_h = Wq_h^T Wk_h, O_h = Wv_h^T Wp_h^T, in fp64
+                hh, cc = attn.num_heads, t["proj_w"].shape[0]
+                wqkv = t["qkv_w"].double().view(3, hh, cc, cc)                       # [s][h][out][in]
+                wp = t["proj_w"].double().view(cc, hh, cc)                            # [out][h][in]
+                t["qk_w"] = torch.einsum("hoj,hoi->hji", wqkv[1], wqkv[0]).reshape(hh * cc, cc).float().contiguous()   # rows [h][j]: sum_o Wk[o][j] Wq[o][i]
+                t["vo_w"] = torch.einsum("ohm,hmi->ohi", wp, wqkv[2]).reshape(cc, hh * cc).float().contiguous()        # [o][h][i]: sum_m Wp[o][h][m] Wv[m][i]
+                for name in ("qkv_w", "proj_w", "mlp1_w", "conv_w", "mlp2_w", "qk_w", "vo_w"):
                     t[name + "p"] = _pack_bfrag(lib, stream, t[name])
+
                 k, cin, co = mw.shape[0], mw.shape[2], merge1.weight.shape[0]
                 comp = torch.empty((k, co, cin), dtype=torch.float32, device=mw.device)   # merge1 o merge as one conv
                 lib.esmi_compose_merge_f32(_ptr(mw), _ptr(t["merge1_w"]), k, cin, co, _ptr(comp), stream)
                 t["merge_cwp"] = _pack_bfrag(lib, stream, comp)
-                _check_split_range(lib, stream, [comp, t["qkv_w"], t["proj_w"], t["mlp1_w"], cw, t["mlp2_w"]],
+                _check_split_range(lib, stream, [comp, t["qkv_w"], t["proj_w"], t["mlp1_w"], cw, t["mlp2_w"], t["qk_w"], t["vo_w"]],
                                    "encoder block weights")
+                # measured (same box, per-op plan): base ES (2 and 4 heads) 9.01 -> 8.48 ms/step; small ES block 0 (ONE head: the
+                # projections shrink 192 -> 64 columns only) 2.22 -> 2.25: folded only where there are heads to share the keys / values
+                if hh < 2 or os.environ.get("ESMI_FOLD_ATTN", "1") == "0":   # (the environment switch: development A/B)
+                    for name in ("qk_w", "qk_wp", "vo_w", "vo_wp"):
+                        del t[name]
                 keep.extend(t.values())
                 out.append((_lib.EncoderBlockWeights(**{k: _ptr(v) for k, v in t.items()}), keep))
             return out, _f32(self.embed.weight)

@@ -121,6 +121,17 @@ typedef struct esmi_encoder_block_weights {
     const float* mlp1_wp;
     const float* conv_wp;
     const float* mlp2_wp;
+    /* Weight-folded attention for the one-kernel-per-op plan (optional; all four or none).  Every head spans the full width C, so
+     *   scores_h = (x Wq_h^T)(x Wk_h^T)^T = (x M_h) x^T          with  M_h = Wq_h^T Wk_h   (C x C)
+     *   out      = sum_h softmax(scores_h) (x Wv_h^T) Wp_h^T + b = sum_h (P_h x) O_h + b   with  O_h = Wv_h^T Wp_h^T (C x C):
+     * ONE projection per head in front of the attention (q_h = x M_h; keys and values are x itself, shared by all heads) and one
+     * behind it instead of q, k, v and proj -- half the projection FLOPs and a third of the activation traffic (3hC -> hC floats per
+     * position).  qk_w (h*C, C): rows [h][:] = M_h^T as a Linear weight; vo_w (C, h*C): columns [h] = O_h^T; *_wp = esmi_pack_bfrag_f32.
+     * Same function up to fp32 rounding of the folded matrices (computed in fp64 by the caller).                                    */
+    const float* qk_w;
+    const float* qk_wp;
+    const float* vo_w;
+    const float* vo_wp;
 } esmi_encoder_block_weights;
 
 typedef struct esmi_encoder_block_shape {
