@@ -828,7 +828,8 @@ static int forward_impl(const esmi_forward_args* a, int stage, esmi_stream_t str
                              (head_gemm_ok(&a->head) && a->head.d4 == 4 * a->dim && a->head.dx2 == a->dec_shape.dx2);
         rc = esmi_mel_decoder_f32(a->dec_blob, &a->dec_shape, feat, head_ok ? h0 : nullptr, cum, a->mel_len,
                                   a->lmax_host < 0 ? a->lmax_dev : nullptr, a->lmax_host, mask != nullptr && B > 1, B, T, a->L_out,
-                                  a->mel, stream);
+                                  a->mel, base + o.ws, o.feat - o.ws,   // (the encoder side's scratch is free again: the decoder's carried rows)
+                                  stream);
         if (rc) return rc;
     }
     return ESMI_OK;

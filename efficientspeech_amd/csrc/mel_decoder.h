@@ -153,8 +153,10 @@ struct MelDecP {
     int apply_mask;
     int B, T, L_out;
     float* mel;            // (B, L_out, n_mel)
-    int halo, TL;
-    int n_tiles;           // windows per utterance
+    int halo;              // rows a window loses per side without carried state: (k/2) * conv layers
+    int seg_len;           // frames per segment (a workgroup's share of an utterance)
+    int n_seg;             // segments per utterance
+    float* carry_ws;       // dx2 = 256 with multi-chunk segments: [workgroup][conv layer][k/2][dx2] floats of scratch, else NULL
     long long* trace;      // development only (-DESMI_DEC_TRACE): [wave][stamp] shader-clock stamps of block (1,0)
 };
 
@@ -210,40 +212,41 @@ __global__ __launch_bounds__(64 * NW, (DX2 <= 128 ? kDecWps128 : NW / 4)) void m
     float* pbuf = lds + (kDecRows + 2 * kDecPadRows) * LDSROW;        // [PB]
     int* src = reinterpret_cast<int*>(pbuf + PB);                     // [128]
 
-    const int tid = (int)threadIdx.x, lane = lane_id(), w = wave_id();
-    const int i = lane & 31, h = lane >> 5;
+    int tid = (int)threadIdx.x, lane = lane_id();       // (re-derived per chunk below: see the chunk loop)
+    const int w = wave_id();
+    int i = lane & 31, h = lane >> 5;
     const int mh = w / NS, ns = w % NS;
     // XCD-aware workgroup -> (utterance, window) map: workgroup id % 8 is the XCD (round-robin dispatch), so the windows
     // of one utterance are given ids that agree mod 8 and its h0 / cum rows are fetched into ONE XCD's L2 instead of eight.
-    int tile, b;
+    int seg, b;
     {
-        const int id = (int)blockIdx.x, per8 = 8 * p.n_tiles;
+        const int id = (int)blockIdx.x, per8 = 8 * p.n_seg;
         const int g = id / per8, r = id - g * per8;
-        tile = r >> 3;
+        seg = r >> 3;
         b = 8 * g + (r & 7);
         if (b >= p.B) return;
     }
     const int L = p.lmax_dev ? *p.lmax_dev : (p.lmax_host >= 0 ? p.lmax_host : batch_max_len(p.mel_len, p.B));
     const int mlen = p.mel_len ? min(p.mel_len[b], L) : L;
-    const int f_lo = tile * p.TL, f0 = f_lo - p.halo;
-    const int out_hi = min(f_lo + p.TL, p.L_out);
     const int valid_end = p.apply_mask ? mlen : L;
-    if (f_lo >= p.L_out) return;
-    if (f_lo >= valid_end) {  // whole window is padding: the final masked_fill (or the [L, L_out) tail) zeroes it
-        const int n = (out_hi - f_lo) * p.n_mel;
-        float* o = p.mel + ((long)b * p.L_out + f_lo) * p.n_mel;
-        for (int e = tid; e < n; e += kDecThreads) o[e] = 0.0f;
-        return;
-    }
+    // The workgroup's segment [s0, s1) of the utterance, walked in chunks of one 128-row tile.  The first chunk of a segment that
+    // does not start the utterance recomputes `halo` rows on its left (nothing to carry in from); every chunk loses `halo` rows on
+    // its right.  STREAM (dx2 = 256): consecutive chunks advance by 128 - halo frames and each conv layer's k/2 input rows in front
+    // of the chunk are CARRIED from the previous chunk (one register per thread and layer) into the tile's top pad rows -- the
+    // left halo is not recomputed: base ES keeps 110 of 128 rows instead of 92.  Without STREAM (dx2 = 128: two workgroups per CU
+    // already balance the chip, and 768 = 7 x 112 leaves nothing to gain) a segment is one chunk.
+    const int s0 = seg * p.seg_len, s1 = min(s0 + p.seg_len, p.L_out);
+    if (s0 >= p.L_out) return;
+    int f0 = 0, f_lo = 0, out_hi = 0;        // this chunk: frame of tile row 0, first / one-past-last frame it stores
     const int n_layers = p.n_blocks * p.block_depth;
     // every read of the packed blob is a buffer load: resource + wave-uniform byte offset in SGPRs, one lane-offset VGPR for all of
     // them (64-bit per-lane pointers into the blob, live across the layer loop, were most of the kernel's register spills)
     const BufRsrc brs = make_rsrc(p.blob, p.lay.total * (long)sizeof(float));
-    const unsigned tid16 = (unsigned)tid * 16u, lane16 = (unsigned)lane * 16u;
+    unsigned tid16 = (unsigned)tid * 16u, lane16 = (unsigned)lane * 16u;
     auto blob_ld = [&](long float_off, unsigned voff) __attribute__((always_inline)) { return buf_ld4s(brs, voff, (unsigned)(float_off * 4)); };
 #ifdef ESMI_DEC_TRACE
     int tr_n = 0;
-    const bool tr_on = p.trace && tile == 3 && b == p.B / 2 + 5 && lane == 0;
+    const bool tr_on = p.trace && seg == (DX2 > 128 ? 0 : 3) && b == p.B / 2 + 5 && lane == 0;
 #define ESMI_STAMP() do { if (tr_on) p.trace[w * 64 + tr_n] = (long long)__builtin_amdgcn_s_memtime(); ++tr_n; } while (0)
 #else
 #define ESMI_STAMP() do {} while (0)
@@ -273,6 +276,51 @@ __global__ __launch_bounds__(64 * NW, (DX2 <= 128 ? kDecWps128 : NW / 4)) void m
     auto commit_A = [&](int) __attribute__((always_inline)) {};
     auto commit_B = [&](int) __attribute__((always_inline)) {};
 
+    constexpr bool STREAM = DX2 > 128;
+    // STREAM: the k/2 input rows of every conv layer in front of the next chunk wait in a global scratch row set of this workgroup
+    // (2 KB per layer; written and read back by the same thread, one chunk apart: no fence needed, and the traffic is nothing)
+    float* const cws = STREAM && p.carry_ws ? p.carry_ws + (long)blockIdx.x * ((long)ESMI_MAX_DEC_LAYERS * PAD * DX2) : nullptr;
+    float cnext = 0.0f;                      // the carried element of the NEXT conv layer, requested one phase ahead
+    const int keep = kDecRows - p.halo;      // tile rows of a chunk that stay valid through every layer (the right halo is lost)
+    bool edge_window = false;
+    unsigned ln_inside = 0;
+    for (int ck = 0;; ++ck) {
+    if constexpr (STREAM) {
+        // the thread indices pass through an opaque move per chunk: otherwise everything derived from them is loop-invariant, LICM
+        // hoists it all out of the chunk loop and the kernel spills (46 VGPRs measured)
+        tid = opaque_i(tid);
+        lane = tid & 63; i = lane & 31; h = lane >> 5;
+        tid16 = (unsigned)tid * 16u; lane16 = (unsigned)lane * 16u;
+    }
+    const int hl = (ck == 0 && s0 > 0) ? p.halo : 0;
+    f0 = s0 + ck * keep - (s0 > 0 ? p.halo : 0);
+    f_lo = f0 + hl;
+    if ((!(STREAM && cws) && ck > 0) || f_lo >= s1) break;
+    out_hi = min(f0 + keep, s1);
+    if (f_lo >= valid_end) {  // the rest of the segment is padding: the final masked_fill (or the [L, L_out) tail) zeroes it
+        const int n = (s1 - f_lo) * p.n_mel;
+        float* o = p.mel + ((long)b * p.L_out + f_lo) * p.n_mel;
+        for (int e = tid; e < n; e += kDecThreads) o[e] = 0.0f;
+        break;
+    }
+    if (ck > 0) __syncthreads();             // the previous chunk's mel stage is done with the parameter slots and the tile
+    // STREAM: conv layer l's PAD input rows in front of this chunk (saved by the previous chunk) are requested with `carry_load`
+    // a phase ahead and written to the tile's top pad rows by `carry_put` at the end of the phase in front of the layer's
+    // depthwise conv; `carry_save` keeps this chunk's rows [keep - PAD, keep) of the same tensor for the next chunk.
+    auto carry_load = [&](int l) __attribute__((always_inline)) {
+        if constexpr (STREAM) cnext = (cws && ck > 0 && tid < PAD * DX2) ? cws[l * (PAD * DX2) + tid] : 0.0f;
+    };
+    auto carry_put = [&]() __attribute__((always_inline)) {
+        if constexpr (STREAM) {
+            if (tid < PAD * DX2) xs[(kDecPadRows - PAD + tid / DX2) * LDSROW + tid % DX2] = cnext;
+        }
+    };
+    auto carry_save = [&](int l) __attribute__((always_inline)) {
+        if constexpr (STREAM) {
+            if (cws && tid < PAD * DX2) cws[l * (PAD * DX2) + tid] = xs[(kDecPadRows + keep - PAD + tid / DX2) * LDSROW + tid % DX2];
+        }
+    };
+
     // ---- phase 0: source row of every window row, zero the LDS pad rows, stage proj + layer-0 params
     if (tid < kDecRows) {
         const int f = f0 + tid;
@@ -293,6 +341,7 @@ __global__ __launch_bounds__(64 * NW, (DX2 <= 128 ? kDecWps128 : NW / 4)) void m
     }
     if (tid < NB4)                                                     // proj_b, proj_g, proj_beta -> group B
         reinterpret_cast<f32x4*>(pbuf + P_PWB)[tid] = blob_ld(p.lay.proj_b, tid16);
+    carry_load(0);
     fetch_A(0);
     commit_A(0);
     __syncthreads();
@@ -304,11 +353,10 @@ __global__ __launch_bounds__(64 * NW, (DX2 <= 128 ? kDecWps128 : NW / 4)) void m
     // 17.8 % of the kernel's LDS cycles were bank conflicts, profiles/r01_l).
     constexpr int LNPER = 16 / RPT;         // waves that share one residue class of rows mod 16
     const int ln_c = lane & (TPR - 1), ln_row0 = 64 * (w / LNPER) + 16 * (lane / TPR) + RPT * (w % LNPER);
-    const bool edge_window = f0 < 0 || f0 + kDecRows > L;   // some window rows lie outside [0, L) (SGPR: a scalar branch)
-    unsigned ln_inside = 0;                 // bit j: row ln_row0 + j exists in the reference (inside [0, L))
+    edge_window = f0 < 0 || f0 + kDecRows > L;   // some window rows lie outside [0, L) (SGPR: a scalar branch)
+    ln_inside = 0;                          // bit j: row ln_row0 + j exists in the reference (inside [0, L))
 #pragma unroll
     for (int j = 0; j < RPT; ++j) ln_inside |= (src[ln_row0 + j] != -1 ? 1u : 0u) << j;
-
     f32x16 acc[MT][NTW];
     f32x4 skip[RPT][NV];
 #pragma unroll
@@ -647,6 +695,7 @@ __global__ __launch_bounds__(64 * NW, (DX2 <= 128 ? kDecWps128 : NW / 4)) void m
                 }
             }
         }
+        carry_put();
         __syncthreads();
     } else {
         zero_acc();
@@ -689,6 +738,7 @@ __global__ __launch_bounds__(64 * NW, (DX2 <= 128 ? kDecWps128 : NW / 4)) void m
                 }
             }
         }
+        carry_put();
         __syncthreads();
     }
 
@@ -712,6 +762,7 @@ __global__ __launch_bounds__(64 * NW, (DX2 <= 128 ? kDecWps128 : NW / 4)) void m
 #pragma unroll
             for (int j = 0; j < KD; ++j) tap[j] = *reinterpret_cast<const f32x4*>(pbt + j * DX2);
             const f32x4 tb = *reinterpret_cast<const f32x4*>(pbt + P_DWB);
+            carry_save(l);       // (this layer's input rows in front of the NEXT chunk, before the planes overwrite them)
             ESMI_STAMP();   // 1: window loaded (issued)
             __syncthreads();
             ESMI_STAMP();   // 2: barrier passed
@@ -758,6 +809,7 @@ __global__ __launch_bounds__(64 * NW, (DX2 <= 128 ? kDecWps128 : NW / 4)) void m
         ESMI_STAMP();   // 8: barrier
         // 4. LayerNorm (+ block-end skip LayerNorm) by row owners; the last one writes the mel Linear's operand planes
         if (l + 1 == n_layers) fetch_B(n_layers);   // mel bias -> group A slots (taps: last read by this layer's depthwise phase)
+        else carry_load(l + 1);
         if (SPLIT && l + 1 == n_layers) {
             if (block_end) ln_pass(pb, TrueC{}, TrueC{});
             else ln_pass(pb, FalseC{}, TrueC{});
@@ -767,6 +819,7 @@ __global__ __launch_bounds__(64 * NW, (DX2 <= 128 ? kDecWps128 : NW / 4)) void m
         }
         ESMI_STAMP();   // 9: LN done
         if (l + 1 == n_layers) gemm_prefetch(p.lay.mel_w);   // (the mel bias went to the unused group A slots by LDS-DMA above)
+        else carry_put();
         __syncthreads();
         ESMI_STAMP();   // 10: barrier
     }
@@ -809,6 +862,7 @@ __global__ __launch_bounds__(64 * NW, (DX2 <= 128 ? kDecWps128 : NW / 4)) void m
             }
         }
     }
+    }   // chunks of the segment
 }
 
 }  // namespace esmi

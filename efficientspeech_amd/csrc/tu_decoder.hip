@@ -82,9 +82,30 @@ int esmi_mel_decoder_pack_f32(const esmi_decoder_weights* w, const esmi_decoder_
     return launch_status();
 }
 
+// segments per utterance / frames per segment of the dx2 = 256 kernel when it may carry rows between chunks: whole utterances when
+// the batch fills the chip, else as many segments per utterance as it takes to give every CU one (a segment's first chunk recomputes
+// its left halo, so fewer, longer segments are cheaper)
+static void stream_geometry(const esmi_decoder_shape* s, int B, int L_out, int* n_seg_out, int* seg_len_out) {
+    const int halo = (s->kernel / 2) * s->n_blocks * s->block_depth;
+    const int keep = kDecRows - halo, chunks = (L_out + keep - 1) / keep;
+    int n_seg = (256 + B - 1) / B;
+    n_seg = n_seg < 1 ? 1 : (n_seg > chunks ? chunks : n_seg);
+    const int per = (chunks + n_seg - 1) / n_seg;           // chunks per segment
+    // (a segment that does not start the utterance yields keep - halo frames from its first chunk)
+    *seg_len_out = n_seg == 1 ? L_out : per * keep - halo;
+    *n_seg_out = (L_out + *seg_len_out - 1) / *seg_len_out;
+}
+
+size_t esmi_mel_decoder_workspace_bytes(const esmi_decoder_shape* s, int B, int L_out) {
+    if (dec_check(s) || s->dx2 != 256 || B <= 0 || L_out <= 0) return 0;
+    int n_seg, seg_len;
+    stream_geometry(s, B, L_out, &n_seg, &seg_len);
+    return (size_t)n_seg * ((B + 7) / 8) * 8 * ESMI_MAX_DEC_LAYERS * (s->kernel / 2) * s->dx2 * sizeof(float);
+}
+
 static int mel_decoder_launch(const float* blob, const esmi_decoder_shape* s, const float* x, const float* h0,
                               const int32_t* cum, const int32_t* mel_len, const int32_t* lmax_dev, int lmax_host, int apply_mask, int B, int T,
-                              int L_out, float* mel, esmi_stream_t stream) {
+                              int L_out, float* mel, void* workspace, size_t workspace_bytes, esmi_stream_t stream) {
     int rc = dec_check(s);
     if (rc) return rc;
     if (!blob || (!x && !h0) || !mel || B <= 0 || L_out <= 0 || !aligned16(blob) || (x && !aligned16(x))) return ESMI_ERR_ARG;
@@ -99,14 +120,24 @@ static int mel_decoder_launch(const float* blob, const esmi_decoder_shape* s, co
     p.x = x; p.h0 = h0; p.cum = cum; p.mel_len = mel_len; p.lmax_dev = lmax_dev; p.lmax_host = lmax_host;
     p.apply_mask = apply_mask && mel_len; p.B = B; p.T = T; p.L_out = L_out; p.mel = mel;
     p.halo = (s->kernel / 2) * s->n_blocks * s->block_depth;
-    p.TL = kDecRows - 2 * p.halo;
     p.trace = nullptr;
 #ifdef ESMI_DEC_TRACE
     p.trace = g_esmi_trace;   // development only, see tools/trace_decoder.py
 #endif
     hipStream_t st = S(stream);
-    p.n_tiles = (L_out + p.TL - 1) / p.TL;
-    dim3 grid((unsigned)(p.n_tiles * ((B + 7) / 8) * 8)), block(kDecThreads);
+    p.carry_ws = nullptr;
+    const size_t need = esmi_mel_decoder_workspace_bytes(s, B, L_out);
+    if (s->dx2 == 256 && workspace && need && workspace_bytes >= need) {
+        // one workgroup per CU walks a segment chunk by chunk, each conv layer's rows in front of a chunk carried in `workspace`
+        stream_geometry(s, B, L_out, &p.n_seg, &p.seg_len);
+        p.carry_ws = static_cast<float*>(workspace);
+    } else {
+        // every 128-row window is its own segment, halo rows recomputed on both sides (dx2 = 128: two workgroups per CU balance
+        // the chip and 768 = 7 x 112 frames leaves nothing to gain; dx2 = 256 without a workspace)
+        p.seg_len = kDecRows - 2 * p.halo;
+        p.n_seg = (L_out + p.seg_len - 1) / p.seg_len;
+    }
+    dim3 grid((unsigned)(p.n_seg * ((B + 7) / 8) * 8)), block(kDecThreads);
     // one translation unit per instantiation (tu_dec_<dx2>_<k>.hip): the kernel is by far the slowest thing to compile
     if (s->dx2 == 128 && s->kernel == 5) return launch_mel_decoder_128_5(p, grid, st);
     if (s->dx2 == 128 && s->kernel == 3) return launch_mel_decoder_128_3(p, grid, st);
@@ -116,7 +147,7 @@ static int mel_decoder_launch(const float* blob, const esmi_decoder_shape* s, co
 
 int esmi_mel_decoder_f32(const float* blob, const esmi_decoder_shape* s, const float* x, const float* h0,
                          const int32_t* cum, const int32_t* mel_len, const int32_t* lmax_dev, int lmax_host, int apply_mask, int B, int T,
-                         int L_out, float* mel, esmi_stream_t stream) {
-    return mel_decoder_launch(blob, s, x, h0, cum, mel_len, lmax_dev, lmax_host, apply_mask, B, T, L_out, mel, stream);
+                         int L_out, float* mel, void* workspace, size_t workspace_bytes, esmi_stream_t stream) {
+    return mel_decoder_launch(blob, s, x, h0, cum, mel_len, lmax_dev, lmax_host, apply_mask, B, T, L_out, mel, workspace, workspace_bytes, stream);
 }
 }  // extern "C"

@@ -580,9 +580,16 @@ class MelDecoder(_PackedModule):
         mel = torch.empty((B, L, self.n_mel_channels), dtype=torch.float32, device=x.device)
         if L > 0:
             shape = self._shape()
+            ws, ws_bytes = self._workspace(lib, shape, B, L, x.device)
             lib.esmi_mel_decoder_f32(_ptr(self._packed(lib, stream)), C.byref(shape), _ptr(x), None, None, None, None, L, 0,
-                                     B, 0, L, _ptr(mel), stream)
+                                     B, 0, L, _ptr(mel), _ptr(ws), ws_bytes, stream)
         return mel
+
+    @staticmethod
+    def _workspace(lib, shape, B, L, dev):
+        """Scratch for the dx2 = 256 kernel's carried rows (esmi_mel_decoder_workspace_bytes; nothing for dx2 = 128)."""
+        n = lib.esmi_mel_decoder_workspace_bytes(C.byref(shape), B, L)
+        return (torch.empty(n, dtype=torch.uint8, device=dev), n) if n else (None, 0)
 
     def _head(self, lib, stream):
         """The decoder's first stage (proj Linear + Tanh + LN) for the encoder side: it is row-wise, so it runs once per
@@ -614,8 +621,9 @@ class MelDecoder(_PackedModule):
             if self.timing is not None and feat.is_cuda and self._launches % self.timing_every == 0:   # events on the launch stream
                 ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
                 ev[0].record()
+            ws, ws_bytes = self._workspace(lib, shape, B, L_out, feat.device)
             lib.esmi_mel_decoder_f32(_ptr(blob), C.byref(shape), _ptr(feat), _ptr(h0), _ptr(cum), _ptr(mel_len), _ptr(lmax_dev),
-               int(lmax_host), int(apply_mask), B, T, L_out, _ptr(mel), stream)
+               int(lmax_host), int(apply_mask), B, T, L_out, _ptr(mel), _ptr(ws), ws_bytes, stream)
             if ev is not None:
                 ev[1].record()
                 self.timing.append(ev)

@@ -356,7 +356,12 @@ int esmi_mel_decoder_pack_f32(const esmi_decoder_weights* w, const esmi_decoder_
 int esmi_mel_decoder_f32(const float* blob, const esmi_decoder_shape* s, const float* x,
                          const float* h0, /* optional, fused mode only: (B,T,dx2) = LN(tanh(proj(x))), see esmi_decoder_head */
                          const int32_t* cum, const int32_t* mel_len, const int32_t* lmax_dev, int lmax_host, int apply_mask, int B,
-                         int T, int L_out, float* mel, esmi_stream_t stream);
+                         int T, int L_out, float* mel,
+                         void* workspace, size_t workspace_bytes, /* esmi_mel_decoder_workspace_bytes, or NULL / 0: dx2 = 256 then
+                                                                     recomputes both halos of every 128-frame window (slower) */
+                         esmi_stream_t stream);
+/* scratch for the dx2 = 256 kernel's carried rows (a workgroup walks its share of an utterance chunk by chunk; 0 for dx2 = 128) */
+size_t esmi_mel_decoder_workspace_bytes(const esmi_decoder_shape* s, int B, int L_out);
 /* ------------------------------------------------------------------ whole inference forward in ONE call
  * Phoneme2Mel.forward (eval), layers/networks.py:415-434 = Encoder blocks -> Fuse + variance adaptor (+ length-regulator scan,
  * + the decoder's phoneme-rate first stage when the fused kernel serves the shape) -> fused mel decoder, enqueued by a C
