@@ -215,6 +215,37 @@ def check_decoder_head(net, cfg, device, seed=11):
         assert d < 2e-5, d
 
 
+def check_decoder_chunk_walk(net, cfg, device, cases=((2, 40, 9), (5, 64, 7)), seed=17):
+    """dx2 = 256: the decoder walking an utterance chunk by chunk with carried rows (a workspace) against the same kernel
+    recomputing both halos of every 128-frame window (no workspace): identical rows, so the outputs must agree to rounding --
+    ragged lengths, several segments per utterance (small B) and, on the GPU, whole-utterance walks (B >= 256)."""
+    import ctypes as C
+    from efficientspeech_amd import networks
+    dec = net.decoder
+    rng = np.random.default_rng(seed)
+    for B, T, D in cases:
+        feat = torch.from_numpy(rng.standard_normal((B, T, cfg.d4)).astype(np.float32)).to(device)
+        dur = torch.from_numpy(rng.integers(1, D + 1, size=(B, T)).astype(np.int32)).to(device)
+        if B > 1:
+            dur[1, T // 2:] = 0                                   # a short utterance: padding frames, all-padding chunks
+        cum = torch.cumsum(dur, 1).to(torch.int32).contiguous()
+        mel_len = cum[:, -1].contiguous()
+        L = int(mel_len.max())
+        lib, stream = networks._runtime(feat)
+        shape, blob = dec._shape(), dec._packed(lib, stream)
+        outs = []
+        for use_ws in (True, False):
+            mel = torch.full((B, L, dec.n_mel_channels), float("nan"), dtype=torch.float32, device=device)
+            ws, n = dec._workspace(lib, shape, B, L, feat.device) if use_ws else (None, 0)
+            assert (n > 0) == (use_ws and cfg.dx2 == 256)
+            lib.esmi_mel_decoder_f32(blob.data_ptr(), C.byref(shape), feat.data_ptr(), None, cum.data_ptr(), mel_len.data_ptr(), None, L, 1,
+                                     B, T, L, mel.data_ptr(), ws.data_ptr() if ws is not None else None, n, stream)
+            outs.append(mel.cpu())
+        assert torch.isfinite(outs[0]).all()
+        d = float((outs[0] - outs[1]).abs().max())
+        assert d < 2e-6, (B, T, D, d)
+
+
 def check_wrapper_and_scheduler(device):
     """model.py-shaped wrapper (`.phoneme2mel`, `.hifigan`, `model(x)`, `predict_step`, Lightning-dict load; model.py:155-164,
     demo.py:66-67) on a padded B > 1 batch and a B == 1 call, and the length-bucketed scheduler, against the oracle."""

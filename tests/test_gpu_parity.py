@@ -457,6 +457,14 @@ def test_decoder_head_at_phoneme_rate(name, nets):
     H.check_decoder_head(net, cfg, DEV)
 
 
+@pytest.mark.parametrize("name", ["small", "base"])
+def test_decoder_chunk_walk_equals_windows(name, nets):
+    """The dx2 = 256 decoder with carried rows (workspace) == the same kernel with every window's halos recomputed: several
+    segments per utterance (B = 3), whole-utterance walks (B = 256: one workgroup per utterance, 6 chunks)."""
+    net, cfg, sd = nets(name)
+    H.check_decoder_chunk_walk(net, cfg, DEV, cases=((3, 70, 9), (256, 100, 6)))
+
+
 def test_split_range_guard_and_encoder_operand_scales():
     """(1) a weight outside the split-f16 range is refused at pack time; (2) encoder-side operands far from O(1): embedding
     rows x 40 (the un-normalised conv output that feeds qkv grows with them), merge / qkv / MixFFN weights x 0.05 .. x 6."""

@@ -255,6 +255,12 @@ def test_simulated_decoder_head_at_phoneme_rate(name, nets):
         H.check_decoder_head(net, cfg, "cpu")
 
 
+def test_simulated_decoder_chunk_walk_equals_windows(nets):
+    net, cfg, sd = nets("small")
+    with use_sim():
+        H.check_decoder_chunk_walk(net, cfg, "cpu", cases=((2, 40, 9),))
+
+
 def test_simulated_split_range_guard(nets):
     """A weight outside the split-f16 operand range is refused at pack time (ValueError naming the fp32 build), not
     silently turned into inf."""
