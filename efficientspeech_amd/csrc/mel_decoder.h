@@ -352,7 +352,7 @@ __global__ __launch_bounds__(64 * NW, (DX2 <= 128 ? kDecWps128 : NW / 4)) void m
     // conflict-free; in general rows 64(w / LNPER) + 16rg + RPT(w % LNPER) + j (with four CONSECUTIVE row quadruples per wave, lanes of neighbouring groups met in the same banks:
     // 17.8 % of the kernel's LDS cycles were bank conflicts, profiles/r01_l).
     constexpr int LNPER = 16 / RPT;         // waves that share one residue class of rows mod 16
-    const int ln_c = lane & (TPR - 1), ln_row0 = 64 * (w / LNPER) + 16 * (lane / TPR) + RPT * (w % LNPER);
+    int ln_c = lane & (TPR - 1), ln_row0 = 64 * (w / LNPER) + 16 * (lane / TPR) + RPT * (w % LNPER);
     edge_window = f0 < 0 || f0 + kDecRows > L;   // some window rows lie outside [0, L) (SGPR: a scalar branch)
     ln_inside = 0;                          // bit j: row ln_row0 + j exists in the reference (inside [0, L))
 #pragma unroll
@@ -743,11 +743,18 @@ __global__ __launch_bounds__(64 * NW, (DX2 <= 128 ? kDecWps128 : NW / 4)) void m
     }
 
     // ---- conv layers
-    const int dw_cg = tid % CG, dw_r0 = (tid / CG) * RS;
+    int dw_cg = tid % CG, dw_r0 = (tid / CG) * RS;
     for (int l = 0; l < n_layers; ++l) {
         const float* pb = pbuf;
         const long lbase = p.lay.layer0 + (long)l * p.lay.layer_stride;
         const bool block_end = ((l + 1) % p.block_depth) == 0;
+        if constexpr (STREAM) {   // (as at the top of the chunk loop: keeps the layer's address arithmetic from being hoisted and spilled)
+            tid = opaque_i(tid);
+            lane = tid & 63; i = lane & 31; h = lane >> 5;
+            tid16 = (unsigned)tid * 16u; lane16 = (unsigned)lane * 16u;
+            ln_c = lane & (TPR - 1); ln_row0 = 64 * (w / LNPER) + 16 * (lane / TPR) + RPT * (w % LNPER);
+            dw_cg = tid % CG; dw_r0 = (tid / CG) * RS;
+        }
         ESMI_STAMP();   // 0: layer start
         // 1. depthwise conv in place: window -> registers | barrier | filtered rows -> tile (as the K loop's operand planes)
         {
