@@ -362,9 +362,10 @@ def main():
     frames_per_step = (B_arg if a.scaling == "strong" else B * world) * L
     value = frames_per_step * a.steps / dt
     flops, nbytes = DECODER_WORK[a.config]
-    # MelDecoder's first stage (proj Linear + Tanh + LN) is row-wise and runs at PHONEME rate inside the fused
-    # variance-adaptor kernel when the shape allows (tiny, T <= 128): the decoder kernel itself then executes this much less
-    head_moved = cfg.d4 == 128 and cfg.dx2 == 128 and T <= 128
+    # MelDecoder's first stage (proj Linear + Tanh + LN) is row-wise and runs at PHONEME rate on the encoder side: the decoder
+    # kernel itself then executes this much less
+    # (round 4: every size -- inside the fused variance-adaptor kernel for tiny at T <= 128, else as one phoneme-rate GEMM launch)
+    head_moved = os.environ.get("ESMI_HEAD_GEMM", "1") != "0" or (cfg.d4 == 128 and cfg.dx2 == 128 and T <= 128)
     kernel_flops = flops - (2 * cfg.d4 * cfg.dx2 if head_moved else 0)
     build_cfg = _lib.load().esmi_build_config().decode()
     split = 3 if build_cfg.startswith("dec_gemm=split-f16x2") else 0      # 16-bit MFMA products per fp32-accurate product
@@ -526,7 +527,7 @@ def main():
                 res["roofline"].update(trace_kernel_us=tr_b, trace_source=tr_bsrc, frac_trace=fb * bb * lb / (tr_b * 1e-6) / 1e12 / peak_tf)
             trf, trf_src, _ = pmc_traffic("base", bb, tb_, a.dur)
             if trf:
-                eb = 4.0 * cfgb.n_mel_channels + 4.0 * cfgb.d4 / a.dur
+                eb = 4.0 * cfgb.n_mel_channels + 4.0 * cfgb.dx2 / a.dur       # h0 rows (dx2 floats per phoneme) in, mel rows out
                 res["roofline"].update(traffic=trf, traffic_source=trf_src, traffic_ratio=trf / (eb * bb * lb))
         # D-rand on base
         rng = np.random.default_rng(1234)

@@ -308,7 +308,7 @@ __global__ __launch_bounds__(64 * NW, (DX2 <= 128 ? kDecWps128 : NW / 4)) void m
     // a phase ahead and written to the tile's top pad rows by `carry_put` at the end of the phase in front of the layer's
     // depthwise conv; `carry_save` keeps this chunk's rows [keep - PAD, keep) of the same tensor for the next chunk.
     auto carry_load = [&](int l) __attribute__((always_inline)) {
-        if constexpr (STREAM) cnext = (cws && ck > 0 && tid < PAD * DX2) ? cws[l * (PAD * DX2) + tid] : 0.0f;
+        if constexpr (STREAM) cnext = (cws && ck > 0 && tid < PAD * DX2) ? cws[l * (PAD * DX2) + opaque_i(tid)] : 0.0f;   // (opaque: the address is not kept live between the phases)
     };
     auto carry_put = [&]() __attribute__((always_inline)) {
         if constexpr (STREAM) {
@@ -317,7 +317,7 @@ __global__ __launch_bounds__(64 * NW, (DX2 <= 128 ? kDecWps128 : NW / 4)) void m
     };
     auto carry_save = [&](int l) __attribute__((always_inline)) {
         if constexpr (STREAM) {
-            if (cws && tid < PAD * DX2) cws[l * (PAD * DX2) + tid] = xs[(kDecPadRows + keep - PAD + tid / DX2) * LDSROW + tid % DX2];
+            if (cws && tid < PAD * DX2) cws[l * (PAD * DX2) + opaque_i(tid)] = xs[(kDecPadRows + keep - PAD + tid / DX2) * LDSROW + tid % DX2];
         }
     };
 
