@@ -157,9 +157,20 @@ struct MelDecP {
     int seg_len;           // frames per segment (a workgroup's share of an utterance)
     int n_seg;             // segments per utterance
     float* carry_ws;       // dx2 = 256 with multi-chunk segments: [workgroup][conv layer][k/2][dx2] floats of scratch, else NULL
+    int carry_lds_layers;  // ... of which the first this many conv layers keep their carried rows in LDS behind the tile (what fits)
     long long* trace;      // development only (-DESMI_DEC_TRACE): [wave][stamp] shader-clock stamps of block (1,0)
 };
 
+// conv layers whose carried rows (k/2 rows of dx2 floats each) fit in LDS behind the tile and the parameter slots (dx2 = 256 only)
+template <int DX2>
+__host__ __device__ constexpr int dec_lds_floats(int kd);
+template <int DX2>
+inline int dec_carry_lds_layers(int kd, int n_layers) {
+    if (DX2 <= 128) return 0;
+    const int free_f = 160 * 1024 / 4 - dec_lds_floats<DX2>(kd), per = (kd / 2) * DX2;
+    const int n = free_f / per;
+    return n < n_layers ? n : n_layers;
+}
 template <int DX2>
 __host__ __device__ constexpr int dec_lds_floats(int kd) {
     return (kDecRows + 2 * kDecPadRows) * (DX2 + 4) + (kd + 6) * DX2 + kDecRows;
@@ -279,7 +290,9 @@ __global__ __launch_bounds__(64 * NW, (DX2 <= 128 ? kDecWps128 : NW / 4)) void m
     constexpr bool STREAM = DX2 > 128;
     // STREAM: the k/2 input rows of every conv layer in front of the next chunk wait in a global scratch row set of this workgroup
     // (2 KB per layer; written and read back by the same thread, one chunk apart: no fence needed, and the traffic is nothing)
+    // (the first `carry_lds_layers` layers' rows stay in LDS; the workspace takes the rest: base ES 7 + 2)
     float* const cws = STREAM && p.carry_ws ? p.carry_ws + (long)blockIdx.x * ((long)ESMI_MAX_DEC_LAYERS * PAD * DX2) : nullptr;
+    float* const cbuf = reinterpret_cast<float*>(src + kDecRows);     // [carry_lds_layers][PAD][DX2]
     float cnext = 0.0f;                      // the carried element of the NEXT conv layer, requested one phase ahead
     const int keep = kDecRows - p.halo;      // tile rows of a chunk that stay valid through every layer (the right halo is lost)
     bool edge_window = false;
@@ -308,7 +321,13 @@ __global__ __launch_bounds__(64 * NW, (DX2 <= 128 ? kDecWps128 : NW / 4)) void m
     // a phase ahead and written to the tile's top pad rows by `carry_put` at the end of the phase in front of the layer's
     // depthwise conv; `carry_save` keeps this chunk's rows [keep - PAD, keep) of the same tensor for the next chunk.
     auto carry_load = [&](int l) __attribute__((always_inline)) {
-        if constexpr (STREAM) cnext = (cws && ck > 0 && tid < PAD * DX2) ? cws[l * (PAD * DX2) + opaque_i(tid)] : 0.0f;   // (opaque: the address is not kept live between the phases)
+        if constexpr (STREAM) {
+            cnext = 0.0f;
+            if (cws && ck > 0 && tid < PAD * DX2) {
+                if (l < p.carry_lds_layers) cnext = cbuf[l * (PAD * DX2) + tid];
+                else cnext = cws[l * (PAD * DX2) + opaque_i(tid)];   // (opaque: the address is not kept live between the phases)
+            }
+        }
     };
     auto carry_put = [&]() __attribute__((always_inline)) {
         if constexpr (STREAM) {
@@ -317,11 +336,13 @@ __global__ __launch_bounds__(64 * NW, (DX2 <= 128 ? kDecWps128 : NW / 4)) void m
     };
     auto carry_save = [&](int l) __attribute__((always_inline)) {
         if constexpr (STREAM) {
-            if (cws && tid < PAD * DX2) cws[l * (PAD * DX2) + opaque_i(tid)] = xs[(kDecPadRows + keep - PAD + tid / DX2) * LDSROW + tid % DX2];
+            if (cws && tid < PAD * DX2) {
+                const float v = xs[(kDecPadRows + keep - PAD + tid / DX2) * LDSROW + tid % DX2];
+                if (l < p.carry_lds_layers) cbuf[l * (PAD * DX2) + tid] = v;
+                else cws[l * (PAD * DX2) + opaque_i(tid)] = v;
+            }
         }
     };
-
-    // ---- phase 0: source row of every window row, zero the LDS pad rows, stage proj + layer-0 params
     if (tid < kDecRows) {
         const int f = f0 + tid;
         int s;

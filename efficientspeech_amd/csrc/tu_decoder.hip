@@ -126,11 +126,13 @@ static int mel_decoder_launch(const float* blob, const esmi_decoder_shape* s, co
 #endif
     hipStream_t st = S(stream);
     p.carry_ws = nullptr;
+    p.carry_lds_layers = 0;
     const size_t need = esmi_mel_decoder_workspace_bytes(s, B, L_out);
     if (s->dx2 == 256 && workspace && need && workspace_bytes >= need) {
         // one workgroup per CU walks a segment chunk by chunk, each conv layer's rows in front of a chunk carried in `workspace`
         stream_geometry(s, B, L_out, &p.n_seg, &p.seg_len);
         p.carry_ws = static_cast<float*>(workspace);
+        p.carry_lds_layers = dec_carry_lds_layers<256>(s->kernel, s->n_blocks * s->block_depth);
     } else {
         // every 128-row window is its own segment, halo rows recomputed on both sides (dx2 = 128: two workgroups per CU balance
         // the chip and 768 = 7 x 112 frames leaves nothing to gain; dx2 = 256 without a workspace)
