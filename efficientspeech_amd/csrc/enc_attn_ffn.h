@@ -69,6 +69,66 @@ inline int enc_block_lds_floats(int C, int h, int expansion, int c_in, int k, in
     return (32 * nw + 2) * (expansion * C + 4) + (stg > qkv ? stg : qkv);
 }
 
+// Attention contractions of the chain kernels (both operands are activations).  Split build: the operands are split into two
+// binary16 pieces on the fly and the three significant products run as v_mfma_f32_32x32x16_f16 (3 x 32 cycles per 16 channels /
+// keys and tile instead of 8 x 64 for v_mfma_f32_32x32x2_f32; the same 22-bit products as every weight GEMM and as
+// attn_lds_kernel); the exact-fp32 build keeps the fp32 instruction.  Block-0 trace before: S^T 8.5k + P V 8.7k cycles of 54k.
+//   s[kt] += K(32 keys x 32 channels) Q^T: qv / kv = the lane's four 16-byte fragments (channels [8g + 4h, +4), g < 4)
+template <int NKT>
+__device__ __forceinline__ void attn_scores_grp(f32x16 (&s)[NKT], const f32x4 (&qv)[4], const f32x4 (&kv)[4][NKT]) {
+#if ESMI_CHAIN_SPLIT
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {
+        const f16x2p qf = split_f16x2(qv[2 * st], qv[2 * st + 1]);
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt) {
+            const f16x2p kf = split_f16x2(kv[2 * st][kt], kv[2 * st + 1][kt]);
+            s[kt] = mfma32_f16(kf.h2, qf.h1, s[kt]);
+            s[kt] = mfma32_f16(kf.h1, qf.h2, s[kt]);
+            s[kt] = mfma32_f16(kf.h1, qf.h1, s[kt]);
+        }
+    }
+#else
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+#pragma unroll
+            for (int kt = 0; kt < NKT; ++kt) s[kt] = mfma32(kv[g][kt][t], qv[g][t], s[kt]);
+        }
+    }
+#endif
+}
+//   o[nt] += P(32 queries x 16 keys) V: pa / pb = the lane's P values of accumulator registers [8u, +4) / [8u + 4, +4) of a key
+//   tile (keys 16u + {0..3} + 4h and 16u + 8 + {0..3} + 4h: the half waves' eight k-slots of one 16-key step), va / vb = V of
+//   those keys at this lane's column of every column tile
+template <int NC>
+__device__ __forceinline__ void attn_pv_step(f32x16 (&o)[NC], const f32x4& pa, const f32x4& pb, const float (&va)[4][NC],
+                                             const float (&vb)[4][NC]) {
+#if ESMI_CHAIN_SPLIT
+    const f16x2p pf = split_f16x2(pa, pb);
+#pragma unroll
+    for (int nt = 0; nt < NC; ++nt) {
+        const f32x4 a = {va[0][nt], va[1][nt], va[2][nt], va[3][nt]}, b = {vb[0][nt], vb[1][nt], vb[2][nt], vb[3][nt]};
+        const f16x2p vf = split_f16x2(a, b);
+        o[nt] = mfma32_f16(pf.h2, vf.h1, o[nt]);
+        o[nt] = mfma32_f16(pf.h1, vf.h2, o[nt]);
+        o[nt] = mfma32_f16(pf.h1, vf.h1, o[nt]);
+    }
+#else
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+#pragma unroll
+        for (int nt = 0; nt < NC; ++nt) o[nt] = mfma32(pa[rr], va[rr][nt], o[nt]);
+    }
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+#pragma unroll
+        for (int nt = 0; nt < NC; ++nt) o[nt] = mfma32(pb[rr], vb[rr][nt], o[nt]);
+    }
+#endif
+}
+
 // NCI == 0: x and qkv come from global memory (written by enc_merge_qkv_kernel).
 // NCI  > 0: WHOLE BLOCK in one launch, for sequences one workgroup covers (N <= 128): each wave first runs the merge
 //           conv + qkv stage of its 32 rows (Cin = 32*NCI, kernel KT, stride STRIDE); q/k/v go to an LDS tile shared by
@@ -108,6 +168,7 @@ __device__ __forceinline__ void enc_attn_ffn_body(const EncAttnFfnP& p) {
         constexpr int CIN = 32 * NCI;
         float* stg = qkv_t + w * ((31 * STRIDE + KT) * (CIN + 4));
         merge_conv_tile<NCI, NC, KT, STRIDE>(p.m, b, r0, stg, lane, xacc);
+        ESMI_CT();   // merge conv done
         const int nq = 3 * p.h * C, ntq = nq >> 5;
         WaveGrp<4> gq;
         wave_prefetch<4>(gq, p.m.qkv_w, ntq, 0, 0, lane);
@@ -127,6 +188,7 @@ __device__ __forceinline__ void enc_attn_ffn_body(const EncAttnFfnP& p) {
             }
         }
         __syncthreads();            // q / k / v of the whole sequence are in place
+        ESMI_CT();   // qkv done
     }
 
     // ---------------- prologue: everything that does not depend on a result is requested now, nothing is waited for.
@@ -190,14 +252,7 @@ __device__ __forceinline__ void enc_attn_ffn_body(const EncAttnFfnP& p) {
                     for (int kt = 0; kt < NKT; ++kt) kv[g][kt] = buf_ld4(r_qkv, k_off[kt] + hd_off + 32u * (kc + g));
                 }
             }
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-#pragma unroll
-                    for (int kt = 0; kt < NKT; ++kt) s[kt] = mfma32(kv[g][kt][t], qv[g][t], s[kt]);
-                }
-            }
+            attn_scores_grp<NKT>(s, qv, kv);
         }
         // P V operands: 4*NKT groups of four key rows; the first two groups are requested before the softmax.
         // keys >= N: V reads 0 (buffer bound) and P = 0.
@@ -247,21 +302,17 @@ __device__ __forceinline__ void enc_attn_ffn_body(const EncAttnFfnP& p) {
         f32x16 o[NC];           // ctx[query][c] = sum_key P[query][key] V[key][c]
         zero_tiles<NC>(o);
 #pragma unroll
-        for (int f = 0; f < 4 * NKT; f += 2) {
+        for (int f = 0; f < 4 * NKT; f += 2) {   // one 16-key step: accumulator registers [4f, 4f + 8) of key tile f >> 2
+            f32x4 pa, pb;
 #pragma unroll
-            for (int rr = 0; rr < 4; ++rr) {
-#pragma unroll
-                for (int nt = 0; nt < NC; ++nt)
-                    o[nt] = mfma32(s[f >> 2][((f & 3) << 2) + rr] * inv, v0.v[rr][nt], o[nt]);
+            for (int e = 0; e < 4; ++e) {
+                pa[e] = s[f >> 2][((f & 3) << 2) + e] * inv;
+                pb[e] = s[f >> 2][((f & 3) << 2) + 4 + e] * inv;
             }
+            VG w0 = v0, w1 = v1;
             if (f + 2 < 4 * NKT) vfetch(f + 2, v0);
-#pragma unroll
-            for (int rr = 0; rr < 4; ++rr) {
-#pragma unroll
-                for (int nt = 0; nt < NC; ++nt)
-                    o[nt] = mfma32(s[(f + 1) >> 2][(((f + 1) & 3) << 2) + rr] * inv, v1.v[rr][nt], o[nt]);
-            }
             if (f + 3 < 4 * NKT) vfetch(f + 3, v1);
+            attn_pv_step<NC>(o, pa, pb, w0.v, w1.v);
         }
         ESMI_CT();   // 3 PV issued
         lds_wave_sync();        // the previous head's proj has finished reading the tile
@@ -487,6 +538,7 @@ __device__ __forceinline__ void enc_attn_ffn_split_body(const EncAttnFfnP& p) {
         constexpr int CIN = 32 * NCI;
         float* stg = qkv_t + w * ((31 * STRIDE + KT) * (CIN + 4));
         merge_conv_tile<NCI, NC, KT, STRIDE>(p.m, b, r0, stg, lane, xacc);
+        ESMI_CT();   // merge conv done
         const int ntq = (3 * 2 * C) >> 5;
         WaveGrp<NC> gq;
         wave_prefetch<NC>(gq, p.m.qkv_w, ntq, 0, c * NC, lane);
@@ -506,6 +558,7 @@ __device__ __forceinline__ void enc_attn_ffn_split_body(const EncAttnFfnP& p) {
             }
         }
         __syncthreads();            // q / k / v of the whole sequence are in place; the x tile has been read
+        ESMI_CT();   // qkv done
     }
 
     // ---------------- prologue loads (nothing waited for)
@@ -566,14 +619,7 @@ __device__ __forceinline__ void enc_attn_ffn_split_body(const EncAttnFfnP& p) {
                 for (int kt = 0; kt < NKT; ++kt) kv[g][kt] = buf_ld4(r_qkv, k_off[kt] + 32u * (kc + g));
             }
         }
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-#pragma unroll
-                for (int kt = 0; kt < NKT; ++kt) s[kt] = mfma32(kv[g][kt][t], qv[g][t], s[kt]);
-            }
-        }
+        attn_scores_grp<NKT>(s, qv, kv);
     }
     struct VG { float v[4][NC]; };
     auto vfetch = [&](int f, VG& gq) __attribute__((always_inline)) {
@@ -591,6 +637,7 @@ __device__ __forceinline__ void enc_attn_ffn_split_body(const EncAttnFfnP& p) {
     VG v0, v1;
     vfetch(0, v0);
     vfetch(1, v1);
+    ESMI_CT();   // S^T issued
     float mx = -INFINITY;
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt) {
@@ -618,21 +665,19 @@ __device__ __forceinline__ void enc_attn_ffn_split_body(const EncAttnFfnP& p) {
     f32x16 o[NC];
     zero_tiles<NC>(o);
 #pragma unroll
-    for (int f = 0; f < 4 * NKT; f += 2) {
+    for (int f = 0; f < 4 * NKT; f += 2) {   // one 16-key step: accumulator registers [4f, 4f + 8) of key tile f >> 2
+        f32x4 pa, pb;
 #pragma unroll
-        for (int rr = 0; rr < 4; ++rr) {
-#pragma unroll
-            for (int nt = 0; nt < NC; ++nt) o[nt] = mfma32(s[f >> 2][((f & 3) << 2) + rr] * inv, v0.v[rr][nt], o[nt]);
+        for (int e = 0; e < 4; ++e) {
+            pa[e] = s[f >> 2][((f & 3) << 2) + e] * inv;
+            pb[e] = s[f >> 2][((f & 3) << 2) + 4 + e] * inv;
         }
+        VG w0 = v0, w1 = v1;
         if (f + 2 < 4 * NKT) vfetch(f + 2, v0);
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr) {
-#pragma unroll
-            for (int nt = 0; nt < NC; ++nt)
-                o[nt] = mfma32(s[(f + 1) >> 2][(((f + 1) & 3) << 2) + rr] * inv, v1.v[rr][nt], o[nt]);
-        }
         if (f + 3 < 4 * NKT) vfetch(f + 3, v1);
+        attn_pv_step<NC>(o, pa, pb, w0.v, w1.v);
     }
+    ESMI_CT();   // softmax + PV issued
     tile_store<NC>(buf, LD, c * C, o, lane);     // contexts of both heads side by side: proj's K dimension
     __syncthreads();
     // ---------------- proj (this wave's output columns, K = 2C), residual, LN1
@@ -664,6 +709,7 @@ __device__ __forceinline__ void enc_attn_ffn_split_body(const EncAttnFfnP& p) {
     }
     tile_store<NCH>(buf, LD, c0, y, lane);
     __syncthreads();
+    ESMI_CT();   // proj + LN1 + store
     // ---------------- MixFFN
     f32x16 m[NEH];
     zero_tiles<NEH>(m);
@@ -677,6 +723,7 @@ __device__ __forceinline__ void enc_attn_ffn_split_body(const EncAttnFfnP& p) {
     __syncthreads();            // both waves finished reading y1
     tile_store<NEH>(buf, LD, e0, m, lane);
     __syncthreads();            // hidden rows of partner and neighbours in place
+    ESMI_CT();   // mlp1 + store
     zero_tiles<NEH>(m);
     {
         const float* const taps[3] = {a_row - LD, a_row, a_row + LD};
@@ -693,6 +740,7 @@ __device__ __forceinline__ void enc_attn_ffn_split_body(const EncAttnFfnP& p) {
     __syncthreads();            // every wave has read what it needs of the hidden tile
     tile_store<NEH>(buf, LD, e0, m, lane);
     __syncthreads();
+    ESMI_CT();   // conv + gelu + store
     f32x16 z[NCH];
     zero_tiles<NCH>(z);
     wave_gemm_k<NCH, NE>(z, g2, a_row, true, p.mlp2_w, NC, 0, c * NCH, lane);

@@ -13,9 +13,11 @@ ids, mask = synth_phonemes(B, T, 1)
 x = {"phoneme": torch.from_numpy(ids).cuda(), "phoneme_mask": torch.from_numpy(mask).cuda(),
      "duration_forced": torch.full((B, T), 6, dtype=torch.int32, device="cuda"), "max_mel_len": 768}
 tr = torch.zeros((6, 64), dtype=torch.int64, device="cuda")
-lib.esmi_dev_set_chain_trace.argtypes = [C.c_void_p]
+setters = [getattr(lib, "esmi_dev_set_chain_trace_" + tu) for tu in ("enc_attn_ffn", "enc_block", "enc_fuse_va", "enc_merge")]
+for f in setters: f.argtypes = [C.c_void_p]
 for _ in range(3): net(x)
-lib.esmi_dev_set_chain_trace(tr.data_ptr()); net(x); torch.cuda.synchronize()
+for f in setters: f(tr.data_ptr())
+net(x); torch.cuda.synchronize()
 t = tr.cpu().numpy()
 for slot, name in ((0, "E2 blk0 (NC=1)"), (1, "E2 blk1 (NC=2)"), (2, "E3 fuse+VA"), (3, "E1 blk0 merge+qkv"), (4, "E1 blk1 merge+qkv")):
     v = t[slot]; n = int((v != 0).sum())
