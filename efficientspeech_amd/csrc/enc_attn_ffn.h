@@ -354,7 +354,7 @@ __device__ __forceinline__ void enc_attn_ffn_body(const EncAttnFfnP& p) {
             y[nt][r] += pb_[nt] + xr;
         }
     }
-    layernorm_tile_regs<NC>(y, g1_, be1_);
+    layernorm_tile_regs_staged<NC>(y, g1_, be1_);
 #pragma unroll
     for (int nt = 0; nt < NC; ++nt) {
 #pragma unroll
@@ -406,7 +406,7 @@ __device__ __forceinline__ void enc_attn_ffn_body(const EncAttnFfnP& p) {
         for (int r = 0; r < 16; ++r) z[nt][r] += b2_[nt] + y[nt][r];
     }
     ESMI_CT();   // 8 mlp2
-    layernorm_tile_regs<NC>(z, g2_, be2_);
+    layernorm_tile_regs_staged<NC>(z, g2_, be2_);
     ESMI_CT();   // 9 LN2
     const int row_lo = p.halo, row_hi = 32 * nw - p.halo;   // workgroup-local rows this workgroup stores
 #pragma unroll
@@ -457,18 +457,22 @@ __device__ __forceinline__ void layernorm_split(f32x16 (&v)[NH], const float (&g
     float mean_l[16], m2_l[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-        float s = 0.0f;
+        mean_l[r] = 0.0f;
 #pragma unroll
-        for (int nt = 0; nt < NH; ++nt) s += v[nt][r];
-        mean_l[r] = row_sum32(s) * inv_h;
-        float q = 0.0f;
+        for (int nt = 0; nt < NH; ++nt) mean_l[r] += v[nt][r];
+    }
+    row_sum32_x16(mean_l);      // stage by stage: the 16 xor-16 round trips in flight together (esmi_dev.h)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        mean_l[r] *= inv_h;
+        m2_l[r] = 0.0f;
 #pragma unroll
         for (int nt = 0; nt < NH; ++nt) {
             const float d = v[nt][r] - mean_l[r];
-            q = fmaf(d, d, q);
+            m2_l[r] = fmaf(d, d, m2_l[r]);
         }
-        m2_l[r] = row_sum32(q);
     }
+    row_sum32_x16(m2_l);
     __syncthreads();            // the statistics buffer is free (previous LayerNorm fully consumed)
     float* mine = stats + ((rt * 2 + c) * 32) * 2;
     const float* other = stats + ((rt * 2 + (c ^ 1)) * 32) * 2;
