@@ -27,6 +27,7 @@ struct EncMergeP {
     float* qkv;            // (B, n_out, 3*h*C)  [nq_override > 0: (B, n_out, nq_override), with qkv_w (nq_override, C)]
     int nq_override;       // 0, or the width of the Linear behind the merge convs when it is not the reference's qkv (folded attention: h*C)
     int tiles_per_b;       // ceil(n_out / 32)
+    const float* emb_conv; // block 0, optional: (k, vocab, C) = embedding folded into the composed merge conv (esmi.h), else NULL
 };
 
 // W'[j][o][i] = sum_m W1[o][m] * Wm[j][m][i]     (fp64 accumulation, once per checkpoint)
@@ -62,6 +63,37 @@ __device__ __forceinline__ void merge_conv_tile(const EncMergeP& p, int b, int t
     constexpr int NROWS = 31 * STRIDE + KT;    // input rows under one 32-row output tile
     constexpr int MAXI = (NROWS + RPI - 1) / RPI;
     const int i = lane & 31, h2 = lane >> 5;
+    if (p.ids && p.emb_conv) {
+        // block 0 with the embedding folded in (esmi.h, emb_conv): x[t] = sum_j E_j[id[t*STRIDE + j - pad]] -- two dependent round trips
+        // (ids, then KT rows of C floats per position) straight into the accumulator layout; no staging tile, no contraction
+        const int* idb = p.ids + (long)b * p.n_in;
+        int id[16][KT];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+#pragma unroll
+            for (int j = 0; j < KT; ++j) {
+                const int ti = (t0 + tile_row(r, lane)) * STRIDE + j - p.pad;
+                const bool ok = ti >= 0 && ti < p.n_in;
+                const int v = idb[ok ? ti : 0];
+                id[r][j] = !ok ? -1 : ((v < 0 || v >= p.vocab) ? 0 : v);   // (the reference raises IndexError; stay in bounds)
+            }
+        }
+        zero_tiles<NC>(x);
+#pragma unroll
+        for (int j = 0; j < KT; ++j) {
+            const float* ej = p.emb_conv + (long)j * p.vocab * C + i;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float* row = ej + (long)(id[r][j] < 0 ? 0 : id[r][j]) * C;
+#pragma unroll
+                for (int nt = 0; nt < NC; ++nt) {
+                    const float v = row[32 * nt];
+                    x[nt][r] += id[r][j] < 0 ? 0.0f : v;
+                }
+            }
+        }
+        return;
+    }
     WaveGrp<NC> gc;
     wave_prefetch<NC>(gc, p.merge_w, NC, 0, 0, lane);
     const int ti0 = t0 * STRIDE - p.pad;        // input position of staged row 0

@@ -163,6 +163,7 @@ int esmi_encoder_block_f32(const esmi_encoder_block_weights* w, const esmi_encod
     m.B = B; m.n_in = s->n_in; m.n_out = n; m.k = s->kernel; m.stride = s->stride; m.pad = s->kernel / 2; m.h = h;
     m.merge_w = w->merge_cwp; m.qkv_w = folded ? w->qk_wp : w->qkv_wp; m.x_out = x_mid; m.qkv = qkv;
     m.nq_override = folded ? nq : 0;
+    m.emb_conv = ids ? w->emb_conv : nullptr;
     m.tiles_per_b = (n + 31) / 32;
     EncAttnFfnP f;
     memset(&f, 0, sizeof f);

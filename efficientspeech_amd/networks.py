@@ -289,6 +289,11 @@ class Encoder(_PackedModule):
                 comp = torch.empty((k, co, cin), dtype=torch.float32, device=mw.device)   # merge1 o merge as one conv
                 lib.esmi_compose_merge_f32(_ptr(mw), _ptr(t["merge1_w"]), k, cin, co, _ptr(comp), stream)
                 t["merge_cwp"] = _pack_bfrag(lib, stream, comp)
+                if len(out) == 0 and os.environ.get("ESMI_FOLD_EMBED", "1") != "0":   # (the environment switch: development A/B)
+                    # block 0: embedding, merge conv and merge 1x1 are linear with nothing in between -> one table per tap,
+                    # E_j = embed @ (merge1 @ merge[j])^T, in fp64 (esmi.h, esmi_encoder_block_weights.emb_conv)
+                    t["emb_conv"] = torch.einsum("vi,jmi,om->jvo", self.embed.weight.detach().double(), mw.double(),
+                                                 t["merge1_w"].double().reshape(co, cin)).float().contiguous()
                 _check_split_range(lib, stream, [comp, t["qkv_w"], t["proj_w"], t["mlp1_w"], cw, t["mlp2_w"], t["qk_w"], t["vo_w"]],
                                    "encoder block weights")
                 # measured (same box, per-op plan): base ES (2 and 4 heads) 9.01 -> 8.48 ms/step; small ES block 0 (ONE head: the

@@ -132,6 +132,12 @@ typedef struct esmi_encoder_block_weights {
     const float* qk_wp;
     const float* vo_w;
     const float* vo_wp;
+    /* Block 0 only (optional): the embedding folded into the composed merge convolution.  Embedding, merge conv and merge 1x1 are
+     * linear with nothing in between (networks.py:56-67), so x[t] = sum_j E_j[id[t*stride + j - pad]] with
+     * E_j = embed @ W'[j]^T, (k, vocab, Cout) row-major, computed once per checkpoint in fp64 by the caller: k row gathers of Cout
+     * floats per position instead of a Cin-wide gather and a k*Cin x Cout contraction.  Taps outside [0, n_in) contribute 0 (the
+     * conv's zero padding).  Used by the chain kernels (merge_cwp path) when ids are given; NULL = contraction as before.        */
+    const float* emb_conv;
 } esmi_encoder_block_weights;
 
 typedef struct esmi_encoder_block_shape {
