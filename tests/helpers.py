@@ -215,6 +215,47 @@ def check_decoder_head(net, cfg, device, seed=11):
         assert d < 2e-5, d
 
 
+def check_embedding_folded_into_merge_conv(net, cfg, device, seed=23):
+    """Block 0 with the embedding folded into the composed merge conv (esmi_encoder_block_weights.emb_conv: one table per tap) against
+    the same block running the gather + contraction: ragged lengths, ids at both ends of the vocabulary, the padding id, a sequence of
+    one position; the table itself against its fp64 definition."""
+    import os
+    enc = net.encoder.encoder
+    rng = np.random.default_rng(seed)
+    blocks, _ = enc._packed(*__import__("efficientspeech_amd").networks._runtime(enc.embed.weight))
+    assert blocks[0][0].emb_conv and not blocks[1][0].emb_conv
+    merge, merge1 = enc.attn_blocks[0][0], enc.attn_blocks[0][1]
+    with torch.no_grad():
+        comp = torch.einsum("om,mij->joi", merge1.weight[:, :, 0].double(), merge.weight.double())          # W'[j] (Cout, Cin)
+        ref = torch.einsum("vi,joi->jvo", enc.embed.weight.double(), comp).float().cpu().numpy()
+    tab = [t for t in blocks[0][1] if t.dim() == 3 and tuple(t.shape) == ref.shape]
+    assert len(tab) == 1 and np.abs(tab[0].cpu().numpy() - ref).max() < 1e-6 * max(1.0, np.abs(ref).max())
+    outs = {}
+    for fold in ("1", "0"):
+        os.environ["ESMI_FOLD_EMBED"] = fold
+        enc._cache.invalidate()
+        try:
+            res = []
+            for B, T in ((3, 37), (2, 128), (1, 1)):
+                ids = rng.integers(1, 153, size=(B, T)) if fold == "1" else outs[("ids", B, T)]
+                if fold == "1":
+                    ids[0, 0], ids[-1, -1] = 152, 1
+                    if T > 8:
+                        ids[-1, T - 5:] = 0                      # padding id (row 0 of the table)
+                    outs[("ids", B, T)] = ids
+                mask = torch.from_numpy(ids == 0).to(device) if B > 1 else None
+                with torch.no_grad():
+                    feats, _ = enc(torch.from_numpy(ids).to(device), mask)
+                res.append([f.cpu().numpy() for f in feats])
+            outs[fold] = res
+        finally:
+            os.environ.pop("ESMI_FOLD_EMBED", None)
+            enc._cache.invalidate()
+    for a, b in zip(outs["1"], outs["0"]):
+        for fa, fb in zip(a, b):
+            assert np.abs(fa - fb).max() < 2e-5, np.abs(fa - fb).max()
+
+
 def check_decoder_chunk_walk(net, cfg, device, cases=((2, 40, 9), (5, 64, 7)), seed=17):
     """dx2 = 256: the decoder walking an utterance chunk by chunk with carried rows (a workspace) against the same kernel
     recomputing both halos of every 128-frame window (no workspace): identical rows, so the outputs must agree to rounding --

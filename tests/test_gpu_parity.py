@@ -457,6 +457,13 @@ def test_decoder_head_at_phoneme_rate(name, nets):
     H.check_decoder_head(net, cfg, DEV)
 
 
+@pytest.mark.parametrize("name", ["tiny", "small", "base"])
+def test_embedding_folded_into_merge_conv(name, nets):
+    """Block 0's table path (emb_conv) == the gather + composed-conv path, for the chain kernels of every size."""
+    net, cfg, sd = nets(name)
+    H.check_embedding_folded_into_merge_conv(net, cfg, DEV)
+
+
 @pytest.mark.parametrize("name", ["small", "base"])
 def test_decoder_chunk_walk_equals_windows(name, nets):
     """The dx2 = 256 decoder with carried rows (workspace) == the same kernel with every window's halos recomputed: several

@@ -255,6 +255,12 @@ def test_simulated_decoder_head_at_phoneme_rate(name, nets):
         H.check_decoder_head(net, cfg, "cpu")
 
 
+def test_simulated_embedding_folded_into_merge_conv(nets):
+    with use_sim():
+        net, cfg, sd = nets("tiny")
+        H.check_embedding_folded_into_merge_conv(net, cfg, "cpu")
+
+
 def test_simulated_decoder_chunk_walk_equals_windows(nets):
     net, cfg, sd = nets("small")
     with use_sim():
