@@ -341,7 +341,10 @@ def check_activation_range_guard(dev):
         ref = net(x)[0]
     mel, mel_len, _ = net.check_activation_range(x)
     if "split-f16" in _lib.load().esmi_build_config().decode():
-        assert torch.equal(mel, ref)                               # same kernels, same arithmetic: the check only observes
+        # same kernels, same operations: the check only observes.  Not bit for bit since the attention operands of the chain kernels
+        # go through the split too (round 4): the checks' branches sit between a product and the sum it feeds, and hipcc contracts
+        # a*b + c into an fma in one build and not in the other -- block 0's output differs by 4 ulp (4.8e-7), the mel by 2e-6.
+        assert float((mel - ref).abs().max()) < 1e-5
     else:                                                          # (ESMI_LIB = the exact-fp32 build: the checked build is the split-f16 one)
         assert float((mel - ref).abs().max()) < 1e-4
     sd2 = {k: v.copy() for k, v in sd.items()}
