@@ -44,6 +44,8 @@ struct EncAttnFfnP {
     int useful;                     // positions stored per workgroup: 32*nw - 2*halo
     int halo;                       // 0: one workgroup covers the sequence, 1: one recomputed row per side
     EncMergeP m;                    // whole-block instantiations (NCI > 0) only: the merge conv / qkv stage's inputs
+    int fold;                       // whole-block instantiations only: 1 = weight-folded attention (esmi.h, qk_w / vo_w): m.qkv_w is the (h*C, C)
+                                    // matrix of q_h = x M_h, keys = values = x for every head, proj_w is the (C, h*C) output matrix
 };
 
 constexpr int kEncMaxWaves = 4;     // waves per workgroup (one per SIMD)
@@ -169,6 +171,31 @@ __device__ __forceinline__ void enc_attn_ffn_body(const EncAttnFfnP& p) {
         float* stg = qkv_t + w * ((31 * STRIDE + KT) * (CIN + 4));
         merge_conv_tile<NCI, NC, KT, STRIDE>(p.m, b, r0, stg, lane, xacc);
         ESMI_CT();   // merge conv done
+        if (p.fold) {
+            // weight-folded attention: only q_h = x M_h is a contraction (h*C columns instead of 3*h*C); keys = values = x for every
+            // head: one copy of this wave's x rows behind the q columns of the shared tile
+            const int ntq = (p.h * C) >> 5;
+            WaveGrp<NC> gq;
+            wave_prefetch<NC>(gq, p.m.qkv_w, ntq, 0, 0, lane);
+            tile_store<NC>(buf, LD, 0, xacc, lane);
+            __syncthreads();        // every wave is done with its staging tile: the region becomes the q | x tile
+#pragma unroll
+            for (int nt = 0; nt < NC; ++nt) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) qkv_t[(r0 + tile_row(r, lane)) * ldq + p.h * C + 32 * nt + i] = xacc[nt][r];
+            }
+            for (int hd = 0; hd < p.h; ++hd) {
+                f32x16 q[NC];
+                zero_tiles<NC>(q);
+                wave_gemm_k<NC, NC>(q, gq, a_row, true, p.m.qkv_w, ntq, 0, hd * NC, lane);
+                if (hd + 1 < p.h) wave_prefetch<NC>(gq, p.m.qkv_w, ntq, 0, (hd + 1) * NC, lane);
+#pragma unroll
+                for (int nt = 0; nt < NC; ++nt) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) qkv_t[(r0 + tile_row(r, lane)) * ldq + hd * C + 32 * nt + i] = q[nt][r];
+                }
+            }
+        } else {
         const int nq = 3 * p.h * C, ntq = nq >> 5;
         WaveGrp<4> gq;
         wave_prefetch<4>(gq, p.m.qkv_w, ntq, 0, 0, lane);
@@ -186,6 +213,7 @@ __device__ __forceinline__ void enc_attn_ffn_body(const EncAttnFfnP& p) {
                     for (int r = 0; r < 16; ++r) qkv_t[(r0 + tile_row(r, lane)) * ldq + n0 + 32 * nt + i] = q[nt][r];
                 }
             }
+        }
         }
         __syncthreads();            // q / k / v of the whole sequence are in place
         ESMI_CT();   // qkv done
@@ -244,7 +272,7 @@ __device__ __forceinline__ void enc_attn_ffn_body(const EncAttnFfnP& p) {
 #pragma unroll
                     for (int kt = 0; kt < NKT; ++kt) {   // key tiles beyond the workgroup's rows alias its last tile (their scores are masked)
                         const int krow = 32 * (kt < nw ? kt : nw - 1) + i;
-                        kv[g][kt] = ld4(qkv_t + krow * ldq + (p.h + hd) * C + 8 * (kc + g) + 4 * h2);
+                        kv[g][kt] = ld4(qkv_t + krow * ldq + (p.fold ? p.h : p.h + hd) * C + 8 * (kc + g) + 4 * h2);
                     }
                 } else {
                     qv[g] = buf_ld4(r_qkv, q_off + hd_off + 32u * (kc + g));
@@ -265,7 +293,7 @@ __device__ __forceinline__ void enc_attn_ffn_body(const EncAttnFfnP& p) {
 #pragma unroll
                 for (int nt = 0; nt < NC; ++nt) {
                     if constexpr (FUSED)   // keys beyond the workgroup's rows: P = 0, any finite V will do
-                        gq.v[rr][nt] = qkv_t[(key < 32 * nw ? key : 32 * nw - 1) * ldq + (2 * p.h + hd) * C + 32 * nt + i];
+                        gq.v[rr][nt] = qkv_t[(key < 32 * nw ? key : 32 * nw - 1) * ldq + (p.fold ? p.h : 2 * p.h + hd) * C + 32 * nt + i];
                     else gq.v[rr][nt] = buf_ld(r_qkv, v_base + (unsigned)((key * ld + 32 * nt) * 4));
                 }
             }
@@ -543,11 +571,27 @@ __device__ __forceinline__ void enc_attn_ffn_split_body(const EncAttnFfnP& p) {
         float* stg = qkv_t + w * ((31 * STRIDE + KT) * (CIN + 4));
         merge_conv_tile<NCI, NC, KT, STRIDE>(p.m, b, r0, stg, lane, xacc);
         ESMI_CT();   // merge conv done
-        const int ntq = (3 * 2 * C) >> 5;
+        const int ntq = ((p.fold ? 1 : 3) * 2 * C) >> 5;
         WaveGrp<NC> gq;
         wave_prefetch<NC>(gq, p.m.qkv_w, ntq, 0, c * NC, lane);
         if (c == 0) tile_store<NC>(buf, LD, 0, xacc, lane);   // both waves of the pair hold the same x
         __syncthreads();            // x tile written; every wave is done with its staging tile
+        if (p.fold) {               // weight-folded attention (see enc_attn_ffn_body): q of head c, and this wave's half of the x copy
+#pragma unroll
+            for (int nt = 0; nt < NCH; ++nt) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    qkv_t[(r0 + tile_row(r, lane)) * ldq + 2 * C + c0 + 32 * nt + i] = c ? xacc[FUSED ? NCH + nt : 0][r] : xacc[FUSED ? nt : 0][r];
+            }
+            f32x16 q[NC];
+            zero_tiles<NC>(q);
+            wave_gemm_k<NC, NC>(q, gq, a_row, true, p.m.qkv_w, ntq, 0, c * NC, lane);
+#pragma unroll
+            for (int nt = 0; nt < NC; ++nt) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) qkv_t[(r0 + tile_row(r, lane)) * ldq + c * C + 32 * nt + i] = q[nt][r];
+            }
+        } else {
 #pragma unroll
         for (int part = 0; part < 3; ++part) {                // q, k, v columns of head c
             f32x16 q[NC];
@@ -560,6 +604,7 @@ __device__ __forceinline__ void enc_attn_ffn_split_body(const EncAttnFfnP& p) {
                 for (int r = 0; r < 16; ++r)
                     qkv_t[(r0 + tile_row(r, lane)) * ldq + (2 * part + c) * C + 32 * nt + i] = q[nt][r];
             }
+        }
         }
         __syncthreads();            // q / k / v of the whole sequence are in place; the x tile has been read
         ESMI_CT();   // qkv done
@@ -615,7 +660,7 @@ __device__ __forceinline__ void enc_attn_ffn_split_body(const EncAttnFfnP& p) {
 #pragma unroll
                 for (int kt = 0; kt < NKT; ++kt) {   // key tiles beyond the workgroup's rows alias its last tile (scores masked)
                     const int krow = 32 * (kt < nw ? kt : nw - 1) + i;
-                    kv[g][kt] = ld4(qkv_t + krow * ldq + (2 + c) * C + 8 * (kc + g) + 4 * h2);
+                    kv[g][kt] = ld4(qkv_t + krow * ldq + (p.fold ? 2 : 2 + c) * C + 8 * (kc + g) + 4 * h2);
                 }
             } else {
                 qv[g] = buf_ld4(r_qkv, q_off + 32u * (kc + g));
@@ -633,7 +678,7 @@ __device__ __forceinline__ void enc_attn_ffn_split_body(const EncAttnFfnP& p) {
             const int key = 32 * kt + tile_row(r4 + rr, lane);
 #pragma unroll
             for (int nt = 0; nt < NC; ++nt) {
-                if constexpr (FUSED) gq.v[rr][nt] = qkv_t[(key < 32 * nw ? key : 32 * nw - 1) * ldq + (4 + c) * C + 32 * nt + i];
+                if constexpr (FUSED) gq.v[rr][nt] = qkv_t[(key < 32 * nw ? key : 32 * nw - 1) * ldq + (p.fold ? 2 : 4 + c) * C + 32 * nt + i];
                 else gq.v[rr][nt] = buf_ld(r_qkv, v_base + (unsigned)((key * ld + 32 * nt) * 4));
             }
         }

@@ -155,7 +155,7 @@ int esmi_encoder_block_f32(const esmi_encoder_block_weights* w, const esmi_encod
     const bool fused2 = packed && (plan & ESMI_FUSE_ATTN_FFN) && enc_attn_ffn_supported(C, n, s->expansion);
     float* x_mid = fused2 ? y1 : x_out;
     // one-kernel-per-op attention with folded weights (esmi.h): the Linear behind the merge convs is x M (h*C wide) instead of qkv
-    const bool folded = !fused2 && w->qk_w && w->qk_wp && w->vo_w && w->vo_wp;
+    const bool folded = !fused2 && h >= 2 && w->qk_w && w->qk_wp && w->vo_w && w->vo_wp;   // (one head: measured no gain per op)
     const int nq = folded ? h * C : 3 * h * C;
     EncMergeP m;
     memset(&m, 0, sizeof m);
@@ -174,11 +174,14 @@ int esmi_encoder_block_f32(const esmi_encoder_block_weights* w, const esmi_encod
     f.mask = mask; f.out = x_out;
     f.mask_pool = s->mask_pool > 0 ? s->mask_pool : 1; f.mask_len = s->mask_pool > 0 ? s->mask_len : n;
     if (fused2 && (plan & ESMI_FUSE_MERGE_QKV) && (plan & ESMI_FUSE_BLOCK)) {   // the whole block in one launch
-        f.m = m;
-        f.x = nullptr; f.qkv = nullptr;
-        rc = launch_enc_block(f, s->expansion, s->c_in, plan, st);
+        EncAttnFfnP fb = f;
+        fb.m = m;
+        fb.x = nullptr; fb.qkv = nullptr;
+        if (w->qk_wp && w->vo_wp) {   // weight-folded attention inside the whole-block kernels: a third of the q / k / v contraction
+            fb.fold = 1; fb.m.qkv_w = w->qk_wp; fb.m.nq_override = 0; fb.proj_w = w->vo_wp;
+        }
+        rc = launch_enc_block(fb, s->expansion, s->c_in, plan, st);
         if (rc != ESMI_ERR_UNSUPPORTED) return rc;
-        f.x = x_mid; f.qkv = qkv;
     }
     if (packed && (plan & ESMI_FUSE_MERGE_QKV)) {   // E1: merge conv + 1x1 + qkv as one wave-chain kernel
         rc = launch_enc_merge_qkv(m, s->c_in, C, st);

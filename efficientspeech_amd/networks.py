@@ -298,7 +298,9 @@ class Encoder(_PackedModule):
                                    "encoder block weights")
                 # measured (same box, per-op plan): base ES (2 and 4 heads) 9.01 -> 8.48 ms/step; small ES block 0 (ONE head: the
                 # projections shrink 192 -> 64 columns only) 2.22 -> 2.25: folded only where there are heads to share the keys / values
-                if hh < 2 or os.environ.get("ESMI_FOLD_ATTN", "1") == "0":   # (the environment switch: development A/B)
+                # (the per-op plan uses them for blocks with two heads or more only -- esmi_encoder_block_f32 decides; the whole-block chain
+                #  kernels for every block)
+                if os.environ.get("ESMI_FOLD_ATTN", "1") == "0":             # (the environment switch: development A/B)
                     for name in ("qk_w", "qk_wp", "vo_w", "vo_wp"):
                         del t[name]
                 keep.extend(t.values())

@@ -121,7 +121,8 @@ typedef struct esmi_encoder_block_weights {
     const float* mlp1_wp;
     const float* conv_wp;
     const float* mlp2_wp;
-    /* Weight-folded attention for the one-kernel-per-op plan (optional; all four or none).  Every head spans the full width C, so
+    /* Weight-folded attention (optional; all four or none): used by the one-kernel-per-op plan for blocks with two or more heads and,
+     * through the *_wp copies, by the whole-block chain kernels for every block.  Every head spans the full width C, so
      *   scores_h = (x Wq_h^T)(x Wk_h^T)^T = (x M_h) x^T          with  M_h = Wq_h^T Wk_h   (C x C)
      *   out      = sum_h softmax(scores_h) (x Wv_h^T) Wp_h^T + b = sum_h (P_h x) O_h + b   with  O_h = Wv_h^T Wp_h^T (C x C):
      * ONE projection per head in front of the attention (q_h = x M_h; keys and values are x itself, shared by all heads) and one
