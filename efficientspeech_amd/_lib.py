@@ -29,7 +29,8 @@ class EncoderBlockWeights(C.Structure):
     _fields_ = [(n, fp) for n in ("merge_w", "merge1_w", "qkv_w", "proj_w", "proj_b", "mlp1_w", "mlp1_b",
                                   "conv_w", "conv_b", "mlp2_w", "mlp2_b", "ln1_g", "ln1_b", "ln2_g", "ln2_b",
                                   "merge_cwp", "qkv_wp", "proj_wp", "mlp1_wp", "conv_wp", "mlp2_wp",
-                                  "qk_w", "qk_wp", "vo_w", "vo_wp", "emb_conv")]
+                                  "qk_w", "qk_wp", "vo_w", "vo_wp", "emb_conv",
+                                  "ffn_cw", "ffn_cwp", "ffn_cb", "ffn_cb_first", "ffn_cb_last")]
 
 
 class EncoderBlockShape(C.Structure):

@@ -63,6 +63,10 @@ struct ConvGemmP {
     // `*_wp` fields of include/esmi.h).  convgemm_dma_kernel then brings its weight tile in by LDS-DMA -- each 1 KiB block of the
     // blob IS one (32-channel tile, 16-k step, piece) operand fragment in lane order -- instead of splitting fp32 rows per workgroup
     const float* Wp;
+    // optional (k = 3, stride 1 convs): what the first / the last row of a sequence lacks of `bias` -- a Linear folded into the conv
+    // behind it leaves its bias in every tap, and the taps that fall on the zero padding do not contribute theirs (esmi.h, ffn_cw)
+    const float* bias_first;
+    const float* bias_last;
 };
 // (s, 1/s) for a tensor whose largest magnitude has the bit pattern *absmax
 __device__ __forceinline__ void conv_pow2_scales(const float* absmax, float* s, float* inv) {
@@ -122,14 +126,24 @@ __device__ __forceinline__ void convgemm_epilogue(f32x16 (&acc)[NT], const ConvG
         cok[nt] = col[nt] < p.c_out;
         bias[nt] = (p.bias && cok[nt]) ? p.bias[col[nt]] : 0.0f;
     }
+    float b_first[NT], b_last[NT];
+    const bool edge = p.bias_first != nullptr;      // kernel-uniform
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        b_first[nt] = (edge && cok[nt]) ? p.bias_first[col[nt]] : 0.0f;
+        b_last[nt] = (edge && cok[nt]) ? p.bias_last[col[nt]] : 0.0f;
+    }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int t = t0 + tile_row(r, lane) * ts;
         const bool rok = t < n_out;
         const long row = (long)b * n_out + t;
+        const int tl = (edge && flat_rows) ? t % p.n_out : t;   // position inside its sequence (flat_rows: t counts rows of the whole batch)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
-            float v = apply_act(fmaf(acc[nt][r], out_s, bias[nt]), p.act);
+            float bv = bias[nt];
+            if (edge) bv = bv - (tl == 0 ? b_first[nt] : 0.0f) - (tl == p.n_out - 1 ? b_last[nt] : 0.0f);
+            float v = apply_act(fmaf(acc[nt][r], out_s, bv), p.act);
             if (p.res && rok && cok[nt]) v += p.res[row * p.ldr + p.r_coff + col[nt]];
             acc[nt][r] = v;
         }

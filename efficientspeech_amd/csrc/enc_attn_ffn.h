@@ -33,8 +33,10 @@ struct EncAttnFfnP {
     // the four weight matrices are in MFMA B-fragment order (esmi_pack_bfrag_f32, see wave_chain.h)
     const float *proj_w, *proj_b;   // (C, h*C), (C)
     const float *ln1_g, *ln1_b;
-    const float *mlp1_w, *mlp1_b;   // (E*C, C)
-    const float *conv_w, *conv_b;   // (3, E*C, E*C) tap-major
+    // MixFFN's Linear(C, E*C) folded into its dense k = 3 conv (esmi.h, ffn_cw): one k = 3 conv C -> E*C.  ffn_b = the bias of an interior
+    // row; a row whose first / last tap falls off the sequence lacks that tap's share of the Linear's bias: ffn_b0 / ffn_b2
+    const float *ffn_w;             // (3, E*C, C) tap-major, MFMA B-fragment order
+    const float *ffn_b, *ffn_b0, *ffn_b2;   // (E*C) each
     const float *mlp2_w, *mlp2_b;   // (C, E*C)
     const float *ln2_g, *ln2_b;
     const unsigned char* mask;      // (B, mask_len) or NULL; row n is padding iff any of mask[n*mask_pool .. +mask_pool) is set / beyond mask_len
@@ -242,7 +244,7 @@ __device__ __forceinline__ void enc_attn_ffn_body(const EncAttnFfnP& p) {
                 xres[nt][r] = buf_ld(r_x, (unsigned)(((t0 + tile_row(r, lane)) * C + 32 * nt + i) * 4));
         }
     }
-    float pb_[NC], g1_[NC], be1_[NC], b2_[NC], g2_[NC], be2_[NC], m1b_[NE], cb_[NE];
+    float pb_[NC], g1_[NC], be1_[NC], b2_[NC], g2_[NC], be2_[NC], cb_[NE], cb0_[NE], cb2_[NE];
 #pragma unroll
     for (int nt = 0; nt < NC; ++nt) {
         const int col = 32 * nt + i;
@@ -251,8 +253,9 @@ __device__ __forceinline__ void enc_attn_ffn_body(const EncAttnFfnP& p) {
     }
 #pragma unroll
     for (int nt = 0; nt < NE; ++nt) {
-        m1b_[nt] = p.mlp1_b[32 * nt + i];
-        cb_[nt] = p.conv_b[32 * nt + i];
+        cb_[nt] = p.ffn_b[32 * nt + i];
+        cb0_[nt] = p.ffn_b0[32 * nt + i];
+        cb2_[nt] = p.ffn_b2[32 * nt + i];
     }
 
     // ---------------- attention, one head at a time; proj accumulates over heads
@@ -355,8 +358,8 @@ __device__ __forceinline__ void enc_attn_ffn_body(const EncAttnFfnP& p) {
         }
         if (hd + 1 < p.h) wave_prefetch<NC>(gp, p.proj_w, NC, ((hd + 1) * C) >> 3, 0, lane);
     }
-    WaveGrp<NE> gm;                 // mlp1 weights
-    wave_prefetch<NE>(gm, p.mlp1_w, NE, 0, 0, lane);
+    WaveGrp<NE> gm;                 // MixFFN conv weights, tap 0
+    wave_prefetch<NE>(gm, p.ffn_w, NE, 0, 0, lane);
 
     // rows that are padding (mask) / outside the sequence
     const unsigned mbits = (unsigned)ballot64(mb != 0);   // bit i = row i (both half waves hold the same rows)
@@ -387,39 +390,32 @@ __device__ __forceinline__ void enc_attn_ffn_body(const EncAttnFfnP& p) {
     for (int nt = 0; nt < NC; ++nt) {
 #pragma unroll
         for (int r = 0; r < 16; ++r)
-            if (rz[r]) y[nt][r] = 0.0f;
+            if (rz[r] || rout[r]) y[nt][r] = 0.0f;   // (rows outside the sequence: the MixFFN conv's zero padding; never stored)
     }
     lds_wave_sync();
     tile_store<NC>(buf, LD, 0, y, lane);
-    lds_wave_sync();
+    __syncthreads();            // the neighbouring waves' boundary rows (and the zero rows) are in place
 
     ESMI_CT();   // 5 LN1 + store done
-    // ---------------- MixFFN: mlp1 -> dense conv k3 -> GELU -> mlp2
+    // ---------------- MixFFN: (Linear folded into) dense conv k3 -> GELU -> mlp2
     f32x16 m[NE];
-    zero_tiles<NE>(m);
-    wave_gemm_k<NE, NC>(m, gm, a_row, true, p.mlp1_w, NE, 0, 0, lane);
-    wave_prefetch<NE>(gm, p.conv_w, NE, 0, 0, lane);   // conv weights, tap 0
-#pragma unroll
-    for (int nt = 0; nt < NE; ++nt) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) m[nt][r] = rout[r] ? 0.0f : m[nt][r] + m1b_[nt];   // outside rows = the conv's zero padding
-    }
-    lds_wave_sync();
-    tile_store<NE>(buf, LD, 0, m, lane);
-    __syncthreads();            // the neighbouring waves' boundary rows (and the zero rows) are in place
-    ESMI_CT();   // 6 mlp1 + store
+    ESMI_CT();   // 6 (the stage of the separate Linear, gone)
     zero_tiles<NE>(m);
     {
         const float* const taps[3] = {a_row - LD, a_row, a_row + LD};
         const bool tok[3] = {true, true, true};
-        wave_gemm_taps<NE, 3, NE, false>(m, gm, taps, tok, p.conv_w, (long)EC * EC, NE, 0, 0, lane);
+        wave_gemm_taps<NE, 3, NC, false>(m, gm, taps, tok, p.ffn_w, (long)EC * C, NE, 0, 0, lane);
     }
     WaveGrp<NC> g2;                 // mlp2 weights
     wave_prefetch<NC>(g2, p.mlp2_w, NC, 0, 0, lane);
 #pragma unroll
-    for (int nt = 0; nt < NE; ++nt) {
+    for (int r = 0; r < 16; ++r) {
+        const int pos = t0 + tile_row(r, lane);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) m[nt][r] = gelu_fast_f32(m[nt][r] + cb_[nt]);
+        for (int nt = 0; nt < NE; ++nt) {
+            const float bias = cb_[nt] - (pos == 0 ? cb0_[nt] : 0.0f) - (pos == p.N - 1 ? cb2_[nt] : 0.0f);
+            m[nt][r] = gelu_fast_f32(m[nt][r] + bias);
+        }
     }
     __syncthreads();            // every wave has read its neighbours' rows
     tile_store<NE>(buf, LD, 0, m, lane);
@@ -635,7 +631,7 @@ __device__ __forceinline__ void enc_attn_ffn_split_body(const EncAttnFfnP& p) {
                 xres[nt][r] = buf_ld(r_x, (unsigned)(((t0 + tile_row(r, lane)) * C + c0 + 32 * nt + i) * 4));
         }
     }
-    float pb_[NCH], g1_[NCH], be1_[NCH], b2_[NCH], g2_[NCH], be2_[NCH], m1b_[NEH], cb_[NEH];
+    float pb_[NCH], g1_[NCH], be1_[NCH], b2_[NCH], g2_[NCH], be2_[NCH], cb_[NEH], cb0_[NEH], cb2_[NEH];
 #pragma unroll
     for (int nt = 0; nt < NCH; ++nt) {
         const int col = c0 + 32 * nt + i;
@@ -644,8 +640,9 @@ __device__ __forceinline__ void enc_attn_ffn_split_body(const EncAttnFfnP& p) {
     }
 #pragma unroll
     for (int nt = 0; nt < NEH; ++nt) {
-        m1b_[nt] = p.mlp1_b[e0 + 32 * nt + i];
-        cb_[nt] = p.conv_b[e0 + 32 * nt + i];
+        cb_[nt] = p.ffn_b[e0 + 32 * nt + i];
+        cb0_[nt] = p.ffn_b0[e0 + 32 * nt + i];
+        cb2_[nt] = p.ffn_b2[e0 + 32 * nt + i];
     }
 
     // ---------------- attention of head c
@@ -734,7 +731,7 @@ __device__ __forceinline__ void enc_attn_ffn_split_body(const EncAttnFfnP& p) {
     zero_tiles<NCH>(y);
     wave_gemm_k<NCH, 2 * NC>(y, gp, a_row, true, p.proj_w, NC, 0, c * NCH, lane);
     WaveGrp<NEH> gm;
-    wave_prefetch<NEH>(gm, p.mlp1_w, NE, 0, c * NEH, lane);
+    wave_prefetch<NEH>(gm, p.ffn_w, NE, 0, c * NEH, lane);
     const unsigned mbits = (unsigned)ballot64(mb != 0);
     bool rz[16], rout[16];
 #pragma unroll
@@ -754,37 +751,30 @@ __device__ __forceinline__ void enc_attn_ffn_split_body(const EncAttnFfnP& p) {
     for (int nt = 0; nt < NCH; ++nt) {
 #pragma unroll
         for (int r = 0; r < 16; ++r)
-            if (rz[r]) y[nt][r] = 0.0f;
+            if (rz[r] || rout[r]) y[nt][r] = 0.0f;   // (rows outside the sequence: the MixFFN conv's zero padding; never stored)
     }
     tile_store<NCH>(buf, LD, c0, y, lane);
     __syncthreads();
     ESMI_CT();   // proj + LN1 + store
-    // ---------------- MixFFN
+    // ---------------- MixFFN: (Linear folded into) dense conv k3 on the y1 rows of partner and neighbours -> GELU -> mlp2
     f32x16 m[NEH];
-    zero_tiles<NEH>(m);
-    wave_gemm_k<NEH, NC>(m, gm, a_row, true, p.mlp1_w, NE, 0, c * NEH, lane);
-    wave_prefetch<NEH>(gm, p.conv_w, NE, 0, c * NEH, lane);
-#pragma unroll
-    for (int nt = 0; nt < NEH; ++nt) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) m[nt][r] = rout[r] ? 0.0f : m[nt][r] + m1b_[nt];
-    }
-    __syncthreads();            // both waves finished reading y1
-    tile_store<NEH>(buf, LD, e0, m, lane);
-    __syncthreads();            // hidden rows of partner and neighbours in place
-    ESMI_CT();   // mlp1 + store
+    ESMI_CT();   // (the stage of the separate Linear, gone)
     zero_tiles<NEH>(m);
     {
         const float* const taps[3] = {a_row - LD, a_row, a_row + LD};
         const bool tok[3] = {true, true, true};
-        wave_gemm_taps<NEH, 3, NE, false>(m, gm, taps, tok, p.conv_w, (long)EC * EC, NE, 0, c * NEH, lane);
+        wave_gemm_taps<NEH, 3, NC, false>(m, gm, taps, tok, p.ffn_w, (long)EC * C, NE, 0, c * NEH, lane);
     }
     WaveGrp<NCH> g2;
     wave_prefetch<NCH>(g2, p.mlp2_w, NC, 0, c * NCH, lane);
 #pragma unroll
-    for (int nt = 0; nt < NEH; ++nt) {
+    for (int r = 0; r < 16; ++r) {
+        const int pos = t0 + tile_row(r, lane);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) m[nt][r] = gelu_fast_f32(m[nt][r] + cb_[nt]);
+        for (int nt = 0; nt < NEH; ++nt) {
+            const float bias = cb_[nt] - (pos == 0 ? cb0_[nt] : 0.0f) - (pos == p.N - 1 ? cb2_[nt] : 0.0f);
+            m[nt][r] = gelu_fast_f32(m[nt][r] + bias);
+        }
     }
     __syncthreads();            // every wave has read what it needs of the hidden tile
     tile_store<NEH>(buf, LD, e0, m, lane);

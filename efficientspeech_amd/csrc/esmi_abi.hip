@@ -151,7 +151,8 @@ int esmi_encoder_block_f32(const esmi_encoder_block_weights* w, const esmi_encod
     bool fused1 = false;
     // With the fused second stage, x (the block input after the merge convs) lives in scratch and the final
     // result is written straight to x_out: tiles read their neighbours' x rows, so in-place is not possible.
-    const bool packed = w->merge_cwp && w->qkv_wp && w->proj_wp && w->mlp1_wp && w->conv_wp && w->mlp2_wp;
+    const bool ffn_folded = w->ffn_cw && w->ffn_cwp && w->ffn_cb && w->ffn_cb_first && w->ffn_cb_last;
+    const bool packed = w->merge_cwp && w->qkv_wp && w->proj_wp && ffn_folded && w->mlp2_wp;
     const bool fused2 = packed && (plan & ESMI_FUSE_ATTN_FFN) && enc_attn_ffn_supported(C, n, s->expansion);
     float* x_mid = fused2 ? y1 : x_out;
     // one-kernel-per-op attention with folded weights (esmi.h): the Linear behind the merge convs is x M (h*C wide) instead of qkv
@@ -169,7 +170,7 @@ int esmi_encoder_block_f32(const esmi_encoder_block_weights* w, const esmi_encod
     memset(&f, 0, sizeof f);
     f.x = x_mid; f.qkv = qkv; f.B = B; f.N = n; f.C = C; f.h = h; f.scale = 1.0f / sqrtf((float)(C / h));
     f.proj_w = w->proj_wp; f.proj_b = w->proj_b; f.ln1_g = w->ln1_g; f.ln1_b = w->ln1_b;
-    f.mlp1_w = w->mlp1_wp; f.mlp1_b = w->mlp1_b; f.conv_w = w->conv_wp; f.conv_b = w->conv_b;
+    f.ffn_w = w->ffn_cwp; f.ffn_b = w->ffn_cb; f.ffn_b0 = w->ffn_cb_first; f.ffn_b2 = w->ffn_cb_last;
     f.mlp2_w = w->mlp2_wp; f.mlp2_b = w->mlp2_b; f.ln2_g = w->ln2_g; f.ln2_b = w->ln2_b;
     f.mask = mask; f.out = x_out;
     f.mask_pool = s->mask_pool > 0 ? s->mask_pool : 1; f.mask_len = s->mask_pool > 0 ? s->mask_len : n;
@@ -234,14 +235,22 @@ int esmi_encoder_block_f32(const esmi_encoder_block_weights* w, const esmi_encod
     p.out = y1; p.ldo = C;
     if ((rc = launch_convgemm(p, st))) return rc;
     // MixFFN, blocks.py:22-29
-    p = conv_defaults();
-    p.B = B; p.n_in = n; p.c_in = C; p.n_out = n; p.c_out = E;
-    p.A = y1; p.lda = C; p.W = w->mlp1_w; p.Wp = w->mlp1_wp; p.bias = w->mlp1_b; p.out = m1; p.ldo = E;
-    if ((rc = launch_convgemm(p, st))) return rc;
-    p = conv_defaults();
-    p.B = B; p.n_in = n; p.c_in = E; p.n_out = n; p.c_out = E; p.k = 3; p.pad = 1;
-    p.A = m1; p.lda = E; p.W = w->conv_w; p.Wp = w->conv_wp; p.bias = w->conv_b; p.act = ACT_GELU; p.out = m2; p.ldo = E;
-    if ((rc = launch_convgemm(p, st))) return rc;
+    if (ffn_folded) {   // Linear folded into the k = 3 conv (esmi.h, ffn_cw): one contraction C -> E, position-dependent bias at the two ends
+        p = conv_defaults();
+        p.B = B; p.n_in = n; p.c_in = C; p.n_out = n; p.c_out = E; p.k = 3; p.pad = 1;
+        p.A = y1; p.lda = C; p.W = w->ffn_cw; p.Wp = w->ffn_cwp; p.bias = w->ffn_cb; p.bias_first = w->ffn_cb_first; p.bias_last = w->ffn_cb_last;
+        p.act = ACT_GELU; p.out = m2; p.ldo = E;
+        if ((rc = launch_convgemm(p, st))) return rc;
+    } else {
+        p = conv_defaults();
+        p.B = B; p.n_in = n; p.c_in = C; p.n_out = n; p.c_out = E;
+        p.A = y1; p.lda = C; p.W = w->mlp1_w; p.Wp = w->mlp1_wp; p.bias = w->mlp1_b; p.out = m1; p.ldo = E;
+        if ((rc = launch_convgemm(p, st))) return rc;
+        p = conv_defaults();
+        p.B = B; p.n_in = n; p.c_in = E; p.n_out = n; p.c_out = E; p.k = 3; p.pad = 1;
+        p.A = m1; p.lda = E; p.W = w->conv_w; p.Wp = w->conv_wp; p.bias = w->conv_b; p.act = ACT_GELU; p.out = m2; p.ldo = E;
+        if ((rc = launch_convgemm(p, st))) return rc;
+    }
     // mlp2 + residual + LN2 + mask, networks.py:80-83
     p = conv_defaults();
     p.B = B; p.n_in = n; p.c_in = E; p.n_out = n; p.c_out = C;

@@ -282,7 +282,15 @@ class Encoder(_PackedModule):
                 wp = t["proj_w"].double().view(cc, hh, cc)                            # [out][h][in]
                 t["qk_w"] = torch.einsum("hoj,hoi->hji", wqkv[1], wqkv[0]).reshape(hh * cc, cc).float().contiguous()   # rows [h][j]: sum_o Wk[o][j] Wq[o][i]
                 t["vo_w"] = torch.einsum("ohm,hmi->ohi", wp, wqkv[2]).reshape(cc, hh * cc).float().contiguous()        # [o][h][i]: sum_m Wp[o][h][m] Wv[m][i]
-                for name in ("qkv_w", "proj_w", "mlp1_w", "conv_w", "mlp2_w", "qk_w", "vo_w"):
+                # MixFFN's Linear folded into its k = 3 conv (include/esmi.h, ffn_cw), in fp64: W'[j] = conv[j] @ mlp1; the Linear's bias
+                # reaches a position through every tap that lies inside the sequence
+                if os.environ.get("ESMI_FOLD_FFN", "1") != "0":                  # (the environment switch: development A/B)
+                    cw64 = cw.double()                                            # (3, eC, eC) tap-major
+                    e = torch.einsum("jom,m->jo", cw64, t["mlp1_b"].double())    # what tap j carries of the Linear's bias
+                    t["ffn_cw"] = torch.einsum("jom,mi->joi", cw64, t["mlp1_w"].double()).float().contiguous()
+                    t["ffn_cb"] = (t["conv_b"].double() + e.sum(0)).float().contiguous()
+                    t["ffn_cb_first"], t["ffn_cb_last"] = e[0].float().contiguous(), e[2].float().contiguous()
+                for name in ("qkv_w", "proj_w", "mlp1_w", "conv_w", "mlp2_w", "qk_w", "vo_w") + (("ffn_cw",) if "ffn_cw" in t else ()):
                     t[name + "p"] = _pack_bfrag(lib, stream, t[name])
 
                 k, cin, co = mw.shape[0], mw.shape[2], merge1.weight.shape[0]
@@ -294,7 +302,8 @@ class Encoder(_PackedModule):
                     # E_j = embed @ (merge1 @ merge[j])^T, in fp64 (esmi.h, esmi_encoder_block_weights.emb_conv)
                     t["emb_conv"] = torch.einsum("vi,jmi,om->jvo", self.embed.weight.detach().double(), mw.double(),
                                                  t["merge1_w"].double().reshape(co, cin)).float().contiguous()
-                _check_split_range(lib, stream, [comp, t["qkv_w"], t["proj_w"], t["mlp1_w"], cw, t["mlp2_w"], t["qk_w"], t["vo_w"]],
+                _check_split_range(lib, stream, [comp, t["qkv_w"], t["proj_w"], t["mlp1_w"], cw, t["mlp2_w"], t["qk_w"], t["vo_w"]]
+                                   + ([t["ffn_cw"]] if "ffn_cw" in t else []),
                                    "encoder block weights")
                 # measured (same box, per-op plan): base ES (2 and 4 heads) 9.01 -> 8.48 ms/step; small ES block 0 (ONE head: the
                 # projections shrink 192 -> 64 columns only) 2.22 -> 2.25: folded only where there are heads to share the keys / values

@@ -139,6 +139,19 @@ typedef struct esmi_encoder_block_weights {
      * floats per position instead of a Cin-wide gather and a k*Cin x Cout contraction.  Taps outside [0, n_in) contribute 0 (the
      * conv's zero padding).  Used by the chain kernels (merge_cwp path) when ids are given; NULL = contraction as before.        */
     const float* emb_conv;
+    /* MixFFN's Linear(C, e*C) folded into the dense k = 3 conv behind it (blocks.py:22-27: nothing in between), optional, all five or
+     * none: ffn_cw[j] = conv_w[j] @ mlp1_w, (3, e*C, C) tap-major, ffn_cwp = esmi_pack_bfrag_f32(ffn_cw, taps = 3) -- a k = 3 conv
+     * C -> e*C instead of a Linear and a k = 3 conv e*C -> e*C (expansion 2: 43 % of the two contractions' FLOPs, and the hidden tensor
+     * of the Linear is never written).  The Linear's bias reaches every position through the taps that lie inside the sequence:
+     * ffn_cb = conv_b + sum_j conv_w[j] @ mlp1_b is the bias of an interior position, the first position lacks
+     * ffn_cb_first = conv_w[0] @ mlp1_b and the last one ffn_cb_last = conv_w[2] @ mlp1_b (a sequence of one position lacks both).
+     * Computed in fp64 by the caller.  The chain kernels need them (with the other *_wp); the one-kernel-per-op plan uses them when
+     * given.  esmi_mixffn_f32 (the module-level MixFFN.forward) keeps the reference's three contractions.                        */
+    const float* ffn_cw;
+    const float* ffn_cwp;
+    const float* ffn_cb;
+    const float* ffn_cb_first;
+    const float* ffn_cb_last;
 } esmi_encoder_block_weights;
 
 typedef struct esmi_encoder_block_shape {
