@@ -464,6 +464,13 @@ def test_embedding_folded_into_merge_conv(name, nets):
     H.check_embedding_folded_into_merge_conv(net, cfg, DEV)
 
 
+@pytest.mark.parametrize("name", ["tiny", "small", "base"])
+def test_ffn_linear_folded_into_conv(name, nets):
+    """MixFFN's folded front (ffn_cw) == Linear + conv, chain kernels and per-op plan, padded batches and one-position sequences."""
+    net, cfg, sd = nets(name)
+    H.check_ffn_linear_folded_into_conv(net, cfg, DEV)
+
+
 @pytest.mark.parametrize("name", ["small", "base"])
 def test_decoder_chunk_walk_equals_windows(name, nets):
     """The dx2 = 256 decoder with carried rows (workspace) == the same kernel with every window's halos recomputed: several

@@ -261,6 +261,13 @@ def test_simulated_embedding_folded_into_merge_conv(nets):
         H.check_embedding_folded_into_merge_conv(net, cfg, "cpu")
 
 
+@pytest.mark.parametrize("name", ["tiny", "base"])
+def test_simulated_ffn_linear_folded_into_conv(name, nets):
+    with use_sim():
+        net, cfg, sd = nets(name)
+        H.check_ffn_linear_folded_into_conv(net, cfg, "cpu")
+
+
 def test_simulated_decoder_chunk_walk_equals_windows(nets):
     net, cfg, sd = nets("small")
     with use_sim():
