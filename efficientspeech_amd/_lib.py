@@ -296,7 +296,11 @@ def load():
                 f"{LIB_PATH} not found: the esmi HIP extension is not built. Run "
                 "`python -c 'import __graft_entry__ as g; g.build()'` (hipcc --offload-arch=gfx950). "
                 "There is no CPU fallback for this path.")
-        _LIB = bind(C.CDLL(LIB_PATH))
+        lib = bind(C.CDLL(LIB_PATH))
+        if lib.esmi_backend().decode() != "hip:gfx950":    # (tests bind the wave simulator through bind(), never through here)
+            raise RuntimeError(f"{LIB_PATH} reports backend {lib.esmi_backend().decode()!r}: the product path only runs the HIP "
+                               "build for gfx950 (no CPU / simulator fallback)")
+        _LIB = lib
     return _LIB
 
 
@@ -307,7 +311,10 @@ def use_library(path):
     key on the binding (`generation()`), so a module used on both sides of the switch re-packs."""
     global _LIB
     old = _LIB
-    _LIB = bind(C.CDLL(os.path.abspath(path)))
+    new = bind(C.CDLL(os.path.abspath(path)))
+    if new.esmi_backend().decode() != "hip:gfx950":
+        raise RuntimeError(f"{path} reports backend {new.esmi_backend().decode()!r}: not a HIP build for gfx950")
+    _LIB = new
     try:
         yield _LIB
     finally:

@@ -741,6 +741,14 @@ int fwd_arena(const esmi_forward_args* a, FwdArena* o) {
     }
     const size_t wv = esmi_fuse_variance_adaptor_workspace_bytes(a->B, a->T, a->dim, a->depth);
     ws = wv > ws ? wv : ws;
+    // the decoder re-uses the encoder side's scratch for its carried rows (dx2 = 256 chunk walk): when the caller knows the output
+    // length at sizing time (L_out > 0) the scratch is made large enough for it, so the one-call forward never drops to the
+    // window form that the module path (which sizes the workspace itself) would not take.  L_out unknown at sizing time (the length
+    // comes from the device): the scratch may be too small for a long batch and the decoder then runs its window form.
+    if (a->L_out > 0) {
+        const size_t wd = esmi_mel_decoder_workspace_bytes(&a->dec_shape, a->B, a->L_out);
+        ws = wd > ws ? wd : ws;
+    }
     const size_t rows = (size_t)a->B * a->T;
     o->ws = off; off += align256(ws);
     o->feat = off; off += align256(rows * 4 * a->dim * 4);

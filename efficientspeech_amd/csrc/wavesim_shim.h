@@ -428,8 +428,9 @@ inline int read_device_flag(const int* dev_flag, hipStream_t stream, int* out) {
 #endif
 }
 #if ESMI_RANGE_CHECK
-// point this translation unit's copy of the device-side range-flag pointer at `flag`
-inline int store_range_flag_pointer(int* flag) {
+// point this translation unit's copy of the device-side range-flag pointer at `flag` (static: the pointer it writes is this unit's own,
+// so an out-of-line copy must not be shared between units)
+static inline int store_range_flag_pointer(int* flag) {
 #ifdef ESMI_WAVESIM
     g_esmi_range_flag = flag;
     return 0;

@@ -878,6 +878,7 @@ class Phoneme2Mel(nn.Module):
         a.duration_pred, a.mel_len, a.lmax_dev = _ptr(st.duration), _ptr(st.mel_len), _ptr(st.lmax)
         a.pitch_pred = a.energy_pred = a.pitch_idx = a.energy_idx = a.dur = a.cum = None
         if stage != 2:
+            a.L_out = st.L_out or 0                                   # known output length: the arena's scratch also fits the decoder's carried rows
             nbytes = lib.esmi_forward_arena_bytes(C.byref(a))
             st.arena = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         a.arena, a.arena_bytes = _ptr(st.arena), st.arena.numel()

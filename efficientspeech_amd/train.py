@@ -869,6 +869,7 @@ def fit(step, loader, epochs, device, base_lr=None, warmup=50, total=5000, first
             dist.all_reduce(mean, op=dist.ReduceOp.SUM, group=step.group)
             mean = mean / step.world
         history.append({"epoch": epoch, "lr": lr, "losses": mean.cpu().tolist() if mean is not None else None})
+        step.epoch = epoch + 1          # what `state_dict()` records: the epoch a resumed `fit(first_epoch=...)` starts with
         if log:
             log(history[-1])
     return history

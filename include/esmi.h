@@ -390,7 +390,9 @@ size_t esmi_mel_decoder_workspace_bytes(const esmi_decoder_shape* s, int B, int 
  * per-stage entry points above.
  *
  * Scratch: ONE caller-provided arena of esmi_forward_arena_bytes() bytes (16-byte aligned base); nothing in it needs to
- * survive the call.  Outputs the reference returns are separate caller buffers: mel, mel_len, duration_pred.            */
+ * survive the call.  Outputs the reference returns are separate caller buffers: mel, mel_len, duration_pred.  When L_out > 0 at
+ * sizing time the arena's scratch also covers esmi_mel_decoder_workspace_bytes(dec_shape, B, L_out) (the dx2 = 256 decoder's carried
+ * rows); with L_out unknown then (length taken from the device) a long batch may run the decoder's window form instead.       */
 typedef struct esmi_forward_args {
     int B, T, depth, dim, fuse_kernel, plan;
     esmi_encoder_block_weights blocks[ESMI_MAX_DEPTH];

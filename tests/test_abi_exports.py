@@ -87,6 +87,21 @@ def test_missing_library_raises(monkeypatch, built):
         _lib.load()
 
 
+def test_load_refuses_a_library_that_is_not_the_hip_build(monkeypatch, built):
+    """ESMI_LIB / LIB_PATH pointing at the wave-simulator build of the same ABI (a CPU library) is refused by the product's load()
+    and use_library(): the only way to bind the simulator is tests/simlib.py's explicit bind()."""
+    from efficientspeech_amd import _lib
+    from tests.simlib import sim_lib, SIM_SO
+    sim_lib()                                         # (built on demand)
+    monkeypatch.setattr(_lib, "_LIB", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", SIM_SO)
+    with pytest.raises(RuntimeError, match="hip:gfx950|HIP build"):
+        _lib.load()
+    with pytest.raises(RuntimeError, match="not a HIP build"):
+        with _lib.use_library(SIM_SO):
+            pass
+
+
 def test_get_mask_from_lengths_matches_reference_semantics():
     """utils/tools.py:43-51: mask[b, t] = t >= lengths[b]; max_len defaults to max(lengths); True marks padding."""
     import torch

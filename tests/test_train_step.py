@@ -368,6 +368,16 @@ def check_checkpoint_resume(dev):
                              a.betas[1], a.eps, a.wd, a.t, 1.0, st)
     for k in a.flat.names:
         assert torch.allclose(mine[k].detach().cpu(), named[k].detach(), rtol=0, atol=2e-7), k
+    # the schedule resumes where it stopped: two epochs through fit() -> the checkpoint records epoch 12, a fresh
+    # TrainStep resumed from it trains its first epoch at lr_at_epoch(12), not at epoch 0's lr of 0
+    hist = train.fit(a, [(x, y)], epochs=2, device=dev, first_epoch=10)
+    assert [h["epoch"] for h in hist] == [10, 11] and a.state_dict()["epoch"] == 12
+    t3, g3, net3, x3, y3 = _setup(dev)
+    c = t3.TrainStep(net3, lr=1e-3)
+    first = c.load_state_dict(a.state_dict())
+    assert first == 12 and c.epoch == 12
+    h3 = t3.fit(c, [(x3, y3)], epochs=1, device=dev, first_epoch=first)
+    assert h3[0]["epoch"] == 12 and h3[0]["lr"] == train.lr_at_epoch(12, 1e-3) > 0 and c.state_dict()["epoch"] == 13
 
 
 @pytest.mark.gpu
