@@ -24,7 +24,12 @@ Prints ONE JSON line (rank 0):
   train_step             the training step (BASELINE configs[4]): ms/step at the reference's batch size per GPU
   cpu_baseline           (N=1) the C oracle (oracle/, fp32 accumulation, OpenMP) on this box's host cores: all cores and
                          n=24 (the reference's --threads default), plus the B=1 fox-sentence latency (BASELINE configs[0]) --
-                         a reported baseline, not the target.
+                         a reported baseline, not the target.  `torch_ops`: the same forward as PyTorch CPU ops (SURVEY 8d's own
+                         definition of the baseline) at torch.set_num_threads(24) and at all physical cores
+  small                  (N=1) BASELINE configs[2]: small ES B=256 T=256 on one GPU, like `base`
+  encoder_side           (N=1) stage 1 of the forward alone (everything in front of the mel decoder): us, FLOPs, fraction of the bound
+  roofline.clock/.pipes  the shader clock measured inside the decoder kernel (+ frac re-priced at it) and the per-pipe busy fractions
+                         of the committed PMC pass
 """
 import argparse
 import json
@@ -141,6 +146,13 @@ def cpu_baseline(cfg, sd, T, dur):
                                       f"{phys} cores / {cores} hardware threads visible), layers single-threaded inside a worker")
     except Exception as e:                         # noqa: BLE001
         out["all_cores"] = {"error": repr(e)}
+    # SURVEY 8d's own definition of the CPU baseline: the path restated with PyTorch ops (the nearest thing to the reference's
+    # `--infer-device cpu`, demo.py:130-135, that can travel: tests/torch_mirror.py, pinned to the reference's fixtures) under
+    # torch.set_num_threads(n) at n = 24 (the reference's --threads default, utils/tools.py:324) and n = all physical cores
+    try:
+        out["torch_ops"] = _torch_ops_cpu(cfg, sd, T, dur, n24, min(_physical_cores(), cores))
+    except Exception as e:                         # noqa: BLE001
+        out["torch_ops"] = {"error": repr(e)}
     fox = np.asarray([FOX_IDS], np.int32)
     for threads, key in ((n24, "b1_fox_latency_ms_n24"), (1, "b1_fox_latency_ms_n1")):
         _omp_threads(threads)
@@ -151,6 +163,37 @@ def cpu_baseline(cfg, sd, T, dur):
                           "median of 5")
     _omp_threads(cores)
     return out
+
+
+def _torch_ops_cpu(cfg, sd, T, dur, n24, nall, b=256, runs=3):
+    """The forward as PyTorch CPU ops (oneDNN convolutions, torch softmax / layer_norm / repeat_interleave in the reference's
+    structure: tests/torch_mirror.eval_forward) on the host cores: >= `runs` timed forwards at B = 256 per thread setting."""
+    from tests import torch_mirror as _mirror
+    from efficientspeech_amd.synth import synth_phonemes
+    net = make_net(cfg, sd, "cpu").eval()
+    ids, mask = synth_phonemes(b, T, 99)
+    x = {"phoneme": torch.from_numpy(ids), "phoneme_mask": torch.from_numpy(mask),
+         "duration_forced": torch.full((b, T), dur, dtype=torch.int32)}
+    res, old = {}, torch.get_num_threads()
+    try:
+        for key, n in (("n24", n24), ("all_physical_cores", nall)):
+            torch.set_num_threads(int(n))
+            with torch.no_grad():
+                _mirror.eval_forward(net, x)                       # warm the thread pool and the primitive cache at this width
+                ts, frames = [], 0
+                while len(ts) < runs or (sum(ts) < 6.0 and len(ts) < 20):
+                    t0 = time.perf_counter()
+                    _, mel_len, _ = _mirror.eval_forward(net, x)
+                    ts.append(time.perf_counter() - t0)
+                    frames = int(mel_len.sum())
+            res[key] = {"value": frames / (sum(ts) / len(ts)), "unit": "mel-frames/s", "threads": int(n), "runs": len(ts),
+                        "seconds_per_run": sum(ts) / len(ts), "best_seconds": min(ts)}
+    finally:
+        torch.set_num_threads(old)
+    res["kind"] = "port (PyTorch CPU ops)"
+    res["sample"] = (f"tests/torch_mirror.eval_forward (plain PyTorch ops on CPU tensors, torch {torch.__version__}), {cfg.name} ES full forward, "
+                     f"B={b} T={T} D-const {dur}")
+    return res
 
 
 def _physical_cores():
@@ -221,6 +264,71 @@ def pmc_traffic(config, B, T, dur):
             m = d["mel_decoder"]
             return m["hbm_traffic_bytes_corrected"], os.path.basename(path), m.get("mfma_pipe_utilisation")
     return None, None, None
+
+
+def pmc_pipes(config, B, T, dur):
+    """Per-pipe busy fractions of the mel decoder and the shader clock under the tracer, from the newest committed PMC summary of
+    this workload that has them (profiles/*pmc_counters.json `mel_decoder.pipes`, tools/prof_summary.py) -> (dict, file) or (None, None)."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_counters.json")), reverse=True):
+        try:
+            d = json.load(open(path))
+        except Exception:
+            continue
+        if d.get("workload", "").startswith(f"{config} ES B={B} T={T} D-const {dur} ") and "pipes" in d.get("mel_decoder", {}):
+            return d["mel_decoder"]["pipes"], os.path.basename(path)
+    return None, None
+
+
+def decoder_clock(net, x, dev, steps=20):
+    """Shader clock during the mel decoder kernel, measured INSIDE the kernel (esmi_mel_decoder_clock_probe: s_memtime / s_memrealtime
+    stamps at the start of the launch's first workgroup and of its last one on the same XCD / the first workgroup's last chunk).
+    -> dict or None.  Its own short run outside the timed region; the probe is disarmed again before returning."""
+    from efficientspeech_amd import _lib
+    lib = _lib.load()
+    slots = torch.zeros(4, dtype=torch.int64, device=dev)
+    ghz, span = [], []
+    try:
+        lib.esmi_mel_decoder_clock_probe(slots.data_ptr())
+        with torch.no_grad():
+            for _ in range(steps):
+                net(x)
+                torch.cuda.synchronize(dev)
+                s0, r0, s1, r1 = (int(v) for v in slots.cpu().tolist())
+                if r1 > r0 and s1 > s0:
+                    ghz.append((s1 - s0) / (r1 - r0) * 0.1)
+                    span.append((r1 - r0) * 0.01)
+    finally:
+        lib.esmi_mel_decoder_clock_probe(None)
+    if not ghz:
+        return None
+    return {"shader_ghz": float(np.median(ghz)), "shader_ghz_min_max": [float(min(ghz)), float(max(ghz))], "launches": len(ghz),
+            "span_us": float(np.median(span)),
+            "how": "s_memtime (shader clock) over s_memrealtime (100 MHz) between the start of the launch's first workgroup and the start "
+                   "of its last workgroup on the same XCD (dx2 = 256: the first workgroup's last chunk): span_us of the launch"}
+
+
+def encoder_side(net, x, dev, cfg, B, T, peak_tf, steps=50):
+    """The encoder side by itself (stage 1 of the one-call forward: encoder blocks, Fuse, variance adaptor, length-regulator scan,
+    the decoder's phoneme-rate first stage), back to back on the launch stream, HIP events around the whole loop."""
+    enc_flops = {"tiny": 262_336, "small": 737_664, "base": 4_489_984}[cfg.name]          # SURVEY 8d, per phoneme
+    with torch.no_grad():
+        for _ in range(5):
+            net._launch(x, stage=1)
+        torch.cuda.synchronize(dev)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(steps):
+            net._launch(x, stage=1)
+        e1.record()
+        torch.cuda.synchronize(dev)
+    us = e0.elapsed_time(e1) * 1e3 / steps
+    ach = enc_flops * B * T / (us * 1e-6) / 1e12
+    return {"us": us, "steps": steps, "algorithmic_flops_per_phoneme": enc_flops, "achieved_tflops": ach, "peak": peak_tf,
+            "frac": ach / peak_tf,
+            "note": "stage 1 of esmi_phoneme2mel_forward_f32 alone, back-to-back launches, HIP events around the loop (launch gaps "
+                    "included); FLOPs = SURVEY 8d's matmul-class FLOPs per phoneme (encoder + fuse + 3 predictors), NOT counting "
+                    "the decoder's first stage that also runs here"}
 
 
 def make_net(cfg, sd, dev):
@@ -426,6 +534,27 @@ def main():
                              "enc_fuse_va_kernel)"},
     }
 
+    if rank == 0 and world == 1 and not a.exact_fp32:
+        # ---- what the decoder kernel's time consists of, in the line itself: the clock the chip actually ran it
+        # at (measured inside the kernel), `frac` re-priced at that clock, and the busy fraction of each pipe from the committed PMC pass
+        try:
+            clk = decoder_clock(net, x, dev)
+            if clk:
+                clk["peak_clock_ghz"] = 2.4
+                clk["frac_at_clock"] = out["roofline"]["frac"] * 2.4 / clk["shader_ghz"]
+                clk["note"] = ("roofline.peak assumes the 2.4 GHz peak engine clock; the chip runs this kernel at shader_ghz (power "
+                               "management), so the matrix pipe's own ceiling during the kernel is peak x shader_ghz / 2.4")
+                out["roofline"]["clock"] = clk
+        except Exception as e:                     # noqa: BLE001
+            out["roofline"]["clock"] = {"error": repr(e)}
+        pipes, pipes_src = pmc_pipes(a.config, B, T, a.dur)
+        if pipes:
+            out["roofline"]["pipes"] = dict(pipes, source=pipes_src)
+        try:
+            out["encoder_side"] = encoder_side(net, x, dev, cfg, B, T, peak_tf)
+        except Exception as e:                     # noqa: BLE001
+            out["encoder_side"] = {"error": repr(e)}
+
     if world > 1 and pipe.gather:
         # the exchange by itself: all-gather of one step's mel shards (what every step hides behind the next step's compute)
         mel_shard = torch.randn((B, L, cfg.n_mel_channels), device=dev)
@@ -512,24 +641,33 @@ def main():
                            "mel all-gather one step behind; frames/s counts the real utterances")
             out[key] = res
 
-    def _base_leg():
-        # ---- BASELINE configs[3] on ONE GPU (the 8-GPU run shards exactly this batch): base ES, B = 512, T = 256
+    def _model_leg(name):
+        # ---- BASELINE configs[2] / configs[3] on ONE GPU (the 8-GPU run of configs[3] shards exactly this batch): small ES B = 256 x
+        # T = 256, base ES B = 512 x T = 256
         steps2, warm2 = max(10, a.steps // 5), max(3, a.warmup // 4)
-        res, netb, xb, cfgb, sdb = _forward_leg("base", DEFAULT_BATCH["base"], DEFAULT_PHONEMES["base"], steps2, warm2, gather=False, events=True)
-        fb = DECODER_WORK["base"][0]
-        bb, tb_ = DEFAULT_BATCH["base"], DEFAULT_PHONEMES["base"]
+        res, netb, xb, cfgb, sdb = _forward_leg(name, DEFAULT_BATCH[name], DEFAULT_PHONEMES[name], steps2, warm2, gather=False, events=True)
+        fb = DECODER_WORK[name][0]
+        bb, tb_ = DEFAULT_BATCH[name], DEFAULT_PHONEMES[name]
         lb = tb_ * a.dur
         if "achieved_tflops" in res:
-            res["roofline"] = {"kernel": "mel_decoder_kernel<256,5,8>", "bound": "mfma", "achieved": res["achieved_tflops"], "peak": peak_tf,
+            res["roofline"] = {"kernel": "mel_decoder_kernel<256,5,8>", "traffic_ratio": None, "bound": "mfma", "achieved": res["achieved_tflops"], "peak": peak_tf,
                                "unit": "TFLOP/s", "frac": res["achieved_tflops"] / peak_tf, "algorithmic_flops_per_frame": fb}
-            tr_b, tr_bsrc = trace_kernel_us("base")
+            tr_b, tr_bsrc = trace_kernel_us(name)
             if tr_b:
                 res["roofline"].update(trace_kernel_us=tr_b, trace_source=tr_bsrc, frac_trace=fb * bb * lb / (tr_b * 1e-6) / 1e12 / peak_tf)
-            trf, trf_src, _ = pmc_traffic("base", bb, tb_, a.dur)
+            trf, trf_src, _ = pmc_traffic(name, bb, tb_, a.dur)
             if trf:
                 eb = 4.0 * cfgb.n_mel_channels + 4.0 * cfgb.dx2 / a.dur       # h0 rows (dx2 floats per phoneme) in, mel rows out
                 res["roofline"].update(traffic=trf, traffic_source=trf_src, traffic_ratio=trf / (eb * bb * lb))
-        # D-rand on base
+        try:
+            ck = decoder_clock(netb, xb, dev, steps=5)
+            if ck and "roofline" in res:
+                ck["frac_at_clock"] = res["roofline"]["frac"] * 2.4 / ck["shader_ghz"]
+                res["roofline"]["clock"] = ck
+            res["encoder_side"] = encoder_side(netb, xb, dev, cfgb, bb, tb_, peak_tf, steps=10)
+        except Exception as e:                     # noqa: BLE001
+            res["encoder_side"] = {"error": repr(e)}
+        # D-rand on this model
         rng = np.random.default_rng(1234)
         d_rand = rng.integers(1, 12, size=(bb, tb_)).astype(np.int32)
         l_rand = int(d_rand.sum(1).max())
@@ -548,13 +686,14 @@ def main():
                          "value": int(d_rand.sum()) / tr_, "mel_len_matches": bool(np.array_equal(len_r.cpu().numpy(), d_rand.sum(1)))}
         del netb
         if not a.exact_fp32 and os.path.exists(fp32_lib):
-            r32, n32_, _, _, _ = _forward_leg("base", bb, tb_, max(5, steps2 // 2), 2, gather=False, lib=fp32_lib, events=True)
+            r32, n32_, _, _, _ = _forward_leg(name, bb, tb_, max(5, steps2 // 2), 2, gather=False, lib=fp32_lib, events=True)
             del n32_
             res["exact_fp32"] = {k: r32[k] for k in ("ms_per_step", "value", "steps", "kernel_ms", "achieved_tflops") if k in r32}
             if "achieved_tflops" in r32:
                 res["exact_fp32"]["frac_of_157.3"] = r32["achieved_tflops"] / FP32_PEAK_TFLOPS
-        res["note"] = "BASELINE configs[3] on one GPU: base ES (3.95 M params), B=512 T=256 D-const, full Phoneme2Mel forward"
-        out["base"] = res
+        res["note"] = (f"BASELINE configs[{2 if name == 'small' else 3}] on one GPU: {name} ES ({sum(v.size for v in sdb.values())} params), "
+                       f"B={bb} T={tb_} D-const, full Phoneme2Mel forward")
+        out[name] = res
 
     def _single_gpu_extras():
         steps2, warm2 = max(10, a.steps // 2), max(5, a.warmup // 2)
@@ -705,10 +844,11 @@ def main():
         except Exception as e:                 # noqa: BLE001
             out["extras_error"] = repr(e)
         if a.config == "tiny" and not a.exact_fp32:
-            try:
-                _base_leg()
-            except Exception as e:             # noqa: BLE001
-                out["base"] = {"error": repr(e)}
+            for leg in ("small", "base"):
+                try:
+                    _model_leg(leg)
+                except Exception as e:         # noqa: BLE001
+                    out[leg] = {"error": repr(e)}
     def _train_leg():
         # ---- BASELINE configs[4]: the training step (forward + loss + backward + AdamW; N > 1: one RCCL all-reduce of the flat
         # gradient buffer per step), tiny-ES-shaped synthetic teacher-forced batch of the reference's default batch size per GPU

@@ -142,7 +142,7 @@ EXPORTS = (
     "esmi_encoder_block_workspace_bytes", "esmi_encoder_block_f32", "esmi_pool_mask_u8",
     "esmi_fuse_workspace_bytes", "esmi_fuse_f32", "esmi_variance_adaptor_workspace_bytes",
     "esmi_variance_adaptor_f32", "esmi_length_regulate_i32", "esmi_length_regulator_indices_i32",
-    "esmi_upsample_f32", "esmi_mel_decoder_blob_bytes", "esmi_mel_decoder_pack_f32", "esmi_mel_decoder_f32", "esmi_mel_decoder_workspace_bytes",
+    "esmi_upsample_f32", "esmi_mel_decoder_blob_bytes", "esmi_mel_decoder_pack_f32", "esmi_mel_decoder_f32", "esmi_mel_decoder_workspace_bytes", "esmi_mel_decoder_clock_probe",
     "esmi_mask_rows_f32", "esmi_pack_bfrag_floats", "esmi_pack_bfrag_f32", "esmi_compose_merge_f32", "esmi_max_i32",
     "esmi_self_attention_workspace_bytes", "esmi_self_attention_f32", "esmi_mixffn_workspace_bytes", "esmi_mixffn_f32",
     "esmi_acoustic_decoder_f32", "esmi_bucket_embedding_f32", "esmi_split_weight_limit", "esmi_absmax_f32",
@@ -200,6 +200,7 @@ def bind(lib):
     lib.esmi_mel_decoder_f32.argtypes = [fp, P(DecoderShape), fp, fp, fp, fp, fp, i, i, i, i, i, fp, fp, sz, fp]
     lib.esmi_mel_decoder_workspace_bytes.argtypes = [P(DecoderShape), i, i]
     lib.esmi_mel_decoder_workspace_bytes.restype = sz
+    lib.esmi_mel_decoder_clock_probe.argtypes = [fp]
     lib.esmi_mask_rows_f32.argtypes = [fp, fp, C.c_int64, i, fp]
     lib.esmi_self_attention_workspace_bytes.argtypes = [i, i, i, i]
     lib.esmi_self_attention_workspace_bytes.restype = sz

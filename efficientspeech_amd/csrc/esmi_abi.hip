@@ -741,14 +741,6 @@ int fwd_arena(const esmi_forward_args* a, FwdArena* o) {
     }
     const size_t wv = esmi_fuse_variance_adaptor_workspace_bytes(a->B, a->T, a->dim, a->depth);
     ws = wv > ws ? wv : ws;
-    // the decoder re-uses the encoder side's scratch for its carried rows (dx2 = 256 chunk walk): when the caller knows the output
-    // length at sizing time (L_out > 0) the scratch is made large enough for it, so the one-call forward never drops to the
-    // window form that the module path (which sizes the workspace itself) would not take.  L_out unknown at sizing time (the length
-    // comes from the device): the scratch may be too small for a long batch and the decoder then runs its window form.
-    if (a->L_out > 0) {
-        const size_t wd = esmi_mel_decoder_workspace_bytes(&a->dec_shape, a->B, a->L_out);
-        ws = wd > ws ? wd : ws;
-    }
     const size_t rows = (size_t)a->B * a->T;
     o->ws = off; off += align256(ws);
     o->feat = off; off += align256(rows * 4 * a->dim * 4);
@@ -762,9 +754,18 @@ int fwd_arena(const esmi_forward_args* a, FwdArena* o) {
 }
 }  // namespace
 
+// The decoder re-uses the encoder side's scratch for its carried rows (dx2 = 256 chunk walk).  When that scratch is too small for a
+// batch (few utterances, long output) and the caller knew the output length at sizing time (L_out > 0), the arena carries a tail
+// region for them behind everything else -- the layout of the other regions never depends on L_out, so a stage-2 call with the
+// length filled in later sees the same offsets.  With L_out unknown at sizing time a long batch runs the decoder's window form.
+static size_t fwd_dec_tail(const esmi_forward_args* a, const FwdArena& o) {
+    if (a->L_out <= 0) return 0;
+    const size_t need = esmi_mel_decoder_workspace_bytes(&a->dec_shape, a->B, a->L_out);
+    return need > o.feat - o.ws ? align256(need) : 0;
+}
 size_t esmi_forward_arena_bytes(const esmi_forward_args* a) {
     FwdArena o;
-    return fwd_arena(a, &o) == ESMI_OK ? o.total : 0;
+    return fwd_arena(a, &o) == ESMI_OK ? o.total + fwd_dec_tail(a, o) : 0;
 }
 
 static int forward_impl(const esmi_forward_args* a, int stage, esmi_stream_t stream);
@@ -847,9 +848,12 @@ static int forward_impl(const esmi_forward_args* a, int stage, esmi_stream_t str
         const bool head_ok = fuse_va_head_ok(fuse_va_chain_ok(&a->fuse, a->depth, a->dim, a->fuse_kernel, o.n[0], T, &a->pitch, &a->energy,
                                                               &a->duration, plan), a->dim, &a->head) ||
                              (head_gemm_ok(&a->head) && a->head.d4 == 4 * a->dim && a->head.dx2 == a->dec_shape.dx2);
+        // the decoder's carried rows: the encoder side's scratch (free again), or the arena's tail region when that is too small
+        const size_t dec_need = esmi_mel_decoder_workspace_bytes(&a->dec_shape, B, a->L_out);
+        const bool use_tail = dec_need > o.feat - o.ws && a->arena_bytes >= o.total + dec_need;
         rc = esmi_mel_decoder_f32(a->dec_blob, &a->dec_shape, feat, head_ok ? h0 : nullptr, cum, a->mel_len,
                                   a->lmax_host < 0 ? a->lmax_dev : nullptr, a->lmax_host, mask != nullptr && B > 1, B, T, a->L_out,
-                                  a->mel, base + o.ws, o.feat - o.ws,   // (the encoder side's scratch is free again: the decoder's carried rows)
+                                  a->mel, use_tail ? base + o.total : base + o.ws, use_tail ? a->arena_bytes - o.total : o.feat - o.ws,
                                   stream);
         if (rc) return rc;
     }

@@ -160,6 +160,21 @@ struct MelDecP {
     int carry_lds_layers;  // ... of which the first this many conv layers keep their carried rows in LDS behind the tile (what fits)
     long long* trace;      // development only (-DESMI_DEC_TRACE): [wave][stamp] shader-clock stamps of block (1,0)
 };
+// measurement aid (esmi_mel_decoder_clock_probe, include/esmi.h): two {shader clock, 100 MHz clock} stamps per launch, see the chunk
+// loop.  A device global per translation unit (like the range flag), not a kernel argument: the kernel is at its register limit.
+#ifdef ESMI_WAVESIM
+static long long* g_dec_clk = nullptr;
+#else
+static __device__ long long* g_dec_clk = nullptr;
+#endif
+static inline int store_dec_clock_pointer(long long* slots) {
+#ifdef ESMI_WAVESIM
+    g_dec_clk = slots;
+    return 0;
+#else
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_dec_clk), &slots, sizeof(slots));
+#endif
+}
 
 // conv layers whose carried rows (k/2 rows of dx2 floats each) fit in LDS behind the tile and the parameter slots (dx2 = 256 only)
 template <int DX2>
@@ -297,6 +312,23 @@ __global__ __launch_bounds__(64 * NW, (DX2 <= 128 ? kDecWps128 : NW / 4)) void m
     const int keep = kDecRows - p.halo;      // tile rows of a chunk that stay valid through every layer (the right halo is lost)
     bool edge_window = false;
     unsigned ln_inside = 0;
+    // measurement aid (g_dec_clk above): thread 0 of the FIRST workgroup stamps {shader clock, 100 MHz clock} when it starts -> slot 0;
+    // the LAST workgroup on the same XCD (ids that agree mod 8 share one) when it starts, and (dx2 = 256) the first workgroup at each
+    // later chunk -> slot 1.  (slot 1 - slot 0) spans most of the launch: shader ticks / 100 MHz ticks = the clock the chip ran it at.
+    // Stamps at starts only -- the thread index is live there anyway; an exit stamp costs the kernel a spilled register -- and, for
+    // the one-chunk dx2 = 128 kernel, outside the chunk loop (inside it the store un-hoists the loop's address arithmetic: 28 spills).
+    auto clk_stamp = [&](int ck_) __attribute__((always_inline)) {
+        long long* const clk = g_dec_clk;
+        if (clk && threadIdx.x == 0) {
+            const int last_id = (((int)gridDim.x - 1) / 8) * 8;
+            if (blockIdx.x == 0 || (int)blockIdx.x == last_id) {
+                const int slot = (blockIdx.x == 0 && ck_ == 0) ? 0 : 1;
+                clk[2 * slot] = clock_shader();
+                clk[2 * slot + 1] = clock_real100();
+            }
+        }
+    };
+    if constexpr (!STREAM) clk_stamp(0);
     for (int ck = 0;; ++ck) {
     if constexpr (STREAM) {
         // the thread indices pass through an opaque move per chunk: otherwise everything derived from them is loop-invariant, LICM
@@ -305,6 +337,7 @@ __global__ __launch_bounds__(64 * NW, (DX2 <= 128 ? kDecWps128 : NW / 4)) void m
         lane = tid & 63; i = lane & 31; h = lane >> 5;
         tid16 = (unsigned)tid * 16u; lane16 = (unsigned)lane * 16u;
     }
+    if constexpr (STREAM) clk_stamp(ck);
     const int hl = (ck == 0 && s0 > 0) ? p.halo : 0;
     f0 = s0 + ck * keep - (s0 > 0 ? p.halo : 0);
     f_lo = f0 + hl;

@@ -12,6 +12,10 @@ int launch_mel_decoder_128_5(const MelDecP& p, dim3 grid, hipStream_t st);
 int launch_mel_decoder_128_3(const MelDecP& p, dim3 grid, hipStream_t st);
 int launch_mel_decoder_256_5(const MelDecP& p, dim3 grid, hipStream_t st);
 int launch_mel_decoder_256_3(const MelDecP& p, dim3 grid, hipStream_t st);
+int set_dec_clock_128_5(long long* slots);
+int set_dec_clock_128_3(long long* slots);
+int set_dec_clock_256_5(long long* slots);
+int set_dec_clock_256_3(long long* slots);
 }  // namespace esmi
 
 #ifdef ESMI_DEC_TRACE
@@ -20,6 +24,15 @@ extern "C" void esmi_dev_set_trace(long long* ptr) { g_esmi_trace = ptr; }
 #endif
 
 extern "C" {
+
+// measurement aid (include/esmi.h): arm / disarm the clock probe of every decoder instantiation (one device global per unit)
+int esmi_mel_decoder_clock_probe(int64_t* dev_slots) {
+    long long* s = reinterpret_cast<long long*>(dev_slots);
+    int (*const setters[])(long long*) = {set_dec_clock_128_5, set_dec_clock_128_3, set_dec_clock_256_5, set_dec_clock_256_3};
+    for (auto set : setters)
+        if (int rc = set(s)) return rc;
+    return ESMI_OK;
+}
 
 static int dec_check(const esmi_decoder_shape* s) {
     if (!s) return ESMI_ERR_ARG;

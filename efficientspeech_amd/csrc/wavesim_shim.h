@@ -296,6 +296,22 @@ __device__ __forceinline__ float rcp_fast_f32(float x) {
     return __builtin_amdgcn_rcpf(x);
 #endif
 }
+// the two clocks a wave can read: the shader clock (s_memtime: advances with the frequency the CU runs at) and the constant
+// 100 MHz clock (s_memrealtime); the simulator has neither
+__device__ __forceinline__ long long clock_shader() {
+#ifdef ESMI_WAVESIM
+    return 0;
+#else
+    return (long long)__builtin_amdgcn_s_memtime();
+#endif
+}
+__device__ __forceinline__ long long clock_real100() {
+#ifdef ESMI_WAVESIM
+    return 0;
+#else
+    return (long long)__builtin_amdgcn_s_memrealtime();
+#endif
+}
 // a value the optimiser must treat as freshly computed (see opaque_i in esmi_dev.h)
 __device__ __forceinline__ int opaque_i(int v) {
 #ifndef ESMI_WAVESIM

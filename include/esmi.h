@@ -32,7 +32,8 @@
 extern "C" {
 #endif
 
-#define ESMI_VERSION 400 /* 0.4.0: esmi_decoder_head.proj_w (the decoder's first stage at phoneme rate for every model size:
+#define ESMI_VERSION 500 /* 0.5.0 (round 5): esmi_mel_decoder_clock_probe;
+                            0.4.0: esmi_decoder_head.proj_w (the decoder's first stage at phoneme rate for every model size:
                           * esmi_decoder_head_f32).  0.3.0: training entry points changed shape (esmi_conv_desc: act / packed_fwd / packed_grad; LayerNorm with
                           * residual / row mask / activation arguments; esmi_train_loss_args.grad_seed; esmi_train_pack_weights_f32,
                           * esmi_train_cat_f32, esmi_reduce_queue); activation-range flag.  0.2.0: launch plan per call (no
@@ -382,6 +383,12 @@ int esmi_mel_decoder_f32(const float* blob, const esmi_decoder_shape* s, const f
                          esmi_stream_t stream);
 /* scratch for the dx2 = 256 kernel's carried rows (a workgroup walks its share of an utterance chunk by chunk; 0 for dx2 = 128) */
 size_t esmi_mel_decoder_workspace_bytes(const esmi_decoder_shape* s, int B, int L_out);
+/* Measurement aid (bench.py `roofline.clock`), not part of the data path: arm (dev_slots != NULL: 4 int64 in device memory) or disarm
+ * (NULL) a probe that every following esmi_mel_decoder_f32 launch fills with {shader clock, 100 MHz clock} read when its first
+ * workgroup starts (slots 0, 1) and when the last workgroup on the same XCD starts / the first workgroup starts its last chunk
+ * (slots 2, 3): (shader ticks / 100 MHz ticks) x 100 MHz is the clock the chip ran the kernel at, which `roofline.peak` (quoted at
+ * 2.4 GHz) has to be scaled by.  Process-wide.                                                                               */
+int esmi_mel_decoder_clock_probe(int64_t* dev_slots);
 /* ------------------------------------------------------------------ whole inference forward in ONE call
  * Phoneme2Mel.forward (eval), layers/networks.py:415-434 = Encoder blocks -> Fuse + variance adaptor (+ length-regulator scan,
  * + the decoder's phoneme-rate first stage when the fused kernel serves the shape) -> fused mel decoder, enqueued by a C

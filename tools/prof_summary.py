@@ -72,6 +72,14 @@ def workload_tag(bench):
             f"{bench['n_gpus']}x MI355X")
 
 
+def trace_avg_us(d, kernel_prefix):
+    path = find(os.path.join(d, "stats"), "*kernel_trace.csv")
+    if not path:
+        return None
+    ts = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in csv.DictReader(open(path)) if kernel_prefix in r["Kernel_Name"]]
+    return sum(ts) / len(ts) if ts else None
+
+
 def scratch_bytes(d, kernel_prefix):
     path = find(os.path.join(d, "stats"), "*kernel_trace.csv")
     if path:
@@ -129,6 +137,28 @@ def main():
                 o["mfma_insts"] = m["SQ_INSTS_MFMA"]
             if "SQ_LDS_BANK_CONFLICT" in m and "SQ_ACTIVE_INST_LDS" in m:
                 o["lds_bank_conflict_over_active"] = m["SQ_LDS_BANK_CONFLICT"] / m["SQ_ACTIVE_INST_LDS"]
+            # per-pipe busy fractions with rocprofiler-sdk's own derived-metric definitions for gfx950 (counter_defs.yaml: MfmaUtil,
+            # VALUBusy, LdsUtil); GRBM_GUI_ACTIVE is summed over the 8 XCDs here (the definitions take its max = sum / 8),
+            # CU_NUM = 256, SIMD_NUM = 1024
+            if "GRBM_GUI_ACTIVE" in m:
+                gui = m["GRBM_GUI_ACTIVE"] / 8.0
+                pipes = {}
+                if "SQ_VALU_MFMA_BUSY_CYCLES" in m:
+                    pipes["MfmaUtil"] = m["SQ_VALU_MFMA_BUSY_CYCLES"] / (gui * 1024)
+                if "SQ_ACTIVE_INST_VALU" in m:
+                    pipes["VALUBusy"] = m["SQ_ACTIVE_INST_VALU"] / 256 / gui
+                if "SQ_LDS_IDX_ACTIVE" in m:
+                    pipes["LdsUtil"] = m["SQ_LDS_IDX_ACTIVE"] / (gui * 256)
+                if "SQ_VALU_MFMA_COEXEC_CYCLES" in m:
+                    pipes["valu_mfma_coexec_over_gui_simd"] = m["SQ_VALU_MFMA_COEXEC_CYCLES"] / (gui * 1024)
+                if "SQ_WAIT_INST_ANY" in m and "SQ_WAVE_CYCLES" in m:
+                    pipes["wait_inst_any_over_wave_cycles"] = m["SQ_WAIT_INST_ANY"] / m["SQ_WAVE_CYCLES"]
+                tr = trace_avg_us(d, "mel_decoder_kernel")
+                if tr:
+                    pipes["shader_ghz_under_tracer"] = gui / tr / 1e3      # busy cycles of one XCD / trace-average duration
+                    pipes["trace_avg_us"] = tr
+                pipes["definitions"] = "rocprofiler-sdk counter_defs.yaml (gfx950): MfmaUtil = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x SIMD_NUM), VALUBusy = SQ_ACTIVE_INST_VALU / CU_NUM / GRBM_GUI_ACTIVE, LdsUtil = SQ_LDS_IDX_ACTIVE / (GRBM_GUI_ACTIVE x CU_NUM)"
+                o["pipes"] = pipes
             sc = scratch_bytes(d, "mel_decoder_kernel")
             if sc is not None:
                 o["scratch_bytes_per_lane"] = sc
