@@ -282,7 +282,7 @@ def pmc_pipes(config, B, T, dur):
 
 def decoder_clock(net, x, dev, steps=20):
     """Shader clock during the mel decoder kernel, measured INSIDE the kernel (esmi_mel_decoder_clock_probe: s_memtime / s_memrealtime
-    stamps at the start of the launch's first workgroup and of its last one on the same XCD / the first workgroup's last chunk).
+    stamps by the launch's first workgroup: at its start and at the start of its last stage / chunk).
     -> dict or None.  Its own short run outside the timed region; the probe is disarmed again before returning."""
     from efficientspeech_amd import _lib
     lib = _lib.load()
@@ -305,7 +305,7 @@ def decoder_clock(net, x, dev, steps=20):
     return {"shader_ghz": float(np.median(ghz)), "shader_ghz_min_max": [float(min(ghz)), float(max(ghz))], "launches": len(ghz),
             "span_us": float(np.median(span)),
             "how": "s_memtime (shader clock) over s_memrealtime (100 MHz) between the start of the launch's first workgroup and the start "
-                   "of its last workgroup on the same XCD (dx2 = 256: the first workgroup's last chunk): span_us of the launch"}
+                   "of its last stage (dx2 = 256: of its last chunk): span_us of that workgroup's life"}
 
 
 def encoder_side(net, x, dev, cfg, B, T, peak_tf, steps=50):

@@ -114,7 +114,7 @@ class ForwardArgs(C.Structure):
 
 
 # launch-plan bits (include/esmi.h ESMI_FUSE_*): passed per call, the library keeps no state
-FUSE_MERGE_QKV, FUSE_ATTN_FFN, FUSE_VARIANCE, FUSE_SPLIT2, FUSE_BLOCK, FUSE_ALL = 1, 2, 4, 8, 16, 31
+FUSE_MERGE_QKV, FUSE_ATTN_FFN, FUSE_VARIANCE, FUSE_SPLIT2, FUSE_BLOCK, FUSE_CHAIN16, FUSE_ALL = 1, 2, 4, 8, 16, 32, 63
 
 
 _tls = threading.local()

@@ -395,7 +395,10 @@ int esmi_fuse_variance_adaptor_f32(const esmi_fuse_weights* fw, int depth, int d
         const bool scan_fused = cum && p.halo == 0;   // one workgroup sees every duration of its utterance
         p.cum = scan_fused ? cum : nullptr; p.mel_len = scan_fused ? mel_len : nullptr;
         if (head_in_chain) { p.head_w = head->proj_wp; p.head_b = head->proj_b; p.head_g = head->ln_g; p.head_beta = head->ln_b; p.h0 = h0; }
-        if (int rc = launch_enc_fuse_va(p, dim, kernel, nw, head_in_chain, S(stream))) return rc;
+        int rc16 = ESMI_ERR_UNSUPPORTED;
+        if ((plan & ESMI_FUSE_CHAIN16) && scan_fused == (cum != nullptr)) rc16 = launch_enc_va16(p, dim, kernel, S(stream));
+        if (rc16 == ESMI_ERR_UNSUPPORTED) rc16 = launch_enc_fuse_va(p, dim, kernel, nw, head_in_chain, S(stream));
+        if (rc16) return rc16;
         if (cum && !scan_fused) ESMI_LAUNCH(length_regulate_kernel, dim3(B), dim3(64), 0, S(stream), dur, T, cum, mel_len, (int*)nullptr);
         if (h0 && !head_in_chain) return esmi_decoder_head_f32(head, (long)B * T, feat, h0, stream);
         return launch_status();
@@ -777,7 +780,7 @@ int esmi_phoneme2mel_forward_f32(const esmi_forward_args* a, int stage, esmi_str
     hipError_t e = hipMemsetAsync(a->range_flag, 0, sizeof(int32_t), S(stream));
     if (e != hipSuccess) return (int)e;
     int (*const setters[])(int*) = {set_range_flag_abi, set_range_flag_convgemm, set_range_flag_attention, set_range_flag_enc_merge,
-                                    set_range_flag_enc_block, set_range_flag_enc_attn_ffn, set_range_flag_enc_fuse_va,
+                                    set_range_flag_enc_block, set_range_flag_enc_attn_ffn, set_range_flag_enc_fuse_va, set_range_flag_enc_va16,
                                     set_range_flag_decoder, set_range_flag_dec_128_5, set_range_flag_dec_128_3, set_range_flag_dec_256_5,
                                     set_range_flag_dec_256_3, set_range_flag_hifigan, set_range_flag_train};
     for (auto set : setters)

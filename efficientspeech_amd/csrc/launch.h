@@ -55,6 +55,8 @@ int launch_enc_merge_qkv(const EncMergeP& p, int c_in, int c_out, hipStream_t st
 int launch_enc_block(const EncAttnFfnP& p, int expansion, int c_in, int plan, hipStream_t st);
 int launch_enc_attn_ffn(const EncAttnFfnP& p, int expansion, int plan, hipStream_t st);
 int launch_enc_fuse_va(const FuseVaP& p, int dim, int kernel, int nw, bool head, hipStream_t st);
+// tu_enc_va16.hip (round 5: 16-row tiles, weights through LDS; ESMI_ERR_UNSUPPORTED for the shapes it is not built for)
+int launch_enc_va16(const FuseVaP& p, int dim, int kernel, hipStream_t st);
 // tu_hifigan.hip
 int launch_resblock(const ResblockP& p, int c, hipStream_t st);
 
@@ -81,6 +83,7 @@ int set_range_flag_enc_merge(int* flag);
 int set_range_flag_enc_block(int* flag);
 int set_range_flag_enc_attn_ffn(int* flag);
 int set_range_flag_enc_fuse_va(int* flag);
+int set_range_flag_enc_va16(int* flag);
 int set_range_flag_decoder(int* flag);
 int set_range_flag_dec_128_5(int* flag);
 int set_range_flag_dec_128_3(int* flag);

@@ -312,17 +312,17 @@ __global__ __launch_bounds__(64 * NW, (DX2 <= 128 ? kDecWps128 : NW / 4)) void m
     const int keep = kDecRows - p.halo;      // tile rows of a chunk that stay valid through every layer (the right halo is lost)
     bool edge_window = false;
     unsigned ln_inside = 0;
-    // measurement aid (g_dec_clk above): thread 0 of the FIRST workgroup stamps {shader clock, 100 MHz clock} when it starts -> slot 0;
-    // the LAST workgroup on the same XCD (ids that agree mod 8 share one) when it starts, and (dx2 = 256) the first workgroup at each
-    // later chunk -> slot 1.  (slot 1 - slot 0) spans most of the launch: shader ticks / 100 MHz ticks = the clock the chip ran it at.
-    // Stamps at starts only -- the thread index is live there anyway; an exit stamp costs the kernel a spilled register -- and, for
-    // the one-chunk dx2 = 128 kernel, outside the chunk loop (inside it the store un-hoists the loop's address arithmetic: 28 spills).
+    // measurement aid (g_dec_clk above): the FIRST workgroup stamps {shader clock, 100 MHz clock} when it starts -> slot 0, and again
+    // -> slot 1 at the start of each later chunk (dx2 = 256) / in front of its mel stage (dx2 = 128, one chunk).  (slot 1 - slot 0) is a
+    // long stretch of the workgroup's life: shader ticks / 100 MHz ticks = the clock the CU ran at.  Both stamps come from ONE workgroup:
+    // the s_memtime counters of different CUs are not comparable (a first version differenced two workgroups and read 9 GHz on some
+    // boxes).  No stamp at the very end of the kernel (it costs a spilled register) nor inside the one-chunk kernel's chunk loop (the
+    // store un-hoists the loop's address arithmetic: 28 spills).
     auto clk_stamp = [&](int ck_) __attribute__((always_inline)) {
         long long* const clk = g_dec_clk;
         if (clk && threadIdx.x == 0) {
-            const int last_id = (((int)gridDim.x - 1) / 8) * 8;
-            if (blockIdx.x == 0 || (int)blockIdx.x == last_id) {
-                const int slot = (blockIdx.x == 0 && ck_ == 0) ? 0 : 1;
+            if (blockIdx.x == 0) {
+                const int slot = ck_ == 0 ? 0 : 1;
                 clk[2 * slot] = clock_shader();
                 clk[2 * slot + 1] = clock_real100();
             }
@@ -886,6 +886,13 @@ __global__ __launch_bounds__(64 * NW, (DX2 <= 128 ? kDecWps128 : NW / 4)) void m
     }
 
     // ---- mel Linear(dx2, n_mel) on skip (held in the tile), masked store
+    if constexpr (!STREAM) {   // clock probe, second stamp of the one-chunk kernel: the first workgroup again, in front of its last stage
+        long long* const clk = g_dec_clk;     // (s_memtime counters of different CUs are not comparable: both stamps come from one workgroup)
+        if (clk && blockIdx.x == 0) {         // every thread of the workgroup stores (a wave's pair in one 16-byte store): a test for one
+            typedef long long i64x2 __attribute__((ext_vector_type(2)));   // thread would keep a lane register alive across the layers
+            *reinterpret_cast<i64x2*>(clk + 2) = i64x2{clock_shader(), clock_real100()};
+        }
+    }
     if (n_layers == 0) {   // (degenerate: proj output straight into the mel Linear, fp32 rows)
         fetch_B(0);
         __syncthreads();

@@ -369,7 +369,12 @@ __device__ __forceinline__ void buf_st(const BufRsrc& r, unsigned off, float v) 
 __device__ __forceinline__ void buf_st_i(const BufRsrc& r, unsigned off, int v) {
     if (off < r.bytes && off + 4u <= r.bytes) *reinterpret_cast<int*>(const_cast<char*>(r.base) + off) = v;
 }
+__device__ __forceinline__ void buf_st4(const BufRsrc& r, unsigned off, const f32x4& v) {
+    if (off < r.bytes && off + 16u <= r.bytes) *reinterpret_cast<f32x4*>(const_cast<char*>(r.base) + off) = v;
+}
 __device__ __forceinline__ void lds_wave_sync() { wavesim::shfl_i(0, 0); }   // a wave-level collective: all 64 fibers arrive
+__device__ __forceinline__ void wait_vm0() {}                                // (LDS-DMA is synchronous in the simulator)
+__device__ __forceinline__ void wg_sync_lds() { __syncthreads(); }
 #else
 typedef __amdgpu_buffer_rsrc_t BufRsrc;
 __device__ __forceinline__ BufRsrc make_rsrc(const void* p, long bytes) {
@@ -396,6 +401,16 @@ __device__ __forceinline__ void buf_st(BufRsrc r, unsigned off, float v) {
 __device__ __forceinline__ void buf_st_i(BufRsrc r, unsigned off, int v) {
     __builtin_amdgcn_raw_buffer_store_b32((unsigned)v, r, (int)off, 0, 0);
 }
+__device__ __forceinline__ void buf_st4(BufRsrc r, unsigned off, const f32x4& v) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, (int)off, 0, 0);
+}
+// every global / LDS-DMA operation of this wave has completed (the LDS-DMA writes are visible to the wave; a workgroup barrier
+// behind it makes them visible to the others)
+__device__ __forceinline__ void wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// Workgroup barrier for LDS hand-offs only: this wave's LDS operations are complete, then s_barrier.  Unlike __syncthreads() it does
+// NOT drain the vector-memory queue, so LDS-DMA weight copies for a later stage (and output stores) stay in flight across it; a
+// barrier that publishes DMA'd data is `wait_vm0(); wg_sync_lds();`.
+__device__ __forceinline__ void wg_sync_lds() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 // Hand-off through LDS between lanes of ONE wave (tile_store -> A-fragment reads): LDS operations of a wave execute
 // in issue order, so only the compiler has to be kept from reordering; no s_barrier, and global loads in flight
 // (weight prefetches) stay in flight.

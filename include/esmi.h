@@ -63,7 +63,10 @@ const char* esmi_build_config(void);
 #define ESMI_FUSE_VARIANCE 4  /* Fuse + 3 predictors + embeddings + round */
 #define ESMI_FUSE_SPLIT2 8    /* two-head blocks on short sequences: two waves per row tile */
 #define ESMI_FUSE_BLOCK 16    /* whole encoder block in one launch when one workgroup covers the sequence */
-#define ESMI_FUSE_ALL 31
+#define ESMI_FUSE_CHAIN16 32  /* round 5: the 16-row-tile chain kernels (two waves per SIMD, weights once per workgroup through LDS) for
+                               * the shapes they are built for (dim = 32 models, one workgroup per utterance); without the bit the
+                               * round-1..4 chain kernels run those shapes too */
+#define ESMI_FUSE_ALL 63
 
 /* ------------------------------------------------------------------ weight packing
  * nn.Conv1d weight (Cout, Cin, k) -> (k, Cout, Cin)            [networks.py:40-42, blocks.py:17] */
@@ -384,10 +387,9 @@ int esmi_mel_decoder_f32(const float* blob, const esmi_decoder_shape* s, const f
 /* scratch for the dx2 = 256 kernel's carried rows (a workgroup walks its share of an utterance chunk by chunk; 0 for dx2 = 128) */
 size_t esmi_mel_decoder_workspace_bytes(const esmi_decoder_shape* s, int B, int L_out);
 /* Measurement aid (bench.py `roofline.clock`), not part of the data path: arm (dev_slots != NULL: 4 int64 in device memory) or disarm
- * (NULL) a probe that every following esmi_mel_decoder_f32 launch fills with {shader clock, 100 MHz clock} read when its first
- * workgroup starts (slots 0, 1) and when the last workgroup on the same XCD starts / the first workgroup starts its last chunk
- * (slots 2, 3): (shader ticks / 100 MHz ticks) x 100 MHz is the clock the chip ran the kernel at, which `roofline.peak` (quoted at
- * 2.4 GHz) has to be scaled by.  Process-wide.                                                                               */
+ * (NULL) a probe that the FIRST workgroup of every following esmi_mel_decoder_f32 launch fills with {shader clock, 100 MHz clock} read
+ * when it starts (slots 0, 1) and when it starts its last chunk / its last stage (slots 2, 3): (shader ticks / 100 MHz ticks) x 100 MHz
+ * is the clock the CU ran the kernel at, which `roofline.peak` (quoted at 2.4 GHz) has to be scaled by.  Process-wide.             */
 int esmi_mel_decoder_clock_probe(int64_t* dev_slots);
 /* ------------------------------------------------------------------ whole inference forward in ONE call
  * Phoneme2Mel.forward (eval), layers/networks.py:415-434 = Encoder blocks -> Fuse + variance adaptor (+ length-regulator scan,

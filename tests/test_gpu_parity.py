@@ -43,8 +43,8 @@ def nets():
 
 # launch plans: everything fused (default: whole-block kernels, column split, scan inside the variance kernel), one chain
 # kernel per stage (merge+qkv | attention+FFN | fuse+variance; also what long sequences use), one kernel per reference op
-PLANS = [_lib.FUSE_ALL, 7, 0]
-PLAN_IDS = ["fused", "staged", "unfused"]
+PLANS = [_lib.FUSE_ALL, 31, 7, 0]     # round-5 chain16 kernels | round-1..4 chain kernels | per-stage | per-op
+PLAN_IDS = ["fused", "fused_r4", "staged", "unfused"]
 
 
 @pytest.mark.parametrize("fusion", PLANS, ids=PLAN_IDS)

@@ -13,8 +13,10 @@ ids, mask = synth_phonemes(B, T, 1)
 x = {"phoneme": torch.from_numpy(ids).cuda(), "phoneme_mask": torch.from_numpy(mask).cuda(),
      "duration_forced": torch.full((B, T), 6, dtype=torch.int32, device="cuda"), "max_mel_len": 768}
 tr = torch.zeros((6, 64), dtype=torch.int64, device="cuda")
-setters = [getattr(lib, "esmi_dev_set_chain_trace_" + tu) for tu in ("enc_attn_ffn", "enc_block", "enc_fuse_va", "enc_merge")]
+setters = [getattr(lib, "esmi_dev_set_chain_trace_" + tu) for tu in ("enc_attn_ffn", "enc_block", "enc_fuse_va", "enc_merge", "enc_va16", "enc_block16") if hasattr(lib, "esmi_dev_set_chain_trace_" + tu)]
 for f in setters: f.argtypes = [C.c_void_p]
+plan = int(sys.argv[2]) if len(sys.argv) > 2 else _lib.FUSE_ALL
+ctx = _lib.launch_plan(plan); ctx.__enter__()
 for _ in range(3): net(x)
 for f in setters: f(tr.data_ptr())
 net(x); torch.cuda.synchronize()
