@@ -181,7 +181,8 @@ int esmi_encoder_block_f32(const esmi_encoder_block_weights* w, const esmi_encod
         if (w->qk_wp && w->vo_wp) {   // weight-folded attention inside the whole-block kernels: a third of the q / k / v contraction
             fb.fold = 1; fb.m.qkv_w = w->qk_wp; fb.m.nq_override = 0; fb.proj_w = w->vo_wp;
         }
-        rc = launch_enc_block(fb, s->expansion, s->c_in, plan, st);
+        rc = (plan & ESMI_FUSE_CHAIN16) ? launch_enc_block16(fb, s->expansion, s->c_in, st) : ESMI_ERR_UNSUPPORTED;
+        if (rc == ESMI_ERR_UNSUPPORTED) rc = launch_enc_block(fb, s->expansion, s->c_in, plan, st);
         if (rc != ESMI_ERR_UNSUPPORTED) return rc;
     }
     if (packed && (plan & ESMI_FUSE_MERGE_QKV)) {   // E1: merge conv + 1x1 + qkv as one wave-chain kernel
@@ -780,7 +781,7 @@ int esmi_phoneme2mel_forward_f32(const esmi_forward_args* a, int stage, esmi_str
     hipError_t e = hipMemsetAsync(a->range_flag, 0, sizeof(int32_t), S(stream));
     if (e != hipSuccess) return (int)e;
     int (*const setters[])(int*) = {set_range_flag_abi, set_range_flag_convgemm, set_range_flag_attention, set_range_flag_enc_merge,
-                                    set_range_flag_enc_block, set_range_flag_enc_attn_ffn, set_range_flag_enc_fuse_va, set_range_flag_enc_va16,
+                                    set_range_flag_enc_block, set_range_flag_enc_attn_ffn, set_range_flag_enc_fuse_va, set_range_flag_enc_va16, set_range_flag_enc_block16,
                                     set_range_flag_decoder, set_range_flag_dec_128_5, set_range_flag_dec_128_3, set_range_flag_dec_256_5,
                                     set_range_flag_dec_256_3, set_range_flag_hifigan, set_range_flag_train};
     for (auto set : setters)

@@ -57,6 +57,8 @@ int launch_enc_attn_ffn(const EncAttnFfnP& p, int expansion, int plan, hipStream
 int launch_enc_fuse_va(const FuseVaP& p, int dim, int kernel, int nw, bool head, hipStream_t st);
 // tu_enc_va16.hip (round 5: 16-row tiles, weights through LDS; ESMI_ERR_UNSUPPORTED for the shapes it is not built for)
 int launch_enc_va16(const FuseVaP& p, int dim, int kernel, hipStream_t st);
+// tu_enc_block16.hip (round 5: whole-block kernels of dim = 32 models on 16-row tiles)
+int launch_enc_block16(const EncAttnFfnP& p, int expansion, int c_in, hipStream_t st);
 // tu_hifigan.hip
 int launch_resblock(const ResblockP& p, int c, hipStream_t st);
 
@@ -84,6 +86,7 @@ int set_range_flag_enc_block(int* flag);
 int set_range_flag_enc_attn_ffn(int* flag);
 int set_range_flag_enc_fuse_va(int* flag);
 int set_range_flag_enc_va16(int* flag);
+int set_range_flag_enc_block16(int* flag);
 int set_range_flag_decoder(int* flag);
 int set_range_flag_dec_128_5(int* flag);
 int set_range_flag_dec_128_3(int* flag);

@@ -1,0 +1,46 @@
+// esmi C-ABI, translation unit "tu_enc_block16.hip": the round-5 whole-block chain kernels of dim = 32 models (enc_block16.h: 16-row
+// tiles, two waves per SIMD, weights once per workgroup through LDS).  Internal launchers are declared in launch.h.
+#include "launch.h"
+#include "enc_block16.h"
+
+using namespace esmi;
+ESMI_TU_RANGE_SETTER(enc_block16)
+ESMI_TU_CHAIN_TRACE_SETTER(enc_block16)
+
+namespace esmi {
+
+// Whole encoder block in one launch, weight-folded attention (EncAttnFfnP::fold), one workgroup per utterance:
+//   block 0 of tiny ES (C = 32, one head, k = 3 stride-1 merge conv folded into embedding tables), N <= 128;
+//   block 1 of tiny ES (C = 64, two heads, k = 1 stride-2 merge conv from 32 channels), N <= 64.
+// ESMI_ERR_UNSUPPORTED otherwise (-> launch_enc_block).  The split-f16 build only.
+int launch_enc_block16(const EncAttnFfnP& p, int expansion, int c_in, hipStream_t st) {
+#if ESMI_CHAIN_SPLIT
+    if (!p.fold || expansion != 1 || p.N < 1 || !p.m.qkv_w || !p.proj_w || !p.ffn_w || !p.mlp2_w) return ESMI_ERR_UNSUPPORTED;
+    EncAttnFfnP q = p;
+    q.wgs_per_b = 1; q.halo = 0;
+    if (p.C == 32 && p.h == 1 && p.m.k == 3 && p.m.stride == 1 && p.m.ids && p.m.emb_conv && p.N <= 128 && p.m.n_in == p.N) {
+        const int nw = (p.N + 15) / 16, lds = B016Lds::total * (int)sizeof(float);
+#define ESMI_B0(NKT) { static AttrOnce once;                                                                              \
+        if (int rc = raise_lds_limit(reinterpret_cast<const void*>(enc_b0_16_kernel<NKT>), once)) return rc;               \
+        ESMI_LAUNCH((enc_b0_16_kernel<NKT>), dim3(p.B), dim3(64 * nw), lds, st, q); return launch_status(); }
+        if (nw <= 2) ESMI_B0(2)
+        if (nw <= 4) ESMI_B0(4)
+        ESMI_B0(8)
+#undef ESMI_B0
+    }
+    if (p.C == 64 && p.h == 2 && p.m.k == 1 && p.m.stride == 2 && c_in == 32 && p.m.x_in && !p.m.ids && p.N <= 64 &&
+        p.m.n_in >= 2 * p.N - 1) {
+        const int nrt = (p.N + 15) / 16, lds = B116Lds::total * (int)sizeof(float);
+        static AttrOnce once;
+        if (int rc = raise_lds_limit(reinterpret_cast<const void*>(enc_b1_16_kernel), once)) return rc;
+        ESMI_LAUNCH(enc_b1_16_kernel, dim3(p.B), dim3(128 * nrt), lds, st, q);
+        return launch_status();
+    }
+    return ESMI_ERR_UNSUPPORTED;
+#else
+    (void)p; (void)expansion; (void)c_in; (void)st;
+    return ESMI_ERR_UNSUPPORTED;
+#endif
+}
+
+}  // namespace esmi
