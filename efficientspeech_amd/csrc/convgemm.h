@@ -386,10 +386,8 @@ constexpr int kGemmRowDw = 20;   // dwords per weight row and plane in LDS (weig
 template <int NT>
 __host__ __device__ constexpr int convgemm_lds_bytes() { return 2 * 2 * 32 * NT * kGemmRowDw * 4; }
 
-#ifndef ESMI_GEMM_LDS_WAVES
-#define ESMI_GEMM_LDS_WAVES 4   // waves sharing one weight tile.  8 halves each wave's share of the staging work but couples 8 waves
-                                // to one barrier: 11.50 vs 10.45 ms/step on base ES in round 2, +2 % on the round-3 kernel: 4
-#endif
+constexpr int kGemmLdsWaves = 4;   // waves sharing one weight tile.  8 halves each wave's share of the staging work but couples 8 waves
+                                   // to one barrier: 11.50 vs 10.45 ms/step on base ES in round 2, +2 % on the round-3 kernel: 4
 #ifdef ESMI_GEMM_TRACE
 extern __device__ long long* g_gemm_trace_dev;
 #endif
@@ -399,11 +397,11 @@ __host__ __device__ inline int convgemm_dma_tile_rows(int mt, int k, int dil) { 
     return 32 * mt + (reach <= kGemmHaloMax ? (reach + 7) / 8 * 8 : 0);
 }
 template <int NT>
-__host__ __device__ inline int convgemm_dma_bytes(int mt, int k, int dil, bool pre, int nwv = ESMI_GEMM_LDS_WAVES) {
+__host__ __device__ inline int convgemm_dma_bytes(int mt, int k, int dil, bool pre, int nwv = kGemmLdsWaves) {
     return (pre ? 2 * 4 * NT * 1024 : convgemm_lds_bytes<NT>()) + nwv * convgemm_dma_tile_rows(mt, k, dil) * 128;
 }
 
-template <int NT, int MT, int NWV = ESMI_GEMM_LDS_WAVES, bool AMP = false, bool PRE = false>
+template <int NT, int MT, int NWV = kGemmLdsWaves, bool AMP = false, bool PRE = false>
 __global__ __launch_bounds__(64 * NWV, 2) void convgemm_dma_kernel(const ConvGemmP p, int nx, int ny) {
     constexpr int BN = 32 * NT, PLANE = BN * kGemmRowDw, NTHR = 64 * NWV, NU = (256 * NT) / NTHR, WROWS = 32 * MT, ROWS = WROWS * NWV;
     static_assert(NU * NTHR == 256 * NT, "staging items divide evenly");

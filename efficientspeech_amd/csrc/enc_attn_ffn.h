@@ -19,10 +19,6 @@
 #include "enc_merge_qkv.h"
 #include "wave_chain.h"
 
-#ifndef ESMI_E2_WPS
-#define ESMI_E2_WPS ESMI_CHAIN_WPS
-#endif
-
 namespace esmi {
 
 struct EncAttnFfnP {
@@ -385,7 +381,7 @@ __device__ __forceinline__ void enc_attn_ffn_body(const EncAttnFfnP& p) {
             y[nt][r] += pb_[nt] + xr;
         }
     }
-    layernorm_tile_regs_staged<NC>(y, g1_, be1_);
+    layernorm_tile_regs<NC>(y, g1_, be1_);
 #pragma unroll
     for (int nt = 0; nt < NC; ++nt) {
 #pragma unroll
@@ -430,7 +426,7 @@ __device__ __forceinline__ void enc_attn_ffn_body(const EncAttnFfnP& p) {
         for (int r = 0; r < 16; ++r) z[nt][r] += b2_[nt] + y[nt][r];
     }
     ESMI_CT();   // 8 mlp2
-    layernorm_tile_regs_staged<NC>(z, g2_, be2_);
+    layernorm_tile_regs<NC>(z, g2_, be2_);
     ESMI_CT();   // 9 LN2
     const int row_lo = p.halo, row_hi = 32 * nw - p.halo;   // workgroup-local rows this workgroup stores
 #pragma unroll
@@ -444,7 +440,7 @@ __device__ __forceinline__ void enc_attn_ffn_body(const EncAttnFfnP& p) {
 }
 
 template <int NKT, int NC, int E, int NCI = 0, int KT = 1, int STRIDE = 1>
-__global__ __launch_bounds__(64 * kEncMaxWaves, ESMI_E2_WPS) void enc_attn_ffn_kernel(const EncAttnFfnP p) {
+__global__ __launch_bounds__(64 * kEncMaxWaves, kChainWps) void enc_attn_ffn_kernel(const EncAttnFfnP p) {
     enc_attn_ffn_body<NKT, NC, E, NCI, KT, STRIDE>(p);
 }
 
@@ -485,7 +481,8 @@ __device__ __forceinline__ void layernorm_split(f32x16 (&v)[NH], const float (&g
 #pragma unroll
         for (int nt = 0; nt < NH; ++nt) mean_l[r] += v[nt][r];
     }
-    row_sum32_x16(mean_l);      // stage by stage: the 16 xor-16 round trips in flight together (esmi_dev.h)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) mean_l[r] = row_sum32(mean_l[r]);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         mean_l[r] *= inv_h;
@@ -496,7 +493,8 @@ __device__ __forceinline__ void layernorm_split(f32x16 (&v)[NH], const float (&g
             m2_l[r] = fmaf(d, d, m2_l[r]);
         }
     }
-    row_sum32_x16(m2_l);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) m2_l[r] = row_sum32(m2_l[r]);
     __syncthreads();            // the statistics buffer is free (previous LayerNorm fully consumed)
     float* mine = stats + ((rt * 2 + c) * 32) * 2;
     const float* other = stats + ((rt * 2 + (c ^ 1)) * 32) * 2;
@@ -802,7 +800,7 @@ __device__ __forceinline__ void enc_attn_ffn_split_body(const EncAttnFfnP& p) {
 }
 
 template <int NKT, int NC, int E, int NCI = 0, int KT = 1, int STRIDE = 1>
-__global__ __launch_bounds__(128 * kEncSplitMaxTiles, ESMI_E2_WPS) void enc_attn_ffn_split_kernel(const EncAttnFfnP p) {
+__global__ __launch_bounds__(128 * kEncSplitMaxTiles, kChainWps) void enc_attn_ffn_split_kernel(const EncAttnFfnP p) {
     enc_attn_ffn_split_body<NKT, NC, E, NCI, KT, STRIDE>(p);
 }
 

@@ -12,10 +12,6 @@
 #include "small_kernels.h"
 #include "wave_chain.h"
 
-#ifndef ESMI_E3_WPS
-#define ESMI_E3_WPS ESMI_CHAIN_WPS
-#endif
-
 namespace esmi {
 
 struct PredW {   // conv1_w / conv2_w in MFMA B-fragment order (esmi_pack_bfrag_f32)
@@ -75,6 +71,67 @@ inline void fuse_va_plan(int n, int dim, int depth, int* nw, int* wgs, int* usef
     }
     *nw = best; *useful = 32 * best - 4; *wgs = (n + *useful - 1) / *useful; *halo = 2;
 }
+
+#ifdef ESMI_E3_STAGED
+// development only: layernorm_tile_regs with the 32-lane reductions of RB rows at a time done stage by stage (all ds_swizzle round trips
+// of a batch in flight together) -- the form that produced wrong rows inside enc_fuse_va_kernel in round 4 for RB = 8 and 16
+#ifndef ESMI_E3_SWZ_FENCE
+#define ESMI_E3_SWZ_FENCE 0
+#endif
+template <int RB>
+__device__ __forceinline__ void row_sum32_batch(float (&s)[RB]) {
+    float t[RB];
+#pragma unroll
+    for (int r = 0; r < RB; ++r) {
+        s[r] += dpp_f<0xB1>(s[r]);
+        s[r] += dpp_f<0x4E>(s[r]);
+        s[r] += dpp_f<0x141>(s[r]);
+        s[r] += dpp_f<0x140>(s[r]);
+    }
+#if ESMI_E3_SWZ_FENCE == 2
+    asm volatile("s_nop 4" ::: "memory");
+#endif
+#pragma unroll
+    for (int r = 0; r < RB; ++r) t[r] = swz_xor16_f(s[r]);
+#if ESMI_E3_SWZ_FENCE >= 1
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+#pragma unroll
+    for (int r = 0; r < RB; ++r) s[r] += t[r];
+}
+template <int NT, int RB>
+__device__ __forceinline__ void layernorm_tile_regs_batched(f32x16 (&v)[NT], const float (&gg)[NT], const float (&bb)[NT], float eps = 1e-5f) {
+    const float inv_c = 1.0f / (float)(32 * NT);
+#pragma unroll
+    for (int r0 = 0; r0 < 16; r0 += RB) {
+        float s[RB], q[RB];
+#pragma unroll
+        for (int r = 0; r < RB; ++r) {
+            s[r] = 0.0f;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) s[r] += v[nt][r0 + r];
+        }
+        row_sum32_batch<RB>(s);
+#pragma unroll
+        for (int r = 0; r < RB; ++r) {
+            s[r] *= inv_c;
+            q[r] = 0.0f;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const float d = v[nt][r0 + r] - s[r];
+                q[r] = fmaf(d, d, q[r]);
+            }
+        }
+        row_sum32_batch<RB>(q);
+#pragma unroll
+        for (int r = 0; r < RB; ++r) {
+            const float rstd = rsqrt_fast_f32(q[r] * inv_c + eps);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) v[nt][r0 + r] = fmaf((v[nt][r0 + r] - s[r]) * rstd, gg[nt], bb[nt]);
+        }
+    }
+}
+#endif
 
 __device__ __forceinline__ int floor_div(int a, int b) { return a >= 0 ? a / b : -((-a + b - 1) / b); }
 
@@ -341,7 +398,11 @@ __device__ __forceinline__ void enc_fuse_va_body(const FuseVaP& p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) c[q][nt][r] = fmaxf(c[q][nt][r] + b1[q][nt], 0.0f);
         }
+#ifdef ESMI_E3_STAGED   // development only (profiles/r05_probes/fuse_va_wrong_rows.md): the round-4 experiment that gave wrong rows on the GPU
+        layernorm_tile_regs_batched<ND, ESMI_E3_STAGED>(c[q], g1[q], be1[q]);
+#else
         layernorm_tile_regs<ND>(c[q], g1[q], be1[q]);
+#endif
 #pragma unroll
         for (int nt = 0; nt < ND; ++nt) {
 #pragma unroll
@@ -493,7 +554,7 @@ __device__ __forceinline__ void enc_fuse_va_body(const FuseVaP& p) {
 }
 
 template <int ND, int KU>
-__global__ __launch_bounds__(64 * kVaMaxWaves, ESMI_E3_WPS) void enc_fuse_va_kernel(const FuseVaP p) {
+__global__ __launch_bounds__(64 * kVaMaxWaves, kChainWps) void enc_fuse_va_kernel(const FuseVaP p) {
     enc_fuse_va_body<ND, KU>(p);
 }
 

@@ -9,10 +9,6 @@
 #pragma once
 #include "wave_chain.h"
 
-#ifndef ESMI_E1_WPS
-#define ESMI_E1_WPS ESMI_CHAIN_WPS
-#endif
-
 namespace esmi {
 
 struct EncMergeP {
@@ -139,7 +135,7 @@ __device__ __forceinline__ void merge_conv_tile(const EncMergeP& p, int b, int t
 }
 
 template <int NCI, int NC, int KT, int STRIDE>   // Cin = 32*NCI, C = 32*NC, merge kernel KT, stride STRIDE
-__global__ __launch_bounds__(64, ESMI_E1_WPS) void enc_merge_qkv_kernel(const EncMergeP p) {
+__global__ __launch_bounds__(64, kChainWps) void enc_merge_qkv_kernel(const EncMergeP p) {
     constexpr int C = 32 * NC;
     constexpr int LD = C + 4;
     ESMI_DYN_LDS(buf);             // input rows [31*STRIDE + KT][Cin + 4], later the x tile [32][LD]

@@ -79,7 +79,29 @@ __device__ __forceinline__ void enc_va16_body(const FuseVaP& p) {
     const f32x4 z4 = zero4();
     const int rot = (int)blockIdx.x;          // request order of the weight fragments, see dma_frags
 
-    // ---------------- entry: the first stage's weights and every parameter vector on their way (LDS-DMA), this lane's input rows requested
+    // ---------------- entry: this lane's input rows requested first (the Fuse stage waits for them), then the first stage's weights and
+    // every parameter vector on their way (LDS-DMA)
+    const bool rout = pos >= p.T;
+    const BufRsrc r_mask = make_rsrc(p.mask ? p.mask + (long)b * p.T : nullptr, p.T);
+    const bool rz = !rout && buf_ld_u8(r_mask, (unsigned)pos) != 0;
+    const BufRsrc r_feat = make_rsrc(p.feat + (long)b * p.T * 4 * DIM, (long)p.T * 4 * DIM * 4);
+    const unsigned frow = rout ? kBufOOB : (unsigned)(pos * 4 * DIM * 4);          // byte offset of this row of feat
+    const BufRsrc r_pt = make_rsrc(p.pitch_t ? p.pitch_t + (long)b * p.T : nullptr, (long)p.T * 4);
+    const BufRsrc r_et = make_rsrc(p.energy_t ? p.energy_t + (long)b * p.T : nullptr, (long)p.T * 4);
+    const BufRsrc r_dt = make_rsrc(p.dur_t ? p.dur_t + (long)b * p.T : nullptr, (long)p.T * 4);
+    const unsigned trow = rout ? kBufOOB : (unsigned)(pos * 4);
+    const float tv_p = buf_ld(r_pt, trow), tv_e = buf_ld(r_et, trow), tv_d = buf_ld(r_dt, trow);   // teacher values (0 when absent)
+    const float lb0 = p.pred[0].lin_b[0], lb1 = p.pred[1].lin_b[0], lb2 = p.pred[2].lin_b[0];
+    // Fuse, level 0 and level 1 operands straight from global memory
+    const int n1 = p.n_i[1];
+    const int n_base = floor_div(r0 - (KU - 1), 2);
+    const int n_i = n_base + i;
+    const BufRsrc r_f0 = make_rsrc(p.feats[0] + (long)b * p.n_i[0] * DIM, (long)p.n_i[0] * DIM * 4);
+    const BufRsrc r_f1 = make_rsrc(p.feats[1] + (long)b * n1 * 2 * DIM, (long)n1 * 2 * DIM * 4);
+    const unsigned o0 = rout ? kBufOOB : (unsigned)(pos * DIM * 4) + gl_lane(lane);
+    const unsigned o1 = (n_i < 0 || n_i >= n1) ? kBufOOB : (unsigned)(n_i * 2 * DIM * 4) + gl_lane(lane);
+    const f32x4 g0a = buf_ld4(r_f0, o0), g0b = buf_ld4(r_f0, o0 + 32u);                       // (split into the f16 pieces behind the entry barrier)
+    const f32x4 g1a = buf_ld4(r_f1, o1), g1b = buf_ld4(r_f1, o1 + 32u), g1c = buf_ld4(r_f1, o1 + 128u), g1d = buf_ld4(r_f1, o1 + 160u);
     {
         // half A: mlp 0 (4 KiB) | mlp 1 (8) | ConvTranspose taps (4 KU) | fuse Linear (8)
         dma_frags(p.mlp_w[0], wA, 4, w, nw, lane, rot);
@@ -115,33 +137,12 @@ __device__ __forceinline__ void enc_va16_body(const FuseVaP& p) {
         }
         if (lane < LDD) tmpP[16 * LDD + lane] = 0u;
     }
-    ESMI_CT();   // (parameters requested)
-    const bool rout = pos >= p.T;
-    const BufRsrc r_mask = make_rsrc(p.mask ? p.mask + (long)b * p.T : nullptr, p.T);
-    const bool rz = !rout && buf_ld_u8(r_mask, (unsigned)pos) != 0;
-    const BufRsrc r_feat = make_rsrc(p.feat + (long)b * p.T * 4 * DIM, (long)p.T * 4 * DIM * 4);
-    const unsigned frow = rout ? kBufOOB : (unsigned)(pos * 4 * DIM * 4);          // byte offset of this row of feat
-    const BufRsrc r_pt = make_rsrc(p.pitch_t ? p.pitch_t + (long)b * p.T : nullptr, (long)p.T * 4);
-    const BufRsrc r_et = make_rsrc(p.energy_t ? p.energy_t + (long)b * p.T : nullptr, (long)p.T * 4);
-    const BufRsrc r_dt = make_rsrc(p.dur_t ? p.dur_t + (long)b * p.T : nullptr, (long)p.T * 4);
-    const unsigned trow = rout ? kBufOOB : (unsigned)(pos * 4);
-    const float tv_p = buf_ld(r_pt, trow), tv_e = buf_ld(r_et, trow), tv_d = buf_ld(r_dt, trow);   // teacher values (0 when absent)
-    const float lb0 = p.pred[0].lin_b[0], lb1 = p.pred[1].lin_b[0], lb2 = p.pred[2].lin_b[0];
-    // Fuse, level 0 and level 1 operands straight from global memory
-    const int n1 = p.n_i[1];
-    const int n_base = floor_div(r0 - (KU - 1), 2);
-    const int n_i = n_base + i;
-    const BufRsrc r_f0 = make_rsrc(p.feats[0] + (long)b * p.n_i[0] * DIM, (long)p.n_i[0] * DIM * 4);
-    const BufRsrc r_f1 = make_rsrc(p.feats[1] + (long)b * n1 * 2 * DIM, (long)n1 * 2 * DIM * 4);
-    const unsigned o0 = rout ? kBufOOB : (unsigned)(pos * DIM * 4) + gl_lane(lane);
-    const unsigned o1 = (n_i < 0 || n_i >= n1) ? kBufOOB : (unsigned)(n_i * 2 * DIM * 4) + gl_lane(lane);
-    const f16x2p a0 = global_bop(r_f0, o0, 0);
-    const f16x2p a10 = global_bop(r_f1, o1, 0), a11 = global_bop(r_f1, o1, 1);
     ESMI_CT();   // (rows requested)
     wait_vm0();
     ESMI_CT();   // (own queue drained)
     wg_sync_lds();              // half A, the parameter vectors and the zero rows are in place
     ESMI_CT();   // 1: entry loads landed
+    const f16x2p a0 = split_f16x2(g0a, g0b), a10 = split_f16x2(g1a, g1b), a11 = split_f16x2(g1c, g1d);
     // the next stage's weights (conv1 of pitch | energy | duration: 12 KiB each) and the embedding tables start now, under the Fuse stage
 #pragma unroll
     for (int q = 0; q < 3; ++q) dma_frags(p.pred[q].conv1_w, wB + q * 12 * 256, 12, w, nw, lane, rot);

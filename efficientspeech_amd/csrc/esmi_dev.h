@@ -168,27 +168,6 @@ __device__ __forceinline__ void layernorm_tile(f32x16 (&v)[NT], const float* __r
     }
 }
 
-// the four in-row (16-lane) steps of row_sum32; the xor-16 step is a ds_swizzle (an LDS round trip)
-__device__ __forceinline__ float row_sum16_part(float v) {
-    v += dpp_f<0xB1>(v);
-    v += dpp_f<0x4E>(v);
-    v += dpp_f<0x141>(v);
-    v += dpp_f<0x140>(v);
-    return v;
-}
-// 32-lane all-reduce of 16 independent values, stage by stage: the 16 ds_swizzle round trips are in flight together.  (Row by row --
-// `for r: row_sum32(v[r])` -- hipcc keeps at most two reductions in flight and every swizzle's LDS latency is exposed: 32 of them per
-// LayerNorm of a tile, the largest part of the chain kernels' LayerNorm stages.)
-__device__ __forceinline__ void row_sum32_x16(float (&s)[16]) {
-    float t[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) s[r] = row_sum16_part(s[r]);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) t[r] = swz_xor16_f(s[r]);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) s[r] += t[r];
-}
-
 // same, gain / bias already in registers (gg[nt], bb[nt] = values of column 32*nt + (lane&31))
 template <int NT>
 __device__ __forceinline__ void layernorm_tile_regs(f32x16 (&v)[NT], const float (&gg)[NT], const float (&bb)[NT],
@@ -214,40 +193,10 @@ __device__ __forceinline__ void layernorm_tile_regs(f32x16 (&v)[NT], const float
 }
 
 
-// layernorm_tile_regs with the reductions of the 16 rows done stage by stage (row_sum32_x16).  Used where it was measured AND the
-// result re-verified on the GPU (enc_attn_ffn.h): enc_fuse_va_kernel sits at 256 VGPRs + 256 AGPRs with spills, and every variant of
-// this change produced wrong rows there on ROCm 7.2 while the simulator and the other kernels were right
-// (profiles/r04_probes/chain_layernorm_round4.md) -- it keeps the row-by-row form above.
-template <int NT>
-__device__ __forceinline__ void layernorm_tile_regs_staged(f32x16 (&v)[NT], const float (&gg)[NT], const float (&bb)[NT],
-                                                    float eps = 1e-5f) {
-    const float inv_c = 1.0f / (float)(32 * NT);
-    float s[16], q[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        s[r] = 0.0f;
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) s[r] += v[nt][r];
-    }
-    row_sum32_x16(s);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        s[r] *= inv_c;                        // mean
-        q[r] = 0.0f;
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            const float d = v[nt][r] - s[r];
-            q[r] = fmaf(d, d, q[r]);
-        }
-    }
-    row_sum32_x16(q);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const float rstd = rsqrt_fast_f32(q[r] * inv_c + eps);
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) v[nt][r] = fmaf((v[nt][r] - s[r]) * rstd, gg[nt], bb[nt]);
-    }
-}
+// (Round 4 used a form of this with the reductions of the 16 rows done stage by stage in the two encoder-block kernels: ~1 % faster,
+// but the same change gave wrong rows on the GPU inside enc_fuse_va_kernel for a reason that was never found
+// (profiles/r04_probes/chain_layernorm_round4.md).  Round 5 replaced those kernels on their hot shapes by the chain16 kernels -- whose
+// LayerNorm needs no per-row reductions at all -- and the kernels that remain as fallbacks use the row-by-row form above everywhere.)
 
 // An offset the optimiser must treat as freshly computed here (`opaque_i`, wavesim_shim.h).  Used on the lane-dependent part of LDS
 // addresses inside loops: without it LLVM's LICM hoists every `base + constant` address of the loop body into its own

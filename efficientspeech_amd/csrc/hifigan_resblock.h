@@ -109,17 +109,13 @@ __device__ __forceinline__ f32x4 lrelu4(const f32x4& v, float slope) {   // 0 <=
     return o;
 }
 
-#ifndef ESMI_RB_WPS
-#define ESMI_RB_WPS 4   // waves per SIMD the kernel is compiled for: 4 = two 8-wave workgroups per CU (128 VGPRs)
-#endif
-#ifndef ESMI_RB_PD
-#define ESMI_RB_PD 1    // weight fragments are fetched this many k-steps ahead
-#endif
+constexpr int kRbWps = 4;   // waves per SIMD the kernels are compiled for: 4 = two 8-wave workgroups per CU (128 VGPRs); 6 / 8 spill (4.1 / 5.2 vs 3.7 ms)
+constexpr int kRbPd = 1;    // weight fragments are fetched this many k-steps ahead (deeper: spills at 128 VGPRs, 4.0-4.9 ms)
 
 template <int C, int K>
-__global__ __launch_bounds__(64 * kRbWaves, ESMI_RB_WPS) void hifigan_resblock_kernel(const ResblockP p) {
+__global__ __launch_bounds__(64 * kRbWaves, kRbWps) void hifigan_resblock_kernel(const ResblockP p) {
     constexpr int RS = rb_row_bytes(C), MT = rb_mtiles(C), CG = (C < 32 ? C : 32) / 8;
-    constexpr int STEPS = rb_ksteps(C, K), HALF = (K - 1) / 2, PD = ESMI_RB_PD < STEPS ? ESMI_RB_PD : STEPS;
+    constexpr int STEPS = rb_ksteps(C, K), HALF = (K - 1) / 2, PD = kRbPd < STEPS ? kRbPd : STEPS;
     static_assert(STEPS >= PD, "prefetch distance reaches at most into the next conv");
     typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
     ESMI_DYN_LDS(lds_f);
@@ -262,11 +258,8 @@ __global__ __launch_bounds__(64 * kRbWaves, ESMI_RB_WPS) void hifigan_resblock_k
 // = four 16-position tiles; the conv's weight fragments (<= 6 steps x 2 planes) stay in registers for the whole K loop and the
 // next conv's are fetched under the epilogue and the barriers, so the K loop is LDS reads + MFMAs only.
 //   A[co = lane&15][32s + 8kb + e] (kb = lane>>4),  B[32s + 8kb + e][pos = lane&15],  D: channels 4kb..4kb+3 of position lane&15
-#ifndef ESMI_RB16_WPS8
-#define ESMI_RB16_WPS8 ESMI_RB_WPS   // waves per SIMD the C = 8 narrow-tile kernel is compiled for; 6 / 8 (three / four workgroups per CU) spill and measured 4.1 / 5.2 ms per forward against 3.7
-#endif
 template <int C, int K>
-__global__ __launch_bounds__(64 * kRbWaves, C == 8 ? ESMI_RB16_WPS8 : ESMI_RB_WPS) void hifigan_resblock16_kernel(const ResblockP p) {
+__global__ __launch_bounds__(64 * kRbWaves, kRbWps) void hifigan_resblock16_kernel(const ResblockP p) {
     static_assert(C == 8 || C == 16, "narrow-tile kernel");
     constexpr int RS = rb_row_bytes(C), STEPS = rb_ksteps16(C, K), HALF = (K - 1) / 2;
     typedef unsigned u32x2 __attribute__((ext_vector_type(2)));

@@ -133,10 +133,9 @@ static __global__ void train_conv_dgrad_kernel(const ConvDesc d, const float* __
 // kTrainChunk rows) its own thread and writes a partial sum, stage 2 adds the partials of an element in chunk order.
 constexpr int kTrainChunk = 256;
 constexpr int kTrainChunkDw = 256;     // rows per workgroup of the depthwise weight gradient (8 sub-chunks of 32 rows, summed in LDS)
-#ifndef ESMI_TRAIN_CHUNK_MFMA
-#define ESMI_TRAIN_CHUNK_MFMA 96    // rows per wave of the MFMA weight gradient (a multiple of 16).  Round 3 (four waves summed in LDS, split-bf16 products): 48 / 80 / 96 / 128 / 160 / 192 rows -> 5.2-5.3 / 5.3 / 5.3-5.4 / 5.5 / 5.5 / 5.7 ms per B = 128 step (+-0.3 ms run to run)
-#endif
-constexpr int kTrainChunkMfma = ESMI_TRAIN_CHUNK_MFMA;    // rows per wave of the matrix-pipe weight gradient (1024 measured slower: too few waves)
+// rows per wave of the matrix-pipe weight gradient (a multiple of 16).  Round 3 (four waves summed in LDS, split-bf16 products): 48 / 80 /
+// 96 / 128 / 160 / 192 rows -> 5.2-5.3 / 5.3 / 5.3-5.4 / 5.5 / 5.5 / 5.7 ms per B = 128 step (+-0.3 ms run to run); 1024: too few waves
+constexpr int kTrainChunkMfma = 96;
 __host__ __device__ inline long train_chunks(long rows, int chunk = kTrainChunk) { return (rows + chunk - 1) / chunk; }
 
 // dw(co, ci, j) = sum over (b, t) of dy[b, t, co] * x[b, in_pos(t, j), ci]: partial[chunk][weight element in checkpoint order]

@@ -8,9 +8,7 @@ ESMI_TU_RANGE_SETTER(attention)
 
 namespace esmi {
 
-#ifndef ESMI_ATTN_LDS_MIN_HEADS
-#define ESMI_ATTN_LDS_MIN_HEADS kAttnLdsMinHeadsDefault    // (wavesim_shim.h: 128 on the GPU, 1 in the simulator)
-#endif
+// (utterance, head) pairs from which attention is LDS-staged: kAttnLdsMinHeadsDefault (wavesim_shim.h: 128 on the GPU, 1 in the simulator)
 int launch_attn(const AttnP& p_in, hipStream_t st) {
     AttnP p = p_in;
     if (!p.q) {                        // the reference's layout: one (B, N, 3, h, C) tensor
@@ -37,7 +35,7 @@ int launch_attn(const AttnP& p_in, hipStream_t st) {
     }
 #if ESMI_CHAIN_SPLIT
     // heads with several query tiles: K and V staged once per (utterance, head) in LDS instead of once per tile from L2
-    if (nkt >= 3 && (p.C <= 128 || p.C % 128 == 0) && attn_lds_bytes(p.N, p.C) <= 150 * 1024 && (long)p.B * p.h >= ESMI_ATTN_LDS_MIN_HEADS) {
+    if (nkt >= 3 && (p.C <= 128 || p.C % 128 == 0) && attn_lds_bytes(p.N, p.C) <= 150 * 1024 && (long)p.B * p.h >= kAttnLdsMinHeadsDefault) {
         const size_t lds = attn_lds_bytes(p.N, p.C);
         dim3 g2((unsigned)(p.B * p.h));
         if (nkt <= 4) {

@@ -7,9 +7,8 @@ using namespace esmi;
 ESMI_TU_RANGE_SETTER(convgemm)
 
 
-#ifndef ESMI_GEMM_LDS_MIN_ROWS   // rows (B * n_out) from which the per-op plan's GEMMs take the LDS-staged kernel
-#define ESMI_GEMM_LDS_MIN_ROWS kGemmLdsMinRowsDefault   // (wavesim_shim.h: 2048 on the GPU, 1 in the simulator)
-#endif
+// rows (B * n_out) from which the per-op plan's GEMMs take the LDS-staged kernel: kGemmLdsMinRowsDefault (wavesim_shim.h: 2048 on the
+// GPU, 1 in the simulator)
 
 #ifdef ESMI_GEMM_TRACE
 namespace esmi { __device__ long long* g_gemm_trace_dev = nullptr; }
@@ -53,10 +52,10 @@ int launch_convgemm(ConvGemmP p, hipStream_t st) {
     // output rows (flat-row addressing) and 32-bit lane offsets: the kernel forms (row + tile rows + halo) * lda BEFORE it clamps, so
     // the bound covers the last workgroup's padded rows and the taps' reach, not just the tensor (the pre-clamp product
     // must not overflow); anything else streams from L2 below
-    if (p.mode == MODE_CONV && p.stride == 1 && !p.ids && (p.c_in & 31) == 0 && p.c_out > 64 && (long)p.B * p.n_out >= ESMI_GEMM_LDS_MIN_ROWS &&
+    if (p.mode == MODE_CONV && p.stride == 1 && !p.ids && (p.c_in & 31) == 0 && p.c_out > 64 && (long)p.B * p.n_out >= kGemmLdsMinRowsDefault &&
         p.n_in == p.n_out &&
-        (((long)p.B * p.n_in + 64L * ESMI_GEMM_LDS_WAVES + 2L * kGemmHaloMax + 8) * p.lda + p.a_coff + p.c_in) < (1L << 31)) {
-        constexpr int NWV = ESMI_GEMM_LDS_WAVES;
+        (((long)p.B * p.n_in + 64L * kGemmLdsWaves + 2L * kGemmHaloMax + 8) * p.lda + p.a_coff + p.c_in) < (1L << 31)) {
+        constexpr int NWV = kGemmLdsWaves;
         const long rows = (long)p.B * p.n_out;
         // a LayerNorm / row-dot epilogue over 129..256 channels needs them all in one wave: 32 rows x 256 channels per wave; else
         // 128 channels per wave and 64 rows when that still gives every CU its two workgroups, 32 otherwise (training at phoneme rate)

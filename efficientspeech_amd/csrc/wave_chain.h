@@ -28,15 +28,10 @@ static __device__ long long* g_chain_trace_dev = nullptr;   // one per translati
 #define ESMI_CT() do {} while (0)
 #endif
 
-#ifndef ESMI_RING_NT1
-#define ESMI_RING_NT1 6   // operand-ring depth (groups in flight) of GEMMs one column tile wide
-#endif
-#ifndef ESMI_RING_NT2
-#define ESMI_RING_NT2 4
-#endif
-#ifndef ESMI_CHAIN_WPS
-#define ESMI_CHAIN_WPS 1   // __launch_bounds__ waves/SIMD of the one-wave chain kernels (3 => at most 168 VGPRs)
-#endif
+namespace esmi {
+constexpr int kChainRingNt1 = 6, kChainRingNt2 = 4;   // operand-ring depth (groups in flight) of GEMMs one / two column tiles wide (4 .. 10: +-1 %)
+constexpr int kChainWps = 1;                           // __launch_bounds__ waves per SIMD of the 32-row-tile chain kernels
+}
 
 namespace esmi {
 
@@ -208,7 +203,7 @@ __device__ __forceinline__ void wave_gemm_taps(f32x16 (&acc)[NT], WaveGrp<NT>& g
     } else {
         // fully unrolled: step n = j*KG + g lives in ring slot n % D (slot 0 = g0); everything is compile-time
         constexpr int STEPS = MAXTAPS * KG;
-        constexpr int D0 = NT == 1 ? ESMI_RING_NT1 : (NT == 2 ? ESMI_RING_NT2 : 2);
+        constexpr int D0 = NT == 1 ? kChainRingNt1 : (NT == 2 ? kChainRingNt2 : 2);
         constexpr int D = D0 < STEPS ? D0 : (STEPS > 1 ? STEPS : 2);
         WaveGrp<NT> ring[D - 1];
         auto slot = [&](int n) __attribute__((always_inline)) -> WaveGrp<NT>& { return n % D == 0 ? g0 : ring[n % D - 1]; };
