@@ -90,6 +90,12 @@ __device__ __forceinline__ void row_sum32_batch(float (&s)[RB]) {
     }
 #if ESMI_E3_SWZ_FENCE == 2
     asm volatile("s_nop 4" ::: "memory");
+#elif ESMI_E3_SWZ_FENCE == 3
+    asm volatile("" ::: "memory");          // compiler-level ordering only
+#elif ESMI_E3_SWZ_FENCE == 4
+    __builtin_amdgcn_sched_barrier(0);      // scheduling fence only
+#elif ESMI_E3_SWZ_FENCE == 5
+    asm volatile("s_nop 0");                // one wait state, no memory clobber
 #endif
 #pragma unroll
     for (int r = 0; r < RB; ++r) t[r] = swz_xor16_f(s[r]);

@@ -6,6 +6,10 @@
 // (i = lane&31, h = lane>>5) reads 16 bytes: channels [8kc+4h, +4) of row i).  Convolutions along the
 // sequence are row shifts of the A fragment inside the tile (halo rows are recomputed by neighbouring
 // tiles); weights stream from L2 in pre-packed MFMA-fragment order, four k-steps per round trip.
+//
+// Rule (profiles/r05_probes/fuse_va_wrong_rows.md): a loop of ds_swizzle round trips that follows a loop of DPP reductions gets a
+// sched_fence() between the two -- with ROCm 7.2 the machine scheduler's interleaving of the two stages over batches of >= 8 rows gave
+// wrong statistics on the GPU (right on the simulator); the row-by-row forms in esmi_dev.h are what the fallback kernels use.
 #pragma once
 #include "esmi_dev.h"
 

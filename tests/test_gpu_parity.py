@@ -87,6 +87,30 @@ def _eval_path_vs_oracle(name, B, T, lens, nets):
         assert not m[b, int(o.mel_len[b]):].any()
 
 
+@pytest.mark.parametrize("B,T", [(1, 31), (1, 32), (2, 64), (1, 128)])
+@pytest.mark.parametrize("fusion", [_lib.FUSE_ALL, 31], ids=["chain16", "chain32"])
+def test_variance_adaptor_last_rows_of_every_tile(B, T, fusion, nets):
+    """Regression test for the wrong-rows mode of round 4 (profiles/r05_probes/fuse_va_wrong_rows.md): a build of enc_fuse_va_kernel whose
+    predictor LayerNorms ran their 32-lane reductions in batches of 8 or 16 rows returned wrong predictions at positions 25..33 of
+    every 32-position tile on the GPU (0.4 .. 1.5 off), right everywhere else and right on the simulator.  Every position's pitch /
+    energy / duration prediction and duration features against the oracle, for the round-5 kernels and for the fallback kernels."""
+    net, cfg, sd = nets("tiny")
+    ids, mask = synth_phonemes(B, T, 11)
+    x = {"phoneme": torch.from_numpy(ids).to(DEV)}
+    if B > 1:
+        x["phoneme_mask"] = torch.from_numpy(mask).to(DEV)
+    with _lib.launch_plan(fusion), torch.no_grad():
+        enc = net.encoder._encode(x, need_lmax=False)
+    o = oracle.phoneme2mel(cfg, oracle.Weights(sd), ids, mask if B > 1 else None)
+    for key, ref in (("pitch", o.pitch), ("energy", o.energy), ("duration", o.duration)):
+        d = np.abs(enc[key].cpu().numpy().reshape(B, T) - ref.reshape(B, T))
+        bad = sorted(set(np.argwhere(d > H.PRED_TOL)[:, 1].tolist()))
+        assert not bad, (key, "positions", bad, float(d.max()))
+    d = np.abs(enc["feat"].cpu().numpy() - o.feat).max(-1)
+    bad = sorted(set(np.argwhere(d > H.PRED_TOL)[:, 1].tolist()))
+    assert not bad, ("feat", "positions", bad, float(d.max()))
+
+
 def test_b1_path_has_no_masks(nets):
     net, cfg, sd = nets("tiny")
     ids, _ = synth_phonemes(1, 50, 5)
