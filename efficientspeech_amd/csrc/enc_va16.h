@@ -84,7 +84,7 @@ __device__ __forceinline__ void enc_va16_body(const FuseVaP& p) {
     const bool rout = pos >= p.T;
     const BufRsrc r_mask = make_rsrc(p.mask ? p.mask + (long)b * p.T : nullptr, p.T);
     const bool rz = !rout && buf_ld_u8(r_mask, (unsigned)pos) != 0;
-    const BufRsrc r_feat = make_rsrc(p.feat + (long)b * p.T * 4 * DIM, (long)p.T * 4 * DIM * 4);
+    const BufRsrc r_feat = make_rsrc(p.feat ? p.feat + (long)b * p.T * 4 * DIM : nullptr, (long)p.T * 4 * DIM * 4);
     const unsigned frow = rout ? kBufOOB : (unsigned)(pos * 4 * DIM * 4);          // byte offset of this row of feat
     const BufRsrc r_pt = make_rsrc(p.pitch_t ? p.pitch_t + (long)b * p.T : nullptr, (long)p.T * 4);
     const BufRsrc r_et = make_rsrc(p.energy_t ? p.energy_t + (long)b * p.T : nullptr, (long)p.T * 4);
@@ -350,28 +350,36 @@ __device__ __forceinline__ void enc_va16_body(const FuseVaP& p) {
     ESMI_CT();   // 6: predictions done
     // ---------------- outputs behind the last barrier that waits for the vector-memory queue (no barrier waits for a store)
     auto store_outputs = [&]() __attribute__((always_inline)) {
+    if (p.feat) {               // (NULL: the lean inference call -- the decoder gathers h0, nobody reads the feature rows)
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-        buf_st4(r_feat, frow + (unsigned)((16 * nt + 4 * g) * 4), fz[nt]);
-        buf_st4(r_feat, frow + (unsigned)((3 * DIM + 16 * nt + 4 * g) * 4), df[nt]);
-    }
+        for (int nt = 0; nt < 2; ++nt) {
+            buf_st4(r_feat, frow + (unsigned)((16 * nt + 4 * g) * 4), fz[nt]);
+            buf_st4(r_feat, frow + (unsigned)((3 * DIM + 16 * nt + 4 * g) * 4), df[nt]);
+        }
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        const unsigned off = frow + (unsigned)(((1 + q) * DIM + 16 * (g >> 1) + 4 * (g & 1)) * 4);
-        buf_st4(r_feat, off, em[q][0]);
-        buf_st4(r_feat, off + 32u, em[q][1]);
+        for (int q = 0; q < 2; ++q) {
+            const unsigned off = frow + (unsigned)(((1 + q) * DIM + 16 * (g >> 1) + 4 * (g & 1)) * 4);
+            buf_st4(r_feat, off, em[q][0]);
+            buf_st4(r_feat, off + 32u, em[q][1]);
+        }
     }
     {
         const unsigned srow = (!rout && g == 0) ? (unsigned)(pos * 4) : kBufOOB;   // one lane per row
 #pragma unroll
         for (int q = 0; q < 3; ++q) {
-            const BufRsrc r_pred = make_rsrc(p.preds[q] + (long)b * p.T, (long)p.T * 4);
-            buf_st(r_pred, srow, pr[q]);
+            if (p.preds[q]) {
+                const BufRsrc r_pred = make_rsrc(p.preds[q] + (long)b * p.T, (long)p.T * 4);
+                buf_st(r_pred, srow, pr[q]);
+            }
         }
-        const BufRsrc r_pi = make_rsrc(p.pitch_idx ? p.pitch_idx + (long)b * p.T : nullptr, (long)p.T * 4);
-        const BufRsrc r_ei = make_rsrc(p.energy_idx ? p.energy_idx + (long)b * p.T : nullptr, (long)p.T * 4);
-        buf_st_i(r_pi, srow, bidx[0]);
-        buf_st_i(r_ei, srow, bidx[1]);
+        if (p.pitch_idx) {
+            const BufRsrc r_pi = make_rsrc(p.pitch_idx + (long)b * p.T, (long)p.T * 4);
+            buf_st_i(r_pi, srow, bidx[0]);
+        }
+        if (p.energy_idx) {
+            const BufRsrc r_ei = make_rsrc(p.energy_idx + (long)b * p.T, (long)p.T * 4);
+            buf_st_i(r_ei, srow, bidx[1]);
+        }
         const BufRsrc r_dur = make_rsrc(p.dur + (long)b * p.T, (long)p.T * 4);
         buf_st_i(r_dur, srow, (int)dval);
     }

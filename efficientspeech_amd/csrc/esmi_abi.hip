@@ -353,6 +353,17 @@ size_t esmi_fuse_variance_adaptor_workspace_bytes(int B, int T, int dim, int dep
     return esmi_fuse_workspace_bytes(B, T, dim, depth) + esmi_variance_adaptor_workspace_bytes(B, T, dim);
 }
 
+// `lean`: the caller (the one-call inference forward) only consumes duration_pred / dur / cum / mel_len / h0 -- when the round-5 chain
+// kernel serves the shape and produces h0, the phoneme-rate feature tensor, the pitch / energy predictions and the bucket indices are
+// not written at all (16.8 MB of stores per tiny-ES batch that nobody reads: the decoder gathers h0)
+static int fuse_variance_adaptor(const esmi_fuse_weights* fw, int depth, int dim, int kernel, int B, int T,
+                                 const float* const* feats, const int* n_i, const esmi_predictor_weights* pitch,
+                                 const esmi_predictor_weights* energy, const esmi_predictor_weights* duration,
+                                 const uint8_t* mask, const float* pitch_target, const float* energy_target,
+                                 const int32_t* duration_target, float* feat, float* pitch_pred, float* energy_pred,
+                                 float* duration_pred, int32_t* pitch_idx, int32_t* energy_idx, int32_t* dur,
+                                 int32_t* cum, int32_t* mel_len, const esmi_decoder_head* head, float* h0, int plan,
+                                 void* workspace, size_t workspace_bytes, esmi_stream_t stream, bool lean);
 int esmi_fuse_variance_adaptor_f32(const esmi_fuse_weights* fw, int depth, int dim, int kernel, int B, int T,
                                    const float* const* feats, const int* n_i, const esmi_predictor_weights* pitch,
                                    const esmi_predictor_weights* energy, const esmi_predictor_weights* duration,
@@ -361,6 +372,18 @@ int esmi_fuse_variance_adaptor_f32(const esmi_fuse_weights* fw, int depth, int d
                                    float* duration_pred, int32_t* pitch_idx, int32_t* energy_idx, int32_t* dur,
                                    int32_t* cum, int32_t* mel_len, const esmi_decoder_head* head, float* h0, int plan,
                                    void* workspace, size_t workspace_bytes, esmi_stream_t stream) {
+    return fuse_variance_adaptor(fw, depth, dim, kernel, B, T, feats, n_i, pitch, energy, duration, mask, pitch_target, energy_target,
+                                 duration_target, feat, pitch_pred, energy_pred, duration_pred, pitch_idx, energy_idx, dur, cum, mel_len,
+                                 head, h0, plan, workspace, workspace_bytes, stream, false);
+}
+static int fuse_variance_adaptor(const esmi_fuse_weights* fw, int depth, int dim, int kernel, int B, int T,
+                                 const float* const* feats, const int* n_i, const esmi_predictor_weights* pitch,
+                                 const esmi_predictor_weights* energy, const esmi_predictor_weights* duration,
+                                 const uint8_t* mask, const float* pitch_target, const float* energy_target,
+                                 const int32_t* duration_target, float* feat, float* pitch_pred, float* energy_pred,
+                                 float* duration_pred, int32_t* pitch_idx, int32_t* energy_idx, int32_t* dur,
+                                 int32_t* cum, int32_t* mel_len, const esmi_decoder_head* head, float* h0, int plan,
+                                 void* workspace, size_t workspace_bytes, esmi_stream_t stream, bool lean) {
     if ((cum == nullptr) != (mel_len == nullptr)) return ESMI_ERR_ARG;
     if (h0 && (!head || (!head->proj_wp && !head->proj_w) || !head->proj_b || !head->ln_g || !head->ln_b)) return ESMI_ERR_ARG;
     if (!fw || !feats || !n_i || !pitch || !energy || !duration || !feat || !pitch_pred || !energy_pred ||
@@ -397,7 +420,11 @@ int esmi_fuse_variance_adaptor_f32(const esmi_fuse_weights* fw, int depth, int d
         p.cum = scan_fused ? cum : nullptr; p.mel_len = scan_fused ? mel_len : nullptr;
         if (head_in_chain) { p.head_w = head->proj_wp; p.head_b = head->proj_b; p.head_g = head->ln_g; p.head_beta = head->ln_b; p.h0 = h0; }
         int rc16 = ESMI_ERR_UNSUPPORTED;
-        if ((plan & ESMI_FUSE_CHAIN16) && scan_fused == (cum != nullptr)) rc16 = launch_enc_va16(p, dim, kernel, S(stream));
+        if ((plan & ESMI_FUSE_CHAIN16) && scan_fused == (cum != nullptr)) {
+            FuseVaP q = p;
+            if (lean && head_in_chain) { q.feat = nullptr; q.preds[0] = q.preds[1] = nullptr; q.pitch_idx = q.energy_idx = nullptr; }
+            rc16 = launch_enc_va16(q, dim, kernel, S(stream));
+        }
         if (rc16 == ESMI_ERR_UNSUPPORTED) rc16 = launch_enc_fuse_va(p, dim, kernel, nw, head_in_chain, S(stream));
         if (rc16) return rc16;
         if (cum && !scan_fused) ESMI_LAUNCH(length_regulate_kernel, dim3(B), dim3(64), 0, S(stream), dur, T, cum, mel_len, (int*)nullptr);
@@ -838,10 +865,12 @@ static int forward_impl(const esmi_forward_args* a, int stage, esmi_stream_t str
         const bool head_ok = fuse_va_head_ok(fuse_va_chain_ok(&a->fuse, a->depth, a->dim, a->fuse_kernel, o.n[0], T, &a->pitch, &a->energy,
                                                               &a->duration, plan), a->dim, &a->head) ||
                              (head_gemm_ok(&a->head) && a->head.d4 == 4 * a->dim && a->head.dx2 == a->dec_shape.dx2);
-        rc = esmi_fuse_variance_adaptor_f32(&a->fuse, a->depth, a->dim, a->fuse_kernel, B, T, feats, o.n, &a->pitch, &a->energy,
-                                            &a->duration, mask, nullptr, nullptr, a->dur_forced, feat, pp, ep, a->duration_pred,
-                                            pi, ei, dur, cum, a->mel_len, head_ok ? &a->head : nullptr, head_ok ? h0 : nullptr, plan,
-                                            base + o.ws, wsb, stream);
+        // (lean: nobody reads the arena's feature / prediction / index buffers when the caller did not ask for them and h0 is produced)
+        const bool lean = !a->pitch_pred && !a->energy_pred && !a->pitch_idx && !a->energy_idx;
+        rc = fuse_variance_adaptor(&a->fuse, a->depth, a->dim, a->fuse_kernel, B, T, feats, o.n, &a->pitch, &a->energy,
+                                   &a->duration, mask, nullptr, nullptr, a->dur_forced, feat, pp, ep, a->duration_pred,
+                                   pi, ei, dur, cum, a->mel_len, head_ok ? &a->head : nullptr, head_ok ? h0 : nullptr, plan,
+                                   base + o.ws, wsb, stream, lean);
         if (rc) return rc;
         if (a->lmax_dev && (rc = esmi_max_i32(a->mel_len, B, a->lmax_dev, stream))) return rc;
     }
