@@ -128,6 +128,31 @@ int esmi_pool_mask_u8(const uint8_t* mask, int B, int T, int pool, uint8_t* out,
 
 size_t esmi_encoder_block_workspace_bytes(const esmi_encoder_block_shape* s) { return s ? enc_ws(s).total : 0; }
 
+// The parameters of a whole encoder block as ONE folded chain-kernel launch (what esmi_encoder_block_f32 below hands
+// launch_enc_block16 / launch_enc_block), for the one-launch encoder side of the one-call forward; false when the block's packed / folded
+// weights are not all there.
+static bool block_chain_params(const esmi_encoder_block_weights* w, const esmi_encoder_block_shape* s, const int32_t* ids, const float* embed,
+                               const float* x_in, const uint8_t* mask, float* x_out, EncAttnFfnP* out) {
+    const bool ffn_folded = w->ffn_cw && w->ffn_cwp && w->ffn_cb && w->ffn_cb_first && w->ffn_cb_last;
+    if (!(w->merge_cwp && w->qkv_wp && w->proj_wp && ffn_folded && w->mlp2_wp && w->qk_wp && w->vo_wp)) return false;
+    const int n = conv_out_len(s->n_in, s->kernel, s->stride, s->kernel / 2);
+    EncAttnFfnP f;
+    memset(&f, 0, sizeof f);
+    EncMergeP& m = f.m;
+    m.ids = ids; m.table = embed; m.vocab = s->vocab; m.x_in = ids ? nullptr : x_in;
+    m.B = s->B; m.n_in = s->n_in; m.n_out = n; m.k = s->kernel; m.stride = s->stride; m.pad = s->kernel / 2; m.h = s->heads;
+    m.merge_w = w->merge_cwp; m.qkv_w = w->qk_wp; m.emb_conv = ids ? w->emb_conv : nullptr; m.tiles_per_b = (n + 31) / 32;
+    f.B = s->B; f.N = n; f.C = s->c_out; f.h = s->heads; f.scale = 1.0f / sqrtf((float)(s->c_out / s->heads));
+    f.proj_w = w->vo_wp; f.proj_b = w->proj_b; f.ln1_g = w->ln1_g; f.ln1_b = w->ln1_b;
+    f.ffn_w = w->ffn_cwp; f.ffn_b = w->ffn_cb; f.ffn_b0 = w->ffn_cb_first; f.ffn_b2 = w->ffn_cb_last;
+    f.mlp2_w = w->mlp2_wp; f.mlp2_b = w->mlp2_b; f.ln2_g = w->ln2_g; f.ln2_b = w->ln2_b;
+    f.mask = mask; f.out = x_out;
+    f.mask_pool = s->mask_pool > 0 ? s->mask_pool : 1; f.mask_len = s->mask_pool > 0 ? s->mask_len : n;
+    f.fold = 1; f.wgs_per_b = 1; f.halo = 0;
+    *out = f;
+    return true;
+}
+
 int esmi_encoder_block_f32(const esmi_encoder_block_weights* w, const esmi_encoder_block_shape* s, const int32_t* ids,
                            const float* embed, const float* x_in, const uint8_t* mask, float* x_out, void* workspace,
                            size_t workspace_bytes, esmi_stream_t stream) {
@@ -353,6 +378,38 @@ size_t esmi_fuse_variance_adaptor_workspace_bytes(int B, int T, int dim, int dep
     return esmi_fuse_workspace_bytes(B, T, dim, depth) + esmi_variance_adaptor_workspace_bytes(B, T, dim);
 }
 
+// the chain kernels' parameter block of the fused Fuse + variance adaptor stage (enc_fuse_va_kernel / enc_va16_kernel)
+static void fuse_va_chain_params(const esmi_fuse_weights* fw, int depth, int dim, int kernel, int B, int T, const float* const* feats,
+                                 const int* n_i, const esmi_predictor_weights* pitch, const esmi_predictor_weights* energy,
+                                 const esmi_predictor_weights* duration, const uint8_t* mask, const float* pitch_target,
+                                 const float* energy_target, const int32_t* duration_target, float* feat, float* pitch_pred,
+                                 float* energy_pred, float* duration_pred, int32_t* pitch_idx, int32_t* energy_idx, int32_t* dur,
+                                 int32_t* cum, int32_t* mel_len, const esmi_decoder_head* head_in_chain, float* h0, FuseVaP* out, int* nw) {
+    FuseVaP p;
+    memset(&p, 0, sizeof p);
+    p.B = B; p.T = T; p.depth = depth; p.kernel = kernel;
+    for (int i = 0; i < depth; ++i) {
+        p.feats[i] = feats[i]; p.n_i[i] = n_i[i];
+        p.mlp_w[i] = fw->mlp_wp[i]; p.mlp_b[i] = fw->mlp_b[i]; p.up_w[i] = fw->up_wp[i]; p.up_b[i] = fw->up_b[i];
+    }
+    p.fuse_w = fw->fuse_wp; p.fuse_b = fw->fuse_b;
+    const esmi_predictor_weights* pw[3] = {pitch, energy, duration};
+    for (int q = 0; q < 3; ++q) {
+        PredW& d = p.pred[q];
+        d.conv1_w = pw[q]->conv1_wp; d.conv1_b = pw[q]->conv1_b; d.ln1_g = pw[q]->ln1_g; d.ln1_b = pw[q]->ln1_b;
+        d.conv2_w = pw[q]->conv2_wp; d.conv2_b = pw[q]->conv2_b; d.ln2_g = pw[q]->ln2_g; d.ln2_b = pw[q]->ln2_b;
+        d.lin_w = pw[q]->lin_w; d.lin_b = pw[q]->lin_b; d.bins = pw[q]->bins; d.emb = pw[q]->emb;
+    }
+    p.mask = mask; p.pitch_t = pitch_target; p.energy_t = energy_target; p.dur_t = duration_target;
+    p.feat = feat; p.preds[0] = pitch_pred; p.preds[1] = energy_pred; p.preds[2] = duration_pred;
+    p.pitch_idx = pitch_idx; p.energy_idx = energy_idx; p.dur = dur;
+    fuse_va_plan(T, dim, depth, nw, &p.wgs_per_b, &p.useful, &p.halo);
+    const bool scan_fused = cum && p.halo == 0;   // one workgroup sees every duration of its utterance
+    p.cum = scan_fused ? cum : nullptr; p.mel_len = scan_fused ? mel_len : nullptr;
+    if (head_in_chain) { p.head_w = head_in_chain->proj_wp; p.head_b = head_in_chain->proj_b; p.head_g = head_in_chain->ln_g; p.head_beta = head_in_chain->ln_b; p.h0 = h0; }
+    *out = p;
+}
+
 // `lean`: the caller (the one-call inference forward) only consumes duration_pred / dur / cum / mel_len / h0 -- when the round-5 chain
 // kernel serves the shape and produces h0, the phoneme-rate feature tensor, the pitch / energy predictions and the bucket indices are
 // not written at all (16.8 MB of stores per tiny-ES batch that nobody reads: the decoder gathers h0)
@@ -396,29 +453,12 @@ static int fuse_variance_adaptor(const esmi_fuse_weights* fw, int depth, int dim
         if ((n_i[i] - 1) * (1 << i) + kernel < T) return ESMI_ERR_UNSUPPORTED;   // torch.cat would raise in the reference
     if (chain) {
         FuseVaP p;
-        memset(&p, 0, sizeof p);
-        p.B = B; p.T = T; p.depth = depth; p.kernel = kernel;
-        for (int i = 0; i < depth; ++i) {
-            p.feats[i] = feats[i]; p.n_i[i] = n_i[i];
-            p.mlp_w[i] = fw->mlp_wp[i]; p.mlp_b[i] = fw->mlp_b[i]; p.up_w[i] = fw->up_wp[i]; p.up_b[i] = fw->up_b[i];
-        }
-        p.fuse_w = fw->fuse_wp; p.fuse_b = fw->fuse_b;
-        const esmi_predictor_weights* pw[3] = {pitch, energy, duration};
-        for (int q = 0; q < 3; ++q) {
-            PredW& d = p.pred[q];
-            d.conv1_w = pw[q]->conv1_wp; d.conv1_b = pw[q]->conv1_b; d.ln1_g = pw[q]->ln1_g; d.ln1_b = pw[q]->ln1_b;
-            d.conv2_w = pw[q]->conv2_wp; d.conv2_b = pw[q]->conv2_b; d.ln2_g = pw[q]->ln2_g; d.ln2_b = pw[q]->ln2_b;
-            d.lin_w = pw[q]->lin_w; d.lin_b = pw[q]->lin_b; d.bins = pw[q]->bins; d.emb = pw[q]->emb;
-        }
-        if (!pitch->bins || !pitch->emb || !energy->bins || !energy->emb) return ESMI_ERR_ARG;
-        p.mask = mask; p.pitch_t = pitch_target; p.energy_t = energy_target; p.dur_t = duration_target;
-        p.feat = feat; p.preds[0] = pitch_pred; p.preds[1] = energy_pred; p.preds[2] = duration_pred;
-        p.pitch_idx = pitch_idx; p.energy_idx = energy_idx; p.dur = dur;
         int nw;
-        fuse_va_plan(T, dim, depth, &nw, &p.wgs_per_b, &p.useful, &p.halo);
+        if (!pitch->bins || !pitch->emb || !energy->bins || !energy->emb) return ESMI_ERR_ARG;
+        fuse_va_chain_params(fw, depth, dim, kernel, B, T, feats, n_i, pitch, energy, duration, mask, pitch_target, energy_target,
+                             duration_target, feat, pitch_pred, energy_pred, duration_pred, pitch_idx, energy_idx, dur, cum, mel_len,
+                             head_in_chain ? head : nullptr, head_in_chain ? h0 : nullptr, &p, &nw);
         const bool scan_fused = cum && p.halo == 0;   // one workgroup sees every duration of its utterance
-        p.cum = scan_fused ? cum : nullptr; p.mel_len = scan_fused ? mel_len : nullptr;
-        if (head_in_chain) { p.head_w = head->proj_wp; p.head_b = head->proj_b; p.head_g = head->ln_g; p.head_beta = head->ln_b; p.h0 = h0; }
         int rc16 = ESMI_ERR_UNSUPPORTED;
         if ((plan & ESMI_FUSE_CHAIN16) && scan_fused == (cum != nullptr)) {
             FuseVaP q = p;
@@ -836,7 +876,48 @@ static int forward_impl(const esmi_forward_args* a, int stage, esmi_stream_t str
     int32_t* cum = a->cum ? a->cum : I(o.cum);
     float* h0 = (a->head.proj_wp || a->head.proj_w) ? F(o.h0) : nullptr;
     const uint8_t* mask = a->mask;
-    if (stage != 2) {
+    bool enc_done = false;
+    if (stage != 2 && (plan & ESMI_FUSE_ALL) == ESMI_FUSE_ALL && a->depth == 2 && (T & 31) == 0) {
+        // ---- the whole encoder side as ONE launch (round 5: enc_all16_kernel = block 0 | block 1 | Fuse + variance adaptor + head behind
+        // each other in one workgroup per utterance) when all three chain16 kernels serve their shapes with the same number of waves
+        esmi_encoder_block_shape sh[2];
+        bool ok = true;
+        int n_in = T;
+        for (int i = 0; i < 2 && ok; ++i) {
+            sh[i] = a->shapes[i];
+            sh[i].B = B; sh[i].n_in = n_in; sh[i].plan = plan; sh[i].mask_pool = 1; sh[i].mask_len = T;
+            if (mask) {
+                sh[i].mask_pool = (int)nearbyint((double)T / o.n[i]);
+                ok = (T + sh[i].mask_pool - 1) / sh[i].mask_pool == o.n[i];
+            }
+            n_in = o.n[i];
+        }
+        EncAttnFfnP b0, b1;
+        ok = ok && block_chain_params(&a->blocks[0], &sh[0], a->ids, a->embed, nullptr, mask, F(o.feats[0]), &b0) &&
+             block_chain_params(&a->blocks[1], &sh[1], nullptr, nullptr, F(o.feats[0]), mask, F(o.feats[1]), &b1);
+        const bool chain = fuse_va_chain_ok(&a->fuse, a->depth, a->dim, a->fuse_kernel, o.n[0], T, &a->pitch, &a->energy, &a->duration, plan);
+        const bool want_head = a->head.proj_wp || a->head.proj_w;
+        const bool head_in_chain = want_head && fuse_va_head_ok(chain, a->dim, &a->head);
+        ok = ok && chain && (!want_head || head_in_chain) && a->pitch.bins && a->pitch.emb && a->energy.bins && a->energy.emb &&
+             (o.n[1] - 1) * 2 + a->fuse_kernel >= T;
+        if (ok) {
+            const float* feats[2] = {F(o.feats[0]), F(o.feats[1])};
+            const bool lean = !a->pitch_pred && !a->energy_pred && !a->pitch_idx && !a->energy_idx && head_in_chain;
+            FuseVaP va;
+            int nw_unused;
+            fuse_va_chain_params(&a->fuse, 2, a->dim, a->fuse_kernel, B, T, feats, o.n, &a->pitch, &a->energy, &a->duration, mask, nullptr, nullptr,
+                                 a->dur_forced, lean ? nullptr : feat, lean ? nullptr : (a->pitch_pred ? a->pitch_pred : F(o.preds[0])),
+                                 lean ? nullptr : (a->energy_pred ? a->energy_pred : F(o.preds[1])), a->duration_pred,
+                                 lean ? nullptr : (a->pitch_idx ? a->pitch_idx : I(o.idx[0])), lean ? nullptr : (a->energy_idx ? a->energy_idx : I(o.idx[1])),
+                                 a->dur ? a->dur : I(o.dur), cum, a->mel_len, head_in_chain ? &a->head : nullptr, head_in_chain ? h0 : nullptr, &va,
+                                 &nw_unused);
+            rc = va.cum ? launch_enc_all16(b0, b1, sh[1].c_in, va, a->dim, a->fuse_kernel, S(stream)) : ESMI_ERR_UNSUPPORTED;
+            if (rc == ESMI_OK) enc_done = true;
+            else if (rc != ESMI_ERR_UNSUPPORTED) return rc;
+        }
+        if (enc_done && a->lmax_dev && (rc = esmi_max_i32(a->mel_len, B, a->lmax_dev, stream))) return rc;
+    }
+    if (stage != 2 && !enc_done) {
         const float* x_in = nullptr;
         int n_in = T;
         for (int i = 0; i < a->depth; ++i) {

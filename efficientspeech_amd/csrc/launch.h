@@ -57,8 +57,12 @@ int launch_enc_attn_ffn(const EncAttnFfnP& p, int expansion, int plan, hipStream
 int launch_enc_fuse_va(const FuseVaP& p, int dim, int kernel, int nw, bool head, hipStream_t st);
 // tu_enc_va16.hip (round 5: 16-row tiles, weights through LDS; ESMI_ERR_UNSUPPORTED for the shapes it is not built for)
 int launch_enc_va16(const FuseVaP& p, int dim, int kernel, hipStream_t st);
+bool enc_va16_ok(const FuseVaP& p, int dim, int kernel);
 // tu_enc_block16.hip (round 5: whole-block kernels of dim = 32 models on 16-row tiles)
 int launch_enc_block16(const EncAttnFfnP& p, int expansion, int c_in, hipStream_t st);
+// ... and the whole encoder side in one launch (block 0 | block 1 | Fuse + variance adaptor), when each of the three chain16 kernels
+// serves its shape and they run the same number of waves; ESMI_ERR_UNSUPPORTED otherwise
+int launch_enc_all16(const EncAttnFfnP& b0, const EncAttnFfnP& b1, int c_in1, const FuseVaP& va, int dim, int kernel, hipStream_t st);
 // tu_hifigan.hip
 int launch_resblock(const ResblockP& p, int c, hipStream_t st);
 

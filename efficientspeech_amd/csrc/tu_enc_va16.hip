@@ -11,9 +11,13 @@ namespace esmi {
 
 // dim = 32, two encoder levels, ConvTranspose kernel 3, one workgroup per utterance (T <= 128); ESMI_ERR_UNSUPPORTED otherwise
 // (-> enc_fuse_va_kernel).  The split-f16 build only: the exact-fp32 library keeps the round-1 kernel.
+bool enc_va16_ok(const FuseVaP& p, int dim, int kernel) {
+    return dim == kVa16Dim && p.depth == 2 && kernel == 3 && p.T >= 1 && p.T <= 16 * kVa16MaxWaves && p.n_i[0] == p.T;
+}
+
 int launch_enc_va16(const FuseVaP& p, int dim, int kernel, hipStream_t st) {
 #if ESMI_CHAIN_SPLIT
-    if (dim != kVa16Dim || p.depth != 2 || kernel != 3 || p.T < 1 || p.T > 16 * kVa16MaxWaves || p.n_i[0] != p.T) return ESMI_ERR_UNSUPPORTED;
+    if (!enc_va16_ok(p, dim, kernel)) return ESMI_ERR_UNSUPPORTED;
     const int nw = (p.T + 15) / 16;
     static AttrOnce once;
     if (int rc = raise_lds_limit(reinterpret_cast<const void*>(enc_va16_kernel<3>), once)) return rc;
