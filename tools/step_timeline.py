@@ -5,7 +5,10 @@ import csv, glob, sys
 path = glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True)[0]
 rows = sorted(csv.DictReader(open(path)), key=lambda r: int(r["Start_Timestamp"]))
 idx = [i for i, r in enumerate(rows) if "mel_decoder" in r["Kernel_Name"]]
-a, b = idx[-2], idx[-1]
+# a step from the middle of the timed region (3 warm-up + 10 timed steps in tools/collect_profiles.sh): the trace's LAST decoder launches
+# belong to bench.py's legs behind the timed region (clock probe: a device->host copy and a sync per launch)
+k = 9 if len(idx) > 10 else len(idx) - 1
+a, b = idx[k - 1], idx[k]
 prev_end = int(rows[a]["End_Timestamp"])
 tot_gap = tot_dur = 0.0
 for r in rows[a + 1:b + 1]:
