@@ -148,10 +148,32 @@ def test_simulated_errors(nets):
             net({"phoneme": torch.ones((2, 8), dtype=torch.int32)})
 
 
-@pytest.mark.parametrize("fusion", [7, 31 - 8], ids=["staged", "no-split"])
+@pytest.mark.parametrize("B,T,lens", [(3, 64, [64, 50, 7]), (2, 96, [96, 40]), (1, 32, None), (2, 128, [128, 77])])
+def test_simulated_one_launch_encoder_side(B, T, lens, nets):
+    """Round 5: for T a multiple of 32 the one-call forward runs the whole encoder side of tiny ES as ONE launch (enc_all16_kernel: the three
+    chain16 bodies behind each other; key tiles beyond a short sequence read zeroed planes).  Against the oracle, and against the round-1..4
+    chain kernels (launch plan 31) and the three chain16 launches of the module path."""
+    net, cfg, sd = nets("tiny")
+    ids, mask = synth_phonemes(B, T, 5, lens)
+    x = {"phoneme": torch.from_numpy(ids)}
+    if B > 1:
+        x["phoneme_mask"] = torch.from_numpy(mask)
+    with use_sim(), torch.no_grad():
+        mel, mel_len, dur = net(x)                                    # one-call forward: enc_all16_kernel
+        enc = net.encoder._encode(x)                                  # module path: three chain16 launches
+        with _lib.launch_plan(31):
+            mel31, _, dur31 = net(x)
+    o = oracle.phoneme2mel(cfg, oracle.Weights(sd), ids, mask if B > 1 else None)
+    err = H.compare_eval_with_oracle(cfg, o, enc, mel, mel_len, sd)
+    assert err == err
+    np.testing.assert_allclose(dur.numpy(), o.duration, atol=H.PRED_TOL, rtol=0)
+    assert float((mel - mel31).abs().max()) < 2e-5 and float((dur - dur31).abs().max()) < 2e-5
+
+
+@pytest.mark.parametrize("fusion", [7, 31 - 8, 31], ids=["staged", "no-split", "chain32"])
 def test_simulated_intermediate_plans(fusion, nets):
     """Fusion masks between 'everything fused' and 'one kernel per op': per-stage chain kernels (7), whole-block
-    without the column-split variant (23)."""
+    without the column-split variant (23), the round-1..4 chain kernels on the shapes the chain16 kernels took over in round 5 (31)."""
     g = np.load(os.path.join(GOLD, "tiny_eval_pad_t17.npz"))
     net, cfg, sd = nets("tiny", g)
     with use_sim(), _lib.launch_plan(fusion):
