@@ -92,6 +92,8 @@ __device__ __forceinline__ void enc_va16_body(const FuseVaP& p) {
     const unsigned trow = rout ? kBufOOB : (unsigned)(pos * 4);
     const float tv_p = buf_ld(r_pt, trow), tv_e = buf_ld(r_et, trow), tv_d = buf_ld(r_dt, trow);   // teacher values (0 when absent)
     const float lb0 = p.pred[0].lin_b[0], lb1 = p.pred[1].lin_b[0], lb2 = p.pred[2].lin_b[0];
+    const int e_i = (lane & 31) < DIM - 1 ? (lane & 31) : DIM - 2;
+    const float edge_p = p.pred[0].bins[e_i], edge_e = p.pred[1].bins[e_i];      // bucket edges (dim - 1 of them), to LDS behind the entry barrier
     // Fuse, level 0 and level 1 operands straight from global memory
     const int n1 = p.n_i[1];
     const int n_base = floor_div(r0 - (KU - 1), 2);
@@ -117,9 +119,9 @@ __device__ __forceinline__ void enc_va16_body(const FuseVaP& p) {
             const float* hi = v8 & 1 ? (v8 & 2 ? a7 : a5) : (v8 & 2 ? a6 : a4);
             return (v8 & 4 ? hi : lo) + c8;
         };
-        // (bins hold dim - 1 floats: the copy of slot PV_EDGE reads one float past each -- inside the allocation's granule -- and the
-        // +inf is written over it below)
-        if (w == 0 % nw) lds_dma16(pick8(p.mlp_b[0], p.mlp_b[1], p.up_b[1], p.fuse_b, p.pred[2].ln2_g, p.pred[2].ln2_b, p.pred[0].bins, p.pred[1].bins), par, lane);
+        // (slots 6, 7 = the bucket edges: dim - 1 floats each, written from registers below -- a 32-float copy would read one float past
+        // the arrays)
+        if (w == 0 % nw) lds_dma16(pick8(p.mlp_b[0], p.mlp_b[1], p.up_b[1], p.fuse_b, p.pred[2].ln2_g, p.pred[2].ln2_b, p.fuse_b, p.fuse_b), par, lane);
 #pragma unroll
         for (int q = 0; q < 3; ++q) {
             const PredW& d = p.pred[q];
@@ -148,7 +150,10 @@ __device__ __forceinline__ void enc_va16_body(const FuseVaP& p) {
     for (int q = 0; q < 3; ++q) dma_frags(p.pred[q].conv1_w, wB + q * 12 * 256, 12, w, nw, lane, rot);
     dma_frags(p.pred[0].emb, embT, 4, w, nw, lane, rot);
     dma_frags(p.pred[1].emb, embT + DIM * DIM, 4, w, nw, lane, rot);
-    if (w == 0 && lane < 2) par[PV_EDGE + 32 * lane + DIM - 1] = INFINITY;          // behind the dim - 1 bucket edges
+    if (w == 0) {                                           // bucket edges, +inf behind the dim - 1 of them (read two barriers later)
+        const int l5 = lane & 31;
+        par[PV_EDGE + lane] = l5 < DIM - 1 ? (lane < 32 ? edge_p : edge_e) : INFINITY;
+    }
     f32x4 acc[2];
     {   // level 0: Linear(dim, dim)
         acc[0] = z4; acc[1] = z4;
