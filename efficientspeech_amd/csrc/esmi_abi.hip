@@ -877,9 +877,9 @@ static int forward_impl(const esmi_forward_args* a, int stage, esmi_stream_t str
     float* h0 = (a->head.proj_wp || a->head.proj_w) ? F(o.h0) : nullptr;
     const uint8_t* mask = a->mask;
     bool enc_done = false;
-    if (stage != 2 && (plan & ESMI_FUSE_ALL) == ESMI_FUSE_ALL && a->depth == 2 && (T & 31) == 0) {
+    if (stage != 2 && (plan & ESMI_FUSE_ALL) == ESMI_FUSE_ALL && a->depth == 2 && T <= 128) {
         // ---- the whole encoder side as ONE launch (round 5: enc_all16_kernel = block 0 | block 1 | Fuse + variance adaptor + head behind
-        // each other in one workgroup per utterance) when all three chain16 kernels serve their shapes with the same number of waves
+        // each other in one workgroup per utterance) when all three chain16 kernels serve their shapes
         esmi_encoder_block_shape sh[2];
         bool ok = true;
         int n_in = T;

@@ -42,8 +42,14 @@ __global__ __launch_bounds__(64 * 8, 2) void enc_all16_kernel(const EncAll16P p)
 int launch_enc_all16(const EncAttnFfnP& b0, const EncAttnFfnP& b1, int c_in1, const FuseVaP& va, int dim, int kernel, hipStream_t st) {
 #if ESMI_CHAIN_SPLIT
     if (!b0_16_ok(b0) || !b1_16_ok(b1, c_in1) || !enc_va16_ok(va, dim, kernel)) return ESMI_ERR_UNSUPPORTED;
-    const int nw = (b0.N + 15) / 16;
-    if (va.T != b0.N || (va.T + 15) / 16 != nw || 2 * ((b1.N + 15) / 16) != nw || b0.B != b1.B || b0.B != va.B) return ESMI_ERR_UNSUPPORTED;
+    if (va.T != b0.N || b0.B != b1.B || b0.B != va.B) return ESMI_ERR_UNSUPPORTED;
+    // one wave count for the three bodies: the largest any of them needs, even (block 1 pairs its waves).  A body that needs fewer treats
+    // the surplus waves' rows like the rows behind the end of a sequence (outside: zero inputs, nothing stored).
+    int nw = (b0.N + 15) / 16;
+    const int nw1 = 2 * ((b1.N + 15) / 16);
+    nw = (nw > nw1 ? nw : nw1);
+    nw += nw & 1;
+    if (nw > 8) return ESMI_ERR_UNSUPPORTED;
     EncAll16P q;
     q.b0 = b0; q.b1 = b1; q.va = va;
     int lds = B016Lds::total > B116Lds::total ? B016Lds::total : B116Lds::total;

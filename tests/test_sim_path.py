@@ -148,10 +148,12 @@ def test_simulated_errors(nets):
             net({"phoneme": torch.ones((2, 8), dtype=torch.int32)})
 
 
-@pytest.mark.parametrize("B,T,lens", [(3, 64, [64, 50, 7]), (2, 96, [96, 40]), (1, 32, None), (2, 128, [128, 77])])
+@pytest.mark.parametrize("B,T,lens", [(3, 64, [64, 50, 7]), (2, 96, [96, 40]), (1, 32, None), (2, 128, [128, 77]), (3, 40, [40, 33, 9]), (1, 31, None),
+                                      (2, 17, [17, 5]), (1, 1, None)])
 def test_simulated_one_launch_encoder_side(B, T, lens, nets):
-    """Round 5: for T a multiple of 32 the one-call forward runs the whole encoder side of tiny ES as ONE launch (enc_all16_kernel: the three
-    chain16 bodies behind each other; key tiles beyond a short sequence read zeroed planes).  Against the oracle, and against the round-1..4
+    """Round 5: for T <= 128 the one-call forward runs the whole encoder side of tiny ES as ONE launch (enc_all16_kernel: the three
+    chain16 bodies behind each other on one wave count -- surplus waves of a body see rows outside the sequence; key tiles beyond a short sequence
+    read zeroed planes).  Against the oracle, and against the round-1..4
     chain kernels (launch plan 31) and the three chain16 launches of the module path."""
     net, cfg, sd = nets("tiny")
     ids, mask = synth_phonemes(B, T, 5, lens)
