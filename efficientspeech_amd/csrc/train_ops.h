@@ -133,9 +133,8 @@ static __global__ void train_conv_dgrad_kernel(const ConvDesc d, const float* __
 // kTrainChunk rows) its own thread and writes a partial sum, stage 2 adds the partials of an element in chunk order.
 constexpr int kTrainChunk = 256;
 constexpr int kTrainChunkDw = 256;     // rows per workgroup of the depthwise weight gradient (8 sub-chunks of 32 rows, summed in LDS)
-// rows per wave of the matrix-pipe weight gradient (a multiple of 16).  Round 3 (four waves summed in LDS, split-bf16 products): 48 / 80 /
-// 96 / 128 / 160 / 192 rows -> 5.2-5.3 / 5.3 / 5.3-5.4 / 5.5 / 5.5 / 5.7 ms per B = 128 step (+-0.3 ms run to run); 1024: too few waves
-constexpr int kTrainChunkMfma = 96;
+// (rows per wave of the matrix-pipe weight gradient: tu_train.hip wgrad_chunk -- a multiple of 16 sized for one round of workgroups.
+// Round 3, when a trip was a chain of exposed load latencies, a fixed 48 ... 192 rows made no difference: 5.2-5.7 ms per B = 128 step.)
 __host__ __device__ inline long train_chunks(long rows, int chunk = kTrainChunk) { return (rows + chunk - 1) / chunk; }
 
 // dw(co, ci, j) = sum over (b, t) of dy[b, t, co] * x[b, in_pos(t, j), ci]: partial[chunk][weight element in checkpoint order]
@@ -264,22 +263,71 @@ static __global__ __launch_bounds__(256) void train_conv_wgrad_dw4_kernel(const 
 // (input tile, output tile).  The (tap 0, first input tile) waves also sum dY's columns: the bias gradient.
 constexpr int kWgradWaves = 4;                      // waves (= row chunks) per workgroup, summed in LDS before anything is written
 constexpr int kWgradLdsBytes = kWgradWaves * 64 * 64 * 4;   // [wave][accumulator register 0..63][lane]
-static __global__ __launch_bounds__(256) void train_conv_wgrad_mfma_kernel(const ConvDesc d, const float* __restrict__ x,
+// One trip's loads of the matrix-pipe weight gradient, ALL issued unconditionally and without a branch (rows past the chunk, taps
+// outside the sequence and channels past the tensor read a valid address and are zeroed by the returned mask when they are used --
+// straight-line code is what lets the compiler count the loads in flight: with a branch around a load it waits for vmcnt(0) and
+// the next trip's loads are no longer in flight under this trip's products): U rows rbase + S u per lane, 16 bytes of dY and one
+// float of X each.  One 32-bit division per trip (rows < 2^31 and n_out >= 8 > S u, so a row is at most ONE utterance further than
+// the trip's first: tu_train.hip wgrad_on_mfma).  Bit u of the result: dY valid, bit 8 + u: X valid.
+template <int U, int S, bool TR>
+__device__ __forceinline__ unsigned wgrad_issue(const ConvDesc& d, const float* __restrict__ x, const float* __restrict__ dy, long rbase,
+                                                long r1, int j, int co4, bool co_ok, int ci, bool ci_ok, f32x4 (&a)[U], float (&bv)[U]) {
+    const unsigned rc = (unsigned)(rbase < r1 ? rbase : r1 - 1), n = (unsigned)d.n_out;
+    const unsigned b = rc / n, t = rc - b * n;
+    const int colA = co_ok ? co4 : 0, colB = ci_ok ? ci : 0;
+    unsigned ok = 0;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const bool rv = rbase + S * u < r1;
+        unsigned tu = t + S * u, bu = b;
+        const bool wrap = tu >= n;
+        tu = rv ? (wrap ? tu - n : tu) : t;
+        bu = rv && wrap ? bu + 1 : bu;
+        int ti;
+        bool tv;
+        if (!TR) {
+            ti = (int)tu * d.stride + j - d.pad;
+            tv = ti >= 0 && ti < d.n_in;
+        } else {                                      // ConvTranspose1d: out[n stride + j - pad] += in[n] W[:, :, j]
+            const int q = (int)tu + d.pad - j, qq = q < 0 ? 0 : q;
+            ti = qq / d.stride;
+            tv = q >= 0 && ti * d.stride == qq && ti < d.n_in;
+        }
+        ti = tv ? ti : 0;
+        a[u] = ld4(dy + (long)(rv ? rc + (unsigned)(S * u) : rc) * d.c_out + colA);
+        bv[u] = x[((long)bu * d.n_in + ti) * d.c_in + colB];
+        ok |= ((rv && co_ok) ? 1u : 0u) << u | ((rv && ci_ok && tv) ? 1u : 0u) << (8 + u);
+    }
+    return ok;
+}
+template <bool TR>
+static __global__ __launch_bounds__(256, 2) void train_conv_wgrad_mfma_kernel(const ConvDesc d, const float* __restrict__ x,
                                                                     const float* __restrict__ dy, float* __restrict__ partial,
                                                                     float* __restrict__ partial_bias, long chunks, long pstride,
-                                                                    int* __restrict__ dy_absmax = nullptr) {
+                                                                    int chunk_rows, int* __restrict__ dy_absmax = nullptr) {
     // dy_absmax (optional): max |dy| as a by-product -- the (tap 0, first input tile) waves read every element of dY exactly once;
     // an integer atomicMax of the magnitude's bit pattern is order-independent (the data-gradient GEMM that follows derives its
     // power-of-two operand scale from it: no separate pass over dY).
     // The four waves of a workgroup take four consecutive row chunks of the SAME weight tile; their accumulators are added in LDS in
     // wave order (fixed order: reproducible) and ONE partial per workgroup leaves the CU -- the partial sums of the two-stage
     // reduction were this kernel's memory traffic (600 chunks x 64 KB for a decoder convolution at B = 128): four times less now.
+    //
+    // Round 5: (a) a trip's loads are issued one trip AHEAD of its products (the kernel was a chain of exposed load latencies: ~3 us
+    // per 16-row trip whatever the size); (b) chunk_rows follows the problem (tu_train.hip wgrad_chunk: small problems get their
+    // parallelism from short chunks); (c) the weight tiles that read the SAME rows of dY are neighbours in one XCD's dispatch order
+    // (workgroup n runs on XCD n % 8: with the tile as the fast grid index the four tiles of a decoder convolution sat on four XCDs
+    // and each pulled dY through its own L2).  gridDim = (tiles, row groups rounded up to a multiple of 8).
     ESMI_DYN_LDS(red);
-    const int lane = lane_id(), i = lane & 31, kh = lane >> 5, w = wave_id();
+    const int lane = lane_id(), i = lane & 31, kh = lane >> 5, w = uniform_i(wave_id());   // (a scalar: the chunk's buffer resource lives in SGPRs)
     const int tci = (d.c_in + 31) / 32;
-    const int tile = (int)blockIdx.x, j = tile % d.k, ci0 = ((tile / d.k) % tci) * 32, cb = (tile / (d.k * tci)) * 128;
-    const long chunk = (long)blockIdx.y * kWgradWaves + w;
-    const long rows = (long)d.B * d.n_out, r0 = chunk * kTrainChunkMfma, r1 = r0 + kTrainChunkMfma < rows ? r0 + kTrainChunkMfma : rows;
+    const long wg = (long)blockIdx.y * gridDim.x + blockIdx.x, slot = wg >> 3;
+    const int tile = (int)(slot % gridDim.x);
+    const long ygrp = (slot / gridDim.x) * 8 + (wg & 7);
+    if (ygrp * kWgradWaves >= chunks) return;          // (the whole workgroup: in front of every barrier)
+    const int j = tile % d.k, ci0 = ((tile / d.k) % tci) * 32, cb = (tile / (d.k * tci)) * 128;
+    const long chunk = ygrp * kWgradWaves + w;
+    const long rows = (long)d.B * d.n_out;
+    long r0 = chunk * chunk_rows, r1 = r0 + chunk_rows < rows ? r0 + chunk_rows : rows;
     const int co4 = cb + 4 * i;                         // this lane's four output channels
     const bool vec_ok = co4 + 3 < d.c_out, ci_ok = ci0 + i < d.c_in;
     f32x16 acc[4] = {zero16(), zero16(), zero16(), zero16()};
@@ -292,32 +340,32 @@ static __global__ __launch_bounds__(256) void train_conv_wgrad_mfma_kernel(const
     // loads dY channels 4i .. 4i+3 and X channel ci0 + i of rows r + 8 kh + (0..7); each of the four dY channels is the A operand of
     // one of four MFMA tiles (channel sets {4m + t}).  24 v_mfma_f32_32x32x16_bf16 (768 cycles) per 16 rows instead of 32
     // v_mfma_f32_32x32x2_f32 (2048 cycles).
-    for (long r = r0; r < r1; r += 16) {                // (chunk >= chunks: no trip)
-        f32x4 a[8];
-        float bv[8];
+    constexpr int kU = 8, kTrip = 16;
+#else
+    constexpr int kU = 4, kTrip = 8;                   // rows r + 2 u + kh: 8 rows per trip, 16 v_mfma_f32_32x32x2_f32
+#endif
+    constexpr int kS = kTrip == 16 ? 1 : 2;
+    const int lane_row = kTrip == 16 ? 8 * kh : kh;
+    const bool stats = j == 0 && ci0 == 0;              // (wave-uniform) the waves that also sum dY's columns and take max |dY|
+    if (r0 >= r1) { r0 = 0; r1 = 0; }                   // (chunk >= chunks: no trip; every load below is then out of range and reads 0)
+    // one trip's products; `ok` masks what the pointer path (ConvTranspose1d) loaded from a clamped address
+    auto products = [&](f32x4 (&a)[kU], float (&bv)[kU], unsigned ok) __attribute__((always_inline)) {
+        if (TR) {
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const long rr = r + 8 * kh + u;
-            a[u] = zero4();
-            bv[u] = 0.0f;
-            if (rr < r1) {
-                const int b = (int)(rr / d.n_out), t = (int)(rr - (long)b * d.n_out);
-                const int ti = conv_in_pos(d, t, j);
-                const float* dr = dy + rr * d.c_out + co4;
-                if (vec_ok) a[u] = ld4(dr);
-                else
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) if (co4 + e < d.c_out) a[u][e] = dr[e];
-                if (ci_ok && ti >= 0) bv[u] = x[((long)b * d.n_in + ti) * d.c_in + ci0 + i];
+            for (int u = 0; u < kU; ++u) {
+                if (!((ok >> u) & 1u)) a[u] = zero4();
+                if (!((ok >> (8 + u)) & 1u)) bv[u] = 0.0f;
             }
         }
-        sched_fence();
+        if (stats) {
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+            for (int u = 0; u < kU; ++u) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) amax_f = fmaxf(amax_f, fabsf(a[u][e]));    // (NaN-transparent enough: a NaN gradient shows up as NaN weights anyway)
-            bsum = bsum + a[u];
+                for (int e = 0; e < 4; ++e) amax_f = fmaxf(amax_f, fabsf(a[u][e]));    // (NaN-transparent enough: a NaN gradient shows up as NaN weights anyway)
+                bsum = bsum + a[u];
+            }
         }
+#if ESMI_CHAIN_SPLIT
         const f32x4 b0 = {bv[0], bv[1], bv[2], bv[3]}, b1 = {bv[4], bv[5], bv[6], bv[7]};
         const bf16x3 b3 = split_bf16x3(b0, b1);
 #pragma unroll
@@ -325,43 +373,80 @@ static __global__ __launch_bounds__(256) void train_conv_wgrad_mfma_kernel(const
             const f32x4 a0 = {a[0][t4], a[1][t4], a[2][t4], a[3][t4]}, a1 = {a[4][t4], a[5][t4], a[6][t4], a[7][t4]};
             acc[t4] = mfma32_split(split_bf16x3(a0, a1), b3.hi, b3.mid, b3.lo, acc[t4]);
         }
-    }
 #else
-    for (long r = r0; r < r1; r += 8) {                 // 8 rows per trip: all eight loads in flight before the 16 MFMAs  (chunk >= chunks: no trip)
-        f32x4 a[4];
-        float bv[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const long rr = r + 2 * u + kh;
-            a[u] = zero4();
-            bv[u] = 0.0f;
-            if (rr < r1) {
-                const int b = (int)(rr / d.n_out), t = (int)(rr - (long)b * d.n_out);
-                const int ti = conv_in_pos(d, t, j);
-                const float* dr = dy + rr * d.c_out + co4;
-                if (vec_ok) a[u] = ld4(dr);
-                else
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) if (co4 + e < d.c_out) a[u][e] = dr[e];
-                if (ci_ok && ti >= 0) bv[u] = x[((long)b * d.n_in + ti) * d.c_in + ci0 + i];
-            }
-        }
-        sched_fence();
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) amax_f = fmaxf(amax_f, fabsf(a[u][e]));    // (NaN-transparent enough: a NaN gradient shows up as NaN weights anyway)
-            bsum = bsum + a[u];
 #pragma unroll
             for (int t4 = 0; t4 < 4; ++t4) acc[t4] = mfma32(a[u][t4], bv[u], acc[t4]);
         }
-    }
 #endif
-    if (dy_absmax && j == 0 && ci0 == 0) {
-        int m = __builtin_bit_cast(int, amax_f) & 0x7FFFFFFF;
+    };
+    // The loads.  Conv1d / Linear: bounds-checked buffer loads, so that nothing is clamped, compared or zeroed per value -- dY through
+    // a resource that ends with the chunk's last row (rows past it read 0; a lane's byte offset is its first row's + a wave-uniform
+    // multiple of the row size: one add per load), X through a resource over the whole tensor with the offset of (row, tap) kept
+    // INCREMENTALLY from trip to trip (n_out >= 16: at most one utterance boundary per trip) and replaced by an out-of-range one where
+    // the tap leaves the utterance or the row leaves the chunk.  (Round 5: the loop was VALU-bound on 64-bit address arithmetic, the
+    // masks and the register rotation of the look-ahead: 640 VALU instructions, 66 of them quarter rate, per 24 MFMAs.)
+    // ConvTranspose1d keeps the pointer path (wgrad_issue).
+    constexpr unsigned kBig = 0x7FFFFFFFu;
+    const BufRsrc r_dy = make_rsrc(dy + r0 * d.c_out, (r1 - r0) * (long)d.c_out * 4);
+    const BufRsrc r_x = make_rsrc(x, (long)d.B * d.n_in * d.c_in * 4);
+    const unsigned rowb = (unsigned)d.c_out * 4u, n = (unsigned)d.n_out;
+    unsigned dy_off = vec_ok ? (unsigned)(lane_row * d.c_out + co4) * 4u : kBig;        // of this lane's first row of the next trip
+    unsigned t_cur, x_off;                                                               // that row's position in its utterance, its X element
+    {
+        const unsigned rb = (unsigned)(r0 + lane_row), b0 = rb / n;
+        t_cur = rb - b0 * n;
+        x_off = (unsigned)(((long)b0 * d.n_in + (long)t_cur * d.stride + (j - d.pad)) * d.c_in + ci0 + i) * 4u;   // (mod 2^32 where the tap is outside)
+    }
+    const unsigned x_step = (unsigned)(d.stride * d.c_in) * 4u, x_wrap = (unsigned)((d.n_in - d.n_out * d.stride) * d.c_in) * 4u;
+    long r_next = r0;                                                                    // first row of the next trip to be issued
+    auto issue = [&](f32x4 (&a)[kU], float (&bv)[kU]) __attribute__((always_inline)) -> unsigned {
+        if (TR) {
+            const unsigned ok = wgrad_issue<kU, kS, TR>(d, x, dy, r_next + lane_row, r1 > r0 ? r1 : 1, j, co4, vec_ok, ci0 + i, ci_ok, a, bv);
+            const bool any = r_next < r1;
+            r_next += kTrip;
+            return any ? ok : 0u;
+        }
 #pragma unroll
-        for (int dd = 32; dd >= 1; dd >>= 1) m = max(m, shfl_i(m, lane ^ dd));
-        if (lane == 0 && m > 0) atomicMax(dy_absmax, m);
+        for (int u = 0; u < kU; ++u) a[u] = buf_ld4(r_dy, dy_off + (unsigned)(kS * u) * rowb);
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {
+            const unsigned tu = t_cur + (unsigned)(kS * u);
+            const bool wrap = tu >= n;
+            const int ti = (int)mul24u(wrap ? tu - n : tu, (unsigned)d.stride) + (j - d.pad);
+            const bool okx = ci_ok && (unsigned)ti < (unsigned)d.n_in && r_next + lane_row + kS * u < r1;
+            const unsigned off = x_off + (unsigned)(kS * u) * x_step + (wrap ? x_wrap : 0u);
+            bv[u] = buf_ld(r_x, okx ? off : kBig);
+        }
+        {   // this lane's first row of the trip after this one
+            t_cur += (unsigned)kTrip;
+            const bool wrap = t_cur >= n;
+            t_cur = wrap ? t_cur - n : t_cur;
+            x_off += (unsigned)kTrip * x_step + (wrap ? x_wrap : 0u);
+            dy_off += (unsigned)kTrip * rowb;
+            r_next += kTrip;
+        }
+        return 0x7FFFu;
+    };
+    // two register sets, each loaded one trip ahead of its products (no rotation: the loop body is two trips)
+    f32x4 a0[kU], a1[kU];
+    float v0[kU], v1[kU];
+    unsigned ok0 = issue(a0, v0), ok1 = 0;
+    for (long r = r0; r < r1; r += 2 * kTrip) {
+        ok1 = issue(a1, v1);
+        sched_fence();
+        products(a0, v0, ok0);
+        if (r + kTrip >= r1) break;
+        ok0 = issue(a0, v0);
+        sched_fence();
+        products(a1, v1, ok1);
+    }
+    int amax_i = 0;
+    if (dy_absmax && stats) {   // (wave-uniform) this wave's max |dY|; the workgroup's four are combined behind the barrier below
+        amax_i = __builtin_bit_cast(int, amax_f) & 0x7FFFFFFF;
+#pragma unroll
+        for (int dd = 32; dd >= 1; dd >>= 1) amax_i = max(amax_i, shfl_i(amax_i, lane ^ dd));
     }
     // ---- sum of the four waves' tiles: wave w0 writes [w0][reg][lane]; wave w then owns accumulator set t4 = w of the sum
     float* mine = red + (w * 64) * 64 + lane;
@@ -377,7 +462,7 @@ static __global__ __launch_bounds__(256) void train_conv_wgrad_mfma_kernel(const
 #pragma unroll
         for (int r = 0; r < 16; ++r) sum[r] += red[((w0 * 64) + 16 * w + r) * 64 + lane];
     }
-    const long out_row = (long)blockIdx.y * pstride;     // one partial row per workgroup
+    const long out_row = ygrp * pstride;                 // one partial row per workgroup
     const int ci = ci0 + i;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -385,7 +470,18 @@ static __global__ __launch_bounds__(256) void train_conv_wgrad_mfma_kernel(const
         long wi;
         if (co < d.c_out && ci < d.c_in && conv_w_index(d, co, ci, j, &wi)) partial[out_row + wi] = sum[r];
     }
-    if (partial_bias && j == 0 && ci0 == 0) {            // bias: column sums of dY, the four waves' again added in wave order
+    if (dy_absmax && stats) {
+        // ONE atomic per workgroup: 800 device-scope atomics on one address cost a decoder-size launch ~10 us (13 ns each, serialised)
+        __syncthreads();
+        int* ired = reinterpret_cast<int*>(red);
+        if (lane == 0) ired[w] = amax_i;
+        __syncthreads();
+        if (w == 0 && lane == 0) {
+            const int m = max(max(ired[0], ired[1]), max(ired[2], ired[3]));
+            if (m > 0) atomicMax(dy_absmax, m);
+        }
+    }
+    if (partial_bias && stats) {                         // bias: column sums of dY, the four waves' again added in wave order
         __syncthreads();
         float* bred = red;                                // [wave][128 channels]
 #pragma unroll
@@ -512,6 +608,46 @@ static __global__ __launch_bounds__(256) void train_ln_fwd_kernel(const float* _
         const float v = fmaf((xr[c] - m) * rs, g[c], b[c]);
         y[r * C + c] = masked ? 0.0f : (relu_out ? fmaxf(v, 0.0f) : v);
     }
+}
+// The same for C = 4 LPR in {32, 64, 128, 256} on 16-byte aligned tensors: LPR lanes per row hold the row in registers (one read of
+// x instead of three, 16-byte accesses), 64 / LPR rows per wave.  (The scalar form moves 78 MB in 30 us at B = 128.)
+template <int LPR>
+static __global__ __launch_bounds__(256) void train_ln_fwd4_kernel(const float* __restrict__ x, const float* __restrict__ g,
+                                                            const float* __restrict__ b, long rows, float eps,
+                                                            float* __restrict__ y, float* __restrict__ mean, float* __restrict__ rstd,
+                                                            const float* __restrict__ res, float* __restrict__ xsum,
+                                                            const unsigned char* __restrict__ rowmask, int relu_out) {
+    constexpr int RPW = 64 / LPR, C = 4 * LPR;
+    const int lane = lane_id(), sub = lane / LPR, l = lane % LPR;
+    const long r = ((long)blockIdx.x * 4 + wave_id()) * RPW + sub;
+    const bool live = r < rows;                        // (no early exit: the row sums are wave collectives)
+    const long rc = live ? r : rows - 1;
+    f32x4 v = ld4(x + rc * C + 4 * l);
+    if (res) {
+        v = v + ld4(res + rc * C + 4 * l);
+        if (live) *reinterpret_cast<f32x4*>(xsum + rc * C + 4 * l) = v;
+    }
+    float m = (v[0] + v[1]) + (v[2] + v[3]);
+#pragma unroll
+    for (int k = LPR / 2; k > 0; k >>= 1) m += shfl_xor_f(m, k);
+    m = m / (float)C;
+    f32x4 dl;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) dl[e] = v[e] - m;
+    float q = fmaf(dl[3], dl[3], fmaf(dl[2], dl[2], fmaf(dl[1], dl[1], dl[0] * dl[0])));
+#pragma unroll
+    for (int k = LPR / 2; k > 0; k >>= 1) q += shfl_xor_f(q, k);
+    const float rs = 1.0f / sqrtf(q / (float)C + eps);
+    if (l == 0 && live) { mean[r] = m; rstd[r] = rs; }
+    const bool masked = rowmask && rowmask[rc];
+    const f32x4 gv = ld4(g + 4 * l), bv = ld4(b + 4 * l);
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float t = fmaf(dl[e] * rs, gv[e], bv[e]);
+        o[e] = masked ? 0.0f : (relu_out ? fmaxf(t, 0.0f) : t);
+    }
+    if (live) *reinterpret_cast<f32x4*>(y + rc * C + 4 * l) = o;
 }
 // derivative of ReLU / tanh from the activation's OUTPUT y (kind as esmi_dev.h Act; 0: 1)
 __device__ __forceinline__ float act_grad_from_output(int kind, float y) {
@@ -830,17 +966,36 @@ static __global__ void train_embed_fwd_kernel(const int* __restrict__ ids, const
     if (id < 0 || id >= V) id = 0;
     out[q] = table[(long)id * C + q % C];
 }
-static __global__ void train_embed_bwd_kernel(const int* __restrict__ ids, const float* __restrict__ dy, long rows, int V, int C,
+// (blockDim = 64.)  The chunk's ids come in by coalesced loads, 64 at a time; one ballot per vocabulary entry of the wave (its 64
+// consecutive (v, c) elements span 64 / C + 1 entries at most) gives every lane the bit mask of ITS entry's rows, and the lane then
+// visits only those, in row order: the same sums in the same order as a compare per (element, row) -- which read ids[r] through the
+// scalar cache once per row (256 dependent ~200 ns loads per thread: 59 us for the phoneme table at B = 128).
+static __global__ __launch_bounds__(64) void train_embed_bwd_kernel(const int* __restrict__ ids, const float* __restrict__ dy, long rows, int V, int C,
                                        int padding_idx, float* __restrict__ partial) {
-    const long q = (long)blockIdx.x * blockDim.x + threadIdx.x;   // partial[chunk][v][c] over the chunk's rows
-    if (q >= (long)V * C) return;
-    const int v = (int)(q / C), c = (int)(q % C);
+    const long q0 = (long)blockIdx.x * 64, q = q0 + threadIdx.x;   // partial[chunk][v][c] over the chunk's rows
+    const long nq = (long)V * C;
+    const bool live = q < nq;
+    const int v = live ? (int)(q / C) : -1, c = live ? (int)(q % C) : 0, lane = lane_id();
+    const bool take = live && v != padding_idx;
+    const long qe = q0 + 63 < nq ? q0 + 63 : nq - 1;
+    const int v_lo = (int)(q0 / C), v_hi = (int)(qe / C);           // wave-uniform
     const long r0 = (long)blockIdx.y * kTrainChunk, r1 = r0 + kTrainChunk < rows ? r0 + kTrainChunk : rows;
     float acc = 0.0f;
-    if (v != padding_idx)
-        for (long r = r0; r < r1; ++r)
-            if (ids[r] == v) acc += dy[r * C + c];
-    partial[(long)blockIdx.y * V * C + q] = acc;
+    for (long base = r0; base < r1; base += 64) {
+        const int idv = base + lane < r1 ? ids[base + lane] : -1;
+        unsigned long long mine = 0ull;
+        for (int vv = v_lo; vv <= v_hi; ++vv) {
+            const unsigned long long m = ballot64(idv == vv);
+            if (vv == v) mine = m;
+        }
+        if (!take) mine = 0ull;
+        while (mine) {                                              // ascending rows
+            const int rr = __builtin_ctzll(mine);
+            mine &= mine - 1;
+            acc += dy[(base + rr) * C + c];
+        }
+    }
+    if (live) partial[(long)blockIdx.y * nq + q] = acc;
 }
 
 // ---- row masking (masked_fill(mask, 0) with a per-row mask), residual add, column-block copy (torch.cat / its gradient)
@@ -896,6 +1051,19 @@ static __global__ void train_repeat_fwd_kernel(const float* __restrict__ feat, c
     while (lo < hi) { const int mid = (lo + hi) >> 1; if (cb[mid] > f) hi = mid; else lo = mid + 1; }
     out[q] = lo < T ? feat[((long)b * T + lo) * C + c] : 0.0f;
 }
+// the same, four channels per thread (C % 4 == 0, 16-byte aligned tensors, B L C / 4 < 2^31): one search per 16 bytes instead of one per float
+static __global__ void train_repeat_fwd4_kernel(const float* __restrict__ feat, const int* __restrict__ cum, int B, int T, int C4, int L,
+                                         float* __restrict__ out) {
+    const unsigned q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= (unsigned)B * (unsigned)L * (unsigned)C4) return;
+    const unsigned row = q / (unsigned)C4, c4 = q - row * (unsigned)C4, b = row / (unsigned)L, f = row - b * (unsigned)L;
+    const int* cb = cum + (long)b * T;
+    int lo = 0, hi = T;
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (cb[mid] > (int)f) hi = mid; else lo = mid + 1; }
+    f32x4 v = zero4();
+    if (lo < T) v = ld4(feat + (((long)b * T + lo) * C4 + c4) * 4);
+    *reinterpret_cast<f32x4*>(out + (long)q * 4) = v;
+}
 static __global__ void train_repeat_bwd_kernel(const float* __restrict__ dout, const int* __restrict__ cum, int B, int T, int C, int L,
                                         float* __restrict__ dfeat) {
     const long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -940,8 +1108,34 @@ static __global__ __launch_bounds__(256) void train_loss_partial_kernel(const Lo
     const long nf = (long)p.B * p.L, np_ = (long)p.B * p.T;
     float cnt_f = 0.0f, cnt_p = 0.0f, a = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
     for (long r = tid; r < nf; r += nth) cnt_f += (p.mel_mask && p.mel_mask[r]) ? 0.0f : 1.0f;
-    for (long q = tid; q < nf * p.n_mel; q += nth)
-        if (!(p.mel_mask && p.mel_mask[q / p.n_mel])) a += fabsf(p.mel_pred[q] - p.mel[q]);
+    const int nm4 = p.n_mel >> 2;
+    const long n4 = nf * nm4;
+    if ((p.n_mel & 3) == 0 && n4 < 0x7FFFFFFFL && ((reinterpret_cast<uintptr_t>(p.mel_pred) | reinterpret_cast<uintptr_t>(p.mel)) & 15) == 0) {
+        // 16 bytes per load, four (prediction, target) pairs in flight per thread, every load unconditional (a clamped index, the
+        // surplus masked): the scalar form below ran 94 dependent element loads and as many 64-bit divisions per thread (81 us at
+        // B = 128 for 49 MB)
+        for (long q0 = tid; q0 < n4; q0 += 4 * nth) {
+            f32x4 pv[4], tv[4];
+            bool ok[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const long qq = q0 + u * nth;
+                const unsigned qc = (unsigned)(qq < n4 ? qq : n4 - 1);
+                ok[u] = qq < n4 && !(p.mel_mask && p.mel_mask[qc / (unsigned)nm4]);
+                pv[u] = ld4(p.mel_pred + (long)qc * 4);
+                tv[u] = ld4(p.mel + (long)qc * 4);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (!ok[u]) continue;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) a += fabsf(pv[u][e] - tv[u][e]);
+            }
+        }
+    } else {
+        for (long q = tid; q < nf * p.n_mel; q += nth)
+            if (!(p.mel_mask && p.mel_mask[q / p.n_mel])) a += fabsf(p.mel_pred[q] - p.mel[q]);
+    }
     for (long r = tid; r < np_; r += nth) {
         if (p.ph_mask && p.ph_mask[r]) continue;
         const float d1 = p.pitch_pred[r] - p.pitch[r], d2 = p.energy_pred[r] - p.energy[r];

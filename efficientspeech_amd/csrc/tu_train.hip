@@ -52,13 +52,38 @@ int reduce_or_defer(esmi_reduce_queue* q, const float* part, long n, long stride
 }
 inline bool wgrad_depthwise(const ConvDesc& c) { return !c.transposed && c.groups == c.c_in && c.c_in == c.c_out && c.k <= 8; }
 inline bool wgrad_on_mfma(const ConvDesc& c);
+inline unsigned wgrad_tiles(const ConvDesc& c) { return (unsigned)(((c.c_out + 127) / 128) * ((c.c_in + 31) / 32) * c.k); }
 inline int wgrad_chunk(const ConvDesc& c) {   // rows per partial sum: fewer for small weights, whose parallelism must come from the chunks
-    if (wgrad_on_mfma(c)) return kTrainChunkMfma;
+    if (wgrad_on_mfma(c)) {
+        // rows per wave, a multiple of 16: as many as give the chip at most two 4-wave workgroups per CU, i.e. ONE round of workgroups
+        // (round 5; before: 96 rows whatever the size -- 800 workgroups = 1.6 rounds for a decoder convolution at B = 128, 34 workgroups
+        // of 6 trips each for the encoder-side ones)
+        const long rows = (long)c.B * c.n_out, want = (rows * wgrad_tiles(c) + 2048 * 16 - 1) / (2048 * 16);
+        return 16 * (int)(want < 1 ? 1 : want > 64 ? 64 : want);
+    }
     if (wgrad_depthwise(c)) return kTrainChunkDw;
     const long nw = (long)(c.transposed ? c.c_in * c.c_out : c.c_out * (c.c_in / c.groups)) * c.k;
     return nw < 1024 ? 32 : kTrainChunk;
 }
-inline bool wgrad_on_mfma(const ConvDesc& c) { return c.groups == 1 && c.c_in >= 8 && c.c_out >= 8 && (c.c_out & 3) == 0; }
+inline bool wgrad_on_mfma(const ConvDesc& c) {
+    // (train_ops.h train_conv_wgrad_mfma_kernel: 32-bit byte offsets into both tensors, one utterance boundary per 16-row trip at most)
+    const long xb = (long)c.B * c.n_in * c.c_in * 4, yb = (long)c.B * c.n_out * c.c_out * 4;
+    return c.groups == 1 && c.c_in >= 8 && c.c_out >= 8 && (c.c_out & 3) == 0 && c.n_out >= 16 && c.n_out < (1 << 23) && xb < 0x7FFFFFFFL && yb < 0x7FFFFFFFL;
+}
+// the matrix-pipe weight gradient (train_ops.h): gridDim = (weight tiles, row groups rounded up to a multiple of 8: XCD-aware order)
+int launch_wgrad_mfma(const ConvDesc& c, const float* x, const float* dy, float* part, float* pb, long chunks, long ps, int* amax, hipStream_t st) {
+    const dim3 grid(wgrad_tiles(c), (unsigned)(((chunks + 3) / 4 + 7) & ~7L));
+    if (c.transposed) {
+        static AttrOnce once;
+        if (int rc = raise_lds_limit(reinterpret_cast<const void*>(train_conv_wgrad_mfma_kernel<true>), once)) return rc;
+        ESMI_LAUNCH(train_conv_wgrad_mfma_kernel<true>, grid, dim3(256), kWgradLdsBytes, st, c, x, dy, part, pb, chunks, ps, wgrad_chunk(c), amax);
+    } else {
+        static AttrOnce once;
+        if (int rc = raise_lds_limit(reinterpret_cast<const void*>(train_conv_wgrad_mfma_kernel<false>), once)) return rc;
+        ESMI_LAUNCH(train_conv_wgrad_mfma_kernel<false>, grid, dim3(256), kWgradLdsBytes, st, c, x, dy, part, pb, chunks, ps, wgrad_chunk(c), amax);
+    }
+    return launch_status();
+}
 }
 // Dense convolutions (groups == 1) of the training step run on the matrix pipe through the inference path's implicit GEMM
 // (convgemm.h) when the caller gives scratch for the tap-major copy of the weight: the forward as it is, the data gradient as
@@ -217,11 +242,7 @@ static int conv_wgrad_impl(const esmi_conv_desc* d, const float* x, const float*
     float* pb = part + nw;
     const long ps = nw + c.c_out;
     if (mfma) {   // dense: one wave per (128 output channels x 32 input channels, tap, chunk) on the fp32 MFMA; bias partials from the tap 0, ci0 = 0 waves
-        const unsigned tiles = (unsigned)(((c.c_out + 127) / 128) * ((c.c_in + 31) / 32) * c.k);
-        static AttrOnce once;
-        if (int rc = raise_lds_limit(reinterpret_cast<const void*>(train_conv_wgrad_mfma_kernel), once)) return rc;
-        ESMI_LAUNCH(train_conv_wgrad_mfma_kernel, dim3(tiles, (unsigned)((chunks + 3) / 4)), dim3(256), kWgradLdsBytes, S(stream), c, x, dy, part,
-                    dbias ? pb : nullptr, chunks, ps);
+        if (int rc = launch_wgrad_mfma(c, x, dy, part, dbias ? pb : nullptr, chunks, ps, nullptr, S(stream))) return rc;
     } else if (depthwise && (c.c_out & 3) == 0 && c.stride == 1 && c.n_in == c.n_out) {
         ESMI_LAUNCH(train_conv_wgrad_dw4_kernel, dim3((unsigned)((c.c_out + 127) / 128), (unsigned)chunks), dim3(256), kDwSub * 9 * 128 * sizeof(float),
                     S(stream), c, x, dy, part, dbias ? pb : nullptr, ps);
@@ -273,18 +294,21 @@ int esmi_train_conv_bwd_f32(const esmi_conv_desc* d, const float* x, const float
     float* part = reinterpret_cast<float*>(ws);
     float* pb = part + nw;
     const long ps = nw + c.c_out;
-    const unsigned tiles = (unsigned)(((c.c_out + 127) / 128) * ((c.c_in + 31) / 32) * c.k);
-    static AttrOnce once;
-    if (int rc = raise_lds_limit(reinterpret_cast<const void*>(train_conv_wgrad_mfma_kernel), once)) return rc;
-    ESMI_LAUNCH(train_conv_wgrad_mfma_kernel, dim3(tiles, (unsigned)((chunks + 3) / 4)), dim3(256), kWgradLdsBytes, S(stream), c, x, dy, part,
-                dbias ? pb : nullptr, chunks, ps, amax);
-    if (int rc = launch_status()) return rc;
+    if (int rc = launch_wgrad_mfma(c, x, dy, part, dbias ? pb : nullptr, chunks, ps, amax, S(stream))) return rc;
     if (int rc = reduce_or_defer(defer, part, dbias ? ps : nw, ps, (chunks + 3) / 4, dw, nw, dbias, S(stream))) return rc;
     return train_conv_gemm(c, true, dy, w, nullptr, dx, wt, d->precision == 16, S(stream), true, false, pre);
 }
 int esmi_train_layernorm_fwd_f32(const float* x, const float* g, const float* b, int64_t rows, int C, float* y, float* mean,
                                  float* rstd, const float* res, float* xsum, const uint8_t* rowmask, int relu_out, esmi_stream_t stream) {
     if (!x || !g || !b || !y || !mean || !rstd || rows <= 0 || C <= 0 || (res && !xsum)) return ESMI_ERR_ARG;
+    uintptr_t al = reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(b);
+    if (res) al |= reinterpret_cast<uintptr_t>(res) | reinterpret_cast<uintptr_t>(xsum);
+    if ((al & 15) == 0 && (C == 32 || C == 64 || C == 128 || C == 256)) {   // rows in registers, 16-byte accesses
+#define ESMI_LN4(LPR) ESMI_LAUNCH(train_ln_fwd4_kernel<LPR>, grid1d(rows, 4 * (64 / LPR)), dim3(256), 0, S(stream), x, g, b, (long)rows, 1e-5f, y, mean, rstd, res, xsum, rowmask, relu_out ? 1 : 0)
+        if (C == 32) ESMI_LN4(8); else if (C == 64) ESMI_LN4(16); else if (C == 128) ESMI_LN4(32); else ESMI_LN4(64);
+#undef ESMI_LN4
+        return launch_status();
+    }
     ESMI_LAUNCH(train_ln_fwd_kernel, grid1d(rows, 4), dim3(256), 0, S(stream), x, g, b, (long)rows, C, 1e-5f, y, mean, rstd, res, xsum, rowmask, relu_out ? 1 : 0);
     return launch_status();
 }
@@ -415,6 +439,10 @@ int esmi_train_cat_f32(float* const* parts, const int* widths, int n, int64_t ro
 }
 int esmi_train_repeat_fwd_f32(const float* feat, const int32_t* cum, int B, int T, int C, int L, float* out, esmi_stream_t stream) {
     if (!feat || !cum || !out || B <= 0 || T <= 0 || C <= 0 || L <= 0) return ESMI_ERR_ARG;
+    if ((C & 3) == 0 && (long)B * L * (C / 4) < 0x7FFFFFFFL && ((reinterpret_cast<uintptr_t>(feat) | reinterpret_cast<uintptr_t>(out)) & 15) == 0) {
+        ESMI_LAUNCH(train_repeat_fwd4_kernel, grid1d((long)B * L * (C / 4)), dim3(256), 0, S(stream), feat, cum, B, T, C / 4, L, out);
+        return launch_status();
+    }
     ESMI_LAUNCH(train_repeat_fwd_kernel, grid1d((long)B * L * C), dim3(256), 0, S(stream), feat, cum, B, T, C, L, out);
     return launch_status();
 }

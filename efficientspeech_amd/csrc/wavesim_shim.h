@@ -197,6 +197,22 @@ __device__ __forceinline__ int shfl_i(int v, int src) {
     return __shfl(v, src, 64);
 #endif
 }
+// a * b for a, b < 2^24 (v_mul_u32_u24: full rate; v_mul_lo_u32 is quarter rate)
+__device__ __forceinline__ unsigned mul24u(unsigned a, unsigned b) {
+#ifdef ESMI_WAVESIM
+    return a * b;
+#else
+    return __umul24(a, b);
+#endif
+}
+// lane `src`'s value for the whole wave, `src` wave-uniform (v_readlane_b32; every lane of the wave must arrive)
+__device__ __forceinline__ int bcast_i(int v, int src) {
+#ifdef ESMI_WAVESIM
+    return wavesim::shfl_i(v, src);
+#else
+    return __builtin_amdgcn_readlane(v, src);
+#endif
+}
 
 __device__ __forceinline__ unsigned long long ballot64(bool pred) {
 #ifdef ESMI_WAVESIM
