@@ -10,6 +10,7 @@
 
 #include "attention.h"
 #include "convgemm.h"
+#include "pwgemm.h"
 #include "hifigan_resblock.h"
 #include "enc_attn_ffn.h"
 #include "enc_fuse_va.h"

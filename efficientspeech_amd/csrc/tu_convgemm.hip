@@ -48,6 +48,36 @@ int launch_convgemm(ConvGemmP p, hipStream_t st) {
         nt = p.c_out > 64 ? 4 : (p.c_out > 32 ? 2 : 1);
     }
 #if ESMI_CHAIN_SPLIT
+    // a Linear over many rows whose whole weight fits in LDS (the training step's decoder GEMMs): pwgemm.h -- one workgroup per CU
+    // stages the weight once and its waves walk the rows
+    if (p.mode == MODE_CONV && p.k == 1 && p.stride == 1 && !p.ids && !p.act_in && (p.c_in == 128 || p.c_in == 80) && p.c_out > 64 && p.c_out <= 128 &&
+        (!p.ln_g || p.c_out == 128) && p.n_in == p.n_out && (long)p.B * p.n_out >= kPwGemmMinRows &&
+        (((long)p.B * p.n_in) * p.lda + p.a_coff + p.c_in) * 4L < (1L << 31)) {
+        const long rows = (long)p.B * p.n_out;
+        // a wave's item: 32 rows x 64 columns (two per row tile: reads and stores of neighbouring items overlap), or x all columns
+        // when the epilogue needs whole rows in one wave
+        const int nh = full_row ? 1 : 2, n_items = (int)((rows + 31) / 32) * nh, want = (n_items + kPwWaves - 1) / kPwWaves;
+        const dim3 grid((unsigned)(want < 256 ? want : 256));
+        static AttrOnce once[8];
+#define ESMI_PW_CASE(KS_, NT_, AMP_, slot)                                                                                     \
+    do {                                                                                                                       \
+        if (int rc = raise_lds_limit(reinterpret_cast<const void*>(pwgemm_kernel<KS_, NT_, AMP_>), once[slot])) return rc;        \
+        ESMI_LAUNCH((pwgemm_kernel<KS_, NT_, AMP_>), grid, dim3(64 * kPwWaves), pwgemm_lds_bytes<KS_>(), st, p, n_items);        \
+    } while (0)
+        const int variant = (p.c_in == 128 ? 0 : 4) + (full_row ? 2 : 0) + (p.amp ? 1 : 0);
+        switch (variant) {
+            case 0: ESMI_PW_CASE(8, 2, false, 0); break;
+            case 1: ESMI_PW_CASE(8, 2, true, 1); break;
+            case 2: ESMI_PW_CASE(8, 4, false, 2); break;
+            case 3: ESMI_PW_CASE(8, 4, true, 3); break;
+            case 4: ESMI_PW_CASE(5, 2, false, 4); break;
+            case 5: ESMI_PW_CASE(5, 2, true, 5); break;
+            case 6: ESMI_PW_CASE(5, 4, false, 6); break;
+            default: ESMI_PW_CASE(5, 4, true, 7); break;
+        }
+#undef ESMI_PW_CASE
+        return launch_status();
+    }
     // large plain convolutions / Linears: operands staged through LDS by convgemm_dma_kernel (convgemm.h) -- needs input rows ==
     // output rows (flat-row addressing) and 32-bit lane offsets: the kernel forms (row + tile rows + halo) * lda BEFORE it clamps, so
     // the bound covers the last workgroup's padded rows and the taps' reach, not just the tensor (the pre-clamp product

@@ -32,12 +32,14 @@ constexpr int kReduceGroups = 4;            // train_ops.h: waves per determinis
 constexpr int kLossBlocks = 8;              // train_ops.h: workgroups of the loss kernel
 constexpr int kAttnLdsMinHeadsDefault = 1;  // tu_attention.hip: (utterance, head) pairs from which attention is LDS-staged
 constexpr int kGemmLdsMinRowsDefault = 1;   // tu_convgemm.hip: rows from which a GEMM is LDS-staged
+constexpr int kPwGemmMinRows = 1;           // tu_convgemm.hip: rows from which a k = 1 GEMM keeps its whole weight in LDS (pwgemm.h)
 #else
 constexpr const char* kBackendName = "hip:gfx950";
 constexpr int kReduceGroups = 16;
 constexpr int kLossBlocks = 256;
 constexpr int kAttnLdsMinHeadsDefault = 128;   // enough (utterance, head) workgroups to occupy the chip at one per CU
 constexpr int kGemmLdsMinRowsDefault = 2048;
+constexpr int kPwGemmMinRows = 32768;       // (one 8-wave workgroup per CU, >= 4 row tiles per wave... below that the staging is not amortised)
 #endif
 
 // ---- MFMA, exact fp32 (v_mfma_f32_32x32x2_f32: 64 cycles/SIMD, == k-ordered fmaf chain)
