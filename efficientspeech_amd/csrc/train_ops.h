@@ -160,6 +160,41 @@ static __global__ void train_conv_wgrad_kernel(const ConvDesc d, const float* __
     }
     partial[(long)blockIdx.y * pstride + q] = acc;
 }
+// A Linear down to ONE channel (the variance predictors' last layer, networks.py:162): its three gradients in one launch -- dx = dy w,
+// and per chunk of <= 64 rows the partial sums of dw = sum_r dy[r] x[r, :] and db = sum_r dy[r] (row order / a fixed butterfly:
+// reproducible).  One wave per chunk: lane l keeps dy of row l, the lanes then run across the channels (coalesced) with dy handed
+// round by v_readlane.  (Before: data gradient, weight gradient and column sum as three launches, the weight gradient with a 64-bit
+// division per row and thread: 5 + 20 + 5 us per predictor at B = 128.)
+static __global__ __launch_bounds__(64) void train_lin1_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ w,
+                                                            long rows, int C, float* __restrict__ dx, float* __restrict__ partial,
+                                                            float* __restrict__ partial_bias, long pstride, int chunk) {
+    const int lane = lane_id();
+    const long r0 = (long)blockIdx.x * chunk;
+    const int nr = (int)(r0 + chunk < rows ? chunk : rows - r0);
+    const float dyv = lane < nr ? dy[r0 + lane] : 0.0f;
+    const int dyb = __builtin_bit_cast(int, dyv);
+    for (int c0 = 0; c0 < C; c0 += 64) {               // (every lane runs the loop: the hand-round is a wave-level exchange)
+        const int c = c0 + lane;
+        const bool ok = c < C;
+        const float wc = ok ? w[c] : 0.0f;
+        float acc = 0.0f;
+#pragma unroll 8
+        for (int rr = 0; rr < nr; ++rr) {
+            const float g = __builtin_bit_cast(float, bcast_i(dyb, rr));
+            if (ok) {
+                acc = fmaf(g, x[(r0 + rr) * C + c], acc);
+                dx[(r0 + rr) * C + c] = g * wc;
+            }
+        }
+        if (ok) partial[(long)blockIdx.x * pstride + c] = acc;
+    }
+    if (partial_bias) {
+        float t = dyv;
+#pragma unroll
+        for (int m = 32; m > 0; m >>= 1) t += shfl_xor_f(t, m);
+        if (lane == 0) partial_bias[(long)blockIdx.x * pstride] = t;
+    }
+}
 // depthwise (groups == C, one input channel per output channel, k <= 8): lanes across the channels (coalesced), every thread
 // keeps the k tap sums and the bias sum of its channel over the chunk's rows
 static __global__ void train_conv_wgrad_dw_kernel(const ConvDesc d, const float* __restrict__ x, const float* __restrict__ dy,

@@ -285,6 +285,16 @@ int esmi_train_conv_bwd_f32(const esmi_conv_desc* d, const float* x, const float
     const bool fused = gemm_bytes > 0 && wgrad_on_mfma(c) &&
                        train_conv_gemm(c, true, dy, w, nullptr, dx, wt, d->precision == 16, S(stream), false, true, pre) == ESMI_OK;
     if (!fused) {
+        if (c.c_out == 1 && c.k == 1 && c.stride == 1 && c.pad == 0 && c.groups == 1 && !c.transposed && c.n_in == c.n_out && wgrad_chunk(c) <= 64) {
+            // a Linear down to one channel: the three gradients in one launch (train_ops.h train_lin1_bwd_kernel)
+            const long rows = (long)c.B * c.n_out, chunks = train_chunks(rows, wgrad_chunk(c));
+            float* part = reinterpret_cast<float*>(ws);
+            const long ps = c.c_in + 1;
+            ESMI_LAUNCH(train_lin1_bwd_kernel, dim3((unsigned)chunks), dim3(64), 0, S(stream), x, dy, w, rows, c.c_in, dx, part, dbias ? part + c.c_in : nullptr, ps,
+                        wgrad_chunk(c));
+            if (int rc = launch_status()) return rc;
+            return reduce_or_defer(defer, part, dbias ? ps : (long)c.c_in, ps, chunks, dw, c.c_in, dbias, S(stream));
+        }
         if (int rc = esmi_train_conv_dgrad_f32(d, dy, w, dx, gemm_bytes ? wt : nullptr, gemm_bytes, stream)) return rc;
         return conv_wgrad_impl(d, x, dy, dw, dbias, workspace, wg_bytes, defer, stream);
     }
