@@ -856,7 +856,7 @@ def main():
         tb, tt = 128, 100
         tnet = make_net(cfg, sd, dev).train()
         tx, ty = _train.synthetic_batch(tb, tt, a.dur, dev, seed=77 + rank)
-        # N = 1: hipGraph replay of the whole step (200 launches; the replay takes the host out of the loop).  N > 1: eager launches --
+        # N = 1: hipGraph replay of the whole step (194 launches; the replay takes the host out of the loop).  N > 1: eager launches --
         # `TrainStep` can replay forward + loss + backward around an eager all-reduce (tested with two gloo ranks on one device), but
         # graph capture next to a live RCCL communicator has never run on hardware, and this leg must not put the headline line at risk
         ts = _train.TrainStep(tnet, world_size=world, graph=(world == 1))
@@ -906,7 +906,7 @@ def main():
                              "roofline": {"bound": "mfma", "algorithmic_flops_per_step": step_flops,
                                           "achieved": step_flops / ttr / 1e12, "peak": F16_PEAK_TFLOPS / 3.0, "unit": "TFLOP/s",
                                           "frac": step_flops / ttr / 1e12 / (F16_PEAK_TFLOPS / 3.0),
-                                          "note": "whole step (200 launches, no dominant kernel): 3 x the forward's "
+                                          "note": "whole step (194 launches, no dominant kernel; per-kernel table: profiles/r05_f_train_kernel_stats.md): 3 x the forward's "
                                                   "contraction FLOPs over the step time against the split-f16 bound; the step is "
                                                   "bound by launch count and by the partial-sum traffic of the deterministic "
                                                   "weight-gradient reductions, not by the matrix pipe (DESIGN.md 3.6)"},

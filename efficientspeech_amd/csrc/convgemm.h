@@ -67,6 +67,10 @@ struct ConvGemmP {
     // behind it leaves its bias in every tap, and the taps that fall on the zero padding do not contribute theirs (esmi.h, ffn_cw)
     const float* bias_first;
     const float* bias_last;
+    // 1: a k = 1 problem over many rows may take pwgemm.h (whole weight resident in LDS).  Its k-slot order differs from the other
+    // kernels', i.e. results differ in the last bits with the row count that selects it: set by the training step only -- the
+    // inference plans promise results that do not depend on how a batch is split
+    int pw_ok;
 };
 // (s, 1/s) for a tensor whose largest magnitude has the bit pattern *absmax
 __device__ __forceinline__ void conv_pow2_scales(const float* absmax, float* s, float* inv) {

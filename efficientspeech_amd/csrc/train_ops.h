@@ -132,7 +132,7 @@ static __global__ void train_conv_dgrad_kernel(const ConvDesc d, const float* __
 // Reductions over the rows (B * n positions) run in two deterministic stages: stage 1 gives every (output element, chunk of
 // kTrainChunk rows) its own thread and writes a partial sum, stage 2 adds the partials of an element in chunk order.
 constexpr int kTrainChunk = 256;
-constexpr int kTrainChunkDw = 256;     // rows per workgroup of the depthwise weight gradient (8 sub-chunks of 32 rows, summed in LDS)
+constexpr int kTrainChunkDw = 128;     // rows per workgroup of the depthwise weight gradient (8 sub-chunks of 16 rows, summed in LDS; 256: 300 workgroups at B = 128, 38 us)
 // (rows per wave of the matrix-pipe weight gradient: tu_train.hip wgrad_chunk -- a multiple of 16 sized for one round of workgroups.
 // Round 3, when a trip was a chain of exposed load latencies, a fixed 48 ... 192 rows made no difference: 5.2-5.7 ms per B = 128 step.)
 __host__ __device__ inline long train_chunks(long rows, int chunk = kTrainChunk) { return (rows + chunk - 1) / chunk; }
@@ -221,7 +221,7 @@ static __global__ void train_conv_wgrad_dw_kernel(const ConvDesc d, const float*
 }
 
 // The same for C % 4 == 0, stride 1, n_in == n_out (every depthwise convolution of the model): a 256-thread workgroup = 32 channel
-// quads x kDwSub row sub-chunks of one chunk.  A thread walks its 32 rows in groups of 8: 8 rows of dY and 8 + k - 1 rows of X
+// quads x kDwSub row sub-chunks of one chunk.  A thread walks its kTrainChunkDw / kDwSub rows in groups of 8: 8 rows of dY and 8 + k - 1 rows of X
 // (16-byte loads; the input row of tap j for flat row r is flat row r + j - pad) feed 8 k fused multiply-adds per channel -- 2.5 loads
 // per row instead of 6 scalar ones; a group that touches an utterance edge takes the tap-by-tap path.  The sub-chunks' sums are
 // added in LDS in sub-chunk order (fixed: reproducible) and one partial row per workgroup goes out.
@@ -578,16 +578,29 @@ static __global__ void train_pack_batch_kernel(const PackBatch b) {
 // the same for a batch of independent reductions in one launch (blockIdx.y = item): the queued second stages of a training step
 struct ReduceItem { const float* partial; long n, stride, chunks; float* out; long n0; float* out1; };
 constexpr int kReduceBatch = 48;
-struct ReduceBatch { int count; ReduceItem items[kReduceBatch]; };
+// (first[i]: the first workgroup of item i in the launch's 1-D grid, first[count]: the grid size.  A 2-D grid sized for the largest
+// item launched ~14,700 workgroups of 16 waves for the step's 48 reductions, most of them leaving at once: 57 us, bound by the dispatcher.)
+struct ReduceBatch { int count; int first[kReduceBatch + 1]; ReduceItem items[kReduceBatch]; };
 static __global__ __launch_bounds__(64 * kReduceGroups) void train_reduce_batch_kernel(const ReduceBatch b) {
     ESMI_DYN_LDS(red);   // 64 * kReduceGroups floats
-    const ReduceItem& it = b.items[blockIdx.y];
+    int ii = 0;
+    while (ii + 1 < b.count && (int)blockIdx.x >= b.first[ii + 1]) ++ii;     // (workgroup-uniform)
+    const ReduceItem& it = b.items[ii];
     const int ex = (int)(threadIdx.x & 63), cy = (int)(threadIdx.x >> 6);
-    const long q = (long)blockIdx.x * 64 + ex;
-    if ((long)blockIdx.x * 64 >= it.n) return;            // (workgroup-uniform: the grid is sized for the largest item)
+    const long q = (long)((int)blockIdx.x - b.first[ii]) * 64 + ex;
     float acc = 0.0f;
     if (q < it.n)
-        for (long c = cy; c < it.chunks; c += kReduceGroups) acc += it.partial[c * it.stride + q];
+        for (long c = cy; c < it.chunks; c += 4 * kReduceGroups) {   // four loads in flight, added in chunk order (the loop was one exposed
+            float v[4];                                               // round trip per partial row: 57 us for the step's 55 MB)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const long cc = c + (long)u * kReduceGroups;
+                v[u] = it.partial[(cc < it.chunks ? cc : c) * it.stride + q];
+                if (cc >= it.chunks) v[u] = 0.0f;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc += v[u];
+        }
     red[cy * 64 + ex] = acc;
     __syncthreads();
     if (cy == 0 && q < it.n) {

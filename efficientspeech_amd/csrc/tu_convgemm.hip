@@ -50,7 +50,7 @@ int launch_convgemm(ConvGemmP p, hipStream_t st) {
 #if ESMI_CHAIN_SPLIT
     // a Linear over many rows whose whole weight fits in LDS (the training step's decoder GEMMs): pwgemm.h -- one workgroup per CU
     // stages the weight once and its waves walk the rows
-    if (p.mode == MODE_CONV && p.k == 1 && p.stride == 1 && !p.ids && !p.act_in && (p.c_in == 128 || p.c_in == 80) && p.c_out > 64 && p.c_out <= 128 &&
+    if (p.pw_ok && p.mode == MODE_CONV && p.k == 1 && p.stride == 1 && !p.ids && !p.act_in && (p.c_in == 128 || p.c_in == 80) && p.c_out > 64 && p.c_out <= 128 &&
         (!p.ln_g || p.c_out == 128) && p.n_in == p.n_out && (long)p.B * p.n_out >= kPwGemmMinRows &&
         (((long)p.B * p.n_in) * p.lda + p.a_coff + p.c_in) * 4L < (1L << 31)) {
         const long rows = (long)p.B * p.n_out;

@@ -28,13 +28,17 @@ int reduce_flush(esmi_reduce_queue* q, hipStream_t st) {
     if (q->count > ESMI_REDUCE_QUEUE_ITEMS) return ESMI_ERR_ARG;
     ReduceBatch b;
     b.count = q->count;
-    long nmax = 0;
+    long blocks = 0;
     for (int i = 0; i < q->count; ++i) {
         const esmi_reduce_item& s = q->items[i];
         b.items[i] = ReduceItem{s.partial, (long)s.n, (long)s.stride, (long)s.chunks, s.out, (long)s.n0, s.out1};
-        nmax = s.n > nmax ? (long)s.n : nmax;
+        b.first[i] = (int)blocks;
+        blocks += ((long)s.n + 63) / 64;
+        if (blocks > 0x7FFFFFFFL) return ESMI_ERR_ARG;
     }
-    ESMI_LAUNCH(train_reduce_batch_kernel, dim3(grid1d(nmax, 64), (unsigned)q->count), dim3(64 * kReduceGroups), 64 * kReduceGroups * sizeof(float), st, b);
+    b.first[q->count] = (int)blocks;
+    if (blocks > 0)
+        ESMI_LAUNCH(train_reduce_batch_kernel, dim3((unsigned)blocks), dim3(64 * kReduceGroups), 64 * kReduceGroups * sizeof(float), st, b);
     q->count = 0;
     return launch_status();
 }
@@ -145,6 +149,7 @@ int train_conv_gemm(const ConvDesc& c, bool grad, const float* in, const float* 
     p.A = in; p.lda = cin; p.W = wuse; p.bias = bias; p.out = out; p.ldo = cout;
     p.amp = amp ? 1 : 0;
     p.act = act;
+    p.pw_ok = 1;
     return launch_convgemm(p, st);
 }
 }  // namespace
