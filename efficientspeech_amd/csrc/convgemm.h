@@ -140,16 +140,23 @@ __device__ __forceinline__ void convgemm_epilogue(f32x16 (&acc)[NT], const ConvG
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int t = t0 + tile_row(r, lane) * ts;
-        const bool rok = t < n_out;
-        const long row = (long)b * n_out + t;
         const int tl = (edge && flat_rows) ? t % p.n_out : t;   // position inside its sequence (flat_rows: t counts rows of the whole batch)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             float bv = bias[nt];
             if (edge) bv = bv - (tl == 0 ? b_first[nt] : 0.0f) - (tl == p.n_out - 1 ? b_last[nt] : 0.0f);
-            float v = apply_act(fmaf(acc[nt][r], out_s, bv), p.act);
-            if (p.res && rok && cok[nt]) v += p.res[row * p.ldr + p.r_coff + col[nt]];
-            acc[nt][r] = v;
+            acc[nt][r] = apply_act(fmaf(acc[nt][r], out_s, bv), p.act);
+        }
+    }
+    if (p.res) {   // (its own loop under a kernel-uniform branch: no load -- and no wait for one -- on the path of a launch without residual)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int t = t0 + tile_row(r, lane) * ts;
+            if (t >= n_out) continue;
+            const long row = (long)b * n_out + t;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+                if (cok[nt]) acc[nt][r] += p.res[row * p.ldr + p.r_coff + col[nt]];
         }
     }
     if (p.dot_out) {
@@ -170,21 +177,47 @@ __device__ __forceinline__ void convgemm_epilogue(f32x16 (&acc)[NT], const ConvG
     }
     if (!p.out) return;
     if (p.ln_g) layernorm_tile<NT>(acc, p.ln_g, p.ln_b, lane);
+    // The row masks first, the stores after them with NO load in between: a load inside the store loop -- even one that a NULL
+    // pointer skips at run time -- makes the compiler wait for it with vmcnt(0) behind the join, and that wait also drains every
+    // store issued so far: the loop ran one HBM write latency per row (11,000 of a decoder-size Linear's 25,000 cycles in a trace).
+    unsigned mbits = 0u;
+    if (p.rowmask) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int t = t0 + tile_row(r, lane) * ts;
+            if (t < n_out && p.rowmask[(long)b * n_out + t]) mbits |= 1u << r;
+        }
+    }
+    if (p.accum) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int t = t0 + tile_row(r, lane) * ts;
+            if (t >= n_out) continue;
+            const long row = (long)b * n_out + t;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                float v = acc[nt][r];
+                if (p.post_relu) v = fmaxf(v, 0.0f);
+                if ((mbits >> r) & 1u) v = 0.0f;
+                if (cok[nt]) {
+                    float* o = p.out + row * p.ldo + p.o_coff + col[nt];
+                    *o = *o + v;
+                }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int t = t0 + tile_row(r, lane) * ts;
         if (t >= n_out) continue;
         const long row = (long)b * n_out + t;
-        const bool masked = p.rowmask && p.rowmask[row];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             float v = acc[nt][r];
             if (p.post_relu) v = fmaxf(v, 0.0f);
-            if (masked) v = 0.0f;
-            if (cok[nt]) {
-                float* o = p.out + row * p.ldo + p.o_coff + col[nt];
-                *o = p.accum ? *o + v : v;
-            }
+            if ((mbits >> r) & 1u) v = 0.0f;
+            if (cok[nt]) p.out[row * p.ldo + p.o_coff + col[nt]] = v;
         }
     }
 }
