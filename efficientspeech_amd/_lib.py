@@ -148,7 +148,7 @@ EXPORTS = (
     "esmi_acoustic_decoder_f32", "esmi_bucket_embedding_f32", "esmi_split_weight_limit", "esmi_absmax_f32",
     "esmi_forward_arena_bytes", "esmi_phoneme2mel_forward_f32", "esmi_hifigan_workspace_bytes", "esmi_hifigan_generator_f32",
     "esmi_pack_resblock_bytes", "esmi_pack_resblock_f16",
-    "esmi_train_conv_fwd_f32", "esmi_train_conv_dgrad_f32", "esmi_train_conv_wgrad_f32", "esmi_train_layernorm_fwd_f32",
+    "esmi_train_conv_fwd_f32", "esmi_train_conv_ln_fwd_f32", "esmi_train_conv_dgrad_f32", "esmi_train_conv_wgrad_f32", "esmi_train_layernorm_fwd_f32",
     "esmi_train_conv_wgrad_workspace_bytes", "esmi_train_layernorm_bwd_workspace_bytes", "esmi_train_conv_workspace_bytes",
     "esmi_train_embedding_bwd_workspace_bytes",
     "esmi_train_layernorm_bwd_f32", "esmi_train_act_fwd_f32", "esmi_train_act_bwd_f32", "esmi_train_attention_fwd_f32",
@@ -218,6 +218,7 @@ def bind(lib):
     lib.esmi_phoneme2mel_forward_f32.argtypes = [P(ForwardArgs), i, fp]
     i64, f, dbl = C.c_int64, C.c_float, C.c_double
     lib.esmi_train_conv_fwd_f32.argtypes = [P(ConvDesc), fp, fp, fp, fp, fp, sz, fp]
+    lib.esmi_train_conv_ln_fwd_f32.argtypes = [P(ConvDesc), fp, fp, fp, fp, fp, fp, fp, i, fp, fp, fp, fp, fp, sz, fp]
     lib.esmi_train_conv_workspace_bytes.argtypes = [P(ConvDesc)]
     lib.esmi_train_conv_workspace_bytes.restype = sz
     lib.esmi_train_conv_dgrad_f32.argtypes = [P(ConvDesc), fp, fp, fp, fp, sz, fp]

@@ -67,6 +67,11 @@ struct ConvGemmP {
     // behind it leaves its bias in every tap, and the taps that fall on the zero padding do not contribute theirs (esmi.h, ffn_cw)
     const float* bias_first;
     const float* bias_last;
+    // training step, conv + LayerNorm in one launch (esmi_train_conv_ln_fwd_f32; all three NULL otherwise, all three set with ln_g):
+    // what the LayerNorm's backward reads -- the normalised tensor itself (act(conv + bias) + res, (rows, c_out)), mean and rstd per row
+    float* ln_pre;
+    float* ln_mean;
+    float* ln_rstd;
     // 1: a k = 1 problem over many rows may take pwgemm.h (whole weight resident in LDS).  Its k-slot order differs from the other
     // kernels', i.e. results differ in the last bits with the row count that selects it: set by the training step only -- the
     // inference plans promise results that do not depend on how a batch is split
@@ -176,10 +181,10 @@ __device__ __forceinline__ void convgemm_epilogue(f32x16 (&acc)[NT], const ConvG
         }
     }
     if (!p.out) return;
-    if (p.ln_g) layernorm_tile<NT>(acc, p.ln_g, p.ln_b, lane);
-    // The row masks first, the stores after them with NO load in between: a load inside the store loop -- even one that a NULL
-    // pointer skips at run time -- makes the compiler wait for it with vmcnt(0) behind the join, and that wait also drains every
-    // store issued so far: the loop ran one HBM write latency per row (11,000 of a decoder-size Linear's 25,000 cycles in a trace).
+    // Every LOAD of this section first -- the row masks, the norm's gain and bias -- and only then stores: a load behind a store,
+    // even one that a NULL pointer skips at run time, makes the compiler wait for it with vmcnt(0) behind the join, and that wait
+    // also drains every store issued so far: the store loop ran one HBM write latency per row (11,000 of a decoder-size Linear's
+    // 25,000 cycles in a trace).
     unsigned mbits = 0u;
     if (p.rowmask) {
 #pragma unroll
@@ -188,6 +193,37 @@ __device__ __forceinline__ void convgemm_epilogue(f32x16 (&acc)[NT], const ConvG
             if (t < n_out && p.rowmask[(long)b * n_out + t]) mbits |= 1u << r;
         }
     }
+    if (p.ln_g && p.ln_pre) {
+        float gg[NT], bb[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) { gg[nt] = p.ln_g[32 * nt + i]; bb[nt] = p.ln_b[32 * nt + i]; }
+        // the pre-norm tensor for the backward, then the norm with its statistics written out (layernorm_tile's arithmetic)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int t = t0 + tile_row(r, lane) * ts;
+            if (t >= n_out) continue;
+            const long row = (long)b * n_out + t;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+                if (cok[nt]) p.ln_pre[row * p.c_out + col[nt]] = acc[nt][r];
+        }
+        const float inv_c = 1.0f / (float)(32 * NT);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float s = 0.0f;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) s += acc[nt][r];
+            const float mean = row_sum32(s) * inv_c;
+            float q = 0.0f;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) { const float d = acc[nt][r] - mean; q = fmaf(d, d, q); }
+            const float rstd = 1.0f / sqrtf(row_sum32(q) * inv_c + 1e-5f);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[nt][r] = fmaf((acc[nt][r] - mean) * rstd, gg[nt], bb[nt]);
+            const int t = t0 + tile_row(r, lane) * ts;
+            if (i == 0 && t < n_out) { p.ln_mean[(long)b * n_out + t] = mean; p.ln_rstd[(long)b * n_out + t] = rstd; }
+        }
+    } else if (p.ln_g) layernorm_tile<NT>(acc, p.ln_g, p.ln_b, lane);
     if (p.accum) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {

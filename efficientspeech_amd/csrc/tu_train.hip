@@ -117,8 +117,10 @@ GemmWeight gemm_weight(const ConvDesc& c, bool grad) {
 // one of the two implicit-GEMM problems of a dense conv: returns ESMI_ERR_UNSUPPORTED when the GEMM does not take the shape
 // (have_absmax: max|in| already sits in the workspace's absmax slot -- the weight-gradient pass of esmi_train_conv_bwd_f32 left it)
 // prepacked: `wt` already holds this step's copy (esmi_train_pack_weights_f32, which also cleared the absmax slot)
+struct ConvLnArgs { const float *res, *g, *b; const unsigned char* rowmask; int relu_out; float *pre, *mean, *rstd; };
 int train_conv_gemm(const ConvDesc& c, bool grad, const float* in, const float* w, const float* bias, float* out, float* wt,
-                    bool amp, hipStream_t st, bool have_absmax = false, bool pack_only = false, bool prepacked = false, int act = 0) {
+                    bool amp, hipStream_t st, bool have_absmax = false, bool pack_only = false, bool prepacked = false, int act = 0,
+                    const ConvLnArgs* ln = nullptr) {
     const GemmWeight g = gemm_weight(c, grad);
     if (!g.ok || !wt) return ESMI_ERR_UNSUPPORTED;
     const int cin = g.cin, cout = g.cout, as_convT = g.as_convT;
@@ -150,6 +152,12 @@ int train_conv_gemm(const ConvDesc& c, bool grad, const float* in, const float* 
     p.amp = amp ? 1 : 0;
     p.act = act;
     p.pw_ok = 1;
+    if (ln) {   // act(conv + bias) + res -> LayerNorm (+ ReLU, + row mask) in the GEMM's epilogue; the pre-norm tensor, mean, rstd kept
+        if (cout != 32 && cout != 64 && cout != 128 && cout != 256) return ESMI_ERR_UNSUPPORTED;
+        p.res = ln->res; p.ldr = cout; p.r_coff = 0;
+        p.ln_g = ln->g; p.ln_b = ln->b; p.rowmask = ln->rowmask; p.post_relu = ln->relu_out;
+        p.ln_pre = ln->pre; p.ln_mean = ln->mean; p.ln_rstd = ln->rstd;
+    }
     return launch_convgemm(p, st);
 }
 }  // namespace
@@ -185,6 +193,18 @@ int esmi_train_pack_weights_f32(const esmi_conv_desc* descs, const float* const*
         }
     }
     return flush();
+}
+int esmi_train_conv_ln_fwd_f32(const esmi_conv_desc* d, const float* x, const float* w, const float* bias, const float* res,
+                               const float* ln_g, const float* ln_b, const uint8_t* rowmask, int relu_out, float* y_pre, float* y,
+                               float* mean, float* rstd, void* workspace, size_t workspace_bytes, esmi_stream_t stream) {
+    ConvDesc c;
+    if (int rc = conv_desc_ok(d, &c)) return rc;
+    if (!x || !w || !ln_g || !ln_b || !y_pre || !y || !mean || !rstd || d->act < 0 || d->act > ACT_TANH) return ESMI_ERR_ARG;
+    if (c.stride != 1 || c.transposed || c.n_in != c.n_out) return ESMI_ERR_UNSUPPORTED;
+    if (!(d->packed_fwd || (workspace && workspace_bytes >= esmi_train_conv_workspace_bytes(d)))) return ESMI_ERR_UNSUPPORTED;
+    float* wt = d->packed_fwd ? d->packed_fwd : static_cast<float*>(workspace);
+    const ConvLnArgs ln{res, ln_g, ln_b, rowmask, relu_out ? 1 : 0, y_pre, mean, rstd};
+    return train_conv_gemm(c, false, x, w, bias, y, wt, d->precision == 16, S(stream), false, false, d->packed_fwd != nullptr, d->act, &ln);
 }
 int esmi_train_conv_fwd_f32(const esmi_conv_desc* d, const float* x, const float* w, const float* bias, float* y, void* workspace,
                             size_t workspace_bytes, esmi_stream_t stream) {

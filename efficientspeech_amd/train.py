@@ -158,6 +158,80 @@ class _LayerNorm(torch.autograd.Function):
         return dx, (None if g_direct else dg), (None if b_direct else db), (dx if ctx.has_res else None), None, None, None
 
 
+class _ConvLN(torch.autograd.Function):
+    """conv (stride 1) / Linear, its activation, an optional residual add, LayerNorm, the norm's ReLU and row mask in ONE forward
+    launch (`esmi_train_conv_ln_fwd_f32`: the norm in the GEMM's epilogue) -- the chain `layer_norm(conv(x, m, act, True), norm, res,
+    mask, in_act=act, relu_out)` of two launches otherwise.  The backward is that chain's: the fused LayerNorm backward (which also
+    runs the activation's), then the convolution's two gradients.  Shapes the fused launch does not take run the two forward launches
+    here, so the saved tensors and the backward are the same either way."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, pad, groups, act, g, beta, res, mask, relu_out):
+        assert act in (0, ACT_RELU, ACT_TANH) and not (act and res is not None)
+        w0 = w
+        x, w = x.contiguous(), w.contiguous()
+        lib, st = _rt(x)
+        B, n, c_in = x.shape
+        w3 = w if w.dim() == 3 else w.unsqueeze(-1)
+        c_out, k = w3.shape[0], w3.shape[2]
+        d = _lib.ConvDesc(B, n, c_in, n, c_out, k, 1, pad, groups, 0, 16 if PRECISION == 16 else 0, act)
+        packed = getattr(w0, "_esmi_packed", None) if (_PACKED_VALID and USE_MATRIX_PIPE) else None
+        if packed is not None:
+            d.packed_fwd, d.packed_grad = _ptr(packed[0]), (_ptr(packed[1]) if USE_MATRIX_PIPE_DGRAD else None)
+        rows = B * n
+        y_pre, y, mean, rstd = _new((B, n, c_out), x), _new((B, n, c_out), x), _new((rows,), x), _new((rows,), x)
+        nws = lib.esmi_train_conv_workspace_bytes(C.byref(d)) if (USE_MATRIX_PIPE and packed is None) else 0
+        ws = _new((nws,), x, torch.uint8) if nws else None
+        if res is not None:
+            res = res.contiguous()
+        fused = False
+        if USE_MATRIX_PIPE and groups == 1:
+            try:
+                lib.esmi_train_conv_ln_fwd_f32(C.byref(d), _ptr(x), _ptr(w), _ptr(b), _ptr(res), _ptr(g), _ptr(beta), _ptr(mask),
+                                               1 if relu_out else 0, _ptr(y_pre), _ptr(y), _ptr(mean), _ptr(rstd), _ptr(ws), nws, st)
+                fused = True
+            except _lib.Unsupported:
+                pass
+        if not fused:                       # the two launches (conv into y, then the norm in place: it reads a row before it writes it)
+            tmp = y if res is not None else y_pre
+            lib.esmi_train_conv_fwd_f32(C.byref(d), _ptr(x), _ptr(w), _ptr(b), _ptr(tmp), _ptr(ws), nws, st)
+            lib.esmi_train_layernorm_fwd_f32(_ptr(tmp), _ptr(g), _ptr(beta), rows, c_out, _ptr(y), _ptr(mean), _ptr(rstd),
+                                             _ptr(res), _ptr(y_pre) if res is not None else None, _ptr(mask), 1 if relu_out else 0, st)
+        ctx.save_for_backward(x, w, y_pre, g, mean, rstd, mask, y if relu_out else None)
+        ctx.d, ctx.params, ctx.has_res, ctx.act = d, (w0, b, g, beta), res is not None, act
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, y_pre, g, mean, rstd, mask, y_relu = ctx.saved_tensors
+        dy = dy.contiguous()
+        lib, st = _rt(dy)
+        d = ctx.d
+        rows, Cc = y_pre.numel() // y_pre.shape[-1], y_pre.shape[-1]
+        w0, b0, g0, beta0 = ctx.params
+        dpre = torch.empty_like(y_pre)
+        (dg, g_direct), (dbt, bt_direct) = _grad_buffer(g0), _grad_buffer(beta0)
+        nws = lib.esmi_train_layernorm_bwd_workspace_bytes(rows, Cc)
+        ws = _new((nws,), x, torch.uint8)
+        lib.esmi_train_layernorm_bwd_f32(_ptr(y_pre), _ptr(g), _ptr(mean), _ptr(rstd), _ptr(dy), rows, Cc, _ptr(dpre), _ptr(dg), _ptr(dbt),
+                                         _ptr(ws), nws, _defer(ws, g_direct, bt_direct), _ptr(mask), ctx.act, _ptr(y_relu), st)
+        dx = torch.empty_like(x)
+        dw, w_direct = _grad_buffer(w0)
+        db, b_direct = _grad_buffer(b0) if b0 is not None else (None, True)
+        if USE_MATRIX_PIPE and USE_MATRIX_PIPE_DGRAD:
+            nws = lib.esmi_train_conv_bwd_workspace_bytes(C.byref(d))
+            ws = _new((nws,), w, torch.uint8)
+            lib.esmi_train_conv_bwd_f32(C.byref(d), _ptr(x), _ptr(dpre), _ptr(w), _ptr(dx), _ptr(dw), _ptr(db), _ptr(ws), nws,
+                                        _defer(ws, w_direct, b_direct), st)
+        else:
+            lib.esmi_train_conv_dgrad_f32(C.byref(d), _ptr(dpre), _ptr(w), _ptr(dx), None, 0, st)
+            nws = lib.esmi_train_conv_wgrad_workspace_bytes(C.byref(d))
+            ws = _new((nws,), w, torch.uint8)
+            lib.esmi_train_conv_wgrad_f32(C.byref(d), _ptr(x), _ptr(dpre), _ptr(dw), _ptr(db), _ptr(ws), nws, st)
+        return (dx, (None if w_direct else dw), (None if b_direct else db), None, None, None, (None if g_direct else dg),
+                (None if bt_direct else dbt), (dpre if ctx.has_res else None), None, None)
+
+
 class _Act(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, kind):
@@ -374,6 +448,23 @@ def layer_norm(x, m, res=None, mask=None, in_act=0, relu_out=False):
     return _LayerNorm.apply(x, m.weight, m.bias, res, mask, in_act, relu_out)
 
 
+FUSE_CONV_LN = False      # True: a convolution and the LayerNorm behind it are ONE forward launch (`_ConvLN`, esmi_train_conv_ln_fwd_f32).
+#                           Measured on tiny ES at B = 128 (profiles/r05_probes/train_conv_ln_fusion.md): 194 -> 182 launches, but 3.14 -> 3.19 ms of
+#                           kernels per step -- the norm in the GEMM's epilogue (two row reductions per row in the MFMA C layout, a second
+#                           full-size store for the pre-norm tensor) costs more than the 15 us stand-alone norm it replaces: off by default
+
+
+def conv_ln(x, m, norm, act=0, res=None, mask=None, relu_out=False):
+    """layer_norm(conv(x, m, act, act_grad_downstream=True), norm, res, mask, in_act=act, relu_out); with FUSE_CONV_LN the norm rides in
+    the convolution's launch (`_ConvLN`).  m: a Linear or a stride-1 Conv1d."""
+    if not FUSE_CONV_LN:
+        return layer_norm(conv(x, m, act=act, act_grad_downstream=bool(act)), norm, res=res, mask=mask, in_act=act, relu_out=relu_out)
+    if isinstance(m, torch.nn.Linear):
+        return _ConvLN.apply(x, m.weight, m.bias, 0, 1, act, norm.weight, norm.bias, res, mask, relu_out)
+    assert not isinstance(m, torch.nn.ConvTranspose1d) and m.stride[0] == 1 and x.shape[1] + 2 * m.padding[0] - (m.kernel_size[0] - 1) == x.shape[1]
+    return _ConvLN.apply(x, m.weight, m.bias, m.padding[0], m.groups, act, norm.weight, norm.bias, res, mask, relu_out)
+
+
 def act(x, kind):
     return _Act.apply(x, kind)
 
@@ -398,10 +489,9 @@ def encoder_forward(enc, phoneme, mask_u8):
     for merge3, merge1, attn, ffn, norm1, norm2 in enc.attn_blocks:
         x = conv(conv(x, merge3), merge1)
         m = _pooled_mask(mask_u8, T, T, x.shape[1]) if mask_u8 is not None else None
-        y = conv(_AttnCore.apply(conv(x, attn.qkv), attn.num_heads), attn.proj)
-        x = layer_norm(y, norm1, res=x, mask=m)                  # LN(attn(x) + x), padded positions zeroed: one launch
-        y = conv(act(conv(conv(x, ffn.mlp1), ffn.conv), ACT_GELU), ffn.mlp2)
-        x = layer_norm(y, norm2, res=x, mask=m)
+        # LN(attn(x) + x) and LN(ffn(x) + x), padded positions zeroed: the add, the norm and the mask ride in the last Linear's launch
+        x = conv_ln(_AttnCore.apply(conv(x, attn.qkv), attn.num_heads), attn.proj, norm1, res=x, mask=m)
+        x = conv_ln(act(conv(conv(x, ffn.mlp1), ffn.conv), ACT_GELU), ffn.mlp2, norm2, res=x, mask=m)
         feats.append(x)
     return feats
 
@@ -421,8 +511,7 @@ def fuse_forward(fuse, feats, mask_u8):
 
 def predictor_forward(dec, fused):
     """AcousticDecoder.forward, networks.py:151-165 -> (pred (B, T, 1), features (B, T, dim))."""
-    y = conv(fused, dec.conv1[0], act=ACT_RELU, act_grad_downstream=True)
-    y = layer_norm(y, dec.norm1, in_act=ACT_RELU, relu_out=True)
+    y = conv_ln(fused, dec.conv1[0], dec.norm1, act=ACT_RELU, relu_out=True)
     y = conv(y, dec.conv2[0], act=ACT_RELU)
     if dec.duration:
         return conv(y, dec.linear, act=ACT_RELU), layer_norm(y, dec.norm2)
@@ -444,11 +533,11 @@ def _bucket_embedding(dec, target):
 
 def decoder_forward(dec, features):
     """MelDecoder.forward, networks.py:291-304."""
-    skip = layer_norm(conv(features, dec.proj[0], act=ACT_TANH, act_grad_downstream=True), dec.proj[2], in_act=ACT_TANH)
+    skip = conv_ln(features, dec.proj[0], dec.proj[2], act=ACT_TANH)
     for convs, skip_norm in dec.blocks:
         x = skip
         for seq, norm in convs:
-            x = layer_norm(conv(conv(x, seq[0]), seq[1], act=ACT_TANH, act_grad_downstream=True), norm, in_act=ACT_TANH)
+            x = conv_ln(conv(x, seq[0]), seq[1], norm, act=ACT_TANH)
         skip = layer_norm(x, skip_norm, res=skip)
     return conv(skip, dec.mel_linear)
 

@@ -549,6 +549,16 @@ int esmi_train_layernorm_fwd_f32(const float* x, const float* g, const float* b,
                                  float* rstd, const float* res /* or NULL */, float* xsum /* with res */,
                                  const uint8_t* rowmask /* or NULL */, int relu_out /* 1: y = relu(LN(.)), networks.py:153-154 */,
                                  esmi_stream_t stream);
+/* A stride-1 convolution / Linear with the LayerNorm behind it in ONE launch (round 5: the norm rides in the GEMM's epilogue, as it does
+ * in the inference plans): y_pre = act(conv(x) + bias) + res is what the norm's backward reads as its `x` (with in_act = d->act when
+ * the activation's backward is to run there), y = mask(relu_out(LN(y_pre))), mean / rstd per row.  Same arguments as the two calls it
+ * replaces (esmi_train_conv_fwd_f32, then esmi_train_layernorm_fwd_f32 with xsum = y_pre).  ESMI_ERR_UNSUPPORTED when the shape does
+ * not run as a GEMM with a whole row per wave (c_out not in {32, 64, 128, 256}, strided / transposed, no workspace): make the two
+ * calls then -- the results agree to fp32 rounding (the sums of the norm run in a different order), the backward is the same. */
+int esmi_train_conv_ln_fwd_f32(const esmi_conv_desc* d, const float* x, const float* w, const float* bias /* or NULL */,
+                               const float* res /* or NULL */, const float* ln_g, const float* ln_b,
+                               const uint8_t* rowmask /* or NULL */, int relu_out, float* y_pre, float* y, float* mean, float* rstd,
+                               void* workspace, size_t workspace_bytes, esmi_stream_t stream);
 size_t esmi_train_layernorm_bwd_workspace_bytes(int64_t rows, int C);
 int esmi_train_layernorm_bwd_f32(const float* x, const float* g, const float* mean, const float* rstd, const float* dy,
                                  int64_t rows, int C, float* dx, float* dg, float* db, void* workspace, size_t workspace_bytes,

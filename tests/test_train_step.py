@@ -2,6 +2,7 @@
 (tools/gen_golden_train.py: the reference's train=True forward, model.py's loss arithmetic, torch autograd, torch AdamW).
 The same checks run on the MI355X through libesmi.so (-m gpu) and on the CPU wave-simulator build of the same kernels;
 the data-parallel step runs as two gloo ranks on the simulator (RCCL on the node: the same torch.distributed call)."""
+import contextlib
 import os
 import socket
 import sys
@@ -175,6 +176,31 @@ def test_simulated_loss_kernel_matches_oracle():
 def test_simulated_loss_and_gradients_match_reference(gold):
     with use_sim():
         check_loss_and_gradients("cpu", gold)
+
+
+@contextlib.contextmanager
+def fused_conv_ln(train):
+    """train.FUSE_CONV_LN for one check: conv + LayerNorm as ONE forward launch (esmi_train_conv_ln_fwd_f32)."""
+    train.FUSE_CONV_LN = True
+    try:
+        yield
+    finally:
+        train.FUSE_CONV_LN = False
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("gold", [GOLD, GOLD_SMALL], ids=["b2_padded", "small"])
+def test_gpu_fused_conv_layernorm_matches_reference(gold):
+    """The same golden losses / gradients with the norm in the convolution's launch (off by default: train.FUSE_CONV_LN)."""
+    from efficientspeech_amd import train
+    with fused_conv_ln(train):
+        check_loss_and_gradients("cuda", gold)
+
+
+def test_simulated_fused_conv_layernorm_matches_reference():
+    from efficientspeech_amd import train
+    with use_sim(), fused_conv_ln(train):
+        check_loss_and_gradients("cpu", GOLD)
 
 
 def test_simulated_adamw_step_matches_reference():
