@@ -46,6 +46,12 @@ int launch_convgemm(ConvGemmP p, hipStream_t st) {
         if (p.ln_g && p.c_out != 32 * nt) return ESMI_ERR_UNSUPPORTED;  // LN width must be 32/64/128/256
     } else {
         nt = p.c_out > 64 ? 4 : (p.c_out > 32 ? 2 : 1);
+        // small problems: narrower column tiles until the launch has ~a wave per SIMD.  A wave splits its OWN 32 nt weight rows into
+        // the f16 pieces at every k-step (this kernel takes the weights as stored), so with 200-400 row tiles -- the training step's
+        // encoder-size GEMMs, 64 workgroups on 256 CUs -- a wave was VALU-bound on splitting 2-4 column tiles' weights while three
+        // quarters of the chip idled.  An output element's products and their order do not depend on nt: bitwise the same results.
+        const long row_tiles = (long)p.B * convgemm_tiles_per_phase(p) * convgemm_row_stride(p);
+        while (nt > 1 && row_tiles * ((p.c_out + 32 * nt - 1) / (32 * nt)) < 1024) nt >>= 1;
     }
 #if ESMI_CHAIN_SPLIT
     // a Linear over many rows whose whole weight fits in LDS (the training step's decoder GEMMs): pwgemm.h -- one workgroup per CU
