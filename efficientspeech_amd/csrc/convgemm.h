@@ -193,7 +193,10 @@ __device__ __forceinline__ void convgemm_epilogue(f32x16 (&acc)[NT], const ConvG
             if (t < n_out && p.rowmask[(long)b * n_out + t]) mbits |= 1u << r;
         }
     }
+    bool ln_done = false;
+    if constexpr (NT <= 4) {   // (the 256-channel instantiations have no registers to spare: the training step's fused form stops at 128)
     if (p.ln_g && p.ln_pre) {
+        ln_done = true;
         float gg[NT], bb[NT];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) { gg[nt] = p.ln_g[32 * nt + i]; bb[nt] = p.ln_b[32 * nt + i]; }
@@ -223,7 +226,9 @@ __device__ __forceinline__ void convgemm_epilogue(f32x16 (&acc)[NT], const ConvG
             const int t = t0 + tile_row(r, lane) * ts;
             if (i == 0 && t < n_out) { p.ln_mean[(long)b * n_out + t] = mean; p.ln_rstd[(long)b * n_out + t] = rstd; }
         }
-    } else if (p.ln_g) layernorm_tile<NT>(acc, p.ln_g, p.ln_b, lane);
+    }
+    }
+    if (p.ln_g && !ln_done) layernorm_tile<NT>(acc, p.ln_g, p.ln_b, lane);
     if (p.accum) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {

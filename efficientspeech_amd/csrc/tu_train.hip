@@ -153,7 +153,7 @@ int train_conv_gemm(const ConvDesc& c, bool grad, const float* in, const float* 
     p.act = act;
     p.pw_ok = 1;
     if (ln) {   // act(conv + bias) + res -> LayerNorm (+ ReLU, + row mask) in the GEMM's epilogue; the pre-norm tensor, mean, rstd kept
-        if (cout != 32 && cout != 64 && cout != 128 && cout != 256) return ESMI_ERR_UNSUPPORTED;
+        if (cout != 32 && cout != 64 && cout != 128) return ESMI_ERR_UNSUPPORTED;   // (256: convgemm_epilogue compiles the fused form for NT <= 4 only)
         p.res = ln->res; p.ldr = cout; p.r_coff = 0;
         p.ln_g = ln->g; p.ln_b = ln->b; p.rowmask = ln->rowmask; p.post_relu = ln->relu_out;
         p.ln_pre = ln->pre; p.ln_mean = ln->mean; p.ln_rstd = ln->rstd;

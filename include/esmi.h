@@ -553,7 +553,7 @@ int esmi_train_layernorm_fwd_f32(const float* x, const float* g, const float* b,
  * in the inference plans): y_pre = act(conv(x) + bias) + res is what the norm's backward reads as its `x` (with in_act = d->act when
  * the activation's backward is to run there), y = mask(relu_out(LN(y_pre))), mean / rstd per row.  Same arguments as the two calls it
  * replaces (esmi_train_conv_fwd_f32, then esmi_train_layernorm_fwd_f32 with xsum = y_pre).  ESMI_ERR_UNSUPPORTED when the shape does
- * not run as a GEMM with a whole row per wave (c_out not in {32, 64, 128, 256}, strided / transposed, no workspace): make the two
+ * not run as a GEMM with a whole row per wave (c_out not in {32, 64, 128}, strided / transposed, no workspace): make the two
  * calls then -- the results agree to fp32 rounding (the sums of the norm run in a different order), the backward is the same. */
 int esmi_train_conv_ln_fwd_f32(const esmi_conv_desc* d, const float* x, const float* w, const float* bias /* or NULL */,
                                const float* res /* or NULL */, const float* ln_g, const float* ln_b,
