@@ -447,37 +447,39 @@ __global__ __launch_bounds__(64 * NKT, 2) void attn_lds_kernel(const AttnP p) {
             }
         }
         __syncthreads();
-        f32x16 o[4];
+        // 64 output channels at a time (round 5: with all 128 in flight -- s: 128 registers, o: 64 -- the <8> instantiation spilled 228 B per
+        // lane; the probabilities are split again for the second half, eight conversions per step against twelve MFMAs)
+        for (int nh = 0; 64 * nh < CK; ++nh) {
+            f32x16 o[2] = {zero16(), zero16()};
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) o[nt] = zero16();
+            for (int kt = 0; kt < NKT; ++kt) {
 #pragma unroll
-        for (int kt = 0; kt < NKT; ++kt) {
+                for (int r8 = 0; r8 < 16; r8 += 8) {
+                    f32x4 pa, pb2;
 #pragma unroll
-            for (int r8 = 0; r8 < 16; r8 += 8) {
-                f32x4 pa, pb2;
+                    for (int e = 0; e < 4; ++e) { pa[e] = s[kt][r8 + e]; pb2[e] = s[kt][r8 + 4 + e]; }
+                    const f16x2p pf = split_f16x2(pa, pb2);
+                    const int slot = 32 * kt + 2 * r8 + 8 * h2;          // this half wave's eight k-slots of the step
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { pa[e] = s[kt][r8 + e]; pb2[e] = s[kt][r8 + 4 + e]; }
-                const f16x2p pf = split_f16x2(pa, pb2);
-                const int slot = 32 * kt + 2 * r8 + 8 * h2;          // this half wave's eight k-slots of the step
-#pragma unroll
-                for (int nt = 0; nt < 4; ++nt) {
-                    if (32 * nt >= CK) continue;                      // workgroup-uniform
-                    const char* a = lds + opaque_i((32 * nt + i) * vrs + slot * 2);
-                    const u32x4 v1 = *reinterpret_cast<const u32x4*>(a), v2 = *reinterpret_cast<const u32x4*>(a + vplane);
-                    o[nt] = mfma32_f16(pf.h2, v1, o[nt]);
-                    o[nt] = mfma32_f16(pf.h1, v2, o[nt]);
-                    o[nt] = mfma32_f16(pf.h1, v1, o[nt]);
+                    for (int nt = 0; nt < 2; ++nt) {
+                        if (32 * (2 * nh + nt) >= CK) continue;           // workgroup-uniform
+                        const char* a = lds + opaque_i((32 * (2 * nh + nt) + i) * vrs + slot * 2);
+                        const u32x4 v1 = *reinterpret_cast<const u32x4*>(a), v2 = *reinterpret_cast<const u32x4*>(a + vplane);
+                        o[nt] = mfma32_f16(pf.h2, v1, o[nt]);
+                        o[nt] = mfma32_f16(pf.h1, v2, o[nt]);
+                        o[nt] = mfma32_f16(pf.h1, v1, o[nt]);
+                    }
                 }
             }
-        }
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int q = q0 + tile_row(r, lane);
-            if (q >= p.N) continue;
-            float* orow = p.ctx + ((long)b * p.N + q) * (p.h * C) + hd * C + c0 + i;
+            for (int r = 0; r < 16; ++r) {
+                const int q = q0 + tile_row(r, lane);
+                if (q >= p.N) continue;
+                float* orow = p.ctx + ((long)b * p.N + q) * (p.h * C) + hd * C + c0 + 64 * nh + i;
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt)
-                if (32 * nt + i < CK) orow[32 * nt] = o[nt][r];
+                for (int nt = 0; nt < 2; ++nt)
+                    if (64 * nh + 32 * nt + i < CK) orow[32 * nt] = o[nt][r];
+            }
         }
     }
 }
