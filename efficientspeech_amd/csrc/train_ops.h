@@ -788,6 +788,95 @@ static __global__ __launch_bounds__(256) void train_ln_bwd_fused_kernel(const fl
     }
 }
 
+// The same for C = 4 LPR in {32, 64, 128} on 16-byte aligned tensors (round 5): LPR lanes per row, 64 / LPR rows per pass, 16-byte
+// accesses, and ALL of a wave's 16 rows loaded before the first is used -- the kernel above walks its rows one by one, every row a
+// dependent round trip (mean, rstd, mask, then x and dy): 20 us for an encoder-size launch of 1.6 MB, 29 us at decoder size.  A lane's
+// dgamma / dbeta sums run over the rows of its lane group; the groups are then added by a fixed butterfly, the waves in wave order.
+template <int LPR>
+static __global__ __launch_bounds__(256) void train_ln_bwd4_kernel(const float* __restrict__ x, const float* __restrict__ g,
+                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                            const float* __restrict__ dy, long rows, float* __restrict__ dx,
+                                                            float* __restrict__ partial, const unsigned char* __restrict__ rowmask,
+                                                            int in_act, const float* __restrict__ y_relu) {
+    constexpr int RPW = 64 / LPR, C = 4 * LPR, WROWS = kLnRows / 4, NP = WROWS / RPW;
+    ESMI_DYN_LDS(red);   // [4 waves][2][256] floats
+    const long chunk = blockIdx.x;
+    const int lane = lane_id(), w = wave_id(), sub = lane / LPR, l = lane % LPR;
+    const long rw0 = chunk * kLnRows + (long)w * WROWS + sub;          // this lane's row of pass p: rw0 + RPW p
+    const f32x4 gv = ld4(g + 4 * l);
+    f32x4 xv[NP], dv[NP];
+    float mm[NP], rr[NP];
+    unsigned livem = 0u, maskm = 0u;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        const long r = rw0 + RPW * p, rc = r < rows ? r : rows - 1;
+        xv[p] = ld4(x + rc * C + 4 * l);
+        dv[p] = ld4(dy + rc * C + 4 * l);
+        mm[p] = mean[rc];
+        rr[p] = rstd[rc];
+        if (r < rows) livem |= 1u << p;
+    }
+    if (rowmask) {
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            const long r = rw0 + RPW * p;
+            if (rowmask[r < rows ? r : rows - 1]) maskm |= 1u << p;
+        }
+    }
+    if (y_relu) {   // dy counts only where the forward's relu(LN(.)) output is positive
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            const long r = rw0 + RPW * p;
+            const f32x4 yv = ld4(y_relu + (r < rows ? r : rows - 1) * C + 4 * l);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) if (!(yv[e] > 0.0f)) dv[p][e] = 0.0f;
+        }
+    }
+    f32x4 dga = zero4(), dba = zero4();
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        const bool live = (livem >> p) & 1u;
+        if (!live || ((maskm >> p) & 1u)) dv[p] = zero4();            // (a zero dy row: dx = 0, no contribution to dgamma / dbeta)
+        f32x4 xh, dh;
+        float s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            xh[e] = (xv[p][e] - mm[p]) * rr[p];
+            dh[e] = dv[p][e] * gv[e];
+            s1 += dh[e];
+            s2 = fmaf(dh[e], xh[e], s2);
+            dga[e] = fmaf(dv[p][e], xh[e], dga[e]);
+            dba[e] += dv[p][e];
+        }
+#pragma unroll
+        for (int k = LPR / 2; k > 0; k >>= 1) { s1 += shfl_xor_f(s1, k); s2 += shfl_xor_f(s2, k); }
+        s1 = s1 / (float)C;
+        s2 = s2 / (float)C;
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = rr[p] * (dh[e] - s1 - xh[e] * s2) * act_grad_from_output(in_act, xv[p][e]);
+        if (live) *reinterpret_cast<f32x4*>(dx + (rw0 + RPW * p) * C + 4 * l) = o;
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+#pragma unroll
+        for (int k = LPR; k < 64; k <<= 1) { dga[e] += shfl_xor_f(dga[e], k); dba[e] += shfl_xor_f(dba[e], k); }
+    }
+    if (sub == 0) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            red[(w * 2 + 0) * 256 + 4 * l + e] = dga[e];
+            red[(w * 2 + 1) * 256 + 4 * l + e] = dba[e];
+        }
+    }
+    __syncthreads();
+    for (int e = (int)threadIdx.x; e < 2 * C; e += 256) {      // e < C: dgamma[e], else dbeta[e - C]
+        const int which = e >= C ? 1 : 0, c = e - which * C;
+        partial[chunk * 2 * C + e] = ((red[(0 * 2 + which) * 256 + c] + red[(1 * 2 + which) * 256 + c]) + red[(2 * 2 + which) * 256 + c]) +
+                                     red[(3 * 2 + which) * 256 + c];
+    }
+}
+
 // partial[chunk][0][c] = sum dy * xhat, partial[chunk][1][c] = sum dy over the chunk's rows
 static __global__ void train_ln_bwd_params_kernel(const float* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ rstd,
                                            const float* __restrict__ dy, long rows, int C, float* __restrict__ partial,

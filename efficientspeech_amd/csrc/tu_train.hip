@@ -361,6 +361,15 @@ int esmi_train_layernorm_bwd_f32(const float* x, const float* g, const float* me
     long chunks;
     if (C <= 256) {   // dx and the parameter partials in one pass
         chunks = train_chunks(rows, kLnRows);
+        uintptr_t al = reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(dx) | reinterpret_cast<uintptr_t>(g);
+        if (y_relu) al |= reinterpret_cast<uintptr_t>(y_relu);
+        if ((al & 15) == 0 && (C == 32 || C == 64 || C == 128)) {   // rows in registers, 16-byte accesses, all rows of a wave loaded up front
+#define ESMI_LNB4(LPR) ESMI_LAUNCH(train_ln_bwd4_kernel<LPR>, dim3((unsigned)chunks), dim3(256), 4 * 2 * 256 * sizeof(float), S(stream), x, g, mean, rstd, dy, (long)rows, dx, part, rowmask, in_act, y_relu)
+            if (C == 32) ESMI_LNB4(8); else if (C == 64) ESMI_LNB4(16); else ESMI_LNB4(32);
+#undef ESMI_LNB4
+            if (int rc = launch_status()) return rc;
+            return reduce_or_defer(defer, part, 2L * C, 2L * C, chunks, dg, (long)C, db, S(stream));
+        }
         ESMI_LAUNCH(train_ln_bwd_fused_kernel, dim3((unsigned)chunks), dim3(256), 4 * 2 * 256 * sizeof(float), S(stream), x, g, mean, rstd, dy, (long)rows, C, dx, part, rowmask, in_act, y_relu);
         if (int rc = launch_status()) return rc;
     } else {
