@@ -793,6 +793,15 @@ class Phoneme2Mel(nn.Module):
             return pred
         # inference: the (B,L,4*dim) tensor is never materialised -- the decoder gathers through the duration scan and
         # applies the final masked_fill itself; the whole forward is ONE C-ABI call (esmi_phoneme2mel_forward_f32)
+        if os.environ.get("ESMI_DEBUG_RANGE") == "1":
+            # the FIRST forward of every set of weights runs on the range-checked build (check_activation_range) and raises
+            # _lib.ActivationRange where the product build would saturate an activation silently; later forwards of the same
+            # weights run the product build.  (Walks the parameters per call: a validation setting, not for serving.)
+            key = (_lib.generation(),) + tuple((q.data_ptr(), q._version) for q in self.parameters())
+            if getattr(self, "_range_ok_key", None) != key:
+                out = self.check_activation_range(x)
+                self._range_ok_key = key
+                return out
         st = self._launch(x)
         return st.mel, st.mel_len, st.duration
 

@@ -386,6 +386,18 @@ def check_activation_range_guard(dev):
     with pytest.raises(_lib.ActivationRange):
         bad.check_activation_range(x)
     net.check_activation_range(x)                                  # the flag pointer was cleared again: a good network still passes
+    # ESMI_DEBUG_RANGE=1: the first forward of a set of weights validates itself, later ones run the product build
+    os.environ["ESMI_DEBUG_RANGE"] = "1"
+    try:
+        with torch.no_grad():
+            with pytest.raises(_lib.ActivationRange):
+                bad(x)
+            first = net(x)[0]
+            assert getattr(net, "_range_ok_key", None) is not None
+            again = net(x)[0]
+        assert float((first - ref).abs().max()) < 1e-4 and torch.equal(again, ref)
+    finally:
+        del os.environ["ESMI_DEBUG_RANGE"]
 
 
 def test_simulated_activation_range_guard():
