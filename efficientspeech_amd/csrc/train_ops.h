@@ -195,6 +195,47 @@ static __global__ __launch_bounds__(64) void train_lin1_bwd_kernel(const float* 
         if (lane == 0) partial_bias[(long)blockIdx.x * pstride] = t;
     }
 }
+// The same for C = 4 LPR in {16 .. 256} on 16-byte aligned tensors and a chunk of 32 rows: LPR lanes per row, 64 / LPR rows per pass,
+// 16-byte accesses, every load of the chunk in flight before the first use; the lane groups' sums are added by a fixed butterfly.
+template <int LPR>
+static __global__ __launch_bounds__(64) void train_lin1_bwd4_kernel(const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ w,
+                                                             long rows, float* __restrict__ dx, float* __restrict__ partial,
+                                                             float* __restrict__ partial_bias, long pstride) {
+    constexpr int RPW = 64 / LPR, C = 4 * LPR, CH = 32, NP = CH / RPW;
+    const int lane = lane_id(), sub = lane / LPR, l = lane % LPR;
+    const long r0 = (long)blockIdx.x * CH + sub;                       // this lane's row of pass p: r0 + RPW p
+    const f32x4 wv = ld4(w + 4 * l);
+    f32x4 xv[NP];
+    float g[NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        const long r = r0 + RPW * p, rc = r < rows ? r : rows - 1;
+        xv[p] = ld4(x + rc * C + 4 * l);
+        g[p] = r < rows ? dy[rc] : 0.0f;
+    }
+    f32x4 acc = zero4();
+    float gs = 0.0f;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        const long r = r0 + RPW * p;
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { acc[e] = fmaf(g[p], xv[p][e], acc[e]); o[e] = g[p] * wv[e]; }
+        gs += g[p];
+        if (r < rows) *reinterpret_cast<f32x4*>(dx + r * C + 4 * l) = o;
+    }
+#pragma unroll
+    for (int k = LPR; k < 64; k <<= 1) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] += shfl_xor_f(acc[e], k);
+        gs += shfl_xor_f(gs, k);
+    }
+    if (sub == 0) {                                   // (pstride = C + 1: the partial rows are not 16-byte aligned)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) partial[(long)blockIdx.x * pstride + 4 * l + e] = acc[e];
+    }
+    if (partial_bias && lane == 0) partial_bias[(long)blockIdx.x * pstride] = gs;
+}
 // depthwise (groups == C, one input channel per output channel, k <= 8): lanes across the channels (coalesced), every thread
 // keeps the k tap sums and the bias sum of its channel over the chunk's rows
 static __global__ void train_conv_wgrad_dw_kernel(const ConvDesc d, const float* __restrict__ x, const float* __restrict__ dy,

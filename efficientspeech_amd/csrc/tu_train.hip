@@ -315,8 +315,17 @@ int esmi_train_conv_bwd_f32(const esmi_conv_desc* d, const float* x, const float
             const long rows = (long)c.B * c.n_out, chunks = train_chunks(rows, wgrad_chunk(c));
             float* part = reinterpret_cast<float*>(ws);
             const long ps = c.c_in + 1;
-            ESMI_LAUNCH(train_lin1_bwd_kernel, dim3((unsigned)chunks), dim3(64), 0, S(stream), x, dy, w, rows, c.c_in, dx, part, dbias ? part + c.c_in : nullptr, ps,
-                        wgrad_chunk(c));
+            const bool al16 = ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dx) | reinterpret_cast<uintptr_t>(w)) & 15) == 0;
+            float* pbias = dbias ? part + c.c_in : nullptr;
+#define ESMI_LIN1(LPR) ESMI_LAUNCH(train_lin1_bwd4_kernel<LPR>, dim3((unsigned)chunks), dim3(64), 0, S(stream), x, dy, w, rows, dx, part, pbias, ps)
+            if (al16 && wgrad_chunk(c) == 32 && c.c_in == 16) ESMI_LIN1(4);
+            else if (al16 && wgrad_chunk(c) == 32 && c.c_in == 32) ESMI_LIN1(8);
+            else if (al16 && wgrad_chunk(c) == 32 && c.c_in == 64) ESMI_LIN1(16);
+            else if (al16 && wgrad_chunk(c) == 32 && c.c_in == 128) ESMI_LIN1(32);
+            else if (al16 && wgrad_chunk(c) == 32 && c.c_in == 256) ESMI_LIN1(64);
+            else
+                ESMI_LAUNCH(train_lin1_bwd_kernel, dim3((unsigned)chunks), dim3(64), 0, S(stream), x, dy, w, rows, c.c_in, dx, part, pbias, ps, wgrad_chunk(c));
+#undef ESMI_LIN1
             if (int rc = launch_status()) return rc;
             return reduce_or_defer(defer, part, dbias ? ps : (long)c.c_in, ps, chunks, dw, c.c_in, dbias, S(stream));
         }
