@@ -282,12 +282,24 @@ static __global__ __launch_bounds__(256) void train_conv_wgrad_dw4_kernel(const 
         const int n = d.n_out, reach = d.k - 1 - d.pad;
         for (long g0 = c0; g0 < c1; g0 += 8) {
             const int t0 = (int)(g0 % n);
+            // every load of the group first, unconditionally (rows clamped into the tensor; what must not count is masked below).  Round 5:
+            // a group that touched an utterance edge took a tap-by-tap path of ~40 dependent loads, and one such lane held its whole wave --
+            // a tenth of the waves ran ~20x longer than the rest (38 us per launch at B = 128 for 78 MB).
+            f32x4 v[15], g[8];
+#pragma unroll
+            for (int r = 0; r < 15; ++r) {
+                long xr = g0 - d.pad + r;
+                xr = xr < 0 ? 0 : (xr >= rows ? rows - 1 : xr);
+                v[r] = r < 8 + d.k - 1 ? ld4(x + xr * d.c_in + c) : zero4();
+            }
+#pragma unroll
+            for (int o = 0; o < 8; ++o) {
+                const bool ok = g0 + o < c1;
+                g[o] = ld4(dy + (ok ? g0 + o : c1 - 1) * d.c_out + c);
+                if (!ok) g[o] = zero4();
+                bs += g[o];
+            }
             if (g0 + 8 <= c1 && t0 >= d.pad && t0 + 7 + reach < n) {     // the whole group and all its taps inside one utterance
-                f32x4 v[15], g[8];
-#pragma unroll
-                for (int r = 0; r < 15; ++r) v[r] = r < 8 + d.k - 1 ? ld4(x + (g0 - d.pad + r) * d.c_in + c) : zero4();
-#pragma unroll
-                for (int o = 0; o < 8; ++o) { g[o] = ld4(dy + (g0 + o) * d.c_out + c); bs += g[o]; }
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     if (j >= d.k) break;
@@ -296,20 +308,16 @@ static __global__ __launch_bounds__(256) void train_conv_wgrad_dw4_kernel(const 
 #pragma unroll
                         for (int e = 0; e < 4; ++e) acc[j][e] = fmaf(g[o][e], v[o + j][e], acc[j][e]);
                 }
-            } else {
-                const long ge = g0 + 8 < c1 ? g0 + 8 : c1;
-                for (long r = g0; r < ge; ++r) {
-                    const int t = (int)(r % n);
-                    const f32x4 gg = ld4(dy + r * d.c_out + c);
-                    bs += gg;
+            } else {                                                      // an utterance edge inside the group: the same sums, tap by tap masked
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        if (j >= d.k) break;
-                        const int ti = t + j - d.pad;
-                        if (ti < 0 || ti >= n) continue;
-                        const f32x4 xv = ld4(x + (r + j - d.pad) * d.c_in + c);
+                for (int j = 0; j < 8; ++j) {
+                    if (j >= d.k) break;
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) acc[j][e] = fmaf(gg[e], xv[e], acc[j][e]);
+                    for (int o = 0; o < 8; ++o) {
+                        const int ti = (t0 + o) % n + j - d.pad;              // (the row's own utterance: rows past the chunk have g = 0)
+                        const bool ok = ti >= 0 && ti < n;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[j][e] = fmaf(g[o][e], ok ? v[o + j][e] : 0.0f, acc[j][e]);
                     }
                 }
             }
