@@ -309,7 +309,7 @@ __global__ __launch_bounds__(256) void convgemm_kernel(const ConvGemmP p) {
                 arow = p.A + ((long)b * p.n_in + ti) * p.lda + p.a_coff;
             }
         }
-        const float* wj = p.W + (long)j * p.c_out * p.c_in;
+        const float* wj = p.W ? p.W + (long)j * p.c_out * p.c_in : nullptr;   // (NULL: the caller gave the pre-split blob alone -- the `pre` loop below covers all of K)
         const float* wrow[NT];
         bool wok[NT];
 #pragma unroll
@@ -341,6 +341,42 @@ __global__ __launch_bounds__(256) void convgemm_kernel(const ConvGemmP p) {
                 }
             }
         };
+        // With the caller's pre-split blob (`Wp`, esmi_pack_bfrag_f32 of W: each 1 KiB block IS one (16-channel step, piece, column tile)
+        // B fragment in lane order, and its k-slot order -- channels 16 st + 4 h + (0..3) and + 8 -- is this kernel's A order) the weights
+        // arrive as one coalesced 16-byte load per lane, piece and tile, and nothing is split: the loop above spends ~58 VALU instructions
+        // per column tile and 16 channels on the weights (three MFMAs' worth of issue time four times over at NT = 4), the same for every
+        // wave of the launch.  (Round 5; the blob's pieces are nearest-rounded, the on-the-fly ones truncated: last-bit differences.)
+        const bool pre = p.Wp != nullptr && (p.c_in & 31) == 0;          // (kernel-uniform)
+        if (pre) {
+            const int ntw = (p.c_out + 31) >> 5, tile0 = n0 >> 5;
+            for (; kc + KG <= kcs; kc += KG) {
+                f32x4 av[KG];
+                u32x4 wb[KG / 2][NT][AMP ? 1 : 2];
+#pragma unroll
+                for (int g = 0; g < KG; ++g) av[g] = ok ? conv_act_in(ld4(arow + 8 * (kc + g) + 4 * h), p, in_s) : zero4();
+#pragma unroll
+                for (int s2 = 0; s2 < KG / 2; ++s2)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                        for (int pl = 0; pl < (AMP ? 1 : 2); ++pl) {
+                            const long blk = ((long)j * (p.c_in >> 3) + kc + 2 * s2 + pl) * ntw + tile0 + nt;
+                            wb[s2][nt][pl] = tile0 + nt < ntw ? __builtin_bit_cast(u32x4, ld4(p.Wp + (blk * 64 + lane) * 4)) : u32x4{0u, 0u, 0u, 0u};
+                        }
+#pragma unroll
+                for (int s2 = 0; s2 < KG / 2; ++s2) {
+                    if constexpr (AMP) {
+                        const u32x4 ah = round_f16x8(av[2 * s2], av[2 * s2 + 1]);
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) acc[nt] = mfma32_f16(ah, wb[s2][nt][0], acc[nt]);
+                    } else {
+                        const f16x2p a2 = split_f16x2(av[2 * s2], av[2 * s2 + 1]);
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) acc[nt] = mfma32_split2(a2, wb[s2][nt][0], wb[s2][nt][AMP ? 0 : 1], acc[nt]);
+                    }
+                }
+            }
+        }
         for (; kc + KG <= kcs; kc += KG) {
             f32x4 av[KG], bv[KG][NT];
 #pragma unroll

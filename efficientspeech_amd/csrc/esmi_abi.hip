@@ -221,13 +221,20 @@ int esmi_encoder_block_f32(const esmi_encoder_block_weights* w, const esmi_encod
         p.k = s->kernel; p.stride = s->stride; p.pad = s->kernel / 2;
         if (ids) { p.ids = ids; p.table = embed; p.ld_table = s->c_in; p.vocab = s->vocab; }
         else { p.A = x_in; p.lda = s->c_in; }
-        p.W = w->merge_w; p.out = t_merge; p.ldo = s->c_in;
-        if ((rc = launch_convgemm(p, st))) return rc;
-        // merge 1x1, networks.py:67
-        p = conv_defaults();
-        p.B = B; p.n_in = n; p.c_in = s->c_in; p.n_out = n; p.c_out = C;
-        p.A = t_merge; p.lda = s->c_in; p.W = w->merge1_w; p.out = x_mid; p.ldo = C;
-        if ((rc = launch_convgemm(p, st))) return rc;
+        if (ESMI_CHAIN_SPLIT && w->merge_cwp && (s->c_in & 31) == 0) {   // (the exact-fp32 build's GEMMs read fp32 weights)
+            // both merge convolutions as ONE launch on the composed, pre-split weights the chain kernels use (merge_cwp: k x k conv . 1x1,
+            // esmi_compose_merge_f32 -> esmi_pack_bfrag_f32): no t_merge round trip, no weight split per wave (round 5)
+            p.c_out = C; p.W = nullptr; p.Wp = w->merge_cwp; p.out = x_mid; p.ldo = C;
+            if ((rc = launch_convgemm(p, st))) return rc;
+        } else {
+            p.W = w->merge_w; p.out = t_merge; p.ldo = s->c_in;
+            if ((rc = launch_convgemm(p, st))) return rc;
+            // merge 1x1, networks.py:67
+            p = conv_defaults();
+            p.B = B; p.n_in = n; p.c_in = s->c_in; p.n_out = n; p.c_out = C;
+            p.A = t_merge; p.lda = s->c_in; p.W = w->merge1_w; p.out = x_mid; p.ldo = C;
+            if ((rc = launch_convgemm(p, st))) return rc;
+        }
         // qkv Linear (bias-free), blocks.py:44
         p = conv_defaults();
         p.B = B; p.n_in = n; p.c_in = C; p.n_out = n; p.c_out = nq;
@@ -315,7 +322,7 @@ int esmi_fuse_f32(const esmi_fuse_weights* w, int depth, int dim, int kernel, in
             p = conv_defaults();  // ConvTranspose1d(dim, dim, k, stride 2^i) cropped to T, networks.py:199-206
             p.mode = MODE_CONVT; p.k = kernel; p.stride = s;
             p.B = B; p.n_in = n_i[i]; p.c_in = dim; p.n_out = T; p.c_out = dim;
-            p.A = tmp; p.lda = dim; p.W = w->up_w[i]; p.bias = w->up_b[i];
+            p.A = tmp; p.lda = dim; p.W = w->up_w[i]; p.Wp = w->up_wp[i]; p.bias = w->up_b[i];   // (the streaming kernel reads the pre-split blob: round 5)
             p.out = cat; p.ldo = dim * depth; p.o_coff = i * dim;
             if ((rc = launch_convgemm(p, st))) return rc;
         }

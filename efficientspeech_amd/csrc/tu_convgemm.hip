@@ -27,7 +27,10 @@ ConvGemmP conv_defaults() {
 // full_row: the epilogue needs a whole output row inside one wave (LayerNorm / row-dot)
 int launch_convgemm(ConvGemmP p, hipStream_t st) {
     if ((p.c_in & 7) || p.c_in <= 0 || p.c_out <= 0 || p.n_out <= 0 || p.B <= 0) return ESMI_ERR_ARG;
-    if (!p.W || !aligned16(p.W)) return ESMI_ERR_ARG;
+    // (weights: the fp32 tensor, or -- split-f16 build, c_in a multiple of 32 -- the pre-split blob alone: every kernel below that is
+    // reached then reads the blob only)
+    const bool blob_only = !p.W && ESMI_CHAIN_SPLIT && p.Wp && aligned16(p.Wp) && (p.c_in & 31) == 0 && p.c_out > 1;
+    if (!blob_only && (!p.W || !aligned16(p.W))) return ESMI_ERR_ARG;
     if (p.ids) {
         if (!p.table || (p.ld_table & 3) || !aligned16(p.table)) return ESMI_ERR_ARG;
     } else if (!p.A || (p.lda & 3) || (p.a_coff & 3) || !aligned16(p.A)) return ESMI_ERR_ARG;
