@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define ESMI_VERSION 500 /* 0.5.0 (round 5): esmi_mel_decoder_clock_probe;
+#define ESMI_VERSION 501 /* 0.5.1: esmi_train_conv_ln_fwd_f32 (an addition; nothing else changed shape).  0.5.0 (round 5): esmi_mel_decoder_clock_probe;
                             0.4.0: esmi_decoder_head.proj_w (the decoder's first stage at phoneme rate for every model size:
                           * esmi_decoder_head_f32).  0.3.0: training entry points changed shape (esmi_conv_desc: act / packed_fwd / packed_grad; LayerNorm with
                           * residual / row mask / activation arguments; esmi_train_loss_args.grad_seed; esmi_train_pack_weights_f32,

@@ -62,7 +62,7 @@ def test_backend_is_hip_gfx950(built):
     from efficientspeech_amd import _lib
     lib = _lib.load()
     assert _lib.backend(lib) == "hip:gfx950"
-    assert lib.esmi_version() == 500
+    assert lib.esmi_version() == 501
 
 
 def test_code_object_targets_gfx950(built):
