@@ -62,7 +62,7 @@ static __global__ void train_conv_fwd_kernel(const ConvDesc d, const float* __re
 // runs the data gradient: dx[t] = sum_j dy[t + pad - j] w[j] = the same correlation with the taps reversed and padding k - 1 - pad.
 // Requires k <= 8; weights (C, 1, k)
 constexpr int kDwRows = 8;
-static __global__ void train_conv_dw_kernel(const ConvDesc d, const float* __restrict__ in, const float* __restrict__ w,
+static __global__ __launch_bounds__(256) void train_conv_dw_kernel(const ConvDesc d, const float* __restrict__ in, const float* __restrict__ w,
                                      const float* __restrict__ bias, float* __restrict__ out, int grad) {
     const int c4 = d.c_out >> 2;
     const int n_o = grad ? d.n_in : d.n_out, n_i = grad ? d.n_out : d.n_in;
@@ -82,17 +82,23 @@ static __global__ void train_conv_dw_kernel(const ConvDesc d, const float* __res
 #pragma unroll
     for (int o = 0; o < kDwRows; ++o) acc[o] = b4;
     const float* base = in + (long)b * n_i * d.c_out + c;
+    // every input row first, unconditionally (clamped into the utterance, zeroed where outside: round 5 -- a load under a per-row
+    // condition is waited for before the next one is issued), then the products: row t0 - pad + r feeds output o through tap j = r - o
+    f32x4 v[kDwRows + 7];
 #pragma unroll
-    for (int r = 0; r < kDwRows + 7; ++r) {            // input row t0 - pad + r feeds output o through tap j = r - o
-        if (r >= kDwRows + d.k - 1) break;
-        const int ti = t0 - pad + r;
-        const f32x4 v = (ti >= 0 && ti < n_i) ? ld4(base + (long)ti * d.c_out) : zero4();
+    for (int r = 0; r < kDwRows + 7; ++r) {
+        const int ti = t0 - pad + r, tc = ti < 0 ? 0 : (ti >= n_i ? n_i - 1 : ti);
+        v[r] = r < kDwRows + d.k - 1 ? ld4(base + (long)tc * d.c_out) : zero4();
+        if (ti != tc) v[r] = zero4();
+    }
+#pragma unroll
+    for (int r = 0; r < kDwRows + 7; ++r) {
 #pragma unroll
         for (int o = 0; o < kDwRows; ++o) {
             const int j = r - o;
             if (j >= 0 && j < 8) {                     // (compile-time after unrolling; taps >= k hold zero weights)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) acc[o][e] = fmaf(v[e], wt[j][e], acc[o][e]);
+                for (int e = 0; e < 4; ++e) acc[o][e] = fmaf(v[r][e], wt[j][e], acc[o][e]);
             }
         }
     }
