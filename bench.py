@@ -331,6 +331,51 @@ def encoder_side(net, x, dev, cfg, B, T, peak_tf, steps=50):
                     "the decoder's first stage that also runs here"}
 
 
+def parity_spot(net, x, cfg, sd, sel=None, decoder_feats=None):
+    """Parity gate of a timed leg (BASELINE.md 4 "parity gate before any timing counts"), OUTSIDE every timed region: the batch the leg
+    just timed goes through the path once more and `sel` utterances of its output (default: the first and the last one) are held
+    against the CPU oracle (oracle/: the checker, never the thing measured) run on the same inputs -- durations as injected,
+    pitch / energy teacher-forced with the path's own predictions so that a bucket decision cannot flip (the predictions themselves
+    are compared at 2e-5), padded to the length the path derived.  `decoder_feats`: MelDecoder.forward alone on frame-rate features.
+    -> {"utterances", "max_abs_err", "mel_len_ok", "ok"}; a leg whose gate fails must report "error" instead of a number."""
+    from oracle import oracle
+    w = oracle.Weights(sd)
+    with torch.no_grad():
+        if decoder_feats is not None:
+            sel = sel or [0, decoder_feats.shape[0] - 1]
+            mel = net.decoder(decoder_feats)[sel].cpu().numpy()         # the batch that was timed; two of its utterances are compared
+            ref = oracle.mel_decoder(cfg, w, decoder_feats[sel].cpu().numpy())
+            err = float(np.abs(mel - ref).max())
+            return {"utterances": sel, "max_abs_err": err, "mel_len_ok": True, "tol": 1e-4, "ok": bool(err < 1e-4)}
+        enc = net.encoder._encode(x)
+        mel, mel_len, _ = net(x)
+    B = mel.shape[0]
+    sel = sel or [0, B - 1]
+    ids, mask = x["phoneme"][sel].cpu().numpy(), x["phoneme_mask"][sel].cpu().numpy()
+    dur = x["duration_forced"][sel].cpu().numpy().astype(np.int32) if "duration_forced" in x else None
+    L = int(mel_len.max())
+    o = oracle.phoneme2mel(cfg, w, ids, mask, pitch=enc["pitch"][sel, :, 0].cpu().numpy(), energy=enc["energy"][sel, :, 0].cpu().numpy(),
+                           duration=dur if dur is not None else enc["dur"][sel].cpu().numpy(), max_mel_len=L)
+    pred_err = max(float(np.abs(enc[k][sel].cpu().numpy() - getattr(o, k)).max()) for k in ("pitch", "energy", "duration"))
+    len_ok = bool(np.array_equal(mel_len[sel].cpu().numpy(), o.mel_len))
+    if dur is not None:
+        len_ok = len_ok and bool(np.array_equal(mel_len.cpu().numpy(), x["duration_forced"].sum(1).cpu().numpy()))
+    m = mel[sel].cpu().numpy()
+    err = float(np.abs(m[:, :L] - o.mel).max()) if L else 0.0
+    tail_zero = not m[:, L:].any() and all(not m[j, int(o.mel_len[j]):].any() for j in range(len(sel)))
+    return {"utterances": [int(v) for v in sel], "max_abs_err": err, "predictor_max_abs_err": pred_err, "mel_len_ok": len_ok,
+            "rows_beyond_mel_len_zero": bool(tail_zero), "tol": 1e-4,
+            "ok": bool(err < 1e-4 and pred_err < 2e-5 and len_ok and tail_zero)}
+
+
+def gate(res, spot):
+    """attach a leg's parity gate; a failed gate replaces the leg's numbers by an error (its timing does not count)"""
+    if spot.get("ok"):
+        res["parity_spot"] = spot
+        return res
+    return {"error": "parity gate failed: the timed batch does not match the oracle", "parity_spot": spot}
+
+
 def make_net(cfg, sd, dev):
     from efficientspeech_amd import build_phoneme2mel, load_numpy_state_dict
     net = build_phoneme2mel(cfg)
@@ -534,6 +579,15 @@ def main():
                              "enc_fuse_va_kernel)"},
     }
 
+    if rank == 0:
+        # ---- parity gate of the headline (outside the timed region): two utterances of the timed batch against the CPU oracle
+        try:
+            out["parity_spot"] = parity_spot(net, x, cfg, sd)
+            if not out["parity_spot"]["ok"]:
+                out["error"] = "parity gate failed: the timed batch does not match the oracle; value withdrawn"
+                out["value_unverified"], out["value"] = out["value"], None
+        except Exception as e:                     # noqa: BLE001
+            out["parity_spot"] = {"error": repr(e)}
     if rank == 0 and world == 1 and not a.exact_fp32:
         # ---- what the decoder kernel's time consists of, in the line itself: the clock the chip actually ran it
         # at (measured inside the kernel), `frac` re-priced at that clock, and the busy fraction of each pipe from the committed PMC pass
@@ -590,7 +644,7 @@ def main():
         del pipe_ng
 
 
-    def _forward_leg(config, b_global, t_ph, steps_, warm_, gather, lib=None, events=False):
+    def _forward_leg(config, b_global, t_ph, steps_, warm_, gather, lib=None, events=False, spot=True):
         """The same timed loop for another model / batch: `b_global` utterances sharded over the ranks (strong), D-const durations.
         -> dict(ms_per_step, value [real frames/s, whole job], per_gpu_batch, kernel_ms)"""
         cfg2 = CONFIGS[config]
@@ -612,6 +666,7 @@ def main():
                 t2 = torch.tensor([dt2], dtype=torch.float64, device=dev)
                 dist.all_reduce(t2, op=dist.ReduceOp.MAX)
                 dt2 = float(t2.item())
+            spot2 = parity_spot(net2, x2, cfg2, sd2) if (spot and rank == 0) else None     # (inside the library context: the build that was timed)
         finally:
             if ctx:
                 ctx.__exit__(None, None, None)
@@ -620,6 +675,8 @@ def main():
         if events and n2:
             f2 = DECODER_WORK[config][0]
             res.update(kernel_ms=dec2, kernel_ms_samples=n2, achieved_tflops=f2 * b_rank * l2 / (dec2 * 1e-3) / 1e12)
+        if spot2 is not None:
+            res = gate(res, spot2)
         return res, net2, x2, cfg2, sd2
 
     if world > 1 and not a.no_extras and a.config == "tiny" and a.scaling == "weak":
@@ -682,13 +739,14 @@ def main():
                 _, len_r, _ = netb(xr)
             torch.cuda.synchronize(dev)
             tr_ = (time.perf_counter() - t0) / 10
-        res["d_rand"] = {"ms_per_step": tr_ * 1e3, "valid_frames_per_step": int(d_rand.sum()), "padded_length": l_rand,
-                         "value": int(d_rand.sum()) / tr_, "mel_len_matches": bool(np.array_equal(len_r.cpu().numpy(), d_rand.sum(1)))}
+        res["d_rand"] = gate({"ms_per_step": tr_ * 1e3, "valid_frames_per_step": int(d_rand.sum()), "padded_length": l_rand,
+                              "value": int(d_rand.sum()) / tr_, "mel_len_matches": bool(np.array_equal(len_r.cpu().numpy(), d_rand.sum(1)))},
+                             parity_spot(netb, xr, cfgb, sdb, sel=[int(d_rand.sum(1).argmin()), int(d_rand.sum(1).argmax())]))
         del netb
         if not a.exact_fp32 and os.path.exists(fp32_lib):
             r32, n32_, _, _, _ = _forward_leg(name, bb, tb_, max(5, steps2 // 2), 2, gather=False, lib=fp32_lib, events=True)
             del n32_
-            res["exact_fp32"] = {k: r32[k] for k in ("ms_per_step", "value", "steps", "kernel_ms", "achieved_tflops") if k in r32}
+            res["exact_fp32"] = {k: r32[k] for k in ("ms_per_step", "value", "steps", "kernel_ms", "achieved_tflops", "parity_spot", "error") if k in r32}
             if "achieved_tflops" in r32:
                 res["exact_fp32"]["frac_of_157.3"] = r32["achieved_tflops"] / FP32_PEAK_TFLOPS
         res["note"] = (f"BASELINE configs[{2 if name == 'small' else 3}] on one GPU: {name} ES ({sum(v.size for v in sdb.values())} params), "
@@ -709,12 +767,13 @@ def main():
                 net.decoder(feats)
             torch.cuda.synchronize(dev)
             td = (time.perf_counter() - t0) / steps2
+        spot_d = parity_spot(net, None, cfg, sd, decoder_feats=feats)
         del feats
-        out["decoder_only"] = {"frames_per_s": B * L / td, "ms": td * 1e3, "steps": steps2,
+        out["decoder_only"] = gate({"frames_per_s": B * L / td, "ms": td * 1e3, "steps": steps2,
                                "achieved_tflops": flops * B * L / td / 1e12, "frac": flops * B * L / td / 1e12 / peak_tf,
                                "hbm_frac": nbytes * B * L / td / 1e9 / HBM_PEAK_GBS,
                                "note": f"MelDecoder.forward alone, features ~ N(0,1) (B={B}, L={L}, {cfg.d4}) resident in HBM, "
-                                       "wall clock over back-to-back launches (includes the proj stage the full forward runs at phoneme rate)"}
+                                       "wall clock over back-to-back launches (includes the proj stage the full forward runs at phoneme rate)"}, spot_d)
         # ---- the same full step with every contraction on the exact-fp32 MFMA instruction
         if not a.exact_fp32 and os.path.exists(fp32_lib):
             with _lib.use_library(fp32_lib):
@@ -722,11 +781,12 @@ def main():
                 pipe32 = ShardedMelPipeline(net32, world_size=1, gather=False)
                 dt32, dec32, n32 = timed_steps(pipe32, net32, x, steps2, warm2, sync_all, a.event_every, False)
                 cfg32 = _lib.load().esmi_build_config().decode()
+                spot32 = parity_spot(net32, x, cfg, sd)
             ach32 = flops * B * L / (dec32 * 1e-3) / 1e12
-            out["exact_fp32"] = {"ms_per_step": dt32 / steps2 * 1e3, "value": frames_per_step * steps2 / dt32, "steps": steps2,
+            out["exact_fp32"] = gate({"ms_per_step": dt32 / steps2 * 1e3, "value": frames_per_step * steps2 / dt32, "steps": steps2,
                                  "kernel_ms": dec32, "kernel_ms_samples": n32, "achieved_tflops": ach32,
                                  "frac_of_157.3": ach32 / FP32_PEAK_TFLOPS, "build_config": cfg32,
-                                 "library": "efficientspeech_amd/libesmi_fp32mfma.so"}
+                                 "library": "efficientspeech_amd/libesmi_fp32mfma.so"}, spot32)
             del net32, pipe32
         # ---- the same forward written with stock PyTorch-ROCm operators (tests/torch_mirror.py: MIOpen / hipBLASLt convolutions,
         # torch softmax / layer_norm / repeat_interleave -- the reference's structure incl. its per-utterance upsampling loop), on
@@ -791,12 +851,13 @@ def main():
                 torch.cuda.synchronize(dev)
                 tr_ = (time.perf_counter() - t0) / n_r
             valid = int(d_rand.sum())
-            out["d_rand"] = {"ms_per_step": tr_ * 1e3, "valid_frames_per_step": valid, "padded_length": L_rand,
+            out["d_rand"] = gate({"ms_per_step": tr_ * 1e3, "valid_frames_per_step": valid, "padded_length": L_rand,
                              "value": valid / tr_, "padding_fraction": 1.0 - valid / float(B * L_rand),
                              "mel_len_matches": bool(np.array_equal(len_r.cpu().numpy(), d_rand.sum(1))),
                              "note": "SURVEY 8d robustness workload: durations U[1, 11] seed 1234, same phoneme batch; frames/s counts "
                                      "valid frames only (windows that are all padding are skipped by the decoder, partly padded ones "
-                                     "are computed as the reference computes them)"}
+                                     "are computed as the reference computes them)"},
+                                 parity_spot(net, xr, cfg, sd, sel=[int(d_rand.sum(1).argmin()), int(d_rand.sum(1).argmax())]))
         except Exception as e:                     # noqa: BLE001
             out["d_rand"] = {"error": repr(e)}
         # ---- the step after the path: HiFi-GAN v2 generator on the mel the forward just produced

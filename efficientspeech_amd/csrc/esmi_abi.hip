@@ -888,7 +888,8 @@ static int forward_impl(const esmi_forward_args* a, int stage, esmi_stream_t str
         // ---- the whole encoder side as ONE launch (round 5: enc_all16_kernel = block 0 | block 1 | Fuse + variance adaptor + head behind
         // each other in one workgroup per utterance) when all three chain16 kernels serve their shapes
         esmi_encoder_block_shape sh[2];
-        bool ok = true;
+        // (the chain16 bodies are built for MixFFN expansion 1 only, like launch_enc_block16: anything else takes the per-block path below)
+        bool ok = a->shapes[0].expansion == 1 && a->shapes[1].expansion == 1;
         int n_in = T;
         for (int i = 0; i < 2 && ok; ++i) {
             sh[i] = a->shapes[i];

@@ -455,6 +455,93 @@ def _full_size_properties(name, B, T, D, nets, n_spot=4):
         del mel, mel2, mel_s, enc
 
 
+def _full_size_drand(name, B, T, nets):
+    """BASELINE shape of one model size on the robustness workload: ragged phoneme lengths, durations U[1, 11]
+    seed 1234 (0 on padded phonemes), the padded length derived on the device.  Against the oracle on >= 4 utterances incl. the
+    shortest, the longest and one whose last decoder windows are all padding (the decoder skips those): mel < 1e-4; on the WHOLE
+    batch: mel_len bit-exact, rows >= mel_len exactly zero.  The spot check is teacher-forced with the HIP path's own pitch /
+    energy predictions so that bucket decisions cannot disagree (the predictions themselves are held to PRED_TOL); the
+    free-running comparison -- no forced values at all, discrete decisions margin-aware -- is `_full_size_free_running`."""
+    net, cfg, sd = nets(name)
+    rng = np.random.default_rng(1234)
+    lens = rng.integers(max(T // 8, 1), T + 1, size=B)
+    lens[0], lens[B - 1] = T, max(T // 8, 1)
+    ids, mask = synth_phonemes(B, T, 1234, lens)
+    dur = rng.integers(1, 12, size=(B, T)).astype(np.int32)
+    dur[mask] = 0
+    ref_len = dur.sum(1).astype(np.int32)
+    L = int(ref_len.max())
+    x = {"phoneme": torch.from_numpy(ids).to(DEV), "phoneme_mask": torch.from_numpy(mask).to(DEV),
+         "duration_forced": torch.from_numpy(dur).to(DEV)}
+    all_pad_tail = np.flatnonzero(ref_len < L - 256)          # at least one whole 128-row tile of padding behind the last valid frame
+    assert all_pad_tail.size, "pick lengths that leave an utterance with an all-padding window"
+    sel = sorted({int(ref_len.argmin()), int(ref_len.argmax()), int(all_pad_tail[len(all_pad_tail) // 2]), 0, B // 2})
+    ref = None
+    for plan in (_lib.FUSE_ALL, 0):
+        for hint in (None, L + 37):      # the reference's call (host sync for L) / an allocation hint above the batch maximum
+            xx = dict(x) if hint is None else dict(x, max_mel_len=hint)
+            with _lib.launch_plan(plan), torch.no_grad():
+                enc = net.encoder._encode(xx)
+                mel, mel_len, _ = net(xx)
+            assert mel_len.dtype == torch.int32 and np.array_equal(mel_len.cpu().numpy(), ref_len), plan
+            assert mel.shape == (B, hint or L, 80) and torch.isfinite(mel).all()
+            beyond = torch.arange(mel.shape[1], device=DEV)[None, :] >= mel_len[:, None].long()
+            assert not mel[beyond].any(), f"plan {plan}: rows >= mel_len are not exactly zero"
+            if ref is None:
+                ref = oracle.phoneme2mel(cfg, oracle.Weights(sd), ids[sel], mask[sel], pitch=enc["pitch"][sel, :, 0].cpu().numpy(),
+                                         energy=enc["energy"][sel, :, 0].cpu().numpy(), duration=dur[sel], max_mel_len=L)
+                np.testing.assert_allclose(enc["pitch"][sel].cpu().numpy(), ref.pitch, atol=H.PRED_TOL, rtol=0)
+                np.testing.assert_allclose(enc["energy"][sel].cpu().numpy(), ref.energy, atol=H.PRED_TOL, rtol=0)
+                np.testing.assert_allclose(enc["duration"][sel].cpu().numpy(), ref.duration, atol=H.PRED_TOL, rtol=0)
+                assert np.array_equal(ref.mel_len, ref_len[sel])
+            err = np.abs(mel[sel, :L].cpu().numpy() - ref.mel).max()
+            assert err < H.MEL_TOL, (plan, hint, err)
+            del mel, enc
+
+
+def _full_size_free_running(name, B, T, nets, n_free=3):
+    """The BASELINE batch with NOTHING forced (predicted durations, predicted pitch / energy buckets) against the oracle's own eval
+    run on `n_free` of its utterances: discrete decisions may differ only inside their margins (helpers.compare_eval_with_oracle);
+    at least one utterance must come through without any flip and is then compared to < 1e-4."""
+    net, cfg, sd = nets(name)
+    lens = np.full(B, T)
+    lens[1::2] = np.random.default_rng(77).integers(T // 2, T + 1, size=B // 2)
+    ids, mask = synth_phonemes(B, T, 99, lens)
+    x = {"phoneme": torch.from_numpy(ids).to(DEV), "phoneme_mask": torch.from_numpy(mask).to(DEV)}
+    with torch.no_grad():
+        enc = net.encoder._encode(x)
+        mel, mel_len, _ = net(x)
+    compared = 0
+    L = int(mel_len.max())
+    assert mel.shape == (B, L, 80)
+    for b in (0, B // 2 + 1, B - 1)[:n_free]:
+        s = [b, b]        # the oracle's masked (B > 1) flow on this utterance alone, padded to the batch's length: the frames in
+        #                   [mel_len, L) are computed and reach the last valid frames through the k-tap convolutions
+        o = oracle.phoneme2mel(cfg, oracle.Weights(sd), ids[s], mask[s], max_mel_len=L)
+        e1 = {k: v[s] for k, v in enc.items() if torch.is_tensor(v) and v.dim() >= 1 and v.shape[0] == B}
+        err = H.compare_eval_with_oracle(cfg, o, e1, mel[s], mel_len[s], sd)
+        compared += err == err
+        assert not mel[b, int(mel_len[b]):].any()
+    assert compared, "every free-running utterance had a decision inside its margin; pick other seeds"
+
+
+def test_full_size_tiny_drand(nets):
+    """BASELINE configs[1] shape on the D-rand / ragged workload + a free-running batch."""
+    _full_size_drand("tiny", 256, 128, nets)
+    _full_size_free_running("tiny", 256, 128, nets)
+
+
+def test_full_size_small_drand(nets):
+    _full_size_drand("small", 256, 256, nets)
+    _full_size_free_running("small", 256, 256, nets)
+
+
+def test_full_size_base_drand(nets):
+    _full_size_drand("base", 512, 256, nets)
+    _full_size_free_running("base", 512, 256, nets, n_free=2)
+    torch.cuda.empty_cache()
+
+
 def test_full_size_small_properties(nets):
     """BASELINE configs[2]: small ES, B=256 T=256, D-const 6 (L=1536): the dim-64 halo-plan instantiations at size."""
     _full_size_properties("small", 256, 256, 6, nets)

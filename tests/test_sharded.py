@@ -108,15 +108,19 @@ def test_two_rank_ragged_batch_is_bit_identical(tmp_path):
 
 
 # ------------------------------------------------------------------------------------------------ the serving loop, N > 1, on one GPU
-def _pipeline_worker(rank, world, port, out_path):
+def _pipeline_worker(rank, world, port, out_path, backend="gloo"):
     """Two ranks share cuda:0 (process group `gloo`: RCCL refuses two ranks on one device; gloo carries CUDA tensors) and run
     `ShardedMelPipeline` -- the loop `bench.py --gpus N` times -- with a different batch every step: side-stream all-gather,
     MAX-reduce of the padded length, `_masked_path_inputs`, the two-stream hand-over.  Rank 0 compares every gathered step with the
     single-process forward of the whole batch."""
     sys.path.insert(0, ROOT)
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    torch.cuda.set_device(0)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if backend == "nccl":          # RCCL: one rank per GPU (the form the 8-GPU node runs)
+        torch.cuda.set_device(rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    else:
+        torch.cuda.set_device(0)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     from tests import helpers as H
     from efficientspeech_amd.sharded import ShardedMelPipeline, shard_batch
     from efficientspeech_amd.synth import synth_phonemes
@@ -164,6 +168,17 @@ def test_gpu_two_rank_serving_loop_on_one_device(tmp_path):
     process -- plain, two-stream, 1-utterance shards (duplicated to stay on the reference's masked B > 1 path), caller-vouched length."""
     out = str(tmp_path / "pipe.npy")
     mp.spawn(_pipeline_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    assert np.load(out).tolist() == [1, 1, 1, 1, 1, 1]
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="RCCL needs one device per rank: runs on the first multi-GPU lease")
+def test_gpu_rccl_serving_loop_is_bit_identical(tmp_path):
+    """The same six serving-loop cases with backend "nccl" (= RCCL over xGMI), one rank per GPU: the MAX all-reduce of the padded
+    length, the side-stream `all_gather_into_tensor` of mel + mel_len one step behind, every gathered step bit-identical to the
+    whole batch in one process.  Auto-skips on a 1-GPU box (every lease of rounds 1-6); the 8-GPU driver run executes it."""
+    out = str(tmp_path / "pipe_rccl.npy")
+    mp.spawn(_pipeline_worker, args=(2, _free_port(), out, "nccl"), nprocs=2, join=True)
     assert np.load(out).tolist() == [1, 1, 1, 1, 1, 1]
 
 

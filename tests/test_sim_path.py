@@ -419,3 +419,30 @@ def test_gpu_activation_range_guard():
             net(x)
     finally:
         net._range_flag = None
+
+
+def test_simulated_tiny_with_expansion_2_takes_the_per_block_path():
+    """the one-launch encoder side (enc_all16_kernel) is built for MixFFN expansion 1 only; a depth-2, dim-32
+    model with the reference's `--expansion 2` must fall through to the per-block path under the default plan instead of running
+    the chain16 bodies on twice-as-wide FFN weights.  Plans 63 (default), 31 and 0 against each other and against the oracle."""
+    import dataclasses
+    from efficientspeech_amd import CONFIGS, build_phoneme2mel, load_numpy_state_dict
+    from efficientspeech_amd.synth import synth_state_dict
+    cfg = dataclasses.replace(CONFIGS["tiny"], name="tiny_e2", expansion=2)
+    sd = synth_state_dict(cfg, 1234)
+    net = build_phoneme2mel(cfg)
+    load_numpy_state_dict(net, sd)
+    ids, mask = synth_phonemes(2, 40, 11, [40, 23])
+    x = {"phoneme": torch.from_numpy(ids), "phoneme_mask": torch.from_numpy(mask)}
+    res = {}
+    with use_sim(), torch.no_grad():
+        for plan in (_lib.FUSE_ALL, 31, 0):
+            with _lib.launch_plan(plan):
+                enc = net.encoder._encode(x)
+                mel, mel_len, dpred = net(x)
+            res[plan] = (mel.numpy().copy(), mel_len.numpy().copy(), dpred.numpy().copy(), enc)
+    o = oracle.phoneme2mel(cfg, oracle.Weights(sd), ids, mask)
+    for plan, (mel, mel_len, dpred, enc) in res.items():
+        np.testing.assert_allclose(dpred, o.duration, atol=H.PRED_TOL, rtol=0, err_msg=f"plan {plan}")
+        err = H.compare_eval_with_oracle(cfg, o, enc, torch.from_numpy(mel), torch.from_numpy(mel_len), sd)
+        assert err == err, f"plan {plan}: a discrete decision inside its margin; pick another seed"

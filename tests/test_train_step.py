@@ -692,14 +692,18 @@ def test_simulated_edge_shapes_match_torch_mirror(B, T, lens):
     assert len(bad) <= 2, bad          # (a ReLU input on zero may take the other branch: see the at-size GPU test)
 
 
-def _ddp_gpu_worker(rank, world, port, out_path):
+def _ddp_gpu_worker(rank, world, port, out_path, backend="gloo"):
     """Two data-parallel ranks on cuda:0 (gloo carries device tensors): the hipGraph-replayed step (forward + loss + backward captured,
     all-reduce + optimizer eager) against the eager step, different batches per rank."""
     import torch.distributed as dist
     sys.path.insert(0, ROOT)
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    torch.cuda.set_device(0)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if backend == "nccl":          # RCCL: one rank per GPU; the flat gradient buffer's all-reduce goes over xGMI
+        torch.cuda.set_device(rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    else:
+        torch.cuda.set_device(0)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     res = {}
     for mode in ("eager", "graph"):
         train, g, net, x, y = _setup("cuda")
@@ -727,4 +731,16 @@ def test_gpu_two_rank_captured_step_equals_eager_step(tmp_path):
     import torch.multiprocessing as mp
     out = str(tmp_path / "ddp_graph.npy")
     mp.spawn(_ddp_gpu_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    assert np.load(out).tolist() == [1, 1, 1, 1]
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="RCCL needs one device per rank: runs on the first multi-GPU lease")
+def test_gpu_rccl_data_parallel_step_keeps_replicas_identical(tmp_path):
+    """BASELINE configs[4]'s collective on the real backend: two ranks, one GPU each, `TrainStep`'s ONE all-reduce of the flat
+    gradient buffer over RCCL (eager and around the hipGraph-replayed step): replicas bit-identical after four steps, replayed ==
+    eager.  Auto-skips on a 1-GPU box."""
+    import torch.multiprocessing as mp
+    out = str(tmp_path / "ddp_rccl.npy")
+    mp.spawn(_ddp_gpu_worker, args=(2, _free_port(), out, "nccl"), nprocs=2, join=True)
     assert np.load(out).tolist() == [1, 1, 1, 1]
