@@ -140,9 +140,32 @@ static __global__ void pack_bslice2h_kernel(const float* __restrict__ src, unsig
     }
 }
 
+// The same layout as the kernel sees it: everything inside a conv layer is a compile-time offset (DX2, KD are template parameters), and
+// the few run-time offsets are 32-bit (the blob is a few MB).  The kernel used to take the 16 64-bit fields of DecLayout as arguments:
+// 32 SGPRs live across the layer loop, which is where the dx2 = 256 kernel's SGPR spills (48) and its uniform values in VGPRs came from.
+template <int DX2, int KD>
+struct DecLay {
+    static constexpr int l_dwb = KD * DX2, l_pwb = l_dwb + DX2, l_g = l_pwb + DX2, l_b = l_g + DX2, l_pw = l_b + DX2,
+                         layer_stride = l_pw + DX2 * DX2;
+    int proj_b, layer0, skip0, mel_w, mel_b, total;
+    __host__ __device__ DecLay(int d4, int n_blocks, int block_depth) {
+        proj_b = d4 * DX2;
+        layer0 = proj_b + 3 * DX2;
+        skip0 = layer0 + layer_stride * n_blocks * block_depth;
+        mel_w = skip0 + 2 * DX2 * n_blocks;
+        mel_b = mel_w + DX2 * DX2;
+        total = mel_b + DX2;
+    }
+    // (the host's dec_layout() is the one the packer writes by; the launcher checks that the two agree)
+    bool matches(const DecLayout& L) const {
+        return L.proj_w == 0 && L.proj_b == proj_b && L.proj_g == proj_b + DX2 && L.proj_beta == proj_b + 2 * DX2 && L.layer0 == layer0 &&
+               L.layer_stride == layer_stride && L.l_dw == 0 && L.l_dwb == l_dwb && L.l_pwb == l_pwb && L.l_g == l_g && L.l_b == l_b &&
+               L.l_pw == l_pw && L.skip0 == skip0 && L.mel_w == mel_w && L.mel_b == mel_b && L.total == total;
+    }
+};
+
 struct MelDecP {
     const float* blob;
-    DecLayout lay;
     int d4, n_blocks, block_depth, n_mel;
     const float* x;        // (B,T,d4) phoneme-rate (cum != NULL) or (B,L,d4) frame-rate
     const float* h0;       // optional (cum != NULL): (B,T,dx2) = LN(tanh(proj(x))) already computed at PHONEME rate
@@ -156,8 +179,12 @@ struct MelDecP {
     int halo;              // rows a window loses per side without carried state: (k/2) * conv layers
     int seg_len;           // frames per segment (a workgroup's share of an utterance)
     int n_seg;             // segments per utterance
-    float* carry_ws;       // dx2 = 256 with multi-chunk segments: [workgroup][conv layer][k/2][dx2] floats of scratch, else NULL
-    int carry_lds_layers;  // ... of which the first this many conv layers keep their carried rows in LDS behind the tile (what fits)
+    float* carry_ws;       // dx2 = 256 with multi-chunk segments: per workgroup `ws_stride` floats of scratch ([conv layer slot][k/2][dx2],
+                           // then [block boundary][kDecBlockCarry4 float4]), else NULL
+    int ws_stride;
+    int carry_lds_layers;  // conv-layer carry slots kept in LDS behind the tile (what fits); the rest live in `carry_ws`
+    int skew;              // dx2 = 256 chunk walk: the tile's frame base steps back by block_depth * k/2 rows at every block boundary
+                           // (a chunk then loses block_depth * k/2 rows on its right instead of the whole halo), see the chunk loop
     long long* trace;      // development only (-DESMI_DEC_TRACE): [wave][stamp] shader-clock stamps of block (1,0)
 };
 // measurement aid (esmi_mel_decoder_clock_probe, include/esmi.h): two {shader clock, 100 MHz clock} stamps per launch, see the chunk
@@ -176,6 +203,8 @@ static inline int store_dec_clock_pointer(long long* slots) {
 #endif
 }
 
+// block skew: a block boundary hands (block_depth + 1) * k/2 rows of dx2 floats to the next chunk, one float4 per thread
+constexpr int kDecBlockCarry4 = 512;
 // conv layers whose carried rows (k/2 rows of dx2 floats each) fit in LDS behind the tile and the parameter slots (dx2 = 256 only)
 template <int DX2>
 __host__ __device__ constexpr int dec_lds_floats(int kd);
@@ -239,7 +268,7 @@ __global__ __launch_bounds__(64 * NW, (DX2 <= 128 ? kDecWps128 : NW / 4)) void m
     int* src = reinterpret_cast<int*>(pbuf + PB);                     // [128]
 
     int tid = (int)threadIdx.x, lane = lane_id();       // (re-derived per chunk below: see the chunk loop)
-    const int w = wave_id();
+    const int w = uniform_i(wave_id());  // an SGPR: everything derived from the wave's place (mh, ns, weight-slice offsets) stays scalar
     int i = lane & 31, h = lane >> 5;
     const int mh = w / NS, ns = w % NS;
     // XCD-aware workgroup -> (utterance, window) map: workgroup id % 8 is the XCD (round-robin dispatch), so the windows
@@ -263,13 +292,14 @@ __global__ __launch_bounds__(64 * NW, (DX2 <= 128 ? kDecWps128 : NW / 4)) void m
     // already balance the chip, and 768 = 7 x 112 leaves nothing to gain) a segment is one chunk.
     const int s0 = seg * p.seg_len, s1 = min(s0 + p.seg_len, p.L_out);
     if (s0 >= p.L_out) return;
-    int f0 = 0, f_lo = 0, out_hi = 0;        // this chunk: frame of tile row 0, first / one-past-last frame it stores
+    int f0 = 0, g0 = 0, f_lo = 0, out_hi = 0;   // this chunk: frame of tile row 0 in block 0 / in the last block, first / one-past-last frame it stores
     const int n_layers = p.n_blocks * p.block_depth;
     // every read of the packed blob is a buffer load: resource + wave-uniform byte offset in SGPRs, one lane-offset VGPR for all of
     // them (64-bit per-lane pointers into the blob, live across the layer loop, were most of the kernel's register spills)
-    const BufRsrc brs = make_rsrc(p.blob, p.lay.total * (long)sizeof(float));
+    const DecLay<DX2, KD> lay(p.d4, p.n_blocks, p.block_depth);
+    const BufRsrc brs = make_rsrc(p.blob, (long)lay.total * (long)sizeof(float));
     unsigned tid16 = (unsigned)tid * 16u, lane16 = (unsigned)lane * 16u;
-    auto blob_ld = [&](long float_off, unsigned voff) __attribute__((always_inline)) { return buf_ld4s(brs, voff, (unsigned)(float_off * 4)); };
+    auto blob_ld = [&](int float_off, unsigned voff) __attribute__((always_inline)) { return buf_ld4s(brs, voff, (unsigned)(float_off * 4)); };
 #ifdef ESMI_DEC_TRACE
     int tr_n = 0;
     const bool tr_on = p.trace && seg == (DX2 > 128 ? 0 : 3) && b == p.B / 2 + 5 && lane == 0;
@@ -281,35 +311,49 @@ __global__ __launch_bounds__(64 * NW, (DX2 <= 128 ? kDecWps128 : NW / 4)) void m
     // ---- parameter staging by LDS-DMA (global_load_lds_dwordx4: memory -> LDS, 16 bytes per lane, no staging registers): issued
     // when the last reader of the slots' old contents has passed a barrier, drained by the barrier in front of the first reader of
     // the new ones.  "layer" n_layers is the mel Linear (its bias goes to the group A slots, unused by then).
-    auto stage = [&](long float_off, float* dst, int n4) __attribute__((always_inline)) {   // n4 float4 from blob + float_off to dst, thread tid -> dst + 4 tid
+    auto stage = [&](int float_off, float* dst, int n4) __attribute__((always_inline)) {   // n4 float4 from blob + float_off to dst, thread tid -> dst + 4 tid
         // (opaque: the per-lane source pointer is formed here, not hoisted out of the layer loop as a live 64-bit register pair)
         if (tid < n4) lds_dma16(p.blob + float_off + opaque_i(4 * tid), dst + 256 * w, lane);
     };
     auto fetch_A = [&](int l) __attribute__((always_inline)) {
-        if (l < n_layers) stage(p.lay.layer0 + (long)l * p.lay.layer_stride, pbuf, NA4);
+        if (l < n_layers) stage(lay.layer0 + l * lay.layer_stride, pbuf, NA4);
     };
     auto fetch_B = [&](int l) __attribute__((always_inline)) {
         if (l < n_layers) {
-            stage(p.lay.layer0 + (long)l * p.lay.layer_stride + p.lay.l_pwb, pbuf + P_PWB, NB4);
+            stage(lay.layer0 + l * lay.layer_stride + lay.l_pwb, pbuf + P_PWB, NB4);
             if (((l + 1) % p.block_depth) == 0) {   // block end: skip LN params, threads NB4 .. NB4 + DX2/2 (whole waves: NB4 is a multiple of 64 floats4? no -- see below)
                 if (tid >= NB4 && tid < NB4 + DX2 / 2)
-                    lds_dma16(p.blob + p.lay.skip0 + (long)(l / p.block_depth) * 2 * DX2 + opaque_i(4 * (tid - NB4)), pbuf + P_PWB + 256 * w, lane);
+                    lds_dma16(p.blob + (lay.skip0 + (l / p.block_depth) * 2 * DX2) + opaque_i(4 * (tid - NB4)), pbuf + P_PWB + 256 * w, lane);
             }
         } else {
-            stage(p.lay.mel_b, pbuf, DX2 / 4);
+            stage(lay.mel_b, pbuf, DX2 / 4);
         }
     };
     auto commit_A = [&](int) __attribute__((always_inline)) {};
     auto commit_B = [&](int) __attribute__((always_inline)) {};
 
     constexpr bool STREAM = DX2 > 128;
-    // STREAM: the k/2 input rows of every conv layer in front of the next chunk wait in a global scratch row set of this workgroup
-    // (2 KB per layer; written and read back by the same thread, one chunk apart: no fence needed, and the traffic is nothing)
-    // (the first `carry_lds_layers` layers' rows stay in LDS; the workspace takes the rest: base ES 7 + 2)
-    float* const cws = STREAM && p.carry_ws ? p.carry_ws + (long)blockIdx.x * ((long)ESMI_MAX_DEC_LAYERS * PAD * DX2) : nullptr;
+    // STREAM: the k/2 input rows of every conv layer in front of the next chunk are carried: in LDS behind the tile (`carry_lds_layers`
+    // slots), else in a global scratch row set of this workgroup (written and read back by the same thread, one chunk apart: no fence)
+    float* const cws = STREAM && p.carry_ws ? p.carry_ws + (long)blockIdx.x * p.ws_stride : nullptr;
     float* const cbuf = reinterpret_cast<float*>(src + kDecRows);     // [carry_lds_layers][PAD][DX2]
     float cnext = 0.0f;                      // the carried element of the NEXT conv layer, requested one phase ahead
-    const int keep = kDecRows - p.halo;      // tile rows of a chunk that stay valid through every layer (the right halo is lost)
+    // BLOCK SKEW (round 6).  Inside a block the tile's rows keep their frames (the skip tensor lives in the row owners' registers), so
+    // every conv layer costs k/2 valid rows on the right: `sh` = block_depth * k/2 per block.  At a block boundary nothing is held in
+    // registers across it except that skip tensor -- which IS the tile at that moment -- so the block-end LayerNorm writes its rows `sh`
+    // rows further down, the top `sh` rows (and the next conv layer's k/2 pad rows) come from the previous chunk's same boundary (the
+    // block carry, scratch), and the owners re-read their skip rows: the next block starts with 128 valid rows again, `sh` frames
+    // earlier.  A chunk therefore advances by keep = 128 - sh frames (base ES 122, small 124) instead of 128 - halo (110 / 116);
+    // tile row r of block b holds frame g0 + (n_blocks - 1 - b) * sh + r.
+    const bool skew = STREAM && cws && p.skew;
+    const int sh = skew ? PAD * p.block_depth : 0;
+    const int off_last = sh * (p.n_blocks - 1);
+    const int bc_n4 = (sh + PAD) * CG;                                // float4 per block carry (<= kDecBlockCarry4: one per thread)
+    float* const bcw = skew ? cws + n_layers * (PAD * DX2) : nullptr; // [block boundary][kDecBlockCarry4] float4
+    // rows in front of the segment's first output frame: none at the start of an utterance (frames < 0 are zero rows); a segment that
+    // starts inside an utterance has nothing carried in and recomputes what its first chunk lacks
+    const int hl0 = s0 > 0 ? (skew ? 2 * p.halo - sh : p.halo) : off_last;
+    const int keep = skew ? kDecRows - sh : kDecRows - p.halo;   // tile rows of a chunk that stay valid through every layer
     bool edge_window = false;
     unsigned ln_inside = 0;
     // measurement aid (g_dec_clk above): the FIRST workgroup stamps {shader clock, 100 MHz clock} when it starts -> slot 0, and again
@@ -338,11 +382,11 @@ __global__ __launch_bounds__(64 * NW, (DX2 <= 128 ? kDecWps128 : NW / 4)) void m
         tid16 = (unsigned)tid * 16u; lane16 = (unsigned)lane * 16u;
     }
     if constexpr (STREAM) clk_stamp(ck);
-    const int hl = (ck == 0 && s0 > 0) ? p.halo : 0;
-    f0 = s0 + ck * keep - (s0 > 0 ? p.halo : 0);
-    f_lo = f0 + hl;
+    g0 = s0 - hl0 + ck * keep;
+    f0 = g0 + off_last;
+    f_lo = max(g0, s0);
     if ((!(STREAM && cws) && ck > 0) || f_lo >= s1) break;
-    out_hi = min(f0 + keep, s1);
+    out_hi = min(g0 + keep, s1);
     if (f_lo >= valid_end) {  // the rest of the segment is padding: the final masked_fill (or the [L, L_out) tail) zeroes it
         const int n = (s1 - f_lo) * p.n_mel;
         float* o = p.mel + ((long)b * p.L_out + f_lo) * p.n_mel;
@@ -353,26 +397,28 @@ __global__ __launch_bounds__(64 * NW, (DX2 <= 128 ? kDecWps128 : NW / 4)) void m
     // STREAM: conv layer l's PAD input rows in front of this chunk (saved by the previous chunk) are requested with `carry_load`
     // a phase ahead and written to the tile's top pad rows by `carry_put` at the end of the phase in front of the layer's
     // depthwise conv; `carry_save` keeps this chunk's rows [keep - PAD, keep) of the same tensor for the next chunk.
-    auto carry_load = [&](int l) __attribute__((always_inline)) {
+    // (`slot`: the conv layer's carry slot; -1 = the first layer of a later block under the block skew, whose pad rows arrive with the
+    // block carry)
+    auto carry_load = [&](int slot) __attribute__((always_inline)) {
         if constexpr (STREAM) {
             cnext = 0.0f;
-            if (cws && ck > 0 && tid < PAD * DX2) {
-                if (l < p.carry_lds_layers) cnext = cbuf[l * (PAD * DX2) + tid];
-                else cnext = cws[l * (PAD * DX2) + opaque_i(tid)];   // (opaque: the address is not kept live between the phases)
+            if (slot >= 0 && cws && ck > 0 && tid < PAD * DX2) {
+                if (slot < p.carry_lds_layers) cnext = cbuf[slot * (PAD * DX2) + tid];
+                else cnext = cws[slot * (PAD * DX2) + opaque_i(tid)];   // (opaque: the address is not kept live between the phases)
             }
         }
     };
-    auto carry_put = [&]() __attribute__((always_inline)) {
+    auto carry_put = [&](int slot) __attribute__((always_inline)) {
         if constexpr (STREAM) {
-            if (tid < PAD * DX2) xs[(kDecPadRows - PAD + tid / DX2) * LDSROW + tid % DX2] = cnext;
+            if (slot >= 0 && tid < PAD * DX2) xs[(kDecPadRows - PAD + tid / DX2) * LDSROW + tid % DX2] = cnext;
         }
     };
-    auto carry_save = [&](int l) __attribute__((always_inline)) {
+    auto carry_save = [&](int slot) __attribute__((always_inline)) {
         if constexpr (STREAM) {
-            if (cws && tid < PAD * DX2) {
+            if (slot >= 0 && cws && tid < PAD * DX2) {
                 const float v = xs[(kDecPadRows + keep - PAD + tid / DX2) * LDSROW + tid % DX2];
-                if (l < p.carry_lds_layers) cbuf[l * (PAD * DX2) + tid] = v;
-                else cws[l * (PAD * DX2) + opaque_i(tid)] = v;
+                if (slot < p.carry_lds_layers) cbuf[slot * (PAD * DX2) + tid] = v;
+                else cws[slot * (PAD * DX2) + opaque_i(tid)] = v;
             }
         }
     };
@@ -394,7 +440,7 @@ __global__ __launch_bounds__(64 * NW, (DX2 <= 128 ? kDecWps128 : NW / 4)) void m
         xs[rr * LDSROW + c] = 0.0f;
     }
     if (tid < NB4)                                                     // proj_b, proj_g, proj_beta -> group B
-        reinterpret_cast<f32x4*>(pbuf + P_PWB)[tid] = blob_ld(p.lay.proj_b, tid16);
+        reinterpret_cast<f32x4*>(pbuf + P_PWB)[tid] = blob_ld(lay.proj_b, tid16);
     carry_load(0);
     fetch_A(0);
     commit_A(0);
@@ -407,10 +453,14 @@ __global__ __launch_bounds__(64 * NW, (DX2 <= 128 ? kDecWps128 : NW / 4)) void m
     // 17.8 % of the kernel's LDS cycles were bank conflicts, profiles/r01_l).
     constexpr int LNPER = 16 / RPT;         // waves that share one residue class of rows mod 16
     int ln_c = lane & (TPR - 1), ln_row0 = 64 * (w / LNPER) + 16 * (lane / TPR) + RPT * (w % LNPER);
-    edge_window = f0 < 0 || f0 + kDecRows > L;   // some window rows lie outside [0, L) (SGPR: a scalar branch)
-    ln_inside = 0;                          // bit j: row ln_row0 + j exists in the reference (inside [0, L))
+    // rows of the tile that lie outside [0, L) for the block whose tile row 0 holds frame `fbase`
+    auto set_edge = [&](int fbase) __attribute__((always_inline)) {
+        edge_window = fbase < 0 || fbase + kDecRows > L;   // some window rows lie outside [0, L) (SGPR: a scalar branch)
+        ln_inside = 0;                          // bit j: row ln_row0 + j exists in the reference (inside [0, L))
 #pragma unroll
-    for (int j = 0; j < RPT; ++j) ln_inside |= (src[ln_row0 + j] != -1 ? 1u : 0u) << j;
+        for (int j = 0; j < RPT; ++j) ln_inside |= ((unsigned)(fbase + ln_row0 + j) < (unsigned)L ? 1u : 0u) << j;
+    };
+    set_edge(f0);
     f32x16 acc[MT][NTW];
     f32x4 skip[RPT][NV];
 #pragma unroll
@@ -433,7 +483,7 @@ __global__ __launch_bounds__(64 * NW, (DX2 <= 128 ? kDecWps128 : NW / 4)) void m
 #if ESMI_DEC_SPLIT
     constexpr int KS16 = KSUB / 2;
     u32x4 bf[NTW][KS16][2];
-    auto load_b = [&](long wsl, int k0) __attribute__((always_inline)) {   // wsl: float offset of the wave's weight slice in the blob
+    auto load_b = [&](int wsl, int k0) __attribute__((always_inline)) {   // wsl: float offset of the wave's weight slice in the blob
 #pragma unroll
         for (int t = 0; t < NTW; ++t) {
 #pragma unroll
@@ -459,7 +509,7 @@ __global__ __launch_bounds__(64 * NW, (DX2 <= 128 ? kDecWps128 : NW / 4)) void m
         }
     };
     // slice pointer of chunk c of the matrix at float offset `off` (planes: 8 steps x 2 planes x 64 lanes x 16 B per tile)
-    auto wslice = [&](long off, int c) __attribute__((always_inline)) { return off + (long)(c * (DX2 / 32) + ns * NTW) * 8 * 2 * 256; };
+    auto wslice = [&](int off, int c) __attribute__((always_inline)) { return off + (c * (DX2 / 32) + ns * NTW) * 8 * 2 * 256; };
 
     // The A operand rows already stored as the two f16 planes (row = [DX2 halves h1 | DX2 halves h2 | pad], written by the
     // depthwise phase / the last LayerNorm): per (16-channel step, row tile) two ds_read_b128 + 3*NTW MFMAs.
@@ -473,8 +523,8 @@ __global__ __launch_bounds__(64 * NW, (DX2 <= 128 ? kDecWps128 : NW / 4)) void m
     constexpr int NSTEP = 8 * KCH, NITEM = NSTEP * MT;
     static_assert(WD >= 0 && WD <= NSTEP && AD >= 1 && AD <= NITEM, "ring depths");
     u32x4 wr[WD > 0 ? WD : 1][NTW][2];
-    auto w_fetch = [&](long off, int s, int slot) __attribute__((always_inline)) {
-        const long wsl = wslice(off, s >> 3);
+    auto w_fetch = [&](int off, int s, int slot) __attribute__((always_inline)) {
+        const int wsl = wslice(off, s >> 3);
 #pragma unroll
         for (int t = 0; t < NTW; ++t) {
 #pragma unroll
@@ -483,14 +533,14 @@ __global__ __launch_bounds__(64 * NW, (DX2 <= 128 ? kDecWps128 : NW / 4)) void m
     };
     // the first WD weight steps of the matrix at `off` (issued ahead of the barrier that precedes the K loop: the L2 round
     // trip then overlaps the barrier wait)
-    auto gemm_prefetch = [&](long off) __attribute__((always_inline)) {
+    auto gemm_prefetch = [&](int off) __attribute__((always_inline)) {
         if constexpr (WD > 0) {
 #pragma unroll
             for (int s = 0; s < WD; ++s) w_fetch(off, s, s);
             sched_fence();
         }
     };
-    auto gemm_planes = [&](long off) __attribute__((always_inline)) {
+    auto gemm_planes = [&](int off) __attribute__((always_inline)) {
         const unsigned* a_base = reinterpret_cast<const unsigned*>(xs) + opaque_i((kDecPadRows + 32 * MT * mh + i) * LDSROW + 4 * h);
         if constexpr (WD == 0) {
 #pragma unroll
@@ -537,7 +587,7 @@ __global__ __launch_bounds__(64 * NW, (DX2 <= 128 ? kDecWps128 : NW / 4)) void m
     };
 #else
     f32x4 bf[NTW][KSUB];
-    auto load_b = [&](long wsl, int k0) __attribute__((always_inline)) {   // wsl: float offset of the wave's weight slice in the blob
+    auto load_b = [&](int wsl, int k0) __attribute__((always_inline)) {   // wsl: float offset of the wave's weight slice in the blob
 #pragma unroll
         for (int t = 0; t < NTW; ++t) {
 #pragma unroll
@@ -560,12 +610,12 @@ __global__ __launch_bounds__(64 * NW, (DX2 <= 128 ? kDecWps128 : NW / 4)) void m
         }
     };
     // slice pointer of chunk c of the matrix at float offset `off`
-    auto wslice = [&](long off, int c) __attribute__((always_inline)) { return off + (long)(c * (DX2 / 32) + ns * NTW) * 16 * 256; };
-    auto gemm_prefetch = [&](long) __attribute__((always_inline)) {};
-    auto gemm_planes = [&](long) __attribute__((always_inline)) {};
+    auto wslice = [&](int off, int c) __attribute__((always_inline)) { return off + (c * (DX2 / 32) + ns * NTW) * 16 * 256; };
+    auto gemm_prefetch = [&](int) __attribute__((always_inline)) {};
+    auto gemm_planes = [&](int) __attribute__((always_inline)) {};
 #endif
     // full dx2-wide contraction over fp32 rows of the tile, un-pipelined
-    auto gemm_rows = [&](long off) __attribute__((always_inline)) {
+    auto gemm_rows = [&](int off) __attribute__((always_inline)) {
 #pragma unroll
         for (int c = 0; c < KCH; ++c) {
 #pragma unroll
@@ -647,7 +697,9 @@ __global__ __launch_bounds__(64 * NW, (DX2 <= 128 ? kDecWps128 : NW / 4)) void m
     // LN pass over the tile (in place): x = LN(x) [; x = LN_s(x + skip), skip = x at a block end]; rows outside [0, L) -> 0.
     // PLANES: the rows are written as the two f16 planes the pipelined K loop reads (the last LayerNorm feeds the mel Linear
     // only), otherwise as fp32.  BLOCK_END is a template-like constant at both call sites so that `skip = v` costs nothing.
-    auto ln_pass = [&](const float* pb0, auto block_end_c, auto planes_c) __attribute__((always_inline)) {
+    // `shw` (BLOCK_END, fp32 rows only): block skew -- the rows are written `shw` rows further down (those that would leave the tile
+    // are dropped: they are the rows the block lost), behind a barrier that waits for every owner to have read its rows.
+    auto ln_pass = [&](const float* pb0, auto block_end_c, auto planes_c, int shw) __attribute__((always_inline)) {
         constexpr bool BLOCK_END = decltype(block_end_c)::value, PLANES = decltype(planes_c)::value;
         const float* pb = pb0 + opaque_i(4 * ln_c);           // this thread's channels of every param vector
         float* ln_ptr = xs + opaque_i((kDecPadRows + ln_row0) * LDSROW + 4 * ln_c);
@@ -679,6 +731,18 @@ __global__ __launch_bounds__(64 * NW, (DX2 <= 128 ? kDecWps128 : NW / 4)) void m
                 for (int k = 0; k < NV; ++k)
                     if (!((ln_inside >> j) & 1u)) v[j][k] = zero4();
             }
+        }
+        if (STREAM && BLOCK_END && !PLANES && shw) {   // (workgroup-uniform)
+            __syncthreads();
+            float* wp = ln_ptr + shw * LDSROW;
+#pragma unroll
+            for (int j = 0; j < RPT; ++j) {
+                if (ln_row0 + j + shw < kDecRows) {
+#pragma unroll
+                    for (int k = 0; k < NV; ++k) *reinterpret_cast<f32x4*>(wp + j * LDSROW + 4 * TPR * k) = v[j][k];
+                }
+            }
+            return;     // (the owners re-read their skip rows from the shifted tile at the start of the next block)
         }
 #pragma unroll
         for (int j = 0; j < RPT; ++j) {
@@ -749,7 +813,7 @@ __global__ __launch_bounds__(64 * NW, (DX2 <= 128 ? kDecWps128 : NW / 4)) void m
                 }
             }
         }
-        carry_put();
+        carry_put(0);
         __syncthreads();
     } else {
         zero_acc();
@@ -766,7 +830,7 @@ __global__ __launch_bounds__(64 * NW, (DX2 <= 128 ? kDecWps128 : NW / 4)) void m
             __syncthreads();
 #pragma unroll
             for (int k0 = 0; k0 < 16; k0 += KSUB) {
-                load_b(wslice(p.lay.proj_w, ch), k0);
+                load_b(wslice(0, ch), k0);
                 mma_sub(0, k0);
             }
         }
@@ -792,22 +856,42 @@ __global__ __launch_bounds__(64 * NW, (DX2 <= 128 ? kDecWps128 : NW / 4)) void m
                 }
             }
         }
-        carry_put();
+        carry_put(0);
         __syncthreads();
     }
 
     // ---- conv layers
     int dw_cg = tid % CG, dw_r0 = (tid / CG) * RS;
+    int blk = 0, lin = 0;                    // block of layer l and the layer's place in it
     for (int l = 0; l < n_layers; ++l) {
         const float* pb = pbuf;
-        const long lbase = p.lay.layer0 + (long)l * p.lay.layer_stride;
-        const bool block_end = ((l + 1) % p.block_depth) == 0;
+        const int lbase = lay.layer0 + l * lay.layer_stride;
+        const bool block_end = lin + 1 == p.block_depth;
+        // conv-layer carry slots (see carry_load): without the skew one per layer; with it the first layer of blocks >= 1 has none
+        const int slot = skew ? ((lin == 0 && l > 0) ? -1 : l - blk) : l;
+        const int slot_next = skew ? (block_end ? -1 : l + 1 - blk) : l + 1;
         if constexpr (STREAM) {   // (as at the top of the chunk loop: keeps the layer's address arithmetic from being hoisted and spilled)
             tid = opaque_i(tid);
             lane = tid & 63; i = lane & 31; h = lane >> 5;
             tid16 = (unsigned)tid * 16u; lane16 = (unsigned)lane * 16u;
             ln_c = lane & (TPR - 1); ln_row0 = 64 * (w / LNPER) + 16 * (lane / TPR) + RPT * (w % LNPER);
             dw_cg = tid % CG; dw_r0 = (tid / CG) * RS;
+            if (skew && lin == 0 && l > 0) {
+                // a block starts on the shifted tile (complete since the barrier behind the last LayerNorm): hand the rows in front of
+                // the NEXT chunk's tile to the block carry (tile rows [keep - PAD, 128): the same thread reads them back one chunk
+                // later), re-read the skip rows, and derive which rows lie outside [0, L) at this block's frame base
+                if (tid < bc_n4) {
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(xs + (kDecPadRows + keep - PAD + tid / CG) * LDSROW + 4 * (tid % CG));
+                    *reinterpret_cast<f32x4*>(bcw + (blk - 1) * (4 * kDecBlockCarry4) + opaque_i(4 * tid)) = v;
+                }
+                const float* ln_ptr = xs + opaque_i((kDecPadRows + ln_row0) * LDSROW + 4 * ln_c);
+#pragma unroll
+                for (int j = 0; j < RPT; ++j) {
+#pragma unroll
+                    for (int k = 0; k < NV; ++k) skip[j][k] = *reinterpret_cast<const f32x4*>(ln_ptr + j * LDSROW + 4 * TPR * k);
+                }
+                set_edge(g0 + sh * (p.n_blocks - 1 - blk));
+            }
         }
         ESMI_STAMP();   // 0: layer start
         // 1. depthwise conv in place: window -> registers | barrier | filtered rows -> tile (as the K loop's operand planes)
@@ -823,7 +907,7 @@ __global__ __launch_bounds__(64 * NW, (DX2 <= 128 ? kDecWps128 : NW / 4)) void m
 #pragma unroll
             for (int j = 0; j < KD; ++j) tap[j] = *reinterpret_cast<const f32x4*>(pbt + j * DX2);
             const f32x4 tb = *reinterpret_cast<const f32x4*>(pbt + P_DWB);
-            carry_save(l);       // (this layer's input rows in front of the NEXT chunk, before the planes overwrite them)
+            carry_save(slot);    // (this layer's input rows in front of the NEXT chunk, before the planes overwrite them)
             ESMI_STAMP();   // 1: window loaded (issued)
             __syncthreads();
             ESMI_STAMP();   // 2: barrier passed
@@ -849,14 +933,14 @@ __global__ __launch_bounds__(64 * NW, (DX2 <= 128 ? kDecWps128 : NW / 4)) void m
             }
         }
         commit_B(l);
-        gemm_prefetch(lbase + p.lay.l_pw);   // first weight steps: in flight across the barrier
+        gemm_prefetch(lbase + lay.l_pw);   // first weight steps: in flight across the barrier
         ESMI_STAMP();   // 3: dw written
         __syncthreads();
         ESMI_STAMP();   // 4: barrier
         // 2. pointwise conv: K = dx2
         zero_acc();
-        if (SPLIT) gemm_planes(lbase + p.lay.l_pw);
-        else gemm_rows(lbase + p.lay.l_pw);
+        if (SPLIT) gemm_planes(lbase + lay.l_pw);
+        else gemm_rows(lbase + lay.l_pw);
         ESMI_STAMP();   // 5: K loop issued
         // 3. bias + tanh on the accumulators (no tile access: ahead of the barrier), then -> tile
         tanh_acc(pb + P_PWB);
@@ -870,19 +954,31 @@ __global__ __launch_bounds__(64 * NW, (DX2 <= 128 ? kDecWps128 : NW / 4)) void m
         ESMI_STAMP();   // 8: barrier
         // 4. LayerNorm (+ block-end skip LayerNorm) by row owners; the last one writes the mel Linear's operand planes
         if (l + 1 == n_layers) fetch_B(n_layers);   // mel bias -> group A slots (taps: last read by this layer's depthwise phase)
-        else carry_load(l + 1);
+        else carry_load(slot_next);
+        // block skew, at the end of every block but the last: the rows go `sh` rows down, the rows in front of them arrive from the
+        // previous chunk (requested here, a phase ahead; zero rows at the start of an utterance -- frames < 0)
+        const int shw = (STREAM && skew && block_end && l + 1 < n_layers) ? sh : 0;
+        f32x4 bcv = zero4();
+        if constexpr (STREAM) {
+            if (shw && ck > 0 && tid < bc_n4) bcv = ld4(bcw + blk * (4 * kDecBlockCarry4) + opaque_i(4 * tid));
+        }
         if (SPLIT && l + 1 == n_layers) {
-            if (block_end) ln_pass(pb, TrueC{}, TrueC{});
-            else ln_pass(pb, FalseC{}, TrueC{});
+            if (block_end) ln_pass(pb, TrueC{}, TrueC{}, 0);
+            else ln_pass(pb, FalseC{}, TrueC{}, 0);
         } else {
-            if (block_end) ln_pass(pb, TrueC{}, FalseC{});
-            else ln_pass(pb, FalseC{}, FalseC{});
+            if (block_end) ln_pass(pb, TrueC{}, FalseC{}, shw);
+            else ln_pass(pb, FalseC{}, FalseC{}, 0);
         }
         ESMI_STAMP();   // 9: LN done
-        if (l + 1 == n_layers) gemm_prefetch(p.lay.mel_w);   // (the mel bias went to the unused group A slots by LDS-DMA above)
-        else carry_put();
+        if (l + 1 == n_layers) gemm_prefetch(lay.mel_w);   // (the mel bias went to the unused group A slots by LDS-DMA above)
+        else carry_put(slot_next);
+        if constexpr (STREAM) {
+            if (shw && tid < bc_n4)   // pad rows of the next conv layer + tile rows [0, sh) of the next block
+                *reinterpret_cast<f32x4*>(xs + (kDecPadRows - PAD + tid / CG) * LDSROW + 4 * (tid % CG)) = bcv;
+        }
         __syncthreads();
         ESMI_STAMP();   // 10: barrier
+        if (++lin == p.block_depth) { lin = 0; ++blk; }
     }
 
     // ---- mel Linear(dx2, n_mel) on skip (held in the tile), masked store
@@ -899,15 +995,15 @@ __global__ __launch_bounds__(64 * NW, (DX2 <= 128 ? kDecWps128 : NW / 4)) void m
     }
     if (ns * WCOLS < p.n_mel) {   // wave-uniform: column slices beyond n_mel have nothing to do
         zero_acc();
-        if (SPLIT && n_layers > 0) gemm_planes(p.lay.mel_w);
-        else gemm_rows(p.lay.mel_w);
+        if (SPLIT && n_layers > 0) gemm_planes(lay.mel_w);
+        else gemm_rows(lay.mel_w);
         const float* mb = pbuf;                      // mel bias (zero padded to dx2)
         const bool vec_ok = (p.n_mel & 3) == 0;      // rows of 16-byte multiples: float4 stores
 #pragma unroll
         for (int t = 0; t < NTW; ++t) {
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
-                const int f = f0 + 32 * MT * mh + 32 * mt + i;
+                const int f = g0 + 32 * MT * mh + 32 * mt + i;
                 if (f < f_lo || f >= out_hi) continue;
                 float* orow = p.mel + ((long)b * p.L_out + f) * p.n_mel;
                 const bool live = f < valid_end;

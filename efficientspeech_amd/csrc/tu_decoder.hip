@@ -2,6 +2,8 @@
 // One of several translation units of libesmi.so (compiled in parallel by __graft_entry__.build(); the simulator build
 // tools/wavesim/build.sh compiles the same files with the host compiler).  Internal launchers are declared in launch.h.
 #include "launch.h"
+#include <cstdlib>
+
 #include "mel_decoder.h"
 
 using namespace esmi;
@@ -98,22 +100,40 @@ int esmi_mel_decoder_pack_f32(const esmi_decoder_weights* w, const esmi_decoder_
 // segments per utterance / frames per segment of the dx2 = 256 kernel when it may carry rows between chunks: whole utterances when
 // the batch fills the chip, else as many segments per utterance as it takes to give every CU one (a segment's first chunk recomputes
 // its left halo, so fewer, longer segments are cheaper)
+// Block skew (mel_decoder.h, the chunk loop): a chunk advances by 128 - block_depth * k/2 frames instead of 128 - halo; used when the
+// model has more than one block and a block carry fits one float4 per thread.
+static bool stream_skew(const esmi_decoder_shape* s) {
+    return s->n_blocks >= 2 && (s->block_depth + 1) * (s->kernel / 2) * (s->dx2 / 4) <= kDecBlockCarry4;
+}
 static void stream_geometry(const esmi_decoder_shape* s, int B, int L_out, int* n_seg_out, int* seg_len_out) {
-    const int halo = (s->kernel / 2) * s->n_blocks * s->block_depth;
-    const int keep = kDecRows - halo, chunks = (L_out + keep - 1) / keep;
-    int n_seg = (256 + B - 1) / B;
+    const int pad = s->kernel / 2, halo = pad * s->n_blocks * s->block_depth;
+    const bool skew = stream_skew(s);
+    const int sh = pad * s->block_depth;
+    // frames a chunk keeps; frames in front of an utterance's first output frame (the last block's tile starts that much early); rows a
+    // segment that starts inside an utterance recomputes (nothing is carried into its first chunk)
+    const int keep = skew ? kDecRows - sh : kDecRows - halo, lead = skew ? halo - sh : 0, lost = skew ? 2 * halo - sh : halo;
+    const int chunks = (L_out + lead + keep - 1) / keep;
+    // (ESMI_DEC_STREAM_WGS: test knob -- the workgroup count the segmentation aims at, default one per CU; 1 = whole-utterance walks
+    // at any batch size, which is how the CPU simulator tests reach multi-chunk segments without a 256-utterance batch)
+    const char* env = getenv("ESMI_DEC_STREAM_WGS");
+    const int target = env && atoi(env) > 0 ? atoi(env) : 256;
+    int n_seg = (target + B - 1) / B;
     n_seg = n_seg < 1 ? 1 : (n_seg > chunks ? chunks : n_seg);
-    const int per = (chunks + n_seg - 1) / n_seg;           // chunks per segment
-    // (a segment that does not start the utterance yields keep - halo frames from its first chunk)
-    *seg_len_out = n_seg == 1 ? L_out : per * keep - halo;
+    int per = (chunks + n_seg - 1) / n_seg;                 // chunks per segment
+    while (n_seg > 1 && per * keep - lost < keep) ++per;    // (short utterances: a later segment must still yield a chunk's worth)
+    *seg_len_out = n_seg == 1 ? L_out : per * keep - lost;
     *n_seg_out = (L_out + *seg_len_out - 1) / *seg_len_out;
+}
+// scratch floats per workgroup: one k/2-row set per conv layer, then one block carry per block boundary
+static int stream_ws_stride(const esmi_decoder_shape* s) {
+    return s->n_blocks * s->block_depth * (s->kernel / 2) * s->dx2 + (s->n_blocks - 1) * 4 * kDecBlockCarry4;
 }
 
 size_t esmi_mel_decoder_workspace_bytes(const esmi_decoder_shape* s, int B, int L_out) {
     if (dec_check(s) || s->dx2 != 256 || B <= 0 || L_out <= 0) return 0;
     int n_seg, seg_len;
     stream_geometry(s, B, L_out, &n_seg, &seg_len);
-    return (size_t)n_seg * ((B + 7) / 8) * 8 * ESMI_MAX_DEC_LAYERS * (s->kernel / 2) * s->dx2 * sizeof(float);
+    return (size_t)n_seg * ((B + 7) / 8) * 8 * stream_ws_stride(s) * sizeof(float);
 }
 
 static int mel_decoder_launch(const float* blob, const esmi_decoder_shape* s, const float* x, const float* h0,
@@ -128,7 +148,12 @@ static int mel_decoder_launch(const float* blob, const esmi_decoder_shape* s, co
     if (!lmax_dev && lmax_host < 0 && (!mel_len || !cum)) return ESMI_ERR_ARG;   // L derived from mel_len
     MelDecP p;
     p.blob = blob;
-    p.lay = dec_layout(s->d4, s->dx2, s->kernel, s->n_blocks, s->block_depth);
+    {   // the kernel derives the blob layout itself (DecLay: compile-time offsets); it must be the one the packer wrote by
+        const DecLayout L = dec_layout(s->d4, s->dx2, s->kernel, s->n_blocks, s->block_depth);
+        const bool same = s->dx2 == 128 ? (s->kernel == 5 ? DecLay<128, 5>(s->d4, s->n_blocks, s->block_depth).matches(L) : DecLay<128, 3>(s->d4, s->n_blocks, s->block_depth).matches(L))
+                                        : (s->kernel == 5 ? DecLay<256, 5>(s->d4, s->n_blocks, s->block_depth).matches(L) : DecLay<256, 3>(s->d4, s->n_blocks, s->block_depth).matches(L));
+        if (!same || L.total > 0x1fffffffL) return ESMI_ERR_UNSUPPORTED;
+    }
     p.d4 = s->d4; p.n_blocks = s->n_blocks; p.block_depth = s->block_depth; p.n_mel = s->n_mel;
     p.x = x; p.h0 = h0; p.cum = cum; p.mel_len = mel_len; p.lmax_dev = lmax_dev; p.lmax_host = lmax_host;
     p.apply_mask = apply_mask && mel_len; p.B = B; p.T = T; p.L_out = L_out; p.mel = mel;
@@ -140,12 +165,17 @@ static int mel_decoder_launch(const float* blob, const esmi_decoder_shape* s, co
     hipStream_t st = S(stream);
     p.carry_ws = nullptr;
     p.carry_lds_layers = 0;
+    p.skew = 0;
+    p.ws_stride = 0;
     const size_t need = esmi_mel_decoder_workspace_bytes(s, B, L_out);
     if (s->dx2 == 256 && workspace && need && workspace_bytes >= need) {
         // one workgroup per CU walks a segment chunk by chunk, each conv layer's rows in front of a chunk carried in `workspace`
         stream_geometry(s, B, L_out, &p.n_seg, &p.seg_len);
         p.carry_ws = static_cast<float*>(workspace);
-        p.carry_lds_layers = dec_carry_lds_layers<256>(s->kernel, s->n_blocks * s->block_depth);
+        p.ws_stride = stream_ws_stride(s);
+        p.skew = stream_skew(s) ? 1 : 0;
+        // conv-layer carry slots: with the skew the first layer of every later block takes its pad rows from the block carry
+        p.carry_lds_layers = dec_carry_lds_layers<256>(s->kernel, s->n_blocks * s->block_depth - (p.skew ? s->n_blocks - 1 : 0));
     } else {
         // every 128-row window is its own segment, halo rows recomputed on both sides (dx2 = 128: two workgroups per CU balance
         // the chip and 768 = 7 x 112 frames leaves nothing to gain; dx2 = 256 without a workspace)

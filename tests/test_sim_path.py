@@ -298,6 +298,17 @@ def test_simulated_decoder_chunk_walk_equals_windows(nets):
         H.check_decoder_chunk_walk(net, cfg, "cpu", cases=((2, 40, 9),))
 
 
+@pytest.mark.parametrize("name,B,T,D", [("small", 2, 60, 9), ("base", 1, 70, 9)])
+def test_simulated_decoder_whole_utterance_walk_with_block_skew(name, B, T, D, nets, monkeypatch):
+    """The dx2 = 256 chunk walk with carried rows AND the block skew over several chunks of one segment (ESMI_DEC_STREAM_WGS=1: whole-
+    utterance walks at any batch size; on the GPU that is the B >= 256 geometry): conv-layer carries in LDS, block carries through the
+    workspace, shifted block-end LayerNorm, skip rows re-read -- against the window form of the same kernel."""
+    monkeypatch.setenv("ESMI_DEC_STREAM_WGS", "1")
+    net, cfg, sd = nets(name)
+    with use_sim():
+        H.check_decoder_chunk_walk(net, cfg, "cpu", cases=((B, T, D),))
+
+
 def test_simulated_split_range_guard(nets):
     """A weight outside the split-f16 operand range is refused at pack time (ValueError naming the fp32 build), not
     silently turned into inf."""
