@@ -51,6 +51,12 @@
 //  * dx2 = 256 (one workgroup per CU, nobody fills the gaps): the K loop's weight fragments run 2 steps ahead in a VGPR ring
 //    (small ES decoder 1774 -> 1687 us; depth 4 spills: 1736), the A fragments one item ahead; 8 waves per window (16: 2.43 vs 1.87 ms).
 constexpr int kDecWps128 = 4, kDecWeightRing256 = 2, kDecARing = 1;
+#ifndef ESMI_DEC_MEL_NT     // dx2 = 256: the chunk's mel rows leave as streaming (non-temporal) stores
+#define ESMI_DEC_MEL_NT 1
+#endif
+#ifndef ESMI_DEC_H0_NT      // dx2 = 256: the h0 row gather as streaming loads
+#define ESMI_DEC_H0_NT 1    // (base ES, B = 512: HBM traffic per launch 1051 MB with plain stores and loads, 576 MB with streaming mel stores,
+#endif                      //  541 MB with both, against 386 MB algorithmic: profiles/r06_probes/decoder256_traffic_ab.txt)
 #define ESMI_DEC_TANH tanh_fast_f32
 #define ESMI_DEC_RSQRT rsqrt_fast_f32   // v_rsq_f32 (1 ulp)
 
@@ -355,7 +361,7 @@ __global__ __launch_bounds__(64 * NW, (DX2 <= 128 ? kDecWps128 : NW / 4)) void m
     const int hl0 = s0 > 0 ? (skew ? 2 * p.halo - sh : p.halo) : off_last;
     const int keep = skew ? kDecRows - sh : kDecRows - p.halo;   // tile rows of a chunk that stay valid through every layer
     bool edge_window = false;
-    unsigned ln_inside = 0;
+    int fb_cur = 0;                          // frame of tile row 0 in the current block (wave-uniform)
     // measurement aid (g_dec_clk above): the FIRST workgroup stamps {shader clock, 100 MHz clock} when it starts -> slot 0, and again
     // -> slot 1 at the start of each later chunk (dx2 = 256) / in front of its mel stage (dx2 = 128, one chunk).  (slot 1 - slot 0) is a
     // long stretch of the workgroup's life: shader ticks / 100 MHz ticks = the clock the CU ran at.  Both stamps come from ONE workgroup:
@@ -456,10 +462,10 @@ __global__ __launch_bounds__(64 * NW, (DX2 <= 128 ? kDecWps128 : NW / 4)) void m
     // rows of the tile that lie outside [0, L) for the block whose tile row 0 holds frame `fbase`
     auto set_edge = [&](int fbase) __attribute__((always_inline)) {
         edge_window = fbase < 0 || fbase + kDecRows > L;   // some window rows lie outside [0, L) (SGPR: a scalar branch)
-        ln_inside = 0;                          // bit j: row ln_row0 + j exists in the reference (inside [0, L))
-#pragma unroll
-        for (int j = 0; j < RPT; ++j) ln_inside |= ((unsigned)(fbase + ln_row0 + j) < (unsigned)L ? 1u : 0u) << j;
+        fb_cur = fbase;                          // row r exists in the reference iff 0 <= fb_cur + r < L (`row_inside`: derived where it is
+                                                 // used -- a per-thread mask kept across the layer loop is a register the dx2 = 256 kernel spills)
     };
+    auto row_inside = [&](int j) __attribute__((always_inline)) { return (unsigned)(fb_cur + ln_row0 + j) < (unsigned)L; };
     set_edge(f0);
     f32x16 acc[MT][NTW];
     f32x4 skip[RPT][NV];
@@ -523,24 +529,29 @@ __global__ __launch_bounds__(64 * NW, (DX2 <= 128 ? kDecWps128 : NW / 4)) void m
     constexpr int NSTEP = 8 * KCH, NITEM = NSTEP * MT;
     static_assert(WD >= 0 && WD <= NSTEP && AD >= 1 && AD <= NITEM, "ring depths");
     u32x4 wr[WD > 0 ? WD : 1][NTW][2];
-    auto w_fetch = [&](int off, int s, int slot) __attribute__((always_inline)) {
-        const int wsl = wslice(off, s >> 3);
+    // (`ntc`: 32-column tiles per wave of THIS contraction -- NTW for the conv layers; 1 for the mel Linear of the dx2 = 256 kernel, whose
+    // n_mel <= 96 columns are packed as three one-tile slices so that three SIMDs share them instead of two)
+    auto w_fetch = [&](int off, int s, int slot, auto ntc) __attribute__((always_inline)) {
+        constexpr int NT = decltype(ntc)::value;
+        const int wsl = off + ((s >> 3) * (4 * NT) + ns * NT) * 8 * 2 * 256;
 #pragma unroll
-        for (int t = 0; t < NTW; ++t) {
+        for (int t = 0; t < NT; ++t) {
 #pragma unroll
             for (int pl = 0; pl < 2; ++pl) wr[slot][t][pl] = __builtin_bit_cast(u32x4, blob_ld(wsl + ((t * 8 + (s & 7)) * 2 + pl) * 256, lane16));
         }
     };
     // the first WD weight steps of the matrix at `off` (issued ahead of the barrier that precedes the K loop: the L2 round
     // trip then overlaps the barrier wait)
-    auto gemm_prefetch = [&](int off) __attribute__((always_inline)) {
+    auto gemm_prefetch = [&](int off, auto ntc) __attribute__((always_inline)) {
         if constexpr (WD > 0) {
 #pragma unroll
-            for (int s = 0; s < WD; ++s) w_fetch(off, s, s);
+            for (int s = 0; s < WD; ++s) w_fetch(off, s, s, ntc);
             sched_fence();
         }
     };
-    auto gemm_planes = [&](int off) __attribute__((always_inline)) {
+    auto gemm_planes = [&](int off, auto ntc) __attribute__((always_inline)) {
+        constexpr int NT = decltype(ntc)::value;
+        static_assert(WD > 0 || NT == NTW, "the un-pipelined form keeps the layers' slice width");
         const unsigned* a_base = reinterpret_cast<const unsigned*>(xs) + opaque_i((kDecPadRows + 32 * MT * mh + i) * LDSROW + 4 * h);
         if constexpr (WD == 0) {
 #pragma unroll
@@ -577,10 +588,10 @@ __global__ __launch_bounds__(64 * NW, (DX2 <= 128 ? kDecWps128 : NW / 4)) void m
             for (int q = 0; q < NITEM; ++q) {
                 const int s = q / MT, mt = q % MT;
 #pragma unroll
-                for (int t = 0; t < NTW; ++t)
+                for (int t = 0; t < NT; ++t)
                     acc[mt][t] = mfma32_split2_wx(wr[s % (WD > 0 ? WD : 1)][t][0], wr[s % (WD > 0 ? WD : 1)][t][1], ar[q % AD], acc[mt][t]);
                 if (q + AD < NITEM) a_fetch(q + AD, q % AD);
-                if (mt == MT - 1 && s + WD < NSTEP) w_fetch(off, s + WD, s % (WD > 0 ? WD : 1));
+                if (mt == MT - 1 && s + WD < NSTEP) w_fetch(off, s + WD, s % (WD > 0 ? WD : 1), ntc);
                 sched_fence();
             }
         }
@@ -611,8 +622,8 @@ __global__ __launch_bounds__(64 * NW, (DX2 <= 128 ? kDecWps128 : NW / 4)) void m
     };
     // slice pointer of chunk c of the matrix at float offset `off`
     auto wslice = [&](int off, int c) __attribute__((always_inline)) { return off + (c * (DX2 / 32) + ns * NTW) * 16 * 256; };
-    auto gemm_prefetch = [&](int) __attribute__((always_inline)) {};
-    auto gemm_planes = [&](int) __attribute__((always_inline)) {};
+    auto gemm_prefetch = [&](int, auto) __attribute__((always_inline)) {};
+    auto gemm_planes = [&](int, auto) __attribute__((always_inline)) {};
 #endif
     // full dx2-wide contraction over fp32 rows of the tile, un-pipelined
     auto gemm_rows = [&](int off) __attribute__((always_inline)) {
@@ -697,10 +708,11 @@ __global__ __launch_bounds__(64 * NW, (DX2 <= 128 ? kDecWps128 : NW / 4)) void m
     // LN pass over the tile (in place): x = LN(x) [; x = LN_s(x + skip), skip = x at a block end]; rows outside [0, L) -> 0.
     // PLANES: the rows are written as the two f16 planes the pipelined K loop reads (the last LayerNorm feeds the mel Linear
     // only), otherwise as fp32.  BLOCK_END is a template-like constant at both call sites so that `skip = v` costs nothing.
-    // `shw` (BLOCK_END, fp32 rows only): block skew -- the rows are written `shw` rows further down (those that would leave the tile
-    // are dropped: they are the rows the block lost), behind a barrier that waits for every owner to have read its rows.
-    auto ln_pass = [&](const float* pb0, auto block_end_c, auto planes_c, int shw) __attribute__((always_inline)) {
-        constexpr bool BLOCK_END = decltype(block_end_c)::value, PLANES = decltype(planes_c)::value;
+    // ONE body with workgroup-uniform branches (block end / operand planes / shifted rows): four template-like copies of the pass made
+    // the register allocator shuffle the 64 skip registers at every join (340 moves per layer on dx2 = 256) and spill around them.
+    // `shw` (block end, fp32 rows only): block skew -- the rows are written `shw` rows further down (those that would leave the tile are
+    // dropped: they are the rows the block lost), behind a barrier that waits for every owner to have read its rows.
+    auto ln_pass = [&](const float* pb0, bool block_end_, bool planes_, int shw) __attribute__((always_inline)) {
         const float* pb = pb0 + opaque_i(4 * ln_c);           // this thread's channels of every param vector
         float* ln_ptr = xs + opaque_i((kDecPadRows + ln_row0) * LDSROW + 4 * ln_c);
         f32x4 g[NV], be[NV];
@@ -714,7 +726,7 @@ __global__ __launch_bounds__(64 * NW, (DX2 <= 128 ? kDecWps128 : NW / 4)) void m
         }
 #pragma unroll
         for (int j = 0; j < RPT; ++j) ln_regs(v[j], g, be);
-        if (BLOCK_END) {  // end of a decoder block: skip = LN_s(x + skip), networks.py:299
+        if (block_end_) {  // end of a decoder block: skip = LN_s(x + skip), networks.py:299
             ln_params(pb + P_SG, g);
             ln_params(pb + P_SB, be);
 #pragma unroll
@@ -729,26 +741,14 @@ __global__ __launch_bounds__(64 * NW, (DX2 <= 128 ? kDecWps128 : NW / 4)) void m
             for (int j = 0; j < RPT; ++j) {
 #pragma unroll
                 for (int k = 0; k < NV; ++k)
-                    if (!((ln_inside >> j) & 1u)) v[j][k] = zero4();
+                    if (!row_inside(j)) v[j][k] = zero4();
             }
         }
-        if (STREAM && BLOCK_END && !PLANES && shw) {   // (workgroup-uniform)
-            __syncthreads();
-            float* wp = ln_ptr + shw * LDSROW;
+        if (SPLIT && planes_) {   // the last LayerNorm feeds the mel Linear: the rows leave as its two f16 operand planes
 #pragma unroll
             for (int j = 0; j < RPT; ++j) {
-                if (ln_row0 + j + shw < kDecRows) {
 #pragma unroll
-                    for (int k = 0; k < NV; ++k) *reinterpret_cast<f32x4*>(wp + j * LDSROW + 4 * TPR * k) = v[j][k];
-                }
-            }
-            return;     // (the owners re-read their skip rows from the shifted tile at the start of the next block)
-        }
-#pragma unroll
-        for (int j = 0; j < RPT; ++j) {
-#pragma unroll
-            for (int k = 0; k < NV; ++k) {
-                if (PLANES) {
+                for (int k = 0; k < NV; ++k) {
                     typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
                     unsigned h1a, h2a, h1b, h2b;
                     split_f16_pair(v[j][k][0], v[j][k][1], h1a, h2a);
@@ -756,26 +756,47 @@ __global__ __launch_bounds__(64 * NW, (DX2 <= 128 ? kDecWps128 : NW / 4)) void m
                     unsigned* rowp = reinterpret_cast<unsigned*>(ln_ptr + j * LDSROW) - 2 * ln_c + 2 * TPR * k;   // dword 2*(channel group)
                     *reinterpret_cast<u32x2*>(rowp) = u32x2{h1a, h1b};
                     *reinterpret_cast<u32x2*>(rowp + DX2 / 2) = u32x2{h2a, h2b};
-                } else {
-                    *reinterpret_cast<f32x4*>(ln_ptr + j * LDSROW + 4 * TPR * k) = v[j][k];
                 }
-                if (BLOCK_END) skip[j][k] = v[j][k];
             }
+            return;
         }
+        float* wp = ln_ptr;
+        if (STREAM && shw) {   // (workgroup-uniform) block skew: every owner has read its rows before any row moves
+            __syncthreads();
+            wp = ln_ptr + shw * LDSROW;
+        }
+#pragma unroll
+        for (int j = 0; j < RPT; ++j) {
+            if (STREAM && ln_row0 + j + shw >= kDecRows) continue;   // (rows the block lost; never without the skew)
+#pragma unroll
+            for (int k = 0; k < NV; ++k) *reinterpret_cast<f32x4*>(wp + j * LDSROW + 4 * TPR * k) = v[j][k];
+        }
+        // (a block end does not keep its result as the new skip tensor in registers: the owners re-read their rows from the tile when
+        // the next block starts)
     };
     typedef std::true_type TrueC;
     typedef std::false_type FalseC;
+    // 32-column tiles per wave: conv layers; mel Linear (split build of the dx2 = 256 kernel: one, on three column slices)
+    constexpr int NTM = (SPLIT && DX2 > 128) ? 1 : NTW;
+    typedef std::integral_constant<int, NTW> NtwC;
+    typedef std::integral_constant<int, NTM> NtmC;
 
     // ---- proj: Linear(d4, dx2) + Tanh + LN.  All three are row-wise, and a frame's input row is its phoneme's row: when
     // the caller supplies h0 = LN(tanh(proj(x))) at PHONEME rate (enc_fuse_va_kernel computes it while the features
     // are still on the CU) the stage reduces to a gather -- one of the six GEMM stages of the window disappears
     // (D frames per phoneme share one row).  Padding frames (zero input rows) get LN(tanh(proj_b)).
     if (p.h0) {
-        for (int e = tid; e < kDecRows * (DX2 / 4); e += kDecThreads) {
+        static_assert(kDecRows * (DX2 / 4) % kDecThreads == 0, "whole passes");
+        for (int it = 0; it < kDecRows * (DX2 / 4) / kDecThreads; ++it) {   // (scalar trip counter: a per-lane one is a 64-bit register pair the dx2 = 256 kernel spilled)
+            const int e = tid + it * kDecThreads;
             const int r = e / (DX2 / 4), q = e - r * (DX2 / 4);
             const int s = src[r];
             f32x4 v = zero4();
+#if ESMI_DEC_H0_NT
+            if (s >= 0) v = STREAM ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p.h0 + (long)s * DX2 + 4 * q)) : ld4(p.h0 + (long)s * DX2 + 4 * q);
+#else
             if (s >= 0) v = ld4(p.h0 + (long)s * DX2 + 4 * q);
+#endif
             else if (s == -2) {
                 const f32x4 bb = *reinterpret_cast<const f32x4*>(pbuf + P_PWB + 4 * q);
 #pragma unroll
@@ -851,7 +872,7 @@ __global__ __launch_bounds__(64 * NW, (DX2 <= 128 ? kDecWps128 : NW / 4)) void m
                 ln_regs(skip[j], g, be);
 #pragma unroll
                 for (int k = 0; k < NV; ++k) {
-                    if (!((ln_inside >> j) & 1u)) skip[j][k] = zero4();
+                    if (!row_inside(j)) skip[j][k] = zero4();
                     *reinterpret_cast<f32x4*>(ln_ptr + j * LDSROW + 4 * TPR * k) = skip[j][k];
                 }
             }
@@ -879,18 +900,20 @@ __global__ __launch_bounds__(64 * NW, (DX2 <= 128 ? kDecWps128 : NW / 4)) void m
             if (skew && lin == 0 && l > 0) {
                 // a block starts on the shifted tile (complete since the barrier behind the last LayerNorm): hand the rows in front of
                 // the NEXT chunk's tile to the block carry (tile rows [keep - PAD, 128): the same thread reads them back one chunk
-                // later), re-read the skip rows, and derive which rows lie outside [0, L) at this block's frame base
+                // later) and derive which rows lie outside [0, L) at this block's frame base
                 if (tid < bc_n4) {
                     const f32x4 v = *reinterpret_cast<const f32x4*>(xs + (kDecPadRows + keep - PAD + tid / CG) * LDSROW + 4 * (tid % CG));
                     *reinterpret_cast<f32x4*>(bcw + (blk - 1) * (4 * kDecBlockCarry4) + opaque_i(4 * tid)) = v;
                 }
-                const float* ln_ptr = xs + opaque_i((kDecPadRows + ln_row0) * LDSROW + 4 * ln_c);
-#pragma unroll
-                for (int j = 0; j < RPT; ++j) {
-#pragma unroll
-                    for (int k = 0; k < NV; ++k) skip[j][k] = *reinterpret_cast<const f32x4*>(ln_ptr + j * LDSROW + 4 * TPR * k);
-                }
                 set_edge(g0 + sh * (p.n_blocks - 1 - blk));
+            }
+        }
+        if (lin == 0 && l > 0) {   // a block starts: its input (the tile, complete since the barrier behind the last LayerNorm) is the skip tensor
+            const float* ln_ptr = xs + opaque_i((kDecPadRows + ln_row0) * LDSROW + 4 * ln_c);
+#pragma unroll
+            for (int j = 0; j < RPT; ++j) {
+#pragma unroll
+                for (int k = 0; k < NV; ++k) skip[j][k] = *reinterpret_cast<const f32x4*>(ln_ptr + j * LDSROW + 4 * TPR * k);
             }
         }
         ESMI_STAMP();   // 0: layer start
@@ -933,13 +956,13 @@ __global__ __launch_bounds__(64 * NW, (DX2 <= 128 ? kDecWps128 : NW / 4)) void m
             }
         }
         commit_B(l);
-        gemm_prefetch(lbase + lay.l_pw);   // first weight steps: in flight across the barrier
+        gemm_prefetch(lbase + lay.l_pw, NtwC{});   // first weight steps: in flight across the barrier
         ESMI_STAMP();   // 3: dw written
         __syncthreads();
         ESMI_STAMP();   // 4: barrier
         // 2. pointwise conv: K = dx2
         zero_acc();
-        if (SPLIT) gemm_planes(lbase + lay.l_pw);
+        if (SPLIT) gemm_planes(lbase + lay.l_pw, NtwC{});
         else gemm_rows(lbase + lay.l_pw);
         ESMI_STAMP();   // 5: K loop issued
         // 3. bias + tanh on the accumulators (no tile access: ahead of the barrier), then -> tile
@@ -958,23 +981,16 @@ __global__ __launch_bounds__(64 * NW, (DX2 <= 128 ? kDecWps128 : NW / 4)) void m
         // block skew, at the end of every block but the last: the rows go `sh` rows down, the rows in front of them arrive from the
         // previous chunk (requested here, a phase ahead; zero rows at the start of an utterance -- frames < 0)
         const int shw = (STREAM && skew && block_end && l + 1 < n_layers) ? sh : 0;
-        f32x4 bcv = zero4();
-        if constexpr (STREAM) {
-            if (shw && ck > 0 && tid < bc_n4) bcv = ld4(bcw + blk * (4 * kDecBlockCarry4) + opaque_i(4 * tid));
-        }
-        if (SPLIT && l + 1 == n_layers) {
-            if (block_end) ln_pass(pb, TrueC{}, TrueC{}, 0);
-            else ln_pass(pb, FalseC{}, TrueC{}, 0);
-        } else {
-            if (block_end) ln_pass(pb, TrueC{}, FalseC{}, shw);
-            else ln_pass(pb, FalseC{}, FalseC{}, 0);
-        }
+        ln_pass(pb, block_end, SPLIT && l + 1 == n_layers, shw);
         ESMI_STAMP();   // 9: LN done
-        if (l + 1 == n_layers) gemm_prefetch(lay.mel_w);   // (the mel bias went to the unused group A slots by LDS-DMA above)
+        if (l + 1 == n_layers) gemm_prefetch(lay.mel_w, NtmC{});   // (the mel bias went to the unused group A slots by LDS-DMA above)
         else carry_put(slot_next);
         if constexpr (STREAM) {
-            if (shw && tid < bc_n4)   // pad rows of the next conv layer + tile rows [0, sh) of the next block
+            if (shw && tid < bc_n4) {  // pad rows of the next conv layer + tile rows [0, sh) of the next block
+                f32x4 bcv = zero4();
+                if (ck > 0) bcv = ld4(bcw + blk * (4 * kDecBlockCarry4) + opaque_i(4 * tid));
                 *reinterpret_cast<f32x4*>(xs + (kDecPadRows - PAD + tid / CG) * LDSROW + 4 * (tid % CG)) = bcv;
+            }
         }
         __syncthreads();
         ESMI_STAMP();   // 10: barrier
@@ -993,14 +1009,62 @@ __global__ __launch_bounds__(64 * NW, (DX2 <= 128 ? kDecWps128 : NW / 4)) void m
         fetch_B(0);
         __syncthreads();
     }
-    if (ns * WCOLS < p.n_mel) {   // wave-uniform: column slices beyond n_mel have nothing to do
+    const bool mel_wave = ns * 32 * NTM < p.n_mel;   // wave-uniform: column slices beyond n_mel have nothing to do
+    const float* mb = pbuf;                          // mel bias (zero padded to dx2)
+    const bool vec_ok = (p.n_mel & 3) == 0;          // rows of 16-byte multiples: float4 stores
+    if (mel_wave) {
         zero_acc();
-        if (SPLIT && n_layers > 0) gemm_planes(lay.mel_w);
+        if (SPLIT && n_layers > 0) gemm_planes(lay.mel_w, NtmC{});
         else gemm_rows(lay.mel_w);
-        const float* mb = pbuf;                      // mel bias (zero padded to dx2)
-        const bool vec_ok = (p.n_mel & 3) == 0;      // rows of 16-byte multiples: float4 stores
+    }
+    if constexpr (STREAM) {
+        // dx2 = 256: the chunk's mel rows are ONE contiguous run of the output (row stride = n_mel floats), so they are put together in
+        // LDS (the tile is free once every wave is through the K loop) and leave as whole-line streaming stores.  Stored straight from the
+        // accumulators a wave instruction scatters 64 x 16 B over 32 rows: as plain stores those pass through the XCD's L2 and evict the
+        // weight slices that every chunk re-reads (round 5: 2.95x the algorithmic HBM traffic on base ES), as streaming stores they
+        // reach HBM as partial lines (measured: writes 2.8x the mel).
+        float* stg = xs;                             // [kDecRows][n_mel rounded up to a multiple of 4]
+        const int mstride = (p.n_mel + 3) & ~3;
+        __syncthreads();
+        if (mel_wave) {
 #pragma unroll
-        for (int t = 0; t < NTW; ++t) {
+            for (int t = 0; t < NTM; ++t) {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    const int r = 32 * MT * mh + 32 * mt + i;
+                    const bool live = g0 + r < valid_end;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int col = ns * 32 * NTM + 32 * t + 8 * g + 4 * h;
+                        if (col >= p.n_mel) continue;
+                        const f32x4 bc = *reinterpret_cast<const f32x4*>(mb + col);
+                        f32x4 v;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = live ? fmaf(acc[mt][t][4 * g + e], WSI, bc[e]) : 0.0f;
+                        *reinterpret_cast<f32x4*>(stg + r * mstride + col) = v;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        const float* sp = stg + (f_lo - g0) * mstride;
+        float* dp = p.mel + ((long)b * p.L_out + f_lo) * p.n_mel;
+        if (vec_ok) {
+            const int n4 = (out_hi - f_lo) * (p.n_mel >> 2);
+            for (int e = tid; e < n4; e += kDecThreads) {
+#if ESMI_DEC_MEL_NT
+                __builtin_nontemporal_store(*reinterpret_cast<const f32x4*>(sp + 4 * e), reinterpret_cast<f32x4*>(dp + 4 * e));
+#else
+                *reinterpret_cast<f32x4*>(dp + 4 * e) = *reinterpret_cast<const f32x4*>(sp + 4 * e);
+#endif
+            }
+        } else {   // rows that are not 16-byte multiples: element by element
+            const int n = (out_hi - f_lo) * p.n_mel;
+            for (int e = tid; e < n; e += kDecThreads) dp[e] = sp[(e / p.n_mel) * mstride + e % p.n_mel];
+        }
+    } else if (mel_wave) {
+#pragma unroll
+        for (int t = 0; t < NTM; ++t) {
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
                 const int f = g0 + 32 * MT * mh + 32 * mt + i;
@@ -1009,7 +1073,7 @@ __global__ __launch_bounds__(64 * NW, (DX2 <= 128 ? kDecWps128 : NW / 4)) void m
                 const bool live = f < valid_end;
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    const int col = ns * WCOLS + 32 * t + 8 * g + 4 * h;
+                    const int col = ns * 32 * NTM + 32 * t + 8 * g + 4 * h;
                     if (col >= p.n_mel) continue;
                     const f32x4 bc = *reinterpret_cast<const f32x4*>(mb + col);
                     f32x4 v;

@@ -60,7 +60,7 @@ int esmi_mel_decoder_pack_f32(const esmi_decoder_weights* w, const esmi_decoder_
     const DecLayout L = dec_layout(s->d4, s->dx2, s->kernel, s->n_blocks, s->block_depth);
     hipStream_t st = S(stream);
     const int dx2 = s->dx2, ntw = dx2 / 128;
-    auto bslice = [&](const float* src, long off, int N, int K) {
+    auto bslice = [&](const float* src, long off, int N, int K, int ntw) {
 #if ESMI_DEC_SPLIT == 2
         const long n = (long)(K / 128) * 4 * ntw * 8 * 2 * 256;
         ESMI_LAUNCH(pack_bslice2h_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src,
@@ -73,7 +73,7 @@ int esmi_mel_decoder_pack_f32(const esmi_decoder_weights* w, const esmi_decoder_
     auto vec = [&](const float* src, long off, int n, int n_pad) {
         ESMI_LAUNCH(copy_pad_kernel, dim3((n_pad + 255) / 256), dim3(256), 0, st, src, blob + off, n, n_pad);
     };
-    bslice(w->proj_w, L.proj_w, dx2, s->d4);
+    bslice(w->proj_w, L.proj_w, dx2, s->d4, ntw);
     vec(w->proj_b, L.proj_b, dx2, dx2);
     vec(w->proj_ln_g, L.proj_g, dx2, dx2);
     vec(w->proj_ln_b, L.proj_beta, dx2, dx2);
@@ -83,7 +83,7 @@ int esmi_mel_decoder_pack_f32(const esmi_decoder_weights* w, const esmi_decoder_
         ESMI_LAUNCH(pack_dw_kernel, dim3((dx2 * s->kernel + 255) / 256), dim3(256), 0, st, w->dw_w[l], blob + base + L.l_dw,
                     dx2, s->kernel);
         vec(w->dw_b[l], base + L.l_dwb, dx2, dx2);
-        bslice(w->pw_w[l], base + L.l_pw, dx2, dx2);
+        bslice(w->pw_w[l], base + L.l_pw, dx2, dx2, ntw);
         vec(w->pw_b[l], base + L.l_pwb, dx2, dx2);
         vec(w->ln_g[l], base + L.l_g, dx2, dx2);
         vec(w->ln_b[l], base + L.l_b, dx2, dx2);
@@ -92,7 +92,12 @@ int esmi_mel_decoder_pack_f32(const esmi_decoder_weights* w, const esmi_decoder_
         vec(w->skip_g[b], L.skip0 + 2L * dx2 * b, dx2, dx2);
         vec(w->skip_b[b], L.skip0 + 2L * dx2 * b + dx2, dx2, dx2);
     }
-    bslice(w->mel_w, L.mel_w, s->n_mel, dx2);
+    // (the mel Linear of the split build's dx2 = 256 kernel: three one-tile column slices, mel_decoder.h NTM)
+#if ESMI_DEC_SPLIT == 2
+    bslice(w->mel_w, L.mel_w, s->n_mel, dx2, 1);
+#else
+    bslice(w->mel_w, L.mel_w, s->n_mel, dx2, ntw);
+#endif
     vec(w->mel_b, L.mel_b, s->n_mel, dx2);
     return launch_status();
 }
