@@ -57,6 +57,9 @@ constexpr int kDecWps128 = 4, kDecWeightRing256 = 2, kDecARing = 1;
 #ifndef ESMI_DEC_H0_NT      // dx2 = 256: the h0 row gather as streaming loads
 #define ESMI_DEC_H0_NT 1    // (base ES, B = 512: HBM traffic per launch 1051 MB with plain stores and loads, 576 MB with streaming mel stores,
 #endif                      //  541 MB with both, against 386 MB algorithmic: profiles/r06_probes/decoder256_traffic_ab.txt)
+#ifndef ESMI_DEC_CUM_LDS    // the utterance's duration scan is copied into LDS (one round trip) and the frame -> phoneme search runs there
+#define ESMI_DEC_CUM_LDS 1  // (0: a binary search in global memory, log2(T) dependent L2 round trips per chunk: profiles/r06_dec_budget.md)
+#endif
 #define ESMI_DEC_TANH tanh_fast_f32
 #define ESMI_DEC_RSQRT rsqrt_fast_f32   // v_rsq_f32 (1 ulp)
 
@@ -309,7 +312,14 @@ __global__ __launch_bounds__(64 * NW, (DX2 <= 128 ? kDecWps128 : NW / 4)) void m
 #ifdef ESMI_DEC_TRACE
     int tr_n = 0;
     const bool tr_on = p.trace && seg == (DX2 > 128 ? 0 : 3) && b == p.B / 2 + 5 && lane == 0;
-#define ESMI_STAMP() do { if (tr_on) p.trace[w * 64 + tr_n] = (long long)__builtin_amdgcn_s_memtime(); ++tr_n; } while (0)
+#define ESMI_STAMP() do { if (tr_on && tr_n < 59) p.trace[w * 64 + tr_n] = (long long)__builtin_amdgcn_s_memtime(); ++tr_n; } while (0)
+    // stamps of the traced workgroup (tools/dec_budget.py): 0 = entry, 1 = sources / parameters staged, 2 = first stage (h0 gather or proj) done,
+    // 3 + 12 l + (0..11) = layer l (see the layer loop; the first four layers fit); fixed slots of the FIRST chunk: 59 = layers done, 60 = mel
+    // K loop issued, 61 = rows stored; slots 62 / 63 = the 100 MHz clock at entry / at the end of the first chunk (the shader clock the
+    // workgroup ran at = stamp span / that span)
+#define ESMI_STAMP_AT(slot) do { if (tr_on && ck == 0) p.trace[w * 64 + (slot)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+    if (tr_on) p.trace[w * 64 + 62] = clock_real100();
+    ESMI_STAMP();
 #else
 #define ESMI_STAMP() do {} while (0)
 #endif
@@ -428,17 +438,15 @@ __global__ __launch_bounds__(64 * NW, (DX2 <= 128 ? kDecWps128 : NW / 4)) void m
             }
         }
     };
-    if (tid < kDecRows) {
-        const int f = f0 + tid;
-        int s;
-        if (f < 0 || f >= L) s = -1;                                   // outside the padded sequence
-        else if (p.cum) {
-            if (f < mlen) {
-                const int ph = frame_to_phoneme(p.cum + b * p.T, p.T, f);
-                s = ph < p.T ? b * p.T + ph : -2;
-            } else s = -2;                                             // padding frame: zero input row
-        } else s = b * L + f;
-        src[tid] = s;
+    // The chunk's rows -> their phonemes (the length regulator's gather, networks.py:233-244).  The search used to run in global memory:
+    // log2(T) DEPENDENT L2 round trips by two of the eight waves before anything else could start -- with the gather and the first
+    // LayerNorm behind it the prologue was 12.8 % of a dx2 = 128 workgroup's life (profiles/r06_dec_budget.md).  Now the utterance's scan
+    // row is copied into the (still unused) tile by all threads, next to the other loads of the prologue, and searched there.
+    int* const cum_s = reinterpret_cast<int*>(xs + kDecPadRows * LDSROW);
+    const bool cum_lds = ESMI_DEC_CUM_LDS && p.cum && p.T <= kDecRows * LDSROW;
+    if (cum_lds) {
+        const int* crow = p.cum + b * p.T;
+        for (int e = tid; e < p.T; e += kDecThreads) cum_s[e] = crow[e];
     }
     for (int e = tid; e < 2 * kDecPadRows * LDSROW; e += kDecThreads) {
         const int r = e / LDSROW, c = e - r * LDSROW;
@@ -450,7 +458,36 @@ __global__ __launch_bounds__(64 * NW, (DX2 <= 128 ? kDecWps128 : NW / 4)) void m
     carry_load(0);
     fetch_A(0);
     commit_A(0);
+#ifdef ESMI_DEC_TRACE
+    ESMI_STAMP_AT(52);   // prologue loads issued
+#endif
+    if (cum_lds) __syncthreads();
+#ifdef ESMI_DEC_TRACE
+    ESMI_STAMP_AT(53);   // scan row in LDS
+#endif
+    if (tid < kDecRows) {
+        const int f = f0 + tid;
+        int s;
+        if (f < 0 || f >= L) s = -1;                                   // outside the padded sequence
+        else if (p.cum) {
+            if (f < mlen) {
+                int ph;
+                if (cum_lds) {                                          // first i with cum[i] > f (searchsorted right); T if none
+                    int lo = 0, hi = p.T;
+                    while (lo < hi) {
+                        const int mid = (lo + hi) >> 1;
+                        if (cum_s[mid] > f) hi = mid;
+                        else lo = mid + 1;
+                    }
+                    ph = lo;
+                } else ph = frame_to_phoneme(p.cum + b * p.T, p.T, f);
+                s = ph < p.T ? b * p.T + ph : -2;
+            } else s = -2;                                             // padding frame: zero input row
+        } else s = b * L + f;
+        src[tid] = s;
+    }
     __syncthreads();
+    ESMI_STAMP();   // 1: sources / parameters staged
 
     // LayerNorm ownership: lane = 16*rg + c; the thread owns rows ln_row0 + (0..3) and the float4 channel groups c + 16*k of
     // each.  The four row groups of a wave sit 16 rows apart (rows 64(w>>2) + 16rg + 4(w&3) + j): the LDS bank of a lane's
@@ -804,7 +841,13 @@ __global__ __launch_bounds__(64 * NW, (DX2 <= 128 ? kDecWps128 : NW / 4)) void m
             }
             *reinterpret_cast<f32x4*>(xs + (kDecPadRows + r) * LDSROW + 4 * q) = v;
         }
+#ifdef ESMI_DEC_TRACE
+        ESMI_STAMP_AT(54);   // h0 rows requested and written to the tile
+#endif
         __syncthreads();
+#ifdef ESMI_DEC_TRACE
+        ESMI_STAMP_AT(55);   // barrier
+#endif
         {   // row owners: LayerNorm only for the padding frames' rows; skip = the stage's output
             const float* pb = pbuf + opaque_i(4 * ln_c);
             float* ln_ptr = xs + opaque_i((kDecPadRows + ln_row0) * LDSROW + 4 * ln_c);
@@ -881,6 +924,7 @@ __global__ __launch_bounds__(64 * NW, (DX2 <= 128 ? kDecWps128 : NW / 4)) void m
         __syncthreads();
     }
 
+    ESMI_STAMP();   // 2: first stage done
     // ---- conv layers
     int dw_cg = tid % CG, dw_r0 = (tid / CG) * RS;
     int blk = 0, lin = 0;                    // block of layer l and the layer's place in it
@@ -968,13 +1012,14 @@ __global__ __launch_bounds__(64 * NW, (DX2 <= 128 ? kDecWps128 : NW / 4)) void m
         // 3. bias + tanh on the accumulators (no tile access: ahead of the barrier), then -> tile
         tanh_acc(pb + P_PWB);
         fetch_A(l + 1);      // next layer's taps (their slots were last read by this layer's depthwise phase)
+        ESMI_STAMP();   // 6: bias + tanh done on the accumulators
         __syncthreads();  // all reads of the filtered tile done
-        ESMI_STAMP();   // 6: barrier
+        ESMI_STAMP();   // 7: barrier
         store_acc();
         commit_A(l + 1);     // (the taps' LDS slots were last read by this layer's depthwise phase)
-        ESMI_STAMP();   // 7: tanh stored
+        ESMI_STAMP();   // 8: tanh stored
         __syncthreads();
-        ESMI_STAMP();   // 8: barrier
+        ESMI_STAMP();   // 9: barrier
         // 4. LayerNorm (+ block-end skip LayerNorm) by row owners; the last one writes the mel Linear's operand planes
         if (l + 1 == n_layers) fetch_B(n_layers);   // mel bias -> group A slots (taps: last read by this layer's depthwise phase)
         else carry_load(slot_next);
@@ -982,7 +1027,7 @@ __global__ __launch_bounds__(64 * NW, (DX2 <= 128 ? kDecWps128 : NW / 4)) void m
         // previous chunk (requested here, a phase ahead; zero rows at the start of an utterance -- frames < 0)
         const int shw = (STREAM && skew && block_end && l + 1 < n_layers) ? sh : 0;
         ln_pass(pb, block_end, SPLIT && l + 1 == n_layers, shw);
-        ESMI_STAMP();   // 9: LN done
+        ESMI_STAMP();   // 10: LN done
         if (l + 1 == n_layers) gemm_prefetch(lay.mel_w, NtmC{});   // (the mel bias went to the unused group A slots by LDS-DMA above)
         else carry_put(slot_next);
         if constexpr (STREAM) {
@@ -993,10 +1038,13 @@ __global__ __launch_bounds__(64 * NW, (DX2 <= 128 ? kDecWps128 : NW / 4)) void m
             }
         }
         __syncthreads();
-        ESMI_STAMP();   // 10: barrier
+        ESMI_STAMP();   // 11: barrier
         if (++lin == p.block_depth) { lin = 0; ++blk; }
     }
 
+#ifdef ESMI_DEC_TRACE
+    ESMI_STAMP_AT(59);   // conv layers done
+#endif
     // ---- mel Linear(dx2, n_mel) on skip (held in the tile), masked store
     if constexpr (!STREAM) {   // clock probe, second stamp of the one-chunk kernel: the first workgroup again, in front of its last stage
         long long* const clk = g_dec_clk;     // (s_memtime counters of different CUs are not comparable: both stamps come from one workgroup)
@@ -1017,6 +1065,9 @@ __global__ __launch_bounds__(64 * NW, (DX2 <= 128 ? kDecWps128 : NW / 4)) void m
         if (SPLIT && n_layers > 0) gemm_planes(lay.mel_w, NtmC{});
         else gemm_rows(lay.mel_w);
     }
+#ifdef ESMI_DEC_TRACE
+    ESMI_STAMP_AT(60);   // mel K loop issued
+#endif
     if constexpr (STREAM) {
         // dx2 = 256: the chunk's mel rows are ONE contiguous run of the output (row stride = n_mel floats), so they are put together in
         // LDS (the tile is free once every wave is through the K loop) and leave as whole-line streaming stores.  Stored straight from the
@@ -1090,6 +1141,10 @@ __global__ __launch_bounds__(64 * NW, (DX2 <= 128 ? kDecWps128 : NW / 4)) void m
             }
         }
     }
+#ifdef ESMI_DEC_TRACE
+    ESMI_STAMP_AT(61);   // rows stored (issued)
+    if (tr_on && ck == 0) p.trace[w * 64 + 63] = clock_real100();
+#endif
     }   // chunks of the segment
 }
 

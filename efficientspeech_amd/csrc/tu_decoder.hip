@@ -165,7 +165,7 @@ static int mel_decoder_launch(const float* blob, const esmi_decoder_shape* s, co
     p.halo = (s->kernel / 2) * s->n_blocks * s->block_depth;
     p.trace = nullptr;
 #ifdef ESMI_DEC_TRACE
-    p.trace = g_esmi_trace;   // development only, see tools/trace_decoder.py
+    p.trace = g_esmi_trace;   // development only, see tools/dec_budget.py
 #endif
     hipStream_t st = S(stream);
     p.carry_ws = nullptr;
