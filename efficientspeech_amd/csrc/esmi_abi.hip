@@ -465,12 +465,19 @@ static int fuse_variance_adaptor(const esmi_fuse_weights* fw, int depth, int dim
         fuse_va_chain_params(fw, depth, dim, kernel, B, T, feats, n_i, pitch, energy, duration, mask, pitch_target, energy_target,
                              duration_target, feat, pitch_pred, energy_pred, duration_pred, pitch_idx, energy_idx, dur, cum, mel_len,
                              head_in_chain ? head : nullptr, head_in_chain ? h0 : nullptr, &p, &nw);
-        const bool scan_fused = cum && p.halo == 0;   // one workgroup sees every duration of its utterance
+        bool scan_fused = cum && p.halo == 0;   // one workgroup sees every duration of its utterance
         int rc16 = ESMI_ERR_UNSUPPORTED;
         if ((plan & ESMI_FUSE_CHAIN16) && scan_fused == (cum != nullptr)) {
             FuseVaP q = p;
             if (lean && head_in_chain) { q.feat = nullptr; q.preds[0] = q.preds[1] = nullptr; q.pitch_idx = q.energy_idx = nullptr; }
             rc16 = launch_enc_va16(q, dim, kernel, S(stream));
+        }
+        if (rc16 == ESMI_ERR_UNSUPPORTED && (plan & ESMI_FUSE_CHAIN16) && !head_in_chain) {
+            // dim = 64, T <= 256 (round 6): one workgroup per utterance, so the length regulator's scan runs inside it
+            FuseVaP q = p;
+            q.cum = cum; q.mel_len = mel_len;
+            rc16 = launch_enc_va64(q, dim, kernel, S(stream));
+            if (rc16 == ESMI_OK) scan_fused = cum != nullptr;
         }
         if (rc16 == ESMI_ERR_UNSUPPORTED) rc16 = launch_enc_fuse_va(p, dim, kernel, nw, head_in_chain, S(stream));
         if (rc16) return rc16;
@@ -855,7 +862,7 @@ int esmi_phoneme2mel_forward_f32(const esmi_forward_args* a, int stage, esmi_str
     hipError_t e = hipMemsetAsync(a->range_flag, 0, sizeof(int32_t), S(stream));
     if (e != hipSuccess) return (int)e;
     int (*const setters[])(int*) = {set_range_flag_abi, set_range_flag_convgemm, set_range_flag_attention, set_range_flag_enc_merge,
-                                    set_range_flag_enc_block, set_range_flag_enc_attn_ffn, set_range_flag_enc_fuse_va, set_range_flag_enc_va16, set_range_flag_enc_block16,
+                                    set_range_flag_enc_block, set_range_flag_enc_attn_ffn, set_range_flag_enc_fuse_va, set_range_flag_enc_va16, set_range_flag_enc_va64, set_range_flag_enc_block16,
                                     set_range_flag_decoder, set_range_flag_dec_128_5, set_range_flag_dec_128_3, set_range_flag_dec_256_5,
                                     set_range_flag_dec_256_3, set_range_flag_hifigan, set_range_flag_train};
     for (auto set : setters)

@@ -59,6 +59,8 @@ int launch_enc_fuse_va(const FuseVaP& p, int dim, int kernel, int nw, bool head,
 // tu_enc_va16.hip (round 5: 16-row tiles, weights through LDS; ESMI_ERR_UNSUPPORTED for the shapes it is not built for)
 int launch_enc_va16(const FuseVaP& p, int dim, int kernel, hipStream_t st);
 bool enc_va16_ok(const FuseVaP& p, int dim, int kernel);
+// tu_enc_va64.hip (round 6: the same stage for dim = 64 models, T <= 256; ESMI_ERR_UNSUPPORTED otherwise)
+int launch_enc_va64(const FuseVaP& p, int dim, int kernel, hipStream_t st);
 // tu_enc_block16.hip (round 5: whole-block kernels of dim = 32 models on 16-row tiles)
 int launch_enc_block16(const EncAttnFfnP& p, int expansion, int c_in, hipStream_t st);
 // ... and the whole encoder side in one launch (block 0 | block 1 | Fuse + variance adaptor), when each of the three chain16 kernels
@@ -91,6 +93,7 @@ int set_range_flag_enc_block(int* flag);
 int set_range_flag_enc_attn_ffn(int* flag);
 int set_range_flag_enc_fuse_va(int* flag);
 int set_range_flag_enc_va16(int* flag);
+int set_range_flag_enc_va64(int* flag);
 int set_range_flag_enc_block16(int* flag);
 int set_range_flag_decoder(int* flag);
 int set_range_flag_dec_128_5(int* flag);
