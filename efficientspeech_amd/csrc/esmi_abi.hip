@@ -3,6 +3,7 @@
 // clang++ with -DESMI_WAVESIM into libesmi_sim.so (CPU wave simulator used only by tests).
 #include "launch.h"
 #include "mel_decoder.h"   // esmi_decoder_shape helpers used by the one-call forward
+#include "enc_ffn64.h"
 
 using namespace esmi;
 ESMI_TU_RANGE_SETTER(abi)
@@ -260,6 +261,15 @@ int esmi_encoder_block_f32(const esmi_encoder_block_weights* w, const esmi_encod
         a.qkv = qkv;
     }
     if ((rc = launch_attn(a, st))) return rc;
+    if ((plan & ESMI_FUSE_CHAIN16) && packed && !folded && C == 64 && h == 1 && s->expansion == 1 && n <= 256) {
+        // round 6: everything behind the attention in ONE launch (enc_ffn64.h) instead of three GEMM launches through HBM
+        PostAttn64P q;
+        q.ctx = ctx; q.x = x_out; q.out = x_out; q.proj_w = w->proj_wp; q.ffn_w = w->ffn_cwp; q.mlp2_w = w->mlp2_wp;
+        q.proj_b = w->proj_b; q.ln1_g = w->ln1_g; q.ln1_b = w->ln1_b; q.ffn_b = w->ffn_cb; q.ffn_b0 = w->ffn_cb_first; q.ffn_b2 = w->ffn_cb_last;
+        q.mlp2_b = w->mlp2_b; q.ln2_g = w->ln2_g; q.ln2_b = w->ln2_b; q.rowmask = mask; q.B = B; q.N = n;
+        rc = launch_enc_post_attn64(q, st);
+        if (rc != ESMI_ERR_UNSUPPORTED) return rc;
+    }
     // proj + residual + LN1 + mask, blocks.py:65 + networks.py:73-75  (folded: ctx holds P_h x, the matrix is [O_h])
     p = conv_defaults();
     p.B = B; p.n_in = n; p.c_in = h * C; p.n_out = n; p.c_out = C;

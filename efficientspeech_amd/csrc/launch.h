@@ -61,6 +61,8 @@ int launch_enc_va16(const FuseVaP& p, int dim, int kernel, hipStream_t st);
 bool enc_va16_ok(const FuseVaP& p, int dim, int kernel);
 // tu_enc_va64.hip (round 6: the same stage for dim = 64 models, T <= 256; ESMI_ERR_UNSUPPORTED otherwise)
 int launch_enc_va64(const FuseVaP& p, int dim, int kernel, hipStream_t st);
+struct PostAttn64P;
+int launch_enc_post_attn64(const PostAttn64P& p, hipStream_t st);   // (enc_ffn64.h: proj + LN1 + MixFFN + LN2 of a C = 64 one-head block, N <= 256)
 // tu_enc_block16.hip (round 5: whole-block kernels of dim = 32 models on 16-row tiles)
 int launch_enc_block16(const EncAttnFfnP& p, int expansion, int c_in, hipStream_t st);
 // ... and the whole encoder side in one launch (block 0 | block 1 | Fuse + variance adaptor), when each of the three chain16 kernels

@@ -5,6 +5,7 @@
 
 #include "launch.h"
 #include "enc_va64.h"
+#include "enc_ffn64.h"
 
 using namespace esmi;
 ESMI_TU_RANGE_SETTER(enc_va64)
@@ -35,6 +36,26 @@ int launch_enc_va64(const FuseVaP& p, int dim, int kernel, hipStream_t st) {
     return launch_status();
 #else
     (void)p; (void)dim; (void)kernel; (void)st;
+    return ESMI_ERR_UNSUPPORTED;
+#endif
+}
+
+// Everything behind the attention of a C = 64 one-head block (N <= 256) in one launch (enc_ffn64.h); ESMI_ERR_UNSUPPORTED in the exact-fp32 build
+int launch_enc_post_attn64(const PostAttn64P& p, hipStream_t st) {
+#if ESMI_CHAIN_SPLIT
+    if (p.N < 1 || p.N > 32 * kVa64MaxWaves || p.B < 1) return ESMI_ERR_UNSUPPORTED;
+    if (p.N <= 16 * kVa64MaxWaves) {
+        static AttrOnce once;
+        if (int rc = raise_lds_limit(reinterpret_cast<const void*>(enc_post_attn64_kernel<1>), once)) return rc;
+        ESMI_LAUNCH((enc_post_attn64_kernel<1>), dim3(p.B), dim3(64 * ((p.N + 15) / 16)), ffn64_lds_bytes(), st, p);
+    } else {
+        static AttrOnce once;
+        if (int rc = raise_lds_limit(reinterpret_cast<const void*>(enc_post_attn64_kernel<2>), once)) return rc;
+        ESMI_LAUNCH((enc_post_attn64_kernel<2>), dim3(p.B), dim3(64 * ((p.N + 31) / 32)), ffn64_lds_bytes(), st, p);
+    }
+    return launch_status();
+#else
+    (void)p; (void)st;
     return ESMI_ERR_UNSUPPORTED;
 #endif
 }
