@@ -1,7 +1,9 @@
 // Fuse + variance adaptor (+ the length regulator's scan) for dim = 64 models (small ES) whose sequence one workgroup covers
 // (T <= 256, two encoder levels, ConvTranspose kernel 3): round 6.  Same reference operations as enc_fuse_va.h / enc_va16.h
-// (layers/networks.py:189-219, :128-165, :346-384, :233-244); the decoder's phoneme-rate first stage stays its own GEMM launch
-// (esmi_decoder_head_f32) behind this kernel.
+// (layers/networks.py:189-219, :128-165, :346-384, :233-244) and, when the caller wants it, the decoder's phoneme-rate first stage
+// h0 = LN(tanh(feat Wp^T + b)) (the row-wise head of :291-294, 4 dim = dx2 = 256) as eight more weight steps per tile behind the
+// predictors -- its four operands (fused rows, the two embedding rows, the duration features) are on the CU at that moment, so the
+// (B, T, 256) feature tensor is neither written nor read back when nobody else wants it.
 //
 // Why not enc_va16.h with DIM = 64: its plan keeps the fused rows and the three predictors' hidden rows as shared LDS tiles
 // (dim 64, 256 rows: 70 KB + 210 KB) and the weights in two 36 KB halves (one dim-64 k = 3 convolution alone is 48 KB).  Here NO
@@ -34,7 +36,7 @@ struct Va64Lds {   // floats / dwords
     static constexpr int wbuf = 12 * 1024;                              // one weight buffer: 48 KB
     static constexpr int w0 = 0, w1 = wbuf;
     static constexpr int par = 2 * wbuf;                                // parameter vectors, see VP_*
-    static constexpr int par_sz = 512 + 3 * 512;
+    static constexpr int par_sz = 512 + 3 * 512 + 768;                  // (+ the decoder head's bias | gain | shift)
     static constexpr int bnd_sz = 2 * kVa64MaxWaves * 2 * 64;           // [tile][first | last][k group 2][piece 2][16 dwords]
     static constexpr int bndF = par + par_sz;
     static constexpr int bndH = bndF + bnd_sz;
@@ -45,7 +47,7 @@ static_assert(Va64Lds::total * 4 <= 160 * 1024, "enc_va64: LDS");
 inline int va64_lds_bytes() { return Va64Lds::total * (int)sizeof(float); }
 // parameter vectors (float offsets inside Va64Lds::par); four 64-float vectors per LDS-DMA instruction
 enum { VP_MLPB0 = 0, VP_MLPB1 = 64, VP_UPB1 = 128, VP_FUSEB = 192, VP_LN2G = 256, VP_LN2B = 320, VP_EDGE = 384 /* pitch, energy: 63 edges, +inf */,
-       VP_PRED = 512 /* + 512 q: conv1_b, ln1_g, ln1_b, conv2_b | lin_w, 3 unused */ };
+       VP_PRED = 512 /* + 512 q: conv1_b, ln1_g, ln1_b, conv2_b | lin_w, 3 unused */, VP_HEADB = 2048, VP_HEADG = 2304, VP_HEADBE = 2560 };
 
 namespace va64 {
 using namespace c16;
@@ -194,17 +196,20 @@ __device__ __forceinline__ void enc_va64_body(const FuseVaP& p) {
             dma_frags(p.up_w[1], dst, 48, w, nw, lane, rot);
         } else if (k == 2) {
             dma_frags(p.fuse_w, dst, 32, w, nw, lane, rot);
-        } else {
+        } else if (k < 9) {
             const int q = (k - 3) >> 1;
             dma_frags((k - 3) & 1 ? p.pred[q].conv2_w : p.pred[q].conv1_w, dst, 48, w, nw, lane, rot);
+        } else {   // the head's k group (k - 9) & 7: 32 channels x 256 outputs = 32 KB (streamed once per tile of the wave)
+            dma_frags(p.head_w + ((k - 9) & 7) * (32 * 256), dst, 32, w, nw, lane, rot);
         }
     };
+    const int nset = p.h0 ? 9 + 8 * NTILE : 9;
     // step k begins: this wave's share of set k has landed, every wave is through step k - 1 (the other buffer is free, the boundary
     // rows written in step k - 1 are visible); then set k + 1 is requested into the buffer step k - 1 used
     auto step_begin = [&](int k) __attribute__((always_inline)) {
         wait_vm0();
         wg_sync_lds();
-        if (k >= 1 && k + 1 < 9) request(k + 1);
+        if (k >= 1 && k + 1 < nset) request(k + 1);
     };
 
     // ---------------- entry: the rows' own inputs, the first two weight sets and every parameter vector on their way
@@ -223,6 +228,11 @@ __device__ __forceinline__ void enc_va64_body(const FuseVaP& p) {
             if (w == (2 + 2 * q) % nw) lds_dma16(pick4(d.conv1_b, d.ln1_g, d.ln1_b, d.conv2_b), par + VP_PRED + 512 * q, lane);
             if (w == (3 + 2 * q) % nw) lds_dma16(pick4(d.lin_w, d.lin_w, d.lin_w, d.lin_w), par + VP_PRED + 512 * q + 256, lane);
         }
+    }
+    if (p.h0) {   // head bias | gain | shift: 256 floats = one instruction each
+        if (w == 0 % nw) lds_dma16(p.head_b + 4 * lane, par + VP_HEADB, lane);
+        if (w == 1 % nw) lds_dma16(p.head_g + 4 * lane, par + VP_HEADG, lane);
+        if (w == 2 % nw) lds_dma16(p.head_beta + 4 * lane, par + VP_HEADBE, lane);
     }
     const float lb0 = p.pred[0].lin_b[0], lb1 = p.pred[1].lin_b[0], lb2 = p.pred[2].lin_b[0];
     const int e_i = lane < DIM - 1 ? lane : DIM - 2;
@@ -410,6 +420,8 @@ __device__ __forceinline__ void enc_va64_body(const FuseVaP& p) {
         }
     }
     // ================================================================ bucketize, embeddings, duration features, durations, outputs
+    int hidx[NTILE][2];            // bucket indices and duration-feature operands for the head
+    f16x2p DF[NTILE][2];
 #pragma unroll
     for (int t = 0; t < NTILE; ++t) {
         pr[2][t] = fmaxf(pr[2][t], 0.0f);
@@ -427,6 +439,7 @@ __device__ __forceinline__ void enc_va64_body(const FuseVaP& p) {
                 for (int e = 0; e < 4; ++e) cnt += e0[e] < v ? 1.0f : 0.0f;
             }
             bidx[q] = (int)row_sum4(cnt);
+            hidx[t][q] = bidx[q];
             if (p.feat) {           // the embedding row: lane group g copies floats [16 g, 16 g + 16) of it
                 const float* row = (q == 0 ? p.pred[0].emb : p.pred[1].emb) + bidx[q] * DIM + 16 * g;
 #pragma unroll
@@ -443,10 +456,12 @@ __device__ __forceinline__ void enc_va64_body(const FuseVaP& p) {
                 df[nt] = cdur[t][nt];
             }
             layernorm<4>(df, gg, bb);
-            if (p.feat) {
 #pragma unroll
-                for (int nt = 0; nt < 4; ++nt) buf_st4(r_feat, frow + (unsigned)((3 * DIM + 16 * nt + 4 * g) * 4), rz[t] ? z4 : df[nt]);
+            for (int nt = 0; nt < 4; ++nt) {
+                if (rz[t]) df[nt] = z4;
+                if (p.feat) buf_st4(r_feat, frow + (unsigned)((3 * DIM + 16 * nt + 4 * g) * 4), df[nt]);
             }
+            if (p.h0) to_bop(df, DF[t], lower);
         }
         float dval = p.dur_t ? (float)__builtin_bit_cast(int, tv_d[t]) : rintf(pr[2][t]);   // torch.round: half to even
         if (p.mask) {                                                                        // networks.py:381-382
@@ -472,6 +487,72 @@ __device__ __forceinline__ void enc_va64_body(const FuseVaP& p) {
         }
         const BufRsrc r_dur = make_rsrc(p.dur + (long)b * p.T, (long)p.T * 4);
         buf_st_i(r_dur, srow, (int)dval);
+    }
+    // ================================================================ decoder head at phoneme rate: h0 = LN(tanh(feat Wp^T + b)), K = fused | pitch emb |
+    // energy emb | duration features (32 channels per step), 256 outputs = 16 tiles of 16; one tile of the wave at a time (its 16 x 4
+    // accumulator registers are what the wave can hold), so the 256 KB of weights stream through the two buffers once per tile
+    if (p.h0) {
+        const BufRsrc r_h0 = make_rsrc(p.h0 + (long)b * p.T * 4 * DIM, (long)p.T * 4 * DIM * 4);
+        const BufRsrc r_ep = make_rsrc(p.pred[0].emb, (long)DIM * DIM * 4), r_ee = make_rsrc(p.pred[1].emb, (long)DIM * DIM * 4);
+        const int lw8 = wlane(lane, 8);
+#pragma unroll
+        for (int t = 0; t < NTILE; ++t) {
+            f32x4 hh[16];
+#pragma unroll
+            for (int nt = 0; nt < 16; ++nt) hh[nt] = z4;
+            f16x2p EM[4];          // the two embedding rows as operands (zero rows for padding phonemes)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const unsigned off = rz[t] ? kBufOOB : (unsigned)(hidx[t][q] * DIM * 4) + gl_lane(lane);
+                EM[2 * q] = global_bop(q == 0 ? r_ep : r_ee, off, 0);
+                EM[2 * q + 1] = global_bop(q == 0 ? r_ep : r_ee, off, 1);
+            }
+#pragma unroll
+            for (int G = 0; G < 8; ++G) {
+                const int k = 9 + 8 * t + G;
+                step_begin(k);
+                const f16x2p op = G < 2 ? F[t][G] : (G < 6 ? EM[G - 2] : DF[t][G - 6]);
+                const float* W = wb[k & 1];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    WFrags<4> wf;
+                    wfrags_load<4, 8, 4>(wf, 0, W + 2 * c * 256, lw8, 0);
+                    f32x4 (&acc4)[4] = *reinterpret_cast<f32x4 (*)[4]>(&hh[4 * c]);
+                    mma_all<4>(acc4, wf, op);
+                }
+            }
+            // bias, tanh, LayerNorm over the 256 channels of the row (two-pass), store
+            float s1 = 0.0f;
+#pragma unroll
+            for (int nt = 0; nt < 16; ++nt) {
+                const f32x4 hb = ld4_lds(par + VP_HEADB + 16 * nt + 4 * g);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    hh[nt][e] = tanh_fast_f32(fmaf(hh[nt][e], kF16WScaleInv, hb[e]));
+                    s1 += hh[nt][e];
+                }
+            }
+            const float mean = row_sum4(s1) * (1.0f / 256.0f);
+            float s2 = 0.0f;
+#pragma unroll
+            for (int nt = 0; nt < 16; ++nt) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    hh[nt][e] -= mean;
+                    s2 = fmaf(hh[nt][e], hh[nt][e], s2);
+                }
+            }
+            const float rstd = rsqrt_fast_f32(row_sum4(s2) * (1.0f / 256.0f) + 1e-5f);
+            const unsigned hrow = rout[t] ? kBufOOB : (unsigned)(pos[t] * 4 * DIM * 4);
+#pragma unroll
+            for (int nt = 0; nt < 16; ++nt) {
+                const f32x4 gg = ld4_lds(par + VP_HEADG + 16 * nt + 4 * g), bb = ld4_lds(par + VP_HEADBE + 16 * nt + 4 * g);
+                f32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = fmaf(hh[nt][e] * rstd, gg[e], bb[e]);
+                buf_st4(r_h0, hrow == kBufOOB ? kBufOOB : hrow + (unsigned)((16 * nt + 4 * g) * 4), o);
+            }
+        }
     }
     if (p.cum) {   // FeatureUpsampler's scan (networks.py:233-244) while the durations are still on the CU; T <= 256 here
         wg_sync_lds();

@@ -482,17 +482,25 @@ static int fuse_variance_adaptor(const esmi_fuse_weights* fw, int depth, int dim
             if (lean && head_in_chain) { q.feat = nullptr; q.preds[0] = q.preds[1] = nullptr; q.pitch_idx = q.energy_idx = nullptr; }
             rc16 = launch_enc_va16(q, dim, kernel, S(stream));
         }
+        bool head_done = head_in_chain;
         if (rc16 == ESMI_ERR_UNSUPPORTED && (plan & ESMI_FUSE_CHAIN16) && !head_in_chain) {
-            // dim = 64, T <= 256 (round 6): one workgroup per utterance, so the length regulator's scan runs inside it
+            // dim = 64, T <= 256 (round 6): one workgroup per utterance, so the length regulator's scan runs inside it -- and the decoder's
+            // phoneme-rate first stage too when the caller wants h0 (4 dim = dx2 = 256, pre-split weights); a lean caller then gets
+            // neither the feature rows nor the pitch / energy outputs written
             FuseVaP q = p;
             q.cum = cum; q.mel_len = mel_len;
+            const bool head64 = h0 && head->proj_wp && head->d4 == 4 * dim && head->dx2 == 4 * dim;
+            if (head64) {
+                q.head_w = head->proj_wp; q.head_b = head->proj_b; q.head_g = head->ln_g; q.head_beta = head->ln_b; q.h0 = h0;
+                if (lean) { q.feat = nullptr; q.preds[0] = q.preds[1] = nullptr; q.pitch_idx = q.energy_idx = nullptr; }
+            }
             rc16 = launch_enc_va64(q, dim, kernel, S(stream));
-            if (rc16 == ESMI_OK) scan_fused = cum != nullptr;
+            if (rc16 == ESMI_OK) { scan_fused = cum != nullptr; head_done = head64; }
         }
         if (rc16 == ESMI_ERR_UNSUPPORTED) rc16 = launch_enc_fuse_va(p, dim, kernel, nw, head_in_chain, S(stream));
         if (rc16) return rc16;
         if (cum && !scan_fused) ESMI_LAUNCH(length_regulate_kernel, dim3(B), dim3(64), 0, S(stream), dur, T, cum, mel_len, (int*)nullptr);
-        if (h0 && !head_in_chain) return esmi_decoder_head_f32(head, (long)B * T, feat, h0, stream);
+        if (h0 && !head_done) return esmi_decoder_head_f32(head, (long)B * T, feat, h0, stream);
         return launch_status();
     }
     if (!workspace || workspace_bytes < esmi_fuse_variance_adaptor_workspace_bytes(B, T, dim, depth)) return ESMI_ERR_WORKSPACE;

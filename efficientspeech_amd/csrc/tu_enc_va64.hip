@@ -15,7 +15,8 @@ namespace esmi {
 // dim = 64, two encoder levels, ConvTranspose kernel 3, one workgroup per utterance (T <= 256); ESMI_ERR_UNSUPPORTED otherwise
 // (-> enc_fuse_va_kernel).  The split-f16 build only: the exact-fp32 library keeps the round-1 kernel.
 bool enc_va64_ok(const FuseVaP& p, int dim, int kernel) {
-    return dim == kVa64Dim && p.depth == 2 && kernel == 3 && p.T >= 1 && p.T <= 32 * kVa64MaxWaves && p.n_i[0] == p.T && !p.h0;
+    return dim == kVa64Dim && p.depth == 2 && kernel == 3 && p.T >= 1 && p.T <= 32 * kVa64MaxWaves && p.n_i[0] == p.T &&
+           (!p.h0 || (p.head_w && p.head_b && p.head_g && p.head_beta));
 }
 
 int launch_enc_va64(const FuseVaP& p, int dim, int kernel, hipStream_t st) {
