@@ -130,24 +130,25 @@ __device__ __forceinline__ f16x2p bnd_read(const unsigned* bnd, int tile, int si
 template <int NTILE>
 __device__ __forceinline__ void conv3(f32x4 (&c)[NTILE][4], const float* W, int lw, const f16x2p (&X)[NTILE][2], const unsigned* bnd, int tile0,
                                       int ntiles, int g) {
-    f16x2p dn[NTILE][2], up[NTILE][2];
-#pragma unroll
-    for (int t = 0; t < NTILE; ++t) {
-        const int tile = tile0 + t;
-#pragma unroll
-        for (int G = 0; G < 2; ++G) {
-            dn[t][G] = rows_dn(X[t][G], bnd_read(bnd, tile - 1, 1, G, g, tile > 0));
-            up[t][G] = rows_up(X[t][G], bnd_read(bnd, tile + 1, 0, G, g, tile + 1 < ntiles));
-        }
-    }
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
+        f16x2p op[NTILE][2];        // the tap's operand rows (shifted one tap at a time: both shifts of both tiles at once are 64 registers)
+#pragma unroll
+        for (int t = 0; t < NTILE; ++t) {
+            const int tile = tile0 + t;
+#pragma unroll
+            for (int G = 0; G < 2; ++G) {
+                if (j == 0) op[t][G] = rows_dn(X[t][G], bnd_read(bnd, tile - 1, 1, G, g, tile > 0));
+                else if (j == 1) op[t][G] = X[t][G];
+                else op[t][G] = rows_up(X[t][G], bnd_read(bnd, tile + 1, 0, G, g, tile + 1 < ntiles));
+            }
+        }
 #pragma unroll
         for (int G = 0; G < 2; ++G) {
             WFrags<4> wf;
             wfrags_load<4, 2, 4>(wf, 0, W + j * (16 * 256), lw, G);
 #pragma unroll
-            for (int t = 0; t < NTILE; ++t) mma_all<4>(c[t], wf, j == 0 ? dn[t][G] : (j == 1 ? X[t][G] : up[t][G]));
+            for (int t = 0; t < NTILE; ++t) mma_all<4>(c[t], wf, op[t][G]);
         }
     }
 }
@@ -235,8 +236,6 @@ __device__ __forceinline__ void enc_va64_body(const FuseVaP& p) {
         if (w == 2 % nw) lds_dma16(p.head_beta + 4 * lane, par + VP_HEADBE, lane);
     }
     const float lb0 = p.pred[0].lin_b[0], lb1 = p.pred[1].lin_b[0], lb2 = p.pred[2].lin_b[0];
-    const int e_i = lane < DIM - 1 ? lane : DIM - 2;
-    const float edge_p = p.pred[0].bins[e_i], edge_e = p.pred[1].bins[e_i];      // bucket edges (dim - 1 of them)
     const BufRsrc r_mask = make_rsrc(p.mask ? p.mask + (long)b * p.T : nullptr, p.T);
     const BufRsrc r_feat = make_rsrc(p.feat ? p.feat + (long)b * p.T * 4 * DIM : nullptr, (long)p.T * 4 * DIM * 4);
     const BufRsrc r_pt = make_rsrc(p.pitch_t ? p.pitch_t + (long)b * p.T : nullptr, (long)p.T * 4);
@@ -254,8 +253,8 @@ __device__ __forceinline__ void enc_va64_body(const FuseVaP& p) {
         pos[t] = 16 * (tile0 + t) + i;
         rout[t] = pos[t] >= p.T;
         rz[t] = !rout[t] && buf_ld_u8(r_mask, (unsigned)pos[t]) != 0;
-        const unsigned trow = rout[t] ? kBufOOB : (unsigned)(pos[t] * 4);
-        tv_p[t] = buf_ld(r_pt, trow); tv_e[t] = buf_ld(r_et, trow); tv_d[t] = buf_ld(r_dt, trow);
+        tv_p[t] = tv_e[t] = tv_d[t] = 0.0f;      // (the teacher values are requested two steps before their use, below: nine steps of life
+                                                 // for six registers is what the two-tile instantiation spilled)
         const unsigned o0 = rout[t] ? kBufOOB : (unsigned)(pos[t] * DIM * 4) + gl_lane(lane);
         const int na = pos[t] >> 1;
         na_ok[t] = !rout[t] && na < n1;
@@ -269,10 +268,6 @@ __device__ __forceinline__ void enc_va64_body(const FuseVaP& p) {
     // ================================================================ step 0: Linear of level 0; Linear of level 1 on row n = pos >> 1 (every level-1 row
     // is computed by the two positions it feeds: the transposed convolution below then needs no gather)
     step_begin(0);
-    if (w == 0) {   // bucket edges, +inf behind the dim - 1 of them (read eight barriers later)
-        par[VP_EDGE + lane] = lane < DIM - 1 ? edge_p : INFINITY;
-        par[VP_EDGE + 64 + lane] = lane < DIM - 1 ? edge_e : INFINITY;
-    }
     f16x2p C0[NTILE][2], Ya[NTILE][2];
     {
         f32x4 a0[NTILE][4], aa[NTILE][4];
@@ -282,16 +277,21 @@ __device__ __forceinline__ void enc_va64_body(const FuseVaP& p) {
             for (int nt = 0; nt < 4; ++nt) { a0[t][nt] = z4; aa[t][nt] = z4; }
         }
         gemm_tiles<NTILE, 2>(a0, wb[0], lw, 0, X0);
+#pragma unroll
+        for (int t = 0; t < NTILE; ++t) {
+            f32x4 v0[4];
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) v0[nt] = fmaf4(a0[t][nt], kF16WScaleInv, ld4_lds(par + VP_MLPB0 + 16 * nt + 4 * g));
+            to_bop(v0, C0[t], lower);
+        }
+        sched_fence();    // (level 0 is through before level 1 starts: both at once is what the two-tile instantiation cannot hold)
         gemm_tiles<NTILE, 4>(aa, wb[0] + 16 * 256, lw, 0, Xa);
 #pragma unroll
         for (int t = 0; t < NTILE; ++t) {
-            f32x4 v0[4], va[4];
+            f32x4 va[4];
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt) {
-                v0[nt] = fmaf4(a0[t][nt], kF16WScaleInv, ld4_lds(par + VP_MLPB0 + 16 * nt + 4 * g));
+            for (int nt = 0; nt < 4; ++nt)
                 va[nt] = na_ok[t] ? fmaf4(aa[t][nt], kF16WScaleInv, ld4_lds(par + VP_MLPB1 + 16 * nt + 4 * g)) : z4;   // rows that do not exist contribute nothing
-            }
-            to_bop(v0, C0[t], lower);
             to_bop(va, Ya[t], lower);
         }
         bnd_publish<NTILE>(bndH, tile0, i, g, Ya);    // (the hidden rows' exchange buffer is free until step 3)
@@ -299,7 +299,13 @@ __device__ __forceinline__ void enc_va64_body(const FuseVaP& p) {
     // ================================================================ step 1: ConvTranspose1d(stride 2, k = 3), cropped to T:
     // out[pos] = W_0 y1[pos/2] + W_2 y1[pos/2 - 1] (pos even) | W_1 y1[(pos-1)/2] (pos odd); a tap that does not apply gets a zero operand.
     // y1[pos/2 - 1] of an even position is what the position above it computed (its n is (pos - 1) >> 1): one row shift.
+    const int e_i = lane < DIM - 1 ? lane : DIM - 2;
+    const float edge_p = p.pred[0].bins[e_i], edge_e = p.pred[1].bins[e_i];      // bucket edges (dim - 1 of them), requested across the barrier
     step_begin(1);
+    if (w == 0) {   // ... and written with +inf behind them (read seven barriers later)
+        par[VP_EDGE + lane] = lane < DIM - 1 ? edge_p : INFINITY;
+        par[VP_EDGE + 64 + lane] = lane < DIM - 1 ? edge_e : INFINITY;
+    }
     f16x2p C1[NTILE][2];
     {
         f32x4 u[NTILE][4];
@@ -370,6 +376,13 @@ __device__ __forceinline__ void enc_va64_body(const FuseVaP& p) {
     for (int q = 0; q < 3; ++q) {
         const float* pv = par + VP_PRED + 512 * q;
         f16x2p H[NTILE][2];
+        if (q == 2) {
+#pragma unroll
+            for (int t = 0; t < NTILE; ++t) {
+                const unsigned trow = rout[t] ? kBufOOB : (unsigned)(pos[t] * 4);
+                tv_p[t] = buf_ld(r_pt, trow); tv_e[t] = buf_ld(r_et, trow); tv_d[t] = buf_ld(r_dt, trow);
+            }
+        }
         step_begin(3 + 2 * q);
         {
             f32x4 c[NTILE][4];

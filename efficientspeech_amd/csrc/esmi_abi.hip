@@ -858,12 +858,13 @@ int fwd_arena(const esmi_forward_args* a, FwdArena* o) {
 }  // namespace
 
 // The decoder re-uses the encoder side's scratch for its carried rows (dx2 = 256 chunk walk).  When that scratch is too small for a
-// batch (few utterances, long output) and the caller knew the output length at sizing time (L_out > 0), the arena carries a tail
-// region for them behind everything else -- the layout of the other regions never depends on L_out, so a stage-2 call with the
-// length filled in later sees the same offsets.  With L_out unknown at sizing time a long batch runs the decoder's window form.
+// batch (few utterances, long output) the arena carries a tail region for them behind everything else -- the layout of the other
+// regions never depends on L_out, so a stage-2 call with the length filled in later sees the same offsets.
 static size_t fwd_dec_tail(const esmi_forward_args* a, const FwdArena& o) {
-    if (a->L_out <= 0) return 0;
-    const size_t need = esmi_mel_decoder_workspace_bytes(&a->dec_shape, a->B, a->L_out);
+    // (L_out unknown at sizing time -- the reference's own call style: stage 1, host sync, stage 2 -- : the need of an arbitrarily long
+    // output, which is bounded: the segmentation never uses more workgroups than max(B, one per CU).  Both call styles then run the same
+    // decoder form)
+    const size_t need = esmi_mel_decoder_workspace_bytes(&a->dec_shape, a->B, a->L_out > 0 ? a->L_out : -1);
     return need > o.feat - o.ws ? align256(need) : 0;
 }
 size_t esmi_forward_arena_bytes(const esmi_forward_args* a) {

@@ -109,7 +109,12 @@ __device__ __forceinline__ f32x4 lrelu4(const f32x4& v, float slope) {   // 0 <=
     return o;
 }
 
-constexpr int kRbWps = 4;   // waves per SIMD the kernels are compiled for: 4 = two 8-wave workgroups per CU (128 VGPRs); 6 / 8 spill (4.1 / 5.2 vs 3.7 ms)
+#ifndef ESMI_RB_WPS     // (A/B knob; the product value is below)
+#define ESMI_RB_WPS 3
+#endif
+constexpr int kRbWps = ESMI_RB_WPS;   // waves per SIMD the kernels are compiled for.  3 (round 6): 155-164 VGPRs, NO scratch, one 8-wave workgroup per CU:
+                                      // 7.13-7.19 ms for the v2 generator at B = 32 against 7.27-7.29 ms at 4 (128 VGPRs, 88-116 B of scratch per lane, two
+                                      // workgroups per CU) and 7.14-7.20 at 2 -- profiles/r06_probes/vocoder_wps.md; 6 / 8 spill more (4.1 / 5.2 vs 3.7 ms, round 2)
 constexpr int kRbPd = 1;    // weight fragments are fetched this many k-steps ahead (deeper: spills at 128 VGPRs, 4.0-4.9 ms)
 
 template <int C, int K>

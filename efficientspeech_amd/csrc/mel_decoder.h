@@ -351,7 +351,7 @@ __global__ __launch_bounds__(64 * NW, (DX2 <= 128 ? kDecWps128 : NW / 4)) void m
     constexpr bool STREAM = DX2 > 128;
     // STREAM: the k/2 input rows of every conv layer in front of the next chunk are carried: in LDS behind the tile (`carry_lds_layers`
     // slots), else in a global scratch row set of this workgroup (written and read back by the same thread, one chunk apart: no fence)
-    float* const cws = STREAM && p.carry_ws ? p.carry_ws + (long)blockIdx.x * p.ws_stride : nullptr;
+    float* const cws = STREAM && p.carry_ws ? p.carry_ws + ((long)seg * p.B + b) * p.ws_stride : nullptr;
     float* const cbuf = reinterpret_cast<float*>(src + kDecRows);     // [carry_lds_layers][PAD][DX2]
     float cnext = 0.0f;                      // the carried element of the NEXT conv layer, requested one phase ahead
     // BLOCK SKEW (round 6).  Inside a block the tile's rows keep their frames (the skip tensor lives in the row owners' registers), so
@@ -1048,8 +1048,8 @@ __global__ __launch_bounds__(64 * NW, (DX2 <= 128 ? kDecWps128 : NW / 4)) void m
     // ---- mel Linear(dx2, n_mel) on skip (held in the tile), masked store
     if constexpr (!STREAM) {   // clock probe, second stamp of the one-chunk kernel: the first workgroup again, in front of its last stage
         long long* const clk = g_dec_clk;     // (s_memtime counters of different CUs are not comparable: both stamps come from one workgroup)
-        if (clk && blockIdx.x == 0) {         // every thread of the workgroup stores (a wave's pair in one 16-byte store): a test for one
-            typedef long long i64x2 __attribute__((ext_vector_type(2)));   // thread would keep a lane register alive across the layers
+        if (clk && blockIdx.x == 0 && w == 0) {   // one wave stores (its 64 lanes write the same 16 bytes: the wave id is a scalar register,
+            typedef long long i64x2 __attribute__((ext_vector_type(2)));   // a test for one THREAD would keep a lane register alive across the layers)
             *reinterpret_cast<i64x2*>(clk + 2) = i64x2{clock_shader(), clock_real100()};
         }
     }

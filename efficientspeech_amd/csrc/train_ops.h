@@ -685,9 +685,11 @@ __device__ __forceinline__ float ln_wave_sum(float v) {
 }
 // res != NULL: the normalised tensor is x + res, written to `xsum` for the backward (LN(f(x) + x), networks.py:75,83,301);
 // rowmask[r] != 0: the output row is zero (masked_fill after the norm, networks.py:76,84) -- the backward kernels take the same mask
-static __global__ __launch_bounds__(256) void train_ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ g,
+// (x and y are NOT __restrict__: the two-launch conv + LayerNorm fallback of train.py runs the norm in place, x == y; every lane reads
+// its elements of a row before it writes them)
+static __global__ __launch_bounds__(256) void train_ln_fwd_kernel(const float* x, const float* __restrict__ g,
                                                            const float* __restrict__ b, long rows, int C, float eps,
-                                                           float* __restrict__ y, float* __restrict__ mean, float* __restrict__ rstd,
+                                                           float* y, float* __restrict__ mean, float* __restrict__ rstd,
                                                            const float* __restrict__ res, float* __restrict__ xsum,
                                                            const unsigned char* __restrict__ rowmask, int relu_out) {
     const long r = (long)blockIdx.x * 4 + wave_id();
@@ -715,9 +717,9 @@ static __global__ __launch_bounds__(256) void train_ln_fwd_kernel(const float* _
 // The same for C = 4 LPR in {32, 64, 128, 256} on 16-byte aligned tensors: LPR lanes per row hold the row in registers (one read of
 // x instead of three, 16-byte accesses), 64 / LPR rows per wave.  (The scalar form moves 78 MB in 30 us at B = 128.)
 template <int LPR>
-static __global__ __launch_bounds__(256) void train_ln_fwd4_kernel(const float* __restrict__ x, const float* __restrict__ g,
+static __global__ __launch_bounds__(256) void train_ln_fwd4_kernel(const float* x, const float* __restrict__ g,
                                                             const float* __restrict__ b, long rows, float eps,
-                                                            float* __restrict__ y, float* __restrict__ mean, float* __restrict__ rstd,
+                                                            float* y, float* __restrict__ mean, float* __restrict__ rstd,
                                                             const float* __restrict__ res, float* __restrict__ xsum,
                                                             const unsigned char* __restrict__ rowmask, int relu_out) {
     constexpr int RPW = 64 / LPR, C = 4 * LPR;

@@ -135,10 +135,17 @@ static int stream_ws_stride(const esmi_decoder_shape* s) {
 }
 
 size_t esmi_mel_decoder_workspace_bytes(const esmi_decoder_shape* s, int B, int L_out) {
-    if (dec_check(s) || s->dx2 != 256 || B <= 0 || L_out <= 0) return 0;
+    if (dec_check(s) || s->dx2 != 256 || B <= 0 || L_out == 0) return 0;
     int n_seg, seg_len;
-    stream_geometry(s, B, L_out, &n_seg, &seg_len);
-    return (size_t)n_seg * ((B + 7) / 8) * 8 * stream_ws_stride(s) * sizeof(float);
+    if (L_out < 0) {
+        // any output length (the caller sizes its scratch before the length is known): the segmentation aims at max(B, one workgroup
+        // per CU) segments and its rounding (whole chunks per segment, the rows a later segment recomputes) stays below 1.15x that
+        stream_geometry(s, B, 1 << 20, &n_seg, &seg_len);
+        n_seg = n_seg + n_seg / 4 + 1;
+    } else {
+        stream_geometry(s, B, L_out, &n_seg, &seg_len);
+    }
+    return (size_t)n_seg * B * stream_ws_stride(s) * sizeof(float);   // one row set per (segment, utterance)
 }
 
 static int mel_decoder_launch(const float* blob, const esmi_decoder_shape* s, const float* x, const float* h0,

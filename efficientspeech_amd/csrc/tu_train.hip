@@ -123,6 +123,9 @@ int train_conv_gemm(const ConvDesc& c, bool grad, const float* in, const float* 
                     const ConvLnArgs* ln = nullptr) {
     const GemmWeight g = gemm_weight(c, grad);
     if (!g.ok || !wt) return ESMI_ERR_UNSUPPORTED;
+    // (the fused conv + LayerNorm epilogue exists for 32 / 64 / 128 output channels: refuse BEFORE anything is enqueued -- the caller's
+    // two-launch fallback then packs once, not twice)
+    if (ln && g.cout != 32 && g.cout != 64 && g.cout != 128) return ESMI_ERR_UNSUPPORTED;
     const int cin = g.cin, cout = g.cout, as_convT = g.as_convT;
     const bool as_flipped_conv = g.flipped;
     const long n = (long)c.k * c.c_out * c.c_in;
@@ -153,7 +156,6 @@ int train_conv_gemm(const ConvDesc& c, bool grad, const float* in, const float* 
     p.act = act;
     p.pw_ok = 1;
     if (ln) {   // act(conv + bias) + res -> LayerNorm (+ ReLU, + row mask) in the GEMM's epilogue; the pre-norm tensor, mean, rstd kept
-        if (cout != 32 && cout != 64 && cout != 128) return ESMI_ERR_UNSUPPORTED;   // (256: convgemm_epilogue compiles the fused form for NT <= 4 only)
         p.res = ln->res; p.ldr = cout; p.r_coff = 0;
         p.ln_g = ln->g; p.ln_b = ln->b; p.rowmask = ln->rowmask; p.post_relu = ln->relu_out;
         p.ln_pre = ln->pre; p.ln_mean = ln->mean; p.ln_rstd = ln->rstd;

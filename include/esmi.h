@@ -384,12 +384,16 @@ int esmi_mel_decoder_f32(const float* blob, const esmi_decoder_shape* s, const f
                          void* workspace, size_t workspace_bytes, /* esmi_mel_decoder_workspace_bytes, or NULL / 0: dx2 = 256 then
                                                                      recomputes both halos of every 128-frame window (slower) */
                          esmi_stream_t stream);
-/* scratch for the dx2 = 256 kernel's carried rows (a workgroup walks its share of an utterance chunk by chunk; 0 for dx2 = 128) */
+/* scratch for the dx2 = 256 kernel's carried rows (a workgroup walks its share of an utterance chunk by chunk; 0 for dx2 = 128).
+ * L_out < 0: an upper bound for ANY output length (for callers that size their scratch before the length is known).             */
 size_t esmi_mel_decoder_workspace_bytes(const esmi_decoder_shape* s, int B, int L_out);
 /* Measurement aid (bench.py `roofline.clock`), not part of the data path: arm (dev_slots != NULL: 4 int64 in device memory) or disarm
  * (NULL) a probe that the FIRST workgroup of every following esmi_mel_decoder_f32 launch fills with {shader clock, 100 MHz clock} read
  * when it starts (slots 0, 1) and when it starts its last chunk / its last stage (slots 2, 3): (shader ticks / 100 MHz ticks) x 100 MHz
- * is the clock the CU ran the kernel at, which `roofline.peak` (quoted at 2.4 GHz) has to be scaled by.  Process-wide.             */
+ * is the clock the CU ran the kernel at, which `roofline.peak` (quoted at 2.4 GHz) has to be scaled by.
+ * Contract: the ONE piece of state the library keeps (a device global per decoder translation unit).  It is set on the CURRENT device
+ * only (single-device processes; a multi-GPU process arms it per device under hipSetDevice), it is process-wide (not per stream), and
+ * the caller MUST disarm it (NULL) before freeing the slots -- an armed probe makes every decoder launch store through the pointer.  */
 int esmi_mel_decoder_clock_probe(int64_t* dev_slots);
 /* ------------------------------------------------------------------ whole inference forward in ONE call
  * Phoneme2Mel.forward (eval), layers/networks.py:415-434 = Encoder blocks -> Fuse + variance adaptor (+ length-regulator scan,

@@ -59,6 +59,7 @@ def test_simulated_unfused_path_matches_golden(path, nets):
 @pytest.mark.parametrize("name,B,T,lens", [
     ("tiny", 3, 70, [70, 41, 9]),        # 3 row tiles; 70 / 35 keys; multi-window decoder (L > 112)
     ("small", 2, 40, [40, 23]),
+    ("small", 2, 150, [150, 97]),        # round 6: enc_va64_kernel<2> (two 16-row tiles per wave, head inside) + enc_post_attn64_kernel<2>
 ])
 def test_simulated_eval_vs_oracle_multi_tile(name, B, T, lens, nets):
     net, cfg, sd = nets(name)
