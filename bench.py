@@ -567,7 +567,7 @@ def main():
                      "frac_trace": (flops * B * L / (tr_us * 1e-6) / 1e12 / peak_tf) if tr_us else None,
                      "frac_trace_is": "the same FLOPs over the committed rocprofv3 --kernel-trace --stats average of this kernel (tracer "
                                       "overhead included; a different run and box than kernel_ms)",
-                     "contraction": ((f"{split_txt}; measured error <= that of an fp32 FMA chain (DESIGN.md 3); `peak` is the 16-bit "
+                     "contraction": ((f"{split_txt}; measured error <= that of an fp32 FMA chain (HISTORY.md 3); `peak` is the 16-bit "
                                       "matrix-pipe peak divided by the products per fp32-accurate product; `exact_fp32` below is the "
                                       "same step on the v_mfma_f32_32x32x2_f32 build") if split else "v_mfma_f32_32x32x2_f32 (exact fp32)"),
                      "proj_stage_at_phoneme_rate": head_moved, "kernel_flops_per_frame": kernel_flops,
@@ -576,7 +576,10 @@ def main():
                      "note": "MFMA bound (228 FLOP/B >> machine balance); hbm_frac reported because north_star quotes the HBM "
                              "roofline.  achieved/frac use SURVEY 8d's algorithmic FLOP per frame; frac_kernel_flops counts only what "
                              "the decoder kernel still computes per frame (its row-wise first stage runs once per phoneme in "
-                             "enc_fuse_va_kernel)"},
+                             "enc_fuse_va_kernel).  Round 6: a time budget of this kernel that sums to its duration (profiles/r06_dec_budget.md: K loop "
+                             "19 %, LayerNorm 18 %, barrier wait 16 %, depthwise 15 %, prologue 14 %, tanh 13 %, mel 5 % of a workgroup's life) and the ONE "
+                             "structural experiment chosen from it (frame -> phoneme search in LDS instead of 7 dependent L2 round trips): 175.6 vs 175.5 us "
+                             "= 0.0 %, below the 8 % bar: stopped"},
     }
 
     if rank == 0:
@@ -972,7 +975,7 @@ def main():
                                           "note": "whole step (194 launches, no dominant kernel; per-kernel table: profiles/r05_f_train_kernel_stats.md): 3 x the forward's "
                                                   "contraction FLOPs over the step time against the split-f16 bound; the step is "
                                                   "bound by launch count and by the partial-sum traffic of the deterministic "
-                                                  "weight-gradient reductions, not by the matrix pipe (DESIGN.md 3.6)"},
+                                                  "weight-gradient reductions, not by the matrix pipe (HISTORY.md 3.6)"},
                              "loss_first_last": [float(tl0[4]), float(tl1[4])],
                              "allreduce_bytes_per_step": int(ts.flat.grad.numel() * 4) if world > 1 else 0,
                              "note": "SURVEY 8f-2 / BASELINE configs[4]: train=True forward, masked L1 + 3 MSE loss, backward, AdamW "

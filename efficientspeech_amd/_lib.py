@@ -302,8 +302,25 @@ def load():
         if lib.esmi_backend().decode() != "hip:gfx950":    # (tests bind the wave simulator through bind(), never through here)
             raise RuntimeError(f"{LIB_PATH} reports backend {lib.esmi_backend().decode()!r}: the product path only runs the HIP "
                                "build for gfx950 (no CPU / simulator fallback)")
+        _check_toolchain(lib)
         _LIB = lib
     return _LIB
+
+
+# the HIP / clang version the compiler work-arounds inside the chain kernels were validated on (esmi_build_config, esmi_abi.hip)
+VALIDATED_HIP = "7.2"
+
+
+def _check_toolchain(lib):
+    """Warn (once, at load) when the library was built by another ROCm release than the one its two compiler work-arounds were validated
+    on: the parity tests (`pytest -m gpu`) and `ESMI_DEBUG_RANGE=1` are the check to run on a new toolchain."""
+    cfg = lib.esmi_build_config().decode()
+    hip = next((f[4:] for f in cfg.split(",") if f.startswith("hip=")), None)
+    if hip is not None and not hip.startswith(VALIDATED_HIP + "."):
+        import warnings
+        warnings.warn(f"libesmi.so was built with HIP {hip}; the encoder-side chain kernels carry two compiler work-arounds validated on "
+                      f"ROCm {VALIDATED_HIP} (csrc/chain16.h, profiles/r05_probes/fuse_va_wrong_rows.md): run `pytest tests -m gpu` on this "
+                      "toolchain before trusting the output", RuntimeWarning, stacklevel=3)
 
 
 @contextlib.contextmanager

@@ -31,17 +31,7 @@ namespace c16 {
 
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
-// lane l <- lane l ^ 16 (VALU only: v_permlane16_swap, gfx950).  The select form: ROCm 7.2 folds `swap(x, x); a + b` of the builtin's
-// two results into x + x (profiles/r04_probes/chain_layernorm_round4.md); selecting one result per lane compiles correctly.
-__device__ __forceinline__ float swap16_f(float v) {
-#ifdef ESMI_WAVESIM
-    return wavesim::shfl(v, lane_id_raw() ^ 16);
-#else
-    const unsigned x = __builtin_bit_cast(unsigned, v);
-    const auto r = __builtin_amdgcn_permlane16_swap(x, x, false, false);   // r[0]: odd rows <- the even rows below them; r[1]: even rows <- the odd rows above
-    return __builtin_bit_cast(float, (lane_id_raw() & 16) ? r[0] : r[1]);
-#endif
-}
+// (swap16_f -- lane l <- lane l ^ 16, v_permlane16_swap -- lives in wavesim_shim.h with the other target-specific primitives)
 // sum over the four lanes that hold one row (lanes i, i + 16, i + 32, i + 48); every lane ends with the same bits
 __device__ __forceinline__ float row_sum4(float v) {
     v += swap16_f(v);

@@ -52,26 +52,8 @@ enum { VP_MLPB0 = 0, VP_MLPB1 = 64, VP_UPB1 = 128, VP_FUSEB = 192, VP_LN2G = 256
 namespace va64 {
 using namespace c16;
 
-// rows one down / one up inside the 16 lanes that hold a tile's rows for one g: lane (i, g) <- lane (i -+ 1, g); the lane at the tile's
-// edge takes `edge` (the neighbouring tile's row, or zero outside the sequence).  v_mov_b32_dpp row_shr:1 / row_shl:1, bound_ctrl off.
-__device__ __forceinline__ unsigned row_dn_u(unsigned v, unsigned edge) {
-#ifdef ESMI_WAVESIM
-    const int l = lane_id_raw();
-    const unsigned s = (unsigned)wavesim::shfl_i((int)v, (l & 15) ? l - 1 : l);
-    return (l & 15) ? s : edge;
-#else
-    return (unsigned)__builtin_amdgcn_update_dpp((int)edge, (int)v, 0x111, 0xF, 0xF, false);
-#endif
-}
-__device__ __forceinline__ unsigned row_up_u(unsigned v, unsigned edge) {
-#ifdef ESMI_WAVESIM
-    const int l = lane_id_raw();
-    const unsigned s = (unsigned)wavesim::shfl_i((int)v, (l & 15) != 15 ? l + 1 : l);
-    return (l & 15) != 15 ? s : edge;
-#else
-    return (unsigned)__builtin_amdgcn_update_dpp((int)edge, (int)v, 0x101, 0xF, 0xF, false);
-#endif
-}
+// rows one down / one up inside the 16 lanes that hold a tile's rows for one g (row_dn_u / row_up_u, wavesim_shim.h): the lane at the
+// tile's edge takes `edge` (the neighbouring tile's row, or zero outside the sequence)
 __device__ __forceinline__ f16x2p rows_dn(const f16x2p& x, const f16x2p& edge) {
     f16x2p o;
 #pragma unroll

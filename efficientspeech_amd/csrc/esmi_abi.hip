@@ -79,10 +79,25 @@ const char* esmi_build_config(void) {
 #else
 #define ESMI_CFG_RC_ ""
 #endif
-#if ESMI_DEC_SPLIT == 2
-    return "dec_gemm=split-f16x2" ESMI_CFG_ENC_ ESMI_CFG_RC_;
+    // ... and the compiler the library was built with: two of the chain kernels' forms are work-arounds validated on ROCm 7.2.0's hipcc
+    // (chain16.h swap16_f: the select form of v_permlane16_swap; the DPP / ds_swizzle scheduling fence of the fallback LayerNorm,
+    // profiles/r05_probes/fuse_va_wrong_rows.md) -- _lib.load() warns when this differs from the validated version
+#define ESMI_STR2_(x) #x
+#define ESMI_STR_(x) ESMI_STR2_(x)
+#if defined(__clang_major__)
+#define ESMI_CFG_CC_ ",clang=" ESMI_STR_(__clang_major__) "." ESMI_STR_(__clang_minor__) "." ESMI_STR_(__clang_patchlevel__)
 #else
-    return "dec_gemm=fp32-mfma" ESMI_CFG_ENC_ ESMI_CFG_RC_;
+#define ESMI_CFG_CC_ ""
+#endif
+#if defined(HIP_VERSION_MAJOR)
+#define ESMI_CFG_HIP_ ",hip=" ESMI_STR_(HIP_VERSION_MAJOR) "." ESMI_STR_(HIP_VERSION_MINOR) "." ESMI_STR_(HIP_VERSION_PATCH)
+#else
+#define ESMI_CFG_HIP_ ""
+#endif
+#if ESMI_DEC_SPLIT == 2
+    return "dec_gemm=split-f16x2" ESMI_CFG_ENC_ ESMI_CFG_RC_ ESMI_CFG_HIP_ ESMI_CFG_CC_;
+#else
+    return "dec_gemm=fp32-mfma" ESMI_CFG_ENC_ ESMI_CFG_RC_ ESMI_CFG_HIP_ ESMI_CFG_CC_;
 #endif
 }
 
@@ -182,7 +197,7 @@ int esmi_encoder_block_f32(const esmi_encoder_block_weights* w, const esmi_encod
     const bool fused2 = packed && (plan & ESMI_FUSE_ATTN_FFN) && enc_attn_ffn_supported(C, n, s->expansion);
     float* x_mid = fused2 ? y1 : x_out;
     // one-kernel-per-op attention with folded weights (esmi.h): the Linear behind the merge convs is x M (h*C wide) instead of qkv
-    const bool folded = !fused2 && h >= 2 && w->qk_w && w->qk_wp && w->vo_w && w->vo_wp;   // (one head: measured no gain per op)
+    const bool folded = !fused2 && h >= 2 && w->qk_w && w->qk_wp && w->vo_w && w->vo_wp;   // (one head: measured no gain per op; HISTORY.md 3.3)
     const int nq = folded ? h * C : 3 * h * C;
     EncMergeP m;
     memset(&m, 0, sizeof m);

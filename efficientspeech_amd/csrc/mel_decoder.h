@@ -45,7 +45,7 @@
 #if ESMI_DEC_SPLIT != 0 && ESMI_DEC_SPLIT != 2
 #error "ESMI_DEC_SPLIT must be 0 (fp32 MFMA) or 2 (split f16x2)"
 #endif
-// Fixed choices (each the measured best on MI355X; the alternatives and their times are in DESIGN.md 3.1, not in the build):
+// Fixed choices (each the measured best on MI355X; the alternatives and their times are in HISTORY.md 3.1, not in the build):
 //  * dx2 = 128: 4 waves per SIMD (128 VGPRs, two workgroups per CU); weight slices of 4 k-steps (split build) / 8 (fp32 build) loaded then
 //    used, no hand-pipelined ring (a ring measured 169 -> 172 / 174 us: the neighbour workgroup already fills the L2 round trips);
 //  * dx2 = 256 (one workgroup per CU, nobody fills the gaps): the K loop's weight fragments run 2 steps ahead in a VGPR ring
@@ -198,19 +198,8 @@ struct MelDecP {
 };
 // measurement aid (esmi_mel_decoder_clock_probe, include/esmi.h): two {shader clock, 100 MHz clock} stamps per launch, see the chunk
 // loop.  A device global per translation unit (like the range flag), not a kernel argument: the kernel is at its register limit.
-#ifdef ESMI_WAVESIM
-static long long* g_dec_clk = nullptr;
-#else
-static __device__ long long* g_dec_clk = nullptr;
-#endif
-static inline int store_dec_clock_pointer(long long* slots) {
-#ifdef ESMI_WAVESIM
-    g_dec_clk = slots;
-    return 0;
-#else
-    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_dec_clk), &slots, sizeof(slots));
-#endif
-}
+ESMI_DEVICE_GLOBAL_PTR(long long, g_dec_clk);
+static inline int store_dec_clock_pointer(long long* slots) { return ESMI_STORE_DEVICE_GLOBAL_PTR(g_dec_clk, slots); }
 
 // block skew: a block boundary hands (block_depth + 1) * k/2 rows of dx2 floats to the next chunk, one float4 per thread
 constexpr int kDecBlockCarry4 = 512;

@@ -10,7 +10,7 @@ namespace esmi {
 int set_dec_clock_128_5(long long* slots) { return store_dec_clock_pointer(slots); }
 
 int launch_mel_decoder_128_5(const MelDecP& p, dim3 grid, hipStream_t st) {
-    constexpr int DX2 = 128, KD = 5, NW = 8;   // waves per window (16 for dx2 = 256 measured 30 % slower: DESIGN.md 3.1)
+    constexpr int DX2 = 128, KD = 5, NW = 8;   // waves per window (16 for dx2 = 256 measured 30 % slower: HISTORY.md 3.1)
     const int lds = (dec_lds_floats<DX2>(KD) + p.carry_lds_layers * (KD / 2) * DX2) * (int)sizeof(float);
     static AttrOnce once;
     if (int rc = raise_lds_limit(reinterpret_cast<const void*>(mel_decoder_kernel<DX2, KD, NW>), once)) return rc;

@@ -1,8 +1,5 @@
 // esmi C-ABI, translation unit "tu_enc_va64.hip": the round-6 Fuse + variance-adaptor kernel of dim = 64 models (enc_va64.h: activations
 // in registers from the input rows to the stored features, LDS for the weights).  Internal launchers are declared in launch.h.
-#include <cstdio>
-#include <cstdlib>
-
 #include "launch.h"
 #include "enc_va64.h"
 #include "enc_ffn64.h"
@@ -22,9 +19,6 @@ bool enc_va64_ok(const FuseVaP& p, int dim, int kernel) {
 int launch_enc_va64(const FuseVaP& p, int dim, int kernel, hipStream_t st) {
 #if ESMI_CHAIN_SPLIT
     if (!enc_va64_ok(p, dim, kernel)) return ESMI_ERR_UNSUPPORTED;
-#ifdef ESMI_WAVESIM
-    if (getenv("ESMI_SIM_TRACE_LAUNCH")) fprintf(stderr, "[sim] enc_va64_kernel<%d> B=%d T=%d\n", p.T <= 16 * kVa64MaxWaves ? 1 : 2, p.B, p.T);
-#endif
     if (p.T <= 16 * kVa64MaxWaves) {      // one 16-row tile per wave
         static AttrOnce once;
         if (int rc = raise_lds_limit(reinterpret_cast<const void*>(enc_va64_kernel<1>), once)) return rc;

@@ -57,7 +57,7 @@ __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
 // An fp32 value is split EXACTLY into three bf16 pieces by truncation: x = hi + mid + lo, 8 + 8 + 8 mantissa bits.  The
 // product of two bf16 values is exact in fp32, so  a.b ~= hi.hi + hi.mid + mid.hi + mid.mid + hi.lo + lo.hi  (the dropped
 // terms are below 2^-24 relative) accumulated in fp32 by v_mfma_f32_32x32x16_bf16 is as accurate as an fp32 FMA chain:
-// measured on K = 128 dot products, max error 3.0e-6 vs 8.5e-6 for sequential fp32 accumulation.
+// measured on K = 128 dot products, max error 3.0e-6 vs 8.5e-6 for sequential fp32 accumulation (HISTORY.md 3.1).
 //   A[i = lane&31][k = 8*(lane>>5) + (0..7)],  B[k = 8*(lane>>5) + (0..7)][j = lane&31]   (8 bf16 = 4 dwords per lane)
 //   D as for the 32x32x2 fp32 MFMA
 __device__ __forceinline__ unsigned pack_hi16(unsigned even, unsigned odd) {   // {odd[31:16], even[31:16]}
@@ -79,7 +79,7 @@ __device__ __forceinline__ f32x16 mfma32_bf16(const u32x4& a, const u32x4& b, f3
 // bits; h1 by round-toward-zero so the residual x - h1 is exact), weights pre-scaled by 2^8 and pre-split the same way
 // (round to nearest), a.w ~= h1.w1 + h1.w2 + h2.w1: the dropped h2.w2 term and the pieces' rounding are ~2^-22 relative,
 // below the fp32 accumulation error of a K >= 32 contraction (numpy emulation, K = 128: max error 0.8-3.2e-6 vs 1.4-4.6e-6
-// for sequential fp32 accumulation).  Operands must be inside the binary16 range: |a| < 65504 and
+// for sequential fp32 accumulation, HISTORY.md 3.1).  Operands must be inside the binary16 range: |a| < 65504 and
 // |w| < 255 (2^8 scale keeps the second piece of weights down to 5e-4 a normal number; smaller ones lose nothing that
 // matters: absolute error < 2.4e-10 per weight).  Layout as for v_mfma_f32_32x32x16_bf16.
 // ---- activation-range check (the `libesmi_checked.so` build, -DESMI_RANGE_CHECK=1): the split-f16 contractions need their operands
@@ -265,6 +265,46 @@ __device__ __forceinline__ float swap32_f(float v) {     // lane l <- lane l^32,
     return __builtin_bit_cast(float, lane_id_raw() < 32 ? r[1] : r[0]);
 #endif
 }
+
+// lane l <- lane l ^ 16 (VALU only: v_permlane16_swap, gfx950).  The select form: ROCm 7.2 folds `swap(x, x); a + b` of the builtin's
+// two results into x + x (profiles/r04_probes/chain_layernorm_round4.md); selecting one result per lane compiles correctly.
+__device__ __forceinline__ float swap16_f(float v) {
+#ifdef ESMI_WAVESIM
+    return wavesim::shfl(v, lane_id_raw() ^ 16);
+#else
+    const unsigned x = __builtin_bit_cast(unsigned, v);
+    const auto r = __builtin_amdgcn_permlane16_swap(x, x, false, false);   // r[0]: odd rows <- the even rows below them; r[1]: even rows <- the odd rows above
+    return __builtin_bit_cast(float, (lane_id_raw() & 16) ? r[0] : r[1]);
+#endif
+}
+// rows one down / one up inside the 16 lanes of a DPP row: lane (i, g) <- lane (i -+ 1, g); the lane at the row's edge takes `edge`
+// (v_mov_b32_dpp row_shr:1 / row_shl:1 with bound_ctrl off: an out-of-row source leaves `old` in place)
+__device__ __forceinline__ unsigned row_dn_u(unsigned v, unsigned edge) {
+#ifdef ESMI_WAVESIM
+    const int l = lane_id_raw();
+    const unsigned s = (unsigned)wavesim::shfl_i((int)v, (l & 15) ? l - 1 : l);
+    return (l & 15) ? s : edge;
+#else
+    return (unsigned)__builtin_amdgcn_update_dpp((int)edge, (int)v, 0x111, 0xF, 0xF, false);
+#endif
+}
+__device__ __forceinline__ unsigned row_up_u(unsigned v, unsigned edge) {
+#ifdef ESMI_WAVESIM
+    const int l = lane_id_raw();
+    const unsigned s = (unsigned)wavesim::shfl_i((int)v, (l & 15) != 15 ? l + 1 : l);
+    return (l & 15) != 15 ? s : edge;
+#else
+    return (unsigned)__builtin_amdgcn_update_dpp((int)edge, (int)v, 0x101, 0xF, 0xF, false);
+#endif
+}
+// a device-side global pointer a translation unit owns (the decoder's clock probe): a plain global in the simulator
+#ifdef ESMI_WAVESIM
+#define ESMI_DEVICE_GLOBAL_PTR(type, name) static type* name = nullptr
+#define ESMI_STORE_DEVICE_GLOBAL_PTR(name, value) ((name) = (value), 0)
+#else
+#define ESMI_DEVICE_GLOBAL_PTR(type, name) static __device__ type* name = nullptr
+#define ESMI_STORE_DEVICE_GLOBAL_PTR(name, value) ((int)hipMemcpyToSymbol(HIP_SYMBOL(name), &(value), sizeof(value)))
+#endif
 
 // ---- activations (fp32; |err| <= ~2e-7 absolute, far inside the 1e-4 parity budget)
 __device__ __forceinline__ float tanh_f32(float x) {

@@ -11,7 +11,7 @@ The gathered result is bit-identical to the single-GPU result (tests/test_sharde
 
 `ShardedMelPipeline` overlaps step i's all-gather (side stream) with step i+1's compute: on xGMI the
 gather of a tiny-ES batch costs about as much as computing it, so serialising them would halve the
-throughput (DESIGN.md §multi-GPU).
+throughput (DESIGN.md 5).
 """
 import torch
 import torch.distributed as dist

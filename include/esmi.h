@@ -305,7 +305,7 @@ int esmi_bucket_embedding_f32(const float* v, const float* bins, const float* em
                               int32_t* idx, esmi_stream_t stream);
 
 /* ------------------------------------------------------------------ operand-range guard of the split-f16 build
- * The default build computes weight GEMMs as fp32-accurate split products on the f16 matrix pipe: 2^8 * W must
+ * The default build computes weight GEMMs as fp32-accurate split products on the f16 matrix pipe (HISTORY.md 3): 2^8 * W must
  * be a finite binary16 number.  esmi_split_weight_limit() is the largest admissible |W| (inf for the fp32-MFMA build);
  * esmi_absmax_f32 reduces max|x| (NaN -> inf) into a device float so that a loader can check a checkpoint ONCE at pack time
  * (efficientspeech_amd/networks.py raises ValueError and names libesmi_fp32mfma.so as the build to use instead).
@@ -336,7 +336,7 @@ int esmi_upsample_f32(const float* feat, const uint8_t* fmask, const int32_t* cu
  * [block_depth x (depthwise k conv -> pointwise conv -> Tanh -> LN); skip LN], mel Linear.
  * Weights are packed once into one blob (MFMA B-fragment order).  In the default build the
  * matrices are stored as two binary16 pieces of 2^8 * W (same bytes as fp32; esmi_build_config() says
- * "dec_gemm=split-f16x2"): |W| must be < 255 and activations inside the binary16 range;
+ * "dec_gemm=split-f16x2"): |W| must be < 255 and activations inside the binary16 range (HISTORY.md 3);
  * the blob is opaque and only valid for the library that packed it.                                  */
 #define ESMI_MAX_DEC_LAYERS 16
 typedef struct esmi_decoder_weights {   /* checkpoint layouts, device pointers */
