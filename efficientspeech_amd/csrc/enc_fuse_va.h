@@ -18,6 +18,22 @@ struct PredW {   // conv1_w / conv2_w in MFMA B-fragment order (esmi_pack_bfrag_
     const float *conv1_w, *conv1_b, *ln1_g, *ln1_b, *conv2_w, *conv2_b, *ln2_g, *ln2_b, *lin_w, *lin_b, *bins, *emb;
 };
 
+// enc_pred128.h (dim = 128: one workgroup per (utterance, predictor))
+struct Pred128P {
+    PredW pred[3];                  // conv1_w / conv2_w: esmi_pack_bfrag_f32 arrays (three taps each)
+    const unsigned char* mask;      // (B, T) or NULL
+    const float* pitch_t;           // teacher values (train = True) or NULL
+    const float* energy_t;
+    const int* dur_t;
+    float* feat;                    // (B, T, 4 dim): channels [0, dim) are read, the rest written
+    float* preds[3];                // (B, T) each
+    int* pitch_idx;
+    int* energy_idx;
+    int* dur;
+    int* cum;                       // (B, T) or NULL
+    int* mel_len;                   // (B)
+    int B, T;
+};
 struct FuseVaP {
     int B, T, depth, kernel;
     const float* feats[4];

@@ -522,11 +522,35 @@ static int fuse_variance_adaptor(const esmi_fuse_weights* fw, int depth, int dim
     const size_t fws = esmi_fuse_workspace_bytes(B, T, dim, depth);
     int rc = esmi_fuse_f32(fw, depth, dim, kernel, B, T, feats, n_i, mask, feat, 4 * dim, workspace, fws, stream);
     if (rc) return rc;
-    rc = esmi_variance_adaptor_f32(pitch, energy, duration, dim, B, T, mask, pitch_target, energy_target,
-                                   duration_target, feat, pitch_pred, energy_pred, duration_pred, pitch_idx, energy_idx,
-                                   dur, static_cast<char*>(workspace) + fws, workspace_bytes - fws, stream);
-    if (rc) return rc;
-    if (cum) ESMI_LAUNCH(length_regulate_kernel, dim3(B), dim3(64), 0, S(stream), dur, T, cum, mel_len, (int*)nullptr);
+    // dim = 128, T <= 256 (round 6): the three predictors as ONE launch -- a workgroup per (utterance, predictor) with the hidden rows in
+    // registers, bucketize / embeddings / duration features / rounding and the length regulator's scan inside (enc_pred128.h) -- instead
+    // of six GEMM launches through HBM + va_tail_kernel + length_regulate_kernel
+    rc = ESMI_ERR_UNSUPPORTED;
+    if ((plan & ESMI_FUSE_CHAIN16) && dim == 128 && pitch->conv1_wp && pitch->conv2_wp && energy->conv1_wp && energy->conv2_wp &&
+        duration->conv1_wp && duration->conv2_wp) {
+        Pred128P q;
+        memset(&q, 0, sizeof q);
+        const esmi_predictor_weights* pw[3] = {pitch, energy, duration};
+        for (int k = 0; k < 3; ++k) {
+            PredW& d = q.pred[k];
+            d.conv1_w = pw[k]->conv1_wp; d.conv1_b = pw[k]->conv1_b; d.ln1_g = pw[k]->ln1_g; d.ln1_b = pw[k]->ln1_b;
+            d.conv2_w = pw[k]->conv2_wp; d.conv2_b = pw[k]->conv2_b; d.ln2_g = pw[k]->ln2_g; d.ln2_b = pw[k]->ln2_b;
+            d.lin_w = pw[k]->lin_w; d.lin_b = pw[k]->lin_b; d.bins = pw[k]->bins; d.emb = pw[k]->emb;
+        }
+        q.mask = mask; q.pitch_t = pitch_target; q.energy_t = energy_target; q.dur_t = duration_target;
+        q.feat = feat; q.preds[0] = pitch_pred; q.preds[1] = energy_pred; q.preds[2] = duration_pred;
+        q.pitch_idx = pitch_idx; q.energy_idx = energy_idx; q.dur = dur; q.cum = cum; q.mel_len = mel_len; q.B = B; q.T = T;
+        rc = launch_enc_pred128(q, dim, S(stream));
+    }
+    if (rc == ESMI_ERR_UNSUPPORTED) {
+        rc = esmi_variance_adaptor_f32(pitch, energy, duration, dim, B, T, mask, pitch_target, energy_target,
+                                       duration_target, feat, pitch_pred, energy_pred, duration_pred, pitch_idx, energy_idx,
+                                       dur, static_cast<char*>(workspace) + fws, workspace_bytes - fws, stream);
+        if (rc) return rc;
+        if (cum) ESMI_LAUNCH(length_regulate_kernel, dim3(B), dim3(64), 0, S(stream), dur, T, cum, mel_len, (int*)nullptr);
+    } else if (rc) {
+        return rc;
+    }
     if (h0) return esmi_decoder_head_f32(head, (long)B * T, feat, h0, stream);
     return launch_status();
 }
@@ -896,7 +920,7 @@ int esmi_phoneme2mel_forward_f32(const esmi_forward_args* a, int stage, esmi_str
     hipError_t e = hipMemsetAsync(a->range_flag, 0, sizeof(int32_t), S(stream));
     if (e != hipSuccess) return (int)e;
     int (*const setters[])(int*) = {set_range_flag_abi, set_range_flag_convgemm, set_range_flag_attention, set_range_flag_enc_merge,
-                                    set_range_flag_enc_block, set_range_flag_enc_attn_ffn, set_range_flag_enc_fuse_va, set_range_flag_enc_va16, set_range_flag_enc_va64, set_range_flag_enc_block16,
+                                    set_range_flag_enc_block, set_range_flag_enc_attn_ffn, set_range_flag_enc_fuse_va, set_range_flag_enc_va16, set_range_flag_enc_va64, set_range_flag_enc_pred128, set_range_flag_enc_block16,
                                     set_range_flag_decoder, set_range_flag_dec_128_5, set_range_flag_dec_128_3, set_range_flag_dec_256_5,
                                     set_range_flag_dec_256_3, set_range_flag_hifigan, set_range_flag_train};
     for (auto set : setters)

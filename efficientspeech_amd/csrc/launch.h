@@ -63,6 +63,8 @@ bool enc_va16_ok(const FuseVaP& p, int dim, int kernel);
 int launch_enc_va64(const FuseVaP& p, int dim, int kernel, hipStream_t st);
 struct PostAttn64P;
 int launch_enc_post_attn64(const PostAttn64P& p, hipStream_t st);   // (enc_ffn64.h: proj + LN1 + MixFFN + LN2 of a C = 64 one-head block, N <= 256)
+// tu_enc_pred128.hip (round 6: the three predictors + variance-adaptor tail + scan of a dim = 128 model, T <= 256; reads feat[:, 0 .. dim))
+int launch_enc_pred128(const Pred128P& p, int dim, hipStream_t st);
 // tu_enc_block16.hip (round 5: whole-block kernels of dim = 32 models on 16-row tiles)
 int launch_enc_block16(const EncAttnFfnP& p, int expansion, int c_in, hipStream_t st);
 // ... and the whole encoder side in one launch (block 0 | block 1 | Fuse + variance adaptor), when each of the three chain16 kernels
@@ -96,6 +98,7 @@ int set_range_flag_enc_attn_ffn(int* flag);
 int set_range_flag_enc_fuse_va(int* flag);
 int set_range_flag_enc_va16(int* flag);
 int set_range_flag_enc_va64(int* flag);
+int set_range_flag_enc_pred128(int* flag);
 int set_range_flag_enc_block16(int* flag);
 int set_range_flag_decoder(int* flag);
 int set_range_flag_dec_128_5(int* flag);

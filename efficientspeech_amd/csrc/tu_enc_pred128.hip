@@ -1,0 +1,35 @@
+// esmi C-ABI, translation unit "tu_enc_pred128.hip": the three predictors of a dim = 128 model (base ES), one workgroup per
+// (utterance, predictor), with the variance adaptor's tail and the length regulator's scan inside (enc_pred128.h).  Internal
+// launchers are declared in launch.h.
+#include "launch.h"
+#include "enc_pred128.h"
+
+using namespace esmi;
+ESMI_TU_RANGE_SETTER(enc_pred128)
+
+namespace esmi {
+
+// dim = 128, one workgroup covers the sequence (T <= 256), pre-split conv weights; ESMI_ERR_UNSUPPORTED otherwise (-> the per-op plan).
+// The split-f16 build only: the exact-fp32 library keeps the per-op plan.
+int launch_enc_pred128(const Pred128P& p, int dim, hipStream_t st) {
+#if ESMI_CHAIN_SPLIT
+    if (dim != 128 || p.T < 1 || p.T > 32 * kVa64MaxWaves || p.B < 1 || !p.feat || !p.dur || !p.preds[0] || !p.preds[1] || !p.preds[2] ||
+        ((p.cum == nullptr) != (p.mel_len == nullptr)))
+        return ESMI_ERR_UNSUPPORTED;
+    for (int q = 0; q < 3; ++q) {
+        const PredW& d = p.pred[q];
+        if (!d.conv1_w || !d.conv2_w || !d.conv1_b || !d.conv2_b || !d.ln1_g || !d.ln1_b || !d.lin_w || !d.lin_b) return ESMI_ERR_UNSUPPORTED;
+        if (q < 2 && (!d.bins || !d.emb)) return ESMI_ERR_UNSUPPORTED;
+        if (q == 2 && (!d.ln2_g || !d.ln2_b)) return ESMI_ERR_UNSUPPORTED;
+    }
+    static AttrOnce once;
+    if (int rc = raise_lds_limit(reinterpret_cast<const void*>(enc_pred128_kernel), once)) return rc;
+    ESMI_LAUNCH(enc_pred128_kernel, dim3(p.B, 3), dim3(64 * ((p.T + 31) / 32)), pred128_lds_bytes(), st, p);
+    return launch_status();
+#else
+    (void)p; (void)dim; (void)st;
+    return ESMI_ERR_UNSUPPORTED;
+#endif
+}
+
+}  // namespace esmi

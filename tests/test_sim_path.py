@@ -56,14 +56,15 @@ def test_simulated_unfused_path_matches_golden(path, nets):
         H.check_against_golden(net, g, "cpu")
 
 
-@pytest.mark.parametrize("name,B,T,lens", [
-    ("tiny", 3, 70, [70, 41, 9]),        # 3 row tiles; 70 / 35 keys; multi-window decoder (L > 112)
-    ("small", 2, 40, [40, 23]),
-    ("small", 2, 150, [150, 97]),        # round 6: enc_va64_kernel<2> (two 16-row tiles per wave, head inside) + enc_post_attn64_kernel<2>
+@pytest.mark.parametrize("name,B,T,lens,seed", [
+    ("tiny", 3, 70, [70, 41, 9], 4321),        # 3 row tiles; 70 / 35 keys; multi-window decoder (L > 112)
+    ("small", 2, 40, [40, 23], 4321),
+    ("small", 2, 150, [150, 97], 4321),        # round 6: enc_va64_kernel<2> (two 16-row tiles per wave, head inside) + enc_post_attn64_kernel<2>
+    ("base", 2, 150, [150, 97], 77),           # round 6: enc_pred128_kernel, five waves x two tiles, the last tile partly / wholly outside
 ])
-def test_simulated_eval_vs_oracle_multi_tile(name, B, T, lens, nets):
+def test_simulated_eval_vs_oracle_multi_tile(name, B, T, lens, seed, nets):
     net, cfg, sd = nets(name)
-    ids, mask = synth_phonemes(B, T, 4321, lens)
+    ids, mask = synth_phonemes(B, T, seed, lens)
     x = {"phoneme": torch.from_numpy(ids), "phoneme_mask": torch.from_numpy(mask)}
     with use_sim(), torch.no_grad():
         enc = net.encoder._encode(x)
