@@ -345,55 +345,146 @@ __host__ __device__ inline size_t attn_lds_bytes(int N, int C) {
     const size_t k = (size_t)2 * nk * (2 * ck + 16), v = (size_t)2 * ck * (2 * nk + 16);
     return k > v ? k : v;
 }
-template <int NKT>
-__global__ __launch_bounds__(64 * NKT, 2) void attn_lds_kernel(const AttnP p) {
+#ifndef ESMI_ATTN_KO
+#define ESMI_ATTN_KO 0   // development (tools/probes/probe_attn.hip): knock a phase out to see what it costs -- 1 K writes, 2 score products,
+#endif                   // 4 V writes, 8 P V products, 16 softmax, 32 K / V requests, 64 Q requests.  0 in every library build.
+// Round 6: every global read is issued a phase ahead of its use.  The round-5 form ran `load -> convert -> ds_write` once per item in
+// runtime-bounded loops (16 dependent L2 round trips per K pass and thread) and fetched the Q fragments inside the product loop, at two
+// waves per SIMD: base ES block 1 (N = 128, C = 256) took 260 us for 17 GFLOP.  Now a phase's items (K: CK / 8 float4 per thread, V: CK / 32
+// groups of four) are requested together into `P` -- the next phase's while this phase's products run (NKT <= 4: there are registers for
+// it), or right behind the score loop in front of the softmax (NKT = 8) -- and a pass's Q fragments are requested in two batches, the
+// first in front of the staging, the second in front of the first batch's products.
+template <int NKT, int CK>      // CK = min(C, 128): 32, 64 or 128
+__global__ __launch_bounds__(64 * NKT, NKT <= 4 ? 2 : 1) void attn_lds_kernel(const AttnP p) {
     ESMI_DYN_LDS(lds_f);
     char* lds = reinterpret_cast<char*>(lds_f);
     typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
     constexpr int NK = 32 * NKT, NTHR = 64 * NKT;
+    constexpr bool kAhead = NKT <= 4;                         // the next phase's rows are in flight under this phase's products
     const int lane = lane_id(), w = wave_id(), tid = (int)threadIdx.x;
     const int hd = (int)blockIdx.x % p.h, b = (int)blockIdx.x / p.h;
     const int i = lane & 31, h2 = lane >> 5, q0 = 32 * w;
-    const int ldq = p.ldq, ldk = p.ldk, ldv = p.ldv, C = p.C, CK = C < 128 ? C : 128;
-    const float* qb = p.q + (long)b * p.N * ldq + hd * p.hsq;
-    const float* kb = p.k + (long)b * p.N * ldk + hd * p.hsk;
-    const float* vb = p.v + (long)b * p.N * ldv + hd * p.hsv;
-    const int krs = 2 * CK + 16, kplane = NK * krs;           // K planes: [2][NK][krs bytes], CK channels per pass
-    const int vrs = 2 * NK + 16, vplane = CK * vrs;           // Vt planes: [2][CK][vrs bytes]
-
-    // ---- S^T[key][query] for this wave's 32 queries, CK channels of K staged at a time (one item = 4 channels of one key)
-    f32x16 s[NKT];
+    const int ldq = p.ldq, ldk = p.ldk, ldv = p.ldv, C = p.C;
+    // buffer resources over this (utterance, head)'s rows: keys / queries >= N read as zeros, and the wave-uniform part of every offset
+    // (item index, pass, row of a group) travels in an SGPR -- one lane-offset register per operand instead of a 64-bit pointer per item
+    const BufRsrc r_q = make_rsrc(p.q + (long)b * p.N * ldq + hd * p.hsq, ((long)(p.N - 1) * ldq + C) * 4);
+    const BufRsrc r_k = make_rsrc(p.k + (long)b * p.N * ldk + hd * p.hsk, ((long)(p.N - 1) * ldk + C) * 4);
+    const BufRsrc r_v = make_rsrc(p.v + (long)b * p.N * ldv + hd * p.hsv, ((long)(p.N - 1) * ldv + C) * 4);
+    const BufRsrc r_o = make_rsrc(p.ctx + (long)b * p.N * (p.h * C) + hd * C, ((long)(p.N - 1) * (p.h * C) + C) * 4);
+    const unsigned o_off = (unsigned)(((q0 + 4 * h2) * (p.h * C) + i) * 4);   // (row q0 + tile_row(0, lane), column i of the head's channels)
+    constexpr int krs = 2 * CK + 16, kplane = NK * krs;       // K planes: [2][NK][krs bytes], CK channels per pass
+    constexpr int vrs = 2 * NK + 16, vplane = CK * vrs;       // Vt planes: [2][CK][vrs bytes]
+    constexpr int c4sh = CK == 128 ? 5 : (CK == 64 ? 4 : 3);  // log2 of the float4 items per key row and pass
+    constexpr int nK = CK >> 3;                               // K items (4 channels of one key) per thread and pass: NK (CK / 4) / NTHR
+    constexpr int nV = CK >> 5;                               // V items (4 keys x 4 channels) per thread and pass: (NK / 4) (CK / 4) / NTHR
+    constexpr int rpi = NTHR >> c4sh;                         // item u of a thread is rpi rows (K) / row groups (V) below item u - 1
+    static_assert(rpi % 8 == 0, "attn_lds: a thread's V items are whole key tiles apart");
+    const int npass = C / CK;
+    const int e_row = tid >> c4sh, e_c = (tid - (e_row << c4sh)) << 2;   // this thread's item 0: row (K) or group of four rows (V), first channel
+    const unsigned k_off = (unsigned)((e_row * ldk + e_c) * 4), v_off = (unsigned)((4 * e_row * ldv + e_c) * 4);
+    f32x4 P[16];
+    auto request_k = [&](int cp) __attribute__((always_inline)) {
 #pragma unroll
-    for (int kt = 0; kt < NKT; ++kt) s[kt] = zero16();
-    const bool qok = q0 + i < p.N;
-    const float* qrow = qb + (long)(qok ? q0 + i : 0) * ldq;
-    for (int cp = 0; cp < C; cp += CK) {
-        if (cp) __syncthreads();                           // the previous pass's fragments have been read
-        for (int e = tid; e < NK * (CK >> 2); e += NTHR) {
-            const int key = e / (CK >> 2), c = (e - key * (CK >> 2)) << 2;
-            const f32x4 v = key < p.N ? ld4(kb + (long)key * ldk + cp + c) : zero4();
+        for (int u = 0; u < nK; ++u) P[u] = (ESMI_ATTN_KO & 32) ? zero4() : buf_ld4s(r_k, k_off, (unsigned)((u * rpi * ldk + cp) * 4));
+    };
+    auto stage_k = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int u = 0; u < nK; ++u) {
             unsigned h1a, h2a, h1b, h2b;
-            split_f16_pair(v[0], v[1], h1a, h2a);
-            split_f16_pair(v[2], v[3], h1b, h2b);
-            char* d = lds + key * krs + c * 2;
-            *reinterpret_cast<u32x2*>(d) = u32x2{h1a, h1b};
-            *reinterpret_cast<u32x2*>(d + kplane) = u32x2{h2a, h2b};
+            split_f16_pair(P[u][0], P[u][1], h1a, h2a);
+            split_f16_pair(P[u][2], P[u][3], h1b, h2b);
+            char* d = lds + opaque_i(e_row * krs + e_c * 2);        // (+ compile-time offsets: nothing per item is kept in registers)
+            if ((ESMI_ATTN_KO & 1) && h1a != 12345u) continue;
+            *reinterpret_cast<u32x2*>(d + u * rpi * krs) = u32x2{h1a, h1b};
+            *reinterpret_cast<u32x2*>(d + kplane + u * rpi * krs) = u32x2{h2a, h2b};
+        }
+    };
+    // V is staged TRANSPOSED: one item = 4 consecutive keys x 4 channels; k-slot of key 32 kt + 8 q + 4 h + e (e < 4) is
+    // 32 kt + 16 (q >> 1) + 8 h + 4 (q & 1) + e, i.e. the eight keys of (kt, step q >> 1, half h) are slots 8 h .. 8 h + 7 of that 16-key step
+    auto request_v = [&](int c0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int u = 0; u < nV; ++u) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) P[4 * u + r] = (ESMI_ATTN_KO & 32) ? zero4() : buf_ld4s(r_v, v_off, (unsigned)(((4 * u * rpi + r) * ldv + c0) * 4));
+        }
+    };
+    auto stage_v = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int u = 0; u < nV; ++u) {
+            // item u's keys are 4 rpi u below item 0's (a multiple of 32: same q, h; kt + rpi u / 8), i.e. 4 rpi u slots further
+            const int key0 = 4 * e_row, kt = key0 >> 5, q = (key0 >> 3) & 3, hh = (key0 >> 2) & 1;
+            const int slot0 = 32 * kt + 16 * (q >> 1) + 8 * hh + 4 * (q & 1);
+            char* d = lds + opaque_i(e_c * vrs + slot0 * 2);
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) {
+                unsigned h1a, h2a, h1b, h2b;
+                split_f16_pair(P[4 * u][cc], P[4 * u + 1][cc], h1a, h2a);
+                split_f16_pair(P[4 * u + 2][cc], P[4 * u + 3][cc], h1b, h2b);
+                if ((ESMI_ATTN_KO & 4) && h1a != 12345u) continue;
+                *reinterpret_cast<u32x2*>(d + cc * vrs + 8 * rpi * u) = u32x2{h1a, h1b};
+                *reinterpret_cast<u32x2*>(d + vplane + cc * vrs + 8 * rpi * u) = u32x2{h2a, h2b};
+            }
+        }
+    };
+
+    // ---- S^T[key][query] for this wave's 32 queries, CK channels of K staged at a time
+    f32x16 s[NKT];                                            // (zeroed behind pass 0's barrier: 32 NKT registers the first requests can use)
+    const unsigned q_off = q0 + i < p.N && !(ESMI_ATTN_KO & 64) ? (unsigned)(((q0 + i) * ldq + 8 * h2) * 4) : kBufOOB;
+    constexpr int nst = CK >> 4;                              // 16-channel steps per pass: 2, 4 or 8
+    if (kAhead) request_k(0);
+    for (int pass = 0; pass < npass; ++pass) {
+        const int cp = pass * CK;
+        f32x4 qa[4][2], qb2[4][2];
+        if (!kAhead) request_k(cp);                           // (NKT = 8: s is half the register file, nothing is carried around the loop)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {                         // steps 0 .. 3 of the pass: on their way while K is staged
+            if (t < nst) {
+                qa[t][0] = buf_ld4s(r_q, q_off, (unsigned)((cp + 16 * t) * 4));
+                qa[t][1] = buf_ld4s(r_q, q_off, (unsigned)((cp + 16 * t + 4) * 4));
+            }
+        }
+        if (pass) __syncthreads();                            // the previous pass's fragments have been read
+        stage_k();
+        if (kAhead) {
+            if (pass + 1 < npass) request_k(cp + CK); else request_v(0);
         }
         __syncthreads();
-        for (int st = 0; st < (CK >> 4); ++st) {
-            const int c = 16 * st + 8 * h2;
-            const f16x2p qf = qok ? split_f16x2(ld4(qrow + cp + c), ld4(qrow + cp + c + 4)) : split_f16x2(zero4(), zero4());
+        if (pass == 0) {
 #pragma unroll
-            for (int kt = 0; kt < NKT; ++kt) {
-                const char* a = lds + opaque_i((32 * kt + i) * krs + c * 2);
-                const u32x4 k1 = *reinterpret_cast<const u32x4*>(a), k2 = *reinterpret_cast<const u32x4*>(a + kplane);
-                s[kt] = mfma32_f16(k2, qf.h1, s[kt]);
-                s[kt] = mfma32_f16(k1, qf.h2, s[kt]);
-                s[kt] = mfma32_f16(k1, qf.h1, s[kt]);
+            for (int kt = 0; kt < NKT; ++kt) s[kt] = zero16();
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {                         // steps 4 .. 7: on their way under the products of steps 0 .. 3
+            if (4 + t < nst) {
+                qb2[t][0] = buf_ld4s(r_q, q_off, (unsigned)((cp + 16 * (4 + t)) * 4));
+                qb2[t][1] = buf_ld4s(r_q, q_off, (unsigned)((cp + 16 * (4 + t) + 4) * 4));
+            }
+        }
+        // fragment addresses: two lane-dependent bases (one per plane: kplane is beyond the 16-bit DS offset field) + compile-time offsets
+        const char* const ka1 = lds + opaque_i(i * krs + 16 * h2);
+        const char* const ka2 = lds + opaque_i(i * krs + 16 * h2 + kplane);
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int st = 4 * half + t;
+                if (st < nst) {
+                    const f16x2p qf = half ? split_f16x2(qb2[t][0], qb2[t][1]) : split_f16x2(qa[t][0], qa[t][1]);
+#pragma unroll
+                    for (int kt = 0; kt < NKT; ++kt) {
+                        if (ESMI_ATTN_KO & 2) { s[kt][st] += __builtin_bit_cast(float, qf.h1[0] ^ qf.h2[1]); continue; }
+                        const u32x4 k1 = *reinterpret_cast<const u32x4*>(ka1 + 32 * kt * krs + 32 * st);
+                        const u32x4 k2 = *reinterpret_cast<const u32x4*>(ka2 + 32 * kt * krs + 32 * st);
+                        s[kt] = mfma32_f16(k2, qf.h1, s[kt]);
+                        s[kt] = mfma32_f16(k1, qf.h2, s[kt]);
+                        s[kt] = mfma32_f16(k1, qf.h1, s[kt]);
+                    }
+                }
             }
         }
     }
-    // ---- softmax over keys (attn_kernel's)
+    if (!kAhead) request_v(0);
+    // ---- softmax over keys (attn_kernel's); the first V pass's rows are in flight
     float mx = -INFINITY;
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt) {
@@ -411,7 +502,7 @@ __global__ __launch_bounds__(64 * NKT, 2) void attn_lds_kernel(const AttnP p) {
     for (int kt = 0; kt < NKT; ++kt) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const float e = expf(s[kt][r] - mx);
+            const float e = (ESMI_ATTN_KO & 16) ? s[kt][r] - mx : expf(s[kt][r] - mx);
             s[kt][r] = e;
             den += e;
         }
@@ -424,33 +515,20 @@ __global__ __launch_bounds__(64 * NKT, 2) void attn_lds_kernel(const AttnP p) {
         for (int r = 0; r < 16; ++r) s[kt][r] *= inv;
     }
 
-    // ---- ctx[query][c] = sum_key P[query][key] V[key][c], CK output channels per pass, V staged TRANSPOSED per pass:
-    // one item = 4 consecutive keys x 4 channels; k-slot of key 32 kt + 8 q + 4 h + e (e < 4) is 32 kt + 16 (q >> 1) + 8 h + 4 (q & 1) + e,
-    // i.e. the eight keys of (kt, step q >> 1, half h) are slots 8 h .. 8 h + 7 of that 16-key step
-    for (int c0 = 0; c0 < C; c0 += CK) {
+    // ---- ctx[query][c] = sum_key P[query][key] V[key][c], CK output channels per pass
+    for (int vp = 0; vp < npass; ++vp) {
+        const int c0 = vp * CK;
+        if (!kAhead && vp) request_v(c0);
         __syncthreads();                                   // K (or the previous pass's V) has been read by every wave
-        for (int e = tid; e < (NK >> 2) * (CK >> 2); e += NTHR) {
-            const int g4 = e / (CK >> 2), c = (e - g4 * (CK >> 2)) << 2;
-            const int key0 = 4 * g4, kt = key0 >> 5, q = (key0 >> 3) & 3, hh = (key0 >> 2) & 1;
-            const int slot0 = 32 * kt + 16 * (q >> 1) + 8 * hh + 4 * (q & 1);
-            f32x4 v[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = key0 + r < p.N ? ld4(vb + (long)(key0 + r) * ldv + c0 + c) : zero4();
-#pragma unroll
-            for (int cc = 0; cc < 4; ++cc) {
-                unsigned h1a, h2a, h1b, h2b;
-                split_f16_pair(v[0][cc], v[1][cc], h1a, h2a);
-                split_f16_pair(v[2][cc], v[3][cc], h1b, h2b);
-                char* d = lds + (c + cc) * vrs + slot0 * 2;
-                *reinterpret_cast<u32x2*>(d) = u32x2{h1a, h1b};
-                *reinterpret_cast<u32x2*>(d + vplane) = u32x2{h2a, h2b};
-            }
-        }
+        stage_v();
+        if (kAhead && vp + 1 < npass) request_v(c0 + CK);
         __syncthreads();
         // 64 output channels at a time (round 5: with all 128 in flight -- s: 128 registers, o: 64 -- the <8> instantiation spilled 228 B per
         // lane; the probabilities are split again for the second half, eight conversions per step against twelve MFMAs)
         for (int nh = 0; 64 * nh < CK; ++nh) {
             f32x16 o[2] = {zero16(), zero16()};
+            const char* const va1 = lds + opaque_i((64 * nh + i) * vrs + 16 * h2);
+            const char* const va2 = lds + opaque_i((64 * nh + i) * vrs + 16 * h2 + vplane);
 #pragma unroll
             for (int kt = 0; kt < NKT; ++kt) {
 #pragma unroll
@@ -459,12 +537,13 @@ __global__ __launch_bounds__(64 * NKT, 2) void attn_lds_kernel(const AttnP p) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { pa[e] = s[kt][r8 + e]; pb2[e] = s[kt][r8 + 4 + e]; }
                     const f16x2p pf = split_f16x2(pa, pb2);
-                    const int slot = 32 * kt + 2 * r8 + 8 * h2;          // this half wave's eight k-slots of the step
+                    // (k-slots 32 kt + 2 r8 + 8 h2 + (0..7): this half wave's eight of the step)
 #pragma unroll
                     for (int nt = 0; nt < 2; ++nt) {
                         if (32 * (2 * nh + nt) >= CK) continue;           // workgroup-uniform
-                        const char* a = lds + opaque_i((32 * (2 * nh + nt) + i) * vrs + slot * 2);
-                        const u32x4 v1 = *reinterpret_cast<const u32x4*>(a), v2 = *reinterpret_cast<const u32x4*>(a + vplane);
+                        if (ESMI_ATTN_KO & 8) { o[nt][kt] += __builtin_bit_cast(float, pf.h1[0] ^ pf.h2[1]); continue; }
+                        const u32x4 v1 = *reinterpret_cast<const u32x4*>(va1 + 32 * nt * vrs + (32 * kt + 2 * r8) * 2);
+                        const u32x4 v2 = *reinterpret_cast<const u32x4*>(va2 + 32 * nt * vrs + (32 * kt + 2 * r8) * 2);
                         o[nt] = mfma32_f16(pf.h2, v1, o[nt]);
                         o[nt] = mfma32_f16(pf.h1, v2, o[nt]);
                         o[nt] = mfma32_f16(pf.h1, v1, o[nt]);
@@ -472,13 +551,11 @@ __global__ __launch_bounds__(64 * NKT, 2) void attn_lds_kernel(const AttnP p) {
                 }
             }
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int q = q0 + tile_row(r, lane);
-                if (q >= p.N) continue;
-                float* orow = p.ctx + ((long)b * p.N + q) * (p.h * C) + hd * C + c0 + 64 * nh + i;
+            for (int r = 0; r < 16; ++r) {                 // row q0 + tile_row(r, lane) = this lane's first row + (r & 3) + 8 (r >> 2); rows >= N are out of range
+                const unsigned so = (unsigned)((((r & 3) + 8 * (r >> 2)) * (p.h * C) + c0 + 64 * nh) * 4);
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt)
-                    if (64 * nh + 32 * nt + i < CK) orow[32 * nt] = o[nt][r];
+                    if (64 * nh + 32 * nt < CK) buf_st_s(r_o, o_off, so + 128u * nt, o[nt][r]);
             }
         }
     }

@@ -35,18 +35,21 @@ int launch_attn(const AttnP& p_in, hipStream_t st) {
     }
 #if ESMI_CHAIN_SPLIT
     // heads with several query tiles: K and V staged once per (utterance, head) in LDS instead of once per tile from L2
-    if (nkt >= 3 && (p.C <= 128 || p.C % 128 == 0) && attn_lds_bytes(p.N, p.C) <= 150 * 1024 && (long)p.B * p.h >= kAttnLdsMinHeadsDefault) {
+    if (nkt >= 3 && (p.C == 32 || p.C == 64 || p.C % 128 == 0) && attn_lds_bytes(p.N, p.C) <= 150 * 1024 && (long)p.B * p.h >= kAttnLdsMinHeadsDefault) {
         const size_t lds = attn_lds_bytes(p.N, p.C);
         dim3 g2((unsigned)(p.B * p.h));
+#define ESMI_ATTN_LDS(NKT, CKV) do { \
+            static AttrOnce once; \
+            if (int rc = raise_lds_limit(reinterpret_cast<const void*>(attn_lds_kernel<NKT, CKV>), once)) return rc; \
+            ESMI_LAUNCH((attn_lds_kernel<NKT, CKV>), g2, dim3(64 * NKT), lds, st, p); \
+        } while (0)
+        const int ck = p.C < 128 ? p.C : 128;
         if (nkt <= 4) {
-            static AttrOnce once;
-            if (int rc = raise_lds_limit(reinterpret_cast<const void*>(attn_lds_kernel<4>), once)) return rc;
-            ESMI_LAUNCH((attn_lds_kernel<4>), g2, dim3(256), lds, st, p);
+            if (ck == 32) ESMI_ATTN_LDS(4, 32); else if (ck == 64) ESMI_ATTN_LDS(4, 64); else ESMI_ATTN_LDS(4, 128);
         } else {
-            static AttrOnce once;
-            if (int rc = raise_lds_limit(reinterpret_cast<const void*>(attn_lds_kernel<8>), once)) return rc;
-            ESMI_LAUNCH((attn_lds_kernel<8>), g2, dim3(512), lds, st, p);
+            if (ck == 32) ESMI_ATTN_LDS(8, 32); else if (ck == 64) ESMI_ATTN_LDS(8, 64); else ESMI_ATTN_LDS(8, 128);
         }
+#undef ESMI_ATTN_LDS
         return launch_status();
     }
 #endif

@@ -427,6 +427,8 @@ __device__ __forceinline__ void buf_st(const BufRsrc& r, unsigned off, float v) 
 __device__ __forceinline__ void buf_st_i(const BufRsrc& r, unsigned off, int v) {
     if (off < r.bytes && off + 4u <= r.bytes) *reinterpret_cast<int*>(const_cast<char*>(r.base) + off) = v;
 }
+// (4 bytes at per-lane offset voff + wave-uniform soff, as buf_ld4s)
+__device__ __forceinline__ void buf_st_s(const BufRsrc& r, unsigned voff, unsigned soff, float v) { buf_st(r, voff == kBufOOB ? kBufOOB : voff + soff, v); }
 __device__ __forceinline__ void buf_st4(const BufRsrc& r, unsigned off, const f32x4& v) {
     if (off < r.bytes && off + 16u <= r.bytes) *reinterpret_cast<f32x4*>(const_cast<char*>(r.base) + off) = v;
 }
@@ -458,6 +460,10 @@ __device__ __forceinline__ void buf_st(BufRsrc r, unsigned off, float v) {
 }
 __device__ __forceinline__ void buf_st_i(BufRsrc r, unsigned off, int v) {
     __builtin_amdgcn_raw_buffer_store_b32((unsigned)v, r, (int)off, 0, 0);
+}
+// (4 bytes at per-lane offset voff + wave-uniform soff, as buf_ld4s; voff = kBufOOB stays out of range for every soff < 2 GiB)
+__device__ __forceinline__ void buf_st_s(BufRsrc r, unsigned voff, unsigned soff, float v) {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, (int)voff, __builtin_amdgcn_readfirstlane((int)soff), 0);
 }
 __device__ __forceinline__ void buf_st4(BufRsrc r, unsigned off, const f32x4& v) {
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, (int)off, 0, 0);
