@@ -520,7 +520,20 @@ static int fuse_variance_adaptor(const esmi_fuse_weights* fw, int depth, int dim
     }
     if (!workspace || workspace_bytes < esmi_fuse_variance_adaptor_workspace_bytes(B, T, dim, depth)) return ESMI_ERR_WORKSPACE;
     const size_t fws = esmi_fuse_workspace_bytes(B, T, dim, depth);
-    int rc = esmi_fuse_f32(fw, depth, dim, kernel, B, T, feats, n_i, mask, feat, 4 * dim, workspace, fws, stream);
+    // dim = 128, two levels, T <= 256 (round 6): the Fuse stage as ONE launch (enc_fuse128.h) instead of four GEMM launches through HBM
+    int rc = ESMI_ERR_UNSUPPORTED;
+    if ((plan & ESMI_FUSE_CHAIN16) && dim == 128 && depth == 2 && fw->mlp_wp[0] && fw->mlp_wp[1] && fw->up_wp[1] && fw->fuse_wp) {
+        FuseVaP q;
+        memset(&q, 0, sizeof q);
+        q.B = B; q.T = T; q.depth = depth; q.kernel = kernel;
+        for (int i = 0; i < depth; ++i) {
+            q.feats[i] = feats[i]; q.n_i[i] = n_i[i];
+            q.mlp_w[i] = fw->mlp_wp[i]; q.mlp_b[i] = fw->mlp_b[i]; q.up_w[i] = fw->up_wp[i]; q.up_b[i] = fw->up_b[i];
+        }
+        q.fuse_w = fw->fuse_wp; q.fuse_b = fw->fuse_b; q.mask = mask; q.feat = feat;
+        rc = launch_enc_fuse128(q, dim, kernel, S(stream));
+    }
+    if (rc == ESMI_ERR_UNSUPPORTED) rc = esmi_fuse_f32(fw, depth, dim, kernel, B, T, feats, n_i, mask, feat, 4 * dim, workspace, fws, stream);
     if (rc) return rc;
     // dim = 128, T <= 256 (round 6): the three predictors as ONE launch -- a workgroup per (utterance, predictor) with the hidden rows in
     // registers, bucketize / embeddings / duration features / rounding and the length regulator's scan inside (enc_pred128.h) -- instead

@@ -3,6 +3,7 @@
 // launchers are declared in launch.h.
 #include "launch.h"
 #include "enc_pred128.h"
+#include "enc_fuse128.h"
 
 using namespace esmi;
 ESMI_TU_RANGE_SETTER(enc_pred128)
@@ -28,6 +29,30 @@ int launch_enc_pred128(const Pred128P& p, int dim, hipStream_t st) {
     return launch_status();
 #else
     (void)p; (void)dim; (void)st;
+    return ESMI_ERR_UNSUPPORTED;
+#endif
+}
+
+// Fuse of a dim = 128 model with two encoder levels as one launch (enc_fuse128.h): feat[:, 0 .. dim) <- the masked fused rows
+int launch_enc_fuse128(const FuseVaP& p, int dim, int kernel, hipStream_t st) {
+#if ESMI_CHAIN_SPLIT
+    if (dim != 128 || p.depth != 2 || (kernel != 3 && kernel != 5) || p.T < 1 || p.T > 32 * kVa64MaxWaves || p.B < 1 || p.n_i[0] != p.T ||
+        p.n_i[1] < 1 || p.n_i[1] > (p.T + 1) / 2 || (p.n_i[1] - 1) * 2 + kernel < p.T || !p.feat || !p.feats[0] || !p.feats[1] || !p.mlp_w[0] ||
+        !p.mlp_w[1] || !p.up_w[1] || !p.fuse_w || !p.mlp_b[0] || !p.mlp_b[1] || !p.up_b[1] || !p.fuse_b)
+        return ESMI_ERR_UNSUPPORTED;
+    const dim3 block(64 * ((p.T + 31) / 32));
+    if (kernel == 5) {
+        static AttrOnce once;
+        if (int rc = raise_lds_limit(reinterpret_cast<const void*>(enc_fuse128_kernel<5>), once)) return rc;
+        ESMI_LAUNCH((enc_fuse128_kernel<5>), dim3(p.B), block, fuse128_lds_bytes(), st, p);
+    } else {
+        static AttrOnce once;
+        if (int rc = raise_lds_limit(reinterpret_cast<const void*>(enc_fuse128_kernel<3>), once)) return rc;
+        ESMI_LAUNCH((enc_fuse128_kernel<3>), dim3(p.B), block, fuse128_lds_bytes(), st, p);
+    }
+    return launch_status();
+#else
+    (void)p; (void)dim; (void)kernel; (void)st;
     return ESMI_ERR_UNSUPPORTED;
 #endif
 }

@@ -459,3 +459,26 @@ def test_simulated_tiny_with_expansion_2_takes_the_per_block_path():
         np.testing.assert_allclose(dpred, o.duration, atol=H.PRED_TOL, rtol=0, err_msg=f"plan {plan}")
         err = H.compare_eval_with_oracle(cfg, o, enc, torch.from_numpy(mel), torch.from_numpy(mel_len), sd)
         assert err == err, f"plan {plan}: a discrete decision inside its margin; pick another seed"
+
+
+def test_simulated_dim128_model_with_kernel_3_and_odd_length():
+    """enc_fuse128_kernel<3> (the reference's default --kernel-size with base's width) at an odd T spread over three waves: the last
+    odd position lies outside the sequence, level-1 rows n - 1 cross two tile boundaries.  Plans 63 (enc_fuse128 + enc_pred128) and
+    31 (per-op launches) against the oracle."""
+    import dataclasses
+    from efficientspeech_amd import CONFIGS, build_phoneme2mel, load_numpy_state_dict
+    from efficientspeech_amd.synth import synth_state_dict
+    cfg = dataclasses.replace(CONFIGS["base"], name="base_k3", kernel_size=3)
+    sd = synth_state_dict(cfg, 1234)
+    net = build_phoneme2mel(cfg)
+    load_numpy_state_dict(net, sd)
+    ids, mask = synth_phonemes(2, 71, 77, [71, 38])
+    x = {"phoneme": torch.from_numpy(ids), "phoneme_mask": torch.from_numpy(mask)}
+    o = oracle.phoneme2mel(cfg, oracle.Weights(sd), ids, mask)
+    with use_sim(), torch.no_grad():
+        for plan in (_lib.FUSE_ALL, 31):
+            with _lib.launch_plan(plan):
+                enc = net.encoder._encode(x)
+                mel, mel_len, _ = net(x)
+            err = H.compare_eval_with_oracle(cfg, o, enc, mel, mel_len, sd)
+            assert err == err, f"plan {plan}: a discrete decision inside its margin; pick another seed"
