@@ -60,6 +60,9 @@ constexpr int kDecWps128 = 4, kDecWeightRing256 = 2, kDecARing = 1;
 #ifndef ESMI_DEC_CUM_LDS    // the utterance's duration scan is copied into LDS (one round trip) and the frame -> phoneme search runs there
 #define ESMI_DEC_CUM_LDS 1  // (0: a binary search in global memory, log2(T) dependent L2 round trips per chunk: profiles/r06_dec_budget.md)
 #endif
+#ifndef ESMI_DEC_LN_ACC     // dx2 = 256: LayerNorm on the K loop's accumulators -- per-(row, column slice) sums through a 1 KB-per-32-rows LDS exchange,
+#define ESMI_DEC_LN_ACC 1   // normalised in registers, stored once (0: tanh rows -> tile -> barrier -> row owners read, normalise, write back)
+#endif
 #define ESMI_DEC_TANH tanh_fast_f32
 #define ESMI_DEC_RSQRT rsqrt_fast_f32   // v_rsq_f32 (1 ulp)
 
@@ -215,7 +218,7 @@ inline int dec_carry_lds_layers(int kd, int n_layers) {
 }
 template <int DX2>
 __host__ __device__ constexpr int dec_lds_floats(int kd) {
-    return (kDecRows + 2 * kDecPadRows) * (DX2 + 4) + (kd + 6) * DX2 + kDecRows;
+    return (kDecRows + 2 * kDecPadRows) * (DX2 + 4) + (kd + 6) * DX2 + kDecRows + (ESMI_DEC_LN_ACC && DX2 > 128 ? 2 * kDecRows * 8 : 0);
 }
 
 // max_b mel_len[b], by every wave for itself: one coalesced read, no extra launch, no atomics; the result is made
@@ -341,7 +344,9 @@ __global__ __launch_bounds__(64 * NW, (DX2 <= 128 ? kDecWps128 : NW / 4)) void m
     // STREAM: the k/2 input rows of every conv layer in front of the next chunk are carried: in LDS behind the tile (`carry_lds_layers`
     // slots), else in a global scratch row set of this workgroup (written and read back by the same thread, one chunk apart: no fence)
     float* const cws = STREAM && p.carry_ws ? p.carry_ws + ((long)seg * p.B + b) * p.ws_stride : nullptr;
-    float* const cbuf = reinterpret_cast<float*>(src + kDecRows);     // [carry_lds_layers][PAD][DX2]
+    constexpr bool LNA = ESMI_DEC_LN_ACC && DX2 > 128;                // LayerNorm on the accumulators (see ln_acc below)
+    float* const stat = reinterpret_cast<float*>(src + kDecRows);     // LNA: [2 exchanges][kDecRows][NS] x (sum, sum of squares)
+    float* const cbuf = stat + (LNA ? 2 * kDecRows * NS * 2 : 0);     // [carry_lds_layers][PAD][DX2]
     float cnext = 0.0f;                      // the carried element of the NEXT conv layer, requested one phase ahead
     // BLOCK SKEW (round 6).  Inside a block the tile's rows keep their frames (the skip tensor lives in the row owners' registers), so
     // every conv layer costs k/2 valid rows on the right: `sh` = block_depth * k/2 per block.  At a block boundary nothing is held in
@@ -494,6 +499,7 @@ __global__ __launch_bounds__(64 * NW, (DX2 <= 128 ? kDecWps128 : NW / 4)) void m
     auto row_inside = [&](int j) __attribute__((always_inline)) { return (unsigned)(fb_cur + ln_row0 + j) < (unsigned)L; };
     set_edge(f0);
     f32x16 acc[MT][NTW];
+    f32x16 skipA[LNA ? MT : 1][LNA ? NTW : 1];   // LNA: the block's skip tensor in the accumulators' layout
     f32x4 skip[RPT][NV];
 #pragma unroll
     for (int j = 0; j < RPT; ++j) {
@@ -698,6 +704,93 @@ __global__ __launch_bounds__(64 * NW, (DX2 <= 128 ? kDecWps128 : NW / 4)) void m
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = acc[mt][t][4 * g + e];
                     *reinterpret_cast<f32x4*>(base + 32 * mt * LDSROW + 8 * g) = v;
+                }
+            }
+        }
+    };
+    // ---- LNA (dx2 = 256): LayerNorm without the tile round trip.  After the K loop lane (i, h) of wave (mh, ns) holds, per row tile mt, row
+    // 64 mh + 32 mt + i x 32 NTW channels of the wave's column slice.  `stats_put`: the lane's sum and sum of squares, + its partner half
+    // (lane ^ 32), written as one (sum, sumsq) pair per (row, ns) -- ahead of the barrier the epilogue needs anyway (last reader of the
+    // operand planes); behind it every lane adds the row's four pairs (`stats_get`: two ds_read_b128), normalises its registers
+    // (`ln_acc`: gain / shift of its own channels, read like the bias in tanh_acc) and stores the finished rows once (`store_ln`).
+    // One-pass variance E[x^2] - mean^2 on |x| <= 1 (tanh) or O(1) (block end) values: parity held at 1e-5 (tests).  Against the
+    // round-5 form: one barrier, 16 ds_write_b128 + 16 ds_read_b128 per thread and the row owners' DPP reductions less per layer.
+    auto stats_put = [&](int buf) __attribute__((always_inline)) {
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            float s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+            for (int t = 0; t < NTW; ++t) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    s1 += acc[mt][t][r];
+                    s2 = fmaf(acc[mt][t][r], acc[mt][t][r], s2);
+                }
+            }
+            s1 += swap32_f(s1);
+            s2 += swap32_f(s2);
+            if (h == 0) *reinterpret_cast<f32x2*>(stat + opaque_i(((buf * kDecRows + 32 * MT * mh + i) * NS + ns) * 2) + 32 * mt * NS * 2) = f32x2{s1, s2};
+        }
+    };
+    auto stats_get = [&](int buf, float (&mean)[MT], float (&rstd)[MT]) __attribute__((always_inline)) {
+        const float* sp = stat + opaque_i((buf * kDecRows + 32 * MT * mh + i) * NS * 2);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(sp + 32 * mt * NS * 2), b = *reinterpret_cast<const f32x4*>(sp + 32 * mt * NS * 2 + 4);
+            const float s1 = (a[0] + a[2]) + (b[0] + b[2]), s2 = (a[1] + a[3]) + (b[1] + b[3]);
+            mean[mt] = s1 * (1.0f / DX2);
+            rstd[mt] = ESMI_DEC_RSQRT(fmaxf(fmaf(-mean[mt], mean[mt], s2 * (1.0f / DX2)), 0.0f) + 1e-5f);
+        }
+    };
+    auto ln_acc = [&](const float* gain, const float* shift, const float (&mean)[MT], const float (&rstd)[MT]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) {
+            const float* gp = gain + opaque_i(ns * WCOLS + 32 * t + 4 * h);
+            const float* bp = shift + opaque_i(ns * WCOLS + 32 * t + 4 * h);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 gv = *reinterpret_cast<const f32x4*>(gp + 8 * g), bv = *reinterpret_cast<const f32x4*>(bp + 8 * g);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[mt][t][4 * g + e] = fmaf((acc[mt][t][4 * g + e] - mean[mt]) * rstd[mt], gv[e], bv[e]);
+                }
+            }
+        }
+    };
+    // the finished rows -> tile: fp32 rows `shw` rows further down (block skew; rows that would leave the tile are the rows the block lost),
+    // or (the last LayerNorm) the mel Linear's two f16 operand planes; rows outside [0, L) are zero rows
+    auto store_ln = [&](bool planes_, int shw) __attribute__((always_inline)) {
+        bool inside[MT], keep_row[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int row = 32 * MT * mh + 32 * mt + i;
+            inside[mt] = !edge_window || (unsigned)(fb_cur + row) < (unsigned)L;
+            keep_row[mt] = row + shw < kDecRows;
+        }
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) {
+            float* base = xs + opaque_i((kDecPadRows + 32 * MT * mh + i + shw) * LDSROW + ns * WCOLS + 32 * t + 4 * h);
+            unsigned* pbase = reinterpret_cast<unsigned*>(xs) + opaque_i((kDecPadRows + 32 * MT * mh + i) * LDSROW + (ns * WCOLS + 32 * t + 4 * h) / 2);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    f32x4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = inside[mt] ? acc[mt][t][4 * g + e] : 0.0f;
+                    if (SPLIT && planes_) {
+                        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+                        unsigned h1a, h2a, h1b, h2b;
+                        split_f16_pair(v[0], v[1], h1a, h2a);
+                        split_f16_pair(v[2], v[3], h1b, h2b);
+                        unsigned* rowp = pbase + 32 * mt * LDSROW + 4 * g;
+                        *reinterpret_cast<u32x2*>(rowp) = u32x2{h1a, h1b};
+                        *reinterpret_cast<u32x2*>(rowp + DX2 / 2) = u32x2{h2a, h2b};
+                    } else if (keep_row[mt]) {
+                        *reinterpret_cast<f32x4*>(base + 32 * mt * LDSROW + 8 * g) = v;
+                    }
                 }
             }
         }
@@ -941,7 +1034,24 @@ __global__ __launch_bounds__(64 * NW, (DX2 <= 128 ? kDecWps128 : NW / 4)) void m
                 set_edge(g0 + sh * (p.n_blocks - 1 - blk));
             }
         }
-        if (lin == 0 && l > 0) {   // a block starts: its input (the tile, complete since the barrier behind the last LayerNorm) is the skip tensor
+        if constexpr (LNA) {
+            if (lin == 0) {        // a block starts (l = 0: behind the first stage): the tile is the skip tensor, read in the accumulators' layout
+#pragma unroll
+                for (int t = 0; t < NTW; ++t) {
+                    const float* base = xs + opaque_i((kDecPadRows + 32 * MT * mh + i) * LDSROW + ns * WCOLS + 32 * t + 4 * h);
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt) {
+                            const f32x4 v = *reinterpret_cast<const f32x4*>(base + 32 * mt * LDSROW + 8 * g);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) skipA[mt][t][4 * g + e] = v[e];
+                        }
+                    }
+                }
+            }
+        }
+        if (!LNA && lin == 0 && l > 0) {   // a block starts: its input (the tile, complete since the barrier behind the last LayerNorm) is the skip tensor
             const float* ln_ptr = xs + opaque_i((kDecPadRows + ln_row0) * LDSROW + 4 * ln_c);
 #pragma unroll
             for (int j = 0; j < RPT; ++j) {
@@ -1000,14 +1110,15 @@ __global__ __launch_bounds__(64 * NW, (DX2 <= 128 ? kDecWps128 : NW / 4)) void m
         ESMI_STAMP();   // 5: K loop issued
         // 3. bias + tanh on the accumulators (no tile access: ahead of the barrier), then -> tile
         tanh_acc(pb + P_PWB);
+        if constexpr (LNA) stats_put(0);
         fetch_A(l + 1);      // next layer's taps (their slots were last read by this layer's depthwise phase)
         ESMI_STAMP();   // 6: bias + tanh done on the accumulators
         __syncthreads();  // all reads of the filtered tile done
         ESMI_STAMP();   // 7: barrier
-        store_acc();
+        if constexpr (!LNA) store_acc();
         commit_A(l + 1);     // (the taps' LDS slots were last read by this layer's depthwise phase)
         ESMI_STAMP();   // 8: tanh stored
-        __syncthreads();
+        if constexpr (!LNA) __syncthreads();
         ESMI_STAMP();   // 9: barrier
         // 4. LayerNorm (+ block-end skip LayerNorm) by row owners; the last one writes the mel Linear's operand planes
         if (l + 1 == n_layers) fetch_B(n_layers);   // mel bias -> group A slots (taps: last read by this layer's depthwise phase)
@@ -1015,7 +1126,25 @@ __global__ __launch_bounds__(64 * NW, (DX2 <= 128 ? kDecWps128 : NW / 4)) void m
         // block skew, at the end of every block but the last: the rows go `sh` rows down, the rows in front of them arrive from the
         // previous chunk (requested here, a phase ahead; zero rows at the start of an utterance -- frames < 0)
         const int shw = (STREAM && skew && block_end && l + 1 < n_layers) ? sh : 0;
-        ln_pass(pb, block_end, SPLIT && l + 1 == n_layers, shw);
+        if constexpr (LNA) {
+            float mean[MT], rstd[MT];
+            stats_get(0, mean, rstd);
+            ln_acc(pb + P_G, pb + P_B, mean, rstd);
+            if (block_end) {   // end of a decoder block: LN_s(x + skip), networks.py:299 (a second exchange: one more barrier, as before)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+                    for (int t = 0; t < NTW; ++t) acc[mt][t] += skipA[mt][t];
+                }
+                stats_put(1);
+                __syncthreads();
+                stats_get(1, mean, rstd);
+                ln_acc(pb + P_SG, pb + P_SB, mean, rstd);
+            }
+            store_ln(SPLIT && l + 1 == n_layers, shw);
+        } else {
+            ln_pass(pb, block_end, SPLIT && l + 1 == n_layers, shw);
+        }
         ESMI_STAMP();   // 10: LN done
         if (l + 1 == n_layers) gemm_prefetch(lay.mel_w, NtmC{});   // (the mel bias went to the unused group A slots by LDS-DMA above)
         else carry_put(slot_next);
