@@ -11,8 +11,11 @@ namespace esmi {
 
 // E2: attention + proj + LN1 + MixFFN + LN2 in one launch.
 int launch_enc_attn_ffn(const EncAttnFfnP& p, int expansion, int plan, hipStream_t st) {
-    if ((p.C & 31) || p.N > 256) return ESMI_ERR_UNSUPPORTED;
-    const int nc = p.C / 32, nkt = p.N <= 64 ? 2 : (p.N <= 128 ? 4 : 8);
+    // N <= 128 only: the 8-key-tile instantiations (N <= 256) spilled 84 .. 820 B per lane at 512 + 256 registers and were slower than the
+    // per-op launches (`enc_attn_ffn_supported`, launch.h, never selected them); round 6 stops building them -- a longer sequence gets
+    // ESMI_ERR_UNSUPPORTED here and the LDS-staged attention + GEMM launches from the caller
+    if ((p.C & 31) || p.N > 128) return ESMI_ERR_UNSUPPORTED;
+    const int nc = p.C / 32, nkt = p.N <= 64 ? 2 : 4;
     int nw, wgs, useful, halo;
     EncAttnFfnP q = p;
     if (p.h == 2 && nc == 2 && expansion == 1 && (plan & ESMI_FUSE_SPLIT2)) {   // two waves per row tile when rows are scarce
@@ -38,7 +41,7 @@ int launch_enc_attn_ffn(const EncAttnFfnP& p, int expansion, int plan, hipStream
         ESMI_LAUNCH((enc_attn_ffn_kernel<NKT, NC, E>), grid, block, lds, st, q);                                               \
         return launch_status();                                                                                                \
     }
-#define ESMI_E2K(NC, E) ESMI_E2(2, NC, E) ESMI_E2(4, NC, E) ESMI_E2(8, NC, E)
+#define ESMI_E2K(NC, E) ESMI_E2(2, NC, E) ESMI_E2(4, NC, E)
     ESMI_E2K(1, 1) ESMI_E2K(2, 1) ESMI_E2K(4, 1) ESMI_E2K(4, 2)
 #undef ESMI_E2K
 #undef ESMI_E2
