@@ -34,6 +34,17 @@ struct Pred128P {
     int* mel_len;                   // (B)
     int B, T;
 };
+// enc_ffn128.h (everything behind the attention of a C = 128, two-head, expansion-2 block: one workgroup per utterance)
+struct PostAttn128P {
+    const float* ctx;        // (B, N, 256) attention context (two heads x 128)
+    const float* x;          // (B, N, 128) the block's input rows (residual)
+    float* y1;               // (B, N, 128) scratch: LN1's output (the second residual)
+    float* out;              // (B, N, 128); may be x
+    const float *proj_w, *ffn_w, *mlp2_w;   // esmi_pack_bfrag_f32 arrays: (128 x 256), three taps of (256 x 128), (128 x 256)
+    const float *proj_b, *ln1_g, *ln1_b, *ffn_b, *ffn_b0, *ffn_b2, *mlp2_b, *ln2_g, *ln2_b;
+    const unsigned char* rowmask;            // (B, N) 1 = padding row, or NULL
+    int B, N;
+};
 struct FuseVaP {
     int B, T, depth, kernel;
     const float* feats[4];

@@ -285,6 +285,15 @@ int esmi_encoder_block_f32(const esmi_encoder_block_weights* w, const esmi_encod
         rc = launch_enc_post_attn64(q, st);
         if (rc != ESMI_ERR_UNSUPPORTED) return rc;
     }
+    if ((plan & ESMI_FUSE_CHAIN16) && packed && folded && ffn_folded && C == 128 && h == 2 && s->expansion == 2 && n <= 256) {
+        // round 6: the same for base ES's block 0 (enc_ffn128.h): ctx = the two heads' P_h x, the projection is the folded [Wv_h^T Wp_h^T]
+        PostAttn128P q;
+        q.ctx = ctx; q.x = x_out; q.y1 = y1; q.out = x_out; q.proj_w = w->vo_wp; q.ffn_w = w->ffn_cwp; q.mlp2_w = w->mlp2_wp;
+        q.proj_b = w->proj_b; q.ln1_g = w->ln1_g; q.ln1_b = w->ln1_b; q.ffn_b = w->ffn_cb; q.ffn_b0 = w->ffn_cb_first; q.ffn_b2 = w->ffn_cb_last;
+        q.mlp2_b = w->mlp2_b; q.ln2_g = w->ln2_g; q.ln2_b = w->ln2_b; q.rowmask = mask; q.B = B; q.N = n;
+        rc = launch_enc_post_attn128(q, st);
+        if (rc != ESMI_ERR_UNSUPPORTED) return rc;
+    }
     // proj + residual + LN1 + mask, blocks.py:65 + networks.py:73-75  (folded: ctx holds P_h x, the matrix is [O_h])
     p = conv_defaults();
     p.B = B; p.n_in = n; p.c_in = h * C; p.n_out = n; p.c_out = C;

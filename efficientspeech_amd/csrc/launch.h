@@ -65,7 +65,9 @@ struct PostAttn64P;
 int launch_enc_post_attn64(const PostAttn64P& p, hipStream_t st);   // (enc_ffn64.h: proj + LN1 + MixFFN + LN2 of a C = 64 one-head block, N <= 256)
 // tu_enc_pred128.hip (round 6: the three predictors + variance-adaptor tail + scan of a dim = 128 model, T <= 256; reads feat[:, 0 .. dim))
 int launch_enc_pred128(const Pred128P& p, int dim, hipStream_t st);
-int launch_enc_fuse128(const FuseVaP& p, int dim, int kernel, hipStream_t st);   // (enc_fuse128.h: the Fuse stage of the same models, one launch)
+int launch_enc_fuse128(const FuseVaP& p, int dim, int kernel, hipStream_t st);
+int launch_enc_post_attn128(const PostAttn128P& p, hipStream_t st);   // (enc_ffn128.h: proj + LN1 + MixFFN + LN2 of a C = 128 two-head expansion-2 block, N <= 256)
+   // (enc_fuse128.h: the Fuse stage of the same models, one launch)
 // tu_enc_block16.hip (round 5: whole-block kernels of dim = 32 models on 16-row tiles)
 int launch_enc_block16(const EncAttnFfnP& p, int expansion, int c_in, hipStream_t st);
 // ... and the whole encoder side in one launch (block 0 | block 1 | Fuse + variance adaptor), when each of the three chain16 kernels

@@ -4,6 +4,7 @@
 #include "launch.h"
 #include "enc_pred128.h"
 #include "enc_fuse128.h"
+#include "enc_ffn128.h"
 
 using namespace esmi;
 ESMI_TU_RANGE_SETTER(enc_pred128)
@@ -53,6 +54,22 @@ int launch_enc_fuse128(const FuseVaP& p, int dim, int kernel, hipStream_t st) {
     return launch_status();
 #else
     (void)p; (void)dim; (void)kernel; (void)st;
+    return ESMI_ERR_UNSUPPORTED;
+#endif
+}
+
+// Everything behind the attention of a C = 128, two-head, expansion-2 block (N <= 256) in one launch (enc_ffn128.h)
+int launch_enc_post_attn128(const PostAttn128P& p, hipStream_t st) {
+#if ESMI_CHAIN_SPLIT
+    if (p.N < 1 || p.N > 32 * kVa64MaxWaves || p.B < 1 || !p.ctx || !p.x || !p.y1 || !p.out || !p.proj_w || !p.ffn_w || !p.mlp2_w || !p.proj_b ||
+        !p.ln1_g || !p.ln1_b || !p.ffn_b || !p.ffn_b0 || !p.ffn_b2 || !p.mlp2_b || !p.ln2_g || !p.ln2_b)
+        return ESMI_ERR_UNSUPPORTED;
+    static AttrOnce once;
+    if (int rc = raise_lds_limit(reinterpret_cast<const void*>(enc_post_attn128_kernel), once)) return rc;
+    ESMI_LAUNCH(enc_post_attn128_kernel, dim3(p.B), dim3(64 * ((p.N + 31) / 32)), ffn128_lds_bytes(), st, p);
+    return launch_status();
+#else
+    (void)p; (void)st;
     return ESMI_ERR_UNSUPPORTED;
 #endif
 }
