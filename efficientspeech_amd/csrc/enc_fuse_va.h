@@ -45,6 +45,14 @@ struct PostAttn128P {
     const unsigned char* rowmask;            // (B, N) 1 = padding row, or NULL
     int B, N;
 };
+// enc_merge256.h (merge convolution stride 2, 128 -> 256, + the folded attention's query GEMM 256 -> heads x 256: one workgroup per utterance)
+struct MergeQ256P {
+    const float* x_in;       // (B, n_in, 128)
+    float* x_out;            // (B, n_out, 256)
+    float* q;                // (B, n_out, heads * 256)
+    const float *merge_w, *q_w;   // esmi_pack_bfrag_f32 arrays: `kernel` taps of (256 x 128); (heads * 256 x 256)
+    int B, n_in, n_out, kernel, heads;
+};
 struct FuseVaP {
     int B, T, depth, kernel;
     const float* feats[4];

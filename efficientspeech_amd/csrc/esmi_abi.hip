@@ -226,7 +226,16 @@ int esmi_encoder_block_f32(const esmi_encoder_block_weights* w, const esmi_encod
         if (rc == ESMI_ERR_UNSUPPORTED) rc = launch_enc_block(fb, s->expansion, s->c_in, plan, st);
         if (rc != ESMI_ERR_UNSUPPORTED) return rc;
     }
-    if (packed && (plan & ESMI_FUSE_MERGE_QKV)) {   // E1: merge conv + 1x1 + qkv as one wave-chain kernel
+    if ((plan & ESMI_FUSE_CHAIN16) && folded && !ids && x_in && s->c_in == 128 && C == 256 && s->stride == 2 && n <= 128 && w->merge_cwp) {
+        // round 6: base ES's block 1 front (enc_merge256.h) -- the strided merge convolution and the folded attention's query GEMM in ONE launch
+        MergeQ256P q;
+        q.x_in = x_in; q.x_out = x_mid; q.q = qkv; q.merge_w = w->merge_cwp; q.q_w = w->qk_wp; q.B = B; q.n_in = s->n_in; q.n_out = n;
+        q.kernel = s->kernel; q.heads = h;
+        rc = launch_enc_merge_q256(q, st);
+        if (rc == ESMI_OK) fused1 = true;
+        else if (rc != ESMI_ERR_UNSUPPORTED) return rc;
+    }
+    if (!fused1 && packed && (plan & ESMI_FUSE_MERGE_QKV)) {   // E1: merge conv + 1x1 + qkv as one wave-chain kernel
         rc = launch_enc_merge_qkv(m, s->c_in, C, st);
         if (rc == ESMI_OK) fused1 = true;
         else if (rc != ESMI_ERR_UNSUPPORTED) return rc;

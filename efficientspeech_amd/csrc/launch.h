@@ -66,7 +66,8 @@ int launch_enc_post_attn64(const PostAttn64P& p, hipStream_t st);   // (enc_ffn6
 // tu_enc_pred128.hip (round 6: the three predictors + variance-adaptor tail + scan of a dim = 128 model, T <= 256; reads feat[:, 0 .. dim))
 int launch_enc_pred128(const Pred128P& p, int dim, hipStream_t st);
 int launch_enc_fuse128(const FuseVaP& p, int dim, int kernel, hipStream_t st);
-int launch_enc_post_attn128(const PostAttn128P& p, hipStream_t st);   // (enc_ffn128.h: proj + LN1 + MixFFN + LN2 of a C = 128 two-head expansion-2 block, N <= 256)
+int launch_enc_post_attn128(const PostAttn128P& p, hipStream_t st);
+int launch_enc_merge_q256(const MergeQ256P& p, hipStream_t st);   // (enc_merge256.h: merge conv k = 5 stride 2, 128 -> 256, + the folded query GEMM, N <= 128)   // (enc_ffn128.h: proj + LN1 + MixFFN + LN2 of a C = 128 two-head expansion-2 block, N <= 256)
    // (enc_fuse128.h: the Fuse stage of the same models, one launch)
 // tu_enc_block16.hip (round 5: whole-block kernels of dim = 32 models on 16-row tiles)
 int launch_enc_block16(const EncAttnFfnP& p, int expansion, int c_in, hipStream_t st);

@@ -5,6 +5,7 @@
 #include "enc_pred128.h"
 #include "enc_fuse128.h"
 #include "enc_ffn128.h"
+#include "enc_merge256.h"
 
 using namespace esmi;
 ESMI_TU_RANGE_SETTER(enc_pred128)
@@ -67,6 +68,22 @@ int launch_enc_post_attn128(const PostAttn128P& p, hipStream_t st) {
     static AttrOnce once;
     if (int rc = raise_lds_limit(reinterpret_cast<const void*>(enc_post_attn128_kernel), once)) return rc;
     ESMI_LAUNCH(enc_post_attn128_kernel, dim3(p.B), dim3(64 * ((p.N + 31) / 32)), ffn128_lds_bytes(), st, p);
+    return launch_status();
+#else
+    (void)p; (void)st;
+    return ESMI_ERR_UNSUPPORTED;
+#endif
+}
+
+// The front of a C = 256 block fed by 128-channel rows (stride 2; N <= 128 output rows) in one launch (enc_merge256.h): base ES's block 1
+int launch_enc_merge_q256(const MergeQ256P& p, hipStream_t st) {
+#if ESMI_CHAIN_SPLIT
+    if (p.kernel != 3 || p.heads != 4 || p.n_out < 1 || p.n_out > 16 * kVa64MaxWaves || p.B < 1 || p.n_out != (p.n_in + 2 * (p.kernel / 2) - p.kernel) / 2 + 1 ||
+        !p.x_in || !p.x_out || !p.q || !p.merge_w || !p.q_w)
+        return ESMI_ERR_UNSUPPORTED;
+    static AttrOnce once;
+    if (int rc = raise_lds_limit(reinterpret_cast<const void*>(enc_merge_q256_kernel<3, 4>), once)) return rc;
+    ESMI_LAUNCH((enc_merge_q256_kernel<3, 4>), dim3(p.B), dim3(64 * ((p.n_out + 15) / 16)), merge256_lds_bytes(), st, p);
     return launch_status();
 #else
     (void)p; (void)st;
