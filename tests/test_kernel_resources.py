@@ -16,7 +16,7 @@ def test_no_scratch_on_the_hot_kernels():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "kernel_resources.py"), LIB, "--all"], capture_output=True, text=True, check=True).stdout
     rows = {m.group(1): int(m.group(2)) for m in re.finditer(r"^\| `(.+?)` \| [^|]+ \| (\d+) \|", out, re.M)}
     assert len(rows) > 100, out[-400:]
-    zero = [r"^enc_all16_kernel<", r"^enc_b0_16_kernel<", r"^enc_b1_16_kernel$", r"^enc_va16_kernel<", r"^mel_decoder_kernel<128, ", r"^mel_decoder_kernel<256, ", r"^enc_va64_kernel<", r"^enc_post_attn64_kernel<", r"^enc_pred128_kernel$", r"^enc_fuse128_kernel<", r"^pwgemm_kernel<\d, 2, ",
+    zero = [r"^enc_all16_kernel<", r"^enc_b0_16_kernel<", r"^enc_b1_16_kernel$", r"^enc_va16_kernel<", r"^mel_decoder_kernel<128, ", r"^mel_decoder_kernel<256, ", r"^enc_va64_kernel<", r"^enc_post_attn64_kernel<", r"^enc_pred128_kernel$", r"^enc_fuse128_kernel<", r"^enc_merge_q256_kernel<", r"^pwgemm_kernel<\d, 2, ",
             r"^train_conv_wgrad_mfma_kernel<", r"^convgemm_kernel<[124], ", r"^convgemm_dma_kernel<4, ", r"^convgemm_dma_kernel<8, 1, 4, (true|false), true>", r"^attn_lds_kernel<"]
     for pat in zero:
         hit = {k: v for k, v in rows.items() if re.search(pat, k)}
