@@ -63,9 +63,11 @@ const char* esmi_build_config(void);
 #define ESMI_FUSE_VARIANCE 4  /* Fuse + 3 predictors + embeddings + round */
 #define ESMI_FUSE_SPLIT2 8    /* two-head blocks on short sequences: two waves per row tile */
 #define ESMI_FUSE_BLOCK 16    /* whole encoder block in one launch when one workgroup covers the sequence */
-#define ESMI_FUSE_CHAIN16 32  /* round 5: the 16-row-tile chain kernels (two waves per SIMD, weights once per workgroup through LDS) for
-                               * the shapes they are built for (dim = 32 models, one workgroup per utterance); without the bit the
-                               * round-1..4 chain kernels run those shapes too */
+#define ESMI_FUSE_CHAIN16 32  /* rounds 5-6: the 16-row-tile kernels (weights once per workgroup through LDS) for the shapes they are built
+                               * for, one workgroup per utterance -- dim = 32 models: the whole encoder side as chain16 kernels; dim = 64
+                               * (T <= 256): enc_va64 / enc_post_attn64; dim = 128 (T <= 256): enc_pred128 / enc_fuse128 / enc_post_attn128 /
+                               * enc_merge_q256 (activations in registers end to end).  Without the bit the round-1..4 chain kernels and
+                               * the one-kernel-per-op launches run those shapes too */
 #define ESMI_FUSE_ALL 63
 
 /* ------------------------------------------------------------------ weight packing
