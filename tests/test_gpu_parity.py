@@ -317,6 +317,43 @@ def test_random_shapes_vs_oracle(seed, nets):
         assert np.abs(m[:, :L] - o.mel).max() < H.MEL_TOL
 
 
+@pytest.mark.parametrize("seed", list(range(6)))
+@pytest.mark.parametrize("name", ["small", "base"])
+def test_random_shapes_wide_models_vs_oracle(name, seed, nets):
+    """The same on small / base ES (round 6: the register-resident dim-64 / dim-128 kernels -- enc_va64, enc_post_attn64, enc_pred128,
+    enc_fuse128, enc_post_attn128, enc_merge_q256 -- own one workgroup per utterance for T <= 256): odd and short lengths, ragged masks,
+    B = 1 without a mask, zero durations, length hints; teacher-forced with the HIP path's own pitch / energy so that bucket decisions
+    cannot disagree (predictions held to PRED_TOL)."""
+    rng = np.random.default_rng(7000 + 31 * seed + (0 if name == "small" else 1))
+    net, cfg, sd = nets(name)
+    B = 1 if seed == 0 else int(rng.integers(2, 6))
+    T = [1, 17, 255, 256][seed] if seed < 4 else int(rng.integers(2, 257))
+    lens = sorted((int(v) for v in rng.integers(1, T + 1, size=B)), reverse=True)
+    lens[0] = T
+    ids, mask = synth_phonemes(B, T, 90 + seed, lens)
+    dur = rng.integers(0, 5, size=(B, T)).astype(np.int32)
+    dur[rng.random((B, T)) < 0.15] = 0
+    x = {"phoneme": torch.from_numpy(ids).to(DEV), "duration_forced": torch.from_numpy(dur).to(DEV)}
+    if B > 1:
+        x["phoneme_mask"] = torch.from_numpy(mask).to(DEV)
+    if seed % 2:
+        x["max_mel_len"] = int(dur.sum(1).max()) + int(rng.integers(0, 40))
+    with torch.no_grad():
+        enc = net.encoder._encode(x)
+        mel, mel_len, _ = net(x)
+    o = oracle.phoneme2mel(cfg, oracle.Weights(sd), ids, mask if B > 1 else None,
+                           pitch=enc["pitch"][..., 0].cpu().numpy(), energy=enc["energy"][..., 0].cpu().numpy(), duration=dur)
+    np.testing.assert_allclose(enc["pitch"].cpu().numpy(), o.pitch, atol=H.PRED_TOL, rtol=0)
+    np.testing.assert_allclose(enc["energy"].cpu().numpy(), o.energy, atol=H.PRED_TOL, rtol=0)
+    np.testing.assert_allclose(enc["duration"].cpu().numpy(), o.duration, atol=H.PRED_TOL, rtol=0)
+    assert np.array_equal(mel_len.cpu().numpy(), o.mel_len)
+    L = o.mel.shape[1]
+    m = mel.cpu().numpy()
+    assert m.shape[1] >= L and not m[:, L:].any()
+    if L:
+        assert np.abs(m[:, :L] - o.mel).max() < H.MEL_TOL
+
+
 def test_large_batch_uses_other_kernels(nets):
     """B = 512, T = 64: too many waves for the column-split block-1 kernel, so the plain whole-block instantiation runs;
     four utterances against the oracle (teacher-forced with the HIP path's own pitch / energy, durations forced)."""
