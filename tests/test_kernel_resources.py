@@ -24,3 +24,5 @@ def test_no_scratch_on_the_hot_kernels():
         assert all(v == 0 for v in hit.values()), {k: v for k, v in hit.items() if v}
     small = {k: v for k, v in rows.items() if re.search(r"^(convgemm_dma_kernel<8|pwgemm_kernel<\d, 4)", k)}
     assert all(v <= 64 for v in small.values()), small          # (the unpacked 256-channel GEMM's 28 B)
+    parked = {k: v for k, v in rows.items() if re.search(r"^enc_post_attn128_kernel$", k)}
+    assert parked and all(v <= 256 for v in parked.values()), parked   # (tile 1's operand parked in scratch during tile 0's FFN pass: 196 B, once per wave)
